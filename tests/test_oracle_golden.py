@@ -1,0 +1,151 @@
+"""Pin the CPU oracle against outputs of the reference itself (tests/golden/*.npz).
+
+CPU-only.  Tolerances: the oracle calls the same LAPACK/BLAS as the reference, but
+contracts trials in a different order, so agreement is to rounding (1e-10 relative
+on well-scaled cases), far inside the 1e-6 gate of BASELINE.json.
+"""
+import numpy as np
+import pytest
+
+import cases as C
+from helpers import golden, load_model_case, relerr, with_jitter
+from oracle import gpcsd_oracle as O
+
+MODEL_CASES = list(C.model_cases().keys())
+
+
+def test_b_fwd():
+    g = golden("ops")
+    assert relerr(O.b_fwd_1d(g["bf1_r"], 100.0), g["bf1_out0"]) < 1e-15
+    assert relerr(O.b_fwd_1d(g["bf1_r"], 37.5), g["bf1_out1"]) < 1e-15
+    assert relerr(O.b_fwd_2d(g["bf2_d1"], g["bf2_d2"], 100.0, 80.0), g["bf2_out_R100_e80"]) < 1e-15
+    assert relerr(O.b_fwd_2d(g["bf2_d1"], g["bf2_d2"], 30.0, 5.0), g["bf2_out_R30_e5"]) < 1e-15
+    assert relerr(O.b_fwd_2d(None, None, 100.0, 80.0, w=g["bf2_w"]), g["bf2_out_w"]) < 1e-15
+
+
+@pytest.mark.parametrize("n", [20, 30, 60, 100, 120])
+def test_gauss_legendre(n):
+    g = golden("ops")
+    gx, gw = O.gauss_legendre(-200.0, 2600.0, n)
+    assert np.array_equal(gx, g["gl_x_%d" % n])
+    assert np.array_equal(gw, g["gl_w_%d" % n])
+
+
+def test_temporal_gram():
+    g = golden("ops")
+    t, tp = g["kt_t"], g["kt_tp"]
+    assert relerr(O.temporal_gram(O.SE, t, t, 4.5, 1.7), g["kt_se_default"]) < 1e-15
+    assert relerr(O.temporal_gram(O.SE, tp, t, 4.5, 1.7), g["kt_se_t_tp"]) < 1e-15
+    assert relerr(O.temporal_gram(O.SE, t, tp, 4.5, 1.7), g["kt_se_tp_only"]) < 1e-15
+    assert relerr(O.temporal_gram(O.MATERN, t, t, 2.5, 0.6), g["kt_ma_default"]) < 1e-15
+    assert relerr(O.temporal_gram(O.MATERN, tp, t, 2.5, 0.6), g["kt_ma_t_tp"]) < 1e-15
+
+
+@pytest.mark.parametrize("tag,a,b,ngl", [("a", 0.0, 2300.0, 100), ("b", -200.0, 2600.0, 30)])
+def test_spatial_1d(tag, a, b, ngl):
+    g = golden("ops")
+    x, z, xp = g["s1_x"], g["s1_z"], g["s1_xp"]
+    gx, gw = O.gauss_legendre(a, b, ngl)
+    assert relerr(O.ks_csd_1d(x, 200.0), g["s1%s_Ks" % tag]) < 1e-15
+    assert relerr(O.kphi_1d(x, gx, gw, 100.0, 200.0), g["s1%s_Kphi" % tag]) < 1e-13
+    assert relerr(O.kphi_1d(x, gx, gw, 100.0, 200.0, xp=xp), g["s1%s_Kphi_xp" % tag]) < 1e-13
+    assert relerr(O.kphig_1d(x, gx, gw, z, 100.0, 200.0), g["s1%s_Kphig" % tag]) < 1e-13
+
+
+def test_spatial_2d():
+    g = golden("ops")
+    x, z, xp = g["s2_x"], g["s2_z"], g["s2_xp"]
+    gx1, gw1 = O.gauss_legendre(0.0, 48.0, 10)
+    gx2, gw2 = O.gauss_legendre(0.0, 440.0, 24)
+    assert np.array_equal(O.expand_grid(gx1, gx2), g["s2_gl_x_grid"])
+    assert relerr(np.prod(O.expand_grid(gw1, gw2), axis=1, keepdims=True), g["s2_gl_w_prod"]) < 1e-15
+    assert relerr(O.ks_csd_2d(x, 30.0, 100.0), g["s2_Ks"]) < 1e-15
+    assert relerr(O.kphi_2d(x, gx1, gw1, gx2, gw2, 60.0, 20.0, 30.0, 100.0), g["s2_Kphi"]) < 1e-13
+    assert relerr(O.kphi_2d(x, gx1, gw1, gx2, gw2, 60.0, 20.0, 30.0, 100.0, xp=xp), g["s2_Kphi_xp"]) < 1e-13
+    assert relerr(O.kphig_2d(x, gx1, gw1, gx2, gw2, z, 60.0, 20.0, 30.0, 100.0), g["s2_Kphig"]) < 1e-13
+    assert relerr(O.kphi_2d(xp, gx1, gw1, gx2, gw2, 60.0, 20.0, 30.0, 100.0), g["s2_Kphi_after_reset"]) < 1e-13
+
+
+def test_eig_D_and_utils():
+    g = golden("ops")
+    Qs, Qt, D = O.eig_D(g["eig_Ks"], g["eig_Kt"], 0.3)
+    assert relerr(D, g["eig_D_scalar"]) < 1e-14
+    assert relerr(O.eig_D(g["eig_Ks"], g["eig_Kt"], g["eig_siglist"])[2], g["eig_D_list"]) < 1e-14
+    assert relerr(Qs @ np.diag(g["eig_es"]) @ Qs.T, g["eig_Ks"]) < 1e-13
+    assert relerr(Qt.T @ Qt, np.eye(14)) < 1e-13
+    assert np.array_equal(O.mykron(g["kron_A"], g["kron_B"]), g["kron_out"])
+    assert np.array_equal(O.expand_grid([1.0, 2.0, 3.5], [-1.0, 0.5]), g["expand_grid_out"])
+
+
+def test_priors():
+    g = golden("ops")
+    a, b = O.invgamma_params(1.2, 80.0)
+    assert relerr([a, b], g["ig_alpha_beta"]) < 1e-15
+    for v, ref_ig, ref_hn in zip(g["prior_x"], g["ig_lpdf"], g["hn_lpdf"]):
+        assert O.invgamma_lpdf(v, a, b) == pytest.approx(ref_ig, rel=1e-15) or (np.isinf(ref_ig) and np.isinf(O.invgamma_lpdf(v, a, b)))
+        assert O.halfnormal_lpdf(v, 0.1) == pytest.approx(ref_hn, rel=1e-15) or (np.isinf(ref_hn) and np.isinf(O.halfnormal_lpdf(v, 0.1)))
+
+
+def test_fwd_models():
+    g = golden("ops")
+    assert relerr(O.fwd_model_1d(g["fm1_arr"], g["fm1_x"], g["fm1_z"], 150.0), g["fm1_out"]) < 1e-13
+    assert relerr(O.fwd_model_2d(g["fm2_arr"], g["fm2_x1"], g["fm2_x2"], g["fm2_z"], 60.0, 20.0), g["fm2_out"]) < 1e-13
+
+
+@pytest.mark.parametrize("name", MODEL_CASES)
+def test_model_loglik(name):
+    c, g, geom, hp, lfp = load_model_case(name)
+    Ks = O.spatial_kphi(geom, hp)
+    assert relerr(np.diag(Ks), g["Ks_diag"]) < 1e-12
+    assert relerr(Ks[0], g["Ks_row0"]) < 1e-12
+    Kt = O.temporal_sum(hp["temporal"], geom.t)
+    assert relerr(Kt[0], g["Kt_row0"]) < 1e-14
+    ll = O.loglik(geom, with_jitter(hp, float(g["jitter"])), lfp)
+    assert abs(ll - float(g["loglik"])) / abs(float(g["loglik"])) < 1e-9
+    if "Dvec" in g.files:
+        Qs, Qt, D = O.eig_D(Ks + float(g["jitter"]) * np.eye(Ks.shape[0]), Kt, hp["sig2n"])
+        assert relerr(D, g["Dvec"]) < 1e-10
+
+
+@pytest.mark.parametrize("name", [n for n in MODEL_CASES if not C.model_cases()[n].get("loglik_only")])
+def test_model_predict(name):
+    c, g, geom, hp, lfp = load_model_case(name)
+    out = O.predict(geom, hp, lfp, c["x"], c["t"], type="both")
+    tol = 1e-7   # the reference inverts a dense (nx*nt)^2 matrix; its own rounding is ~1e-9 of max|pred|
+    assert relerr(out["csd"], g["csd_pred"]) < tol
+    if c.get("predict_light"):
+        assert relerr(out["lfp"][:, :, :1], g["lfp_pred_trial0"]) < tol
+        return
+    assert relerr(out["lfp"], g["lfp_pred"]) < tol
+    for i in range(len(hp["temporal"])):
+        assert relerr(out["csd_list"][i], g["csd_pred_%d" % i]) < tol
+        assert relerr(out["lfp_list"][i], g["lfp_pred_%d" % i]) < tol
+    o2 = O.predict(geom, hp, lfp, g["z2"], c["t"], type="csd")
+    assert set(o2.keys()) == {"csd", "csd_list"}
+    assert relerr(o2["csd"], g["csd_pred_z2"]) < tol
+    o3 = O.predict(geom, hp, lfp, g["z2"], g["tq"], type="lfp")
+    assert relerr(o3["lfp"], g["lfp_pred_z2_tq"]) < tol
+    with pytest.raises(ValueError):
+        O.predict(geom, hp, lfp, g["z2"], c["t"][:-1], type="csd")
+
+
+def test_sample_prior():
+    g = golden("sample_prior")
+    c, gm, geom, hp, lfp = load_model_case("cfg1_1d_24x100x1")
+    out, Ls, Lt = O.sample_prior_from_normals(geom, hp, g["sp1_normals"], which="csd", jitter=1e-8)
+    assert relerr(out, g["sp1_csd"]) < 1e-10
+    c, gm, geom, hp, lfp = load_model_case("2d_grid_48x40x2")
+    out, Ls, Lt = O.sample_prior_from_normals(geom, hp, g["sp2_normals"], which="csd", jitter=1e-7)
+    assert relerr(out, g["sp2_csd"]) < 1e-10
+    assert bool(g["sp2_lfp_isnan"])
+
+
+def test_dense_cholesky_crosscheck():
+    """Kronecker-eigen loglik == dense Cholesky loglik for scalar sig2n (SURVEY 'three facts' item 1)."""
+    c, g, geom, hp, lfp = load_model_case("1d_odd_17x37x5")
+    hpj = with_jitter(hp, 1e-8)
+    Ks = O.spatial_kphi(geom, hpj) + 1e-8 * np.eye(17)
+    Kt = O.temporal_sum(hp["temporal"], geom.t)
+    a = O.loglik_from_K(lfp, Ks, Kt, hp["sig2n"])
+    b = O.loglik_dense_cholesky(lfp, Ks, Kt, hp["sig2n"])
+    assert abs(a - b) / abs(b) < 1e-9
