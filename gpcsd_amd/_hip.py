@@ -1,0 +1,429 @@
+"""ctypes binding of libgpcsd_hip.so (include/gpcsd_hip.h).  No CPU fallback: if the HIP library is missing
+or no GPU is visible, every compute entry point raises."""
+import ctypes
+import os
+import threading
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libgpcsd_hip.so")
+
+MAX_TEMPORAL = 8
+KIND_SE, KIND_MATERN = 0, 1
+PRED_CSD, PRED_LFP, PRED_BOTH = 1, 2, 3
+
+_c_double_p = ctypes.POINTER(ctypes.c_double)
+
+
+class HParams(ctypes.Structure):
+    """struct gpcsd_hparams"""
+    _fields_ = [("R", ctypes.c_double), ("eps", ctypes.c_double), ("ell_s", ctypes.c_double * 2),
+                ("n_temporal", ctypes.c_int), ("kind", ctypes.c_int * MAX_TEMPORAL),
+                ("ell_t", ctypes.c_double * MAX_TEMPORAL), ("sigma2_t", ctypes.c_double * MAX_TEMPORAL),
+                ("n_sig2n", ctypes.c_int), ("sig2n", _c_double_p), ("jitter", ctypes.c_double)]
+
+
+class HipUnavailable(RuntimeError):
+    pass
+
+
+_lib = None
+_lib_lock = threading.Lock()
+
+# name -> (restype, argtypes); every symbol include/gpcsd_hip.h declares
+_P = ctypes.c_void_p
+_D = ctypes.c_double
+_I = ctypes.c_int
+_L = ctypes.c_long
+_DP = _c_double_p
+SIGNATURES = {
+    "gpcsd_ctx_create": (_I, [_I, ctypes.POINTER(_P)]),
+    "gpcsd_ctx_destroy": (_I, [_P]),
+    "gpcsd_last_error": (ctypes.c_char_p, [_P]),
+    "gpcsd_version": (_I, []),
+    "gpcsd_device_synchronize": (_I, [_P]),
+    "gpcsd_set_lfp": (_I, [_P, _DP, _I, _I, _I]),
+    "gpcsd_set_geometry_1d": (_I, [_P, _DP, _I, _DP, _DP, _I]),
+    "gpcsd_set_geometry_2d": (_I, [_P, _DP, _I, _DP, _DP, _I, _DP, _DP, _I]),
+    "gpcsd_set_time": (_I, [_P, _DP, _I]),
+    "gpcsd_b_fwd_1d": (_I, [_P, _DP, _L, _D, _DP]),
+    "gpcsd_b_fwd_2d": (_I, [_P, _DP, _DP, _DP, _L, _D, _D, _DP]),
+    "gpcsd_gram_temporal": (_I, [_P, _I, _DP, _I, _DP, _I, _D, _D, _DP]),
+    "gpcsd_ks_csd_1d": (_I, [_P, _DP, _I, _D, _DP]),
+    "gpcsd_ks_csd_2d": (_I, [_P, _DP, _I, _D, _D, _DP]),
+    "gpcsd_kphi_1d": (_I, [_P, _DP, _I, _DP, _DP, _I, _D, _D, _DP, _I, _DP]),
+    "gpcsd_kphig_1d": (_I, [_P, _DP, _I, _DP, _DP, _I, _DP, _I, _D, _D, _DP]),
+    "gpcsd_kphi_2d": (_I, [_P, _DP, _I, _DP, _DP, _I, _DP, _DP, _I, _D, _D, _D, _D, _DP, _I, _DP]),
+    "gpcsd_kphig_2d": (_I, [_P, _DP, _I, _DP, _DP, _I, _DP, _DP, _I, _DP, _I, _D, _D, _D, _D, _DP]),
+    "gpcsd_eigh": (_I, [_P, _DP, _I, _DP, _DP]),
+    "gpcsd_eig_D": (_I, [_P, _DP, _I, _DP, _I, _DP, _I, _DP, _DP, _DP]),
+    "gpcsd_potrf": (_I, [_P, _DP, _I, _DP]),
+    "gpcsd_logdet_chol": (_I, [_P, _DP, _I, _DP]),
+    "gpcsd_trsm_lower": (_I, [_P, _DP, _I, _DP, _I, _DP]),
+    "gpcsd_gemm": (_I, [_P, _I, _I, _I, _I, _I, _DP, _DP, _DP]),
+    "gpcsd_loglik_dense_chol": (_I, [_P, _DP, _I, _DP, _I, _D, _DP, _I, _DP]),
+    "gpcsd_loglik": (_I, [_P, ctypes.POINTER(HParams), _DP]),
+    "gpcsd_loglik_parts": (_I, [_P, ctypes.POINTER(HParams), _DP]),
+    "gpcsd_loglik_grad_parts": (_I, [_P, ctypes.POINTER(HParams), _DP, _DP, _DP, _I]),
+    "gpcsd_predict": (_I, [_P, ctypes.POINTER(HParams), _DP, _I, _DP, _I, _I, _DP, _DP, _DP, _DP]),
+    "gpcsd_predict_resident": (_I, [_P, ctypes.POINTER(HParams), _DP, _I, _DP, _I, _I, _I]),
+    "gpcsd_fetch": (_I, [_P, ctypes.c_char_p, _DP, _L]),
+    "gpcsd_sample_prior": (_I, [_P, ctypes.POINTER(HParams), _I, _DP, _I, _DP]),
+    "gpcsd_prof_enable": (_I, [_P, _I]),
+    "gpcsd_prof_reset": (_I, [_P]),
+    "gpcsd_prof_get": (_I, [_P, ctypes.c_char_p, _DP, ctypes.POINTER(_L), _DP]),
+    "gpcsd_prof_names": (_I, [_P, ctypes.c_char_p, _I]),
+    "gpcsd_mfma_f64_peak": (_I, [_P, _DP]),
+    "gpcsd_hbm_copy_peak": (_I, [_P, _L, _DP]),
+}
+
+
+def load_library():
+    """dlopen the in-tree HIP library and declare every prototype.  Raises HipUnavailable if it is not built."""
+    global _lib
+    with _lib_lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise HipUnavailable("%s not found: build it with `python -m gpcsd_amd.build` "
+                                 "(gpcsd_amd has no CPU fallback)" % LIB_PATH)
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)          # AttributeError if a declared symbol is not exported
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+        return lib
+
+
+def _arr(a, shape=None, name="array"):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    if shape is not None and tuple(a.shape) != tuple(shape):
+        raise ValueError("%s has shape %s, expected %s" % (name, a.shape, tuple(shape)))
+    return a
+
+
+def _ptr(a):
+    return a.ctypes.data_as(_c_double_p) if a is not None else None
+
+
+class Context:
+    """One device + stream + resident LFP / geometry (gpcsd_ctx)."""
+
+    def __init__(self, device=None):
+        lib = load_library()
+        if device is None:
+            device = int(os.environ.get("LOCAL_RANK", "0"))
+        h = ctypes.c_void_p()
+        rc = lib.gpcsd_ctx_create(int(device), ctypes.byref(h))
+        if rc != 0:
+            msg = lib.gpcsd_last_error(None)
+            raise HipUnavailable("gpcsd_ctx_create(device=%d) failed (rc=%d): %s -- gpcsd_amd needs an AMD GPU; "
+                                 "there is no CPU fallback" % (device, rc, (msg or b"").decode()))
+        self._lib = lib
+        self._h = h
+        self.device = int(device)
+        self._keep = []
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.gpcsd_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- error convention (include/gpcsd_hip.h) ----
+    def _check(self, rc):
+        if rc == 0:
+            return
+        msg = (self._lib.gpcsd_last_error(self._h) or b"").decode()
+        if rc > 0:
+            raise np.linalg.LinAlgError(msg or "numerical failure (status %d)" % rc)
+        if rc in (-3, -22):
+            raise ValueError(msg)
+        raise RuntimeError("libgpcsd_hip error %d: %s" % (rc, msg))
+
+    def make_hparams(self, R, eps, ell_s, temporal, sig2n, jitter):
+        """temporal: list of (kind, ell, sigma2).  Returns (HParams, keepalive)."""
+        hp = HParams()
+        hp.R = float(R)
+        hp.eps = float(eps) if eps is not None else 0.0
+        ell_s = np.atleast_1d(np.asarray(ell_s, dtype=np.float64))
+        hp.ell_s[0] = float(ell_s[0])
+        hp.ell_s[1] = float(ell_s[1]) if ell_s.size > 1 else 0.0
+        if not (1 <= len(temporal) <= MAX_TEMPORAL):
+            raise ValueError("between 1 and %d temporal covariance components are supported" % MAX_TEMPORAL)
+        hp.n_temporal = len(temporal)
+        for i, (k, ell, s2) in enumerate(temporal):
+            hp.kind[i] = int(k)
+            hp.ell_t[i] = float(ell)
+            hp.sigma2_t[i] = float(s2)
+        sig = np.ascontiguousarray(np.atleast_1d(np.asarray(sig2n, dtype=np.float64)))
+        hp.n_sig2n = int(sig.size)
+        hp.sig2n = _ptr(sig)
+        hp.jitter = float(jitter)
+        return hp, sig
+
+    # ---- resident data ----
+    def set_lfp(self, lfp):
+        lfp = _arr(np.atleast_3d(lfp))
+        nx, nt, R = lfp.shape
+        self._check(self._lib.gpcsd_set_lfp(self._h, _ptr(lfp), nx, nt, R))
+
+    def set_geometry_1d(self, x, gl_x, gl_w):
+        x = _arr(x).reshape(-1)
+        gl_x, gl_w = _arr(gl_x).reshape(-1), _arr(gl_w).reshape(-1)
+        self._check(self._lib.gpcsd_set_geometry_1d(self._h, _ptr(x), x.size, _ptr(gl_x), _ptr(gl_w), gl_x.size))
+
+    def set_geometry_2d(self, xy, gl_x1, gl_w1, gl_x2, gl_w2):
+        xy = _arr(xy)
+        gl_x1, gl_w1, gl_x2, gl_w2 = (_arr(v).reshape(-1) for v in (gl_x1, gl_w1, gl_x2, gl_w2))
+        self._check(self._lib.gpcsd_set_geometry_2d(self._h, _ptr(xy), xy.shape[0], _ptr(gl_x1), _ptr(gl_w1), gl_x1.size,
+                                                    _ptr(gl_x2), _ptr(gl_w2), gl_x2.size))
+
+    def set_time(self, t):
+        t = _arr(t).reshape(-1)
+        self._check(self._lib.gpcsd_set_time(self._h, _ptr(t), t.size))
+
+    # ---- operators ----
+    def b_fwd_1d(self, r, R):
+        r = _arr(r)
+        out = np.empty_like(r)
+        self._check(self._lib.gpcsd_b_fwd_1d(self._h, _ptr(r), r.size, float(R), _ptr(out)))
+        return out
+
+    def b_fwd_2d(self, d1, d2, R, eps, w=None):
+        if w is not None:
+            w = _arr(w)
+            out = np.empty_like(w)
+            self._check(self._lib.gpcsd_b_fwd_2d(self._h, None, None, _ptr(w), w.size, float(R), float(eps), _ptr(out)))
+            return out
+        d1, d2 = np.broadcast_arrays(np.asarray(d1, dtype=np.float64), np.asarray(d2, dtype=np.float64))
+        d1, d2 = _arr(d1), _arr(d2)
+        out = np.empty_like(d1)
+        self._check(self._lib.gpcsd_b_fwd_2d(self._h, _ptr(d1), _ptr(d2), None, d1.size, float(R), float(eps), _ptr(out)))
+        return out
+
+    def gram_temporal(self, kind, t, tp, ell, sigma2):
+        t, tp = _arr(t).reshape(-1), _arr(tp).reshape(-1)
+        out = np.empty((t.size, tp.size))
+        self._check(self._lib.gpcsd_gram_temporal(self._h, int(kind), _ptr(t), t.size, _ptr(tp), tp.size, float(ell),
+                                                  float(sigma2), _ptr(out)))
+        return out
+
+    def ks_csd_1d(self, x, ell):
+        x = _arr(x).reshape(-1)
+        out = np.empty((x.size, x.size))
+        self._check(self._lib.gpcsd_ks_csd_1d(self._h, _ptr(x), x.size, float(ell), _ptr(out)))
+        return out
+
+    def ks_csd_2d(self, xy, ell1, ell2):
+        xy = _arr(xy)
+        n = xy.shape[0]
+        out = np.empty((n, n))
+        self._check(self._lib.gpcsd_ks_csd_2d(self._h, _ptr(xy), n, float(ell1), float(ell2), _ptr(out)))
+        return out
+
+    def kphi_1d(self, x, gl_x, gl_w, R, ell, xp=None):
+        x, gl_x, gl_w = _arr(x).reshape(-1), _arr(gl_x).reshape(-1), _arr(gl_w).reshape(-1)
+        xp_ = None if xp is None else _arr(xp).reshape(-1)
+        n2 = x.size if xp_ is None else xp_.size
+        out = np.empty((x.size, n2))
+        self._check(self._lib.gpcsd_kphi_1d(self._h, _ptr(x), x.size, _ptr(gl_x), _ptr(gl_w), gl_x.size, float(R), float(ell),
+                                            _ptr(xp_), 0 if xp_ is None else xp_.size, _ptr(out)))
+        return out
+
+    def kphig_1d(self, x, gl_x, gl_w, z, R, ell):
+        x, gl_x, gl_w, z = (_arr(v).reshape(-1) for v in (x, gl_x, gl_w, z))
+        out = np.empty((x.size, z.size))
+        self._check(self._lib.gpcsd_kphig_1d(self._h, _ptr(x), x.size, _ptr(gl_x), _ptr(gl_w), gl_x.size, _ptr(z), z.size,
+                                             float(R), float(ell), _ptr(out)))
+        return out
+
+    def kphi_2d(self, xy, gl_x1, gl_w1, gl_x2, gl_w2, R, eps, ell1, ell2, xp=None):
+        xy = _arr(xy)
+        gl_x1, gl_w1, gl_x2, gl_w2 = (_arr(v).reshape(-1) for v in (gl_x1, gl_w1, gl_x2, gl_w2))
+        xp_ = None if xp is None else _arr(xp)
+        n2 = xy.shape[0] if xp_ is None else xp_.shape[0]
+        out = np.empty((xy.shape[0], n2))
+        self._check(self._lib.gpcsd_kphi_2d(self._h, _ptr(xy), xy.shape[0], _ptr(gl_x1), _ptr(gl_w1), gl_x1.size, _ptr(gl_x2),
+                                            _ptr(gl_w2), gl_x2.size, float(R), float(eps), float(ell1), float(ell2),
+                                            _ptr(xp_), 0 if xp_ is None else xp_.shape[0], _ptr(out)))
+        return out
+
+    def kphig_2d(self, xy, gl_x1, gl_w1, gl_x2, gl_w2, z, R, eps, ell1, ell2):
+        xy, z = _arr(xy), _arr(z)
+        gl_x1, gl_w1, gl_x2, gl_w2 = (_arr(v).reshape(-1) for v in (gl_x1, gl_w1, gl_x2, gl_w2))
+        out = np.empty((xy.shape[0], z.shape[0]))
+        self._check(self._lib.gpcsd_kphig_2d(self._h, _ptr(xy), xy.shape[0], _ptr(gl_x1), _ptr(gl_w1), gl_x1.size, _ptr(gl_x2),
+                                             _ptr(gl_w2), gl_x2.size, _ptr(z), z.shape[0], float(R), float(eps), float(ell1),
+                                             float(ell2), _ptr(out)))
+        return out
+
+    def eigh(self, A):
+        A = _arr(A)
+        n = A.shape[0]
+        if A.shape != (n, n):
+            raise ValueError("eigh needs a square matrix")
+        w, V = np.empty(n), np.empty((n, n))
+        self._check(self._lib.gpcsd_eigh(self._h, _ptr(A), n, _ptr(w), _ptr(V)))
+        return w, V
+
+    def eig_D(self, Ks, Kt, sig2n):
+        Ks, Kt = _arr(Ks), _arr(Kt)
+        nx, nt = Ks.shape[0], Kt.shape[0]
+        sig = np.ascontiguousarray(np.atleast_1d(np.asarray(sig2n, dtype=np.float64)))
+        Qs, Qt, D = np.empty((nx, nx)), np.empty((nt, nt)), np.empty(nx * nt)
+        self._check(self._lib.gpcsd_eig_D(self._h, _ptr(Ks), nx, _ptr(Kt), nt, _ptr(sig), sig.size, _ptr(Qs), _ptr(Qt), _ptr(D)))
+        return Qs, Qt, D
+
+    def potrf(self, A):
+        A = _arr(A)
+        n = A.shape[0]
+        L = np.empty((n, n))
+        self._check(self._lib.gpcsd_potrf(self._h, _ptr(A), n, _ptr(L)))
+        return L
+
+    def logdet_chol(self, L):
+        L = _arr(L)
+        out = np.empty(1)
+        self._check(self._lib.gpcsd_logdet_chol(self._h, _ptr(L), L.shape[0], _ptr(out)))
+        return float(out[0])
+
+    def trsm_lower(self, L, B):
+        L, B = _arr(L), _arr(B)
+        B2 = B.reshape(L.shape[0], -1)
+        X = np.empty_like(B2)
+        self._check(self._lib.gpcsd_trsm_lower(self._h, _ptr(L), L.shape[0], _ptr(B2), B2.shape[1], _ptr(X)))
+        return X.reshape(B.shape)
+
+    def gemm(self, A, B, transA=False, transB=False):
+        A, B = _arr(A), _arr(B)
+        M, K = (A.shape[1], A.shape[0]) if transA else A.shape
+        N = B.shape[0] if transB else B.shape[1]
+        K2 = B.shape[1] if transB else B.shape[0]
+        if K != K2:
+            raise ValueError("gemm: inner dimensions differ (%d vs %d)" % (K, K2))
+        C = np.empty((M, N))
+        self._check(self._lib.gpcsd_gemm(self._h, int(transA), int(transB), M, N, K, _ptr(A), _ptr(B), _ptr(C)))
+        return C
+
+    def loglik_dense_chol(self, Ks, Kt, sig2n, lfp):
+        Ks, Kt, lfp = _arr(Ks), _arr(Kt), _arr(np.atleast_3d(lfp))
+        out = np.empty(1)
+        self._check(self._lib.gpcsd_loglik_dense_chol(self._h, _ptr(Ks), Ks.shape[0], _ptr(Kt), Kt.shape[0], float(sig2n),
+                                                      _ptr(lfp), lfp.shape[2], _ptr(out)))
+        return float(out[0])
+
+    # ---- fused hot calls ----
+    def loglik(self, hp):
+        out = np.empty(1)
+        self._check(self._lib.gpcsd_loglik(self._h, ctypes.byref(hp), _ptr(out)))
+        return float(out[0])
+
+    def loglik_parts(self, hp):
+        out = np.empty(2)
+        self._check(self._lib.gpcsd_loglik_parts(self._h, ctypes.byref(hp), _ptr(out)))
+        return float(out[0]), float(out[1])
+
+    def loglik_grad_parts(self, hp, ngrad):
+        out = np.empty(2)
+        gl, gq = np.empty(ngrad), np.empty(ngrad)
+        self._check(self._lib.gpcsd_loglik_grad_parts(self._h, ctypes.byref(hp), _ptr(out), _ptr(gl), _ptr(gq), int(ngrad)))
+        return float(out[0]), float(out[1]), gl, gq
+
+    def predict(self, hp, z, tstar, type_code, shape, want_lists=True):
+        """shape = (nz, ntstar, ntrials).  Returns dict of arrays for the requested type."""
+        z = _arr(z)
+        tstar = _arr(tstar).reshape(-1)
+        nz, ntstar, R = shape
+        C = hp.n_temporal
+        res = {}
+        bufs = {}
+        for name, bit in (("csd", PRED_CSD), ("lfp", PRED_LFP)):
+            if type_code & bit:
+                bufs[name] = np.empty((nz, ntstar, R))
+                bufs[name + "_list"] = np.empty((C, nz, ntstar, R)) if want_lists else None
+            else:
+                bufs[name] = None
+                bufs[name + "_list"] = None
+        self._check(self._lib.gpcsd_predict(self._h, ctypes.byref(hp), _ptr(z), nz, _ptr(tstar), tstar.size, int(type_code),
+                                            _ptr(bufs["csd_list"]), _ptr(bufs["csd"]), _ptr(bufs["lfp_list"]), _ptr(bufs["lfp"])))
+        for k, v in bufs.items():
+            if v is not None:
+                res[k] = v
+        return res
+
+    def predict_resident(self, hp, z, tstar, type_code, want_lists=True):
+        """Compute the posterior mean into device buffers only (no PCIe traffic); read back with fetch()."""
+        z = _arr(z)
+        tstar = _arr(tstar).reshape(-1)
+        self._check(self._lib.gpcsd_predict_resident(self._h, ctypes.byref(hp), _ptr(z), z.shape[0], _ptr(tstar), tstar.size,
+                                                     int(type_code), int(bool(want_lists))))
+
+    def fetch(self, name, shape):
+        out = np.empty(shape)
+        self._check(self._lib.gpcsd_fetch(self._h, name.encode(), _ptr(out), out.size))
+        return out
+
+    def sample_prior(self, hp, which, normals):
+        normals = _arr(np.atleast_3d(normals))
+        out = np.empty_like(normals)
+        self._check(self._lib.gpcsd_sample_prior(self._h, ctypes.byref(hp), int(which), _ptr(normals), normals.shape[2], _ptr(out)))
+        return out
+
+    # ---- measurement ----
+    def synchronize(self):
+        self._check(self._lib.gpcsd_device_synchronize(self._h))
+
+    def prof_enable(self, on=True):
+        self._check(self._lib.gpcsd_prof_enable(self._h, int(bool(on))))
+
+    def prof_reset(self):
+        self._check(self._lib.gpcsd_prof_reset(self._h))
+
+    def prof_names(self):
+        buf = ctypes.create_string_buffer(8192)
+        self._check(self._lib.gpcsd_prof_names(self._h, buf, len(buf)))
+        s = buf.value.decode()
+        return [n for n in s.split(";") if n]
+
+    def prof_get(self, name):
+        ms, fl = ctypes.c_double(), ctypes.c_double()
+        cnt = ctypes.c_long()
+        rc = self._lib.gpcsd_prof_get(self._h, name.encode(), ctypes.byref(ms), ctypes.byref(cnt), ctypes.byref(fl))
+        if rc == -2:
+            return None
+        self._check(rc)
+        return {"ms": ms.value, "count": cnt.value, "flops": fl.value}
+
+    def prof_all(self):
+        return {n: self.prof_get(n) for n in self.prof_names()}
+
+    def mfma_f64_peak(self):
+        out = ctypes.c_double()
+        self._check(self._lib.gpcsd_mfma_f64_peak(self._h, ctypes.byref(out)))
+        return out.value
+
+    def hbm_copy_peak(self, nbytes=1 << 30):
+        out = ctypes.c_double()
+        self._check(self._lib.gpcsd_hbm_copy_peak(self._h, int(nbytes), ctypes.byref(out)))
+        return out.value
+
+
+_default_ctx = None
+_default_lock = threading.Lock()
+
+
+def default_context():
+    """Process-wide context for the stand-alone operator surface; created lazily (never at import: fork safety)."""
+    global _default_ctx
+    with _default_lock:
+        if _default_ctx is None:
+            _default_ctx = Context()
+        return _default_ctx

@@ -1,0 +1,944 @@
+// extern "C" surface of libgpcsd_hip.so (include/gpcsd_hip.h) and the host-side orchestration of the hot path.
+#include <cmath>
+#include <mutex>
+
+#include "kernels.hpp"
+
+using namespace gpcsd;
+
+static std::string g_last_error;
+static std::mutex g_err_mutex;
+
+static int fail(gpcsd_ctx *c, const HipError &e) {
+    if (c) c->last_error = e.msg;
+    std::lock_guard<std::mutex> lk(g_err_mutex);
+    g_last_error = e.msg;
+    return e.code;
+}
+
+#define GP_API_BEGIN(ctx)                                                                      \
+    if (!(ctx)) return fail(nullptr, HipError{-1, "null context"});                            \
+    try {                                                                                      \
+        GP_HIP(hipSetDevice((ctx)->device));
+#define GP_API_END(ctx)                                                                        \
+    }                                                                                          \
+    catch (const HipError &e) { return fail((ctx), e); }                                       \
+    catch (const std::exception &e) { return fail((ctx), HipError{-99, e.what()}); }
+
+void gpcsd_ctx::prof_collect() {
+    for (auto &kv : prof) {
+        ProfEntry &p = kv.second;
+        for (size_t i = 0; i < p.pending.size(); ++i) {
+            float ms = 0.f;
+            if (hipEventSynchronize(p.pending[i].second) == hipSuccess &&
+                hipEventElapsedTime(&ms, p.pending[i].first, p.pending[i].second) == hipSuccess) {
+                p.ms += ms;
+                p.count += 1;
+                p.flops += p.pending_flops[i];
+            }
+            event_pool.push_back(p.pending[i].first);
+            event_pool.push_back(p.pending[i].second);
+        }
+        p.pending.clear();
+        p.pending_flops.clear();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// internal pipelines (device pointers)
+// ------------------------------------------------------------------------------------------------
+namespace {
+
+struct Geo {     // device-side geometry description (either resident in ctx or uploaded per operator call)
+    int dim = 0;
+    const double *x = nullptr;   // (nx) or (nx,2)
+    int nx = 0;
+    const double *gx1 = nullptr, *gw1 = nullptr, *gx2 = nullptr, *gw2 = nullptr;
+    int ngl1 = 0, ngl2 = 0;
+    int G() const { return dim == 1 ? ngl1 : ngl1 * ngl2; }
+};
+
+Geo resident_geo(gpcsd_ctx *c) {
+    GP_REQUIRE(c->dim == 1 || c->dim == 2, -4, "geometry not set (call gpcsd_set_geometry_1d/2d)");
+    Geo g;
+    g.dim = c->dim;
+    g.nx = c->geo_nx;
+    g.x = (const double *)c->bufs["geo_x"].p;
+    g.gx1 = (const double *)c->bufs["geo_gx1"].p;
+    g.gw1 = (const double *)c->bufs["geo_gw1"].p;
+    g.ngl1 = c->ngl1;
+    if (c->dim == 2) {
+        g.gx2 = (const double *)c->bufs["geo_gx2"].p;
+        g.gw2 = (const double *)c->bufs["geo_gw2"].p;
+        g.ngl2 = c->ngl2;
+    }
+    return g;
+}
+
+// A(n, G) forward weights for the point set pts (n points)
+void fwd_weights(gpcsd_ctx *c, const Geo &g, const double *pts, int n, double R, double eps, double *A, hipStream_t s) {
+    if (g.dim == 1) k_fwd_weights_1d(c, pts, n, g.gx1, g.gw1, g.ngl1, R, A, s);
+    else k_fwd_weights_2d(c, pts, n, g.gx1, g.gw1, g.ngl1, g.gx2, g.gw2, g.ngl2, R, eps, A, s);
+}
+
+// Kphi(nx, nxp) = A Kgl Axp^T (+ jitter I when square and jitter != 0)     covariances.py:74-96 / :204-232
+void build_kphi(gpcsd_ctx *c, const Geo &g, double R, double eps, const double *ell, const double *xp, int nxp, double jitter,
+                double *out, hipStream_t s) {
+    const int G = g.G();
+    double *A = c->buf<double>("ks_A", (size_t)g.nx * G);
+    double *Kgl = c->buf<double>("ks_Kgl", (size_t)G * G);
+    double *T = c->buf<double>("ks_T", (size_t)g.nx * G);
+    fwd_weights(c, g, g.x, g.nx, R, eps, A, s);
+    if (g.dim == 1) k_se_1d(c, g.gx1, G, g.gx1, G, ell[0], Kgl, s);
+    else k_se_2d(c, g.gx1, g.gx2, G, g.ngl2, g.gx1, g.gx2, G, g.ngl2, ell[0], ell[1], Kgl, s);
+    GemmDesc d1;                                   // T = A Kgl
+    d1.M = g.nx; d1.N = G; d1.K = G;
+    d1.A = A; d1.lda = G; d1.B = Kgl; d1.ldb = G; d1.C = T; d1.ldc = G;
+    d1.prof_name = "gemm_Ks_AKgl";
+    gemm_f64(c, d1, s);
+    const double *Axp = A;
+    int n2 = g.nx;
+    if (xp) {
+        double *A2 = c->buf<double>("ks_Axp", (size_t)nxp * G);
+        fwd_weights(c, g, xp, nxp, R, eps, A2, s);
+        Axp = A2;
+        n2 = nxp;
+    }
+    GemmDesc d2;                                   // out = T Axp^T
+    d2.M = g.nx; d2.N = n2; d2.K = G;
+    d2.A = T; d2.lda = G; d2.B = Axp; d2.ldb = G; d2.transB = true; d2.C = out; d2.ldc = n2;
+    d2.prof_name = "gemm_Ks_TAt";
+    gemm_f64(c, d2, s);
+    if (jitter != 0.0 && n2 == g.nx) k_add_diag(c, out, g.nx, jitter, s);
+}
+
+// Kphig(nx, nz) = A Kcross, Kcross[g, z] = SE(gl_g, z)                     covariances.py:58-72 / :188-202
+void build_kphig(gpcsd_ctx *c, const Geo &g, double R, double eps, const double *ell, const double *z, int nz, double *out,
+                 hipStream_t s) {
+    const int G = g.G();
+    double *A = c->buf<double>("ks_A", (size_t)g.nx * G);
+    double *Kc = c->buf<double>("ks_Kcross", (size_t)G * nz);
+    fwd_weights(c, g, g.x, g.nx, R, eps, A, s);
+    if (g.dim == 1) k_se_1d(c, g.gx1, G, z, nz, ell[0], Kc, s);
+    else k_se_2d(c, g.gx1, g.gx2, G, g.ngl2, z, nullptr, nz, 0, ell[0], ell[1], Kc, s);
+    GemmDesc d;
+    d.M = g.nx; d.N = nz; d.K = G;
+    d.A = A; d.lda = G; d.B = Kc; d.ldb = nz; d.C = out; d.ldc = nz;
+    d.prof_name = "gemm_Kphig";
+    gemm_f64(c, d, s);
+}
+
+void build_ks_csd(gpcsd_ctx *c, const Geo &g, const double *ell, double *out, hipStream_t s) {
+    if (g.dim == 1) k_se_1d(c, g.x, g.nx, g.x, g.nx, ell[0], out, s);
+    else k_se_2d(c, g.x, nullptr, g.nx, 0, g.x, nullptr, g.nx, 0, ell[0], ell[1], out, s);
+}
+
+void build_kt(gpcsd_ctx *c, const gpcsd_hparams *hp, const double *t, int n, const double *tp, int m, double *out,
+              hipStream_t s) {
+    k_temporal_gram(c, hp->n_temporal, hp->kind, hp->ell_t, hp->sigma2_t, t, n, tp, m, out, s);
+}
+
+void check_hp(gpcsd_ctx *c, const gpcsd_hparams *hp, int nx) {
+    GP_REQUIRE(hp != nullptr, -3, "null hparams");
+    GP_REQUIRE(hp->n_temporal >= 1 && hp->n_temporal <= GPCSD_MAX_TEMPORAL, -3, "n_temporal=%d outside [1,%d]",
+               hp->n_temporal, GPCSD_MAX_TEMPORAL);
+    GP_REQUIRE(hp->sig2n != nullptr && (hp->n_sig2n == 1 || hp->n_sig2n == nx), -3,
+               "sig2n must have 1 or nx=%d entries (got %d)", nx, hp->n_sig2n);
+}
+
+// Eigen-decompose Ks (stream) and Kt (stream2) concurrently; D and sum(log D).
+// Inputs Ks, Kt are destroyed.  Outputs: Qs, es, Qt, et, D, sumlog (device).
+void eig_pair_D(gpcsd_ctx *c, double *Ks, int nx, double *Kt, int nt, const double *d_sig, int nsig, double *Qs, double *es,
+                double *Qt, double *et, double *D, double *d_sumlog, int *d_status) {
+    GP_HIP(hipEventRecord(c->ev_fork, c->stream));
+    GP_HIP(hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
+    eigh_device(c, Kt, nt, et, Qt, d_status, c->stream2, "eigh_t");
+    eigh_device(c, Ks, nx, es, Qs, d_status, c->stream, "eigh_s");
+    GP_HIP(hipEventRecord(c->ev_join, c->stream2));
+    GP_HIP(hipStreamWaitEvent(c->stream, c->ev_join, 0));
+    k_build_D(c, es, nx, et, nt, d_sig, nsig, D, d_sumlog, c->stream);
+}
+
+struct EigState {
+    double *Qs, *Qt, *es, *et, *D, *scal;   // scal[0] = sumlog, scal[1] = quad, ...
+    int *status;
+};
+
+// Shared front half of loglik / predict: Ks (+jitter), Kt, eigen-decompositions, D.
+EigState front_half(gpcsd_ctx *c, const gpcsd_hparams *hp, double jitter) {
+    const Geo g = resident_geo(c);
+    GP_REQUIRE(c->d_lfp != nullptr, -4, "lfp not set (call gpcsd_set_lfp)");
+    GP_REQUIRE(c->time_nt == c->nt, -4, "time grid has %d points but lfp has nt=%d", c->time_nt, c->nt);
+    GP_REQUIRE(g.nx == c->nx, -4, "geometry has %d electrodes but lfp has nx=%d", g.nx, c->nx);
+    check_hp(c, hp, c->nx);
+    const int nx = c->nx, nt = c->nt;
+    hipStream_t s = c->stream;
+    EigState e;
+    double *Ks = c->buf<double>("Ks", (size_t)nx * nx);
+    double *Kt = c->buf<double>("Kt", (size_t)nt * nt);
+    e.Qs = c->buf<double>("Qs", (size_t)nx * nx);
+    e.Qt = c->buf<double>("Qt", (size_t)nt * nt);
+    e.es = c->buf<double>("es", nx);
+    e.et = c->buf<double>("et", nt);
+    e.D = c->buf<double>("D", (size_t)nx * nt);
+    e.scal = c->buf<double>("scalars", 64);
+    e.status = c->buf<int>("status", 4);
+    double *d_sig = c->upload<double>("sig2n", hp->sig2n, hp->n_sig2n);
+    GP_HIP(hipMemsetAsync(e.status, 0, 4 * sizeof(int), s));
+    const double *t = (const double *)c->bufs["time_t"].p;
+    build_kphi(c, g, hp->R, hp->eps, hp->ell_s, nullptr, 0, jitter, Ks, s);
+    build_kt(c, hp, t, nt, t, nt, Kt, s);
+    eig_pair_D(c, Ks, nx, Kt, nt, d_sig, hp->n_sig2n, e.Qs, e.es, e.Qt, e.et, e.D, e.scal, e.status);
+    return e;
+}
+
+int finish_status(gpcsd_ctx *c, const int *d_status) {
+    int st[4];
+    c->download(st, d_status, sizeof(st));
+    c->sync();
+    if (c->prof_on) c->prof_collect();
+    if (st[0] != 0) {
+        char b[128];
+        snprintf(b, sizeof(b), "numerical failure (status %d): eigensolver did not converge or matrix not positive definite", st[0]);
+        c->last_error = b;
+        return st[0] > 0 ? st[0] : 1;
+    }
+    return 0;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------
+// context
+// ------------------------------------------------------------------------------------------------
+extern "C" int gpcsd_version(void) { return 100; }
+
+extern "C" const char *gpcsd_last_error(gpcsd_ctx *ctx) {
+    if (ctx) return ctx->last_error.c_str();
+    return g_last_error.c_str();
+}
+
+extern "C" int gpcsd_ctx_create(int device, gpcsd_ctx **out) {
+    if (!out) return -1;
+    *out = nullptr;
+    gpcsd_ctx *c = nullptr;
+    try {
+        int ndev = 0;
+        GP_HIP(hipGetDeviceCount(&ndev));
+        GP_REQUIRE(ndev > 0, -5, "no HIP device visible");
+        GP_REQUIRE(device >= 0 && device < ndev, -5, "device %d out of range (have %d)", device, ndev);
+        GP_HIP(hipSetDevice(device));
+        c = new gpcsd_ctx();
+        c->device = device;
+        GP_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+        GP_HIP(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
+        GP_HIP(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+        GP_HIP(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
+        *out = c;
+        return 0;
+    } catch (const HipError &e) {
+        delete c;
+        return fail(nullptr, e);
+    }
+}
+
+extern "C" int gpcsd_ctx_destroy(gpcsd_ctx *c) {
+    if (!c) return 0;
+    (void)hipSetDevice(c->device);
+    (void)hipDeviceSynchronize();
+    for (auto &kv : c->bufs)
+        if (kv.second.p) (void)hipFree(kv.second.p);
+    if (c->d_lfp) (void)hipFree(c->d_lfp);
+    for (auto &kv : c->prof)
+        for (auto &p : kv.second.pending) {
+            (void)hipEventDestroy(p.first);
+            (void)hipEventDestroy(p.second);
+        }
+    for (auto e : c->event_pool) (void)hipEventDestroy(e);
+    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    if (c->stream2) (void)hipStreamDestroy(c->stream2);
+    delete c;
+    return 0;
+}
+
+extern "C" int gpcsd_device_synchronize(gpcsd_ctx *c) {
+    GP_API_BEGIN(c)
+    GP_HIP(hipStreamSynchronize(c->stream2));
+    c->sync();
+    return 0;
+    GP_API_END(c)
+}
+
+// ------------------------------------------------------------------------------------------------
+// resident data
+// ------------------------------------------------------------------------------------------------
+extern "C" int gpcsd_set_lfp(gpcsd_ctx *c, const double *lfp, int nx, int nt, int ntrials) {
+    GP_API_BEGIN(c)
+    GP_REQUIRE(lfp && nx > 0 && nt > 0 && ntrials > 0, -3, "set_lfp: bad shape (%d,%d,%d)", nx, nt, ntrials);
+    const size_t n = (size_t)nx * nt * ntrials;
+    double *stage = c->upload<double>("lfp_stage", lfp, n);
+    if (c->d_lfp) {
+        c->sync();
+        GP_HIP(hipFree(c->d_lfp));
+        c->d_lfp = nullptr;
+    }
+    GP_HIP(hipMalloc((void **)&c->d_lfp, n * sizeof(double)));
+    k_swap_last2(c, stage, c->d_lfp, nx, nt, ntrials, c->stream);     // (x,t,r) -> (x,r,t)
+    c->sync();
+    c->nx = nx; c->nt = nt; c->ntrials = ntrials;
+    return 0;
+    GP_API_END(c)
+}
+
+extern "C" int gpcsd_set_geometry_1d(gpcsd_ctx *c, const double *x, int nx, const double *gl_x, const double *gl_w, int ngl) {
+    GP_API_BEGIN(c)
+    GP_REQUIRE(x && gl_x && gl_w && nx > 0 && ngl > 0, -3, "set_geometry_1d: bad arguments");
+    c->upload<double>("geo_x", x, nx);
+    c->upload<double>("geo_gx1", gl_x, ngl);
+    c->upload<double>("geo_gw1", gl_w, ngl);
+    c->sync();
+    c->dim = 1; c->geo_nx = nx; c->ngl1 = ngl; c->ngl2 = 0;
+    return 0;
+    GP_API_END(c)
+}
+
+extern "C" int gpcsd_set_geometry_2d(gpcsd_ctx *c, const double *xy, int nx, const double *gl_x1, const double *gl_w1, int ngl1,
+                                     const double *gl_x2, const double *gl_w2, int ngl2) {
+    GP_API_BEGIN(c)
+    GP_REQUIRE(xy && gl_x1 && gl_w1 && gl_x2 && gl_w2 && nx > 0 && ngl1 > 0 && ngl2 > 0, -3, "set_geometry_2d: bad arguments");
+    c->upload<double>("geo_x", xy, (size_t)nx * 2);
+    c->upload<double>("geo_gx1", gl_x1, ngl1);
+    c->upload<double>("geo_gw1", gl_w1, ngl1);
+    c->upload<double>("geo_gx2", gl_x2, ngl2);
+    c->upload<double>("geo_gw2", gl_w2, ngl2);
+    c->sync();
+    c->dim = 2; c->geo_nx = nx; c->ngl1 = ngl1; c->ngl2 = ngl2;
+    return 0;
+    GP_API_END(c)
+}
+
+extern "C" int gpcsd_set_time(gpcsd_ctx *c, const double *t, int nt) {
+    GP_API_BEGIN(c)
+    GP_REQUIRE(t && nt > 0, -3, "set_time: bad arguments");
+    c->upload<double>("time_t", t, nt);
+    c->sync();
+    c->time_nt = nt;
+    return 0;
+    GP_API_END(c)
+}
+
+// ------------------------------------------------------------------------------------------------
+// operator surface
+// ------------------------------------------------------------------------------------------------
+extern "C" int gpcsd_b_fwd_1d(gpcsd_ctx *c, const double *r, long n, double R, double *out) {
+    GP_API_BEGIN(c)
+    if (n <= 0) return 0;
+    double *d = c->upload<double>("op_in0", r, n);
+    double *o = c->buf<double>("op_out", n);
+    k_b_fwd_1d(c, d, n, R, o, c->stream);
+    c->download(out, o, n * sizeof(double));
+    c->sync();
+    return 0;
+    GP_API_END(c)
+}
+
+extern "C" int gpcsd_b_fwd_2d(gpcsd_ctx *c, const double *d1, const double *d2, const double *w, long n, double R, double eps,
+                              double *out) {
+    GP_API_BEGIN(c)
+    if (n <= 0) return 0;
+    double *dd1 = nullptr, *dd2 = nullptr, *dw = nullptr;
+    if (w) dw = c->upload<double>("op_in0", w, n);
+    else {
+        GP_REQUIRE(d1 && d2, -3, "b_fwd_2d: need delta1 and delta2 when w is NULL");
+        dd1 = c->upload<double>("op_in0", d1, n);
+        dd2 = c->upload<double>("op_in1", d2, n);
+    }
+    double *o = c->buf<double>("op_out", n);
+    k_b_fwd_2d(c, dd1, dd2, dw, n, R, eps, o, c->stream);
+    c->download(out, o, n * sizeof(double));
+    c->sync();
+    return 0;
+    GP_API_END(c)
+}
+
+extern "C" int gpcsd_gram_temporal(gpcsd_ctx *c, int kind, const double *t, int n, const double *tp, int m, double ell,
+                                   double sigma2, double *out) {
+    GP_API_BEGIN(c)
+    GP_REQUIRE(kind == GPCSD_KIND_SE || kind == GPCSD_KIND_MATERN, -3, "unknown temporal kernel kind %d", kind);
+    if (n <= 0 || m <= 0) return 0;
+    double *dt = c->upload<double>("op_in0", t, n);
+    double *dtp = c->upload<double>("op_in1", tp, m);
+    double *o = c->buf<double>("op_out", (size_t)n * m);
+    k_temporal_gram(c, 1, &kind, &ell, &sigma2, dt, n, dtp, m, o, c->stream);
+    c->download(out, o, (size_t)n * m * sizeof(double));
+    c->sync();
+    return 0;
+    GP_API_END(c)
+}
+
+extern "C" int gpcsd_ks_csd_1d(gpcsd_ctx *c, const double *x, int nx, double ell, double *out) {
+    GP_API_BEGIN(c)
+    double *dx = c->upload<double>("op_in0", x, nx);
+    double *o = c->buf<double>("op_out", (size_t)nx * nx);
+    k_se_1d(c, dx, nx, dx, nx, ell, o, c->stream);
+    c->download(out, o, (size_t)nx * nx * sizeof(double));
+    c->sync();
+    return 0;
+    GP_API_END(c)
+}
+
+extern "C" int gpcsd_ks_csd_2d(gpcsd_ctx *c, const double *xy, int nx, double ell1, double ell2, double *out) {
+    GP_API_BEGIN(c)
+    double *dx = c->upload<double>("op_in0", xy, (size_t)nx * 2);
+    double *o = c->buf<double>("op_out", (size_t)nx * nx);
+    k_se_2d(c, dx, nullptr, nx, 0, dx, nullptr, nx, 0, ell1, ell2, o, c->stream);
+    c->download(out, o, (size_t)nx * nx * sizeof(double));
+    c->sync();
+    return 0;
+    GP_API_END(c)
+}
+
+static Geo upload_geo_1d(gpcsd_ctx *c, const double *x, int nx, const double *gl_x, const double *gl_w, int ngl) {
+    GP_REQUIRE(x && gl_x && gl_w && nx > 0 && ngl > 0, -3, "bad 1D geometry arguments");
+    Geo g;
+    g.dim = 1; g.nx = nx; g.ngl1 = ngl;
+    g.x = c->upload<double>("op_x", x, nx);
+    g.gx1 = c->upload<double>("op_gx1", gl_x, ngl);
+    g.gw1 = c->upload<double>("op_gw1", gl_w, ngl);
+    return g;
+}
+
+static Geo upload_geo_2d(gpcsd_ctx *c, const double *xy, int nx, const double *gx1, const double *gw1, int ngl1,
+                         const double *gx2, const double *gw2, int ngl2) {
+    GP_REQUIRE(xy && gx1 && gw1 && gx2 && gw2 && nx > 0 && ngl1 > 0 && ngl2 > 0, -3, "bad 2D geometry arguments");
+    Geo g;
+    g.dim = 2; g.nx = nx; g.ngl1 = ngl1; g.ngl2 = ngl2;
+    g.x = c->upload<double>("op_x", xy, (size_t)nx * 2);
+    g.gx1 = c->upload<double>("op_gx1", gx1, ngl1);
+    g.gw1 = c->upload<double>("op_gw1", gw1, ngl1);
+    g.gx2 = c->upload<double>("op_gx2", gx2, ngl2);
+    g.gw2 = c->upload<double>("op_gw2", gw2, ngl2);
+    return g;
+}
+
+extern "C" int gpcsd_kphi_1d(gpcsd_ctx *c, const double *x, int nx, const double *gl_x, const double *gl_w, int ngl, double R,
+                             double ell, const double *xp, int nxp, double *out) {
+    GP_API_BEGIN(c)
+    Geo g = upload_geo_1d(c, x, nx, gl_x, gl_w, ngl);
+    const double *dxp = nullptr;
+    if (xp) {
+        GP_REQUIRE(nxp > 0, -3, "kphi_1d: nxp must be positive");
+        dxp = c->upload<double>("op_xp", xp, nxp);
+    }
+    const int n2 = xp ? nxp : nx;
+    double *o = c->buf<double>("op_out", (size_t)nx * n2);
+    build_kphi(c, g, R, 0.0, &ell, dxp, nxp, 0.0, o, c->stream);
+    c->download(out, o, (size_t)nx * n2 * sizeof(double));
+    c->sync();
+    return 0;
+    GP_API_END(c)
+}
+
+extern "C" int gpcsd_kphig_1d(gpcsd_ctx *c, const double *x, int nx, const double *gl_x, const double *gl_w, int ngl,
+                              const double *z, int nz, double R, double ell, double *out) {
+    GP_API_BEGIN(c)
+    GP_REQUIRE(z && nz > 0, -3, "kphig_1d: bad z");
+    Geo g = upload_geo_1d(c, x, nx, gl_x, gl_w, ngl);
+    double *dz = c->upload<double>("op_xp", z, nz);
+    double *o = c->buf<double>("op_out", (size_t)nx * nz);
+    build_kphig(c, g, R, 0.0, &ell, dz, nz, o, c->stream);
+    c->download(out, o, (size_t)nx * nz * sizeof(double));
+    c->sync();
+    return 0;
+    GP_API_END(c)
+}
+
+extern "C" int gpcsd_kphi_2d(gpcsd_ctx *c, const double *xy, int nx, const double *gl_x1, const double *gl_w1, int ngl1,
+                             const double *gl_x2, const double *gl_w2, int ngl2, double R, double eps, double ell1, double ell2,
+                             const double *xp, int nxp, double *out) {
+    GP_API_BEGIN(c)
+    Geo g = upload_geo_2d(c, xy, nx, gl_x1, gl_w1, ngl1, gl_x2, gl_w2, ngl2);
+    const double *dxp = nullptr;
+    if (xp) {
+        GP_REQUIRE(nxp > 0, -3, "kphi_2d: nxp must be positive");
+        dxp = c->upload<double>("op_xp", xp, (size_t)nxp * 2);
+    }
+    const int n2 = xp ? nxp : nx;
+    const double ell[2] = {ell1, ell2};
+    double *o = c->buf<double>("op_out", (size_t)nx * n2);
+    build_kphi(c, g, R, eps, ell, dxp, nxp, 0.0, o, c->stream);
+    c->download(out, o, (size_t)nx * n2 * sizeof(double));
+    c->sync();
+    return 0;
+    GP_API_END(c)
+}
+
+extern "C" int gpcsd_kphig_2d(gpcsd_ctx *c, const double *xy, int nx, const double *gl_x1, const double *gl_w1, int ngl1,
+                              const double *gl_x2, const double *gl_w2, int ngl2, const double *z, int nz, double R, double eps,
+                              double ell1, double ell2, double *out) {
+    GP_API_BEGIN(c)
+    GP_REQUIRE(z && nz > 0, -3, "kphig_2d: bad z");
+    Geo g = upload_geo_2d(c, xy, nx, gl_x1, gl_w1, ngl1, gl_x2, gl_w2, ngl2);
+    double *dz = c->upload<double>("op_xp", z, (size_t)nz * 2);
+    const double ell[2] = {ell1, ell2};
+    double *o = c->buf<double>("op_out", (size_t)nx * nz);
+    build_kphig(c, g, R, eps, ell, dz, nz, o, c->stream);
+    c->download(out, o, (size_t)nx * nz * sizeof(double));
+    c->sync();
+    return 0;
+    GP_API_END(c)
+}
+
+extern "C" int gpcsd_eigh(gpcsd_ctx *c, const double *A, int n, double *evals, double *evecs) {
+    GP_API_BEGIN(c)
+    GP_REQUIRE(A && evals && evecs && n > 0, -3, "eigh: bad arguments");
+    double *dA = c->upload<double>("op_in0", A, (size_t)n * n);
+    double *dw = c->buf<double>("op_w", n);
+    double *dV = c->buf<double>("op_out", (size_t)n * n);
+    int *st = c->buf<int>("status", 4);
+    GP_HIP(hipMemsetAsync(st, 0, 4 * sizeof(int), c->stream));
+    eigh_device(c, dA, n, dw, dV, st, c->stream, "eigh");
+    c->download(evals, dw, n * sizeof(double));
+    c->download(evecs, dV, (size_t)n * n * sizeof(double));
+    return finish_status(c, st);
+    GP_API_END(c)
+}
+
+extern "C" int gpcsd_eig_D(gpcsd_ctx *c, const double *Ks, int nx, const double *Kt, int nt, const double *sig2n, int n_sig,
+                           double *Qs, double *Qt, double *Dvec) {
+    GP_API_BEGIN(c)
+    GP_REQUIRE(Ks && Kt && sig2n && nx > 0 && nt > 0 && (n_sig == 1 || n_sig == nx), -3, "eig_D: bad arguments");
+    double *dKs = c->upload<double>("Ks", Ks, (size_t)nx * nx);
+    double *dKt = c->upload<double>("Kt", Kt, (size_t)nt * nt);
+    double *dsig = c->upload<double>("sig2n", sig2n, n_sig);
+    double *dQs = c->buf<double>("Qs", (size_t)nx * nx), *dQt = c->buf<double>("Qt", (size_t)nt * nt);
+    double *es = c->buf<double>("es", nx), *et = c->buf<double>("et", nt);
+    double *D = c->buf<double>("D", (size_t)nx * nt);
+    double *scal = c->buf<double>("scalars", 64);
+    int *st = c->buf<int>("status", 4);
+    GP_HIP(hipMemsetAsync(st, 0, 4 * sizeof(int), c->stream));
+    eig_pair_D(c, dKs, nx, dKt, nt, dsig, n_sig, dQs, es, dQt, et, D, scal, st);
+    if (Qs) c->download(Qs, dQs, (size_t)nx * nx * sizeof(double));
+    if (Qt) c->download(Qt, dQt, (size_t)nt * nt * sizeof(double));
+    if (Dvec) c->download(Dvec, D, (size_t)nx * nt * sizeof(double));
+    return finish_status(c, st);
+    GP_API_END(c)
+}
+
+extern "C" int gpcsd_potrf(gpcsd_ctx *c, const double *A, int n, double *L) {
+    GP_API_BEGIN(c)
+    GP_REQUIRE(A && L && n > 0, -3, "potrf: bad arguments");
+    double *dA = c->upload<double>("op_in0", A, (size_t)n * n);
+    int *st = c->buf<int>("status", 4);
+    GP_HIP(hipMemsetAsync(st, 0, 4 * sizeof(int), c->stream));
+    potrf_device(c, dA, n, st, c->stream);
+    c->download(L, dA, (size_t)n * n * sizeof(double));
+    return finish_status(c, st);
+    GP_API_END(c)
+}
+
+extern "C" int gpcsd_logdet_chol(gpcsd_ctx *c, const double *L, int n, double *out) {
+    GP_API_BEGIN(c)
+    GP_REQUIRE(L && out && n > 0, -3, "logdet_chol: bad arguments");
+    double *dL = c->upload<double>("op_in0", L, (size_t)n * n);
+    double *scal = c->buf<double>("scalars", 64);
+    logdet_chol_device(c, dL, n, scal, c->stream);
+    c->download(out, scal, sizeof(double));
+    c->sync();
+    return 0;
+    GP_API_END(c)
+}
+
+extern "C" int gpcsd_trsm_lower(gpcsd_ctx *c, const double *L, int n, const double *B, int nrhs, double *X) {
+    GP_API_BEGIN(c)
+    GP_REQUIRE(L && B && X && n > 0 && nrhs > 0, -3, "trsm_lower: bad arguments");
+    double *dL = c->upload<double>("op_in0", L, (size_t)n * n);
+    double *dB = c->upload<double>("op_in1", B, (size_t)n * nrhs);
+    trsm_lower_device(c, dL, n, dB, nrhs, c->stream);
+    c->download(X, dB, (size_t)n * nrhs * sizeof(double));
+    c->sync();
+    if (c->prof_on) c->prof_collect();
+    return 0;
+    GP_API_END(c)
+}
+
+extern "C" int gpcsd_gemm(gpcsd_ctx *c, int transA, int transB, int M, int N, int K, const double *A, const double *B,
+                          double *C) {
+    GP_API_BEGIN(c)
+    GP_REQUIRE(A && B && C && M > 0 && N > 0 && K > 0, -3, "gemm: bad arguments");
+    double *dA = c->upload<double>("op_in0", A, (size_t)M * K);
+    double *dB = c->upload<double>("op_in1", B, (size_t)K * N);
+    double *dC = c->buf<double>("op_out", (size_t)M * N);
+    GemmDesc g;
+    g.M = M; g.N = N; g.K = K;
+    g.A = dA; g.transA = transA != 0; g.lda = transA ? M : K;
+    g.B = dB; g.transB = transB != 0; g.ldb = transB ? K : N;
+    g.C = dC; g.ldc = N;
+    gemm_f64(c, g, c->stream);
+    c->download(C, dC, (size_t)M * N * sizeof(double));
+    c->sync();
+    if (c->prof_on) c->prof_collect();
+    return 0;
+    GP_API_END(c)
+}
+
+// K[(x,i),(x',i')] = Ks[x,x'] Kt[i,i'] + sig2n delta
+__global__ void kron_plus_diag_kernel(const double *__restrict__ Ks, int nx, const double *__restrict__ Kt, int nt, double sig2n,
+                                      double *__restrict__ K) {
+    const long N = (long)nx * nt;
+    const long row = blockIdx.y;
+    const int x = (int)(row / nt), i = (int)(row % nt);
+    for (long col = blockIdx.x * (long)blockDim.x + threadIdx.x; col < N; col += (long)gridDim.x * blockDim.x) {
+        const int xp = (int)(col / nt), ip = (int)(col % nt);
+        double v = Ks[(long)x * nx + xp] * Kt[(long)i * nt + ip];
+        if (col == row) v += sig2n;
+        K[row * N + col] = v;
+    }
+}
+
+extern "C" int gpcsd_loglik_dense_chol(gpcsd_ctx *c, const double *Ks, int nx, const double *Kt, int nt, double sig2n,
+                                       const double *lfp, int ntrials, double *out) {
+    GP_API_BEGIN(c)
+    GP_REQUIRE(Ks && Kt && lfp && out && nx > 0 && nt > 0 && ntrials > 0, -3, "loglik_dense_chol: bad arguments");
+    const long N = (long)nx * nt;
+    GP_REQUIRE(N <= 16384, -3, "loglik_dense_chol: N = nx*nt = %ld too large for the dense cross-check (max 16384)", N);
+    GP_REQUIRE(N <= 65535, -3, "grid limit");
+    hipStream_t s = c->stream;
+    double *dKs = c->upload<double>("Ks", Ks, (size_t)nx * nx);
+    double *dKt = c->upload<double>("Kt", Kt, (size_t)nt * nt);
+    double *K = c->buf<double>("dense_K", (size_t)N * N);
+    double *y = c->upload<double>("dense_y", lfp, (size_t)N * ntrials);   // (nx,nt,R) C-order == (N, R)
+    double *scal = c->buf<double>("scalars", 64);
+    int *st = c->buf<int>("status", 4);
+    GP_HIP(hipMemsetAsync(st, 0, 4 * sizeof(int), s));
+    hipLaunchKernelGGL(kron_plus_diag_kernel, dim3(ceil_div(N, 256) > 64 ? 64 : ceil_div(N, 256), (unsigned)N), dim3(256), 0, s,
+                       (const double *)dKs, nx, (const double *)dKt, nt, sig2n, K);
+    potrf_device(c, K, (int)N, st, s);
+    logdet_chol_device(c, K, (int)N, scal, s);
+    trsm_lower_device(c, K, (int)N, y, ntrials, s);
+    sumsq_device(c, y, N * ntrials, scal + 1, s);
+    double h[2];
+    c->download(h, scal, sizeof(h));
+    int rc = finish_status(c, st);
+    *out = -0.5 * ntrials * h[0] - 0.5 * h[1];
+    return rc;
+    GP_API_END(c)
+}
+
+// ------------------------------------------------------------------------------------------------
+// fused hot calls
+// ------------------------------------------------------------------------------------------------
+extern "C" int gpcsd_loglik_parts(gpcsd_ctx *c, const gpcsd_hparams *hp, double *out2) {
+    GP_API_BEGIN(c)
+    GP_REQUIRE(out2 != nullptr, -3, "null output");
+    EigState e = front_half(c, hp, hp->jitter);
+    const int nx = c->nx, nt = c->nt, R = c->ntrials;
+    hipStream_t s = c->stream;
+    double *W = c->buf<double>("proj_W", (size_t)nx * R * nt);
+    GemmDesc g1;                          // W[x'][(r,t)] = sum_x Qs[x][x'] Y[x][(r,t)]        (gpcsd1d.py:125 inner dot)
+    g1.M = nx; g1.N = R * nt; g1.K = nx;
+    g1.A = e.Qs; g1.lda = nx; g1.transA = true;
+    g1.B = c->d_lfp; g1.ldb = (long)R * nt;
+    g1.C = W; g1.ldc = (long)R * nt;
+    g1.prof_name = "gemm_proj_spatial";
+    gemm_f64(c, g1, s);
+    GemmDesc g2;                          // alpha[(x',r)][i'] = sum_t W[(x',r)][t] Qt[t][i'];  quad = sum alpha^2 / D
+    g2.M = nx * R; g2.N = nt; g2.K = nt;
+    g2.A = W; g2.lda = nt;
+    g2.B = e.Qt; g2.ldb = nt;
+    g2.epi = EPI_QUAD; g2.D = e.D; g2.rdiv = R; g2.ldd = nt; g2.quad_out = e.scal + 1;
+    g2.prof_name = "gemm_proj_temporal_quad";
+    gemm_f64(c, g2, s);
+    c->download(out2, e.scal, 2 * sizeof(double));
+    return finish_status(c, e.status);
+    GP_API_END(c)
+}
+
+extern "C" int gpcsd_loglik(gpcsd_ctx *c, const gpcsd_hparams *hp, double *out) {
+    if (!out) return fail(c, HipError{-3, "null output"});
+    double p[2] = {0.0, 0.0};
+    int rc = gpcsd_loglik_parts(c, hp, p);
+    if (rc < 0) return rc;
+    *out = -0.5 * (double)c->ntrials * p[0] - 0.5 * p[1];      // gpcsd1d.py:122,127-128
+    return rc;
+}
+
+// Posterior mean into ctx-owned device buffers, already in the reference's output layout (z, t, trial):
+//   pred_out_csd / pred_out_lfp            (nz, ntstar, R)
+//   pred_out_csd_list / pred_out_lfp_list  (C, nz, ntstar, R)     when want_lists
+static int predict_impl(gpcsd_ctx *c, const gpcsd_hparams *hp, const double *z, int nz, const double *tstar, int ntstar,
+                        int type, bool want_lists) {
+    GP_REQUIRE(z && tstar && nz > 0 && ntstar > 0, -3, "predict: bad arguments");
+    GP_REQUIRE(type >= 1 && type <= 3, -3, "predict: type must be CSD(1), LFP(2) or BOTH(3)");
+    GP_REQUIRE(c->nt > 0 && ntstar == c->nt, -22,
+               "predict: len(t)=%d must equal the training nt=%d (the reference's reshape raises ValueError, gpcsd1d.py:279)",
+               ntstar, c->nt);
+    EigState e = front_half(c, hp, 0.0);           // no jitter in predict (gpcsd1d.py:258)
+    const Geo g = resident_geo(c);
+    const int nx = c->nx, nt = c->nt, R = c->ntrials, C = hp->n_temporal;
+    const long RT = (long)R * nt;
+    hipStream_t s = c->stream;
+    double *W = c->buf<double>("proj_W", (size_t)nx * RT);
+    double *Bm = c->buf<double>("pred_B", (size_t)nx * RT);
+    GemmDesc g1;                          // W = Qs^T Y
+    g1.M = nx; g1.N = (int)RT; g1.K = nx;
+    g1.A = e.Qs; g1.lda = nx; g1.transA = true;
+    g1.B = c->d_lfp; g1.ldb = RT; g1.C = W; g1.ldc = RT;
+    g1.prof_name = "gemm_proj_spatial";
+    gemm_f64(c, g1, s);
+    GemmDesc g2;                          // Bm = (W Qt) / D
+    g2.M = nx * R; g2.N = nt; g2.K = nt;
+    g2.A = W; g2.lda = nt; g2.B = e.Qt; g2.ldb = nt; g2.C = Bm; g2.ldc = nt;
+    g2.epi = EPI_DIV_D; g2.D = e.D; g2.rdiv = R; g2.ldd = nt;
+    g2.prof_name = "gemm_pred_temporal_div";
+    gemm_f64(c, g2, s);
+    GemmDesc g3;                          // W = Bm Qt^T
+    g3.M = nx * R; g3.N = nt; g3.K = nt;
+    g3.A = Bm; g3.lda = nt; g3.B = e.Qt; g3.ldb = nt; g3.transB = true; g3.C = W; g3.ldc = nt;
+    g3.prof_name = "gemm_pred_temporal_back";
+    gemm_f64(c, g3, s);
+    GemmDesc g4;                          // InvY = Qs W    (== invmat @ yvec, gpcsd1d.py:262-265)
+    g4.M = nx; g4.N = (int)RT; g4.K = nx;
+    g4.A = e.Qs; g4.lda = nx; g4.B = W; g4.ldb = RT; g4.C = Bm; g4.ldc = RT;
+    g4.prof_name = "gemm_pred_spatial_back";
+    gemm_f64(c, g4, s);
+    double *InvY = Bm;
+
+    double *dz = c->upload<double>("pred_z", z, (size_t)nz * g.dim);
+    double *dts = c->upload<double>("pred_tstar", tstar, ntstar);
+    const double *t = (const double *)c->bufs["time_t"].p;
+    double *Kc = c->buf<double>("pred_Kcross", (size_t)nx * nz);
+    double *S = c->buf<double>("pred_S", (size_t)nz * RT);
+    double *comp = c->buf<double>("pred_comp", (size_t)nz * RT);
+    double *tot = c->buf<double>("pred_tot", (size_t)nz * RT);
+    double *Kts = c->buf<double>("pred_Ktstar", (size_t)ntstar * nt);
+    const size_t out_elems = (size_t)nz * RT;
+
+    for (int which = 1; which <= 2; ++which) {
+        if (!(type & which)) continue;
+        double *o_sum = c->buf<double>(which == 1 ? "pred_out_csd" : "pred_out_lfp", out_elems);
+        double *o_list = want_lists ? c->buf<double>(which == 1 ? "pred_out_csd_list" : "pred_out_lfp_list", out_elems * C)
+                                    : nullptr;
+        if (which == 1) build_kphig(c, g, hp->R, hp->eps, hp->ell_s, dz, nz, Kc, s);        // gpcsd1d.py:273
+        else build_kphi(c, g, hp->R, hp->eps, hp->ell_s, dz, nz, 0.0, Kc, s);               // gpcsd1d.py:275
+        GemmDesc g5;                      // S[z][(r,t)] = sum_x Kc[x][z] InvY[x][(r,t)]
+        g5.M = nz; g5.N = (int)RT; g5.K = nx;
+        g5.A = Kc; g5.lda = nz; g5.transA = true; g5.B = InvY; g5.ldb = RT; g5.C = S; g5.ldc = RT;
+        g5.prof_name = "gemm_pred_cross";
+        gemm_f64(c, g5, s);
+        k_fill(c, tot, (long)out_elems, 0.0, s);
+        for (int cc = 0; cc < C; ++cc) {
+            // Ktstar_c = cov_c.compute_Kt(tstar): (ntstar, nt); its FIRST axis is contracted with the training
+            // time index of InvY (reference quirk when tstar != t)      gpcsd1d.py:277-279
+            k_temporal_gram(c, 1, &hp->kind[cc], &hp->ell_t[cc], &hp->sigma2_t[cc], dts, ntstar, t, nt, Kts, s);
+            GemmDesc g6;
+            g6.M = nz * R; g6.N = nt; g6.K = ntstar;
+            g6.A = S; g6.lda = nt; g6.B = Kts; g6.ldb = nt; g6.C = comp; g6.ldc = nt; g6.C2 = tot;
+            g6.epi = EPI_DUAL;
+            g6.prof_name = "gemm_pred_tstar";
+            gemm_f64(c, g6, s);
+            if (o_list) k_swap_last2(c, comp, o_list + (size_t)cc * out_elems, nz, R, nt, s);   // (z,r,t) -> (z,t,r)
+        }
+        k_swap_last2(c, tot, o_sum, nz, R, nt, s);
+    }
+    return finish_status(c, e.status);
+}
+
+extern "C" int gpcsd_predict_resident(gpcsd_ctx *c, const gpcsd_hparams *hp, const double *z, int nz, const double *tstar,
+                                      int ntstar, int type, int want_lists) {
+    GP_API_BEGIN(c)
+    return predict_impl(c, hp, z, nz, tstar, ntstar, type, want_lists != 0);
+    GP_API_END(c)
+}
+
+extern "C" int gpcsd_fetch(gpcsd_ctx *c, const char *name, double *host, long count) {
+    GP_API_BEGIN(c)
+    GP_REQUIRE(name && host && count > 0, -3, "fetch: bad arguments");
+    auto it = c->bufs.find(name);
+    GP_REQUIRE(it != c->bufs.end() && it->second.p, -2, "fetch: no device buffer named '%s'", name);
+    GP_REQUIRE((size_t)count * sizeof(double) <= it->second.bytes, -3, "fetch: '%s' holds %zu bytes, asked for %ld doubles", name,
+               it->second.bytes, count);
+    c->download(host, it->second.p, (size_t)count * sizeof(double));
+    c->sync();
+    return 0;
+    GP_API_END(c)
+}
+
+extern "C" int gpcsd_predict(gpcsd_ctx *c, const gpcsd_hparams *hp, const double *z, int nz, const double *tstar, int ntstar,
+                             int type, double *csd_list, double *csd, double *lfp_list, double *lfp) {
+    GP_API_BEGIN(c)
+    const bool want_lists = (csd_list != nullptr) || (lfp_list != nullptr);
+    int rc = predict_impl(c, hp, z, nz, tstar, ntstar, type, want_lists);
+    if (rc < 0) return rc;
+    const size_t out_elems = (size_t)nz * ntstar * c->ntrials;
+    const int C = hp->n_temporal;
+    if ((type & 1) && csd) c->download(csd, c->bufs["pred_out_csd"].p, out_elems * sizeof(double));
+    if ((type & 1) && csd_list) c->download(csd_list, c->bufs["pred_out_csd_list"].p, out_elems * C * sizeof(double));
+    if ((type & 2) && lfp) c->download(lfp, c->bufs["pred_out_lfp"].p, out_elems * sizeof(double));
+    if ((type & 2) && lfp_list) c->download(lfp_list, c->bufs["pred_out_lfp_list"].p, out_elems * C * sizeof(double));
+    c->sync();
+    return rc;
+    GP_API_END(c)
+}
+
+extern "C" int gpcsd_sample_prior(gpcsd_ctx *c, const gpcsd_hparams *hp, int which, const double *normals, int ntrials,
+                                  double *out) {
+    GP_API_BEGIN(c)
+    const Geo g = resident_geo(c);
+    GP_REQUIRE(normals && out && ntrials > 0, -3, "sample_prior: bad arguments");
+    GP_REQUIRE(which == GPCSD_PRED_CSD || which == GPCSD_PRED_LFP, -3, "sample_prior: which must be CSD(1) or LFP(2)");
+    GP_REQUIRE(c->time_nt > 0, -4, "time grid not set");
+    check_hp(c, hp, g.nx);
+    const int nx = g.nx, nt = c->time_nt, R = ntrials;
+    const long RT = (long)R * nt;
+    hipStream_t s = c->stream;
+    double *Ks = c->buf<double>("Ks", (size_t)nx * nx);
+    double *Kt = c->buf<double>("Kt", (size_t)nt * nt);
+    int *st = c->buf<int>("status", 4);
+    GP_HIP(hipMemsetAsync(st, 0, 4 * sizeof(int), s));
+    const double *t = (const double *)c->bufs["time_t"].p;
+    if (which == GPCSD_PRED_CSD) {
+        build_ks_csd(c, g, hp->ell_s, Ks, s);                                      // gpcsd1d.py:298
+        k_add_diag(c, Ks, nx, hp->jitter, s);
+    } else {
+        build_kphi(c, g, hp->R, hp->eps, hp->ell_s, nullptr, 0, hp->jitter, Ks, s);   // gpcsd2d.py:346-347
+    }
+    build_kt(c, hp, t, nt, t, nt, Kt, s);
+    potrf_device(c, Kt, nt, st, s);                                                 // Lt
+    potrf_device(c, Ks, nx, st, s);                                                 // Ls
+    double *stage = c->upload<double>("sp_stage", normals, (size_t)nx * RT);
+    double *Z = c->buf<double>("sp_Z", (size_t)nx * RT);
+    double *T1 = c->buf<double>("sp_T1", (size_t)nx * RT);
+    k_swap_last2(c, stage, Z, nx, nt, R, s);                                        // (x,t,r) -> (x,r,t)
+    GemmDesc g1;                          // T1[x'][(r,t)] = sum_x Ls[x'][x] Z[x][(r,t)]
+    g1.M = nx; g1.N = (int)RT; g1.K = nx;
+    g1.A = Ks; g1.lda = nx; g1.B = Z; g1.ldb = RT; g1.C = T1; g1.ldc = RT;
+    g1.prof_name = "gemm_sample_spatial";
+    gemm_f64(c, g1, s);
+    GemmDesc g2;                          // out[(x',r)][t'] = sum_t T1[(x',r)][t] Lt[t'][t]
+    g2.M = nx * R; g2.N = nt; g2.K = nt;
+    g2.A = T1; g2.lda = nt; g2.B = Kt; g2.ldb = nt; g2.transB = true; g2.C = Z; g2.ldc = nt;
+    g2.prof_name = "gemm_sample_temporal";
+    gemm_f64(c, g2, s);
+    k_swap_last2(c, Z, stage, nx, R, nt, s);                                        // (x,r,t) -> (x,t,r)
+    c->download(out, stage, (size_t)nx * RT * sizeof(double));
+    return finish_status(c, st);
+    GP_API_END(c)
+}
+
+extern "C" int gpcsd_loglik_grad_parts(gpcsd_ctx *c, const gpcsd_hparams *hp, double *out2, double *grad_logdet,
+                                       double *grad_quad, int ngrad) {
+    (void)hp; (void)out2; (void)grad_logdet; (void)grad_quad; (void)ngrad;
+    return fail(c, HipError{-38, "gpcsd_loglik_grad_parts: not implemented in this build"});
+}
+
+// ------------------------------------------------------------------------------------------------
+// measurement
+// ------------------------------------------------------------------------------------------------
+extern "C" int gpcsd_prof_enable(gpcsd_ctx *c, int on) {
+    GP_API_BEGIN(c)
+    c->prof_on = (on != 0);
+    return 0;
+    GP_API_END(c)
+}
+
+extern "C" int gpcsd_prof_reset(gpcsd_ctx *c) {
+    GP_API_BEGIN(c)
+    c->sync();
+    c->prof_collect();
+    c->prof.clear();
+    return 0;
+    GP_API_END(c)
+}
+
+extern "C" int gpcsd_prof_get(gpcsd_ctx *c, const char *name, double *ms, long *count, double *flops) {
+    GP_API_BEGIN(c)
+    c->prof_collect();
+    auto it = c->prof.find(name ? name : "");
+    if (it == c->prof.end()) return -2;
+    if (ms) *ms = it->second.ms;
+    if (count) *count = it->second.count;
+    if (flops) *flops = it->second.flops;
+    return 0;
+    GP_API_END(c)
+}
+
+extern "C" int gpcsd_prof_names(gpcsd_ctx *c, char *buf, int buflen) {
+    GP_API_BEGIN(c)
+    std::string sres;
+    for (auto &kv : c->prof) {
+        if (!sres.empty()) sres += ";";
+        sres += kv.first;
+    }
+    if (!buf || buflen <= 0) return (int)sres.size();
+    snprintf(buf, buflen, "%s", sres.c_str());
+    return 0;
+    GP_API_END(c)
+}
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+
+// 4 independent accumulator chains per wave, one wave per SIMD x 2, operands in registers.
+__global__ __launch_bounds__(256) void mfma_f64_peak_kernel(double *out, int iters) {
+    d4 a0 = {0, 0, 0, 0}, a1 = a0, a2 = a0, a3 = a0;
+    const double x = 1.0 + 1e-9 * threadIdx.x, y = 1.0 - 1e-9 * threadIdx.x;
+    for (int i = 0; i < iters; ++i) {
+        a0 = __builtin_amdgcn_mfma_f64_16x16x4f64(x, y, a0, 0, 0, 0);
+        a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(y, x, a1, 0, 0, 0);
+        a2 = __builtin_amdgcn_mfma_f64_16x16x4f64(x, x, a2, 0, 0, 0);
+        a3 = __builtin_amdgcn_mfma_f64_16x16x4f64(y, y, a3, 0, 0, 0);
+    }
+    d4 r = a0 + a1 + a2 + a3;
+    if (r[0] == 123.456) out[blockIdx.x] = r[0] + r[1] + r[2] + r[3];
+}
+
+extern "C" int gpcsd_mfma_f64_peak(gpcsd_ctx *c, double *tflops) {
+    GP_API_BEGIN(c)
+    GP_REQUIRE(tflops != nullptr, -3, "null output");
+    double *o = c->buf<double>("peak_out", 4096);
+    const int iters = 20000, blocks = 256 * 4;
+    hipEvent_t e0 = c->get_event(), e1 = c->get_event();
+    hipLaunchKernelGGL(mfma_f64_peak_kernel, dim3(blocks), dim3(256), 0, c->stream, o, 100);   // warm-up
+    GP_HIP(hipEventRecord(e0, c->stream));
+    hipLaunchKernelGGL(mfma_f64_peak_kernel, dim3(blocks), dim3(256), 0, c->stream, o, iters);
+    GP_HIP(hipEventRecord(e1, c->stream));
+    GP_HIP(hipEventSynchronize(e1));
+    float ms = 0.f;
+    GP_HIP(hipEventElapsedTime(&ms, e0, e1));
+    const double flops = (double)blocks * 4 /*waves*/ * iters * 4.0 * 2048.0;
+    *tflops = flops / (ms * 1e-3) / 1e12;
+    c->event_pool.push_back(e0);
+    c->event_pool.push_back(e1);
+    return 0;
+    GP_API_END(c)
+}
+
+__global__ void copy_peak_kernel(const double2 *__restrict__ in, double2 *__restrict__ out, long n) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) out[i] = in[i];
+}
+
+extern "C" int gpcsd_hbm_copy_peak(gpcsd_ctx *c, long bytes, double *gbs) {
+    GP_API_BEGIN(c)
+    GP_REQUIRE(gbs != nullptr && bytes >= (1 << 20), -3, "hbm_copy_peak: need >= 1 MiB");
+    const long n = bytes / 16;
+    double2 *a = (double2 *)c->buf<double>("peak_a", n * 2);
+    double2 *b = (double2 *)c->buf<double>("peak_b", n * 2);
+    GP_HIP(hipMemsetAsync(a, 0, n * 16, c->stream));
+    hipEvent_t e0 = c->get_event(), e1 = c->get_event();
+    hipLaunchKernelGGL(copy_peak_kernel, dim3(2048), dim3(256), 0, c->stream, (const double2 *)a, b, n);
+    GP_HIP(hipEventRecord(e0, c->stream));
+    const int reps = 10;
+    for (int i = 0; i < reps; ++i)
+        hipLaunchKernelGGL(copy_peak_kernel, dim3(2048), dim3(256), 0, c->stream, (const double2 *)a, b, n);
+    GP_HIP(hipEventRecord(e1, c->stream));
+    GP_HIP(hipEventSynchronize(e1));
+    float ms = 0.f;
+    GP_HIP(hipEventElapsedTime(&ms, e0, e1));
+    *gbs = 2.0 * n * 16.0 * reps / (ms * 1e-3) / 1e9;
+    c->event_pool.push_back(e0);
+    c->event_pool.push_back(e1);
+    return 0;
+    GP_API_END(c)
+}

@@ -1,0 +1,142 @@
+// Internal context of libgpcsd_hip.so: device, stream, named device buffers, profiling events.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/gpcsd_hip.h"
+
+namespace gpcsd {
+
+struct HipError {
+    int code;
+    std::string msg;
+};
+
+#define GP_HIP(expr)                                                                          \
+    do {                                                                                      \
+        hipError_t _e = (expr);                                                               \
+        if (_e != hipSuccess) {                                                               \
+            char _b[512];                                                                     \
+            snprintf(_b, sizeof(_b), "%s:%d: %s -> %s", __FILE__, __LINE__, #expr,            \
+                     hipGetErrorString(_e));                                                  \
+            throw gpcsd::HipError{-100 - (int)_e, _b};                                        \
+        }                                                                                     \
+    } while (0)
+
+#define GP_REQUIRE(cond, code, ...)                                                           \
+    do {                                                                                      \
+        if (!(cond)) {                                                                        \
+            char _b[512];                                                                     \
+            snprintf(_b, sizeof(_b), __VA_ARGS__);                                            \
+            throw gpcsd::HipError{(code), _b};                                                \
+        }                                                                                     \
+    } while (0)
+
+struct ProfEntry {
+    double ms = 0.0;
+    long count = 0;
+    double flops = 0.0;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+    std::vector<double> pending_flops;
+};
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t bytes = 0;
+};
+
+}  // namespace gpcsd
+
+struct gpcsd_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipStream_t stream2 = nullptr;          // second stream: the two eigenproblems are independent
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    std::string last_error;
+    std::map<std::string, gpcsd::DevBuf> bufs;
+    bool prof_on = false;
+    std::map<std::string, gpcsd::ProfEntry> prof;
+    std::vector<hipEvent_t> event_pool;
+
+    // resident problem
+    int dim = 0;                            // 1 or 2 once geometry is set
+    int nx = 0, nt = 0, ntrials = 0;        // lfp shape
+    int geo_nx = 0, ngl1 = 0, ngl2 = 0;     // geometry
+    int time_nt = 0;
+    double *d_lfp = nullptr;                // [x][r][t]
+
+    // ---- device buffers: grow-only, keyed by name, freed in destroy ----
+    template <typename T = double>
+    T *buf(const std::string &name, size_t count) {
+        size_t bytes = count * sizeof(T);
+        if (bytes == 0) bytes = sizeof(T);
+        gpcsd::DevBuf &b = bufs[name];
+        if (b.bytes < bytes) {
+            if (b.p) GP_HIP(hipFree(b.p));
+            b.p = nullptr;
+            b.bytes = 0;
+            GP_HIP(hipMalloc(&b.p, bytes));
+            b.bytes = bytes;
+        }
+        return reinterpret_cast<T *>(b.p);
+    }
+    template <typename T = double>
+    T *upload(const std::string &name, const T *host, size_t count) {
+        T *d = buf<T>(name, count);
+        if (count) GP_HIP(hipMemcpyAsync(d, host, count * sizeof(T), hipMemcpyHostToDevice, stream));
+        return d;
+    }
+    void download(void *host, const void *dev, size_t bytes) {
+        GP_HIP(hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, stream));
+    }
+    void sync() { GP_HIP(hipStreamSynchronize(stream)); }
+
+    hipEvent_t get_event() {
+        if (!event_pool.empty()) {
+            hipEvent_t e = event_pool.back();
+            event_pool.pop_back();
+            return e;
+        }
+        hipEvent_t e;
+        GP_HIP(hipEventCreate(&e));
+        return e;
+    }
+    void prof_collect();
+};
+
+namespace gpcsd {
+
+// RAII scope that brackets kernel launches on a stream with events when profiling is on.
+struct ProfScope {
+    gpcsd_ctx *c;
+    const char *name;
+    hipStream_t s;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    double flops;
+    ProfScope(gpcsd_ctx *ctx, const char *nm, double fl = 0.0, hipStream_t st = nullptr)
+        : c(ctx), name(nm), s(st ? st : ctx->stream), flops(fl) {
+        if (c->prof_on) {
+            e0 = c->get_event();
+            e1 = c->get_event();
+            (void)hipEventRecord(e0, s);
+        }
+    }
+    ~ProfScope() {
+        if (c->prof_on && e0) {
+            (void)hipEventRecord(e1, s);
+            ProfEntry &p = c->prof[name];
+            p.pending.emplace_back(e0, e1);
+            p.pending_flops.push_back(flops);
+        }
+    }
+};
+
+inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }
+
+}  // namespace gpcsd

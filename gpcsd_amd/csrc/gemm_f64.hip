@@ -1,0 +1,271 @@
+// fp64 MFMA GEMM core for gfx950 (v_mfma_f64_16x16x4_f64), row-major, optional transposes, fused epilogues.
+//
+// Every dense contraction of the GPCSD hot path runs through this kernel:
+//   K7  Ks = A Kgl A^T                      (covariances.py:90,95 / :223,231)
+//   K8  Kphig = A Kcross                    (covariances.py:66-72 / :198-202)
+//   K14 alpha = Qs^T Y Qt                   (gpcsd1d.py:124-125 / gpcsd2d.py:147-148)
+//   K15 sum alpha^2 / D                     fused epilogue EPI_QUAD (gpcsd1d.py:126-127)
+//   K16/K17 predict contractions            (gpcsd1d.py:262-285)
+//
+// Design (MI355X): 256 threads = 4 waves in a 2x2 grid, each wave owns FM x FN MFMA 16x16 fragments
+// (block tile 32FM x 32FN, 128x128 for the large flat GEMMs).  BK = 16 (four k=4 MFMA steps).  Operand tiles
+// are register-staged global -> LDS, double-buffered, one barrier per K tile.  LDS row strides are chosen so the
+// ds_read_b64 fragment reads are bank-conflict free on the 64-bank b64 path:
+//   [k][o] tiles: stride BO+16 doubles (second k row lands on the other 32 banks),
+//   [o][k] tiles: stride BK+2 = 18 doubles (18*i mod 32 distinct even slots for the 16 rows of a fragment).
+// f64 MFMA fragment maps (cdna_hip_programming.md section 3): A lane l holds A[l&15][l>>4], B lane l holds
+// B[l>>4][l&15], C/D lane l reg r holds C[(l>>4) + 4r][l&15].
+#include "kernels.hpp"
+
+namespace gpcsd {
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+
+constexpr int BK = 16;
+constexpr int PAD_KO = 16;
+constexpr int LD_OK = BK + 2;
+
+struct GemmK {
+    int M, N, K;
+    const double *A;
+    long lda;
+    const double *B;
+    long ldb;
+    double *C;
+    long ldc;
+    double *C2;
+    long sA, sB, sC;
+    double alpha;
+    const double *D;
+    int rdiv;
+    long ldd;
+    double *partials;
+    int tiles_n;
+};
+
+// One operand tile: BO "outer" rows/cols (M or N side) x BK.  KMAJOR: global storage is [K][O].
+template <int BO, bool KMAJOR>
+struct Tile {
+    static constexpr int LDS_ELEMS = KMAJOR ? BK * (BO + PAD_KO) : BO * LD_OK;
+    static constexpr int PER_THREAD = BO * BK / 256;
+
+    __device__ static __forceinline__ int lds_index(int o, int k) {
+        return KMAJOR ? k * (BO + PAD_KO) + o : o * LD_OK + k;
+    }
+    __device__ static __forceinline__ void gload(double (&r)[PER_THREAD], const double *__restrict__ base, long ld, int o0,
+                                                 int k0, int Olim, int K, int tid) {
+#pragma unroll
+        for (int i = 0; i < PER_THREAD; ++i) {
+            int e = tid + 256 * i;
+            int o, k;
+            if (KMAJOR) {
+                k = e / BO;
+                o = e % BO;
+            } else {
+                o = e / BK;
+                k = e % BK;
+            }
+            int go = o0 + o, gk = k0 + k;
+            bool ok = (go < Olim) && (gk < K);
+            long idx = KMAJOR ? (long)gk * ld + go : (long)go * ld + gk;
+            r[i] = ok ? base[idx] : 0.0;
+        }
+    }
+    __device__ static __forceinline__ void sstore(const double (&r)[PER_THREAD], double *lds, int tid) {
+#pragma unroll
+        for (int i = 0; i < PER_THREAD; ++i) {
+            int e = tid + 256 * i;
+            int o, k;
+            if (KMAJOR) {
+                k = e / BO;
+                o = e % BO;
+            } else {
+                o = e / BK;
+                k = e % BK;
+            }
+            lds[lds_index(o, k)] = r[i];
+        }
+    }
+};
+
+template <int FM, int FN, bool TA, bool TB, int EPI>
+__global__ __launch_bounds__(256) void gemm_f64_kernel(GemmK g) {
+    constexpr int BM = 32 * FM, BN = 32 * FN;
+    using TileA = Tile<BM, TA>;    // transA: global [K][M]
+    using TileB = Tile<BN, !TB>;   // !transB: global [K][N]
+    __shared__ double lds[2 * (TileA::LDS_ELEMS + TileB::LDS_ELEMS)];
+    // buffer `b` of operand A at lds + b*LDS_ELEMS; operand B follows the two A buffers
+    auto ldsA = [&](int b) -> double * { return lds + b * TileA::LDS_ELEMS; };
+    auto ldsB = [&](int b) -> double * { return lds + 2 * TileA::LDS_ELEMS + b * TileB::LDS_ELEMS; };
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wid = tid >> 6;
+    const int wr = wid >> 1, wc = wid & 1;
+    const int tile_m = blockIdx.x / g.tiles_n, tile_n = blockIdx.x % g.tiles_n;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const long bz = blockIdx.z;
+    const double *__restrict__ A = g.A + bz * g.sA;
+    const double *__restrict__ B = g.B + bz * g.sB;
+
+    d4 acc[FM][FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) acc[i][j] = d4{0.0, 0.0, 0.0, 0.0};
+
+    double ra[TileA::PER_THREAD], rb[TileB::PER_THREAD];
+    const int nk = (g.K + BK - 1) / BK;
+
+    TileA::gload(ra, A, g.lda, m0, 0, g.M, g.K, tid);
+    TileB::gload(rb, B, g.ldb, n0, 0, g.N, g.K, tid);
+    TileA::sstore(ra, ldsA(0), tid);
+    TileB::sstore(rb, ldsB(0), tid);
+    __syncthreads();
+
+    const int fr = lane & 15, fq = lane >> 4;
+    int cur = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+        const bool more = (kt + 1 < nk);
+        if (more) {
+            TileA::gload(ra, A, g.lda, m0, (kt + 1) * BK, g.M, g.K, tid);
+            TileB::gload(rb, B, g.ldb, n0, (kt + 1) * BK, g.N, g.K, tid);
+        }
+        const double *sa = ldsA(cur);
+        const double *sb = ldsB(cur);
+#pragma unroll
+        for (int kk = 0; kk < BK / 4; ++kk) {
+            const int k = kk * 4 + fq;
+            double a[FM], b[FN];
+#pragma unroll
+            for (int i = 0; i < FM; ++i) a[i] = sa[TileA::lds_index(wr * 16 * FM + i * 16 + fr, k)];
+#pragma unroll
+            for (int j = 0; j < FN; ++j) b[j] = sb[TileB::lds_index(wc * 16 * FN + j * 16 + fr, k)];
+#pragma unroll
+            for (int i = 0; i < FM; ++i)
+#pragma unroll
+                for (int j = 0; j < FN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        if (more) {
+            TileA::sstore(ra, ldsA(cur ^ 1), tid);
+            TileB::sstore(rb, ldsB(cur ^ 1), tid);
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+
+    // ---- epilogue ----
+    double qsum = 0.0;
+    double *__restrict__ C = (EPI == EPI_QUAD) ? nullptr : g.C + bz * g.sC;
+    double *__restrict__ C2 = (EPI == EPI_DUAL) ? g.C2 + bz * g.sC : nullptr;
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = m0 + wr * 16 * FM + i * 16 + fq + 4 * r;
+            if (row >= g.M) continue;
+            long drow = 0;
+            if (EPI == EPI_DIV_D || EPI == EPI_QUAD) drow = (long)(row / g.rdiv) * g.ldd;
+#pragma unroll
+            for (int j = 0; j < FN; ++j) {
+                const int col = n0 + wc * 16 * FN + j * 16 + fr;
+                if (col >= g.N) continue;
+                const double v = acc[i][j][r];
+                if (EPI == EPI_STORE) {
+                    C[(long)row * g.ldc + col] = g.alpha * v;
+                } else if (EPI == EPI_ACCUM) {
+                    C[(long)row * g.ldc + col] += g.alpha * v;
+                } else if (EPI == EPI_DUAL) {
+                    const double o = g.alpha * v;
+                    C[(long)row * g.ldc + col] = o;
+                    C2[(long)row * g.ldc + col] += o;
+                } else if (EPI == EPI_DIV_D) {
+                    C[(long)row * g.ldc + col] = v / g.D[drow + col];
+                } else {
+                    qsum += v * v / g.D[drow + col];
+                }
+            }
+        }
+    }
+    if (EPI == EPI_QUAD) {
+        // wave reduction (64 lanes) then the four waves through LDS; fixed order -> deterministic
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) qsum += __shfl_down(qsum, off, 64);
+        __shared__ double wsum[4];
+        if (lane == 0) wsum[wid] = qsum;
+        __syncthreads();
+        if (tid == 0) g.partials[bz * gridDim.x + blockIdx.x] = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
+    }
+}
+
+// Deterministic final reduction of per-block partials (single workgroup, fixed tree).
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const double *__restrict__ p, long n, double *out) {
+    __shared__ double sh[256];
+    double s = 0.0;
+    for (long i = threadIdx.x; i < n; i += 256) s += p[i];
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) sh[threadIdx.x] += sh[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = sh[0];
+}
+
+template <int FM, int FN, bool TA, bool TB>
+static void launch_epi(const GemmK &k, int epi, dim3 grid, hipStream_t s) {
+    switch (epi) {
+        case EPI_STORE: hipLaunchKernelGGL((gemm_f64_kernel<FM, FN, TA, TB, EPI_STORE>), grid, dim3(256), 0, s, k); break;
+        case EPI_DIV_D: hipLaunchKernelGGL((gemm_f64_kernel<FM, FN, TA, TB, EPI_DIV_D>), grid, dim3(256), 0, s, k); break;
+        case EPI_QUAD: hipLaunchKernelGGL((gemm_f64_kernel<FM, FN, TA, TB, EPI_QUAD>), grid, dim3(256), 0, s, k); break;
+        case EPI_ACCUM: hipLaunchKernelGGL((gemm_f64_kernel<FM, FN, TA, TB, EPI_ACCUM>), grid, dim3(256), 0, s, k); break;
+        case EPI_DUAL: hipLaunchKernelGGL((gemm_f64_kernel<FM, FN, TA, TB, EPI_DUAL>), grid, dim3(256), 0, s, k); break;
+        default: throw HipError{-3, "gemm_f64: bad epilogue"};
+    }
+}
+
+template <int FM, int FN>
+static void launch_trans(const GemmK &k, bool ta, bool tb, int epi, dim3 grid, hipStream_t s) {
+    if (!ta && !tb) launch_epi<FM, FN, false, false>(k, epi, grid, s);
+    else if (ta && !tb) launch_epi<FM, FN, true, false>(k, epi, grid, s);
+    else if (!ta && tb) launch_epi<FM, FN, false, true>(k, epi, grid, s);
+    else launch_epi<FM, FN, true, true>(k, epi, grid, s);
+}
+
+void gemm_f64(gpcsd_ctx *c, const GemmDesc &g, hipStream_t s) {
+    if (!s) s = c->stream;
+    GP_REQUIRE(g.M > 0 && g.N > 0 && g.K > 0, -3, "gemm_f64: empty problem %dx%dx%d", g.M, g.N, g.K);
+    GemmK k;
+    k.M = g.M; k.N = g.N; k.K = g.K;
+    k.A = g.A; k.lda = g.lda; k.B = g.B; k.ldb = g.ldb; k.C = g.C; k.ldc = g.ldc; k.C2 = g.C2;
+    k.sA = g.sA; k.sB = g.sB; k.sC = g.sC;
+    k.alpha = g.alpha; k.D = g.D; k.rdiv = g.rdiv > 0 ? g.rdiv : 1; k.ldd = g.ldd;
+    k.partials = nullptr;
+
+    auto tiles = [&](int b) { return (long)ceil_div(g.M, b) * ceil_div(g.N, b) * g.batch; };
+    int bt;                                   // block tile edge
+    if (tiles(128) >= 192) bt = 128;          // enough 128^2 tiles to cover the 256 CUs
+    else if (tiles(64) >= 96) bt = 64;
+    else bt = 32;
+    const int tm = ceil_div(g.M, bt), tn = ceil_div(g.N, bt);
+    k.tiles_n = tn;
+    dim3 grid(tm * tn, 1, g.batch);
+    const long nblocks = (long)tm * tn * g.batch;
+    if (g.epi == EPI_QUAD) k.partials = c->buf<double>("gemm_partials", nblocks);
+
+    const double flops = 2.0 * g.M * (double)g.N * g.K * g.batch;
+    {
+        ProfScope ps(c, g.prof_name, flops, s);
+        if (bt == 128) launch_trans<4, 4>(k, g.transA, g.transB, g.epi, grid, s);
+        else if (bt == 64) launch_trans<2, 2>(k, g.transA, g.transB, g.epi, grid, s);
+        else launch_trans<1, 1>(k, g.transA, g.transB, g.epi, grid, s);
+        GP_HIP(hipGetLastError());
+    }
+    if (g.epi == EPI_QUAD) {
+        hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(256), 0, s, (const double *)k.partials, nblocks, g.quad_out);
+        GP_HIP(hipGetLastError());
+    }
+}
+
+}  // namespace gpcsd

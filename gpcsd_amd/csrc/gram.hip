@@ -1,0 +1,343 @@
+// Elementwise / pairwise Gram builders of the GPCSD hot path.
+//
+// These are tiny (<= 1200^2 outputs) and transcendental-bound, never HBM-bound; the rules that matter are
+// coalesced stores, coordinates staged through LDS once per tile, and operation order identical to the
+// reference expressions so results agree to the last few ulps (no fast-math, IEEE div/sqrt).
+#include "kernels.hpp"
+
+namespace gpcsd {
+
+// ------------------------------------------------------------------------------------------------
+// forward-model weights
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double dev_b_fwd_1d(double r, double R) {
+    // sqrt((r/R)^2 + 1) - sqrt((r/R)^2)            forward_models.py:16
+    const double q = (r / R) * (r / R);
+    return sqrt(q + 1.0) - sqrt(q);
+}
+
+__device__ __forceinline__ double dev_b_fwd_2d_w(double w, double R, double eps) {
+    // log(R+eps+sqrt((R+eps)^2+w^2)) - log(eps+sqrt(eps^2+w^2))      forward_models.py:53
+    const double re = R + eps;
+    return log(re + sqrt(re * re + w * w)) - log(eps + sqrt(eps * eps + w * w));
+}
+
+__global__ void b_fwd_1d_kernel(const double *__restrict__ r, long n, double R, double *__restrict__ out) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+        out[i] = dev_b_fwd_1d(r[i], R);
+}
+
+__global__ void b_fwd_2d_kernel(const double *__restrict__ d1, const double *__restrict__ d2, const double *__restrict__ w,
+                                long n, double R, double eps, double *__restrict__ out) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const double ww = w ? w[i] : sqrt(d1[i] * d1[i] + d2[i] * d2[i]);   // forward_models.py:52
+        out[i] = dev_b_fwd_2d_w(ww, R, eps);
+    }
+}
+
+static inline int ew_grid(long n) {
+    long b = (n + 255) / 256;
+    return (int)(b < 1 ? 1 : (b > 2048 ? 2048 : b));
+}
+
+void k_b_fwd_1d(gpcsd_ctx *c, const double *r, long n, double R, double *out, hipStream_t s) {
+    hipLaunchKernelGGL(b_fwd_1d_kernel, dim3(ew_grid(n)), dim3(256), 0, s, r, n, R, out);
+    GP_HIP(hipGetLastError());
+}
+
+void k_b_fwd_2d(gpcsd_ctx *c, const double *d1, const double *d2, const double *w, long n, double R, double eps,
+                double *out, hipStream_t s) {
+    hipLaunchKernelGGL(b_fwd_2d_kernel, dim3(ew_grid(n)), dim3(256), 0, s, d1, d2, w, n, R, eps, out);
+    GP_HIP(hipGetLastError());
+}
+
+// ------------------------------------------------------------------------------------------------
+// pairwise kernels: 64 x 16 output tile per 256-thread block, coordinates staged in LDS
+// ------------------------------------------------------------------------------------------------
+constexpr int PT_COLS = 64, PT_ROWS = 16;
+
+struct TemporalParams {
+    int ncomp;
+    int kind[GPCSD_MAX_TEMPORAL];
+    double ell[GPCSD_MAX_TEMPORAL];
+    double sigma2[GPCSD_MAX_TEMPORAL];
+};
+
+__global__ __launch_bounds__(256) void temporal_gram_kernel(TemporalParams p, const double *__restrict__ t, int n,
+                                                            const double *__restrict__ tp, int m, double *__restrict__ out) {
+    __shared__ double st[PT_ROWS], stp[PT_COLS];
+    const int c0 = blockIdx.x * PT_COLS, r0 = blockIdx.y * PT_ROWS;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    if (threadIdx.x < PT_COLS) stp[threadIdx.x] = (c0 + threadIdx.x < m) ? tp[c0 + threadIdx.x] : 0.0;
+    else if (threadIdx.x < PT_COLS + PT_ROWS) {
+        int i = threadIdx.x - PT_COLS;
+        st[i] = (r0 + i < n) ? t[r0 + i] : 0.0;
+    }
+    __syncthreads();
+    const int col = c0 + tx;
+    if (col >= m) return;
+#pragma unroll
+    for (int k = 0; k < PT_ROWS / 4; ++k) {
+        const int rr = ty + 4 * k;
+        const int row = r0 + rr;
+        if (row >= n) continue;
+        const double d = st[rr] - stp[tx];
+        double acc = 0.0;                                              // Kt = zeros; Kt = Kt + K_c (gpcsd1d.py:118-120)
+        for (int cc = 0; cc < p.ncomp; ++cc) {
+            double v;
+            if (p.kind[cc] == GPCSD_KIND_SE)
+                v = p.sigma2[cc] * exp(-0.5 * (d * d) / (p.ell[cc] * p.ell[cc]));   // covariances.py:270
+            else
+                v = p.sigma2[cc] * exp(-sqrt(d * d) / p.ell[cc]);                   // covariances.py:304
+            acc = acc + v;
+        }
+        out[(long)row * m + col] = acc;
+    }
+}
+
+void k_temporal_gram(gpcsd_ctx *c, int ncomp, const int *kind, const double *ell, const double *sigma2, const double *t, int n,
+                     const double *tp, int m, double *out, hipStream_t s) {
+    GP_REQUIRE(ncomp >= 1 && ncomp <= GPCSD_MAX_TEMPORAL, -3, "temporal gram: %d components (max %d)", ncomp,
+               GPCSD_MAX_TEMPORAL);
+    TemporalParams p;
+    p.ncomp = ncomp;
+    for (int i = 0; i < ncomp; ++i) {
+        p.kind[i] = kind[i];
+        p.ell[i] = ell[i];
+        p.sigma2[i] = sigma2[i];
+    }
+    dim3 grid(ceil_div(m, PT_COLS), ceil_div(n, PT_ROWS));
+    ProfScope ps(c, "gram_temporal", 0.0, s);
+    hipLaunchKernelGGL(temporal_gram_kernel, grid, dim3(256), 0, s, p, t, n, tp, m, out);
+    GP_HIP(hipGetLastError());
+}
+
+// A(nx, ngl) = gl_w[g] * b_fwd_1d(gl_x[g] - x[i], R)                      covariances.py:86-88
+__global__ __launch_bounds__(256) void fwd_weights_1d_kernel(const double *__restrict__ x, int nx,
+                                                             const double *__restrict__ gl_x,
+                                                             const double *__restrict__ gl_w, int ngl, double R,
+                                                             double *__restrict__ A) {
+    const long n = (long)nx * ngl;
+    for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) {
+        const int i = (int)(e / ngl), g = (int)(e % ngl);
+        A[e] = gl_w[g] * dev_b_fwd_1d(gl_x[g] - x[i], R);
+    }
+}
+
+void k_fwd_weights_1d(gpcsd_ctx *c, const double *x, int nx, const double *gl_x, const double *gl_w, int ngl, double R,
+                      double *A, hipStream_t s) {
+    hipLaunchKernelGGL(fwd_weights_1d_kernel, dim3(ew_grid((long)nx * ngl)), dim3(256), 0, s, x, nx, gl_x, gl_w, ngl, R, A);
+    GP_HIP(hipGetLastError());
+}
+
+// A(nx, G) with g = g1*ngl2 + g2 (expand_grid order, utility_functions.py:22):
+//   gl_w_prod[g] * b_fwd_2d(w = |gl_g - x_i|)                             covariances.py:125-131, :220-221
+__global__ __launch_bounds__(256) void fwd_weights_2d_kernel(const double *__restrict__ xy, int nx,
+                                                             const double *__restrict__ gx1,
+                                                             const double *__restrict__ gw1, int ngl1,
+                                                             const double *__restrict__ gx2,
+                                                             const double *__restrict__ gw2, int ngl2, double R, double eps,
+                                                             double *__restrict__ A) {
+    const int G = ngl1 * ngl2;
+    const int i = blockIdx.y;
+    const double x1 = xy[2 * i], x2 = xy[2 * i + 1];
+    for (int g = blockIdx.x * blockDim.x + threadIdx.x; g < G; g += gridDim.x * blockDim.x) {
+        const int g1 = g / ngl2, g2 = g % ngl2;
+        const double d1 = gx1[g1] - x1, d2 = gx2[g2] - x2;
+        const double w = sqrt(d1 * d1 + d2 * d2);
+        A[(long)i * G + g] = (gw1[g1] * gw2[g2]) * dev_b_fwd_2d_w(w, R, eps);
+    }
+}
+
+void k_fwd_weights_2d(gpcsd_ctx *c, const double *xy, int nx, const double *gx1, const double *gw1, int ngl1, const double *gx2,
+                      const double *gw2, int ngl2, double R, double eps, double *A, hipStream_t s) {
+    const int G = ngl1 * ngl2;
+    dim3 grid(ceil_div(G, 256), nx);
+    ProfScope ps(c, "fwd_weights_2d", 0.0, s);
+    hipLaunchKernelGGL(fwd_weights_2d_kernel, grid, dim3(256), 0, s, xy, nx, gx1, gw1, ngl1, gx2, gw2, ngl2, R, eps, A);
+    GP_HIP(hipGetLastError());
+}
+
+// out(n,m) = exp(-0.5 ((a_i - b_j)/ell)^2)      covariances.py:55, :67, :89
+__global__ __launch_bounds__(256) void se_1d_kernel(const double *__restrict__ a, int n, const double *__restrict__ b, int m,
+                                                    double ell, double *__restrict__ out) {
+    __shared__ double sa[PT_ROWS], sb[PT_COLS];
+    const int c0 = blockIdx.x * PT_COLS, r0 = blockIdx.y * PT_ROWS;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    if (threadIdx.x < PT_COLS) sb[threadIdx.x] = (c0 + threadIdx.x < m) ? b[c0 + threadIdx.x] : 0.0;
+    else if (threadIdx.x < PT_COLS + PT_ROWS) {
+        int i = threadIdx.x - PT_COLS;
+        sa[i] = (r0 + i < n) ? a[r0 + i] : 0.0;
+    }
+    __syncthreads();
+    const int col = c0 + tx;
+    if (col >= m) return;
+#pragma unroll
+    for (int k = 0; k < PT_ROWS / 4; ++k) {
+        const int rr = ty + 4 * k, row = r0 + rr;
+        if (row >= n) continue;
+        const double q = (sa[rr] - sb[tx]) / ell;
+        out[(long)row * m + col] = exp(-0.5 * (q * q));
+    }
+}
+
+void k_se_1d(gpcsd_ctx *c, const double *a, int n, const double *b, int m, double ell, double *out, hipStream_t s) {
+    dim3 grid(ceil_div(m, PT_COLS), ceil_div(n, PT_ROWS));
+    hipLaunchKernelGGL(se_1d_kernel, grid, dim3(256), 0, s, a, n, b, m, ell, out);
+    GP_HIP(hipGetLastError());
+}
+
+// Anisotropic SE between 2D point sets.  A set is either a tensor grid (n2 > 0: point i = (p1[i / n2], p2[i % n2]))
+// or an explicit (n,2) list (n2 == 0: p1 = base, point i = (p1[2i], p1[2i+1])).
+// Both sets grids -> exp(-0.5 d1^2 / ell1^2) * exp(-0.5 d2^2 / ell2^2)          covariances.py:216
+// otherwise       -> exp(-0.5 (d1/ell1)^2)   * exp(-0.5 (d2/ell2)^2)            covariances.py:186, :199
+__global__ __launch_bounds__(256) void se_2d_kernel(const double *__restrict__ a1, const double *__restrict__ a2, int na,
+                                                    int na2, const double *__restrict__ b1, const double *__restrict__ b2,
+                                                    int nb, int nb2, double ell1, double ell2, double *__restrict__ out) {
+    __shared__ double sa[2][PT_ROWS], sb[2][PT_COLS];
+    const int c0 = blockIdx.x * PT_COLS, r0 = blockIdx.y * PT_ROWS;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    if (threadIdx.x < PT_COLS) {
+        const int j = c0 + threadIdx.x;
+        double v1 = 0.0, v2 = 0.0;
+        if (j < nb) {
+            if (nb2 > 0) { v1 = b1[j / nb2]; v2 = b2[j % nb2]; }
+            else { v1 = b1[2 * j]; v2 = b1[2 * j + 1]; }
+        }
+        sb[0][threadIdx.x] = v1;
+        sb[1][threadIdx.x] = v2;
+    } else if (threadIdx.x < PT_COLS + PT_ROWS) {
+        const int ii = threadIdx.x - PT_COLS, i = r0 + ii;
+        double v1 = 0.0, v2 = 0.0;
+        if (i < na) {
+            if (na2 > 0) { v1 = a1[i / na2]; v2 = a2[i % na2]; }
+            else { v1 = a1[2 * i]; v2 = a1[2 * i + 1]; }
+        }
+        sa[0][ii] = v1;
+        sa[1][ii] = v2;
+    }
+    __syncthreads();
+    const int col = c0 + tx;
+    if (col >= nb) return;
+    const bool grid_form = (na2 > 0) && (nb2 > 0);
+#pragma unroll
+    for (int k = 0; k < PT_ROWS / 4; ++k) {
+        const int rr = ty + 4 * k, row = r0 + rr;
+        if (row >= na) continue;
+        const double d1 = sa[0][rr] - sb[0][tx], d2 = sa[1][rr] - sb[1][tx];
+        double v;
+        if (grid_form) v = exp(-0.5 * (d1 * d1) / (ell1 * ell1)) * exp(-0.5 * (d2 * d2) / (ell2 * ell2));
+        else {
+            const double q1 = d1 / ell1, q2 = d2 / ell2;
+            v = exp(-0.5 * (q1 * q1)) * exp(-0.5 * (q2 * q2));
+        }
+        out[(long)row * nb + col] = v;
+    }
+}
+
+void k_se_2d(gpcsd_ctx *c, const double *a1, const double *a2, int na, int na2, const double *b1, const double *b2, int nb,
+             int nb2, double ell1, double ell2, double *out, hipStream_t s) {
+    dim3 grid(ceil_div(nb, PT_COLS), ceil_div(na, PT_ROWS));
+    ProfScope ps(c, "gram_se_2d", 0.0, s);
+    hipLaunchKernelGGL(se_2d_kernel, grid, dim3(256), 0, s, a1, a2, na, na2, b1, b2, nb, nb2, ell1, ell2, out);
+    GP_HIP(hipGetLastError());
+}
+
+__global__ void add_diag_kernel(double *A, int n, double v) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) A[(long)i * n + i] += v;
+}
+void k_add_diag(gpcsd_ctx *c, double *A, int n, double v, hipStream_t s) {
+    hipLaunchKernelGGL(add_diag_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, s, A, n, v);
+    GP_HIP(hipGetLastError());
+}
+
+__global__ void fill_kernel(double *p, long n, double v) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) p[i] = v;
+}
+void k_fill(gpcsd_ctx *c, double *p, long n, double v, hipStream_t s) {
+    hipLaunchKernelGGL(fill_kernel, dim3(ew_grid(n)), dim3(256), 0, s, p, n, v);
+    GP_HIP(hipGetLastError());
+}
+
+// ------------------------------------------------------------------------------------------------
+// D = repeat(es, nt) * tile(et, nx) + sig2n_vec  and  sum(log D)          utility_functions.py:54-63, gpcsd1d.py:122
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void build_D_kernel(const double *__restrict__ es, int nx, const double *__restrict__ et,
+                                                      int nt, const double *__restrict__ sig, int nsig,
+                                                      double *__restrict__ D, double *__restrict__ partials) {
+    const long n = (long)nx * nt;
+    double s = 0.0;
+    for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) {
+        const int x = (int)(e / nt), i = (int)(e % nt);
+        const double d = es[x] * et[i] + (nsig == 1 ? sig[0] : sig[x]);
+        D[e] = d;
+        s += log(d);
+    }
+    __shared__ double sh[256];
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) sh[threadIdx.x] += sh[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) partials[blockIdx.x] = sh[0];
+}
+
+__global__ __launch_bounds__(256) void sum_small_kernel(const double *__restrict__ p, int n, double *out) {
+    __shared__ double sh[256];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < n; i += 256) s += p[i];
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) sh[threadIdx.x] += sh[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = sh[0];
+}
+
+void k_build_D(gpcsd_ctx *c, const double *es, int nx, const double *et, int nt, const double *sig, int nsig, double *D,
+               double *sumlog_out, hipStream_t s) {
+    const long n = (long)nx * nt;
+    int blocks = (int)((n + 1023) / 1024);
+    if (blocks > 256) blocks = 256;
+    if (blocks < 1) blocks = 1;
+    double *part = c->buf<double>("buildD_partials", 256);
+    ProfScope ps(c, "build_D_logdet", 0.0, s);
+    hipLaunchKernelGGL(build_D_kernel, dim3(blocks), dim3(256), 0, s, es, nx, et, nt, sig, nsig, D, part);
+    hipLaunchKernelGGL(sum_small_kernel, dim3(1), dim3(256), 0, s, (const double *)part, blocks, sumlog_out);
+    GP_HIP(hipGetLastError());
+}
+
+// ------------------------------------------------------------------------------------------------
+// [n0][n1][n2] -> [n0][n2][n1]   (lfp (x,t,r) -> (x,r,t) on upload; predictions (z,r,t) -> (z,t,r) on download)
+// LDS-tiled 32x32 transpose, both sides coalesced.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void swap_last2_kernel(const double *__restrict__ in, double *__restrict__ out, int n1,
+                                                         int n2) {
+    __shared__ double tile[32][33];
+    const long base = (long)blockIdx.z * n1 * n2;
+    const int j0 = blockIdx.x * 32, i0 = blockIdx.y * 32;       // i over n1, j over n2
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;     // 32 x 8
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int i = i0 + ty + 8 * k, j = j0 + tx;
+        if (i < n1 && j < n2) tile[ty + 8 * k][tx] = in[base + (long)i * n2 + j];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int j = j0 + ty + 8 * k, i = i0 + tx;
+        if (i < n1 && j < n2) out[base + (long)j * n1 + i] = tile[tx][ty + 8 * k];
+    }
+}
+
+void k_swap_last2(gpcsd_ctx *c, const double *in, double *out, int n0, int n1, int n2, hipStream_t s) {
+    dim3 grid(ceil_div(n2, 32), ceil_div(n1, 32), n0);
+    ProfScope ps(c, "relayout", 0.0, s);
+    hipLaunchKernelGGL(swap_last2_kernel, grid, dim3(256), 0, s, in, out, n1, n2);
+    GP_HIP(hipGetLastError());
+}
+
+}  // namespace gpcsd

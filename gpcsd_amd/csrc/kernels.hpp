@@ -1,0 +1,81 @@
+// Device-pointer launchers shared between translation units of libgpcsd_hip.so.
+#pragma once
+#include "ctx.hpp"
+
+namespace gpcsd {
+
+// ---------------------------------------------------------------- fp64 MFMA GEMM core
+enum Epi : int {
+    EPI_STORE = 0,   // C = alpha * acc
+    EPI_DIV_D = 1,   // C = acc / D[(row / rdiv) * ldd + col]
+    EPI_QUAD = 2,    // no store; partial sums of acc^2 / D[...] (deterministic two-stage reduce)
+    EPI_ACCUM = 3,   // C += alpha * acc
+    EPI_DUAL = 4     // C = alpha*acc and C2 += alpha*acc   (predict: per-component + running sum)
+};
+
+struct GemmDesc {
+    int M = 0, N = 0, K = 0;
+    const double *A = nullptr;
+    long lda = 0;
+    bool transA = false;   // false: A is (M,K) row-major; true: A stored (K,M) row-major
+    const double *B = nullptr;
+    long ldb = 0;
+    bool transB = false;   // false: B is (K,N) row-major; true: B stored (N,K) row-major
+    double *C = nullptr;
+    long ldc = 0;
+    double *C2 = nullptr;  // EPI_DUAL
+    int batch = 1;
+    long sA = 0, sB = 0, sC = 0;
+    double alpha = 1.0;
+    int epi = EPI_STORE;
+    const double *D = nullptr;
+    int rdiv = 1;
+    long ldd = 0;
+    double *quad_out = nullptr;   // EPI_QUAD: one double, written by the final reduce
+    const char *prof_name = "gemm_f64";
+};
+
+void gemm_f64(gpcsd_ctx *c, const GemmDesc &g, hipStream_t s = nullptr);
+
+// ---------------------------------------------------------------- elementwise / Gram builders (gram.hip)
+void k_b_fwd_1d(gpcsd_ctx *c, const double *r, long n, double R, double *out, hipStream_t s);
+void k_b_fwd_2d(gpcsd_ctx *c, const double *d1, const double *d2, const double *w, long n, double R, double eps,
+                double *out, hipStream_t s);
+// out(n,m) = sum_c sigma2_c k_c(t_i - tp_j); ncomp components fused (K1-K3 of SURVEY 2a)
+void k_temporal_gram(gpcsd_ctx *c, int ncomp, const int *kind, const double *ell, const double *sigma2,
+                     const double *t, int n, const double *tp, int m, double *out, hipStream_t s);
+// A(nx, G) = gl_w[g] * b_fwd_1d(gl_x[g] - x[i], R)
+void k_fwd_weights_1d(gpcsd_ctx *c, const double *x, int nx, const double *gl_x, const double *gl_w, int ngl, double R,
+                      double *A, hipStream_t s);
+// A(nx, G=ngl1*ngl2) = w1[g1] w2[g2] * b_fwd_2d(|gl - x|)
+void k_fwd_weights_2d(gpcsd_ctx *c, const double *xy, int nx, const double *gx1, const double *gw1, int ngl1,
+                      const double *gx2, const double *gw2, int ngl2, double R, double eps, double *A, hipStream_t s);
+// SE kernel between two 1D point sets: out(n,m) = exp(-0.5 ((a_i - b_j)/ell)^2)
+void k_se_1d(gpcsd_ctx *c, const double *a, int n, const double *b, int m, double ell, double *out, hipStream_t s);
+// anisotropic SE between two 2D point sets given as separate coordinate generators:
+// point i of set A = (a1[i / na2], a2[i % na2]) if na2 > 0 (tensor grid) else (a[2i], a[2i+1]) (explicit list)
+void k_se_2d(gpcsd_ctx *c, const double *a1, const double *a2, int na, int na2, const double *b1, const double *b2,
+             int nb, int nb2, double ell1, double ell2, double *out, hipStream_t s);
+void k_add_diag(gpcsd_ctx *c, double *A, int n, double v, hipStream_t s);
+// D[x*nt + i] = es[x]*et[i] + sig[x or 0]; also sumlog -> *sumlog_out (deterministic)
+void k_build_D(gpcsd_ctx *c, const double *es, int nx, const double *et, int nt, const double *sig, int nsig, double *D,
+               double *sumlog_out, hipStream_t s);
+// lfp host layout [x][t][r] -> device layout [x][r][t] (and back for predictions [z][r][t] -> [z][t][r])
+void k_swap_last2(gpcsd_ctx *c, const double *in, double *out, int n0, int n1, int n2, hipStream_t s);
+void k_fill(gpcsd_ctx *c, double *p, long n, double v, hipStream_t s);
+
+// ---------------------------------------------------------------- eigensolver (eigh.hip)
+// Symmetric eigendecomposition of A (n,n) on device.  evals ascending; evecs (n,n) row-major with
+// eigenvectors in COLUMNS (numpy.linalg.eigh convention).  A is destroyed.  status: device int (0 ok).
+void eigh_device(gpcsd_ctx *c, double *A, int n, double *evals, double *evecs, int *d_status, hipStream_t s,
+                 const char *tag);
+
+// ---------------------------------------------------------------- Cholesky (chol.hip)
+// In-place lower Cholesky of A (n,n) row-major; strictly-upper part zeroed.  d_status: 0 ok, k+1 = pivot k <= 0.
+void potrf_device(gpcsd_ctx *c, double *A, int n, int *d_status, hipStream_t s);
+// X = L^{-1} B in place (B (n,nrhs) row-major)
+void trsm_lower_device(gpcsd_ctx *c, const double *L, int n, double *B, int nrhs, hipStream_t s);
+void logdet_chol_device(gpcsd_ctx *c, const double *L, int n, double *out, hipStream_t s);
+void sumsq_device(gpcsd_ctx *c, const double *x, long n, double *out, hipStream_t s);
+
+}  // namespace gpcsd

@@ -1,0 +1,362 @@
+"""Shared machinery of GPCSD1D / GPCSD2D: hyper-parameter (un)packing, device residency, loglik / predict /
+sample_prior on the GPU, and the multi-restart MAP fit.
+
+Behavioural contract (reference: src/gpcsd/gpcsd1d.py, src/gpcsd/gpcsd2d.py):
+  * hyper-parameters live in mutable dicts (`self.R`, `self.sig2n`, `spatial_cov.params`, `temporal_cov_list[i].params`)
+    and are re-read at every call;
+  * loglik adds JITTER*I to Ks, predict does not; neither adds the -N/2 log(2 pi) constant;
+  * fit optimises -(loglik + log-prior) over log-parameters with L-BFGS-B from prior-sampled restarts and keeps the
+    best finite optimum; the reference's autograd gradient is replaced by an analytic gradient computed on the GPU
+    (scalar sig2n) or central differences of GPU evaluations (per-electrode sig2n list);
+  * predict(z, t, type) fills csd_pred / csd_pred_list / lfp_pred / lfp_pred_list / t_pred / x_pred.
+"""
+import numpy as np
+import scipy.optimize
+from tqdm import tqdm
+
+from . import _hip
+from .covariances import GPCSDTemporalCov
+
+
+def _same_array(a, b):
+    return a is b or (np.shape(a) == np.shape(b) and np.array_equal(a, b))
+
+
+class GPCSDModel:
+    """Base of GPCSD1D / GPCSD2D.  Subclasses set `dim`, `JITTER`, `_spatial_names` and build the covariances."""
+
+    dim = None
+    JITTER = None
+    _spatial_names = ()          # names of the spatial length-scale params in spatial_cov.params
+
+    # ------------------------------------------------------------------ device residency
+    def _context(self):
+        ctx = getattr(self, "_ctx", None)
+        if ctx is None:
+            ctx = _hip.Context(getattr(self, "_device", None))
+            self._ctx = ctx
+            self._resident = {}
+        return ctx
+
+    def set_device(self, device):
+        """Pin this model to a GPU ordinal (default: $LOCAL_RANK or 0).  Must be called before the first evaluation."""
+        if getattr(self, "_ctx", None) is not None:
+            raise RuntimeError("device already initialised for this model")
+        self._device = int(device)
+
+    def shard_trials(self, sharding):
+        """Evaluate only this rank's contiguous block of trials and combine partial sums across ranks
+        (gpcsd_amd.dist.TrialSharding).  `self.lfp` keeps the full array; predictions are returned for the local block
+        unless `sharding.gather_predictions` is set."""
+        self._sharding = sharding
+        self._resident = {} if getattr(self, "_ctx", None) is not None else getattr(self, "_resident", {})
+
+    def invalidate(self):
+        """Force re-upload of lfp / coordinates at the next call (use after editing arrays in place)."""
+        self._resident = {}
+
+    def _local_lfp(self):
+        lfp = np.atleast_3d(self.lfp)
+        sh = getattr(self, "_sharding", None)
+        if sh is None:
+            return lfp
+        return lfp[:, :, sh.local_slice(lfp.shape[2])]
+
+    def _sync_device(self, need_lfp=True):
+        ctx = self._context()
+        res = self._resident
+        sc = self.spatial_cov
+        # time grid: the reference evaluates each temporal covariance on its own `t`; they must agree
+        t = self.temporal_cov_list[0].t
+        for tc in self.temporal_cov_list[1:]:
+            if not _same_array(tc.t, t):
+                raise ValueError("temporal covariance components hold different time grids")
+        if "t" not in res or not _same_array(res["t"], t):
+            ctx.set_time(t)
+            res["t"] = np.array(t, dtype=np.float64, copy=True)
+        if self.dim == 1:
+            key = (np.asarray(sc.x, dtype=np.float64).reshape(-1), np.asarray(sc.gl_x), np.asarray(sc.gl_w))
+        else:
+            key = (np.asarray(sc.x, dtype=np.float64), np.asarray(sc.gl_x1), np.asarray(sc.gl_w1), np.asarray(sc.gl_x2),
+                   np.asarray(sc.gl_w2))
+        old = res.get("geo")
+        if old is None or len(old) != len(key) or not all(_same_array(a, b) for a, b in zip(old, key)):
+            if self.dim == 1:
+                ctx.set_geometry_1d(*key)
+            else:
+                ctx.set_geometry_2d(*key)
+            res["geo"] = tuple(np.array(k, copy=True) for k in key)
+        if need_lfp:
+            lfp = self.lfp
+            if np.ndim(lfp) != 3:
+                raise ValueError("lfp must have shape (n_spatial, n_time, n_trials)")
+            sh = getattr(self, "_sharding", None)
+            ident = (id(lfp), lfp.__array_interface__["data"][0], lfp.shape, lfp.strides,
+                     None if sh is None else (sh.rank, sh.world_size))
+            if res.get("lfp") != ident:
+                ctx.set_lfp(self._local_lfp())
+                res["lfp"] = ident
+        return ctx
+
+    # ------------------------------------------------------------------ hyper-parameters
+    def _temporal_triplets(self):
+        out = []
+        for tc in self.temporal_cov_list:
+            kind = getattr(tc, "kind", None)
+            if not isinstance(tc, GPCSDTemporalCov) or kind not in (_hip.KIND_SE, _hip.KIND_MATERN):
+                raise TypeError("temporal covariance %r is not GPCSDTemporalCovSE / GPCSDTemporalCovMatern: the GPU path "
+                                "implements those two kernels (no CPU fallback)" % type(tc).__name__)
+            out.append((kind, tc.params["ell"]["value"], tc.params["sigma2"]["value"]))
+        return out
+
+    def _hparams(self, jitter):
+        ell_s = [self.spatial_cov.params[n]["value"] for n in self._spatial_names]
+        eps = getattr(self, "eps", 0.0)
+        ctx = self._context()
+        hp, keep = ctx.make_hparams(self.R["value"], eps, ell_s, self._temporal_triplets(), self.sig2n["value"], jitter)
+        return hp, keep
+
+    def _sig2n_is_scalar(self):
+        return np.isscalar(self.sig2n["value"]) or np.ndim(self.sig2n["value"]) == 0
+
+    def extract_model_params(self):
+        p = {"R": self.R["value"]}
+        if self.dim == 2:
+            p["eps"] = self.eps
+        p["sig2n"] = self.sig2n["value"]
+        if self.dim == 1:
+            p["spatial_ell"] = self.spatial_cov.params["ell"]["value"]
+        else:
+            p["spatial_ell1"] = self.spatial_cov.params["ell1"]["value"]
+            p["spatial_ell2"] = self.spatial_cov.params["ell2"]["value"]
+        p["temporal_ell_list"] = [tc.params["ell"]["value"] for tc in self.temporal_cov_list]
+        p["temporal_sigma2_list"] = [tc.params["sigma2"]["value"] for tc in self.temporal_cov_list]
+        return p
+
+    def restore_model_params(self, params):
+        self.R["value"] = params["R"]
+        if self.dim == 2:
+            self.eps = params["eps"]
+        self.sig2n["value"] = params["sig2n"]
+        if self.dim == 1:
+            self.spatial_cov.params["ell"]["value"] = params["spatial_ell"]
+        else:
+            self.spatial_cov.params["ell1"]["value"] = params["spatial_ell1"]
+            self.spatial_cov.params["ell2"]["value"] = params["spatial_ell2"]
+        if len(self.temporal_cov_list) != len(params["temporal_ell_list"]):
+            print("different number of temporal covariance functions! stopping.")
+            return
+        for tc, ell, s2 in zip(self.temporal_cov_list, params["temporal_ell_list"], params["temporal_sigma2_list"]):
+            tc.params["ell"]["value"] = ell
+            tc.params["sigma2"]["value"] = s2
+
+    def _describe(self, header_lines):
+        s = "GPCSD1D object\n"          # (the reference prints this header for both classes)
+        s += "LFP shape: (%d, %d, %d)\n" % tuple(np.shape(self.lfp)[:3])
+        for line in header_lines:
+            s += line
+        s += "R parameter prior: %s\n" % str(self.R["prior"])
+        s += "R parameter value %0.4g\n" % self.R["value"]
+        return s
+
+    def _describe_temporal(self):
+        s = ""
+        for i, tc in enumerate(self.temporal_cov_list):
+            s += "Temporal covariance %d class name: %s\n" % (i + 1, type(tc).__name__)
+            s += "Temporal covariance %d ell prior: %s\n" % (i + 1, str(tc.params["ell"]["prior"]))
+            s += "Temporal covariance %d ell value %0.4g\n" % (i + 1, tc.params["ell"]["value"])
+            s += "Temporal covariance %d sigma2 prior: %s\n" % (i + 1, str(tc.params["sigma2"]["prior"]))
+            s += "Temporal covariance %d sigma2 value %0.4g\n" % (i + 1, tc.params["sigma2"]["value"])
+        return s
+
+    # ------------------------------------------------------------------ likelihood
+    def loglik(self):
+        """Log marginal likelihood (up to the 2*pi constant) of all trials under the current hyper-parameters."""
+        ctx = self._sync_device()
+        hp, _keep = self._hparams(self.JITTER)
+        sumlog, quad = ctx.loglik_parts(hp)
+        sh = getattr(self, "_sharding", None)
+        if sh is not None:
+            quad = float(sh.allreduce_sum(np.array([quad]))[0])
+        ntrials = np.shape(self.lfp)[2]
+        return np.float64(-0.5 * ntrials * sumlog - 0.5 * quad)
+
+    def _loglik_and_grad_natural(self):
+        """(loglik, d loglik / d[R, ell_s.., (ell_t, sigma2_t).., sig2n]) on the GPU (scalar sig2n)."""
+        ctx = self._sync_device()
+        hp, _keep = self._hparams(self.JITTER)
+        ng = 1 + self.dim + 2 * len(self.temporal_cov_list) + 1
+        sumlog, quad, g_logdet, g_quad = ctx.loglik_grad_parts(hp, ng)
+        sh = getattr(self, "_sharding", None)
+        if sh is not None:
+            red = sh.allreduce_sum(np.concatenate([[quad], g_quad]))
+            quad, g_quad = float(red[0]), red[1:]
+        ntrials = np.shape(self.lfp)[2]
+        return (-0.5 * ntrials * sumlog - 0.5 * quad), (-0.5 * ntrials * g_logdet - 0.5 * g_quad)
+
+    # ------------------------------------------------------------------ fit
+    def _param_slots(self):
+        """[(getter, setter, prior, (min, max), scale)] in the reference's log-parameter order."""
+        slots = []
+
+        def dict_slot(d, scale):
+            return (lambda: d["value"], lambda v: d.__setitem__("value", v), d["prior"], (d["min"], d["max"]), scale)
+        slots.append(dict_slot(self.R, 100.0))
+        for n in self._spatial_names:
+            slots.append(dict_slot(self.spatial_cov.params[n], 100.0))
+        for tc in self.temporal_cov_list:
+            slots.append(dict_slot(tc.params["ell"], 1.0))
+            slots.append(dict_slot(tc.params["sigma2"], 1.0))
+        return slots
+
+    def _bounds(self):
+        b = []
+        with np.errstate(divide="ignore"):
+            for _, _, _, (lo, hi), scale in self._param_slots():
+                b.append((np.log(lo / scale), np.log(hi / scale)))
+            if self._sig2n_is_scalar():
+                b.append((np.log(self.sig2n["min"]), np.log(self.sig2n["max"])))
+            else:
+                for lo, hi in zip(self.sig2n["min"], self.sig2n["max"]):
+                    b.append((np.log(lo), np.log(hi)))
+        return b
+
+    def _set_from_tparams(self, tparams, fix_R):
+        slots = self._param_slots()
+        for i, (_, setter, _, _, scale) in enumerate(slots):
+            if i == 0 and fix_R:
+                continue
+            setter(np.exp(tparams[i]) * scale)
+        p = len(slots)
+        if self._sig2n_is_scalar():
+            self.sig2n["value"] = np.exp(tparams[p])
+        else:
+            self.sig2n["value"] = np.exp(tparams[p:])
+
+    def _log_prior(self):
+        lp = 0.0
+        for getter, _, prior, _, _ in self._param_slots():
+            lp = lp + prior.lpdf(getter())
+        if self._sig2n_is_scalar():
+            lp = lp + self.sig2n["prior"].lpdf(self.sig2n["value"])
+        else:
+            for pr, v in zip(self.sig2n["prior"], self.sig2n["value"]):
+                lp = lp + pr.lpdf(v)
+        return lp
+
+    def _safe_loglik(self):
+        return self.loglik()
+
+    def _objective(self, tparams, fix_R):
+        """-(loglik + log prior) at log-parameters `tparams` (writes them into the param dicts, as the reference does)."""
+        self._set_from_tparams(tparams, fix_R)
+        lp = self._log_prior()
+        return -1.0 * (self._safe_loglik() + lp)
+
+    def _objective_grad(self, tparams, fix_R, fd_step=1e-6):
+        """Gradient of `_objective` w.r.t. the log-parameters."""
+        tparams = np.asarray(tparams, dtype=np.float64)
+        if self._sig2n_is_scalar() and getattr(self, "_use_analytic_grad", True):
+            try:
+                self._set_from_tparams(tparams, fix_R)
+                _, g_nat = self._loglik_and_grad_natural()
+                slots = self._param_slots()
+                g = np.zeros_like(tparams)
+                for i, (getter, _, prior, _, _) in enumerate(slots):
+                    v = getter()
+                    g[i] = -(g_nat[i] + prior.dlpdf(v)) * v          # d/dlog(v) = v d/dv
+                v = self.sig2n["value"]
+                g[len(slots)] = -(g_nat[len(slots)] + self.sig2n["prior"].dlpdf(v)) * v
+                if fix_R:
+                    g[0] = 0.0
+                return g
+            except RuntimeError as e:        # entry point not built -> central differences of GPU evaluations
+                if "not implemented" not in str(e):
+                    raise
+        g = np.zeros_like(tparams)
+        for i in range(tparams.size):
+            if i == 0 and fix_R:
+                continue
+            e = np.zeros_like(tparams)
+            e[i] = fd_step
+            g[i] = (self._objective(tparams + e, fix_R) - self._objective(tparams - e, fix_R)) / (2 * fd_step)
+        self._set_from_tparams(tparams, fix_R)
+        return g
+
+    def _sample_start(self, fix_R):
+        slots = self._param_slots()
+        tp = []
+        for i, (getter, _, prior, _, scale) in enumerate(slots):
+            if i == 0 and fix_R:
+                tp.append(np.log(getter()) - np.log(scale))
+            else:
+                tp.append(np.log(prior.sample()) - np.log(scale))
+        if self._sig2n_is_scalar():
+            tp.append(np.log(self.sig2n["prior"].sample()))
+        else:
+            for pr in self.sig2n["prior"]:
+                tp.append(np.log(pr.sample()))
+        return np.array(tp)
+
+    def _fit(self, n_restarts, method, fix_R, verbose, options, starts=None):
+        nll_values, params, term_msg = [], [], []
+        bounds = self._bounds()
+        for k in tqdm(range(n_restarts), desc="Restarts"):
+            tparams0 = self._sample_start(fix_R) if starts is None else np.asarray(starts[k], dtype=np.float64)
+            try:
+                res = scipy.optimize.minimize(lambda tp: self._objective(tp, fix_R), tparams0, method=method, options=options,
+                                              bounds=bounds, jac=lambda tp: self._objective_grad(tp, fix_R))
+                nll_values.append(res.fun)
+                params.append(res.x)
+                term_msg.append(res.message)
+            except (ValueError, np.linalg.LinAlgError) as e:
+                print(e)
+                if self.dim == 2:
+                    print("\nrestarting optimization...")
+        nll_values = np.array(nll_values)
+        if len(nll_values) < 1:
+            print("problem with optimization!")
+            return None
+        finite = np.isfinite(nll_values)
+        best_ind = np.argmin(nll_values[finite])
+        params = [p for p, ok in zip(params, finite) if ok]
+        if verbose:
+            print("\nNeg log lik values across different initializations:")
+            print(nll_values)
+            print("Best index termination message")
+            print(term_msg[best_ind])
+        self._set_from_tparams(params[best_ind], fix_R)
+        self.fit_nll_values_ = nll_values
+        self.fit_params_ = params
+        return None
+
+    # ------------------------------------------------------------------ prediction
+    def predict(self, z, t, type="csd"):
+        """Posterior mean of CSD and/or LFP at sites z and times t for every (local) trial."""
+        if type not in ("csd", "lfp", "both"):
+            raise ValueError("type must be 'csd', 'lfp' or 'both'")
+        ctx = self._sync_device()
+        hp, _keep = self._hparams(0.0)                     # no jitter in predict
+        z = np.asarray(z, dtype=np.float64)
+        z2 = z.reshape(-1, 1) if self.dim == 1 else z
+        t = np.asarray(t)
+        code = {"csd": _hip.PRED_CSD, "lfp": _hip.PRED_LFP, "both": _hip.PRED_BOTH}[type]
+        R_local = self._local_lfp().shape[2]
+        res = ctx.predict(hp, z2, t, code, (z2.shape[0], t.shape[0], R_local))
+        sh = getattr(self, "_sharding", None)
+        if sh is not None and getattr(sh, "gather_predictions", False):
+            res = {k: sh.gather_trials(v) for k, v in res.items()}
+        if "csd" in res:
+            self.csd_pred_list = [res["csd_list"][i] for i in range(res["csd_list"].shape[0])]
+            self.csd_pred = res["csd"]
+        if "lfp" in res:
+            self.lfp_pred_list = [res["lfp_list"][i] for i in range(res["lfp_list"].shape[0])]
+            self.lfp_pred = res["lfp"]
+        self.t_pred = t
+        self.x_pred = z
+
+    def _sample_prior_from_normals(self, normals, which):
+        """Ls Z_r Lt^T on the GPU for host-supplied standard normals (nx, nt, ntrials)."""
+        ctx = self._sync_device(need_lfp=False)
+        hp, _keep = self._hparams(self.JITTER)
+        return ctx.sample_prior(hp, which, normals)

@@ -1,0 +1,171 @@
+/*
+ * gpcsd_hip.h -- C ABI of libgpcsd_hip.so, the MI355X (gfx950) implementation of the
+ * GPCSD covariance-assembly / Kronecker-eigen marginal-likelihood / posterior-predict
+ * hot path.
+ *
+ * The reference (natalieklein/gpcsd) is pure Python and has no FFI; the boundary it
+ * offers is its Python class + operator surface.  Every entry point below names the
+ * reference function (file:line under /root/reference/) whose arithmetic it replaces;
+ * the Python package `gpcsd_amd` mirrors the reference classes and calls these through
+ * ctypes (see INTEGRATION.md for the binding a reference maintainer would add).
+ *
+ * Conventions
+ *   - All arrays are C-contiguous float64 HOST buffers owned by the caller unless a
+ *     name ends in `_dev`.  The library never retains a host pointer past the call.
+ *   - Every function returns int: 0 ok; >0 numerical failure (eigensolver did not
+ *     converge, Cholesky pivot <= 0 at column k -> return k+1) which the Python shim
+ *     turns into numpy.linalg.LinAlgError exactly where the reference would raise it
+ *     (gpcsd1d.py:219, gpcsd2d.py:217,258); <0 usage / HIP runtime error.
+ *     NaN/Inf in results are returned, not trapped (reference runs under
+ *     np.seterr(all='ignore'), gpcsd1d.py:7).
+ *   - One ctx = one device + one HIP stream; calls on one ctx must be serialised by
+ *     the caller.  Contexts are created lazily by the Python layer (fork safety).
+ */
+#ifndef GPCSD_HIP_H
+#define GPCSD_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GPCSD_MAX_TEMPORAL 8
+#define GPCSD_KIND_SE      0   /* covariances.py:257-271 */
+#define GPCSD_KIND_MATERN  1   /* covariances.py:291-305 */
+
+#define GPCSD_PRED_CSD  1
+#define GPCSD_PRED_LFP  2
+#define GPCSD_PRED_BOTH 3
+
+typedef struct gpcsd_ctx gpcsd_ctx;
+
+/* Hyper-parameters read from the reference's mutable param dicts at every call
+ * (gpcsd1d.py:53-62, gpcsd2d.py:67-79, covariances.py:48,174,254,288). */
+typedef struct gpcsd_hparams {
+    double R;                               /* forward-model radius                      */
+    double eps;                             /* 2D singularity offset (ignored in 1D)     */
+    double ell_s[2];                        /* spatial length scale(s): 1D uses [0]      */
+    int    n_temporal;                      /* number of temporal components (<= 8)      */
+    int    kind[GPCSD_MAX_TEMPORAL];        /* GPCSD_KIND_*                              */
+    double ell_t[GPCSD_MAX_TEMPORAL];
+    double sigma2_t[GPCSD_MAX_TEMPORAL];
+    int    n_sig2n;                         /* 1 = scalar noise, nx = per-electrode list */
+    const double *sig2n;                    /* host pointer, n_sig2n doubles             */
+    double jitter;                          /* JITTER added to Ks in loglik (gpcsd1d.py:17, gpcsd2d.py:16) */
+} gpcsd_hparams;
+
+/* ---- context -------------------------------------------------------------------- */
+int  gpcsd_ctx_create(int device, gpcsd_ctx **out);
+int  gpcsd_ctx_destroy(gpcsd_ctx *ctx);
+const char *gpcsd_last_error(gpcsd_ctx *ctx);     /* ctx may be NULL: last global error */
+int  gpcsd_version(void);
+int  gpcsd_device_synchronize(gpcsd_ctx *ctx);
+
+/* ---- resident data (copied; re-laid-out on device) ----------------------------- */
+/* lfp is (nx, nt, ntrials) C-order as held by GPCSD{1,2}D.lfp (gpcsd1d.py:34, gpcsd2d.py:36);
+ * stored on device electrode-major / trial / time so both projections are flat GEMMs. */
+int gpcsd_set_lfp(gpcsd_ctx *ctx, const double *lfp, int nx, int nt, int ntrials);
+/* GPCSD1DSpatialCov.__init__ state (covariances.py:12-27): electrodes + mapped GL rule */
+int gpcsd_set_geometry_1d(gpcsd_ctx *ctx, const double *x, int nx,
+                          const double *gl_x, const double *gl_w, int ngl);
+/* GPCSD2DSpatialCov.__init__/reset_x state (covariances.py:99-137): xy is (nx,2) */
+int gpcsd_set_geometry_2d(gpcsd_ctx *ctx, const double *xy, int nx,
+                          const double *gl_x1, const double *gl_w1, int ngl1,
+                          const double *gl_x2, const double *gl_w2, int ngl2);
+int gpcsd_set_time(gpcsd_ctx *ctx, const double *t, int nt);   /* GPCSDTemporalCov.t */
+
+/* ---- operator surface (stand-alone; host in / host out) ------------------------- */
+/* b_fwd_1d(r, R)                        forward_models.py:9-17   (elementwise, n values) */
+int gpcsd_b_fwd_1d(gpcsd_ctx *ctx, const double *r, long n, double R, double *out);
+/* b_fwd_2d(delta1, delta2, R, eps, w)   forward_models.py:42-54  (w != NULL -> d1,d2 ignored) */
+int gpcsd_b_fwd_2d(gpcsd_ctx *ctx, const double *d1, const double *d2, const double *w, long n,
+                   double R, double eps, double *out);
+/* GPCSDTemporalCov{SE,Matern}.compute_Kt(t, tprime)   covariances.py:257-271 / :291-305; out (n, m) */
+int gpcsd_gram_temporal(gpcsd_ctx *ctx, int kind, const double *t, int n, const double *tp, int m,
+                        double ell, double sigma2, double *out);
+/* GPCSD1DSpatialCovSE.compute_Ks        covariances.py:50-56 ; out (nx, nx) */
+int gpcsd_ks_csd_1d(gpcsd_ctx *ctx, const double *x, int nx, double ell, double *out);
+/* GPCSD2DSpatialCovSE.compute_Ks        covariances.py:177-186 */
+int gpcsd_ks_csd_2d(gpcsd_ctx *ctx, const double *xy, int nx, double ell1, double ell2, double *out);
+/* compKphi_1d(R, xp)                    covariances.py:74-96 ; out (nx, nxp); xp NULL -> x */
+int gpcsd_kphi_1d(gpcsd_ctx *ctx, const double *x, int nx, const double *gl_x, const double *gl_w, int ngl,
+                  double R, double ell, const double *xp, int nxp, double *out);
+/* compKphig_1d(z, R)                    covariances.py:58-72 ; out (nx, nz) */
+int gpcsd_kphig_1d(gpcsd_ctx *ctx, const double *x, int nx, const double *gl_x, const double *gl_w, int ngl,
+                   const double *z, int nz, double R, double ell, double *out);
+/* compKphi_2d(R, eps, xp)               covariances.py:204-232 ; xy (nx,2), xp (nxp,2) or NULL */
+int gpcsd_kphi_2d(gpcsd_ctx *ctx, const double *xy, int nx,
+                  const double *gl_x1, const double *gl_w1, int ngl1,
+                  const double *gl_x2, const double *gl_w2, int ngl2,
+                  double R, double eps, double ell1, double ell2,
+                  const double *xp, int nxp, double *out);
+/* compKphig_2d(z, R, eps)               covariances.py:188-202 ; z (nz,2) */
+int gpcsd_kphig_2d(gpcsd_ctx *ctx, const double *xy, int nx,
+                   const double *gl_x1, const double *gl_w1, int ngl1,
+                   const double *gl_x2, const double *gl_w2, int ngl2,
+                   const double *z, int nz, double R, double eps, double ell1, double ell2, double *out);
+/* numpy.linalg.eigh as used by comp_eig_D (utility_functions.py:58-59): ascending evals, evecs in columns */
+int gpcsd_eigh(gpcsd_ctx *ctx, const double *A, int n, double *evals, double *evecs);
+/* comp_eig_D(Ks, Kt, sig2n)             utility_functions.py:44-64 ; Dvec has nx*nt entries */
+int gpcsd_eig_D(gpcsd_ctx *ctx, const double *Ks, int nx, const double *Kt, int nt,
+                const double *sig2n, int n_sig, double *Qs, double *Qt, double *Dvec);
+/* numpy.linalg.cholesky (gpcsd1d.py:303-304, gpcsd2d.py:343-350): lower factor, upper part zeroed */
+int gpcsd_potrf(gpcsd_ctx *ctx, const double *A, int n, double *L);
+/* sum(log(diag(L))) * 2 = log det(A) for A = L L^T */
+int gpcsd_logdet_chol(gpcsd_ctx *ctx, const double *L, int n, double *out);
+/* solve L X = B (lower, non-transposed), B and X are (n, nrhs) */
+int gpcsd_trsm_lower(gpcsd_ctx *ctx, const double *L, int n, const double *B, int nrhs, double *X);
+/* C(M,N) = op(A) op(B), row-major; transA: A stored (K,M); transB: B stored (N,K).  The fp64 MFMA core. */
+int gpcsd_gemm(gpcsd_ctx *ctx, int transA, int transB, int M, int N, int K,
+               const double *A, const double *B, double *C);
+/* dense cross-check path (scalar sig2n): chol(kron(Ks,Kt)+sig2n I) log-det + triangular solves.
+ * lfp (nx,nt,ntrials) host.  Not a reference code path; see DESIGN.md. */
+int gpcsd_loglik_dense_chol(gpcsd_ctx *ctx, const double *Ks, int nx, const double *Kt, int nt, double sig2n,
+                            const double *lfp, int ntrials, double *out);
+
+/* ---- fused hot calls on resident data ------------------------------------------- */
+/* GPCSD1D.loglik() gpcsd1d.py:113-128 / GPCSD2D.loglik() gpcsd2d.py:136-151 */
+int gpcsd_loglik(gpcsd_ctx *ctx, const gpcsd_hparams *hp, double *out);
+/* Sharded form: out[0] = sum(log D) (identical on every shard), out[1] = sum_r sum alpha^2/D over the
+ * resident trials; loglik = -0.5*R_total*out[0] - 0.5*sum_over_shards(out[1]) */
+int gpcsd_loglik_parts(gpcsd_ctx *ctx, const gpcsd_hparams *hp, double *out2);
+/* loglik and its gradient w.r.t. the natural hyper-parameters
+ * [R, ell_s(dim), (ell_t, sigma2_t) per component, sig2n]  (scalar sig2n only).  Replaces the
+ * autograd tape of gpcsd1d.py:211 / gpcsd2d.py:250.  parts2 as in gpcsd_loglik_parts; grad_logdet and
+ * grad_quad are the derivatives of out2[0] and out2[1] so shards can be combined linearly. */
+int gpcsd_loglik_grad_parts(gpcsd_ctx *ctx, const gpcsd_hparams *hp, double *out2,
+                            double *grad_logdet, double *grad_quad, int ngrad);
+/* GPCSD{1,2}D.predict(z, t, type) gpcsd1d.py:248-293 / gpcsd2d.py:289-334.
+ * z (nz, dim), tstar (ntstar) with ntstar == nt (the reference raises ValueError otherwise -> rc -22).
+ * Outputs (any may be NULL): *_list is (n_temporal, nz, ntstar, ntrials), sums are (nz, ntstar, ntrials). */
+int gpcsd_predict(gpcsd_ctx *ctx, const gpcsd_hparams *hp, const double *z, int nz,
+                  const double *tstar, int ntstar, int type,
+                  double *csd_list, double *csd, double *lfp_list, double *lfp);
+/* Same computation, results left in ctx-owned device buffers in the output layout (z, t, trial); nothing crosses
+ * PCIe.  Buffers: "pred_out_csd", "pred_out_lfp" (nz*ntstar*ntrials) and, when want_lists,
+ * "pred_out_csd_list", "pred_out_lfp_list" (n_temporal times that).  Read them back with gpcsd_fetch. */
+int gpcsd_predict_resident(gpcsd_ctx *ctx, const gpcsd_hparams *hp, const double *z, int nz,
+                           const double *tstar, int ntstar, int type, int want_lists);
+/* copy `count` doubles of the named ctx-owned device buffer to host; rc -2 if the name is unknown */
+int gpcsd_fetch(gpcsd_ctx *ctx, const char *name, double *host, long count);
+/* sample_prior with host-supplied standard normals (nx, nt, ntrials): Ls Z_r Lt^T
+ * gpcsd1d.py:295-309 / gpcsd2d.py:336-360.  which: GPCSD_PRED_CSD (compute_Ks) or GPCSD_PRED_LFP (compKphi) */
+int gpcsd_sample_prior(gpcsd_ctx *ctx, const gpcsd_hparams *hp, int which,
+                       const double *normals, int ntrials, double *out);
+
+/* ---- measurement --------------------------------------------------------------- */
+/* When enabled, every launch of a named hot kernel is bracketed by hipEvents on the ctx stream. */
+int gpcsd_prof_enable(gpcsd_ctx *ctx, int on);
+int gpcsd_prof_reset(gpcsd_ctx *ctx);
+/* total ms, launch count and algorithmic flops accumulated under `name`; rc -2 if unknown */
+int gpcsd_prof_get(gpcsd_ctx *ctx, const char *name, double *ms, long *count, double *flops);
+/* names, ';'-separated, into buf */
+int gpcsd_prof_names(gpcsd_ctx *ctx, char *buf, int buflen);
+/* back-to-back v_mfma_f64_16x16x4_f64 microbenchmark: measured TFLOP/s */
+int gpcsd_mfma_f64_peak(gpcsd_ctx *ctx, double *tflops);
+/* streaming copy microbenchmark over `bytes` bytes: measured GB/s (read+write counted) */
+int gpcsd_hbm_copy_peak(gpcsd_ctx *ctx, long bytes, double *gbs);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GPCSD_HIP_H */

@@ -1,0 +1,91 @@
+"""Multi-process (world_size 2, gloo, CPU) test of the trial-sharding layer used by the N>1 bench path.
+The local evaluator is the CPU oracle here (tests may use it as the checker); on GPUs it is the HIP context."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import torch.distributed as td
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    td.init_process_group("gloo", rank=rank, world_size=world)
+    from gpcsd_amd.dist import TrialSharding, sharded_loglik
+    from helpers import load_model_case, with_jitter
+    from oracle import gpcsd_oracle as O
+    c, g, geom, hp, lfp = load_model_case("1d_odd_17x37x5")
+    hp = with_jitter(hp, 1e-8)
+    sh = TrialSharding(gather_predictions=True)
+    sl = sh.local_slice(lfp.shape[2])
+    local = lfp[:, :, sl]
+
+    def parts():
+        Ks = O.spatial_kphi(geom, hp) + hp["jitter"] * np.eye(17)
+        Kt = O.temporal_sum(hp["temporal"], geom.t)
+        Qs, Qt, D = O.eig_D(Ks, Kt, hp["sig2n"])
+        Y = np.moveaxis(local, 2, 0)
+        alpha = np.matmul(np.matmul(Qs.T, Y), Qt)
+        return float(np.sum(np.log(D))), float(np.sum(alpha ** 2 / D.reshape(1, 17, 37)))
+
+    ll = sharded_loglik(parts, lfp.shape[2], sh)
+    hp0 = with_jitter(hp, 0.0)
+    pred_local = O.predict(geom, hp0, local, c["x"], c["t"], type="csd")["csd"]
+    pred_full = sh.gather_trials(pred_local)
+    vec = sh.broadcast(np.arange(5.0) * (1 + rank), src=0)
+    if rank == 0:
+        ref = O.loglik(geom, hp, lfp)
+        pref = O.predict(geom, hp0, lfp, c["x"], c["t"], type="csd")["csd"]
+        q.put((ll, ref, float(np.max(np.abs(pred_full - pref))), vec.tolist(), (sl.start, sl.stop)))
+    else:
+        q.put((ll, None, None, vec.tolist(), (sl.start, sl.stop)))
+    td.destroy_process_group()
+
+
+def test_block_partition():
+    from gpcsd_amd.dist import TrialSharding
+    for n, w in [(400, 8), (5, 2), (3, 4), (50, 1)]:
+        blocks = [TrialSharding.block(n, r, w) for r in range(w)]
+        assert blocks[0][0] == 0 and blocks[-1][1] == n
+        assert all(blocks[i][1] == blocks[i + 1][0] for i in range(w - 1))
+        sizes = [b - a for a, b in blocks]
+        assert max(sizes) - min(sizes) <= 1
+    assert TrialSharding.block(400, 3, 8) == (150, 200)
+
+
+@pytest.mark.timeout(300)
+def test_sharded_loglik_and_gather_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in procs]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    lls = [r[0] for r in res]
+    ref = [r[1] for r in res if r[1] is not None][0]
+    assert abs(lls[0] - lls[1]) < 1e-9 * abs(ref)
+    assert abs(lls[0] - ref) / abs(ref) < 1e-12
+    perr = [r[2] for r in res if r[2] is not None][0]
+    assert perr < 1e-12
+    assert all(r[3] == [0.0, 1.0, 2.0, 3.0, 4.0] for r in res)
+    assert sorted(r[4] for r in res) == [(0, 3), (3, 5)]

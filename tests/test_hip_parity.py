@@ -1,0 +1,314 @@
+"""GPU parity tests: the HIP path (through the C ABI, via the mirrored Python surface) against the golden
+fixtures (outputs of the reference itself) and the CPU oracle on the same seeded inputs.
+
+Tolerances (float64 throughout):
+  * elementwise operators: 1e-13 relative (libm vs ocml transcendental ulps);
+  * Gram contractions: 1e-11 relative to max|K| (different summation order);
+  * loglik and posterior mean: 1e-6 relative, the gate BASELINE.json states; observed values are ~1e-10.
+"""
+import numpy as np
+import pytest
+
+import cases as C
+from helpers import golden, load_model_case, relerr, with_jitter
+from oracle import gpcsd_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+GATE = 1e-6
+MODEL_CASES = list(C.model_cases().keys())
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from gpcsd_amd import _hip
+    return _hip.default_context()
+
+
+# ------------------------------------------------------------------------------------------------ operators
+def test_b_fwd_ops():
+    from gpcsd_amd import forward_models as F
+    g = golden("ops")
+    assert relerr(F.b_fwd_1d(g["bf1_r"], 100.0), g["bf1_out0"]) < 1e-13
+    assert relerr(F.b_fwd_1d(g["bf1_r"], 37.5), g["bf1_out1"]) < 1e-13
+    assert F.b_fwd_1d(g["bf1_r"], 100.0).shape == g["bf1_r"].shape
+    assert relerr(F.b_fwd_2d(g["bf2_d1"], g["bf2_d2"], 100.0, 80.0), g["bf2_out_R100_e80"]) < 1e-13
+    assert relerr(F.b_fwd_2d(g["bf2_d1"], g["bf2_d2"], 30.0, 5.0), g["bf2_out_R30_e5"]) < 1e-13
+    assert relerr(F.b_fwd_2d(None, None, 100.0, 80.0, w=g["bf2_w"]), g["bf2_out_w"]) < 1e-13
+    # broadcasting form used by fwd_model_2d: (nx1,1) x (1,nx2)
+    d1 = np.linspace(-3, 3, 5)[:, None]
+    d2 = np.linspace(-100, 100, 7)[None, :]
+    assert relerr(F.b_fwd_2d(d1, d2, 60.0, 20.0), O.b_fwd_2d(d1, d2, 60.0, 20.0)) < 1e-13
+    assert F.b_fwd_1d(np.zeros((0,)), 1.0).shape == (0,)
+
+
+def test_fwd_models():
+    from gpcsd_amd import forward_models as F
+    g = golden("ops")
+    assert relerr(F.fwd_model_1d(g["fm1_arr"], g["fm1_x"], g["fm1_z"], 150.0), g["fm1_out"]) < 1e-12
+    assert relerr(F.fwd_model_2d(g["fm2_arr"], g["fm2_x1"], g["fm2_x2"], g["fm2_z"], 60.0, 20.0), g["fm2_out"]) < 1e-12
+
+
+def test_temporal_cov_classes():
+    from gpcsd_amd.covariances import GPCSDTemporalCovSE, GPCSDTemporalCovMatern
+    g = golden("ops")
+    np.random.seed(1)
+    t, tp = g["kt_t"], g["kt_tp"]
+    se = GPCSDTemporalCovSE(t)
+    se.params["ell"]["value"], se.params["sigma2"]["value"] = 4.5, 1.7
+    ma = GPCSDTemporalCovMatern(t)
+    ma.params["ell"]["value"], ma.params["sigma2"]["value"] = 2.5, 0.6
+    assert relerr(se.compute_Kt(), g["kt_se_default"]) < 1e-13
+    assert relerr(se.compute_Kt(tp, t), g["kt_se_t_tp"]) < 1e-13
+    assert relerr(se.compute_Kt(tprime=tp), g["kt_se_tp_only"]) < 1e-13
+    assert relerr(ma.compute_Kt(), g["kt_ma_default"]) < 1e-13
+    assert relerr(ma.compute_Kt(tp, t), g["kt_ma_t_tp"]) < 1e-13
+    assert se.compute_Kt(tp, t).shape == (47, 61)
+
+
+@pytest.mark.parametrize("tag,a,b,ngl", [("a", 0.0, 2300.0, 100), ("b", -200.0, 2600.0, 30)])
+def test_spatial_cov_1d(tag, a, b, ngl):
+    from gpcsd_amd.covariances import GPCSD1DSpatialCovSE
+    g = golden("ops")
+    np.random.seed(2)
+    sc = GPCSD1DSpatialCovSE(g["s1_x"], a=a, b=b, ngl=ngl)
+    sc.params["ell"]["value"] = 200.0
+    assert np.array_equal(sc.gl_x, O.gauss_legendre(a, b, ngl)[0])
+    assert relerr(sc.compute_Ks(), g["s1%s_Ks" % tag]) < 1e-13
+    assert relerr(sc.compKphi_1d(100.0), g["s1%s_Kphi" % tag]) < 1e-11
+    assert relerr(sc.compKphi_1d(100.0, xp=g["s1_xp"]), g["s1%s_Kphi_xp" % tag]) < 1e-11
+    assert relerr(sc.compKphig_1d(g["s1_z"], 100.0), g["s1%s_Kphig" % tag]) < 1e-11
+
+
+def test_spatial_cov_2d():
+    from gpcsd_amd.covariances import GPCSD2DSpatialCovSE
+    g = golden("ops")
+    np.random.seed(2)
+    sc = GPCSD2DSpatialCovSE(g["s2_x"], a1=0.0, b1=48.0, a2=0.0, b2=440.0, ngl1=10, ngl2=24)
+    sc.params["ell1"]["value"], sc.params["ell2"]["value"] = 30.0, 100.0
+    assert np.array_equal(sc.gl_x_grid, g["s2_gl_x_grid"])
+    assert relerr(sc.gl_w_prod, g["s2_gl_w_prod"]) < 1e-15
+    assert relerr(sc.compute_Ks(), g["s2_Ks"]) < 1e-13
+    assert relerr(sc.compKphi_2d(60.0, 20.0), g["s2_Kphi"]) < 1e-11
+    assert relerr(sc.compKphi_2d(60.0, 20.0, xp=g["s2_xp"]), g["s2_Kphi_xp"]) < 1e-11
+    assert relerr(sc.compKphig_2d(g["s2_z"], 60.0, 20.0), g["s2_Kphig"]) < 1e-11
+    sc.reset_x(g["s2_xp"])
+    assert relerr(sc.compKphi_2d(60.0, 20.0), g["s2_Kphi_after_reset"]) < 1e-11
+
+
+@pytest.mark.parametrize("shape", [(1, 1, 1), (16, 16, 4), (24, 500, 24), (37, 53, 41), (130, 70, 257), (384, 96, 1200),
+                                   (300, 300, 300)])
+@pytest.mark.parametrize("ta,tb", [(False, False), (True, False), (False, True), (True, True)])
+def test_gemm_f64_mfma(ctx, shape, ta, tb):
+    """fp64 MFMA core against numpy on asymmetric random operands (catches row/col swaps), all transposes, tile edges."""
+    M, N, K = shape
+    rs = np.random.RandomState(M * 7 + N * 3 + K)
+    A = rs.standard_normal((K, M) if ta else (M, K))
+    B = rs.standard_normal((N, K) if tb else (K, N))
+    ref = (A.T if ta else A) @ (B.T if tb else B)
+    out = ctx.gemm(A, B, transA=ta, transB=tb)
+    assert relerr(out, ref) < 1e-13 * max(1, K) ** 0.5
+
+
+def _check_eigh(ctx, A, tol_scale=1.0):
+    n = A.shape[0]
+    w, V = ctx.eigh(A)
+    wr = np.linalg.eigvalsh(A)
+    nrm = max(np.max(np.abs(wr)), 1e-300)
+    assert np.all(np.diff(w) >= 0)
+    assert np.max(np.abs(w - wr)) / nrm < 1e-13 * n * tol_scale
+    assert np.max(np.abs(V.T @ V - np.eye(n))) < 1e-13 * n * tol_scale
+    assert np.max(np.abs(A @ V - V * w[None, :])) / nrm < 1e-13 * n * tol_scale
+    return w, V
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 9, 24, 33, 64, 65, 100, 257])
+def test_eigh_random(ctx, n):
+    rs = np.random.RandomState(n)
+    M = rs.standard_normal((n, n))
+    _check_eigh(ctx, (M + M.T) * 0.5)
+
+
+def test_eigh_structured(ctx):
+    """Clusters / rank deficiency / indefinite / diagonal inputs -- the shapes the GPCSD Grams actually have."""
+    rs = np.random.RandomState(0)
+    Q, _ = np.linalg.qr(rs.standard_normal((96, 96)))
+    lam = np.concatenate([np.zeros(60), np.full(10, 1.0), np.linspace(2, 5, 20), [1e6] * 6])
+    _check_eigh(ctx, (Q * lam) @ Q.T)                                # clusters + exact rank deficiency
+    _check_eigh(ctx, np.diag(np.arange(40.0)[::-1]))                  # already diagonal, descending
+    _check_eigh(ctx, -np.eye(17))                                     # negative definite, fully degenerate
+    t = np.arange(120.0)[:, None]
+    Kt = 0.5 * np.exp(-0.5 * (t - t.T) ** 2 / 400.0) + 0.7 * np.exp(-np.abs(t - t.T) / 5.0)
+    _check_eigh(ctx, Kt)
+    g = golden("ops")
+    w, V = _check_eigh(ctx, g["eig_Ks"])
+    assert relerr(w, g["eig_es"]) < 1e-13
+
+
+def test_comp_eig_D():
+    from gpcsd_amd.utility_functions import comp_eig_D
+    g = golden("ops")
+    Qs, Qt, D = comp_eig_D(g["eig_Ks"], g["eig_Kt"], 0.3)
+    assert relerr(D, g["eig_D_scalar"]) < 1e-12
+    assert relerr(Qs @ np.diag(g["eig_es"]) @ Qs.T, g["eig_Ks"]) < 1e-12
+    assert relerr(Qt @ np.diag(g["eig_et"]) @ Qt.T, g["eig_Kt"]) < 1e-12
+    assert relerr(comp_eig_D(g["eig_Ks"], g["eig_Kt"], g["eig_siglist"])[2], g["eig_D_list"]) < 1e-12
+
+
+@pytest.mark.parametrize("n", [1, 5, 64, 65, 130, 300])
+def test_potrf_trsm_logdet(ctx, n):
+    rs = np.random.RandomState(n)
+    M = rs.standard_normal((n, n))
+    A = M @ M.T + n * np.eye(n)
+    L = ctx.potrf(A)
+    Lr = np.linalg.cholesky(A)
+    assert relerr(L, Lr) < 1e-12
+    assert np.all(np.triu(L, 1) == 0.0)
+    assert abs(ctx.logdet_chol(L) - np.linalg.slogdet(A)[1]) < 1e-10 * n
+    B = rs.standard_normal((n, 7))
+    X = ctx.trsm_lower(Lr, B)
+    assert relerr(Lr @ X, B) < 1e-11
+
+
+def test_potrf_not_positive_definite(ctx):
+    A = np.eye(70)
+    A[40, 40] = -1.0
+    with pytest.raises(np.linalg.LinAlgError):
+        ctx.potrf(A)
+
+
+# ------------------------------------------------------------------------------------------------ models
+def _build_model(name):
+    """The mirrored Python class, configured like the golden generator configured the reference."""
+    from gpcsd_amd.gpcsd1d import GPCSD1D
+    from gpcsd_amd.gpcsd2d import GPCSD2D
+    from gpcsd_amd.covariances import GPCSDTemporalCovSE, GPCSDTemporalCovMatern
+    c, g, geom, hp, lfp = load_model_case(name)
+    np.random.seed(0)
+    tcl = []
+    for (kind, ell, _), s2 in zip(c["temporal"], g["temporal_sigma2"]):
+        tc = GPCSDTemporalCovSE(c["t"]) if kind == C.SE else GPCSDTemporalCovMatern(c["t"])
+        tc.params["ell"]["value"] = ell
+        tc.params["sigma2"]["value"] = float(s2)
+        tcl.append(tc)
+    if c["dim"] == 1:
+        m = GPCSD1D(lfp, c["x"], c["t"], a=c["a"], b=c["b"], ngl=c["ngl"], temporal_cov_list=tcl)
+        m.spatial_cov.params["ell"]["value"] = c["ell_s"][0]
+    else:
+        m = GPCSD2D(lfp, c["x"], c["t"], ngl1=c["ngl1"], ngl2=c["ngl2"], temporal_cov_list=tcl, eps=c["eps"])
+        m.spatial_cov.params["ell1"]["value"] = c["ell_s"][0]
+        m.spatial_cov.params["ell2"]["value"] = c["ell_s"][1]
+    m.R["value"] = c["R"]
+    m.sig2n["value"] = c["sig2n"]
+    return m, c, g, geom, hp, lfp
+
+
+@pytest.mark.parametrize("name", MODEL_CASES)
+def test_model_loglik_vs_reference_golden(name):
+    m, c, g, geom, hp, lfp = _build_model(name)
+    ll = m.loglik()
+    ref = float(g["loglik"])
+    assert abs(ll - ref) / abs(ref) < GATE
+    # oracle on the same inputs agrees as well (and much tighter than the gate)
+    llo = O.loglik(geom, with_jitter(hp, float(g["jitter"])), lfp)
+    assert abs(ll - llo) / abs(llo) < 1e-8
+    # Ks / Kt assembled by the operator surface match the reference's
+    if c["dim"] == 1:
+        Ks = m.spatial_cov.compKphi_1d(c["R"])
+    else:
+        Ks = m.spatial_cov.compKphi_2d(c["R"], c["eps"])
+    assert relerr(np.diag(Ks), g["Ks_diag"]) < 1e-11
+    assert relerr(Ks[0], g["Ks_row0"]) < 1e-11
+
+
+@pytest.mark.parametrize("name", [n for n in MODEL_CASES if not C.model_cases()[n].get("loglik_only")])
+def test_model_predict_vs_reference_golden(name):
+    m, c, g, geom, hp, lfp = _build_model(name)
+    m.predict(c["x"], c["t"], type="both")
+    assert relerr(m.csd_pred, g["csd_pred"]) < GATE
+    assert m.csd_pred.shape == (c["x"].shape[0], c["t"].shape[0], c["R_trials"])
+    assert m.t_pred is not None and m.x_pred is not None
+    if c.get("predict_light"):
+        assert relerr(m.lfp_pred[:, :, :1], g["lfp_pred_trial0"]) < GATE
+        return
+    assert relerr(m.lfp_pred, g["lfp_pred"]) < GATE
+    assert len(m.csd_pred_list) == len(c["temporal"])
+    for i in range(len(c["temporal"])):
+        assert relerr(m.csd_pred_list[i], g["csd_pred_%d" % i]) < GATE
+        assert relerr(m.lfp_pred_list[i], g["lfp_pred_%d" % i]) < GATE
+    m.predict(g["z2"], c["t"], type="csd")
+    assert relerr(m.csd_pred, g["csd_pred_z2"]) < GATE
+    m.predict(g["z2"], g["tq"], type="lfp")                      # t* != t, equal length: reference axis quirk
+    assert relerr(m.lfp_pred, g["lfp_pred_z2_tq"]) < GATE
+    with pytest.raises(ValueError):
+        m.predict(g["z2"], c["t"][:-1], type="csd")
+
+
+def test_sample_prior_vs_reference_golden():
+    g = golden("sample_prior")
+    m, c, *_ = _build_model("cfg1_1d_24x100x1")
+    np.random.seed(77)
+    out = m.sample_prior(3)
+    assert relerr(out, g["sp1_csd"]) < 1e-9
+    m, c, *_ = _build_model("2d_grid_48x40x2")
+    csd, lfp = m.sample_prior(2, type="csd", seed=5)
+    assert relerr(csd, g["sp2_csd"]) < 1e-9
+    assert np.all(np.isnan(lfp))
+
+
+def test_dense_cholesky_crosscheck(ctx):
+    """Kronecker-eigen loglik == dense potrf/log-det/trsm loglik on the GPU (scalar sig2n), and both == oracle."""
+    m, c, g, geom, hp, lfp = _build_model("1d_odd_17x37x5")
+    Ks = O.spatial_kphi(geom, hp) + 1e-8 * np.eye(17)
+    Kt = O.temporal_sum(hp["temporal"], geom.t)
+    dense = ctx.loglik_dense_chol(Ks, Kt, c["sig2n"], lfp)
+    ll = m.loglik()
+    assert abs(dense - ll) / abs(ll) < 1e-9
+    assert abs(dense - O.loglik_dense_cholesky(lfp, Ks, Kt, c["sig2n"])) / abs(ll) < 1e-9
+
+
+def test_update_lfp_and_param_mutation():
+    """Device state follows the Python-side mutation pattern of the reference scripts."""
+    m, c, g, geom, hp, lfp = _build_model("1d_wide_24x60x3")
+    ll0 = m.loglik()
+    m.R["value"] = 90.0
+    hp2 = dict(hp)
+    hp2["R"] = 90.0
+    ll1 = m.loglik()
+    assert abs(ll1 - O.loglik(geom, with_jitter(hp2, 1e-8), lfp)) / abs(ll1) < 1e-8 and ll1 != ll0
+    new = C.synth_lfp(99, 24, 60, 2)
+    m.update_lfp(new, c["t"])
+    ll2 = m.loglik()
+    assert abs(ll2 - O.loglik(geom, with_jitter(hp2, 1e-8), new)) / abs(ll2) < 1e-8
+    p = m.extract_model_params()
+    m.R["value"] = 10.0
+    m.restore_model_params(p)
+    assert m.loglik() == ll2          # deterministic kernels: bit-identical re-evaluation
+
+
+def test_full_size_properties_cfg3():
+    """BASELINE cfg3 shape (384 x 500, reduced trials): size-independent properties of the hot path."""
+    from gpcsd_amd import _hip
+    m, c, g, geom, hp, lfp = _build_model("cfg3s_2d_384x500x2")
+    ll = m.loglik()
+    assert m.loglik() == ll                                           # run-to-run determinism
+    # linearity of the posterior mean in the data: predict(a*Y) == a*predict(Y)
+    z = c["x"][::16]
+    m.predict(z, c["t"], type="csd")
+    p1 = m.csd_pred.copy()
+    m.update_lfp(2.5 * lfp, c["t"])
+    m.predict(z, c["t"], type="csd")
+    assert relerr(m.csd_pred, 2.5 * p1) < 1e-10
+    # sum over components == total; trial independence: each trial alone gives the same prediction
+    assert relerr(sum(m.csd_pred_list), m.csd_pred) < 1e-12
+    m.update_lfp(lfp[:, :, 1:2].copy(), c["t"])
+    m.predict(z, c["t"], type="csd")
+    assert relerr(m.csd_pred[:, :, 0], p1[:, :, 1]) < 1e-9
+    # quadratic term is additive over trials: ll(Y1 u Y2) - logdet part
+    hp_c, keep = m._hparams(m.JITTER)
+    s1, q1 = m._sync_device().loglik_parts(hp_c)
+    m.update_lfp(lfp[:, :, 0:1].copy(), c["t"])
+    s0, q0 = m._sync_device().loglik_parts(hp_c)
+    m.update_lfp(lfp, c["t"])
+    s, q = m._sync_device().loglik_parts(hp_c)
+    assert s0 == s1 == s and abs((q0 + q1) - q) / abs(q) < 1e-12
