@@ -58,6 +58,8 @@ SIGNATURES = {
     "gpcsd_kphig_2d": (_I, [_P, _DP, _I, _DP, _DP, _I, _DP, _DP, _I, _DP, _I, _D, _D, _D, _D, _DP]),
     "gpcsd_eigh": (_I, [_P, _DP, _I, _DP, _DP]),
     "gpcsd_eig_D": (_I, [_P, _DP, _I, _DP, _I, _DP, _I, _DP, _DP, _DP]),
+    "gpcsd_debug_sytrd": (_I, [_P, _DP, _I, _DP, _DP, _DP, _DP]),
+    "gpcsd_debug_stedc": (_I, [_P, _DP, _DP, _I, _DP, _DP]),
     "gpcsd_potrf": (_I, [_P, _DP, _I, _DP]),
     "gpcsd_logdet_chol": (_I, [_P, _DP, _I, _DP]),
     "gpcsd_trsm_lower": (_I, [_P, _DP, _I, _DP, _I, _DP]),
@@ -273,6 +275,20 @@ class Context:
         w, V = np.empty(n), np.empty((n, n))
         self._check(self._lib.gpcsd_eigh(self._h, _ptr(A), n, _ptr(w), _ptr(V)))
         return w, V
+
+    def debug_sytrd(self, A):
+        A = _arr(A)
+        n = A.shape[0]
+        d, e, tau, V = np.empty(n), np.empty(n), np.empty(n), np.empty((n, n))
+        self._check(self._lib.gpcsd_debug_sytrd(self._h, _ptr(A), n, _ptr(d), _ptr(e), _ptr(V), _ptr(tau)))
+        return d, e[:n - 1], V, tau
+
+    def debug_stedc(self, d, e):
+        d, e = _arr(d).reshape(-1), _arr(e).reshape(-1)
+        n = d.size
+        w, Z = np.empty(n), np.empty((n, n))
+        self._check(self._lib.gpcsd_debug_stedc(self._h, _ptr(d), _ptr(e), n, _ptr(w), _ptr(Z)))
+        return w, Z
 
     def eig_D(self, Ks, Kt, sig2n):
         Ks, Kt = _arr(Ks), _arr(Kt)

@@ -150,12 +150,11 @@ void check_hp(gpcsd_ctx *c, const gpcsd_hparams *hp, int nx) {
 // Inputs Ks, Kt are destroyed.  Outputs: Qs, es, Qt, et, D, sumlog (device).
 void eig_pair_D(gpcsd_ctx *c, double *Ks, int nx, double *Kt, int nt, const double *d_sig, int nsig, double *Qs, double *es,
                 double *Qt, double *et, double *D, double *d_sumlog, int *d_status) {
-    GP_HIP(hipEventRecord(c->ev_fork, c->stream));
-    GP_HIP(hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
-    eigh_device(c, Kt, nt, et, Qt, d_status, c->stream2, "eigh_t");
-    eigh_device(c, Ks, nx, es, Qs, d_status, c->stream, "eigh_s");
-    GP_HIP(hipEventRecord(c->ev_join, c->stream2));
-    GP_HIP(hipStreamWaitEvent(c->stream, c->ev_join, 0));
+    {
+        // both problems share every launch of the per-column tridiagonalisation (batched), so one stream suffices
+        ProfScope ps(c, "eigh_pair", 9.0 * ((double)nx * nx * nx + (double)nt * nt * nt), c->stream);
+        eigh_pair_device(c, Ks, nx, es, Qs, Kt, nt, et, Qt, d_status, c->stream);
+    }
     k_build_D(c, es, nx, et, nt, d_sig, nsig, D, d_sumlog, c->stream);
 }
 
@@ -502,6 +501,41 @@ extern "C" int gpcsd_eigh(gpcsd_ctx *c, const double *A, int n, double *evals, d
     eigh_device(c, dA, n, dw, dV, st, c->stream, "eigh");
     c->download(evals, dw, n * sizeof(double));
     c->download(evecs, dV, (size_t)n * n * sizeof(double));
+    return finish_status(c, st);
+    GP_API_END(c)
+}
+
+// diagnostics: the stages of the large-n eigensolver on their own (tests compare them with LAPACK-free identities)
+extern "C" int gpcsd_debug_sytrd(gpcsd_ctx *c, const double *A, int n, double *d, double *e, double *V, double *tau) {
+    GP_API_BEGIN(c)
+    GP_REQUIRE(A && d && e && V && tau && n > 0, -3, "debug_sytrd: bad arguments");
+    double *dA = c->upload<double>("op_in0", A, (size_t)n * n);
+    double *dd = c->buf<double>("dbg_d", n), *de = c->buf<double>("dbg_e", n), *dt = c->buf<double>("dbg_tau", n);
+    double *dV = c->buf<double>("op_out", (size_t)n * n);
+    sytrd_device(c, dA, n, dd, de, dV, dt, c->stream);
+    c->download(d, dd, n * sizeof(double));
+    c->download(e, de, n * sizeof(double));
+    c->download(tau, dt, n * sizeof(double));
+    c->download(V, dV, (size_t)n * n * sizeof(double));
+    c->sync();
+    return 0;
+    GP_API_END(c)
+}
+
+extern "C" int gpcsd_debug_stedc(gpcsd_ctx *c, const double *d, const double *e, int n, double *w, double *Z) {
+    GP_API_BEGIN(c)
+    GP_REQUIRE(d && e && w && Z && n > 0, -3, "debug_stedc: bad arguments");
+    double *dd = c->upload<double>("dbg_d", d, n);
+    double *de = c->buf<double>("dbg_e", n);
+    GP_HIP(hipMemsetAsync(de, 0, n * sizeof(double), c->stream));
+    if (n > 1) GP_HIP(hipMemcpyAsync(de, e, (n - 1) * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    double *dw = c->buf<double>("op_w", n);
+    double *dZ = c->buf<double>("op_out", (size_t)n * n);
+    int *st = c->buf<int>("status", 4);
+    GP_HIP(hipMemsetAsync(st, 0, 4 * sizeof(int), c->stream));
+    stedc_device(c, dd, de, n, dw, dZ, st, c->stream, "dbg");
+    c->download(w, dw, n * sizeof(double));
+    c->download(Z, dZ, (size_t)n * n * sizeof(double));
     return finish_status(c, st);
     GP_API_END(c)
 }
@@ -880,15 +914,15 @@ extern "C" int gpcsd_prof_names(gpcsd_ctx *c, char *buf, int buflen) {
 
 typedef double d4 __attribute__((ext_vector_type(4)));
 
-// 4 independent accumulator chains per wave, one wave per SIMD x 2, operands in registers.
+// Back-to-back v_mfma_f64_16x16x4_f64 with the accumulators pinned to VGPRs (inline asm keeps hipcc from shuttling
+// them through AGPRs every iteration); 4 independent chains per wave, 4 waves per SIMD.
+#define GP_MF(acc) asm volatile("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+v"(acc) : "v"(x), "v"(y))
 __global__ __launch_bounds__(256) void mfma_f64_peak_kernel(double *out, int iters) {
     d4 a0 = {0, 0, 0, 0}, a1 = a0, a2 = a0, a3 = a0;
-    const double x = 1.0 + 1e-9 * threadIdx.x, y = 1.0 - 1e-9 * threadIdx.x;
+    const double x = 1.0 + 1e-3 * threadIdx.x, y = 0.7 - 1e-3 * threadIdx.x;
     for (int i = 0; i < iters; ++i) {
-        a0 = __builtin_amdgcn_mfma_f64_16x16x4f64(x, y, a0, 0, 0, 0);
-        a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(y, x, a1, 0, 0, 0);
-        a2 = __builtin_amdgcn_mfma_f64_16x16x4f64(x, x, a2, 0, 0, 0);
-        a3 = __builtin_amdgcn_mfma_f64_16x16x4f64(y, y, a3, 0, 0, 0);
+        GP_MF(a0); GP_MF(a1); GP_MF(a2); GP_MF(a3);
+        GP_MF(a0); GP_MF(a1); GP_MF(a2); GP_MF(a3);
     }
     d4 r = a0 + a1 + a2 + a3;
     if (r[0] == 123.456) out[blockIdx.x] = r[0] + r[1] + r[2] + r[3];
@@ -907,7 +941,7 @@ extern "C" int gpcsd_mfma_f64_peak(gpcsd_ctx *c, double *tflops) {
     GP_HIP(hipEventSynchronize(e1));
     float ms = 0.f;
     GP_HIP(hipEventElapsedTime(&ms, e0, e1));
-    const double flops = (double)blocks * 4 /*waves*/ * iters * 4.0 * 2048.0;
+    const double flops = (double)blocks * 4 /*waves*/ * iters * 8.0 * 2048.0;
     *tflops = flops / (ms * 1e-3) / 1e12;
     c->event_pool.push_back(e0);
     c->event_pool.push_back(e1);

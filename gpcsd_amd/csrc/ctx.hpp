@@ -63,6 +63,7 @@ struct gpcsd_ctx {
     bool prof_on = false;
     std::map<std::string, gpcsd::ProfEntry> prof;
     std::vector<hipEvent_t> event_pool;
+    std::map<std::string, int> int_cache;   // small host-side memo (e.g. which n a device-side plan table was built for)
 
     // resident problem
     int dim = 0;                            // 1 or 2 once geometry is set

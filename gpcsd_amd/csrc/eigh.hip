@@ -1,146 +1,20 @@
-// Symmetric eigensolver -- replaces numpy.linalg.eigh at utility_functions.py:58-59.
+// Symmetric eigensolver front end -- replaces numpy.linalg.eigh at utility_functions.py:58-59.
 //
-// Stage 1 (this file, round 1 baseline): two-sided cyclic Jacobi with round-robin parallel ordering, one
-// workgroup per matrix.  n <= JACOBI_LDS_MAX keeps A and V in LDS (the nx = 24 spatial problems of GPCSD1D and
-// the leaves of the divide-and-conquer solver); larger n runs the same code on L2-resident global memory.
-// Jacobi is normwise backward stable and returns orthogonal eigenvectors to ~n*eps, which is what parity with
-// LAPACK dsyevd needs (eigenvalues to n*eps*||A||, invariant subspaces of clusters).
+//   n <= 64 : two-sided cyclic Jacobi, one workgroup, A and V resident in LDS (the nx = 24 spatial problems of
+//             GPCSD1D; also the leaf solver of the divide-and-conquer path).
+//   n  > 64 : Householder tridiagonalisation + divide & conquer + compact-WY back-transformation (eigh_dc.hip).
+// GPCSD_EIGH=jacobi in the environment forces the single-workgroup Jacobi on global memory for any n (slow; kept as
+// an independent cross-check of the large-n solver).
+#include <cstdlib>
+
+#include "jacobi.hpp"
 #include "kernels.hpp"
 
 namespace gpcsd {
 
-constexpr int JACOBI_LDS_MAX = 64;
-constexpr int JACOBI_MAX_N = 1024;
-constexpr int JACOBI_MAX_SWEEPS = 60;
-
-// pair k of round-robin step `step` over m (even) players; returns p < q
-__device__ __forceinline__ void rr_pair(int k, int step, int m, int &p, int &q) {
-    int a, b;
-    if (k == 0) {
-        a = m - 1;
-        b = step % (m - 1);
-    } else {
-        a = (step + k) % (m - 1);
-        b = (step - k + (m - 1)) % (m - 1);
-    }
-    p = a < b ? a : b;
-    q = a < b ? b : a;
-}
-
-template <int NT>
-__device__ void jacobi_body(double *A, int lda, double *V, int ldv, int n, double *evals, double *evecs, int *status,
-                            double *cs, int *pq, double *red) {
-    const int tid = threadIdx.x;
-    const int m = (n + 1) & ~1;
-    const int npairs = m / 2;
-    __shared__ int s_rot;
-    __shared__ double s_thresh;
-
-    // V = I, Frobenius norm
-    double acc = 0.0;
-    for (int e = tid; e < n * n; e += NT) {
-        const int i = e / n, j = e % n;
-        V[i * ldv + j] = (i == j) ? 1.0 : 0.0;
-        const double a = A[i * lda + j];
-        acc += a * a;
-    }
-    red[tid] = acc;
-    __syncthreads();
-    for (int w = NT / 2; w > 0; w >>= 1) {
-        if (tid < w) red[tid] += red[tid + w];
-        __syncthreads();
-    }
-    if (tid == 0) s_thresh = sqrt(red[0]) * 1.1102230246251565e-16 / (double)n;
-    __syncthreads();
-    const double thresh = s_thresh;
-
-    int sweep = 0;
-    bool converged = (n <= 1);
-    for (; sweep < JACOBI_MAX_SWEEPS && !converged; ++sweep) {
-        if (tid == 0) s_rot = 0;
-        __syncthreads();
-        for (int step = 0; step < m - 1; ++step) {
-            // (a) rotation parameters for the disjoint pairs of this step
-            for (int k = tid; k < npairs; k += NT) {
-                int p, q;
-                rr_pair(k, step, m, p, q);
-                double c = 1.0, s = 0.0;
-                int active = 0;
-                if (q < n) {
-                    const double apq = A[p * lda + q];
-                    if (fabs(apq) > thresh) {
-                        const double app = A[p * lda + p], aqq = A[q * lda + q];
-                        const double theta = (aqq - app) / (2.0 * apq);
-                        double t;
-                        if (fabs(theta) > 1e150) t = 0.5 / theta;
-                        else t = copysign(1.0, theta) / (fabs(theta) + sqrt(theta * theta + 1.0));
-                        c = 1.0 / sqrt(t * t + 1.0);
-                        s = t * c;
-                        active = 1;
-                    }
-                }
-                cs[2 * k] = c;
-                cs[2 * k + 1] = s;
-                pq[2 * k] = active ? p : -1;
-                pq[2 * k + 1] = q;
-                if (active) s_rot = 1;
-            }
-            __syncthreads();
-            // (b) column phase: A <- A J, V <- V J.  Consecutive threads take consecutive pairs of ONE row.
-            for (int e = tid; e < npairs * n; e += NT) {
-                const int k = e % npairs, i = e / npairs;
-                const int p = pq[2 * k];
-                if (p < 0) continue;
-                const int q = pq[2 * k + 1];
-                const double c = cs[2 * k], s = cs[2 * k + 1];
-                const double aip = A[i * lda + p], aiq = A[i * lda + q];
-                A[i * lda + p] = c * aip - s * aiq;
-                A[i * lda + q] = s * aip + c * aiq;
-                const double vip = V[i * ldv + p], viq = V[i * ldv + q];
-                V[i * ldv + p] = c * vip - s * viq;
-                V[i * ldv + q] = s * vip + c * viq;
-            }
-            __syncthreads();
-            // (c) row phase: A <- J^T A.  Consecutive threads take consecutive columns of one row pair.
-            for (int e = tid; e < npairs * n; e += NT) {
-                const int j = e % n, k = e / n;
-                const int p = pq[2 * k];
-                if (p < 0) continue;
-                const int q = pq[2 * k + 1];
-                const double c = cs[2 * k], s = cs[2 * k + 1];
-                const double apj = A[p * lda + j], aqj = A[q * lda + j];
-                double np_ = c * apj - s * aqj, nq_ = s * apj + c * aqj;
-                if (j == q) np_ = 0.0;      // the annihilated element, exactly
-                if (j == p) nq_ = 0.0;
-                A[p * lda + j] = np_;
-                A[q * lda + j] = nq_;
-            }
-            __syncthreads();
-        }
-        converged = (s_rot == 0);
-        __syncthreads();
-    }
-
-    // sort ascending (rank by counting; ties by index) and scatter eigenpairs
-    for (int i = tid; i < n; i += NT) red[i] = A[i * lda + i];
-    __syncthreads();
-    for (int i = tid; i < n; i += NT) {
-        const double di = red[i];
-        int rank = 0;
-        for (int j = 0; j < n; ++j) {
-            const double dj = red[j];
-            rank += (dj < di) || (dj == di && j < i);
-        }
-        pq[i] = rank;
-        evals[rank] = di;
-    }
-    __syncthreads();
-    for (int e = tid; e < n * n; e += NT) {
-        const int i = e / n, j = e % n;
-        evecs[(long)i * n + pq[j]] = V[i * ldv + j];
-    }
-    if (tid == 0 && !converged) atomicMax(status, 1);
-}
+struct EigProb;   // eigh_dc.hip
+void eigh_large_pair(gpcsd_ctx *c, double *A0, int n0, double *w0, double *Z0, const char *tag0, double *A1, int n1, double *w1,
+                     double *Z1, const char *tag1, int *d_status, hipStream_t s);
 
 template <int NT>
 __global__ __launch_bounds__(NT) void jacobi_lds_kernel(const double *__restrict__ Ag, int n, double *evals, double *evecs,
@@ -154,7 +28,7 @@ __global__ __launch_bounds__(NT) void jacobi_lds_kernel(const double *__restrict
     __shared__ int pq[2 * JACOBI_LDS_MAX + 2];
     for (int e = threadIdx.x; e < n * n; e += NT) A[(e / n) * ld + (e % n)] = Ag[e];
     __syncthreads();
-    jacobi_body<NT>(A, ld, V, ld, n, evals, evecs, status, cs, pq, red);
+    jacobi_body<NT>(A, ld, V, ld, n, evals, evecs, n, status, cs, pq, red);
 }
 
 template <int NT>
@@ -163,14 +37,21 @@ __global__ __launch_bounds__(NT) void jacobi_global_kernel(double *A, double *V,
     __shared__ double cs[JACOBI_MAX_N + 2];
     __shared__ int pq[JACOBI_MAX_N + 2];
     __shared__ double red[JACOBI_MAX_N > NT ? JACOBI_MAX_N : NT];
-    jacobi_body<NT>(A, n, V, n, n, evals, evecs, status, cs, pq, red);
+    jacobi_body<NT>(A, n, V, n, n, evals, evecs, n, status, cs, pq, red);
 }
 
-void eigh_device(gpcsd_ctx *c, double *A, int n, double *evals, double *evecs, int *d_status, hipStream_t s,
-                 const char *tag) {
-    GP_REQUIRE(n >= 1 && n <= JACOBI_MAX_N, -3, "eigh: n=%d outside [1,%d]", n, JACOBI_MAX_N);
-    const double flops = 9.0 * (double)n * n * n;   // nominal dsyevd-with-vectors count
-    ProfScope ps(c, tag ? tag : "eigh", flops, s);
+static bool force_jacobi() {
+    static int v = -1;
+    if (v < 0) {
+        const char *e = getenv("GPCSD_EIGH");
+        v = (e && std::string(e) == "jacobi") ? 1 : 0;
+    }
+    return v == 1;
+}
+
+static void eigh_jacobi(gpcsd_ctx *c, double *A, int n, double *evals, double *evecs, int *d_status, hipStream_t s,
+                        const char *tag) {
+    ProfScope ps(c, "eigh_jacobi", 9.0 * (double)n * n * n, s);
     if (n <= JACOBI_LDS_MAX) {
         const int ld = n | 1;
         const size_t sh = sizeof(double) * (2 * (size_t)n * ld + 2 * (JACOBI_LDS_MAX / 2 + 1) + 256);
@@ -180,6 +61,26 @@ void eigh_device(gpcsd_ctx *c, double *A, int n, double *evals, double *evecs, i
         hipLaunchKernelGGL((jacobi_global_kernel<1024>), dim3(1), dim3(1024), 0, s, A, V, n, evals, evecs, d_status);
     }
     GP_HIP(hipGetLastError());
+}
+
+void eigh_pair_device(gpcsd_ctx *c, double *A0, int n0, double *w0, double *Z0, double *A1, int n1, double *w1, double *Z1,
+                      int *d_status, hipStream_t s) {
+    GP_REQUIRE(n0 <= JACOBI_MAX_N && n1 <= JACOBI_MAX_N, -3, "eigh: n=%d/%d exceeds %d", n0, n1, JACOBI_MAX_N);
+    const bool small0 = n0 <= JACOBI_LDS_MAX || force_jacobi();
+    const bool small1 = n1 <= JACOBI_LDS_MAX || force_jacobi();
+    if (n0 > 0 && small0) eigh_jacobi(c, A0, n0, w0, Z0, d_status, s, "p0");
+    if (n1 > 0 && small1) eigh_jacobi(c, A1, n1, w1, Z1, d_status, s, "p1");
+    const bool big0 = n0 > 0 && !small0, big1 = n1 > 0 && !small1;
+    if (big0 || big1)
+        eigh_large_pair(c, big0 ? A0 : nullptr, big0 ? n0 : 0, w0, Z0, "p0", big1 ? A1 : nullptr, big1 ? n1 : 0, w1, Z1, "p1",
+                        d_status, s);
+}
+
+void eigh_device(gpcsd_ctx *c, double *A, int n, double *evals, double *evecs, int *d_status, hipStream_t s,
+                 const char *tag) {
+    GP_REQUIRE(n >= 1 && n <= JACOBI_MAX_N, -3, "eigh: n=%d outside [1,%d]", n, JACOBI_MAX_N);
+    (void)tag;
+    eigh_pair_device(c, A, n, evals, evecs, nullptr, 0, nullptr, nullptr, d_status, s);
 }
 
 }  // namespace gpcsd

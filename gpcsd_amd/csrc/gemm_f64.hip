@@ -7,8 +7,10 @@
 //   K15 sum alpha^2 / D                     fused epilogue EPI_QUAD (gpcsd1d.py:126-127)
 //   K16/K17 predict contractions            (gpcsd1d.py:262-285)
 //
-// Design (MI355X): 256 threads = 4 waves in a 2x2 grid, each wave owns FM x FN MFMA 16x16 fragments
-// (block tile 32FM x 32FN, 128x128 for the large flat GEMMs).  BK = 16 (four k=4 MFMA steps).  Operand tiles
+// Design (MI355X): WM x WN waves per workgroup, each wave owns FM x FN MFMA 16x16 fragments.  The large flat GEMMs
+// use a 128x128 block tile with 8 waves (4x2) of 32x64: 64 accumulator VGPRs per lane, so two workgroups fit a CU
+// and every SIMD always has another wave's MFMAs to issue while one waits on LDS or the barrier
+// (measured: v_mfma_f64_16x16x4_f64 issues every 64 cycles per wave; 78 TFLOP/s chip-wide, tools/mfma_f64_probe).  BK = 16 (four k=4 MFMA steps).  Operand tiles
 // are register-staged global -> LDS, double-buffered, one barrier per K tile.  LDS row strides are chosen so the
 // ds_read_b64 fragment reads are bank-conflict free on the 64-bank b64 path:
 //   [k][o] tiles: stride BO+16 doubles (second k row lands on the other 32 banks),
@@ -41,13 +43,16 @@ struct GemmK {
     long ldd;
     double *partials;
     int tiles_n;
+    const int *dyn;     // optional device scalar: effective N and K (= *dyn) of this launch (D&C merge GEMMs)
 };
 
-// One operand tile: BO "outer" rows/cols (M or N side) x BK.  KMAJOR: global storage is [K][O].
-template <int BO, bool KMAJOR>
+// One operand tile: BO "outer" rows/cols (M or N side) x BK, staged by NT threads.  KMAJOR: global storage is [K][O].
+// Loads are branch-free: out-of-range elements read a clamped (always valid) address and are zeroed by a select.
+template <int BO, bool KMAJOR, int NT>
 struct Tile {
     static constexpr int LDS_ELEMS = KMAJOR ? BK * (BO + PAD_KO) : BO * LD_OK;
-    static constexpr int PER_THREAD = BO * BK / 256;
+    static constexpr int PER_THREAD = BO * BK / NT;
+    static_assert(BO * BK % NT == 0, "tile must divide evenly over the workgroup");
 
     __device__ static __forceinline__ int lds_index(int o, int k) {
         return KMAJOR ? k * (BO + PAD_KO) + o : o * LD_OK + k;
@@ -56,7 +61,7 @@ struct Tile {
                                                  int k0, int Olim, int K, int tid) {
 #pragma unroll
         for (int i = 0; i < PER_THREAD; ++i) {
-            int e = tid + 256 * i;
+            const int e = tid + NT * i;
             int o, k;
             if (KMAJOR) {
                 k = e / BO;
@@ -65,16 +70,18 @@ struct Tile {
                 o = e / BK;
                 k = e % BK;
             }
-            int go = o0 + o, gk = k0 + k;
-            bool ok = (go < Olim) && (gk < K);
-            long idx = KMAJOR ? (long)gk * ld + go : (long)go * ld + gk;
-            r[i] = ok ? base[idx] : 0.0;
+            const int go = o0 + o, gk = k0 + k;
+            const bool ok = (go < Olim) && (gk < K);
+            const int goc = go < Olim ? go : Olim - 1, gkc = gk < K ? gk : K - 1;
+            const long idx = KMAJOR ? (long)gkc * ld + goc : (long)goc * ld + gkc;
+            const double v = base[idx];
+            r[i] = ok ? v : 0.0;
         }
     }
     __device__ static __forceinline__ void sstore(const double (&r)[PER_THREAD], double *lds, int tid) {
 #pragma unroll
         for (int i = 0; i < PER_THREAD; ++i) {
-            int e = tid + 256 * i;
+            const int e = tid + NT * i;
             int o, k;
             if (KMAJOR) {
                 k = e / BO;
@@ -88,11 +95,12 @@ struct Tile {
     }
 };
 
-template <int FM, int FN, bool TA, bool TB, int EPI>
-__global__ __launch_bounds__(256) void gemm_f64_kernel(GemmK g) {
-    constexpr int BM = 32 * FM, BN = 32 * FN;
-    using TileA = Tile<BM, TA>;    // transA: global [K][M]
-    using TileB = Tile<BN, !TB>;   // !transB: global [K][N]
+template <int WM, int WN, int FM, int FN, bool TA, bool TB, int EPI>
+__global__ __launch_bounds__(64 * WM * WN) void gemm_f64_kernel(GemmK g) {
+    constexpr int NT = 64 * WM * WN;
+    constexpr int BM = 16 * FM * WM, BN = 16 * FN * WN;
+    using TileA = Tile<BM, TA, NT>;    // transA: global [K][M]
+    using TileB = Tile<BN, !TB, NT>;   // !transB: global [K][N]
     __shared__ double lds[2 * (TileA::LDS_ELEMS + TileB::LDS_ELEMS)];
     // buffer `b` of operand A at lds + b*LDS_ELEMS; operand B follows the two A buffers
     auto ldsA = [&](int b) -> double * { return lds + b * TileA::LDS_ELEMS; };
@@ -101,9 +109,15 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(GemmK g) {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wid = tid >> 6;
-    const int wr = wid >> 1, wc = wid & 1;
+    const int wr = wid / WN, wc = wid % WN;
     const int tile_m = blockIdx.x / g.tiles_n, tile_n = blockIdx.x % g.tiles_n;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
+    if (g.dyn) {                        // wave-uniform: sizes decided on the device (deflation count)
+        const int kk = g.dyn[blockIdx.z];
+        g.N = kk;
+        g.K = kk;
+        if (n0 >= kk) return;
+    }
     const long bz = blockIdx.z;
     const double *__restrict__ A = g.A + bz * g.sA;
     const double *__restrict__ B = g.B + bz * g.sB;
@@ -189,13 +203,18 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(GemmK g) {
         }
     }
     if (EPI == EPI_QUAD) {
-        // wave reduction (64 lanes) then the four waves through LDS; fixed order -> deterministic
+        // wave reduction (64 lanes) then the waves through LDS; fixed order -> deterministic
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) qsum += __shfl_down(qsum, off, 64);
-        __shared__ double wsum[4];
+        __shared__ double wsum[WM * WN];
         if (lane == 0) wsum[wid] = qsum;
         __syncthreads();
-        if (tid == 0) g.partials[bz * gridDim.x + blockIdx.x] = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
+        if (tid == 0) {
+            double t = 0.0;
+#pragma unroll
+            for (int i = 0; i < WM * WN; ++i) t += wsum[i];
+            g.partials[bz * gridDim.x + blockIdx.x] = t;
+        }
     }
 }
 
@@ -213,24 +232,25 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const double *__re
     if (threadIdx.x == 0) out[0] = sh[0];
 }
 
-template <int FM, int FN, bool TA, bool TB>
+template <int WM, int WN, int FM, int FN, bool TA, bool TB>
 static void launch_epi(const GemmK &k, int epi, dim3 grid, hipStream_t s) {
+    const dim3 blk(64 * WM * WN);
     switch (epi) {
-        case EPI_STORE: hipLaunchKernelGGL((gemm_f64_kernel<FM, FN, TA, TB, EPI_STORE>), grid, dim3(256), 0, s, k); break;
-        case EPI_DIV_D: hipLaunchKernelGGL((gemm_f64_kernel<FM, FN, TA, TB, EPI_DIV_D>), grid, dim3(256), 0, s, k); break;
-        case EPI_QUAD: hipLaunchKernelGGL((gemm_f64_kernel<FM, FN, TA, TB, EPI_QUAD>), grid, dim3(256), 0, s, k); break;
-        case EPI_ACCUM: hipLaunchKernelGGL((gemm_f64_kernel<FM, FN, TA, TB, EPI_ACCUM>), grid, dim3(256), 0, s, k); break;
-        case EPI_DUAL: hipLaunchKernelGGL((gemm_f64_kernel<FM, FN, TA, TB, EPI_DUAL>), grid, dim3(256), 0, s, k); break;
+        case EPI_STORE: hipLaunchKernelGGL((gemm_f64_kernel<WM, WN, FM, FN, TA, TB, EPI_STORE>), grid, blk, 0, s, k); break;
+        case EPI_DIV_D: hipLaunchKernelGGL((gemm_f64_kernel<WM, WN, FM, FN, TA, TB, EPI_DIV_D>), grid, blk, 0, s, k); break;
+        case EPI_QUAD: hipLaunchKernelGGL((gemm_f64_kernel<WM, WN, FM, FN, TA, TB, EPI_QUAD>), grid, blk, 0, s, k); break;
+        case EPI_ACCUM: hipLaunchKernelGGL((gemm_f64_kernel<WM, WN, FM, FN, TA, TB, EPI_ACCUM>), grid, blk, 0, s, k); break;
+        case EPI_DUAL: hipLaunchKernelGGL((gemm_f64_kernel<WM, WN, FM, FN, TA, TB, EPI_DUAL>), grid, blk, 0, s, k); break;
         default: throw HipError{-3, "gemm_f64: bad epilogue"};
     }
 }
 
-template <int FM, int FN>
+template <int WM, int WN, int FM, int FN>
 static void launch_trans(const GemmK &k, bool ta, bool tb, int epi, dim3 grid, hipStream_t s) {
-    if (!ta && !tb) launch_epi<FM, FN, false, false>(k, epi, grid, s);
-    else if (ta && !tb) launch_epi<FM, FN, true, false>(k, epi, grid, s);
-    else if (!ta && tb) launch_epi<FM, FN, false, true>(k, epi, grid, s);
-    else launch_epi<FM, FN, true, true>(k, epi, grid, s);
+    if (!ta && !tb) launch_epi<WM, WN, FM, FN, false, false>(k, epi, grid, s);
+    else if (ta && !tb) launch_epi<WM, WN, FM, FN, true, false>(k, epi, grid, s);
+    else if (!ta && tb) launch_epi<WM, WN, FM, FN, false, true>(k, epi, grid, s);
+    else launch_epi<WM, WN, FM, FN, true, true>(k, epi, grid, s);
 }
 
 void gemm_f64(gpcsd_ctx *c, const GemmDesc &g, hipStream_t s) {
@@ -242,6 +262,7 @@ void gemm_f64(gpcsd_ctx *c, const GemmDesc &g, hipStream_t s) {
     k.sA = g.sA; k.sB = g.sB; k.sC = g.sC;
     k.alpha = g.alpha; k.D = g.D; k.rdiv = g.rdiv > 0 ? g.rdiv : 1; k.ldd = g.ldd;
     k.partials = nullptr;
+    k.dyn = g.dyn;
 
     auto tiles = [&](int b) { return (long)ceil_div(g.M, b) * ceil_div(g.N, b) * g.batch; };
     int bt;                                   // block tile edge
@@ -257,9 +278,10 @@ void gemm_f64(gpcsd_ctx *c, const GemmDesc &g, hipStream_t s) {
     const double flops = 2.0 * g.M * (double)g.N * g.K * g.batch;
     {
         ProfScope ps(c, g.prof_name, flops, s);
-        if (bt == 128) launch_trans<4, 4>(k, g.transA, g.transB, g.epi, grid, s);
-        else if (bt == 64) launch_trans<2, 2>(k, g.transA, g.transB, g.epi, grid, s);
-        else launch_trans<1, 1>(k, g.transA, g.transB, g.epi, grid, s);
+        // 128x128: 8 waves (4x2), each 32x64 -> 64 accumulator VGPRs, two waves per SIMD from one workgroup
+        if (bt == 128) launch_trans<4, 2, 2, 4>(k, g.transA, g.transB, g.epi, grid, s);
+        else if (bt == 64) launch_trans<2, 2, 2, 2>(k, g.transA, g.transB, g.epi, grid, s);
+        else launch_trans<2, 2, 1, 1>(k, g.transA, g.transB, g.epi, grid, s);
         GP_HIP(hipGetLastError());
     }
     if (g.epi == EPI_QUAD) {

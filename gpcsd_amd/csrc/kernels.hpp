@@ -32,6 +32,7 @@ struct GemmDesc {
     int rdiv = 1;
     long ldd = 0;
     double *quad_out = nullptr;   // EPI_QUAD: one double, written by the final reduce
+    const int *dyn = nullptr;     // device int per batch entry: effective N = K = dyn[batch] (tiles beyond it exit)
     const char *prof_name = "gemm_f64";
 };
 
@@ -69,6 +70,14 @@ void k_fill(gpcsd_ctx *c, double *p, long n, double v, hipStream_t s);
 // eigenvectors in COLUMNS (numpy.linalg.eigh convention).  A is destroyed.  status: device int (0 ok).
 void eigh_device(gpcsd_ctx *c, double *A, int n, double *evals, double *evecs, int *d_status, hipStream_t s,
                  const char *tag);
+// Two independent problems at once (Ks and Kt of one likelihood evaluation): the launch-per-column
+// tridiagonalisation is batched so both share every launch.  Either n may be <= 0 to skip.
+void eigh_pair_device(gpcsd_ctx *c, double *A0, int n0, double *w0, double *Z0, double *A1, int n1, double *w1, double *Z1,
+                      int *d_status, hipStream_t s);
+// stages of the large-n solver, exposed for tests / diagnostics
+void sytrd_device(gpcsd_ctx *c, double *A, int n, double *d, double *e, double *V, double *tau, hipStream_t s);
+void stedc_device(gpcsd_ctx *c, const double *d, const double *e, int n, double *w, double *Z, int *d_status,
+                  hipStream_t s, const char *tag);
 
 // ---------------------------------------------------------------- Cholesky (chol.hip)
 // In-place lower Cholesky of A (n,n) row-major; strictly-upper part zeroed.  d_status: 0 ok, k+1 = pivot k <= 0.

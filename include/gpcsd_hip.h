@@ -105,7 +105,12 @@ int gpcsd_kphig_2d(gpcsd_ctx *ctx, const double *xy, int nx,
                    const double *z, int nz, double R, double eps, double ell1, double ell2, double *out);
 /* numpy.linalg.eigh as used by comp_eig_D (utility_functions.py:58-59): ascending evals, evecs in columns */
 int gpcsd_eigh(gpcsd_ctx *ctx, const double *A, int n, double *evals, double *evecs);
-/* comp_eig_D(Ks, Kt, sig2n)             utility_functions.py:44-64 ; Dvec has nx*nt entries */
+/* Diagnostics for the large-n eigensolver stages (no reference counterpart; LAPACK does these inside dsyevd):
+ * Householder tridiagonalisation A = Q T Q^T: d (n), e (n, last unused), reflectors V (n,n) by rows, tau (n) */
+int gpcsd_debug_sytrd(gpcsd_ctx *ctx, const double *A, int n, double *d, double *e, double *V, double *tau);
+/* divide & conquer eigen-decomposition of tridiag(d (n), e (n-1)): w ascending, Z (n,n) eigenvectors in columns */
+int gpcsd_debug_stedc(gpcsd_ctx *ctx, const double *d, const double *e, int n, double *w, double *Z);
+/* comp_eig_D(Ks, Kt, sig2n)            utility_functions.py:44-64 ; Dvec has nx*nt entries */
 int gpcsd_eig_D(gpcsd_ctx *ctx, const double *Ks, int nx, const double *Kt, int nt,
                 const double *sig2n, int n_sig, double *Qs, double *Qt, double *Dvec);
 /* numpy.linalg.cholesky (gpcsd1d.py:303-304, gpcsd2d.py:343-350): lower factor, upper part zeroed */

@@ -312,3 +312,75 @@ def test_full_size_properties_cfg3():
     m.update_lfp(lfp, c["t"])
     s, q = m._sync_device().loglik_parts(hp_c)
     assert s0 == s1 == s and abs((q0 + q1) - q) / abs(q) < 1e-12
+
+
+# ------------------------------------------------------------------------------------------------ large-n eigensolver stages
+def _house_Q(V, tau):
+    n = V.shape[0]
+    Q = np.eye(n)
+    for k in range(n - 2):
+        v = V[k]
+        Q = Q - tau[k] * (Q @ v)[:, None] * v[None, :]          # Q H_k
+    return Q
+
+
+@pytest.mark.parametrize("n", [3, 4, 17, 65, 130, 300])
+def test_sytrd_stage(ctx, n):
+    rs = np.random.RandomState(n)
+    M = rs.standard_normal((n, n))
+    A = (M + M.T) * 0.5
+    d, e, V, tau = ctx.debug_sytrd(A)
+    T = np.diag(d) + np.diag(e, 1) + np.diag(e, -1)
+    Q = _house_Q(V, tau)
+    nrm = np.max(np.abs(A))
+    assert np.max(np.abs(Q.T @ Q - np.eye(n))) < 1e-13 * n
+    assert np.max(np.abs(Q.T @ A @ Q - T)) / nrm < 1e-13 * n
+    for k in range(n - 2):
+        assert np.all(V[k, :k + 1] == 0.0) and V[k, k + 1] == 1.0
+
+
+@pytest.mark.parametrize("n", [2, 5, 33, 64, 65, 100, 257, 500])
+def test_stedc_stage_random(ctx, n):
+    rs = np.random.RandomState(n)
+    d, e = rs.standard_normal(n), rs.standard_normal(n - 1)
+    w, Z = ctx.debug_stedc(d, e)
+    T = np.diag(d) + np.diag(e, 1) + np.diag(e, -1)
+    wr = np.linalg.eigvalsh(T)
+    nrm = np.max(np.abs(wr))
+    assert np.all(np.diff(w) >= 0)
+    assert np.max(np.abs(w - wr)) / nrm < 1e-13 * n
+    assert np.max(np.abs(Z.T @ Z - np.eye(n))) < 1e-13 * n
+    assert np.max(np.abs(T @ Z - Z * w[None, :])) / nrm < 1e-13 * n
+
+
+def test_stedc_stage_hard_cases(ctx):
+    def run(d, e, tol=1e-13):
+        n = len(d)
+        w, Z = ctx.debug_stedc(d, e)
+        T = np.diag(d) + np.diag(e, 1) + np.diag(e, -1)
+        wr = np.linalg.eigvalsh(T)
+        nrm = max(np.max(np.abs(wr)), 1e-300)
+        assert np.max(np.abs(w - wr)) / nrm < tol * n
+        assert np.max(np.abs(Z.T @ Z - np.eye(n))) < tol * n
+        assert np.max(np.abs(T @ Z - Z * w[None, :])) / nrm < tol * n
+    n = 201
+    run(np.abs(np.arange(n) - 100.0), np.ones(n - 1))                # Wilkinson W201+: pairs of nearly equal eigenvalues
+    e = np.zeros(99)
+    e[::7] = 1e-9
+    run(np.ones(100), e)                                             # near-identity, tiny couplings
+    run(np.zeros(128), np.ones(127))                                 # Toeplitz (all-deflating symmetries)
+    run(np.arange(70.0), np.zeros(69))                               # already diagonal
+    run(np.full(90, 3.0), np.full(89, -0.5))                         # negative off-diagonals
+
+
+@pytest.mark.parametrize("n", [100, 384, 500])
+def test_eigh_gpcsd_shaped(ctx, n):
+    """The actual Gram matrices of the hot path: numerically rank-deficient Ks, slowly decaying Kt."""
+    t = 0.4 * np.arange(n)[:, None]
+    Kt = 0.5 * np.exp(-0.5 * (t - t.T) ** 2 / 400.0) + 0.7 * np.exp(-np.abs(t - t.T) / 5.0)
+    _check_eigh(ctx, Kt)
+    x = C.neuropixels_xy(n)
+    geom = O.Geometry2D(x, t, ngl1=10, ngl2=30)
+    hp = O.make_hparams(100.0, (40.0, 150.0), [(O.SE, 20.0, 0.5)], 0.05, eps=80.0)
+    Ks = O.spatial_kphi(geom, hp)
+    w, V = _check_eigh(ctx, Ks + 1e-7 * np.eye(n))
