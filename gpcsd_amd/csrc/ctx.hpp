@@ -63,7 +63,14 @@ struct gpcsd_ctx {
     bool prof_on = false;
     std::map<std::string, gpcsd::ProfEntry> prof;
     std::vector<hipEvent_t> event_pool;
-    std::map<std::string, int> int_cache;   // small host-side memo (e.g. which n a device-side plan table was built for)
+    std::map<std::string, int> int_cache;
+    long alloc_epoch = 0;
+    struct GraphSlot {
+        hipGraphExec_t exec = nullptr;
+        long epoch = -1;          // alloc_epoch the executable graph was captured under
+        long seen_epoch = -1;     // alloc_epoch after the last eager run of this key
+    };
+    std::map<std::string, GraphSlot> graphs;   // small host-side memo (e.g. which n a device-side plan table was built for)
 
     // resident problem
     int dim = 0;                            // 1 or 2 once geometry is set
@@ -84,6 +91,7 @@ struct gpcsd_ctx {
             b.bytes = 0;
             GP_HIP(hipMalloc(&b.p, bytes));
             b.bytes = bytes;
+            ++alloc_epoch;                       // captured graphs hold raw pointers: any (re)allocation retires them
         }
         return reinterpret_cast<T *>(b.p);
     }

@@ -63,9 +63,8 @@ static void eigh_jacobi(gpcsd_ctx *c, double *A, int n, double *evals, double *e
     GP_HIP(hipGetLastError());
 }
 
-void eigh_pair_device(gpcsd_ctx *c, double *A0, int n0, double *w0, double *Z0, double *A1, int n1, double *w1, double *Z1,
-                      int *d_status, hipStream_t s) {
-    GP_REQUIRE(n0 <= JACOBI_MAX_N && n1 <= JACOBI_MAX_N, -3, "eigh: n=%d/%d exceeds %d", n0, n1, JACOBI_MAX_N);
+static void eigh_pair_enqueue(gpcsd_ctx *c, double *A0, int n0, double *w0, double *Z0, double *A1, int n1, double *w1,
+                              double *Z1, int *d_status, hipStream_t s) {
     const bool small0 = n0 <= JACOBI_LDS_MAX || force_jacobi();
     const bool small1 = n1 <= JACOBI_LDS_MAX || force_jacobi();
     if (n0 > 0 && small0) eigh_jacobi(c, A0, n0, w0, Z0, d_status, s, "p0");
@@ -74,6 +73,63 @@ void eigh_pair_device(gpcsd_ctx *c, double *A0, int n0, double *w0, double *Z0, 
     if (big0 || big1)
         eigh_large_pair(c, big0 ? A0 : nullptr, big0 ? n0 : 0, w0, Z0, "p0", big1 ? A1 : nullptr, big1 ? n1 : 0, w1, Z1, "p1",
                         d_status, s);
+}
+
+static bool graphs_enabled() {
+    static int v = -1;
+    if (v < 0) {
+        const char *e = getenv("GPCSD_NO_GRAPH");
+        v = (e && e[0] == '1') ? 0 : 1;
+    }
+    return v == 1;
+}
+
+// The large-n path is ~700 dependent launches with nothing decided on the host (deflation counts stay on the
+// device), so it replays as a hipGraph: first call eager (allocates workspaces), second call captured, later calls
+// replayed.  A graph is retired whenever any context buffer is (re)allocated, since it holds raw device pointers.
+void eigh_pair_device(gpcsd_ctx *c, double *A0, int n0, double *w0, double *Z0, double *A1, int n1, double *w1, double *Z1,
+                      int *d_status, hipStream_t s) {
+    GP_REQUIRE(n0 <= JACOBI_MAX_N && n1 <= JACOBI_MAX_N, -3, "eigh: n=%d/%d exceeds %d", n0, n1, JACOBI_MAX_N);
+    const bool any_large = !force_jacobi() && (n0 > JACOBI_LDS_MAX || n1 > JACOBI_LDS_MAX);
+    if (!any_large || c->prof_on || !graphs_enabled()) {
+        eigh_pair_enqueue(c, A0, n0, w0, Z0, A1, n1, w1, Z1, d_status, s);
+        return;
+    }
+    char key[256];
+    snprintf(key, sizeof(key), "eigh|%p|%d|%p|%p|%p|%d|%p|%p|%p|%p", (void *)A0, n0, (void *)w0, (void *)Z0, (void *)A1, n1,
+             (void *)w1, (void *)Z1, (void *)d_status, (void *)s);
+    gpcsd_ctx::GraphSlot &g = c->graphs[key];
+    if (g.exec && g.epoch == c->alloc_epoch) {
+        GP_HIP(hipGraphLaunch(g.exec, s));
+        return;
+    }
+    if (g.seen_epoch == c->alloc_epoch) {          // allocations are stable since the last eager run: capture now
+        if (g.exec) {
+            (void)hipGraphExecDestroy(g.exec);
+            g.exec = nullptr;
+        }
+        hipGraph_t graph = nullptr;
+        GP_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+        try {
+            eigh_pair_enqueue(c, A0, n0, w0, Z0, A1, n1, w1, Z1, d_status, s);
+        } catch (...) {
+            (void)hipStreamEndCapture(s, &graph);
+            if (graph) (void)hipGraphDestroy(graph);
+            throw;
+        }
+        GP_HIP(hipStreamEndCapture(s, &graph));
+        if (g.seen_epoch == c->alloc_epoch) {
+            GP_HIP(hipGraphInstantiate(&g.exec, graph, nullptr, nullptr, 0));
+            g.epoch = c->alloc_epoch;
+        }
+        (void)hipGraphDestroy(graph);
+        if (g.exec && g.epoch == c->alloc_epoch) {
+            GP_HIP(hipGraphLaunch(g.exec, s));
+            return;
+        }
+    }
+    eigh_pair_enqueue(c, A0, n0, w0, Z0, A1, n1, w1, Z1, d_status, s);
+    g.seen_epoch = c->alloc_epoch;
 }
 
 void eigh_device(gpcsd_ctx *c, double *A, int n, double *evals, double *evecs, int *d_status, hipStream_t s,

@@ -10,7 +10,7 @@
 // Design (MI355X): WM x WN waves per workgroup, each wave owns FM x FN MFMA 16x16 fragments.  The large flat GEMMs
 // use a 128x128 block tile with 8 waves (4x2) of 32x64: 64 accumulator VGPRs per lane, so two workgroups fit a CU
 // and every SIMD always has another wave's MFMAs to issue while one waits on LDS or the barrier
-// (measured: v_mfma_f64_16x16x4_f64 issues every 64 cycles per wave; 78 TFLOP/s chip-wide, tools/mfma_f64_probe).  BK = 16 (four k=4 MFMA steps).  Operand tiles
+// (measured: v_mfma_f64_16x16x4_f64 issues every 64 cycles per wave; 78 TFLOP/s chip-wide, tools/mfma_f64_probe).  BK = 16 (four k=4 MFMA steps) for the large tile.  Operand tiles
 // are register-staged global -> LDS, double-buffered, one barrier per K tile.  LDS row strides are chosen so the
 // ds_read_b64 fragment reads are bank-conflict free on the 64-bank b64 path:
 //   [k][o] tiles: stride BO+16 doubles (second k row lands on the other 32 banks),
@@ -23,9 +23,7 @@ namespace gpcsd {
 
 typedef double d4 __attribute__((ext_vector_type(4)));
 
-constexpr int BK = 16;
 constexpr int PAD_KO = 16;
-constexpr int LD_OK = BK + 2;
 
 struct GemmK {
     int M, N, K;
@@ -48,8 +46,9 @@ struct GemmK {
 
 // One operand tile: BO "outer" rows/cols (M or N side) x BK, staged by NT threads.  KMAJOR: global storage is [K][O].
 // Loads are branch-free: out-of-range elements read a clamped (always valid) address and are zeroed by a select.
-template <int BO, bool KMAJOR, int NT>
+template <int BO, bool KMAJOR, int NT, int BK>
 struct Tile {
+    static constexpr int LD_OK = BK + 2;       // (BK+2) mod 32 == 2 for BK = 16, 64: rows land on distinct even slots
     static constexpr int LDS_ELEMS = KMAJOR ? BK * (BO + PAD_KO) : BO * LD_OK;
     static constexpr int PER_THREAD = BO * BK / NT;
     static_assert(BO * BK % NT == 0, "tile must divide evenly over the workgroup");
@@ -95,12 +94,12 @@ struct Tile {
     }
 };
 
-template <int WM, int WN, int FM, int FN, bool TA, bool TB, int EPI>
+template <int WM, int WN, int FM, int FN, int BK, bool TA, bool TB, int EPI>
 __global__ __launch_bounds__(64 * WM * WN) void gemm_f64_kernel(GemmK g) {
     constexpr int NT = 64 * WM * WN;
     constexpr int BM = 16 * FM * WM, BN = 16 * FN * WN;
-    using TileA = Tile<BM, TA, NT>;    // transA: global [K][M]
-    using TileB = Tile<BN, !TB, NT>;   // !transB: global [K][N]
+    using TileA = Tile<BM, TA, NT, BK>;    // transA: global [K][M]
+    using TileB = Tile<BN, !TB, NT, BK>;   // !transB: global [K][N]
     __shared__ double lds[2 * (TileA::LDS_ELEMS + TileB::LDS_ELEMS)];
     // buffer `b` of operand A at lds + b*LDS_ELEMS; operand B follows the two A buffers
     auto ldsA = [&](int b) -> double * { return lds + b * TileA::LDS_ELEMS; };
@@ -232,25 +231,25 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const double *__re
     if (threadIdx.x == 0) out[0] = sh[0];
 }
 
-template <int WM, int WN, int FM, int FN, bool TA, bool TB>
+template <int WM, int WN, int FM, int FN, int BK, bool TA, bool TB>
 static void launch_epi(const GemmK &k, int epi, dim3 grid, hipStream_t s) {
     const dim3 blk(64 * WM * WN);
     switch (epi) {
-        case EPI_STORE: hipLaunchKernelGGL((gemm_f64_kernel<WM, WN, FM, FN, TA, TB, EPI_STORE>), grid, blk, 0, s, k); break;
-        case EPI_DIV_D: hipLaunchKernelGGL((gemm_f64_kernel<WM, WN, FM, FN, TA, TB, EPI_DIV_D>), grid, blk, 0, s, k); break;
-        case EPI_QUAD: hipLaunchKernelGGL((gemm_f64_kernel<WM, WN, FM, FN, TA, TB, EPI_QUAD>), grid, blk, 0, s, k); break;
-        case EPI_ACCUM: hipLaunchKernelGGL((gemm_f64_kernel<WM, WN, FM, FN, TA, TB, EPI_ACCUM>), grid, blk, 0, s, k); break;
-        case EPI_DUAL: hipLaunchKernelGGL((gemm_f64_kernel<WM, WN, FM, FN, TA, TB, EPI_DUAL>), grid, blk, 0, s, k); break;
+        case EPI_STORE: hipLaunchKernelGGL((gemm_f64_kernel<WM, WN, FM, FN, BK, TA, TB, EPI_STORE>), grid, blk, 0, s, k); break;
+        case EPI_DIV_D: hipLaunchKernelGGL((gemm_f64_kernel<WM, WN, FM, FN, BK, TA, TB, EPI_DIV_D>), grid, blk, 0, s, k); break;
+        case EPI_QUAD: hipLaunchKernelGGL((gemm_f64_kernel<WM, WN, FM, FN, BK, TA, TB, EPI_QUAD>), grid, blk, 0, s, k); break;
+        case EPI_ACCUM: hipLaunchKernelGGL((gemm_f64_kernel<WM, WN, FM, FN, BK, TA, TB, EPI_ACCUM>), grid, blk, 0, s, k); break;
+        case EPI_DUAL: hipLaunchKernelGGL((gemm_f64_kernel<WM, WN, FM, FN, BK, TA, TB, EPI_DUAL>), grid, blk, 0, s, k); break;
         default: throw HipError{-3, "gemm_f64: bad epilogue"};
     }
 }
 
-template <int WM, int WN, int FM, int FN>
+template <int WM, int WN, int FM, int FN, int BK>
 static void launch_trans(const GemmK &k, bool ta, bool tb, int epi, dim3 grid, hipStream_t s) {
-    if (!ta && !tb) launch_epi<WM, WN, FM, FN, false, false>(k, epi, grid, s);
-    else if (ta && !tb) launch_epi<WM, WN, FM, FN, true, false>(k, epi, grid, s);
-    else if (!ta && tb) launch_epi<WM, WN, FM, FN, false, true>(k, epi, grid, s);
-    else launch_epi<WM, WN, FM, FN, true, true>(k, epi, grid, s);
+    if (!ta && !tb) launch_epi<WM, WN, FM, FN, BK, false, false>(k, epi, grid, s);
+    else if (ta && !tb) launch_epi<WM, WN, FM, FN, BK, true, false>(k, epi, grid, s);
+    else if (!ta && tb) launch_epi<WM, WN, FM, FN, BK, false, true>(k, epi, grid, s);
+    else launch_epi<WM, WN, FM, FN, BK, true, true>(k, epi, grid, s);
 }
 
 void gemm_f64(gpcsd_ctx *c, const GemmDesc &g, hipStream_t s) {
@@ -279,9 +278,10 @@ void gemm_f64(gpcsd_ctx *c, const GemmDesc &g, hipStream_t s) {
     {
         ProfScope ps(c, g.prof_name, flops, s);
         // 128x128: 8 waves (4x2), each 32x64 -> 64 accumulator VGPRs, two waves per SIMD from one workgroup
-        if (bt == 128) launch_trans<4, 2, 2, 4>(k, g.transA, g.transB, g.epi, grid, s);
-        else if (bt == 64) launch_trans<2, 2, 2, 2>(k, g.transA, g.transB, g.epi, grid, s);
-        else launch_trans<2, 2, 1, 1>(k, g.transA, g.transB, g.epi, grid, s);
+        // the small-tile configurations are latency-bound (few MFMAs per K tile), so they take 64-deep K tiles
+        if (bt == 128) launch_trans<4, 2, 2, 4, 16>(k, g.transA, g.transB, g.epi, grid, s);
+        else if (bt == 64) launch_trans<2, 2, 2, 2, 32>(k, g.transA, g.transB, g.epi, grid, s);
+        else launch_trans<2, 2, 1, 1, 64>(k, g.transA, g.transB, g.epi, grid, s);
         GP_HIP(hipGetLastError());
     }
     if (g.epi == EPI_QUAD) {

@@ -1,0 +1,825 @@
+// Divide & conquer eigensolver for symmetric tridiagonal matrices on gfx950 (stage 2 of the large-n eigensolver; the
+// work LAPACK does in dstedc behind numpy.linalg.eigh, src/gpcsd/utility_functions.py:58-59).
+//
+// Cuppen tearing with every tear applied up front; leaves (<= DC_LEAF rows) by Jacobi in LDS, one wave each; then
+// bottom-up merges.  Per merge: z from the boundary rows of the two eigenvector blocks, stable merge order, dlaed2-style
+// deflation scan, secular equation with origin shift (one wave per root, rational two-pole iteration safeguarded by
+// bisection), Gu/Eisenstat z-hat through the Loewner formula so the eigenvector block is orthogonal to working
+// precision, U = zhat_i / (d_i - lam_j) normalised, Z_new = Q2 U, rank sort of {roots} and {deflated poles}.
+//
+// Launch structure (latency is what matters at n <= 1024):
+//   * several independent problems share every launch (blockIdx.z);
+//   * levels whose merges have <= DC_SMALL rows run as ONE launch each (a workgroup walks all phases of its merge,
+//     matmul included); larger levels run one launch per phase and the Q2 U product on the fp64 MFMA GEMM with the
+//     non-deflated count read on the device (no host round trip anywhere).
+// tools/dc_prototype.py is the NumPy model this was validated against before porting.
+#include <algorithm>
+#include <string>
+#include <vector>
+
+#include "devutil.hpp"
+#include "jacobi.hpp"
+#include "kernels.hpp"
+
+namespace gpcsd {
+
+constexpr int DC_LEAF = 8;
+constexpr int DC_SMALL = 64;          // merges up to this size use the fused single-launch level kernel
+constexpr int NT_SMALL = 512;
+
+struct Seg {
+    int lo, mid, hi;
+};
+
+struct DcWork {            // per problem, all device pointers
+    int n;
+    double *dcur, *dnext;  // eigenvalues of the current / next level (n)
+    double *Qcur, *Qnext;  // block-diagonal eigenvector matrices (n x n)
+    double *dwork;         // torn diagonal, later d after deflation (n)
+    double *dk, *zk;       // compacted non-deflated poles / weights, stored at [lo, lo+K)
+    double *mu, *lam, *zhat, *invn;
+    int *org, *ndidx, *deflidx, *rota, *rotb, *meta;   // meta[2*m] = K, meta[2*m+1] = nrot
+    double *rotc, *rots;
+    double *Q2w, *Uw, *Ww; // n x n workspaces (diagonal blocks used)
+    const double *d0, *e;  // the input tridiagonal
+    int *Kdyn;             // K per merge of the current level (device ints for the dynamic-size GEMM)
+    const int *tbl;        // leaf_lo | bounds | per-level Seg triples
+};
+
+struct DcLevel {           // kernel argument of one level
+    DcWork w[MAX_BATCH];
+    int seg_off[MAX_BATCH];   // offset of this level's Seg triples inside tbl
+    int nseg[MAX_BATCH];      // 0: problem absent at this level
+    int aux[MAX_BATCH];       // leaves: number of leaves; tears: number of boundaries (offset in seg_off)
+};
+
+__device__ __forceinline__ Seg load_seg(const DcWork &w, int off, int m) {
+    const int *p = w.tbl + off + 3 * m;
+    return Seg{p[0], p[1], p[2]};
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// tears + leaves
+// ------------------------------------------------------------------------------------------------------------------
+__global__ void dc_tear_kernel(DcLevel L) {
+    const DcWork &w = L.w[blockIdx.y];
+    const int n = w.n, nb = L.aux[blockIdx.y];
+    const int *bounds = w.tbl + L.seg_off[blockIdx.y];
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double v = w.d0[i];
+    for (int t = 0; t < nb; ++t) {
+        const int a = bounds[t];
+        if (a - 1 == i || a == i) v -= fabs(w.e[a - 1]);
+    }
+    w.dwork[i] = v;
+}
+
+// one wave per leaf: dense leaf matrix in LDS -> Jacobi -> dcur[lo:hi], Qcur diagonal block
+__global__ __launch_bounds__(64) void dc_leaf_kernel(DcLevel L, int *status) {
+    const DcWork &w = L.w[blockIdx.y];
+    if ((int)blockIdx.x >= L.aux[blockIdx.y]) return;
+    const int n = w.n;
+    const int lo = w.tbl[blockIdx.x], hi = w.tbl[blockIdx.x + 1];
+    const int m = hi - lo;
+    constexpr int LD = DC_LEAF + 1;
+    __shared__ double A[DC_LEAF * LD], V[DC_LEAF * LD], cs[DC_LEAF + 2], red[64];
+    __shared__ int pq[2 * DC_LEAF + 2];
+    for (int idx = threadIdx.x; idx < m * m; idx += 64) {
+        const int i = idx / m, j = idx % m;
+        double v = 0.0;
+        if (i == j) v = w.dwork[lo + i];
+        else if (j == i + 1) v = w.e[lo + i];
+        else if (i == j + 1) v = w.e[lo + j];
+        A[i * LD + j] = v;
+    }
+    __syncthreads();
+    jacobi_body<64>(A, LD, V, LD, m, w.dcur + lo, w.Qcur + (long)lo * n + lo, (long)n, status, cs, pq, red);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// merge phases as device functions (called by the per-phase kernels and by the fused small-level kernel)
+// ------------------------------------------------------------------------------------------------------------------
+struct SetupShared {
+    double sd[EIG_MAXN], sz[EIG_MAXN];   // by local index
+    double ds[EIG_MAXN], zs[EIG_MAXN];   // in merged ascending order
+    double cd[EIG_MAXN], cz[EIG_MAXN];   // survivors of the negligible-weight test, merged order
+    int sperm[EIG_MAXN], cidx[EIG_MAXN];
+    unsigned char sdefl[EIG_MAXN];
+    double red[16];
+    int K, nrot, nsurv;
+};
+
+// z, merged order, deflation scan, compacted poles.  Whole workgroup (NW waves).
+template <int NW>
+__device__ void dc_setup_body(const DcWork &w, const Seg sg, const int m, SetupShared &S) {
+    constexpr int NT = 64 * NW;
+    const int lo = sg.lo, mid = sg.mid, hi = sg.hi, n = w.n;
+    const int N = hi - lo, n1 = mid - lo;
+    const int tid = threadIdx.x;
+    const double beta = w.e[mid - 1];
+    const double rho = 2.0 * fabs(beta);
+    const double sgn = beta >= 0.0 ? 1.0 : -1.0;
+    const double isq2 = 0.70710678118654752440;
+    double dmax = 0.0, zmax = 0.0;
+    for (int i = tid; i < N; i += NT) {
+        const double dv = w.dcur[lo + i];
+        const double zv = (i < n1 ? w.Qcur[(long)(mid - 1) * n + lo + i] : sgn * w.Qcur[(long)mid * n + lo + i]) * isq2;
+        S.sd[i] = dv;
+        S.sz[i] = zv;
+        S.sdefl[i] = 0;
+        dmax = fmax(dmax, fabs(dv));
+        zmax = fmax(zmax, fabs(zv));
+    }
+    dmax = block_max<NW>(dmax, S.red);
+    zmax = block_max<NW>(zmax, S.red);
+    const double tol = 8.0 * EPS_U * fmax(dmax, zmax);
+    // stable merge ranks of the two ascending halves
+    for (int i = tid; i < N; i += NT) {
+        const double v = S.sd[i];
+        int cnt;
+        if (i < n1) {                      // # of second-half entries strictly below v
+            int a = n1, bnd = N;
+            while (a < bnd) {
+                const int mdl = (a + bnd) >> 1;
+                if (S.sd[mdl] < v) a = mdl + 1; else bnd = mdl;
+            }
+            cnt = i + (a - n1);
+        } else {                           // # of first-half entries <= v
+            int a = 0, bnd = n1;
+            while (a < bnd) {
+                const int mdl = (a + bnd) >> 1;
+                if (S.sd[mdl] <= v) a = mdl + 1; else bnd = mdl;
+            }
+            cnt = (i - n1) + a;
+        }
+        S.sperm[cnt] = i;
+        S.ds[cnt] = v;
+        S.zs[cnt] = S.sz[i];
+    }
+    __syncthreads();
+    const bool all_defl = (rho * zmax <= tol);
+    // type-(a) deflation (negligible weight) is elementwise; survivors are compacted in merged order so the
+    // sequential part below only walks poles that can still pair up
+    for (int jj = tid; jj < N; jj += NT)
+        if (all_defl || rho * fabs(S.zs[jj]) <= tol) S.sdefl[S.sperm[jj]] = 1;
+    __syncthreads();
+    if (tid < 64) {                      // wave 0: stable compaction of the survivors by ballot prefix
+        int base = 0;
+        for (int j0 = 0; j0 < N; j0 += 64) {
+            const int jj = j0 + tid;
+            const bool keep = (jj < N) && !S.sdefl[S.sperm[jj]];
+            const unsigned long long mask = __ballot(keep);
+            if (keep) {
+                const int pos = base + __popcll(mask & ((1ull << tid) - 1ull));
+                S.cidx[pos] = S.sperm[jj];
+                S.cd[pos] = S.ds[jj];
+                S.cz[pos] = S.zs[jj];
+            }
+            base += __popcll(mask);
+        }
+        if (tid == 0) S.nsurv = base;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        // sequential dlaed2 close-pair scan over the survivors; the pending pole lives in registers and the next
+        // survivor is loaded one iteration ahead so LDS latency overlaps the arithmetic
+        const int ns = S.nsurv;
+        int K = 0, nrot = 0;
+        if (ns > 0) {
+            int pj = S.cidx[0];
+            double dpj = S.cd[0], zpj = S.cz[0];
+            int nidx = ns > 1 ? S.cidx[1] : 0;
+            double nd = ns > 1 ? S.cd[1] : 0.0, nz = ns > 1 ? S.cz[1] : 0.0;
+            for (int p = 1; p < ns; ++p) {
+                const int idx = nidx;
+                double dn = nd, zn = nz;
+                if (p + 1 < ns) {
+                    nidx = S.cidx[p + 1];
+                    nd = S.cd[p + 1];
+                    nz = S.cz[p + 1];
+                }
+                const double t = dn - dpj;
+                bool merged = false;
+                // |t c s| <= tol  <=>  |t| |zp zn| <= tol (zp^2 + zn^2): sqrt- and division-free reject
+                if (fabs(t) * fabs(zpj * zn) <= tol * (zpj * zpj + zn * zn) * (1.0 + 1e-10)) {
+                    const double tau = hypot(zn, zpj);
+                    const double c_ = zn / tau, s_ = -zpj / tau;
+                    if (fabs(t * c_ * s_) <= tol) {
+                        w.rota[lo + nrot] = pj;
+                        w.rotb[lo + nrot] = idx;
+                        w.rotc[lo + nrot] = c_;
+                        w.rots[lo + nrot] = s_;
+                        ++nrot;
+                        S.sd[pj] = dpj * c_ * c_ + dn * s_ * s_;
+                        S.sdefl[pj] = 1;
+                        dn = dpj * s_ * s_ + dn * c_ * c_;
+                        zn = tau;
+                        merged = true;
+                    }
+                }
+                if (!merged) {
+                    w.ndidx[lo + K] = pj;
+                    w.dk[lo + K] = dpj;
+                    w.zk[lo + K] = zpj;
+                    ++K;
+                }
+                pj = idx; dpj = dn; zpj = zn;
+            }
+            w.ndidx[lo + K] = pj;
+            w.dk[lo + K] = dpj;
+            w.zk[lo + K] = zpj;
+            ++K;
+        }
+        S.K = K;
+        S.nrot = nrot;
+        w.meta[2 * m] = K;
+        w.meta[2 * m + 1] = nrot;
+        w.Kdyn[m] = K;
+    }
+    __syncthreads();
+    if (tid < 64) {                      // deflated local indices in index order (final positions come from the rank sort)
+        int base = 0;
+        for (int i0 = 0; i0 < N; i0 += 64) {
+            const int i = i0 + tid;
+            const bool df = (i < N) && S.sdefl[i];
+            const unsigned long long mask = __ballot(df);
+            if (df) w.deflidx[lo + base + __popcll(mask & ((1ull << tid) - 1ull))] = i;
+            base += __popcll(mask);
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < N; i += NT) w.dwork[lo + i] = S.sd[i];
+}
+
+// Apply the recorded Givens chain to row r of the merge block (in place).  One thread per row; the chained column
+// stays in a register, the partner column of the next rotation is independent of the chain.
+__device__ __forceinline__ void dc_rotate_row(const DcWork &w, const int lo, const int nrot, double *q) {
+    if (nrot <= 0) return;
+    int a = w.rota[lo];
+    double carry = q[a];
+    for (int t = 0; t < nrot; ++t) {
+        const int bb = w.rotb[lo + t];
+        const double c_ = w.rotc[lo + t], s_ = w.rots[lo + t];
+        const double qb = q[bb];
+        q[a] = c_ * carry + s_ * qb;
+        carry = -s_ * carry + c_ * qb;
+        if (t + 1 < nrot) {
+            const int an = w.rota[lo + t + 1];
+            if (an != bb) {
+                q[bb] = carry;
+                carry = q[an];
+            }
+            a = an;
+        } else {
+            q[bb] = carry;
+        }
+    }
+}
+
+// rows [r0, r1) of the merge block: rotations (one thread per row) then compaction of the non-deflated columns into
+// Q2w[:, lo : lo+K), coalesced along the column index.  Whole workgroup.
+template <int NT>
+__device__ void dc_rotate_compact_body(const DcWork &w, const Seg sg, const int K, const int nrot, const int r0, const int r1) {
+    const int lo = sg.lo, n = w.n;
+    if (nrot > 0) {
+        const int r = r0 + (int)threadIdx.x;
+        if (r < r1) dc_rotate_row(w, lo, nrot, w.Qcur + (long)r * n + lo);
+        __syncthreads();
+    }
+    const int rows = r1 - r0;
+    for (int idx = threadIdx.x; idx < rows * K; idx += NT) {
+        const int r = r0 + idx / K, t = idx % K;
+        w.Q2w[(long)r * n + lo + t] = w.Qcur[(long)r * n + lo + w.ndidx[lo + t]];
+    }
+}
+
+// One wave: root i of 1 + rho sum_j zk_j^2 / (dk_j - lam) = 0, i in [0, K).  Writes org / mu / lam.
+__device__ void dc_secular_root(const DcWork &w, const int lo, const int K, const double rho, const int i) {
+    const int lane = threadIdx.x & 63;
+    const double *__restrict__ dk = w.dk + lo;
+    const double *__restrict__ zk = w.zk + lo;
+    if (K == 1) {
+        if (lane == 0) {
+            const double m = rho * zk[0] * zk[0];
+            w.org[lo] = 0;
+            w.mu[lo] = m;
+            w.lam[lo] = dk[0] + m;
+        }
+        return;
+    }
+    const bool last = (i == K - 1);
+    int org;
+    double lo_b, hi_b;
+    if (last) {
+        org = K - 1;
+        double s = 0.0;
+        for (int j = lane; j < K; j += 64) s += zk[j] * zk[j];
+        s = wave_sum(s);
+        lo_b = 0.0;
+        hi_b = rho * s;
+    } else {
+        const double di = dk[i];
+        const double half = 0.5 * (dk[i + 1] - di);
+        double s = 0.0;
+        for (int j = lane; j < K; j += 64) s += zk[j] * zk[j] / ((dk[j] - di) - half);
+        const double fmid = 1.0 + rho * wave_sum(s);
+        if (fmid >= 0.0) {
+            org = i;
+            lo_b = 0.0;
+            hi_b = half;
+        } else {
+            org = i + 1;
+            lo_b = -half;
+            hi_b = 0.0;
+        }
+    }
+    const double dorg = dk[org];
+    const double pl = dk[i] - dorg;
+    const double pr = last ? 0.0 : dk[i + 1] - dorg;
+    double mu = last ? 0.5 * hi_b : 0.5 * (lo_b + hi_b);
+    for (int it = 0; it < 100; ++it) {
+        double psi = 0.0, dpsi = 0.0, phi = 0.0, dphi = 0.0;
+        for (int j = lane; j < K; j += 64) {
+            const double rinv = 1.0 / ((dk[j] - dorg) - mu);
+            const double term = zk[j] * zk[j] * rinv;
+            if (j <= i) {
+                psi += term;
+                dpsi += term * rinv;
+            } else {
+                phi += term;
+                dphi += term * rinv;
+            }
+        }
+        psi = rho * wave_sum(psi);
+        dpsi = rho * wave_sum(dpsi);
+        phi = rho * wave_sum(phi);
+        dphi = rho * wave_sum(dphi);
+        const double f = 1.0 + psi + phi;
+        const double err = 8.0 * EPS_U * (1.0 + fabs(psi) + fabs(phi)) + fabs(mu) * EPS_U * (dpsi + dphi);
+        if (fabs(f) <= err) break;
+        if (f < 0.0) lo_b = fmax(lo_b, mu);
+        else hi_b = fmin(hi_b, mu);
+        if (hi_b - lo_b <= 2.0 * EPS_U * fmax(fabs(lo_b), fabs(hi_b))) break;
+        const double D1 = pl - mu;
+        double eta = INFINITY;
+        if (last) {
+            const double g = 1.0 + psi - dpsi * D1;
+            if (g > 0.0) eta = D1 + dpsi * D1 * D1 / g;
+        } else {
+            const double D2 = pr - mu;
+            const double A = f - dpsi * D1 - dphi * D2;
+            const double B = A * (D1 + D2) + dpsi * D1 * D1 + dphi * D2 * D2;
+            const double C = D1 * D2 * f;
+            double disc = B * B - 4.0 * A * C;
+            if (disc < 0.0) disc = 0.0;
+            const double sq = sqrt(disc);
+            if (A == 0.0) {
+                if (B != 0.0) eta = C / B;
+            } else {
+                double r1, r2;
+                if (B >= 0.0) {
+                    r2 = (B + sq) / (2.0 * A);
+                    r1 = (B + sq) != 0.0 ? (2.0 * C) / (B + sq) : (B - sq) / (2.0 * A);
+                } else {
+                    r1 = (B - sq) / (2.0 * A);
+                    r2 = (B - sq) != 0.0 ? (2.0 * C) / (B - sq) : (B + sq) / (2.0 * A);
+                }
+                const bool ok1 = isfinite(r1) && r1 > D1 && r1 < D2;
+                const bool ok2 = isfinite(r2) && r2 > D1 && r2 < D2;
+                if (ok1 && ok2) eta = fabs(r1) <= fabs(r2) ? r1 : r2;
+                else if (ok1) eta = r1;
+                else if (ok2) eta = r2;
+            }
+        }
+        double nw = mu + eta;
+        if (!isfinite(nw) || nw <= lo_b || nw >= hi_b) {
+            if (lo_b > 0.0 && hi_b / lo_b > 16.0) nw = sqrt(lo_b * hi_b);
+            else if (hi_b < 0.0 && lo_b / hi_b > 16.0) nw = -sqrt(lo_b * hi_b);
+            else {
+                nw = 0.5 * (lo_b + hi_b);
+                if (nw == lo_b || nw == hi_b) break;
+            }
+        }
+        mu = nw;
+    }
+    if (lane == 0) {
+        w.org[lo + i] = org;
+        w.mu[lo + i] = mu;
+        w.lam[lo + i] = dorg + mu;
+    }
+}
+
+// One wave: zhat_i = sign(z_i) sqrt( prod_j (lam_j - d_i) / (rho prod_{j != i} (d_j - d_i)) )
+__device__ __forceinline__ void dc_zhat_one(const DcWork &w, const int lo, const int K, const double rho, const int i) {
+    const int lane = threadIdx.x & 63;
+    const double *__restrict__ dk = w.dk + lo;
+    const double di = dk[i];
+    double p = 1.0;
+    for (int j = lane; j < K; j += 64) {
+        const double num = (dk[w.org[lo + j]] - di) + w.mu[lo + j];       // lam_j - d_i
+        const double den = (j == i) ? 1.0 : dk[j] - di;
+        p *= num / den;
+    }
+    p = wave_prod(p);
+    if (lane == 0) {
+        const double zh = sqrt(fabs(p / rho));
+        w.zhat[lo + i] = (w.zk[lo + i] >= 0.0) ? zh : -zh;
+    }
+}
+
+// One wave: 1 / || zhat_i / (d_i - lam_j) ||_2 for root j
+__device__ __forceinline__ void dc_colnorm_one(const DcWork &w, const int lo, const int K, const int j) {
+    const int lane = threadIdx.x & 63;
+    const double *__restrict__ dk = w.dk + lo;
+    const double dorg = dk[w.org[lo + j]], muj = w.mu[lo + j];
+    double s = 0.0;
+    for (int i = lane; i < K; i += 64) {
+        const double u = w.zhat[lo + i] / ((dk[i] - dorg) - muj);
+        s += u * u;
+    }
+    s = wave_sum(s);
+    if (lane == 0) w.invn[lo + j] = 1.0 / sqrt(s);
+}
+
+__device__ __forceinline__ double dc_u_elem(const DcWork &w, const int lo, const int i, const int j) {
+    const double *__restrict__ dk = w.dk + lo;
+    return w.zhat[lo + i] / ((dk[i] - dk[w.org[lo + j]]) - w.mu[lo + j]) * w.invn[lo + j];
+}
+
+// rank-sort {roots} U {deflated poles}: dnext ascending; rank / source tables into rota / rotb.  Whole workgroup.
+template <int NT>
+__device__ void dc_rank_body(const DcWork &w, const Seg sg, const int K, double *val, int *src) {
+    const int lo = sg.lo, N = sg.hi - sg.lo;
+    const int tid = threadIdx.x;
+    for (int t = tid; t < N; t += NT) {
+        if (t < K) {
+            val[t] = w.lam[lo + t];
+            src[t] = -1 - t;                         // column t of Ww
+        } else {
+            const int idx = w.deflidx[lo + (t - K)];
+            val[t] = w.dwork[lo + idx];
+            src[t] = idx;                            // column idx of Qcur
+        }
+    }
+    __syncthreads();
+    for (int t = tid; t < N; t += NT) {
+        const double v = val[t];
+        int rk = 0;
+        for (int u = 0; u < N; ++u) {
+            const double x = val[u];
+            rk += (x < v) || (x == v && u < t);
+        }
+        w.dnext[lo + rk] = v;
+        w.rota[lo + t] = rk;                         // the rotation list has been consumed: reuse as tables
+        w.rotb[lo + t] = src[t];
+    }
+}
+
+// rows [r0, r1): Qnext[:, rank[t]] = root ? Ww[:, t] : Qcur[:, deflated idx]
+template <int NT>
+__device__ void dc_place_body(const DcWork &w, const Seg sg, const int r0, const int r1) {
+    const int lo = sg.lo, n = w.n, N = sg.hi - sg.lo;
+    const int rows = r1 - r0;
+    for (int idx = threadIdx.x; idx < rows * N; idx += NT) {
+        const int r = r0 + idx / N, t = idx % N;
+        const int sc = w.rotb[lo + t];
+        const double v = (sc < 0) ? w.Ww[(long)r * n + lo + (-1 - sc)] : w.Qcur[(long)r * n + lo + sc];
+        w.Qnext[(long)r * n + lo + w.rota[lo + t]] = v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// per-phase kernels for the large levels (grid: x = work tiles, y = merge, z = problem)
+// ------------------------------------------------------------------------------------------------------------------
+#define DC_PROLOGUE                                                \
+    const DcWork &w = L.w[blockIdx.z];                             \
+    const int m = blockIdx.y;                                      \
+    if (m >= L.nseg[blockIdx.z]) return;                           \
+    const Seg sg = load_seg(w, L.seg_off[blockIdx.z], m);
+
+__global__ __launch_bounds__(256) void dc_setup_kernel(DcLevel L) {
+    DC_PROLOGUE
+    __shared__ SetupShared S;
+    dc_setup_body<4>(w, sg, m, S);
+}
+
+constexpr int ROT_ROWS = 32;
+__global__ __launch_bounds__(256) void dc_rotate_compact_kernel(DcLevel L) {
+    DC_PROLOGUE
+    const int r0 = sg.lo + blockIdx.x * ROT_ROWS;
+    if (r0 >= sg.hi) return;
+    dc_rotate_compact_body<256>(w, sg, w.meta[2 * m], w.meta[2 * m + 1], r0, min(r0 + ROT_ROWS, sg.hi));
+}
+
+__global__ __launch_bounds__(256) void dc_secular_kernel(DcLevel L) {
+    DC_PROLOGUE
+    const int K = w.meta[2 * m];
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= K) return;
+    dc_secular_root(w, sg.lo, K, 2.0 * fabs(w.e[sg.mid - 1]), i);
+}
+
+__global__ __launch_bounds__(256) void dc_zhat_kernel(DcLevel L) {
+    DC_PROLOGUE
+    const int K = w.meta[2 * m];
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= K) return;
+    dc_zhat_one(w, sg.lo, K, 2.0 * fabs(w.e[sg.mid - 1]), i);
+}
+
+__global__ __launch_bounds__(256) void dc_colnorm_kernel(DcLevel L) {
+    DC_PROLOGUE
+    const int K = w.meta[2 * m];
+    const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (j >= K) return;
+    dc_colnorm_one(w, sg.lo, K, j);
+}
+
+// U into the diagonal block of Uw, 64 columns x 16 rows per workgroup (coalesced along j); blockIdx.x packs both tiles
+__global__ __launch_bounds__(256) void dc_build_U_kernel(DcLevel L, int tiles_j) {
+    DC_PROLOGUE
+    const int lo = sg.lo, n = w.n;
+    const int K = w.meta[2 * m];
+    const int j = (blockIdx.x % tiles_j) * 64 + (threadIdx.x & 63);
+    const int i0 = (blockIdx.x / tiles_j) * 16 + (threadIdx.x >> 6) * 4;
+    if (j >= K) return;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int i = i0 + q;
+        if (i < K) w.Uw[(long)(lo + i) * n + lo + j] = dc_u_elem(w, lo, i, j);
+    }
+}
+
+__global__ __launch_bounds__(256) void dc_rank_kernel(DcLevel L) {
+    DC_PROLOGUE
+    __shared__ double val[EIG_MAXN];
+    __shared__ int src[EIG_MAXN];
+    dc_rank_body<256>(w, sg, w.meta[2 * m], val, src);
+}
+
+__global__ __launch_bounds__(256) void dc_place_kernel(DcLevel L) {
+    DC_PROLOGUE
+    const int r0 = sg.lo + blockIdx.x * 4;
+    if (r0 >= sg.hi) return;
+    dc_place_body<256>(w, sg, r0, min(r0 + 4, sg.hi));
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// fused level kernel for small merges (N <= DC_SMALL): one workgroup walks every phase of its merge
+// ------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(NT_SMALL) void dc_small_level_kernel(DcLevel L) {
+    const DcWork &w = L.w[blockIdx.z];
+    const int m = blockIdx.x;
+    if (m >= L.nseg[blockIdx.z]) return;
+    const Seg sg = load_seg(w, L.seg_off[blockIdx.z], m);
+    constexpr int NW = NT_SMALL / 64;
+    __shared__ SetupShared S;
+    const int lo = sg.lo, hi = sg.hi, n = w.n, N = hi - lo;
+    const int tid = threadIdx.x, wid = tid >> 6;
+    dc_setup_body<NW>(w, sg, m, S);
+    __syncthreads();
+    const int K = S.K, nrot = S.nrot;
+    dc_rotate_compact_body<NT_SMALL>(w, sg, K, nrot, lo, hi);
+    const double rho = 2.0 * fabs(w.e[sg.mid - 1]);
+    __syncthreads();
+    for (int i = wid; i < K; i += NW) dc_secular_root(w, lo, K, rho, i);
+    __syncthreads();
+    for (int i = wid; i < K; i += NW) dc_zhat_one(w, lo, K, rho, i);
+    __syncthreads();
+    for (int j = wid; j < K; j += NW) dc_colnorm_one(w, lo, K, j);
+    __syncthreads();
+    // U (K x K) into LDS (reusing the setup arrays: 2 * EIG_MAXN doubles >= 64 * 64 / 2 ... use sd|sz|ds|zs = 4096 doubles)
+    double *U = S.sd;                                     // sd, sz, ds, zs are contiguous: 4 * EIG_MAXN doubles
+    for (int idx = tid; idx < K * K; idx += NT_SMALL) {
+        const int i = idx / K, j = idx % K;
+        U[i * DC_SMALL + j] = dc_u_elem(w, lo, i, j);
+    }
+    __syncthreads();
+    // W = Q2 U  (N x K): Q2 staged in LDS (row stride DC_SMALL+1 keeps the j-walk conflict free), U in LDS
+    __shared__ double Q2s[DC_SMALL * (DC_SMALL + 1)];
+    for (int idx = tid; idx < N * K; idx += NT_SMALL) {
+        const int r = idx / K, j = idx % K;
+        Q2s[r * (DC_SMALL + 1) + j] = w.Q2w[(long)(lo + r) * n + lo + j];
+    }
+    __syncthreads();
+    for (int idx = tid; idx < N * K; idx += NT_SMALL) {
+        const int r = idx / K, t = idx % K;
+        const double *q2 = Q2s + r * (DC_SMALL + 1);
+        double acc = 0.0;
+        for (int j = 0; j < K; ++j) acc += q2[j] * U[j * DC_SMALL + t];
+        w.Ww[(long)(lo + r) * n + lo + t] = acc;
+    }
+    __syncthreads();
+    double *val = S.sd;
+    int *src = S.sperm;
+    dc_rank_body<NT_SMALL>(w, sg, K, val, src);
+    __syncthreads();
+    dc_place_body<NT_SMALL>(w, sg, lo, hi);
+}
+static_assert(4 * EIG_MAXN >= DC_SMALL * DC_SMALL, "U tile must fit the reused setup arrays");
+
+__global__ void copy_vec_kernel(const double *__restrict__ a, double *__restrict__ b, long n) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) b[i] = a[i];
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// host side: plan (depends only on n), workspace, level loop
+// ------------------------------------------------------------------------------------------------------------------
+struct DcPlan {
+    int n = 0;
+    std::vector<int> leaf_lo;                 // leaves + 1 entries
+    std::vector<int> bounds;                  // interior leaf boundaries (tears)
+    std::vector<std::vector<Seg>> levels;     // bottom-up
+    std::vector<int> tbl;                     // leaf_lo | bounds | level triples
+    int off_bounds = 0;
+    std::vector<int> lvl_off;
+};
+
+static DcPlan make_plan(int n) {
+    DcPlan p;
+    p.n = n;
+    std::vector<std::pair<int, int>> segs = {{0, n}};
+    std::vector<std::vector<Seg>> rev;
+    for (;;) {
+        int mx = 0;
+        for (auto &sg : segs) mx = std::max(mx, sg.second - sg.first);
+        if (mx <= DC_LEAF) break;
+        std::vector<std::pair<int, int>> nxt;
+        std::vector<Seg> lvl;
+        for (auto &sg : segs) {
+            const int m = (sg.first + sg.second) / 2;
+            nxt.push_back({sg.first, m});
+            nxt.push_back({m, sg.second});
+            lvl.push_back(Seg{sg.first, m, sg.second});
+        }
+        rev.push_back(lvl);
+        segs = nxt;
+    }
+    for (auto &sg : segs) p.leaf_lo.push_back(sg.first);
+    p.leaf_lo.push_back(n);
+    for (size_t i = 1; i + 1 < p.leaf_lo.size(); ++i) p.bounds.push_back(p.leaf_lo[i]);
+    p.levels.assign(rev.rbegin(), rev.rend());
+    p.tbl.insert(p.tbl.end(), p.leaf_lo.begin(), p.leaf_lo.end());
+    p.off_bounds = (int)p.tbl.size();
+    p.tbl.insert(p.tbl.end(), p.bounds.begin(), p.bounds.end());
+    for (auto &lv : p.levels) {
+        p.lvl_off.push_back((int)p.tbl.size());
+        for (auto &sg : lv) {
+            p.tbl.push_back(sg.lo);
+            p.tbl.push_back(sg.mid);
+            p.tbl.push_back(sg.hi);
+        }
+    }
+    return p;
+}
+
+struct StedcProb {
+    const double *d, *e;
+    int n;
+    double *w, *Z;
+    std::string tag;
+};
+
+static DcWork make_work(gpcsd_ctx *c, const StedcProb &p, const DcPlan &plan, hipStream_t s) {
+    const int n = p.n;
+    const size_t nn = (size_t)n * n;
+    const std::string T = "dc_" + p.tag + "_";
+    DcWork w;
+    w.n = n;
+    w.d0 = p.d;
+    w.e = p.e;
+    w.dcur = c->buf<double>(T + "dcur", n);
+    w.dnext = c->buf<double>(T + "dnext", n);
+    w.Qcur = c->buf<double>(T + "Qcur", nn);
+    w.Qnext = c->buf<double>(T + "Qnext", nn);
+    w.dwork = c->buf<double>(T + "dwork", n);
+    w.dk = c->buf<double>(T + "dk", n);
+    w.zk = c->buf<double>(T + "zk", n);
+    w.mu = c->buf<double>(T + "mu", n);
+    w.lam = c->buf<double>(T + "lam", n);
+    w.zhat = c->buf<double>(T + "zhat", n);
+    w.invn = c->buf<double>(T + "invn", n);
+    w.org = c->buf<int>(T + "org", n);
+    w.ndidx = c->buf<int>(T + "ndidx", n);
+    w.deflidx = c->buf<int>(T + "deflidx", n);
+    w.rota = c->buf<int>(T + "rota", n);
+    w.rotb = c->buf<int>(T + "rotb", n);
+    w.rotc = c->buf<double>(T + "rotc", n);
+    w.rots = c->buf<double>(T + "rots", n);
+    w.meta = c->buf<int>(T + "meta", 2 * n + 2);
+    w.Kdyn = c->buf<int>(T + "Kdyn", n + 2);
+    w.Q2w = c->buf<double>(T + "Q2w", nn);
+    w.Uw = c->buf<double>(T + "Uw", nn);
+    w.Ww = c->buf<double>(T + "Ww", nn);
+    int *dtbl = c->buf<int>(T + "plan", plan.tbl.size() + 4);
+    int &cached_n = c->int_cache[T + "plan_n"];
+    if (cached_n != n) {                  // the table depends only on n: upload once per (tag, n)
+        GP_HIP(hipMemcpyAsync(dtbl, plan.tbl.data(), plan.tbl.size() * sizeof(int), hipMemcpyHostToDevice, s));
+        GP_HIP(hipStreamSynchronize(s));  // plan is a temporary of the caller
+        cached_n = n;
+    }
+    w.tbl = dtbl;
+    // both ping-pong matrices start at zero: a merge reads the off-diagonal blocks between its two halves, which no
+    // earlier level writes (blocks are nested, so zeros outside the blocks of a level survive until they are merged)
+    GP_HIP(hipMemsetAsync(w.Qcur, 0, nn * sizeof(double), s));
+    GP_HIP(hipMemsetAsync(w.Qnext, 0, nn * sizeof(double), s));
+    return w;
+}
+
+void stedc_batch_device(gpcsd_ctx *c, StedcProb *probs, int count, int *d_status, hipStream_t s) {
+    GP_REQUIRE(count >= 1 && count <= MAX_BATCH, -3, "stedc batch size %d outside [1,%d]", count, MAX_BATCH);
+    std::vector<DcPlan> plans;
+    DcLevel L{};
+    size_t nlevels = 0;
+    int nmax = 0, max_leaves = 0;
+    for (int p = 0; p < count; ++p) {
+        GP_REQUIRE(probs[p].n >= 1 && probs[p].n <= EIG_MAXN, -3, "stedc: n=%d outside [1,%d]", probs[p].n, EIG_MAXN);
+        plans.push_back(make_plan(probs[p].n));
+        L.w[p] = make_work(c, probs[p], plans[p], s);
+        nlevels = std::max(nlevels, plans[p].levels.size());
+        nmax = std::max(nmax, probs[p].n);
+        max_leaves = std::max(max_leaves, (int)plans[p].leaf_lo.size() - 1);
+    }
+    // tears + leaves
+    for (int p = 0; p < count; ++p) {
+        L.seg_off[p] = plans[p].off_bounds;
+        L.aux[p] = (int)plans[p].bounds.size();
+    }
+    hipLaunchKernelGGL(dc_tear_kernel, dim3(ceil_div(nmax, 256), count), dim3(256), 0, s, L);
+    for (int p = 0; p < count; ++p) L.aux[p] = (int)plans[p].leaf_lo.size() - 1;
+    hipLaunchKernelGGL(dc_leaf_kernel, dim3(max_leaves, count), dim3(64), 0, s, L, d_status);
+    GP_HIP(hipGetLastError());
+
+    // Problems with fewer levels idle at the bottom: level index counts from the TOP so the final merges align.
+    for (size_t li = 0; li < nlevels; ++li) {
+        int maxN = 0, max_seg = 0;
+        for (int p = 0; p < count; ++p) {
+            const long own = (long)plans[p].levels.size() - (long)(nlevels - li);   // this problem's level index, or < 0
+            if (own < 0) {
+                L.nseg[p] = 0;
+                L.seg_off[p] = 0;
+                continue;
+            }
+            const auto &lv = plans[p].levels[own];
+            L.nseg[p] = (int)lv.size();
+            L.seg_off[p] = plans[p].lvl_off[own];
+            max_seg = std::max(max_seg, (int)lv.size());
+            for (auto &sg : lv) maxN = std::max(maxN, sg.hi - sg.lo);
+        }
+        if (maxN <= DC_SMALL) {
+            hipLaunchKernelGGL(dc_small_level_kernel, dim3(max_seg, 1, count), dim3(NT_SMALL), 0, s, L);
+        } else {
+            hipLaunchKernelGGL(dc_setup_kernel, dim3(1, max_seg, count), dim3(256), 0, s, L);
+            hipLaunchKernelGGL(dc_rotate_compact_kernel, dim3(ceil_div(maxN, ROT_ROWS), max_seg, count), dim3(256), 0, s, L);
+            hipLaunchKernelGGL(dc_secular_kernel, dim3(ceil_div(maxN, 4), max_seg, count), dim3(256), 0, s, L);
+            hipLaunchKernelGGL(dc_zhat_kernel, dim3(ceil_div(maxN, 4), max_seg, count), dim3(256), 0, s, L);
+            hipLaunchKernelGGL(dc_colnorm_kernel, dim3(ceil_div(maxN, 4), max_seg, count), dim3(256), 0, s, L);
+            const int tj = ceil_div(maxN, 64);
+            hipLaunchKernelGGL(dc_build_U_kernel, dim3(tj * ceil_div(maxN, 16), max_seg, count), dim3(256), 0, s, L, tj);
+            GP_HIP(hipGetLastError());
+            for (int p = 0; p < count; ++p) {                 // W = Q2 (N x K) U (K x K), K read on the device
+                const long own = (long)plans[p].levels.size() - (long)(nlevels - li);
+                if (own < 0) continue;
+                const auto &lv = plans[p].levels[own];
+                const DcWork &w = L.w[p];
+                const int n = w.n;
+                for (int m = 0; m < (int)lv.size(); ++m) {
+                    const Seg &sg = lv[m];
+                    const int N = sg.hi - sg.lo;
+                    GemmDesc g;
+                    g.M = N; g.N = N; g.K = N;
+                    g.A = w.Q2w + (long)sg.lo * n + sg.lo; g.lda = n;
+                    g.B = w.Uw + (long)sg.lo * n + sg.lo; g.ldb = n;
+                    g.C = w.Ww + (long)sg.lo * n + sg.lo; g.ldc = n;
+                    g.dyn = w.Kdyn + m;
+                    g.prof_name = "gemm_dc_merge";
+                    gemm_f64(c, g, s);
+                }
+            }
+            hipLaunchKernelGGL(dc_rank_kernel, dim3(1, max_seg, count), dim3(256), 0, s, L);
+            hipLaunchKernelGGL(dc_place_kernel, dim3(ceil_div(maxN, 4), max_seg, count), dim3(256), 0, s, L);
+        }
+        GP_HIP(hipGetLastError());
+        for (int p = 0; p < count; ++p) {
+            if (L.nseg[p] == 0) continue;
+            std::swap(L.w[p].dcur, L.w[p].dnext);
+            std::swap(L.w[p].Qcur, L.w[p].Qnext);
+        }
+    }
+    for (int p = 0; p < count; ++p) {
+        const size_t nn = (size_t)probs[p].n * probs[p].n;
+        hipLaunchKernelGGL(copy_vec_kernel, dim3(1), dim3(256), 0, s, (const double *)L.w[p].dcur, probs[p].w, (long)probs[p].n);
+        hipLaunchKernelGGL(copy_vec_kernel, dim3(256), dim3(256), 0, s, (const double *)L.w[p].Qcur, probs[p].Z, (long)nn);
+    }
+    GP_HIP(hipGetLastError());
+}
+
+void stedc_device(gpcsd_ctx *c, const double *d, const double *e, int n, double *wout, double *Zout, int *d_status,
+                  hipStream_t s, const char *tag) {
+    StedcProb p;
+    p.d = d; p.e = e; p.n = n; p.w = wout; p.Z = Zout; p.tag = tag ? tag : "";
+    stedc_batch_device(c, &p, 1, d_status, s);
+}
+
+}  // namespace gpcsd
