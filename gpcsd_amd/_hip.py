@@ -67,7 +67,7 @@ SIGNATURES = {
     "gpcsd_loglik_dense_chol": (_I, [_P, _DP, _I, _DP, _I, _D, _DP, _I, _DP]),
     "gpcsd_loglik": (_I, [_P, ctypes.POINTER(HParams), _DP]),
     "gpcsd_loglik_parts": (_I, [_P, ctypes.POINTER(HParams), _DP]),
-    "gpcsd_loglik_grad_parts": (_I, [_P, ctypes.POINTER(HParams), _DP, _DP, _DP, _I]),
+    "gpcsd_loglik_grad": (_I, [_P, ctypes.POINTER(HParams), _DP, _DP, _I]),
     "gpcsd_predict": (_I, [_P, ctypes.POINTER(HParams), _DP, _I, _DP, _I, _I, _DP, _DP, _DP, _DP]),
     "gpcsd_predict_resident": (_I, [_P, ctypes.POINTER(HParams), _DP, _I, _DP, _I, _I, _I]),
     "gpcsd_fetch": (_I, [_P, ctypes.c_char_p, _DP, _L]),
@@ -347,11 +347,12 @@ class Context:
         self._check(self._lib.gpcsd_loglik_parts(self._h, ctypes.byref(hp), _ptr(out)))
         return float(out[0]), float(out[1])
 
-    def loglik_grad_parts(self, hp, ngrad):
+    def loglik_grad(self, hp, ngrad):
+        """(sum log D, local quad, d L_loc / d natural params) with L_loc = -0.5*R_resident*sumlog - 0.5*quad."""
         out = np.empty(2)
-        gl, gq = np.empty(ngrad), np.empty(ngrad)
-        self._check(self._lib.gpcsd_loglik_grad_parts(self._h, ctypes.byref(hp), _ptr(out), _ptr(gl), _ptr(gq), int(ngrad)))
-        return float(out[0]), float(out[1]), gl, gq
+        g = np.empty(ngrad)
+        self._check(self._lib.gpcsd_loglik_grad(self._h, ctypes.byref(hp), _ptr(out), _ptr(g), int(ngrad)))
+        return float(out[0]), float(out[1]), g
 
     def predict(self, hp, z, tstar, type_code, shape, want_lists=True):
         """shape = (nz, ntstar, ntrials).  Returns dict of arrays for the requested type."""

@@ -862,10 +862,117 @@ extern "C" int gpcsd_sample_prior(gpcsd_ctx *c, const gpcsd_hparams *hp, int whi
     GP_API_END(c)
 }
 
-extern "C" int gpcsd_loglik_grad_parts(gpcsd_ctx *c, const gpcsd_hparams *hp, double *out2, double *grad_logdet,
-                                       double *grad_quad, int ngrad) {
-    (void)hp; (void)out2; (void)grad_logdet; (void)grad_quad; (void)ngrad;
-    return fail(c, HipError{-38, "gpcsd_loglik_grad_parts: not implemented in this build"});
+extern "C" int gpcsd_loglik_grad(gpcsd_ctx *c, const gpcsd_hparams *hp, double *out2, double *grad, int ngrad) {
+    GP_API_BEGIN(c)
+    GP_REQUIRE(out2 && grad && hp, -3, "loglik_grad: null argument");
+    GP_REQUIRE(hp->n_sig2n == 1, -3, "loglik_grad: the analytic gradient needs a scalar sig2n (per-electrode lists: use finite differences)");
+    EigState e = front_half(c, hp, hp->jitter);        // leaves A, Kgl, T = A Kgl in the ks_* buffers
+    const Geo g = resident_geo(c);
+    const int nx = c->nx, nt = c->nt, R = c->ntrials, C = hp->n_temporal, G = g.G();
+    GP_REQUIRE(ngrad == 1 + g.dim + 2 * C + 1, -3, "loglik_grad: ngrad=%d, expected %d", ngrad, 1 + g.dim + 2 * C + 1);
+    const long RT = (long)R * nt;
+    hipStream_t s = c->stream;
+    const double *A = (const double *)c->bufs["ks_A"].p, *Kgl = (const double *)c->bufs["ks_Kgl"].p,
+                 *T = (const double *)c->bufs["ks_T"].p;
+    double *W = c->buf<double>("proj_W", (size_t)nx * RT);
+    double *Bm = c->buf<double>("pred_B", (size_t)nx * RT);
+    double *Bet = c->buf<double>("grad_Bet", (size_t)nx * RT);
+    double *Bes = c->buf<double>("grad_Bes", (size_t)nx * RT);
+    double *gdev = c->buf<double>("grad_out", 64);
+    GemmDesc g1;                          // W = Qs^T Y
+    g1.M = nx; g1.N = (int)RT; g1.K = nx;
+    g1.A = e.Qs; g1.lda = nx; g1.transA = true; g1.B = c->d_lfp; g1.ldb = RT; g1.C = W; g1.ldc = RT;
+    g1.prof_name = "gemm_proj_spatial";
+    gemm_f64(c, g1, s);
+    GemmDesc g2;                          // alpha = W Qt;  B = alpha / D, B*et, B*es;  sum alpha*B, sum B^2
+    g2.M = nx * R; g2.N = nt; g2.K = nt;
+    g2.A = W; g2.lda = nt; g2.B = e.Qt; g2.ldb = nt; g2.C = Bm; g2.ldc = nt; g2.C2 = Bet; g2.C3 = Bes;
+    g2.epi = EPI_GRAD; g2.D = e.D; g2.rdiv = R; g2.ldd = nt; g2.colscale = e.et; g2.rowscale = e.es;
+    g2.quad_out = e.scal + 1;             // scal[1] = quad, scal[2] = sum B^2
+    g2.prof_name = "gemm_grad_temporal";
+    gemm_f64(c, g2, s);
+    double *av = c->buf<double>("grad_a", nx), *bv = c->buf<double>("grad_b", nt);
+    k_D_sums(c, e.D, e.es, e.et, nx, nt, av, bv, e.scal + 3, s);          // scal[3] = sum 1/D
+
+    // Ghat_s = 1/2 sum_r (B_r et) B_r^T - R/2 diag(a)      (one GEMM per trial, batched; then a fixed-order sum)
+    double *Cs = c->buf<double>("grad_Cs", (size_t)R * nx * nx);
+    GemmDesc gs;
+    gs.M = nx; gs.N = nx; gs.K = nt;
+    gs.A = Bet; gs.lda = RT; gs.B = Bm; gs.ldb = RT; gs.transB = true; gs.C = Cs; gs.ldc = nx;
+    gs.batch = R; gs.sA = nt; gs.sB = nt; gs.sC = (long)nx * nx;
+    gs.prof_name = "gemm_grad_Gs";
+    gemm_f64(c, gs, s);
+    double *Ghs = c->buf<double>("grad_Ghs", (size_t)nx * nx);
+    k_batch_reduce(c, Cs, R, (long)nx * nx, nx, 0.5, av, -0.5 * R, Ghs, s);
+    // Ghat_t = 1/2 sum_{(x,r)} (B es)^T B - R/2 diag(b)    (row chunks of 512, batched; remainder separately)
+    const long rows = (long)nx * R;
+    const int CH = 512;
+    const int nfull = (int)(rows / CH), rem = (int)(rows % CH);
+    double *Ct = c->buf<double>("grad_Ct", (size_t)(nfull + 1) * nt * nt);
+    if (nfull > 0) {
+        GemmDesc gt;
+        gt.M = nt; gt.N = nt; gt.K = CH;
+        gt.A = Bes; gt.lda = nt; gt.transA = true; gt.B = Bm; gt.ldb = nt; gt.C = Ct; gt.ldc = nt;
+        gt.batch = nfull; gt.sA = (long)CH * nt; gt.sB = (long)CH * nt; gt.sC = (long)nt * nt;
+        gt.prof_name = "gemm_grad_Gt";
+        gemm_f64(c, gt, s);
+    }
+    if (rem > 0) {
+        GemmDesc gt;
+        gt.M = nt; gt.N = nt; gt.K = rem;
+        gt.A = Bes + (long)nfull * CH * nt; gt.lda = nt; gt.transA = true; gt.B = Bm + (long)nfull * CH * nt; gt.ldb = nt;
+        gt.C = Ct + (long)nfull * nt * nt; gt.ldc = nt;
+        gt.prof_name = "gemm_grad_Gt";
+        gemm_f64(c, gt, s);
+    }
+    double *Ght = c->buf<double>("grad_Ght", (size_t)nt * nt);
+    k_batch_reduce(c, Ct, nfull + (rem > 0 ? 1 : 0), (long)nt * nt, nt, 0.5, bv, -0.5 * R, Ght, s);
+    // back to the original bases: Gs = Qs Ghat_s Qs^T, Gt = Qt Ghat_t Qt^T
+    double *T1 = c->buf<double>("grad_T1", (size_t)std::max(nx, nt) * std::max(nx, nt));
+    double *Gs = c->buf<double>("grad_Gs", (size_t)nx * nx), *Gt = c->buf<double>("grad_Gt", (size_t)nt * nt);
+    auto sandwich = [&](const double *Q, const double *H, int n, double *out) {
+        GemmDesc a;
+        a.M = n; a.N = n; a.K = n; a.A = Q; a.lda = n; a.B = H; a.ldb = n; a.C = T1; a.ldc = n;
+        a.prof_name = "gemm_grad_sandwich";
+        gemm_f64(c, a, s);
+        GemmDesc b;
+        b.M = n; b.N = n; b.K = n; b.A = T1; b.lda = n; b.B = Q; b.ldb = n; b.transB = true; b.C = out; b.ldc = n;
+        b.prof_name = "gemm_grad_sandwich";
+        gemm_f64(c, b, s);
+    };
+    sandwich(e.Qs, Ghs, nx, Gs);
+    sandwich(e.Qt, Ght, nt, Gt);
+    // natural-parameter order: [R, ell_s (dim), (ell_t, sigma2_t) per component, sig2n]
+    const double *t = (const double *)c->bufs["time_t"].p;
+    k_temporal_grad(c, hp, Gt, t, nt, gdev + 1 + g.dim, s);
+    double *P = c->buf<double>("grad_P", (size_t)nx * G);
+    double *Mg = c->buf<double>("grad_M", (size_t)G * G);
+    GemmDesc gp;                          // P = Gs A
+    gp.M = nx; gp.N = G; gp.K = nx; gp.A = Gs; gp.lda = nx; gp.B = A; gp.ldb = G; gp.C = P; gp.ldc = G;
+    gp.prof_name = "gemm_grad_GsA";
+    gemm_f64(c, gp, s);
+    GemmDesc gm;                          // M = A^T P
+    gm.M = G; gm.N = G; gm.K = nx; gm.A = A; gm.lda = G; gm.transA = true; gm.B = P; gm.ldb = G; gm.C = Mg; gm.ldc = G;
+    gm.prof_name = "gemm_grad_AtP";
+    gemm_f64(c, gm, s);
+    double *ellg = c->buf<double>("grad_ell", 2);
+    k_kgl_grad(c, Mg, Kgl, g.gx1, g.gx2, G, g.dim == 2 ? g.ngl2 : 0, hp->ell_s[0], hp->ell_s[1], ellg, s);
+    GP_HIP(hipMemcpyAsync(gdev + 1, ellg, g.dim * sizeof(double), hipMemcpyDeviceToDevice, s));
+    GemmDesc gr;                          // S = Gs T  (T = A Kgl from the forward pass)
+    gr.M = nx; gr.N = G; gr.K = nx; gr.A = Gs; gr.lda = nx; gr.B = T; gr.ldb = G; gr.C = P; gr.ldc = G;
+    gr.prof_name = "gemm_grad_GsT";
+    gemm_f64(c, gr, s);
+    k_fwdR_grad(c, P, g.x, nx, g.gx1, g.gw1, g.gx2, g.gw2, G, g.dim == 2 ? g.ngl2 : 0, hp->R, hp->eps, gdev, s);
+    double hs[4], hg[64];
+    c->download(hs, e.scal, 4 * sizeof(double));
+    c->download(hg, gdev, ngrad * sizeof(double));
+    const int rc = finish_status(c, e.status);
+    out2[0] = hs[0];
+    out2[1] = hs[1];
+    for (int k = 0; k < ngrad - 1; ++k) grad[k] = hg[k];
+    grad[ngrad - 1] = -0.5 * R * hs[3] + 0.5 * hs[2];
+    return rc;
+    GP_API_END(c)
 }
 
 // ------------------------------------------------------------------------------------------------

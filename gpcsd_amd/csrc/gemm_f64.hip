@@ -34,6 +34,8 @@ struct GemmK {
     double *C;
     long ldc;
     double *C2;
+    double *C3;
+    const double *colscale, *rowscale;
     long sA, sB, sC;
     double alpha;
     const double *D;
@@ -169,9 +171,10 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f64_kernel(GemmK g) {
     }
 
     // ---- epilogue ----
-    double qsum = 0.0;
+    double qsum = 0.0, qsum2 = 0.0;
     double *__restrict__ C = (EPI == EPI_QUAD) ? nullptr : g.C + bz * g.sC;
-    double *__restrict__ C2 = (EPI == EPI_DUAL) ? g.C2 + bz * g.sC : nullptr;
+    double *__restrict__ C2 = (EPI == EPI_DUAL || EPI == EPI_GRAD) ? g.C2 + bz * g.sC : nullptr;
+    double *__restrict__ C3 = (EPI == EPI_GRAD) ? g.C3 + bz * g.sC : nullptr;
 #pragma unroll
     for (int i = 0; i < FM; ++i) {
 #pragma unroll
@@ -179,7 +182,8 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f64_kernel(GemmK g) {
             const int row = m0 + wr * 16 * FM + i * 16 + fq + 4 * r;
             if (row >= g.M) continue;
             long drow = 0;
-            if (EPI == EPI_DIV_D || EPI == EPI_QUAD) drow = (long)(row / g.rdiv) * g.ldd;
+            if (EPI == EPI_DIV_D || EPI == EPI_QUAD || EPI == EPI_GRAD) drow = (long)(row / g.rdiv) * g.ldd;
+            const double rsc = (EPI == EPI_GRAD) ? g.rowscale[row / g.rdiv] : 0.0;
 #pragma unroll
             for (int j = 0; j < FN; ++j) {
                 const int col = n0 + wc * 16 * FN + j * 16 + fr;
@@ -195,24 +199,43 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f64_kernel(GemmK g) {
                     C2[(long)row * g.ldc + col] += o;
                 } else if (EPI == EPI_DIV_D) {
                     C[(long)row * g.ldc + col] = v / g.D[drow + col];
+                } else if (EPI == EPI_GRAD) {
+                    // b = alpha / D; also b * et[col], b * es[row / rdiv]; partial sums of alpha*b and b*b
+                    const double bq = v / g.D[drow + col];
+                    C[(long)row * g.ldc + col] = bq;
+                    C2[(long)row * g.ldc + col] = bq * g.colscale[col];
+                    C3[(long)row * g.ldc + col] = bq * rsc;
+                    qsum += v * bq;
+                    qsum2 += bq * bq;
                 } else {
                     qsum += v * v / g.D[drow + col];
                 }
             }
         }
     }
-    if (EPI == EPI_QUAD) {
+    if (EPI == EPI_QUAD || EPI == EPI_GRAD) {
         // wave reduction (64 lanes) then the waves through LDS; fixed order -> deterministic
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) qsum += __shfl_down(qsum, off, 64);
-        __shared__ double wsum[WM * WN];
-        if (lane == 0) wsum[wid] = qsum;
+        for (int off = 32; off > 0; off >>= 1) {
+            qsum += __shfl_down(qsum, off, 64);
+            if (EPI == EPI_GRAD) qsum2 += __shfl_down(qsum2, off, 64);
+        }
+        __shared__ double wsum[2 * WM * WN];
+        if (lane == 0) {
+            wsum[wid] = qsum;
+            wsum[WM * WN + wid] = qsum2;
+        }
         __syncthreads();
         if (tid == 0) {
-            double t = 0.0;
+            double t = 0.0, t2 = 0.0;
 #pragma unroll
-            for (int i = 0; i < WM * WN; ++i) t += wsum[i];
-            g.partials[bz * gridDim.x + blockIdx.x] = t;
+            for (int i = 0; i < WM * WN; ++i) {
+                t += wsum[i];
+                t2 += wsum[WM * WN + i];
+            }
+            const long nb = (long)gridDim.x * gridDim.z, me = bz * gridDim.x + blockIdx.x;
+            g.partials[me] = t;
+            if (EPI == EPI_GRAD) g.partials[nb + me] = t2;
         }
     }
 }
@@ -240,6 +263,7 @@ static void launch_epi(const GemmK &k, int epi, dim3 grid, hipStream_t s) {
         case EPI_QUAD: hipLaunchKernelGGL((gemm_f64_kernel<WM, WN, FM, FN, BK, TA, TB, EPI_QUAD>), grid, blk, 0, s, k); break;
         case EPI_ACCUM: hipLaunchKernelGGL((gemm_f64_kernel<WM, WN, FM, FN, BK, TA, TB, EPI_ACCUM>), grid, blk, 0, s, k); break;
         case EPI_DUAL: hipLaunchKernelGGL((gemm_f64_kernel<WM, WN, FM, FN, BK, TA, TB, EPI_DUAL>), grid, blk, 0, s, k); break;
+        case EPI_GRAD: hipLaunchKernelGGL((gemm_f64_kernel<WM, WN, FM, FN, BK, TA, TB, EPI_GRAD>), grid, blk, 0, s, k); break;
         default: throw HipError{-3, "gemm_f64: bad epilogue"};
     }
 }
@@ -257,7 +281,8 @@ void gemm_f64(gpcsd_ctx *c, const GemmDesc &g, hipStream_t s) {
     GP_REQUIRE(g.M > 0 && g.N > 0 && g.K > 0, -3, "gemm_f64: empty problem %dx%dx%d", g.M, g.N, g.K);
     GemmK k;
     k.M = g.M; k.N = g.N; k.K = g.K;
-    k.A = g.A; k.lda = g.lda; k.B = g.B; k.ldb = g.ldb; k.C = g.C; k.ldc = g.ldc; k.C2 = g.C2;
+    k.A = g.A; k.lda = g.lda; k.B = g.B; k.ldb = g.ldb; k.C = g.C; k.ldc = g.ldc; k.C2 = g.C2; k.C3 = g.C3;
+    k.colscale = g.colscale; k.rowscale = g.rowscale;
     k.sA = g.sA; k.sB = g.sB; k.sC = g.sC;
     k.alpha = g.alpha; k.D = g.D; k.rdiv = g.rdiv > 0 ? g.rdiv : 1; k.ldd = g.ldd;
     k.partials = nullptr;
@@ -272,7 +297,7 @@ void gemm_f64(gpcsd_ctx *c, const GemmDesc &g, hipStream_t s) {
     k.tiles_n = tn;
     dim3 grid(tm * tn, 1, g.batch);
     const long nblocks = (long)tm * tn * g.batch;
-    if (g.epi == EPI_QUAD) k.partials = c->buf<double>("gemm_partials", nblocks);
+    if (g.epi == EPI_QUAD || g.epi == EPI_GRAD) k.partials = c->buf<double>("gemm_partials", 2 * nblocks);
 
     const double flops = 2.0 * g.M * (double)g.N * g.K * g.batch;
     {
@@ -284,8 +309,11 @@ void gemm_f64(gpcsd_ctx *c, const GemmDesc &g, hipStream_t s) {
         else launch_trans<2, 2, 1, 1, 64>(k, g.transA, g.transB, g.epi, grid, s);
         GP_HIP(hipGetLastError());
     }
-    if (g.epi == EPI_QUAD) {
+    if (g.epi == EPI_QUAD || g.epi == EPI_GRAD) {
         hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(256), 0, s, (const double *)k.partials, nblocks, g.quad_out);
+        if (g.epi == EPI_GRAD)
+            hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(256), 0, s, (const double *)(k.partials + nblocks), nblocks,
+                               g.quad_out + 1);
         GP_HIP(hipGetLastError());
     }
 }

@@ -1,0 +1,221 @@
+// Analytic gradient of the log marginal likelihood: the contractions that replace the
+// reference's autograd tape (gpcsd1d.py:211, gpcsd2d.py:250).  With B_r = alpha_r / D (eigenbasis) and scalar sig2n:
+//   Ghat_s = 1/2 sum_r B_r diag(et) B_r^T - R/2 diag(a),  a_x = sum_i et_i / D_xi,   Gs = Qs Ghat_s Qs^T
+//   Ghat_t = 1/2 sum_r B_r^T diag(es) B_r - R/2 diag(b),  b_i = sum_x es_x / D_xi,   Gt = Qt Ghat_t Qt^T
+//   dL/dtheta_t = <Gt, dKt/dtheta_t>,  dL/dell_s = <A^T Gs A, dKgl/dell_s>,  dL/dR = 2 <Gs (A Kgl), dA/dR>,
+//   dL/dsig2n  = -R/2 sum 1/D + 1/2 sum B^2.
+// The GEMMs run on the fp64 MFMA core (capi.hip wires them); this file holds the elementwise derivative kernels and
+// the deterministic reductions (per-block partials in fixed order, then one block per output value).
+#include "devutil.hpp"
+#include "kernels.hpp"
+
+namespace gpcsd {
+
+constexpr int GR_MAXV = 2 * GPCSD_MAX_TEMPORAL;
+
+template <int NV>
+__device__ __forceinline__ void block_partials(double (&v)[NV], double *partials, int nblocks, int b) {
+    __shared__ double red[NV][4];
+#pragma unroll
+    for (int q = 0; q < NV; ++q) {
+        const double s = wave_sum(v[q]);
+        if ((threadIdx.x & 63) == 0) red[q][threadIdx.x >> 6] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < NV) partials[(long)threadIdx.x * nblocks + b] = (red[threadIdx.x][0] + red[threadIdx.x][1]) +
+                                                                      (red[threadIdx.x][2] + red[threadIdx.x][3]);
+}
+
+// out[v] = scale[v-th] * sum_b partials[v*nblocks + b]; one workgroup per value
+__global__ __launch_bounds__(256) void final_sums_kernel(const double *__restrict__ partials, int nblocks, double *out) {
+    __shared__ double red[4];
+    const int v = blockIdx.x;
+    double s = 0.0;
+    for (int b = threadIdx.x; b < nblocks; b += 256) s += partials[(long)v * nblocks + b];
+    s = block_sum256(s, red);
+    if (threadIdx.x == 0) out[v] = s;
+}
+
+// a_x = sum_i et_i / D_xi and per-row partial of sum 1/D; one workgroup per eigen-row x
+__global__ __launch_bounds__(256) void d_rowsums_kernel(const double *__restrict__ D, const double *__restrict__ et, int nt,
+                                                        double *__restrict__ a, double *__restrict__ s1row) {
+    __shared__ double red[4];
+    const int x = blockIdx.x;
+    double sa = 0.0, s1 = 0.0;
+    for (int i = threadIdx.x; i < nt; i += 256) {
+        const double inv = 1.0 / D[(long)x * nt + i];
+        sa += et[i] * inv;
+        s1 += inv;
+    }
+    sa = block_sum256(sa, red);
+    s1 = block_sum256(s1, red);
+    if (threadIdx.x == 0) {
+        a[x] = sa;
+        s1row[x] = s1;
+    }
+}
+
+// b_i = sum_x es_x / D_xi; one thread per eigen-column i (coalesced across i)
+__global__ __launch_bounds__(256) void d_colsums_kernel(const double *__restrict__ D, const double *__restrict__ es, int nx,
+                                                        int nt, double *__restrict__ b) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= nt) return;
+    double s = 0.0;
+    for (int x = 0; x < nx; ++x) s += es[x] / D[(long)x * nt + i];
+    b[i] = s;
+}
+
+void k_D_sums(gpcsd_ctx *c, const double *D, const double *es, const double *et, int nx, int nt, double *a, double *b,
+              double *s1_out, hipStream_t s) {
+    double *s1row = c->buf<double>("grad_s1row", nx);
+    hipLaunchKernelGGL(d_rowsums_kernel, dim3(nx), dim3(256), 0, s, D, et, nt, a, s1row);
+    hipLaunchKernelGGL(d_colsums_kernel, dim3(ceil_div(nt, 256)), dim3(256), 0, s, D, es, nx, nt, b);
+    hipLaunchKernelGGL(final_sums_kernel, dim3(1), dim3(256), 0, s, (const double *)s1row, nx, s1_out);
+    GP_HIP(hipGetLastError());
+}
+
+// out[e] = scale * sum_b in[b*stride + e]  (+ dscale * dvec[i] on the diagonal of the n x n output)
+__global__ __launch_bounds__(256) void batch_reduce_kernel(const double *__restrict__ in, int nb, long stride, int n, double scale,
+                                                           const double *__restrict__ dvec, double dscale,
+                                                           double *__restrict__ out) {
+    const long e = blockIdx.x * 256L + threadIdx.x;
+    if (e >= (long)n * n) return;
+    double s = 0.0;
+    for (int b = 0; b < nb; ++b) s += in[b * stride + e];
+    s *= scale;
+    const int i = (int)(e / n), j = (int)(e % n);
+    if (i == j) s += dscale * dvec[i];
+    out[e] = s;
+}
+
+void k_batch_reduce(gpcsd_ctx *c, const double *in, int nb, long stride, int n, double scale, const double *dvec, double dscale,
+                    double *out, hipStream_t s) {
+    hipLaunchKernelGGL(batch_reduce_kernel, dim3(ceil_div((long)n * n, 256)), dim3(256), 0, s, in, nb, stride, n, scale, dvec,
+                       dscale, out);
+    GP_HIP(hipGetLastError());
+}
+
+// ---- temporal: sum_ij Gt_ij dKt_ij/d(ell_c), sum_ij Gt_ij dKt_ij/d(sigma2_c)    (covariances.py:269-270, :303-304)
+struct TGradParams {
+    int ncomp;
+    int kind[GPCSD_MAX_TEMPORAL];
+    double ell[GPCSD_MAX_TEMPORAL];
+    double sigma2[GPCSD_MAX_TEMPORAL];
+};
+
+__global__ __launch_bounds__(256) void temporal_grad_kernel(TGradParams p, const double *__restrict__ Gt,
+                                                            const double *__restrict__ t, int nt, double *partials) {
+    double v[GR_MAXV];
+#pragma unroll
+    for (int q = 0; q < GR_MAXV; ++q) v[q] = 0.0;
+    const long n2 = (long)nt * nt;
+    for (long e = blockIdx.x * 256L + threadIdx.x; e < n2; e += (long)gridDim.x * 256) {
+        const int i = (int)(e / nt), j = (int)(e % nt);
+        const double g = Gt[e];
+        const double d = t[i] - t[j];
+#pragma unroll
+        for (int cc = 0; cc < GPCSD_MAX_TEMPORAL; ++cc) {
+            if (cc < p.ncomp) {
+                const double ell = p.ell[cc];
+                double k, dk;                     // unit-variance kernel and its ell-derivative
+                if (p.kind[cc] == GPCSD_KIND_SE) {
+                    k = exp(-0.5 * (d * d) / (ell * ell));
+                    dk = k * (d * d) / (ell * ell * ell);
+                } else {
+                    const double ad = fabs(d);
+                    k = exp(-ad / ell);
+                    dk = k * ad / (ell * ell);
+                }
+                v[2 * cc] += g * p.sigma2[cc] * dk;
+                v[2 * cc + 1] += g * k;
+            }
+        }
+    }
+    block_partials<GR_MAXV>(v, partials, gridDim.x, blockIdx.x);
+}
+
+void k_temporal_grad(gpcsd_ctx *c, const gpcsd_hparams *hp, const double *Gt, const double *t, int nt, double *out2C,
+                     hipStream_t s) {
+    TGradParams p;
+    p.ncomp = hp->n_temporal;
+    for (int i = 0; i < hp->n_temporal; ++i) {
+        p.kind[i] = hp->kind[i];
+        p.ell[i] = hp->ell_t[i];
+        p.sigma2[i] = hp->sigma2_t[i];
+    }
+    const int nblocks = 256;
+    double *part = c->buf<double>("grad_partials", (size_t)GR_MAXV * 1024);
+    double *tmp = c->buf<double>("grad_tmp", GR_MAXV);
+    hipLaunchKernelGGL(temporal_grad_kernel, dim3(nblocks), dim3(256), 0, s, p, Gt, t, nt, part);
+    hipLaunchKernelGGL(final_sums_kernel, dim3(2 * hp->n_temporal), dim3(256), 0, s, (const double *)part, nblocks, tmp);
+    GP_HIP(hipMemcpyAsync(out2C, tmp, 2 * hp->n_temporal * sizeof(double), hipMemcpyDeviceToDevice, s));
+    GP_HIP(hipGetLastError());
+}
+
+// ---- spatial length scales: sum_gh M_gh Kgl_gh d_gh^2 / ell^3       (covariances.py:89, :216)
+__global__ __launch_bounds__(256) void kgl_grad_kernel(const double *__restrict__ M, const double *__restrict__ Kgl,
+                                                       const double *__restrict__ gx1, const double *__restrict__ gx2, int G,
+                                                       int ngl2, double ell1, double ell2, double *partials) {
+    double v[2] = {0.0, 0.0};
+    const long n2 = (long)G * G;
+    for (long e = blockIdx.x * 256L + threadIdx.x; e < n2; e += (long)gridDim.x * 256) {
+        const int g = (int)(e / G), h = (int)(e % G);
+        const double mk = M[e] * Kgl[e];
+        if (ngl2 > 0) {
+            const double d1 = gx1[g / ngl2] - gx1[h / ngl2], d2 = gx2[g % ngl2] - gx2[h % ngl2];
+            v[0] += mk * (d1 * d1) / (ell1 * ell1 * ell1);
+            v[1] += mk * (d2 * d2) / (ell2 * ell2 * ell2);
+        } else {
+            const double d1 = gx1[g] - gx1[h];
+            v[0] += mk * (d1 * d1) / (ell1 * ell1 * ell1);
+        }
+    }
+    block_partials<2>(v, partials, gridDim.x, blockIdx.x);
+}
+
+void k_kgl_grad(gpcsd_ctx *c, const double *M, const double *Kgl, const double *gx1, const double *gx2, int G, int ngl2,
+                double ell1, double ell2, double *out2, hipStream_t s) {
+    const int nblocks = 512;
+    double *part = c->buf<double>("grad_partials", (size_t)GR_MAXV * 1024);
+    hipLaunchKernelGGL(kgl_grad_kernel, dim3(nblocks), dim3(256), 0, s, M, Kgl, gx1, gx2, G, ngl2, ell1, ell2, part);
+    hipLaunchKernelGGL(final_sums_kernel, dim3(2), dim3(256), 0, s, (const double *)part, nblocks, out2);
+    GP_HIP(hipGetLastError());
+}
+
+// ---- forward-model radius: 2 sum_xg S_xg dA_xg/dR                      (forward_models.py:16, :53)
+//   1D: A = w_g (sqrt(q+1) - sqrt(q)), q = (r/R)^2   ->  dA/dR = w_g (sqrt(q) - q / sqrt(q+1)) / R
+//   2D: A = w_g (log(R+eps+sqrt((R+eps)^2+w^2)) - ...)  ->  dA/dR = w_g / sqrt((R+eps)^2 + w^2)
+__global__ __launch_bounds__(256) void fwdR_grad_kernel(const double *__restrict__ S, const double *__restrict__ x, int nx,
+                                                        const double *__restrict__ gx1, const double *__restrict__ gw1,
+                                                        const double *__restrict__ gx2, const double *__restrict__ gw2, int G,
+                                                        int ngl2, double R, double eps, double *partials) {
+    double v[1] = {0.0};
+    const long n2 = (long)nx * G;
+    for (long e = blockIdx.x * 256L + threadIdx.x; e < n2; e += (long)gridDim.x * 256) {
+        const int i = (int)(e / G), g = (int)(e % G);
+        double dA;
+        if (ngl2 > 0) {
+            const int g1 = g / ngl2, g2 = g % ngl2;
+            const double d1 = gx1[g1] - x[2 * i], d2 = gx2[g2] - x[2 * i + 1];
+            const double re = R + eps;
+            dA = (gw1[g1] * gw2[g2]) / sqrt(re * re + (d1 * d1 + d2 * d2));
+        } else {
+            const double r = gx1[g] - x[i];
+            const double q = (r / R) * (r / R);
+            dA = gw1[g] * (sqrt(q) - q / sqrt(q + 1.0)) / R;
+        }
+        v[0] += 2.0 * S[e] * dA;
+    }
+    block_partials<1>(v, partials, gridDim.x, blockIdx.x);
+}
+
+void k_fwdR_grad(gpcsd_ctx *c, const double *S, const double *x, int nx, const double *gx1, const double *gw1, const double *gx2,
+                 const double *gw2, int G, int ngl2, double R, double eps, double *out1, hipStream_t s) {
+    const int nblocks = 256;
+    double *part = c->buf<double>("grad_partials", (size_t)GR_MAXV * 1024);
+    hipLaunchKernelGGL(fwdR_grad_kernel, dim3(nblocks), dim3(256), 0, s, S, x, nx, gx1, gw1, gx2, gw2, G, ngl2, R, eps, part);
+    hipLaunchKernelGGL(final_sums_kernel, dim3(1), dim3(256), 0, s, (const double *)part, nblocks, out1);
+    GP_HIP(hipGetLastError());
+}
+
+}  // namespace gpcsd

@@ -10,7 +10,8 @@ enum Epi : int {
     EPI_DIV_D = 1,   // C = acc / D[(row / rdiv) * ldd + col]
     EPI_QUAD = 2,    // no store; partial sums of acc^2 / D[...] (deterministic two-stage reduce)
     EPI_ACCUM = 3,   // C += alpha * acc
-    EPI_DUAL = 4     // C = alpha*acc and C2 += alpha*acc   (predict: per-component + running sum)
+    EPI_DUAL = 4,    // C = alpha*acc and C2 += alpha*acc   (predict: per-component + running sum)
+    EPI_GRAD = 5     // b = acc / D: C = b, C2 = b*colscale[col], C3 = b*rowscale[row/rdiv]; sums of acc*b and b*b
 };
 
 struct GemmDesc {
@@ -23,7 +24,9 @@ struct GemmDesc {
     bool transB = false;   // false: B is (K,N) row-major; true: B stored (N,K) row-major
     double *C = nullptr;
     long ldc = 0;
-    double *C2 = nullptr;  // EPI_DUAL
+    double *C2 = nullptr;  // EPI_DUAL, EPI_GRAD
+    double *C3 = nullptr;  // EPI_GRAD
+    const double *colscale = nullptr, *rowscale = nullptr;   // EPI_GRAD
     int batch = 1;
     long sA = 0, sB = 0, sC = 0;
     double alpha = 1.0;
@@ -31,7 +34,7 @@ struct GemmDesc {
     const double *D = nullptr;
     int rdiv = 1;
     long ldd = 0;
-    double *quad_out = nullptr;   // EPI_QUAD: one double, written by the final reduce
+    double *quad_out = nullptr;   // EPI_QUAD: one double (EPI_GRAD: two), written by the final reduce
     const int *dyn = nullptr;     // device int per batch entry: effective N = K = dyn[batch] (tiles beyond it exit)
     const char *prof_name = "gemm_f64";
 };
@@ -78,6 +81,23 @@ void eigh_pair_device(gpcsd_ctx *c, double *A0, int n0, double *w0, double *Z0, 
 void sytrd_device(gpcsd_ctx *c, double *A, int n, double *d, double *e, double *V, double *tau, hipStream_t s);
 void stedc_device(gpcsd_ctx *c, const double *d, const double *e, int n, double *w, double *Z, int *d_status,
                   hipStream_t s, const char *tag);
+
+// ---------------------------------------------------------------- analytic gradient pieces (grad.hip)
+// a_x = sum_i et_i/D_xi, b_i = sum_x es_x/D_xi, s1 = sum 1/D
+void k_D_sums(gpcsd_ctx *c, const double *D, const double *es, const double *et, int nx, int nt, double *a, double *b,
+              double *s1_out, hipStream_t s);
+// out (n,n) = scale * sum_b in[b*stride + e] + dscale * diag(dvec)
+void k_batch_reduce(gpcsd_ctx *c, const double *in, int nb, long stride, int n, double scale, const double *dvec, double dscale,
+                    double *out, hipStream_t s);
+// out[2c] = <Gt, dKt/d ell_c>, out[2c+1] = <Gt, dKt/d sigma2_c>
+void k_temporal_grad(gpcsd_ctx *c, const gpcsd_hparams *hp, const double *Gt, const double *t, int nt, double *out2C,
+                     hipStream_t s);
+// out[0..1] = <M, dKgl/d ell_1>, <M, dKgl/d ell_2>   (ngl2 == 0: 1D, only out[0] meaningful)
+void k_kgl_grad(gpcsd_ctx *c, const double *M, const double *Kgl, const double *gx1, const double *gx2, int G, int ngl2,
+                double ell1, double ell2, double *out2, hipStream_t s);
+// out[0] = 2 <S, dA/dR>
+void k_fwdR_grad(gpcsd_ctx *c, const double *S, const double *x, int nx, const double *gx1, const double *gw1, const double *gx2,
+                 const double *gw2, int G, int ngl2, double R, double eps, double *out1, hipStream_t s);
 
 // ---------------------------------------------------------------- Cholesky (chol.hip)
 // In-place lower Cholesky of A (n,n) row-major; strictly-upper part zeroed.  d_status: 0 ok, k+1 = pivot k <= 0.

@@ -133,12 +133,11 @@ int gpcsd_loglik(gpcsd_ctx *ctx, const gpcsd_hparams *hp, double *out);
 /* Sharded form: out[0] = sum(log D) (identical on every shard), out[1] = sum_r sum alpha^2/D over the
  * resident trials; loglik = -0.5*R_total*out[0] - 0.5*sum_over_shards(out[1]) */
 int gpcsd_loglik_parts(gpcsd_ctx *ctx, const gpcsd_hparams *hp, double *out2);
-/* loglik and its gradient w.r.t. the natural hyper-parameters
- * [R, ell_s(dim), (ell_t, sigma2_t) per component, sig2n]  (scalar sig2n only).  Replaces the
- * autograd tape of gpcsd1d.py:211 / gpcsd2d.py:250.  parts2 as in gpcsd_loglik_parts; grad_logdet and
- * grad_quad are the derivatives of out2[0] and out2[1] so shards can be combined linearly. */
-int gpcsd_loglik_grad_parts(gpcsd_ctx *ctx, const gpcsd_hparams *hp, double *out2,
-                            double *grad_logdet, double *grad_quad, int ngrad);
+/* Local log-likelihood pieces and the gradient of  L_loc = -0.5*ntrials_resident*out2[0] - 0.5*out2[1]  with respect
+ * to the natural hyper-parameters [R, ell_s (dim), (ell_t, sigma2_t) per component, sig2n] (scalar sig2n only).
+ * Replaces the autograd tape of gpcsd1d.py:211 / gpcsd2d.py:250.  Both L_loc and grad are sums over trials plus a
+ * term linear in the resident trial count, so shards combine by plain summation over ranks. */
+int gpcsd_loglik_grad(gpcsd_ctx *ctx, const gpcsd_hparams *hp, double *out2, double *grad, int ngrad);
 /* GPCSD{1,2}D.predict(z, t, type) gpcsd1d.py:248-293 / gpcsd2d.py:289-334.
  * z (nz, dim), tstar (ntstar) with ntstar == nt (the reference raises ValueError otherwise -> rc -22).
  * Outputs (any may be NULL): *_list is (n_temporal, nz, ntstar, ntrials), sums are (nz, ntstar, ntrials). */
