@@ -84,6 +84,10 @@ def synth_data(w, m, ntrials, seed):
     Kt = sum(tc.compute_Kt() for tc in m.temporal_cov_list)
     es, Qs = ctx.eigh(Ks)
     et, Qt = ctx.eigh(Kt)
+    # eigenvector signs are solver-dependent: fix them (largest |component| positive) so the synthetic data set does
+    # not change when the eigensolver does
+    for Q in (Qs, Qt):
+        Q *= np.sign(Q[np.argmax(np.abs(Q), axis=0), np.arange(Q.shape[1])])[None, :]
     Ls = Qs * np.sqrt(np.maximum(es, 0.0))[None, :]
     Lt = Qt * np.sqrt(np.maximum(et, 0.0))[None, :]
     rs = np.random.RandomState(seed)

@@ -78,6 +78,7 @@ SIGNATURES = {
     "gpcsd_prof_names": (_I, [_P, ctypes.c_char_p, _I]),
     "gpcsd_mfma_f64_peak": (_I, [_P, _DP]),
     "gpcsd_hbm_copy_peak": (_I, [_P, _L, _DP]),
+    "gpcsd_gemm_bench": (_I, [_P, _I, _I, _I, _I, _I, _I, _I, _DP]),
 }
 
 
@@ -426,6 +427,13 @@ class Context:
         out = ctypes.c_double()
         self._check(self._lib.gpcsd_mfma_f64_peak(self._h, ctypes.byref(out)))
         return out.value
+
+    def gemm_bench(self, M, N, K, transA=False, transB=False, cfg=0, reps=10):
+        """(ms per launch, TFLOP/s) of the fp64 MFMA GEMM on device-resident operands."""
+        out = ctypes.c_double()
+        self._check(self._lib.gpcsd_gemm_bench(self._h, int(transA), int(transB), int(M), int(N), int(K), int(cfg), int(reps),
+                                               ctypes.byref(out)))
+        return out.value, 2.0 * M * N * K / (out.value * 1e-3) / 1e12
 
     def hbm_copy_peak(self, nbytes=1 << 30):
         out = ctypes.c_double()

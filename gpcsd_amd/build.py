@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJDIR = os.path.join(CSRC, "_build")
 LIB = os.path.join(HERE, "libgpcsd_hip.so")
-SOURCES = ["capi.hip", "gemm_f64.hip", "gram.hip", "eigh.hip", "eigh_dc.hip", "stedc.hip", "grad.hip", "chol.hip"]
+SOURCES = ["capi.hip", "gemm_f64.hip", "gram.hip", "eigh.hip", "eigh_dc.hip", "stedc.hip", "wy.hip", "grad.hip", "chol.hip"]
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=" + ARCH, "-fno-fast-math", "-Wall", "-Wno-unused-function"]
 # the elementwise Gram builders keep the reference's operation order exactly (no FMA contraction)

@@ -146,14 +146,82 @@ void check_hp(gpcsd_ctx *c, const gpcsd_hparams *hp, int nx) {
                "sig2n must have 1 or nx=%d entries (got %d)", nx, hp->n_sig2n);
 }
 
+// ---- reflection symmetry of a point set (host): find the involution i -> P(i) with pts[P(i)] = 2*centre - pts[i]
+// along the dimensions flagged in `reflect`, and upload its orbit tables.  Returns an empty SymDev if there is none.
+SymDev find_symmetry(gpcsd_ctx *c, const std::string &name, const double *pts, int n, int dim, const double *centre,
+                     const bool *reflect) {
+    SymDev out;
+    if (n < 2) return out;
+    double scale = 0.0;
+    for (int i = 0; i < n * dim; ++i) scale = std::max(scale, std::fabs(pts[i] - centre[i % dim]));
+    const double tol = 1e-9 * std::max(scale, 1e-300);
+    std::vector<int> perm(n, -1);
+    for (int i = 0; i < n; ++i) {
+        double tgt[2];
+        for (int d = 0; d < dim; ++d) tgt[d] = reflect[d] ? 2.0 * centre[d] - pts[i * dim + d] : pts[i * dim + d];
+        int best = -1;
+        double bd = 1e300;
+        for (int j = 0; j < n; ++j) {
+            double dist = 0.0;
+            for (int d = 0; d < dim; ++d) dist = std::max(dist, std::fabs(pts[j * dim + d] - tgt[d]));
+            if (dist < bd) {
+                bd = dist;
+                best = j;
+            }
+        }
+        if (best < 0 || bd > tol) return out;
+        perm[i] = best;
+    }
+    int npairs = 0;
+    for (int i = 0; i < n; ++i) {
+        if (perm[perm[i]] != i) return out;
+        if (perm[i] > i) ++npairs;
+    }
+    if (npairs == 0) return out;
+    const int ns = n - npairs, na = npairs;
+    std::vector<int> tbl(2 * ns + 2 * n);
+    int *rep_i = tbl.data(), *rep_j = rep_i + ns, *orb = rep_j + ns, *sgn = orb + n;
+    int a = 0;
+    for (int i = 0; i < n; ++i)
+        if (perm[i] > i) {
+            rep_i[a] = i; rep_j[a] = perm[i];
+            orb[i] = a; sgn[i] = 1;
+            orb[perm[i]] = a; sgn[perm[i]] = -1;
+            ++a;
+        }
+    for (int i = 0; i < n; ++i)
+        if (perm[i] == i) {
+            rep_i[a] = i; rep_j[a] = i;
+            orb[i] = a; sgn[i] = 0;
+            ++a;
+        }
+    int *d = c->buf<int>(name, tbl.size());
+    GP_HIP(hipMemcpyAsync(d, tbl.data(), tbl.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
+    GP_HIP(hipStreamSynchronize(c->stream));
+    out.ns = ns; out.na = na;
+    out.rep_i = d; out.rep_j = d + ns; out.orb = d + 2 * ns; out.sgn = d + 2 * ns + n;
+    return out;
+}
+
+bool rule_is_symmetric(const double *gx, const double *gw, int n, double *centre) {
+    *centre = 0.5 * (gx[0] + gx[n - 1]);
+    const double scale = std::max(std::fabs(gx[n - 1] - gx[0]), 1e-300);
+    for (int k = 0; k < n; ++k) {
+        if (std::fabs(gx[k] + gx[n - 1 - k] - 2.0 * *centre) > 1e-11 * scale) return false;
+        if (std::fabs(gw[k] - gw[n - 1 - k]) > 1e-11 * std::fabs(gw[k])) return false;
+    }
+    return true;
+}
+
 // Eigen-decompose Ks (stream) and Kt (stream2) concurrently; D and sum(log D).
 // Inputs Ks, Kt are destroyed.  Outputs: Qs, es, Qt, et, D, sumlog (device).
 void eig_pair_D(gpcsd_ctx *c, double *Ks, int nx, double *Kt, int nt, const double *d_sig, int nsig, double *Qs, double *es,
-                double *Qt, double *et, double *D, double *d_sumlog, int *d_status) {
+                double *Qt, double *et, double *D, double *d_sumlog, int *d_status, const SymDev *sym_s = nullptr,
+                const SymDev *sym_t = nullptr) {
     {
-        // both problems share every launch of the per-column tridiagonalisation (batched), so one stream suffices
+        // all problems share every launch of the per-column tridiagonalisation (batched), so one stream suffices
         ProfScope ps(c, "eigh_pair", 9.0 * ((double)nx * nx * nx + (double)nt * nt * nt), c->stream);
-        eigh_pair_device(c, Ks, nx, es, Qs, Kt, nt, et, Qt, d_status, c->stream);
+        eigh_pair_device(c, Ks, nx, es, Qs, sym_s, Kt, nt, et, Qt, sym_t, d_status, c->stream);
     }
     k_build_D(c, es, nx, et, nt, d_sig, nsig, D, d_sumlog, c->stream);
 }
@@ -187,7 +255,9 @@ EigState front_half(gpcsd_ctx *c, const gpcsd_hparams *hp, double jitter) {
     const double *t = (const double *)c->bufs["time_t"].p;
     build_kphi(c, g, hp->R, hp->eps, hp->ell_s, nullptr, 0, jitter, Ks, s);
     build_kt(c, hp, t, nt, t, nt, Kt, s);
-    eig_pair_D(c, Ks, nx, Kt, nt, d_sig, hp->n_sig2n, e.Qs, e.es, e.Qt, e.et, e.D, e.scal, e.status);
+    // the symmetries come from the resident geometry / time grid, so they hold for the Grams built from them
+    eig_pair_D(c, Ks, nx, Kt, nt, d_sig, hp->n_sig2n, e.Qs, e.es, e.Qt, e.et, e.D, e.scal, e.status,
+               c->sym_s.ns > 0 ? &c->sym_s : nullptr, c->sym_t.ns > 0 ? &c->sym_t : nullptr);
     return e;
 }
 
@@ -254,6 +324,12 @@ extern "C" int gpcsd_ctx_destroy(gpcsd_ctx *c) {
             (void)hipEventDestroy(p.second);
         }
     for (auto e : c->event_pool) (void)hipEventDestroy(e);
+    for (auto &kv : c->graphs)
+        if (kv.second.exec) (void)hipGraphExecDestroy(kv.second.exec);
+    for (int i = 0; i < 4; ++i) {
+        if (c->side_ev[i]) (void)hipEventDestroy(c->side_ev[i]);
+        if (c->side[i]) (void)hipStreamDestroy(c->side[i]);
+    }
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -299,6 +375,13 @@ extern "C" int gpcsd_set_geometry_1d(gpcsd_ctx *c, const double *x, int nx, cons
     c->upload<double>("geo_gw1", gl_w, ngl);
     c->sync();
     c->dim = 1; c->geo_nx = nx; c->ngl1 = ngl; c->ngl2 = 0;
+    // electrodes mirror-symmetric about the centre of a symmetric quadrature rule -> Ks commutes with the reflection
+    c->sym_s = SymDev();
+    double ctr;
+    if (rule_is_symmetric(gl_x, gl_w, ngl, &ctr)) {
+        const bool refl[1] = {true};
+        c->sym_s = find_symmetry(c, "sym_s_tbl", x, nx, 1, &ctr, refl);
+    }
     return 0;
     GP_API_END(c)
 }
@@ -314,6 +397,16 @@ extern "C" int gpcsd_set_geometry_2d(gpcsd_ctx *c, const double *xy, int nx, con
     c->upload<double>("geo_gw2", gl_w2, ngl2);
     c->sync();
     c->dim = 2; c->geo_nx = nx; c->ngl1 = ngl1; c->ngl2 = ngl2;
+    // reflections about the centre of the (symmetric) tensor quadrature rule that map the electrode set onto itself:
+    // point reflection first (the Neuropixels checkerboard has it), then single-axis mirrors
+    c->sym_s = SymDev();
+    double ctr[2];
+    const bool s1 = rule_is_symmetric(gl_x1, gl_w1, ngl1, &ctr[0]), s2 = rule_is_symmetric(gl_x2, gl_w2, ngl2, &ctr[1]);
+    const bool cand[3][2] = {{true, true}, {false, true}, {true, false}};
+    for (int k = 0; k < 3 && c->sym_s.ns == 0; ++k) {
+        if ((cand[k][0] && !s1) || (cand[k][1] && !s2)) continue;
+        c->sym_s = find_symmetry(c, "sym_s_tbl", xy, nx, 2, ctr, cand[k]);
+    }
     return 0;
     GP_API_END(c)
 }
@@ -324,6 +417,15 @@ extern "C" int gpcsd_set_time(gpcsd_ctx *c, const double *t, int nt) {
     c->upload<double>("time_t", t, nt);
     c->sync();
     c->time_nt = nt;
+    // a time grid symmetric about its midpoint (any uniform grid) makes every stationary Kt centro-symmetric
+    double lo = t[0], hi = t[0];
+    for (int i = 1; i < nt; ++i) {
+        lo = std::min(lo, t[i]);
+        hi = std::max(hi, t[i]);
+    }
+    const double ctr = 0.5 * (lo + hi);
+    const bool refl[1] = {true};
+    c->sym_t = find_symmetry(c, "sym_t_tbl", t, nt, 1, &ctr, refl);
     return 0;
     GP_API_END(c)
 }
@@ -618,6 +720,46 @@ extern "C" int gpcsd_gemm(gpcsd_ctx *c, int transA, int transB, int M, int N, in
     GP_API_END(c)
 }
 
+__global__ void fill_pattern_kernel(double *p, long n, double a) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        unsigned long long h = (unsigned long long)i * 6364136223846793005ull + 1442695040888963407ull;
+        h ^= h >> 29;
+        p[i] = a * ((double)(h & 0xFFFFFF) / 8388608.0 - 1.0);          // pseudo-random in [-a, a)
+    }
+}
+
+// Time the fp64 MFMA GEMM on device-resident pseudo-random operands: average ms per launch over `reps` launches.
+// cfg = 0 picks the tile configuration automatically, 1..6 forces one (tuning aid; see gemm_f64.hip).
+extern "C" int gpcsd_gemm_bench(gpcsd_ctx *c, int transA, int transB, int M, int N, int K, int cfg, int reps, double *ms_out) {
+    GP_API_BEGIN(c)
+    GP_REQUIRE(M > 0 && N > 0 && K > 0 && reps > 0 && ms_out, -3, "gemm_bench: bad arguments");
+    double *dA = c->buf<double>("bench_A", (size_t)M * K);
+    double *dB = c->buf<double>("bench_B", (size_t)K * N);
+    double *dC = c->buf<double>("bench_C", (size_t)M * N);
+    hipLaunchKernelGGL(fill_pattern_kernel, dim3(1024), dim3(256), 0, c->stream, dA, (long)M * K, 1.0);
+    hipLaunchKernelGGL(fill_pattern_kernel, dim3(1024), dim3(256), 0, c->stream, dB, (long)K * N, 0.5);
+    GemmDesc g;
+    g.M = M; g.N = N; g.K = K;
+    g.A = dA; g.transA = transA != 0; g.lda = transA ? M : K;
+    g.B = dB; g.transB = transB != 0; g.ldb = transB ? K : N;
+    g.C = dC; g.ldc = N;
+    g.cfg = cfg;
+    g.prof_name = "gemm_bench";
+    gemm_f64(c, g, c->stream);                      // warm-up
+    hipEvent_t e0 = c->get_event(), e1 = c->get_event();
+    GP_HIP(hipEventRecord(e0, c->stream));
+    for (int i = 0; i < reps; ++i) gemm_f64(c, g, c->stream);
+    GP_HIP(hipEventRecord(e1, c->stream));
+    GP_HIP(hipEventSynchronize(e1));
+    float ms = 0.f;
+    GP_HIP(hipEventElapsedTime(&ms, e0, e1));
+    *ms_out = ms / reps;
+    c->event_pool.push_back(e0);
+    c->event_pool.push_back(e1);
+    return 0;
+    GP_API_END(c)
+}
+
 // K[(x,i),(x',i')] = Ks[x,x'] Kt[i,i'] + sig2n delta
 __global__ void kron_plus_diag_kernel(const double *__restrict__ Ks, int nx, const double *__restrict__ Kt, int nt, double sig2n,
                                       double *__restrict__ K) {
@@ -728,17 +870,10 @@ static int predict_impl(gpcsd_ctx *c, const gpcsd_hparams *hp, const double *z, 
     g2.epi = EPI_DIV_D; g2.D = e.D; g2.rdiv = R; g2.ldd = nt;
     g2.prof_name = "gemm_pred_temporal_div";
     gemm_f64(c, g2, s);
-    GemmDesc g3;                          // W = Bm Qt^T
-    g3.M = nx * R; g3.N = nt; g3.K = nt;
-    g3.A = Bm; g3.lda = nt; g3.B = e.Qt; g3.ldb = nt; g3.transB = true; g3.C = W; g3.ldc = nt;
-    g3.prof_name = "gemm_pred_temporal_back";
-    gemm_f64(c, g3, s);
-    GemmDesc g4;                          // InvY = Qs W    (== invmat @ yvec, gpcsd1d.py:262-265)
-    g4.M = nx; g4.N = (int)RT; g4.K = nx;
-    g4.A = e.Qs; g4.lda = nx; g4.B = W; g4.ldb = RT; g4.C = Bm; g4.ldc = RT;
-    g4.prof_name = "gemm_pred_spatial_back";
-    gemm_f64(c, g4, s);
-    double *InvY = Bm;
+    // invy = (Qs (x) Qt) vec(Bm) (gpcsd1d.py:262-265) is never formed: the cross-covariance contraction
+    //   out_c = Kc^T Qs Bm Qt^T Kt*_c  is re-associated as  (Kc^T Qs) Bm (Qt^T Kt*_c),
+    // i.e. two small (n^3) products M1, Pc and two flat GEMMs, instead of back-projecting to the original bases first
+    // (saves 2 nx^2 nt + 2 nx nt^2 flops per trial; identical up to rounding).
 
     double *dz = c->upload<double>("pred_z", z, (size_t)nz * g.dim);
     double *dts = c->upload<double>("pred_tstar", tstar, ntstar);
@@ -748,6 +883,8 @@ static int predict_impl(gpcsd_ctx *c, const gpcsd_hparams *hp, const double *z, 
     double *comp = c->buf<double>("pred_comp", (size_t)nz * RT);
     double *tot = c->buf<double>("pred_tot", (size_t)nz * RT);
     double *Kts = c->buf<double>("pred_Ktstar", (size_t)ntstar * nt);
+    double *M1 = c->buf<double>("pred_M1", (size_t)nz * nx);
+    double *Pc = c->buf<double>("pred_Pc", (size_t)nt * nt);
     const size_t out_elems = (size_t)nz * RT;
 
     for (int which = 1; which <= 2; ++which) {
@@ -757,19 +894,29 @@ static int predict_impl(gpcsd_ctx *c, const gpcsd_hparams *hp, const double *z, 
                                     : nullptr;
         if (which == 1) build_kphig(c, g, hp->R, hp->eps, hp->ell_s, dz, nz, Kc, s);        // gpcsd1d.py:273
         else build_kphi(c, g, hp->R, hp->eps, hp->ell_s, dz, nz, 0.0, Kc, s);               // gpcsd1d.py:275
-        GemmDesc g5;                      // S[z][(r,t)] = sum_x Kc[x][z] InvY[x][(r,t)]
+        GemmDesc gm;                      // M1[z][x'] = sum_x Kc[x][z] Qs[x][x']
+        gm.M = nz; gm.N = nx; gm.K = nx;
+        gm.A = Kc; gm.lda = nz; gm.transA = true; gm.B = e.Qs; gm.ldb = nx; gm.C = M1; gm.ldc = nx;
+        gm.prof_name = "gemm_pred_M1";
+        gemm_f64(c, gm, s);
+        GemmDesc g5;                      // S[z][(r,i')] = sum_x' M1[z][x'] Bm[x'][(r,i')]
         g5.M = nz; g5.N = (int)RT; g5.K = nx;
-        g5.A = Kc; g5.lda = nz; g5.transA = true; g5.B = InvY; g5.ldb = RT; g5.C = S; g5.ldc = RT;
+        g5.A = M1; g5.lda = nx; g5.B = Bm; g5.ldb = RT; g5.C = S; g5.ldc = RT;
         g5.prof_name = "gemm_pred_cross";
         gemm_f64(c, g5, s);
         k_fill(c, tot, (long)out_elems, 0.0, s);
         for (int cc = 0; cc < C; ++cc) {
             // Ktstar_c = cov_c.compute_Kt(tstar): (ntstar, nt); its FIRST axis is contracted with the training
-            // time index of InvY (reference quirk when tstar != t)      gpcsd1d.py:277-279
+            // time index (reference quirk when tstar != t)      gpcsd1d.py:277-279
             k_temporal_gram(c, 1, &hp->kind[cc], &hp->ell_t[cc], &hp->sigma2_t[cc], dts, ntstar, t, nt, Kts, s);
-            GemmDesc g6;
-            g6.M = nz * R; g6.N = nt; g6.K = ntstar;
-            g6.A = S; g6.lda = nt; g6.B = Kts; g6.ldb = nt; g6.C = comp; g6.ldc = nt; g6.C2 = tot;
+            GemmDesc gp;                  // Pc[i'][t'] = sum_j Qt[j][i'] Ktstar[j][t']
+            gp.M = nt; gp.N = nt; gp.K = ntstar;
+            gp.A = e.Qt; gp.lda = nt; gp.transA = true; gp.B = Kts; gp.ldb = nt; gp.C = Pc; gp.ldc = nt;
+            gp.prof_name = "gemm_pred_Pc";
+            gemm_f64(c, gp, s);
+            GemmDesc g6;                  // out_c[(z,r)][t'] = sum_i' S[(z,r)][i'] Pc[i'][t']
+            g6.M = nz * R; g6.N = nt; g6.K = nt;
+            g6.A = S; g6.lda = nt; g6.B = Pc; g6.ldb = nt; g6.C = comp; g6.ldc = nt; g6.C2 = tot;
             g6.epi = EPI_DUAL;
             g6.prof_name = "gemm_pred_tstar";
             gemm_f64(c, g6, s);

@@ -51,6 +51,14 @@ struct DevBuf {
     size_t bytes = 0;
 };
 
+// An involutive permutation P with P K P = K, as orbit tables on the device: orbit a < ns has representatives
+// (rep_i[a], rep_j[a]); the na pairs come first, fixed points have rep_i == rep_j; orb[row] = orbit of a row,
+// sgn[row] = 0 (fixed point), +1 (first of a pair), -1 (second of a pair).  ns == 0: no symmetry known.
+struct SymDev {
+    int ns = 0, na = 0;
+    const int *rep_i = nullptr, *rep_j = nullptr, *orb = nullptr, *sgn = nullptr;
+};
+
 }  // namespace gpcsd
 
 struct gpcsd_ctx {
@@ -58,6 +66,22 @@ struct gpcsd_ctx {
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;          // second stream: the two eigenproblems are independent
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipStream_t side[4] = {nullptr, nullptr, nullptr, nullptr};   // fork/join branches for independent small chains
+    hipEvent_t side_ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    // Forking the independent back-transformation / merge-GEMM chains onto side streams was measured SLOWER on MI355X
+    // (8.8 vs 6.7 ms per cfg3 step: every cross-stream event wait costs more than the launches it overlaps), so it is
+    // off unless GPCSD_FORK=1.
+    static bool fork_on() {
+        static const bool v = (getenv("GPCSD_FORK") && getenv("GPCSD_FORK")[0] == '1');
+        return v;
+    }
+    hipStream_t side_stream(int i) {
+        if (!side[i]) {
+            GP_HIP(hipStreamCreateWithFlags(&side[i], hipStreamNonBlocking));
+            GP_HIP(hipEventCreateWithFlags(&side_ev[i], hipEventDisableTiming));
+        }
+        return side[i];
+    }
     std::string last_error;
     std::map<std::string, gpcsd::DevBuf> bufs;
     bool prof_on = false;
@@ -78,6 +102,7 @@ struct gpcsd_ctx {
     int geo_nx = 0, ngl1 = 0, ngl2 = 0;     // geometry
     int time_nt = 0;
     double *d_lfp = nullptr;                // [x][r][t]
+    gpcsd::SymDev sym_s, sym_t;             // reflection symmetry of the electrode / time grids (ns == 0: none found)
 
     // ---- device buffers: grow-only, keyed by name, freed in destroy ----
     template <typename T = double>

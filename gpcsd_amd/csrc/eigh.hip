@@ -2,9 +2,15 @@
 //
 //   n <= 64 : two-sided cyclic Jacobi, one workgroup, A and V resident in LDS (the nx = 24 spatial problems of
 //             GPCSD1D; also the leaf solver of the divide-and-conquer path).
-//   n  > 64 : Householder tridiagonalisation + divide & conquer + compact-WY back-transformation (eigh_dc.hip).
-// GPCSD_EIGH=jacobi in the environment forces the single-workgroup Jacobi on global memory for any n (slow; kept as
-// an independent cross-check of the large-n solver).
+//   n  > 64 : Householder tridiagonalisation + divide & conquer + compact-WY back-transformation (eigh_dc.hip,
+//             stedc.hip), all requested problems sharing every launch, replayed as a hipGraph.
+//   symmetry: when the caller knows an involutive permutation P with P K P = K (a uniform time grid makes Kt
+//             centro-symmetric; a probe that is symmetric about the centre of the integration box does the same for
+//             Ks), K is block-diagonalised by the (e_i +- e_Pi)/sqrt(2) basis into a symmetric and an antisymmetric
+//             half-size problem.  The tridiagonalisation is launch-latency bound (one dependent launch per column), so
+//             halving n halves its time; the eigenvalues are the union of the two spectra, merged in ascending order.
+// GPCSD_EIGH=jacobi forces the single-workgroup Jacobi on global memory for any n (slow; independent cross-check).
+// GPCSD_NO_GRAPH=1 disables graph replay, GPCSD_NO_SYMFOLD=1 disables the symmetry folding.
 #include <cstdlib>
 
 #include "jacobi.hpp"
@@ -12,9 +18,7 @@
 
 namespace gpcsd {
 
-struct EigProb;   // eigh_dc.hip
-void eigh_large_pair(gpcsd_ctx *c, double *A0, int n0, double *w0, double *Z0, const char *tag0, double *A1, int n1, double *w1,
-                     double *Z1, const char *tag1, int *d_status, hipStream_t s);
+void eigh_large_multi(gpcsd_ctx *c, const EigReq *reqs, int count, int *d_status, hipStream_t s);   // eigh_dc.hip
 
 template <int NT>
 __global__ __launch_bounds__(NT) void jacobi_lds_kernel(const double *__restrict__ Ag, int n, double *evals, double *evecs,
@@ -40,13 +44,21 @@ __global__ __launch_bounds__(NT) void jacobi_global_kernel(double *A, double *V,
     jacobi_body<NT>(A, n, V, n, n, evals, evecs, n, status, cs, pq, red);
 }
 
+static bool env_flag(const char *name, const char *value) {
+    const char *e = getenv(name);
+    return e && std::string(e) == value;
+}
 static bool force_jacobi() {
-    static int v = -1;
-    if (v < 0) {
-        const char *e = getenv("GPCSD_EIGH");
-        v = (e && std::string(e) == "jacobi") ? 1 : 0;
-    }
-    return v == 1;
+    static const bool v = env_flag("GPCSD_EIGH", "jacobi");
+    return v;
+}
+static bool graphs_enabled() {
+    static const bool v = !env_flag("GPCSD_NO_GRAPH", "1");
+    return v;
+}
+static bool symfold_enabled() {
+    static const bool v = !env_flag("GPCSD_NO_SYMFOLD", "1");
+    return v;
 }
 
 static void eigh_jacobi(gpcsd_ctx *c, double *A, int n, double *evals, double *evecs, int *d_status, hipStream_t s,
@@ -63,41 +75,139 @@ static void eigh_jacobi(gpcsd_ctx *c, double *A, int n, double *evals, double *e
     GP_HIP(hipGetLastError());
 }
 
-static void eigh_pair_enqueue(gpcsd_ctx *c, double *A0, int n0, double *w0, double *Z0, double *A1, int n1, double *w1,
-                              double *Z1, int *d_status, hipStream_t s) {
-    const bool small0 = n0 <= JACOBI_LDS_MAX || force_jacobi();
-    const bool small1 = n1 <= JACOBI_LDS_MAX || force_jacobi();
-    if (n0 > 0 && small0) eigh_jacobi(c, A0, n0, w0, Z0, d_status, s, "p0");
-    if (n1 > 0 && small1) eigh_jacobi(c, A1, n1, w1, Z1, d_status, s, "p1");
-    const bool big0 = n0 > 0 && !small0, big1 = n1 > 0 && !small1;
-    if (big0 || big1)
-        eigh_large_pair(c, big0 ? A0 : nullptr, big0 ? n0 : 0, w0, Z0, "p0", big1 ? A1 : nullptr, big1 ? n1 : 0, w1, Z1, "p1",
-                        d_status, s);
-}
-
-static bool graphs_enabled() {
-    static int v = -1;
-    if (v < 0) {
-        const char *e = getenv("GPCSD_NO_GRAPH");
-        v = (e && e[0] == '1') ? 0 : 1;
+// ------------------------------------------------------------------------------------------------------------------
+// symmetry folding
+// ------------------------------------------------------------------------------------------------------------------
+// orbit a < ns has representatives (rep_i[a], rep_j[a]); pairs come first (a < na), fixed points have rep_i == rep_j.
+//   Ksym[a][b] = wa wb sum_{r in {i,j}} sum_{c in {k,l}} K[r][c]   (w = 1/sqrt2 for a pair, 1 for a fixed point)
+//   Kanti[a][b] = 1/2 (K[i][k] - K[i][l] - K[j][k] + K[j][l])      (pairs only)
+__global__ __launch_bounds__(256) void sym_fold_kernel(const double *__restrict__ K, int n, SymDev sy, double *__restrict__ Ksym,
+                                                       double *__restrict__ Kanti) {
+    const long e = blockIdx.x * 256L + threadIdx.x;
+    const int ns = sy.ns, na = sy.na;
+    if (e >= (long)ns * ns) return;
+    const int a = (int)(e / ns), b = (int)(e % ns);
+    const int i = sy.rep_i[a], j = sy.rep_j[a], k = sy.rep_i[b], l = sy.rep_j[b];
+    const double kik = K[(long)i * n + k];
+    double ssum = kik, asum = kik;
+    if (l != k) {
+        const double v = K[(long)i * n + l];
+        ssum += v;
+        asum -= v;
     }
-    return v == 1;
+    if (j != i) {
+        const double v = K[(long)j * n + k];
+        ssum += v;
+        asum -= v;
+        if (l != k) {
+            const double v2 = K[(long)j * n + l];
+            ssum += v2;
+            asum += v2;
+        }
+    }
+    const double isq2 = 0.70710678118654752440;
+    const double wa = (i == j) ? 1.0 : isq2, wb = (k == l) ? 1.0 : isq2;
+    Ksym[e] = wa * wb * ssum;
+    if (a < na && b < na) Kanti[(long)a * na + b] = 0.5 * asum;
 }
 
-// The large-n path is ~700 dependent launches with nothing decided on the host (deflation counts stay on the
+// merge the two ascending spectra and expand the half-size eigenvectors: Z[:, rank] from (Us | Ua)
+__global__ __launch_bounds__(256) void sym_unfold_kernel(int n, SymDev sy, const double *__restrict__ ws,
+                                                         const double *__restrict__ Us, const double *__restrict__ wa,
+                                                         const double *__restrict__ Ua, double *__restrict__ w,
+                                                         double *__restrict__ Z) {
+    const int ns = sy.ns, na = sy.na;
+    const int col = blockIdx.x;                 // 0..ns-1: symmetric eigenvectors, ns..n-1: antisymmetric
+    const bool is_sym = col < ns;
+    const int cc = is_sym ? col : col - ns;
+    const double val = is_sym ? ws[cc] : wa[cc];
+    // stable merge rank: symmetric entries go first on ties
+    int lo = 0, hi = is_sym ? na : ns;
+    const double *other = is_sym ? wa : ws;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        const bool before = is_sym ? (other[mid] < val) : (other[mid] <= val);
+        if (before) lo = mid + 1; else hi = mid;
+    }
+    const int rank = cc + lo;
+    if (threadIdx.x == 0) w[rank] = val;
+    const double isq2 = 0.70710678118654752440;
+    for (int row = threadIdx.x; row < n; row += 256) {
+        const int a = sy.orb[row];
+        const int sg = sy.sgn[row];             // 0 fixed point, +1 first of a pair, -1 second of a pair
+        double v;
+        if (is_sym) v = Us[(long)a * ns + cc] * (sg == 0 ? 1.0 : isq2);
+        else v = (sg == 0) ? 0.0 : Ua[(long)a * na + cc] * isq2 * (double)sg;
+        Z[(long)row * n + rank] = v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// drivers
+// ------------------------------------------------------------------------------------------------------------------
+static void eigh_pair_enqueue(gpcsd_ctx *c, double *A0, int n0, double *w0, double *Z0, const SymDev *sym0, double *A1, int n1,
+                              double *w1, double *Z1, const SymDev *sym1, int *d_status, hipStream_t s) {
+    double *A[2] = {A0, A1}, *w[2] = {w0, w1}, *Z[2] = {Z0, Z1};
+    const int n[2] = {n0, n1};
+    const SymDev *sym[2] = {sym0, sym1};
+    EigReq large[MAX_EIG_BATCH];
+    int nlarge = 0;
+    struct Fold {
+        bool on = false;
+        double *ws, *Us, *wa, *Ua;
+    } fold[2];
+    static const char *tags[2][3] = {{"p0", "p0s", "p0a"}, {"p1", "p1s", "p1a"}};
+    auto submit = [&](double *Am, int nm, double *wm, double *Zm, const char *tag) {
+        if (nm <= 0) return;
+        if (nm <= JACOBI_LDS_MAX || force_jacobi()) eigh_jacobi(c, Am, nm, wm, Zm, d_status, s, tag);
+        else {
+            large[nlarge].A = Am; large[nlarge].n = nm; large[nlarge].w = wm; large[nlarge].Z = Zm; large[nlarge].tag = tag;
+            ++nlarge;
+        }
+    };
+    for (int p = 0; p < 2; ++p) {
+        if (n[p] <= 0) continue;
+        const SymDev *sy = sym[p];
+        if (sy && sy->ns > 0 && sy->ns + sy->na == n[p] && n[p] > JACOBI_LDS_MAX && symfold_enabled() && !force_jacobi()) {
+            const int ns = sy->ns, na = sy->na;
+            const std::string T = std::string("fold_") + tags[p][0] + "_";
+            double *Ks = c->buf<double>(T + "Ks", (size_t)ns * ns), *Ka = c->buf<double>(T + "Ka", (size_t)std::max(na, 1) * na);
+            fold[p].on = true;
+            fold[p].ws = c->buf<double>(T + "ws", ns);
+            fold[p].Us = c->buf<double>(T + "Us", (size_t)ns * ns);
+            fold[p].wa = c->buf<double>(T + "wa", std::max(na, 1));
+            fold[p].Ua = c->buf<double>(T + "Ua", (size_t)std::max(na, 1) * na);
+            hipLaunchKernelGGL(sym_fold_kernel, dim3(ceil_div((long)ns * ns, 256)), dim3(256), 0, s, (const double *)A[p], n[p],
+                               *sy, Ks, Ka);
+            submit(Ks, ns, fold[p].ws, fold[p].Us, tags[p][1]);
+            submit(Ka, na, fold[p].wa, fold[p].Ua, tags[p][2]);
+        } else {
+            submit(A[p], n[p], w[p], Z[p], tags[p][0]);
+        }
+    }
+    if (nlarge) eigh_large_multi(c, large, nlarge, d_status, s);
+    for (int p = 0; p < 2; ++p)
+        if (fold[p].on)
+            hipLaunchKernelGGL(sym_unfold_kernel, dim3(n[p]), dim3(256), 0, s, n[p], *sym[p], (const double *)fold[p].ws,
+                               (const double *)fold[p].Us, (const double *)fold[p].wa, (const double *)fold[p].Ua, w[p], Z[p]);
+    GP_HIP(hipGetLastError());
+}
+
+// The large-n path is hundreds of dependent launches with nothing decided on the host (deflation counts stay on the
 // device), so it replays as a hipGraph: first call eager (allocates workspaces), second call captured, later calls
 // replayed.  A graph is retired whenever any context buffer is (re)allocated, since it holds raw device pointers.
-void eigh_pair_device(gpcsd_ctx *c, double *A0, int n0, double *w0, double *Z0, double *A1, int n1, double *w1, double *Z1,
-                      int *d_status, hipStream_t s) {
+void eigh_pair_device(gpcsd_ctx *c, double *A0, int n0, double *w0, double *Z0, const SymDev *sym0, double *A1, int n1,
+                      double *w1, double *Z1, const SymDev *sym1, int *d_status, hipStream_t s) {
     GP_REQUIRE(n0 <= JACOBI_MAX_N && n1 <= JACOBI_MAX_N, -3, "eigh: n=%d/%d exceeds %d", n0, n1, JACOBI_MAX_N);
     const bool any_large = !force_jacobi() && (n0 > JACOBI_LDS_MAX || n1 > JACOBI_LDS_MAX);
     if (!any_large || c->prof_on || !graphs_enabled()) {
-        eigh_pair_enqueue(c, A0, n0, w0, Z0, A1, n1, w1, Z1, d_status, s);
+        eigh_pair_enqueue(c, A0, n0, w0, Z0, sym0, A1, n1, w1, Z1, sym1, d_status, s);
         return;
     }
-    char key[256];
-    snprintf(key, sizeof(key), "eigh|%p|%d|%p|%p|%p|%d|%p|%p|%p|%p", (void *)A0, n0, (void *)w0, (void *)Z0, (void *)A1, n1,
-             (void *)w1, (void *)Z1, (void *)d_status, (void *)s);
+    char key[320];
+    snprintf(key, sizeof(key), "eigh|%p|%d|%p|%p|%p|%d|%p|%d|%p|%p|%p|%d|%p|%p", (void *)A0, n0, (void *)w0, (void *)Z0,
+             (void *)(sym0 ? sym0->rep_i : nullptr), sym0 ? sym0->ns : 0, (void *)A1, n1, (void *)w1, (void *)Z1,
+             (void *)(sym1 ? sym1->rep_i : nullptr), sym1 ? sym1->ns : 0, (void *)d_status, (void *)s);
     gpcsd_ctx::GraphSlot &g = c->graphs[key];
     if (g.exec && g.epoch == c->alloc_epoch) {
         GP_HIP(hipGraphLaunch(g.exec, s));
@@ -111,7 +221,7 @@ void eigh_pair_device(gpcsd_ctx *c, double *A0, int n0, double *w0, double *Z0, 
         hipGraph_t graph = nullptr;
         GP_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
         try {
-            eigh_pair_enqueue(c, A0, n0, w0, Z0, A1, n1, w1, Z1, d_status, s);
+            eigh_pair_enqueue(c, A0, n0, w0, Z0, sym0, A1, n1, w1, Z1, sym1, d_status, s);
         } catch (...) {
             (void)hipStreamEndCapture(s, &graph);
             if (graph) (void)hipGraphDestroy(graph);
@@ -128,7 +238,7 @@ void eigh_pair_device(gpcsd_ctx *c, double *A0, int n0, double *w0, double *Z0, 
             return;
         }
     }
-    eigh_pair_enqueue(c, A0, n0, w0, Z0, A1, n1, w1, Z1, d_status, s);
+    eigh_pair_enqueue(c, A0, n0, w0, Z0, sym0, A1, n1, w1, Z1, sym1, d_status, s);
     g.seen_epoch = c->alloc_epoch;
 }
 
@@ -136,7 +246,7 @@ void eigh_device(gpcsd_ctx *c, double *A, int n, double *evals, double *evecs, i
                  const char *tag) {
     GP_REQUIRE(n >= 1 && n <= JACOBI_MAX_N, -3, "eigh: n=%d outside [1,%d]", n, JACOBI_MAX_N);
     (void)tag;
-    eigh_pair_device(c, A, n, evals, evecs, nullptr, 0, nullptr, nullptr, d_status, s);
+    eigh_pair_device(c, A, n, evals, evecs, nullptr, nullptr, 0, nullptr, nullptr, nullptr, d_status, s);
 }
 
 }  // namespace gpcsd

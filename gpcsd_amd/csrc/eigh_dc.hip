@@ -376,30 +376,52 @@ void eigh_large_batch(gpcsd_ctx *c, EigProb *probs, int count, int *d_status, hi
         }
         stedc_batch_device(c, sp, count, d_status, s);
     }
-    for (int i = 0; i < count; ++i) {
-        EigProb &p = probs[i];
-        {
-            ProfScope ps(c, "eigh_backtransform", 0.0, s);
-            ormtr_device(c, p.sp.V, p.sp.tau, p.n, p.Z, s, "eig_" + p.tag + "_");
+    // The back-transformations are independent chains of small GEMMs: fork one branch per problem (parallel branches
+    // of the captured graph; concurrent streams when run eagerly) and join.
+    if (wy_fused_supported(nmax)) {
+        ProfScope ps(c, "eigh_backtransform", 0.0, s);
+        WyBatch wb;
+        for (int i = 0; i < count; ++i) {
+            EigProb &p = probs[i];
+            const int nrefl = p.n - 2, P = ceil_div(nrefl, WY_NB);
+            wb.p[i].V = p.sp.V; wb.p[i].tau = p.sp.tau; wb.p[i].Z = p.Z;
+            wb.p[i].T = c->buf<double>("eig_" + p.tag + "_wyT", (size_t)P * WY_NB * WY_NB);
+            wb.p[i].n = p.n; wb.p[i].npanels = P; wb.p[i].nrefl = nrefl;
         }
-        hipLaunchKernelGGL(scale_vec_kernel, dim3(ceil_div(p.n, 256)), dim3(256), 0, s, p.w, p.n, (const double *)p.amax);
+        wy_batch_device(c, wb, count, s);
+        for (int i = 0; i < count; ++i)
+            hipLaunchKernelGGL(scale_vec_kernel, dim3(ceil_div(probs[i].n, 256)), dim3(256), 0, s, probs[i].w, probs[i].n,
+                               (const double *)probs[i].amax);
+    } else {
+        ProfScope ps(c, "eigh_backtransform", 0.0, s);
+        if (count > 1 && c->fork_on()) GP_HIP(hipEventRecord(c->ev_fork, s));
+        for (int i = 0; i < count; ++i) {
+            EigProb &p = probs[i];
+            hipStream_t bs = s;
+            if (i > 0 && c->fork_on()) {
+                bs = c->side_stream(i);
+                GP_HIP(hipStreamWaitEvent(bs, c->ev_fork, 0));
+            }
+            ormtr_device(c, p.sp.V, p.sp.tau, p.n, p.Z, bs, "eig_" + p.tag + "_");
+            hipLaunchKernelGGL(scale_vec_kernel, dim3(ceil_div(p.n, 256)), dim3(256), 0, bs, p.w, p.n, (const double *)p.amax);
+            if (i > 0 && c->fork_on()) {
+                GP_HIP(hipEventRecord(c->side_ev[i], bs));
+                GP_HIP(hipStreamWaitEvent(s, c->side_ev[i], 0));
+            }
+        }
     }
     GP_HIP(hipGetLastError());
 }
 
-void eigh_large_pair(gpcsd_ctx *c, double *A0, int n0, double *w0, double *Z0, const char *tag0, double *A1, int n1, double *w1,
-                     double *Z1, const char *tag1, int *d_status, hipStream_t s) {
-    EigProb probs[2];
-    int count = 0;
-    if (A0 && n0 > 0) {
-        probs[count].A = A0; probs[count].n = n0; probs[count].w = w0; probs[count].Z = Z0; probs[count].tag = tag0;
-        ++count;
+void eigh_large_multi(gpcsd_ctx *c, const EigReq *reqs, int count, int *d_status, hipStream_t s) {
+    static_assert(MAX_EIG_BATCH <= MAX_BATCH, "batch limits");
+    GP_REQUIRE(count >= 1 && count <= MAX_BATCH, -3, "eigh batch size %d outside [1,%d]", count, MAX_BATCH);
+    EigProb probs[MAX_BATCH];
+    for (int i = 0; i < count; ++i) {
+        probs[i].A = reqs[i].A; probs[i].n = reqs[i].n; probs[i].w = reqs[i].w; probs[i].Z = reqs[i].Z;
+        probs[i].tag = reqs[i].tag;
     }
-    if (A1 && n1 > 0) {
-        probs[count].A = A1; probs[count].n = n1; probs[count].w = w1; probs[count].Z = Z1; probs[count].tag = tag1;
-        ++count;
-    }
-    if (count) eigh_large_batch(c, probs, count, d_status, s);
+    eigh_large_batch(c, probs, count, d_status, s);
 }
 
 }  // namespace gpcsd

@@ -288,12 +288,20 @@ void gemm_f64(gpcsd_ctx *c, const GemmDesc &g, hipStream_t s) {
     k.partials = nullptr;
     k.dyn = g.dyn;
 
-    auto tiles = [&](int b) { return (long)ceil_div(g.M, b) * ceil_div(g.N, b) * g.batch; };
-    int bt;                                   // block tile edge
-    if (tiles(128) >= 192) bt = 128;          // enough 128^2 tiles to cover the 256 CUs
-    else if (tiles(64) >= 96) bt = 64;
-    else bt = 32;
-    const int tm = ceil_div(g.M, bt), tn = ceil_div(g.N, bt);
+    // Tile configurations (block tile, waves, K depth).  Large flat GEMMs want many resident workgroups per CU so the
+    // hardware dispatcher balances the tail; tiny GEMMs are latency-bound and want deep K tiles.
+    //   1: 128x128, 8 waves, BK16   2: 128x64, 4 waves, BK8    3: 64x64, 4 waves, BK16
+    //   4: 64x64, 4 waves, BK32     5: 32x32, 4 waves, BK64    6: 128x64, 4 waves, BK16
+    static const int CFG_BM[7] = {0, 128, 128, 64, 64, 32, 128}, CFG_BN[7] = {0, 128, 64, 64, 64, 32, 64};
+    int cfg = g.cfg;
+    if (cfg <= 0 || cfg > 6) {
+        auto tiles = [&](int bm, int bn) { return (long)ceil_div(g.M, bm) * ceil_div(g.N, bn) * g.batch; };
+        // measured on MI355X (tools/gemm_sweep.py): 64x64 tiles reach the same ~40 TF/s as 128x128 on the large
+        // flat GEMMs and balance the tail better; everything smaller is latency-bound and wants 32x32 / BK64
+        cfg = (tiles(64, 64) >= 512) ? 3 : 5;
+    }
+    const int bm = CFG_BM[cfg], bn = CFG_BN[cfg];
+    const int tm = ceil_div(g.M, bm), tn = ceil_div(g.N, bn);
     k.tiles_n = tn;
     dim3 grid(tm * tn, 1, g.batch);
     const long nblocks = (long)tm * tn * g.batch;
@@ -302,11 +310,14 @@ void gemm_f64(gpcsd_ctx *c, const GemmDesc &g, hipStream_t s) {
     const double flops = 2.0 * g.M * (double)g.N * g.K * g.batch;
     {
         ProfScope ps(c, g.prof_name, flops, s);
-        // 128x128: 8 waves (4x2), each 32x64 -> 64 accumulator VGPRs, two waves per SIMD from one workgroup
-        // the small-tile configurations are latency-bound (few MFMAs per K tile), so they take 64-deep K tiles
-        if (bt == 128) launch_trans<4, 2, 2, 4, 16>(k, g.transA, g.transB, g.epi, grid, s);
-        else if (bt == 64) launch_trans<2, 2, 2, 2, 32>(k, g.transA, g.transB, g.epi, grid, s);
-        else launch_trans<2, 2, 1, 1, 64>(k, g.transA, g.transB, g.epi, grid, s);
+        switch (cfg) {
+            case 1: launch_trans<4, 2, 2, 4, 16>(k, g.transA, g.transB, g.epi, grid, s); break;
+            case 2: launch_trans<2, 2, 4, 2, 8>(k, g.transA, g.transB, g.epi, grid, s); break;
+            case 3: launch_trans<2, 2, 2, 2, 16>(k, g.transA, g.transB, g.epi, grid, s); break;
+            case 4: launch_trans<2, 2, 2, 2, 32>(k, g.transA, g.transB, g.epi, grid, s); break;
+            case 5: launch_trans<2, 2, 1, 1, 64>(k, g.transA, g.transB, g.epi, grid, s); break;
+            default: launch_trans<2, 2, 4, 2, 16>(k, g.transA, g.transB, g.epi, grid, s); break;
+        }
         GP_HIP(hipGetLastError());
     }
     if (g.epi == EPI_QUAD || g.epi == EPI_GRAD) {

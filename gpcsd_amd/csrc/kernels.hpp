@@ -36,6 +36,7 @@ struct GemmDesc {
     long ldd = 0;
     double *quad_out = nullptr;   // EPI_QUAD: one double (EPI_GRAD: two), written by the final reduce
     const int *dyn = nullptr;     // device int per batch entry: effective N = K = dyn[batch] (tiles beyond it exit)
+    int cfg = 0;                  // 0 = choose the tile configuration automatically, 1..6 = force (see gemm_f64.hip)
     const char *prof_name = "gemm_f64";
 };
 
@@ -73,10 +74,28 @@ void k_fill(gpcsd_ctx *c, double *p, long n, double v, hipStream_t s);
 // eigenvectors in COLUMNS (numpy.linalg.eigh convention).  A is destroyed.  status: device int (0 ok).
 void eigh_device(gpcsd_ctx *c, double *A, int n, double *evals, double *evecs, int *d_status, hipStream_t s,
                  const char *tag);
-// Two independent problems at once (Ks and Kt of one likelihood evaluation): the launch-per-column
-// tridiagonalisation is batched so both share every launch.  Either n may be <= 0 to skip.
-void eigh_pair_device(gpcsd_ctx *c, double *A0, int n0, double *w0, double *Z0, double *A1, int n1, double *w1, double *Z1,
-                      int *d_status, hipStream_t s);
+constexpr int MAX_EIG_BATCH = 4;
+struct EigReq {
+    double *A;
+    int n;
+    double *w, *Z;
+    const char *tag;
+};
+// Two independent problems at once (Ks and Kt of one likelihood evaluation): every stage is batched so they share
+// launches; with a known symmetry each splits into two half-size problems first.  Either n may be <= 0 to skip.
+void eigh_pair_device(gpcsd_ctx *c, double *A0, int n0, double *w0, double *Z0, const SymDev *sym0, double *A1, int n1,
+                      double *w1, double *Z1, const SymDev *sym1, int *d_status, hipStream_t s);
+// fused compact-WY back-transformation (wy.hip): all panels of all problems in two launches
+struct WyProb {
+    const double *V, *tau;   // reflectors by rows ((n + 64) x n, zero padded), tau (n + 64)
+    double *T, *Z;           // T factors (npanels x 64 x 64 workspace), eigenvector matrix updated in place
+    int n, npanels, nrefl;
+};
+struct WyBatch {
+    WyProb p[MAX_EIG_BATCH];
+};
+bool wy_fused_supported(int nmax);
+void wy_batch_device(gpcsd_ctx *c, const WyBatch &b, int count, hipStream_t s);
 // stages of the large-n solver, exposed for tests / diagnostics
 void sytrd_device(gpcsd_ctx *c, double *A, int n, double *d, double *e, double *V, double *tau, hipStream_t s);
 void stedc_device(gpcsd_ctx *c, const double *d, const double *e, int n, double *w, double *Z, int *d_status,

@@ -778,12 +778,19 @@ void stedc_batch_device(gpcsd_ctx *c, StedcProb *probs, int count, int *d_status
             const int tj = ceil_div(maxN, 64);
             hipLaunchKernelGGL(dc_build_U_kernel, dim3(tj * ceil_div(maxN, 16), max_seg, count), dim3(256), 0, s, L, tj);
             GP_HIP(hipGetLastError());
-            for (int p = 0; p < count; ++p) {                 // W = Q2 (N x K) U (K x K), K read on the device
+            // W = Q2 (N x K) U (K x K), K read on the device; one fork/join branch per problem
+            if (count > 1 && c->fork_on()) GP_HIP(hipEventRecord(c->ev_fork, s));
+            for (int p = 0; p < count; ++p) {
                 const long own = (long)plans[p].levels.size() - (long)(nlevels - li);
                 if (own < 0) continue;
                 const auto &lv = plans[p].levels[own];
                 const DcWork &w = L.w[p];
                 const int n = w.n;
+                hipStream_t bs = s;
+                if (p > 0 && c->fork_on()) {
+                    bs = c->side_stream(p);
+                    GP_HIP(hipStreamWaitEvent(bs, c->ev_fork, 0));
+                }
                 for (int m = 0; m < (int)lv.size(); ++m) {
                     const Seg &sg = lv[m];
                     const int N = sg.hi - sg.lo;
@@ -794,7 +801,11 @@ void stedc_batch_device(gpcsd_ctx *c, StedcProb *probs, int count, int *d_status
                     g.C = w.Ww + (long)sg.lo * n + sg.lo; g.ldc = n;
                     g.dyn = w.Kdyn + m;
                     g.prof_name = "gemm_dc_merge";
-                    gemm_f64(c, g, s);
+                    gemm_f64(c, g, bs);
+                }
+                if (p > 0 && c->fork_on()) {
+                    GP_HIP(hipEventRecord(c->side_ev[p], bs));
+                    GP_HIP(hipStreamWaitEvent(s, c->side_ev[p], 0));
                 }
             }
             hipLaunchKernelGGL(dc_rank_kernel, dim3(1, max_seg, count), dim3(256), 0, s, L);

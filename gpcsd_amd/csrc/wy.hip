@@ -1,0 +1,162 @@
+// Back-transformation of the tridiagonal eigenvectors, Z <- (H_0 H_1 ... H_{n-3}) Z, for several independent problems in
+// TWO launches (stage 3 of the large-n eigensolver; LAPACK's dormtr behind numpy.linalg.eigh).
+//
+// Reflectors are grouped in panels of 64: Q_p = I - V_p^T T_p V_p (V_p holds the reflectors by rows), and
+// Q Z = Q_0 (Q_1 (... (Q_{P-1} Z))).  Columns of Z are independent, so one workgroup keeps a 16-column slab of Z in LDS
+// and walks ALL panels on it with fp64 MFMA 16x16x4 -- no launch per panel, no traffic for Z between panels:
+//     W1 = V_p Zc (64x16),  W2 = T_p W1,  Zc -= V_p^T W2.
+// The T factors come from a preparation launch (one workgroup per panel and problem): G = V_p V_p^T on MFMA, then
+// T = (diag(1/tau) + striu(G))^{-1} by wave-parallel back substitution (closed form of the compact-WY T factor).
+// Every launch-bound GEMM chain this replaces cost ~8 us per panel and problem.
+#include <algorithm>
+
+#include "devutil.hpp"
+#include "kernels.hpp"
+
+namespace gpcsd {
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+
+constexpr int WY_NB = 64;
+constexpr int WY_ZC = 16;             // columns of Z per workgroup (one MFMA fragment wide)
+constexpr int WY_LD = WY_ZC + 2;      // LDS row stride: 18*i mod 32 gives distinct even slots for the b64 fragment reads
+
+// G = V_p V_p^T (16 waves, one 16x16 fragment each), then T by back substitution (4 columns per wave).
+__global__ __launch_bounds__(1024) void wy_prep_kernel(WyBatch b) {
+    const WyProb &P = b.p[blockIdx.y];
+    const int p = blockIdx.x;
+    if (p >= P.npanels) return;
+    const int n = P.n;
+    __shared__ double g[WY_NB][WY_NB + 1];
+    __shared__ double st[WY_NB];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int fr = lane & 15, fq = lane >> 4;
+    const double *__restrict__ Vp = P.V + (long)p * WY_NB * n;
+    {
+        const int fa = wid >> 2, fb = wid & 3;
+        const double *__restrict__ ra = Vp + (long)(16 * fa + fr) * n;
+        const double *__restrict__ rb = Vp + (long)(16 * fb + fr) * n;
+        d4 acc = {0.0, 0.0, 0.0, 0.0};
+        const int kstart = (p * WY_NB) & ~3;               // reflector k is zero up to column k
+        for (int k0 = kstart; k0 < n; k0 += 4) {
+            const int k = k0 + fq;
+            const double a = (k < n) ? ra[k] : 0.0;
+            const double bb = (k < n) ? rb[k] : 0.0;
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bb, acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) g[16 * fa + fq + 4 * r][16 * fb + fr] = acc[r];
+    }
+    if (tid < WY_NB) {
+        const int kk = p * WY_NB + tid;
+        st[tid] = (kk < P.nrefl) ? P.tau[kk] : 0.0;
+    }
+    __syncthreads();
+    // column c of T solves (diag(1/tau) + striu(G)) x = e_c; lane l carries the running right-hand side b_l
+    for (int q = 0; q < 4; ++q) {
+        const int c = wid * 4 + q;
+        double bv = (lane == c) ? 1.0 : 0.0, x = 0.0;
+        for (int j = c; j >= 0; --j) {
+            const double xj = st[j] * __shfl(bv, j, 64);
+            if (lane == j) x = xj;
+            if (lane < j) bv -= g[lane][j] * xj;
+        }
+        P.T[(long)p * WY_NB * WY_NB + (long)lane * WY_NB + c] = (lane <= c) ? x : 0.0;
+    }
+}
+
+// one workgroup = 16 columns of Z resident in LDS, all panels applied in sequence
+__global__ __launch_bounds__(256) void wy_apply_kernel(WyBatch b) {
+    const WyProb &P = b.p[blockIdx.y];
+    const int n = P.n;
+    const int c0 = blockIdx.x * WY_ZC;
+    if (c0 >= n) return;
+    extern __shared__ double smem[];
+    double *Zs = smem;                         // [n][WY_LD]
+    double *W1 = Zs + (size_t)n * WY_LD;       // [64][WY_LD]
+    double *W2 = W1 + WY_NB * WY_LD;           // [64][WY_LD]
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int fr = lane & 15, fq = lane >> 4;
+    for (int idx = tid; idx < n * WY_ZC; idx += 256) {
+        const int r = idx / WY_ZC, j = idx % WY_ZC;
+        Zs[r * WY_LD + j] = (c0 + j < n) ? P.Z[(long)r * n + c0 + j] : 0.0;
+    }
+    __syncthreads();
+    const int nfrag = (n + 15) / 16;
+    for (int p = P.npanels - 1; p >= 0; --p) {
+        const double *__restrict__ Vp = P.V + (long)p * WY_NB * n;
+        const double *__restrict__ Tp = P.T + (long)p * WY_NB * WY_NB;
+        const int kstart = (p * WY_NB) & ~3;
+        // W1 = V_p Zc : wave w owns panel rows 16w .. 16w+15
+        {
+            const double *__restrict__ ra = Vp + (long)(16 * wid + fr) * n;
+            d4 acc = {0.0, 0.0, 0.0, 0.0};
+            for (int k0 = kstart; k0 < n; k0 += 4) {
+                const int k = k0 + fq;
+                const double a = (k < n) ? ra[k] : 0.0;
+                const double bb = (k < n) ? Zs[k * WY_LD + fr] : 0.0;
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bb, acc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) W1[(16 * wid + fq + 4 * r) * WY_LD + fr] = acc[r];
+        }
+        __syncthreads();
+        // W2 = T_p W1
+        {
+            const double *__restrict__ ta = Tp + (long)(16 * wid + fr) * WY_NB;
+            d4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll 4
+            for (int k0 = 0; k0 < WY_NB; k0 += 4) {
+                const int k = k0 + fq;
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ta[k], W1[k * WY_LD + fr], acc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) W2[(16 * wid + fq + 4 * r) * WY_LD + fr] = acc[r];
+        }
+        __syncthreads();
+        // Zc -= V_p^T W2 : rows below the panel's first reflector only
+        for (int fm = (p * WY_NB) / 16 + wid; fm < nfrag; fm += 4) {
+            const int m = 16 * fm + fr;
+            d4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll 4
+            for (int k0 = 0; k0 < WY_NB; k0 += 4) {
+                const int k = k0 + fq;
+                const double a = (m < n) ? Vp[(long)k * n + m] : 0.0;
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, W2[k * WY_LD + fr], acc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = 16 * fm + fq + 4 * r;
+                if (row < n) Zs[row * WY_LD + fr] -= acc[r];
+            }
+        }
+        __syncthreads();
+    }
+    for (int idx = tid; idx < n * WY_ZC; idx += 256) {
+        const int r = idx / WY_ZC, j = idx % WY_ZC;
+        if (c0 + j < n) P.Z[(long)r * n + c0 + j] = Zs[r * WY_LD + j];
+    }
+}
+
+bool wy_fused_supported(int nmax) { return ((size_t)nmax * WY_LD + 2 * WY_NB * WY_LD) * sizeof(double) <= 160 * 1024; }
+
+void wy_batch_device(gpcsd_ctx *c, const WyBatch &b, int count, hipStream_t s) {
+    int maxP = 0, nmax = 0;
+    for (int i = 0; i < count; ++i) {
+        maxP = std::max(maxP, b.p[i].npanels);
+        nmax = std::max(nmax, b.p[i].n);
+    }
+    if (maxP == 0) return;
+    const size_t sh = ((size_t)nmax * WY_LD + 2 * WY_NB * WY_LD) * sizeof(double);
+    static bool attr_set = false;
+    if (!attr_set) {
+        GP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(wy_apply_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   160 * 1024));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(wy_prep_kernel, dim3(maxP, count), dim3(1024), 0, s, b);
+    hipLaunchKernelGGL(wy_apply_kernel, dim3(ceil_div(nmax, WY_ZC), count), dim3(256), sh, s, b);
+    GP_HIP(hipGetLastError());
+}
+
+}  // namespace gpcsd

@@ -166,6 +166,9 @@ int gpcsd_prof_get(gpcsd_ctx *ctx, const char *name, double *ms, long *count, do
 int gpcsd_prof_names(gpcsd_ctx *ctx, char *buf, int buflen);
 /* back-to-back v_mfma_f64_16x16x4_f64 microbenchmark: measured TFLOP/s */
 int gpcsd_mfma_f64_peak(gpcsd_ctx *ctx, double *tflops);
+/* average ms per launch of the fp64 MFMA GEMM on device-resident pseudo-random operands; cfg 0 = automatic tile
+ * configuration, 1..6 = forced (tuning aid) */
+int gpcsd_gemm_bench(gpcsd_ctx *ctx, int transA, int transB, int M, int N, int K, int cfg, int reps, double *ms_out);
 /* streaming copy microbenchmark over `bytes` bytes: measured GB/s (read+write counted) */
 int gpcsd_hbm_copy_peak(gpcsd_ctx *ctx, long bytes, double *gbs);
 
