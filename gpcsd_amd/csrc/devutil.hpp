@@ -8,20 +8,42 @@ constexpr int EIG_MAXN = 1024;                       // LDS vectors of the eigen
 constexpr int MAX_BATCH = 4;                         // independent eigenproblems sharing launches
 constexpr double EPS_U = 1.1102230246251565e-16;     // unit roundoff (LAPACK dlamch('E'))
 
+// Wave-wide reductions, result valid in every lane.  __shfl_xor on a double compiles to two ds_bpermute_b32 per stage
+// (12 LDS-crossbar round trips per reduction, ~600 cycles); the DPP forms below stay in the VALU: four v_mov_dpp
+// stages fold each 16-lane row, then the four row totals are combined through v_readlane (8x fewer cycles, same
+// fixed association for every call -> bit-reproducible).
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xF, 0xF, false);
+    hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xF, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double lane_get(double v, int l) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), l), hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+    return __hiloint2double(hi, lo);
+}
+// DPP controls: 0xB1 = quad_perm [1,0,3,2], 0x4E = quad_perm [2,3,0,1], 0x141 = row_half_mirror, 0x140 = row_mirror
 __device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-    return v;
+    v += dpp_mov<0xB1>(v);
+    v += dpp_mov<0x4E>(v);
+    v += dpp_mov<0x141>(v);
+    v += dpp_mov<0x140>(v);
+    return (lane_get(v, 0) + lane_get(v, 16)) + (lane_get(v, 32) + lane_get(v, 48));
 }
 __device__ __forceinline__ double wave_prod(double v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v *= __shfl_xor(v, off, 64);
-    return v;
+    v *= dpp_mov<0xB1>(v);
+    v *= dpp_mov<0x4E>(v);
+    v *= dpp_mov<0x141>(v);
+    v *= dpp_mov<0x140>(v);
+    return (lane_get(v, 0) * lane_get(v, 16)) * (lane_get(v, 32) * lane_get(v, 48));
 }
 __device__ __forceinline__ double wave_max(double v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_xor(v, off, 64));
-    return v;
+    v = fmax(v, dpp_mov<0xB1>(v));
+    v = fmax(v, dpp_mov<0x4E>(v));
+    v = fmax(v, dpp_mov<0x141>(v));
+    v = fmax(v, dpp_mov<0x140>(v));
+    return fmax(fmax(lane_get(v, 0), lane_get(v, 16)), fmax(lane_get(v, 32), lane_get(v, 48)));
 }
 
 // Reductions over a workgroup of NW waves; the result is valid in every thread.  red: >= NW doubles of LDS.

@@ -68,6 +68,7 @@ struct SytrdProb {
     double *tau, *d, *e;  // n each
     double *y0, *y1;      // ping-pong A v products
     int n;
+    int k_tail;           // first column handled by the in-LDS tail kernel (n - 1: no tail)
 };
 struct SytrdBatch {
     SytrdProb p[MAX_BATCH];
@@ -80,7 +81,7 @@ template <int JQ>
 __global__ __launch_bounds__(256) void sytrd_step_kernel(SytrdBatch b, int k) {
     const SytrdProb &P = b.p[blockIdx.y];
     const int n = P.n;
-    if (k > n - 2) return;
+    if (k >= P.k_tail) return;
     const int row0 = k + 1 + blockIdx.x * SY_RPW;
     if (row0 >= n) return;
     constexpr int PQ = JQ / 4 + 1;
@@ -205,7 +206,7 @@ __global__ __launch_bounds__(256) void sytrd_step_kernel(SytrdBatch b, int k) {
 // d[n-1] after the final step: the single trailing element lives in the buffer written by step n-2
 __global__ void sytrd_last_diag_kernel(SytrdBatch b) {
     const SytrdProb &P = b.p[blockIdx.x];
-    if (threadIdx.x != 0 || P.n < 1) return;
+    if (threadIdx.x != 0 || P.n < 1 || P.k_tail < P.n - 1) return;
     const int n = P.n;
     if (n == 1) {
         P.d[0] = P.A0[0];
@@ -219,8 +220,115 @@ __global__ void sytrd_last_diag_kernel(SytrdBatch b) {
     if (n >= 2) P.tau[n - 2] = 0.0;
 }
 
+// The last SY_TAIL columns of every problem in ONE launch: the trailing block (<= 113 x 113) lives in LDS, so a column
+// costs a few workgroup barriers (~0.7 us) instead of a dependent launch (~4 us).  512 threads, 4 per trailing row.
+constexpr int SY_TAIL = 112;
+constexpr int SY_TLD = SY_TAIL + 2;          // LDS row stride (even + 1 would also do; 114 keeps b64 column walks 2-way at worst)
+
+__global__ __launch_bounds__(512) void sytrd_tail_kernel(SytrdBatch b) {
+    const SytrdProb &P = b.p[blockIdx.x];
+    const int n = P.n, k0 = P.k_tail;
+    if (k0 >= n - 1) return;
+    const int T = n - k0;                    // rows / columns k0 .. n-1
+    extern __shared__ double sm[];
+    double *As = sm;                         // [T][SY_TLD]
+    double *v = As + (SY_TAIL + 1) * SY_TLD, *w = v + 128, *y = w + 128, *red = y + 128;
+    const int tid = threadIdx.x;
+    const double *__restrict__ Ain = (k0 & 1) ? P.A1 : P.A0;
+    const double *__restrict__ yin = (k0 & 1) ? P.y1 : P.y0;
+    // pending rank-2 update of step k0-1
+    if (k0 > 0) {
+        const double *__restrict__ vp = P.V + (long)(k0 - 1) * n;
+        const double taup = P.tau[k0 - 1];
+        double pv = 0.0, py = 0.0;
+        if (tid < T) {
+            pv = vp[k0 + tid];
+            py = yin[k0 + tid];
+        }
+        const double dot = block_sum<8>(pv * py, red);
+        const double cc = 0.5 * taup * taup * dot;
+        if (tid < T) {
+            v[tid] = pv;
+            w[tid] = taup * py - cc * pv;
+        }
+    } else if (tid < T) {
+        v[tid] = 0.0;
+        w[tid] = 0.0;
+    }
+    __syncthreads();
+    for (int idx = tid; idx < T * T; idx += 512) {
+        const int i = idx / T, j = idx % T;
+        As[i * SY_TLD + j] = Ain[(long)(k0 + i) * n + k0 + j] - v[i] * w[j] - w[i] * v[j];
+    }
+    __syncthreads();
+    const int grp = tid >> 2, sub = tid & 3;             // 4 threads per trailing row
+    for (int kk = 0; kk < T - 1; ++kk) {
+        const int k = k0 + kk;
+        const int m = T - kk - 1;                        // trailing size below the pivot
+        const double *prow = As + kk * SY_TLD;
+        double part = 0.0;
+        for (int j = kk + 2 + tid; j < T; j += 512) part += prow[j] * prow[j];
+        const double xnorm2 = block_sum<8>(part, red);
+        const double dk = prow[kk], alpha = prow[kk + 1];
+        double tau = 0.0, beta = alpha, scal = 0.0;
+        if (m >= 2 && xnorm2 > 0.0) {
+            beta = -copysign(sqrt(alpha * alpha + xnorm2), alpha);
+            tau = (beta - alpha) / beta;
+            scal = 1.0 / (alpha - beta);
+        }
+        double *vrow = P.V + (long)k * n + k0;
+        for (int j = kk + 1 + tid; j < T; j += 512) {
+            const double vj = (j == kk + 1) ? 1.0 : prow[j] * scal;
+            v[j] = vj;
+            vrow[j] = vj;
+        }
+        if (tid == 0) {
+            P.d[k] = dk;
+            P.e[k] = beta;
+            P.tau[k] = tau;
+        }
+        __syncthreads();
+        if (tau != 0.0) {
+            // y = A22 v  (rows kk+1 .. T-1)
+            const int i = kk + 1 + grp;
+            double acc = 0.0;
+            if (i < T) {
+                const double *ar = As + i * SY_TLD;
+                for (int j = kk + 1 + sub; j < T; j += 4) acc += ar[j] * v[j];
+            }
+            acc += dpp_mov<0xB1>(acc);               // fold the 4 threads of a row (quad permutes stay in the VALU)
+            acc += dpp_mov<0x4E>(acc);
+            if (i < T && sub == 0) y[i] = acc;
+            __syncthreads();
+            double pd = 0.0;
+            for (int j = kk + 1 + tid; j < T; j += 512) pd += y[j] * v[j];
+            const double dot = block_sum<8>(pd, red);
+            const double cc = 0.5 * tau * tau * dot;
+            for (int j = kk + 1 + tid; j < T; j += 512) w[j] = tau * y[j] - cc * v[j];
+            __syncthreads();
+            if (i < T) {
+                double *ar = As + i * SY_TLD;
+                const double vi = v[i], wi = w[i];
+                for (int j = kk + 1 + sub; j < T; j += 4) ar[j] -= vi * w[j] + wi * v[j];
+            }
+            __syncthreads();
+        }
+    }
+    if (tid == 0) {
+        P.d[n - 1] = As[(T - 1) * SY_TLD + (T - 1)];
+        P.e[n - 1] = 0.0;
+        P.tau[n - 1] = 0.0;
+    }
+}
+
 static void sytrd_batch_launch(gpcsd_ctx *c, const SytrdBatch &b, int count, int nmax, hipStream_t s) {
-    for (int k = 0; k <= nmax - 2; ++k) {
+    int klast = -1;                                        // last column handled by per-column launches
+    bool any_tail = false, all_tail = true;
+    for (int i = 0; i < count; ++i) {
+        klast = std::max(klast, b.p[i].k_tail - 1);
+        if (b.p[i].k_tail < b.p[i].n - 1) any_tail = true; else all_tail = false;
+    }
+    for (int k = 0; k <= klast; ++k) {
         const int m = nmax - k - 1;
         dim3 grid(ceil_div(m, SY_RPW), count);
         if (m <= 128) hipLaunchKernelGGL(sytrd_step_kernel<2>, grid, dim3(256), 0, s, b, k);
@@ -228,7 +336,17 @@ static void sytrd_batch_launch(gpcsd_ctx *c, const SytrdBatch &b, int count, int
         else if (m <= 512) hipLaunchKernelGGL(sytrd_step_kernel<8>, grid, dim3(256), 0, s, b, k);
         else hipLaunchKernelGGL(sytrd_step_kernel<16>, grid, dim3(256), 0, s, b, k);
     }
-    hipLaunchKernelGGL(sytrd_last_diag_kernel, dim3(count), dim3(64), 0, s, b);
+    if (any_tail) {
+        const size_t sh = ((size_t)(SY_TAIL + 1) * SY_TLD + 3 * 128 + 32) * sizeof(double);
+        static bool attr_set = false;
+        if (!attr_set) {
+            GP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(sytrd_tail_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(sytrd_tail_kernel, dim3(count), dim3(512), sh, s, b);
+    }
+    if (!all_tail) hipLaunchKernelGGL(sytrd_last_diag_kernel, dim3(count), dim3(64), 0, s, b);
     GP_HIP(hipGetLastError());
 }
 
@@ -320,6 +438,10 @@ static void prep_problem(gpcsd_ctx *c, EigProb &p, hipStream_t s) {
     const std::string T = "eig_" + p.tag + "_";
     p.amax = c->buf<double>(T + "amax", 2 + AMAX_PARTS);
     p.sp.n = n;
+    {
+        static const bool no_tail = getenv("GPCSD_NO_TAIL") && getenv("GPCSD_NO_TAIL")[0] == '1';
+        p.sp.k_tail = no_tail ? n - 1 : std::max(0, n - 1 - 112);      // SY_TAIL columns finish inside one workgroup
+    }
     p.sp.A0 = c->buf<double>(T + "A0", nn);
     p.sp.A1 = c->buf<double>(T + "A1", nn);
     p.sp.V = c->buf<double>(T + "V", (size_t)(n + WY_NB) * n);
@@ -328,18 +450,71 @@ static void prep_problem(gpcsd_ctx *c, EigProb &p, hipStream_t s) {
     p.sp.e = c->buf<double>(T + "e", n);
     p.sp.y0 = c->buf<double>(T + "y0", n);
     p.sp.y1 = c->buf<double>(T + "y1", n);
-    hipLaunchKernelGGL(absmax_partial_kernel, dim3(AMAX_PARTS), dim3(256), 0, s, (const double *)p.A, (long)nn, p.amax);
-    hipLaunchKernelGGL(scale_copy_kernel, dim3(128), dim3(256), 0, s, (const double *)p.A, (long)nn, p.amax, p.sp.A0);
-    GP_HIP(hipMemsetAsync(p.sp.V, 0, (size_t)(n + WY_NB) * n * sizeof(double), s));
-    GP_HIP(hipMemsetAsync(p.sp.tau, 0, (size_t)(n + WY_NB) * sizeof(double), s));
+    (void)nn;
+    (void)s;
+}
+
+// scaling, copy into the ping-pong buffer and zeroing of the reflector storage for ALL problems in two launches
+struct PrepBatch {
+    const double *A[MAX_BATCH];
+    double *amax[MAX_BATCH];
+    SytrdProb sp[MAX_BATCH];
+    double *w[MAX_BATCH];       // eigenvalue outputs (for the final rescale)
+};
+__global__ __launch_bounds__(256) void absmax_partial_batch_kernel(PrepBatch b) {
+    __shared__ double red[4];
+    const int p = blockIdx.y;
+    const long n2 = (long)b.sp[p].n * b.sp[p].n;
+    const double *__restrict__ A = b.A[p];
+    double m = 0.0;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n2; i += (long)gridDim.x * 256) m = fmax(m, fabs(A[i]));
+    m = block_max256(m, red);
+    if (threadIdx.x == 0) b.amax[p][2 + blockIdx.x] = m;
+}
+__global__ __launch_bounds__(256) void scale_copy_zero_batch_kernel(PrepBatch b) {
+    const int p = blockIdx.y;
+    const SytrdProb &P = b.sp[p];
+    const long n = P.n, n2 = n * n;
+    double *amax = b.amax[p];
+    double m = 0.0;
+    for (int i = 0; i < AMAX_PARTS; ++i) m = fmax(m, amax[2 + i]);
+    m = (m > 0.0 && m < 1e300) ? m : 1.0;
+    if (blockIdx.x == 0 && threadIdx.x == 0) amax[0] = m;
+    const double inv = 1.0 / m;
+    const double *__restrict__ A = b.A[p];
+    const long stride = (long)gridDim.x * 256, i0 = blockIdx.x * 256L + threadIdx.x;
+    for (long i = i0; i < n2; i += stride) P.A0[i] = A[i] * inv;
+    const long nv = (n + WY_NB) * n;
+    for (long i = i0; i < nv; i += stride) P.V[i] = 0.0;
+    for (long i = i0; i < n + WY_NB; i += stride) P.tau[i] = 0.0;
+}
+__global__ __launch_bounds__(256) void scale_vec_batch_kernel(PrepBatch b) {
+    const int p = blockIdx.y;
+    const int n = b.sp[p].n;
+    const double m = b.amax[p][0];
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) b.w[p][i] *= m;
+}
+
+static PrepBatch prep_batch_launch(gpcsd_ctx *c, EigProb *probs, int count, hipStream_t s) {
+    PrepBatch pb;
+    for (int i = 0; i < count; ++i) {
+        prep_problem(c, probs[i], s);
+        pb.A[i] = probs[i].A;
+        pb.amax[i] = probs[i].amax;
+        pb.sp[i] = probs[i].sp;
+        pb.w[i] = probs[i].w;
+    }
+    hipLaunchKernelGGL(absmax_partial_batch_kernel, dim3(AMAX_PARTS, count), dim3(256), 0, s, pb);
+    hipLaunchKernelGGL(scale_copy_zero_batch_kernel, dim3(128, count), dim3(256), 0, s, pb);
     GP_HIP(hipGetLastError());
+    return pb;
 }
 
 void sytrd_device(gpcsd_ctx *c, double *A, int n, double *d, double *e, double *V, double *tau, hipStream_t s) {
     GP_REQUIRE(n >= 1 && n <= EIG_MAXN, -3, "sytrd: n=%d outside [1,%d]", n, EIG_MAXN);
     EigProb p;
     p.A = A; p.n = n; p.tag = "dbg"; p.w = nullptr; p.Z = nullptr;
-    prep_problem(c, p, s);
+    prep_batch_launch(c, &p, 1, s);
     SytrdBatch b;
     b.p[0] = p.sp;
     sytrd_batch_launch(c, b, 1, n, s);
@@ -359,10 +534,10 @@ void eigh_large_batch(gpcsd_ctx *c, EigProb *probs, int count, int *d_status, hi
     int nmax = 0;
     for (int i = 0; i < count; ++i) {
         GP_REQUIRE(probs[i].n > 2 && probs[i].n <= EIG_MAXN, -3, "eigh(large): n=%d outside (2,%d]", probs[i].n, EIG_MAXN);
-        prep_problem(c, probs[i], s);
-        b.p[i] = probs[i].sp;
         nmax = std::max(nmax, probs[i].n);
     }
+    const PrepBatch pb = prep_batch_launch(c, probs, count, s);
+    for (int i = 0; i < count; ++i) b.p[i] = probs[i].sp;
     {
         ProfScope ps(c, "eigh_sytrd", 0.0, s);
         sytrd_batch_launch(c, b, count, nmax, s);
@@ -389,9 +564,7 @@ void eigh_large_batch(gpcsd_ctx *c, EigProb *probs, int count, int *d_status, hi
             wb.p[i].n = p.n; wb.p[i].npanels = P; wb.p[i].nrefl = nrefl;
         }
         wy_batch_device(c, wb, count, s);
-        for (int i = 0; i < count; ++i)
-            hipLaunchKernelGGL(scale_vec_kernel, dim3(ceil_div(probs[i].n, 256)), dim3(256), 0, s, probs[i].w, probs[i].n,
-                               (const double *)probs[i].amax);
+        hipLaunchKernelGGL(scale_vec_batch_kernel, dim3(ceil_div(nmax, 256), count), dim3(256), 0, s, pb);
     } else {
         ProfScope ps(c, "eigh_backtransform", 0.0, s);
         if (count > 1 && c->fork_on()) GP_HIP(hipEventRecord(c->ev_fork, s));

@@ -44,6 +44,7 @@ struct DcWork {            // per problem, all device pointers
     const double *d0, *e;  // the input tridiagonal
     int *Kdyn;             // K per merge of the current level (device ints for the dynamic-size GEMM)
     const int *tbl;        // leaf_lo | bounds | per-level Seg triples
+    double *wout, *Zout;   // caller's outputs
 };
 
 struct DcLevel {           // kernel argument of one level
@@ -61,18 +62,36 @@ __device__ __forceinline__ Seg load_seg(const DcWork &w, int off, int m) {
 // ------------------------------------------------------------------------------------------------------------------
 // tears + leaves
 // ------------------------------------------------------------------------------------------------------------------
-__global__ void dc_tear_kernel(DcLevel L) {
+// Tears, plus zeroing of both ping-pong eigenvector matrices: a merge reads the off-diagonal blocks between its two
+// halves, which no earlier level writes (blocks are nested, so zeros outside the blocks of a level survive until they
+// are merged).
+__global__ __launch_bounds__(256) void dc_tear_kernel(DcLevel L) {
     const DcWork &w = L.w[blockIdx.y];
     const int n = w.n, nb = L.aux[blockIdx.y];
     const int *bounds = w.tbl + L.seg_off[blockIdx.y];
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    double v = w.d0[i];
-    for (int t = 0; t < nb; ++t) {
-        const int a = bounds[t];
-        if (a - 1 == i || a == i) v -= fabs(w.e[a - 1]);
+    const long stride = (long)gridDim.x * 256, i0 = blockIdx.x * 256L + threadIdx.x;
+    const long nn = (long)n * n;
+    for (long i = i0; i < nn; i += stride) {
+        w.Qcur[i] = 0.0;
+        w.Qnext[i] = 0.0;
     }
-    w.dwork[i] = v;
+    for (long i = i0; i < n; i += stride) {
+        double v = w.d0[i];
+        for (int t = 0; t < nb; ++t) {
+            const int a = bounds[t];
+            if (a - 1 == i || a == i) v -= fabs(w.e[a - 1]);
+        }
+        w.dwork[i] = v;
+    }
+}
+
+// eigenvalues / eigenvectors of the top level into the caller's arrays, all problems in one launch
+__global__ __launch_bounds__(256) void dc_output_kernel(DcLevel L) {
+    const DcWork &w = L.w[blockIdx.y];
+    const long n = w.n, nn = n * n;
+    const long stride = (long)gridDim.x * 256, i0 = blockIdx.x * 256L + threadIdx.x;
+    for (long i = i0; i < nn; i += stride) w.Zout[i] = w.Qcur[i];
+    for (long i = i0; i < n; i += stride) w.wout[i] = w.dcur[i];
 }
 
 // one wave per leaf: dense leaf matrix in LDS -> Jacobi -> dcur[lo:hi], Qcur diagonal block
@@ -720,10 +739,8 @@ static DcWork make_work(gpcsd_ctx *c, const StedcProb &p, const DcPlan &plan, hi
         cached_n = n;
     }
     w.tbl = dtbl;
-    // both ping-pong matrices start at zero: a merge reads the off-diagonal blocks between its two halves, which no
-    // earlier level writes (blocks are nested, so zeros outside the blocks of a level survive until they are merged)
-    GP_HIP(hipMemsetAsync(w.Qcur, 0, nn * sizeof(double), s));
-    GP_HIP(hipMemsetAsync(w.Qnext, 0, nn * sizeof(double), s));
+    w.wout = p.w;
+    w.Zout = p.Z;
     return w;
 }
 
@@ -746,7 +763,7 @@ void stedc_batch_device(gpcsd_ctx *c, StedcProb *probs, int count, int *d_status
         L.seg_off[p] = plans[p].off_bounds;
         L.aux[p] = (int)plans[p].bounds.size();
     }
-    hipLaunchKernelGGL(dc_tear_kernel, dim3(ceil_div(nmax, 256), count), dim3(256), 0, s, L);
+    hipLaunchKernelGGL(dc_tear_kernel, dim3(64, count), dim3(256), 0, s, L);
     for (int p = 0; p < count; ++p) L.aux[p] = (int)plans[p].leaf_lo.size() - 1;
     hipLaunchKernelGGL(dc_leaf_kernel, dim3(max_leaves, count), dim3(64), 0, s, L, d_status);
     GP_HIP(hipGetLastError());
@@ -818,11 +835,7 @@ void stedc_batch_device(gpcsd_ctx *c, StedcProb *probs, int count, int *d_status
             std::swap(L.w[p].Qcur, L.w[p].Qnext);
         }
     }
-    for (int p = 0; p < count; ++p) {
-        const size_t nn = (size_t)probs[p].n * probs[p].n;
-        hipLaunchKernelGGL(copy_vec_kernel, dim3(1), dim3(256), 0, s, (const double *)L.w[p].dcur, probs[p].w, (long)probs[p].n);
-        hipLaunchKernelGGL(copy_vec_kernel, dim3(256), dim3(256), 0, s, (const double *)L.w[p].Qcur, probs[p].Z, (long)nn);
-    }
+    hipLaunchKernelGGL(dc_output_kernel, dim3(64, count), dim3(256), 0, s, L);
     GP_HIP(hipGetLastError());
 }
 
