@@ -223,7 +223,7 @@ __global__ void sytrd_last_diag_kernel(SytrdBatch b) {
 // The last SY_TAIL columns of every problem in ONE launch: the trailing block (<= 113 x 113) lives in LDS, so a column
 // costs a few workgroup barriers (~0.7 us) instead of a dependent launch (~4 us).  512 threads, 4 per trailing row.
 constexpr int SY_TAIL = 112;
-constexpr int SY_TLD = SY_TAIL + 2;          // LDS row stride (even + 1 would also do; 114 keeps b64 column walks 2-way at worst)
+constexpr int SY_TLD = 132;                  // LDS row stride, = 4 mod 32: the 8 rows x 4 doubles a half-wave reads hit 64 distinct banks
 
 __global__ __launch_bounds__(512) void sytrd_tail_kernel(SytrdBatch b) {
     const SytrdProb &P = b.p[blockIdx.x];
@@ -233,6 +233,7 @@ __global__ __launch_bounds__(512) void sytrd_tail_kernel(SytrdBatch b) {
     extern __shared__ double sm[];
     double *As = sm;                         // [T][SY_TLD]
     double *v = As + (SY_TAIL + 1) * SY_TLD, *w = v + 128, *y = w + 128, *red = y + 128;
+    double *sd = red + 32, *se = sd + 128, *st = se + 128;      // d, e, tau of the tail columns (flushed at the end)
     const int tid = threadIdx.x;
     const double *__restrict__ Ain = (k0 & 1) ? P.A1 : P.A0;
     const double *__restrict__ yin = (k0 & 1) ? P.y1 : P.y0;
@@ -262,13 +263,18 @@ __global__ __launch_bounds__(512) void sytrd_tail_kernel(SytrdBatch b) {
     }
     __syncthreads();
     const int grp = tid >> 2, sub = tid & 3;             // 4 threads per trailing row
+    __shared__ double s_xn;
+    double xnorm2;
+    {
+        double part = 0.0;
+        for (int j = 2 + tid; j < T; j += 512) part += As[j] * As[j];
+        xnorm2 = block_sum<8>(part, red);
+    }
+    // Four barriers per column: publish v | (y and v.y via one block reduction) | update + next column's norm.
     for (int kk = 0; kk < T - 1; ++kk) {
         const int k = k0 + kk;
         const int m = T - kk - 1;                        // trailing size below the pivot
         const double *prow = As + kk * SY_TLD;
-        double part = 0.0;
-        for (int j = kk + 2 + tid; j < T; j += 512) part += prow[j] * prow[j];
-        const double xnorm2 = block_sum<8>(part, red);
         const double dk = prow[kk], alpha = prow[kk + 1];
         double tau = 0.0, beta = alpha, scal = 0.0;
         if (m >= 2 && xnorm2 > 0.0) {
@@ -276,43 +282,67 @@ __global__ __launch_bounds__(512) void sytrd_tail_kernel(SytrdBatch b) {
             tau = (beta - alpha) / beta;
             scal = 1.0 / (alpha - beta);
         }
-        double *vrow = P.V + (long)k * n + k0;
-        for (int j = kk + 1 + tid; j < T; j += 512) {
-            const double vj = (j == kk + 1) ? 1.0 : prow[j] * scal;
-            v[j] = vj;
-            vrow[j] = vj;
-        }
+        // No global traffic inside the loop (a barrier would wait for the stores): the reflector replaces the consumed
+        // pivot row in LDS, LAPACK-style, and d / e / tau collect in LDS; everything is flushed once after the loop.
+        for (int j = kk + 1 + tid; j < T; j += 512) v[j] = (j == kk + 1) ? 1.0 : prow[j] * scal;
         if (tid == 0) {
-            P.d[k] = dk;
-            P.e[k] = beta;
-            P.tau[k] = tau;
+            sd[kk] = dk;
+            se[kk] = beta;
+            st[kk] = tau;
         }
+        (void)k;
         __syncthreads();
-        if (tau != 0.0) {
-            // y = A22 v  (rows kk+1 .. T-1)
-            const int i = kk + 1 + grp;
+        for (int j = kk + 1 + tid; j < T; j += 512) As[kk * SY_TLD + j] = v[j];
+        const bool upd = (tau != 0.0);
+        const int i = kk + 1 + grp;
+        double vi = 0.0, wi = 0.0, cc = 0.0;
+        if (upd) {
+            // y = A22 v (rows kk+1 .. T-1, 4 threads per row); v.y from the same registers
             double acc = 0.0;
             if (i < T) {
                 const double *ar = As + i * SY_TLD;
+#pragma unroll 8
                 for (int j = kk + 1 + sub; j < T; j += 4) acc += ar[j] * v[j];
             }
-            acc += dpp_mov<0xB1>(acc);               // fold the 4 threads of a row (quad permutes stay in the VALU)
+            acc += dpp_mov<0xB1>(acc);                   // fold the 4 threads of a row (quad permutes stay in the VALU)
             acc += dpp_mov<0x4E>(acc);
             if (i < T && sub == 0) y[i] = acc;
-            __syncthreads();
-            double pd = 0.0;
-            for (int j = kk + 1 + tid; j < T; j += 512) pd += y[j] * v[j];
-            const double dot = block_sum<8>(pd, red);
-            const double cc = 0.5 * tau * tau * dot;
-            for (int j = kk + 1 + tid; j < T; j += 512) w[j] = tau * y[j] - cc * v[j];
-            __syncthreads();
+            const double dot = block_sum<8>((i < T && sub == 0) ? acc * v[i] : 0.0, red);   // its barriers publish y
+            cc = 0.5 * tau * tau * dot;
             if (i < T) {
-                double *ar = As + i * SY_TLD;
-                const double vi = v[i], wi = w[i];
-                for (int j = kk + 1 + sub; j < T; j += 4) ar[j] -= vi * w[j] + wi * v[j];
+                vi = v[i];
+                wi = tau * y[i] - cc * vi;
             }
-            __syncthreads();
         }
+        // rank-2 update with w_j = tau y_j - cc v_j formed on the fly, and ||next pivot row||^2 by that row's threads
+        double xn = 0.0;
+        if (i < T) {
+            double *ar = As + i * SY_TLD;
+#pragma unroll 8
+            for (int j = kk + 1 + sub; j < T; j += 4) {
+                double a = ar[j];
+                if (upd) {
+                    const double vj = v[j];
+                    a -= vi * (tau * y[j] - cc * vj) + wi * vj;
+                    ar[j] = a;
+                }
+                if (j >= kk + 3) xn += a * a;
+            }
+        }
+        xn += dpp_mov<0xB1>(xn);
+        xn += dpp_mov<0x4E>(xn);
+        if (i == kk + 1 && sub == 0) s_xn = xn;
+        __syncthreads();
+        xnorm2 = s_xn;
+    }
+    for (int idx = tid; idx < (T - 1) * T; idx += 512) {
+        const int kk = idx / T, j = idx % T;
+        if (j > kk) P.V[(long)(k0 + kk) * n + k0 + j] = As[kk * SY_TLD + j];
+    }
+    for (int kk = tid; kk < T - 1; kk += 512) {
+        P.d[k0 + kk] = sd[kk];
+        P.e[k0 + kk] = se[kk];
+        P.tau[k0 + kk] = st[kk];
     }
     if (tid == 0) {
         P.d[n - 1] = As[(T - 1) * SY_TLD + (T - 1)];
@@ -337,11 +367,11 @@ static void sytrd_batch_launch(gpcsd_ctx *c, const SytrdBatch &b, int count, int
         else hipLaunchKernelGGL(sytrd_step_kernel<16>, grid, dim3(256), 0, s, b, k);
     }
     if (any_tail) {
-        const size_t sh = ((size_t)(SY_TAIL + 1) * SY_TLD + 3 * 128 + 32) * sizeof(double);
+        const size_t sh = ((size_t)(SY_TAIL + 1) * SY_TLD + 6 * 128 + 32) * sizeof(double);
         static bool attr_set = false;
         if (!attr_set) {
             GP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(sytrd_tail_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
             attr_set = true;
         }
         hipLaunchKernelGGL(sytrd_tail_kernel, dim3(count), dim3(512), sh, s, b);
