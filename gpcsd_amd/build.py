@@ -15,7 +15,10 @@ OBJDIR = os.path.join(CSRC, "_build")
 LIB = os.path.join(HERE, "libgpcsd_hip.so")
 SOURCES = ["capi.hip", "gemm_f64.hip", "gram.hip", "eigh.hip", "eigh_dc.hip", "stedc.hip", "wy.hip", "grad.hip", "chol.hip"]
 ARCH = "gfx950"
-FLAGS = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=" + ARCH, "-fno-fast-math", "-Wall", "-Wno-unused-function"]
+# -amdgpu-mfma-vgpr-form: keep MFMA accumulators in VGPRs; the default AGPR form made hipcc copy all of them AGPR<->VGPR
+# around every K tile of the GEMM main loop (64 v_accvgpr moves + s_nop per 16 MFMAs)
+FLAGS = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=" + ARCH, "-fno-fast-math", "-Wall", "-Wno-unused-function",
+         "-mllvm", "-amdgpu-mfma-vgpr-form=1"]
 # the elementwise Gram builders keep the reference's operation order exactly (no FMA contraction)
 EXTRA = {"gram.hip": ["-ffp-contract=off"]}
 

@@ -47,7 +47,11 @@ struct GemmK {
 };
 
 // One operand tile: BO "outer" rows/cols (M or N side) x BK, staged by NT threads.  KMAJOR: global storage is [K][O].
-// Loads are branch-free: out-of-range elements read a clamped (always valid) address and are zeroed by a select.
+// Each thread owns PER_THREAD fixed (o, k) slots of the tile.  Their global pointers are formed once (outer index
+// clamped into range: a duplicated edge row only feeds accumulators the epilogue never stores) and advance by a
+// constant per K tile, so a full tile costs one global_load per slot and NO address arithmetic or select -- the
+// loaded registers are first touched by the LDS store after the MFMA block, which is what lets the loads overlap the
+// MFMAs.  Only the last, partial K tile takes the clamped + zero-masked path.
 template <int BO, bool KMAJOR, int NT, int BK>
 struct Tile {
     static constexpr int LD_OK = BK + 2;       // (BK+2) mod 32 == 2 for BK = 16, 64: rows land on distinct even slots
@@ -58,40 +62,51 @@ struct Tile {
     __device__ static __forceinline__ int lds_index(int o, int k) {
         return KMAJOR ? k * (BO + PAD_KO) + o : o * LD_OK + k;
     }
-    __device__ static __forceinline__ void gload(double (&r)[PER_THREAD], const double *__restrict__ base, long ld, int o0,
-                                                 int k0, int Olim, int K, int tid) {
-#pragma unroll
-        for (int i = 0; i < PER_THREAD; ++i) {
-            const int e = tid + NT * i;
-            int o, k;
-            if (KMAJOR) {
-                k = e / BO;
-                o = e % BO;
-            } else {
-                o = e / BK;
-                k = e % BK;
-            }
-            const int go = o0 + o, gk = k0 + k;
-            const bool ok = (go < Olim) && (gk < K);
-            const int goc = go < Olim ? go : Olim - 1, gkc = gk < K ? gk : K - 1;
-            const long idx = KMAJOR ? (long)gkc * ld + goc : (long)goc * ld + gkc;
-            const double v = base[idx];
-            r[i] = ok ? v : 0.0;
+    __device__ static __forceinline__ void slot(int tid, int i, int &o, int &k) {
+        const int e = tid + NT * i;
+        if (KMAJOR) {
+            k = e / BO;
+            o = e % BO;
+        } else {
+            o = e / BK;
+            k = e % BK;
         }
     }
-    __device__ static __forceinline__ void sstore(const double (&r)[PER_THREAD], double *lds, int tid) {
+    // pointers of this thread's slots in K tile 0
+    __device__ static __forceinline__ void setup(const double *(&p)[PER_THREAD], const double *__restrict__ base, long ld,
+                                                 int o0, int Olim, int tid) {
 #pragma unroll
         for (int i = 0; i < PER_THREAD; ++i) {
-            const int e = tid + NT * i;
             int o, k;
-            if (KMAJOR) {
-                k = e / BO;
-                o = e % BO;
-            } else {
-                o = e / BK;
-                k = e % BK;
-            }
-            lds[lds_index(o, k)] = r[i];
+            slot(tid, i, o, k);
+            const int go = o0 + o, goc = go < Olim ? go : Olim - 1;
+            p[i] = base + (KMAJOR ? (long)k * ld + goc : (long)goc * ld + k);
+        }
+    }
+    __device__ static __forceinline__ long step(long ld) { return KMAJOR ? (long)BK * ld : (long)BK; }
+    // full tile number kt: plain loads
+    __device__ static __forceinline__ void gload(double (&r)[PER_THREAD], const double *const (&p)[PER_THREAD], long off) {
+#pragma unroll
+        for (int i = 0; i < PER_THREAD; ++i) r[i] = p[i][off];
+    }
+    // partial tile starting at k0: out-of-range k reads the slot's k = K-1 element instead (always valid)
+    __device__ static __forceinline__ void gload_tail(double (&r)[PER_THREAD], const double *const (&p)[PER_THREAD], long ld,
+                                                      int k0, int K, int tid) {
+#pragma unroll
+        for (int i = 0; i < PER_THREAD; ++i) {
+            int o, k;
+            slot(tid, i, o, k);
+            const int gk = k0 + k, gkc = gk < K ? gk : K - 1;
+            r[i] = p[i][KMAJOR ? (long)(gkc - k) * ld : (long)(gkc - k)];
+        }
+    }
+    template <bool MASK>
+    __device__ static __forceinline__ void sstore(const double (&r)[PER_THREAD], double *lds, int k0, int K, int tid) {
+#pragma unroll
+        for (int i = 0; i < PER_THREAD; ++i) {
+            int o, k;
+            slot(tid, i, o, k);
+            lds[lds_index(o, k)] = (!MASK || k0 + k < K) ? r[i] : 0.0;
         }
     }
 };
@@ -111,15 +126,30 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f64_kernel(GemmK g) {
     const int lane = tid & 63;
     const int wid = tid >> 6;
     const int wr = wid / WN, wc = wid % WN;
-    const int tile_m = blockIdx.x / g.tiles_n, tile_n = blockIdx.x % g.tiles_n;
+    // XCD-aware tile order: workgroups are dealt round-robin to the 8 XCDs (private L2 each), so without a remap the
+    // tn tiles that share one A row panel land on 8 different L2s and the panel is fetched 8 times (measured with
+    // FETCH_SIZE: 740 MB read per launch for 156 MB of operands).  Give XCD x the contiguous range of logical tiles
+    // [x*q + min(x,r), ...): a bijection for any grid, and the n-tiles of a panel become L2 neighbours in time.
+    int bx = blockIdx.x;
+    long bz = blockIdx.z;
+    {
+        const int total = gridDim.x * gridDim.z;
+        if (total >= 64) {
+            const int L = blockIdx.z * gridDim.x + blockIdx.x;
+            const int x = L & 7, q = total >> 3, r = total & 7;
+            const int logical = x * q + (x < r ? x : r) + (L >> 3);
+            bz = logical / gridDim.x;
+            bx = logical % gridDim.x;
+        }
+    }
+    const int tile_m = bx / g.tiles_n, tile_n = bx % g.tiles_n;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
     if (g.dyn) {                        // wave-uniform: sizes decided on the device (deflation count)
-        const int kk = g.dyn[blockIdx.z];
+        const int kk = g.dyn[bz];
         g.N = kk;
         g.K = kk;
         if (n0 >= kk) return;
     }
-    const long bz = blockIdx.z;
     const double *__restrict__ A = g.A + bz * g.sA;
     const double *__restrict__ B = g.B + bz * g.sB;
 
@@ -130,24 +160,31 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f64_kernel(GemmK g) {
         for (int j = 0; j < FN; ++j) acc[i][j] = d4{0.0, 0.0, 0.0, 0.0};
 
     double ra[TileA::PER_THREAD], rb[TileB::PER_THREAD];
+    const double *pa[TileA::PER_THREAD], *pb[TileB::PER_THREAD];
+    TileA::setup(pa, A, g.lda, m0, g.M, tid);
+    TileB::setup(pb, B, g.ldb, n0, g.N, tid);
+    const long stepA = TileA::step(g.lda), stepB = TileB::step(g.ldb);
     const int nk = (g.K + BK - 1) / BK;
+    const int nfull = g.K / BK;                  // tiles [0, nfull) are complete
 
-    TileA::gload(ra, A, g.lda, m0, 0, g.M, g.K, tid);
-    TileB::gload(rb, B, g.ldb, n0, 0, g.N, g.K, tid);
-    TileA::sstore(ra, ldsA(0), tid);
-    TileB::sstore(rb, ldsB(0), tid);
+    if (nfull > 0) {
+        TileA::gload(ra, pa, 0);
+        TileB::gload(rb, pb, 0);
+        TileA::template sstore<false>(ra, ldsA(0), 0, g.K, tid);
+        TileB::template sstore<false>(rb, ldsB(0), 0, g.K, tid);
+    } else {
+        TileA::gload_tail(ra, pa, g.lda, 0, g.K, tid);
+        TileB::gload_tail(rb, pb, g.ldb, 0, g.K, tid);
+        TileA::template sstore<true>(ra, ldsA(0), 0, g.K, tid);
+        TileB::template sstore<true>(rb, ldsB(0), 0, g.K, tid);
+    }
     __syncthreads();
 
     const int fr = lane & 15, fq = lane >> 4;
     int cur = 0;
-    for (int kt = 0; kt < nk; ++kt) {
-        const bool more = (kt + 1 < nk);
-        if (more) {
-            TileA::gload(ra, A, g.lda, m0, (kt + 1) * BK, g.M, g.K, tid);
-            TileB::gload(rb, B, g.ldb, n0, (kt + 1) * BK, g.N, g.K, tid);
-        }
-        const double *sa = ldsA(cur);
-        const double *sb = ldsB(cur);
+    auto mma_tile = [&](int buf) {
+        const double *sa = ldsA(buf);
+        const double *sb = ldsB(buf);
 #pragma unroll
         for (int kk = 0; kk < BK / 4; ++kk) {
             const int k = kk * 4 + fq;
@@ -162,13 +199,28 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f64_kernel(GemmK g) {
                 for (int j = 0; j < FN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
         }
-        if (more) {
-            TileA::sstore(ra, ldsA(cur ^ 1), tid);
-            TileB::sstore(rb, ldsB(cur ^ 1), tid);
-        }
+    };
+    // steady state: the next tile is complete -> straight-line loads, MFMAs, LDS stores (no selects, no branches)
+    int kt = 0;
+    for (; kt + 1 < nfull; ++kt) {
+        TileA::gload(ra, pa, (kt + 1) * stepA);
+        TileB::gload(rb, pb, (kt + 1) * stepB);
+        mma_tile(cur);
+        TileA::template sstore<false>(ra, ldsA(cur ^ 1), 0, g.K, tid);
+        TileB::template sstore<false>(rb, ldsB(cur ^ 1), 0, g.K, tid);
         __syncthreads();
         cur ^= 1;
     }
+    if (kt + 1 < nk) {                         // one partial K tile follows
+        TileA::gload_tail(ra, pa, g.lda, (kt + 1) * BK, g.K, tid);
+        TileB::gload_tail(rb, pb, g.ldb, (kt + 1) * BK, g.K, tid);
+        mma_tile(cur);
+        TileA::template sstore<true>(ra, ldsA(cur ^ 1), (kt + 1) * BK, g.K, tid);
+        TileB::template sstore<true>(rb, ldsB(cur ^ 1), (kt + 1) * BK, g.K, tid);
+        __syncthreads();
+        cur ^= 1;
+    }
+    mma_tile(cur);
 
     // ---- epilogue ----
     double qsum = 0.0, qsum2 = 0.0;
@@ -233,7 +285,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f64_kernel(GemmK g) {
                 t += wsum[i];
                 t2 += wsum[WM * WN + i];
             }
-            const long nb = (long)gridDim.x * gridDim.z, me = bz * gridDim.x + blockIdx.x;
+            const long nb = (long)gridDim.x * gridDim.z, me = bz * gridDim.x + bx;
             g.partials[me] = t;
             if (EPI == EPI_GRAD) g.partials[nb + me] = t2;
         }
