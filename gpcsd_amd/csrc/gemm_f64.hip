@@ -17,6 +17,8 @@
 //   [o][k] tiles: stride BK+2 = 18 doubles (18*i mod 32 distinct even slots for the 16 rows of a fragment).
 // f64 MFMA fragment maps (cdna_hip_programming.md section 3): A lane l holds A[l&15][l>>4], B lane l holds
 // B[l>>4][l&15], C/D lane l reg r holds C[(l>>4) + 4r][l&15].
+#include <type_traits>
+
 #include "kernels.hpp"
 
 namespace gpcsd {
@@ -47,67 +49,82 @@ struct GemmK {
 };
 
 // One operand tile: BO "outer" rows/cols (M or N side) x BK, staged by NT threads.  KMAJOR: global storage is [K][O].
-// Each thread owns PER_THREAD fixed (o, k) slots of the tile.  Their global pointers are formed once (outer index
-// clamped into range: a duplicated edge row only feeds accumulators the epilogue never stores) and advance by a
-// constant per K tile, so a full tile costs one global_load per slot and NO address arithmetic or select -- the
-// loaded registers are first touched by the LDS store after the MFMA block, which is what lets the loads overlap the
-// MFMAs.  Only the last, partial K tile takes the clamped + zero-masked path.
+// Each thread owns PER_THREAD fixed (o, k) slots of the tile.
+//
+// On MI355X the fp64 MFMA runs at the plain fp64 vector rate (78.6 TF/s both), i.e. it occupies the SIMD's vector ALU
+// for its 64 cycles, and every other VALU instruction of ANY wave on that SIMD is time taken from the MFMAs (measured:
+// 3.2 VALU per MFMA in the old loop = 72 % MFMA duty).  So the steady-state loop is written to need no VALU at all:
+//   * global loads use a wave-uniform 64-bit tile base (advanced on the scalar ALU) + loop-invariant 32-bit per-thread
+//     byte offsets (outer index clamped into range once: a duplicated edge row only feeds accumulators the epilogue
+//     never stores), i.e. `global_load_dwordx2 v, v_off, s[base]` with nothing to compute per tile;
+//   * LDS addresses are one per-thread base + compile-time immediates (the double buffer index is a template constant);
+//   * loaded registers are first touched by the LDS store after the MFMA block, so the loads overlap the MFMAs.
+// Only the last, partial K tile takes a clamped + zero-masked path.
 template <int BO, bool KMAJOR, int NT, int BK>
 struct Tile {
     static constexpr int LD_OK = BK + 2;       // (BK+2) mod 32 == 2 for BK = 16, 64: rows land on distinct even slots
     static constexpr int LDS_ELEMS = KMAJOR ? BK * (BO + PAD_KO) : BO * LD_OK;
     static constexpr int PER_THREAD = BO * BK / NT;
     static_assert(BO * BK % NT == 0, "tile must divide evenly over the workgroup");
+    static_assert(NT % BO == 0 && NT % BK == 0, "slot i of a thread must sit a constant distance from its slot 0");
 
-    __device__ static __forceinline__ int lds_index(int o, int k) {
+    __device__ static __forceinline__ constexpr int lds_index(int o, int k) {
         return KMAJOR ? k * (BO + PAD_KO) + o : o * LD_OK + k;
     }
-    __device__ static __forceinline__ void slot(int tid, int i, int &o, int &k) {
-        const int e = tid + NT * i;
+    // slot 0 of thread tid; slot i adds (DO * i, DK * i)
+    static constexpr int DO = KMAJOR ? 0 : NT / BK, DK = KMAJOR ? NT / BO : 0;
+    __device__ static __forceinline__ void slot0(int tid, int &o, int &k) {
         if (KMAJOR) {
-            k = e / BO;
-            o = e % BO;
+            k = tid / BO;
+            o = tid % BO;
         } else {
-            o = e / BK;
-            k = e % BK;
+            o = tid / BK;
+            k = tid % BK;
         }
     }
-    // pointers of this thread's slots in K tile 0
-    __device__ static __forceinline__ void setup(const double *(&p)[PER_THREAD], const double *__restrict__ base, long ld,
-                                                 int o0, int Olim, int tid) {
+    // wave-uniform buffer resource over the operand, based at the tile's first outer row/column (raw buffer, no bounds)
+    __device__ static __forceinline__ __amdgpu_buffer_rsrc_t rsrc(const double *p, long ld, int o0) {
+        const double *b = p + (KMAJOR ? (long)o0 : (long)o0 * ld);
+        return __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(b), 0, 0xFFFFFFFF, 0x00020000);
+    }
+    __device__ static __forceinline__ long step_bytes(long ld) { return 8 * (KMAJOR ? (long)BK * ld : (long)BK); }
+    // byte offsets of this thread's slots from the tile base (host side checks they fit 32 bits)
+    __device__ static __forceinline__ void setup(unsigned (&off)[PER_THREAD], long ld, int o0, int Olim, int tid) {
+        int o, k;
+        slot0(tid, o, k);
 #pragma unroll
         for (int i = 0; i < PER_THREAD; ++i) {
-            int o, k;
-            slot(tid, i, o, k);
-            const int go = o0 + o, goc = go < Olim ? go : Olim - 1;
-            p[i] = base + (KMAJOR ? (long)k * ld + goc : (long)goc * ld + k);
+            const int go = o0 + o + DO * i, rel = (go < Olim ? go : Olim - 1) - o0;
+            off[i] = (unsigned)((KMAJOR ? (long)(k + DK * i) * ld + rel : (long)rel * ld + k) * 8);
         }
     }
-    __device__ static __forceinline__ long step(long ld) { return KMAJOR ? (long)BK * ld : (long)BK; }
-    // full tile number kt: plain loads
-    __device__ static __forceinline__ void gload(double (&r)[PER_THREAD], const double *const (&p)[PER_THREAD], long off) {
-#pragma unroll
-        for (int i = 0; i < PER_THREAD; ++i) r[i] = p[i][off];
+    __device__ static __forceinline__ double bload(__amdgpu_buffer_rsrc_t r, unsigned voff, int soff) {
+        return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0));
     }
-    // partial tile starting at k0: out-of-range k reads the slot's k = K-1 element instead (always valid)
-    __device__ static __forceinline__ void gload_tail(double (&r)[PER_THREAD], const double *const (&p)[PER_THREAD], long ld,
-                                                      int k0, int K, int tid) {
+    // full tile at scalar byte offset soff: buffer_load_dwordx2 v, voff, s[rsrc], soff offen -- no VALU at all
+    __device__ static __forceinline__ void gload(double (&r)[PER_THREAD], __amdgpu_buffer_rsrc_t rs, int soff,
+                                                 const unsigned (&off)[PER_THREAD]) {
+#pragma unroll
+        for (int i = 0; i < PER_THREAD; ++i) r[i] = bload(rs, off[i], soff);
+    }
+    // partial tile with kleft (>= 1) valid k: out-of-range k reads the last valid one instead (always a legal address)
+    __device__ static __forceinline__ void gload_tail(double (&r)[PER_THREAD], __amdgpu_buffer_rsrc_t rs, int soff, long ld, int o0,
+                                                      int Olim, int kleft, int tid) {
+        int o, k;
+        slot0(tid, o, k);
 #pragma unroll
         for (int i = 0; i < PER_THREAD; ++i) {
-            int o, k;
-            slot(tid, i, o, k);
-            const int gk = k0 + k, gkc = gk < K ? gk : K - 1;
-            r[i] = p[i][KMAJOR ? (long)(gkc - k) * ld : (long)(gkc - k)];
+            const int go = o0 + o + DO * i, rel = (go < Olim ? go : Olim - 1) - o0;
+            const int kk = k + DK * i, kc = kk < kleft ? kk : kleft - 1;
+            r[i] = bload(rs, (unsigned)((KMAJOR ? (long)kc * ld + rel : (long)rel * ld + kc) * 8), soff);
         }
     }
+    // thr = this thread's slot-0 address inside the destination buffer
     template <bool MASK>
-    __device__ static __forceinline__ void sstore(const double (&r)[PER_THREAD], double *lds, int k0, int K, int tid) {
+    __device__ static __forceinline__ void sstore(const double (&r)[PER_THREAD], double *thr, int k_slot0, int kleft) {
 #pragma unroll
-        for (int i = 0; i < PER_THREAD; ++i) {
-            int o, k;
-            slot(tid, i, o, k);
-            lds[lds_index(o, k)] = (!MASK || k0 + k < K) ? r[i] : 0.0;
-        }
+        for (int i = 0; i < PER_THREAD; ++i)
+            thr[lds_index(DO * i, DK * i)] = (!MASK || k_slot0 + DK * i < kleft) ? r[i] : 0.0;
     }
 };
 
@@ -118,10 +135,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f64_kernel(GemmK g) {
     using TileA = Tile<BM, TA, NT, BK>;    // transA: global [K][M]
     using TileB = Tile<BN, !TB, NT, BK>;   // !transB: global [K][N]
     __shared__ double lds[2 * (TileA::LDS_ELEMS + TileB::LDS_ELEMS)];
-    // buffer `b` of operand A at lds + b*LDS_ELEMS; operand B follows the two A buffers
-    auto ldsA = [&](int b) -> double * { return lds + b * TileA::LDS_ELEMS; };
-    auto ldsB = [&](int b) -> double * { return lds + 2 * TileA::LDS_ELEMS + b * TileB::LDS_ELEMS; };
-
+    // operand A buffers 0,1 at lds + b*TileA::LDS_ELEMS; operand B buffers follow the two A buffers
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wid = tid >> 6;
@@ -160,39 +174,62 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f64_kernel(GemmK g) {
         for (int j = 0; j < FN; ++j) acc[i][j] = d4{0.0, 0.0, 0.0, 0.0};
 
     double ra[TileA::PER_THREAD], rb[TileB::PER_THREAD];
-    const double *pa[TileA::PER_THREAD], *pb[TileB::PER_THREAD];
-    TileA::setup(pa, A, g.lda, m0, g.M, tid);
-    TileB::setup(pb, B, g.ldb, n0, g.N, tid);
-    const long stepA = TileA::step(g.lda), stepB = TileB::step(g.ldb);
+    unsigned offA[TileA::PER_THREAD], offB[TileB::PER_THREAD];
+    TileA::setup(offA, g.lda, m0, g.M, tid);
+    TileB::setup(offB, g.ldb, n0, g.N, tid);
+    const __amdgpu_buffer_rsrc_t rsA = TileA::rsrc(A, g.lda, m0), rsB = TileB::rsrc(B, g.ldb, n0);   // wave-uniform
+    const int stepA = (int)TileA::step_bytes(g.lda), stepB = (int)TileB::step_bytes(g.ldb);
     const int nk = (g.K + BK - 1) / BK;
     const int nfull = g.K / BK;                  // tiles [0, nfull) are complete
 
-    if (nfull > 0) {
-        TileA::gload(ra, pa, 0);
-        TileB::gload(rb, pb, 0);
-        TileA::template sstore<false>(ra, ldsA(0), 0, g.K, tid);
-        TileB::template sstore<false>(rb, ldsB(0), 0, g.K, tid);
-    } else {
-        TileA::gload_tail(ra, pa, g.lda, 0, g.K, tid);
-        TileB::gload_tail(rb, pb, g.ldb, 0, g.K, tid);
-        TileA::template sstore<true>(ra, ldsA(0), 0, g.K, tid);
-        TileB::template sstore<true>(rb, ldsB(0), 0, g.K, tid);
-    }
-    __syncthreads();
-
     const int fr = lane & 15, fq = lane >> 4;
-    int cur = 0;
-    auto mma_tile = [&](int buf) {
-        const double *sa = ldsA(buf);
-        const double *sb = ldsB(buf);
+    int oa0, ka0, ob0, kb0;
+    TileA::slot0(tid, oa0, ka0);
+    TileB::slot0(tid, ob0, kb0);
+    double *const swA = lds + TileA::lds_index(oa0, ka0);                                   // LDS store bases (buffer 0)
+    double *const swB = lds + 2 * TileA::LDS_ELEMS + TileB::lds_index(ob0, kb0);
+    const double *const srA = lds + TileA::lds_index(wr * 16 * FM + fr, fq);                // fragment read bases (buffer 0)
+    const double *const srB = lds + 2 * TileA::LDS_ELEMS + TileB::lds_index(wc * 16 * FN + fr, fq);
+    using Buf0 = std::integral_constant<int, 0>;
+    using Buf1 = std::integral_constant<int, 1>;
+
+    auto load_full = [&](int t) {
+        TileA::gload(ra, rsA, t * stepA, offA);
+        TileB::gload(rb, rsB, t * stepB, offB);
+    };
+    auto load_any = [&](int t) {
+        if (t < nfull) {
+            load_full(t);
+        } else {
+            TileA::gload_tail(ra, rsA, t * stepA, g.lda, m0, g.M, g.K - t * BK, tid);
+            TileB::gload_tail(rb, rsB, t * stepB, g.ldb, n0, g.N, g.K - t * BK, tid);
+        }
+    };
+    auto store_full = [&](auto bufc) {
+        constexpr int buf = decltype(bufc)::value;
+        TileA::template sstore<false>(ra, swA + buf * TileA::LDS_ELEMS, 0, 0);
+        TileB::template sstore<false>(rb, swB + buf * TileB::LDS_ELEMS, 0, 0);
+    };
+    auto store_any = [&](auto bufc, int t) {
+        constexpr int buf = decltype(bufc)::value;
+        if (t < nfull) {
+            store_full(bufc);
+        } else {
+            TileA::template sstore<true>(ra, swA + buf * TileA::LDS_ELEMS, ka0, g.K - t * BK);
+            TileB::template sstore<true>(rb, swB + buf * TileB::LDS_ELEMS, kb0, g.K - t * BK);
+        }
+    };
+    auto mma_tile = [&](auto bufc) {
+        constexpr int buf = decltype(bufc)::value;
+        const double *sa = srA + buf * TileA::LDS_ELEMS;
+        const double *sb = srB + buf * TileB::LDS_ELEMS;
 #pragma unroll
         for (int kk = 0; kk < BK / 4; ++kk) {
-            const int k = kk * 4 + fq;
             double a[FM], b[FN];
 #pragma unroll
-            for (int i = 0; i < FM; ++i) a[i] = sa[TileA::lds_index(wr * 16 * FM + i * 16 + fr, k)];
+            for (int i = 0; i < FM; ++i) a[i] = sa[TileA::lds_index(i * 16, kk * 4)];
 #pragma unroll
-            for (int j = 0; j < FN; ++j) b[j] = sb[TileB::lds_index(wc * 16 * FN + j * 16 + fr, k)];
+            for (int j = 0; j < FN; ++j) b[j] = sb[TileB::lds_index(j * 16, kk * 4)];
 #pragma unroll
             for (int i = 0; i < FM; ++i)
 #pragma unroll
@@ -200,27 +237,44 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f64_kernel(GemmK g) {
                     acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
         }
     };
-    // steady state: the next tile is complete -> straight-line loads, MFMAs, LDS stores (no selects, no branches)
+
+    load_any(0);
+    store_any(Buf0{}, 0);
+    __syncthreads();
+    // steady state, two K tiles per trip so the buffer index is a compile-time constant
     int kt = 0;
-    for (; kt + 1 < nfull; ++kt) {
-        TileA::gload(ra, pa, (kt + 1) * stepA);
-        TileB::gload(rb, pb, (kt + 1) * stepB);
-        mma_tile(cur);
-        TileA::template sstore<false>(ra, ldsA(cur ^ 1), 0, g.K, tid);
-        TileB::template sstore<false>(rb, ldsB(cur ^ 1), 0, g.K, tid);
+    for (; kt + 2 < nfull; kt += 2) {
+        load_full(kt + 1);
+        __builtin_amdgcn_sched_barrier(0);     // keep the order loads | MFMAs | LDS stores: the MFMAs are the loads' cover
+        mma_tile(Buf0{});
+        __builtin_amdgcn_sched_barrier(0);
+        store_full(Buf1{});
         __syncthreads();
-        cur ^= 1;
-    }
-    if (kt + 1 < nk) {                         // one partial K tile follows
-        TileA::gload_tail(ra, pa, g.lda, (kt + 1) * BK, g.K, tid);
-        TileB::gload_tail(rb, pb, g.ldb, (kt + 1) * BK, g.K, tid);
-        mma_tile(cur);
-        TileA::template sstore<true>(ra, ldsA(cur ^ 1), (kt + 1) * BK, g.K, tid);
-        TileB::template sstore<true>(rb, ldsB(cur ^ 1), (kt + 1) * BK, g.K, tid);
+        load_full(kt + 2);
+        __builtin_amdgcn_sched_barrier(0);
+        mma_tile(Buf1{});
+        __builtin_amdgcn_sched_barrier(0);
+        store_full(Buf0{});
         __syncthreads();
-        cur ^= 1;
     }
-    mma_tile(cur);
+    // tile kt sits in buffer 0 and at most two more follow (the last one possibly partial)
+    if (kt + 1 < nk) {
+        load_any(kt + 1);
+        mma_tile(Buf0{});
+        store_any(Buf1{}, kt + 1);
+        __syncthreads();
+        if (kt + 2 < nk) {
+            load_any(kt + 2);
+            mma_tile(Buf1{});
+            store_any(Buf0{}, kt + 2);
+            __syncthreads();
+            mma_tile(Buf0{});
+        } else {
+            mma_tile(Buf1{});
+        }
+    } else {
+        mma_tile(Buf0{});
+    }
 
     // ---- epilogue ----
     double qsum = 0.0, qsum2 = 0.0;
@@ -331,6 +385,9 @@ static void launch_trans(const GemmK &k, bool ta, bool tb, int epi, dim3 grid, h
 void gemm_f64(gpcsd_ctx *c, const GemmDesc &g, hipStream_t s) {
     if (!s) s = c->stream;
     GP_REQUIRE(g.M > 0 && g.N > 0 && g.K > 0, -3, "gemm_f64: empty problem %dx%dx%d", g.M, g.N, g.K);
+    // 32-bit byte offsets inside one batch entry's operand (buffer_load voffset + soffset)
+    GP_REQUIRE((g.transA ? (long)g.K : (long)g.M) * g.lda < (1L << 28) && (g.transB ? (long)g.N : (long)g.K) * g.ldb < (1L << 28), -3,
+               "gemm_f64: operand too large for 32-bit offsets (lda %ld, ldb %ld)", g.lda, g.ldb);
     GemmK k;
     k.M = g.M; k.N = g.N; k.K = g.K;
     k.A = g.A; k.lda = g.lda; k.B = g.B; k.ldb = g.ldb; k.C = g.C; k.ldc = g.ldc; k.C2 = g.C2; k.C3 = g.C3;
