@@ -147,6 +147,28 @@ def cpu_baseline(w, m, lfp_sample):
             "loglik_evals_per_sec": reps / t_ll, "predict_trials_per_sec": Rs * reps / t_pr}, ll
 
 
+# Epilogue template index of each profiled GEMM role (last template argument of gemm_f64_kernel in rocprofv3's names)
+GEMM_EPI_OF = {"gemm_pred_tstar": 4, "gemm_pred_temporal_div": 1, "gemm_proj_temporal_quad": 2}
+PMC_PROFILE = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+
+
+def pmc_traffic(prof_name):
+    """HBM bytes per launch of the roofline kernel from the committed rocprofv3 --pmc passes (FETCH_SIZE x2 on gfx950 +
+    WRITE_SIZE, separate passes over this same bench command; tools/pmc_summary.py).  None if no profile is committed."""
+    epi = GEMM_EPI_OF.get(prof_name)
+    if epi is None or not os.path.exists(PMC_PROFILE):
+        return None, None
+    with open(PMC_PROFILE) as fh:
+        rows = json.load(fh)["rows"]
+    cand = [r for r in rows if r["kernel"].startswith("gemm_f64_kernel<") and r["kernel"].endswith(", %d>" % epi)
+            and "hbm_traffic_bytes_per_launch" in r]
+    if not cand:
+        return None, None
+    r = max(cand, key=lambda r: r["hbm_traffic_bytes_per_launch"])
+    return r["hbm_traffic_bytes_per_launch"], {"read": r["hbm_read_bytes_per_launch"], "write": r["hbm_write_bytes_per_launch"],
+                                              "source": "profiles/" + os.path.basename(PMC_PROFILE), "kernel": r["kernel"]}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -257,8 +279,10 @@ def main():
         ach = (g["flops"] / g["count"]) / (avg_ms * 1e-3) / 1e12
         mfma_meas = ctx.mfma_f64_peak()
         all_gemm_tf = sum(v["flops"] for v in gemms.values()) / (sum(v["ms"] for v in gemms.values()) * 1e-3) / 1e12
+        traffic, traffic_detail = pmc_traffic(name)
         roof = {"bound": "mfma", "achieved": ach, "peak": FP64_MFMA_SPEC_TFLOPS, "unit": "TFLOP/s",
-                "frac": ach / FP64_MFMA_SPEC_TFLOPS, "traffic": None, "kernel": "gemm_f64_kernel [" + name + "]",
+                "frac": ach / FP64_MFMA_SPEC_TFLOPS, "traffic": traffic, "traffic_unit": "bytes/launch",
+                "traffic_detail": traffic_detail, "kernel": "gemm_f64_kernel [" + name + "]",
                 "avg_launch_ms": avg_ms, "flops_per_launch": g["flops"] / g["count"],
                 "measured_mfma_f64_peak_tflops": mfma_meas, "all_gemm_tflops": all_gemm_tf,
                 "per_kernel_ms_per_step": {k: v["ms"] / 3.0 for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])}}

@@ -44,7 +44,8 @@ struct GemmK {
     int rdiv;
     long ldd;
     double *partials;
-    int tiles_n;
+    int tiles_n, tiles_m;
+    int m_fastest;      // logical tile order: 1 = tile_m varies fastest (few row tiles, many column tiles)
     const int *dyn;     // optional device scalar: effective N and K (= *dyn) of this launch (D&C merge GEMMs)
 };
 
@@ -156,7 +157,9 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f64_kernel(GemmK g) {
             bx = logical % gridDim.x;
         }
     }
-    const int tile_m = bx / g.tiles_n, tile_n = bx % g.tiles_n;
+    // consecutive logical tiles share the operand panel of the LONGER tile dimension, so that panel is fetched from HBM
+    // once per XCD neighbourhood while the short dimension's operand stays L2 resident as a whole
+    const int tile_m = g.m_fastest ? bx % g.tiles_m : bx / g.tiles_n, tile_n = g.m_fastest ? bx / g.tiles_m : bx % g.tiles_n;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
     if (g.dyn) {                        // wave-uniform: sizes decided on the device (deflation count)
         const int kk = g.dyn[bz];
@@ -412,6 +415,8 @@ void gemm_f64(gpcsd_ctx *c, const GemmDesc &g, hipStream_t s) {
     const int bm = CFG_BM[cfg], bn = CFG_BN[cfg];
     const int tm = ceil_div(g.M, bm), tn = ceil_div(g.N, bn);
     k.tiles_n = tn;
+    k.tiles_m = tm;
+    k.m_fastest = (tm < tn) ? 1 : 0;
     dim3 grid(tm * tn, 1, g.batch);
     const long nblocks = (long)tm * tn * g.batch;
     if (g.epi == EPI_QUAD || g.epi == EPI_GRAD) k.partials = c->buf<double>("gemm_partials", 2 * nblocks);
