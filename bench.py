@@ -183,13 +183,20 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # rehearsal knobs (one-GPU box): GPCSD_BENCH_BACKEND=gloo + GPCSD_DEVICE=0 run N ranks on one card
+    backend = os.environ.get("GPCSD_BENCH_BACKEND", "nccl")
+    if "GPCSD_DEVICE" in os.environ:
+        local_rank = int(os.environ["GPCSD_DEVICE"])
     import torch
     torch.cuda.set_device(local_rank)
     sharding = None
     if world > 1:
         import torch.distributed as td
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        td.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            td.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            td.init_process_group(backend, rank=rank, world_size=world)
     n_gpus = world
 
     from gpcsd_amd import _hip
@@ -251,7 +258,7 @@ def main():
     elapsed = time.perf_counter() - t0
     if world > 1:
         import torch.distributed as td
-        tt = torch.tensor([elapsed, t_ll, t_pr], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([elapsed, t_ll, t_pr], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         td.all_reduce(tt, op=td.ReduceOp.MAX)
         elapsed, t_ll, t_pr = (float(v) for v in tt.cpu())
 

@@ -117,7 +117,7 @@ class Context:
     def __init__(self, device=None):
         lib = load_library()
         if device is None:
-            device = int(os.environ.get("LOCAL_RANK", "0"))
+            device = int(os.environ.get("GPCSD_DEVICE", os.environ.get("LOCAL_RANK", "0")))
         h = ctypes.c_void_p()
         rc = lib.gpcsd_ctx_create(int(device), ctypes.byref(h))
         if rc != 0:

@@ -1,0 +1,228 @@
+// Register-resident tail of the Householder tridiagonalisation (included by eigh_dc.hip after SytrdBatch).
+//
+// The trailing block (T <= 192 rows) of every problem lives in the VGPRs of ONE workgroup of 768 threads: thread
+// (row group g, column part h) keeps the 4 x 12 tile rows 4g..4g+3, columns 12h..12h+11 (96 VGPRs).  A wave is four
+// row groups x sixteen column parts, i.e. one 16-lane DPP row per row group, so the row sums of y = A v fold with four
+// DPP stages and never touch LDS.  Per column:
+//   gen   the wave that owns row kk copies that row (= column kk by symmetry) out of its registers, forms the
+//         Householder vector and publishes v (length T) -- a wave-local section that overlaps the other waves' rank-2
+//         update of the previous column;
+//   A     barrier;  y = A v from registers (48 FMAs + 4 DPP folds per thread), v.y partials;
+//   B     barrier;  w = tau y - cc v formed on the fly, rank-2 update of the tile (96 FMAs per thread).
+// Two barriers and ~0.3 k VALU instructions per thread and column instead of a dependent launch (4.6 us) or an LDS-resident
+// sweep (3.1 us at T = 113).  Dead rows / columns need no masks in the FMA loops: v and y are zero there.
+#pragma once
+
+namespace gpcsd {
+
+constexpr int RT_R = 4, RT_C = 12, RT_T = 192, RT_NTH = (RT_T / RT_R) * (RT_T / RT_C), RT_NW = RT_NTH / 64;
+static_assert(RT_T / RT_C == 16 && RT_NTH == 768, "one DPP row per row group");
+
+// sum over the 16 lanes of a DPP row, result in every lane of the row
+__device__ __forceinline__ double row16_sum(double v) {
+    v += dpp_mov<0xB1>(v);
+    v += dpp_mov<0x4E>(v);
+    v += dpp_mov<0x141>(v);
+    v += dpp_mov<0x140>(v);
+    return v;
+}
+
+__global__ __launch_bounds__(RT_NTH) void sytrd_rtail_kernel(SytrdBatch b) {
+    const SytrdProb &P = b.p[blockIdx.x];
+    const int n = P.n, k0 = P.k_tail;
+    if (k0 >= n - 1) return;
+    const int T = n - k0;                          // rows / columns k0 .. n-1, T <= RT_T
+    __shared__ __attribute__((aligned(16))) double sx[RT_T], sv2[2][RT_T], sy[RT_T];
+    __shared__ double red[RT_NW];
+    __shared__ double sd[RT_T], se[RT_T], st[RT_T];
+    __shared__ double s_tau;
+    // v is double-buffered: the wave generating reflector kk+1 writes it while slower waves still read v of column kk
+    double *sv = sv2[0];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int gg = lane >> 4, h = lane & 15;       // row group inside the wave, column part
+    const int row0 = 16 * wid + 4 * gg, c0 = RT_C * h;
+    const double *__restrict__ Ain = (k0 & 1) ? P.A1 : P.A0;
+    const double *__restrict__ yin = (k0 & 1) ? P.y1 : P.y0;
+
+    // pending rank-2 update of step k0-1 (its reflector and y = A v are in global memory): v -> sv, w -> sy
+    {
+        double pv = 0.0, py = 0.0, taup = 0.0;
+        if (k0 > 0) {
+            taup = P.tau[k0 - 1];
+            if (tid < T) {
+                pv = P.V[(long)(k0 - 1) * n + k0 + tid];
+                py = yin[k0 + tid];
+            }
+        }
+        const double part = wave_sum(pv * py);
+        if (lane == 0) red[wid] = part;
+        __syncthreads();
+        double dot = 0.0;
+#pragma unroll
+        for (int q = 0; q < RT_NW; ++q) dot += red[q];
+        const double cc = 0.5 * taup * taup * dot;
+        if (tid < RT_T) {
+            sv[tid] = pv;
+            sy[tid] = taup * py - cc * pv;
+        }
+        __syncthreads();
+    }
+    double a[RT_R][RT_C];
+#pragma unroll
+    for (int r = 0; r < RT_R; ++r) {
+        const int i = row0 + r;
+        const bool rok = i < T;
+        const double *__restrict__ arow = Ain + (long)(k0 + (rok ? i : 0)) * n + k0;
+        const double vi = sv[i], wi = sy[i];
+#pragma unroll
+        for (int j = 0; j < RT_C; ++j) {
+            const int c = c0 + j;
+            const bool ok = rok && c < T;
+            const double g = ok ? arow[c] : 0.0;
+            a[r][j] = ok ? g - vi * sy[c] - wi * sv[c] : 0.0;
+        }
+    }
+    __syncthreads();
+
+    // copy row `row` (owned by this wave) into sx.  The register row is picked with selects on the wave-uniform row
+    // index: a branchy version is merged by the compiler into a dynamically indexed copy of the tile in scratch memory.
+    auto publish_row = [&](int row) {
+        const int rk = row & 3, ggk = (row >> 2) & 3;
+        double x[RT_C];
+#pragma unroll
+        for (int j = 0; j < RT_C; ++j) {
+            const double lo = (rk & 1) ? a[1][j] : a[0][j];
+            const double hi = (rk & 1) ? a[3][j] : a[2][j];
+            x[j] = (rk & 2) ? hi : lo;
+        }
+        if (gg == ggk) {
+#pragma unroll
+            for (int j = 0; j < RT_C; ++j) sx[c0 + j] = x[j];
+        }
+    };
+
+    for (int kk = 0; kk < T - 1; ++kk) {
+        sv = sv2[kk & 1];
+        // ---- gen: only the wave owning row kk (wave-uniform branch).  Row kk (= column kk by symmetry) goes to LDS, then
+        // all 64 lanes work on three entries each: norm, Householder scalars, v.  Every other wave waits for this section
+        // at barrier A, so it is kept short (~200 instructions) and issues ahead of the waves sharing its SIMD.
+        if (wid == (kk >> 4)) {
+            __builtin_amdgcn_s_setprio(3);
+            publish_row(kk);
+            double x[3], part = 0.0;                                 // same wave wrote sx: LDS is in order
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                x[q] = sx[64 * q + lane];
+                part += (64 * q + lane >= kk + 2) ? x[q] * x[q] : 0.0;
+            }
+            const double xnorm2 = wave_sum(part);
+            const double dk = sx[kk], alpha = sx[kk + 1];
+            const int m = T - kk - 1;
+            double tau = 0.0, beta = alpha, scal = 0.0;
+            if (m >= 2 && xnorm2 > 0.0) {
+                beta = -copysign(sqrt(alpha * alpha + xnorm2), alpha);
+                const double amb = alpha - beta;
+                const double q = 1.0 / (beta * amb);                 // one division: tau = (beta-alpha)/beta, scal = 1/(alpha-beta)
+                tau = -amb * amb * q;
+                scal = beta * q;
+            }
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                const int c = 64 * q + lane;
+                double t = (c > kk + 1) ? x[q] * scal : 0.0;
+                t = (c == kk + 1) ? 1.0 : t;
+                sv[c] = t;
+            }
+            if (lane == 0) {
+                sd[kk] = dk;
+                se[kk] = beta;
+                st[kk] = tau;
+                s_tau = tau;
+            }
+            __builtin_amdgcn_s_setprio(0);
+        }
+        __syncthreads();                                             // ---- A: v, tau published
+        const double tau = s_tau;
+        if (tid < T) P.V[(long)(k0 + kk) * n + k0 + tid] = sv[tid];  // reflector kk (zeros up to kk, 1 at kk+1)
+        const bool live = (16 * wid + 15 > kk) && (tau != 0.0);      // wave-uniform: still owns a row > kk
+        // v is re-read from LDS pair by pair in both phases (6 ds_read_b128 each) instead of being held in 24 VGPRs:
+        // the 4 x 12 tile already takes 96 of the 168 registers a thread may use at three waves per SIMD
+        if (live) {
+            double vrow[RT_R], yr[RT_R];
+#pragma unroll
+            for (int r = 0; r < RT_R; r += 2) {
+                const double2 t = *reinterpret_cast<const double2 *>(sv + row0 + r);
+                vrow[r] = t.x;
+                vrow[r + 1] = t.y;
+            }
+            double acc[RT_R] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int j = 0; j < RT_C; j += 2) {
+                const double2 vv = *reinterpret_cast<const double2 *>(sv + c0 + j);
+#pragma unroll
+                for (int r = 0; r < RT_R; ++r) acc[r] = fma(a[r][j + 1], vv.y, fma(a[r][j], vv.x, acc[r]));
+            }
+            double dp = 0.0;
+#pragma unroll
+            for (int r = 0; r < RT_R; ++r) {
+                const double y = row16_sum(acc[r]);
+                yr[r] = (row0 + r > kk) ? y : 0.0;
+                dp += vrow[r] * yr[r];
+            }
+            if (h == 0) {
+                *reinterpret_cast<double2 *>(sy + row0) = double2{yr[0], yr[1]};
+                *reinterpret_cast<double2 *>(sy + row0 + 2) = double2{yr[2], yr[3]};
+            }
+            // dp is replicated over the 16 lanes of each row group: add the four groups of the wave
+            dp = (lane_get(dp, 0) + lane_get(dp, 16)) + (lane_get(dp, 32) + lane_get(dp, 48));
+            if (lane == 0) red[wid] = dp;
+        } else if (lane == 0) {
+            red[wid] = 0.0;
+        }
+        __syncthreads();                                             // ---- B: y, v.y partials published
+        if (live) {
+            double dot = 0.0;
+#pragma unroll
+            for (int q = 0; q < RT_NW; ++q) dot += red[q];
+            const double cc = 0.5 * tau * tau * dot;
+            double wrow[RT_R], vrow[RT_R];                           // re-read rather than kept live across the barrier
+#pragma unroll
+            for (int r = 0; r < RT_R; r += 2) {
+                const double2 tv = *reinterpret_cast<const double2 *>(sv + row0 + r);
+                const double2 ty = *reinterpret_cast<const double2 *>(sy + row0 + r);
+                vrow[r] = tv.x;
+                vrow[r + 1] = tv.y;
+                wrow[r] = tau * ty.x - cc * tv.x;
+                wrow[r + 1] = tau * ty.y - cc * tv.y;
+            }
+#pragma unroll
+            for (int j = 0; j < RT_C; j += 2) {
+                const double2 yy = *reinterpret_cast<const double2 *>(sy + c0 + j);
+                const double2 vv = *reinterpret_cast<const double2 *>(sv + c0 + j);
+                const double w0 = tau * yy.x - cc * vv.x, w1 = tau * yy.y - cc * vv.y;
+#pragma unroll
+                for (int r = 0; r < RT_R; ++r) {
+                    a[r][j] = fma(-wrow[r], vv.x, fma(-vrow[r], w0, a[r][j]));
+                    a[r][j + 1] = fma(-wrow[r], vv.y, fma(-vrow[r], w1, a[r][j + 1]));
+                }
+            }
+        }
+    }
+    // last diagonal element a[T-1][T-1]
+    if (wid == ((T - 1) >> 4)) {
+        publish_row(T - 1);
+        if (lane == 0) {
+            sd[T - 1] = sx[T - 1];
+            se[T - 1] = 0.0;
+            st[T - 1] = 0.0;
+        }
+    }
+    __syncthreads();
+    for (int kk = tid; kk < T; kk += RT_NTH) {
+        P.d[k0 + kk] = sd[kk];
+        P.e[k0 + kk] = se[kk];
+        P.tau[k0 + kk] = st[kk];
+    }
+}
+
+}  // namespace gpcsd
