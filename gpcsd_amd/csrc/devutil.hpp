@@ -15,8 +15,10 @@ constexpr double EPS_U = 1.1102230246251565e-16;     // unit roundoff (LAPACK dl
 template <int CTRL>
 __device__ __forceinline__ double dpp_mov(double v) {
     int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xF, 0xF, false);
-    hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xF, 0xF, false);
+    // every control used here has a source lane for every lane, so `old` is never read: with bound_ctrl set and a
+    // constant old the compiler drops the v_mov that otherwise copies the source into the tied destination first
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, true);
     return __hiloint2double(hi, lo);
 }
 __device__ __forceinline__ double lane_get(double v, int l) {
