@@ -587,13 +587,250 @@ __global__ __launch_bounds__(256) void dc_place_kernel(DcLevel L) {
 // ------------------------------------------------------------------------------------------------------------------
 // fused level kernel for small merges (N <= DC_SMALL): one workgroup walks every phase of its merge
 // ------------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(NT_SMALL) void dc_small_level_kernel(DcLevel L) {
+// ---- helpers of the fused kernel: everything between the deflation scan and the placement stays in LDS / registers.
+// Reciprocal to ~2 ulp (v_rcp_f64 + two Newton steps, 5 instructions instead of the ~35 of an IEEE division); used where
+// the result feeds a sum whose rounding error is of the same order anyway.
+__device__ __forceinline__ double fast_rcp(double x) {
+    double r = __builtin_amdgcn_rcp(x);
+    r = fma(fma(-x, r, 1.0), r, r);
+    r = fma(fma(-x, r, 1.0), r, r);
+    return r;
+}
+// sum / product over the 8 lanes of an aligned lane octet (two quads), result in all 8 lanes
+__device__ __forceinline__ double oct_sum(double v) {
+    v += dpp_mov<0xB1>(v);
+    v += dpp_mov<0x4E>(v);
+    v += dpp_mov<0x141>(v);
+    return v;
+}
+__device__ __forceinline__ double oct_prod(double v) {
+    v *= dpp_mov<0xB1>(v);
+    v *= dpp_mov<0x4E>(v);
+    v *= dpp_mov<0x141>(v);
+    return v;
+}
+
+struct SmallShared {
+    double kd[DC_SMALL], kz[DC_SMALL];          // non-deflated poles / weights
+    double mu[DC_SMALL], lam[DC_SMALL], zh[DC_SMALL];
+    int org[DC_SMALL];
+};
+
+// Secular equation, EIGHT lanes per root (octet o = root, lane s of the octet sums poles s, s+8, ...): all K <= 64 roots
+// of the merge advance together on the 512 threads.  Same iteration as dc_secular_root (origin shift to the nearer pole,
+// two-pole rational step, bisection safeguard); the step itself uses fast reciprocals, the convergence test does not
+// depend on them.
+__device__ void dc_secular_oct(const SmallShared &Q, SmallShared &Qw, const int K, const double rho) {
+    const int i = threadIdx.x >> 3, s = threadIdx.x & 7;
+    const double *__restrict__ dk = Q.kd;
+    const double *__restrict__ zk = Q.kz;
+    if (i >= K) return;                               // whole octets leave together
+    if (K == 1) {
+        if (s == 0) {
+            const double m = rho * zk[0] * zk[0];
+            Qw.org[0] = 0;
+            Qw.mu[0] = m;
+            Qw.lam[0] = dk[0] + m;
+        }
+        return;
+    }
+    const bool last = (i == K - 1);
+    int org;
+    double lo_b, hi_b;
+    if (last) {
+        org = K - 1;
+        double t = 0.0;
+        for (int j = s; j < K; j += 8) t += zk[j] * zk[j];
+        lo_b = 0.0;
+        hi_b = rho * oct_sum(t);
+    } else {
+        const double di = dk[i];
+        const double half = 0.5 * (dk[i + 1] - di);
+        double t = 0.0;
+        for (int j = s; j < K; j += 8) t += zk[j] * zk[j] / ((dk[j] - di) - half);
+        const double fmid = 1.0 + rho * oct_sum(t);
+        if (fmid >= 0.0) {
+            org = i;
+            lo_b = 0.0;
+            hi_b = half;
+        } else {
+            org = i + 1;
+            lo_b = -half;
+            hi_b = 0.0;
+        }
+    }
+    const double dorg = dk[org];
+    const double pl = dk[i] - dorg;
+    const double pr = last ? 0.0 : dk[i + 1] - dorg;
+    // this lane's poles, shifted to the origin, stay in registers
+    double del[8], zz[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const int j = s + 8 * q;
+        del[q] = (j < K) ? dk[j] - dorg : 1e300;            // padding: rinv ~ 1e-300, weight 0
+        zz[q] = (j < K) ? zk[j] * zk[j] : 0.0;
+    }
+    double mu = last ? 0.5 * hi_b : 0.5 * (lo_b + hi_b);
+    for (int it = 0; it < 100; ++it) {
+        double psi = 0.0, dpsi = 0.0, phi = 0.0, dphi = 0.0;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const double rinv = fast_rcp(del[q] - mu);
+            const double term = zz[q] * rinv;
+            if (s + 8 * q <= i) {
+                psi += term;
+                dpsi += term * rinv;
+            } else {
+                phi += term;
+                dphi += term * rinv;
+            }
+        }
+        psi = rho * oct_sum(psi);
+        dpsi = rho * oct_sum(dpsi);
+        phi = rho * oct_sum(phi);
+        dphi = rho * oct_sum(dphi);
+        const double f = 1.0 + psi + phi;
+        const double err = 16.0 * EPS_U * (1.0 + fabs(psi) + fabs(phi)) + fabs(mu) * EPS_U * (dpsi + dphi);
+        if (fabs(f) <= err) break;
+        if (f < 0.0) lo_b = fmax(lo_b, mu);
+        else hi_b = fmin(hi_b, mu);
+        if (hi_b - lo_b <= 2.0 * EPS_U * fmax(fabs(lo_b), fabs(hi_b))) break;
+        const double D1 = pl - mu;
+        double eta = INFINITY;
+        if (last) {
+            const double g = 1.0 + psi - dpsi * D1;
+            if (g > 0.0) eta = D1 + dpsi * D1 * D1 * fast_rcp(g);
+        } else {
+            const double D2 = pr - mu;
+            const double A = f - dpsi * D1 - dphi * D2;
+            const double B = A * (D1 + D2) + dpsi * D1 * D1 + dphi * D2 * D2;
+            const double C = D1 * D2 * f;
+            double disc = B * B - 4.0 * A * C;
+            if (disc < 0.0) disc = 0.0;
+            const double sq = sqrt(disc);
+            if (A == 0.0) {
+                if (B != 0.0) eta = C * fast_rcp(B);
+            } else {
+                const double bs = (B >= 0.0) ? B + sq : B - sq;          // the larger-magnitude combination
+                const double ia = fast_rcp(2.0 * A);
+                const double r_big = bs * ia;                             // (B +- sq) / 2A
+                const double r_small = (bs != 0.0) ? 2.0 * C * fast_rcp(bs) : ((B >= 0.0) ? B - sq : B + sq) * ia;
+                const bool ok1 = isfinite(r_small) && r_small > D1 && r_small < D2;
+                const bool ok2 = isfinite(r_big) && r_big > D1 && r_big < D2;
+                if (ok1 && ok2) eta = fabs(r_small) <= fabs(r_big) ? r_small : r_big;
+                else if (ok1) eta = r_small;
+                else if (ok2) eta = r_big;
+            }
+        }
+        double nw = mu + eta;
+        if (!isfinite(nw) || nw <= lo_b || nw >= hi_b) {
+            if (lo_b > 0.0 && hi_b / lo_b > 16.0) nw = sqrt(lo_b * hi_b);
+            else if (hi_b < 0.0 && lo_b / hi_b > 16.0) nw = -sqrt(lo_b * hi_b);
+            else {
+                nw = 0.5 * (lo_b + hi_b);
+                if (nw == lo_b || nw == hi_b) break;
+            }
+        }
+        mu = nw;
+    }
+    if (s == 0) {
+        Qw.org[i] = org;
+        Qw.mu[i] = mu;
+        Qw.lam[i] = dorg + mu;
+    }
+}
+
+typedef double dc_d4 __attribute__((ext_vector_type(4)));
+constexpr int Q2_LD = DC_SMALL + 1;
+
+// Everything after the deflation scan of a small merge, on LDS-resident data: roots (8 lanes each), z-hat (8 lanes per
+// pole), U with normalised columns, W = Q2 U on fp64 MFMA 16x16x4 (operands from LDS), rank sort, placement.
+__device__ void dc_small_tail(const DcWork &w, const Seg sg, SetupShared &S, SmallShared &Q, double *Q2s, const int K,
+                              const double rho) {
+    const int lo = sg.lo, hi = sg.hi, n = w.n, N = hi - lo;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int o = tid >> 3, s = tid & 7;                  // octet index (root / pole / column), lane inside the octet
+    dc_secular_oct(Q, Q, K, rho);
+    __syncthreads();
+    if (tid < K) w.lam[lo + tid] = Q.lam[tid];            // the rank sort reads the roots from global memory
+    if (o < K) {                                          // zhat_o = sign(z_o) sqrt( prod_j (lam_j - d_o) / (rho prod_{j != o} (d_j - d_o)) )
+        const double di = Q.kd[o];
+        double p = 1.0;
+        for (int j = s; j < K; j += 8) {
+            const double num = (Q.kd[Q.org[j]] - di) + Q.mu[j];
+            const double den = (j == o) ? 1.0 : Q.kd[j] - di;
+            p *= num / den;
+        }
+        p = oct_prod(p);
+        if (s == 0) {
+            const double zh = sqrt(fabs(p / rho));
+            Q.zh[o] = (Q.kz[o] >= 0.0) ? zh : -zh;
+        }
+    }
+    __syncthreads();
+    double *U = S.sd;                                     // sd | sz | ds | zs: 4 * EIG_MAXN doubles >= 64 x 64
+    {                                                     // column o of U, rows s, s+8, ...; zero padded to 64 x 64
+        double u[8], ss = 0.0;
+        const bool colok = o < K;
+        const double dorg = colok ? Q.kd[Q.org[o]] : 0.0, muo = colok ? Q.mu[o] : 0.0;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int i = s + 8 * q;
+            u[q] = (colok && i < K) ? Q.zh[i] / ((Q.kd[i] - dorg) - muo) : 0.0;
+            ss += u[q] * u[q];
+        }
+        ss = oct_sum(ss);
+        const double inv = colok ? 1.0 / sqrt(ss) : 0.0;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) U[(s + 8 * q) * DC_SMALL + o] = u[q] * inv;
+    }
+    for (int idx = tid; idx < DC_SMALL * DC_SMALL; idx += NT_SMALL) {
+        const int r = idx / DC_SMALL, j = idx % DC_SMALL;
+        Q2s[r * Q2_LD + j] = (r < N && j < K) ? w.Q2w[(long)(lo + r) * n + lo + j] : 0.0;
+    }
+    __syncthreads();
+    // W = Q2 U: 4 x 4 output fragments of 16 x 16, two per wave (A lane l holds A[l&15][l>>4], B holds B[l>>4][l&15])
+    dc_d4 acc[2];
+    const int fr = lane & 15, fq = lane >> 4;
+    const int ksteps = (K + 3) >> 2;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int tile = wid + 8 * t, tm = tile >> 2, tn = tile & 3;
+        acc[t] = dc_d4{0.0, 0.0, 0.0, 0.0};
+        if (16 * tm < N && 16 * tn < K) {                 // wave-uniform
+            const double *qa = Q2s + (16 * tm + fr) * Q2_LD + fq;
+            const double *ub = U + fq * DC_SMALL + 16 * tn + fr;
+            for (int ks = 0; ks < ksteps; ++ks)
+                acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(qa[4 * ks], ub[4 * ks * DC_SMALL], acc[t], 0, 0, 0);
+        }
+    }
+    __syncthreads();                                      // every fragment read of Q2s is done: reuse it for W
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int tile = wid + 8 * t, tm = tile >> 2, tn = tile & 3;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Q2s[(16 * tm + fq + 4 * r) * Q2_LD + 16 * tn + fr] = acc[t][r];
+    }
+    __syncthreads();
+    dc_rank_body<NT_SMALL>(w, sg, K, S.sd, S.sperm);      // U is dead: its storage holds the sort keys
+    __syncthreads();
+    for (int idx = tid; idx < N * N; idx += NT_SMALL) {   // Qnext[:, rank[t]] = root ? W[:, t] : Qcur[:, deflated idx]
+        const int r = idx / N, t = idx % N;
+        const int sc = w.rotb[lo + t];
+        const double v = (sc < 0) ? Q2s[r * Q2_LD + (-1 - sc)] : w.Qcur[(long)(lo + r) * n + lo + sc];
+        w.Qnext[(long)(lo + r) * n + lo + w.rota[lo + t]] = v;
+    }
+}
+
+__global__ __launch_bounds__(NT_SMALL) void dc_small_level_kernel(DcLevel L, int fast) {
     const DcWork &w = L.w[blockIdx.z];
     const int m = blockIdx.x;
     if (m >= L.nseg[blockIdx.z]) return;
     const Seg sg = load_seg(w, L.seg_off[blockIdx.z], m);
     constexpr int NW = NT_SMALL / 64;
     __shared__ SetupShared S;
+    __shared__ SmallShared Q;
+    __shared__ double Q2s[DC_SMALL * Q2_LD];
     const int lo = sg.lo, hi = sg.hi, n = w.n, N = hi - lo;
     const int tid = threadIdx.x, wid = tid >> 6;
     dc_setup_body<NW>(w, sg, m, S);
@@ -601,7 +838,15 @@ __global__ __launch_bounds__(NT_SMALL) void dc_small_level_kernel(DcLevel L) {
     const int K = S.K, nrot = S.nrot;
     dc_rotate_compact_body<NT_SMALL>(w, sg, K, nrot, lo, hi);
     const double rho = 2.0 * fabs(w.e[sg.mid - 1]);
+    if (tid < DC_SMALL) {
+        Q.kd[tid] = (tid < K) ? w.dk[lo + tid] : 0.0;
+        Q.kz[tid] = (tid < K) ? w.zk[lo + tid] : 0.0;
+    }
     __syncthreads();
+    if (fast) {
+        dc_small_tail(w, sg, S, Q, Q2s, K, rho);
+        return;
+    }
     for (int i = wid; i < K; i += NW) dc_secular_root(w, lo, K, rho, i);
     __syncthreads();
     for (int i = wid; i < K; i += NW) dc_zhat_one(w, lo, K, rho, i);
@@ -616,7 +861,6 @@ __global__ __launch_bounds__(NT_SMALL) void dc_small_level_kernel(DcLevel L) {
     }
     __syncthreads();
     // W = Q2 U  (N x K): Q2 staged in LDS (row stride DC_SMALL+1 keeps the j-walk conflict free), U in LDS
-    __shared__ double Q2s[DC_SMALL * (DC_SMALL + 1)];
     for (int idx = tid; idx < N * K; idx += NT_SMALL) {
         const int r = idx / K, j = idx % K;
         Q2s[r * (DC_SMALL + 1) + j] = w.Q2w[(long)(lo + r) * n + lo + j];
@@ -785,7 +1029,8 @@ void stedc_batch_device(gpcsd_ctx *c, StedcProb *probs, int count, int *d_status
             for (auto &sg : lv) maxN = std::max(maxN, sg.hi - sg.lo);
         }
         if (maxN <= DC_SMALL) {
-            hipLaunchKernelGGL(dc_small_level_kernel, dim3(max_seg, 1, count), dim3(NT_SMALL), 0, s, L);
+            static const int fast = !(getenv("GPCSD_DC_SMALL") && !strcmp(getenv("GPCSD_DC_SMALL"), "old"));
+            hipLaunchKernelGGL(dc_small_level_kernel, dim3(max_seg, 1, count), dim3(NT_SMALL), 0, s, L, fast);
         } else {
             hipLaunchKernelGGL(dc_setup_kernel, dim3(1, max_seg, count), dim3(256), 0, s, L);
             hipLaunchKernelGGL(dc_rotate_compact_kernel, dim3(ceil_div(maxN, ROT_ROWS), max_seg, count), dim3(256), 0, s, L);
