@@ -9,6 +9,20 @@ constexpr int JACOBI_LDS_MAX = 64;
 constexpr int JACOBI_MAX_N = 1024;
 constexpr int JACOBI_MAX_SWEEPS = 60;
 
+// reciprocal and reciprocal square root to ~2 ulp: hardware seed + two Newton steps
+__device__ __forceinline__ double jac_rcp(double x) {
+    double r = __builtin_amdgcn_rcp(x);
+    r = fma(fma(-x, r, 1.0), r, r);
+    r = fma(fma(-x, r, 1.0), r, r);
+    return r;
+}
+__device__ __forceinline__ double jac_rsqrt(double x) {        // x in [1, 1e300]
+    double r = __builtin_amdgcn_rsq(x);
+    r = r * fma(-0.5 * x * r, r, 1.5);
+    r = r * fma(-0.5 * x * r, r, 1.5);
+    return r;
+}
+
 // pair k of round-robin step `step` over m (even) players; returns p < q
 __device__ __forceinline__ void rr_pair(int k, int step, int m, int &p, int &q) {
     int a, b;
@@ -65,12 +79,19 @@ __device__ void jacobi_body(double *A, int lda, double *V, int ldv, int n, doubl
                 if (q < n) {
                     const double apq = A[p * lda + q];
                     if (fabs(apq) > thresh) {
+                        // The rotation angle only steers convergence; what must hold to rounding is c^2 + s^2 = 1, and
+                        // s = t c with c = rsqrt(1 + t^2) gives that for any t.  So the reciprocal / root chain uses the
+                        // ~2 ulp Newton forms (15 instructions) instead of three IEEE sequences (~110): this section is
+                        // a serial dependency of every Jacobi step.
                         const double app = A[p * lda + p], aqq = A[q * lda + q];
-                        const double theta = (aqq - app) / (2.0 * apq);
+                        const double theta = (aqq - app) * jac_rcp(2.0 * apq);
                         double t;
-                        if (fabs(theta) > 1e150) t = 0.5 / theta;
-                        else t = copysign(1.0, theta) / (fabs(theta) + sqrt(theta * theta + 1.0));
-                        c = 1.0 / sqrt(t * t + 1.0);
+                        if (fabs(theta) > 1e150) t = 0.5 * jac_rcp(theta);
+                        else {
+                            const double th2 = theta * theta + 1.0;
+                            t = copysign(1.0, theta) * jac_rcp(fabs(theta) + th2 * jac_rsqrt(th2));
+                        }
+                        c = jac_rsqrt(t * t + 1.0);
                         s = t * c;
                         active = 1;
                     }

@@ -112,11 +112,20 @@ __global__ __launch_bounds__(256) void wy_apply_kernel(WyBatch b) {
         {
             const double *__restrict__ ra = Vp + (long)(16 * wid + fr) * n;
             d4 acc = {0.0, 0.0, 0.0, 0.0};
-            for (int k0 = kstart; k0 < n; k0 += 4) {
-                const int k = k0 + fq;
-                const double a = (k < n) ? ra[k] : 0.0;
-                const double bb = (k < n) ? Zs[k * WY_LD + fr] : 0.0;
-                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bb, acc, 0, 0, 0);
+            // the panel rows come straight from L2: eight clamped (branch-free) loads in flight ahead of each MFMA run
+            for (int k0 = kstart; k0 < n; k0 += 32) {
+                double a8[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int k = k0 + 4 * u + fq;
+                    a8[u] = ra[k < n ? k : n - 1];
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int k = k0 + 4 * u + fq;
+                    const double bb = Zs[(k < n ? k : n - 1) * WY_LD + fr];
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(k < n ? a8[u] : 0.0, bb, acc, 0, 0, 0);
+                }
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) W1[(16 * wid + fq + 4 * r) * WY_LD + fr] = acc[r];
@@ -126,7 +135,7 @@ __global__ __launch_bounds__(256) void wy_apply_kernel(WyBatch b) {
         {
             const double *__restrict__ ta = Tp + (long)(16 * wid + fr) * WY_NB;
             d4 acc = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll 4
+#pragma unroll
             for (int k0 = 0; k0 < WY_NB; k0 += 4) {
                 const int k = k0 + fq;
                 acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ta[k], W1[k * WY_LD + fr], acc, 0, 0, 0);
@@ -139,12 +148,13 @@ __global__ __launch_bounds__(256) void wy_apply_kernel(WyBatch b) {
         for (int fm = (p * WY_NB) / 16 + wid; fm < nfrag; fm += 4) {
             const int m = 16 * fm + fr;
             d4 acc = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll 4
-            for (int k0 = 0; k0 < WY_NB; k0 += 4) {
-                const int k = k0 + fq;
-                const double a = (m < n) ? Vp[(long)k * n + m] : 0.0;
-                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, W2[k * WY_LD + fr], acc, 0, 0, 0);
-            }
+            const double *__restrict__ vm = Vp + (m < n ? m : n - 1);       // clamped column: rows >= n are never stored
+            double a16[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) a16[u] = vm[(long)(4 * u + fq) * n];
+#pragma unroll
+            for (int u = 0; u < 16; ++u)
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a16[u], W2[(4 * u + fq) * WY_LD + fr], acc, 0, 0, 0);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int row = 16 * fm + fq + 4 * r;
