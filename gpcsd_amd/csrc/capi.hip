@@ -904,7 +904,6 @@ static int predict_impl(gpcsd_ctx *c, const gpcsd_hparams *hp, const double *z, 
         g5.A = M1; g5.lda = nx; g5.B = Bm; g5.ldb = RT; g5.C = S; g5.ldc = RT;
         g5.prof_name = "gemm_pred_cross";
         gemm_f64(c, g5, s);
-        k_fill(c, tot, (long)out_elems, 0.0, s);
         for (int cc = 0; cc < C; ++cc) {
             // Ktstar_c = cov_c.compute_Kt(tstar): (ntstar, nt); its FIRST axis is contracted with the training
             // time index (reference quirk when tstar != t)      gpcsd1d.py:277-279
@@ -917,7 +916,7 @@ static int predict_impl(gpcsd_ctx *c, const gpcsd_hparams *hp, const double *z, 
             GemmDesc g6;                  // out_c[(z,r)][t'] = sum_i' S[(z,r)][i'] Pc[i'][t']
             g6.M = nz * R; g6.N = nt; g6.K = nt;
             g6.A = S; g6.lda = nt; g6.B = Pc; g6.ldb = nt; g6.C = comp; g6.ldc = nt; g6.C2 = tot;
-            g6.epi = EPI_DUAL;
+            g6.epi = (cc == 0) ? EPI_DUAL_INIT : EPI_DUAL;       // the first component initialises the running sum
             g6.prof_name = "gemm_pred_tstar";
             gemm_f64(c, g6, s);
             if (o_list) k_swap_last2(c, comp, o_list + (size_t)cc * out_elems, nz, R, nt, s);   // (z,r,t) -> (z,t,r)
@@ -1012,11 +1011,14 @@ extern "C" int gpcsd_sample_prior(gpcsd_ctx *c, const gpcsd_hparams *hp, int whi
 extern "C" int gpcsd_loglik_grad(gpcsd_ctx *c, const gpcsd_hparams *hp, double *out2, double *grad, int ngrad) {
     GP_API_BEGIN(c)
     GP_REQUIRE(out2 && grad && hp, -3, "loglik_grad: null argument");
-    GP_REQUIRE(hp->n_sig2n == 1, -3, "loglik_grad: the analytic gradient needs a scalar sig2n (per-electrode lists: use finite differences)");
     EigState e = front_half(c, hp, hp->jitter);        // leaves A, Kgl, T = A Kgl in the ks_* buffers
     const Geo g = resident_geo(c);
     const int nx = c->nx, nt = c->nt, R = c->ntrials, C = hp->n_temporal, G = g.G();
-    GP_REQUIRE(ngrad == 1 + g.dim + 2 * C + 1, -3, "loglik_grad: ngrad=%d, expected %d", ngrad, 1 + g.dim + 2 * C + 1);
+    // scalar sig2n: one trailing entry; per-electrode list (indexed by eigen-row like the reference's D): nx entries
+    const int nsig = hp->n_sig2n;
+    GP_REQUIRE(nsig == 1 || nsig == nx, -3, "loglik_grad: sig2n must be a scalar or a list of nx=%d values (got %d)", nx, nsig);
+    const int nhead = 1 + g.dim + 2 * C;
+    GP_REQUIRE(ngrad == nhead + nsig, -3, "loglik_grad: ngrad=%d, expected %d", ngrad, nhead + nsig);
     const long RT = (long)R * nt;
     hipStream_t s = c->stream;
     const double *A = (const double *)c->bufs["ks_A"].p, *Kgl = (const double *)c->bufs["ks_Kgl"].p,
@@ -1111,13 +1113,24 @@ extern "C" int gpcsd_loglik_grad(gpcsd_ctx *c, const gpcsd_hparams *hp, double *
     gemm_f64(c, gr, s);
     k_fwdR_grad(c, P, g.x, nx, g.gx1, g.gw1, g.gx2, g.gw2, G, g.dim == 2 ? g.ngl2 : 0, hp->R, hp->eps, gdev, s);
     double hs[4], hg[64];
+    std::vector<double> hb2, hinv;
+    if (nsig > 1) {                       // d/d sig2n_x = -R/2 sum_i 1/D_xi + 1/2 sum_{r,i} B_{(x,r),i}^2
+        double *b2row = c->buf<double>("grad_b2row", nx);
+        k_rowgroup_sumsq(c, Bm, nx, RT, b2row, s);
+        hb2.resize(nx);
+        hinv.resize(nx);
+        c->download(hb2.data(), b2row, nx * sizeof(double));
+        c->download(hinv.data(), c->bufs["grad_s1row"].p, nx * sizeof(double));   // written by k_D_sums
+    }
     c->download(hs, e.scal, 4 * sizeof(double));
-    c->download(hg, gdev, ngrad * sizeof(double));
+    c->download(hg, gdev, nhead * sizeof(double));
     const int rc = finish_status(c, e.status);
     out2[0] = hs[0];
     out2[1] = hs[1];
-    for (int k = 0; k < ngrad - 1; ++k) grad[k] = hg[k];
-    grad[ngrad - 1] = -0.5 * R * hs[3] + 0.5 * hs[2];
+    for (int k = 0; k < nhead; ++k) grad[k] = hg[k];
+    if (nsig == 1) grad[nhead] = -0.5 * R * hs[3] + 0.5 * hs[2];
+    else
+        for (int x = 0; x < nx; ++x) grad[nhead + x] = -0.5 * R * hinv[x] + 0.5 * hb2[x];
     return rc;
     GP_API_END(c)
 }

@@ -282,7 +282,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f64_kernel(GemmK g) {
     // ---- epilogue ----
     double qsum = 0.0, qsum2 = 0.0;
     double *__restrict__ C = (EPI == EPI_QUAD) ? nullptr : g.C + bz * g.sC;
-    double *__restrict__ C2 = (EPI == EPI_DUAL || EPI == EPI_GRAD) ? g.C2 + bz * g.sC : nullptr;
+    double *__restrict__ C2 = (EPI == EPI_DUAL || EPI == EPI_DUAL_INIT || EPI == EPI_GRAD) ? g.C2 + bz * g.sC : nullptr;
     double *__restrict__ C3 = (EPI == EPI_GRAD) ? g.C3 + bz * g.sC : nullptr;
 #pragma unroll
     for (int i = 0; i < FM; ++i) {
@@ -306,6 +306,10 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f64_kernel(GemmK g) {
                     const double o = g.alpha * v;
                     C[(long)row * g.ldc + col] = o;
                     C2[(long)row * g.ldc + col] += o;
+                } else if (EPI == EPI_DUAL_INIT) {
+                    const double o = g.alpha * v;
+                    C[(long)row * g.ldc + col] = o;
+                    C2[(long)row * g.ldc + col] = o;
                 } else if (EPI == EPI_DIV_D) {
                     C[(long)row * g.ldc + col] = v / g.D[drow + col];
                 } else if (EPI == EPI_GRAD) {
@@ -373,6 +377,7 @@ static void launch_epi(const GemmK &k, int epi, dim3 grid, hipStream_t s) {
         case EPI_ACCUM: hipLaunchKernelGGL((gemm_f64_kernel<WM, WN, FM, FN, BK, TA, TB, EPI_ACCUM>), grid, blk, 0, s, k); break;
         case EPI_DUAL: hipLaunchKernelGGL((gemm_f64_kernel<WM, WN, FM, FN, BK, TA, TB, EPI_DUAL>), grid, blk, 0, s, k); break;
         case EPI_GRAD: hipLaunchKernelGGL((gemm_f64_kernel<WM, WN, FM, FN, BK, TA, TB, EPI_GRAD>), grid, blk, 0, s, k); break;
+        case EPI_DUAL_INIT: hipLaunchKernelGGL((gemm_f64_kernel<WM, WN, FM, FN, BK, TA, TB, EPI_DUAL_INIT>), grid, blk, 0, s, k); break;
         default: throw HipError{-3, "gemm_f64: bad epilogue"};
     }
 }

@@ -218,4 +218,20 @@ void k_fwdR_grad(gpcsd_ctx *c, const double *S, const double *x, int nx, const d
     GP_HIP(hipGetLastError());
 }
 
+// out[x] = sum_k B[x*rowlen + k]^2 : per eigen-row sums of B^2 over all trials and times (d loglik / d sig2n_x for a
+// per-electrode noise list, utility_functions.py:54-63).  One workgroup per x, fixed reduction order.
+__global__ __launch_bounds__(256) void rowgroup_sumsq_kernel(const double *__restrict__ B, long rowlen, double *__restrict__ out) {
+    __shared__ double red[4];
+    const double *__restrict__ b = B + (long)blockIdx.x * rowlen;
+    double s = 0.0;
+    for (long k = threadIdx.x; k < rowlen; k += 256) s += b[k] * b[k];
+    s = block_sum256(s, red);
+    if (threadIdx.x == 0) out[blockIdx.x] = s;
+}
+
+void k_rowgroup_sumsq(gpcsd_ctx *c, const double *B, int nrows, long rowlen, double *out, hipStream_t s) {
+    hipLaunchKernelGGL(rowgroup_sumsq_kernel, dim3(nrows), dim3(256), 0, s, B, rowlen, out);
+    GP_HIP(hipGetLastError());
+}
+
 }  // namespace gpcsd

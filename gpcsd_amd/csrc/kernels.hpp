@@ -11,7 +11,8 @@ enum Epi : int {
     EPI_QUAD = 2,    // no store; partial sums of acc^2 / D[...] (deterministic two-stage reduce)
     EPI_ACCUM = 3,   // C += alpha * acc
     EPI_DUAL = 4,    // C = alpha*acc and C2 += alpha*acc   (predict: per-component + running sum)
-    EPI_GRAD = 5     // b = acc / D: C = b, C2 = b*colscale[col], C3 = b*rowscale[row/rdiv]; sums of acc*b and b*b
+    EPI_GRAD = 5,    // b = acc / D: C = b, C2 = b*colscale[col], C3 = b*rowscale[row/rdiv]; sums of acc*b and b*b
+    EPI_DUAL_INIT = 6  // C = alpha*acc and C2 = alpha*acc (first term of a running sum: no read, no zero fill)
 };
 
 struct GemmDesc {
@@ -105,6 +106,8 @@ void stedc_device(gpcsd_ctx *c, const double *d, const double *e, int n, double 
 // a_x = sum_i et_i/D_xi, b_i = sum_x es_x/D_xi, s1 = sum 1/D
 void k_D_sums(gpcsd_ctx *c, const double *D, const double *es, const double *et, int nx, int nt, double *a, double *b,
               double *s1_out, hipStream_t s);
+// out[x] = sum_k B[x*rowlen + k]^2
+void k_rowgroup_sumsq(gpcsd_ctx *c, const double *B, int nrows, long rowlen, double *out, hipStream_t s);
 // out (n,n) = scale * sum_b in[b*stride + e] + dscale * diag(dvec)
 void k_batch_reduce(gpcsd_ctx *c, const double *in, int nb, long stride, int n, double scale, const double *dvec, double dscale,
                     double *out, hipStream_t s);

@@ -182,10 +182,11 @@ class GPCSDModel:
         return np.float64(-0.5 * ntrials * sumlog - 0.5 * quad)
 
     def _loglik_and_grad_natural(self):
-        """(loglik, d loglik / d[R, ell_s.., (ell_t, sigma2_t).., sig2n]) on the GPU (scalar sig2n)."""
+        """(loglik, d loglik / d[R, ell_s.., (ell_t, sigma2_t).., sig2n or sig2n_0..sig2n_{nx-1}]) on the GPU."""
         ctx = self._sync_device()
         hp, _keep = self._hparams(self.JITTER)
-        ng = 1 + self.dim + 2 * len(self.temporal_cov_list) + 1
+        nsig = 1 if self._sig2n_is_scalar() else len(self.sig2n["value"])
+        ng = 1 + self.dim + 2 * len(self.temporal_cov_list) + nsig
         sumlog, quad, g = ctx.loglik_grad(hp, ng)
         r_local = self._local_lfp().shape[2]
         ll = -0.5 * r_local * sumlog - 0.5 * quad
@@ -257,7 +258,7 @@ class GPCSDModel:
     def _objective_grad(self, tparams, fix_R, fd_step=1e-6):
         """Gradient of `_objective` w.r.t. the log-parameters."""
         tparams = np.asarray(tparams, dtype=np.float64)
-        if self._sig2n_is_scalar() and getattr(self, "_use_analytic_grad", True):
+        if getattr(self, "_use_analytic_grad", True):
             try:
                 self._set_from_tparams(tparams, fix_R)
                 _, g_nat = self._loglik_and_grad_natural()
@@ -266,8 +267,13 @@ class GPCSDModel:
                 for i, (getter, _, prior, _, _) in enumerate(slots):
                     v = getter()
                     g[i] = -(g_nat[i] + prior.dlpdf(v)) * v          # d/dlog(v) = v d/dv
-                v = self.sig2n["value"]
-                g[len(slots)] = -(g_nat[len(slots)] + self.sig2n["prior"].dlpdf(v)) * v
+                p = len(slots)
+                if self._sig2n_is_scalar():
+                    v = self.sig2n["value"]
+                    g[p] = -(g_nat[p] + self.sig2n["prior"].dlpdf(v)) * v
+                else:                                                # per-electrode noise list (gpcsd1d.py:71-73)
+                    for k, (pr, v) in enumerate(zip(self.sig2n["prior"], self.sig2n["value"])):
+                        g[p + k] = -(g_nat[p + k] + pr.dlpdf(v)) * v
                 if fix_R:
                     g[0] = 0.0
                 return g

@@ -404,19 +404,28 @@ def test_loglik_gradient_vs_finite_differences(name):
     assert np.max(np.abs(g_log - fd)) / scale < 2e-5, (g_log, fd)
 
 
-def test_gradient_rejects_sig2n_list_and_fit_falls_back():
+def test_gradient_with_per_electrode_noise_list():
+    """sig2n given per electrode (utility_functions.py:54-63 indexes it by eigen-row): the analytic gradient carries one
+    entry per list element and matches central differences of the oracle; the fit objective gradient uses it."""
     from gpcsd_amd.priors import GPCSDHalfNormalPrior
     m, c, g, geom, hp, lfp = _build_model("1d_siglist_12x40x4")
     m.sig2n = {"value": np.array(c["sig2n"]), "prior": [GPCSDHalfNormalPrior(0.1) for _ in range(12)],
                "min": [1e-8] * 12, "max": [0.5] * 12}
-    with pytest.raises(ValueError):
-        m._loglik_and_grad_natural()
-    # objective gradient still available (central differences of GPU evaluations)
-    tp = m._sample_start(False) * 0 + np.log(np.concatenate([[c["R"] / 100, c["ell_s"][0] / 100],
-                                                             [v for (_, ell, s2) in hp["temporal"] for v in (ell, s2)],
-                                                             c["sig2n"]]))
+    ll, g_nat = m._loglik_and_grad_natural()
+    assert g_nat.shape == (1 + 1 + 2 * len(hp["temporal"]) + 12,)
+    assert abs(ll - float(g["loglik"])) / abs(float(g["loglik"])) < GATE
+    kinds = [k for k, _, _ in hp["temporal"]]
+    vals = np.concatenate([[c["R"]], list(c["ell_s"]), [v for (_, ell, s2) in hp["temporal"] for v in (ell, s2)], c["sig2n"]])
+    scales = np.array([100.0] * 2 + [1.0] * (2 * len(kinds) + 12))
+    tp = np.log(vals / scales)
+    fd = O.loglik_grad_fd(geom, lfp, tp, kinds, 12, eps=c["eps"], jitter=float(g["jitter"]), h=1e-5)
+    assert np.max(np.abs(g_nat * vals - fd)) / np.max(np.abs(fd)) < 2e-5, (g_nat * vals, fd)
+    # objective gradient (log-parameters, priors included) agrees with central differences of the GPU objective
+    ga = m._objective_grad(tp, False)
+    m._use_analytic_grad = False
     gfd = m._objective_grad(tp, False)
-    assert gfd.shape == tp.shape and np.all(np.isfinite(gfd))
+    m._use_analytic_grad = True
+    assert np.max(np.abs(ga - gfd)) / np.max(np.abs(gfd)) < 1e-4, (ga, gfd)
 
 
 def test_fit_improves_objective_and_matches_cpu_optimiser():
