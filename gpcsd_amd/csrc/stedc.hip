@@ -126,7 +126,7 @@ struct SetupShared {
     int sperm[EIG_MAXN], cidx[EIG_MAXN];
     unsigned char sdefl[EIG_MAXN];
     double red[16];
-    int K, nrot, nsurv;
+    int K, nrot, nsurv, close_pairs;
 };
 
 // z, merged order, deflation scan, compacted poles.  Whole workgroup (NW waves).
@@ -200,7 +200,37 @@ __device__ void dc_setup_body(const DcWork &w, const Seg sg, const int m, SetupS
         if (tid == 0) S.nsurv = base;
     }
     __syncthreads();
-    if (tid == 0) {
+    // Close-pair (type b) deflation chains are rare for well separated spectra (none in the Matern/SE temporal Gram
+    // matrices): test every neighbouring pair of survivors with its ORIGINAL values in parallel.  Until the first pair
+    // passes, that is exactly what the sequential scan evaluates, so "no pair passes" means K = nsurv and no rotations,
+    // and the survivors are copied out in parallel.  Otherwise the sequential scan below decides.
+    {
+        const int ns = S.nsurv;
+        if (tid == 0) S.close_pairs = 0;
+        __syncthreads();
+        bool hit = false;
+        for (int p = 1 + tid; p < ns; p += NT) {
+            const double t = S.cd[p] - S.cd[p - 1], zp = S.cz[p - 1], zn = S.cz[p];
+            hit |= fabs(t) * fabs(zp * zn) <= tol * (zp * zp + zn * zn) * (1.0 + 1e-10);
+        }
+        if (hit) S.close_pairs = 1;                 // benign race: every writer stores 1
+        __syncthreads();
+        if (!S.close_pairs) {
+            for (int p = tid; p < ns; p += NT) {
+                w.ndidx[lo + p] = S.cidx[p];
+                w.dk[lo + p] = S.cd[p];
+                w.zk[lo + p] = S.cz[p];
+            }
+            if (tid == 0) {
+                S.K = ns;
+                S.nrot = 0;
+                w.meta[2 * m] = ns;
+                w.meta[2 * m + 1] = 0;
+                w.Kdyn[m] = ns;
+            }
+        }
+    }
+    if (tid == 0 && S.close_pairs) {
         // sequential dlaed2 close-pair scan over the survivors; the pending pole lives in registers and the next
         // survivor is loaded one iteration ahead so LDS latency overlaps the arithmetic
         const int ns = S.nsurv;
