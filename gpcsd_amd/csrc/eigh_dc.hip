@@ -356,177 +356,7 @@ __global__ __launch_bounds__(512) void sytrd_tail_kernel(SytrdBatch b) {
     }
 }
 
-// Register-resident tail: the trailing block (T <= TPR*CPT rows) lives in the VGPRs of ONE workgroup -- thread (row i,
-// part h) keeps columns [h*CPT, (h+1)*CPT) of row i -- so a column step touches LDS only for the four length-T vectors
-// (x = column kk, v, w) and costs four barriers + ~3 CPT fp64 FMAs per thread instead of a dependent launch (4.6 us) or
-// an LDS-resident sweep (3.1 us at T = 113).  The matrix is kept full (both triangles) so the pivot ROW kk is read as
-// COLUMN kk: every row thread extracts its own element a[i][kk] with one indexed register read (kk is wave-uniform).
-// Dead rows / columns need no masks in the inner loops: v and w are published with zeros there.
-typedef double d16 __attribute__((ext_vector_type(16)));
-
-template <int TPR, int CPT>
-__global__ __launch_bounds__(TPR *TPR *CPT) void sytrd_regtail_kernel(SytrdBatch b) {
-    constexpr int TMAX = TPR * CPT, NTH = TMAX * TPR, NW = NTH / 64, NCH = CPT / 16;
-    static_assert(CPT % 16 == 0 && (TPR == 2 || TPR == 4) && NTH % 64 == 0, "layout");
-    const SytrdProb &P = b.p[blockIdx.x];
-    const int n = P.n, k0 = P.k_tail;
-    if (k0 >= n - 1) return;
-    const int T = n - k0;                    // rows / columns k0 .. n-1, T <= TMAX
-    __shared__ double sx[TMAX], sv[TMAX], sw[TMAX], red[2][NW];
-    __shared__ double sd[TMAX], se[TMAX], st[TMAX];
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int i = tid / TPR, h = tid % TPR;  // my row, my column part
-    const int c0 = h * CPT;
-    const double *__restrict__ Ain = (k0 & 1) ? P.A1 : P.A0;
-    const double *__restrict__ yin = (k0 & 1) ? P.y1 : P.y0;
-
-    // pending rank-2 update of step k0-1 (its reflector and y = A v are in global memory)
-    {
-        double pv = 0.0, py = 0.0, taup = 0.0;
-        if (k0 > 0) {
-            taup = P.tau[k0 - 1];
-            if (tid < T) {
-                pv = P.V[(long)(k0 - 1) * n + k0 + tid];
-                py = yin[k0 + tid];
-            }
-        }
-        double part = wave_sum(pv * py);
-        if (lane == 0) red[0][wid] = part;
-        __syncthreads();
-        double dot = 0.0;
-#pragma unroll
-        for (int q = 0; q < NW; ++q) dot += red[0][q];
-        const double cc = 0.5 * taup * taup * dot;
-        if (tid < TMAX) {
-            sv[tid] = pv;
-            sw[tid] = taup * py - cc * pv;
-        }
-        __syncthreads();
-    }
-    d16 a[NCH];
-    {
-        const bool rok = i < T;
-        const double *__restrict__ arow = Ain + (long)(k0 + (rok ? i : 0)) * n + k0;
-        const double vi = sv[i], wi = sw[i];
-#pragma unroll
-        for (int q = 0; q < NCH; ++q)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int c = c0 + 16 * q + r;
-                const double g = (rok && c < T) ? arow[c] : 0.0;
-                a[q][r] = (rok && c < T) ? g - vi * sw[c] - wi * sv[c] : 0.0;
-            }
-    }
-    __syncthreads();
-
-    for (int kk = 0; kk < T - 1; ++kk) {
-        const int hk = kk / CPT, jk = kk % CPT;          // wave-uniform
-        const bool live = (wid + 1) * (64 / TPR) - 1 > kk;   // this wave still owns a row > kk (wave-uniform)
-        // (1) x = column kk; ||x[kk+2:]||^2
-        double xi = 0.0, part = 0.0;
-        if (h == hk) {
-#pragma unroll
-            for (int q = 0; q < NCH; ++q)
-                if (jk / 16 == q) xi = a[q][jk % 16];
-            sx[i] = xi;
-            part = (i > kk + 1) ? xi * xi : 0.0;
-        }
-        part = wave_sum(part);
-        if (lane == 0) red[0][wid] = part;
-        __syncthreads();
-        double xnorm2 = 0.0;
-#pragma unroll
-        for (int q = 0; q < NW; ++q) xnorm2 += red[0][q];
-        const double dk = sx[kk], alpha = sx[kk + 1];
-        const int m = T - kk - 1;
-        double tau = 0.0, beta = alpha, scal = 0.0;
-        if (m >= 2 && xnorm2 > 0.0) {
-            beta = -copysign(sqrt(alpha * alpha + xnorm2), alpha);
-            tau = (beta - alpha) / beta;
-            scal = 1.0 / (alpha - beta);
-        }
-        // (2) publish the reflector (zeros on dead entries make every later loop mask-free)
-        double vi = 0.0;
-        if (h == hk) {
-            vi = (i > kk + 1) ? xi * scal : (i == kk + 1 ? 1.0 : 0.0);
-            sv[i] = vi;
-            if (i < T) P.V[(long)(k0 + kk) * n + k0 + i] = vi;
-        }
-        if (tid == 0) {
-            sd[kk] = dk;
-            se[kk] = beta;
-            st[kk] = tau;
-        }
-        __syncthreads();
-        if (tau != 0.0) {                                  // uniform: tau == 0 means H = I, nothing to update
-            // (3) y_i = sum_c a[i][c] v_c over my columns, folded over the TPR threads of the row
-            double yi = 0.0;
-            if (live) {
-                const double2 *__restrict__ v2 = reinterpret_cast<const double2 *>(sv + c0);
-                double acc0 = 0.0, acc1 = 0.0;
-#pragma unroll
-                for (int q = 0; q < NCH; ++q)
-#pragma unroll
-                    for (int r = 0; r < 16; r += 2) {
-                        const double2 vv = v2[(16 * q + r) / 2];
-                        acc0 += a[q][r] * vv.x;
-                        acc1 += a[q][r + 1] * vv.y;
-                    }
-                yi = acc0 + acc1;
-                yi += dpp_mov<0xB1>(yi);
-                if (TPR == 4) yi += dpp_mov<0x4E>(yi);
-                if (i <= kk) yi = 0.0;
-            }
-            vi = sv[i];
-            double dp = (h == 0) ? vi * yi : 0.0;
-            dp = wave_sum(dp);
-            if (lane == 0) red[1][wid] = dp;
-            __syncthreads();
-            double dot = 0.0;
-#pragma unroll
-            for (int q = 0; q < NW; ++q) dot += red[1][q];
-            const double cc = 0.5 * tau * tau * dot;
-            // (4) w = tau y - cc v (zero on dead rows because y and v are)
-            const double wi = tau * yi - cc * vi;
-            if (h == 0) sw[i] = wi;
-            __syncthreads();
-            // (5) rank-2 update of my row segment
-            if (live) {
-                const double2 *__restrict__ v2 = reinterpret_cast<const double2 *>(sv + c0);
-                const double2 *__restrict__ w2 = reinterpret_cast<const double2 *>(sw + c0);
-#pragma unroll
-                for (int q = 0; q < NCH; ++q)
-#pragma unroll
-                    for (int r = 0; r < 16; r += 2) {
-                        const double2 vv = v2[(16 * q + r) / 2], ww = w2[(16 * q + r) / 2];
-                        a[q][r] -= vi * ww.x + wi * vv.x;
-                        a[q][r + 1] -= vi * ww.y + wi * vv.y;
-                    }
-            }
-        }
-    }
-    // last diagonal element: a[T-1][T-1]
-    {
-        const int kk = T - 1, hk = kk / CPT, jk = kk % CPT;
-        if (i == kk && h == hk) {
-            double xi = 0.0;
-#pragma unroll
-            for (int q = 0; q < NCH; ++q)
-                if (jk / 16 == q) xi = a[q][jk % 16];
-            sd[kk] = xi;
-            se[kk] = 0.0;
-            st[kk] = 0.0;
-        }
-    }
-    __syncthreads();
-    for (int kk = tid; kk < T; kk += NTH) {
-        P.d[k0 + kk] = sd[kk];
-        P.e[k0 + kk] = se[kk];
-        P.tau[k0 + kk] = st[kk];
-    }
-}
-
-constexpr int SY_REGTAIL = 192;             // = TPR * CPT of the instantiation launched below
+constexpr int SY_REGTAIL = RT_T;            // rows the register-resident tail (sytrd_regtail.hpp) can hold
 static bool sytrd_reg_tail() {               // GPCSD_TAIL=lds selects the older LDS-resident tail (A/B comparisons)
     static const bool lds = getenv("GPCSD_TAIL") && !strcmp(getenv("GPCSD_TAIL"), "lds");
     return !lds;
@@ -548,9 +378,7 @@ static void sytrd_batch_launch(gpcsd_ctx *c, const SytrdBatch &b, int count, int
         else hipLaunchKernelGGL(sytrd_step_kernel<16>, grid, dim3(256), 0, s, b, k);
     }
     if (any_tail && sytrd_reg_tail()) {
-        static const bool v1 = getenv("GPCSD_TAIL") && !strcmp(getenv("GPCSD_TAIL"), "reg1");
-        if (v1) hipLaunchKernelGGL((sytrd_regtail_kernel<4, 48>), dim3(count), dim3(768), 0, s, b);
-        else hipLaunchKernelGGL(sytrd_rtail_kernel, dim3(count), dim3(RT_NTH), 0, s, b);
+        hipLaunchKernelGGL(sytrd_rtail_kernel, dim3(count), dim3(RT_NTH), 0, s, b);
     } else if (any_tail) {
         const size_t sh = ((size_t)(SY_TAIL + 1) * SY_TLD + 6 * 128 + 32) * sizeof(double);
         static bool attr_set = false;
