@@ -48,6 +48,7 @@ static bool env_flag(const char *name, const char *value) {
     const char *e = getenv(name);
     return e && std::string(e) == value;
 }
+constexpr int EIG_BATCH_MIN_N = 16;      // smallest problem sent through the tridiagonalisation + D&C pipeline
 static bool force_jacobi() {
     static const bool v = env_flag("GPCSD_EIGH", "jacobi");
     return v;
@@ -157,9 +158,13 @@ static void eigh_pair_enqueue(gpcsd_ctx *c, double *A0, int n0, double *w0, doub
         double *ws, *Us, *wa, *Ua;
     } fold[2];
     static const char *tags[2][3] = {{"p0", "p0s", "p0a"}, {"p1", "p1s", "p1a"}};
+    // A small problem next to a large one rides along in the large problem's launches for free (GPCSD1D: 24 electrodes
+    // next to 500 time points), instead of a serial 250 us single-workgroup Jacobi in front of them.
+    const bool pair_has_large = !force_jacobi() && (n0 > JACOBI_LDS_MAX || n1 > JACOBI_LDS_MAX);
     auto submit = [&](double *Am, int nm, double *wm, double *Zm, const char *tag) {
         if (nm <= 0) return;
-        if (nm <= JACOBI_LDS_MAX || force_jacobi()) eigh_jacobi(c, Am, nm, wm, Zm, d_status, s, tag);
+        const bool small = nm <= JACOBI_LDS_MAX && !(pair_has_large && nm >= EIG_BATCH_MIN_N);
+        if (small || force_jacobi()) eigh_jacobi(c, Am, nm, wm, Zm, d_status, s, tag);
         else {
             large[nlarge].A = Am; large[nlarge].n = nm; large[nlarge].w = wm; large[nlarge].Z = Zm; large[nlarge].tag = tag;
             ++nlarge;

@@ -386,6 +386,27 @@ def test_eigh_gpcsd_shaped(ctx, n):
     w, V = _check_eigh(ctx, Ks + 1e-7 * np.eye(n))
 
 
+@pytest.mark.parametrize("ns,nl", [(24, 100), (17, 130), (40, 96), (64, 65), (16, 250)])
+def test_small_problem_rides_in_the_large_batch(ctx, ns, nl):
+    """A small Gram matrix next to a large one goes through the batched sytrd/D&C pipeline (not Jacobi): check both
+    decompositions of the pair at eigenvector level."""
+    rs = np.random.RandomState(ns * 1000 + nl)
+    def spd(n):
+        X = rs.standard_normal((n, n + 3))
+        return X @ X.T / n
+    Ks, Kt = spd(ns), spd(nl)
+    Qs, Qt, D = ctx.eig_D(Ks, Kt, 0.1)
+    for K, Q in ((Ks, Qs), (Kt, Qt)):
+        n = K.shape[0]
+        w = np.linalg.eigvalsh(K)
+        lam = np.einsum("ij,ij->j", Q, K @ Q)
+        assert np.max(np.abs(Q.T @ Q - np.eye(n))) < 1e-13 * n
+        assert np.max(np.abs(np.sort(lam) - w)) < 1e-13 * n * np.abs(w).max()
+        assert np.max(np.abs(K @ Q - Q * lam[None, :])) < 1e-12 * n * np.abs(w).max()
+    es, et = np.linalg.eigvalsh(Ks), np.linalg.eigvalsh(Kt)
+    assert relerr(np.sort(D), np.sort(np.outer(es, et).ravel() + 0.1)) < 1e-12
+
+
 # ------------------------------------------------------------------------------------------------ gradient + fit
 @pytest.mark.parametrize("name", ["1d_wide_24x60x3", "cfg1_1d_24x100x1", "1d_odd_17x37x5", "2d_grid_48x40x2"])
 def test_loglik_gradient_vs_finite_differences(name):
