@@ -1008,6 +1008,11 @@ extern "C" int gpcsd_sample_prior(gpcsd_ctx *c, const gpcsd_hparams *hp, int whi
     GP_API_END(c)
 }
 
+static bool env_flag_off(const char *name) {       // NAME=0 switches a term off (diagnostics)
+    const char *v = getenv(name);
+    return v && v[0] == '0';
+}
+
 extern "C" int gpcsd_loglik_grad(gpcsd_ctx *c, const gpcsd_hparams *hp, double *out2, double *grad, int ngrad) {
     GP_API_BEGIN(c)
     GP_REQUIRE(out2 && grad && hp, -3, "loglik_grad: null argument");
@@ -1053,6 +1058,19 @@ extern "C" int gpcsd_loglik_grad(gpcsd_ctx *c, const gpcsd_hparams *hp, double *
     gemm_f64(c, gs, s);
     double *Ghs = c->buf<double>("grad_Ghs", (size_t)nx * nx);
     k_batch_reduce(c, Cs, R, (long)nx * nx, nx, 0.5, av, -0.5 * R, Ghs, s);
+    if (nsig > 1 && !env_flag_off("GPCSD_SIGLIST_EIGVEC_TERM")) {
+        // noise tied to the eigen-index: eigenvector-rotation term, S = sum_r B_r B_r^T (see grad.hip)
+        GemmDesc g3 = gs;
+        g3.A = Bm;
+        g3.prof_name = "gemm_grad_BBt";
+        gemm_f64(c, g3, s);
+        double *Ssum = c->buf<double>("grad_Ssum", (size_t)nx * nx);
+        double *zero = c->buf<double>("grad_zero", nx);
+        k_fill(c, zero, nx, 0.0, s);
+        k_batch_reduce(c, Cs, R, (long)nx * nx, nx, 1.0, zero, 0.0, Ssum, s);
+        double *dsig = c->upload<double>("grad_sig", hp->sig2n, nx);
+        k_siglist_eigvec_term(c, Ghs, Ssum, e.es, dsig, nx, 0.0, s);
+    }
     // Ghat_t = 1/2 sum_{(x,r)} (B es)^T B - R/2 diag(b)    (row chunks of 512, batched; remainder separately)
     const long rows = (long)nx * R;
     const int CH = 512;

@@ -234,4 +234,27 @@ void k_rowgroup_sumsq(gpcsd_ctx *c, const double *B, int nrows, long rowlen, dou
     GP_HIP(hipGetLastError());
 }
 
+// Per-electrode noise lists are attached to the EIGEN-index of Ks (utility_functions.py:54-63), so the objective is not a
+// function of Ks alone: rotating the eigenvectors moves noise between them.  With B = alpha/D and S = sum_r B_r B_r^T
+// the extra first-order term is  -1/2 sum_{x != y} dKhat_yx (sig_y - sig_x)/(es_x - es_y) S_xy, i.e. a symmetric
+// correction of Ghat_s (what the reference's autograd obtains from the eigh VJP).  Pairs whose eigenvalues coincide to
+// rounding are skipped (the reference produces inf/NaN there).
+__global__ __launch_bounds__(256) void siglist_eigvec_term_kernel(double *__restrict__ Ghs, const double *__restrict__ Ssum,
+                                                                  const double *__restrict__ es, const double *__restrict__ sig,
+                                                                  int nx, double tiny) {
+    const long e = blockIdx.x * 256L + threadIdx.x;
+    if (e >= (long)nx * nx) return;
+    const int y = (int)(e / nx), x = (int)(e % nx);
+    if (x == y) return;
+    const double de = es[x] - es[y];
+    if (fabs(de) <= tiny) return;
+    Ghs[e] += -0.5 * (sig[y] - sig[x]) / de * Ssum[(long)x * nx + y];
+}
+
+void k_siglist_eigvec_term(gpcsd_ctx *c, double *Ghs, const double *Ssum, const double *es, const double *sig, int nx,
+                           double tiny, hipStream_t s) {
+    hipLaunchKernelGGL(siglist_eigvec_term_kernel, dim3(ceil_div((long)nx * nx, 256)), dim3(256), 0, s, Ghs, Ssum, es, sig, nx, tiny);
+    GP_HIP(hipGetLastError());
+}
+
 }  // namespace gpcsd

@@ -106,6 +106,9 @@ void stedc_device(gpcsd_ctx *c, const double *d, const double *e, int n, double 
 // a_x = sum_i et_i/D_xi, b_i = sum_x es_x/D_xi, s1 = sum 1/D
 void k_D_sums(gpcsd_ctx *c, const double *D, const double *es, const double *et, int nx, int nt, double *a, double *b,
               double *s1_out, hipStream_t s);
+// Ghs[y][x] += -1/2 (sig_y - sig_x)/(es_x - es_y) Ssum[x][y] for x != y, |es_x - es_y| > tiny
+void k_siglist_eigvec_term(gpcsd_ctx *c, double *Ghs, const double *Ssum, const double *es, const double *sig, int nx,
+                           double tiny, hipStream_t s);
 // out[x] = sum_k B[x*rowlen + k]^2
 void k_rowgroup_sumsq(gpcsd_ctx *c, const double *B, int nrows, long rowlen, double *out, hipStream_t s);
 // out (n,n) = scale * sum_b in[b*stride + e] + dscale * diag(dvec)

@@ -135,7 +135,8 @@ int gpcsd_loglik(gpcsd_ctx *ctx, const gpcsd_hparams *hp, double *out);
 int gpcsd_loglik_parts(gpcsd_ctx *ctx, const gpcsd_hparams *hp, double *out2);
 /* Local log-likelihood pieces and the gradient of  L_loc = -0.5*ntrials_resident*out2[0] - 0.5*out2[1]  with respect
  * to the natural hyper-parameters [R, ell_s (dim), (ell_t, sigma2_t) per component, sig2n]; with a per-electrode
- * noise list (hp->n_sig2n == nx, indexed by eigen-row as utility_functions.py:54-63) the tail holds nx entries.
+ * noise list (hp->n_sig2n == nx, indexed by eigen-row as utility_functions.py:54-63) the tail holds nx entries and the
+ * spatial entries include the eigenvector-rotation term (the objective is then not a function of Ks alone).
  * Replaces the autograd tape of gpcsd1d.py:211 / gpcsd2d.py:250.  Both L_loc and grad are sums over trials plus a
  * term linear in the resident trial count, so shards combine by plain summation over ranks. */
 int gpcsd_loglik_grad(gpcsd_ctx *ctx, const gpcsd_hparams *hp, double *out2, double *grad, int ngrad);
