@@ -304,33 +304,102 @@ class GPCSDModel:
                 tp.append(np.log(pr.sample()))
         return np.array(tp)
 
-    def _fit(self, n_restarts, method, fix_R, verbose, options, starts=None):
-        nll_values, params, term_msg = [], [], []
+    # ------------------------------------------------------------------ restarts: concurrency and sharding
+    def shard_restarts(self, sharding):
+        """Split the restarts of `fit` across ranks (restart k runs on rank k % world_size, every rank holds all trials);
+        results are combined with two tiny all-reduces and every rank ends with the same best parameters
+        (BASELINE cfg5).  `sharding`: gpcsd_amd.dist.TrialSharding (only rank / world_size / allreduce)."""
+        self._restart_sharding = sharding
+
+    def _clone_for_worker(self):
+        """Independent hyper-parameter state on top of the SAME data arrays, with its own device context (= own HIP stream):
+        restarts are latency-bound chains of small kernels, so several of them interleave well on one GPU."""
+        import copy
+        m = copy.copy(self)
+        m.R = copy.deepcopy(self.R)
+        m.sig2n = copy.deepcopy(self.sig2n)
+        m.spatial_cov = copy.copy(self.spatial_cov)
+        m.spatial_cov.params = copy.deepcopy(self.spatial_cov.params)
+        m.temporal_cov_list = []
+        for tc in self.temporal_cov_list:
+            t2 = copy.copy(tc)
+            t2.params = copy.deepcopy(tc.params)
+            m.temporal_cov_list.append(t2)
+        m._ctx = None
+        m._resident = {}
+        return m
+
+    def _run_restart(self, tparams0, method, fix_R, options, bounds):
+        try:
+            res = scipy.optimize.minimize(lambda tp: self._objective(tp, fix_R), tparams0, method=method, options=options,
+                                          bounds=bounds, jac=lambda tp: self._objective_grad(tp, fix_R))
+            return res.fun, res.x, res.message
+        except (ValueError, np.linalg.LinAlgError) as e:
+            print(e)
+            if self.dim == 2:
+                print("\nrestarting optimization...")
+            return None
+
+    def _fit(self, n_restarts, method, fix_R, verbose, options, starts=None, workers=1):
         bounds = self._bounds()
-        for k in tqdm(range(n_restarts), desc="Restarts"):
-            tparams0 = self._sample_start(fix_R) if starts is None else np.asarray(starts[k], dtype=np.float64)
-            try:
-                res = scipy.optimize.minimize(lambda tp: self._objective(tp, fix_R), tparams0, method=method, options=options,
-                                              bounds=bounds, jac=lambda tp: self._objective_grad(tp, fix_R))
-                nll_values.append(res.fun)
-                params.append(res.x)
-                term_msg.append(res.message)
-            except (ValueError, np.linalg.LinAlgError) as e:
-                print(e)
-                if self.dim == 2:
-                    print("\nrestarting optimization...")
-        nll_values = np.array(nll_values)
+        # starting points are drawn up front, in the order the sequential loop of the reference consumes the RNG
+        # (the optimiser itself draws nothing), so results do not depend on `workers` or on the number of ranks
+        if starts is None:
+            starts = [self._sample_start(fix_R) for _ in range(n_restarts)]
+        starts = [np.asarray(s0, dtype=np.float64) for s0 in starts]
+        rs = getattr(self, "_restart_sharding", None)
+        mine = [k for k in range(n_restarts) if rs is None or k % rs.world_size == rs.rank]
+        results = {}
+        workers = max(1, min(int(workers), len(mine)))
+        if workers == 1:
+            for k in tqdm(mine, desc="Restarts"):
+                results[k] = self._run_restart(starts[k], method, fix_R, options, bounds)
+        else:
+            from concurrent.futures import ThreadPoolExecutor
+            import queue
+            pool = queue.Queue()
+            for _ in range(workers):
+                pool.put(self._clone_for_worker())
+
+            def job(k):
+                m = pool.get()
+                try:
+                    return k, m._run_restart(starts[k], method, fix_R, options, bounds)
+                finally:
+                    pool.put(m)
+            with ThreadPoolExecutor(max_workers=workers) as ex:
+                for k, r in ex.map(job, mine):
+                    results[k] = r
+        p = len(starts[0]) if starts else 0
+        status = np.zeros(n_restarts)            # 0 failed, 1 finite optimum, 2 non-finite objective
+        nll_all = np.zeros(n_restarts)
+        par_all = np.zeros((n_restarts, p))
+        msgs = {}
+        for k, r in results.items():
+            if r is None:
+                continue
+            fun, x, msg = r
+            status[k] = 1 if np.isfinite(fun) else 2
+            nll_all[k] = fun if np.isfinite(fun) else 0.0
+            par_all[k] = x
+            msgs[k] = msg
+        if rs is not None:
+            status = rs.allreduce_sum(status)
+            nll_all = rs.allreduce_sum(nll_all)
+            par_all = rs.allreduce_sum(par_all.ravel()).reshape(n_restarts, p)
+        done = [k for k in range(n_restarts) if status[k] > 0]
+        nll_values = np.array([nll_all[k] if status[k] == 1 else np.inf for k in done])
         if len(nll_values) < 1:
             print("problem with optimization!")
             return None
         finite = np.isfinite(nll_values)
+        params = [par_all[k] for k, ok in zip(done, finite) if ok]
         best_ind = np.argmin(nll_values[finite])
-        params = [p for p, ok in zip(params, finite) if ok]
         if verbose:
             print("\nNeg log lik values across different initializations:")
             print(nll_values)
             print("Best index termination message")
-            print(term_msg[best_ind])
+            print(msgs.get([k for k, ok in zip(done, finite) if ok][best_ind], "(other rank)"))
         self._set_from_tparams(params[best_ind], fix_R)
         self.fit_nll_values_ = nll_values
         self.fit_params_ = params

@@ -89,3 +89,83 @@ def test_sharded_loglik_and_gather_world2():
     assert perr < 1e-12
     assert all(r[3] == [0.0, 1.0, 2.0, 3.0, 4.0] for r in res)
     assert sorted(r[4] for r in res) == [(0, 3), (3, 5)]
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# fit(): restarts run concurrently (workers) and sharded over ranks -- host logic only, the objective is a stub
+# ---------------------------------------------------------------------------------------------------------------------
+def _stub_model():
+    """GPCSDModel whose objective is an analytic multi-well function of two log-parameters (no device needed)."""
+    from gpcsd_amd.model_base import GPCSDModel
+
+    class _P:
+        params = {}
+
+    class Stub(GPCSDModel):
+        dim = 1
+
+        def __init__(self):
+            self.R = {"value": 1.0}
+            self.sig2n = {"value": 0.1}
+            self.spatial_cov = _P()
+            self.temporal_cov_list = []
+            self.best = None
+
+        def _bounds(self):
+            return [(-3.0, 3.0), (-3.0, 3.0)]
+
+        def _objective(self, tp, fix_R):
+            x, y = tp
+            return float((x * x - 1.0) ** 2 + 0.3 * x + (y - 0.5) ** 2)
+
+        def _objective_grad(self, tp, fix_R, fd_step=1e-6):
+            x, y = tp
+            return np.array([4.0 * x * (x * x - 1.0) + 0.3, 2.0 * (y - 0.5)])
+
+        def _set_from_tparams(self, tp, fix_R):
+            self.best = np.array(tp, dtype=np.float64)
+
+    return Stub()
+
+
+def _restart_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as td
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    td.init_process_group("gloo", rank=rank, world_size=world)
+    from gpcsd_amd.dist import TrialSharding
+    m = _stub_model()
+    m.shard_restarts(TrialSharding())
+    starts = [np.array([s, -s]) for s in np.linspace(-2.0, 2.0, 7)]
+    m._fit(7, "L-BFGS-B", False, False, {"maxiter": 200}, starts=starts, workers=2)
+    q.put((rank, m.best.tolist(), np.asarray(m.fit_nll_values_).tolist()))
+    td.destroy_process_group()
+
+
+def test_fit_restarts_workers_match_sequential():
+    starts = [np.array([s, -s]) for s in np.linspace(-2.0, 2.0, 7)]
+    a, b = _stub_model(), _stub_model()
+    a._fit(7, "L-BFGS-B", False, False, {"maxiter": 200}, starts=starts, workers=1)
+    b._fit(7, "L-BFGS-B", False, False, {"maxiter": 200}, starts=starts, workers=3)
+    assert np.allclose(a.fit_nll_values_, b.fit_nll_values_, rtol=0, atol=0)
+    assert np.array_equal(a.best, b.best)
+    assert abs(a.best[0] + 1.03) < 0.02 and abs(a.best[1] - 0.5) < 1e-5       # the deeper of the two wells
+
+
+@pytest.mark.timeout(300)
+def test_fit_restart_sharding_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_restart_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=240) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+    seq = _stub_model()
+    seq._fit(7, "L-BFGS-B", False, False, {"maxiter": 200}, starts=[np.array([s, -s]) for s in np.linspace(-2.0, 2.0, 7)])
+    for rank, best, nll in res:
+        assert np.allclose(best, seq.best, rtol=0, atol=1e-12)
+        assert np.allclose(nll, seq.fit_nll_values_, rtol=0, atol=1e-12)

@@ -497,3 +497,18 @@ def test_fit_improves_objective_and_matches_cpu_optimiser():
     res = scipy.optimize.minimize(cpu_obj, start, method="L-BFGS-B", bounds=m._bounds(),
                                   options={"maxiter": 60, "gtol": 1e-6, "ftol": 1e-12})
     assert abs(res.fun - nll_fit) / abs(res.fun) < 1e-4
+
+
+def test_fit_concurrent_restarts_match_sequential():
+    """fit(workers=k): restarts run concurrently on one GPU, each on its own context / stream, and give the same optima
+    as the sequential loop (deterministic kernels, starts drawn up front)."""
+    m1, c, g, geom, hp, lfp = _build_model("1d_odd_17x37x5")
+    m2, *_ = _build_model("1d_odd_17x37x5")
+    np.random.seed(11)
+    starts = [m1._sample_start(False) for _ in range(4)]
+    opts = {"maxiter": 25, "disp": False, "gtol": 1e-5, "ftol": 1e7 * np.finfo(float).eps}
+    m1.fit(n_restarts=4, options=opts, starts=starts, workers=1)
+    m2.fit(n_restarts=4, options=opts, starts=starts, workers=3)
+    assert np.allclose(m1.fit_nll_values_, m2.fit_nll_values_, rtol=1e-10, atol=0)
+    assert abs(m1.R["value"] - m2.R["value"]) <= 1e-9 * abs(m1.R["value"])
+    assert abs(m1.loglik() - m2.loglik()) <= 1e-9 * abs(m1.loglik())
