@@ -7,7 +7,7 @@ Behavioural contract (reference: src/gpcsd/gpcsd1d.py, src/gpcsd/gpcsd2d.py):
   * loglik adds JITTER*I to Ks, predict does not; neither adds the -N/2 log(2 pi) constant;
   * fit optimises -(loglik + log-prior) over log-parameters with L-BFGS-B from prior-sampled restarts and keeps the
     best finite optimum; the reference's autograd gradient is replaced by an analytic gradient computed on the GPU
-    (scalar sig2n) or central differences of GPU evaluations (per-electrode sig2n list);
+    (scalar sig2n or a per-electrode list); restarts can run concurrently (`workers`) and be sharded over ranks;
   * predict(z, t, type) fills csd_pred / csd_pred_list / lfp_pred / lfp_pred_list / t_pred / x_pred.
 """
 import numpy as np
