@@ -161,7 +161,10 @@ def pmc_traffic(prof_name):
         return None, None
     with open(PMC_PROFILE) as fh:
         rows = json.load(fh)["rows"]
-    cand = [r for r in rows if r["kernel"].startswith("gemm_f64_kernel<") and r["kernel"].endswith(", %d>" % epi)
+    def epi_of(kernel):                      # gemm_f64_kernel<WM, WN, FM, FN, BK, TA, TB, EPI, NBUF>
+        args = kernel[kernel.index("<") + 1:kernel.rindex(">")].split(",")
+        return int(args[7]) if len(args) >= 8 else -1
+    cand = [r for r in rows if r["kernel"].startswith("gemm_f64_kernel<") and epi_of(r["kernel"]) == epi
             and "hbm_traffic_bytes_per_launch" in r]
     if not cand:
         return None, None
