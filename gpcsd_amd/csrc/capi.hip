@@ -229,9 +229,25 @@ void eig_pair_D(gpcsd_ctx *c, double *Ks, int nx, double *Kt, int nt, const doub
 struct EigState {
     double *Qs, *Qt, *es, *et, *D, *scal;   // scal[0] = sumlog, scal[1] = quad, ...
     int *status;
+    // two-stream front half: the temporal chain (Kt, its eigen-decomposition) runs on stream2 and has not been waited
+    // for yet; join_temporal() makes Qt / et / D available on the main stream
+    bool pending = false;
+    const double *d_sig = nullptr;
+    int nsig = 0;
 };
 
+static bool two_stream_front() {            // GPCSD_TWO_STREAM=0: single batched chain (A/B comparisons)
+    static const bool off = getenv("GPCSD_TWO_STREAM") && getenv("GPCSD_TWO_STREAM")[0] == '0';
+    return !off;
+}
+
 // Shared front half of loglik / predict: Ks (+jitter), Kt, eigen-decompositions, D.
+//
+// The spatial and the temporal side are independent until D = es (x) et + sig2n, and both are chains of small
+// latency-bound launches.  They run on two streams: stream2 builds Kt and decomposes it, the main stream assembles Ks
+// (three GEMMs, ~0.2 ms at 384 electrodes) and decomposes it; the caller then keeps working on the main stream with Qs
+// alone (the spatial projection W = Qs^T Y, ~0.15 ms) and calls join_temporal() right before the first use of
+// Qt / et / D.  At cfg3 the temporal chain (1.2 ms) is the critical path and everything spatial hides behind it.
 EigState front_half(gpcsd_ctx *c, const gpcsd_hparams *hp, double jitter) {
     const Geo g = resident_geo(c);
     GP_REQUIRE(c->d_lfp != nullptr, -4, "lfp not set (call gpcsd_set_lfp)");
@@ -253,12 +269,40 @@ EigState front_half(gpcsd_ctx *c, const gpcsd_hparams *hp, double jitter) {
     double *d_sig = c->upload<double>("sig2n", hp->sig2n, hp->n_sig2n);
     GP_HIP(hipMemsetAsync(e.status, 0, 4 * sizeof(int), s));
     const double *t = (const double *)c->bufs["time_t"].p;
+    const SymDev *sym_s = c->sym_s.ns > 0 ? &c->sym_s : nullptr, *sym_t = c->sym_t.ns > 0 ? &c->sym_t : nullptr;
+    if (!two_stream_front()) {
+        build_kphi(c, g, hp->R, hp->eps, hp->ell_s, nullptr, 0, jitter, Ks, s);
+        build_kt(c, hp, t, nt, t, nt, Kt, s);
+        // the symmetries come from the resident geometry / time grid, so they hold for the Grams built from them
+        eig_pair_D(c, Ks, nx, Kt, nt, d_sig, hp->n_sig2n, e.Qs, e.es, e.Qt, e.et, e.D, e.scal, e.status, sym_s, sym_t);
+        return e;
+    }
+    hipStream_t s2 = c->stream2;
+    GP_HIP(hipEventRecord(c->ev_fork, s));                 // stream2 starts after the uploads / memset queued above
+    GP_HIP(hipStreamWaitEvent(s2, c->ev_fork, 0));
+    build_kt(c, hp, t, nt, t, nt, Kt, s2);
+    {
+        ProfScope ps(c, "eigh_temporal", 9.0 * (double)nt * nt * nt, s2);
+        eigh_pair_device(c, nullptr, 0, nullptr, nullptr, nullptr, Kt, nt, e.et, e.Qt, sym_t, e.status, s2);
+    }
+    GP_HIP(hipEventRecord(c->ev_join, s2));
     build_kphi(c, g, hp->R, hp->eps, hp->ell_s, nullptr, 0, jitter, Ks, s);
-    build_kt(c, hp, t, nt, t, nt, Kt, s);
-    // the symmetries come from the resident geometry / time grid, so they hold for the Grams built from them
-    eig_pair_D(c, Ks, nx, Kt, nt, d_sig, hp->n_sig2n, e.Qs, e.es, e.Qt, e.et, e.D, e.scal, e.status,
-               c->sym_s.ns > 0 ? &c->sym_s : nullptr, c->sym_t.ns > 0 ? &c->sym_t : nullptr);
+    {
+        ProfScope ps(c, "eigh_spatial", 9.0 * (double)nx * nx * nx, s);
+        eigh_pair_device(c, Ks, nx, e.es, e.Qs, sym_s, nullptr, 0, nullptr, nullptr, nullptr, e.status, s);
+    }
+    e.pending = true;
+    e.d_sig = d_sig;
+    e.nsig = hp->n_sig2n;
     return e;
+}
+
+// Main stream waits for the temporal chain; then D and sum(log D).  No-op after the single-stream front half.
+void join_temporal(gpcsd_ctx *c, EigState &e) {
+    if (!e.pending) return;
+    GP_HIP(hipStreamWaitEvent(c->stream, c->ev_join, 0));
+    k_build_D(c, e.es, c->nx, e.et, c->nt, e.d_sig, e.nsig, e.D, e.scal, c->stream);
+    e.pending = false;
 }
 
 int finish_status(gpcsd_ctx *c, const int *d_status) {
@@ -820,6 +864,7 @@ extern "C" int gpcsd_loglik_parts(gpcsd_ctx *c, const gpcsd_hparams *hp, double 
     g1.C = W; g1.ldc = (long)R * nt;
     g1.prof_name = "gemm_proj_spatial";
     gemm_f64(c, g1, s);
+    join_temporal(c, e);
     GemmDesc g2;                          // alpha[(x',r)][i'] = sum_t W[(x',r)][t] Qt[t][i'];  quad = sum alpha^2 / D
     g2.M = nx * R; g2.N = nt; g2.K = nt;
     g2.A = W; g2.lda = nt;
@@ -864,6 +909,7 @@ static int predict_impl(gpcsd_ctx *c, const gpcsd_hparams *hp, const double *z, 
     g1.B = c->d_lfp; g1.ldb = RT; g1.C = W; g1.ldc = RT;
     g1.prof_name = "gemm_proj_spatial";
     gemm_f64(c, g1, s);
+    join_temporal(c, e);
     GemmDesc g2;                          // Bm = (W Qt) / D
     g2.M = nx * R; g2.N = nt; g2.K = nt;
     g2.A = W; g2.lda = nt; g2.B = e.Qt; g2.ldb = nt; g2.C = Bm; g2.ldc = nt;
@@ -1038,6 +1084,7 @@ extern "C" int gpcsd_loglik_grad(gpcsd_ctx *c, const gpcsd_hparams *hp, double *
     g1.A = e.Qs; g1.lda = nx; g1.transA = true; g1.B = c->d_lfp; g1.ldb = RT; g1.C = W; g1.ldc = RT;
     g1.prof_name = "gemm_proj_spatial";
     gemm_f64(c, g1, s);
+    join_temporal(c, e);
     GemmDesc g2;                          // alpha = W Qt;  B = alpha / D, B*et, B*es;  sum alpha*B, sum B^2
     g2.M = nx * R; g2.N = nt; g2.K = nt;
     g2.A = W; g2.lda = nt; g2.B = e.Qt; g2.ldb = nt; g2.C = Bm; g2.ldc = nt; g2.C2 = Bet; g2.C3 = Bes;
