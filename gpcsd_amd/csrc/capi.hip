@@ -909,18 +909,10 @@ static int predict_impl(gpcsd_ctx *c, const gpcsd_hparams *hp, const double *z, 
     g1.B = c->d_lfp; g1.ldb = RT; g1.C = W; g1.ldc = RT;
     g1.prof_name = "gemm_proj_spatial";
     gemm_f64(c, g1, s);
-    join_temporal(c, e);
-    GemmDesc g2;                          // Bm = (W Qt) / D
-    g2.M = nx * R; g2.N = nt; g2.K = nt;
-    g2.A = W; g2.lda = nt; g2.B = e.Qt; g2.ldb = nt; g2.C = Bm; g2.ldc = nt;
-    g2.epi = EPI_DIV_D; g2.D = e.D; g2.rdiv = R; g2.ldd = nt;
-    g2.prof_name = "gemm_pred_temporal_div";
-    gemm_f64(c, g2, s);
     // invy = (Qs (x) Qt) vec(Bm) (gpcsd1d.py:262-265) is never formed: the cross-covariance contraction
     //   out_c = Kc^T Qs Bm Qt^T Kt*_c  is re-associated as  (Kc^T Qs) Bm (Qt^T Kt*_c),
     // i.e. two small (n^3) products M1, Pc and two flat GEMMs, instead of back-projecting to the original bases first
     // (saves 2 nx^2 nt + 2 nx nt^2 flops per trial; identical up to rounding).
-
     double *dz = c->upload<double>("pred_z", z, (size_t)nz * g.dim);
     double *dts = c->upload<double>("pred_tstar", tstar, ntstar);
     const double *t = (const double *)c->bufs["time_t"].p;
@@ -928,35 +920,48 @@ static int predict_impl(gpcsd_ctx *c, const gpcsd_hparams *hp, const double *z, 
     double *S = c->buf<double>("pred_S", (size_t)nz * RT);
     double *comp = c->buf<double>("pred_comp", (size_t)nz * RT);
     double *tot = c->buf<double>("pred_tot", (size_t)nz * RT);
-    double *Kts = c->buf<double>("pred_Ktstar", (size_t)ntstar * nt);
-    double *M1 = c->buf<double>("pred_M1", (size_t)nz * nx);
+    double *Kts = c->buf<double>("pred_Ktstar", (size_t)C * ntstar * nt);
+    double *M1 = c->buf<double>("pred_M1", (size_t)2 * nz * nx);
     double *Pc = c->buf<double>("pred_Pc", (size_t)nt * nt);
     const size_t out_elems = (size_t)nz * RT;
-
+    // Everything that needs only Qs is queued before the join, i.e. it runs beside the temporal eigensolver:
+    // cross-covariances Kc, M1 = Kc^T Qs for the requested outputs, and the prediction-time temporal Grams.
+    for (int which = 1; which <= 2; ++which) {
+        if (!(type & which)) continue;
+        if (which == 1) build_kphig(c, g, hp->R, hp->eps, hp->ell_s, dz, nz, Kc, s);        // gpcsd1d.py:273
+        else build_kphi(c, g, hp->R, hp->eps, hp->ell_s, dz, nz, 0.0, Kc, s);               // gpcsd1d.py:275
+        GemmDesc gm;                      // M1[z][x'] = sum_x Kc[x][z] Qs[x][x']
+        gm.M = nz; gm.N = nx; gm.K = nx;
+        gm.A = Kc; gm.lda = nz; gm.transA = true; gm.B = e.Qs; gm.ldb = nx; gm.C = M1 + (size_t)(which - 1) * nz * nx; gm.ldc = nx;
+        gm.prof_name = "gemm_pred_M1";
+        gemm_f64(c, gm, s);
+    }
+    for (int cc = 0; cc < C; ++cc) {
+        // Ktstar_c = cov_c.compute_Kt(tstar): (ntstar, nt); its FIRST axis is contracted with the training
+        // time index (reference quirk when tstar != t)      gpcsd1d.py:277-279
+        k_temporal_gram(c, 1, &hp->kind[cc], &hp->ell_t[cc], &hp->sigma2_t[cc], dts, ntstar, t, nt, Kts + (size_t)cc * ntstar * nt, s);
+    }
+    join_temporal(c, e);
+    GemmDesc g2;                          // Bm = (W Qt) / D
+    g2.M = nx * R; g2.N = nt; g2.K = nt;
+    g2.A = W; g2.lda = nt; g2.B = e.Qt; g2.ldb = nt; g2.C = Bm; g2.ldc = nt;
+    g2.epi = EPI_DIV_D; g2.D = e.D; g2.rdiv = R; g2.ldd = nt;
+    g2.prof_name = "gemm_pred_temporal_div";
+    gemm_f64(c, g2, s);
     for (int which = 1; which <= 2; ++which) {
         if (!(type & which)) continue;
         double *o_sum = c->buf<double>(which == 1 ? "pred_out_csd" : "pred_out_lfp", out_elems);
         double *o_list = want_lists ? c->buf<double>(which == 1 ? "pred_out_csd_list" : "pred_out_lfp_list", out_elems * C)
                                     : nullptr;
-        if (which == 1) build_kphig(c, g, hp->R, hp->eps, hp->ell_s, dz, nz, Kc, s);        // gpcsd1d.py:273
-        else build_kphi(c, g, hp->R, hp->eps, hp->ell_s, dz, nz, 0.0, Kc, s);               // gpcsd1d.py:275
-        GemmDesc gm;                      // M1[z][x'] = sum_x Kc[x][z] Qs[x][x']
-        gm.M = nz; gm.N = nx; gm.K = nx;
-        gm.A = Kc; gm.lda = nz; gm.transA = true; gm.B = e.Qs; gm.ldb = nx; gm.C = M1; gm.ldc = nx;
-        gm.prof_name = "gemm_pred_M1";
-        gemm_f64(c, gm, s);
         GemmDesc g5;                      // S[z][(r,i')] = sum_x' M1[z][x'] Bm[x'][(r,i')]
         g5.M = nz; g5.N = (int)RT; g5.K = nx;
-        g5.A = M1; g5.lda = nx; g5.B = Bm; g5.ldb = RT; g5.C = S; g5.ldc = RT;
+        g5.A = M1 + (size_t)(which - 1) * nz * nx; g5.lda = nx; g5.B = Bm; g5.ldb = RT; g5.C = S; g5.ldc = RT;
         g5.prof_name = "gemm_pred_cross";
         gemm_f64(c, g5, s);
         for (int cc = 0; cc < C; ++cc) {
-            // Ktstar_c = cov_c.compute_Kt(tstar): (ntstar, nt); its FIRST axis is contracted with the training
-            // time index (reference quirk when tstar != t)      gpcsd1d.py:277-279
-            k_temporal_gram(c, 1, &hp->kind[cc], &hp->ell_t[cc], &hp->sigma2_t[cc], dts, ntstar, t, nt, Kts, s);
             GemmDesc gp;                  // Pc[i'][t'] = sum_j Qt[j][i'] Ktstar[j][t']
             gp.M = nt; gp.N = nt; gp.K = ntstar;
-            gp.A = e.Qt; gp.lda = nt; gp.transA = true; gp.B = Kts; gp.ldb = nt; gp.C = Pc; gp.ldc = nt;
+            gp.A = e.Qt; gp.lda = nt; gp.transA = true; gp.B = Kts + (size_t)cc * ntstar * nt; gp.ldb = nt; gp.C = Pc; gp.ldc = nt;
             gp.prof_name = "gemm_pred_Pc";
             gemm_f64(c, gp, s);
             GemmDesc g6;                  // out_c[(z,r)][t'] = sum_i' S[(z,r)][i'] Pc[i'][t']
