@@ -58,6 +58,7 @@ SIGNATURES = {
     "gpcsd_kphig_2d": (_I, [_P, _DP, _I, _DP, _DP, _I, _DP, _DP, _I, _DP, _I, _D, _D, _D, _D, _DP]),
     "gpcsd_eigh": (_I, [_P, _DP, _I, _DP, _DP]),
     "gpcsd_eig_D": (_I, [_P, _DP, _I, _DP, _I, _DP, _I, _DP, _DP, _DP]),
+    "gpcsd_whitened_quad": (_I, [_P, _DP, _I, _DP, _I, _DP, _DP, _I, _DP]),
     "gpcsd_debug_sytrd": (_I, [_P, _DP, _I, _DP, _DP, _DP, _DP]),
     "gpcsd_debug_stedc": (_I, [_P, _DP, _DP, _I, _DP, _DP]),
     "gpcsd_potrf": (_I, [_P, _DP, _I, _DP]),
@@ -298,6 +299,18 @@ class Context:
         Qs, Qt, D = np.empty((nx, nx)), np.empty((nt, nt)), np.empty(nx * nt)
         self._check(self._lib.gpcsd_eig_D(self._h, _ptr(Ks), nx, _ptr(Kt), nt, _ptr(sig), sig.size, _ptr(Qs), _ptr(Qt), _ptr(D)))
         return Qs, Qt, D
+
+    def whitened_quad(self, Qs, Qt, Dvec, resid):
+        """sum((Qs^T resid_b Qt)^2 / Dvec) for every trial b of resid (nx, nt, nb) -> (nb,)."""
+        Qs, Qt = _arr(Qs), _arr(Qt)
+        nx, nt = Qs.shape[0], Qt.shape[0]
+        resid = np.ascontiguousarray(np.atleast_3d(np.asarray(resid, dtype=np.float64)))
+        if resid.shape[:2] != (nx, nt):
+            raise ValueError("resid has shape %s, expected (%d, %d, nb)" % (resid.shape, nx, nt))
+        Dv = _arr(np.asarray(Dvec, dtype=np.float64).reshape(-1), (nx * nt,), "Dvec")
+        out = np.empty(resid.shape[2])
+        self._check(self._lib.gpcsd_whitened_quad(self._h, _ptr(Qs), nx, _ptr(Qt), nt, _ptr(Dv), _ptr(resid), resid.shape[2], _ptr(out)))
+        return out
 
     def potrf(self, A):
         A = _arr(A)

@@ -707,6 +707,37 @@ extern "C" int gpcsd_eig_D(gpcsd_ctx *c, const double *Ks, int nx, const double 
     GP_API_END(c)
 }
 
+extern "C" int gpcsd_whitened_quad(gpcsd_ctx *c, const double *Qs, int nx, const double *Qt, int nt, const double *Dvec,
+                                   const double *resid, int nb, double *out) {
+    GP_API_BEGIN(c)
+    GP_REQUIRE(Qs && Qt && Dvec && resid && out && nx > 0 && nt > 0 && nb > 0, -3, "whitened_quad: bad arguments");
+    hipStream_t s = c->stream;
+    double *dQs = c->upload<double>("wq_Qs", Qs, (size_t)nx * nx);
+    double *dQt = c->upload<double>("wq_Qt", Qt, (size_t)nt * nt);
+    double *dD = c->upload<double>("wq_D", Dvec, (size_t)nx * nt);
+    double *raw = c->upload<double>("wq_raw", resid, (size_t)nx * nt * nb);
+    const long BT = (long)nb * nt;
+    double *Y = c->buf<double>("wq_Y", (size_t)nx * BT);
+    k_swap_last2(c, raw, Y, nx, nt, nb, s);                 // (x, t, b) -> (x, b, t): both projections become flat GEMMs
+    double *W = c->buf<double>("wq_W", (size_t)nx * BT), *Al = c->buf<double>("wq_alpha", (size_t)nx * BT);
+    GemmDesc g1;                                            // W = Qs^T Y
+    g1.M = nx; g1.N = (int)BT; g1.K = nx;
+    g1.A = dQs; g1.lda = nx; g1.transA = true; g1.B = Y; g1.ldb = BT; g1.C = W; g1.ldc = BT;
+    g1.prof_name = "gemm_wq_spatial";
+    gemm_f64(c, g1, s);
+    GemmDesc g2;                                            // alpha[(x,b)][i] = sum_t W[(x,b)][t] Qt[t][i]
+    g2.M = nx * nb; g2.N = nt; g2.K = nt;
+    g2.A = W; g2.lda = nt; g2.B = dQt; g2.ldb = nt; g2.C = Al; g2.ldc = nt;
+    g2.prof_name = "gemm_wq_temporal";
+    gemm_f64(c, g2, s);
+    double *dq = c->buf<double>("wq_out", nb);
+    k_per_trial_quad(c, Al, dD, nx, nb, nt, dq, s);
+    c->download(out, dq, (size_t)nb * sizeof(double));
+    c->sync();
+    return 0;
+    GP_API_END(c)
+}
+
 extern "C" int gpcsd_potrf(gpcsd_ctx *c, const double *A, int n, double *L) {
     GP_API_BEGIN(c)
     GP_REQUIRE(A && L && n > 0, -3, "potrf: bad arguments");

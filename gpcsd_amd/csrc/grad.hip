@@ -257,4 +257,25 @@ void k_siglist_eigvec_term(gpcsd_ctx *c, double *Ghs, const double *Ssum, const 
     GP_HIP(hipGetLastError());
 }
 
+// out[b] = sum_x sum_i alpha[(x*nb + b)*nt + i]^2 / D[x*nt + i] : per-trial whitened quadratic forms (one workgroup per
+// trial, fixed reduction order).  alpha = Qs^T resid_b Qt for every trial b at once.
+__global__ __launch_bounds__(256) void per_trial_quad_kernel(const double *__restrict__ alpha, const double *__restrict__ D, int nx,
+                                                             int nb, int nt, double *__restrict__ out) {
+    __shared__ double red[4];
+    const int b = blockIdx.x;
+    double s = 0.0;
+    for (long e = threadIdx.x; e < (long)nx * nt; e += 256) {
+        const int x = (int)(e / nt), i = (int)(e % nt);
+        const double a = alpha[((long)x * nb + b) * nt + i];
+        s += a * a / D[e];
+    }
+    s = block_sum256(s, red);
+    if (threadIdx.x == 0) out[b] = s;
+}
+
+void k_per_trial_quad(gpcsd_ctx *c, const double *alpha, const double *D, int nx, int nb, int nt, double *out, hipStream_t s) {
+    hipLaunchKernelGGL(per_trial_quad_kernel, dim3(nb), dim3(256), 0, s, alpha, D, nx, nb, nt, out);
+    GP_HIP(hipGetLastError());
+}
+
 }  // namespace gpcsd

@@ -109,6 +109,8 @@ void k_D_sums(gpcsd_ctx *c, const double *D, const double *es, const double *et,
 // Ghs[y][x] += -1/2 (sig_y - sig_x)/(es_x - es_y) Ssum[x][y] for x != y, |es_x - es_y| > tiny
 void k_siglist_eigvec_term(gpcsd_ctx *c, double *Ghs, const double *Ssum, const double *es, const double *sig, int nx,
                            double tiny, hipStream_t s);
+// out[b] = sum_{x,i} alpha[(x*nb + b)*nt + i]^2 / D[x*nt + i]
+void k_per_trial_quad(gpcsd_ctx *c, const double *alpha, const double *D, int nx, int nb, int nt, double *out, hipStream_t s);
 // out[x] = sum_k B[x*rowlen + k]^2
 void k_rowgroup_sumsq(gpcsd_ctx *c, const double *B, int nrows, long rowlen, double *out, hipStream_t s);
 // out (n,n) = scale * sum_b in[b*stride + e] + dscale * diag(dvec)

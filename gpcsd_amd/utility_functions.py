@@ -47,3 +47,12 @@ def comp_eig_D(Ks, Kt, sig2n):
     D[x*nt + i] = evals_s[x]*evals_t[i] + sig2n   (scalar) or + sig2n[x] (per-electrode list, indexed by the
     ascending eigen-index x exactly as the reference does).  Returns (evec_s, evec_t, Dvec)."""
     return _hip.default_context().eig_D(Ks, Kt, sig2n)
+
+
+def whitened_quadratic_forms(evec_s, evec_t, Dvec, resid):
+    """Per-trial `sum((evec_s.T @ resid_b @ evec_t)**2 / Dvec)` for residuals `resid` of shape (nx, nt) or (nx, nt, nb),
+    given the outputs of `comp_eig_D`.  Not a function of the reference package itself: it is the projection step of
+    `loglik` (gpcsd1d.py:124-127) as reused by downstream per-trial objectives (auditory_lfp/fit_mean_function.py:311-321),
+    batched over trials on the GPU."""
+    from . import _hip
+    return _hip.default_context().whitened_quad(evec_s, evec_t, Dvec, resid)

@@ -158,6 +158,13 @@ int gpcsd_fetch(gpcsd_ctx *ctx, const char *name, double *host, long count);
 int gpcsd_sample_prior(gpcsd_ctx *ctx, const gpcsd_hparams *hp, int which,
                        const double *normals, int ntrials, double *out);
 
+/* Per-trial whitened quadratic forms  out[b] = sum( (Qs^T resid_b Qt)^2 / Dvec )  for nb residual matrices at once, given a
+ * cached decomposition (Qs, Qt, Dvec) from gpcsd_eig_D.  resid is (nx, nt, nb) C-order like lfp.  This is the projection
+ * kernel of loglik (gpcsd1d.py:124-127) exposed for downstream per-trial consumers, e.g. the shift-optimisation objective
+ * of auditory_lfp/fit_mean_function.py:311-321 (alpha = Qs^T resid Qt; quad = -0.5 * sum(alpha^2 / Dvec)). */
+int gpcsd_whitened_quad(gpcsd_ctx *ctx, const double *Qs, int nx, const double *Qt, int nt, const double *Dvec,
+                        const double *resid, int nb, double *out);
+
 /* ---- measurement --------------------------------------------------------------- */
 /* When enabled, every launch of a named hot kernel is bracketed by hipEvents on the ctx stream. */
 int gpcsd_prof_enable(gpcsd_ctx *ctx, int on);

@@ -407,6 +407,20 @@ def test_small_problem_rides_in_the_large_batch(ctx, ns, nl):
     assert relerr(np.sort(D), np.sort(np.outer(es, et).ravel() + 0.1)) < 1e-12
 
 
+def test_whitened_quadratic_forms(ctx):
+    """N4: per-trial quadratic forms against cached (Qs, Qt, Dvec), the projection kernel reused by downstream objectives."""
+    from gpcsd_amd.utility_functions import comp_eig_D, whitened_quadratic_forms
+    g = golden("ops")
+    Qs, Qt, D = comp_eig_D(g["eig_Ks"], g["eig_Kt"], 0.3)
+    nx, nt = Qs.shape[0], Qt.shape[0]
+    rs = np.random.RandomState(5)
+    resid = rs.standard_normal((nx, nt, 7))
+    got = whitened_quadratic_forms(Qs, Qt, D, resid)
+    ref = np.array([np.sum((Qs.T @ resid[:, :, b] @ Qt).reshape(-1) ** 2 / D) for b in range(7)])
+    assert relerr(got, ref) < 1e-12
+    assert relerr(whitened_quadratic_forms(Qs, Qt, D, resid[:, :, 0]), ref[:1]) < 1e-12
+
+
 # ------------------------------------------------------------------------------------------------ gradient + fit
 @pytest.mark.parametrize("name", ["1d_wide_24x60x3", "cfg1_1d_24x100x1", "1d_odd_17x37x5", "2d_grid_48x40x2"])
 def test_loglik_gradient_vs_finite_differences(name):
