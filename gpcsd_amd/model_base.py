@@ -256,7 +256,12 @@ class GPCSDModel:
         return -1.0 * (self._safe_loglik() + lp)
 
     def _objective_grad(self, tparams, fix_R, fd_step=1e-6):
-        """Gradient of `_objective` w.r.t. the log-parameters."""
+        """Gradient of `_objective` w.r.t. the log-parameters (non-finite values are passed through to the optimiser
+        silently, as under the reference's module-level `np.seterr(all='ignore')`, gpcsd1d.py:7)."""
+        with np.errstate(all="ignore"):
+            return self._objective_grad_impl(tparams, fix_R, fd_step)
+
+    def _objective_grad_impl(self, tparams, fix_R, fd_step):
         tparams = np.asarray(tparams, dtype=np.float64)
         if getattr(self, "_use_analytic_grad", True):
             try:
