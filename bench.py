@@ -148,7 +148,7 @@ def cpu_baseline(w, m, lfp_sample):
 
 
 # Epilogue template index of each profiled GEMM role (last template argument of gemm_f64_kernel in rocprofv3's names)
-GEMM_EPI_OF = {"gemm_pred_tstar": 4,   # (the first component of a predict uses 6 = DUAL_INIT: same flops, no C2 read)
+GEMM_EPI_OF = {"gemm_pred_tstar": 0,   # all temporal components in one plain-store GEMM (largest EPI 0 launch of the step)
                "gemm_pred_temporal_div": 1, "gemm_proj_temporal_quad": 2}
 PMC_PROFILE = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
 

@@ -949,11 +949,10 @@ static int predict_impl(gpcsd_ctx *c, const gpcsd_hparams *hp, const double *z, 
     const double *t = (const double *)c->bufs["time_t"].p;
     double *Kc = c->buf<double>("pred_Kcross", (size_t)nx * nz);
     double *S = c->buf<double>("pred_S", (size_t)nz * RT);
-    double *comp = c->buf<double>("pred_comp", (size_t)nz * RT);
-    double *tot = c->buf<double>("pred_tot", (size_t)nz * RT);
+    double *comp = c->buf<double>("pred_comp", (size_t)C * nz * RT);
     double *Kts = c->buf<double>("pred_Ktstar", (size_t)C * ntstar * nt);
     double *M1 = c->buf<double>("pred_M1", (size_t)2 * nz * nx);
-    double *Pc = c->buf<double>("pred_Pc", (size_t)nt * nt);
+    double *Pc = c->buf<double>("pred_Pc", (size_t)C * nt * nt);
     const size_t out_elems = (size_t)nz * RT;
     // Everything that needs only Qs is queued before the join, i.e. it runs beside the temporal eigensolver:
     // cross-covariances Kc, M1 = Kc^T Qs for the requested outputs, and the prediction-time temporal Grams.
@@ -990,20 +989,22 @@ static int predict_impl(gpcsd_ctx *c, const gpcsd_hparams *hp, const double *z, 
         g5.prof_name = "gemm_pred_cross";
         gemm_f64(c, g5, s);
         for (int cc = 0; cc < C; ++cc) {
-            GemmDesc gp;                  // Pc[i'][t'] = sum_j Qt[j][i'] Ktstar[j][t']
+            GemmDesc gp;                  // Pcat[i'][cc*nt + t'] = sum_j Qt[j][i'] Ktstar_cc[j][t']
             gp.M = nt; gp.N = nt; gp.K = ntstar;
-            gp.A = e.Qt; gp.lda = nt; gp.transA = true; gp.B = Kts + (size_t)cc * ntstar * nt; gp.ldb = nt; gp.C = Pc; gp.ldc = nt;
+            gp.A = e.Qt; gp.lda = nt; gp.transA = true; gp.B = Kts + (size_t)cc * ntstar * nt; gp.ldb = nt;
+            gp.C = Pc + (size_t)cc * nt; gp.ldc = (long)C * nt;
             gp.prof_name = "gemm_pred_Pc";
             gemm_f64(c, gp, s);
-            GemmDesc g6;                  // out_c[(z,r)][t'] = sum_i' S[(z,r)][i'] Pc[i'][t']
-            g6.M = nz * R; g6.N = nt; g6.K = nt;
-            g6.A = S; g6.lda = nt; g6.B = Pc; g6.ldb = nt; g6.C = comp; g6.ldc = nt; g6.C2 = tot;
-            g6.epi = (cc == 0) ? EPI_DUAL_INIT : EPI_DUAL;       // the first component initialises the running sum
-            g6.prof_name = "gemm_pred_tstar";
-            gemm_f64(c, g6, s);
-            if (o_list) k_swap_last2(c, comp, o_list + (size_t)cc * out_elems, nz, R, nt, s);   // (z,r,t) -> (z,t,r)
         }
-        k_swap_last2(c, tot, o_sum, nz, R, nt, s);
+        // All temporal components in ONE flat GEMM: out[(z,r)][cc*nt + t'] = sum_i' S[(z,r)][i'] Pcat[i'][cc*nt + t'],
+        // then one pass writes every component in the reference's (z, t, r) layout plus their sum (no read-modify-write
+        // epilogue, one launch instead of C, a single relayout pass instead of C + 1).
+        GemmDesc g6;
+        g6.M = nz * R; g6.N = C * nt; g6.K = nt;
+        g6.A = S; g6.lda = nt; g6.B = Pc; g6.ldb = (long)C * nt; g6.C = comp; g6.ldc = (long)C * nt;
+        g6.prof_name = "gemm_pred_tstar";
+        gemm_f64(c, g6, s);
+        k_swap_last2_sum(c, comp, C, o_list, (long)out_elems, o_sum, nz, R, nt, s);     // (z,r,c,t) -> (c,z,t,r), sum over c
     }
     return finish_status(c, e.status);
 }

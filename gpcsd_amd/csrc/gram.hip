@@ -340,4 +340,47 @@ void k_swap_last2(gpcsd_ctx *c, const double *in, double *out, int n0, int n1, i
     GP_HIP(hipGetLastError());
 }
 
+// Predictions of all C temporal components arrive from ONE GEMM as in[(z, r)][c*n2 + t] (row stride C*n2).  One pass
+// writes every component in the reference's (z, t, r) layout and their sum: per (z, c) a 32x32 LDS-tiled transpose of the
+// (r, t) block, the sum accumulated in registers over c.  list may be null (sum only).
+__global__ __launch_bounds__(256) void swap_last2_sum_kernel(const double *__restrict__ in, int C, double *__restrict__ list,
+                                                             long list_stride, double *__restrict__ sum, int n1, int n2) {
+    __shared__ double tile[32][33];
+    const long zin = (long)blockIdx.z * n1 * C * n2, zout = (long)blockIdx.z * n1 * n2;
+    const int j0 = blockIdx.x * 32, i0 = blockIdx.y * 32;       // i over n1 (trials), j over n2 (times)
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;     // 32 x 8
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int c = 0; c < C; ++c) {
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int i = i0 + ty + 8 * k, j = j0 + tx;
+            if (i < n1 && j < n2) tile[ty + 8 * k][tx] = in[zin + (long)i * C * n2 + (long)c * n2 + j];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int j = j0 + ty + 8 * k, i = i0 + tx;
+            if (i < n1 && j < n2) {
+                const double v = tile[tx][ty + 8 * k];
+                if (list) list[(long)c * list_stride + zout + (long)j * n1 + i] = v;
+                acc[k] += v;                                    // components summed in index order, as the reference does
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int j = j0 + ty + 8 * k, i = i0 + tx;
+        if (i < n1 && j < n2) sum[zout + (long)j * n1 + i] = acc[k];
+    }
+}
+
+void k_swap_last2_sum(gpcsd_ctx *c, const double *in, int C, double *list, long list_stride, double *sum, int n0, int n1, int n2,
+                      hipStream_t s) {
+    dim3 grid(ceil_div(n2, 32), ceil_div(n1, 32), n0);
+    ProfScope ps(c, "relayout", 0.0, s);
+    hipLaunchKernelGGL(swap_last2_sum_kernel, grid, dim3(256), 0, s, in, C, list, list_stride, sum, n1, n2);
+    GP_HIP(hipGetLastError());
+}
+
 }  // namespace gpcsd

@@ -69,6 +69,9 @@ void k_build_D(gpcsd_ctx *c, const double *es, int nx, const double *et, int nt,
 // lfp host layout [x][t][r] -> device layout [x][r][t] (and back for predictions [z][r][t] -> [z][t][r])
 void k_swap_last2(gpcsd_ctx *c, const double *in, double *out, int n0, int n1, int n2, hipStream_t s);
 void k_fill(gpcsd_ctx *c, double *p, long n, double v, hipStream_t s);
+// in[(z, r)][c*n2 + t] (C components side by side) -> list[c][z][t][r] (optional) and sum[z][t][r] = sum_c
+void k_swap_last2_sum(gpcsd_ctx *c, const double *in, int C, double *list, long list_stride, double *sum, int n0, int n1, int n2,
+                      hipStream_t s);
 
 // ---------------------------------------------------------------- eigensolver (eigh.hip)
 // Symmetric eigendecomposition of A (n,n) on device.  evals ascending; evecs (n,n) row-major with
