@@ -251,9 +251,10 @@ class GPCSDModel:
 
     def _objective(self, tparams, fix_R):
         """-(loglik + log prior) at log-parameters `tparams` (writes them into the param dicts, as the reference does)."""
-        self._set_from_tparams(tparams, fix_R)
-        lp = self._log_prior()
-        return -1.0 * (self._safe_loglik() + lp)
+        with np.errstate(all="ignore"):          # the reference runs under np.seterr(all='ignore') (gpcsd1d.py:7)
+            self._set_from_tparams(tparams, fix_R)
+            lp = self._log_prior()
+            return -1.0 * (self._safe_loglik() + lp)
 
     def _objective_grad(self, tparams, fix_R, fd_step=1e-6):
         """Gradient of `_objective` w.r.t. the log-parameters (non-finite values are passed through to the optimiser
