@@ -266,26 +266,32 @@ EigState front_half(gpcsd_ctx *c, const gpcsd_hparams *hp, double jitter) {
     e.D = c->buf<double>("D", (size_t)nx * nt);
     e.scal = c->buf<double>("scalars", 64);
     e.status = c->buf<int>("status", 4);
-    double *d_sig = c->upload<double>("sig2n", hp->sig2n, hp->n_sig2n);
-    GP_HIP(hipMemsetAsync(e.status, 0, 4 * sizeof(int), s));
     const double *t = (const double *)c->bufs["time_t"].p;
     const SymDev *sym_s = c->sym_s.ns > 0 ? &c->sym_s : nullptr, *sym_t = c->sym_t.ns > 0 ? &c->sym_t : nullptr;
     if (!two_stream_front()) {
+        double *d_sig = c->upload<double>("sig2n", hp->sig2n, hp->n_sig2n);
+        GP_HIP(hipMemsetAsync(e.status, 0, 4 * sizeof(int), s));
         build_kphi(c, g, hp->R, hp->eps, hp->ell_s, nullptr, 0, jitter, Ks, s);
         build_kt(c, hp, t, nt, t, nt, Kt, s);
         // the symmetries come from the resident geometry / time grid, so they hold for the Grams built from them
         eig_pair_D(c, Ks, nx, Kt, nt, d_sig, hp->n_sig2n, e.Qs, e.es, e.Qt, e.et, e.D, e.scal, e.status, sym_s, sym_t);
         return e;
     }
+    // The temporal chain is the critical path: it is queued first, before any upload of this call.  It needs nothing
+    // from the main stream except that the previous call has finished with Kt / Qt (ev_fork), and reports numerical
+    // failure in its own status word (status[1]; the spatial chain uses status[0]).
     hipStream_t s2 = c->stream2;
-    GP_HIP(hipEventRecord(c->ev_fork, s));                 // stream2 starts after the uploads / memset queued above
+    GP_HIP(hipEventRecord(c->ev_fork, s));
     GP_HIP(hipStreamWaitEvent(s2, c->ev_fork, 0));
+    GP_HIP(hipMemsetAsync(e.status + 1, 0, sizeof(int), s2));
     build_kt(c, hp, t, nt, t, nt, Kt, s2);
     {
         ProfScope ps(c, "eigh_temporal", 9.0 * (double)nt * nt * nt, s2);
-        eigh_pair_device(c, nullptr, 0, nullptr, nullptr, nullptr, Kt, nt, e.et, e.Qt, sym_t, e.status, s2);
+        eigh_pair_device(c, nullptr, 0, nullptr, nullptr, nullptr, Kt, nt, e.et, e.Qt, sym_t, e.status + 1, s2);
     }
     GP_HIP(hipEventRecord(c->ev_join, s2));
+    double *d_sig = c->upload<double>("sig2n", hp->sig2n, hp->n_sig2n);
+    GP_HIP(hipMemsetAsync(e.status, 0, sizeof(int), s));
     build_kphi(c, g, hp->R, hp->eps, hp->ell_s, nullptr, 0, jitter, Ks, s);
     {
         ProfScope ps(c, "eigh_spatial", 9.0 * (double)nx * nx * nx, s);
@@ -310,6 +316,7 @@ int finish_status(gpcsd_ctx *c, const int *d_status) {
     c->download(st, d_status, sizeof(st));
     c->sync();
     if (c->prof_on) c->prof_collect();
+    if (st[0] == 0 && st[1] != 0) st[0] = st[1];      // status[1]: the temporal chain of the two-stream front half
     if (st[0] != 0) {
         char b[128];
         snprintf(b, sizeof(b), "numerical failure (status %d): eigensolver did not converge or matrix not positive definite", st[0]);
