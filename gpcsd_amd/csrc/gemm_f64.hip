@@ -17,6 +17,7 @@
 //   [o][k] tiles: stride BK+2 = 18 doubles (18*i mod 32 distinct even slots for the 16 rows of a fragment).
 // f64 MFMA fragment maps (cdna_hip_programming.md section 3): A lane l holds A[l&15][l>>4], B lane l holds
 // B[l>>4][l&15], C/D lane l reg r holds C[(l>>4) + 4r][l&15].
+#include <algorithm>
 #include <cstdlib>
 #include <type_traits>
 
@@ -47,6 +48,7 @@ struct GemmK {
     double *partials;
     int tiles_n, tiles_m;
     int m_fastest;      // logical tile order: 1 = tile_m varies fastest (few row tiles, many column tiles)
+    int n_group;        // otherwise: n-tiles per sweep over the row panels
     const int *dyn;     // optional device scalar: effective N and K (= *dyn) of this launch (D&C merge GEMMs)
 };
 
@@ -163,7 +165,20 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f64_kernel(GemmK g) {
     }
     // consecutive logical tiles share the operand panel of the LONGER tile dimension, so that panel is fetched from HBM
     // once per XCD neighbourhood while the short dimension's operand stays L2 resident as a whole
-    const int tile_m = g.m_fastest ? bx % g.tiles_m : bx / g.tiles_n, tile_n = g.m_fastest ? bx / g.tiles_m : bx % g.tiles_n;
+    int tile_m, tile_n;
+    if (g.m_fastest) {
+        tile_m = bx % g.tiles_m;
+        tile_n = bx / g.tiles_m;
+    } else {
+        // n-tiles in groups of n_group: one sweep over all row panels per group, so the group's slice of B (<= ~2 MB)
+        // stays in the 4 MB L2 for the whole sweep instead of being evicted by the streaming A panels
+        const int per_group = g.tiles_m * g.n_group;
+        const int gi = bx / per_group, rem = bx - gi * per_group;
+        const int n_first = gi * g.n_group;
+        const int ng = (g.tiles_n - n_first < g.n_group) ? g.tiles_n - n_first : g.n_group;
+        tile_m = rem / ng;
+        tile_n = n_first + rem - tile_m * ng;
+    }
     const int m0 = tile_m * BM, n0 = tile_n * BN;
     if (g.dyn) {                        // wave-uniform: sizes decided on the device (deflation count)
         const int kk = g.dyn[bz];
@@ -452,6 +467,12 @@ void gemm_f64(gpcsd_ctx *c, const GemmDesc &g, hipStream_t s) {
     k.tiles_n = tn;
     k.tiles_m = tm;
     k.m_fastest = (tm < tn) ? 1 : 0;
+    {
+        const long bytes_per_ntile = (long)g.K * bn * 8;                      // one column panel of B
+        long ngp = bytes_per_ntile > 0 ? (2L << 20) / bytes_per_ntile : tn;  // ~2 MB of B per sweep
+        if (g.sB != 0 && g.batch > 1) ngp = tn;                               // B differs per batch entry: nothing to keep
+        k.n_group = (int)std::max(1L, std::min<long>(tn, ngp));
+    }
     dim3 grid(tm * tn, 1, g.batch);
     const long nblocks = (long)tm * tn * g.batch;
     if (g.epi == EPI_QUAD || g.epi == EPI_GRAD) k.partials = c->buf<double>("gemm_partials", 2 * nblocks);
