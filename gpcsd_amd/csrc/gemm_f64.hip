@@ -241,6 +241,29 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f64_kernel(GemmK g) {
             TileB::template sstore<true>(rb, swB + buf * TileB::LDS_ELEMS, kb0, g.K - t * BK);
         }
     };
+    // k-steps (of 4) the LAST K tile needs: a partial tile is zero-filled in LDS, but its all-zero steps are skipped
+    // (K = 500, BK = 16: one step instead of four, 2.3 % of the MFMAs of the whole GEMM)
+    const int last_steps = (nk > nfull) ? (g.K - nfull * BK + 3) / 4 : BK / 4;
+    auto mma_last = [&](auto bufc) {
+        constexpr int buf = decltype(bufc)::value;
+        const double *sa = srA + buf * TileA::LDS_ELEMS;
+        const double *sb = srB + buf * TileB::LDS_ELEMS;
+#pragma unroll
+        for (int kk = 0; kk < BK / 4; ++kk) {
+            if (kk < last_steps) {                  // wave-uniform
+                double a[FM], b[FN];
+#pragma unroll
+                for (int i = 0; i < FM; ++i) a[i] = sa[TileA::lds_index(i * 16, kk * 4)];
+#pragma unroll
+                for (int j = 0; j < FN; ++j) b[j] = sb[TileB::lds_index(j * 16, kk * 4)];
+#pragma unroll
+                for (int i = 0; i < FM; ++i)
+#pragma unroll
+                    for (int j = 0; j < FN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+            }
+        }
+    };
     auto mma_tile = [&](auto bufc) {
         constexpr int buf = decltype(bufc)::value;
         const double *sa = srA + buf * TileA::LDS_ELEMS;
@@ -281,7 +304,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f64_kernel(GemmK g) {
             store_any(Buf0{}, kt + 1);
             __syncthreads();
         }
-        mma_tile(Buf0{});
+        mma_last(Buf0{});
     } else {
         load_any(0);
         store_any(Buf0{}, 0);
@@ -313,12 +336,12 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f64_kernel(GemmK g) {
                 mma_tile(Buf1{});
                 store_any(Buf0{}, kt + 2);
                 __syncthreads();
-                mma_tile(Buf0{});
+                mma_last(Buf0{});
             } else {
-                mma_tile(Buf1{});
+                mma_last(Buf1{});
             }
         } else {
-            mma_tile(Buf0{});
+            mma_last(Buf0{});
         }
     }
 
