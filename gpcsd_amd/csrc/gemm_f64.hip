@@ -40,6 +40,7 @@ struct GemmK {
     double *C2;
     double *C3;
     const double *colscale, *rowscale;
+    long sColscale;
     long sA, sB, sC;
     double alpha;
     const double *D;
@@ -365,7 +366,8 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f64_kernel(GemmK g) {
                 if (col >= g.N) continue;
                 const double v = acc[i][j][r];
                 if (EPI == EPI_STORE) {
-                    C[(long)row * g.ldc + col] = g.alpha * v;
+                    const double sc = g.colscale ? g.colscale[bz * g.sColscale + col] : 1.0;     // wave-uniform test
+                    C[(long)row * g.ldc + col] = g.alpha * v * sc;
                 } else if (EPI == EPI_ACCUM) {
                     C[(long)row * g.ldc + col] += g.alpha * v;
                 } else if (EPI == EPI_DUAL) {
@@ -465,7 +467,7 @@ void gemm_f64(gpcsd_ctx *c, const GemmDesc &g, hipStream_t s) {
     GemmK k;
     k.M = g.M; k.N = g.N; k.K = g.K;
     k.A = g.A; k.lda = g.lda; k.B = g.B; k.ldb = g.ldb; k.C = g.C; k.ldc = g.ldc; k.C2 = g.C2; k.C3 = g.C3;
-    k.colscale = g.colscale; k.rowscale = g.rowscale;
+    k.colscale = g.colscale; k.rowscale = g.rowscale; k.sColscale = g.sColscale;
     k.sA = g.sA; k.sB = g.sB; k.sC = g.sC;
     k.alpha = g.alpha; k.D = g.D; k.rdiv = g.rdiv > 0 ? g.rdiv : 1; k.ldd = g.ldd;
     k.partials = nullptr;

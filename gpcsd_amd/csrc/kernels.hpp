@@ -27,7 +27,8 @@ struct GemmDesc {
     long ldc = 0;
     double *C2 = nullptr;  // EPI_DUAL, EPI_GRAD
     double *C3 = nullptr;  // EPI_GRAD
-    const double *colscale = nullptr, *rowscale = nullptr;   // EPI_GRAD
+    const double *colscale = nullptr, *rowscale = nullptr;   // EPI_GRAD; EPI_STORE: optional C = alpha*acc*colscale[col]
+    long sColscale = 0;                                      // batch stride of colscale (EPI_STORE)
     int batch = 1;
     long sA = 0, sB = 0, sC = 0;
     double alpha = 1.0;

@@ -614,6 +614,62 @@ __global__ __launch_bounds__(256) void dc_place_kernel(DcLevel L) {
     dc_place_body<256>(w, sg, r0, min(r0 + 4, sg.hi));
 }
 
+// ---- large levels, fused launches: phases that only share their inputs run as one launch with a role per workgroup
+// (every launch is a dependent ~5 us step of the chain).
+//   A: rotations + compaction of Q2 | secular equation           (both need the deflation scan only)
+//   B: z-hat                         | rank sort of roots + poles (both need the roots only)
+//   C: column norms                  | UNNORMALISED U             (both need z-hat; the norms scale the GEMM's columns)
+__global__ __launch_bounds__(256) void dc_rotsec_kernel(DcLevel L, int rot_blocks) {
+    DC_PROLOGUE
+    const int K = w.meta[2 * m];
+    if ((int)blockIdx.x < rot_blocks) {
+        const int r0 = sg.lo + blockIdx.x * ROT_ROWS;
+        if (r0 >= sg.hi) return;
+        dc_rotate_compact_body<256>(w, sg, K, w.meta[2 * m + 1], r0, min(r0 + ROT_ROWS, sg.hi));
+    } else {
+        const int i = ((int)blockIdx.x - rot_blocks) * 4 + (threadIdx.x >> 6);
+        if (i >= K) return;
+        dc_secular_root(w, sg.lo, K, 2.0 * fabs(w.e[sg.mid - 1]), i);
+    }
+}
+
+__global__ __launch_bounds__(256) void dc_zhat_rank_kernel(DcLevel L, int zhat_blocks) {
+    DC_PROLOGUE
+    const int K = w.meta[2 * m];
+    if ((int)blockIdx.x < zhat_blocks) {
+        const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+        if (i >= K) return;
+        dc_zhat_one(w, sg.lo, K, 2.0 * fabs(w.e[sg.mid - 1]), i);
+    } else {
+        __shared__ double val[EIG_MAXN];
+        __shared__ int src[EIG_MAXN];
+        dc_rank_body<256>(w, sg, K, val, src);       // consumes rota / rotb: the rotations ran in the previous launch
+    }
+}
+
+__global__ __launch_bounds__(256) void dc_colnorm_U_kernel(DcLevel L, int norm_blocks, int tiles_j) {
+    DC_PROLOGUE
+    const int lo = sg.lo, n = w.n;
+    const int K = w.meta[2 * m];
+    if ((int)blockIdx.x < norm_blocks) {
+        const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
+        if (j >= K) return;
+        dc_colnorm_one(w, lo, K, j);
+    } else {
+        const int bx = (int)blockIdx.x - norm_blocks;
+        const int j = (bx % tiles_j) * 64 + (threadIdx.x & 63);
+        const int i0 = (bx / tiles_j) * 16 + (threadIdx.x >> 6) * 4;
+        if (j >= K) return;
+        const double *__restrict__ dk = w.dk + lo;
+        const double dorg = dk[w.org[lo + j]], muj = w.mu[lo + j];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int i = i0 + q;
+            if (i < K) w.Uw[(long)(lo + i) * n + lo + j] = w.zhat[lo + i] / ((dk[i] - dorg) - muj);
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------------------------
 // fused level kernel for small merges (N <= DC_SMALL): one workgroup walks every phase of its merge
 // ------------------------------------------------------------------------------------------------------------------
@@ -1063,27 +1119,25 @@ void stedc_batch_device(gpcsd_ctx *c, StedcProb *probs, int count, int *d_status
             hipLaunchKernelGGL(dc_small_level_kernel, dim3(max_seg, 1, count), dim3(NT_SMALL), 0, s, L, fast);
         } else {
             hipLaunchKernelGGL(dc_setup_kernel, dim3(1, max_seg, count), dim3(256), 0, s, L);
-            hipLaunchKernelGGL(dc_rotate_compact_kernel, dim3(ceil_div(maxN, ROT_ROWS), max_seg, count), dim3(256), 0, s, L);
-            hipLaunchKernelGGL(dc_secular_kernel, dim3(ceil_div(maxN, 4), max_seg, count), dim3(256), 0, s, L);
-            hipLaunchKernelGGL(dc_zhat_kernel, dim3(ceil_div(maxN, 4), max_seg, count), dim3(256), 0, s, L);
-            hipLaunchKernelGGL(dc_colnorm_kernel, dim3(ceil_div(maxN, 4), max_seg, count), dim3(256), 0, s, L);
-            const int tj = ceil_div(maxN, 64);
-            hipLaunchKernelGGL(dc_build_U_kernel, dim3(tj * ceil_div(maxN, 16), max_seg, count), dim3(256), 0, s, L, tj);
+            const int rot_blocks = ceil_div(maxN, ROT_ROWS), root_blocks = ceil_div(maxN, 4), tj = ceil_div(maxN, 64);
+            hipLaunchKernelGGL(dc_rotsec_kernel, dim3(rot_blocks + root_blocks, max_seg, count), dim3(256), 0, s, L, rot_blocks);
+            hipLaunchKernelGGL(dc_zhat_rank_kernel, dim3(root_blocks + 1, max_seg, count), dim3(256), 0, s, L, root_blocks);
+            hipLaunchKernelGGL(dc_colnorm_U_kernel, dim3(root_blocks + tj * ceil_div(maxN, 16), max_seg, count), dim3(256), 0, s, L,
+                               root_blocks, tj);
             GP_HIP(hipGetLastError());
-            // W = Q2 (N x K) U (K x K), K read on the device; one fork/join branch per problem
-            if (count > 1 && c->fork_on()) GP_HIP(hipEventRecord(c->ev_fork, s));
+            // W = Q2 (N x K) U (K x K) diag(invn), K read on the device.  The merges of one problem are one batched
+            // launch when they have the same size (their blocks sit a constant stride apart on the diagonal).
             for (int p = 0; p < count; ++p) {
                 const long own = (long)plans[p].levels.size() - (long)(nlevels - li);
                 if (own < 0) continue;
                 const auto &lv = plans[p].levels[own];
                 const DcWork &w = L.w[p];
                 const int n = w.n;
-                hipStream_t bs = s;
-                if (p > 0 && c->fork_on()) {
-                    bs = c->side_stream(p);
-                    GP_HIP(hipStreamWaitEvent(bs, c->ev_fork, 0));
-                }
-                for (int m = 0; m < (int)lv.size(); ++m) {
+                bool uniform = true;
+                for (size_t m = 1; m < lv.size(); ++m)
+                    uniform = uniform && (lv[m].hi - lv[m].lo == lv[0].hi - lv[0].lo) && (lv[m].lo - lv[m - 1].lo == lv[1].lo - lv[0].lo);
+                const int nlaunch = uniform ? 1 : (int)lv.size();
+                for (int m = 0; m < nlaunch; ++m) {
                     const Seg &sg = lv[m];
                     const int N = sg.hi - sg.lo;
                     GemmDesc g;
@@ -1091,16 +1145,18 @@ void stedc_batch_device(gpcsd_ctx *c, StedcProb *probs, int count, int *d_status
                     g.A = w.Q2w + (long)sg.lo * n + sg.lo; g.lda = n;
                     g.B = w.Uw + (long)sg.lo * n + sg.lo; g.ldb = n;
                     g.C = w.Ww + (long)sg.lo * n + sg.lo; g.ldc = n;
+                    g.colscale = w.invn + sg.lo;
                     g.dyn = w.Kdyn + m;
+                    if (uniform && lv.size() > 1) {
+                        const long step = lv[1].lo - lv[0].lo;
+                        g.batch = (int)lv.size();
+                        g.sA = g.sB = g.sC = step * n + step;
+                        g.sColscale = step;
+                    }
                     g.prof_name = "gemm_dc_merge";
-                    gemm_f64(c, g, bs);
-                }
-                if (p > 0 && c->fork_on()) {
-                    GP_HIP(hipEventRecord(c->side_ev[p], bs));
-                    GP_HIP(hipStreamWaitEvent(s, c->side_ev[p], 0));
+                    gemm_f64(c, g, s);
                 }
             }
-            hipLaunchKernelGGL(dc_rank_kernel, dim3(1, max_seg, count), dim3(256), 0, s, L);
             hipLaunchKernelGGL(dc_place_kernel, dim3(ceil_div(maxN, 4), max_seg, count), dim3(256), 0, s, L);
         }
         GP_HIP(hipGetLastError());
