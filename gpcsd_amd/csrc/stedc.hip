@@ -554,58 +554,6 @@ __global__ __launch_bounds__(256) void dc_setup_kernel(DcLevel L) {
 }
 
 constexpr int ROT_ROWS = 32;
-__global__ __launch_bounds__(256) void dc_rotate_compact_kernel(DcLevel L) {
-    DC_PROLOGUE
-    const int r0 = sg.lo + blockIdx.x * ROT_ROWS;
-    if (r0 >= sg.hi) return;
-    dc_rotate_compact_body<256>(w, sg, w.meta[2 * m], w.meta[2 * m + 1], r0, min(r0 + ROT_ROWS, sg.hi));
-}
-
-__global__ __launch_bounds__(256) void dc_secular_kernel(DcLevel L) {
-    DC_PROLOGUE
-    const int K = w.meta[2 * m];
-    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (i >= K) return;
-    dc_secular_root(w, sg.lo, K, 2.0 * fabs(w.e[sg.mid - 1]), i);
-}
-
-__global__ __launch_bounds__(256) void dc_zhat_kernel(DcLevel L) {
-    DC_PROLOGUE
-    const int K = w.meta[2 * m];
-    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (i >= K) return;
-    dc_zhat_one(w, sg.lo, K, 2.0 * fabs(w.e[sg.mid - 1]), i);
-}
-
-__global__ __launch_bounds__(256) void dc_colnorm_kernel(DcLevel L) {
-    DC_PROLOGUE
-    const int K = w.meta[2 * m];
-    const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (j >= K) return;
-    dc_colnorm_one(w, sg.lo, K, j);
-}
-
-// U into the diagonal block of Uw, 64 columns x 16 rows per workgroup (coalesced along j); blockIdx.x packs both tiles
-__global__ __launch_bounds__(256) void dc_build_U_kernel(DcLevel L, int tiles_j) {
-    DC_PROLOGUE
-    const int lo = sg.lo, n = w.n;
-    const int K = w.meta[2 * m];
-    const int j = (blockIdx.x % tiles_j) * 64 + (threadIdx.x & 63);
-    const int i0 = (blockIdx.x / tiles_j) * 16 + (threadIdx.x >> 6) * 4;
-    if (j >= K) return;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int i = i0 + q;
-        if (i < K) w.Uw[(long)(lo + i) * n + lo + j] = dc_u_elem(w, lo, i, j);
-    }
-}
-
-__global__ __launch_bounds__(256) void dc_rank_kernel(DcLevel L) {
-    DC_PROLOGUE
-    __shared__ double val[EIG_MAXN];
-    __shared__ int src[EIG_MAXN];
-    dc_rank_body<256>(w, sg, w.meta[2 * m], val, src);
-}
 
 __global__ __launch_bounds__(256) void dc_place_kernel(DcLevel L) {
     DC_PROLOGUE
