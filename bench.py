@@ -322,7 +322,7 @@ def main():
     }
     if roof:
         out["roofline"] = roof
-    if not args.no_cpu_baseline:
+    if not args.no_cpu_baseline and world == 1:      # the CPU baseline is reported at N=1 only
         cb, ll_cpu = cpu_baseline(w, m, lfp[:, :, :args.cpu_sample_trials])
         out["cpu_baseline"] = cb
         # parity spot check beside the numbers: GPU loglik on the same sample vs the oracle
