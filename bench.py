@@ -234,12 +234,13 @@ def main():
             hp0, keep0 = ctx.make_hparams(vec[0], vec[1], vec[2:4], temporal, vec[4 + 2 * C], 0.0)
         ta = time.perf_counter()
         sumlog, quad = ctx.loglik_parts(hp)
-        if sharding is not None:
-            quad = float(sharding.allreduce_sum(np.array([quad]))[0])
-        ll = -0.5 * R_total * sumlog - 0.5 * quad
+        pending = sharding.allreduce_sum_async(np.array([quad])) if sharding is not None else None
         tb = time.perf_counter()
         ctx.predict_resident(hp0, z, w["t"], _hip.PRED_CSD, want_lists=True)
         tc = time.perf_counter()
+        if pending is not None:                  # the global log-likelihood is consumed after predict was queued
+            quad = float(pending()[0])
+        ll = -0.5 * R_total * sumlog - 0.5 * quad
         return ll, tb - ta, tc - tb
 
     def fence():

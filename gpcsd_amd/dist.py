@@ -43,6 +43,17 @@ class TrialSharding:
         self._td.all_reduce(t, op=self._td.ReduceOp.SUM, group=self._group)
         return t.cpu().numpy()
 
+    def allreduce_sum_async(self, values):
+        """Start the sum all-reduce and return a callable that waits for it and yields the NumPy result: the caller can
+        queue independent GPU work (e.g. predict after loglik) while the collective is in flight."""
+        t = self._tensor(values)
+        work = self._td.all_reduce(t, op=self._td.ReduceOp.SUM, group=self._group, async_op=True)
+
+        def result():
+            work.wait()
+            return t.cpu().numpy()
+        return result
+
     def broadcast(self, values, src=0):
         t = self._tensor(values)
         self._td.broadcast(t, src=src, group=self._group)

@@ -49,6 +49,8 @@ def _worker(rank, world, port, q):
     pred_local = O.predict(geom, hp0, local, c["x"], c["t"], type="csd")["csd"]
     pred_full = sh.gather_trials(pred_local)
     vec = sh.broadcast(np.arange(5.0) * (1 + rank), src=0)
+    pend = sh.allreduce_sum_async(np.array([1.0 + rank, 2.0]))
+    assert np.allclose(pend(), [3.0, 4.0])
     if rank == 0:
         ref = O.loglik(geom, hp, lfp)
         pref = O.predict(geom, hp0, lfp, c["x"], c["t"], type="csd")["csd"]
