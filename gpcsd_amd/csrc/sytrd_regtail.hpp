@@ -148,13 +148,6 @@ __global__ __launch_bounds__(RT_NTH) void sytrd_rtail_kernel(SytrdBatch b) {
         // v is re-read from LDS pair by pair in both phases (6 ds_read_b128 each) instead of being held in 24 VGPRs:
         // the 4 x 12 tile already takes 96 of the 168 registers a thread may use at three waves per SIMD
         if (live) {
-            double vrow[RT_R], yr[RT_R];
-#pragma unroll
-            for (int r = 0; r < RT_R; r += 2) {
-                const double2 t = *reinterpret_cast<const double2 *>(sv + row0 + r);
-                vrow[r] = t.x;
-                vrow[r + 1] = t.y;
-            }
             double acc[RT_R] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
             for (int j = 0; j < RT_C; j += 2) {
@@ -162,18 +155,24 @@ __global__ __launch_bounds__(RT_NTH) void sytrd_rtail_kernel(SytrdBatch b) {
 #pragma unroll
                 for (int r = 0; r < RT_R; ++r) acc[r] = fma(a[r][j + 1], vv.y, fma(a[r][j], vv.x, acc[r]));
             }
+            // Four row sums over the 16 lanes of the row group as a reduce-scatter: each exchange halves the number of
+            // sums a lane still carries (2 + 1 DPP adds), two rotations finish them: 27 instructions instead of the 48 of
+            // four full butterflies.  Lane h ends with the sum of row rl = 2*(h&1) + ((h>>1)&1), replicated in its 4 quads.
+            const bool b0 = h & 1, b1 = h & 2;
+            const double t0 = (b0 ? acc[2] : acc[0]) + dpp_mov<0xB1>(b0 ? acc[0] : acc[2]);
+            const double t1 = (b0 ? acc[3] : acc[1]) + dpp_mov<0xB1>(b0 ? acc[1] : acc[3]);
+            double y = (b1 ? t1 : t0) + dpp_mov<0x4E>(b1 ? t0 : t1);
+            y += dpp_mov<0x124>(y);                                  // row_ror:4
+            y += dpp_mov<0x128>(y);                                  // row_ror:8
+            const int myrow = row0 + 2 * (h & 1) + ((h >> 1) & 1);
+            y = (myrow > kk) ? y : 0.0;
             double dp = 0.0;
-#pragma unroll
-            for (int r = 0; r < RT_R; ++r) {
-                const double y = row16_sum(acc[r]);
-                yr[r] = (row0 + r > kk) ? y : 0.0;
-                dp += vrow[r] * yr[r];
+            if (h < 4) {                                             // one lane per row publishes y and its v.y term
+                sy[myrow] = y;
+                dp = sv[myrow] * y;
             }
-            if (h == 0) {
-                *reinterpret_cast<double2 *>(sy + row0) = double2{yr[0], yr[1]};
-                *reinterpret_cast<double2 *>(sy + row0 + 2) = double2{yr[2], yr[3]};
-            }
-            // dp is replicated over the 16 lanes of each row group: add the four groups of the wave
+            dp += dpp_mov<0xB1>(dp);                                 // the four rows of the group (lanes 0..3 of the DPP row)
+            dp += dpp_mov<0x4E>(dp);
             dp = (lane_get(dp, 0) + lane_get(dp, 16)) + (lane_get(dp, 32) + lane_get(dp, 48));
             if (lane == 0) red[wid] = dp;
         } else if (lane == 0) {
