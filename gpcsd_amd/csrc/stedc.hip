@@ -94,6 +94,88 @@ __global__ __launch_bounds__(256) void dc_output_kernel(DcLevel L) {
     for (long i = i0; i < n; i += stride) w.wout[i] = w.dcur[i];
 }
 
+// Register-resident Jacobi for a leaf (m <= 8): lane (i, j) = (lane >> 3, lane & 7) holds A[i][j] and V[i][j]; rotation
+// parameters and partner rows / columns move with lane shuffles, nothing goes through LDS arrays and there is no barrier.
+// Same cyclic round-robin schedule and the same (p < q) rotation formulas as jacobi_body.
+__device__ __forceinline__ int rr_partner8(int x, int step7) {        // partner of index x at round-robin step (8 players)
+    if (x == 7) return step7;
+    if (x == step7) return 7;
+    int y = 2 * step7 - x;
+    y += (y < 0) ? 7 : 0;
+    y -= (y >= 7) ? 7 : 0;
+    return y;
+}
+
+__global__ __launch_bounds__(64) void dc_leaf_reg_kernel(DcLevel L, int *status) {
+    const DcWork &w = L.w[blockIdx.y];
+    if ((int)blockIdx.x >= L.aux[blockIdx.y]) return;
+    const int n = w.n;
+    const int lo = w.tbl[blockIdx.x], hi = w.tbl[blockIdx.x + 1];
+    const int m = hi - lo;
+    const int lane = threadIdx.x, i = lane >> 3, j = lane & 7;
+    double a = 0.0;
+    if (i < m && j < m) {
+        if (i == j) a = w.dwork[lo + i];
+        else if (j == i + 1) a = w.e[lo + i];
+        else if (i == j + 1) a = w.e[lo + j];
+    }
+    double v = (i == j) ? 1.0 : 0.0;
+    const double thresh = sqrt(wave_sum(a * a)) * EPS_U / (double)m;
+    bool converged = (m <= 1);
+    int sweep = 0;
+    for (; sweep < JACOBI_MAX_SWEEPS && !converged; ++sweep) {
+        bool rotated = false;
+        for (int step = 0; step < 7; ++step) {
+            // rotation of the column pair {j, pc}: parameters from A[p][p], A[q][q], A[p][q] (p < q)
+            const int pc = rr_partner8(j, step), p = min(j, pc), q = max(j, pc);
+            const double app = __shfl(a, 9 * p, 64), aqq = __shfl(a, 9 * q, 64), apq = __shfl(a, 8 * p + q, 64);
+            const bool act = (q < m) && (fabs(apq) > thresh);
+            double c = 1.0, sn = 0.0;
+            if (act) {
+                const double theta = (aqq - app) * jac_rcp(2.0 * apq);
+                double t;
+                if (fabs(theta) > 1e150) t = 0.5 * jac_rcp(theta);
+                else {
+                    const double th2 = theta * theta + 1.0;
+                    t = copysign(1.0, theta) * jac_rcp(fabs(theta) + th2 * jac_rsqrt(th2));
+                }
+                c = jac_rsqrt(t * t + 1.0);
+                sn = t * c;
+            }
+            rotated |= act;
+            // column phase: A <- A J, V <- V J
+            {
+                const double ao = __shfl(a, 8 * i + pc, 64), vo = __shfl(v, 8 * i + pc, 64);
+                a = (j == p) ? c * a - sn * ao : sn * ao + c * a;
+                v = (j == p) ? c * v - sn * vo : sn * vo + c * v;
+            }
+            // row phase: A <- J^T A with the parameters of the row pair {i, pr} (held by lane (pr.., i) as a column pair)
+            {
+                const int pr = rr_partner8(i, step), rp = min(i, pr), rq = max(i, pr);
+                const double cr = __shfl(c, i, 64), sr = __shfl(sn, i, 64);       // lane (0, i): column pair of index i
+                const double ao = __shfl(a, 8 * pr + j, 64);
+                double an = (i == rp) ? cr * a - sr * ao : sr * ao + cr * a;
+                const bool ract = (sr != 0.0) || (cr != 1.0);
+                if (ract && ((i == rp && j == rq) || (i == rq && j == rp))) an = 0.0;   // the annihilated element, exactly
+                a = an;
+            }
+        }
+        converged = (__ballot(rotated) == 0ull);
+    }
+    // ascending order by rank counting (ties by index), scatter eigenpairs
+    const double dj = __shfl(a, 9 * j, 64);                   // eigenvalue of column j
+    int rank = 0;
+    for (int k = 0; k < m; ++k) {
+        const double dk = __shfl(a, 9 * k, 64);
+        rank += (dk < dj) || (dk == dj && k < j);
+    }
+    if (i < m && j < m) {
+        if (i == 0) w.dcur[lo + rank] = dj;
+        w.Qcur[(long)(lo + i) * n + lo + rank] = v;
+    }
+    if (lane == 0 && !converged) atomicMax(status, 1);
+}
+
 // one wave per leaf: dense leaf matrix in LDS -> Jacobi -> dcur[lo:hi], Qcur diagonal block
 __global__ __launch_bounds__(64) void dc_leaf_kernel(DcLevel L, int *status) {
     const DcWork &w = L.w[blockIdx.y];
@@ -1043,7 +1125,10 @@ void stedc_batch_device(gpcsd_ctx *c, StedcProb *probs, int count, int *d_status
     }
     hipLaunchKernelGGL(dc_tear_kernel, dim3(64, count), dim3(256), 0, s, L);
     for (int p = 0; p < count; ++p) L.aux[p] = (int)plans[p].leaf_lo.size() - 1;
-    hipLaunchKernelGGL(dc_leaf_kernel, dim3(max_leaves, count), dim3(64), 0, s, L, d_status);
+    static_assert(DC_LEAF == 8, "the register leaf solver maps an 8 x 8 block onto one wave");
+    static const bool lds_leaf = getenv("GPCSD_DC_LEAF") && !strcmp(getenv("GPCSD_DC_LEAF"), "lds");
+    if (lds_leaf) hipLaunchKernelGGL(dc_leaf_kernel, dim3(max_leaves, count), dim3(64), 0, s, L, d_status);
+    else hipLaunchKernelGGL(dc_leaf_reg_kernel, dim3(max_leaves, count), dim3(64), 0, s, L, d_status);
     GP_HIP(hipGetLastError());
 
     // Problems with fewer levels idle at the bottom: level index counts from the TOP so the final merges align.
