@@ -26,6 +26,10 @@
 namespace gpcsd {
 
 typedef double d4 __attribute__((ext_vector_type(4)));
+// Fragment reads as volatile LDS loads: the compiler otherwise fuses neighbouring reads into ds_read2_b64, which is banked
+// modulo 32 (two-way conflicts on these layouts, 25 % of the LDS cycles) instead of ds_read_b64's 64 banks.
+typedef const volatile double __attribute__((address_space(3))) *lds_frag_ptr;
+#define LDS_FRAG(p) (*(lds_frag_ptr)(p))
 
 constexpr int PAD_KO = 16;
 
@@ -254,9 +258,9 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f64_kernel(GemmK g) {
             if (kk < last_steps) {                  // wave-uniform
                 double a[FM], b[FN];
 #pragma unroll
-                for (int i = 0; i < FM; ++i) a[i] = sa[TileA::lds_index(i * 16, kk * 4)];
+                for (int i = 0; i < FM; ++i) a[i] = LDS_FRAG(sa + TileA::lds_index(i * 16, kk * 4));
 #pragma unroll
-                for (int j = 0; j < FN; ++j) b[j] = sb[TileB::lds_index(j * 16, kk * 4)];
+                for (int j = 0; j < FN; ++j) b[j] = LDS_FRAG(sb + TileB::lds_index(j * 16, kk * 4));
 #pragma unroll
                 for (int i = 0; i < FM; ++i)
 #pragma unroll
@@ -273,9 +277,9 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f64_kernel(GemmK g) {
         for (int kk = 0; kk < BK / 4; ++kk) {
             double a[FM], b[FN];
 #pragma unroll
-            for (int i = 0; i < FM; ++i) a[i] = sa[TileA::lds_index(i * 16, kk * 4)];
+            for (int i = 0; i < FM; ++i) a[i] = LDS_FRAG(sa + TileA::lds_index(i * 16, kk * 4));
 #pragma unroll
-            for (int j = 0; j < FN; ++j) b[j] = sb[TileB::lds_index(j * 16, kk * 4)];
+            for (int j = 0; j < FN; ++j) b[j] = LDS_FRAG(sb + TileB::lds_index(j * 16, kk * 4));
 #pragma unroll
             for (int i = 0; i < FM; ++i)
 #pragma unroll
