@@ -355,6 +355,36 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f64_kernel(GemmK g) {
     double *__restrict__ C = (EPI == EPI_QUAD) ? nullptr : g.C + bz * g.sC;
     double *__restrict__ C2 = (EPI == EPI_DUAL || EPI == EPI_DUAL_INIT || EPI == EPI_GRAD) ? g.C2 + bz * g.sC : nullptr;
     double *__restrict__ C3 = (EPI == EPI_GRAD) ? g.C3 + bz * g.sC : nullptr;
+    if (EPI == EPI_STORE) {
+        // The plain store is the hot epilogue: every VALU instruction here is taken from the MFMAs of the workgroups that
+        // share the SIMD, so the per-column factor (alpha, optional column scale) and the validity of the FN columns are
+        // formed once, rows advance by pointer increments, and the FN stores of a row use immediate offsets.
+        const int colb = n0 + wc * 16 * FN + fr;
+        double asc[FN];
+        bool cok[FN];
+#pragma unroll
+        for (int j = 0; j < FN; ++j) {
+            cok[j] = colb + 16 * j < g.N;
+            asc[j] = g.alpha;
+            if (g.colscale) asc[j] *= g.colscale[bz * g.sColscale + (cok[j] ? colb + 16 * j : 0)];       // wave-uniform test
+        }
+        const int rowb = m0 + wr * 16 * FM + fq;
+        double *pr = C + (long)rowb * g.ldc + colb;
+        const long step4 = 4 * g.ldc;
+#pragma unroll
+        for (int i = 0; i < FM; ++i) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if (rowb + 16 * i + 4 * r < g.M) {
+#pragma unroll
+                    for (int j = 0; j < FN; ++j)
+                        if (cok[j]) pr[16 * j] = asc[j] * acc[i][j][r];
+                }
+                pr += step4;
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < FM; ++i) {
 #pragma unroll
@@ -369,10 +399,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f64_kernel(GemmK g) {
                 const int col = n0 + wc * 16 * FN + j * 16 + fr;
                 if (col >= g.N) continue;
                 const double v = acc[i][j][r];
-                if (EPI == EPI_STORE) {
-                    const double sc = g.colscale ? g.colscale[bz * g.sColscale + col] : 1.0;     // wave-uniform test
-                    C[(long)row * g.ldc + col] = g.alpha * v * sc;
-                } else if (EPI == EPI_ACCUM) {
+                if (EPI == EPI_ACCUM) {
                     C[(long)row * g.ldc + col] += g.alpha * v;
                 } else if (EPI == EPI_DUAL) {
                     const double o = g.alpha * v;
