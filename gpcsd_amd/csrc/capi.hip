@@ -216,18 +216,18 @@ bool rule_is_symmetric(const double *gx, const double *gw, int n, double *centre
 // Eigen-decompose Ks (stream) and Kt (stream2) concurrently; D and sum(log D).
 // Inputs Ks, Kt are destroyed.  Outputs: Qs, es, Qt, et, D, sumlog (device).
 void eig_pair_D(gpcsd_ctx *c, double *Ks, int nx, double *Kt, int nt, const double *d_sig, int nsig, double *Qs, double *es,
-                double *Qt, double *et, double *D, double *d_sumlog, int *d_status, const SymDev *sym_s = nullptr,
+                double *Qt, double *et, double *D, double *Dinv, double *d_sumlog, int *d_status, const SymDev *sym_s = nullptr,
                 const SymDev *sym_t = nullptr) {
     {
         // all problems share every launch of the per-column tridiagonalisation (batched), so one stream suffices
         ProfScope ps(c, "eigh_pair", 9.0 * ((double)nx * nx * nx + (double)nt * nt * nt), c->stream);
         eigh_pair_device(c, Ks, nx, es, Qs, sym_s, Kt, nt, et, Qt, sym_t, d_status, c->stream);
     }
-    k_build_D(c, es, nx, et, nt, d_sig, nsig, D, d_sumlog, c->stream);
+    k_build_D(c, es, nx, et, nt, d_sig, nsig, D, Dinv, d_sumlog, c->stream);
 }
 
 struct EigState {
-    double *Qs, *Qt, *es, *et, *D, *scal;   // scal[0] = sumlog, scal[1] = quad, ...
+    double *Qs, *Qt, *es, *et, *D, *Dinv, *scal;   // scal[0] = sumlog, scal[1] = quad, ...; Dinv = 1/D for the GEMM epilogues
     int *status;
     // two-stream front half: the temporal chain (Kt, its eigen-decomposition) runs on stream2 and has not been waited
     // for yet; join_temporal() makes Qt / et / D available on the main stream
@@ -264,6 +264,7 @@ EigState front_half(gpcsd_ctx *c, const gpcsd_hparams *hp, double jitter) {
     e.es = c->buf<double>("es", nx);
     e.et = c->buf<double>("et", nt);
     e.D = c->buf<double>("D", (size_t)nx * nt);
+    e.Dinv = c->buf<double>("Dinv", (size_t)nx * nt);
     e.scal = c->buf<double>("scalars", 64);
     e.status = c->buf<int>("status", 4);
     const double *t = (const double *)c->bufs["time_t"].p;
@@ -274,7 +275,7 @@ EigState front_half(gpcsd_ctx *c, const gpcsd_hparams *hp, double jitter) {
         build_kphi(c, g, hp->R, hp->eps, hp->ell_s, nullptr, 0, jitter, Ks, s);
         build_kt(c, hp, t, nt, t, nt, Kt, s);
         // the symmetries come from the resident geometry / time grid, so they hold for the Grams built from them
-        eig_pair_D(c, Ks, nx, Kt, nt, d_sig, hp->n_sig2n, e.Qs, e.es, e.Qt, e.et, e.D, e.scal, e.status, sym_s, sym_t);
+        eig_pair_D(c, Ks, nx, Kt, nt, d_sig, hp->n_sig2n, e.Qs, e.es, e.Qt, e.et, e.D, e.Dinv, e.scal, e.status, sym_s, sym_t);
         return e;
     }
     // The temporal chain is the critical path: it is queued first, before any upload of this call.  It needs nothing
@@ -307,7 +308,7 @@ EigState front_half(gpcsd_ctx *c, const gpcsd_hparams *hp, double jitter) {
 void join_temporal(gpcsd_ctx *c, EigState &e) {
     if (!e.pending) return;
     GP_HIP(hipStreamWaitEvent(c->stream, c->ev_join, 0));
-    k_build_D(c, e.es, c->nx, e.et, c->nt, e.d_sig, e.nsig, e.D, e.scal, c->stream);
+    k_build_D(c, e.es, c->nx, e.et, c->nt, e.d_sig, e.nsig, e.D, e.Dinv, e.scal, c->stream);
     e.pending = false;
 }
 
@@ -706,7 +707,7 @@ extern "C" int gpcsd_eig_D(gpcsd_ctx *c, const double *Ks, int nx, const double 
     double *scal = c->buf<double>("scalars", 64);
     int *st = c->buf<int>("status", 4);
     GP_HIP(hipMemsetAsync(st, 0, 4 * sizeof(int), c->stream));
-    eig_pair_D(c, dKs, nx, dKt, nt, dsig, n_sig, dQs, es, dQt, et, D, scal, st);
+    eig_pair_D(c, dKs, nx, dKt, nt, dsig, n_sig, dQs, es, dQt, et, D, nullptr, scal, st);
     if (Qs) c->download(Qs, dQs, (size_t)nx * nx * sizeof(double));
     if (Qt) c->download(Qt, dQt, (size_t)nt * nt * sizeof(double));
     if (Dvec) c->download(Dvec, D, (size_t)nx * nt * sizeof(double));
@@ -907,7 +908,7 @@ extern "C" int gpcsd_loglik_parts(gpcsd_ctx *c, const gpcsd_hparams *hp, double 
     g2.M = nx * R; g2.N = nt; g2.K = nt;
     g2.A = W; g2.lda = nt;
     g2.B = e.Qt; g2.ldb = nt;
-    g2.epi = EPI_QUAD; g2.D = e.D; g2.rdiv = R; g2.ldd = nt; g2.quad_out = e.scal + 1;
+    g2.epi = EPI_QUAD; g2.D = e.Dinv; g2.rdiv = R; g2.ldd = nt; g2.quad_out = e.scal + 1;
     g2.prof_name = "gemm_proj_temporal_quad";
     gemm_f64(c, g2, s);
     c->download(out2, e.scal, 2 * sizeof(double));
@@ -982,7 +983,7 @@ static int predict_impl(gpcsd_ctx *c, const gpcsd_hparams *hp, const double *z, 
     GemmDesc g2;                          // Bm = (W Qt) / D
     g2.M = nx * R; g2.N = nt; g2.K = nt;
     g2.A = W; g2.lda = nt; g2.B = e.Qt; g2.ldb = nt; g2.C = Bm; g2.ldc = nt;
-    g2.epi = EPI_DIV_D; g2.D = e.D; g2.rdiv = R; g2.ldd = nt;
+    g2.epi = EPI_DIV_D; g2.D = e.Dinv; g2.rdiv = R; g2.ldd = nt;
     g2.prof_name = "gemm_pred_temporal_div";
     gemm_f64(c, g2, s);
     for (int which = 1; which <= 2; ++which) {
@@ -1132,7 +1133,7 @@ extern "C" int gpcsd_loglik_grad(gpcsd_ctx *c, const gpcsd_hparams *hp, double *
     GemmDesc g2;                          // alpha = W Qt;  B = alpha / D, B*et, B*es;  sum alpha*B, sum B^2
     g2.M = nx * R; g2.N = nt; g2.K = nt;
     g2.A = W; g2.lda = nt; g2.B = e.Qt; g2.ldb = nt; g2.C = Bm; g2.ldc = nt; g2.C2 = Bet; g2.C3 = Bes;
-    g2.epi = EPI_GRAD; g2.D = e.D; g2.rdiv = R; g2.ldd = nt; g2.colscale = e.et; g2.rowscale = e.es;
+    g2.epi = EPI_GRAD; g2.D = e.Dinv; g2.rdiv = R; g2.ldd = nt; g2.colscale = e.et; g2.rowscale = e.es;
     g2.quad_out = e.scal + 1;             // scal[1] = quad, scal[2] = sum B^2
     g2.prof_name = "gemm_grad_temporal";
     gemm_f64(c, g2, s);

@@ -410,17 +410,17 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f64_kernel(GemmK g) {
                     C[(long)row * g.ldc + col] = o;
                     C2[(long)row * g.ldc + col] = o;
                 } else if (EPI == EPI_DIV_D) {
-                    C[(long)row * g.ldc + col] = v / g.D[drow + col];
+                    C[(long)row * g.ldc + col] = v * g.D[drow + col];
                 } else if (EPI == EPI_GRAD) {
                     // b = alpha / D; also b * et[col], b * es[row / rdiv]; partial sums of alpha*b and b*b
-                    const double bq = v / g.D[drow + col];
+                    const double bq = v * g.D[drow + col];
                     C[(long)row * g.ldc + col] = bq;
                     C2[(long)row * g.ldc + col] = bq * g.colscale[col];
                     C3[(long)row * g.ldc + col] = bq * rsc;
                     qsum += v * bq;
                     qsum2 += bq * bq;
                 } else {
-                    qsum += v * v / g.D[drow + col];
+                    qsum += v * v * g.D[drow + col];
                 }
             }
         }

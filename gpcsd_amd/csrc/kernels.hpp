@@ -7,11 +7,11 @@ namespace gpcsd {
 // ---------------------------------------------------------------- fp64 MFMA GEMM core
 enum Epi : int {
     EPI_STORE = 0,   // C = alpha * acc
-    EPI_DIV_D = 1,   // C = acc / D[(row / rdiv) * ldd + col]
-    EPI_QUAD = 2,    // no store; partial sums of acc^2 / D[...] (deterministic two-stage reduce)
+    EPI_DIV_D = 1,   // C = acc * D[(row / rdiv) * ldd + col]   with D = the RECIPROCALS 1/D_xi (k_build_D's Dinv)
+    EPI_QUAD = 2,    // no store; partial sums of acc^2 * D[...] (reciprocals; deterministic two-stage reduce)
     EPI_ACCUM = 3,   // C += alpha * acc
     EPI_DUAL = 4,    // C = alpha*acc and C2 += alpha*acc   (predict: per-component + running sum)
-    EPI_GRAD = 5,    // b = acc / D: C = b, C2 = b*colscale[col], C3 = b*rowscale[row/rdiv]; sums of acc*b and b*b
+    EPI_GRAD = 5,    // b = acc * D (reciprocals): C = b, C2 = b*colscale[col], C3 = b*rowscale[row/rdiv]; sums of acc*b and b*b
     EPI_DUAL_INIT = 6  // C = alpha*acc and C2 = alpha*acc (first term of a running sum: no read, no zero fill)
 };
 
@@ -66,7 +66,7 @@ void k_se_2d(gpcsd_ctx *c, const double *a1, const double *a2, int na, int na2, 
 void k_add_diag(gpcsd_ctx *c, double *A, int n, double v, hipStream_t s);
 // D[x*nt + i] = es[x]*et[i] + sig[x or 0]; also sumlog -> *sumlog_out (deterministic)
 void k_build_D(gpcsd_ctx *c, const double *es, int nx, const double *et, int nt, const double *sig, int nsig, double *D,
-               double *sumlog_out, hipStream_t s);
+               double *Dinv, double *sumlog_out, hipStream_t s);   // Dinv (optional) = 1/D elementwise
 // lfp host layout [x][t][r] -> device layout [x][r][t] (and back for predictions [z][r][t] -> [z][t][r])
 void k_swap_last2(gpcsd_ctx *c, const double *in, double *out, int n0, int n1, int n2, hipStream_t s);
 void k_fill(gpcsd_ctx *c, double *p, long n, double v, hipStream_t s);
