@@ -265,8 +265,9 @@ EigState front_half(gpcsd_ctx *c, const gpcsd_hparams *hp, double jitter) {
     e.et = c->buf<double>("et", nt);
     e.D = c->buf<double>("D", (size_t)nx * nt);
     e.Dinv = c->buf<double>("Dinv", (size_t)nx * nt);
-    e.scal = c->buf<double>("scalars", 64);
-    e.status = c->buf<int>("status", 4);
+    // scalars and status words share one allocation so that a call ends with ONE small device-to-host copy
+    e.scal = c->buf<double>("scal_status", 64 + 2);
+    e.status = reinterpret_cast<int *>(e.scal + 64);
     const double *t = (const double *)c->bufs["time_t"].p;
     const SymDev *sym_s = c->sym_s.ns > 0 ? &c->sym_s : nullptr, *sym_t = c->sym_t.ns > 0 ? &c->sym_t : nullptr;
     if (!two_stream_front()) {
@@ -310,6 +311,25 @@ void join_temporal(gpcsd_ctx *c, EigState &e) {
     GP_HIP(hipStreamWaitEvent(c->stream, c->ev_join, 0));
     k_build_D(c, e.es, c->nx, e.et, c->nt, e.d_sig, e.nsig, e.D, e.Dinv, e.scal, c->stream);
     e.pending = false;
+}
+
+// End of a fused call: one copy brings back the leading `nscal` scalars and the status words, then the stream is drained.
+int finish_call(gpcsd_ctx *c, const EigState &e, double *scal_out, int nscal) {
+    double host[66];
+    c->download(host, e.scal, sizeof(host));
+    c->sync();
+    if (c->prof_on) c->prof_collect();
+    for (int i = 0; i < nscal; ++i) scal_out[i] = host[i];
+    int st[4];
+    memcpy(st, host + 64, sizeof(st));
+    if (st[0] == 0 && st[1] != 0) st[0] = st[1];      // status[1]: the temporal chain of the two-stream front half
+    if (st[0] != 0) {
+        char b[128];
+        snprintf(b, sizeof(b), "numerical failure (status %d): eigensolver did not converge or matrix not positive definite", st[0]);
+        c->last_error = b;
+        return st[0] > 0 ? st[0] : 1;
+    }
+    return 0;
 }
 
 int finish_status(gpcsd_ctx *c, const int *d_status) {
@@ -911,8 +931,7 @@ extern "C" int gpcsd_loglik_parts(gpcsd_ctx *c, const gpcsd_hparams *hp, double 
     g2.epi = EPI_QUAD; g2.D = e.Dinv; g2.rdiv = R; g2.ldd = nt; g2.quad_out = e.scal + 1;
     g2.prof_name = "gemm_proj_temporal_quad";
     gemm_f64(c, g2, s);
-    c->download(out2, e.scal, 2 * sizeof(double));
-    return finish_status(c, e.status);
+    return finish_call(c, e, out2, 2);
     GP_API_END(c)
 }
 
@@ -1014,7 +1033,7 @@ static int predict_impl(gpcsd_ctx *c, const gpcsd_hparams *hp, const double *z, 
         gemm_f64(c, g6, s);
         k_swap_last2_sum(c, comp, C, o_list, (long)out_elems, o_sum, nz, R, nt, s);     // (z,r,c,t) -> (c,z,t,r), sum over c
     }
-    return finish_status(c, e.status);
+    return finish_call(c, e, nullptr, 0);
 }
 
 extern "C" int gpcsd_predict_resident(gpcsd_ctx *c, const gpcsd_hparams *hp, const double *z, int nz, const double *tstar,
