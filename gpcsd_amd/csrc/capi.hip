@@ -315,8 +315,8 @@ void join_temporal(gpcsd_ctx *c, EigState &e) {
 
 // End of a fused call: one copy brings back the leading `nscal` scalars and the status words, then the stream is drained.
 int finish_call(gpcsd_ctx *c, const EigState &e, double *scal_out, int nscal) {
-    double host[66];
-    c->download(host, e.scal, sizeof(host));
+    double *host = c->h_result;                        // pinned: a true asynchronous copy, no staging
+    c->download(host, e.scal, 66 * sizeof(double));
     c->sync();
     if (c->prof_on) c->prof_collect();
     for (int i = 0; i < nscal; ++i) scal_out[i] = host[i];
@@ -375,6 +375,7 @@ extern "C" int gpcsd_ctx_create(int device, gpcsd_ctx **out) {
         GP_HIP(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
         GP_HIP(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
         GP_HIP(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
+        GP_HIP(hipHostMalloc(reinterpret_cast<void **>(&c->h_result), 66 * sizeof(double), hipHostMallocDefault));
         *out = c;
         return 0;
     } catch (const HipError &e) {
@@ -406,6 +407,7 @@ extern "C" int gpcsd_ctx_destroy(gpcsd_ctx *c) {
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     if (c->stream2) (void)hipStreamDestroy(c->stream2);
+    if (c->h_result) (void)hipHostFree(c->h_result);
     delete c;
     return 0;
 }

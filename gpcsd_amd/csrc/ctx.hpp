@@ -65,6 +65,7 @@ struct gpcsd_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;          // second stream: the two eigenproblems are independent
+    double *h_result = nullptr;             // pinned host landing zone for the end-of-call copy (66 doubles)
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     hipStream_t side[4] = {nullptr, nullptr, nullptr, nullptr};   // fork/join branches for independent small chains
     hipEvent_t side_ev[4] = {nullptr, nullptr, nullptr, nullptr};
