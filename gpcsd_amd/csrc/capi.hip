@@ -271,7 +271,7 @@ EigState front_half(gpcsd_ctx *c, const gpcsd_hparams *hp, double jitter) {
     const double *t = (const double *)c->bufs["time_t"].p;
     const SymDev *sym_s = c->sym_s.ns > 0 ? &c->sym_s : nullptr, *sym_t = c->sym_t.ns > 0 ? &c->sym_t : nullptr;
     if (!two_stream_front()) {
-        double *d_sig = c->upload<double>("sig2n", hp->sig2n, hp->n_sig2n);
+        double *d_sig = c->upload_cached<double>("sig2n", hp->sig2n, hp->n_sig2n);
         GP_HIP(hipMemsetAsync(e.status, 0, 4 * sizeof(int), s));
         build_kphi(c, g, hp->R, hp->eps, hp->ell_s, nullptr, 0, jitter, Ks, s);
         build_kt(c, hp, t, nt, t, nt, Kt, s);
@@ -292,7 +292,7 @@ EigState front_half(gpcsd_ctx *c, const gpcsd_hparams *hp, double jitter) {
         eigh_pair_device(c, nullptr, 0, nullptr, nullptr, nullptr, Kt, nt, e.et, e.Qt, sym_t, e.status + 1, s2);
     }
     GP_HIP(hipEventRecord(c->ev_join, s2));
-    double *d_sig = c->upload<double>("sig2n", hp->sig2n, hp->n_sig2n);
+    double *d_sig = c->upload_cached<double>("sig2n", hp->sig2n, hp->n_sig2n);
     GP_HIP(hipMemsetAsync(e.status, 0, sizeof(int), s));
     build_kphi(c, g, hp->R, hp->eps, hp->ell_s, nullptr, 0, jitter, Ks, s);
     {
@@ -973,8 +973,8 @@ static int predict_impl(gpcsd_ctx *c, const gpcsd_hparams *hp, const double *z, 
     //   out_c = Kc^T Qs Bm Qt^T Kt*_c  is re-associated as  (Kc^T Qs) Bm (Qt^T Kt*_c),
     // i.e. two small (n^3) products M1, Pc and two flat GEMMs, instead of back-projecting to the original bases first
     // (saves 2 nx^2 nt + 2 nx nt^2 flops per trial; identical up to rounding).
-    double *dz = c->upload<double>("pred_z", z, (size_t)nz * g.dim);
-    double *dts = c->upload<double>("pred_tstar", tstar, ntstar);
+    double *dz = c->upload_cached<double>("pred_z", z, (size_t)nz * g.dim);
+    double *dts = c->upload_cached<double>("pred_tstar", tstar, ntstar);
     const double *t = (const double *)c->bufs["time_t"].p;
     double *Kc = c->buf<double>("pred_Kcross", (size_t)nx * nz);
     double *S = c->buf<double>("pred_S", (size_t)nz * RT);
