@@ -66,6 +66,7 @@ struct gpcsd_ctx {
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;          // second stream: the two eigenproblems are independent
     double *h_result = nullptr;             // pinned host landing zone for the end-of-call copy (66 doubles)
+    bool capturing = false;                 // inside a stream capture: profiling scopes stay silent
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     hipStream_t side[4] = {nullptr, nullptr, nullptr, nullptr};   // fork/join branches for independent small chains
     hipEvent_t side_ev[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -171,14 +172,14 @@ struct ProfScope {
     double flops;
     ProfScope(gpcsd_ctx *ctx, const char *nm, double fl = 0.0, hipStream_t st = nullptr)
         : c(ctx), name(nm), s(st ? st : ctx->stream), flops(fl) {
-        if (c->prof_on) {
+        if (c->prof_on && !c->capturing) {
             e0 = c->get_event();
             e1 = c->get_event();
             (void)hipEventRecord(e0, s);
         }
     }
     ~ProfScope() {
-        if (c->prof_on && e0) {
+        if (c->prof_on && e0 && !c->capturing) {
             (void)hipEventRecord(e1, s);
             ProfEntry &p = c->prof[name];
             p.pending.emplace_back(e0, e1);
