@@ -106,17 +106,36 @@ __device__ __forceinline__ int rr_partner8(int x, int step7) {        // partner
     return y;
 }
 
-__global__ __launch_bounds__(64) void dc_leaf_reg_kernel(DcLevel L, int *status) {
+// Workgroups [0, nleaf_max) solve leaves; workgroup nleaf_max + r zeroes row r of both ping-pong eigenvector matrices
+// outside the row's own leaf block (a merge reads the off-diagonal blocks between its halves, which no level writes).
+// The Cuppen tears are applied here as well: every leaf boundary is the boundary of some merge, so the first / last
+// diagonal entry of a leaf loses |e| of the coupling it was cut from.  One launch instead of tear + leaf.
+__global__ __launch_bounds__(64) void dc_leaf_reg_kernel(DcLevel L, int *status, int nleaf_max) {
     const DcWork &w = L.w[blockIdx.y];
-    if ((int)blockIdx.x >= L.aux[blockIdx.y]) return;
-    const int n = w.n;
+    const int n = w.n, nleaf = L.aux[blockIdx.y];
+    if ((int)blockIdx.x >= nleaf_max) {
+        const int r = (int)blockIdx.x - nleaf_max;
+        if (r >= n) return;
+        int lf = 0;
+        while (lf + 1 < nleaf && w.tbl[lf + 1] <= r) ++lf;          // wave-uniform scan of <= 128 leaf bounds
+        const int blo = w.tbl[lf], bhi = w.tbl[lf + 1];
+        for (int cidx = threadIdx.x; cidx < n; cidx += 64) {
+            if (cidx < blo || cidx >= bhi) w.Qcur[(long)r * n + cidx] = 0.0;
+            w.Qnext[(long)r * n + cidx] = 0.0;
+        }
+        return;
+    }
+    if ((int)blockIdx.x >= nleaf) return;
     const int lo = w.tbl[blockIdx.x], hi = w.tbl[blockIdx.x + 1];
     const int m = hi - lo;
     const int lane = threadIdx.x, i = lane >> 3, j = lane & 7;
     double a = 0.0;
     if (i < m && j < m) {
-        if (i == j) a = w.dwork[lo + i];
-        else if (j == i + 1) a = w.e[lo + i];
+        if (i == j) {
+            a = w.d0[lo + i];
+            if (i == 0 && lo > 0) a -= fabs(w.e[lo - 1]);
+            if (i == m - 1 && hi < n) a -= fabs(w.e[hi - 1]);
+        } else if (j == i + 1) a = w.e[lo + i];
         else if (i == j + 1) a = w.e[lo + j];
     }
     double v = (i == j) ? 1.0 : 0.0;
@@ -1123,12 +1142,16 @@ void stedc_batch_device(gpcsd_ctx *c, StedcProb *probs, int count, int *d_status
         L.seg_off[p] = plans[p].off_bounds;
         L.aux[p] = (int)plans[p].bounds.size();
     }
-    hipLaunchKernelGGL(dc_tear_kernel, dim3(64, count), dim3(256), 0, s, L);
-    for (int p = 0; p < count; ++p) L.aux[p] = (int)plans[p].leaf_lo.size() - 1;
     static_assert(DC_LEAF == 8, "the register leaf solver maps an 8 x 8 block onto one wave");
     static const bool lds_leaf = getenv("GPCSD_DC_LEAF") && !strcmp(getenv("GPCSD_DC_LEAF"), "lds");
-    if (lds_leaf) hipLaunchKernelGGL(dc_leaf_kernel, dim3(max_leaves, count), dim3(64), 0, s, L, d_status);
-    else hipLaunchKernelGGL(dc_leaf_reg_kernel, dim3(max_leaves, count), dim3(64), 0, s, L, d_status);
+    if (lds_leaf) {
+        hipLaunchKernelGGL(dc_tear_kernel, dim3(64, count), dim3(256), 0, s, L);
+        for (int p = 0; p < count; ++p) L.aux[p] = (int)plans[p].leaf_lo.size() - 1;
+        hipLaunchKernelGGL(dc_leaf_kernel, dim3(max_leaves, count), dim3(64), 0, s, L, d_status);
+    } else {
+        for (int p = 0; p < count; ++p) L.aux[p] = (int)plans[p].leaf_lo.size() - 1;
+        hipLaunchKernelGGL(dc_leaf_reg_kernel, dim3(max_leaves + nmax, count), dim3(64), 0, s, L, d_status, max_leaves);
+    }
     GP_HIP(hipGetLastError());
 
     // Problems with fewer levels idle at the bottom: level index counts from the TOP so the final merges align.
@@ -1146,6 +1169,13 @@ void stedc_batch_device(gpcsd_ctx *c, StedcProb *probs, int count, int *d_status
             L.seg_off[p] = plans[p].lvl_off[own];
             max_seg = std::max(max_seg, (int)lv.size());
             for (auto &sg : lv) maxN = std::max(maxN, sg.hi - sg.lo);
+        }
+        if (li + 1 == nlevels) {               // the top merge covers the whole matrix: place it in the caller's arrays
+            for (int p = 0; p < count; ++p)
+                if (L.nseg[p] > 0) {
+                    L.w[p].Qnext = L.w[p].Zout;
+                    L.w[p].dnext = L.w[p].wout;
+                }
         }
         if (maxN <= DC_SMALL) {
             static const int fast = !(getenv("GPCSD_DC_SMALL") && !strcmp(getenv("GPCSD_DC_SMALL"), "old"));
@@ -1199,7 +1229,9 @@ void stedc_batch_device(gpcsd_ctx *c, StedcProb *probs, int count, int *d_status
             std::swap(L.w[p].Qcur, L.w[p].Qnext);
         }
     }
-    hipLaunchKernelGGL(dc_output_kernel, dim3(64, count), dim3(256), 0, s, L);
+    bool need_copy = false;                    // only a problem without any merge level (n <= DC_LEAF) still needs the copy
+    for (int p = 0; p < count; ++p) need_copy = need_copy || plans[p].levels.empty();
+    if (need_copy) hipLaunchKernelGGL(dc_output_kernel, dim3(64, count), dim3(256), 0, s, L);
     GP_HIP(hipGetLastError());
 }
 
