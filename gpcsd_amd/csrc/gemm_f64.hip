@@ -137,16 +137,13 @@ struct Tile {
     }
 };
 
-// NBUF = 2: double-buffered operand tiles, one barrier per K tile.  NBUF = 1: a single LDS buffer and two barriers per
-// K tile -- half the LDS, so a fifth workgroup fits a CU (1280 instead of 1024 resident tiles): used where the tile count
-// of the launch quantises badly on 1024 (2400 tiles = 2.34 rounds -> 1.875 rounds).
-template <int WM, int WN, int FM, int FN, int BK, bool TA, bool TB, int EPI, int NBUF>
+template <int WM, int WN, int FM, int FN, int BK, bool TA, bool TB, int EPI>
 __global__ __launch_bounds__(64 * WM * WN) void gemm_f64_kernel(GemmK g) {
     constexpr int NT = 64 * WM * WN;
     constexpr int BM = 16 * FM * WM, BN = 16 * FN * WN;
     using TileA = Tile<BM, TA, NT, BK>;    // transA: global [K][M]
     using TileB = Tile<BN, !TB, NT, BK>;   // !transB: global [K][N]
-    __shared__ double lds[NBUF * (TileA::LDS_ELEMS + TileB::LDS_ELEMS)];
+    __shared__ double lds[2 * (TileA::LDS_ELEMS + TileB::LDS_ELEMS)];
     // operand A buffers at lds + b*TileA::LDS_ELEMS; operand B buffers follow the A buffers
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -214,9 +211,9 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f64_kernel(GemmK g) {
     TileA::slot0(tid, oa0, ka0);
     TileB::slot0(tid, ob0, kb0);
     double *const swA = lds + TileA::lds_index(oa0, ka0);                                   // LDS store bases (buffer 0)
-    double *const swB = lds + NBUF * TileA::LDS_ELEMS + TileB::lds_index(ob0, kb0);
+    double *const swB = lds + 2 * TileA::LDS_ELEMS + TileB::lds_index(ob0, kb0);
     const double *const srA = lds + TileA::lds_index(wr * 16 * FM + fr, fq);                // fragment read bases (buffer 0)
-    const double *const srB = lds + NBUF * TileA::LDS_ELEMS + TileB::lds_index(wc * 16 * FN + fr, fq);
+    const double *const srB = lds + 2 * TileA::LDS_ELEMS + TileB::lds_index(wc * 16 * FN + fr, fq);
     using Buf0 = std::integral_constant<int, 0>;
     using Buf1 = std::integral_constant<int, 1>;
 
@@ -288,72 +285,48 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f64_kernel(GemmK g) {
         }
     };
 
-    if constexpr (NBUF == 1) {
-        load_any(0);
-        store_any(Buf0{}, 0);
+    load_any(0);
+    store_any(Buf0{}, 0);
+    __syncthreads();
+    // steady state, two K tiles per trip so the buffer index is a compile-time constant
+    int kt = 0;
+    for (; kt + 2 < nfull; kt += 2) {
+        load_full(kt + 1);
+        __builtin_amdgcn_sched_barrier(0);     // keep the order loads | MFMAs | LDS stores: the MFMAs are the loads' cover
+        mma_tile(Buf0{});
+        __builtin_amdgcn_sched_barrier(0);
+        store_full(Buf1{});
         __syncthreads();
-        int kt = 0;
-        for (; kt + 1 < nfull; ++kt) {
-            load_full(kt + 1);
-            __builtin_amdgcn_sched_barrier(0);
-            mma_tile(Buf0{});
-            __builtin_amdgcn_sched_barrier(0);
-            __syncthreads();                       // every wave is done reading the tile
-            store_full(Buf0{});
-            __syncthreads();
-        }
-        if (kt + 1 < nk) {                         // one partial K tile follows
-            load_any(kt + 1);
-            mma_tile(Buf0{});
-            __syncthreads();
-            store_any(Buf0{}, kt + 1);
-            __syncthreads();
-        }
-        mma_last(Buf0{});
-    } else {
-        load_any(0);
-        store_any(Buf0{}, 0);
+        load_full(kt + 2);
+        __builtin_amdgcn_sched_barrier(0);
+        mma_tile(Buf1{});
+        __builtin_amdgcn_sched_barrier(0);
+        store_full(Buf0{});
         __syncthreads();
-        // steady state, two K tiles per trip so the buffer index is a compile-time constant
-        int kt = 0;
-        for (; kt + 2 < nfull; kt += 2) {
-            load_full(kt + 1);
-            __builtin_amdgcn_sched_barrier(0);     // keep the order loads | MFMAs | LDS stores: the MFMAs are the loads' cover
-            mma_tile(Buf0{});
-            __builtin_amdgcn_sched_barrier(0);
-            store_full(Buf1{});
-            __syncthreads();
-            load_full(kt + 2);
-            __builtin_amdgcn_sched_barrier(0);
+    }
+    // tile kt sits in buffer 0 and at most two more follow (the last one possibly partial)
+    if (kt + 1 < nk) {
+        load_any(kt + 1);
+        mma_tile(Buf0{});
+        store_any(Buf1{}, kt + 1);
+        __syncthreads();
+        if (kt + 2 < nk) {
+            load_any(kt + 2);
             mma_tile(Buf1{});
-            __builtin_amdgcn_sched_barrier(0);
-            store_full(Buf0{});
+            store_any(Buf0{}, kt + 2);
             __syncthreads();
-        }
-        // tile kt sits in buffer 0 and at most two more follow (the last one possibly partial)
-        if (kt + 1 < nk) {
-            load_any(kt + 1);
-            mma_tile(Buf0{});
-            store_any(Buf1{}, kt + 1);
-            __syncthreads();
-            if (kt + 2 < nk) {
-                load_any(kt + 2);
-                mma_tile(Buf1{});
-                store_any(Buf0{}, kt + 2);
-                __syncthreads();
-                mma_last(Buf0{});
-            } else {
-                mma_last(Buf1{});
-            }
-        } else {
             mma_last(Buf0{});
+        } else {
+            mma_last(Buf1{});
         }
+    } else {
+        mma_last(Buf0{});
     }
 
     // ---- epilogue ----
     double qsum = 0.0, qsum2 = 0.0;
     double *__restrict__ C = (EPI == EPI_QUAD) ? nullptr : g.C + bz * g.sC;
-    double *__restrict__ C2 = (EPI == EPI_DUAL || EPI == EPI_DUAL_INIT || EPI == EPI_GRAD) ? g.C2 + bz * g.sC : nullptr;
+    double *__restrict__ C2 = (EPI == EPI_GRAD) ? g.C2 + bz * g.sC : nullptr;
     double *__restrict__ C3 = (EPI == EPI_GRAD) ? g.C3 + bz * g.sC : nullptr;
     if (EPI == EPI_STORE) {
         // The plain store is the hot epilogue: every VALU instruction here is taken from the MFMAs of the workgroups that
@@ -401,14 +374,6 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f64_kernel(GemmK g) {
                 const double v = acc[i][j][r];
                 if (EPI == EPI_ACCUM) {
                     C[(long)row * g.ldc + col] += g.alpha * v;
-                } else if (EPI == EPI_DUAL) {
-                    const double o = g.alpha * v;
-                    C[(long)row * g.ldc + col] = o;
-                    C2[(long)row * g.ldc + col] += o;
-                } else if (EPI == EPI_DUAL_INIT) {
-                    const double o = g.alpha * v;
-                    C[(long)row * g.ldc + col] = o;
-                    C2[(long)row * g.ldc + col] = o;
                 } else if (EPI == EPI_DIV_D) {
                     C[(long)row * g.ldc + col] = v * g.D[drow + col];
                 } else if (EPI == EPI_GRAD) {
@@ -466,27 +431,25 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const double *__re
     if (threadIdx.x == 0) out[0] = sh[0];
 }
 
-template <int WM, int WN, int FM, int FN, int BK, bool TA, bool TB, int NBUF>
+template <int WM, int WN, int FM, int FN, int BK, bool TA, bool TB>
 static void launch_epi(const GemmK &k, int epi, dim3 grid, hipStream_t s) {
     const dim3 blk(64 * WM * WN);
     switch (epi) {
-        case EPI_STORE: hipLaunchKernelGGL((gemm_f64_kernel<WM, WN, FM, FN, BK, TA, TB, EPI_STORE, NBUF>), grid, blk, 0, s, k); break;
-        case EPI_DIV_D: hipLaunchKernelGGL((gemm_f64_kernel<WM, WN, FM, FN, BK, TA, TB, EPI_DIV_D, NBUF>), grid, blk, 0, s, k); break;
-        case EPI_QUAD: hipLaunchKernelGGL((gemm_f64_kernel<WM, WN, FM, FN, BK, TA, TB, EPI_QUAD, NBUF>), grid, blk, 0, s, k); break;
-        case EPI_ACCUM: hipLaunchKernelGGL((gemm_f64_kernel<WM, WN, FM, FN, BK, TA, TB, EPI_ACCUM, NBUF>), grid, blk, 0, s, k); break;
-        case EPI_DUAL: hipLaunchKernelGGL((gemm_f64_kernel<WM, WN, FM, FN, BK, TA, TB, EPI_DUAL, NBUF>), grid, blk, 0, s, k); break;
-        case EPI_GRAD: hipLaunchKernelGGL((gemm_f64_kernel<WM, WN, FM, FN, BK, TA, TB, EPI_GRAD, NBUF>), grid, blk, 0, s, k); break;
-        case EPI_DUAL_INIT: hipLaunchKernelGGL((gemm_f64_kernel<WM, WN, FM, FN, BK, TA, TB, EPI_DUAL_INIT, NBUF>), grid, blk, 0, s, k); break;
+        case EPI_STORE: hipLaunchKernelGGL((gemm_f64_kernel<WM, WN, FM, FN, BK, TA, TB, EPI_STORE>), grid, blk, 0, s, k); break;
+        case EPI_DIV_D: hipLaunchKernelGGL((gemm_f64_kernel<WM, WN, FM, FN, BK, TA, TB, EPI_DIV_D>), grid, blk, 0, s, k); break;
+        case EPI_QUAD: hipLaunchKernelGGL((gemm_f64_kernel<WM, WN, FM, FN, BK, TA, TB, EPI_QUAD>), grid, blk, 0, s, k); break;
+        case EPI_ACCUM: hipLaunchKernelGGL((gemm_f64_kernel<WM, WN, FM, FN, BK, TA, TB, EPI_ACCUM>), grid, blk, 0, s, k); break;
+        case EPI_GRAD: hipLaunchKernelGGL((gemm_f64_kernel<WM, WN, FM, FN, BK, TA, TB, EPI_GRAD>), grid, blk, 0, s, k); break;
         default: throw HipError{-3, "gemm_f64: bad epilogue"};
     }
 }
 
-template <int WM, int WN, int FM, int FN, int BK, int NBUF = 2>
+template <int WM, int WN, int FM, int FN, int BK>
 static void launch_trans(const GemmK &k, bool ta, bool tb, int epi, dim3 grid, hipStream_t s) {
-    if (!ta && !tb) launch_epi<WM, WN, FM, FN, BK, false, false, NBUF>(k, epi, grid, s);
-    else if (ta && !tb) launch_epi<WM, WN, FM, FN, BK, true, false, NBUF>(k, epi, grid, s);
-    else if (!ta && tb) launch_epi<WM, WN, FM, FN, BK, false, true, NBUF>(k, epi, grid, s);
-    else launch_epi<WM, WN, FM, FN, BK, true, true, NBUF>(k, epi, grid, s);
+    if (!ta && !tb) launch_epi<WM, WN, FM, FN, BK, false, false>(k, epi, grid, s);
+    else if (ta && !tb) launch_epi<WM, WN, FM, FN, BK, true, false>(k, epi, grid, s);
+    else if (!ta && tb) launch_epi<WM, WN, FM, FN, BK, false, true>(k, epi, grid, s);
+    else launch_epi<WM, WN, FM, FN, BK, true, true>(k, epi, grid, s);
 }
 
 void gemm_f64(gpcsd_ctx *c, const GemmDesc &g, hipStream_t s) {
@@ -506,17 +469,15 @@ void gemm_f64(gpcsd_ctx *c, const GemmDesc &g, hipStream_t s) {
 
     // Tile configurations (block tile, waves, K depth).  Large flat GEMMs want many resident workgroups per CU so the
     // hardware dispatcher balances the tail; tiny GEMMs are latency-bound and want deep K tiles.
-    //   1: 128x128, 8 waves, BK16   2: 128x64, 4 waves, BK8    3: 64x64, 4 waves, BK16
-    //   4: 64x64, 4 waves, BK32     5: 32x32, 4 waves, BK64    6: 128x64, 4 waves, BK16
-    //   7: as 3 with a single LDS buffer (5 workgroups per CU)
-    static const int CFG_BM[8] = {0, 128, 128, 64, 64, 32, 128, 64}, CFG_BN[8] = {0, 128, 64, 64, 64, 32, 64, 64};
+    //   1: 128x128, 8 waves, BK16   3: 64x64, 4 waves, BK16   5: 32x32, 4 waves, BK64
+    // (128x64 / BK8 / BK32 / single-LDS-buffer variants were measured and dropped: tools/gemm_sweep.py)
+    static const int CFG_BM[6] = {0, 128, 0, 64, 0, 32}, CFG_BN[6] = {0, 128, 0, 64, 0, 32};
     int cfg = g.cfg;
-    if (cfg <= 0 || cfg > 7) {
+    if (cfg != 1 && cfg != 3 && cfg != 5) {
         auto tiles = [&](int bm, int bn) { return (long)ceil_div(g.M, bm) * ceil_div(g.N, bn) * g.batch; };
         // measured on MI355X (tools/gemm_sweep.py): 64x64 tiles reach the same ~40 TF/s as 128x128 on the large
         // flat GEMMs and balance the tail better; everything smaller is latency-bound and wants 32x32 / BK64
-        static const int big_cfg = getenv("GPCSD_GEMM_BIG_CFG") ? atoi(getenv("GPCSD_GEMM_BIG_CFG")) : 3;   // A/B knob
-        cfg = (tiles(64, 64) >= 512) ? big_cfg : 5;
+        cfg = (tiles(64, 64) >= 512) ? 3 : 5;
     }
     const int bm = CFG_BM[cfg], bn = CFG_BN[cfg];
     const int tm = ceil_div(g.M, bm), tn = ceil_div(g.N, bn);
@@ -538,12 +499,8 @@ void gemm_f64(gpcsd_ctx *c, const GemmDesc &g, hipStream_t s) {
         ProfScope ps(c, g.prof_name, flops, s);
         switch (cfg) {
             case 1: launch_trans<4, 2, 2, 4, 16>(k, g.transA, g.transB, g.epi, grid, s); break;
-            case 2: launch_trans<2, 2, 4, 2, 8>(k, g.transA, g.transB, g.epi, grid, s); break;
             case 3: launch_trans<2, 2, 2, 2, 16>(k, g.transA, g.transB, g.epi, grid, s); break;
-            case 4: launch_trans<2, 2, 2, 2, 32>(k, g.transA, g.transB, g.epi, grid, s); break;
-            case 5: launch_trans<2, 2, 1, 1, 64>(k, g.transA, g.transB, g.epi, grid, s); break;
-            case 7: launch_trans<2, 2, 2, 2, 16, 1>(k, g.transA, g.transB, g.epi, grid, s); break;
-            default: launch_trans<2, 2, 4, 2, 16>(k, g.transA, g.transB, g.epi, grid, s); break;
+            default: launch_trans<2, 2, 1, 1, 64>(k, g.transA, g.transB, g.epi, grid, s); break;
         }
         GP_HIP(hipGetLastError());
     }

@@ -10,8 +10,7 @@ enum Epi : int {
     EPI_DIV_D = 1,   // C = acc * D[(row / rdiv) * ldd + col]   with D = the RECIPROCALS 1/D_xi (k_build_D's Dinv)
     EPI_QUAD = 2,    // no store; partial sums of acc^2 * D[...] (reciprocals; deterministic two-stage reduce)
     EPI_ACCUM = 3,   // C += alpha * acc
-    EPI_DUAL = 4,    // C = alpha*acc and C2 += alpha*acc   (predict: per-component + running sum)
-    EPI_GRAD = 5,    // b = acc * D (reciprocals): C = b, C2 = b*colscale[col], C3 = b*rowscale[row/rdiv]; sums of acc*b and b*b
+    EPI_GRAD = 4,    // b = acc * D (reciprocals): C = b, C2 = b*colscale[col], C3 = b*rowscale[row/rdiv]; sums of acc*b and b*b
     EPI_DUAL_INIT = 6  // C = alpha*acc and C2 = alpha*acc (first term of a running sum: no read, no zero fill)
 };
 
@@ -25,7 +24,7 @@ struct GemmDesc {
     bool transB = false;   // false: B is (K,N) row-major; true: B stored (N,K) row-major
     double *C = nullptr;
     long ldc = 0;
-    double *C2 = nullptr;  // EPI_DUAL, EPI_GRAD
+    double *C2 = nullptr;  // EPI_GRAD
     double *C3 = nullptr;  // EPI_GRAD
     const double *colscale = nullptr, *rowscale = nullptr;   // EPI_GRAD; EPI_STORE: optional C = alpha*acc*colscale[col]
     long sColscale = 0;                                      // batch stride of colscale (EPI_STORE)
@@ -38,7 +37,7 @@ struct GemmDesc {
     long ldd = 0;
     double *quad_out = nullptr;   // EPI_QUAD: one double (EPI_GRAD: two), written by the final reduce
     const int *dyn = nullptr;     // device int per batch entry: effective N = K = dyn[batch] (tiles beyond it exit)
-    int cfg = 0;                  // 0 = choose the tile configuration automatically, 1..6 = force (see gemm_f64.hip)
+    int cfg = 0;                  // 0 = choose the tile configuration automatically, 1 / 3 / 5 = force (see gemm_f64.hip)
     const char *prof_name = "gemm_f64";
 };
 
