@@ -112,19 +112,31 @@ __global__ __launch_bounds__(256) void wy_apply_kernel(WyBatch b) {
         {
             const double *__restrict__ ra = Vp + (long)(16 * wid + fr) * n;
             d4 acc = {0.0, 0.0, 0.0, 0.0};
-            // the panel rows come straight from L2: eight clamped (branch-free) loads in flight ahead of each MFMA run
-            for (int k0 = kstart; k0 < n; k0 += 32) {
-                double a8[8];
+            // the panel rows come straight from L2: batches of eight clamped (branch-free) loads, the NEXT batch issued
+            // before the MFMAs of the current one, so the chain never waits for a full L2 round trip
+            double a8[8], b8[8];
+            auto load8 = [&](double (&dst)[8], int k0) {
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
                     const int k = k0 + 4 * u + fq;
-                    a8[u] = ra[k < n ? k : n - 1];
+                    dst[u] = ra[k < n ? k : n - 1];
                 }
+            };
+            auto mma8 = [&](const double (&src)[8], int k0) {
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
                     const int k = k0 + 4 * u + fq;
                     const double bb = Zs[(k < n ? k : n - 1) * WY_LD + fr];
-                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(k < n ? a8[u] : 0.0, bb, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(k < n ? src[u] : 0.0, bb, acc, 0, 0, 0);
+                }
+            };
+            load8(a8, kstart);
+            for (int k0 = kstart; k0 < n; k0 += 64) {
+                if (k0 + 32 < n) load8(b8, k0 + 32);
+                mma8(a8, k0);
+                if (k0 + 32 < n) {
+                    if (k0 + 64 < n) load8(a8, k0 + 64);
+                    mma8(b8, k0 + 32);
                 }
             }
 #pragma unroll
@@ -145,20 +157,35 @@ __global__ __launch_bounds__(256) void wy_apply_kernel(WyBatch b) {
         }
         __syncthreads();
         // Zc -= V_p^T W2 : rows below the panel's first reflector only
-        for (int fm = (p * WY_NB) / 16 + wid; fm < nfrag; fm += 4) {
-            const int m = 16 * fm + fr;
-            d4 acc = {0.0, 0.0, 0.0, 0.0};
-            const double *__restrict__ vm = Vp + (m < n ? m : n - 1);       // clamped column: rows >= n are never stored
-            double a16[16];
+        {
+            // the sixteen V_p^T loads of the NEXT row fragment are issued before the MFMAs of the current one
+            double a16[16], b16[16];
+            auto loadf = [&](double (&dst)[16], int fm) {
+                const int m = 16 * fm + fr;
+                const double *__restrict__ vm = Vp + (m < n ? m : n - 1);   // clamped column: rows >= n are never stored
 #pragma unroll
-            for (int u = 0; u < 16; ++u) a16[u] = vm[(long)(4 * u + fq) * n];
+                for (int u = 0; u < 16; ++u) dst[u] = vm[(long)(4 * u + fq) * n];
+            };
+            auto applyf = [&](const double (&src)[16], int fm) {
+                d4 acc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-            for (int u = 0; u < 16; ++u)
-                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a16[u], W2[(4 * u + fq) * WY_LD + fr], acc, 0, 0, 0);
+                for (int u = 0; u < 16; ++u)
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(src[u], W2[(4 * u + fq) * WY_LD + fr], acc, 0, 0, 0);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = 16 * fm + fq + 4 * r;
-                if (row < n) Zs[row * WY_LD + fr] -= acc[r];
+                for (int r = 0; r < 4; ++r) {
+                    const int row = 16 * fm + fq + 4 * r;
+                    if (row < n) Zs[row * WY_LD + fr] -= acc[r];
+                }
+            };
+            int fm = (p * WY_NB) / 16 + wid;
+            if (fm < nfrag) loadf(a16, fm);
+            for (; fm < nfrag; fm += 8) {
+                if (fm + 4 < nfrag) loadf(b16, fm + 4);
+                applyf(a16, fm);
+                if (fm + 4 < nfrag) {
+                    if (fm + 8 < nfrag) loadf(a16, fm + 8);
+                    applyf(b16, fm + 4);
+                }
             }
         }
         __syncthreads();
