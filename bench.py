@@ -141,7 +141,23 @@ def cpu_baseline(w, m, lfp_sample):
         t_ll += t1 - t0
         t_pr += t2 - t1
         reps += 1
+    # the reference projects trial by trial on strided slices lfp[:, :, r] (gpcsd2d.py:147-148); the oracle above uses
+    # contiguous trials and one batched matmul ("fair" flavour).  Price the reference's access pattern too.
+    nxs = lfp_sample.shape[0]
+    Ks = O.spatial_kphi(geom, hp) + hp["jitter"] * np.eye(nxs)
+    Kt = O.temporal_sum(hp["temporal"], geom.t)
+    Qs, Qt, _ = O.eig_D(Ks, Kt, hp["sig2n"])
+    ts = time.perf_counter()
+    for r in range(min(2, Rs)):
+        np.dot(np.dot(Qs.T, lfp_sample[:, :, r]), Qt)
+    strided_ms = (time.perf_counter() - ts) * 1e3 / min(2, Rs)
+    Yc = np.ascontiguousarray(np.moveaxis(lfp_sample, 2, 0))
+    ts = time.perf_counter()
+    for r in range(min(2, Rs)):
+        np.dot(np.dot(Qs.T, Yc[r]), Qt)
+    contiguous_ms = (time.perf_counter() - ts) * 1e3 / min(2, Rs)
     return {"value": Rs * reps / (t_ll + t_pr), "unit": "trials/s", "cores": int(cores), "kind": "port",
+            "projection_ms_per_trial_reference_layout": strided_ms, "projection_ms_per_trial_contiguous": contiguous_ms,
             "sample": "%d trials x %d reps of oracle loglik+predict(csd) at the bench geometry (NumPy %s, BLAS threads=%d)"
                       % (Rs, reps, np.__version__, cores),
             "loglik_evals_per_sec": reps / t_ll, "predict_trials_per_sec": Rs * reps / t_pr}, ll
