@@ -171,3 +171,48 @@ def test_fit_restart_sharding_world2():
     for rank, best, nll in res:
         assert np.allclose(best, seq.best, rtol=0, atol=1e-12)
         assert np.allclose(nll, seq.fit_nll_values_, rtol=0, atol=1e-12)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the same sharding layer over the HIP path: two ranks share the one GPU of the test box (gloo for the tiny collectives)
+# ---------------------------------------------------------------------------------------------------------------------
+def _gpu_shard_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["GPCSD_DEVICE"] = "0"
+    import torch.distributed as td
+    td.init_process_group("gloo", rank=rank, world_size=world)
+    from gpcsd_amd.dist import TrialSharding
+    import test_hip_parity as T
+    m, c, g, geom, hp, lfp = T._build_model("1d_odd_17x37x5")
+    m.shard_trials(TrialSharding(gather_predictions=True))
+    ll = float(m.loglik())
+    ll2, grad = m._loglik_and_grad_natural()
+    m.predict(c["x"], c["t"], type="csd")
+    perr = float(np.max(np.abs(m.csd_pred - g["csd_pred"])) / np.max(np.abs(g["csd_pred"])))
+    q.put((rank, ll, float(ll2), np.asarray(grad).tolist(), tuple(m.csd_pred.shape), perr, float(g["loglik"])))
+    td.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(300)
+def test_hip_path_trial_sharding_world2_one_gpu():
+    """model.shard_trials over the HIP path: each rank evaluates its block of trials on the GPU, the partial sums are
+    all-reduced, predictions gathered; every rank reproduces the reference's loglik / posterior mean of the full data."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_gpu_shard_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=240) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+    for rank, ll, ll2, grad, shape, perr, ll_ref in res:
+        assert abs(ll - ll_ref) / abs(ll_ref) < 1e-6
+        assert abs(ll2 - ll_ref) / abs(ll_ref) < 1e-6
+        assert shape[2] == 5 and perr < 1e-6
+    assert np.allclose(res[0][3], res[1][3], rtol=1e-12, atol=0)      # the reduced gradient is identical on both ranks
