@@ -7,7 +7,8 @@ import threading
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libgpcsd_hip.so")
+# GPCSD_LIB_PATH: developer knob for A/B timing of two builds in one session (tools/ab_bench.py); the default is the in-tree build
+LIB_PATH = os.environ.get("GPCSD_LIB_PATH") or os.path.join(_HERE, "libgpcsd_hip.so")
 
 MAX_TEMPORAL = 8
 KIND_SE, KIND_MATERN = 0, 1

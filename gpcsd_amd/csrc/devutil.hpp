@@ -8,6 +8,14 @@ constexpr int EIG_MAXN = 1024;                       // LDS vectors of the eigen
 constexpr int MAX_BATCH = 4;                         // independent eigenproblems sharing launches
 constexpr double EPS_U = 1.1102230246251565e-16;     // unit roundoff (LAPACK dlamch('E'))
 
+// reciprocal to ~2 ulp: hardware seed + two Newton steps (5 dependent operations instead of the ~12 of an IEEE division)
+__device__ __forceinline__ double fast_rcp(double x) {
+    double r = __builtin_amdgcn_rcp(x);
+    r = fma(fma(-x, r, 1.0), r, r);
+    r = fma(fma(-x, r, 1.0), r, r);
+    return r;
+}
+
 // Wave-wide reductions, result valid in every lane.  __shfl_xor on a double compiles to two ds_bpermute_b32 per stage
 // (12 LDS-crossbar round trips per reduction, ~600 cycles); the DPP forms below stay in the VALU: four v_mov_dpp
 // stages fold each 16-lane row, then the four row totals are combined through v_readlane (8x fewer cycles, same

@@ -723,14 +723,8 @@ __global__ __launch_bounds__(256) void dc_colnorm_U_kernel(DcLevel L, int norm_b
 // fused level kernel for small merges (N <= DC_SMALL): one workgroup walks every phase of its merge
 // ------------------------------------------------------------------------------------------------------------------
 // ---- helpers of the fused kernel: everything between the deflation scan and the placement stays in LDS / registers.
-// Reciprocal to ~2 ulp (v_rcp_f64 + two Newton steps, 5 instructions instead of the ~35 of an IEEE division); used where
+// fast_rcp (devutil.hpp: v_rcp_f64 + two Newton steps, 5 instructions instead of the ~35 of an IEEE division) is used where
 // the result feeds a sum whose rounding error is of the same order anyway.
-__device__ __forceinline__ double fast_rcp(double x) {
-    double r = __builtin_amdgcn_rcp(x);
-    r = fma(fma(-x, r, 1.0), r, r);
-    r = fma(fma(-x, r, 1.0), r, r);
-    return r;
-}
 // sum / product over the 8 lanes of an aligned lane octet (two quads), result in all 8 lanes
 __device__ __forceinline__ double oct_sum(double v) {
     v += dpp_mov<0xB1>(v);

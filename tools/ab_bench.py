@@ -1,0 +1,22 @@
+"""A/B timing of two builds of libgpcsd_hip.so on the SAME box, interleaved (run-to-run and box-to-box variation of the
+bench step is ~1.5 %, more than most single kernel changes).  python tools/ab_bench.py base.so new.so [rounds] [steps]"""
+import json, os, subprocess, sys
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+libs = [os.path.abspath(sys.argv[1]), os.path.abspath(sys.argv[2])]
+rounds = int(sys.argv[3]) if len(sys.argv) > 3 else 4
+steps = sys.argv[4] if len(sys.argv) > 4 else "40"
+res = {l: [] for l in libs}
+for r in range(rounds):
+    for l in libs:
+        env = dict(os.environ, GPCSD_LIB_PATH=l)
+        out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--no-cpu-baseline", "--steps", steps, "--warmup", "5"],
+                             env=env, capture_output=True, text=True)
+        if out.returncode != 0:
+            print(out.stderr[-2000:])
+            sys.exit(1)
+        d = json.loads(out.stdout.strip().splitlines()[-1])
+        res[l].append(d["ms_per_step"])
+        print(r, os.path.basename(l), "%.4f ms/step" % d["ms_per_step"], flush=True)
+for l in libs:
+    v = sorted(res[l])
+    print(os.path.basename(l), "min %.4f median %.4f" % (v[0], v[len(v) // 2]))
