@@ -74,6 +74,7 @@ SIGNATURES = {
     "gpcsd_predict_resident": (_I, [_P, ctypes.POINTER(HParams), _DP, _I, _DP, _I, _I, _I]),
     "gpcsd_fetch": (_I, [_P, ctypes.c_char_p, _DP, _L]),
     "gpcsd_sample_prior": (_I, [_P, ctypes.POINTER(HParams), _I, _DP, _I, _DP]),
+    "gpcsd_fold_gemm": (_I, [_P, _I, ctypes.POINTER(_L)]),
     "gpcsd_prof_enable": (_I, [_P, _I]),
     "gpcsd_prof_reset": (_I, [_P]),
     "gpcsd_prof_get": (_I, [_P, ctypes.c_char_p, _DP, ctypes.POINTER(_L), _DP]),
@@ -412,6 +413,12 @@ class Context:
     # ---- measurement ----
     def synchronize(self):
         self._check(self._lib.gpcsd_device_synchronize(self._h))
+
+    def fold_gemm(self, on=None):
+        """Switch (True/False) or query (None) the folded-basis GEMM path; returns the number of folded calls so far."""
+        n = _L(0)
+        self._check(self._lib.gpcsd_fold_gemm(self._h, -1 if on is None else int(bool(on)), ctypes.byref(n)))
+        return int(n.value)
 
     def prof_enable(self, on=True):
         self._check(self._lib.gpcsd_prof_enable(self._h, int(bool(on))))

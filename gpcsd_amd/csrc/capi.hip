@@ -277,6 +277,8 @@ EigState front_half(gpcsd_ctx *c, const gpcsd_hparams *hp, double jitter) {
         build_kt(c, hp, t, nt, t, nt, Kt, s);
         // the symmetries come from the resident geometry / time grid, so they hold for the Grams built from them
         eig_pair_D(c, Ks, nx, Kt, nt, d_sig, hp->n_sig2n, e.Qs, e.es, e.Qt, e.et, e.D, e.Dinv, e.scal, e.status, sym_s, sym_t);
+        e.d_sig = d_sig;
+        e.nsig = hp->n_sig2n;
         return e;
     }
     // The temporal chain is the critical path: it is queued first, before any upload of this call.  It needs nothing
@@ -305,11 +307,61 @@ EigState front_half(gpcsd_ctx *c, const gpcsd_hparams *hp, double jitter) {
     return e;
 }
 
-// Main stream waits for the temporal chain; then D and sum(log D).  No-op after the single-stream front half.
-void join_temporal(gpcsd_ctx *c, EigState &e) {
-    if (!e.pending) return;
-    GP_HIP(hipStreamWaitEvent(c->stream, c->ev_join, 0));
-    k_build_D(c, e.es, c->nx, e.et, c->nt, e.d_sig, e.nsig, e.D, e.Dinv, e.scal, c->stream);
+// ---- folded-basis GEMMs -------------------------------------------------------------------------------------------
+// When both Gram matrices were decomposed through their reflection symmetry (eigh.hip, symmetry folding), the half-size
+// eigenvector blocks Us/Ua, Vs/Va are all the flat GEMMs need: with F = fold operator (orthogonal), Qs = Fs^T diag(Us, Ua) Pi
+// (Pi = the rank merge of the two spectra), so
+//     Qs^T Y Qt = Pi_s^T [diag(Us,Ua)^T (Fs Y Ft^T) diag(Vs,Va)] Pi_t ,
+// and loglik / predict only ever need sums over all (x', i') pairs or products in which Pi cancels.  The data is folded
+// once per geometry (Fs Y Ft^T, one HBM pass), every projection becomes two half-size GEMMs (half the flops), D is built
+// from the spectra in fold order.  Needs a scalar noise variance: a per-electrode list is indexed by eigen-RANK in the
+// reference, which only the merged order provides.  GPCSD_NO_FOLD_GEMM=1 switches it off (A/B, tests).
+struct FoldMode {
+    bool on = false;
+    FoldView fs, ft;
+};
+
+static FoldMode fold_mode(gpcsd_ctx *c, const gpcsd_hparams *hp) {
+    static const bool off = getenv("GPCSD_NO_FOLD_GEMM") && getenv("GPCSD_NO_FOLD_GEMM")[0] == '1';
+    FoldMode fm;
+    if (off || !c->fold_gemm_on || hp->n_sig2n != 1 || c->sym_s.ns == 0 || c->sym_t.ns == 0) return fm;
+    fm.fs = eigh_fold_view(c, 0, &c->sym_s, c->nx);
+    fm.ft = eigh_fold_view(c, 1, &c->sym_t, c->nt);
+    fm.on = fm.fs.on && fm.ft.on;
+    return fm;
+}
+
+// Fs Y Ft^T in the layout of the resident data ([fold x][r][fold t]); rebuilt when data, geometry or time grid change
+static const double *folded_lfp(gpcsd_ctx *c) {
+    double *Yf = c->buf<double>("lfp_fold", (size_t)c->nx * c->ntrials * c->nt);
+    if (!c->lfp_fold_valid) {
+        k_fold_lfp(c, c->d_lfp, c->nx, c->ntrials, c->nt, c->sym_s, c->sym_t, Yf, c->stream);
+        c->lfp_fold_valid = true;
+    }
+    return Yf;
+}
+
+// out[p-block rows] = U_p^T in[p-block rows] for p = symmetric, antisymmetric: the spatial projection in the folded basis
+static void fold_proj_spatial(gpcsd_ctx *c, const FoldView &fs, const double *in, double *out, long ncols, hipStream_t s) {
+    for (int p = 0; p < 2; ++p) {
+        const int np = p ? fs.na : fs.ns;
+        const long r0 = p ? fs.ns : 0;
+        GemmDesc g;
+        g.M = np; g.N = (int)ncols; g.K = np;
+        g.A = fs.U + (p ? (size_t)fs.ns * fs.ns : 0); g.lda = np; g.transA = true;
+        g.B = in + r0 * ncols; g.ldb = ncols;
+        g.C = out + r0 * ncols; g.ldc = ncols;
+        g.prof_name = "gemm_proj_spatial";
+        gemm_f64(c, g, s);
+    }
+}
+
+// Main stream waits for the temporal chain; then D and sum(log D) -- from the spectra in fold order when fm is on.
+// No-op after the single-stream front half unless the fold order is asked for.
+void join_temporal(gpcsd_ctx *c, EigState &e, const FoldMode *fm = nullptr) {
+    if (e.pending) GP_HIP(hipStreamWaitEvent(c->stream, c->ev_join, 0));
+    if (fm && fm->on) k_build_D(c, fm->fs.w, c->nx, fm->ft.w, c->nt, e.d_sig, e.nsig, e.D, e.Dinv, e.scal, c->stream);
+    else if (e.pending) k_build_D(c, e.es, c->nx, e.et, c->nt, e.d_sig, e.nsig, e.D, e.Dinv, e.scal, c->stream);
     e.pending = false;
 }
 
@@ -437,6 +489,7 @@ extern "C" int gpcsd_set_lfp(gpcsd_ctx *c, const double *lfp, int nx, int nt, in
     k_swap_last2(c, stage, c->d_lfp, nx, nt, ntrials, c->stream);     // (x,t,r) -> (x,r,t)
     c->sync();
     c->nx = nx; c->nt = nt; c->ntrials = ntrials;
+    c->lfp_fold_valid = false;
     return 0;
     GP_API_END(c)
 }
@@ -451,10 +504,16 @@ extern "C" int gpcsd_set_geometry_1d(gpcsd_ctx *c, const double *x, int nx, cons
     c->dim = 1; c->geo_nx = nx; c->ngl1 = ngl; c->ngl2 = 0;
     // electrodes mirror-symmetric about the centre of a symmetric quadrature rule -> Ks commutes with the reflection
     c->sym_s = SymDev();
+    c->sym_z = SymDev();
+    c->sym_z_pts.clear();
+    c->lfp_fold_valid = false;
+    c->geo_host.assign(x, x + nx);
     double ctr;
     if (rule_is_symmetric(gl_x, gl_w, ngl, &ctr)) {
         const bool refl[1] = {true};
         c->sym_s = find_symmetry(c, "sym_s_tbl", x, nx, 1, &ctr, refl);
+        c->sym_s_ctr[0] = ctr;
+        c->sym_s_refl[0] = true;
     }
     return 0;
     GP_API_END(c)
@@ -474,12 +533,18 @@ extern "C" int gpcsd_set_geometry_2d(gpcsd_ctx *c, const double *xy, int nx, con
     // reflections about the centre of the (symmetric) tensor quadrature rule that map the electrode set onto itself:
     // point reflection first (the Neuropixels checkerboard has it), then single-axis mirrors
     c->sym_s = SymDev();
+    c->sym_z = SymDev();
+    c->sym_z_pts.clear();
+    c->lfp_fold_valid = false;
+    c->geo_host.assign(xy, xy + (size_t)nx * 2);
     double ctr[2];
     const bool s1 = rule_is_symmetric(gl_x1, gl_w1, ngl1, &ctr[0]), s2 = rule_is_symmetric(gl_x2, gl_w2, ngl2, &ctr[1]);
     const bool cand[3][2] = {{true, true}, {false, true}, {true, false}};
     for (int k = 0; k < 3 && c->sym_s.ns == 0; ++k) {
         if ((cand[k][0] && !s1) || (cand[k][1] && !s2)) continue;
         c->sym_s = find_symmetry(c, "sym_s_tbl", xy, nx, 2, ctr, cand[k]);
+        c->sym_s_ctr[0] = ctr[0]; c->sym_s_ctr[1] = ctr[1];
+        c->sym_s_refl[0] = cand[k][0]; c->sym_s_refl[1] = cand[k][1];
     }
     return 0;
     GP_API_END(c)
@@ -491,6 +556,8 @@ extern "C" int gpcsd_set_time(gpcsd_ctx *c, const double *t, int nt) {
     c->upload<double>("time_t", t, nt);
     c->sync();
     c->time_nt = nt;
+    c->time_host.assign(t, t + nt);
+    c->lfp_fold_valid = false;
     // a time grid symmetric about its midpoint (any uniform grid) makes every stationary Kt centro-symmetric
     double lo = t[0], hi = t[0];
     for (int i = 1; i < nt; ++i) {
@@ -908,16 +975,48 @@ extern "C" int gpcsd_loglik_dense_chol(gpcsd_ctx *c, const double *Ks, int nx, c
     GP_API_END(c)
 }
 
+extern "C" int gpcsd_fold_gemm(gpcsd_ctx *c, int on, long *calls) {
+    GP_API_BEGIN(c)
+    if (on >= 0) c->fold_gemm_on = on != 0;
+    if (calls) *calls = c->fold_gemm_calls;
+    return 0;
+    GP_API_END(c)
+}
+
 // ------------------------------------------------------------------------------------------------
 // fused hot calls
 // ------------------------------------------------------------------------------------------------
 extern "C" int gpcsd_loglik_parts(gpcsd_ctx *c, const gpcsd_hparams *hp, double *out2) {
     GP_API_BEGIN(c)
     GP_REQUIRE(out2 != nullptr, -3, "null output");
+    GP_REQUIRE(c->d_lfp != nullptr, -4, "lfp not set (call gpcsd_set_lfp)");
+    const FoldMode fm = fold_mode(c, hp);                           // before the front half: first use allocates
+    const double *Yf = fm.on ? folded_lfp(c) : nullptr;
     EigState e = front_half(c, hp, hp->jitter);
     const int nx = c->nx, nt = c->nt, R = c->ntrials;
     hipStream_t s = c->stream;
     double *W = c->buf<double>("proj_W", (size_t)nx * R * nt);
+    if (fm.on) {
+        // the same two projections in the folded basis: 2 + 2 half-size GEMMs, the quadratic form as two partial sums
+        ++c->fold_gemm_calls;
+        fold_proj_spatial(c, fm.fs, Yf, W, (long)R * nt, s);
+        join_temporal(c, e, &fm);
+        for (int p = 0; p < 2; ++p) {
+            const int np = p ? fm.ft.na : fm.ft.ns, c0 = p ? fm.ft.ns : 0;
+            GemmDesc g2;
+            g2.M = nx * R; g2.N = np; g2.K = np;
+            g2.A = W + c0; g2.lda = nt;
+            g2.B = fm.ft.U + (p ? (size_t)fm.ft.ns * fm.ft.ns : 0); g2.ldb = np;
+            g2.epi = EPI_QUAD; g2.D = e.Dinv + c0; g2.rdiv = R; g2.ldd = nt; g2.quad_out = e.scal + 1 + p;
+            g2.prof_name = "gemm_proj_temporal_quad";
+            gemm_f64(c, g2, s);
+        }
+        double h3[3] = {0.0, 0.0, 0.0};
+        const int rc = finish_call(c, e, h3, 3);
+        out2[0] = h3[0];
+        out2[1] = h3[1] + h3[2];
+        return rc;
+    }
     GemmDesc g1;                          // W[x'][(r,t)] = sum_x Qs[x][x'] Y[x][(r,t)]        (gpcsd1d.py:125 inner dot)
     g1.M = nx; g1.N = R * nt; g1.K = nx;
     g1.A = e.Qs; g1.lda = nx; g1.transA = true;
@@ -946,6 +1045,116 @@ extern "C" int gpcsd_loglik(gpcsd_ctx *c, const gpcsd_hparams *hp, double *out) 
     return rc;
 }
 
+// Reflection symmetry of the prediction sites under the SAME reflection as the electrodes (then the cross-covariances
+// commute with the pair of involutions and fold as well).  Cached on the site coordinates; ns == 0: none.
+static const SymDev &site_symmetry(gpcsd_ctx *c, const double *z, int nz, int dim) {
+    const size_t cnt = (size_t)nz * dim;
+    if (c->sym_z_pts.size() == cnt && memcmp(c->sym_z_pts.data(), z, cnt * sizeof(double)) == 0) return c->sym_z;
+    c->sym_z_pts.assign(z, z + cnt);
+    if (c->geo_host.size() == cnt && memcmp(c->geo_host.data(), z, cnt * sizeof(double)) == 0) c->sym_z = c->sym_s;
+    else c->sym_z = find_symmetry(c, "sym_z_tbl", z, nz, dim, c->sym_s_ctr, c->sym_s_refl);
+    return c->sym_z;
+}
+
+// predict_impl in the folded basis (see FoldMode).  Prediction sites and times must share the symmetry of the grids:
+//   out_c = Fz^T [ diag_p( (Kc_pp^T U_p) ) Bm~ diag_q( V_q^T Kt*_c,qq ) ] Ft   with Bm~ = (diag(U)^T Y~ diag(V)) / D~ ,
+// every flat GEMM split in its two parity blocks; the last pass unfolds sites and times while it transposes.
+static int predict_fold(gpcsd_ctx *c, const gpcsd_hparams *hp, EigState &e, const FoldMode &fm, const double *Yf, const SymDev &sz,
+                        const double *dz, int nz, const double *dts, int type, bool want_lists) {
+    const Geo g = resident_geo(c);
+    const int nx = c->nx, nt = c->nt, R = c->ntrials, C = hp->n_temporal;
+    const long RT = (long)R * nt;
+    const int ns = fm.fs.ns, na = fm.fs.na, nts = fm.ft.ns, nta = fm.ft.na, nzs = sz.ns, nza = sz.na;
+    hipStream_t s = c->stream;
+    double *W = c->buf<double>("proj_W", (size_t)nx * RT);
+    double *Bm = c->buf<double>("pred_B", (size_t)nx * RT);
+    const double *t = (const double *)c->bufs["time_t"].p;
+    double *Kc = c->buf<double>("pred_Kcross", (size_t)nx * nz);
+    double *Kcf = c->buf<double>("pred_Kcross_fold", (size_t)ns * nzs + (size_t)na * nza);
+    double *S = c->buf<double>("pred_S", (size_t)nz * RT);
+    double *comp = c->buf<double>("pred_comp", (size_t)C * nz * RT);
+    double *Kts = c->buf<double>("pred_Ktstar", (size_t)C * nt * nt);
+    const size_t ktf_sz = (size_t)nts * nts + (size_t)nta * nta;
+    double *Ktf = c->buf<double>("pred_Ktstar_fold", (size_t)C * ktf_sz);
+    const size_t m1_sz = (size_t)nzs * ns + (size_t)nza * na;
+    double *M1 = c->buf<double>("pred_M1", 2 * std::max(m1_sz, (size_t)nz * nx));
+    double *Pc = c->buf<double>("pred_Pc", std::max((size_t)C * ktf_sz, (size_t)C * nt * nt));
+    const size_t out_elems = (size_t)nz * RT;
+    ++c->fold_gemm_calls;
+    fold_proj_spatial(c, fm.fs, Yf, W, RT, s);                      // W~ = diag(U)^T Y~
+    // everything that needs only the spatial eigenvectors runs beside the temporal eigensolver
+    for (int which = 1; which <= 2; ++which) {
+        if (!(type & which)) continue;
+        if (which == 1) build_kphig(c, g, hp->R, hp->eps, hp->ell_s, dz, nz, Kc, s);        // gpcsd1d.py:273
+        else build_kphi(c, g, hp->R, hp->eps, hp->ell_s, dz, nz, 0.0, Kc, s);               // gpcsd1d.py:275
+        k_sym_fold_rect(c, Kc, nz, c->sym_s, sz, Kcf, Kcf + (size_t)ns * nzs, s);
+        for (int p = 0; p < 2; ++p) {
+            const int np = p ? na : ns, nzp = p ? nza : nzs;
+            GemmDesc gm;                  // M1_p[zq][x'] = sum_xq Kc~_pp[xq][zq] U_p[xq][x']
+            gm.M = nzp; gm.N = np; gm.K = np;
+            gm.A = Kcf + (p ? (size_t)ns * nzs : 0); gm.lda = nzp; gm.transA = true;
+            gm.B = fm.fs.U + (p ? (size_t)ns * ns : 0); gm.ldb = np;
+            gm.C = M1 + (size_t)(which - 1) * m1_sz + (p ? (size_t)nzs * ns : 0); gm.ldc = np;
+            gm.prof_name = "gemm_pred_M1";
+            gemm_f64(c, gm, s);
+        }
+    }
+    for (int cc = 0; cc < C; ++cc) {
+        k_temporal_gram(c, 1, &hp->kind[cc], &hp->ell_t[cc], &hp->sigma2_t[cc], dts, nt, t, nt, Kts + (size_t)cc * nt * nt, s);
+        k_sym_fold_rect(c, Kts + (size_t)cc * nt * nt, nt, c->sym_t, c->sym_t, Ktf + cc * ktf_sz,
+                        Ktf + cc * ktf_sz + (size_t)nts * nts, s);
+    }
+    join_temporal(c, e, &fm);
+    for (int p = 0; p < 2; ++p) {
+        const int np = p ? nta : nts, c0 = p ? nts : 0;
+        GemmDesc g2;                      // Bm~[:, p block] = (W~[:, p block] V_p) / D~
+        g2.M = nx * R; g2.N = np; g2.K = np;
+        g2.A = W + c0; g2.lda = nt;
+        g2.B = fm.ft.U + (p ? (size_t)nts * nts : 0); g2.ldb = np;
+        g2.C = Bm + c0; g2.ldc = nt;
+        g2.epi = EPI_DIV_D; g2.D = e.Dinv + c0; g2.rdiv = R; g2.ldd = nt;
+        g2.prof_name = "gemm_pred_temporal_div";
+        gemm_f64(c, g2, s);
+        for (int cc = 0; cc < C; ++cc) {
+            GemmDesc gp;                  // Pcat_p[i'][cc*np + b] = sum_j V_p[j][i'] Kt*~_cc,pp[j][b]
+            gp.M = np; gp.N = np; gp.K = np;
+            gp.A = fm.ft.U + (p ? (size_t)nts * nts : 0); gp.lda = np; gp.transA = true;
+            gp.B = Ktf + cc * ktf_sz + (p ? (size_t)nts * nts : 0); gp.ldb = np;
+            gp.C = Pc + (p ? (size_t)C * nts * nts : 0) + (size_t)cc * np; gp.ldc = (long)C * np;
+            gp.prof_name = "gemm_pred_Pc";
+            gemm_f64(c, gp, s);
+        }
+    }
+    for (int which = 1; which <= 2; ++which) {
+        if (!(type & which)) continue;
+        double *o_sum = c->buf<double>(which == 1 ? "pred_out_csd" : "pred_out_lfp", out_elems);
+        double *o_list = want_lists ? c->buf<double>(which == 1 ? "pred_out_csd_list" : "pred_out_lfp_list", out_elems * C)
+                                    : nullptr;
+        for (int p = 0; p < 2; ++p) {
+            const int np = p ? na : ns, nzp = p ? nza : nzs;
+            GemmDesc g5;                  // S~[p rows] = M1_p Bm~[p rows]
+            g5.M = nzp; g5.N = (int)RT; g5.K = np;
+            g5.A = M1 + (size_t)(which - 1) * m1_sz + (p ? (size_t)nzs * ns : 0); g5.lda = np;
+            g5.B = Bm + (p ? (size_t)ns * RT : 0); g5.ldb = RT;
+            g5.C = S + (p ? (size_t)nzs * RT : 0); g5.ldc = RT;
+            g5.prof_name = "gemm_pred_cross";
+            gemm_f64(c, g5, s);
+        }
+        for (int p = 0; p < 2; ++p) {
+            const int np = p ? nta : nts, c0 = p ? nts : 0;
+            GemmDesc g6;                  // comp~[(zq, r)][p][cc][b] = sum_i' S~[(zq, r)][p block i'] Pcat_p[i'][cc*np + b]
+            g6.M = nz * R; g6.N = C * np; g6.K = np;
+            g6.A = S + c0; g6.lda = nt;
+            g6.B = Pc + (p ? (size_t)C * nts * nts : 0); g6.ldb = (long)C * np;
+            g6.C = comp + (p ? (size_t)C * nts : 0); g6.ldc = (long)C * nt;
+            g6.prof_name = "gemm_pred_tstar";
+            gemm_f64(c, g6, s);
+        }
+        k_unfold_swap_sum(c, comp, C, o_list, (long)out_elems, o_sum, R, nt, sz, c->sym_t, s);
+    }
+    return finish_call(c, e, nullptr, 0);
+}
+
 // Posterior mean into ctx-owned device buffers, already in the reference's output layout (z, t, trial):
 //   pred_out_csd / pred_out_lfp            (nz, ntstar, R)
 //   pred_out_csd_list / pred_out_lfp_list  (C, nz, ntstar, R)     when want_lists
@@ -956,6 +1165,20 @@ static int predict_impl(gpcsd_ctx *c, const gpcsd_hparams *hp, const double *z, 
     GP_REQUIRE(c->nt > 0 && ntstar == c->nt, -22,
                "predict: len(t)=%d must equal the training nt=%d (the reference's reshape raises ValueError, gpcsd1d.py:279)",
                ntstar, c->nt);
+    GP_REQUIRE(c->d_lfp != nullptr, -4, "lfp not set (call gpcsd_set_lfp)");
+    // folded basis when the grids, the prediction sites and the prediction times all share the reflection symmetries
+    const FoldMode fm = fold_mode(c, hp);
+    if (fm.on && ntstar == c->nt && (int)c->time_host.size() == c->nt &&
+        memcmp(c->time_host.data(), tstar, (size_t)ntstar * sizeof(double)) == 0) {
+        const SymDev &sz = site_symmetry(c, z, nz, c->dim);
+        if (sz.ns > 0 && sz.ns + sz.na == nz) {
+            const double *Yf = folded_lfp(c);
+            double *dzf = c->upload_cached<double>("pred_z", z, (size_t)nz * c->dim);
+            double *dtf = c->upload_cached<double>("pred_tstar", tstar, ntstar);
+            EigState ef = front_half(c, hp, 0.0);  // no jitter in predict (gpcsd1d.py:258)
+            return predict_fold(c, hp, ef, fm, Yf, sz, dzf, nz, dtf, type, want_lists);
+        }
+    }
     EigState e = front_half(c, hp, 0.0);           // no jitter in predict (gpcsd1d.py:258)
     const Geo g = resident_geo(c);
     const int nx = c->nx, nt = c->nt, R = c->ntrials, C = hp->n_temporal;

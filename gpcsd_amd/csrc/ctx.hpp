@@ -105,6 +105,16 @@ struct gpcsd_ctx {
     int time_nt = 0;
     double *d_lfp = nullptr;                // [x][r][t]
     gpcsd::SymDev sym_s, sym_t;             // reflection symmetry of the electrode / time grids (ns == 0: none found)
+    // folded-basis GEMMs (capi.hip): what the electrode symmetry reflects about, host copies of the grids to recognise
+    // prediction sites / times with the same symmetry, the symmetry of the last prediction sites, and whether the
+    // resident data has been folded for the current geometry
+    double sym_s_ctr[2] = {0.0, 0.0};
+    bool sym_s_refl[2] = {false, false};
+    std::vector<double> geo_host, time_host, sym_z_pts;
+    gpcsd::SymDev sym_z;
+    bool lfp_fold_valid = false;
+    bool fold_gemm_on = true;               // gpcsd_fold_gemm()
+    long fold_gemm_calls = 0;
 
     // ---- device buffers: grow-only, keyed by name, freed in destroy ----
     template <typename T = double>

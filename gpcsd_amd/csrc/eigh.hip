@@ -146,6 +146,25 @@ __global__ __launch_bounds__(256) void sym_unfold_kernel(int n, SymDev sy, const
 // ------------------------------------------------------------------------------------------------------------------
 // drivers
 // ------------------------------------------------------------------------------------------------------------------
+static bool fold_applies(const SymDev *sy, int n) {
+    return sy && sy->ns > 0 && sy->ns + sy->na == n && n > JACOBI_LDS_MAX && symfold_enabled() && !force_jacobi();
+}
+
+// The half-size spectra and eigenvectors of problem `slot` (0: first / spatial, 1: second / temporal) of eigh_pair_device,
+// in FOLD order: w = (ws | wa), U = (Us (ns x ns) | Ua (na x na)), eigenvectors in columns.  The same predicate and buffers
+// as the solver itself uses, so callers that stay in the folded basis (capi.hip) read what the last solve left there.
+FoldView eigh_fold_view(gpcsd_ctx *c, int slot, const SymDev *sy, int n) {
+    FoldView v;
+    if (!fold_applies(sy, n)) return v;
+    const std::string T = std::string("fold_p") + (slot ? "1" : "0") + "_";
+    v.on = true;
+    v.ns = sy->ns;
+    v.na = sy->na;
+    v.w = c->buf<double>(T + "w", n);
+    v.U = c->buf<double>(T + "U", (size_t)v.ns * v.ns + (size_t)v.na * v.na);
+    return v;
+}
+
 static void eigh_pair_enqueue(gpcsd_ctx *c, double *A0, int n0, double *w0, double *Z0, const SymDev *sym0, double *A1, int n1,
                               double *w1, double *Z1, const SymDev *sym1, int *d_status, hipStream_t s) {
     double *A[2] = {A0, A1}, *w[2] = {w0, w1}, *Z[2] = {Z0, Z1};
@@ -173,15 +192,16 @@ static void eigh_pair_enqueue(gpcsd_ctx *c, double *A0, int n0, double *w0, doub
     for (int p = 0; p < 2; ++p) {
         if (n[p] <= 0) continue;
         const SymDev *sy = sym[p];
-        if (sy && sy->ns > 0 && sy->ns + sy->na == n[p] && n[p] > JACOBI_LDS_MAX && symfold_enabled() && !force_jacobi()) {
+        if (fold_applies(sy, n[p])) {
             const int ns = sy->ns, na = sy->na;
             const std::string T = std::string("fold_") + tags[p][0] + "_";
             double *Ks = c->buf<double>(T + "Ks", (size_t)ns * ns), *Ka = c->buf<double>(T + "Ka", (size_t)std::max(na, 1) * na);
+            const FoldView fv = eigh_fold_view(c, p, sy, n[p]);
             fold[p].on = true;
-            fold[p].ws = c->buf<double>(T + "ws", ns);
-            fold[p].Us = c->buf<double>(T + "Us", (size_t)ns * ns);
-            fold[p].wa = c->buf<double>(T + "wa", std::max(na, 1));
-            fold[p].Ua = c->buf<double>(T + "Ua", (size_t)std::max(na, 1) * na);
+            fold[p].ws = fv.w;
+            fold[p].Us = fv.U;
+            fold[p].wa = fv.w + ns;
+            fold[p].Ua = fv.U + (size_t)ns * ns;
             hipLaunchKernelGGL(sym_fold_kernel, dim3(ceil_div((long)ns * ns, 256)), dim3(256), 0, s, (const double *)A[p], n[p],
                                *sy, Ks, Ka);
             submit(Ks, ns, fold[p].ws, fold[p].Us, tags[p][1]);

@@ -385,4 +385,170 @@ void k_swap_last2_sum(gpcsd_ctx *c, const double *in, int C, double *list, long 
     GP_HIP(hipGetLastError());
 }
 
+// ------------------------------------------------------------------------------------------------
+// Folded-basis helpers.  With mirror-symmetric electrode and time grids every covariance of the model commutes with the
+// reflections, so in the basis of symmetric / antisymmetric combinations (F = fold operator, orthogonal) all of them are
+// block diagonal and the flat GEMMs of loglik / predict split into two half-size products each (half the flops).  Fold
+// order of an index: the ns symmetric orbits first (pairs, then fixed points), then the na antisymmetric pairs.
+// ------------------------------------------------------------------------------------------------
+// out_ss[a][b] = wa wb sum_{r in orbit a} sum_{c in orbit b} K[r][c];  out_aa[a][b] = 1/2 (K_ik - K_il - K_jk + K_jl)
+__global__ __launch_bounds__(256) void sym_fold_rect_kernel(const double *__restrict__ K, long ldk, SymDev rs, SymDev cs,
+                                                            double *__restrict__ out_ss, double *__restrict__ out_aa) {
+    const long e = blockIdx.x * 256L + threadIdx.x;
+    if (e >= (long)rs.ns * cs.ns) return;
+    const int a = (int)(e / cs.ns), b = (int)(e % cs.ns);
+    const int i = rs.rep_i[a], j = rs.rep_j[a], k = cs.rep_i[b], l = cs.rep_j[b];
+    const double kik = K[(long)i * ldk + k];
+    double ssum = kik, asum = kik;
+    if (l != k) {
+        const double v = K[(long)i * ldk + l];
+        ssum += v;
+        asum -= v;
+    }
+    if (j != i) {
+        const double v = K[(long)j * ldk + k];
+        ssum += v;
+        asum -= v;
+        if (l != k) {
+            const double v2 = K[(long)j * ldk + l];
+            ssum += v2;
+            asum += v2;
+        }
+    }
+    const double isq2 = 0.70710678118654752440;
+    const double wa = (i == j) ? 1.0 : isq2, wb = (k == l) ? 1.0 : isq2;
+    out_ss[e] = wa * wb * ssum;
+    if (a < rs.na && b < cs.na) out_aa[(long)a * cs.na + b] = 0.5 * asum;
+}
+
+void k_sym_fold_rect(gpcsd_ctx *c, const double *K, long ldk, const SymDev &rs, const SymDev &cs, double *out_ss, double *out_aa,
+                     hipStream_t s) {
+    (void)c;
+    hipLaunchKernelGGL(sym_fold_rect_kernel, dim3(ceil_div((long)rs.ns * cs.ns, 256)), dim3(256), 0, s, K, ldk, rs, cs, out_ss,
+                       out_aa);
+    GP_HIP(hipGetLastError());
+}
+
+// Y[x][r][t] -> out[q][r][b], q / b = fold index of the electrode / the time point
+__global__ __launch_bounds__(256) void fold_lfp_kernel(const double *__restrict__ Y, int nx, int R, int nt, SymDev ss, SymDev st,
+                                                       double *__restrict__ out) {
+    const long e = blockIdx.x * 256L + threadIdx.x;
+    if (e >= (long)nx * R * nt) return;
+    const int b = (int)(e % nt);
+    const long qr = e / nt;
+    const int r = (int)(qr % R), q = (int)(qr / R);
+    const bool qa = q >= ss.ns, ba = b >= st.ns;
+    const int a = qa ? q - ss.ns : q, bb = ba ? b - st.ns : b;
+    const int i = ss.rep_i[a], j = ss.rep_j[a], k = st.rep_i[bb], l = st.rep_j[bb];
+    const double isq2 = 0.70710678118654752440;
+    const double wq = (i == j) ? 1.0 : isq2, wb = (k == l) ? 1.0 : isq2;
+    const double sj = qa ? -1.0 : 1.0, sl = ba ? -1.0 : 1.0;
+    const double *__restrict__ yi = Y + ((long)i * R + r) * nt, *__restrict__ yj = Y + ((long)j * R + r) * nt;
+    double v = yi[k];
+    if (l != k) v += sl * yi[l];
+    if (j != i) {
+        double u = yj[k];
+        if (l != k) u += sl * yj[l];
+        v += sj * u;
+    }
+    out[e] = wq * wb * v;
+}
+
+void k_fold_lfp(gpcsd_ctx *c, const double *Y, int nx, int R, int nt, const SymDev &ss, const SymDev &st, double *out,
+                hipStream_t s) {
+    ProfScope ps(c, "fold_lfp", 0.0, s);
+    hipLaunchKernelGGL(fold_lfp_kernel, dim3(ceil_div((long)nx * R * nt, 256)), dim3(256), 0, s, Y, nx, R, nt, ss, st, out);
+    GP_HIP(hipGetLastError());
+}
+
+// Predictions in the folded basis, in[(zq, r)][pt][c][b] (zq = fold index of the site; pt = 0: the C symmetric time blocks of
+// width st.ns, pt = 1: the C antisymmetric blocks of width st.na; row stride C*nt) -> list[c][z][t][r] (optional) and
+// sum[z][t][r].  One workgroup owns a site orbit x 32 time orbits x 32 trials: it reads the four parity tiles once and
+// writes the (up to) four mirror images, transposing (r, t) -> (t, r) through LDS like swap_last2_sum_kernel.
+__global__ __launch_bounds__(256) void unfold_swap_sum_kernel(const double *__restrict__ in, int C, double *__restrict__ list,
+                                                              long list_stride, double *__restrict__ sum, int R, int nt,
+                                                              SymDev sz, SymDev st) {
+    __shared__ double tile[2][2][32][33];
+    const int az = blockIdx.z;                                  // site orbit
+    const int b0 = blockIdx.x * 32, i0 = blockIdx.y * 32;       // time orbits, trials
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;     // 32 x 8
+    const int zi = sz.rep_i[az], zj = sz.rep_j[az];
+    const double isq2 = 0.70710678118654752440;
+    const double wz = (zi == zj) ? 1.0 : isq2;
+    const long ldin = (long)C * nt;
+    double acc[4][4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) acc[m][k] = 0.0;
+    for (int c = 0; c < C; ++c) {
+        __syncthreads();
+#pragma unroll
+        for (int pz = 0; pz < 2; ++pz)
+#pragma unroll
+            for (int pt = 0; pt < 2; ++pt) {
+                const bool zok = pz == 0 || az < sz.na;
+                const long row = pz ? (long)sz.ns + az : az;
+                const int wdt = pt ? st.na : st.ns;
+                const long col0 = (pt ? (long)C * st.ns : 0) + (long)c * wdt;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int i = i0 + ty + 8 * k, b = b0 + tx;
+                    double v = 0.0;
+                    if (zok && i < R && b < wdt) v = in[(row * R + i) * ldin + col0 + b];
+                    tile[pz][pt][ty + 8 * k][tx] = v;
+                }
+            }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int b = b0 + ty + 8 * k, i = i0 + tx;
+            if (i < R && b < st.ns) {
+                const int tk = st.rep_i[b], tl = st.rep_j[b];
+                const double wt = (tk == tl) ? 1.0 : isq2;
+                const double ss = wz * wt * tile[0][0][tx][ty + 8 * k], sa = wz * isq2 * tile[0][1][tx][ty + 8 * k];
+                const double as = isq2 * wt * tile[1][0][tx][ty + 8 * k], aa = 0.5 * tile[1][1][tx][ty + 8 * k];
+                const double v0 = (ss + sa) + (as + aa);        // (zi, tk)
+                const double v1 = (ss - sa) + (as - aa);        // (zi, tl)
+                const double v2 = (ss + sa) - (as + aa);        // (zj, tk)
+                const double v3 = (ss - sa) - (as - aa);        // (zj, tl)
+                acc[0][k] += v0;                                // components summed in index order, as the reference does
+                acc[1][k] += v1;
+                acc[2][k] += v2;
+                acc[3][k] += v3;
+                if (list) {
+                    double *__restrict__ lc = list + (long)c * list_stride;
+                    lc[((long)zi * nt + tk) * R + i] = v0;
+                    if (tl != tk) lc[((long)zi * nt + tl) * R + i] = v1;
+                    if (zj != zi) {
+                        lc[((long)zj * nt + tk) * R + i] = v2;
+                        if (tl != tk) lc[((long)zj * nt + tl) * R + i] = v3;
+                    }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int b = b0 + ty + 8 * k, i = i0 + tx;
+        if (i < R && b < st.ns) {
+            const int tk = st.rep_i[b], tl = st.rep_j[b];
+            sum[((long)zi * nt + tk) * R + i] = acc[0][k];
+            if (tl != tk) sum[((long)zi * nt + tl) * R + i] = acc[1][k];
+            if (zj != zi) {
+                sum[((long)zj * nt + tk) * R + i] = acc[2][k];
+                if (tl != tk) sum[((long)zj * nt + tl) * R + i] = acc[3][k];
+            }
+        }
+    }
+}
+
+void k_unfold_swap_sum(gpcsd_ctx *c, const double *in, int C, double *list, long list_stride, double *sum, int R, int nt,
+                       const SymDev &sz, const SymDev &st, hipStream_t s) {
+    dim3 grid(ceil_div(st.ns, 32), ceil_div(R, 32), sz.ns);
+    ProfScope ps(c, "relayout", 0.0, s);
+    hipLaunchKernelGGL(unfold_swap_sum_kernel, grid, dim3(256), 0, s, in, C, list, list_stride, sum, R, nt, sz, st);
+    GP_HIP(hipGetLastError());
+}
+
 }  // namespace gpcsd

@@ -73,6 +73,16 @@ void k_fill(gpcsd_ctx *c, double *p, long n, double v, hipStream_t s);
 void k_swap_last2_sum(gpcsd_ctx *c, const double *in, int C, double *list, long list_stride, double *sum, int n0, int n1, int n2,
                       hipStream_t s);
 
+// folded-basis helpers (gram.hip): rectangular fold of a covariance that commutes with the reflections of its row and
+// column grids (out_ss: rs.ns x cs.ns, out_aa: rs.na x cs.na), the fold of the resident data in both indices, and the
+// final pass of a folded prediction (unfold in site and time, (r, t) -> (t, r), sum over components)
+void k_sym_fold_rect(gpcsd_ctx *c, const double *K, long ldk, const SymDev &rs, const SymDev &cs, double *out_ss, double *out_aa,
+                     hipStream_t s);
+void k_fold_lfp(gpcsd_ctx *c, const double *Y, int nx, int R, int nt, const SymDev &ss, const SymDev &st, double *out,
+                hipStream_t s);
+void k_unfold_swap_sum(gpcsd_ctx *c, const double *in, int C, double *list, long list_stride, double *sum, int R, int nt,
+                       const SymDev &sz, const SymDev &st, hipStream_t s);
+
 // ---------------------------------------------------------------- eigensolver (eigh.hip)
 // Symmetric eigendecomposition of A (n,n) on device.  evals ascending; evecs (n,n) row-major with
 // eigenvectors in COLUMNS (numpy.linalg.eigh convention).  A is destroyed.  status: device int (0 ok).
@@ -89,6 +99,13 @@ struct EigReq {
 // launches; with a known symmetry each splits into two half-size problems first.  Either n may be <= 0 to skip.
 void eigh_pair_device(gpcsd_ctx *c, double *A0, int n0, double *w0, double *Z0, const SymDev *sym0, double *A1, int n1,
                       double *w1, double *Z1, const SymDev *sym1, int *d_status, hipStream_t s);
+// Half-size results of a symmetry-folded problem, in fold order (see eigh.hip); on == false: the problem is not folded.
+struct FoldView {
+    bool on = false;
+    int ns = 0, na = 0;
+    double *w = nullptr, *U = nullptr;      // w = (ws | wa);  U = (Us, ns x ns | Ua, na x na), eigenvectors in columns
+};
+FoldView eigh_fold_view(gpcsd_ctx *c, int slot, const SymDev *sy, int n);
 // fused compact-WY back-transformation (wy.hip): all panels of all problems in two launches
 struct WyProb {
     const double *V, *tau;   // reflectors by rows ((n + 64) x n, zero padded), tau (n + 64)

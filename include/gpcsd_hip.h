@@ -165,6 +165,13 @@ int gpcsd_sample_prior(gpcsd_ctx *ctx, const gpcsd_hparams *hp, int which,
 int gpcsd_whitened_quad(gpcsd_ctx *ctx, const double *Qs, int nx, const double *Qt, int nt, const double *Dvec,
                         const double *resid, int nb, double *out);
 
+/* Folded-basis GEMMs: with mirror-symmetric electrode and time grids (detected in set_geometry / set_time) loglik and predict
+ * run their projections (gpcsd1d.py:124-127, 262-279) as half-size products in the symmetric / antisymmetric basis; same
+ * results to rounding, half the flops.  on = 0 / 1 switches the path for this context (default 1; GPCSD_NO_FOLD_GEMM=1 in
+ * the environment disables it process-wide), on < 0 only queries.  *calls (optional) receives how many loglik / predict
+ * calls of this context have taken the folded path so far. */
+int gpcsd_fold_gemm(gpcsd_ctx *ctx, int on, long *calls);
+
 /* ---- measurement --------------------------------------------------------------- */
 /* When enabled, every launch of a named hot kernel is bracketed by hipEvents on the ctx stream. */
 int gpcsd_prof_enable(gpcsd_ctx *ctx, int on);

@@ -526,3 +526,115 @@ def test_fit_concurrent_restarts_match_sequential():
     assert np.allclose(m1.fit_nll_values_, m2.fit_nll_values_, rtol=1e-10, atol=0)
     assert abs(m1.R["value"] - m2.R["value"]) <= 1e-9 * abs(m1.R["value"])
     assert abs(m1.loglik() - m2.loglik()) <= 1e-9 * abs(m1.loglik())
+
+
+# ------------------------------------------------------------------------------------------------ folded-basis GEMMs
+FOLD_CASES = [n for n in MODEL_CASES if C.model_cases()[n]["x"].shape[0] > 64 and C.model_cases()[n]["t"].shape[0] > 64
+              and np.ndim(C.model_cases()[n]["sig2n"]) == 0]
+
+
+@pytest.mark.parametrize("name", FOLD_CASES)
+def test_folded_gemm_path_matches_unfolded(name):
+    """Mirror-symmetric grids: loglik / predict run their projections as half-size GEMMs in the symmetric/antisymmetric
+    basis.  Same numbers as the full-size path (and as the reference's goldens), and the folded path is the one taken."""
+    m, c, g, geom, hp, lfp = _build_model(name)
+    ctx = m._context()
+    n0 = ctx.fold_gemm(True)
+    ll_f = float(m.loglik())
+    assert ctx.fold_gemm() == n0 + 1, "grids are symmetric: the folded path must be taken"
+    pred_both = not c.get("loglik_only")
+    if pred_both:
+        m.predict(c["x"], c["t"], type="both")
+        assert ctx.fold_gemm() == n0 + 2
+        csd_f, lfp_f = m.csd_pred.copy(), m.lfp_pred.copy()
+        lists_f = [a.copy() for a in m.csd_pred_list]
+    n1 = ctx.fold_gemm(False)
+    ll_u = float(m.loglik())
+    assert ctx.fold_gemm() == n1
+    assert abs(ll_f - ll_u) / abs(ll_u) < 1e-11
+    assert abs(ll_f - float(g["loglik"])) / abs(float(g["loglik"])) < GATE
+    if pred_both:
+        m.predict(c["x"], c["t"], type="both")
+        assert relerr(csd_f, m.csd_pred) < 1e-10 and relerr(lfp_f, m.lfp_pred) < 1e-10
+        for a, b in zip(lists_f, m.csd_pred_list):
+            assert relerr(a, b) < 1e-10
+        assert relerr(csd_f, g["csd_pred"]) < GATE
+    ctx.fold_gemm(True)
+
+
+def test_folded_gemm_falls_back_when_symmetry_is_missing():
+    """Prediction sites without the electrodes' mirror symmetry, prediction times other than the training grid, or a
+    per-electrode noise list (indexed by eigen-rank in the reference) take the full-size path; results agree with it."""
+    name = FOLD_CASES[0]
+    m, c, g, geom, hp, lfp = _build_model(name)
+    ctx = m._context()
+    ctx.fold_gemm(True)
+    x, t = c["x"], c["t"]
+    z_asym = np.array(x[: x.shape[0] - 3], dtype=np.float64)          # drop three sites: no longer mirror-symmetric
+    n0 = ctx.fold_gemm()
+    m.predict(z_asym, t, type="csd")
+    assert ctx.fold_gemm() == n0
+    p_asym = m.csd_pred.copy()
+    m.predict(x, t, type="csd")
+    assert ctx.fold_gemm() == n0 + 1
+    assert relerr(p_asym, m.csd_pred[: z_asym.shape[0]]) < 1e-10      # same sites, either path
+    t_shift = t + 0.37 * (t[1] - t[0])
+    m.predict(x, t_shift, type="csd")
+    assert ctx.fold_gemm() == n0 + 1
+    p_shift = m.csd_pred.copy()
+    ctx.fold_gemm(False)
+    m.predict(x, t_shift, type="csd")
+    assert relerr(p_shift, m.csd_pred) < 1e-12
+    ctx.fold_gemm(True)
+    # a mirror-symmetric set of sites that is NOT the electrode grid folds as well
+    z_sym = np.concatenate([x[:5], x[-5:]]) if c["dim"] == 1 else None
+    if z_sym is not None:
+        n1 = ctx.fold_gemm()
+        m.predict(z_sym, t, type="csd")
+        assert ctx.fold_gemm() == n1 + 1
+    m.sig2n["value"] = list(np.full(x.shape[0], float(c["sig2n"])) * np.linspace(0.5, 1.5, x.shape[0]))
+    n2 = ctx.fold_gemm()
+    ll = float(m.loglik())
+    assert ctx.fold_gemm() == n2 and np.isfinite(ll)
+
+
+def test_folded_gemm_1d_odd_sizes_vs_oracle():
+    """GPCSD1D with an odd number of electrodes and time points (fixed points of both reflections, ns != na), folded path
+    against the oracle: loglik, predictions at the electrodes and at a symmetric subset of sites."""
+    from gpcsd_amd.gpcsd1d import GPCSD1D
+    from gpcsd_amd.covariances import GPCSDTemporalCovSE, GPCSDTemporalCovMatern
+    rs = np.random.RandomState(5)
+    nx, nt, R = 81, 71, 3
+    x = np.linspace(0.0, 2400.0, nx).reshape(-1, 1)
+    t = np.linspace(0.0, 70.0, nt).reshape(-1, 1)
+    lfp = rs.standard_normal((nx, nt, R))
+    tse, tma = GPCSDTemporalCovSE(t), GPCSDTemporalCovMatern(t)
+    tse.params["ell"]["value"], tse.params["sigma2"]["value"] = 9.0, 0.8
+    tma.params["ell"]["value"], tma.params["sigma2"]["value"] = 4.0, 0.3
+    m = GPCSD1D(lfp, x, t, a=0.0, b=2400.0, ngl=60, temporal_cov_list=[tse, tma])
+    m.spatial_cov.params["ell"]["value"] = 180.0
+    m.R["value"] = 120.0
+    m.sig2n["value"] = 0.07
+    geom = O.Geometry1D(x, t, a=0.0, b=2400.0, ngl=60)
+    hp = O.make_hparams(120.0, (180.0,), [(C.SE, 9.0, 0.8), (C.MATERN, 4.0, 0.3)], 0.07)
+    ctx = m._context()
+    n0 = ctx.fold_gemm(True)
+    ll = float(m.loglik())
+    assert ctx.fold_gemm() == n0 + 1
+    llo = O.loglik(geom, with_jitter(hp, m.JITTER), lfp)
+    assert abs(ll - llo) / abs(llo) < 1e-8
+    for z in (x, x[::2]):
+        n1 = ctx.fold_gemm()
+        m.predict(z, t, type="both")
+        assert ctx.fold_gemm() == n1 + 1
+        csd_f, lfp_f, lst_f = m.csd_pred.copy(), m.lfp_pred.copy(), [a.copy() for a in m.csd_pred_list]
+        ctx.fold_gemm(False)
+        m.predict(z, t, type="both")
+        ctx.fold_gemm(True)
+        ref = O.predict(geom, hp, lfp, z, t, type="both")
+        # 81 electrodes 30 um apart under a 180 um length scale: Ks is numerically singular and predict adds no jitter
+        # (gpcsd1d.py:258), so two correct fp64 evaluations differ by ~1e-7 in the small components
+        assert relerr(csd_f, m.csd_pred) < 1e-7 and relerr(lfp_f, m.lfp_pred) < 1e-7
+        assert relerr(csd_f, ref["csd"]) < 1e-6 and relerr(lfp_f, ref["lfp"]) < 1e-6
+        for a, b in zip(lst_f, ref["csd_list"]):
+            assert relerr(a, b) < 1e-6

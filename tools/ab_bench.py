@@ -1,14 +1,18 @@
 """A/B timing of two builds of libgpcsd_hip.so on the SAME box, interleaved (run-to-run and box-to-box variation of the
-bench step is ~1.5 %, more than most single kernel changes).  python tools/ab_bench.py base.so new.so [rounds] [steps]"""
+bench step is ~1.5 %, more than most single kernel changes).  python tools/ab_bench.py base.so new.so [rounds] [steps]
+A side may carry environment settings after '@':  new.so@GPCSD_NO_FOLD_GEMM=1  (the same library under two switches)."""
 import json, os, subprocess, sys
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-libs = [os.path.abspath(sys.argv[1]), os.path.abspath(sys.argv[2])]
+libs = [sys.argv[1], sys.argv[2]]
 rounds = int(sys.argv[3]) if len(sys.argv) > 3 else 4
 steps = sys.argv[4] if len(sys.argv) > 4 else "40"
 res = {l: [] for l in libs}
 for r in range(rounds):
     for l in libs:
-        env = dict(os.environ, GPCSD_LIB_PATH=l)
+        path, _, extra = l.partition("@")
+        env = dict(os.environ, GPCSD_LIB_PATH=os.path.abspath(path))
+        for kv in filter(None, extra.split(",")):
+            env[kv.split("=", 1)[0]] = kv.split("=", 1)[1]
         out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--no-cpu-baseline", "--steps", steps, "--warmup", "5"],
                              env=env, capture_output=True, text=True)
         if out.returncode != 0:
