@@ -341,19 +341,37 @@ static const double *folded_lfp(gpcsd_ctx *c) {
     return Yf;
 }
 
+// The two parity blocks of one folded product.  Equal block shapes (even grids: the usual case) go out as ONE batched
+// launch -- twice the tiles per launch, so the last partial wave of workgroups weighs half as much -- otherwise as two.
+// Returns true when batched (an EPI_QUAD pair then leaves the whole sum in g0.quad_out, else g1.quad_out holds the rest).
+static bool gemm_pair(gpcsd_ctx *c, GemmDesc g0, const GemmDesc &g1, hipStream_t s) {
+    if (g0.M == g1.M && g0.N == g1.N && g0.K == g1.K && g0.lda == g1.lda && g0.ldb == g1.ldb && g0.ldc == g1.ldc) {
+        g0.batch = 2;
+        g0.sA = g1.A - g0.A;
+        g0.sB = g1.B - g0.B;
+        g0.sC = (g0.C && g1.C) ? g1.C - g0.C : 0;
+        g0.sD = (g0.D && g1.D) ? g1.D - g0.D : 0;
+        gemm_f64(c, g0, s);
+        return true;
+    }
+    gemm_f64(c, g0, s);
+    gemm_f64(c, g1, s);
+    return false;
+}
+
 // out[p-block rows] = U_p^T in[p-block rows] for p = symmetric, antisymmetric: the spatial projection in the folded basis
 static void fold_proj_spatial(gpcsd_ctx *c, const FoldView &fs, const double *in, double *out, long ncols, hipStream_t s) {
+    GemmDesc g[2];
     for (int p = 0; p < 2; ++p) {
         const int np = p ? fs.na : fs.ns;
         const long r0 = p ? fs.ns : 0;
-        GemmDesc g;
-        g.M = np; g.N = (int)ncols; g.K = np;
-        g.A = fs.U + (p ? (size_t)fs.ns * fs.ns : 0); g.lda = np; g.transA = true;
-        g.B = in + r0 * ncols; g.ldb = ncols;
-        g.C = out + r0 * ncols; g.ldc = ncols;
-        g.prof_name = "gemm_proj_spatial";
-        gemm_f64(c, g, s);
+        g[p].M = np; g[p].N = (int)ncols; g[p].K = np;
+        g[p].A = fs.U + (p ? (size_t)fs.ns * fs.ns : 0); g[p].lda = np; g[p].transA = true;
+        g[p].B = in + r0 * ncols; g[p].ldb = ncols;
+        g[p].C = out + r0 * ncols; g[p].ldc = ncols;
+        g[p].prof_name = "gemm_proj_spatial";
     }
+    gemm_pair(c, g[0], g[1], s);
 }
 
 // Main stream waits for the temporal chain; then D and sum(log D) -- from the spectra in fold order when fm is on.
@@ -1001,20 +1019,20 @@ extern "C" int gpcsd_loglik_parts(gpcsd_ctx *c, const gpcsd_hparams *hp, double 
         ++c->fold_gemm_calls;
         fold_proj_spatial(c, fm.fs, Yf, W, (long)R * nt, s);
         join_temporal(c, e, &fm);
+        GemmDesc g2[2];
         for (int p = 0; p < 2; ++p) {
             const int np = p ? fm.ft.na : fm.ft.ns, c0 = p ? fm.ft.ns : 0;
-            GemmDesc g2;
-            g2.M = nx * R; g2.N = np; g2.K = np;
-            g2.A = W + c0; g2.lda = nt;
-            g2.B = fm.ft.U + (p ? (size_t)fm.ft.ns * fm.ft.ns : 0); g2.ldb = np;
-            g2.epi = EPI_QUAD; g2.D = e.Dinv + c0; g2.rdiv = R; g2.ldd = nt; g2.quad_out = e.scal + 1 + p;
-            g2.prof_name = "gemm_proj_temporal_quad";
-            gemm_f64(c, g2, s);
+            g2[p].M = nx * R; g2[p].N = np; g2[p].K = np;
+            g2[p].A = W + c0; g2[p].lda = nt;
+            g2[p].B = fm.ft.U + (p ? (size_t)fm.ft.ns * fm.ft.ns : 0); g2[p].ldb = np;
+            g2[p].epi = EPI_QUAD; g2[p].D = e.Dinv + c0; g2[p].rdiv = R; g2[p].ldd = nt; g2[p].quad_out = e.scal + 1 + p;
+            g2[p].prof_name = "gemm_proj_temporal_quad";
         }
+        const bool batched = gemm_pair(c, g2[0], g2[1], s);
         double h3[3] = {0.0, 0.0, 0.0};
         const int rc = finish_call(c, e, h3, 3);
         out2[0] = h3[0];
-        out2[1] = h3[1] + h3[2];
+        out2[1] = batched ? h3[1] : h3[1] + h3[2];
         return rc;
     }
     GemmDesc g1;                          // W[x'][(r,t)] = sum_x Qs[x][x'] Y[x][(r,t)]        (gpcsd1d.py:125 inner dot)
@@ -1105,16 +1123,19 @@ static int predict_fold(gpcsd_ctx *c, const gpcsd_hparams *hp, EigState &e, cons
                         Ktf + cc * ktf_sz + (size_t)nts * nts, s);
     }
     join_temporal(c, e, &fm);
+    GemmDesc g2[2];                       // Bm~[:, p block] = (W~[:, p block] V_p) / D~
     for (int p = 0; p < 2; ++p) {
         const int np = p ? nta : nts, c0 = p ? nts : 0;
-        GemmDesc g2;                      // Bm~[:, p block] = (W~[:, p block] V_p) / D~
-        g2.M = nx * R; g2.N = np; g2.K = np;
-        g2.A = W + c0; g2.lda = nt;
-        g2.B = fm.ft.U + (p ? (size_t)nts * nts : 0); g2.ldb = np;
-        g2.C = Bm + c0; g2.ldc = nt;
-        g2.epi = EPI_DIV_D; g2.D = e.Dinv + c0; g2.rdiv = R; g2.ldd = nt;
-        g2.prof_name = "gemm_pred_temporal_div";
-        gemm_f64(c, g2, s);
+        g2[p].M = nx * R; g2[p].N = np; g2[p].K = np;
+        g2[p].A = W + c0; g2[p].lda = nt;
+        g2[p].B = fm.ft.U + (p ? (size_t)nts * nts : 0); g2[p].ldb = np;
+        g2[p].C = Bm + c0; g2[p].ldc = nt;
+        g2[p].epi = EPI_DIV_D; g2[p].D = e.Dinv + c0; g2[p].rdiv = R; g2[p].ldd = nt;
+        g2[p].prof_name = "gemm_pred_temporal_div";
+    }
+    gemm_pair(c, g2[0], g2[1], s);
+    for (int p = 0; p < 2; ++p) {
+        const int np = p ? nta : nts;
         for (int cc = 0; cc < C; ++cc) {
             GemmDesc gp;                  // Pcat_p[i'][cc*np + b] = sum_j V_p[j][i'] Kt*~_cc,pp[j][b]
             gp.M = np; gp.N = np; gp.K = np;
@@ -1130,26 +1151,25 @@ static int predict_fold(gpcsd_ctx *c, const gpcsd_hparams *hp, EigState &e, cons
         double *o_sum = c->buf<double>(which == 1 ? "pred_out_csd" : "pred_out_lfp", out_elems);
         double *o_list = want_lists ? c->buf<double>(which == 1 ? "pred_out_csd_list" : "pred_out_lfp_list", out_elems * C)
                                     : nullptr;
-        for (int p = 0; p < 2; ++p) {
+        GemmDesc g5[2], g6[2];
+        for (int p = 0; p < 2; ++p) {     // S~[p rows] = M1_p Bm~[p rows]
             const int np = p ? na : ns, nzp = p ? nza : nzs;
-            GemmDesc g5;                  // S~[p rows] = M1_p Bm~[p rows]
-            g5.M = nzp; g5.N = (int)RT; g5.K = np;
-            g5.A = M1 + (size_t)(which - 1) * m1_sz + (p ? (size_t)nzs * ns : 0); g5.lda = np;
-            g5.B = Bm + (p ? (size_t)ns * RT : 0); g5.ldb = RT;
-            g5.C = S + (p ? (size_t)nzs * RT : 0); g5.ldc = RT;
-            g5.prof_name = "gemm_pred_cross";
-            gemm_f64(c, g5, s);
+            g5[p].M = nzp; g5[p].N = (int)RT; g5[p].K = np;
+            g5[p].A = M1 + (size_t)(which - 1) * m1_sz + (p ? (size_t)nzs * ns : 0); g5[p].lda = np;
+            g5[p].B = Bm + (p ? (size_t)ns * RT : 0); g5[p].ldb = RT;
+            g5[p].C = S + (p ? (size_t)nzs * RT : 0); g5[p].ldc = RT;
+            g5[p].prof_name = "gemm_pred_cross";
         }
-        for (int p = 0; p < 2; ++p) {
+        gemm_pair(c, g5[0], g5[1], s);
+        for (int p = 0; p < 2; ++p) {     // comp~[(zq, r)][p][cc][b] = sum_i' S~[(zq, r)][p block i'] Pcat_p[i'][cc*np + b]
             const int np = p ? nta : nts, c0 = p ? nts : 0;
-            GemmDesc g6;                  // comp~[(zq, r)][p][cc][b] = sum_i' S~[(zq, r)][p block i'] Pcat_p[i'][cc*np + b]
-            g6.M = nz * R; g6.N = C * np; g6.K = np;
-            g6.A = S + c0; g6.lda = nt;
-            g6.B = Pc + (p ? (size_t)C * nts * nts : 0); g6.ldb = (long)C * np;
-            g6.C = comp + (p ? (size_t)C * nts : 0); g6.ldc = (long)C * nt;
-            g6.prof_name = "gemm_pred_tstar";
-            gemm_f64(c, g6, s);
+            g6[p].M = nz * R; g6[p].N = C * np; g6[p].K = np;
+            g6[p].A = S + c0; g6[p].lda = nt;
+            g6[p].B = Pc + (p ? (size_t)C * nts * nts : 0); g6[p].ldb = (long)C * np;
+            g6[p].C = comp + (p ? (size_t)C * nts : 0); g6[p].ldc = (long)C * nt;
+            g6[p].prof_name = "gemm_pred_tstar";
         }
+        gemm_pair(c, g6[0], g6[1], s);
         k_unfold_swap_sum(c, comp, C, o_list, (long)out_elems, o_sum, R, nt, sz, c->sym_t, s);
     }
     return finish_call(c, e, nullptr, 0);

@@ -49,7 +49,7 @@ struct GemmK {
     double alpha;
     const double *D;
     int rdiv;
-    long ldd;
+    long ldd, sD;
     double *partials;
     int tiles_n, tiles_m;
     int m_fastest;      // logical tile order: 1 = tile_m varies fastest (few row tiles, many column tiles)
@@ -326,6 +326,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f64_kernel(GemmK g) {
     // ---- epilogue ----
     double qsum = 0.0, qsum2 = 0.0;
     double *__restrict__ C = (EPI == EPI_QUAD) ? nullptr : g.C + bz * g.sC;
+    const double *__restrict__ Dz = g.D + bz * g.sD;
     double *__restrict__ C2 = (EPI == EPI_GRAD) ? g.C2 + bz * g.sC : nullptr;
     double *__restrict__ C3 = (EPI == EPI_GRAD) ? g.C3 + bz * g.sC : nullptr;
     if (EPI == EPI_STORE) {
@@ -375,17 +376,17 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f64_kernel(GemmK g) {
                 if (EPI == EPI_ACCUM) {
                     C[(long)row * g.ldc + col] += g.alpha * v;
                 } else if (EPI == EPI_DIV_D) {
-                    C[(long)row * g.ldc + col] = v * g.D[drow + col];
+                    C[(long)row * g.ldc + col] = v * Dz[drow + col];
                 } else if (EPI == EPI_GRAD) {
                     // b = alpha / D; also b * et[col], b * es[row / rdiv]; partial sums of alpha*b and b*b
-                    const double bq = v * g.D[drow + col];
+                    const double bq = v * Dz[drow + col];
                     C[(long)row * g.ldc + col] = bq;
                     C2[(long)row * g.ldc + col] = bq * g.colscale[col];
                     C3[(long)row * g.ldc + col] = bq * rsc;
                     qsum += v * bq;
                     qsum2 += bq * bq;
                 } else {
-                    qsum += v * v * g.D[drow + col];
+                    qsum += v * v * Dz[drow + col];
                 }
             }
         }
@@ -463,7 +464,7 @@ void gemm_f64(gpcsd_ctx *c, const GemmDesc &g, hipStream_t s) {
     k.A = g.A; k.lda = g.lda; k.B = g.B; k.ldb = g.ldb; k.C = g.C; k.ldc = g.ldc; k.C2 = g.C2; k.C3 = g.C3;
     k.colscale = g.colscale; k.rowscale = g.rowscale; k.sColscale = g.sColscale;
     k.sA = g.sA; k.sB = g.sB; k.sC = g.sC;
-    k.alpha = g.alpha; k.D = g.D; k.rdiv = g.rdiv > 0 ? g.rdiv : 1; k.ldd = g.ldd;
+    k.alpha = g.alpha; k.D = g.D; k.rdiv = g.rdiv > 0 ? g.rdiv : 1; k.ldd = g.ldd; k.sD = g.sD;
     k.partials = nullptr;
     k.dyn = g.dyn;
 
