@@ -356,7 +356,12 @@ __global__ __launch_bounds__(512) void sytrd_tail_kernel(SytrdBatch b) {
     }
 }
 
-constexpr int SY_REGTAIL = RT_T;            // rows the register-resident tail (sytrd_regtail.hpp) can hold
+// rows the single-workgroup tail (sytrd_regtail.hpp) can hold: 192 in registers + up to 64 strip rows in LDS
+// (GPCSD_TAIL_STRIP=0: registers only, the leading rows go through per-column launches as before)
+static int sy_regtail_rows() {
+    static const bool nostrip = getenv("GPCSD_TAIL_STRIP") && getenv("GPCSD_TAIL_STRIP")[0] == '0';
+    return nostrip ? RT_T : RT_TMAX;
+}
 static bool sytrd_reg_tail() {               // GPCSD_TAIL=lds selects the older LDS-resident tail (A/B comparisons)
     static const bool lds = getenv("GPCSD_TAIL") && !strcmp(getenv("GPCSD_TAIL"), "lds");
     return !lds;
@@ -378,7 +383,16 @@ static void sytrd_batch_launch(gpcsd_ctx *c, const SytrdBatch &b, int count, int
         else hipLaunchKernelGGL(sytrd_step_kernel<16>, grid, dim3(256), 0, s, b, k);
     }
     if (any_tail && sytrd_reg_tail()) {
-        hipLaunchKernelGGL(sytrd_rtail_kernel, dim3(count), dim3(RT_NTH), 0, s, b);
+        size_t sh = 0;
+        for (int i = 0; i < count; ++i)
+            if (b.p[i].k_tail < b.p[i].n - 1) sh = std::max(sh, rt_strip_bytes(b.p[i].n - b.p[i].k_tail));
+        static bool rt_attr_set = false;
+        if (!rt_attr_set) {
+            GP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(sytrd_rtail_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)rt_strip_bytes(RT_TMAX)));
+            rt_attr_set = true;
+        }
+        hipLaunchKernelGGL(sytrd_rtail_kernel, dim3(count), dim3(RT_NTH), sh, s, b);
     } else if (any_tail) {
         const size_t sh = ((size_t)(SY_TAIL + 1) * SY_TLD + 6 * 128 + 32) * sizeof(double);
         static bool attr_set = false;
@@ -484,7 +498,7 @@ static void prep_problem(gpcsd_ctx *c, EigProb &p, hipStream_t s) {
     {
         static const bool no_tail = getenv("GPCSD_NO_TAIL") && getenv("GPCSD_NO_TAIL")[0] == '1';
         // the trailing block finishes inside one workgroup (registers: 192 rows; LDS variant: 113 rows)
-        p.sp.k_tail = no_tail ? n - 1 : (sytrd_reg_tail() ? std::max(0, n - SY_REGTAIL) : std::max(0, n - 1 - 112));
+        p.sp.k_tail = no_tail ? n - 1 : (sytrd_reg_tail() ? std::max(0, n - sy_regtail_rows()) : std::max(0, n - 1 - 112));
     }
     p.sp.A0 = c->buf<double>(T + "A0", nn);
     p.sp.A1 = c->buf<double>(T + "A1", nn);
