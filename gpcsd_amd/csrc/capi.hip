@@ -1136,15 +1136,14 @@ static int predict_fold(gpcsd_ctx *c, const gpcsd_hparams *hp, EigState &e, cons
     gemm_pair(c, g2[0], g2[1], s);
     for (int p = 0; p < 2; ++p) {
         const int np = p ? nta : nts;
-        for (int cc = 0; cc < C; ++cc) {
-            GemmDesc gp;                  // Pcat_p[i'][cc*np + b] = sum_j V_p[j][i'] Kt*~_cc,pp[j][b]
-            gp.M = np; gp.N = np; gp.K = np;
-            gp.A = fm.ft.U + (p ? (size_t)nts * nts : 0); gp.lda = np; gp.transA = true;
-            gp.B = Ktf + cc * ktf_sz + (p ? (size_t)nts * nts : 0); gp.ldb = np;
-            gp.C = Pc + (p ? (size_t)C * nts * nts : 0) + (size_t)cc * np; gp.ldc = (long)C * np;
-            gp.prof_name = "gemm_pred_Pc";
-            gemm_f64(c, gp, s);
-        }
+        GemmDesc gp;                      // Pcat_p[i'][cc*np + b] = sum_j V_p[j][i'] Kt*~_cc,pp[j][b], all components batched
+        gp.M = np; gp.N = np; gp.K = np;
+        gp.A = fm.ft.U + (p ? (size_t)nts * nts : 0); gp.lda = np; gp.transA = true;
+        gp.B = Ktf + (p ? (size_t)nts * nts : 0); gp.ldb = np;
+        gp.C = Pc + (p ? (size_t)C * nts * nts : 0); gp.ldc = (long)C * np;
+        gp.batch = C; gp.sA = 0; gp.sB = (long)ktf_sz; gp.sC = np;
+        gp.prof_name = "gemm_pred_Pc";
+        gemm_f64(c, gp, s);
     }
     for (int which = 1; which <= 2; ++which) {
         if (!(type & which)) continue;
