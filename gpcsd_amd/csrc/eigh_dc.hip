@@ -77,6 +77,7 @@ struct SytrdBatch {
 
 }  // namespace gpcsd
 #include "sytrd_regtail.hpp"
+#include "sytrd_regtail6.hpp"
 namespace gpcsd {
 
 // JQ = ceil(trailing columns / 64) this launch may need (2, 4, 8 or 16).  Every global load of the step -- the slab
@@ -390,9 +391,16 @@ static void sytrd_batch_launch(gpcsd_ctx *c, const SytrdBatch &b, int count, int
         if (!rt_attr_set) {
             GP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(sytrd_rtail_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)rt_strip_bytes(RT_TMAX)));
+            GP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(sytrd_rtail6_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)rt_strip_bytes(RT_TMAX)));
             rt_attr_set = true;
         }
-        hipLaunchKernelGGL(sytrd_rtail_kernel, dim3(count), dim3(RT_NTH), sh, s, b);
+        // default: 768 threads, 4 x 12 tiles.  GPCSD_TAIL_V=6: 512 threads, 6 x 12 tiles (sytrd_regtail6.hpp) -- fewer LDS
+        // instructions and waves, measured 8 % SLOWER per launch (two waves per SIMD hide the dependent fp64 chains of the
+        // reductions worse than three); kept selectable for A/B runs on other problem shapes
+        static const bool v6 = getenv("GPCSD_TAIL_V") && getenv("GPCSD_TAIL_V")[0] == '6';
+        if (v6) hipLaunchKernelGGL(sytrd_rtail6_kernel, dim3(count), dim3(R6_NTH), sh, s, b);
+        else hipLaunchKernelGGL(sytrd_rtail_kernel, dim3(count), dim3(RT_NTH), sh, s, b);
     } else if (any_tail) {
         const size_t sh = ((size_t)(SY_TAIL + 1) * SY_TLD + 6 * 128 + 32) * sizeof(double);
         static bool attr_set = false;
