@@ -74,6 +74,7 @@ SIGNATURES = {
     "gpcsd_predict_resident": (_I, [_P, ctypes.POINTER(HParams), _DP, _I, _DP, _I, _I, _I]),
     "gpcsd_fetch": (_I, [_P, ctypes.c_char_p, _DP, _L]),
     "gpcsd_sample_prior": (_I, [_P, ctypes.POINTER(HParams), _I, _DP, _I, _DP]),
+    "gpcsd_set_gram_precision": (_I, [_P, _I]),
     "gpcsd_fold_gemm": (_I, [_P, _I, ctypes.POINTER(_L)]),
     "gpcsd_prof_enable": (_I, [_P, _I]),
     "gpcsd_prof_reset": (_I, [_P]),
@@ -413,6 +414,10 @@ class Context:
     # ---- measurement ----
     def synchronize(self):
         self._check(self._lib.gpcsd_device_synchronize(self._h))
+
+    def set_gram_precision(self, bits):
+        """64 (default): Gram builders as the reference evaluates them; 32: single-precision Gram build, fp64 everything else."""
+        self._check(self._lib.gpcsd_set_gram_precision(self._h, int(bits)))
 
     def fold_gemm(self, on=None):
         """Switch (True/False) or query (None) the folded-basis GEMM path; returns the number of folded calls so far."""

@@ -993,6 +993,14 @@ extern "C" int gpcsd_loglik_dense_chol(gpcsd_ctx *c, const double *Ks, int nx, c
     GP_API_END(c)
 }
 
+extern "C" int gpcsd_set_gram_precision(gpcsd_ctx *c, int bits) {
+    GP_API_BEGIN(c)
+    GP_REQUIRE(bits == 32 || bits == 64, -3, "gram precision must be 32 or 64 bits (got %d)", bits);
+    c->gram_fp32 = bits == 32;
+    return 0;
+    GP_API_END(c)
+}
+
 extern "C" int gpcsd_fold_gemm(gpcsd_ctx *c, int on, long *calls) {
     GP_API_BEGIN(c)
     if (on >= 0) c->fold_gemm_on = on != 0;

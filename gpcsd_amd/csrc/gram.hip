@@ -10,28 +10,33 @@ namespace gpcsd {
 // ------------------------------------------------------------------------------------------------
 // forward-model weights
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ double dev_b_fwd_1d(double r, double R) {
+// T = double everywhere on the default path.  T = float is the "fp32 kernel build" of BASELINE cfg5: the Gram builders
+// evaluate in single precision (coordinates and hyper-parameters rounded to float, float exp/log/sqrt) and widen the result,
+// everything downstream (GEMMs, eigensolver, likelihood) stays fp64.  gpcsd_set_gram_precision() selects it per context.
+template <typename T>
+__device__ __forceinline__ T dev_b_fwd_1d(T r, T R) {
     // sqrt((r/R)^2 + 1) - sqrt((r/R)^2)            forward_models.py:16
-    const double q = (r / R) * (r / R);
-    return sqrt(q + 1.0) - sqrt(q);
+    const T q = (r / R) * (r / R);
+    return sqrt(q + T(1)) - sqrt(q);
 }
 
-__device__ __forceinline__ double dev_b_fwd_2d_w(double w, double R, double eps) {
+template <typename T>
+__device__ __forceinline__ T dev_b_fwd_2d_w(T w, T R, T eps) {
     // log(R+eps+sqrt((R+eps)^2+w^2)) - log(eps+sqrt(eps^2+w^2))      forward_models.py:53
-    const double re = R + eps;
+    const T re = R + eps;
     return log(re + sqrt(re * re + w * w)) - log(eps + sqrt(eps * eps + w * w));
 }
 
 __global__ void b_fwd_1d_kernel(const double *__restrict__ r, long n, double R, double *__restrict__ out) {
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
-        out[i] = dev_b_fwd_1d(r[i], R);
+        out[i] = dev_b_fwd_1d<double>(r[i], R);
 }
 
 __global__ void b_fwd_2d_kernel(const double *__restrict__ d1, const double *__restrict__ d2, const double *__restrict__ w,
                                 long n, double R, double eps, double *__restrict__ out) {
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
         const double ww = w ? w[i] : sqrt(d1[i] * d1[i] + d2[i] * d2[i]);   // forward_models.py:52
-        out[i] = dev_b_fwd_2d_w(ww, R, eps);
+        out[i] = dev_b_fwd_2d_w<double>(ww, R, eps);
     }
 }
 
@@ -63,15 +68,16 @@ struct TemporalParams {
     double sigma2[GPCSD_MAX_TEMPORAL];
 };
 
+template <typename T>
 __global__ __launch_bounds__(256) void temporal_gram_kernel(TemporalParams p, const double *__restrict__ t, int n,
                                                             const double *__restrict__ tp, int m, double *__restrict__ out) {
-    __shared__ double st[PT_ROWS], stp[PT_COLS];
+    __shared__ T st[PT_ROWS], stp[PT_COLS];
     const int c0 = blockIdx.x * PT_COLS, r0 = blockIdx.y * PT_ROWS;
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-    if (threadIdx.x < PT_COLS) stp[threadIdx.x] = (c0 + threadIdx.x < m) ? tp[c0 + threadIdx.x] : 0.0;
+    if (threadIdx.x < PT_COLS) stp[threadIdx.x] = (c0 + threadIdx.x < m) ? T(tp[c0 + threadIdx.x]) : T(0);
     else if (threadIdx.x < PT_COLS + PT_ROWS) {
         int i = threadIdx.x - PT_COLS;
-        st[i] = (r0 + i < n) ? t[r0 + i] : 0.0;
+        st[i] = (r0 + i < n) ? T(t[r0 + i]) : T(0);
     }
     __syncthreads();
     const int col = c0 + tx;
@@ -81,17 +87,18 @@ __global__ __launch_bounds__(256) void temporal_gram_kernel(TemporalParams p, co
         const int rr = ty + 4 * k;
         const int row = r0 + rr;
         if (row >= n) continue;
-        const double d = st[rr] - stp[tx];
-        double acc = 0.0;                                              // Kt = zeros; Kt = Kt + K_c (gpcsd1d.py:118-120)
+        const T d = st[rr] - stp[tx];
+        T acc = T(0);                                                  // Kt = zeros; Kt = Kt + K_c (gpcsd1d.py:118-120)
         for (int cc = 0; cc < p.ncomp; ++cc) {
-            double v;
+            const T ell = T(p.ell[cc]), s2 = T(p.sigma2[cc]);
+            T v;
             if (p.kind[cc] == GPCSD_KIND_SE)
-                v = p.sigma2[cc] * exp(-0.5 * (d * d) / (p.ell[cc] * p.ell[cc]));   // covariances.py:270
+                v = s2 * exp(T(-0.5) * (d * d) / (ell * ell));         // covariances.py:270
             else
-                v = p.sigma2[cc] * exp(-sqrt(d * d) / p.ell[cc]);                   // covariances.py:304
+                v = s2 * exp(-sqrt(d * d) / ell);                      // covariances.py:304
             acc = acc + v;
         }
-        out[(long)row * m + col] = acc;
+        out[(long)row * m + col] = (double)acc;
     }
 }
 
@@ -108,11 +115,13 @@ void k_temporal_gram(gpcsd_ctx *c, int ncomp, const int *kind, const double *ell
     }
     dim3 grid(ceil_div(m, PT_COLS), ceil_div(n, PT_ROWS));
     ProfScope ps(c, "gram_temporal", 0.0, s);
-    hipLaunchKernelGGL(temporal_gram_kernel, grid, dim3(256), 0, s, p, t, n, tp, m, out);
+    if (c->gram_fp32) hipLaunchKernelGGL(temporal_gram_kernel<float>, grid, dim3(256), 0, s, p, t, n, tp, m, out);
+    else hipLaunchKernelGGL(temporal_gram_kernel<double>, grid, dim3(256), 0, s, p, t, n, tp, m, out);
     GP_HIP(hipGetLastError());
 }
 
 // A(nx, ngl) = gl_w[g] * b_fwd_1d(gl_x[g] - x[i], R)                      covariances.py:86-88
+template <typename T>
 __global__ __launch_bounds__(256) void fwd_weights_1d_kernel(const double *__restrict__ x, int nx,
                                                              const double *__restrict__ gl_x,
                                                              const double *__restrict__ gl_w, int ngl, double R,
@@ -120,18 +129,22 @@ __global__ __launch_bounds__(256) void fwd_weights_1d_kernel(const double *__res
     const long n = (long)nx * ngl;
     for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) {
         const int i = (int)(e / ngl), g = (int)(e % ngl);
-        A[e] = gl_w[g] * dev_b_fwd_1d(gl_x[g] - x[i], R);
+        A[e] = (double)(T(gl_w[g]) * dev_b_fwd_1d<T>(T(gl_x[g]) - T(x[i]), T(R)));
     }
 }
 
 void k_fwd_weights_1d(gpcsd_ctx *c, const double *x, int nx, const double *gl_x, const double *gl_w, int ngl, double R,
                       double *A, hipStream_t s) {
-    hipLaunchKernelGGL(fwd_weights_1d_kernel, dim3(ew_grid((long)nx * ngl)), dim3(256), 0, s, x, nx, gl_x, gl_w, ngl, R, A);
+    if (c->gram_fp32)
+        hipLaunchKernelGGL(fwd_weights_1d_kernel<float>, dim3(ew_grid((long)nx * ngl)), dim3(256), 0, s, x, nx, gl_x, gl_w, ngl, R, A);
+    else
+        hipLaunchKernelGGL(fwd_weights_1d_kernel<double>, dim3(ew_grid((long)nx * ngl)), dim3(256), 0, s, x, nx, gl_x, gl_w, ngl, R, A);
     GP_HIP(hipGetLastError());
 }
 
 // A(nx, G) with g = g1*ngl2 + g2 (expand_grid order, utility_functions.py:22):
 //   gl_w_prod[g] * b_fwd_2d(w = |gl_g - x_i|)                             covariances.py:125-131, :220-221
+template <typename T>
 __global__ __launch_bounds__(256) void fwd_weights_2d_kernel(const double *__restrict__ xy, int nx,
                                                              const double *__restrict__ gx1,
                                                              const double *__restrict__ gw1, int ngl1,
@@ -140,12 +153,12 @@ __global__ __launch_bounds__(256) void fwd_weights_2d_kernel(const double *__res
                                                              double *__restrict__ A) {
     const int G = ngl1 * ngl2;
     const int i = blockIdx.y;
-    const double x1 = xy[2 * i], x2 = xy[2 * i + 1];
+    const T x1 = T(xy[2 * i]), x2 = T(xy[2 * i + 1]);
     for (int g = blockIdx.x * blockDim.x + threadIdx.x; g < G; g += gridDim.x * blockDim.x) {
         const int g1 = g / ngl2, g2 = g % ngl2;
-        const double d1 = gx1[g1] - x1, d2 = gx2[g2] - x2;
-        const double w = sqrt(d1 * d1 + d2 * d2);
-        A[(long)i * G + g] = (gw1[g1] * gw2[g2]) * dev_b_fwd_2d_w(w, R, eps);
+        const T d1 = T(gx1[g1]) - x1, d2 = T(gx2[g2]) - x2;
+        const T w = sqrt(d1 * d1 + d2 * d2);
+        A[(long)i * G + g] = (double)((T(gw1[g1]) * T(gw2[g2])) * dev_b_fwd_2d_w<T>(w, T(R), T(eps)));
     }
 }
 
@@ -154,20 +167,24 @@ void k_fwd_weights_2d(gpcsd_ctx *c, const double *xy, int nx, const double *gx1,
     const int G = ngl1 * ngl2;
     dim3 grid(ceil_div(G, 256), nx);
     ProfScope ps(c, "fwd_weights_2d", 0.0, s);
-    hipLaunchKernelGGL(fwd_weights_2d_kernel, grid, dim3(256), 0, s, xy, nx, gx1, gw1, ngl1, gx2, gw2, ngl2, R, eps, A);
+    if (c->gram_fp32)
+        hipLaunchKernelGGL(fwd_weights_2d_kernel<float>, grid, dim3(256), 0, s, xy, nx, gx1, gw1, ngl1, gx2, gw2, ngl2, R, eps, A);
+    else
+        hipLaunchKernelGGL(fwd_weights_2d_kernel<double>, grid, dim3(256), 0, s, xy, nx, gx1, gw1, ngl1, gx2, gw2, ngl2, R, eps, A);
     GP_HIP(hipGetLastError());
 }
 
 // out(n,m) = exp(-0.5 ((a_i - b_j)/ell)^2)      covariances.py:55, :67, :89
+template <typename T>
 __global__ __launch_bounds__(256) void se_1d_kernel(const double *__restrict__ a, int n, const double *__restrict__ b, int m,
                                                     double ell, double *__restrict__ out) {
-    __shared__ double sa[PT_ROWS], sb[PT_COLS];
+    __shared__ T sa[PT_ROWS], sb[PT_COLS];
     const int c0 = blockIdx.x * PT_COLS, r0 = blockIdx.y * PT_ROWS;
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-    if (threadIdx.x < PT_COLS) sb[threadIdx.x] = (c0 + threadIdx.x < m) ? b[c0 + threadIdx.x] : 0.0;
+    if (threadIdx.x < PT_COLS) sb[threadIdx.x] = (c0 + threadIdx.x < m) ? T(b[c0 + threadIdx.x]) : T(0);
     else if (threadIdx.x < PT_COLS + PT_ROWS) {
         int i = threadIdx.x - PT_COLS;
-        sa[i] = (r0 + i < n) ? a[r0 + i] : 0.0;
+        sa[i] = (r0 + i < n) ? T(a[r0 + i]) : T(0);
     }
     __syncthreads();
     const int col = c0 + tx;
@@ -176,14 +193,15 @@ __global__ __launch_bounds__(256) void se_1d_kernel(const double *__restrict__ a
     for (int k = 0; k < PT_ROWS / 4; ++k) {
         const int rr = ty + 4 * k, row = r0 + rr;
         if (row >= n) continue;
-        const double q = (sa[rr] - sb[tx]) / ell;
-        out[(long)row * m + col] = exp(-0.5 * (q * q));
+        const T q = (sa[rr] - sb[tx]) / T(ell);
+        out[(long)row * m + col] = (double)exp(T(-0.5) * (q * q));
     }
 }
 
 void k_se_1d(gpcsd_ctx *c, const double *a, int n, const double *b, int m, double ell, double *out, hipStream_t s) {
     dim3 grid(ceil_div(m, PT_COLS), ceil_div(n, PT_ROWS));
-    hipLaunchKernelGGL(se_1d_kernel, grid, dim3(256), 0, s, a, n, b, m, ell, out);
+    if (c->gram_fp32) hipLaunchKernelGGL(se_1d_kernel<float>, grid, dim3(256), 0, s, a, n, b, m, ell, out);
+    else hipLaunchKernelGGL(se_1d_kernel<double>, grid, dim3(256), 0, s, a, n, b, m, ell, out);
     GP_HIP(hipGetLastError());
 }
 
@@ -191,10 +209,12 @@ void k_se_1d(gpcsd_ctx *c, const double *a, int n, const double *b, int m, doubl
 // or an explicit (n,2) list (n2 == 0: p1 = base, point i = (p1[2i], p1[2i+1])).
 // Both sets grids -> exp(-0.5 d1^2 / ell1^2) * exp(-0.5 d2^2 / ell2^2)          covariances.py:216
 // otherwise       -> exp(-0.5 (d1/ell1)^2)   * exp(-0.5 (d2/ell2)^2)            covariances.py:186, :199
+template <typename T>
 __global__ __launch_bounds__(256) void se_2d_kernel(const double *__restrict__ a1, const double *__restrict__ a2, int na,
                                                     int na2, const double *__restrict__ b1, const double *__restrict__ b2,
-                                                    int nb, int nb2, double ell1, double ell2, double *__restrict__ out) {
-    __shared__ double sa[2][PT_ROWS], sb[2][PT_COLS];
+                                                    int nb, int nb2, double ell1d, double ell2d, double *__restrict__ out) {
+    __shared__ T sa[2][PT_ROWS], sb[2][PT_COLS];
+    const T ell1 = T(ell1d), ell2 = T(ell2d);
     const int c0 = blockIdx.x * PT_COLS, r0 = blockIdx.y * PT_ROWS;
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     if (threadIdx.x < PT_COLS) {
@@ -204,8 +224,8 @@ __global__ __launch_bounds__(256) void se_2d_kernel(const double *__restrict__ a
             if (nb2 > 0) { v1 = b1[j / nb2]; v2 = b2[j % nb2]; }
             else { v1 = b1[2 * j]; v2 = b1[2 * j + 1]; }
         }
-        sb[0][threadIdx.x] = v1;
-        sb[1][threadIdx.x] = v2;
+        sb[0][threadIdx.x] = T(v1);
+        sb[1][threadIdx.x] = T(v2);
     } else if (threadIdx.x < PT_COLS + PT_ROWS) {
         const int ii = threadIdx.x - PT_COLS, i = r0 + ii;
         double v1 = 0.0, v2 = 0.0;
@@ -213,8 +233,8 @@ __global__ __launch_bounds__(256) void se_2d_kernel(const double *__restrict__ a
             if (na2 > 0) { v1 = a1[i / na2]; v2 = a2[i % na2]; }
             else { v1 = a1[2 * i]; v2 = a1[2 * i + 1]; }
         }
-        sa[0][ii] = v1;
-        sa[1][ii] = v2;
+        sa[0][ii] = T(v1);
+        sa[1][ii] = T(v2);
     }
     __syncthreads();
     const int col = c0 + tx;
@@ -224,14 +244,14 @@ __global__ __launch_bounds__(256) void se_2d_kernel(const double *__restrict__ a
     for (int k = 0; k < PT_ROWS / 4; ++k) {
         const int rr = ty + 4 * k, row = r0 + rr;
         if (row >= na) continue;
-        const double d1 = sa[0][rr] - sb[0][tx], d2 = sa[1][rr] - sb[1][tx];
-        double v;
-        if (grid_form) v = exp(-0.5 * (d1 * d1) / (ell1 * ell1)) * exp(-0.5 * (d2 * d2) / (ell2 * ell2));
+        const T d1 = sa[0][rr] - sb[0][tx], d2 = sa[1][rr] - sb[1][tx];
+        T v;
+        if (grid_form) v = exp(T(-0.5) * (d1 * d1) / (ell1 * ell1)) * exp(T(-0.5) * (d2 * d2) / (ell2 * ell2));
         else {
-            const double q1 = d1 / ell1, q2 = d2 / ell2;
-            v = exp(-0.5 * (q1 * q1)) * exp(-0.5 * (q2 * q2));
+            const T q1 = d1 / ell1, q2 = d2 / ell2;
+            v = exp(T(-0.5) * (q1 * q1)) * exp(T(-0.5) * (q2 * q2));
         }
-        out[(long)row * nb + col] = v;
+        out[(long)row * nb + col] = (double)v;
     }
 }
 
@@ -239,7 +259,8 @@ void k_se_2d(gpcsd_ctx *c, const double *a1, const double *a2, int na, int na2, 
              int nb2, double ell1, double ell2, double *out, hipStream_t s) {
     dim3 grid(ceil_div(nb, PT_COLS), ceil_div(na, PT_ROWS));
     ProfScope ps(c, "gram_se_2d", 0.0, s);
-    hipLaunchKernelGGL(se_2d_kernel, grid, dim3(256), 0, s, a1, a2, na, na2, b1, b2, nb, nb2, ell1, ell2, out);
+    if (c->gram_fp32) hipLaunchKernelGGL(se_2d_kernel<float>, grid, dim3(256), 0, s, a1, a2, na, na2, b1, b2, nb, nb2, ell1, ell2, out);
+    else hipLaunchKernelGGL(se_2d_kernel<double>, grid, dim3(256), 0, s, a1, a2, na, na2, b1, b2, nb, nb2, ell1, ell2, out);
     GP_HIP(hipGetLastError());
 }
 

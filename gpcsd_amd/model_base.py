@@ -62,10 +62,17 @@ class GPCSDModel:
             return lfp
         return lfp[:, :, sh.local_slice(lfp.shape[2])]
 
+    # "fp32 kernel build + fp64 factor" (BASELINE cfg5): set `model.gram_precision = 32` to evaluate the Gram builders of
+    # this model's fused calls in single precision; everything after the Gram matrices stays fp64.  Default 64 = the reference.
+    gram_precision = 64
+
     def _sync_device(self, need_lfp=True):
         ctx = self._context()
         res = self._resident
         sc = self.spatial_cov
+        if res.get("gram_precision") != self.gram_precision:
+            ctx.set_gram_precision(self.gram_precision)
+            res["gram_precision"] = self.gram_precision
         # time grid: the reference evaluates each temporal covariance on its own `t`; they must agree
         t = self.temporal_cov_list[0].t
         for tc in self.temporal_cov_list[1:]:

@@ -165,6 +165,13 @@ int gpcsd_sample_prior(gpcsd_ctx *ctx, const gpcsd_hparams *hp, int which,
 int gpcsd_whitened_quad(gpcsd_ctx *ctx, const double *Qs, int nx, const double *Qt, int nt, const double *Dvec,
                         const double *resid, int nb, double *out);
 
+/* Precision of the Gram builders (temporal SE / Matern, spatial SE, forward-model weights; covariances.py:50-96,177-232,
+ * 257-305): bits = 64 (default) evaluates them exactly as the reference does; bits = 32 is the "fp32 kernel build + fp64
+ * factor" variant of the fit benchmark: coordinates and hyper-parameters are rounded to float, exp/log/sqrt are
+ * single precision, the result is widened and every later stage (GEMMs, eigensolver, likelihood, gradient) stays fp64.
+ * Applies to the operator entry points and to the fused calls of this context. */
+int gpcsd_set_gram_precision(gpcsd_ctx *ctx, int bits);
+
 /* Folded-basis GEMMs: with mirror-symmetric electrode and time grids (detected in set_geometry / set_time) loglik and predict
  * run their projections (gpcsd1d.py:124-127, 262-279) as half-size products in the symmetric / antisymmetric basis; same
  * results to rounding, half the flops.  on = 0 / 1 switches the path for this context (default 1; GPCSD_NO_FOLD_GEMM=1 in

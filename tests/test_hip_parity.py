@@ -638,3 +638,33 @@ def test_folded_gemm_1d_odd_sizes_vs_oracle():
         assert relerr(csd_f, ref["csd"]) < 1e-6 and relerr(lfp_f, ref["lfp"]) < 1e-6
         for a, b in zip(lst_f, ref["csd_list"]):
             assert relerr(a, b) < 1e-6
+
+
+# ------------------------------------------------------------------------------------------------ fp32 Gram build (cfg5)
+def test_fp32_gram_build_variant(ctx):
+    """BASELINE cfg5 names an "fp32 kernel build + fp64 factor" variant: the Gram builders evaluate in single precision,
+    everything after them stays fp64.  The switch is per context; deviations are those of float rounding of the Gram
+    entries (reported in DESIGN.md), the default path is untouched."""
+    t = np.linspace(0.0, 499.0, 500).reshape(-1, 1)
+    try:
+        K64 = ctx.gram_temporal(C.SE, t, t, 20.0, 0.5) + ctx.gram_temporal(C.MATERN, t, t, 5.0, 0.7)
+        ctx.set_gram_precision(32)
+        K32 = ctx.gram_temporal(C.SE, t, t, 20.0, 0.5) + ctx.gram_temporal(C.MATERN, t, t, 5.0, 0.7)
+    finally:
+        ctx.set_gram_precision(64)
+    dev = np.max(np.abs(K32 - K64)) / np.max(np.abs(K64))
+    assert 1e-10 < dev < 3e-6, dev
+    assert np.array_equal(ctx.gram_temporal(C.SE, t, t, 20.0, 0.5) + ctx.gram_temporal(C.MATERN, t, t, 5.0, 0.7), K64)
+    with pytest.raises(ValueError):
+        ctx.set_gram_precision(16)
+    for name in ("cfg2s_1d_24x500x8", "2d_npx_96x120x3"):
+        m, c, g, geom, hp, lfp = _build_model(name)
+        ll64 = float(m.loglik())
+        m.gram_precision = 32
+        ll32 = float(m.loglik())
+        _, g32 = m._loglik_and_grad_natural()
+        m.gram_precision = 64
+        assert float(m.loglik()) == ll64                       # switching back restores the reference arithmetic bit for bit
+        dev_ll = abs(ll32 - ll64) / abs(ll64)
+        print("fp32 Gram build, %s: loglik deviation %.2e" % (name, dev_ll))
+        assert 0.0 < dev_ll < 1e-3 and np.all(np.isfinite(g32))

@@ -10,9 +10,15 @@ m.update_lfp(lfp, w["t"])
 np.random.seed(0)
 starts = [m._sample_start(False) for _ in range(8)]
 opts = {"maxiter": 15, "disp": False, "gtol": 1e-5, "ftol": 1e7 * np.finfo(float).eps}
-for workers in (1, 2, 4, 8):
-    mm = bench.build_model(w, lfp)
-    t0 = time.perf_counter()
-    mm.fit(n_restarts=8, options=opts, starts=starts, workers=workers)
-    dt = time.perf_counter() - t0
-    print("workers=%d: 8 restarts x <=15 iterations in %.2f s (%.2f restarts/s), best nll %.6f" % (workers, dt, 8 / dt, np.nanmin(mm.fit_nll_values_)), flush=True)
+best = {}
+for bits in (64, 32):                    # 32 = the "fp32 kernel build + fp64 factor" variant of BASELINE cfg5
+    for workers in (1, 2, 4, 8):
+        mm = bench.build_model(w, lfp)
+        mm.gram_precision = bits
+        t0 = time.perf_counter()
+        mm.fit(n_restarts=8, options=opts, starts=starts, workers=workers)
+        dt = time.perf_counter() - t0
+        best[bits] = float(np.nanmin(mm.fit_nll_values_))
+        print("gram fp%d workers=%d: 8 restarts x <=15 iterations in %.2f s (%.2f restarts/s), best nll %.6f"
+              % (bits, workers, dt, 8 / dt, best[bits]), flush=True)
+print("best nll, fp32 Gram build vs fp64: relative deviation %.2e" % (abs(best[32] - best[64]) / abs(best[64])))
