@@ -324,7 +324,9 @@ def _house_Q(V, tau):
     return Q
 
 
-@pytest.mark.parametrize("n", [3, 4, 17, 65, 130, 300])
+# 130: register block only; 193 / 250 / 255: LDS strip in front of it (odd and even tails, no per-column launches);
+# 300: 44 per-column launches, then a full 256-row tail with a pending rank-2 update
+@pytest.mark.parametrize("n", [3, 4, 17, 65, 130, 193, 250, 255, 300])
 def test_sytrd_stage(ctx, n):
     rs = np.random.RandomState(n)
     M = rs.standard_normal((n, n))
@@ -668,3 +670,24 @@ def test_fp32_gram_build_variant(ctx):
         dev_ll = abs(ll32 - ll64) / abs(ll64)
         print("fp32 Gram build, %s: loglik deviation %.2e" % (name, dev_ll))
         assert 0.0 < dev_ll < 1e-3 and np.all(np.isfinite(g32))
+
+
+def test_folded_predict_without_component_lists(ctx):
+    """gpcsd_predict_resident(want_lists=0) on the folded path: only the sum over temporal components is written; it equals
+    the sum of the per-component predictions of a call that asks for the lists."""
+    name = FOLD_CASES[0]
+    m, c, g, geom, hp, lfp = _build_model(name)
+    mctx = m._sync_device()
+    hp0, keep = m._hparams(0.0)
+    nz, nt, R = c["x"].shape[0], c["t"].shape[0], lfp.shape[2]
+    C_ = len(c["temporal"])
+    n0 = mctx.fold_gemm(True)
+    mctx.predict_resident(hp0, c["x"], c["t"], 1, want_lists=True)
+    lists = mctx.fetch("pred_out_csd_list", (C_, nz, nt, R))
+    tot = mctx.fetch("pred_out_csd", (nz, nt, R))
+    mctx.predict_resident(hp0, c["x"], c["t"], 1, want_lists=False)
+    assert mctx.fold_gemm() == n0 + 2
+    tot2 = mctx.fetch("pred_out_csd", (nz, nt, R))
+    assert np.array_equal(tot, tot2)
+    assert relerr(lists.sum(axis=0), tot) < 1e-13
+    assert relerr(tot, g["csd_pred"]) < GATE
