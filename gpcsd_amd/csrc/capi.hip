@@ -316,27 +316,70 @@ EigState front_half(gpcsd_ctx *c, const gpcsd_hparams *hp, double jitter) {
 // once per geometry (Fs Y Ft^T, one HBM pass), every projection becomes two half-size GEMMs (half the flops), D is built
 // from the spectra in fold order.  Needs a scalar noise variance: a per-electrode list is indexed by eigen-RANK in the
 // reference, which only the merged order provides.  GPCSD_NO_FOLD_GEMM=1 switches it off (A/B, tests).
+// One side may be unfolded (GPCSD1D: 24 electrodes go through Jacobi, 500 time points fold): it then takes part as a single
+// "symmetric" block of full size -- its fold operator is the identity (every index a fixed point), U = Q, w = the merged
+// spectrum -- and every kernel and GEMM below runs unchanged; empty antisymmetric blocks are skipped.
 struct FoldMode {
     bool on = false;
-    FoldView fs, ft;
+    FoldView fs, ft;            // .on: the side is really folded; otherwise ns = n, na = 0, U = Q, w = eigenvalues
+    SymDev sym_s, sym_t;        // effective fold tables of the two sides (identity for an unfolded side)
+    int sig() const { return 1 + (fs.on ? 2 : 0) + (ft.on ? 4 : 0); }
 };
+
+// identity "symmetry" of n points: every index its own orbit (fixed point)
+static SymDev identity_sym(gpcsd_ctx *c, int n) {
+    const std::string name = "sym_id_" + std::to_string(n);
+    int *d = c->buf<int>(name, (size_t)4 * n);
+    int &have = c->int_cache[name];
+    if (have != n) {
+        std::vector<int> tbl((size_t)4 * n);
+        for (int i = 0; i < n; ++i) {
+            tbl[i] = i;                  // rep_i
+            tbl[n + i] = i;              // rep_j
+            tbl[2 * n + i] = i;          // orb
+            tbl[3 * n + i] = 0;          // sgn
+        }
+        GP_HIP(hipMemcpyAsync(d, tbl.data(), tbl.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
+        GP_HIP(hipStreamSynchronize(c->stream));
+        have = n;
+    }
+    SymDev sy;
+    sy.ns = n; sy.na = 0;
+    sy.rep_i = d; sy.rep_j = d + n; sy.orb = d + 2 * n; sy.sgn = d + 3 * n;
+    return sy;
+}
 
 static FoldMode fold_mode(gpcsd_ctx *c, const gpcsd_hparams *hp) {
     static const bool off = getenv("GPCSD_NO_FOLD_GEMM") && getenv("GPCSD_NO_FOLD_GEMM")[0] == '1';
     FoldMode fm;
-    if (off || !c->fold_gemm_on || hp->n_sig2n != 1 || c->sym_s.ns == 0 || c->sym_t.ns == 0) return fm;
-    fm.fs = eigh_fold_view(c, 0, &c->sym_s, c->nx);
-    fm.ft = eigh_fold_view(c, 1, &c->sym_t, c->nt);
-    fm.on = fm.fs.on && fm.ft.on;
+    if (off || !c->fold_gemm_on || hp->n_sig2n != 1 || c->nx <= 0 || c->nt <= 0) return fm;
+    if (c->sym_s.ns > 0) fm.fs = eigh_fold_view(c, 0, &c->sym_s, c->nx);
+    if (c->sym_t.ns > 0) fm.ft = eigh_fold_view(c, 1, &c->sym_t, c->nt);
+    if (!fm.fs.on && !fm.ft.on) return fm;
+    fm.on = true;
+    if (fm.fs.on) fm.sym_s = c->sym_s;
+    else {
+        fm.sym_s = identity_sym(c, c->nx);
+        fm.fs.ns = c->nx; fm.fs.na = 0;
+        fm.fs.w = c->buf<double>("es", c->nx);                       // front_half's buffers: merged spectrum / full eigenvectors
+        fm.fs.U = c->buf<double>("Qs", (size_t)c->nx * c->nx);
+    }
+    if (fm.ft.on) fm.sym_t = c->sym_t;
+    else {
+        fm.sym_t = identity_sym(c, c->nt);
+        fm.ft.ns = c->nt; fm.ft.na = 0;
+        fm.ft.w = c->buf<double>("et", c->nt);
+        fm.ft.U = c->buf<double>("Qt", (size_t)c->nt * c->nt);
+    }
     return fm;
 }
 
 // Fs Y Ft^T in the layout of the resident data ([fold x][r][fold t]); rebuilt when data, geometry or time grid change
-static const double *folded_lfp(gpcsd_ctx *c) {
+static const double *folded_lfp(gpcsd_ctx *c, const FoldMode &fm) {
     double *Yf = c->buf<double>("lfp_fold", (size_t)c->nx * c->ntrials * c->nt);
-    if (!c->lfp_fold_valid) {
-        k_fold_lfp(c, c->d_lfp, c->nx, c->ntrials, c->nt, c->sym_s, c->sym_t, Yf, c->stream);
-        c->lfp_fold_valid = true;
+    if (c->lfp_fold_sig != fm.sig()) {                               // 0: invalid; else which sides the resident copy folds
+        k_fold_lfp(c, c->d_lfp, c->nx, c->ntrials, c->nt, fm.sym_s, fm.sym_t, Yf, c->stream);
+        c->lfp_fold_sig = fm.sig();
     }
     return Yf;
 }
@@ -345,6 +388,10 @@ static const double *folded_lfp(gpcsd_ctx *c) {
 // launch -- twice the tiles per launch, so the last partial wave of workgroups weighs half as much -- otherwise as two.
 // Returns true when batched (an EPI_QUAD pair then leaves the whole sum in g0.quad_out, else g1.quad_out holds the rest).
 static bool gemm_pair(gpcsd_ctx *c, GemmDesc g0, const GemmDesc &g1, hipStream_t s) {
+    if (g1.M <= 0 || g1.N <= 0 || g1.K <= 0) {                       // unfolded side: no antisymmetric block
+        gemm_f64(c, g0, s);
+        return true;
+    }
     if (g0.M == g1.M && g0.N == g1.N && g0.K == g1.K && g0.lda == g1.lda && g0.ldb == g1.ldb && g0.ldc == g1.ldc) {
         g0.batch = 2;
         g0.sA = g1.A - g0.A;
@@ -507,7 +554,7 @@ extern "C" int gpcsd_set_lfp(gpcsd_ctx *c, const double *lfp, int nx, int nt, in
     k_swap_last2(c, stage, c->d_lfp, nx, nt, ntrials, c->stream);     // (x,t,r) -> (x,r,t)
     c->sync();
     c->nx = nx; c->nt = nt; c->ntrials = ntrials;
-    c->lfp_fold_valid = false;
+    c->lfp_fold_sig = 0;
     return 0;
     GP_API_END(c)
 }
@@ -524,7 +571,7 @@ extern "C" int gpcsd_set_geometry_1d(gpcsd_ctx *c, const double *x, int nx, cons
     c->sym_s = SymDev();
     c->sym_z = SymDev();
     c->sym_z_pts.clear();
-    c->lfp_fold_valid = false;
+    c->lfp_fold_sig = 0;
     c->geo_host.assign(x, x + nx);
     double ctr;
     if (rule_is_symmetric(gl_x, gl_w, ngl, &ctr)) {
@@ -553,7 +600,7 @@ extern "C" int gpcsd_set_geometry_2d(gpcsd_ctx *c, const double *xy, int nx, con
     c->sym_s = SymDev();
     c->sym_z = SymDev();
     c->sym_z_pts.clear();
-    c->lfp_fold_valid = false;
+    c->lfp_fold_sig = 0;
     c->geo_host.assign(xy, xy + (size_t)nx * 2);
     double ctr[2];
     const bool s1 = rule_is_symmetric(gl_x1, gl_w1, ngl1, &ctr[0]), s2 = rule_is_symmetric(gl_x2, gl_w2, ngl2, &ctr[1]);
@@ -575,7 +622,7 @@ extern "C" int gpcsd_set_time(gpcsd_ctx *c, const double *t, int nt) {
     c->sync();
     c->time_nt = nt;
     c->time_host.assign(t, t + nt);
-    c->lfp_fold_valid = false;
+    c->lfp_fold_sig = 0;
     // a time grid symmetric about its midpoint (any uniform grid) makes every stationary Kt centro-symmetric
     double lo = t[0], hi = t[0];
     for (int i = 1; i < nt; ++i) {
@@ -1017,7 +1064,7 @@ extern "C" int gpcsd_loglik_parts(gpcsd_ctx *c, const gpcsd_hparams *hp, double 
     GP_REQUIRE(out2 != nullptr, -3, "null output");
     GP_REQUIRE(c->d_lfp != nullptr, -4, "lfp not set (call gpcsd_set_lfp)");
     const FoldMode fm = fold_mode(c, hp);                           // before the front half: first use allocates
-    const double *Yf = fm.on ? folded_lfp(c) : nullptr;
+    const double *Yf = fm.on ? folded_lfp(c, fm) : nullptr;
     EigState e = front_half(c, hp, hp->jitter);
     const int nx = c->nx, nt = c->nt, R = c->ntrials;
     hipStream_t s = c->stream;
@@ -1113,9 +1160,10 @@ static int predict_fold(gpcsd_ctx *c, const gpcsd_hparams *hp, EigState &e, cons
         if (!(type & which)) continue;
         if (which == 1) build_kphig(c, g, hp->R, hp->eps, hp->ell_s, dz, nz, Kc, s);        // gpcsd1d.py:273
         else build_kphi(c, g, hp->R, hp->eps, hp->ell_s, dz, nz, 0.0, Kc, s);               // gpcsd1d.py:275
-        k_sym_fold_rect(c, Kc, nz, c->sym_s, sz, Kcf, Kcf + (size_t)ns * nzs, s);
+        k_sym_fold_rect(c, Kc, nz, fm.sym_s, sz, Kcf, Kcf + (size_t)ns * nzs, s);
         for (int p = 0; p < 2; ++p) {
             const int np = p ? na : ns, nzp = p ? nza : nzs;
+            if (np == 0 || nzp == 0) continue;
             GemmDesc gm;                  // M1_p[zq][x'] = sum_xq Kc~_pp[xq][zq] U_p[xq][x']
             gm.M = nzp; gm.N = np; gm.K = np;
             gm.A = Kcf + (p ? (size_t)ns * nzs : 0); gm.lda = nzp; gm.transA = true;
@@ -1127,7 +1175,7 @@ static int predict_fold(gpcsd_ctx *c, const gpcsd_hparams *hp, EigState &e, cons
     }
     for (int cc = 0; cc < C; ++cc) {
         k_temporal_gram(c, 1, &hp->kind[cc], &hp->ell_t[cc], &hp->sigma2_t[cc], dts, nt, t, nt, Kts + (size_t)cc * nt * nt, s);
-        k_sym_fold_rect(c, Kts + (size_t)cc * nt * nt, nt, c->sym_t, c->sym_t, Ktf + cc * ktf_sz,
+        k_sym_fold_rect(c, Kts + (size_t)cc * nt * nt, nt, fm.sym_t, fm.sym_t, Ktf + cc * ktf_sz,
                         Ktf + cc * ktf_sz + (size_t)nts * nts, s);
     }
     join_temporal(c, e, &fm);
@@ -1144,6 +1192,7 @@ static int predict_fold(gpcsd_ctx *c, const gpcsd_hparams *hp, EigState &e, cons
     gemm_pair(c, g2[0], g2[1], s);
     for (int p = 0; p < 2; ++p) {
         const int np = p ? nta : nts;
+        if (np == 0) continue;
         GemmDesc gp;                      // Pcat_p[i'][cc*np + b] = sum_j V_p[j][i'] Kt*~_cc,pp[j][b], all components batched
         gp.M = np; gp.N = np; gp.K = np;
         gp.A = fm.ft.U + (p ? (size_t)nts * nts : 0); gp.lda = np; gp.transA = true;
@@ -1177,7 +1226,7 @@ static int predict_fold(gpcsd_ctx *c, const gpcsd_hparams *hp, EigState &e, cons
             g6[p].prof_name = "gemm_pred_tstar";
         }
         gemm_pair(c, g6[0], g6[1], s);
-        k_unfold_swap_sum(c, comp, C, o_list, (long)out_elems, o_sum, R, nt, sz, c->sym_t, s);
+        k_unfold_swap_sum(c, comp, C, o_list, (long)out_elems, o_sum, R, nt, sz, fm.sym_t, s);
     }
     return finish_call(c, e, nullptr, 0);
 }
@@ -1195,11 +1244,15 @@ static int predict_impl(gpcsd_ctx *c, const gpcsd_hparams *hp, const double *z, 
     GP_REQUIRE(c->d_lfp != nullptr, -4, "lfp not set (call gpcsd_set_lfp)");
     // folded basis when the grids, the prediction sites and the prediction times all share the reflection symmetries
     const FoldMode fm = fold_mode(c, hp);
-    if (fm.on && ntstar == c->nt && (int)c->time_host.size() == c->nt &&
-        memcmp(c->time_host.data(), tstar, (size_t)ntstar * sizeof(double)) == 0) {
-        const SymDev &sz = site_symmetry(c, z, nz, c->dim);
+    // a folded side needs its outputs on a grid with the same symmetry (t* = t; mirror-symmetric sites); an unfolded side
+    // takes any sites / times
+    const bool t_ok = fm.on && ntstar == c->nt &&
+                      (!fm.ft.on || ((int)c->time_host.size() == c->nt &&
+                                     memcmp(c->time_host.data(), tstar, (size_t)ntstar * sizeof(double)) == 0));
+    if (t_ok) {
+        const SymDev sz = fm.fs.on ? site_symmetry(c, z, nz, c->dim) : identity_sym(c, nz);
         if (sz.ns > 0 && sz.ns + sz.na == nz) {
-            const double *Yf = folded_lfp(c);
+            const double *Yf = folded_lfp(c, fm);
             double *dzf = c->upload_cached<double>("pred_z", z, (size_t)nz * c->dim);
             double *dtf = c->upload_cached<double>("pred_tstar", tstar, ntstar);
             EigState ef = front_half(c, hp, 0.0);  // no jitter in predict (gpcsd1d.py:258)

@@ -112,7 +112,7 @@ struct gpcsd_ctx {
     bool sym_s_refl[2] = {false, false};
     std::vector<double> geo_host, time_host, sym_z_pts;
     gpcsd::SymDev sym_z;
-    bool lfp_fold_valid = false;
+    int lfp_fold_sig = 0;                   // 0: the folded copy of the data is stale; else FoldMode::sig() it was built for
     bool gram_fp32 = false;                 // gpcsd_set_gram_precision(): Gram builders evaluate in float (cfg5 variant)
     bool fold_gemm_on = true;               // gpcsd_fold_gemm()
     long fold_gemm_calls = 0;

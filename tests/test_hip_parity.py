@@ -531,7 +531,8 @@ def test_fit_concurrent_restarts_match_sequential():
 
 
 # ------------------------------------------------------------------------------------------------ folded-basis GEMMs
-FOLD_CASES = [n for n in MODEL_CASES if C.model_cases()[n]["x"].shape[0] > 64 and C.model_cases()[n]["t"].shape[0] > 64
+# both sides fold (2D probes with > 64 sites) or only the temporal one (GPCSD1D: 24 electrodes go through Jacobi)
+FOLD_CASES = [n for n in MODEL_CASES if (C.model_cases()[n]["x"].shape[0] > 64 or C.model_cases()[n]["t"].shape[0] > 64)
               and np.ndim(C.model_cases()[n]["sig2n"]) == 0]
 
 
@@ -567,7 +568,7 @@ def test_folded_gemm_path_matches_unfolded(name):
 def test_folded_gemm_falls_back_when_symmetry_is_missing():
     """Prediction sites without the electrodes' mirror symmetry, prediction times other than the training grid, or a
     per-electrode noise list (indexed by eigen-rank in the reference) take the full-size path; results agree with it."""
-    name = FOLD_CASES[0]
+    name = "2d_npx_96x120x3"                                          # both sides folded: both output grids are constrained
     m, c, g, geom, hp, lfp = _build_model(name)
     ctx = m._context()
     ctx.fold_gemm(True)
@@ -691,3 +692,26 @@ def test_folded_predict_without_component_lists(ctx):
     assert np.array_equal(tot, tot2)
     assert relerr(lists.sum(axis=0), tot) < 1e-13
     assert relerr(tot, g["csd_pred"]) < GATE
+
+
+def test_one_sided_fold_takes_any_prediction_sites():
+    """GPCSD1D with 24 electrodes: only the temporal side folds, the spatial one takes part as one full-size block, so the
+    folded path serves arbitrary (asymmetric, finer) prediction sites; it still needs t* = t."""
+    m, c, g, geom, hp, lfp = _build_model("cfg2s_1d_24x500x8")
+    ctx = m._context()
+    ctx.fold_gemm(True)
+    x, t = c["x"], c["t"]
+    z = np.linspace(float(x.min()) + 13.0, float(x.max()) - 111.0, 31).reshape(-1, 1)     # not mirror-symmetric, nz != nx
+    n0 = ctx.fold_gemm()
+    m.predict(z, t, type="both")
+    assert ctx.fold_gemm() == n0 + 1
+    csd_f, lfp_f = m.csd_pred.copy(), m.lfp_pred.copy()
+    ctx.fold_gemm(False)
+    m.predict(z, t, type="both")
+    ctx.fold_gemm(True)
+    assert relerr(csd_f, m.csd_pred) < 1e-10 and relerr(lfp_f, m.lfp_pred) < 1e-10
+    ref = O.predict(geom, hp, lfp, z, t, type="both")
+    assert relerr(csd_f, ref["csd"]) < GATE and relerr(lfp_f, ref["lfp"]) < GATE
+    n1 = ctx.fold_gemm()
+    m.predict(z, t + 0.25, type="csd")                                # shifted prediction times: full-size path
+    assert ctx.fold_gemm() == n1
