@@ -33,7 +33,8 @@ struct StedcProb {
     double *w, *Z;
     std::string tag;
 };
-void stedc_batch_device(gpcsd_ctx *c, StedcProb *probs, int count, int *d_status, hipStream_t s);
+// wy != nullptr: the leaf launch also forms the T factors of these back-transformations (wy_batch_device: prep_done)
+void stedc_batch_device(gpcsd_ctx *c, StedcProb *probs, int count, int *d_status, hipStream_t s, const WyBatch *wy = nullptr);
 
 // ------------------------------------------------------------------------------------------------------------------
 // stage 0: scaling  A0 = A / max|A|   (two launches: per-workgroup partial maxima, then scale + final maximum)
@@ -608,20 +609,10 @@ void eigh_large_batch(gpcsd_ctx *c, EigProb *probs, int count, int *d_status, hi
         ProfScope ps(c, "eigh_sytrd", 0.0, s);
         sytrd_batch_launch(c, b, count, nmax, s);
     }
-    {
-        ProfScope ps(c, "eigh_stedc", 0.0, s);
-        StedcProb sp[MAX_BATCH];
-        for (int i = 0; i < count; ++i) {
-            sp[i].d = probs[i].sp.d; sp[i].e = probs[i].sp.e; sp[i].n = probs[i].n;
-            sp[i].w = probs[i].w; sp[i].Z = probs[i].Z; sp[i].tag = probs[i].tag;
-        }
-        stedc_batch_device(c, sp, count, d_status, s);
-    }
-    // The back-transformations are independent chains of small GEMMs: fork one branch per problem (parallel branches
-    // of the captured graph; concurrent streams when run eagerly) and join.
-    if (wy_fused_supported(nmax)) {
-        ProfScope ps(c, "eigh_backtransform", 0.0, s);
-        WyBatch wb;
+    const bool wy_fused = wy_fused_supported(nmax);
+    static const bool wy_in_leaf = !(getenv("GPCSD_WY_IN_LEAF") && getenv("GPCSD_WY_IN_LEAF")[0] == '0');
+    WyBatch wb;
+    if (wy_fused)
         for (int i = 0; i < count; ++i) {
             EigProb &p = probs[i];
             const int nrefl = p.n - 2, P = ceil_div(nrefl, WY_NB);
@@ -629,7 +620,25 @@ void eigh_large_batch(gpcsd_ctx *c, EigProb *probs, int count, int *d_status, hi
             wb.p[i].T = c->buf<double>("eig_" + p.tag + "_wyT", (size_t)P * WY_NB * WY_NB);
             wb.p[i].n = p.n; wb.p[i].npanels = P; wb.p[i].nrefl = nrefl;
         }
-        wy_batch_device(c, wb, count, s);
+    bool prep_done = false;
+    {
+        ProfScope ps(c, "eigh_stedc", 0.0, s);
+        StedcProb sp[MAX_BATCH];
+        for (int i = 0; i < count; ++i) {
+            sp[i].d = probs[i].sp.d; sp[i].e = probs[i].sp.e; sp[i].n = probs[i].n;
+            sp[i].w = probs[i].w; sp[i].Z = probs[i].Z; sp[i].tag = probs[i].tag;
+        }
+        // the T factors of the back-transformation need the reflectors only: they ride in the leaf launch of the D&C stage
+        // (GPCSD_WY_IN_LEAF=0: their own launch after it; GPCSD_DC_LEAF=lds has no combined kernel either)
+        static const bool lds_leaf = getenv("GPCSD_DC_LEAF") && !strcmp(getenv("GPCSD_DC_LEAF"), "lds");
+        prep_done = wy_fused && wy_in_leaf && !lds_leaf;
+        stedc_batch_device(c, sp, count, d_status, s, prep_done ? &wb : nullptr);
+    }
+    // The back-transformations are independent chains of small GEMMs: fork one branch per problem (parallel branches
+    // of the captured graph; concurrent streams when run eagerly) and join.
+    if (wy_fused) {
+        ProfScope ps(c, "eigh_backtransform", 0.0, s);
+        wy_batch_device(c, wb, count, s, prep_done);
         hipLaunchKernelGGL(scale_vec_batch_kernel, dim3(ceil_div(nmax, 256), count), dim3(256), 0, s, pb);
     } else {
         ProfScope ps(c, "eigh_backtransform", 0.0, s);

@@ -117,7 +117,8 @@ struct WyBatch {
     WyProb p[MAX_EIG_BATCH];
 };
 bool wy_fused_supported(int nmax);
-void wy_batch_device(gpcsd_ctx *c, const WyBatch &b, int count, hipStream_t s);
+// prep_done: the T factors were already formed by the D&C leaf launch (stedc_batch_device with a WyBatch)
+void wy_batch_device(gpcsd_ctx *c, const WyBatch &b, int count, hipStream_t s, bool prep_done = false);
 // stages of the large-n solver, exposed for tests / diagnostics
 void sytrd_device(gpcsd_ctx *c, double *A, int n, double *d, double *e, double *V, double *tau, hipStream_t s);
 void stedc_device(gpcsd_ctx *c, const double *d, const double *e, int n, double *w, double *Z, int *d_status,

@@ -20,6 +20,7 @@
 #include "devutil.hpp"
 #include "jacobi.hpp"
 #include "kernels.hpp"
+#include "wy_prep.hpp"
 
 namespace gpcsd {
 
@@ -110,25 +111,28 @@ __device__ __forceinline__ int rr_partner8(int x, int step7) {        // partner
 // outside the row's own leaf block (a merge reads the off-diagonal blocks between its halves, which no level writes).
 // The Cuppen tears are applied here as well: every leaf boundary is the boundary of some merge, so the first / last
 // diagonal entry of a leaf loses |e| of the coupling it was cut from.  One launch instead of tear + leaf.
-__global__ __launch_bounds__(64) void dc_leaf_reg_kernel(DcLevel L, int *status, int nleaf_max) {
-    const DcWork &w = L.w[blockIdx.y];
-    const int n = w.n, nleaf = L.aux[blockIdx.y];
-    if ((int)blockIdx.x >= nleaf_max) {
-        const int r = (int)blockIdx.x - nleaf_max;
+// One wave = one unit of work: bx < nleaf_max is a leaf, bx - nleaf_max a row to zero-fill; no barriers, no LDS, so the
+// body runs as a 64-thread workgroup (dc_leaf_reg_kernel) or as one wave of a larger one (dc_leaf_wyprep_kernel).
+__device__ __forceinline__ void dc_leaf_reg_body(const DcLevel &L, int *status, const int nleaf_max, const int bx, const int by,
+                                                 const int lane) {
+    const DcWork &w = L.w[by];
+    const int n = w.n, nleaf = L.aux[by];
+    if (bx >= nleaf_max) {
+        const int r = bx - nleaf_max;
         if (r >= n) return;
         int lf = 0;
         while (lf + 1 < nleaf && w.tbl[lf + 1] <= r) ++lf;          // wave-uniform scan of <= 128 leaf bounds
         const int blo = w.tbl[lf], bhi = w.tbl[lf + 1];
-        for (int cidx = threadIdx.x; cidx < n; cidx += 64) {
+        for (int cidx = lane; cidx < n; cidx += 64) {
             if (cidx < blo || cidx >= bhi) w.Qcur[(long)r * n + cidx] = 0.0;
             w.Qnext[(long)r * n + cidx] = 0.0;
         }
         return;
     }
-    if ((int)blockIdx.x >= nleaf) return;
-    const int lo = w.tbl[blockIdx.x], hi = w.tbl[blockIdx.x + 1];
+    if (bx >= nleaf) return;
+    const int lo = w.tbl[bx], hi = w.tbl[bx + 1];
     const int m = hi - lo;
-    const int lane = threadIdx.x, i = lane >> 3, j = lane & 7;
+    const int i = lane >> 3, j = lane & 7;
     double a = 0.0;
     if (i < m && j < m) {
         if (i == j) {
@@ -193,6 +197,24 @@ __global__ __launch_bounds__(64) void dc_leaf_reg_kernel(DcLevel L, int *status,
         w.Qcur[(long)(lo + i) * n + lo + rank] = v;
     }
     if (lane == 0 && !converged) atomicMax(status, 1);
+}
+
+__global__ __launch_bounds__(64) void dc_leaf_reg_kernel(DcLevel L, int *status, int nleaf_max) {
+    dc_leaf_reg_body(L, status, nleaf_max, (int)blockIdx.x, (int)blockIdx.y, (int)threadIdx.x);
+}
+
+// The leaf launch with a second role: workgroups x < nprep form the T factors of the compact-WY panels of the
+// back-transformation (wy_prep.hpp) -- they depend on the reflectors only, i.e. on the same predecessor as the leaves, and
+// would otherwise be a 35 us launch of their own later in the chain; the others run sixteen leaf / zero-fill units each.
+__global__ __launch_bounds__(1024) void dc_leaf_wyprep_kernel(DcLevel L, int *status, int nleaf_max, int nunits, WyBatch wb,
+                                                              int nprep) {
+    if ((int)blockIdx.x < nprep) {
+        wy_prep_body(wb.p[blockIdx.y], (int)blockIdx.x, (int)threadIdx.x);
+        return;
+    }
+    const int bx = ((int)blockIdx.x - nprep) * 16 + ((int)threadIdx.x >> 6);
+    if (bx >= nunits) return;
+    dc_leaf_reg_body(L, status, nleaf_max, bx, (int)blockIdx.y, (int)threadIdx.x & 63);
 }
 
 // one wave per leaf: dense leaf matrix in LDS -> Jacobi -> dcur[lo:hi], Qcur diagonal block
@@ -1117,7 +1139,7 @@ static DcWork make_work(gpcsd_ctx *c, const StedcProb &p, const DcPlan &plan, hi
     return w;
 }
 
-void stedc_batch_device(gpcsd_ctx *c, StedcProb *probs, int count, int *d_status, hipStream_t s) {
+void stedc_batch_device(gpcsd_ctx *c, StedcProb *probs, int count, int *d_status, hipStream_t s, const WyBatch *wy) {
     GP_REQUIRE(count >= 1 && count <= MAX_BATCH, -3, "stedc batch size %d outside [1,%d]", count, MAX_BATCH);
     std::vector<DcPlan> plans;
     DcLevel L{};
@@ -1144,7 +1166,15 @@ void stedc_batch_device(gpcsd_ctx *c, StedcProb *probs, int count, int *d_status
         hipLaunchKernelGGL(dc_leaf_kernel, dim3(max_leaves, count), dim3(64), 0, s, L, d_status);
     } else {
         for (int p = 0; p < count; ++p) L.aux[p] = (int)plans[p].leaf_lo.size() - 1;
-        hipLaunchKernelGGL(dc_leaf_reg_kernel, dim3(max_leaves + nmax, count), dim3(64), 0, s, L, d_status, max_leaves);
+        if (wy) {                              // the T factors of the back-transformation ride in the leaf launch
+            int nprep = 0;
+            for (int p = 0; p < count; ++p) nprep = std::max(nprep, wy->p[p].npanels);
+            const int nunits = max_leaves + nmax;
+            hipLaunchKernelGGL(dc_leaf_wyprep_kernel, dim3(nprep + ceil_div(nunits, 16), count), dim3(1024), 0, s, L, d_status,
+                               max_leaves, nunits, *wy, nprep);
+        } else {
+            hipLaunchKernelGGL(dc_leaf_reg_kernel, dim3(max_leaves + nmax, count), dim3(64), 0, s, L, d_status, max_leaves);
+        }
     }
     GP_HIP(hipGetLastError());
 
@@ -1233,7 +1263,7 @@ void stedc_device(gpcsd_ctx *c, const double *d, const double *e, int n, double 
                   hipStream_t s, const char *tag) {
     StedcProb p;
     p.d = d; p.e = e; p.n = n; p.w = wout; p.Z = Zout; p.tag = tag ? tag : "";
-    stedc_batch_device(c, &p, 1, d_status, s);
+    stedc_batch_device(c, &p, 1, d_status, s, nullptr);
 }
 
 }  // namespace gpcsd

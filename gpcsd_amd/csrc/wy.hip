@@ -12,79 +12,15 @@
 
 #include "devutil.hpp"
 #include "kernels.hpp"
+#include "wy_prep.hpp"
 
 namespace gpcsd {
 
-typedef double d4 __attribute__((ext_vector_type(4)));
-
-constexpr int WY_NB = 64;
 constexpr int WY_ZC = 16;             // columns of Z per workgroup (one MFMA fragment wide)
 constexpr int WY_LD = WY_ZC + 2;      // LDS row stride: 18*i mod 32 gives distinct even slots for the b64 fragment reads
-constexpr int WY_KC = 64;             // K chunk of a panel staged through LDS by the preparation kernel
 
-// G = V_p V_p^T (16 waves, one 16x16 fragment each), then T by back substitution (4 columns per wave).
-__global__ __launch_bounds__(1024) void wy_prep_kernel(WyBatch b) {
-    const WyProb &P = b.p[blockIdx.y];
-    const int p = blockIdx.x;
-    if (p >= P.npanels) return;
-    const int n = P.n;
-    __shared__ double g[WY_NB][WY_NB + 1];
-    __shared__ double st[WY_NB];
-    __shared__ double vs[WY_NB][WY_KC + 2];                // one K chunk of the panel, [reflector][k], stride = 2 mod 32
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int fr = lane & 15, fq = lane >> 4;
-    const double *__restrict__ Vp = P.V + (long)p * WY_NB * n;
-    {
-        // G = V_p V_p^T.  The panel is staged through LDS in chunks of WY_KC columns with coalesced loads (the direct
-        // version issued one dependent L2 round trip per MFMA step: 63 of them at n = 250).
-        const int fa = wid >> 2, fb = wid & 3;
-        d4 acc = {0.0, 0.0, 0.0, 0.0};
-        const int kstart = (p * WY_NB) & ~3;               // reflector k is zero up to column k
-        for (int kc = kstart; kc < n; kc += WY_KC) {
-            __syncthreads();
-            for (int idx = tid; idx < WY_NB * WY_KC; idx += 1024) {
-                const int r = idx / WY_KC, k = idx % WY_KC;
-                vs[r][k] = (kc + k < n) ? Vp[(long)r * n + kc + k] : 0.0;
-            }
-            __syncthreads();
-#pragma unroll 4
-            for (int k0 = 0; k0 < WY_KC; k0 += 4)
-                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(vs[16 * fa + fr][k0 + fq], vs[16 * fb + fr][k0 + fq], acc, 0, 0, 0);
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) g[16 * fa + fq + 4 * r][16 * fb + fr] = acc[r];
-    }
-    if (tid < WY_NB) {
-        const int kk = p * WY_NB + tid;
-        st[tid] = (kk < P.nrefl) ? P.tau[kk] : 0.0;
-    }
-    __syncthreads();
-    // column c of T solves (diag(1/tau) + striu(G)) x = e_c; lane l carries the running right-hand side b_l.  The four
-    // columns of a wave are independent chains walked together (j runs over the longest), lane reads stay in the VALU.
-    {
-        const int cb = wid * 4;
-        double bv[4], x[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            bv[q] = (lane == cb + q) ? 1.0 : 0.0;
-            x[q] = 0.0;
-        }
-        for (int j = cb + 3; j >= 0; --j) {
-            const double tj = st[j], gj = g[lane][j];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                if (j <= cb + q) {                         // wave-uniform
-                    const double xj = tj * lane_get(bv[q], j);
-                    if (lane == j) x[q] = xj;
-                    if (lane < j) bv[q] -= gj * xj;
-                }
-            }
-        }
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-            P.T[(long)p * WY_NB * WY_NB + (long)lane * WY_NB + cb + q] = (lane <= cb + q) ? x[q] : 0.0;
-    }
-}
+// G = V_p V_p^T (16 waves, one 16x16 fragment each), then T by back substitution (4 columns per wave): wy_prep.hpp
+__global__ __launch_bounds__(1024) void wy_prep_kernel(WyBatch b) { wy_prep_body(b.p[blockIdx.y], blockIdx.x, threadIdx.x); }
 
 // one workgroup = 16 columns of Z resident in LDS, all panels applied in sequence
 __global__ __launch_bounds__(256) void wy_apply_kernel(WyBatch b) {
@@ -198,7 +134,7 @@ __global__ __launch_bounds__(256) void wy_apply_kernel(WyBatch b) {
 
 bool wy_fused_supported(int nmax) { return ((size_t)nmax * WY_LD + 2 * WY_NB * WY_LD) * sizeof(double) <= 160 * 1024; }
 
-void wy_batch_device(gpcsd_ctx *c, const WyBatch &b, int count, hipStream_t s) {
+void wy_batch_device(gpcsd_ctx *c, const WyBatch &b, int count, hipStream_t s, bool prep_done) {
     int maxP = 0, nmax = 0;
     for (int i = 0; i < count; ++i) {
         maxP = std::max(maxP, b.p[i].npanels);
@@ -212,7 +148,7 @@ void wy_batch_device(gpcsd_ctx *c, const WyBatch &b, int count, hipStream_t s) {
                                    160 * 1024));
         attr_set = true;
     }
-    hipLaunchKernelGGL(wy_prep_kernel, dim3(maxP, count), dim3(1024), 0, s, b);
+    if (!prep_done) hipLaunchKernelGGL(wy_prep_kernel, dim3(maxP, count), dim3(1024), 0, s, b);
     hipLaunchKernelGGL(wy_apply_kernel, dim3(ceil_div(nmax, WY_ZC), count), dim3(256), sh, s, b);
     GP_HIP(hipGetLastError());
 }
