@@ -217,11 +217,11 @@ bool rule_is_symmetric(const double *gx, const double *gw, int n, double *centre
 // Inputs Ks, Kt are destroyed.  Outputs: Qs, es, Qt, et, D, sumlog (device).
 void eig_pair_D(gpcsd_ctx *c, double *Ks, int nx, double *Kt, int nt, const double *d_sig, int nsig, double *Qs, double *es,
                 double *Qt, double *et, double *D, double *Dinv, double *d_sumlog, int *d_status, const SymDev *sym_s = nullptr,
-                const SymDev *sym_t = nullptr) {
+                const SymDev *sym_t = nullptr, bool need_merged = true) {
     {
         // all problems share every launch of the per-column tridiagonalisation (batched), so one stream suffices
         ProfScope ps(c, "eigh_pair", 9.0 * ((double)nx * nx * nx + (double)nt * nt * nt), c->stream);
-        eigh_pair_device(c, Ks, nx, es, Qs, sym_s, Kt, nt, et, Qt, sym_t, d_status, c->stream);
+        eigh_pair_device(c, Ks, nx, es, Qs, sym_s, Kt, nt, et, Qt, sym_t, d_status, c->stream, need_merged);
     }
     k_build_D(c, es, nx, et, nt, d_sig, nsig, D, Dinv, d_sumlog, c->stream);
 }
@@ -248,7 +248,10 @@ static bool two_stream_front() {            // GPCSD_TWO_STREAM=0: single batche
 // (three GEMMs, ~0.2 ms at 384 electrodes) and decomposes it; the caller then keeps working on the main stream with Qs
 // alone (the spatial projection W = Qs^T Y, ~0.15 ms) and calls join_temporal() right before the first use of
 // Qt / et / D.  At cfg3 the temporal chain (1.2 ms) is the critical path and everything spatial hides behind it.
-EigState front_half(gpcsd_ctx *c, const gpcsd_hparams *hp, double jitter) {
+// need_merged = false: the caller runs the folded-basis GEMMs and never reads the merged Qs / Qt / es / et of a folded side
+// (one small launch less at the end of each chain).  NOTE: D from the single-stream front half is then in merged order of
+// stale spectra -- such callers rebuild it in fold order (join_temporal with a FoldMode).
+EigState front_half(gpcsd_ctx *c, const gpcsd_hparams *hp, double jitter, bool need_merged = true) {
     const Geo g = resident_geo(c);
     GP_REQUIRE(c->d_lfp != nullptr, -4, "lfp not set (call gpcsd_set_lfp)");
     GP_REQUIRE(c->time_nt == c->nt, -4, "time grid has %d points but lfp has nt=%d", c->time_nt, c->nt);
@@ -276,7 +279,8 @@ EigState front_half(gpcsd_ctx *c, const gpcsd_hparams *hp, double jitter) {
         build_kphi(c, g, hp->R, hp->eps, hp->ell_s, nullptr, 0, jitter, Ks, s);
         build_kt(c, hp, t, nt, t, nt, Kt, s);
         // the symmetries come from the resident geometry / time grid, so they hold for the Grams built from them
-        eig_pair_D(c, Ks, nx, Kt, nt, d_sig, hp->n_sig2n, e.Qs, e.es, e.Qt, e.et, e.D, e.Dinv, e.scal, e.status, sym_s, sym_t);
+        eig_pair_D(c, Ks, nx, Kt, nt, d_sig, hp->n_sig2n, e.Qs, e.es, e.Qt, e.et, e.D, e.Dinv, e.scal, e.status, sym_s, sym_t,
+                   need_merged);
         e.d_sig = d_sig;
         e.nsig = hp->n_sig2n;
         return e;
@@ -291,7 +295,7 @@ EigState front_half(gpcsd_ctx *c, const gpcsd_hparams *hp, double jitter) {
     build_kt(c, hp, t, nt, t, nt, Kt, s2);
     {
         ProfScope ps(c, "eigh_temporal", 9.0 * (double)nt * nt * nt, s2);
-        eigh_pair_device(c, nullptr, 0, nullptr, nullptr, nullptr, Kt, nt, e.et, e.Qt, sym_t, e.status + 1, s2);
+        eigh_pair_device(c, nullptr, 0, nullptr, nullptr, nullptr, Kt, nt, e.et, e.Qt, sym_t, e.status + 1, s2, need_merged);
     }
     GP_HIP(hipEventRecord(c->ev_join, s2));
     double *d_sig = c->upload_cached<double>("sig2n", hp->sig2n, hp->n_sig2n);
@@ -299,7 +303,7 @@ EigState front_half(gpcsd_ctx *c, const gpcsd_hparams *hp, double jitter) {
     build_kphi(c, g, hp->R, hp->eps, hp->ell_s, nullptr, 0, jitter, Ks, s);
     {
         ProfScope ps(c, "eigh_spatial", 9.0 * (double)nx * nx * nx, s);
-        eigh_pair_device(c, Ks, nx, e.es, e.Qs, sym_s, nullptr, 0, nullptr, nullptr, nullptr, e.status, s);
+        eigh_pair_device(c, Ks, nx, e.es, e.Qs, sym_s, nullptr, 0, nullptr, nullptr, nullptr, e.status, s, need_merged);
     }
     e.pending = true;
     e.d_sig = d_sig;
@@ -1065,7 +1069,7 @@ extern "C" int gpcsd_loglik_parts(gpcsd_ctx *c, const gpcsd_hparams *hp, double 
     GP_REQUIRE(c->d_lfp != nullptr, -4, "lfp not set (call gpcsd_set_lfp)");
     const FoldMode fm = fold_mode(c, hp);                           // before the front half: first use allocates
     const double *Yf = fm.on ? folded_lfp(c, fm) : nullptr;
-    EigState e = front_half(c, hp, hp->jitter);
+    EigState e = front_half(c, hp, hp->jitter, !fm.on);
     const int nx = c->nx, nt = c->nt, R = c->ntrials;
     hipStream_t s = c->stream;
     double *W = c->buf<double>("proj_W", (size_t)nx * R * nt);
@@ -1255,7 +1259,7 @@ static int predict_impl(gpcsd_ctx *c, const gpcsd_hparams *hp, const double *z, 
             const double *Yf = folded_lfp(c, fm);
             double *dzf = c->upload_cached<double>("pred_z", z, (size_t)nz * c->dim);
             double *dtf = c->upload_cached<double>("pred_tstar", tstar, ntstar);
-            EigState ef = front_half(c, hp, 0.0);  // no jitter in predict (gpcsd1d.py:258)
+            EigState ef = front_half(c, hp, 0.0, false);  // no jitter in predict (gpcsd1d.py:258)
             return predict_fold(c, hp, ef, fm, Yf, sz, dzf, nz, dtf, type, want_lists);
         }
     }

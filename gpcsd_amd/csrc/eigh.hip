@@ -166,7 +166,7 @@ FoldView eigh_fold_view(gpcsd_ctx *c, int slot, const SymDev *sy, int n) {
 }
 
 static void eigh_pair_enqueue(gpcsd_ctx *c, double *A0, int n0, double *w0, double *Z0, const SymDev *sym0, double *A1, int n1,
-                              double *w1, double *Z1, const SymDev *sym1, int *d_status, hipStream_t s) {
+                              double *w1, double *Z1, const SymDev *sym1, int *d_status, hipStream_t s, bool need_merged) {
     double *A[2] = {A0, A1}, *w[2] = {w0, w1}, *Z[2] = {Z0, Z1};
     const int n[2] = {n0, n1};
     const SymDev *sym[2] = {sym0, sym1};
@@ -211,8 +211,9 @@ static void eigh_pair_enqueue(gpcsd_ctx *c, double *A0, int n0, double *w0, doub
         }
     }
     if (nlarge) eigh_large_multi(c, large, nlarge, d_status, s);
+    // need_merged == false: the caller stays in the folded basis (eigh_fold_view) and never reads w / Z of a folded problem
     for (int p = 0; p < 2; ++p)
-        if (fold[p].on)
+        if (fold[p].on && need_merged)
             hipLaunchKernelGGL(sym_unfold_kernel, dim3(n[p]), dim3(256), 0, s, n[p], *sym[p], (const double *)fold[p].ws,
                                (const double *)fold[p].Us, (const double *)fold[p].wa, (const double *)fold[p].Ua, w[p], Z[p]);
     GP_HIP(hipGetLastError());
@@ -222,19 +223,19 @@ static void eigh_pair_enqueue(gpcsd_ctx *c, double *A0, int n0, double *w0, doub
 // device), so it replays as a hipGraph: first call eager (allocates workspaces), second call captured, later calls
 // replayed.  A graph is retired whenever any context buffer is (re)allocated, since it holds raw device pointers.
 void eigh_pair_device(gpcsd_ctx *c, double *A0, int n0, double *w0, double *Z0, const SymDev *sym0, double *A1, int n1,
-                      double *w1, double *Z1, const SymDev *sym1, int *d_status, hipStream_t s) {
+                      double *w1, double *Z1, const SymDev *sym1, int *d_status, hipStream_t s, bool need_merged) {
     GP_REQUIRE(n0 <= JACOBI_MAX_N && n1 <= JACOBI_MAX_N, -3, "eigh: n=%d/%d exceeds %d", n0, n1, JACOBI_MAX_N);
     const bool any_large = !force_jacobi() && (n0 > JACOBI_LDS_MAX || n1 > JACOBI_LDS_MAX);
     // GPCSD_PROF_GRAPH=1: keep replaying graphs while profiling, so the outer scopes time the chains as they run in production
     static const bool prof_graph = getenv("GPCSD_PROF_GRAPH") != nullptr;
     if (!any_large || (c->prof_on && !prof_graph) || !graphs_enabled()) {
-        eigh_pair_enqueue(c, A0, n0, w0, Z0, sym0, A1, n1, w1, Z1, sym1, d_status, s);
+        eigh_pair_enqueue(c, A0, n0, w0, Z0, sym0, A1, n1, w1, Z1, sym1, d_status, s, need_merged);
         return;
     }
     char key[320];
-    snprintf(key, sizeof(key), "eigh|%p|%d|%p|%p|%p|%d|%p|%d|%p|%p|%p|%d|%p|%p", (void *)A0, n0, (void *)w0, (void *)Z0,
+    snprintf(key, sizeof(key), "eigh|%p|%d|%p|%p|%p|%d|%p|%d|%p|%p|%p|%d|%p|%p|%d", (void *)A0, n0, (void *)w0, (void *)Z0,
              (void *)(sym0 ? sym0->rep_i : nullptr), sym0 ? sym0->ns : 0, (void *)A1, n1, (void *)w1, (void *)Z1,
-             (void *)(sym1 ? sym1->rep_i : nullptr), sym1 ? sym1->ns : 0, (void *)d_status, (void *)s);
+             (void *)(sym1 ? sym1->rep_i : nullptr), sym1 ? sym1->ns : 0, (void *)d_status, (void *)s, (int)need_merged);
     gpcsd_ctx::GraphSlot &g = c->graphs[key];
     if (g.exec && g.epoch == c->alloc_epoch) {
         GP_HIP(hipGraphLaunch(g.exec, s));
@@ -249,7 +250,7 @@ void eigh_pair_device(gpcsd_ctx *c, double *A0, int n0, double *w0, double *Z0, 
         GP_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
         c->capturing = true;
         try {
-            eigh_pair_enqueue(c, A0, n0, w0, Z0, sym0, A1, n1, w1, Z1, sym1, d_status, s);
+            eigh_pair_enqueue(c, A0, n0, w0, Z0, sym0, A1, n1, w1, Z1, sym1, d_status, s, need_merged);
         } catch (...) {
             c->capturing = false;
             (void)hipStreamEndCapture(s, &graph);
@@ -268,7 +269,7 @@ void eigh_pair_device(gpcsd_ctx *c, double *A0, int n0, double *w0, double *Z0, 
             return;
         }
     }
-    eigh_pair_enqueue(c, A0, n0, w0, Z0, sym0, A1, n1, w1, Z1, sym1, d_status, s);
+    eigh_pair_enqueue(c, A0, n0, w0, Z0, sym0, A1, n1, w1, Z1, sym1, d_status, s, need_merged);
     g.seen_epoch = c->alloc_epoch;
 }
 
@@ -276,7 +277,7 @@ void eigh_device(gpcsd_ctx *c, double *A, int n, double *evals, double *evecs, i
                  const char *tag) {
     GP_REQUIRE(n >= 1 && n <= JACOBI_MAX_N, -3, "eigh: n=%d outside [1,%d]", n, JACOBI_MAX_N);
     (void)tag;
-    eigh_pair_device(c, A, n, evals, evecs, nullptr, nullptr, 0, nullptr, nullptr, nullptr, d_status, s);
+    eigh_pair_device(c, A, n, evals, evecs, nullptr, nullptr, 0, nullptr, nullptr, nullptr, d_status, s, true);
 }
 
 }  // namespace gpcsd

@@ -619,6 +619,7 @@ void eigh_large_batch(gpcsd_ctx *c, EigProb *probs, int count, int *d_status, hi
             wb.p[i].V = p.sp.V; wb.p[i].tau = p.sp.tau; wb.p[i].Z = p.Z;
             wb.p[i].T = c->buf<double>("eig_" + p.tag + "_wyT", (size_t)P * WY_NB * WY_NB);
             wb.p[i].n = p.n; wb.p[i].npanels = P; wb.p[i].nrefl = nrefl;
+            wb.p[i].w_scale = pb.w[i]; wb.p[i].amax = pb.amax[i];   // the final rescale of the eigenvalues rides in the apply launch
         }
     bool prep_done = false;
     {
@@ -639,7 +640,6 @@ void eigh_large_batch(gpcsd_ctx *c, EigProb *probs, int count, int *d_status, hi
     if (wy_fused) {
         ProfScope ps(c, "eigh_backtransform", 0.0, s);
         wy_batch_device(c, wb, count, s, prep_done);
-        hipLaunchKernelGGL(scale_vec_batch_kernel, dim3(ceil_div(nmax, 256), count), dim3(256), 0, s, pb);
     } else {
         ProfScope ps(c, "eigh_backtransform", 0.0, s);
         if (count > 1 && c->fork_on()) GP_HIP(hipEventRecord(c->ev_fork, s));

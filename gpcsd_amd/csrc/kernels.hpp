@@ -98,8 +98,9 @@ struct EigReq {
 };
 // Two independent problems at once (Ks and Kt of one likelihood evaluation): every stage is batched so they share
 // launches; with a known symmetry each splits into two half-size problems first.  Either n may be <= 0 to skip.
+// need_merged = false: a caller that stays in the folded basis (eigh_fold_view) skips the unfold + rank merge of folded problems
 void eigh_pair_device(gpcsd_ctx *c, double *A0, int n0, double *w0, double *Z0, const SymDev *sym0, double *A1, int n1,
-                      double *w1, double *Z1, const SymDev *sym1, int *d_status, hipStream_t s);
+                      double *w1, double *Z1, const SymDev *sym1, int *d_status, hipStream_t s, bool need_merged = true);
 // Half-size results of a symmetry-folded problem, in fold order (see eigh.hip); on == false: the problem is not folded.
 struct FoldView {
     bool on = false;
@@ -112,6 +113,8 @@ struct WyProb {
     const double *V, *tau;   // reflectors by rows ((n + 64) x n, zero padded), tau (n + 64)
     double *T, *Z;           // T factors (npanels x 64 x 64 workspace), eigenvector matrix updated in place
     int n, npanels, nrefl;
+    double *w_scale = nullptr;       // optional: eigenvalues of the SCALED matrix, multiplied by *amax in the apply launch
+    const double *amax = nullptr;    // (saves the separate rescale launch at the end of the dependent chain)
 };
 struct WyBatch {
     WyProb p[MAX_EIG_BATCH];

@@ -34,6 +34,10 @@ __global__ __launch_bounds__(256) void wy_apply_kernel(WyBatch b) {
     double *W2 = W1 + WY_NB * WY_LD;           // [64][WY_LD]
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int fr = lane & 15, fq = lane >> 4;
+    if (blockIdx.x == 0 && P.w_scale) {        // eigenvalues back to the scale of the input matrix (nobody reads them here)
+        const double m = P.amax[0];
+        for (int i = tid; i < n; i += 256) P.w_scale[i] *= m;
+    }
     for (int idx = tid; idx < n * WY_ZC; idx += 256) {
         const int r = idx / WY_ZC, j = idx % WY_ZC;
         Zs[r * WY_LD + j] = (c0 + j < n) ? P.Z[(long)r * n + c0 + j] : 0.0;
