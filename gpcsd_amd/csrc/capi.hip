@@ -275,7 +275,8 @@ EigState front_half(gpcsd_ctx *c, const gpcsd_hparams *hp, double jitter, bool n
     const SymDev *sym_s = c->sym_s.ns > 0 ? &c->sym_s : nullptr, *sym_t = c->sym_t.ns > 0 ? &c->sym_t : nullptr;
     if (!two_stream_front()) {
         double *d_sig = c->upload_cached<double>("sig2n", hp->sig2n, hp->n_sig2n);
-        GP_HIP(hipMemsetAsync(e.status, 0, 4 * sizeof(int), s));
+        if (!c->status_zeroed) GP_HIP(hipMemsetAsync(e.status, 0, 4 * sizeof(int), s));
+        c->status_zeroed = false;
         build_kphi(c, g, hp->R, hp->eps, hp->ell_s, nullptr, 0, jitter, Ks, s);
         build_kt(c, hp, t, nt, t, nt, Kt, s);
         // the symmetries come from the resident geometry / time grid, so they hold for the Grams built from them
@@ -289,9 +290,12 @@ EigState front_half(gpcsd_ctx *c, const gpcsd_hparams *hp, double jitter, bool n
     // from the main stream except that the previous call has finished with Kt / Qt (ev_fork), and reports numerical
     // failure in its own status word (status[1]; the spatial chain uses status[0]).
     hipStream_t s2 = c->stream2;
+    // The status words are zeroed at the END of the previous call (finish_call / finish_status), off the critical path of
+    // this one; only a call that did not end that way (first call, an exception in between) clears them here.
+    if (!c->status_zeroed) GP_HIP(hipMemsetAsync(e.status, 0, 4 * sizeof(int), s));
+    c->status_zeroed = false;
     GP_HIP(hipEventRecord(c->ev_fork, s));
     GP_HIP(hipStreamWaitEvent(s2, c->ev_fork, 0));
-    GP_HIP(hipMemsetAsync(e.status + 1, 0, sizeof(int), s2));
     build_kt(c, hp, t, nt, t, nt, Kt, s2);
     {
         ProfScope ps(c, "eigh_temporal", 9.0 * (double)nt * nt * nt, s2);
@@ -299,7 +303,6 @@ EigState front_half(gpcsd_ctx *c, const gpcsd_hparams *hp, double jitter, bool n
     }
     GP_HIP(hipEventRecord(c->ev_join, s2));
     double *d_sig = c->upload_cached<double>("sig2n", hp->sig2n, hp->n_sig2n);
-    GP_HIP(hipMemsetAsync(e.status, 0, sizeof(int), s));
     build_kphi(c, g, hp->R, hp->eps, hp->ell_s, nullptr, 0, jitter, Ks, s);
     {
         ProfScope ps(c, "eigh_spatial", 9.0 * (double)nx * nx * nx, s);
@@ -438,7 +441,9 @@ void join_temporal(gpcsd_ctx *c, EigState &e, const FoldMode *fm = nullptr) {
 int finish_call(gpcsd_ctx *c, const EigState &e, double *scal_out, int nscal) {
     double *host = c->h_result;                        // pinned: a true asynchronous copy, no staging
     c->download(host, e.scal, 66 * sizeof(double));
+    GP_HIP(hipMemsetAsync(e.status, 0, 4 * sizeof(int), c->stream));   // clean status words for the next call, after the copy
     c->sync();
+    c->status_zeroed = true;
     if (c->prof_on) c->prof_collect();
     for (int i = 0; i < nscal; ++i) scal_out[i] = host[i];
     int st[4];

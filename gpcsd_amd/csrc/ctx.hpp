@@ -113,6 +113,7 @@ struct gpcsd_ctx {
     std::vector<double> geo_host, time_host, sym_z_pts;
     gpcsd::SymDev sym_z;
     int lfp_fold_sig = 0;                   // 0: the folded copy of the data is stale; else FoldMode::sig() it was built for
+    bool status_zeroed = false;             // the fused calls' status words were cleared at the end of the previous call
     bool gram_fp32 = false;                 // gpcsd_set_gram_precision(): Gram builders evaluate in float (cfg5 variant)
     bool fold_gemm_on = true;               // gpcsd_fold_gemm()
     long fold_gemm_calls = 0;

@@ -527,6 +527,7 @@ struct PrepBatch {
     double *amax[MAX_BATCH];
     SytrdProb sp[MAX_BATCH];
     double *w[MAX_BATCH];       // eigenvalue outputs (for the final rescale)
+    int *status;                // numerical-failure word of the call (non-finite input is reported there)
 };
 __global__ __launch_bounds__(256) void absmax_partial_batch_kernel(PrepBatch b) {
     __shared__ double red[4];
@@ -550,7 +551,18 @@ __global__ __launch_bounds__(256) void scale_copy_zero_batch_kernel(PrepBatch b)
     const double inv = 1.0 / m;
     const double *__restrict__ A = b.A[p];
     const long stride = (long)gridDim.x * 256, i0 = blockIdx.x * 256L + threadIdx.x;
-    for (long i = i0; i < n2; i += stride) P.A0[i] = A[i] * inv;
+    // Non-finite input (a NaN hyper-parameter makes a whole Gram matrix NaN) must not reach the solver: its rank sorts and
+    // merges assume a total order and would index out of range.  Such entries are zeroed and the call reports failure.
+    bool bad = false;
+    for (long i = i0; i < n2; i += stride) {
+        double v = A[i] * inv;
+        if (!(fabs(v) <= 2.0)) {
+            v = 0.0;
+            bad = true;
+        }
+        P.A0[i] = v;
+    }
+    if (bad && b.status) atomicMax(b.status, 4);
     const long nv = (n + WY_NB) * n;
     for (long i = i0; i < nv; i += stride) P.V[i] = 0.0;
     for (long i = i0; i < n + WY_NB; i += stride) P.tau[i] = 0.0;
@@ -562,8 +574,9 @@ __global__ __launch_bounds__(256) void scale_vec_batch_kernel(PrepBatch b) {
     for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) b.w[p][i] *= m;
 }
 
-static PrepBatch prep_batch_launch(gpcsd_ctx *c, EigProb *probs, int count, hipStream_t s) {
+static PrepBatch prep_batch_launch(gpcsd_ctx *c, EigProb *probs, int count, hipStream_t s, int *d_status = nullptr) {
     PrepBatch pb;
+    pb.status = d_status;
     for (int i = 0; i < count; ++i) {
         prep_problem(c, probs[i], s);
         pb.A[i] = probs[i].A;
@@ -603,7 +616,7 @@ void eigh_large_batch(gpcsd_ctx *c, EigProb *probs, int count, int *d_status, hi
         GP_REQUIRE(probs[i].n > 2 && probs[i].n <= EIG_MAXN, -3, "eigh(large): n=%d outside (2,%d]", probs[i].n, EIG_MAXN);
         nmax = std::max(nmax, probs[i].n);
     }
-    const PrepBatch pb = prep_batch_launch(c, probs, count, s);
+    const PrepBatch pb = prep_batch_launch(c, probs, count, s, d_status);
     for (int i = 0; i < count; ++i) b.p[i] = probs[i].sp;
     {
         ProfScope ps(c, "eigh_sytrd", 0.0, s);

@@ -146,7 +146,7 @@ __device__ void jacobi_body(double *A, int lda, double *V, int ldv, int n, doubl
         int rank = 0;
         for (int j = 0; j < n; ++j) {
             const double dj = red[j];
-            rank += (dj < di) || (dj == di && j < i);
+            rank += (dj < di) || (!(di < dj) && j < i);      // a valid permutation even for unordered (NaN) values
         }
         pq[i] = rank;
         evals[rank] = di;

@@ -190,7 +190,7 @@ __device__ __forceinline__ void dc_leaf_reg_body(const DcLevel &L, int *status, 
     int rank = 0;
     for (int k = 0; k < m; ++k) {
         const double dk = __shfl(a, 9 * k, 64);
-        rank += (dk < dj) || (dk == dj && k < j);
+        rank += (dk < dj) || (!(dj < dk) && k < j);         // a valid permutation even for unordered (NaN) values
     }
     if (i < m && j < m) {
         if (i == 0) w.dcur[lo + rank] = dj;
@@ -640,7 +640,7 @@ __device__ void dc_rank_body(const DcWork &w, const Seg sg, const int K, double 
         int rk = 0;
         for (int u = 0; u < N; ++u) {
             const double x = val[u];
-            rk += (x < v) || (x == v && u < t);
+            rk += (x < v) || (!(v < x) && u < t);           // a valid permutation even for unordered (NaN) values
         }
         w.dnext[lo + rk] = v;
         w.rota[lo + t] = rk;                         // the rotation list has been consumed: reuse as tables

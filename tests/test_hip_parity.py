@@ -715,3 +715,29 @@ def test_one_sided_fold_takes_any_prediction_sites():
     n1 = ctx.fold_gemm()
     m.predict(z, t + 0.25, type="csd")                                # shifted prediction times: full-size path
     assert ctx.fold_gemm() == n1
+
+
+@pytest.mark.parametrize("name", ["cfg2s_1d_24x500x8", "2d_npx_96x120x3"])
+def test_failed_call_leaves_a_clean_context(name):
+    """A fused call that fails numerically (NaN hyper-parameter: the eigensolvers cannot converge) must not poison the next
+    one: the status words are cleared between calls (at the end of a call, or at the start of one that follows a failure)."""
+    m, c, g, geom, hp, lfp = _build_model(name)
+    ref = float(g["loglik"])
+    assert abs(float(m.loglik()) - ref) / abs(ref) < GATE
+    sname = m._spatial_names[0]
+    slots = [(m.temporal_cov_list[0].params["ell"], float("nan")), (m.spatial_cov.params[sname], float("nan")),
+             (m.R, float("nan")), (m.temporal_cov_list[0].params["ell"], 0.0), (m.temporal_cov_list[-1].params["sigma2"], float("inf"))]
+    for slot, badval in slots:
+        good = slot["value"]
+        slot["value"] = badval
+        for call in (m.loglik, lambda: m.predict(c["x"], c["t"], type="csd")):
+            try:
+                out = call()
+                assert out is None or not np.isfinite(out)
+            except (np.linalg.LinAlgError, ValueError, RuntimeError):
+                pass
+        slot["value"] = good
+        for _ in range(2):
+            assert abs(float(m.loglik()) - ref) / abs(ref) < GATE
+    m.predict(c["x"], c["t"], type="csd")
+    assert relerr(m.csd_pred, g["csd_pred"]) < GATE
