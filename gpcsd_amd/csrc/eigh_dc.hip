@@ -51,7 +51,7 @@ __global__ __launch_bounds__(256) void scale_copy_kernel(const double *__restric
                                                          double *__restrict__ out) {
     double m = 0.0;
     for (int i = 0; i < AMAX_PARTS; ++i) m = fmax(m, amax[2 + i]);
-    m = (m > 0.0 && m < 1e300) ? m : 1.0;
+    m = (m > 0.0 && m <= 1.7e308) ? m : 1.0;
     if (blockIdx.x == 0 && threadIdx.x == 0) amax[0] = m;
     const double inv = 1.0 / m;
     for (long i = blockIdx.x * 256L + threadIdx.x; i < n2; i += (long)gridDim.x * 256) out[i] = A[i] * inv;
@@ -160,7 +160,10 @@ __global__ __launch_bounds__(256) void sytrd_step_kernel(SytrdBatch b, int k) {
     const double dk = s_dk;
     const double alpha = s_alpha;
     double tau = 0.0, beta = alpha, scal = 0.0;
-    if (k <= n - 3 && xnorm2 > 0.0) {
+    // The matrix is scaled to max|a| = 1: a column with |x|^2 + alpha^2 < 1e-100 is rounding noise of rounding noise (exactly
+    // low-rank inputs shrink by 1e-15 per column); its squares lose their bits as subnormals and the reflector built from them
+    // is not orthogonal, so it counts as a zero column like in the single-workgroup tail (sytrd_regtail.hpp).
+    if (k <= n - 3 && xnorm2 > 0.0 && alpha * alpha + xnorm2 > 1e-100) {
         beta = -copysign(sqrt(alpha * alpha + xnorm2), alpha);
         tau = (beta - alpha) / beta;
         scal = 1.0 / (alpha - beta);
@@ -284,7 +287,7 @@ __global__ __launch_bounds__(512) void sytrd_tail_kernel(SytrdBatch b) {
         const double *prow = As + kk * SY_TLD;
         const double dk = prow[kk], alpha = prow[kk + 1];
         double tau = 0.0, beta = alpha, scal = 0.0;
-        if (m >= 2 && xnorm2 > 0.0) {
+        if (m >= 2 && xnorm2 > 0.0 && alpha * alpha + xnorm2 > 1e-100) {
             beta = -copysign(sqrt(alpha * alpha + xnorm2), alpha);
             tau = (beta - alpha) / beta;
             scal = 1.0 / (alpha - beta);
@@ -546,7 +549,7 @@ __global__ __launch_bounds__(256) void scale_copy_zero_batch_kernel(PrepBatch b)
     double *amax = b.amax[p];
     double m = 0.0;
     for (int i = 0; i < AMAX_PARTS; ++i) m = fmax(m, amax[2 + i]);
-    m = (m > 0.0 && m < 1e300) ? m : 1.0;
+    m = (m > 0.0 && m <= 1.7e308) ? m : 1.0;
     if (blockIdx.x == 0 && threadIdx.x == 0) amax[0] = m;
     const double inv = 1.0 / m;
     const double *__restrict__ A = b.A[p];
@@ -555,7 +558,7 @@ __global__ __launch_bounds__(256) void scale_copy_zero_batch_kernel(PrepBatch b)
     // merges assume a total order and would index out of range.  Such entries are zeroed and the call reports failure.
     bool bad = false;
     for (long i = i0; i < n2; i += stride) {
-        double v = A[i] * inv;
+        double v = (m > 1e300) ? A[i] / m : A[i] * inv;         // 1 / m is subnormal beyond 1e300
         if (!(fabs(v) <= 2.0)) {
             v = 0.0;
             bad = true;

@@ -46,6 +46,36 @@ __device__ void jacobi_body(double *A, int lda, double *V, int ldv, int n, doubl
     __shared__ int s_rot;
     __shared__ double s_thresh;
 
+    // Scale to max|a| = 1 as LAPACK does, so the squares in the norm and the rotation formulas neither overflow nor vanish
+    // (1e290 * G and 1e-300 * G used to come back wrong / NaN); non-finite entries are zeroed and reported as a failure.
+    __shared__ double s_scale;
+    {
+        double mx = 0.0;
+        int bad = 0;
+        for (int e = tid; e < n * n; e += NT) {
+            const double a = fabs(A[(e / n) * lda + (e % n)]);
+            if (a <= 1.7e308) mx = fmax(mx, a);
+            else bad = 1;
+        }
+        red[tid] = mx;
+        bad = __syncthreads_or(bad);
+        for (int w = NT / 2; w > 0; w >>= 1) {
+            if (tid < w) red[tid] = fmax(red[tid], red[tid + w]);
+            __syncthreads();
+        }
+        if (tid == 0) {
+            s_scale = red[0] > 0.0 ? red[0] : 1.0;
+            if (bad) atomicMax(status, 4);
+        }
+        __syncthreads();
+        const double sc = s_scale;
+        for (int e = tid; e < n * n; e += NT) {
+            const int idx = (e / n) * lda + (e % n);
+            const double a = A[idx];
+            A[idx] = (fabs(a) <= 1.7e308) ? a / sc : 0.0;
+        }
+        __syncthreads();
+    }
     // V = I, Frobenius norm
     double acc = 0.0;
     for (int e = tid; e < n * n; e += NT) {
@@ -149,7 +179,7 @@ __device__ void jacobi_body(double *A, int lda, double *V, int ldv, int n, doubl
             rank += (dj < di) || (!(di < dj) && j < i);      // a valid permutation even for unordered (NaN) values
         }
         pq[i] = rank;
-        evals[rank] = di;
+        evals[rank] = di * s_scale;
     }
     __syncthreads();
     for (int e = tid; e < n * n; e += NT) {

@@ -133,15 +133,31 @@ __device__ __forceinline__ void dc_leaf_reg_body(const DcLevel &L, int *status, 
     const int lo = w.tbl[bx], hi = w.tbl[bx + 1];
     const int m = hi - lo;
     const int i = lane >> 3, j = lane & 7;
+    // A non-finite d / e (they should not occur: the drivers sanitise their input) must not reach the merges, whose rank
+    // sorts would index out of range: read as zero, repaired in place for the later launches, reported as a failure.
+    bool bad = false;
+    auto san = [&](double x) {
+        if (fabs(x) <= 1.7e308) return x;
+        bad = true;
+        return 0.0;
+    };
     double a = 0.0;
     if (i < m && j < m) {
         if (i == j) {
-            a = w.d0[lo + i];
-            if (i == 0 && lo > 0) a -= fabs(w.e[lo - 1]);
-            if (i == m - 1 && hi < n) a -= fabs(w.e[hi - 1]);
-        } else if (j == i + 1) a = w.e[lo + i];
-        else if (i == j + 1) a = w.e[lo + j];
+            a = san(w.d0[lo + i]);
+            if (i == 0 && lo > 0) a -= fabs(san(w.e[lo - 1]));
+            if (i == m - 1 && hi < n) {
+                const double eb = w.e[hi - 1];
+                if (!(fabs(eb) <= 1.7e308)) const_cast<double *>(w.e)[hi - 1] = 0.0;   // the coupling this leaf owns
+                a -= fabs(san(eb));
+            }
+        } else if (j == i + 1) {
+            const double ee = w.e[lo + i];
+            if (!(fabs(ee) <= 1.7e308)) const_cast<double *>(w.e)[lo + i] = 0.0;
+            a = san(ee);
+        } else if (i == j + 1) a = san(w.e[lo + j]);
     }
+    if (__ballot(bad) != 0ull && lane == 0) atomicMax(status, 4);
     double v = (i == j) ? 1.0 : 0.0;
     const double thresh = sqrt(wave_sum(a * a)) * EPS_U / (double)m;
     bool converged = (m <= 1);
@@ -265,11 +281,13 @@ __device__ void dc_setup_body(const DcWork &w, const Seg sg, const int m, SetupS
     const double isq2 = 0.70710678118654752440;
     double dmax = 0.0, zmax = 0.0;
     for (int i = tid; i < N; i += NT) {
-        const double dv = w.dcur[lo + i];
+        double dv = w.dcur[lo + i];
+        dv = (dv == dv) ? dv : 1.7e308;          // an unordered value would break the merge ranks (indices out of range)
         const double zv = (i < n1 ? w.Qcur[(long)(mid - 1) * n + lo + i] : sgn * w.Qcur[(long)mid * n + lo + i]) * isq2;
         S.sd[i] = dv;
         S.sz[i] = zv;
         S.sdefl[i] = 0;
+        S.sperm[i] = i;                          // every slot holds a valid index even if the halves were not ascending
         dmax = fmax(dmax, fabs(dv));
         zmax = fmax(zmax, fabs(zv));
     }

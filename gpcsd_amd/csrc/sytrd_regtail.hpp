@@ -51,14 +51,16 @@ __device__ __forceinline__ double row16_sum(double v) {
 // u = (alpha - beta, x_2, ..) left UN-normalised: u is known as soon as s = sqrt(alpha^2 + |x|^2) is, and
 // tau = 1 / (s (|alpha| + s)) = r / |u_1| is formed by every wave after the barrier, off the generating wave's chain.
 // s and r = 1/s come out of one coupled Newton (Goldschmidt) iteration on the hardware rsq seed (6 dependent operations
-// instead of the ~25 of an IEEE sqrt and two divisions).  The matrix is scaled to max|a| = 1, so s^2 < 1e-290 is a zero
-// column (H = I: r = 0).  `ok` false forces H = I (last column).
+// instead of the ~25 of an IEEE sqrt and two divisions).  The matrix is scaled to max|a| = 1 and tau grows like 1 / s^2, so
+// a column with s < 1e-50 is treated as zero (H = I: r = 0; the entries dropped are 1e-34 of an ulp of the matrix) -- an
+// exactly low-rank input (e.g. all ones) leaves columns that are rounding noise of rounding noise, shrinking by 1e-15 per
+// column, and 1 / s^2 overflowed on the eighth of them.  `ok` false forces H = I (last column).
 __device__ __forceinline__ void rt_house(double alpha, double xnorm2, bool ok, double &r, double &u1, double &beta) {
     const double s2 = fma(alpha, alpha, xnorm2);
     r = 0.0;
     u1 = 1.0;
     beta = alpha;
-    if (ok && xnorm2 > 0.0 && s2 > 1e-290) {                         // wave-uniform
+    if (ok && xnorm2 > 0.0 && s2 > 1e-100) {                         // wave-uniform
         const double y0 = __builtin_amdgcn_rsq(s2);
         double g = s2 * y0, hh = 0.5 * y0;
         double e = fma(-hh, g, 0.5);

@@ -741,3 +741,31 @@ def test_failed_call_leaves_a_clean_context(name):
             assert abs(float(m.loglik()) - ref) / abs(ref) < GATE
     m.predict(c["x"], c["t"], type="csd")
     assert relerr(m.csd_pred, g["csd_pred"]) < GATE
+
+
+@pytest.mark.parametrize("n", [24, 70, 250, 384])
+def test_eigh_edge_inputs(ctx, n):
+    """Inputs at the edges of the solver's assumptions: zero / exactly low-rank / identity / badly scaled matrices stay
+    accurate (exactly low-rank ones leave columns that are rounding noise of rounding noise: they once overflowed the
+    reflector scalars and, through NaNs in the rank sorts, faulted the GPU), non-finite ones raise LinAlgError, and the
+    context keeps working afterwards.  tools/eigh_edge.py is the long version."""
+    rs = np.random.RandomState(n)
+    X = rs.standard_normal((n, n))
+    G = X + X.T
+    cases = {"zeros": np.zeros((n, n)), "ones": np.ones((n, n)), "identity": np.eye(n), "tiny": 1e-300 * G, "huge": 1e290 * G,
+             "graded": np.diag(np.logspace(-300, 300, n)), "rank2": np.outer(X[0], X[0]) + np.outer(X[1], X[1])}
+    for name, A in cases.items():
+        w, Z = ctx.eigh(A)
+        wr = np.linalg.eigvalsh(A)
+        sc = max(np.abs(wr).max(), 1e-300)
+        assert np.abs(w - wr).max() / sc < 1e-12 * n, name
+        assert np.abs(Z.T @ Z - np.eye(n)).max() < 1e-12 * n, name
+        with np.errstate(all="ignore"):
+            assert np.abs((A / sc) @ Z - Z * (w / sc)).max() < 1e-11 * n, name
+    for bad in (np.nan, np.inf):
+        A = G.copy()
+        A[n // 3, n // 2] = A[n // 2, n // 3] = bad
+        with pytest.raises(np.linalg.LinAlgError):
+            ctx.eigh(A)
+    w, Z = ctx.eigh(G)
+    assert np.abs(w - np.linalg.eigvalsh(G)).max() < 1e-11 * n
