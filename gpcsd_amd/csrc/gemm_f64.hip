@@ -470,15 +470,18 @@ void gemm_f64(gpcsd_ctx *c, const GemmDesc &g, hipStream_t s) {
 
     // Tile configurations (block tile, waves, K depth).  Large flat GEMMs want many resident workgroups per CU so the
     // hardware dispatcher balances the tail; tiny GEMMs are latency-bound and want deep K tiles.
-    //   1: 128x128, 8 waves, BK16   3: 64x64, 4 waves, BK16   5: 32x32, 4 waves, BK64
+    //   1: 128x128, 8 waves, BK16   2: 64x64, 4 waves, BK8   3: 64x64, 4 waves, BK16   5: 32x32, 4 waves, BK64
     // (128x64 / BK8 / BK32 / single-LDS-buffer variants were measured and dropped: tools/gemm_sweep.py)
-    static const int CFG_BM[6] = {0, 128, 0, 64, 0, 32}, CFG_BN[6] = {0, 128, 0, 64, 0, 32};
+    static const int CFG_BM[6] = {0, 128, 64, 64, 0, 32}, CFG_BN[6] = {0, 128, 64, 64, 0, 32};
     int cfg = g.cfg;
-    if (cfg != 1 && cfg != 3 && cfg != 5) {
+    if (cfg != 1 && cfg != 2 && cfg != 3 && cfg != 5) {
         auto tiles = [&](int bm, int bn) { return (long)ceil_div(g.M, bm) * ceil_div(g.N, bn) * g.batch; };
         // measured on MI355X (tools/gemm_sweep.py): 64x64 tiles reach the same ~40 TF/s as 128x128 on the large
         // flat GEMMs and balance the tail better; everything smaller is latency-bound and wants 32x32 / BK64
-        cfg = (tiles(64, 64) >= 512) ? 3 : 5;
+        // short K (the folded GEMMs: 192 / 250): the same tile with BK 8 -- half the pipeline fill per tile and half the LDS,
+        // 46-48 TF/s against 40-41 with BK 16 at 192x25000x192 / 19200x250x250; equal from K = 500 up
+        static const bool bk8 = !(getenv("GPCSD_GEMM_BK8") && getenv("GPCSD_GEMM_BK8")[0] == '0');
+        cfg = (tiles(64, 64) >= 512) ? ((bk8 && g.K <= 320) ? 2 : 3) : 5;
     }
     const int bm = CFG_BM[cfg], bn = CFG_BN[cfg];
     const int tm = ceil_div(g.M, bm), tn = ceil_div(g.N, bn);
@@ -500,6 +503,7 @@ void gemm_f64(gpcsd_ctx *c, const GemmDesc &g, hipStream_t s) {
         ProfScope ps(c, g.prof_name, flops, s);
         switch (cfg) {
             case 1: launch_trans<4, 2, 2, 4, 16>(k, g.transA, g.transB, g.epi, grid, s); break;
+            case 2: launch_trans<2, 2, 2, 2, 8>(k, g.transA, g.transB, g.epi, grid, s); break;
             case 3: launch_trans<2, 2, 2, 2, 16>(k, g.transA, g.transB, g.epi, grid, s); break;
             default: launch_trans<2, 2, 1, 1, 64>(k, g.transA, g.transB, g.epi, grid, s); break;
         }

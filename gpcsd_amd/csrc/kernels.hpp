@@ -38,7 +38,7 @@ struct GemmDesc {
     long sD = 0;                  // batch stride of D
     double *quad_out = nullptr;   // EPI_QUAD: one double (EPI_GRAD: two), written by the final reduce
     const int *dyn = nullptr;     // device int per batch entry: effective N = K = dyn[batch] (tiles beyond it exit)
-    int cfg = 0;                  // 0 = choose the tile configuration automatically, 1 / 3 / 5 = force (see gemm_f64.hip)
+    int cfg = 0;                  // 0 = choose the tile configuration automatically, 1 / 2 / 3 / 5 = force (see gemm_f64.hip)
     const char *prof_name = "gemm_f64";
 };
 
