@@ -17,7 +17,7 @@ shapes = [  # (name, M, N, K, transA, transB)
 ]
 for name, M, N, K, ta, tb in shapes:
     row = []
-    for cfg in (0, 1, 3, 5):
+    for cfg in (0, 1, 2, 3, 5):
         try:
             ms, tf = ctx.gemm_bench(M, N, K, ta, tb, cfg=cfg, reps=5)
             row.append("%d:%6.1fus/%5.1fTF" % (cfg, ms * 1e3, tf))
