@@ -176,7 +176,7 @@ def test_fit_restart_sharding_world2():
 # ---------------------------------------------------------------------------------------------------------------------
 # the same sharding layer over the HIP path: two ranks share the one GPU of the test box (gloo for the tiny collectives)
 # ---------------------------------------------------------------------------------------------------------------------
-def _gpu_shard_worker(rank, world, port, q):
+def _gpu_shard_worker(rank, world, port, q, case="1d_odd_17x37x5"):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
@@ -187,7 +187,7 @@ def _gpu_shard_worker(rank, world, port, q):
     td.init_process_group("gloo", rank=rank, world_size=world)
     from gpcsd_amd.dist import TrialSharding
     import test_hip_parity as T
-    m, c, g, geom, hp, lfp = T._build_model("1d_odd_17x37x5")
+    m, c, g, geom, hp, lfp = T._build_model(case)
     m.shard_trials(TrialSharding(gather_predictions=True))
     ll = float(m.loglik())
     ll2, grad = m._loglik_and_grad_natural()
@@ -199,13 +199,14 @@ def _gpu_shard_worker(rank, world, port, q):
 
 @pytest.mark.gpu
 @pytest.mark.timeout(300)
-def test_hip_path_trial_sharding_world2_one_gpu():
+@pytest.mark.parametrize("case", ["1d_odd_17x37x5", "2d_npx_96x120x3"])      # unfolded path / folded-basis path, uneven shards
+def test_hip_path_trial_sharding_world2_one_gpu(case):
     """model.shard_trials over the HIP path: each rank evaluates its block of trials on the GPU, the partial sums are
     all-reduced, predictions gathered; every rank reproduces the reference's loglik / posterior mean of the full data."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_gpu_shard_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_gpu_shard_worker, args=(r, 2, port, q, case)) for r in range(2)]
     for p in procs:
         p.start()
     res = sorted(q.get(timeout=240) for _ in procs)
@@ -214,5 +215,5 @@ def test_hip_path_trial_sharding_world2_one_gpu():
     for rank, ll, ll2, grad, shape, perr, ll_ref in res:
         assert abs(ll - ll_ref) / abs(ll_ref) < 1e-6
         assert abs(ll2 - ll_ref) / abs(ll_ref) < 1e-6
-        assert shape[2] == 5 and perr < 1e-6
+        assert shape[2] == (5 if case.startswith("1d_odd") else 3) and perr < 1e-6
     assert np.allclose(res[0][3], res[1][3], rtol=1e-12, atol=0)      # the reduced gradient is identical on both ranks
