@@ -788,4 +788,5 @@ def test_random_models_vs_oracle():
         nfold += folds > 0
         gate = 1e-4 if "siglist=1" in desc else 1e-6
         assert e_ll < gate and e_c < gate and e_l < gate, (desc, e_ll, e_c, e_l)
-    assert nfold > 5
+    if not (os.environ.get("GPCSD_NO_FOLD_GEMM") == "1" or os.environ.get("GPCSD_NO_SYMFOLD") == "1"):
+        assert nfold > 5
