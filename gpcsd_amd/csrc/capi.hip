@@ -430,11 +430,16 @@ static void fold_proj_spatial(gpcsd_ctx *c, const FoldView &fs, const double *in
 
 // Main stream waits for the temporal chain; then D and sum(log D) -- from the spectra in fold order when fm is on.
 // No-op after the single-stream front half unless the fold order is asked for.
-void join_temporal(gpcsd_ctx *c, EigState &e, const FoldMode *fm = nullptr) {
+// sumlog = false: the caller either does not need sum(log D) (predict) or folds the final sum of the partials into a later
+// launch (loglik: the reduce of the quadratic form); returns the number of partials left in "buildD_partials" (0: none built).
+int join_temporal(gpcsd_ctx *c, EigState &e, const FoldMode *fm = nullptr, bool sumlog = true) {
     if (e.pending) GP_HIP(hipStreamWaitEvent(c->stream, c->ev_join, 0));
-    if (fm && fm->on) k_build_D(c, fm->fs.w, c->nx, fm->ft.w, c->nt, e.d_sig, e.nsig, e.D, e.Dinv, e.scal, c->stream);
-    else if (e.pending) k_build_D(c, e.es, c->nx, e.et, c->nt, e.d_sig, e.nsig, e.D, e.Dinv, e.scal, c->stream);
+    double *out = sumlog ? e.scal : nullptr;
+    int np = 0;
+    if (fm && fm->on) np = k_build_D(c, fm->fs.w, c->nx, fm->ft.w, c->nt, e.d_sig, e.nsig, e.D, e.Dinv, out, c->stream);
+    else if (e.pending) np = k_build_D(c, e.es, c->nx, e.et, c->nt, e.d_sig, e.nsig, e.D, e.Dinv, out, c->stream);
     e.pending = false;
+    return np;
 }
 
 // End of a fused call: one copy brings back the leading `nscal` scalars and the status words, then the stream is drained.
@@ -1082,8 +1087,11 @@ extern "C" int gpcsd_loglik_parts(gpcsd_ctx *c, const gpcsd_hparams *hp, double 
         // the same two projections in the folded basis: 2 + 2 half-size GEMMs, the quadratic form as two partial sums
         ++c->fold_gemm_calls;
         fold_proj_spatial(c, fm.fs, Yf, W, (long)R * nt, s);
-        join_temporal(c, e, &fm);
+        const int nparts = join_temporal(c, e, &fm, false);         // sum(log D): summed by the reduce launch of the GEMM below
         GemmDesc g2[2];
+        g2[0].extra_sum_in = c->buf<double>("buildD_partials", 256);
+        g2[0].extra_sum_n = nparts;
+        g2[0].extra_sum_out = e.scal;
         for (int p = 0; p < 2; ++p) {
             const int np = p ? fm.ft.na : fm.ft.ns, c0 = p ? fm.ft.ns : 0;
             g2[p].M = nx * R; g2[p].N = np; g2[p].K = np;
@@ -1187,7 +1195,7 @@ static int predict_fold(gpcsd_ctx *c, const gpcsd_hparams *hp, EigState &e, cons
         k_sym_fold_rect(c, Kts + (size_t)cc * nt * nt, nt, fm.sym_t, fm.sym_t, Ktf + cc * ktf_sz,
                         Ktf + cc * ktf_sz + (size_t)nts * nts, s);
     }
-    join_temporal(c, e, &fm);
+    join_temporal(c, e, &fm, false);      // predict never reads sum(log D)
     GemmDesc g2[2];                       // Bm~[:, p block] = (W~[:, p block] V_p) / D~
     for (int p = 0; p < 2; ++p) {
         const int np = p ? nta : nts, c0 = p ? nts : 0;
@@ -1312,7 +1320,7 @@ static int predict_impl(gpcsd_ctx *c, const gpcsd_hparams *hp, const double *z, 
         // time index (reference quirk when tstar != t)      gpcsd1d.py:277-279
         k_temporal_gram(c, 1, &hp->kind[cc], &hp->ell_t[cc], &hp->sigma2_t[cc], dts, ntstar, t, nt, Kts + (size_t)cc * ntstar * nt, s);
     }
-    join_temporal(c, e);
+    join_temporal(c, e, nullptr, false);      // predict never reads sum(log D)
     GemmDesc g2;                          // Bm = (W Qt) / D
     g2.M = nx * R; g2.N = nt; g2.K = nt;
     g2.A = W; g2.lda = nt; g2.B = e.Qt; g2.ldb = nt; g2.C = Bm; g2.ldc = nt;

@@ -419,7 +419,16 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f64_kernel(GemmK g) {
 }
 
 // Deterministic final reduction of per-block partials (single workgroup, fixed tree).
-__global__ __launch_bounds__(256) void reduce_partials_kernel(const double *__restrict__ p, long n, double *out) {
+// A second workgroup may carry an unrelated reduction of the same shape (p2, n2 -> out2: the sum of log D partials of the
+// likelihood, which would otherwise be a launch of its own in the dependent tail of the call).
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const double *__restrict__ p, long n, double *out,
+                                                              const double *__restrict__ p2 = nullptr, long n2 = 0,
+                                                              double *out2 = nullptr) {
+    if (blockIdx.x == 1) {
+        p = p2;
+        n = n2;
+        out = out2;
+    }
     __shared__ double sh[256];
     double s = 0.0;
     for (long i = threadIdx.x; i < n; i += 256) s += p[i];
@@ -510,10 +519,11 @@ void gemm_f64(gpcsd_ctx *c, const GemmDesc &g, hipStream_t s) {
         GP_HIP(hipGetLastError());
     }
     if (g.epi == EPI_QUAD || g.epi == EPI_GRAD) {
-        hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(256), 0, s, (const double *)k.partials, nblocks, g.quad_out);
+        hipLaunchKernelGGL(reduce_partials_kernel, dim3(g.extra_sum_out ? 2 : 1), dim3(256), 0, s, (const double *)k.partials,
+                           nblocks, g.quad_out, g.extra_sum_in, (long)g.extra_sum_n, g.extra_sum_out);
         if (g.epi == EPI_GRAD)
             hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(256), 0, s, (const double *)(k.partials + nblocks), nblocks,
-                               g.quad_out + 1);
+                               g.quad_out + 1, (const double *)nullptr, 0L, (double *)nullptr);
         GP_HIP(hipGetLastError());
     }
 }

@@ -320,8 +320,8 @@ __global__ __launch_bounds__(256) void sum_small_kernel(const double *__restrict
     if (threadIdx.x == 0) out[0] = sh[0];
 }
 
-void k_build_D(gpcsd_ctx *c, const double *es, int nx, const double *et, int nt, const double *sig, int nsig, double *D,
-               double *Dinv, double *sumlog_out, hipStream_t s) {
+int k_build_D(gpcsd_ctx *c, const double *es, int nx, const double *et, int nt, const double *sig, int nsig, double *D,
+              double *Dinv, double *sumlog_out, hipStream_t s) {
     const long n = (long)nx * nt;
     int blocks = (int)((n + 1023) / 1024);
     if (blocks > 256) blocks = 256;
@@ -329,8 +329,9 @@ void k_build_D(gpcsd_ctx *c, const double *es, int nx, const double *et, int nt,
     double *part = c->buf<double>("buildD_partials", 256);
     ProfScope ps(c, "build_D_logdet", 0.0, s);
     hipLaunchKernelGGL(build_D_kernel, dim3(blocks), dim3(256), 0, s, es, nx, et, nt, sig, nsig, D, Dinv, part);
-    hipLaunchKernelGGL(sum_small_kernel, dim3(1), dim3(256), 0, s, (const double *)part, blocks, sumlog_out);
+    if (sumlog_out) hipLaunchKernelGGL(sum_small_kernel, dim3(1), dim3(256), 0, s, (const double *)part, blocks, sumlog_out);
     GP_HIP(hipGetLastError());
+    return blocks;
 }
 
 // ------------------------------------------------------------------------------------------------

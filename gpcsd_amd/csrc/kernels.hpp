@@ -37,6 +37,9 @@ struct GemmDesc {
     long ldd = 0;
     long sD = 0;                  // batch stride of D
     double *quad_out = nullptr;   // EPI_QUAD: one double (EPI_GRAD: two), written by the final reduce
+    const double *extra_sum_in = nullptr;   // EPI_QUAD: an unrelated vector of partials summed by the same reduce launch
+    int extra_sum_n = 0;                     //   (sum_small_kernel's association: bit-identical to k_build_D's own sum)
+    double *extra_sum_out = nullptr;
     const int *dyn = nullptr;     // device int per batch entry: effective N = K = dyn[batch] (tiles beyond it exit)
     int cfg = 0;                  // 0 = choose the tile configuration automatically, 1 / 2 / 3 / 5 = force (see gemm_f64.hip)
     const char *prof_name = "gemm_f64";
@@ -65,8 +68,10 @@ void k_se_2d(gpcsd_ctx *c, const double *a1, const double *a2, int na, int na2, 
              int nb, int nb2, double ell1, double ell2, double *out, hipStream_t s);
 void k_add_diag(gpcsd_ctx *c, double *A, int n, double v, hipStream_t s);
 // D[x*nt + i] = es[x]*et[i] + sig[x or 0]; also sumlog -> *sumlog_out (deterministic)
-void k_build_D(gpcsd_ctx *c, const double *es, int nx, const double *et, int nt, const double *sig, int nsig, double *D,
-               double *Dinv, double *sumlog_out, hipStream_t s);   // Dinv (optional) = 1/D elementwise
+// Dinv (optional) = 1/D elementwise.  sumlog_out == nullptr: no final sum; the per-block partials stay in the ctx buffer
+// "buildD_partials" and the return value is their count (a later launch may fold the sum in, or nobody needs it)
+int k_build_D(gpcsd_ctx *c, const double *es, int nx, const double *et, int nt, const double *sig, int nsig, double *D,
+              double *Dinv, double *sumlog_out, hipStream_t s);
 // lfp host layout [x][t][r] -> device layout [x][r][t] (and back for predictions [z][r][t] -> [z][t][r])
 void k_swap_last2(gpcsd_ctx *c, const double *in, double *out, int n0, int n1, int n2, hipStream_t s);
 void k_fill(gpcsd_ctx *c, double *p, long n, double v, hipStream_t s);
