@@ -10,5 +10,6 @@ from . import priors, forward_models, utility_functions, covariances, predict_cs
 from . import gpcsd1d, gpcsd2d, dist  # noqa: F401
 from .gpcsd1d import GPCSD1D  # noqa: F401
 from .gpcsd2d import GPCSD2D  # noqa: F401
+from ._hip import GPCSDCapacityError, HipUnavailable  # noqa: F401
 
 __version__ = "0.1.0"

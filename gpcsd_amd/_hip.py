@@ -11,7 +11,10 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GPCSD_LIB_PATH") or os.path.join(_HERE, "libgpcsd_hip.so")
 
 MAX_TEMPORAL = 8
-KIND_SE, KIND_MATERN = 0, 1
+KIND_SE, KIND_MATERN, KIND_HOST = 0, 1, 2
+ERR_CAPACITY = -7
+MAX_EIG_N = 1024                 # GPCSD_MAX_EIG_N: rows of one eigenproblem (after symmetry folding)
+MAX_GEMM_OPERAND = 1 << 28       # GPCSD_MAX_GEMM_OPERAND: doubles in one flat GEMM operand (nx * ntrials * nt)
 PRED_CSD, PRED_LFP, PRED_BOTH = 1, 2, 3
 
 _c_double_p = ctypes.POINTER(ctypes.c_double)
@@ -27,6 +30,11 @@ class HParams(ctypes.Structure):
 
 class HipUnavailable(RuntimeError):
     pass
+
+
+class GPCSDCapacityError(RuntimeError):
+    """A problem exceeds a capacity limit of this build (include/gpcsd_hip.h: GPCSD_MAX_EIG_N, GPCSD_MAX_GEMM_OPERAND).
+    Deliberately not a ValueError / LinAlgError: fit() must not treat it as a failed restart and carry on."""
 
 
 _lib = None
@@ -48,6 +56,7 @@ SIGNATURES = {
     "gpcsd_set_geometry_1d": (_I, [_P, _DP, _I, _DP, _DP, _I]),
     "gpcsd_set_geometry_2d": (_I, [_P, _DP, _I, _DP, _DP, _I, _DP, _DP, _I]),
     "gpcsd_set_time": (_I, [_P, _DP, _I]),
+    "gpcsd_set_host_temporal_gram": (_I, [_P, _DP, _I, _DP, _I, _I]),
     "gpcsd_b_fwd_1d": (_I, [_P, _DP, _L, _D, _DP]),
     "gpcsd_b_fwd_2d": (_I, [_P, _DP, _DP, _DP, _L, _D, _D, _DP]),
     "gpcsd_gram_temporal": (_I, [_P, _I, _DP, _I, _DP, _I, _D, _D, _DP]),
@@ -151,6 +160,8 @@ class Context:
         msg = (self._lib.gpcsd_last_error(self._h) or b"").decode()
         if rc > 0:
             raise np.linalg.LinAlgError(msg or "numerical failure (status %d)" % rc)
+        if rc == ERR_CAPACITY:
+            raise GPCSDCapacityError(msg)
         if rc in (-3, -22):
             raise ValueError(msg)
         raise RuntimeError("libgpcsd_hip error %d: %s" % (rc, msg))
@@ -196,6 +207,25 @@ class Context:
     def set_time(self, t):
         t = _arr(t).reshape(-1)
         self._check(self._lib.gpcsd_set_time(self._h, _ptr(t), t.size))
+
+    def set_host_temporal_gram(self, Kt, Kt_cross=None):
+        """Temporal Gram matrices of user-defined covariances, evaluated by the caller: Kt (nt, nt) summed over components
+        and optionally Kt_cross (C, ntstar, nt) per component for predict.  Kt=None returns to the built-in builders."""
+        if Kt is None:
+            self._check(self._lib.gpcsd_set_host_temporal_gram(self._h, None, 0, None, 0, 0))
+            return
+        Kt = _arr(Kt)
+        nt = Kt.shape[0]
+        if Kt.shape != (nt, nt):
+            raise ValueError("Kt must be square, got %s" % (Kt.shape,))
+        if Kt_cross is None:
+            self._check(self._lib.gpcsd_set_host_temporal_gram(self._h, _ptr(Kt), nt, None, 0, 0))
+            return
+        Kt_cross = _arr(Kt_cross)
+        if Kt_cross.ndim != 3 or Kt_cross.shape[2] != nt:
+            raise ValueError("Kt_cross must have shape (C, ntstar, %d), got %s" % (nt, Kt_cross.shape))
+        self._check(self._lib.gpcsd_set_host_temporal_gram(self._h, _ptr(Kt), nt, _ptr(Kt_cross), Kt_cross.shape[0],
+                                                           Kt_cross.shape[1]))
 
     # ---- operators ----
     def b_fwd_1d(self, r, R):

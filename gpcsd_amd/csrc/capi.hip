@@ -22,8 +22,17 @@ static int fail(gpcsd_ctx *c, const HipError &e) {
         GP_HIP(hipSetDevice((ctx)->device));
 #define GP_API_END(ctx)                                                                        \
     }                                                                                          \
-    catch (const HipError &e) { return fail((ctx), e); }                                       \
-    catch (const std::exception &e) { return fail((ctx), HipError{-99, e.what()}); }
+    catch (const HipError &e) { drain_after_failure(ctx); return fail((ctx), e); }             \
+    catch (const std::exception &e) { drain_after_failure(ctx); return fail((ctx), HipError{-99, e.what()}); }
+
+// A call that throws after queueing work must not return while kernels or asynchronous copies that read the caller's
+// buffers are still in flight, and must not leave stale work on stream2 for the next call to race with (best effort).
+static void drain_after_failure(gpcsd_ctx *c) {
+    if (!c) return;
+    if (c->stream2) (void)hipStreamSynchronize(c->stream2);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    c->status_zeroed = false;
+}
 
 void gpcsd_ctx::prof_collect() {
     for (auto &kv : prof) {
@@ -138,12 +147,44 @@ void build_kt(gpcsd_ctx *c, const gpcsd_hparams *hp, const double *t, int n, con
     k_temporal_gram(c, hp->n_temporal, hp->kind, hp->ell_t, hp->sigma2_t, t, n, tp, m, out, s);
 }
 
+bool uses_host_kt(const gpcsd_hparams *hp);
+
+// Kt*_c = cov_c.compute_Kt(tstar) (ntstar, nt) of component cc (gpcsd1d.py:277): built on the device for SE / Matern, copied
+// from the caller's matrices when the temporal covariances are user-defined
+void temporal_cross_gram(gpcsd_ctx *c, const gpcsd_hparams *hp, int cc, const double *dts, int ntstar, const double *t, int nt,
+                         double *out, hipStream_t s) {
+    if (uses_host_kt(hp)) {
+        GP_REQUIRE(c->host_kt_C == hp->n_temporal && c->host_kt_ntstar == ntstar && c->host_kt_nt == nt &&
+                       c->host_kt_cross.size() == (size_t)hp->n_temporal * ntstar * nt, -3,
+                   "predict with user-defined temporal covariances needs the per-component cross Grams "
+                   "(gpcsd_set_host_temporal_gram: Kt_cross of shape (%d, %d, %d))", hp->n_temporal, ntstar, nt);
+        GP_HIP(hipMemcpyAsync(out, c->host_kt_cross.data() + (size_t)cc * ntstar * nt, (size_t)ntstar * nt * sizeof(double),
+                              hipMemcpyHostToDevice, s));
+        return;
+    }
+    k_temporal_gram(c, 1, &hp->kind[cc], &hp->ell_t[cc], &hp->sigma2_t[cc], dts, ntstar, t, nt, out, s);
+}
+
 void check_hp(gpcsd_ctx *c, const gpcsd_hparams *hp, int nx) {
     GP_REQUIRE(hp != nullptr, -3, "null hparams");
     GP_REQUIRE(hp->n_temporal >= 1 && hp->n_temporal <= GPCSD_MAX_TEMPORAL, -3, "n_temporal=%d outside [1,%d]",
                hp->n_temporal, GPCSD_MAX_TEMPORAL);
     GP_REQUIRE(hp->sig2n != nullptr && (hp->n_sig2n == 1 || hp->n_sig2n == nx), -3,
                "sig2n must have 1 or nx=%d entries (got %d)", nx, hp->n_sig2n);
+    for (int i = 0; i < hp->n_temporal; ++i) {
+        const int k = hp->kind[i];
+        GP_REQUIRE(k == GPCSD_KIND_SE || k == GPCSD_KIND_MATERN || k == GPCSD_KIND_HOST, -3, "unknown temporal kernel kind %d", k);
+        GP_REQUIRE(k != GPCSD_KIND_HOST || c->host_kt_on, -3,
+                   "temporal component %d is GPCSD_KIND_HOST but no Gram matrix was supplied (gpcsd_set_host_temporal_gram)", i);
+    }
+}
+
+// true when the temporal Gram matrices of this call come from the caller (any component of kind HOST)
+bool uses_host_kt(const gpcsd_hparams *hp) {
+    if (!hp) return false;
+    for (int i = 0; i < hp->n_temporal; ++i)
+        if (hp->kind[i] == GPCSD_KIND_HOST) return true;
+    return false;
 }
 
 // ---- reflection symmetry of a point set (host): find the involution i -> P(i) with pts[P(i)] = 2*centre - pts[i]
@@ -272,13 +313,22 @@ EigState front_half(gpcsd_ctx *c, const gpcsd_hparams *hp, double jitter, bool n
     e.scal = c->buf<double>("scal_status", 64 + 2);
     e.status = reinterpret_cast<int *>(e.scal + 64);
     const double *t = (const double *)c->bufs["time_t"].p;
-    const SymDev *sym_s = c->sym_s.ns > 0 ? &c->sym_s : nullptr, *sym_t = c->sym_t.ns > 0 ? &c->sym_t : nullptr;
+    const bool host_kt = uses_host_kt(hp);
+    if (host_kt)
+        GP_REQUIRE(c->host_kt_nt == nt && (int)c->host_kt.size() == nt * nt, -3,
+                   "host temporal Gram is %d x %d but the resident data has nt=%d", c->host_kt_nt, c->host_kt_nt, nt);
+    // a caller-supplied Gram need not commute with the reflection of the time grid (non-stationary kernels): no folding
+    const SymDev *sym_s = c->sym_s.ns > 0 ? &c->sym_s : nullptr, *sym_t = (c->sym_t.ns > 0 && !host_kt) ? &c->sym_t : nullptr;
+    auto make_kt = [&](hipStream_t st) {
+        if (host_kt) GP_HIP(hipMemcpyAsync(Kt, c->host_kt.data(), (size_t)nt * nt * sizeof(double), hipMemcpyHostToDevice, st));
+        else build_kt(c, hp, t, nt, t, nt, Kt, st);
+    };
     if (!two_stream_front()) {
         double *d_sig = c->upload_cached<double>("sig2n", hp->sig2n, hp->n_sig2n);
         if (!c->status_zeroed) GP_HIP(hipMemsetAsync(e.status, 0, 4 * sizeof(int), s));
         c->status_zeroed = false;
         build_kphi(c, g, hp->R, hp->eps, hp->ell_s, nullptr, 0, jitter, Ks, s);
-        build_kt(c, hp, t, nt, t, nt, Kt, s);
+        make_kt(s);
         // the symmetries come from the resident geometry / time grid, so they hold for the Grams built from them
         eig_pair_D(c, Ks, nx, Kt, nt, d_sig, hp->n_sig2n, e.Qs, e.es, e.Qt, e.et, e.D, e.Dinv, e.scal, e.status, sym_s, sym_t,
                    need_merged);
@@ -296,7 +346,7 @@ EigState front_half(gpcsd_ctx *c, const gpcsd_hparams *hp, double jitter, bool n
     c->status_zeroed = false;
     GP_HIP(hipEventRecord(c->ev_fork, s));
     GP_HIP(hipStreamWaitEvent(s2, c->ev_fork, 0));
-    build_kt(c, hp, t, nt, t, nt, Kt, s2);
+    make_kt(s2);
     {
         ProfScope ps(c, "eigh_temporal", 9.0 * (double)nt * nt * nt, s2);
         eigh_pair_device(c, nullptr, 0, nullptr, nullptr, nullptr, Kt, nt, e.et, e.Qt, sym_t, e.status + 1, s2, need_merged);
@@ -361,7 +411,7 @@ static FoldMode fold_mode(gpcsd_ctx *c, const gpcsd_hparams *hp) {
     FoldMode fm;
     if (off || !c->fold_gemm_on || hp->n_sig2n != 1 || c->nx <= 0 || c->nt <= 0) return fm;
     if (c->sym_s.ns > 0) fm.fs = eigh_fold_view(c, 0, &c->sym_s, c->nx);
-    if (c->sym_t.ns > 0) fm.ft = eigh_fold_view(c, 1, &c->sym_t, c->nt);
+    if (c->sym_t.ns > 0 && !uses_host_kt(hp)) fm.ft = eigh_fold_view(c, 1, &c->sym_t, c->nt);
     if (!fm.fs.on && !fm.ft.on) return fm;
     fm.on = true;
     if (fm.fs.on) fm.sym_s = c->sym_s;
@@ -530,10 +580,6 @@ extern "C" int gpcsd_ctx_destroy(gpcsd_ctx *c) {
     for (auto e : c->event_pool) (void)hipEventDestroy(e);
     for (auto &kv : c->graphs)
         if (kv.second.exec) (void)hipGraphExecDestroy(kv.second.exec);
-    for (int i = 0; i < 4; ++i) {
-        if (c->side_ev[i]) (void)hipEventDestroy(c->side_ev[i]);
-        if (c->side[i]) (void)hipStreamDestroy(c->side[i]);
-    }
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -1054,6 +1100,34 @@ extern "C" int gpcsd_loglik_dense_chol(gpcsd_ctx *c, const double *Ks, int nx, c
     GP_API_END(c)
 }
 
+extern "C" int gpcsd_set_host_temporal_gram(gpcsd_ctx *c, const double *Kt, int nt, const double *Kt_cross, int ncomp,
+                                            int ntstar) {
+    GP_API_BEGIN(c)
+    if (!Kt) {                                  // back to the built-in SE / Matern builders
+        c->host_kt_on = false;
+        c->host_kt.clear();
+        c->host_kt_cross.clear();
+        c->host_kt_nt = c->host_kt_C = c->host_kt_ntstar = 0;
+        return 0;
+    }
+    GP_REQUIRE(nt > 0, -3, "set_host_temporal_gram: nt must be positive");
+    GP_REQUIRE(!Kt_cross || (ncomp >= 1 && ncomp <= GPCSD_MAX_TEMPORAL && ntstar > 0), -3,
+               "set_host_temporal_gram: bad cross-Gram shape (%d, %d, %d)", ncomp, ntstar, nt);
+    c->host_kt.assign(Kt, Kt + (size_t)nt * nt);
+    c->host_kt_nt = nt;
+    if (Kt_cross) {
+        c->host_kt_cross.assign(Kt_cross, Kt_cross + (size_t)ncomp * ntstar * nt);
+        c->host_kt_C = ncomp;
+        c->host_kt_ntstar = ntstar;
+    } else {
+        c->host_kt_cross.clear();
+        c->host_kt_C = c->host_kt_ntstar = 0;
+    }
+    c->host_kt_on = true;
+    return 0;
+    GP_API_END(c)
+}
+
 extern "C" int gpcsd_set_gram_precision(gpcsd_ctx *c, int bits) {
     GP_API_BEGIN(c)
     GP_REQUIRE(bits == 32 || bits == 64, -3, "gram precision must be 32 or 64 bits (got %d)", bits);
@@ -1191,7 +1265,7 @@ static int predict_fold(gpcsd_ctx *c, const gpcsd_hparams *hp, EigState &e, cons
         }
     }
     for (int cc = 0; cc < C; ++cc) {
-        k_temporal_gram(c, 1, &hp->kind[cc], &hp->ell_t[cc], &hp->sigma2_t[cc], dts, nt, t, nt, Kts + (size_t)cc * nt * nt, s);
+        temporal_cross_gram(c, hp, cc, dts, nt, t, nt, Kts + (size_t)cc * nt * nt, s);
         k_sym_fold_rect(c, Kts + (size_t)cc * nt * nt, nt, fm.sym_t, fm.sym_t, Ktf + cc * ktf_sz,
                         Ktf + cc * ktf_sz + (size_t)nts * nts, s);
     }
@@ -1318,7 +1392,7 @@ static int predict_impl(gpcsd_ctx *c, const gpcsd_hparams *hp, const double *z, 
     for (int cc = 0; cc < C; ++cc) {
         // Ktstar_c = cov_c.compute_Kt(tstar): (ntstar, nt); its FIRST axis is contracted with the training
         // time index (reference quirk when tstar != t)      gpcsd1d.py:277-279
-        k_temporal_gram(c, 1, &hp->kind[cc], &hp->ell_t[cc], &hp->sigma2_t[cc], dts, ntstar, t, nt, Kts + (size_t)cc * ntstar * nt, s);
+        temporal_cross_gram(c, hp, cc, dts, ntstar, t, nt, Kts + (size_t)cc * ntstar * nt, s);
     }
     join_temporal(c, e, nullptr, false);      // predict never reads sum(log D)
     GemmDesc g2;                          // Bm = (W Qt) / D
@@ -1417,7 +1491,12 @@ extern "C" int gpcsd_sample_prior(gpcsd_ctx *c, const gpcsd_hparams *hp, int whi
     } else {
         build_kphi(c, g, hp->R, hp->eps, hp->ell_s, nullptr, 0, hp->jitter, Ks, s);   // gpcsd2d.py:346-347
     }
-    build_kt(c, hp, t, nt, t, nt, Kt, s);
+    if (uses_host_kt(hp)) {
+        GP_REQUIRE(c->host_kt_nt == nt && (int)c->host_kt.size() == nt * nt, -3, "host temporal Gram does not match nt=%d", nt);
+        GP_HIP(hipMemcpyAsync(Kt, c->host_kt.data(), (size_t)nt * nt * sizeof(double), hipMemcpyHostToDevice, s));
+    } else {
+        build_kt(c, hp, t, nt, t, nt, Kt, s);
+    }
     potrf_device(c, Kt, nt, st, s);                                                 // Lt
     potrf_device(c, Ks, nx, st, s);                                                 // Ls
     double *stage = c->upload<double>("sp_stage", normals, (size_t)nx * RT);
@@ -1448,14 +1527,19 @@ static bool env_flag_off(const char *name) {       // NAME=0 switches a term off
 extern "C" int gpcsd_loglik_grad(gpcsd_ctx *c, const gpcsd_hparams *hp, double *out2, double *grad, int ngrad) {
     GP_API_BEGIN(c)
     GP_REQUIRE(out2 && grad && hp, -3, "loglik_grad: null argument");
-    EigState e = front_half(c, hp, hp->jitter);        // leaves A, Kgl, T = A Kgl in the ks_* buffers
+    // every argument check comes before any work is queued (front_half launches on two streams and uploads hp->sig2n)
     const Geo g = resident_geo(c);
+    GP_REQUIRE(c->d_lfp != nullptr, -4, "lfp not set (call gpcsd_set_lfp)");
+    check_hp(c, hp, c->nx);
+    GP_REQUIRE(!uses_host_kt(hp), -3, "loglik_grad: no analytic gradient for user-defined temporal covariances "
+                                      "(their derivative is not known to the library; use finite differences of gpcsd_loglik)");
     const int nx = c->nx, nt = c->nt, R = c->ntrials, C = hp->n_temporal, G = g.G();
     // scalar sig2n: one trailing entry; per-electrode list (indexed by eigen-row like the reference's D): nx entries
     const int nsig = hp->n_sig2n;
     GP_REQUIRE(nsig == 1 || nsig == nx, -3, "loglik_grad: sig2n must be a scalar or a list of nx=%d values (got %d)", nx, nsig);
     const int nhead = 1 + g.dim + 2 * C;
     GP_REQUIRE(ngrad == nhead + nsig, -3, "loglik_grad: ngrad=%d, expected %d", ngrad, nhead + nsig);
+    EigState e = front_half(c, hp, hp->jitter);        // leaves A, Kgl, T = A Kgl in the ks_* buffers
     const long RT = (long)R * nt;
     hipStream_t s = c->stream;
     const double *A = (const double *)c->bufs["ks_A"].p, *Kgl = (const double *)c->bufs["ks_Kgl"].p,

@@ -68,22 +68,6 @@ struct gpcsd_ctx {
     double *h_result = nullptr;             // pinned host landing zone for the end-of-call copy (66 doubles)
     bool capturing = false;                 // inside a stream capture: profiling scopes stay silent
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-    hipStream_t side[4] = {nullptr, nullptr, nullptr, nullptr};   // fork/join branches for independent small chains
-    hipEvent_t side_ev[4] = {nullptr, nullptr, nullptr, nullptr};
-    // Forking the independent back-transformation / merge-GEMM chains onto side streams was measured SLOWER on MI355X
-    // (8.8 vs 6.7 ms per cfg3 step: every cross-stream event wait costs more than the launches it overlaps), so it is
-    // off unless GPCSD_FORK=1.
-    static bool fork_on() {
-        static const bool v = (getenv("GPCSD_FORK") && getenv("GPCSD_FORK")[0] == '1');
-        return v;
-    }
-    hipStream_t side_stream(int i) {
-        if (!side[i]) {
-            GP_HIP(hipStreamCreateWithFlags(&side[i], hipStreamNonBlocking));
-            GP_HIP(hipEventCreateWithFlags(&side_ev[i], hipEventDisableTiming));
-        }
-        return side[i];
-    }
     std::string last_error;
     std::map<std::string, gpcsd::DevBuf> bufs;
     bool prof_on = false;
@@ -117,6 +101,12 @@ struct gpcsd_ctx {
     bool gram_fp32 = false;                 // gpcsd_set_gram_precision(): Gram builders evaluate in float (cfg5 variant)
     bool fold_gemm_on = true;               // gpcsd_fold_gemm()
     long fold_gemm_calls = 0;
+    // user-defined temporal covariances (covariances.py:235-238: any object with compute_Kt): the caller evaluates the
+    // Gram matrices on the host and hands them over (gpcsd_set_host_temporal_gram); the fused calls then upload them
+    // instead of running the SE / Matern builders.  Copies: no host pointer outlives the setter.
+    bool host_kt_on = false;
+    std::vector<double> host_kt, host_kt_cross;   // (nt, nt) sum over components; (C, ntstar, nt) per component or empty
+    int host_kt_nt = 0, host_kt_C = 0, host_kt_ntstar = 0;
 
     // ---- device buffers: grow-only, keyed by name, freed in destroy ----
     template <typename T = double>

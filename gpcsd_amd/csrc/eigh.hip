@@ -11,6 +11,7 @@
 //             halving n halves its time; the eigenvalues are the union of the two spectra, merged in ascending order.
 // GPCSD_EIGH=jacobi forces the single-workgroup Jacobi on global memory for any n (slow; independent cross-check).
 // GPCSD_NO_GRAPH=1 disables graph replay, GPCSD_NO_SYMFOLD=1 disables the symmetry folding.
+#include <algorithm>
 #include <cstdlib>
 
 #include "jacobi.hpp"
@@ -224,7 +225,12 @@ static void eigh_pair_enqueue(gpcsd_ctx *c, double *A0, int n0, double *w0, doub
 // replayed.  A graph is retired whenever any context buffer is (re)allocated, since it holds raw device pointers.
 void eigh_pair_device(gpcsd_ctx *c, double *A0, int n0, double *w0, double *Z0, const SymDev *sym0, double *A1, int n1,
                       double *w1, double *Z1, const SymDev *sym1, int *d_status, hipStream_t s, bool need_merged) {
-    GP_REQUIRE(n0 <= JACOBI_MAX_N && n1 <= JACOBI_MAX_N, -3, "eigh: n=%d/%d exceeds %d", n0, n1, JACOBI_MAX_N);
+    // the limit applies to what the solver actually factorises: a symmetry-folded problem is two half-size ones
+    const int m0 = fold_applies(sym0, n0) ? std::max(sym0->ns, sym0->na) : n0;
+    const int m1 = fold_applies(sym1, n1) ? std::max(sym1->ns, sym1->na) : n1;
+    GP_REQUIRE(m0 <= JACOBI_MAX_N && m1 <= JACOBI_MAX_N, GPCSD_ERR_CAPACITY,
+               "eigh: matrix order %d / %d (after symmetry folding: %d / %d) exceeds the eigensolver's capacity of %d rows "
+               "(GPCSD_MAX_EIG_N)", n0, n1, m0, m1, JACOBI_MAX_N);
     const bool any_large = !force_jacobi() && (n0 > JACOBI_LDS_MAX || n1 > JACOBI_LDS_MAX);
     // GPCSD_PROF_GRAPH=1: keep replaying graphs while profiling, so the outer scopes time the chains as they run in production
     static const bool prof_graph = getenv("GPCSD_PROF_GRAPH") != nullptr;
@@ -275,7 +281,9 @@ void eigh_pair_device(gpcsd_ctx *c, double *A0, int n0, double *w0, double *Z0, 
 
 void eigh_device(gpcsd_ctx *c, double *A, int n, double *evals, double *evecs, int *d_status, hipStream_t s,
                  const char *tag) {
-    GP_REQUIRE(n >= 1 && n <= JACOBI_MAX_N, -3, "eigh: n=%d outside [1,%d]", n, JACOBI_MAX_N);
+    GP_REQUIRE(n >= 1, -3, "eigh: n=%d must be positive", n);
+    GP_REQUIRE(n <= JACOBI_MAX_N, GPCSD_ERR_CAPACITY, "eigh: matrix order %d exceeds the eigensolver's capacity of %d rows (GPCSD_MAX_EIG_N)", n,
+               JACOBI_MAX_N);
     (void)tag;
     eigh_pair_device(c, A, n, evals, evecs, nullptr, nullptr, 0, nullptr, nullptr, nullptr, d_status, s, true);
 }

@@ -78,7 +78,6 @@ struct SytrdBatch {
 
 }  // namespace gpcsd
 #include "sytrd_regtail.hpp"
-#include "sytrd_regtail6.hpp"
 namespace gpcsd {
 
 // JQ = ceil(trailing columns / 64) this launch may need (2, 4, 8 or 16).  Every global load of the step -- the slab
@@ -230,146 +229,11 @@ __global__ void sytrd_last_diag_kernel(SytrdBatch b) {
     if (n >= 2) P.tau[n - 2] = 0.0;
 }
 
-// The last SY_TAIL columns of every problem in ONE launch: the trailing block (<= 113 x 113) lives in LDS, so a column
-// costs a few workgroup barriers (~0.7 us) instead of a dependent launch (~4 us).  512 threads, 4 per trailing row.
-constexpr int SY_TAIL = 112;
-constexpr int SY_TLD = 132;                  // LDS row stride, = 4 mod 32: the 8 rows x 4 doubles a half-wave reads hit 64 distinct banks
-
-__global__ __launch_bounds__(512) void sytrd_tail_kernel(SytrdBatch b) {
-    const SytrdProb &P = b.p[blockIdx.x];
-    const int n = P.n, k0 = P.k_tail;
-    if (k0 >= n - 1) return;
-    const int T = n - k0;                    // rows / columns k0 .. n-1
-    extern __shared__ double sm[];
-    double *As = sm;                         // [T][SY_TLD]
-    double *v = As + (SY_TAIL + 1) * SY_TLD, *w = v + 128, *y = w + 128, *red = y + 128;
-    double *sd = red + 32, *se = sd + 128, *st = se + 128;      // d, e, tau of the tail columns (flushed at the end)
-    const int tid = threadIdx.x;
-    const double *__restrict__ Ain = (k0 & 1) ? P.A1 : P.A0;
-    const double *__restrict__ yin = (k0 & 1) ? P.y1 : P.y0;
-    // pending rank-2 update of step k0-1
-    if (k0 > 0) {
-        const double *__restrict__ vp = P.V + (long)(k0 - 1) * n;
-        const double taup = P.tau[k0 - 1];
-        double pv = 0.0, py = 0.0;
-        if (tid < T) {
-            pv = vp[k0 + tid];
-            py = yin[k0 + tid];
-        }
-        const double dot = block_sum<8>(pv * py, red);
-        const double cc = 0.5 * taup * taup * dot;
-        if (tid < T) {
-            v[tid] = pv;
-            w[tid] = taup * py - cc * pv;
-        }
-    } else if (tid < T) {
-        v[tid] = 0.0;
-        w[tid] = 0.0;
-    }
-    __syncthreads();
-    for (int idx = tid; idx < T * T; idx += 512) {
-        const int i = idx / T, j = idx % T;
-        As[i * SY_TLD + j] = Ain[(long)(k0 + i) * n + k0 + j] - v[i] * w[j] - w[i] * v[j];
-    }
-    __syncthreads();
-    const int grp = tid >> 2, sub = tid & 3;             // 4 threads per trailing row
-    __shared__ double s_xn;
-    double xnorm2;
-    {
-        double part = 0.0;
-        for (int j = 2 + tid; j < T; j += 512) part += As[j] * As[j];
-        xnorm2 = block_sum<8>(part, red);
-    }
-    // Four barriers per column: publish v | (y and v.y via one block reduction) | update + next column's norm.
-    for (int kk = 0; kk < T - 1; ++kk) {
-        const int k = k0 + kk;
-        const int m = T - kk - 1;                        // trailing size below the pivot
-        const double *prow = As + kk * SY_TLD;
-        const double dk = prow[kk], alpha = prow[kk + 1];
-        double tau = 0.0, beta = alpha, scal = 0.0;
-        if (m >= 2 && xnorm2 > 0.0 && alpha * alpha + xnorm2 > 1e-100) {
-            beta = -copysign(sqrt(alpha * alpha + xnorm2), alpha);
-            tau = (beta - alpha) / beta;
-            scal = 1.0 / (alpha - beta);
-        }
-        // No global traffic inside the loop (a barrier would wait for the stores): the reflector replaces the consumed
-        // pivot row in LDS, LAPACK-style, and d / e / tau collect in LDS; everything is flushed once after the loop.
-        for (int j = kk + 1 + tid; j < T; j += 512) v[j] = (j == kk + 1) ? 1.0 : prow[j] * scal;
-        if (tid == 0) {
-            sd[kk] = dk;
-            se[kk] = beta;
-            st[kk] = tau;
-        }
-        (void)k;
-        __syncthreads();
-        for (int j = kk + 1 + tid; j < T; j += 512) As[kk * SY_TLD + j] = v[j];
-        const bool upd = (tau != 0.0);
-        const int i = kk + 1 + grp;
-        double vi = 0.0, wi = 0.0, cc = 0.0;
-        if (upd) {
-            // y = A22 v (rows kk+1 .. T-1, 4 threads per row); v.y from the same registers
-            double acc = 0.0;
-            if (i < T) {
-                const double *ar = As + i * SY_TLD;
-#pragma unroll 8
-                for (int j = kk + 1 + sub; j < T; j += 4) acc += ar[j] * v[j];
-            }
-            acc += dpp_mov<0xB1>(acc);                   // fold the 4 threads of a row (quad permutes stay in the VALU)
-            acc += dpp_mov<0x4E>(acc);
-            if (i < T && sub == 0) y[i] = acc;
-            const double dot = block_sum<8>((i < T && sub == 0) ? acc * v[i] : 0.0, red);   // its barriers publish y
-            cc = 0.5 * tau * tau * dot;
-            if (i < T) {
-                vi = v[i];
-                wi = tau * y[i] - cc * vi;
-            }
-        }
-        // rank-2 update with w_j = tau y_j - cc v_j formed on the fly, and ||next pivot row||^2 by that row's threads
-        double xn = 0.0;
-        if (i < T) {
-            double *ar = As + i * SY_TLD;
-#pragma unroll 8
-            for (int j = kk + 1 + sub; j < T; j += 4) {
-                double a = ar[j];
-                if (upd) {
-                    const double vj = v[j];
-                    a -= vi * (tau * y[j] - cc * vj) + wi * vj;
-                    ar[j] = a;
-                }
-                if (j >= kk + 3) xn += a * a;
-            }
-        }
-        xn += dpp_mov<0xB1>(xn);
-        xn += dpp_mov<0x4E>(xn);
-        if (i == kk + 1 && sub == 0) s_xn = xn;
-        __syncthreads();
-        xnorm2 = s_xn;
-    }
-    for (int idx = tid; idx < (T - 1) * T; idx += 512) {
-        const int kk = idx / T, j = idx % T;
-        if (j > kk) P.V[(long)(k0 + kk) * n + k0 + j] = As[kk * SY_TLD + j];
-    }
-    for (int kk = tid; kk < T - 1; kk += 512) {
-        P.d[k0 + kk] = sd[kk];
-        P.e[k0 + kk] = se[kk];
-        P.tau[k0 + kk] = st[kk];
-    }
-    if (tid == 0) {
-        P.d[n - 1] = As[(T - 1) * SY_TLD + (T - 1)];
-        P.e[n - 1] = 0.0;
-        P.tau[n - 1] = 0.0;
-    }
-}
-
 // rows the single-workgroup tail (sytrd_regtail.hpp) can hold: 192 in registers + up to 64 strip rows in LDS
-// (GPCSD_TAIL_STRIP=0: registers only, the leading rows go through per-column launches as before)
+// (GPCSD_TAIL_STRIP=0: registers only, the leading rows go through per-column launches)
 static int sy_regtail_rows() {
     static const bool nostrip = getenv("GPCSD_TAIL_STRIP") && getenv("GPCSD_TAIL_STRIP")[0] == '0';
     return nostrip ? RT_T : RT_TMAX;
-}
-static bool sytrd_reg_tail() {               // GPCSD_TAIL=lds selects the older LDS-resident tail (A/B comparisons)
-    static const bool lds = getenv("GPCSD_TAIL") && !strcmp(getenv("GPCSD_TAIL"), "lds");
-    return !lds;
 }
 
 static void sytrd_batch_launch(gpcsd_ctx *c, const SytrdBatch &b, int count, int nmax, hipStream_t s) {
@@ -387,7 +251,7 @@ static void sytrd_batch_launch(gpcsd_ctx *c, const SytrdBatch &b, int count, int
         else if (m <= 512) hipLaunchKernelGGL(sytrd_step_kernel<8>, grid, dim3(256), 0, s, b, k);
         else hipLaunchKernelGGL(sytrd_step_kernel<16>, grid, dim3(256), 0, s, b, k);
     }
-    if (any_tail && sytrd_reg_tail()) {
+    if (any_tail) {
         size_t sh = 0;
         for (int i = 0; i < count; ++i)
             if (b.p[i].k_tail < b.p[i].n - 1) sh = std::max(sh, rt_strip_bytes(b.p[i].n - b.p[i].k_tail));
@@ -395,25 +259,9 @@ static void sytrd_batch_launch(gpcsd_ctx *c, const SytrdBatch &b, int count, int
         if (!rt_attr_set) {
             GP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(sytrd_rtail_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)rt_strip_bytes(RT_TMAX)));
-            GP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(sytrd_rtail6_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)rt_strip_bytes(RT_TMAX)));
             rt_attr_set = true;
         }
-        // default: 768 threads, 4 x 12 tiles.  GPCSD_TAIL_V=6: 512 threads, 6 x 12 tiles (sytrd_regtail6.hpp) -- fewer LDS
-        // instructions and waves, measured 8 % SLOWER per launch (two waves per SIMD hide the dependent fp64 chains of the
-        // reductions worse than three); kept selectable for A/B runs on other problem shapes
-        static const bool v6 = getenv("GPCSD_TAIL_V") && getenv("GPCSD_TAIL_V")[0] == '6';
-        if (v6) hipLaunchKernelGGL(sytrd_rtail6_kernel, dim3(count), dim3(R6_NTH), sh, s, b);
-        else hipLaunchKernelGGL(sytrd_rtail_kernel, dim3(count), dim3(RT_NTH), sh, s, b);
-    } else if (any_tail) {
-        const size_t sh = ((size_t)(SY_TAIL + 1) * SY_TLD + 6 * 128 + 32) * sizeof(double);
-        static bool attr_set = false;
-        if (!attr_set) {
-            GP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(sytrd_tail_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
-            attr_set = true;
-        }
-        hipLaunchKernelGGL(sytrd_tail_kernel, dim3(count), dim3(512), sh, s, b);
+        hipLaunchKernelGGL(sytrd_rtail_kernel, dim3(count), dim3(RT_NTH), sh, s, b);
     }
     if (!all_tail) hipLaunchKernelGGL(sytrd_last_diag_kernel, dim3(count), dim3(64), 0, s, b);
     GP_HIP(hipGetLastError());
@@ -509,8 +357,8 @@ static void prep_problem(gpcsd_ctx *c, EigProb &p, hipStream_t s) {
     p.sp.n = n;
     {
         static const bool no_tail = getenv("GPCSD_NO_TAIL") && getenv("GPCSD_NO_TAIL")[0] == '1';
-        // the trailing block finishes inside one workgroup (registers: 192 rows; LDS variant: 113 rows)
-        p.sp.k_tail = no_tail ? n - 1 : (sytrd_reg_tail() ? std::max(0, n - sy_regtail_rows()) : std::max(0, n - 1 - 112));
+        // the trailing block finishes inside one workgroup (192 rows in registers + up to 64 strip rows in LDS)
+        p.sp.k_tail = no_tail ? n - 1 : std::max(0, n - sy_regtail_rows());
     }
     p.sp.A0 = c->buf<double>(T + "A0", nn);
     p.sp.A1 = c->buf<double>(T + "A1", nn);
@@ -646,32 +494,19 @@ void eigh_large_batch(gpcsd_ctx *c, EigProb *probs, int count, int *d_status, hi
             sp[i].w = probs[i].w; sp[i].Z = probs[i].Z; sp[i].tag = probs[i].tag;
         }
         // the T factors of the back-transformation need the reflectors only: they ride in the leaf launch of the D&C stage
-        // (GPCSD_WY_IN_LEAF=0: their own launch after it; GPCSD_DC_LEAF=lds has no combined kernel either)
-        static const bool lds_leaf = getenv("GPCSD_DC_LEAF") && !strcmp(getenv("GPCSD_DC_LEAF"), "lds");
-        prep_done = wy_fused && wy_in_leaf && !lds_leaf;
+        // (GPCSD_WY_IN_LEAF=0: their own launch after it)
+        prep_done = wy_fused && wy_in_leaf;
         stedc_batch_device(c, sp, count, d_status, s, prep_done ? &wb : nullptr);
     }
-    // The back-transformations are independent chains of small GEMMs: fork one branch per problem (parallel branches
-    // of the captured graph; concurrent streams when run eagerly) and join.
     if (wy_fused) {
         ProfScope ps(c, "eigh_backtransform", 0.0, s);
         wy_batch_device(c, wb, count, s, prep_done);
-    } else {
+    } else {                                   // n too large for the LDS-resident apply kernel: GEMM chain per panel
         ProfScope ps(c, "eigh_backtransform", 0.0, s);
-        if (count > 1 && c->fork_on()) GP_HIP(hipEventRecord(c->ev_fork, s));
         for (int i = 0; i < count; ++i) {
             EigProb &p = probs[i];
-            hipStream_t bs = s;
-            if (i > 0 && c->fork_on()) {
-                bs = c->side_stream(i);
-                GP_HIP(hipStreamWaitEvent(bs, c->ev_fork, 0));
-            }
-            ormtr_device(c, p.sp.V, p.sp.tau, p.n, p.Z, bs, "eig_" + p.tag + "_");
-            hipLaunchKernelGGL(scale_vec_kernel, dim3(ceil_div(p.n, 256)), dim3(256), 0, bs, p.w, p.n, (const double *)p.amax);
-            if (i > 0 && c->fork_on()) {
-                GP_HIP(hipEventRecord(c->side_ev[i], bs));
-                GP_HIP(hipStreamWaitEvent(s, c->side_ev[i], 0));
-            }
+            ormtr_device(c, p.sp.V, p.sp.tau, p.n, p.Z, s, "eig_" + p.tag + "_");
+            hipLaunchKernelGGL(scale_vec_kernel, dim3(ceil_div(p.n, 256)), dim3(256), 0, s, p.w, p.n, (const double *)p.amax);
         }
     }
     GP_HIP(hipGetLastError());

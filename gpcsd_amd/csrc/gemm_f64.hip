@@ -466,8 +466,12 @@ void gemm_f64(gpcsd_ctx *c, const GemmDesc &g, hipStream_t s) {
     if (!s) s = c->stream;
     GP_REQUIRE(g.M > 0 && g.N > 0 && g.K > 0, -3, "gemm_f64: empty problem %dx%dx%d", g.M, g.N, g.K);
     // 32-bit byte offsets inside one batch entry's operand (buffer_load voffset + soffset)
-    GP_REQUIRE((g.transA ? (long)g.K : (long)g.M) * g.lda < (1L << 28) && (g.transB ? (long)g.N : (long)g.K) * g.ldb < (1L << 28), -3,
-               "gemm_f64: operand too large for 32-bit offsets (lda %ld, ldb %ld)", g.lda, g.ldb);
+    GP_REQUIRE((g.transA ? (long)g.K : (long)g.M) * g.lda < (1L << 28) && (g.transB ? (long)g.N : (long)g.K) * g.ldb < (1L << 28),
+               GPCSD_ERR_CAPACITY,
+               "gemm_f64: operand of %ld x %ld doubles exceeds the 2^28-element capacity of one flat GEMM operand "
+               "(GPCSD_MAX_GEMM_OPERAND; e.g. nx * ntrials * nt per resident block of trials)",
+               (g.transA ? (long)g.K : (long)g.M) * g.lda >= (1L << 28) ? (g.transA ? (long)g.K : (long)g.M) : (g.transB ? (long)g.N : (long)g.K),
+               (g.transA ? (long)g.K : (long)g.M) * g.lda >= (1L << 28) ? g.lda : g.ldb);
     GemmK k;
     k.M = g.M; k.N = g.N; k.K = g.K;
     k.A = g.A; k.lda = g.lda; k.B = g.B; k.ldb = g.ldb; k.C = g.C; k.ldc = g.ldc; k.C2 = g.C2; k.C3 = g.C3;

@@ -63,29 +63,6 @@ __device__ __forceinline__ Seg load_seg(const DcWork &w, int off, int m) {
 // ------------------------------------------------------------------------------------------------------------------
 // tears + leaves
 // ------------------------------------------------------------------------------------------------------------------
-// Tears, plus zeroing of both ping-pong eigenvector matrices: a merge reads the off-diagonal blocks between its two
-// halves, which no earlier level writes (blocks are nested, so zeros outside the blocks of a level survive until they
-// are merged).
-__global__ __launch_bounds__(256) void dc_tear_kernel(DcLevel L) {
-    const DcWork &w = L.w[blockIdx.y];
-    const int n = w.n, nb = L.aux[blockIdx.y];
-    const int *bounds = w.tbl + L.seg_off[blockIdx.y];
-    const long stride = (long)gridDim.x * 256, i0 = blockIdx.x * 256L + threadIdx.x;
-    const long nn = (long)n * n;
-    for (long i = i0; i < nn; i += stride) {
-        w.Qcur[i] = 0.0;
-        w.Qnext[i] = 0.0;
-    }
-    for (long i = i0; i < n; i += stride) {
-        double v = w.d0[i];
-        for (int t = 0; t < nb; ++t) {
-            const int a = bounds[t];
-            if (a - 1 == i || a == i) v -= fabs(w.e[a - 1]);
-        }
-        w.dwork[i] = v;
-    }
-}
-
 // eigenvalues / eigenvectors of the top level into the caller's arrays, all problems in one launch
 __global__ __launch_bounds__(256) void dc_output_kernel(DcLevel L) {
     const DcWork &w = L.w[blockIdx.y];
@@ -231,28 +208,6 @@ __global__ __launch_bounds__(1024) void dc_leaf_wyprep_kernel(DcLevel L, int *st
     const int bx = ((int)blockIdx.x - nprep) * 16 + ((int)threadIdx.x >> 6);
     if (bx >= nunits) return;
     dc_leaf_reg_body(L, status, nleaf_max, bx, (int)blockIdx.y, (int)threadIdx.x & 63);
-}
-
-// one wave per leaf: dense leaf matrix in LDS -> Jacobi -> dcur[lo:hi], Qcur diagonal block
-__global__ __launch_bounds__(64) void dc_leaf_kernel(DcLevel L, int *status) {
-    const DcWork &w = L.w[blockIdx.y];
-    if ((int)blockIdx.x >= L.aux[blockIdx.y]) return;
-    const int n = w.n;
-    const int lo = w.tbl[blockIdx.x], hi = w.tbl[blockIdx.x + 1];
-    const int m = hi - lo;
-    constexpr int LD = DC_LEAF + 1;
-    __shared__ double A[DC_LEAF * LD], V[DC_LEAF * LD], cs[DC_LEAF + 2], red[64];
-    __shared__ int pq[2 * DC_LEAF + 2];
-    for (int idx = threadIdx.x; idx < m * m; idx += 64) {
-        const int i = idx / m, j = idx % m;
-        double v = 0.0;
-        if (i == j) v = w.dwork[lo + i];
-        else if (j == i + 1) v = w.e[lo + i];
-        else if (i == j + 1) v = w.e[lo + j];
-        A[i * LD + j] = v;
-    }
-    __syncthreads();
-    jacobi_body<64>(A, LD, V, LD, m, w.dcur + lo, w.Qcur + (long)lo * n + lo, (long)n, status, cs, pq, red);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -991,7 +946,7 @@ __device__ void dc_small_tail(const DcWork &w, const Seg sg, SetupShared &S, Sma
     }
 }
 
-__global__ __launch_bounds__(NT_SMALL) void dc_small_level_kernel(DcLevel L, int fast) {
+__global__ __launch_bounds__(NT_SMALL) void dc_small_level_kernel(DcLevel L) {
     const DcWork &w = L.w[blockIdx.z];
     const int m = blockIdx.x;
     if (m >= L.nseg[blockIdx.z]) return;
@@ -1012,42 +967,7 @@ __global__ __launch_bounds__(NT_SMALL) void dc_small_level_kernel(DcLevel L, int
         Q.kz[tid] = (tid < K) ? w.zk[lo + tid] : 0.0;
     }
     __syncthreads();
-    if (fast) {
-        dc_small_tail(w, sg, S, Q, Q2s, K, rho);
-        return;
-    }
-    for (int i = wid; i < K; i += NW) dc_secular_root(w, lo, K, rho, i);
-    __syncthreads();
-    for (int i = wid; i < K; i += NW) dc_zhat_one(w, lo, K, rho, i);
-    __syncthreads();
-    for (int j = wid; j < K; j += NW) dc_colnorm_one(w, lo, K, j);
-    __syncthreads();
-    // U (K x K) into LDS (reusing the setup arrays: 2 * EIG_MAXN doubles >= 64 * 64 / 2 ... use sd|sz|ds|zs = 4096 doubles)
-    double *U = S.sd;                                     // sd, sz, ds, zs are contiguous: 4 * EIG_MAXN doubles
-    for (int idx = tid; idx < K * K; idx += NT_SMALL) {
-        const int i = idx / K, j = idx % K;
-        U[i * DC_SMALL + j] = dc_u_elem(w, lo, i, j);
-    }
-    __syncthreads();
-    // W = Q2 U  (N x K): Q2 staged in LDS (row stride DC_SMALL+1 keeps the j-walk conflict free), U in LDS
-    for (int idx = tid; idx < N * K; idx += NT_SMALL) {
-        const int r = idx / K, j = idx % K;
-        Q2s[r * (DC_SMALL + 1) + j] = w.Q2w[(long)(lo + r) * n + lo + j];
-    }
-    __syncthreads();
-    for (int idx = tid; idx < N * K; idx += NT_SMALL) {
-        const int r = idx / K, t = idx % K;
-        const double *q2 = Q2s + r * (DC_SMALL + 1);
-        double acc = 0.0;
-        for (int j = 0; j < K; ++j) acc += q2[j] * U[j * DC_SMALL + t];
-        w.Ww[(long)(lo + r) * n + lo + t] = acc;
-    }
-    __syncthreads();
-    double *val = S.sd;
-    int *src = S.sperm;
-    dc_rank_body<NT_SMALL>(w, sg, K, val, src);
-    __syncthreads();
-    dc_place_body<NT_SMALL>(w, sg, lo, hi);
+    dc_small_tail(w, sg, S, Q, Q2s, K, rho);
 }
 static_assert(4 * EIG_MAXN >= DC_SMALL * DC_SMALL, "U tile must fit the reused setup arrays");
 
@@ -1171,28 +1091,17 @@ void stedc_batch_device(gpcsd_ctx *c, StedcProb *probs, int count, int *d_status
         nmax = std::max(nmax, probs[p].n);
         max_leaves = std::max(max_leaves, (int)plans[p].leaf_lo.size() - 1);
     }
-    // tears + leaves
-    for (int p = 0; p < count; ++p) {
-        L.seg_off[p] = plans[p].off_bounds;
-        L.aux[p] = (int)plans[p].bounds.size();
-    }
+    // tears + leaves (one launch: dc_leaf_reg_body applies the tears and zero-fills the off-diagonal blocks)
     static_assert(DC_LEAF == 8, "the register leaf solver maps an 8 x 8 block onto one wave");
-    static const bool lds_leaf = getenv("GPCSD_DC_LEAF") && !strcmp(getenv("GPCSD_DC_LEAF"), "lds");
-    if (lds_leaf) {
-        hipLaunchKernelGGL(dc_tear_kernel, dim3(64, count), dim3(256), 0, s, L);
-        for (int p = 0; p < count; ++p) L.aux[p] = (int)plans[p].leaf_lo.size() - 1;
-        hipLaunchKernelGGL(dc_leaf_kernel, dim3(max_leaves, count), dim3(64), 0, s, L, d_status);
+    for (int p = 0; p < count; ++p) L.aux[p] = (int)plans[p].leaf_lo.size() - 1;
+    if (wy) {                                  // the T factors of the back-transformation ride in the leaf launch
+        int nprep = 0;
+        for (int p = 0; p < count; ++p) nprep = std::max(nprep, wy->p[p].npanels);
+        const int nunits = max_leaves + nmax;
+        hipLaunchKernelGGL(dc_leaf_wyprep_kernel, dim3(nprep + ceil_div(nunits, 16), count), dim3(1024), 0, s, L, d_status,
+                           max_leaves, nunits, *wy, nprep);
     } else {
-        for (int p = 0; p < count; ++p) L.aux[p] = (int)plans[p].leaf_lo.size() - 1;
-        if (wy) {                              // the T factors of the back-transformation ride in the leaf launch
-            int nprep = 0;
-            for (int p = 0; p < count; ++p) nprep = std::max(nprep, wy->p[p].npanels);
-            const int nunits = max_leaves + nmax;
-            hipLaunchKernelGGL(dc_leaf_wyprep_kernel, dim3(nprep + ceil_div(nunits, 16), count), dim3(1024), 0, s, L, d_status,
-                               max_leaves, nunits, *wy, nprep);
-        } else {
-            hipLaunchKernelGGL(dc_leaf_reg_kernel, dim3(max_leaves + nmax, count), dim3(64), 0, s, L, d_status, max_leaves);
-        }
+        hipLaunchKernelGGL(dc_leaf_reg_kernel, dim3(max_leaves + nmax, count), dim3(64), 0, s, L, d_status, max_leaves);
     }
     GP_HIP(hipGetLastError());
 
@@ -1220,8 +1129,7 @@ void stedc_batch_device(gpcsd_ctx *c, StedcProb *probs, int count, int *d_status
                 }
         }
         if (maxN <= DC_SMALL) {
-            static const int fast = !(getenv("GPCSD_DC_SMALL") && !strcmp(getenv("GPCSD_DC_SMALL"), "old"));
-            hipLaunchKernelGGL(dc_small_level_kernel, dim3(max_seg, 1, count), dim3(NT_SMALL), 0, s, L, fast);
+            hipLaunchKernelGGL(dc_small_level_kernel, dim3(max_seg, 1, count), dim3(NT_SMALL), 0, s, L);
         } else {
             hipLaunchKernelGGL(dc_setup_kernel, dim3(1, max_seg, count), dim3(256), 0, s, L);
             const int rot_blocks = ceil_div(maxN, ROT_ROWS), root_blocks = ceil_div(maxN, 4), tj = ceil_div(maxN, 64);

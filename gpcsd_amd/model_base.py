@@ -107,20 +107,41 @@ class GPCSDModel:
 
     # ------------------------------------------------------------------ hyper-parameters
     def _temporal_triplets(self):
+        """[(kind, ell, sigma2)] per temporal component.  SE / Matern are evaluated by the library's own Gram builders; any
+        other object with a `compute_Kt` method (the reference accepts those: covariances.py:235-238, gpcsd1d.py:118-120)
+        is marked KIND_HOST and its Gram matrices are evaluated on the host by that method (see `_hparams`)."""
         out = []
         for tc in self.temporal_cov_list:
             kind = getattr(tc, "kind", None)
-            if not isinstance(tc, GPCSDTemporalCov) or kind not in (_hip.KIND_SE, _hip.KIND_MATERN):
-                raise TypeError("temporal covariance %r is not GPCSDTemporalCovSE / GPCSDTemporalCovMatern: the GPU path "
-                                "implements those two kernels (no CPU fallback)" % type(tc).__name__)
-            out.append((kind, tc.params["ell"]["value"], tc.params["sigma2"]["value"]))
+            if isinstance(tc, GPCSDTemporalCov) and kind in (_hip.KIND_SE, _hip.KIND_MATERN):
+                out.append((kind, tc.params["ell"]["value"], tc.params["sigma2"]["value"]))
+            elif callable(getattr(tc, "compute_Kt", None)):
+                out.append((_hip.KIND_HOST, 0.0, 0.0))
+            else:
+                raise TypeError("temporal covariance %r has no compute_Kt method" % type(tc).__name__)
         return out
 
-    def _hparams(self, jitter):
+    def _uses_host_kt(self):
+        return any(k == _hip.KIND_HOST for k, _, _ in self._temporal_triplets())
+
+    def _hparams(self, jitter, tstar=None):
         ell_s = [self.spatial_cov.params[n]["value"] for n in self._spatial_names]
         eps = getattr(self, "eps", 0.0)
         ctx = self._context()
-        hp, keep = ctx.make_hparams(self.R["value"], eps, ell_s, self._temporal_triplets(), self.sig2n["value"], jitter)
+        trip = self._temporal_triplets()
+        if any(k == _hip.KIND_HOST for k, _, _ in trip):
+            # user-defined temporal covariance: its Gram matrices come from its own compute_Kt (host NumPy), everything after
+            # them -- eigensolver, projections, predict chain -- still runs on the GPU
+            Kt = sum(np.asarray(tc.compute_Kt(), dtype=np.float64) for tc in self.temporal_cov_list)
+            cross = None
+            if tstar is not None:
+                cross = np.stack([np.asarray(tc.compute_Kt(tstar), dtype=np.float64) for tc in self.temporal_cov_list])
+            ctx.set_host_temporal_gram(Kt, cross)
+            self._resident["host_kt"] = True
+        elif self._resident.get("host_kt"):
+            ctx.set_host_temporal_gram(None)
+            self._resident["host_kt"] = False
+        hp, keep = ctx.make_hparams(self.R["value"], eps, ell_s, trip, self.sig2n["value"], jitter)
         return hp, keep
 
     def _sig2n_is_scalar(self):
@@ -190,6 +211,8 @@ class GPCSDModel:
 
     def _loglik_and_grad_natural(self):
         """(loglik, d loglik / d[R, ell_s.., (ell_t, sigma2_t).., sig2n or sig2n_0..sig2n_{nx-1}]) on the GPU."""
+        if self._uses_host_kt():
+            raise NotImplementedError("no analytic gradient for user-defined temporal covariances")
         ctx = self._sync_device()
         hp, _keep = self._hparams(self.JITTER)
         nsig = 1 if self._sig2n_is_scalar() else len(self.sig2n["value"])
@@ -266,41 +289,56 @@ class GPCSDModel:
     def _objective_grad(self, tparams, fix_R, fd_step=1e-6):
         """Gradient of `_objective` w.r.t. the log-parameters (non-finite values are passed through to the optimiser
         silently, as under the reference's module-level `np.seterr(all='ignore')`, gpcsd1d.py:7)."""
-        with np.errstate(all="ignore"):
-            return self._objective_grad_impl(tparams, fix_R, fd_step)
+        return self._objective_and_grad(tparams, fix_R, fd_step)[1]
 
-    def _objective_grad_impl(self, tparams, fix_R, fd_step):
-        tparams = np.asarray(tparams, dtype=np.float64)
-        if getattr(self, "_use_analytic_grad", True):
-            try:
-                self._set_from_tparams(tparams, fix_R)
-                _, g_nat = self._loglik_and_grad_natural()
-                slots = self._param_slots()
-                g = np.zeros_like(tparams)
-                for i, (getter, _, prior, _, _) in enumerate(slots):
-                    v = getter()
-                    g[i] = -(g_nat[i] + prior.dlpdf(v)) * v          # d/dlog(v) = v d/dv
-                p = len(slots)
-                if self._sig2n_is_scalar():
-                    v = self.sig2n["value"]
-                    g[p] = -(g_nat[p] + self.sig2n["prior"].dlpdf(v)) * v
-                else:                                                # per-electrode noise list (gpcsd1d.py:71-73)
-                    for k, (pr, v) in enumerate(zip(self.sig2n["prior"], self.sig2n["value"])):
-                        g[p + k] = -(g_nat[p + k] + pr.dlpdf(v)) * v
-                if fix_R:
-                    g[0] = 0.0
-                return g
-            except NotImplementedError:      # (kept for builds without the gradient entry point)
-                pass
+    def _chain_rule(self, tparams, g_nat, fix_R):
+        """d(-(loglik + log prior)) / d log-parameters from the natural-parameter gradient of loglik."""
+        slots = self._param_slots()
         g = np.zeros_like(tparams)
-        for i in range(tparams.size):
-            if i == 0 and fix_R:
-                continue
-            e = np.zeros_like(tparams)
-            e[i] = fd_step
-            g[i] = (self._objective(tparams + e, fix_R) - self._objective(tparams - e, fix_R)) / (2 * fd_step)
-        self._set_from_tparams(tparams, fix_R)
+        for i, (getter, _, prior, _, _) in enumerate(slots):
+            v = getter()
+            g[i] = -(g_nat[i] + prior.dlpdf(v)) * v          # d/dlog(v) = v d/dv
+        p = len(slots)
+        if self._sig2n_is_scalar():
+            v = self.sig2n["value"]
+            g[p] = -(g_nat[p] + self.sig2n["prior"].dlpdf(v)) * v
+        else:                                                # per-electrode noise list (gpcsd1d.py:71-73)
+            for k, (pr, v) in enumerate(zip(self.sig2n["prior"], self.sig2n["value"])):
+                g[p + k] = -(g_nat[p + k] + pr.dlpdf(v)) * v
+        if fix_R:
+            g[0] = 0.0
         return g
+
+    def _objective_and_grad(self, tparams, fix_R, fd_step=1e-6):
+        """(objective, gradient) from ONE device evaluation: the front half (Gram builds + both eigendecompositions) is most
+        of an evaluation, so the optimiser is driven with jac=True instead of separate fun / jac callbacks that would each
+        run it.  A numerical failure raises LinAlgError, which ends the restart exactly as the reference's jac callback
+        does (gpcsd1d.py:219, gpcsd2d.py:258)."""
+        with np.errstate(all="ignore"):          # the reference runs under np.seterr(all='ignore') (gpcsd1d.py:7)
+            tparams = np.asarray(tparams, dtype=np.float64)
+            if getattr(self, "_use_analytic_grad", True) and not self._uses_host_kt():
+                self._set_from_tparams(tparams, fix_R)
+                lp = self._log_prior()
+                ll, g_nat = self._loglik_and_grad_natural()
+                return -1.0 * (ll + lp), self._chain_rule(tparams, g_nat, fix_R)
+            # finite differences of the objective (user-defined temporal covariances; diagnostics)
+            f = self._objective(tparams, fix_R)
+            g = np.zeros_like(tparams)
+            for i in range(tparams.size):
+                if i == 0 and fix_R:
+                    continue
+                e = np.zeros_like(tparams)
+                e[i] = fd_step
+                g[i] = (self._objective(tparams + e, fix_R) - self._objective(tparams - e, fix_R)) / (2 * fd_step)
+            self._set_from_tparams(tparams, fix_R)
+            return f, g
+
+    def _current_tparams(self):
+        """The log-parameter vector of the current hyper-parameter state (inverse of `_set_from_tparams`)."""
+        with np.errstate(divide="ignore"):
+            tp = [np.log(getter() / scale) for getter, _, _, _, scale in self._param_slots()]
+            tp.extend(np.log(np.atleast_1d(np.asarray(self.sig2n["value"], dtype=np.float64))))
+        return np.array(tp, dtype=np.float64)
 
     def _sample_start(self, fix_R):
         slots = self._param_slots()
@@ -344,8 +382,8 @@ class GPCSDModel:
 
     def _run_restart(self, tparams0, method, fix_R, options, bounds):
         try:
-            res = scipy.optimize.minimize(lambda tp: self._objective(tp, fix_R), tparams0, method=method, options=options,
-                                          bounds=bounds, jac=lambda tp: self._objective_grad(tp, fix_R))
+            res = scipy.optimize.minimize(lambda tp: self._objective_and_grad(tp, fix_R), tparams0, method=method,
+                                          options=options, bounds=bounds, jac=True)
             return res.fun, res.x, res.message
         except (ValueError, np.linalg.LinAlgError) as e:
             print(e)
@@ -361,6 +399,17 @@ class GPCSDModel:
             starts = [self._sample_start(fix_R) for _ in range(n_restarts)]
         starts = [np.asarray(s0, dtype=np.float64) for s0 in starts]
         rs = getattr(self, "_restart_sharding", None)
+        # Ranks do not share a random stream: constructors and `_sample_start` draw from each process's own NumPy RNG.
+        # Under trial sharding every rank must walk the SAME optimiser trajectory (the all-reduces inside the objective pair
+        # up call by call), under restart sharding restart k must mean the same start everywhere: rank 0's current
+        # hyper-parameters (fix_R reads R from them) and rank 0's starts are broadcast before anything is evaluated.
+        sync = getattr(self, "_sharding", None) or rs
+        if sync is not None and sync.world_size > 1:
+            self._set_from_tparams(sync.broadcast(self._current_tparams(), src=0), False)
+            if len(starts):
+                flat = sync.broadcast(np.stack(starts).ravel(), src=0)
+                starts = [row.copy() for row in flat.reshape(len(starts), -1)]
+        self.fit_starts_ = [s0.copy() for s0 in starts]
         mine = [k for k in range(n_restarts) if rs is None or k % rs.world_size == rs.rank]
         results = {}
         workers = max(1, min(int(workers), len(mine)))
@@ -424,10 +473,10 @@ class GPCSDModel:
         if type not in ("csd", "lfp", "both"):
             raise ValueError("type must be 'csd', 'lfp' or 'both'")
         ctx = self._sync_device()
-        hp, _keep = self._hparams(0.0)                     # no jitter in predict
         z = np.asarray(z, dtype=np.float64)
         z2 = z.reshape(-1, 1) if self.dim == 1 else z
         t = np.asarray(t)
+        hp, _keep = self._hparams(0.0, tstar=t)            # no jitter in predict
         code = {"csd": _hip.PRED_CSD, "lfp": _hip.PRED_LFP, "both": _hip.PRED_BOTH}[type]
         R_local = self._local_lfp().shape[2]
         res = ctx.predict(hp, z2, t, code, (z2.shape[0], t.shape[0], R_local))

@@ -31,6 +31,18 @@ extern "C" {
 #define GPCSD_MAX_TEMPORAL 8
 #define GPCSD_KIND_SE      0   /* covariances.py:257-271 */
 #define GPCSD_KIND_MATERN  1   /* covariances.py:291-305 */
+#define GPCSD_KIND_HOST    2   /* user-defined GPCSDTemporalCov subclass (covariances.py:235-238): its Gram matrices are
+                                  evaluated by the caller's compute_Kt and handed over with gpcsd_set_host_temporal_gram */
+
+/* Capacity limits of this build (no counterpart in the reference, which is bounded by host memory only).  Exceeding one
+ * returns GPCSD_ERR_CAPACITY (-7), which the Python layer raises as gpcsd_amd.GPCSDCapacityError -- a RuntimeError, so
+ * that fit()'s LinAlgError / ValueError handlers (gpcsd1d.py:219, gpcsd2d.py:217,258) do not swallow it.
+ *   GPCSD_MAX_EIG_N         rows of one symmetric eigenproblem: nx and nt of the fused calls, n of gpcsd_eigh / gpcsd_eig_D
+ *   GPCSD_MAX_GEMM_OPERAND  doubles in one flat GEMM operand: nx * ntrials * nt of the resident block of trials
+ *                           (2 GiB of fp64; shard trials over ranks or evaluate them in several blocks beyond that)   */
+#define GPCSD_MAX_EIG_N         1024
+#define GPCSD_MAX_GEMM_OPERAND  (1L << 28)
+#define GPCSD_ERR_CAPACITY      (-7)
 
 #define GPCSD_PRED_CSD  1
 #define GPCSD_PRED_LFP  2
@@ -72,6 +84,13 @@ int gpcsd_set_geometry_2d(gpcsd_ctx *ctx, const double *xy, int nx,
                           const double *gl_x1, const double *gl_w1, int ngl1,
                           const double *gl_x2, const double *gl_w2, int ngl2);
 int gpcsd_set_time(gpcsd_ctx *ctx, const double *t, int nt);   /* GPCSDTemporalCov.t */
+/* User-defined temporal covariances (covariances.py:235-238; gpcsd1d.py:118-120 accepts any object with compute_Kt):
+ * Kt = sum_c cov_c.compute_Kt() (nt, nt) and, for predict, Kt_cross[c] = cov_c.compute_Kt(tstar) (ncomp, ntstar, nt;
+ * may be NULL for loglik), evaluated by the caller.  Copied; used by every later fused call whose hparams carry a
+ * component of kind GPCSD_KIND_HOST, in place of the built-in Gram builders (the eigensolver, projections and predict
+ * chain are unchanged; the reflection fold of the time axis is skipped since such a kernel need not be stationary).
+ * Kt == NULL clears it.  gpcsd_loglik_grad refuses such hparams (-3): the library cannot differentiate a host kernel. */
+int gpcsd_set_host_temporal_gram(gpcsd_ctx *ctx, const double *Kt, int nt, const double *Kt_cross, int ncomp, int ntstar);
 
 /* ---- operator surface (stand-alone; host in / host out) ------------------------- */
 /* b_fwd_1d(r, R)                        forward_models.py:9-17   (elementwise, n values) */
