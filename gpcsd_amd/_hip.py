@@ -3,6 +3,7 @@ or no GPU is visible, every compute entry point raises."""
 import ctypes
 import os
 import threading
+import weakref
 
 import numpy as np
 
@@ -52,6 +53,8 @@ SIGNATURES = {
     "gpcsd_last_error": (ctypes.c_char_p, [_P]),
     "gpcsd_version": (_I, []),
     "gpcsd_device_synchronize": (_I, [_P]),
+    "gpcsd_host_alloc": (_I, [ctypes.c_size_t, ctypes.POINTER(_P)]),
+    "gpcsd_host_free": (_I, [_P]),
     "gpcsd_set_lfp": (_I, [_P, _DP, _I, _I, _I]),
     "gpcsd_set_geometry_1d": (_I, [_P, _DP, _I, _DP, _DP, _I]),
     "gpcsd_set_geometry_2d": (_I, [_P, _DP, _I, _DP, _DP, _I, _DP, _DP, _I]),
@@ -122,6 +125,52 @@ def _arr(a, shape=None, name="array"):
 
 def _ptr(a):
     return a.ctypes.data_as(_c_double_p) if a is not None else None
+
+
+class PinnedPool:
+    """Recycled page-locked result arrays.  predict() returns host arrays (gpcsd2d.py:328-334) of up to hundreds of MB per
+    call; landing them in fresh pageable memory costs a page fault per 4 KiB and a staged copy (~9 GB/s measured).  The pool
+    hands out NumPy arrays backed by pinned blocks; a block returns to the pool when the last array viewing it is garbage
+    collected (a finalizer on the backing buffer), so results a caller keeps alive are never overwritten -- a caller that
+    replaces them call after call (the usual loop) ping-pongs between two blocks and allocates nothing."""
+    MIN_BYTES = 1 << 20          # smaller results are not worth a pinned block
+    MAX_FREE_PER_SIZE = 3
+
+    def __init__(self):
+        self._free = {}
+        self._lock = threading.Lock()
+
+    def empty(self, shape):
+        n = int(np.prod(shape))
+        nbytes = 8 * n
+        if nbytes < self.MIN_BYTES:
+            return np.empty(shape)
+        lib = load_library()
+        with self._lock:
+            lst = self._free.get(nbytes)
+            ptr = lst.pop() if lst else None
+        if ptr is None:
+            h = ctypes.c_void_p()
+            if lib.gpcsd_host_alloc(nbytes, ctypes.byref(h)) != 0 or not h.value:
+                return np.empty(shape)                       # pinning refused (limits): pageable still works, slower
+            ptr = h.value
+        buf = (ctypes.c_double * n).from_address(ptr)
+        weakref.finalize(buf, self._release, ptr, nbytes)
+        return np.frombuffer(buf, dtype=np.float64).reshape(shape)
+
+    def _release(self, ptr, nbytes):
+        with self._lock:
+            lst = self._free.setdefault(nbytes, [])
+            if len(lst) < self.MAX_FREE_PER_SIZE:
+                lst.append(ptr)
+                return
+        try:
+            load_library().gpcsd_host_free(ctypes.c_void_p(ptr))
+        except Exception:
+            pass
+
+
+pinned_pool = PinnedPool()
 
 
 class Context:
@@ -411,8 +460,8 @@ class Context:
         bufs = {}
         for name, bit in (("csd", PRED_CSD), ("lfp", PRED_LFP)):
             if type_code & bit:
-                bufs[name] = np.empty((nz, ntstar, R))
-                bufs[name + "_list"] = np.empty((C, nz, ntstar, R)) if want_lists else None
+                bufs[name] = pinned_pool.empty((nz, ntstar, R))
+                bufs[name + "_list"] = pinned_pool.empty((C, nz, ntstar, R)) if want_lists else None
             else:
                 bufs[name] = None
                 bufs[name + "_list"] = None
@@ -431,7 +480,7 @@ class Context:
                                                      int(type_code), int(bool(want_lists))))
 
     def fetch(self, name, shape):
-        out = np.empty(shape)
+        out = pinned_pool.empty(shape)
         self._check(self._lib.gpcsd_fetch(self._h, name.encode(), _ptr(out), out.size))
         return out
 

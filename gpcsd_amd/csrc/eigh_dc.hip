@@ -261,6 +261,14 @@ static void sytrd_batch_launch(gpcsd_ctx *c, const SytrdBatch &b, int count, int
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)rt_strip_bytes(RT_TMAX)));
             rt_attr_set = true;
         }
+        // profiled on its own: this single launch (one workgroup per problem) is the largest share of the GPU time of an
+        // evaluation; flops = (4/3) T^3 per problem, the nominal count of a Householder tridiagonalisation
+        double fl = 0.0;
+        for (int i = 0; i < count; ++i) {
+            const double T = b.p[i].n - b.p[i].k_tail;
+            if (b.p[i].k_tail < b.p[i].n - 1) fl += 4.0 / 3.0 * T * T * T;
+        }
+        ProfScope ps(c, "sytrd_rtail", fl, s);
         hipLaunchKernelGGL(sytrd_rtail_kernel, dim3(count), dim3(RT_NTH), sh, s, b);
     }
     if (!all_tail) hipLaunchKernelGGL(sytrd_last_diag_kernel, dim3(count), dim3(64), 0, s, b);

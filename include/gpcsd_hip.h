@@ -24,6 +24,8 @@
 #ifndef GPCSD_HIP_H
 #define GPCSD_HIP_H
 
+#include <stddef.h>
+
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -71,6 +73,11 @@ int  gpcsd_ctx_destroy(gpcsd_ctx *ctx);
 const char *gpcsd_last_error(gpcsd_ctx *ctx);     /* ctx may be NULL: last global error */
 int  gpcsd_version(void);
 int  gpcsd_device_synchronize(gpcsd_ctx *ctx);
+/* Page-locked host blocks for result arrays (gpcsd2d.py:328-334 returns host arrays of (1+C)*nz*nt*ntrials doubles: 231 MB
+ * at 384 x 500 x 50).  Outputs handed to gpcsd_predict / gpcsd_fetch / gpcsd_sample_prior may live in such a block, in which
+ * case the device-to-host copy is a single DMA at link speed; any other host pointer still works (staged, slower). */
+int  gpcsd_host_alloc(size_t bytes, void **out);
+int  gpcsd_host_free(void *p);
 
 /* ---- resident data (copied; re-laid-out on device) ----------------------------- */
 /* lfp is (nx, nt, ntrials) C-order as held by GPCSD{1,2}D.lfp (gpcsd1d.py:34, gpcsd2d.py:36);

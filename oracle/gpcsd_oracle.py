@@ -390,6 +390,34 @@ def loglik_grad_fd(geom, lfp, tp, kinds, n_sig, eps=0.0, jitter=0.0, h=1e-6):
 
 
 # --------------------------------------------------------------------------------------
+# downstream per-trial consumer of (Qs, Qt, Dvec)
+# --------------------------------------------------------------------------------------
+def whitened_quad(Qs, Qt, Dvec, resid):
+    """sum((Qs^T resid_b Qt)^2 / Dvec) per trial b of resid (nx, nt, nb) -- the projection step of loglik
+    (gpcsd1d.py:124-127) as auditory_lfp/fit_mean_function.py:317-318 reuses it."""
+    resid = np.atleast_3d(resid)
+    nx, nt, nb = resid.shape
+    alpha = np.matmul(np.matmul(Qs.T, np.moveaxis(resid, 2, 0)), Qt)
+    return np.sum(np.square(alpha) / np.asarray(Dvec).reshape(1, nx, nt), axis=(1, 2))
+
+
+def shift_objective(Qs, Qt, Dvec, lfp_trial, mu_lfp, t, tau, mutau=0.0, sigtau=10.0):
+    """Negative log posterior of the per-component time shifts tau of one trial --
+    auditory_lfp/fit_mean_function.py:311-321: mean = background mu_lfp[:, :, 0] + sum_i mu_i(t + tau_i) (linear
+    interpolation with extrapolation, scipy interp1d as at :308), residual whitened by the cached decomposition,
+    Gaussian prior N(mutau, sigtau^2) on each shift."""
+    import scipy.interpolate
+    tt = np.asarray(t, dtype=np.float64).reshape(-1)
+    tau = np.asarray(tau, dtype=np.float64).reshape(-1)
+    mu = np.array(mu_lfp[:, :, 0], dtype=np.float64, copy=True)
+    for i in range(1, mu_lfp.shape[2]):
+        f = scipy.interpolate.interp1d(tt, mu_lfp[:, :, i], axis=1, fill_value="extrapolate")
+        mu += f(tt + tau[i - 1])
+    quad = whitened_quad(Qs, Qt, Dvec, (lfp_trial - mu)[:, :, None])[0]
+    return 0.5 * quad + 0.5 * np.sum(np.square((tau - mutau) / sigtau))
+
+
+# --------------------------------------------------------------------------------------
 # trapezoid forward simulators (SURVEY section 8f row N3)
 # --------------------------------------------------------------------------------------
 def fwd_model_1d(arr, x, z, R, varsigma=1.0):

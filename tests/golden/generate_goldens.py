@@ -256,7 +256,64 @@ def gen_sample_prior():
     print("wrote sample_prior")
 
 
+def gen_shift_objective():
+    """Fixture for the downstream per-trial consumer of (Qs, Qt, Dvec): the trial-shift objective of
+    auditory_lfp/fit_mean_function.py.  That script cannot be imported (it loads Zenodo data at module level), so the
+    pieces it takes from the package are run here exactly as it runs them -- the model with a per-electrode noise list,
+    Ks + 1e-8 I, Kt summed over the components and the reference's own comp_eig_D (lines 87-106) -- and its objective
+    (lines 311-321: background + time-shifted component means, residual whitened by Qs / Qt / Dvec, Gaussian prior on the
+    shifts) is evaluated on synthetic component means."""
+    import scipy.interpolate
+    out = dict(META)
+    rs = np.random.RandomState(41)
+    nx, nt, ntrials, nseg = 12, 40, 5, 2
+    x = np.linspace(0, 1100, nx)[:, None]
+    t = np.linspace(0, 39, nt)[:, None]
+    lfp = rs.standard_normal((nx, nt, ntrials))
+    np.random.seed(0)
+    spatial_cov = rcov.GPCSD1DSpatialCovSE(x, a=-100.0, b=1200.0)
+    matern_cov = rcov.GPCSDTemporalCovMatern(t)
+    se_cov = rcov.GPCSDTemporalCovSE(t)
+    sig2n_prior = [rpr.GPCSDHalfNormalPrior(0.1) for _ in range(nx)]
+    m = GPCSD1D(lfp, x, t, sig2n_prior=sig2n_prior, spatial_cov=spatial_cov, temporal_cov_list=[se_cov, matern_cov],
+                a=-100.0, b=1200.0)
+    m.R["value"] = 90.0
+    m.spatial_cov.params["ell"]["value"] = 70.0
+    se_cov.params["ell"]["value"], se_cov.params["sigma2"]["value"] = 6.0, 0.8
+    matern_cov.params["ell"]["value"], matern_cov.params["sigma2"]["value"] = 3.0, 0.4
+    m.sig2n["value"] = np.linspace(0.02, 0.3, nx)
+    Kt = m.temporal_cov_list[0].compute_Kt() + m.temporal_cov_list[1].compute_Kt()
+    Ks = m.spatial_cov.compKphi_1d(m.R["value"]) + 1e-8 * np.eye(nx)
+    Qs, Qt, Dvec = ruf.comp_eig_D(Ks, Kt, m.sig2n["value"])
+    # synthetic background + two evoked components (smooth bumps), then the shifted-mean objective
+    tt = t.squeeze()
+    mu_lfp = np.zeros((nx, nt, nseg + 1))
+    mu_lfp[:, :, 0] = 0.1 * rs.standard_normal((nx, 1)) * np.ones((1, nt))
+    for i in range(1, nseg + 1):
+        prof = np.exp(-0.5 * np.square((np.arange(nx) - 3.0 * i) / 2.0))[:, None]
+        mu_lfp[:, :, i] = prof * np.exp(-0.5 * np.square((tt - 10.0 * i) / 3.0))[None, :]
+    mu_f = {i: scipy.interpolate.interp1d(tt, mu_lfp[:, :, i], axis=1, fill_value="extrapolate") for i in range(1, nseg + 1)}
+    mutau, sigtau = 0.0, 10.0
+    taus = np.array([[0.0, 0.0], [1.5, -2.0], [-3.25, 0.75], [6.0, 4.0]])
+    nll = np.zeros((ntrials, taus.shape[0]))
+    resid = np.zeros((nx, nt, ntrials, taus.shape[0]))
+    for ti in range(ntrials):
+        for k, tau in enumerate(taus):
+            mu_new = np.copy(mu_lfp[:, :, 0])
+            for i in range(1, nseg + 1):
+                mu_new += mu_f[i](tt + tau[i - 1])
+            r = lfp[:, :, ti] - mu_new
+            alpha = np.reshape(np.linalg.multi_dot([Qs.T, r, Qt]), (nx * nt))
+            nll[ti, k] = 0.5 * np.sum(alpha ** 2 / Dvec) + 0.5 * np.sum(np.square((tau - mutau) / sigtau))
+            resid[:, :, ti, k] = r
+    out.update(x=x, t=t, lfp=lfp, mu_lfp=mu_lfp, taus=taus, mutau=mutau, sigtau=sigtau, Ks=Ks, Kt=Kt,
+               sig2n=m.sig2n["value"], Qs=Qs, Qt=Qt, Dvec=Dvec, nll=nll, resid=resid)
+    np.savez_compressed(os.path.join(HERE, "shift_objective.npz"), **out)
+    print("wrote shift_objective")
+
+
 if __name__ == "__main__":
+    gen_shift_objective()
     gen_ops()
     gen_sample_prior()
     gen_models()

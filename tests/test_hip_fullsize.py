@@ -1,0 +1,346 @@
+"""GPU parity at the sizes BASELINE.json quotes (-m gpu): the HIP path through the C-ABI against the CPU oracle.
+
+  cfg3  GPCSD2D 384 x 500: predict (csd + lfp, per-component lists) on the folded-basis path and with fold_gemm(False)
+  cfg2  GPCSD1D 24 x 500 x 200 trials: loglik and predict (the long R*nt GEMM dimension of the flat projections)
+  cfg5  GPCSD1D 24 x 500 x 200: analytic gradient vs central differences of the oracle; fit() of 2 restarts (fp64 and the
+        fp32 Gram build) against SciPy on the oracle objective
+plus the contract edges added in round 2: user-defined temporal covariances, capacity errors, time grids beyond 1024
+points (symmetry-folded), the trial-shift objective fixture (N4), pinned result arrays, and the multi-rank bench step.
+"""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import cases as C
+from helpers import golden, load_model_case, relerr, with_jitter
+from oracle import gpcsd_oracle as O
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GATE = 1e-6                                   # north_star: 1e-6 relative on fp64 log-likelihood and posterior mean
+
+
+def _model_from_case(c, g, lfp):
+    from gpcsd_amd.gpcsd1d import GPCSD1D
+    from gpcsd_amd.gpcsd2d import GPCSD2D
+    from gpcsd_amd.covariances import GPCSDTemporalCovSE, GPCSDTemporalCovMatern
+    np.random.seed(0)
+    tcl = []
+    for (kind, ell, _), s2 in zip(c["temporal"], g["temporal_sigma2"]):
+        tc = GPCSDTemporalCovSE(c["t"]) if kind == C.SE else GPCSDTemporalCovMatern(c["t"])
+        tc.params["ell"]["value"], tc.params["sigma2"]["value"] = ell, float(s2)
+        tcl.append(tc)
+    if c["dim"] == 1:
+        m = GPCSD1D(lfp, c["x"], c["t"], a=c["a"], b=c["b"], ngl=c["ngl"], temporal_cov_list=tcl)
+        m.spatial_cov.params["ell"]["value"] = c["ell_s"][0]
+    else:
+        m = GPCSD2D(lfp, c["x"], c["t"], ngl1=c["ngl1"], ngl2=c["ngl2"], temporal_cov_list=tcl, eps=c["eps"])
+        m.spatial_cov.params["ell1"]["value"], m.spatial_cov.params["ell2"]["value"] = c["ell_s"]
+    m.R["value"] = c["R"]
+    m.sig2n["value"] = c["sig2n"]
+    return m
+
+
+# ------------------------------------------------------------------------------------------------ cfg3: 384 x 500
+@pytest.mark.parametrize("fold", [True, False])
+def test_cfg3_geometry_predict_vs_oracle(fold):
+    """The headline geometry, z = electrodes, type='both' with per-component lists, three trials: every output against the
+    oracle's structured predict (gpcsd2d.py:289-334); folded-basis GEMMs and the full-size path."""
+    c, g, geom, hp, _ = load_model_case("cfg3s_2d_384x500x2")
+    lfp = C.synth_lfp(231, 384, 500, 3)
+    m = _model_from_case(c, g, lfp)
+    ctx = m._sync_device()
+    ctx.fold_gemm(fold)
+    n0 = ctx.fold_gemm()
+    ll = m.loglik()
+    assert abs(ll - O.loglik(geom, with_jitter(hp, 1e-7), lfp)) / abs(ll) < 1e-9
+    m.predict(c["x"], c["t"], type="both")
+    assert (ctx.fold_gemm() - n0 > 0) == fold                  # the path that was asked for is the one that ran
+    ref = O.predict(geom, hp, lfp, c["x"], c["t"], type="both")
+    errs = {"csd": relerr(m.csd_pred, ref["csd"]), "lfp": relerr(m.lfp_pred, ref["lfp"])}
+    for i in range(2):
+        errs["csd_%d" % i] = relerr(m.csd_pred_list[i], ref["csd_list"][i])
+        errs["lfp_%d" % i] = relerr(m.lfp_pred_list[i], ref["lfp_list"][i])
+    print("cfg3 predict rel err (fold=%s):" % fold, {k: "%.2e" % v for k, v in errs.items()})
+    assert m.csd_pred.shape == (384, 500, 3) and len(m.csd_pred_list) == 2
+    assert max(errs.values()) < GATE, errs
+    # asymmetric prediction sites fall back to the full-size path and still agree
+    z = c["x"][5:77] + np.array([[3.0, -7.0]])
+    m.predict(z, c["t"], type="csd")
+    assert relerr(m.csd_pred, O.predict(geom, hp, lfp, z, c["t"], type="csd")["csd"]) < GATE
+
+
+def test_cfg3_geometry_noise_list_predict_vs_oracle():
+    """Per-electrode noise list at 384 x 500 (the merged-order path: the list is indexed by eigen-rank)."""
+    c, g, geom, hp, _ = load_model_case("cfg3s_2d_384x500x2")
+    lfp = C.synth_lfp(232, 384, 500, 2)
+    m = _model_from_case(c, g, lfp)
+    sig = np.linspace(0.03, 0.12, 384)
+    m.sig2n["value"] = sig
+    m.sig2n["prior"] = [m.sig2n["prior"]] * 384
+    hp2 = dict(hp)
+    hp2["sig2n"] = sig
+    ll = m.loglik()
+    assert abs(ll - O.loglik(geom, with_jitter(hp2, 1e-7), lfp)) / abs(ll) < GATE
+    zsel = c["x"][::8]
+    m.predict(zsel, c["t"], type="csd")
+    assert relerr(m.csd_pred, O.predict(geom, hp2, lfp, zsel, c["t"], type="csd")["csd"]) < GATE
+
+
+# ------------------------------------------------------------------------------------------------ cfg2: 24 x 500 x 200
+def test_cfg2_shape_200_trials_vs_oracle():
+    c, g, geom, hp, _ = load_model_case("cfg2s_1d_24x500x8")
+    lfp = C.synth_lfp(241, 24, 500, 200)
+    m = _model_from_case(c, g, lfp)
+    ll = m.loglik()
+    assert abs(ll - O.loglik(geom, with_jitter(hp, 1e-8), lfp)) / abs(ll) < 1e-9
+    m.predict(c["x"], c["t"], type="both")
+    ref = O.predict(geom, hp, lfp, c["x"], c["t"], type="both")
+    assert m.csd_pred.shape == (24, 500, 200)
+    e = max(relerr(m.csd_pred, ref["csd"]), relerr(m.lfp_pred, ref["lfp"]),
+            relerr(m.csd_pred_list[1], ref["csd_list"][1]), relerr(m.lfp_pred_list[0], ref["lfp_list"][0]))
+    print("cfg2 (R=200) predict rel err %.2e" % e)
+    assert e < GATE
+    z = np.linspace(-50.0, 2400.0, 37)[:, None]                 # arbitrary prediction sites
+    m.predict(z, c["t"], type="csd")
+    assert relerr(m.csd_pred, O.predict(geom, hp, lfp, z, c["t"], type="csd")["csd"]) < GATE
+
+
+# ------------------------------------------------------------------------------------------------ cfg5: gradient and fit
+def _cfg5_model(gram_precision=64):
+    c, g, geom, hp, _ = load_model_case("cfg2s_1d_24x500x8")
+    # data with structure (a draw from the model + noise) so that the optimiser has something to find
+    rs = np.random.RandomState(251)
+    Ks = O.spatial_kphi(geom, hp)
+    Kt = O.temporal_sum(hp["temporal"], geom.t)
+    es, Qs = np.linalg.eigh(Ks)
+    et, Qt = np.linalg.eigh(Kt)
+    Ls, Lt = Qs * np.sqrt(np.maximum(es, 0.0)), Qt * np.sqrt(np.maximum(et, 0.0))
+    Y = np.matmul(np.matmul(Ls, rs.standard_normal((200, 24, 500))), Lt.T)
+    Y = Y / Y.std() + np.sqrt(0.05) * rs.standard_normal(Y.shape)
+    lfp = np.ascontiguousarray(np.moveaxis(Y, 0, 2))
+    m = _model_from_case(c, g, lfp)
+    m.gram_precision = gram_precision
+    return m, c, geom, lfp
+
+
+def _cpu_objective(m, geom, lfp, kinds):
+    def lp_of(hp):
+        lp = m.R["prior"].lpdf(hp["R"]) + m.spatial_cov.params["ell"]["prior"].lpdf(hp["ell_s"][0])
+        for tc, (_, ell, s2) in zip(m.temporal_cov_list, hp["temporal"]):
+            lp += tc.params["ell"]["prior"].lpdf(ell) + tc.params["sigma2"]["prior"].lpdf(s2)
+        return lp + m.sig2n["prior"].lpdf(hp["sig2n"])
+
+    def f(tp):
+        hp = O.hparams_from_tparams(tp, 1, kinds, 1, jitter=1e-8)
+        return -(O.loglik(geom, hp, lfp) + lp_of(hp))
+
+    def fg(tp):
+        g = np.zeros_like(tp)
+        for i in range(tp.size):
+            e = np.zeros_like(tp)
+            e[i] = 1e-6
+            g[i] = (f(tp + e) - f(tp - e)) / 2e-6
+        return f(tp), g
+    return f, fg
+
+
+def test_cfg5_shape_gradient_vs_oracle_finite_differences():
+    m, c, geom, lfp = _cfg5_model()
+    kinds = [k for k, _, _ in c["temporal"]]
+    tp = m._current_tparams()
+    f, fg = _cpu_objective(m, geom, lfp, kinds)
+    val, grad = m._objective_and_grad(tp, False)
+    fval, fgrad = fg(tp)
+    assert abs(val - fval) / abs(fval) < 1e-9
+    err = np.max(np.abs(grad - fgrad)) / np.max(np.abs(fgrad))
+    print("cfg5-shape gradient vs oracle central differences: %.2e of the largest component" % err)
+    assert err < 2e-5
+
+
+@pytest.mark.parametrize("gram_precision", [64, 32])
+def test_cfg5_shape_fit_two_restarts_vs_scipy_on_oracle(gram_precision):
+    """fit() at 24 x 500 x 200 through the real HIP objective: 2 restarts x <= 8 iterations, against SciPy L-BFGS-B on the
+    oracle objective from the same starts.  fp64 must land on the same truncated optimum; the fp32 Gram build (BASELINE
+    cfg5 'fp32 kernel build + fp64 factor') is a perturbed objective whose deviation is reported, with a loose gate."""
+    import scipy.optimize
+    m, c, geom, lfp = _cfg5_model(gram_precision)
+    kinds = [k for k, _, _ in c["temporal"]]
+    f, fg = _cpu_objective(m, geom, lfp, kinds)
+    tp0 = m._current_tparams()
+    starts = [tp0 + 0.15 * np.array([1, -1, 1, -1, 1, -1, 1.0]), tp0 - 0.1 * np.array([1, 1, -1, 1, -1, 1, 1.0])]
+    opts = {"maxiter": 8, "disp": False, "gtol": 1e-5, "ftol": 1e7 * np.finfo(float).eps}
+    nll_start = [f(s0) for s0 in starts]
+    m.fit(n_restarts=2, options=opts, starts=starts)
+    got = np.asarray(m.fit_nll_values_)
+    assert got.shape == (2,) and np.all(got < np.asarray(nll_start))
+    # the objective value reported at the optimum IS the oracle's objective there (pins the device objective at cfg5's shape)
+    for k in range(2):
+        at_opt = f(np.asarray(m.fit_params_[k]))
+        tol = 1e-8 if gram_precision == 64 else 1e-3
+        assert abs(at_opt - got[k]) / abs(at_opt) < tol, (k, at_opt, got[k])
+    ref = [scipy.optimize.minimize(fg, s0, jac=True, method="L-BFGS-B", bounds=m._bounds(), options=opts).fun for s0 in starts]
+    dev = np.abs(got - np.asarray(ref)) / np.abs(ref)
+    print("cfg5-shape fit (gram %d bit): nll GPU %s  SciPy-on-oracle %s  rel dev %s" % (gram_precision, got, ref, dev))
+    assert np.all(dev < (2e-3 if gram_precision == 64 else 5e-2))
+
+
+# ------------------------------------------------------------------------------------------------ contract edges
+class _RationalQuadraticCov:
+    """A user-defined temporal covariance (covariances.py:235-238 lets any object with compute_Kt in): not stationary-in-
+    the-library's-sense, not one of the two built-in kernels, evaluated on the host by its own method."""
+
+    def __init__(self, t, ell, sigma2, alpha=1.5, trend=0.0):
+        from gpcsd_amd.priors import GPCSDInvGammaPrior, GPCSDHalfNormalPrior
+        self.t = t
+        self.alpha, self.trend = alpha, trend
+        self.params = {"ell": {"value": ell, "prior": GPCSDInvGammaPrior(), "min": 1e-3, "max": 1e3},
+                       "sigma2": {"value": sigma2, "prior": GPCSDHalfNormalPrior(1.0), "min": 1e-8, "max": np.inf}}
+
+    def compute_Kt(self, t=None, tprime=None):
+        t = self.t if t is None else t
+        tprime = self.t if tprime is None else tprime
+        a = np.asarray(t, dtype=np.float64).reshape(-1, 1)
+        b = np.asarray(tprime, dtype=np.float64).reshape(1, -1)
+        k = self.params["sigma2"]["value"] * (1.0 + (a - b) ** 2 / (2 * self.alpha * self.params["ell"]["value"] ** 2)) ** (-self.alpha)
+        return k * (1.0 + self.trend * a) * (1.0 + self.trend * b)       # trend != 0: non-stationary (no reflection symmetry)
+
+
+@pytest.mark.parametrize("trend", [0.0, 0.004])
+def test_user_defined_temporal_covariance(trend):
+    from gpcsd_amd.gpcsd1d import GPCSD1D
+    from gpcsd_amd.covariances import GPCSDTemporalCovSE
+    x = np.linspace(0, 2300, 24)[:, None]
+    t = np.linspace(0, 119, 120)[:, None]
+    lfp = C.synth_lfp(261, 24, 120, 3)
+    np.random.seed(0)
+    se = GPCSDTemporalCovSE(t)
+    se.params["ell"]["value"], se.params["sigma2"]["value"] = 9.0, 0.6
+    rq = _RationalQuadraticCov(t, 4.0, 0.5, trend=trend)
+    m = GPCSD1D(lfp, x, t, a=0.0, b=2300.0, ngl=60, temporal_cov_list=[se, rq])
+    m.R["value"], m.sig2n["value"] = 110.0, 0.07
+    m.spatial_cov.params["ell"]["value"] = 210.0
+    geom = O.Geometry1D(x, t, a=0.0, b=2300.0, ngl=60)
+    hp = O.make_hparams(110.0, (210.0,), [(O.SE, 9.0, 0.6)], 0.07, jitter=1e-8)
+    Ks = O.spatial_kphi(geom, hp)
+    Kt = O.temporal_sum(hp["temporal"], t) + rq.compute_Kt()
+    ll_ref = O.loglik_from_K(lfp, Ks + 1e-8 * np.eye(24), Kt, 0.07)
+    ll = m.loglik()
+    assert abs(ll - ll_ref) / abs(ll_ref) < 1e-9
+    # predict: structured posterior mean with the user's cross-covariances
+    m.predict(x, t, type="csd")
+    Qs, Qt, D = O.eig_D(Ks, Kt, 0.07)
+    B = np.matmul(np.matmul(Qs.T, np.moveaxis(lfp, 2, 0)), Qt) / D.reshape(1, 24, 120)
+    InvY = np.matmul(np.matmul(Qs, B), Qt.T)
+    S = np.matmul(O.spatial_kphig(geom, hp, x).T, InvY)
+    comps = [np.moveaxis(np.matmul(S, K), 0, 2) for K in (O.temporal_gram(O.SE, t, t, 9.0, 0.6), rq.compute_Kt(t))]
+    assert relerr(m.csd_pred_list[1], comps[1]) < GATE and relerr(m.csd_pred, comps[0] + comps[1]) < GATE
+    # no analytic gradient for a host kernel: the fit objective falls back to finite differences of the device loglik
+    tp = m._current_tparams()
+    f0, g0 = m._objective_and_grad(tp, False)
+    e = np.zeros_like(tp)
+    e[2] = 1e-5
+    assert abs((m._objective(tp + e, False) - m._objective(tp - e, False)) / 2e-5 - g0[2]) <= 1e-4 * max(1.0, abs(g0[2]))
+    # switching back to built-in kernels on the same context drops the host Gram
+    m.temporal_cov_list = [se]
+    hp1 = O.make_hparams(110.0, (210.0,), [(O.SE, 9.0, 0.6)], 0.07, jitter=1e-8)
+    assert abs(m.loglik() - O.loglik(geom, hp1, lfp)) / abs(ll_ref) < 1e-9
+
+
+def test_time_grid_beyond_1024_points_and_capacity_error():
+    """nt = 1400 on a uniform grid: the eigensolver's limit applies to the symmetry-folded halves (700 rows each).  A grid
+    with no reflection symmetry of that length exceeds the capacity and raises GPCSDCapacityError, which fit() does not
+    swallow (it is not a ValueError / LinAlgError)."""
+    import gpcsd_amd
+    from gpcsd_amd.gpcsd1d import GPCSD1D
+    from gpcsd_amd.covariances import GPCSDTemporalCovSE, GPCSDTemporalCovMatern
+    x = np.linspace(0, 2300, 24)[:, None]
+    t = 0.5 * np.arange(1400.0)[:, None]
+    lfp = C.synth_lfp(271, 24, 1400, 2)
+
+    def build(tgrid):
+        np.random.seed(0)
+        tcl = [GPCSDTemporalCovSE(tgrid), GPCSDTemporalCovMatern(tgrid)]
+        tcl[0].params["ell"]["value"], tcl[0].params["sigma2"]["value"] = 12.0, 0.5
+        tcl[1].params["ell"]["value"], tcl[1].params["sigma2"]["value"] = 4.0, 0.7
+        mm = GPCSD1D(lfp, x, tgrid, a=0.0, b=2300.0, ngl=100, temporal_cov_list=tcl)
+        mm.R["value"], mm.sig2n["value"] = 100.0, 0.05
+        mm.spatial_cov.params["ell"]["value"] = 200.0
+        return mm
+    m = build(t)
+    geom = O.Geometry1D(x, t, a=0.0, b=2300.0, ngl=100)
+    hp = O.make_hparams(100.0, (200.0,), [(O.SE, 12.0, 0.5), (O.MATERN, 4.0, 0.7)], 0.05, jitter=1e-8)
+    ll = m.loglik()
+    assert abs(ll - O.loglik(geom, hp, lfp)) / abs(ll) < 1e-8
+    t_bad = t.copy()
+    t_bad[-1, 0] += 0.123                                         # breaks the mirror symmetry of the grid
+    mb = build(t_bad)
+    with pytest.raises(gpcsd_amd.GPCSDCapacityError):
+        mb.loglik()
+    with pytest.raises(gpcsd_amd.GPCSDCapacityError):
+        mb.fit(n_restarts=1, options={"maxiter": 2})
+    assert not issubclass(gpcsd_amd.GPCSDCapacityError, (ValueError, np.linalg.LinAlgError))
+
+
+def test_shift_objective_fixture_whitened_quadratic_forms():
+    """N4: the per-trial quadratic form behind the trial-shift objective (auditory_lfp/fit_mean_function.py:311-321), against
+    the fixture produced with the reference's own comp_eig_D, and end to end through the library's comp_eig_D."""
+    from gpcsd_amd.utility_functions import comp_eig_D, whitened_quadratic_forms
+    g = golden("shift_objective")
+    ntr, ntau = g["nll"].shape
+    prior = 0.5 * np.sum(np.square((g["taus"] - g["mutau"]) / g["sigtau"]), axis=1)
+    resid = g["resid"].reshape(12, 40, ntr * ntau)                 # every (trial, tau) residual in ONE batched call
+    q = whitened_quadratic_forms(g["Qs"], g["Qt"], g["Dvec"], resid).reshape(ntr, ntau)
+    assert np.allclose(0.5 * q + prior[None, :], g["nll"], rtol=1e-10, atol=0)
+    Qs, Qt, D = comp_eig_D(g["Ks"], g["Kt"], g["sig2n"])           # device eigensolver, per-electrode noise list
+    q2 = whitened_quadratic_forms(Qs, Qt, D, resid).reshape(ntr, ntau)
+    assert np.allclose(0.5 * q2 + prior[None, :], g["nll"], rtol=1e-7, atol=0)
+
+
+def test_predict_returns_pinned_arrays_that_are_not_overwritten():
+    """predict() lands its host arrays in recycled page-locked blocks; arrays a caller keeps must survive later calls."""
+    c, g, geom, hp, lfp = load_model_case("2d_npx_96x120x3")
+    m = _model_from_case(c, g, lfp)
+    m.predict(c["x"], c["t"], type="csd")
+    keep = m.csd_pred
+    snapshot = keep.copy()
+    m.update_lfp(2.0 * lfp, c["t"])
+    for _ in range(3):
+        m.predict(c["x"], c["t"], type="csd")
+    assert np.array_equal(keep, snapshot)                          # the kept result was not recycled under the caller
+    assert relerr(m.csd_pred, 2.0 * snapshot) < 1e-12
+    assert relerr(snapshot, g["csd_pred"]) < GATE
+
+
+# ------------------------------------------------------------------------------------------------ multi-rank bench step
+def _run(cmd, env, timeout=600):
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
+    assert r.returncode == 0, "command failed:\n%s\n%s" % (r.stdout[-3000:], r.stderr[-3000:])
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert lines, r.stdout[-2000:]
+    return json.loads(lines[-1])
+
+
+@pytest.mark.timeout(900)
+def test_bench_step_two_ranks_gloo_on_one_gpu():
+    """bench.py's own N>1 path (trial sharding, hyper-parameter broadcast, partial-sum all-reduce, max-over-ranks timing),
+    rehearsed with two ranks sharing the one GPU of the test box over gloo: the global log-likelihood the two ranks report
+    equals the single-process evaluation of the same 2 x 4 trials."""
+    env = dict(os.environ, GPCSD_BENCH_BACKEND="gloo", GPCSD_DEVICE="0", MASTER_ADDR="127.0.0.1")
+    port = 29500 + os.getpid() % 400
+    common = ["--steps", "2", "--warmup", "1", "--setup-steps", "3", "--trials-per-gpu", "4", "--no-cpu-baseline"]
+    two = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                "127.0.0.1", "--master-port", str(port), "bench.py", "--gpus", "2"] + common, env)
+    assert two["n_gpus"] == 2 and two["config"]["total_trials"] == 8 and two["value"] > 0 and two["setup_steps"] == 3
+    sys.path.insert(0, ROOT)
+    import bench
+    w = bench.workload("cfg3")
+    m = bench.build_model(w, np.zeros((w["nx"], w["nt"], 1)))
+    blocks = [bench.synth_data(w, m, 4, seed=1000 + r) for r in range(2)]
+    m.update_lfp(np.concatenate(blocks, axis=2), w["t"])
+    ll = float(m.loglik())
+    assert abs(ll - two["loglik"]) / abs(ll) < 1e-10

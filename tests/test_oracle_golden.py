@@ -149,3 +149,23 @@ def test_dense_cholesky_crosscheck():
     a = O.loglik_from_K(lfp, Ks, Kt, hp["sig2n"])
     b = O.loglik_dense_cholesky(lfp, Ks, Kt, hp["sig2n"])
     assert abs(a - b) / abs(b) < 1e-9
+
+
+def test_shift_objective_vs_reference_pieces():
+    """N4: the trial-shift objective (auditory_lfp/fit_mean_function.py:311-321) on the decomposition the reference's own
+    comp_eig_D produced with a per-electrode noise list."""
+    g = golden("shift_objective")
+    Qs, Qt, D = O.eig_D(g["Ks"], g["Kt"], g["sig2n"])
+    assert relerr(D, g["Dvec"]) < 1e-10
+    for ti in range(g["lfp"].shape[2]):
+        for k, tau in enumerate(g["taus"]):
+            got = O.shift_objective(g["Qs"], g["Qt"], g["Dvec"], g["lfp"][:, :, ti], g["mu_lfp"], g["t"], tau,
+                                    float(g["mutau"]), float(g["sigtau"]))
+            assert abs(got - g["nll"][ti, k]) <= 1e-11 * abs(g["nll"][ti, k])
+            # with the oracle's own eigenvectors (sign / ordering conventions of this LAPACK build) as well
+            got2 = O.shift_objective(Qs, Qt, D, g["lfp"][:, :, ti], g["mu_lfp"], g["t"], tau, float(g["mutau"]),
+                                     float(g["sigtau"]))
+            assert abs(got2 - g["nll"][ti, k]) <= 1e-8 * abs(g["nll"][ti, k])
+    q = O.whitened_quad(g["Qs"], g["Qt"], g["Dvec"], g["resid"][:, :, :, 1])
+    prior = 0.5 * np.sum(np.square((g["taus"][1] - g["mutau"]) / g["sigtau"]))
+    assert np.allclose(0.5 * q + prior, g["nll"][:, 1], rtol=1e-11, atol=0)

@@ -51,6 +51,8 @@ def main():
     ap.add_argument("dirs", nargs="+")
     ap.add_argument("--out", default=None)
     ap.add_argument("--unit-bytes", type=float, default=1024.0, help="bytes per FETCH_SIZE/WRITE_SIZE unit")
+    ap.add_argument("--per-step-kernel", default="unfold_swap_sum_kernel",
+                    help="a kernel launched exactly once per bench step: its launch count is the number of steps profiled")
     args = ap.parse_args()
     merged = defaultdict(dict)
     for d in args.dirs:
@@ -75,9 +77,15 @@ def main():
         print("%-70s grid %9d x%-5d n=%4d  read %10.3f MB  write %10.3f MB" % (
             r["kernel"][:70], r["grid"], r["workgroup"], r.get("launches", 0),
             r.get("hbm_read_bytes_per_launch", float("nan")) / 1e6, r.get("hbm_write_bytes_per_launch", float("nan")) / 1e6))
+    steps = sum(r.get("launches", 0) for r in rows if r["kernel"].startswith(args.per_step_kernel))
+    total = sum(r.get("hbm_traffic_bytes_per_launch", 0.0) * r.get("launches", 0) for r in rows)
+    per_step = total / steps if steps else None
+    if per_step:
+        print("steps profiled: %d   HBM traffic per step: %.1f MB" % (steps, per_step / 1e6))
     if args.out:
         with open(args.out, "w") as fh:
-            json.dump({"unit_bytes": args.unit_bytes, "fetch_correction": 2.0, "rows": rows}, fh, indent=1)
+            json.dump({"unit_bytes": args.unit_bytes, "fetch_correction": 2.0, "steps_profiled": steps,
+                       "hbm_traffic_bytes_per_step": per_step, "rows": rows}, fh, indent=1)
 
 
 if __name__ == "__main__":
