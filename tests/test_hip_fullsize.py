@@ -84,11 +84,24 @@ def test_cfg3_geometry_noise_list_predict_vs_oracle():
     m.sig2n["prior"] = [m.sig2n["prior"]] * 384
     hp2 = dict(hp)
     hp2["sig2n"] = sig
+    # The reference ties noise variance x to eigen-RANK x of Ks.  At this geometry ~350 of the 384 eigenvalues of Ks are
+    # rounding noise, so their order -- hence the objective -- depends on the eigensolver's rounding: LAPACK drivers
+    # disagree with each other by 3e-4 .. 1e-3 here (measured: evd / evr / ev).  The GPU path is held to that spread.
+    hpj = with_jitter(hp2, 1e-7)
     ll = m.loglik()
-    assert abs(ll - O.loglik(geom, with_jitter(hp2, 1e-7), lfp)) / abs(ll) < GATE
+    ref = O.loglik(geom, hpj, lfp)
+    spread = O.driver_spread(lambda: O.loglik(geom, hpj, lfp))
+    dev = abs(ll - ref) / abs(ref)
+    print("384 x 500 noise list: GPU vs dsyevd %.2e, LAPACK driver spread %.2e" % (dev, spread))
+    assert spread > 1e-5                                   # the situation this test documents
+    assert dev < max(GATE, 3.0 * spread)
     zsel = c["x"][::8]
     m.predict(zsel, c["t"], type="csd")
-    assert relerr(m.csd_pred, O.predict(geom, hp2, lfp, zsel, c["t"], type="csd")["csd"]) < GATE
+    refp = O.predict(geom, hp2, lfp, zsel, c["t"], type="csd")["csd"]
+    spread_p = O.driver_spread(lambda: O.predict(geom, hp2, lfp, zsel, c["t"], type="csd")["csd"])
+    devp = relerr(m.csd_pred, refp)
+    print("384 x 500 noise list predict: GPU vs dsyevd %.2e, LAPACK driver spread %.2e" % (devp, spread_p))
+    assert devp < max(GATE, 3.0 * spread_p)
 
 
 # ------------------------------------------------------------------------------------------------ cfg2: 24 x 500 x 200

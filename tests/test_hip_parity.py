@@ -786,7 +786,9 @@ def test_random_models_vs_oracle():
         except ZeroDivisionError:
             continue
         nfold += folds > 0
-        gate = 1e-4 if "siglist=1" in desc else 1e-6
-        assert e_ll < gate and e_c < gate and e_l < gate, (desc, e_ll, e_c, e_l)
+        # 1e-6 everywhere; with a per-electrode noise list the reference's objective depends on the order of the rounding-
+        # noise eigenvalues of Ks (O.driver_spread): the gate there is 3x what LAPACK drivers disagree by on the same draw
+        gates = [max(1e-6, 3.0 * v) for v in F.one_case.last_spread]
+        assert e_ll < gates[0] and e_c < gates[1] and e_l < gates[2], (desc, e_ll, e_c, e_l, F.one_case.last_spread)
     if not (os.environ.get("GPCSD_NO_FOLD_GEMM") == "1" or os.environ.get("GPCSD_NO_SYMFOLD") == "1"):
         assert nfold > 5

@@ -87,6 +87,15 @@ def one_case(rs, k):
     ref = O.predict(geom, hp0, lfp, z, ts, type="both")
     e_c, e_l = relerr(m.csd_pred, ref["csd"]), relerr(m.lfp_pred, ref["lfp"])
     folds = m._context().fold_gemm()
+    if np.ndim(sig) > 0:
+        # per-electrode noise list: the objective depends on the ORDER of the (near-)degenerate eigenvalues of Ks, i.e. on
+        # the rounding of the eigensolver; measure how much equally valid LAPACK drivers disagree on THIS draw
+        sp = (O.driver_spread(lambda: O.loglik(geom, hp, lfp)),
+              O.driver_spread(lambda: O.predict(geom, hp0, lfp, z, ts, type="csd")["csd"]),
+              O.driver_spread(lambda: O.predict(geom, hp0, lfp, z, ts, type="lfp")["lfp"]))
+        one_case.last_spread = sp
+    else:
+        one_case.last_spread = (0.0, 0.0, 0.0)
     if os.environ.get("FUZZ_GRAD"):
         # analytic gradient (natural parameters) against central differences of the library's own loglik
         ll0, g = m._loglik_and_grad_natural()
@@ -129,13 +138,17 @@ if __name__ == "__main__":
         nfold += folds > 0
         # a per-electrode noise list is attached to eigen-RANKS (reference quirk): with near-degenerate tiny eigenvalues the
         # assignment depends on rounding, two correct solvers differ at 1e-6..1e-5
-        gate = 1e-4 if "siglist=1" in desc else 1e-6
-        bad = e_ll > gate or e_c > gate or e_l > gate
+        sp = one_case.last_spread
+        gates = [max(1e-6, 3.0 * v) for v in sp]
+        bad = e_ll > gates[0] or e_c > gates[1] or e_l > gates[2]
+        if "siglist=1" in desc:
+            print("    noise list: LAPACK driver spread ll %.1e csd %.1e lfp %.1e | GPU vs dsyevd ll %.1e csd %.1e lfp %.1e"
+                  % (sp[0], sp[1], sp[2], e_ll, e_c, e_l), flush=True)
         nbad += bad
         worst = [max(worst[0], e_ll), max(worst[1], e_c), max(worst[2], e_l)]
         if bad or k % 10 == 0:
             print("%3d %-44s ll %.1e csd %.1e lfp %.1e folded_calls %d %s" % (k, desc, e_ll, e_c, e_l, folds, "<-- FAIL" if bad else ""), flush=True)
-    print("cases %d failures %d (gate 1e-6; 1e-4 with a noise list) worst ll %.1e csd %.1e lfp %.1e; cases that used the folded path: %d; %.0f s"
+    print("cases %d failures %d (gate 1e-6; with a noise list 3x the spread between LAPACK drivers on the same draw) worst ll %.1e csd %.1e lfp %.1e; cases that used the folded path: %d; %.0f s"
           % (ncases, nbad, worst[0], worst[1], worst[2], nfold, time.time() - t0))
     if "worst_g" in globals():
         print("worst gradient deviation from central differences (relative to the largest component): %.1e" % globals()["worst_g"])
