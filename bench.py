@@ -400,7 +400,8 @@ def run_step_bench(args, w, rank, world, local_rank, backend):
     ms_per_step = 1e3 * elapsed / args.steps
 
     # ---- the class API as a drop-in user calls it: predict() returns host arrays (PCIe inclusive), rank-local ----
-    m.predict(z, w["t"], type="csd")                           # first call pins / registers its landing buffers
+    for _ in range(3):                                         # the result arrays ping-pong between two pinned blocks of the
+        m.predict(z, w["t"], type="csd")                       # pool: both exist after the second call (steady state of a loop)
     t1 = time.perf_counter()
     n_pcie = 3
     for _ in range(n_pcie):

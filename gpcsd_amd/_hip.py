@@ -70,6 +70,7 @@ SIGNATURES = {
     "gpcsd_kphi_2d": (_I, [_P, _DP, _I, _DP, _DP, _I, _DP, _DP, _I, _D, _D, _D, _D, _DP, _I, _DP]),
     "gpcsd_kphig_2d": (_I, [_P, _DP, _I, _DP, _DP, _I, _DP, _DP, _I, _DP, _I, _D, _D, _D, _D, _DP]),
     "gpcsd_eigh": (_I, [_P, _DP, _I, _DP, _DP]),
+    "gpcsd_eigh_batch": (_I, [_P, _DP, _I, _I, _DP, _DP, ctypes.POINTER(_I)]),
     "gpcsd_eig_D": (_I, [_P, _DP, _I, _DP, _I, _DP, _I, _DP, _DP, _DP]),
     "gpcsd_whitened_quad": (_I, [_P, _DP, _I, _DP, _I, _DP, _DP, _I, _DP]),
     "gpcsd_debug_sytrd": (_I, [_P, _DP, _I, _DP, _DP, _DP, _DP]),
@@ -359,6 +360,18 @@ class Context:
         w, V = np.empty(n), np.empty((n, n))
         self._check(self._lib.gpcsd_eigh(self._h, _ptr(A), n, _ptr(w), _ptr(V)))
         return w, V
+
+    def eigh_batch(self, A):
+        """A (count, n, n) -> (evals (count, n), evecs (count, n, n), status (count,)) through one shared chain of launches."""
+        A = _arr(A)
+        if A.ndim != 3 or A.shape[1] != A.shape[2]:
+            raise ValueError("eigh_batch needs an array of shape (count, n, n)")
+        count, n = A.shape[0], A.shape[1]
+        w, V = np.empty((count, n)), np.empty((count, n, n))
+        st = np.zeros(count, dtype=np.int32)
+        self._check(self._lib.gpcsd_eigh_batch(self._h, _ptr(A), n, count, _ptr(w), _ptr(V),
+                                               st.ctypes.data_as(ctypes.POINTER(ctypes.c_int))))
+        return w, V, st
 
     def debug_sytrd(self, A):
         A = _arr(A)

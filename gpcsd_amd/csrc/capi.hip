@@ -894,6 +894,28 @@ extern "C" int gpcsd_eigh(gpcsd_ctx *c, const double *A, int n, double *evals, d
     GP_API_END(c)
 }
 
+// `count` independent symmetric matrices of the same order in ONE chain of launches (the replicated-class machinery behind
+// gpcsd_loglik_grad_batch, exposed for tests): A (count, n, n) -> evals (count, n), evecs (count, n, n), status (count):
+// 0 ok, > 0 numerical failure of that matrix alone.
+extern "C" int gpcsd_eigh_batch(gpcsd_ctx *c, const double *A, int n, int count, double *evals, double *evecs, int *status) {
+    GP_API_BEGIN(c)
+    GP_REQUIRE(A && evals && evecs && status && n > 0 && count > 0, -3, "eigh_batch: bad arguments");
+    const size_t nn = (size_t)n * n;
+    double *dA = c->upload<double>("op_in0", A, nn * count);
+    double *dw = c->buf<double>("op_w", (size_t)n * count);
+    double *dV = c->buf<double>("op_out", nn * count);
+    int *st = c->buf<int>("status_batch", (size_t)count);
+    GP_HIP(hipMemsetAsync(st, 0, (size_t)count * sizeof(int), c->stream));
+    eigh_pair_device(c, dA, n, dw, dV, nullptr, nullptr, 0, nullptr, nullptr, nullptr, st, c->stream, true, count, 1);
+    c->download(evals, dw, (size_t)n * count * sizeof(double));
+    c->download(evecs, dV, nn * count * sizeof(double));
+    c->download(status, st, (size_t)count * sizeof(int));
+    c->sync();
+    if (c->prof_on) c->prof_collect();
+    return 0;
+    GP_API_END(c)
+}
+
 // diagnostics: the stages of the large-n eigensolver on their own (tests compare them with LAPACK-free identities)
 extern "C" int gpcsd_debug_sytrd(gpcsd_ctx *c, const double *A, int n, double *d, double *e, double *V, double *tau) {
     GP_API_BEGIN(c)

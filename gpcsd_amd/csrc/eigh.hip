@@ -19,11 +19,16 @@
 
 namespace gpcsd {
 
-void eigh_large_multi(gpcsd_ctx *c, const EigReq *reqs, int count, int *d_status, hipStream_t s);   // eigh_dc.hip
+void eigh_large_multi(gpcsd_ctx *c, const EigReq *reqs, int nclass, int *d_status, int status_stride, hipStream_t s);   // eigh_dc.hip
 
+// blockIdx.x = replica: inputs sA apart, eigenvalues sw apart, eigenvectors sZ apart, status words status_stride apart
 template <int NT>
 __global__ __launch_bounds__(NT) void jacobi_lds_kernel(const double *__restrict__ Ag, int n, double *evals, double *evecs,
-                                                        int *status) {
+                                                        int *status, long sA, long sw, long sZ, int status_stride) {
+    Ag += blockIdx.x * sA;
+    evals += blockIdx.x * sw;
+    evecs += blockIdx.x * sZ;
+    status += (long)blockIdx.x * status_stride;
     extern __shared__ double smem[];
     const int ld = n | 1;
     double *A = smem;
@@ -63,16 +68,19 @@ static bool symfold_enabled() {
     return v;
 }
 
-static void eigh_jacobi(gpcsd_ctx *c, double *A, int n, double *evals, double *evecs, int *d_status, hipStream_t s,
-                        const char *tag) {
-    ProfScope ps(c, "eigh_jacobi", 9.0 * (double)n * n * n, s);
+static void eigh_jacobi(gpcsd_ctx *c, const EigReq &q, int *d_status, int status_stride, hipStream_t s) {
+    const int n = q.n, count = q.count > 1 ? q.count : 1;
+    ProfScope ps(c, "eigh_jacobi", 9.0 * (double)n * n * n * count, s);
     if (n <= JACOBI_LDS_MAX) {
         const int ld = n | 1;
         const size_t sh = sizeof(double) * (2 * (size_t)n * ld + 2 * (JACOBI_LDS_MAX / 2 + 1) + 256);
-        hipLaunchKernelGGL((jacobi_lds_kernel<256>), dim3(1), dim3(256), sh, s, (const double *)A, n, evals, evecs, d_status);
-    } else {
-        double *V = c->buf<double>(std::string("eigh_V_") + (tag ? tag : ""), (size_t)n * n);
-        hipLaunchKernelGGL((jacobi_global_kernel<1024>), dim3(1), dim3(1024), 0, s, A, V, n, evals, evecs, d_status);
+        hipLaunchKernelGGL((jacobi_lds_kernel<256>), dim3(count), dim3(256), sh, s, (const double *)q.A, n, q.w, q.Z, d_status,
+                           q.sA, q.sw, q.sZ, status_stride);
+    } else {                                   // GPCSD_EIGH=jacobi diagnostics path: one replica at a time
+        double *V = c->buf<double>(std::string("eigh_V_") + (q.tag ? q.tag : ""), (size_t)n * n);
+        for (int r = 0; r < count; ++r)
+            hipLaunchKernelGGL((jacobi_global_kernel<1024>), dim3(1), dim3(1024), 0, s, q.A + r * q.sA, V, n, q.w + r * q.sw,
+                               q.Z + r * q.sZ, d_status + (long)r * status_stride);
     }
     GP_HIP(hipGetLastError());
 }
@@ -83,10 +91,14 @@ static void eigh_jacobi(gpcsd_ctx *c, double *A, int n, double *evals, double *e
 // orbit a < ns has representatives (rep_i[a], rep_j[a]); pairs come first (a < na), fixed points have rep_i == rep_j.
 //   Ksym[a][b] = wa wb sum_{r in {i,j}} sum_{c in {k,l}} K[r][c]   (w = 1/sqrt2 for a pair, 1 for a fixed point)
 //   Kanti[a][b] = 1/2 (K[i][k] - K[i][l] - K[j][k] + K[j][l])      (pairs only)
+// blockIdx.y = replica (K n*n apart, Ksym ns*ns apart, Kanti na*na apart)
 __global__ __launch_bounds__(256) void sym_fold_kernel(const double *__restrict__ K, int n, SymDev sy, double *__restrict__ Ksym,
                                                        double *__restrict__ Kanti) {
     const long e = blockIdx.x * 256L + threadIdx.x;
     const int ns = sy.ns, na = sy.na;
+    K += (long)blockIdx.y * n * n;
+    Ksym += (long)blockIdx.y * ns * ns;
+    Kanti += (long)blockIdx.y * na * na;
     if (e >= (long)ns * ns) return;
     const int a = (int)(e / ns), b = (int)(e % ns);
     const int i = sy.rep_i[a], j = sy.rep_j[a], k = sy.rep_i[b], l = sy.rep_j[b];
@@ -119,6 +131,11 @@ __global__ __launch_bounds__(256) void sym_unfold_kernel(int n, SymDev sy, const
                                                          const double *__restrict__ Ua, double *__restrict__ w,
                                                          double *__restrict__ Z) {
     const int ns = sy.ns, na = sy.na;
+    {                                           // blockIdx.y = replica: half spectra n apart, half eigenvectors ns^2+na^2 apart
+        const long r = blockIdx.y, su = (long)ns * ns + (long)na * na;
+        ws += r * n; wa += r * n; Us += r * su; Ua += r * su;
+        w += r * n; Z += r * (long)n * n;
+    }
     const int col = blockIdx.x;                 // 0..ns-1: symmetric eigenvectors, ns..n-1: antisymmetric
     const bool is_sym = col < ns;
     const int cc = is_sym ? col : col - ns;
@@ -154,20 +171,24 @@ static bool fold_applies(const SymDev *sy, int n) {
 // The half-size spectra and eigenvectors of problem `slot` (0: first / spatial, 1: second / temporal) of eigh_pair_device,
 // in FOLD order: w = (ws | wa), U = (Us (ns x ns) | Ua (na x na)), eigenvectors in columns.  The same predicate and buffers
 // as the solver itself uses, so callers that stay in the folded basis (capi.hip) read what the last solve left there.
-FoldView eigh_fold_view(gpcsd_ctx *c, int slot, const SymDev *sy, int n) {
+FoldView eigh_fold_view(gpcsd_ctx *c, int slot, const SymDev *sy, int n, int count) {
     FoldView v;
     if (!fold_applies(sy, n)) return v;
+    if (count < 1) count = 1;
     const std::string T = std::string("fold_p") + (slot ? "1" : "0") + "_";
     v.on = true;
     v.ns = sy->ns;
     v.na = sy->na;
-    v.w = c->buf<double>(T + "w", n);
-    v.U = c->buf<double>(T + "U", (size_t)v.ns * v.ns + (size_t)v.na * v.na);
+    v.sw = n;
+    v.sU = (long)v.ns * v.ns + (long)v.na * v.na;
+    v.w = c->buf<double>(T + "w", (size_t)n * count);
+    v.U = c->buf<double>(T + "U", (size_t)v.sU * count);
     return v;
 }
 
 static void eigh_pair_enqueue(gpcsd_ctx *c, double *A0, int n0, double *w0, double *Z0, const SymDev *sym0, double *A1, int n1,
-                              double *w1, double *Z1, const SymDev *sym1, int *d_status, hipStream_t s, bool need_merged) {
+                              double *w1, double *Z1, const SymDev *sym1, int *d_status, hipStream_t s, bool need_merged,
+                              int count, int status_stride) {
     double *A[2] = {A0, A1}, *w[2] = {w0, w1}, *Z[2] = {Z0, Z1};
     const int n[2] = {n0, n1};
     const SymDev *sym[2] = {sym0, sym1};
@@ -181,41 +202,43 @@ static void eigh_pair_enqueue(gpcsd_ctx *c, double *A0, int n0, double *w0, doub
     // A small problem next to a large one rides along in the large problem's launches for free (GPCSD1D: 24 electrodes
     // next to 500 time points), instead of a serial 250 us single-workgroup Jacobi in front of them.
     const bool pair_has_large = !force_jacobi() && (n0 > JACOBI_LDS_MAX || n1 > JACOBI_LDS_MAX);
-    auto submit = [&](double *Am, int nm, double *wm, double *Zm, const char *tag) {
+    auto submit = [&](double *Am, int nm, double *wm, double *Zm, const char *tag, long sA, long sw, long sZ) {
         if (nm <= 0) return;
+        EigReq q;
+        q.A = Am; q.n = nm; q.w = wm; q.Z = Zm; q.tag = tag;
+        q.count = count; q.sA = sA; q.sw = sw; q.sZ = sZ;
         const bool small = nm <= JACOBI_LDS_MAX && !(pair_has_large && nm >= EIG_BATCH_MIN_N);
-        if (small || force_jacobi()) eigh_jacobi(c, Am, nm, wm, Zm, d_status, s, tag);
-        else {
-            large[nlarge].A = Am; large[nlarge].n = nm; large[nlarge].w = wm; large[nlarge].Z = Zm; large[nlarge].tag = tag;
-            ++nlarge;
-        }
+        if (small || force_jacobi()) eigh_jacobi(c, q, d_status, status_stride, s);
+        else large[nlarge++] = q;
     };
     for (int p = 0; p < 2; ++p) {
         if (n[p] <= 0) continue;
         const SymDev *sy = sym[p];
+        const long nn = (long)n[p] * n[p];
         if (fold_applies(sy, n[p])) {
             const int ns = sy->ns, na = sy->na;
             const std::string T = std::string("fold_") + tags[p][0] + "_";
-            double *Ks = c->buf<double>(T + "Ks", (size_t)ns * ns), *Ka = c->buf<double>(T + "Ka", (size_t)std::max(na, 1) * na);
-            const FoldView fv = eigh_fold_view(c, p, sy, n[p]);
+            double *Ks = c->buf<double>(T + "Ks", (size_t)ns * ns * count),
+                   *Ka = c->buf<double>(T + "Ka", (size_t)std::max(na, 1) * na * count);
+            const FoldView fv = eigh_fold_view(c, p, sy, n[p], count);
             fold[p].on = true;
             fold[p].ws = fv.w;
             fold[p].Us = fv.U;
             fold[p].wa = fv.w + ns;
             fold[p].Ua = fv.U + (size_t)ns * ns;
-            hipLaunchKernelGGL(sym_fold_kernel, dim3(ceil_div((long)ns * ns, 256)), dim3(256), 0, s, (const double *)A[p], n[p],
-                               *sy, Ks, Ka);
-            submit(Ks, ns, fold[p].ws, fold[p].Us, tags[p][1]);
-            submit(Ka, na, fold[p].wa, fold[p].Ua, tags[p][2]);
+            hipLaunchKernelGGL(sym_fold_kernel, dim3(ceil_div((long)ns * ns, 256), count), dim3(256), 0, s, (const double *)A[p],
+                               n[p], *sy, Ks, Ka);
+            submit(Ks, ns, fold[p].ws, fold[p].Us, tags[p][1], (long)ns * ns, fv.sw, fv.sU);
+            submit(Ka, na, fold[p].wa, fold[p].Ua, tags[p][2], (long)na * na, fv.sw, fv.sU);
         } else {
-            submit(A[p], n[p], w[p], Z[p], tags[p][0]);
+            submit(A[p], n[p], w[p], Z[p], tags[p][0], nn, n[p], nn);
         }
     }
-    if (nlarge) eigh_large_multi(c, large, nlarge, d_status, s);
+    if (nlarge) eigh_large_multi(c, large, nlarge, d_status, status_stride, s);
     // need_merged == false: the caller stays in the folded basis (eigh_fold_view) and never reads w / Z of a folded problem
     for (int p = 0; p < 2; ++p)
         if (fold[p].on && need_merged)
-            hipLaunchKernelGGL(sym_unfold_kernel, dim3(n[p]), dim3(256), 0, s, n[p], *sym[p], (const double *)fold[p].ws,
+            hipLaunchKernelGGL(sym_unfold_kernel, dim3(n[p], count), dim3(256), 0, s, n[p], *sym[p], (const double *)fold[p].ws,
                                (const double *)fold[p].Us, (const double *)fold[p].wa, (const double *)fold[p].Ua, w[p], Z[p]);
     GP_HIP(hipGetLastError());
 }
@@ -224,7 +247,9 @@ static void eigh_pair_enqueue(gpcsd_ctx *c, double *A0, int n0, double *w0, doub
 // device), so it replays as a hipGraph: first call eager (allocates workspaces), second call captured, later calls
 // replayed.  A graph is retired whenever any context buffer is (re)allocated, since it holds raw device pointers.
 void eigh_pair_device(gpcsd_ctx *c, double *A0, int n0, double *w0, double *Z0, const SymDev *sym0, double *A1, int n1,
-                      double *w1, double *Z1, const SymDev *sym1, int *d_status, hipStream_t s, bool need_merged) {
+                      double *w1, double *Z1, const SymDev *sym1, int *d_status, hipStream_t s, bool need_merged, int count,
+                      int status_stride) {
+    if (count < 1) count = 1;
     // the limit applies to what the solver actually factorises: a symmetry-folded problem is two half-size ones
     const int m0 = fold_applies(sym0, n0) ? std::max(sym0->ns, sym0->na) : n0;
     const int m1 = fold_applies(sym1, n1) ? std::max(sym1->ns, sym1->na) : n1;
@@ -235,13 +260,14 @@ void eigh_pair_device(gpcsd_ctx *c, double *A0, int n0, double *w0, double *Z0, 
     // GPCSD_PROF_GRAPH=1: keep replaying graphs while profiling, so the outer scopes time the chains as they run in production
     static const bool prof_graph = getenv("GPCSD_PROF_GRAPH") != nullptr;
     if (!any_large || (c->prof_on && !prof_graph) || !graphs_enabled()) {
-        eigh_pair_enqueue(c, A0, n0, w0, Z0, sym0, A1, n1, w1, Z1, sym1, d_status, s, need_merged);
+        eigh_pair_enqueue(c, A0, n0, w0, Z0, sym0, A1, n1, w1, Z1, sym1, d_status, s, need_merged, count, status_stride);
         return;
     }
     char key[320];
-    snprintf(key, sizeof(key), "eigh|%p|%d|%p|%p|%p|%d|%p|%d|%p|%p|%p|%d|%p|%p|%d", (void *)A0, n0, (void *)w0, (void *)Z0,
+    snprintf(key, sizeof(key), "eigh|%p|%d|%p|%p|%p|%d|%p|%d|%p|%p|%p|%d|%p|%p|%d|%d|%d", (void *)A0, n0, (void *)w0, (void *)Z0,
              (void *)(sym0 ? sym0->rep_i : nullptr), sym0 ? sym0->ns : 0, (void *)A1, n1, (void *)w1, (void *)Z1,
-             (void *)(sym1 ? sym1->rep_i : nullptr), sym1 ? sym1->ns : 0, (void *)d_status, (void *)s, (int)need_merged);
+             (void *)(sym1 ? sym1->rep_i : nullptr), sym1 ? sym1->ns : 0, (void *)d_status, (void *)s, (int)need_merged, count,
+             status_stride);
     gpcsd_ctx::GraphSlot &g = c->graphs[key];
     if (g.exec && g.epoch == c->alloc_epoch) {
         GP_HIP(hipGraphLaunch(g.exec, s));
@@ -256,7 +282,7 @@ void eigh_pair_device(gpcsd_ctx *c, double *A0, int n0, double *w0, double *Z0, 
         GP_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
         c->capturing = true;
         try {
-            eigh_pair_enqueue(c, A0, n0, w0, Z0, sym0, A1, n1, w1, Z1, sym1, d_status, s, need_merged);
+            eigh_pair_enqueue(c, A0, n0, w0, Z0, sym0, A1, n1, w1, Z1, sym1, d_status, s, need_merged, count, status_stride);
         } catch (...) {
             c->capturing = false;
             (void)hipStreamEndCapture(s, &graph);
@@ -275,7 +301,7 @@ void eigh_pair_device(gpcsd_ctx *c, double *A0, int n0, double *w0, double *Z0, 
             return;
         }
     }
-    eigh_pair_enqueue(c, A0, n0, w0, Z0, sym0, A1, n1, w1, Z1, sym1, d_status, s, need_merged);
+    eigh_pair_enqueue(c, A0, n0, w0, Z0, sym0, A1, n1, w1, Z1, sym1, d_status, s, need_merged, count, status_stride);
     g.seen_epoch = c->alloc_epoch;
 }
 
@@ -285,7 +311,7 @@ void eigh_device(gpcsd_ctx *c, double *A, int n, double *evals, double *evecs, i
     GP_REQUIRE(n <= JACOBI_MAX_N, GPCSD_ERR_CAPACITY, "eigh: matrix order %d exceeds the eigensolver's capacity of %d rows (GPCSD_MAX_EIG_N)", n,
                JACOBI_MAX_N);
     (void)tag;
-    eigh_pair_device(c, A, n, evals, evecs, nullptr, nullptr, 0, nullptr, nullptr, nullptr, d_status, s, true);
+    eigh_pair_device(c, A, n, evals, evecs, nullptr, nullptr, 0, nullptr, nullptr, nullptr, d_status, s, true, 1, 0);
 }
 
 }  // namespace gpcsd

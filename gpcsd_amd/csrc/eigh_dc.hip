@@ -27,14 +27,17 @@ constexpr int WY_NB = 64;            // reflectors per compact-WY panel
 constexpr int AMAX_PARTS = 64;
 
 // stedc.hip
-struct StedcProb {
+struct StedcProb {               // one class of tridiagonal problems (replicas: d / e s_in apart, outputs sw / sZ apart)
     const double *d, *e;
     int n;
     double *w, *Z;
     std::string tag;
+    int count = 1;
+    long s_in = 0, sw = 0, sZ = 0;
 };
 // wy != nullptr: the leaf launch also forms the T factors of these back-transformations (wy_batch_device: prep_done)
-void stedc_batch_device(gpcsd_ctx *c, StedcProb *probs, int count, int *d_status, hipStream_t s, const WyBatch *wy = nullptr);
+void stedc_batch_device(gpcsd_ctx *c, StedcProb *probs, int nclass, int *d_status, int status_stride, hipStream_t s,
+                        const WyBatch *wy = nullptr);
 
 // ------------------------------------------------------------------------------------------------------------------
 // stage 0: scaling  A0 = A / max|A|   (two launches: per-workgroup partial maxima, then scale + final maximum)
@@ -64,6 +67,8 @@ __global__ void scale_vec_kernel(double *w, int n, const double *__restrict__ am
 // ------------------------------------------------------------------------------------------------------------------
 // stage 1: tridiagonalisation
 // ------------------------------------------------------------------------------------------------------------------
+// One class of problems (see EigReq): the pointers are those of replica 0, every buffer of replica r sits r * blk doubles
+// further (all of them are slices of one arena per class).
 struct SytrdProb {
     double *A0, *A1;      // ping-pong full symmetric storage (n x n)
     double *V;            // (n + WY_NB) x n, row k = reflector k (zero for j <= k, V[k][k+1] = 1)
@@ -71,10 +76,20 @@ struct SytrdProb {
     double *y0, *y1;      // ping-pong A v products
     int n;
     int k_tail;           // first column handled by the in-LDS tail kernel (n - 1: no tail)
+    long blk;             // replica stride of the arena, in doubles
 };
 struct SytrdBatch {
     SytrdProb p[MAX_BATCH];
+    int start[MAX_BATCH + 1];
 };
+__device__ __forceinline__ SytrdProb sy_resolve(const SytrdBatch &b, int g) {
+    int cls, rep;
+    class_of(b.start, g, cls, rep);
+    SytrdProb P = b.p[cls];
+    const long o = rep * P.blk;
+    P.A0 += o; P.A1 += o; P.V += o; P.tau += o; P.d += o; P.e += o; P.y0 += o; P.y1 += o;
+    return P;
+}
 
 }  // namespace gpcsd
 #include "sytrd_regtail.hpp"
@@ -85,7 +100,7 @@ namespace gpcsd {
 // L2/Infinity-Cache round trip plus LDS reductions instead of a chain of dependent loads.
 template <int JQ>
 __global__ __launch_bounds__(256) void sytrd_step_kernel(SytrdBatch b, int k) {
-    const SytrdProb &P = b.p[blockIdx.y];
+    const SytrdProb P = sy_resolve(b, blockIdx.y);
     const int n = P.n;
     if (k >= P.k_tail) return;
     const int row0 = k + 1 + blockIdx.x * SY_RPW;
@@ -214,7 +229,7 @@ __global__ __launch_bounds__(256) void sytrd_step_kernel(SytrdBatch b, int k) {
 
 // d[n-1] after the final step: the single trailing element lives in the buffer written by step n-2
 __global__ void sytrd_last_diag_kernel(SytrdBatch b) {
-    const SytrdProb &P = b.p[blockIdx.x];
+    const SytrdProb P = sy_resolve(b, blockIdx.x);
     if (threadIdx.x != 0 || P.n < 1 || P.k_tail < P.n - 1) return;
     const int n = P.n;
     if (n == 1) {
@@ -236,13 +251,14 @@ static int sy_regtail_rows() {
     return nostrip ? RT_T : RT_TMAX;
 }
 
-static void sytrd_batch_launch(gpcsd_ctx *c, const SytrdBatch &b, int count, int nmax, hipStream_t s) {
+static void sytrd_batch_launch(gpcsd_ctx *c, const SytrdBatch &b, int nclass, int nmax, hipStream_t s) {
     int klast = -1;                                        // last column handled by per-column launches
     bool any_tail = false, all_tail = true;
-    for (int i = 0; i < count; ++i) {
+    for (int i = 0; i < nclass; ++i) {
         klast = std::max(klast, b.p[i].k_tail - 1);
         if (b.p[i].k_tail < b.p[i].n - 1) any_tail = true; else all_tail = false;
     }
+    const int count = b.start[MAX_BATCH];                  // workgroup rows: every replica of every class
     for (int k = 0; k <= klast; ++k) {
         const int m = nmax - k - 1;
         dim3 grid(ceil_div(m, SY_RPW), count);
@@ -253,7 +269,7 @@ static void sytrd_batch_launch(gpcsd_ctx *c, const SytrdBatch &b, int count, int
     }
     if (any_tail) {
         size_t sh = 0;
-        for (int i = 0; i < count; ++i)
+        for (int i = 0; i < nclass; ++i)
             if (b.p[i].k_tail < b.p[i].n - 1) sh = std::max(sh, rt_strip_bytes(b.p[i].n - b.p[i].k_tail));
         static bool rt_attr_set = false;
         if (!rt_attr_set) {
@@ -264,9 +280,9 @@ static void sytrd_batch_launch(gpcsd_ctx *c, const SytrdBatch &b, int count, int
         // profiled on its own: this single launch (one workgroup per problem) is the largest share of the GPU time of an
         // evaluation; flops = (4/3) T^3 per problem, the nominal count of a Householder tridiagonalisation
         double fl = 0.0;
-        for (int i = 0; i < count; ++i) {
+        for (int i = 0; i < nclass; ++i) {
             const double T = b.p[i].n - b.p[i].k_tail;
-            if (b.p[i].k_tail < b.p[i].n - 1) fl += 4.0 / 3.0 * T * T * T;
+            if (b.p[i].k_tail < b.p[i].n - 1) fl += 4.0 / 3.0 * T * T * T * (b.start[i + 1] - b.start[i]);
         }
         ProfScope ps(c, "sytrd_rtail", fl, s);
         hipLaunchKernelGGL(sytrd_rtail_kernel, dim3(count), dim3(RT_NTH), sh, s, b);
@@ -349,114 +365,160 @@ static void ormtr_device(gpcsd_ctx *c, const double *V, const double *tau, int n
 // ------------------------------------------------------------------------------------------------------------------
 // drivers
 // ------------------------------------------------------------------------------------------------------------------
-struct EigProb {
+struct EigProb {                 // one class: `count` replicas, inputs / outputs sA / sw / sZ apart
     double *A, *w, *Z;
     int n;
     std::string tag;
-    double *amax;
+    int count = 1;
+    long sA = 0, sw = 0, sZ = 0;
+    double *amax;                // 2 + AMAX_PARTS doubles per replica (in the arena)
+    double *wyT;                 // T factors of the compact-WY panels (in the arena)
     SytrdProb sp;
+};
+
+// Workspace of a class: ONE allocation holding `count` identical blocks, so that replica r of every buffer is the
+// replica-0 pointer + r * blk (what sy_resolve / wy_resolve / the prep kernels add).  Slices are 16-byte aligned.
+struct ArenaLayout {
+    size_t off = 0;
+    size_t take(size_t ndoubles) {
+        const size_t o = off;
+        off += (ndoubles + 1) & ~(size_t)1;
+        return o;
+    }
 };
 
 static void prep_problem(gpcsd_ctx *c, EigProb &p, hipStream_t s) {
     const int n = p.n;
     const size_t nn = (size_t)n * n;
     const std::string T = "eig_" + p.tag + "_";
-    p.amax = c->buf<double>(T + "amax", 2 + AMAX_PARTS);
     p.sp.n = n;
     {
         static const bool no_tail = getenv("GPCSD_NO_TAIL") && getenv("GPCSD_NO_TAIL")[0] == '1';
         // the trailing block finishes inside one workgroup (192 rows in registers + up to 64 strip rows in LDS)
         p.sp.k_tail = no_tail ? n - 1 : std::max(0, n - sy_regtail_rows());
     }
-    p.sp.A0 = c->buf<double>(T + "A0", nn);
-    p.sp.A1 = c->buf<double>(T + "A1", nn);
-    p.sp.V = c->buf<double>(T + "V", (size_t)(n + WY_NB) * n);
-    p.sp.tau = c->buf<double>(T + "tau", n + WY_NB);
-    p.sp.d = c->buf<double>(T + "d", n);
-    p.sp.e = c->buf<double>(T + "e", n);
-    p.sp.y0 = c->buf<double>(T + "y0", n);
-    p.sp.y1 = c->buf<double>(T + "y1", n);
-    (void)nn;
+    const int npanels = std::max(1, ceil_div(std::max(n - 2, 1), WY_NB));
+    ArenaLayout L;
+    const size_t oA0 = L.take(nn), oA1 = L.take(nn), oV = L.take((size_t)(n + WY_NB) * n), otau = L.take(n + WY_NB);
+    const size_t od = L.take(n), oe = L.take(n), oy0 = L.take(n), oy1 = L.take(n), oamax = L.take(2 + AMAX_PARTS);
+    const size_t oT = L.take((size_t)npanels * WY_NB * WY_NB);
+    double *base = c->buf<double>(T + "arena", L.off * (size_t)std::max(p.count, 1));
+    p.sp.blk = (long)L.off;
+    p.sp.A0 = base + oA0; p.sp.A1 = base + oA1; p.sp.V = base + oV; p.sp.tau = base + otau;
+    p.sp.d = base + od; p.sp.e = base + oe; p.sp.y0 = base + oy0; p.sp.y1 = base + oy1;
+    p.amax = base + oamax;
+    p.wyT = base + oT;
     (void)s;
 }
 
 // scaling, copy into the ping-pong buffer and zeroing of the reflector storage for ALL problems in two launches
 struct PrepBatch {
     const double *A[MAX_BATCH];
-    double *amax[MAX_BATCH];
+    long sA[MAX_BATCH];
+    double *amax[MAX_BATCH];    // in the class arena: replica stride sp[].blk
     SytrdProb sp[MAX_BATCH];
     double *w[MAX_BATCH];       // eigenvalue outputs (for the final rescale)
-    int *status;                // numerical-failure word of the call (non-finite input is reported there)
+    long sw[MAX_BATCH];
+    int start[MAX_BATCH + 1];
+    int *status;                // numerical-failure words of the call (non-finite input is reported there) ...
+    int status_stride;          // ... one per replica index when != 0
 };
+struct PrepView {
+    const double *A;
+    double *amax, *w;
+    SytrdProb P;
+    int *status;
+};
+__device__ __forceinline__ PrepView prep_resolve(const PrepBatch &b, int g) {
+    int cls, rep;
+    class_of(b.start, g, cls, rep);
+    PrepView v;
+    v.P = b.sp[cls];
+    const long o = rep * v.P.blk;
+    v.P.A0 += o; v.P.A1 += o; v.P.V += o; v.P.tau += o; v.P.d += o; v.P.e += o; v.P.y0 += o; v.P.y1 += o;
+    v.A = b.A[cls] + rep * b.sA[cls];
+    v.amax = b.amax[cls] + o;
+    v.w = b.w[cls] ? b.w[cls] + rep * b.sw[cls] : nullptr;
+    v.status = b.status ? b.status + (long)rep * b.status_stride : nullptr;
+    return v;
+}
 __global__ __launch_bounds__(256) void absmax_partial_batch_kernel(PrepBatch b) {
     __shared__ double red[4];
-    const int p = blockIdx.y;
-    const long n2 = (long)b.sp[p].n * b.sp[p].n;
-    const double *__restrict__ A = b.A[p];
+    const PrepView v = prep_resolve(b, blockIdx.y);
+    const long n2 = (long)v.P.n * v.P.n;
+    const double *__restrict__ A = v.A;
     double m = 0.0;
     for (long i = blockIdx.x * 256L + threadIdx.x; i < n2; i += (long)gridDim.x * 256) m = fmax(m, fabs(A[i]));
     m = block_max256(m, red);
-    if (threadIdx.x == 0) b.amax[p][2 + blockIdx.x] = m;
+    if (threadIdx.x == 0) v.amax[2 + blockIdx.x] = m;
 }
 __global__ __launch_bounds__(256) void scale_copy_zero_batch_kernel(PrepBatch b) {
-    const int p = blockIdx.y;
-    const SytrdProb &P = b.sp[p];
+    const PrepView v = prep_resolve(b, blockIdx.y);
+    const SytrdProb &P = v.P;
     const long n = P.n, n2 = n * n;
-    double *amax = b.amax[p];
+    double *amax = v.amax;
     double m = 0.0;
     for (int i = 0; i < AMAX_PARTS; ++i) m = fmax(m, amax[2 + i]);
     m = (m > 0.0 && m <= 1.7e308) ? m : 1.0;
     if (blockIdx.x == 0 && threadIdx.x == 0) amax[0] = m;
     const double inv = 1.0 / m;
-    const double *__restrict__ A = b.A[p];
+    const double *__restrict__ A = v.A;
     const long stride = (long)gridDim.x * 256, i0 = blockIdx.x * 256L + threadIdx.x;
     // Non-finite input (a NaN hyper-parameter makes a whole Gram matrix NaN) must not reach the solver: its rank sorts and
     // merges assume a total order and would index out of range.  Such entries are zeroed and the call reports failure.
     bool bad = false;
     for (long i = i0; i < n2; i += stride) {
-        double v = (m > 1e300) ? A[i] / m : A[i] * inv;         // 1 / m is subnormal beyond 1e300
-        if (!(fabs(v) <= 2.0)) {
-            v = 0.0;
+        double x = (m > 1e300) ? A[i] / m : A[i] * inv;         // 1 / m is subnormal beyond 1e300
+        if (!(fabs(x) <= 2.0)) {
+            x = 0.0;
             bad = true;
         }
-        P.A0[i] = v;
+        P.A0[i] = x;
     }
-    if (bad && b.status) atomicMax(b.status, 4);
+    if (bad && v.status) atomicMax(v.status, 4);
     const long nv = (n + WY_NB) * n;
     for (long i = i0; i < nv; i += stride) P.V[i] = 0.0;
     for (long i = i0; i < n + WY_NB; i += stride) P.tau[i] = 0.0;
 }
-__global__ __launch_bounds__(256) void scale_vec_batch_kernel(PrepBatch b) {
-    const int p = blockIdx.y;
-    const int n = b.sp[p].n;
-    const double m = b.amax[p][0];
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) b.w[p][i] *= m;
-}
 
-static PrepBatch prep_batch_launch(gpcsd_ctx *c, EigProb *probs, int count, hipStream_t s, int *d_status = nullptr) {
-    PrepBatch pb;
+static PrepBatch prep_batch_launch(gpcsd_ctx *c, EigProb *probs, int nclass, hipStream_t s, int *d_status = nullptr,
+                                   int status_stride = 0) {
+    PrepBatch pb{};
     pb.status = d_status;
-    for (int i = 0; i < count; ++i) {
+    pb.status_stride = status_stride;
+    int total = 0;
+    for (int i = 0; i < MAX_BATCH; ++i) {
+        pb.start[i] = total;
+        if (i >= nclass) continue;
         prep_problem(c, probs[i], s);
         pb.A[i] = probs[i].A;
+        pb.sA[i] = probs[i].sA;
         pb.amax[i] = probs[i].amax;
         pb.sp[i] = probs[i].sp;
         pb.w[i] = probs[i].w;
+        pb.sw[i] = probs[i].sw;
+        total += std::max(probs[i].count, 1);
     }
-    hipLaunchKernelGGL(absmax_partial_batch_kernel, dim3(AMAX_PARTS, count), dim3(256), 0, s, pb);
-    hipLaunchKernelGGL(scale_copy_zero_batch_kernel, dim3(128, count), dim3(256), 0, s, pb);
+    pb.start[MAX_BATCH] = total;
+    hipLaunchKernelGGL(absmax_partial_batch_kernel, dim3(AMAX_PARTS, total), dim3(256), 0, s, pb);
+    hipLaunchKernelGGL(scale_copy_zero_batch_kernel, dim3(128, total), dim3(256), 0, s, pb);
     GP_HIP(hipGetLastError());
     return pb;
+}
+
+static SytrdBatch sytrd_batch_of(const PrepBatch &pb) {
+    SytrdBatch b{};
+    for (int i = 0; i < MAX_BATCH; ++i) b.p[i] = pb.sp[i];
+    for (int i = 0; i <= MAX_BATCH; ++i) b.start[i] = pb.start[i];
+    return b;
 }
 
 void sytrd_device(gpcsd_ctx *c, double *A, int n, double *d, double *e, double *V, double *tau, hipStream_t s) {
     GP_REQUIRE(n >= 1 && n <= EIG_MAXN, -3, "sytrd: n=%d outside [1,%d]", n, EIG_MAXN);
     EigProb p;
     p.A = A; p.n = n; p.tag = "dbg"; p.w = nullptr; p.Z = nullptr;
-    prep_batch_launch(c, &p, 1, s);
-    SytrdBatch b;
-    b.p[0] = p.sp;
-    sytrd_batch_launch(c, b, 1, n, s);
+    const PrepBatch pb = prep_batch_launch(c, &p, 1, s);
+    sytrd_batch_launch(c, sytrd_batch_of(pb), 1, n, s);
     GP_HIP(hipMemcpyAsync(d, p.sp.d, n * sizeof(double), hipMemcpyDeviceToDevice, s));
     GP_HIP(hipMemcpyAsync(e, p.sp.e, n * sizeof(double), hipMemcpyDeviceToDevice, s));
     GP_HIP(hipMemcpyAsync(tau, p.sp.tau, n * sizeof(double), hipMemcpyDeviceToDevice, s));
@@ -467,51 +529,57 @@ void sytrd_device(gpcsd_ctx *c, double *A, int n, double *d, double *e, double *
     GP_HIP(hipGetLastError());
 }
 
-void eigh_large_batch(gpcsd_ctx *c, EigProb *probs, int count, int *d_status, hipStream_t s) {
-    GP_REQUIRE(count >= 1 && count <= MAX_BATCH, -3, "eigh batch size %d outside [1,%d]", count, MAX_BATCH);
-    SytrdBatch b;
+void eigh_large_batch(gpcsd_ctx *c, EigProb *probs, int nclass, int *d_status, int status_stride, hipStream_t s) {
+    GP_REQUIRE(nclass >= 1 && nclass <= MAX_BATCH, -3, "eigh: %d problem classes outside [1,%d]", nclass, MAX_BATCH);
     int nmax = 0;
-    for (int i = 0; i < count; ++i) {
+    bool replicated = false;
+    for (int i = 0; i < nclass; ++i) {
         GP_REQUIRE(probs[i].n > 2 && probs[i].n <= EIG_MAXN, -3, "eigh(large): n=%d outside (2,%d]", probs[i].n, EIG_MAXN);
         nmax = std::max(nmax, probs[i].n);
+        replicated = replicated || probs[i].count > 1;
     }
-    const PrepBatch pb = prep_batch_launch(c, probs, count, s, d_status);
-    for (int i = 0; i < count; ++i) b.p[i] = probs[i].sp;
+    const PrepBatch pb = prep_batch_launch(c, probs, nclass, s, d_status, status_stride);
     {
         ProfScope ps(c, "eigh_sytrd", 0.0, s);
-        sytrd_batch_launch(c, b, count, nmax, s);
+        sytrd_batch_launch(c, sytrd_batch_of(pb), nclass, nmax, s);
     }
     const bool wy_fused = wy_fused_supported(nmax);
+    GP_REQUIRE(wy_fused || !replicated, GPCSD_ERR_CAPACITY,
+               "eigh: replicated (batched) problems need the fused back-transformation, n=%d is too large for it", nmax);
     static const bool wy_in_leaf = !(getenv("GPCSD_WY_IN_LEAF") && getenv("GPCSD_WY_IN_LEAF")[0] == '0');
-    WyBatch wb;
+    WyBatch wb{};
+    for (int i = 0; i <= MAX_BATCH; ++i) wb.start[i] = pb.start[i];
     if (wy_fused)
-        for (int i = 0; i < count; ++i) {
+        for (int i = 0; i < nclass; ++i) {
             EigProb &p = probs[i];
             const int nrefl = p.n - 2, P = ceil_div(nrefl, WY_NB);
             wb.p[i].V = p.sp.V; wb.p[i].tau = p.sp.tau; wb.p[i].Z = p.Z;
-            wb.p[i].T = c->buf<double>("eig_" + p.tag + "_wyT", (size_t)P * WY_NB * WY_NB);
+            wb.p[i].T = p.wyT;
             wb.p[i].n = p.n; wb.p[i].npanels = P; wb.p[i].nrefl = nrefl;
             wb.p[i].w_scale = pb.w[i]; wb.p[i].amax = pb.amax[i];   // the final rescale of the eigenvalues rides in the apply launch
+            wb.p[i].blk = p.sp.blk; wb.p[i].sZ = p.sZ; wb.p[i].sw = p.sw;
         }
     bool prep_done = false;
     {
         ProfScope ps(c, "eigh_stedc", 0.0, s);
         StedcProb sp[MAX_BATCH];
-        for (int i = 0; i < count; ++i) {
+        for (int i = 0; i < nclass; ++i) {
             sp[i].d = probs[i].sp.d; sp[i].e = probs[i].sp.e; sp[i].n = probs[i].n;
             sp[i].w = probs[i].w; sp[i].Z = probs[i].Z; sp[i].tag = probs[i].tag;
+            sp[i].count = std::max(probs[i].count, 1);
+            sp[i].s_in = probs[i].sp.blk; sp[i].sw = probs[i].sw; sp[i].sZ = probs[i].sZ;
         }
         // the T factors of the back-transformation need the reflectors only: they ride in the leaf launch of the D&C stage
         // (GPCSD_WY_IN_LEAF=0: their own launch after it)
         prep_done = wy_fused && wy_in_leaf;
-        stedc_batch_device(c, sp, count, d_status, s, prep_done ? &wb : nullptr);
+        stedc_batch_device(c, sp, nclass, d_status, status_stride, s, prep_done ? &wb : nullptr);
     }
     if (wy_fused) {
         ProfScope ps(c, "eigh_backtransform", 0.0, s);
-        wy_batch_device(c, wb, count, s, prep_done);
+        wy_batch_device(c, wb, nclass, s, prep_done);
     } else {                                   // n too large for the LDS-resident apply kernel: GEMM chain per panel
         ProfScope ps(c, "eigh_backtransform", 0.0, s);
-        for (int i = 0; i < count; ++i) {
+        for (int i = 0; i < nclass; ++i) {
             EigProb &p = probs[i];
             ormtr_device(c, p.sp.V, p.sp.tau, p.n, p.Z, s, "eig_" + p.tag + "_");
             hipLaunchKernelGGL(scale_vec_kernel, dim3(ceil_div(p.n, 256)), dim3(256), 0, s, p.w, p.n, (const double *)p.amax);
@@ -520,15 +588,17 @@ void eigh_large_batch(gpcsd_ctx *c, EigProb *probs, int count, int *d_status, hi
     GP_HIP(hipGetLastError());
 }
 
-void eigh_large_multi(gpcsd_ctx *c, const EigReq *reqs, int count, int *d_status, hipStream_t s) {
+void eigh_large_multi(gpcsd_ctx *c, const EigReq *reqs, int nclass, int *d_status, int status_stride, hipStream_t s) {
     static_assert(MAX_EIG_BATCH <= MAX_BATCH, "batch limits");
-    GP_REQUIRE(count >= 1 && count <= MAX_BATCH, -3, "eigh batch size %d outside [1,%d]", count, MAX_BATCH);
+    GP_REQUIRE(nclass >= 1 && nclass <= MAX_BATCH, -3, "eigh: %d problem classes outside [1,%d]", nclass, MAX_BATCH);
     EigProb probs[MAX_BATCH];
-    for (int i = 0; i < count; ++i) {
+    for (int i = 0; i < nclass; ++i) {
         probs[i].A = reqs[i].A; probs[i].n = reqs[i].n; probs[i].w = reqs[i].w; probs[i].Z = reqs[i].Z;
         probs[i].tag = reqs[i].tag;
+        probs[i].count = std::max(reqs[i].count, 1);
+        probs[i].sA = reqs[i].sA; probs[i].sw = reqs[i].sw; probs[i].sZ = reqs[i].sZ;
     }
-    eigh_large_batch(c, probs, count, d_status, s);
+    eigh_large_batch(c, probs, nclass, d_status, status_stride, s);
 }
 
 }  // namespace gpcsd

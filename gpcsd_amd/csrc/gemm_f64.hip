@@ -55,6 +55,9 @@ struct GemmK {
     int m_fastest;      // logical tile order: 1 = tile_m varies fastest (few row tiles, many column tiles)
     int n_group;        // otherwise: n-tiles per sweep over the row panels
     const int *dyn;     // optional device scalar: effective N and K (= *dyn) of this launch (D&C merge GEMMs)
+    // outer batch level (GemmDesc::batch2): grid z = z2 * batch1 + z1
+    int batch1;
+    long sA2, sB2, sC2, sD2, sColscale2, sRowscale2, sDyn2;
 };
 
 // One operand tile: BO "outer" rows/cols (M or N side) x BK, staged by NT threads.  KMAJOR: global storage is [K][O].
@@ -182,14 +185,20 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f64_kernel(GemmK g) {
         tile_n = n_first + rem - tile_m * ng;
     }
     const int m0 = tile_m * BM, n0 = tile_n * BN;
+    // two batch levels: z1 the inner entry (stride s?), z2 the outer one (stride s?2; replicas of a hyper-parameter batch)
+    long z1 = bz, z2 = 0;
+    if (g.batch1 > 0) {                 // wave-uniform; only launches with an outer level pay the division
+        z2 = bz / g.batch1;
+        z1 = bz - z2 * g.batch1;
+    }
     if (g.dyn) {                        // wave-uniform: sizes decided on the device (deflation count)
-        const int kk = g.dyn[bz];
+        const int kk = g.dyn[z2 * g.sDyn2 + z1];
         g.N = kk;
         g.K = kk;
         if (n0 >= kk) return;
     }
-    const double *__restrict__ A = g.A + bz * g.sA;
-    const double *__restrict__ B = g.B + bz * g.sB;
+    const double *__restrict__ A = g.A + z1 * g.sA + z2 * g.sA2;
+    const double *__restrict__ B = g.B + z1 * g.sB + z2 * g.sB2;
 
     d4 acc[FM][FN];
 #pragma unroll
@@ -325,10 +334,13 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f64_kernel(GemmK g) {
 
     // ---- epilogue ----
     double qsum = 0.0, qsum2 = 0.0;
-    double *__restrict__ C = (EPI == EPI_QUAD) ? nullptr : g.C + bz * g.sC;
-    const double *__restrict__ Dz = g.D + bz * g.sD;
-    double *__restrict__ C2 = (EPI == EPI_GRAD) ? g.C2 + bz * g.sC : nullptr;
-    double *__restrict__ C3 = (EPI == EPI_GRAD) ? g.C3 + bz * g.sC : nullptr;
+    const long offC = z1 * g.sC + z2 * g.sC2;
+    double *__restrict__ C = (EPI == EPI_QUAD) ? nullptr : g.C + offC;
+    const double *__restrict__ Dz = g.D + z1 * g.sD + z2 * g.sD2;
+    double *__restrict__ C2 = (EPI == EPI_GRAD) ? g.C2 + offC : nullptr;
+    double *__restrict__ C3 = (EPI == EPI_GRAD) ? g.C3 + offC : nullptr;
+    const double *__restrict__ colscale = g.colscale ? g.colscale + z1 * g.sColscale + z2 * g.sColscale2 : nullptr;
+    const double *__restrict__ rowscale = (EPI == EPI_GRAD) ? g.rowscale + z2 * g.sRowscale2 : nullptr;
     if (EPI == EPI_STORE) {
         // The plain store is the hot epilogue: every VALU instruction here is taken from the MFMAs of the workgroups that
         // share the SIMD, so the per-column factor (alpha, optional column scale) and the validity of the FN columns are
@@ -340,7 +352,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f64_kernel(GemmK g) {
         for (int j = 0; j < FN; ++j) {
             cok[j] = colb + 16 * j < g.N;
             asc[j] = g.alpha;
-            if (g.colscale) asc[j] *= g.colscale[bz * g.sColscale + (cok[j] ? colb + 16 * j : 0)];       // wave-uniform test
+            if (colscale) asc[j] *= colscale[cok[j] ? colb + 16 * j : 0];       // wave-uniform test
         }
         const int rowb = m0 + wr * 16 * FM + fq;
         double *pr = C + (long)rowb * g.ldc + colb;
@@ -367,7 +379,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f64_kernel(GemmK g) {
             if (row >= g.M) continue;
             long drow = 0;
             if (EPI == EPI_DIV_D || EPI == EPI_QUAD || EPI == EPI_GRAD) drow = (long)(row / g.rdiv) * g.ldd;
-            const double rsc = (EPI == EPI_GRAD) ? g.rowscale[row / g.rdiv] : 0.0;
+            const double rsc = (EPI == EPI_GRAD) ? rowscale[row / g.rdiv] : 0.0;
 #pragma unroll
             for (int j = 0; j < FN; ++j) {
                 const int col = n0 + wc * 16 * FN + j * 16 + fr;
@@ -381,7 +393,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f64_kernel(GemmK g) {
                     // b = alpha / D; also b * et[col], b * es[row / rdiv]; partial sums of alpha*b and b*b
                     const double bq = v * Dz[drow + col];
                     C[(long)row * g.ldc + col] = bq;
-                    C2[(long)row * g.ldc + col] = bq * g.colscale[col];
+                    C2[(long)row * g.ldc + col] = bq * colscale[col];
                     C3[(long)row * g.ldc + col] = bq * rsc;
                     qsum += v * bq;
                     qsum2 += bq * bq;
@@ -421,13 +433,18 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f64_kernel(GemmK g) {
 // Deterministic final reduction of per-block partials (single workgroup, fixed tree).
 // A second workgroup may carry an unrelated reduction of the same shape (p2, n2 -> out2: the sum of log D partials of the
 // likelihood, which would otherwise be a launch of its own in the dependent tail of the call).
+// blockIdx.y = segment of an outer batch level: partials [y * n, (y + 1) * n) -> out[y * ostride].
 __global__ __launch_bounds__(256) void reduce_partials_kernel(const double *__restrict__ p, long n, double *out,
                                                               const double *__restrict__ p2 = nullptr, long n2 = 0,
-                                                              double *out2 = nullptr) {
+                                                              double *out2 = nullptr, long ostride = 0) {
     if (blockIdx.x == 1) {
+        if (blockIdx.y != 0) return;
         p = p2;
         n = n2;
         out = out2;
+    } else {
+        p += blockIdx.y * n;
+        out += blockIdx.y * ostride;
     }
     __shared__ double sh[256];
     double s = 0.0;
@@ -480,6 +497,10 @@ void gemm_f64(gpcsd_ctx *c, const GemmDesc &g, hipStream_t s) {
     k.alpha = g.alpha; k.D = g.D; k.rdiv = g.rdiv > 0 ? g.rdiv : 1; k.ldd = g.ldd; k.sD = g.sD;
     k.partials = nullptr;
     k.dyn = g.dyn;
+    const int batch2 = g.batch2 > 1 ? g.batch2 : 1;
+    k.batch1 = batch2 > 1 ? g.batch : 0;
+    k.sA2 = g.sA2; k.sB2 = g.sB2; k.sC2 = g.sC2; k.sD2 = g.sD2; k.sColscale2 = g.sColscale2; k.sRowscale2 = g.sRowscale2;
+    k.sDyn2 = g.sDyn2;
 
     // Tile configurations (block tile, waves, K depth).  Large flat GEMMs want many resident workgroups per CU so the
     // hardware dispatcher balances the tail; tiny GEMMs are latency-bound and want deep K tiles.
@@ -488,7 +509,7 @@ void gemm_f64(gpcsd_ctx *c, const GemmDesc &g, hipStream_t s) {
     static const int CFG_BM[6] = {0, 128, 64, 64, 0, 32}, CFG_BN[6] = {0, 128, 64, 64, 0, 32};
     int cfg = g.cfg;
     if (cfg != 1 && cfg != 2 && cfg != 3 && cfg != 5) {
-        auto tiles = [&](int bm, int bn) { return (long)ceil_div(g.M, bm) * ceil_div(g.N, bn) * g.batch; };
+        auto tiles = [&](int bm, int bn) { return (long)ceil_div(g.M, bm) * ceil_div(g.N, bn) * g.batch * batch2; };
         // measured on MI355X (tools/gemm_sweep.py): 64x64 tiles reach the same ~40 TF/s as 128x128 on the large
         // flat GEMMs and balance the tail better; everything smaller is latency-bound and wants 32x32 / BK64
         // short K (the folded GEMMs: 192 / 250): the same tile with BK 8 -- half the pipeline fill per tile and half the LDS,
@@ -504,14 +525,14 @@ void gemm_f64(gpcsd_ctx *c, const GemmDesc &g, hipStream_t s) {
     {
         const long bytes_per_ntile = (long)g.K * bn * 8;                      // one column panel of B
         long ngp = bytes_per_ntile > 0 ? (2L << 20) / bytes_per_ntile : tn;  // ~2 MB of B per sweep
-        if (g.sB != 0 && g.batch > 1) ngp = tn;                               // B differs per batch entry: nothing to keep
+        if ((g.sB != 0 && g.batch > 1) || (g.sB2 != 0 && batch2 > 1)) ngp = tn;   // B differs per batch entry: nothing to keep
         k.n_group = (int)std::max(1L, std::min<long>(tn, ngp));
     }
-    dim3 grid(tm * tn, 1, g.batch);
-    const long nblocks = (long)tm * tn * g.batch;
+    dim3 grid(tm * tn, 1, g.batch * batch2);
+    const long nblocks = (long)tm * tn * g.batch * batch2;
     if (g.epi == EPI_QUAD || g.epi == EPI_GRAD) k.partials = c->buf<double>("gemm_partials", 2 * nblocks);
 
-    const double flops = 2.0 * g.M * (double)g.N * g.K * g.batch;
+    const double flops = 2.0 * g.M * (double)g.N * g.K * g.batch * batch2;
     {
         ProfScope ps(c, g.prof_name, flops, s);
         switch (cfg) {
@@ -523,11 +544,13 @@ void gemm_f64(gpcsd_ctx *c, const GemmDesc &g, hipStream_t s) {
         GP_HIP(hipGetLastError());
     }
     if (g.epi == EPI_QUAD || g.epi == EPI_GRAD) {
-        hipLaunchKernelGGL(reduce_partials_kernel, dim3(g.extra_sum_out ? 2 : 1), dim3(256), 0, s, (const double *)k.partials,
-                           nblocks, g.quad_out, g.extra_sum_in, (long)g.extra_sum_n, g.extra_sum_out);
+        // one sum per outer batch entry: the partials of entry z2 are contiguous (grid z = z2 * batch + z1)
+        const long per = nblocks / batch2;
+        hipLaunchKernelGGL(reduce_partials_kernel, dim3(g.extra_sum_out ? 2 : 1, batch2), dim3(256), 0, s, (const double *)k.partials,
+                           per, g.quad_out, g.extra_sum_in, (long)g.extra_sum_n, g.extra_sum_out, g.sQuad2);
         if (g.epi == EPI_GRAD)
-            hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(256), 0, s, (const double *)(k.partials + nblocks), nblocks,
-                               g.quad_out + 1, (const double *)nullptr, 0L, (double *)nullptr);
+            hipLaunchKernelGGL(reduce_partials_kernel, dim3(1, batch2), dim3(256), 0, s, (const double *)(k.partials + nblocks), per,
+                               g.quad_out + 1, (const double *)nullptr, 0L, (double *)nullptr, g.sQuad2);
         GP_HIP(hipGetLastError());
     }
 }

@@ -30,6 +30,11 @@ struct GemmDesc {
     long sColscale = 0;                                      // batch stride of colscale (EPI_STORE)
     int batch = 1;
     long sA = 0, sB = 0, sC = 0;
+    // second (outer) batch level: entry z = z2 * batch + z1 adds z2 * s?2 to the operand bases.  Used to run the same
+    // product for several hyper-parameter sets (replicas) whose buffers sit a fixed stride apart.
+    int batch2 = 1;
+    long sA2 = 0, sB2 = 0, sC2 = 0, sD2 = 0, sColscale2 = 0, sRowscale2 = 0, sDyn2 = 0;
+    long sQuad2 = 0;              // EPI_QUAD / EPI_GRAD: quad_out of outer entry z2 is quad_out + z2 * sQuad2
     double alpha = 1.0;
     int epi = EPI_STORE;
     const double *D = nullptr;
@@ -95,24 +100,40 @@ void k_unfold_swap_sum(gpcsd_ctx *c, const double *in, int C, double *list, long
 void eigh_device(gpcsd_ctx *c, double *A, int n, double *evals, double *evecs, int *d_status, hipStream_t s,
                  const char *tag);
 constexpr int MAX_EIG_BATCH = 4;
+// One CLASS of eigenproblems: `count` replicas of the same order n whose inputs / outputs sit a fixed stride apart
+// (replica r reads A + r*sA, writes w + r*sw and Z + r*sZ).  The launches of a chain are shared by up to MAX_EIG_BATCH
+// classes (the symmetric / antisymmetric halves of Ks and Kt) times any number of replicas (hyper-parameter sets of a
+// batched evaluation): kernel arguments describe the classes by value, a workgroup derives its replica's pointers by
+// adding replica * stride -- no per-problem table in the arguments or in memory.
 struct EigReq {
     double *A;
     int n;
     double *w, *Z;
     const char *tag;
+    int count = 1;
+    long sA = 0, sw = 0, sZ = 0;
 };
+// flat problem index g -> (class, replica) from the prefix sums start[0..MAX_EIG_BATCH] (unused classes repeat the total)
+__device__ __forceinline__ void class_of(const int *start, int g, int &cls, int &rep) {
+    cls = (g >= start[1]) + (g >= start[2]) + (g >= start[3]);
+    rep = g - start[cls];
+}
 // Two independent problems at once (Ks and Kt of one likelihood evaluation): every stage is batched so they share
 // launches; with a known symmetry each splits into two half-size problems first.  Either n may be <= 0 to skip.
 // need_merged = false: a caller that stays in the folded basis (eigh_fold_view) skips the unfold + rank merge of folded problems
+// count > 1: `count` replicas of both problems (inputs n*n apart, eigenvalues n apart, eigenvectors n*n apart); replica r
+// reports numerical failure in d_status[r * status_stride] (status_stride 0: one shared word)
 void eigh_pair_device(gpcsd_ctx *c, double *A0, int n0, double *w0, double *Z0, const SymDev *sym0, double *A1, int n1,
-                      double *w1, double *Z1, const SymDev *sym1, int *d_status, hipStream_t s, bool need_merged = true);
+                      double *w1, double *Z1, const SymDev *sym1, int *d_status, hipStream_t s, bool need_merged = true,
+                      int count = 1, int status_stride = 0);
 // Half-size results of a symmetry-folded problem, in fold order (see eigh.hip); on == false: the problem is not folded.
 struct FoldView {
     bool on = false;
     int ns = 0, na = 0;
     double *w = nullptr, *U = nullptr;      // w = (ws | wa);  U = (Us, ns x ns | Ua, na x na), eigenvectors in columns
+    long sw = 0, sU = 0;                    // replica strides of w (= n) and U (= ns^2 + na^2)
 };
-FoldView eigh_fold_view(gpcsd_ctx *c, int slot, const SymDev *sy, int n);
+FoldView eigh_fold_view(gpcsd_ctx *c, int slot, const SymDev *sy, int n, int count = 1);
 // fused compact-WY back-transformation (wy.hip): all panels of all problems in two launches
 struct WyProb {
     const double *V, *tau;   // reflectors by rows ((n + 64) x n, zero padded), tau (n + 64)
@@ -120,13 +141,26 @@ struct WyProb {
     int n, npanels, nrefl;
     double *w_scale = nullptr;       // optional: eigenvalues of the SCALED matrix, multiplied by *amax in the apply launch
     const double *amax = nullptr;    // (saves the separate rescale launch at the end of the dependent chain)
+    long blk = 0, sZ = 0, sw = 0;    // replica strides: V / tau / T / amax live in the class arena (blk), Z and w_scale are the caller's
 };
 struct WyBatch {
-    WyProb p[MAX_EIG_BATCH];
+    WyProb p[MAX_EIG_BATCH];         // one entry per class
+    int start[MAX_EIG_BATCH + 1];    // prefix sums of the replica counts (see class_of)
 };
+__device__ __forceinline__ WyProb wy_resolve(const WyBatch &b, int g) {
+    int cls, rep;
+    class_of(b.start, g, cls, rep);
+    WyProb P = b.p[cls];
+    const long o = rep * P.blk;
+    P.V += o; P.tau += o; P.T += o;
+    if (P.amax) P.amax += o;
+    P.Z += rep * P.sZ;
+    if (P.w_scale) P.w_scale += rep * P.sw;
+    return P;
+}
 bool wy_fused_supported(int nmax);
 // prep_done: the T factors were already formed by the D&C leaf launch (stedc_batch_device with a WyBatch)
-void wy_batch_device(gpcsd_ctx *c, const WyBatch &b, int count, hipStream_t s, bool prep_done = false);
+void wy_batch_device(gpcsd_ctx *c, const WyBatch &b, int nclass, hipStream_t s, bool prep_done = false);
 // stages of the large-n solver, exposed for tests / diagnostics
 void sytrd_device(gpcsd_ctx *c, double *A, int n, double *d, double *e, double *V, double *tau, hipStream_t s);
 void stedc_device(gpcsd_ctx *c, const double *d, const double *e, int n, double *w, double *Z, int *d_status,

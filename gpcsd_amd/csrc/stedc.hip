@@ -46,14 +46,37 @@ struct DcWork {            // per problem, all device pointers
     int *Kdyn;             // K per merge of the current level (device ints for the dynamic-size GEMM)
     const int *tbl;        // leaf_lo | bounds | per-level Seg triples
     double *wout, *Zout;   // caller's outputs
+    // replicas of the class (see EigReq): workspace pointers are those of replica 0 in an arena of `blk` doubles per
+    // replica; the input tridiagonal lives in the tridiagonalisation's arena (s_in), the outputs are the caller's (sw, sZ)
+    long blk, s_in, sw, sZ;
+    int top;               // this level is the top merge: it places its result in wout / Zout instead of dnext / Qnext
 };
 
-struct DcLevel {           // kernel argument of one level
+struct DcLevel {           // kernel argument of one level: one DcWork per CLASS
     DcWork w[MAX_BATCH];
     int seg_off[MAX_BATCH];   // offset of this level's Seg triples inside tbl
     int nseg[MAX_BATCH];      // 0: problem absent at this level
     int aux[MAX_BATCH];       // leaves: number of leaves; tears: number of boundaries (offset in seg_off)
+    int start[MAX_BATCH + 1]; // prefix sums of the replica counts (class_of)
+    int status_stride;        // replica r reports failure in status[r * status_stride]
 };
+
+// workgroup's problem index g -> its class and replica, and the class's DcWork with every pointer moved to the replica
+__device__ __forceinline__ DcWork dc_resolve(const DcLevel &L, int g, int &cls, int &rep) {
+    class_of(L.start, g, cls, rep);
+    DcWork w = L.w[cls];
+    const long o = rep * w.blk, oi = 2 * o;           // int slices live in the same arena: 2 ints per double
+    w.dcur += o; w.dnext += o; w.Qcur += o; w.Qnext += o; w.dwork += o; w.dk += o; w.zk += o;
+    w.mu += o; w.lam += o; w.zhat += o; w.invn += o; w.rotc += o; w.rots += o; w.Q2w += o; w.Uw += o; w.Ww += o;
+    w.org += oi; w.ndidx += oi; w.deflidx += oi; w.rota += oi; w.rotb += oi; w.meta += oi; w.Kdyn += oi;
+    w.d0 += rep * w.s_in; w.e += rep * w.s_in;
+    w.wout += rep * w.sw; w.Zout += rep * w.sZ;
+    if (w.top) {
+        w.dnext = w.wout;
+        w.Qnext = w.Zout;
+    }
+    return w;
+}
 
 __device__ __forceinline__ Seg load_seg(const DcWork &w, int off, int m) {
     const int *p = w.tbl + off + 3 * m;
@@ -65,7 +88,8 @@ __device__ __forceinline__ Seg load_seg(const DcWork &w, int off, int m) {
 // ------------------------------------------------------------------------------------------------------------------
 // eigenvalues / eigenvectors of the top level into the caller's arrays, all problems in one launch
 __global__ __launch_bounds__(256) void dc_output_kernel(DcLevel L) {
-    const DcWork &w = L.w[blockIdx.y];
+    int cls, rep;
+    const DcWork w = dc_resolve(L, blockIdx.y, cls, rep);
     const long n = w.n, nn = n * n;
     const long stride = (long)gridDim.x * 256, i0 = blockIdx.x * 256L + threadIdx.x;
     for (long i = i0; i < nn; i += stride) w.Zout[i] = w.Qcur[i];
@@ -92,8 +116,10 @@ __device__ __forceinline__ int rr_partner8(int x, int step7) {        // partner
 // body runs as a 64-thread workgroup (dc_leaf_reg_kernel) or as one wave of a larger one (dc_leaf_wyprep_kernel).
 __device__ __forceinline__ void dc_leaf_reg_body(const DcLevel &L, int *status, const int nleaf_max, const int bx, const int by,
                                                  const int lane) {
-    const DcWork &w = L.w[by];
-    const int n = w.n, nleaf = L.aux[by];
+    int cls, rep;
+    const DcWork w = dc_resolve(L, by, cls, rep);
+    status += (long)rep * L.status_stride;
+    const int n = w.n, nleaf = L.aux[cls];
     if (bx >= nleaf_max) {
         const int r = bx - nleaf_max;
         if (r >= n) return;
@@ -202,7 +228,7 @@ __global__ __launch_bounds__(64) void dc_leaf_reg_kernel(DcLevel L, int *status,
 __global__ __launch_bounds__(1024) void dc_leaf_wyprep_kernel(DcLevel L, int *status, int nleaf_max, int nunits, WyBatch wb,
                                                               int nprep) {
     if ((int)blockIdx.x < nprep) {
-        wy_prep_body(wb.p[blockIdx.y], (int)blockIdx.x, (int)threadIdx.x);
+        wy_prep_body(wy_resolve(wb, blockIdx.y), (int)blockIdx.x, (int)threadIdx.x);
         return;
     }
     const int bx = ((int)blockIdx.x - nprep) * 16 + ((int)threadIdx.x >> 6);
@@ -638,10 +664,11 @@ __device__ void dc_place_body(const DcWork &w, const Seg sg, const int r0, const
 // per-phase kernels for the large levels (grid: x = work tiles, y = merge, z = problem)
 // ------------------------------------------------------------------------------------------------------------------
 #define DC_PROLOGUE                                                \
-    const DcWork &w = L.w[blockIdx.z];                             \
+    int cls, rep;                                                  \
+    const DcWork w = dc_resolve(L, blockIdx.z, cls, rep);          \
     const int m = blockIdx.y;                                      \
-    if (m >= L.nseg[blockIdx.z]) return;                           \
-    const Seg sg = load_seg(w, L.seg_off[blockIdx.z], m);
+    if (m >= L.nseg[cls]) return;                                  \
+    const Seg sg = load_seg(w, L.seg_off[cls], m);
 
 __global__ __launch_bounds__(256) void dc_setup_kernel(DcLevel L) {
     DC_PROLOGUE
@@ -947,10 +974,11 @@ __device__ void dc_small_tail(const DcWork &w, const Seg sg, SetupShared &S, Sma
 }
 
 __global__ __launch_bounds__(NT_SMALL) void dc_small_level_kernel(DcLevel L) {
-    const DcWork &w = L.w[blockIdx.z];
+    int cls, rep;
+    const DcWork w = dc_resolve(L, blockIdx.z, cls, rep);
     const int m = blockIdx.x;
-    if (m >= L.nseg[blockIdx.z]) return;
-    const Seg sg = load_seg(w, L.seg_off[blockIdx.z], m);
+    if (m >= L.nseg[cls]) return;
+    const Seg sg = load_seg(w, L.seg_off[cls], m);
     constexpr int NW = NT_SMALL / 64;
     __shared__ SetupShared S;
     __shared__ SmallShared Q;
@@ -1026,47 +1054,54 @@ static DcPlan make_plan(int n) {
     return p;
 }
 
-struct StedcProb {
+struct StedcProb {               // one class of tridiagonal problems (replicas: d / e s_in apart, outputs sw / sZ apart)
     const double *d, *e;
     int n;
     double *w, *Z;
     std::string tag;
+    int count = 1;
+    long s_in = 0, sw = 0, sZ = 0;
 };
 
+// Workspace of a class as ONE arena of `count` identical blocks (dc_resolve adds replica * blk to every pointer); the int
+// slices are carved out of the same arena (two ints per double, 16-byte aligned slices).
 static DcWork make_work(gpcsd_ctx *c, const StedcProb &p, const DcPlan &plan, hipStream_t s) {
     const int n = p.n;
     const size_t nn = (size_t)n * n;
     const std::string T = "dc_" + p.tag + "_";
+    size_t off = 0;
+    auto take = [&](size_t ndoubles) {
+        const size_t o = off;
+        off += (ndoubles + 1) & ~(size_t)1;
+        return o;
+    };
+    auto take_int = [&](size_t nints) { return take((nints + 1) / 2); };
+    const size_t o_dcur = take(n), o_dnext = take(n), o_Qcur = take(nn), o_Qnext = take(nn), o_dwork = take(n), o_dk = take(n),
+                 o_zk = take(n), o_mu = take(n), o_lam = take(n), o_zhat = take(n), o_invn = take(n), o_rotc = take(n),
+                 o_rots = take(n), o_Q2w = take(nn), o_Uw = take(nn), o_Ww = take(nn);
+    const size_t o_org = take_int(n), o_ndidx = take_int(n), o_deflidx = take_int(n), o_rota = take_int(n), o_rotb = take_int(n),
+                 o_meta = take_int(2 * n + 2), o_Kdyn = take_int(n + 2);
+    double *base = c->buf<double>(T + "arena", off * (size_t)std::max(p.count, 1));
     DcWork w;
     w.n = n;
     w.d0 = p.d;
     w.e = p.e;
-    w.dcur = c->buf<double>(T + "dcur", n);
-    w.dnext = c->buf<double>(T + "dnext", n);
-    w.Qcur = c->buf<double>(T + "Qcur", nn);
-    w.Qnext = c->buf<double>(T + "Qnext", nn);
-    w.dwork = c->buf<double>(T + "dwork", n);
-    w.dk = c->buf<double>(T + "dk", n);
-    w.zk = c->buf<double>(T + "zk", n);
-    w.mu = c->buf<double>(T + "mu", n);
-    w.lam = c->buf<double>(T + "lam", n);
-    w.zhat = c->buf<double>(T + "zhat", n);
-    w.invn = c->buf<double>(T + "invn", n);
-    w.org = c->buf<int>(T + "org", n);
-    w.ndidx = c->buf<int>(T + "ndidx", n);
-    w.deflidx = c->buf<int>(T + "deflidx", n);
-    w.rota = c->buf<int>(T + "rota", n);
-    w.rotb = c->buf<int>(T + "rotb", n);
-    w.rotc = c->buf<double>(T + "rotc", n);
-    w.rots = c->buf<double>(T + "rots", n);
-    w.meta = c->buf<int>(T + "meta", 2 * n + 2);
-    w.Kdyn = c->buf<int>(T + "Kdyn", n + 2);
-    w.Q2w = c->buf<double>(T + "Q2w", nn);
-    w.Uw = c->buf<double>(T + "Uw", nn);
-    w.Ww = c->buf<double>(T + "Ww", nn);
-    int *dtbl = c->buf<int>(T + "plan", plan.tbl.size() + 4);
-    int &cached_n = c->int_cache[T + "plan_n"];
-    if (cached_n != n) {                  // the table depends only on n: upload once per (tag, n)
+    w.dcur = base + o_dcur; w.dnext = base + o_dnext; w.Qcur = base + o_Qcur; w.Qnext = base + o_Qnext;
+    w.dwork = base + o_dwork; w.dk = base + o_dk; w.zk = base + o_zk; w.mu = base + o_mu; w.lam = base + o_lam;
+    w.zhat = base + o_zhat; w.invn = base + o_invn; w.rotc = base + o_rotc; w.rots = base + o_rots;
+    w.Q2w = base + o_Q2w; w.Uw = base + o_Uw; w.Ww = base + o_Ww;
+    auto ip = [&](size_t o) { return reinterpret_cast<int *>(base + o); };
+    w.org = ip(o_org); w.ndidx = ip(o_ndidx); w.deflidx = ip(o_deflidx); w.rota = ip(o_rota); w.rotb = ip(o_rotb);
+    w.meta = ip(o_meta); w.Kdyn = ip(o_Kdyn);
+    w.blk = (long)off;
+    w.s_in = p.s_in; w.sw = p.sw; w.sZ = p.sZ;
+    w.top = 0;
+    // the table depends only on n: its own buffer per (tag, n), uploaded once.  (One buffer per tag that was re-uploaded when
+    // n changed put a synchronising copy inside a later stream capture of a chain whose eager run had seen the other n.)
+    const std::string PN = T + "plan_" + std::to_string(n);
+    int *dtbl = c->buf<int>(PN, plan.tbl.size() + 4);
+    int &cached_n = c->int_cache[PN];
+    if (cached_n != n) {
         GP_HIP(hipMemcpyAsync(dtbl, plan.tbl.data(), plan.tbl.size() * sizeof(int), hipMemcpyHostToDevice, s));
         GP_HIP(hipStreamSynchronize(s));  // plan is a temporary of the caller
         cached_n = n;
@@ -1077,26 +1112,32 @@ static DcWork make_work(gpcsd_ctx *c, const StedcProb &p, const DcPlan &plan, hi
     return w;
 }
 
-void stedc_batch_device(gpcsd_ctx *c, StedcProb *probs, int count, int *d_status, hipStream_t s, const WyBatch *wy) {
-    GP_REQUIRE(count >= 1 && count <= MAX_BATCH, -3, "stedc batch size %d outside [1,%d]", count, MAX_BATCH);
+void stedc_batch_device(gpcsd_ctx *c, StedcProb *probs, int nclass, int *d_status, int status_stride, hipStream_t s,
+                        const WyBatch *wy) {
+    GP_REQUIRE(nclass >= 1 && nclass <= MAX_BATCH, -3, "stedc: %d problem classes outside [1,%d]", nclass, MAX_BATCH);
     std::vector<DcPlan> plans;
     DcLevel L{};
+    L.status_stride = status_stride;
     size_t nlevels = 0;
-    int nmax = 0, max_leaves = 0;
-    for (int p = 0; p < count; ++p) {
+    int nmax = 0, max_leaves = 0, count = 0;
+    for (int p = 0; p < MAX_BATCH; ++p) {
+        L.start[p] = count;
+        if (p >= nclass) continue;
         GP_REQUIRE(probs[p].n >= 1 && probs[p].n <= EIG_MAXN, -3, "stedc: n=%d outside [1,%d]", probs[p].n, EIG_MAXN);
         plans.push_back(make_plan(probs[p].n));
         L.w[p] = make_work(c, probs[p], plans[p], s);
         nlevels = std::max(nlevels, plans[p].levels.size());
         nmax = std::max(nmax, probs[p].n);
         max_leaves = std::max(max_leaves, (int)plans[p].leaf_lo.size() - 1);
+        count += std::max(probs[p].count, 1);
     }
+    L.start[MAX_BATCH] = count;                 // workgroup rows / planes of every launch: all replicas of all classes
     // tears + leaves (one launch: dc_leaf_reg_body applies the tears and zero-fills the off-diagonal blocks)
     static_assert(DC_LEAF == 8, "the register leaf solver maps an 8 x 8 block onto one wave");
-    for (int p = 0; p < count; ++p) L.aux[p] = (int)plans[p].leaf_lo.size() - 1;
+    for (int p = 0; p < nclass; ++p) L.aux[p] = (int)plans[p].leaf_lo.size() - 1;
     if (wy) {                                  // the T factors of the back-transformation ride in the leaf launch
         int nprep = 0;
-        for (int p = 0; p < count; ++p) nprep = std::max(nprep, wy->p[p].npanels);
+        for (int p = 0; p < nclass; ++p) nprep = std::max(nprep, wy->p[p].npanels);
         const int nunits = max_leaves + nmax;
         hipLaunchKernelGGL(dc_leaf_wyprep_kernel, dim3(nprep + ceil_div(nunits, 16), count), dim3(1024), 0, s, L, d_status,
                            max_leaves, nunits, *wy, nprep);
@@ -1108,7 +1149,7 @@ void stedc_batch_device(gpcsd_ctx *c, StedcProb *probs, int count, int *d_status
     // Problems with fewer levels idle at the bottom: level index counts from the TOP so the final merges align.
     for (size_t li = 0; li < nlevels; ++li) {
         int maxN = 0, max_seg = 0;
-        for (int p = 0; p < count; ++p) {
+        for (int p = 0; p < nclass; ++p) {
             const long own = (long)plans[p].levels.size() - (long)(nlevels - li);   // this problem's level index, or < 0
             if (own < 0) {
                 L.nseg[p] = 0;
@@ -1121,13 +1162,9 @@ void stedc_batch_device(gpcsd_ctx *c, StedcProb *probs, int count, int *d_status
             max_seg = std::max(max_seg, (int)lv.size());
             for (auto &sg : lv) maxN = std::max(maxN, sg.hi - sg.lo);
         }
-        if (li + 1 == nlevels) {               // the top merge covers the whole matrix: place it in the caller's arrays
-            for (int p = 0; p < count; ++p)
-                if (L.nseg[p] > 0) {
-                    L.w[p].Qnext = L.w[p].Zout;
-                    L.w[p].dnext = L.w[p].wout;
-                }
-        }
+        if (li + 1 == nlevels)                 // the top merge covers the whole matrix: placed in the caller's arrays (dc_resolve)
+            for (int p = 0; p < nclass; ++p)
+                if (L.nseg[p] > 0) L.w[p].top = 1;
         if (maxN <= DC_SMALL) {
             hipLaunchKernelGGL(dc_small_level_kernel, dim3(max_seg, 1, count), dim3(NT_SMALL), 0, s, L);
         } else {
@@ -1138,9 +1175,10 @@ void stedc_batch_device(gpcsd_ctx *c, StedcProb *probs, int count, int *d_status
             hipLaunchKernelGGL(dc_colnorm_U_kernel, dim3(root_blocks + tj * ceil_div(maxN, 16), max_seg, count), dim3(256), 0, s, L,
                                root_blocks, tj);
             GP_HIP(hipGetLastError());
-            // W = Q2 (N x K) U (K x K) diag(invn), K read on the device.  The merges of one problem are one batched
-            // launch when they have the same size (their blocks sit a constant stride apart on the diagonal).
-            for (int p = 0; p < count; ++p) {
+            // W = Q2 (N x K) U (K x K) diag(invn), K read on the device.  The merges of one class are one batched launch
+            // when they have the same size (their blocks sit a constant stride apart on the diagonal); the replicas of the
+            // class are the outer batch level (arena stride).
+            for (int p = 0; p < nclass; ++p) {
                 const long own = (long)plans[p].levels.size() - (long)(nlevels - li);
                 if (own < 0) continue;
                 const auto &lv = plans[p].levels[own];
@@ -1166,6 +1204,9 @@ void stedc_batch_device(gpcsd_ctx *c, StedcProb *probs, int count, int *d_status
                         g.sA = g.sB = g.sC = step * n + step;
                         g.sColscale = step;
                     }
+                    g.batch2 = L.start[p + 1] - L.start[p];
+                    g.sA2 = g.sB2 = g.sC2 = g.sColscale2 = w.blk;
+                    g.sDyn2 = 2 * w.blk;
                     g.prof_name = "gemm_dc_merge";
                     gemm_f64(c, g, s);
                 }
@@ -1173,14 +1214,14 @@ void stedc_batch_device(gpcsd_ctx *c, StedcProb *probs, int count, int *d_status
             hipLaunchKernelGGL(dc_place_kernel, dim3(ceil_div(maxN, 4), max_seg, count), dim3(256), 0, s, L);
         }
         GP_HIP(hipGetLastError());
-        for (int p = 0; p < count; ++p) {
+        for (int p = 0; p < nclass; ++p) {
             if (L.nseg[p] == 0) continue;
             std::swap(L.w[p].dcur, L.w[p].dnext);
             std::swap(L.w[p].Qcur, L.w[p].Qnext);
         }
     }
     bool need_copy = false;                    // only a problem without any merge level (n <= DC_LEAF) still needs the copy
-    for (int p = 0; p < count; ++p) need_copy = need_copy || plans[p].levels.empty();
+    for (int p = 0; p < nclass; ++p) need_copy = need_copy || plans[p].levels.empty();
     if (need_copy) hipLaunchKernelGGL(dc_output_kernel, dim3(64, count), dim3(256), 0, s, L);
     GP_HIP(hipGetLastError());
 }
@@ -1189,7 +1230,7 @@ void stedc_device(gpcsd_ctx *c, const double *d, const double *e, int n, double 
                   hipStream_t s, const char *tag) {
     StedcProb p;
     p.d = d; p.e = e; p.n = n; p.w = wout; p.Z = Zout; p.tag = tag ? tag : "";
-    stedc_batch_device(c, &p, 1, d_status, s, nullptr);
+    stedc_batch_device(c, &p, 1, d_status, 0, s, nullptr);
 }
 
 }  // namespace gpcsd

@@ -76,7 +76,7 @@ __device__ __forceinline__ void rt_house(double alpha, double xnorm2, bool ok, d
 }
 
 __global__ __launch_bounds__(RT_NTH) void sytrd_rtail_kernel(SytrdBatch b) {
-    const SytrdProb &P = b.p[blockIdx.x];
+    const SytrdProb P = sy_resolve(b, blockIdx.x);
     const int n = P.n, k0 = P.k_tail;
     if (k0 >= n - 1) return;
     const int T = n - k0;                          // rows / columns k0 .. n-1, T <= RT_TMAX

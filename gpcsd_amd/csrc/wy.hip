@@ -20,11 +20,11 @@ constexpr int WY_ZC = 16;             // columns of Z per workgroup (one MFMA fr
 constexpr int WY_LD = WY_ZC + 2;      // LDS row stride: 18*i mod 32 gives distinct even slots for the b64 fragment reads
 
 // G = V_p V_p^T (16 waves, one 16x16 fragment each), then T by back substitution (4 columns per wave): wy_prep.hpp
-__global__ __launch_bounds__(1024) void wy_prep_kernel(WyBatch b) { wy_prep_body(b.p[blockIdx.y], blockIdx.x, threadIdx.x); }
+__global__ __launch_bounds__(1024) void wy_prep_kernel(WyBatch b) { wy_prep_body(wy_resolve(b, blockIdx.y), blockIdx.x, threadIdx.x); }
 
 // one workgroup = 16 columns of Z resident in LDS, all panels applied in sequence
 __global__ __launch_bounds__(256) void wy_apply_kernel(WyBatch b) {
-    const WyProb &P = b.p[blockIdx.y];
+    const WyProb P = wy_resolve(b, blockIdx.y);
     const int n = P.n;
     const int c0 = blockIdx.x * WY_ZC;
     if (c0 >= n) return;
@@ -138,13 +138,14 @@ __global__ __launch_bounds__(256) void wy_apply_kernel(WyBatch b) {
 
 bool wy_fused_supported(int nmax) { return ((size_t)nmax * WY_LD + 2 * WY_NB * WY_LD) * sizeof(double) <= 160 * 1024; }
 
-void wy_batch_device(gpcsd_ctx *c, const WyBatch &b, int count, hipStream_t s, bool prep_done) {
+void wy_batch_device(gpcsd_ctx *c, const WyBatch &b, int nclass, hipStream_t s, bool prep_done) {
     int maxP = 0, nmax = 0;
-    for (int i = 0; i < count; ++i) {
+    for (int i = 0; i < nclass; ++i) {
         maxP = std::max(maxP, b.p[i].npanels);
         nmax = std::max(nmax, b.p[i].n);
     }
     if (maxP == 0) return;
+    const int count = b.start[MAX_EIG_BATCH];          // all replicas of all classes
     const size_t sh = ((size_t)nmax * WY_LD + 2 * WY_NB * WY_LD) * sizeof(double);
     static bool attr_set = false;
     if (!attr_set) {

@@ -131,6 +131,9 @@ int gpcsd_kphig_2d(gpcsd_ctx *ctx, const double *xy, int nx,
                    const double *z, int nz, double R, double eps, double ell1, double ell2, double *out);
 /* numpy.linalg.eigh as used by comp_eig_D (utility_functions.py:58-59): ascending evals, evecs in columns */
 int gpcsd_eigh(gpcsd_ctx *ctx, const double *A, int n, double *evals, double *evecs);
+/* `count` matrices of the same order through one shared chain of launches (batched hyper-parameter evaluations decompose
+ * all their Gram matrices this way): A (count,n,n) -> evals (count,n), evecs (count,n,n); status[i] > 0: matrix i failed. */
+int gpcsd_eigh_batch(gpcsd_ctx *ctx, const double *A, int n, int count, double *evals, double *evecs, int *status);
 /* Diagnostics for the large-n eigensolver stages (no reference counterpart; LAPACK does these inside dsyevd):
  * Householder tridiagonalisation A = Q T Q^T: d (n), e (n, last unused), reflectors V (n,n) by rows, tau (n) */
 int gpcsd_debug_sytrd(gpcsd_ctx *ctx, const double *A, int n, double *d, double *e, double *V, double *tau);

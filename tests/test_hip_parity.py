@@ -792,3 +792,29 @@ def test_random_models_vs_oracle():
         assert e_ll < gates[0] and e_c < gates[1] and e_l < gates[2], (desc, e_ll, e_c, e_l, F.one_case.last_spread)
     if not (os.environ.get("GPCSD_NO_FOLD_GEMM") == "1" or os.environ.get("GPCSD_NO_SYMFOLD") == "1"):
         assert nfold > 5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,count", [(24, 5), (100, 3), (250, 8), (300, 2)])
+def test_eigh_batch_is_bitwise_the_sequential_solver(ctx, n, count):
+    """Replicated problems share every launch of the chain (kernel arguments describe classes, workgroups add
+    replica * stride): each replica must get exactly the bits a solve on its own produces."""
+    rs = np.random.RandomState(100 + n)
+    t = np.arange(n, dtype=np.float64)[:, None]
+    mats = []
+    for k in range(count):
+        G = np.exp(-0.5 * ((t - t.T) / (3.0 + k)) ** 2) + 0.3 * np.exp(-np.abs(t - t.T) / (2.0 + 0.5 * k))
+        B = rs.standard_normal((n, n))
+        mats.append(G + 1e-3 * (B + B.T))
+    A = np.stack(mats)
+    w, V, st = ctx.eigh_batch(A)
+    assert np.all(st == 0)
+    for k in range(count):
+        wk, Vk = ctx.eigh(A[k])
+        assert np.array_equal(w[k], wk) and np.array_equal(V[k], Vk)
+        assert np.abs(w[k] - np.linalg.eigvalsh(A[k])).max() < 1e-12 * n * np.abs(wk).max()
+    # a non-finite matrix fails alone
+    A[1, 3, 4] = A[1, 4, 3] = np.nan
+    w2, V2, st2 = ctx.eigh_batch(A)
+    assert st2[1] != 0 and np.all(np.delete(st2, 1) == 0)
+    assert np.array_equal(w2[0], w[0]) and np.array_equal(V2[count - 1], V[count - 1])
