@@ -318,8 +318,7 @@ def main():
 
     w = workload(args.workload)
     if args.workload == "cfg5":
-        from tools.fit_bench import run_fit_bench
-        out = run_fit_bench(args, w, rank, world, local_rank, backend, build_model, synth_data)
+        out = run_fit_bench(args, w, rank, world, local_rank, backend)
     else:
         out = run_step_bench(args, w, rank, world, local_rank, backend)
     if rank == 0 and out is not None:
@@ -505,6 +504,118 @@ def run_step_bench(args, w, rank, world, local_rank, backend):
         got = ctx.fetch("pred_out_csd", (z.shape[0], w["nt"], R_local))
         out["parity_rel_err_predict_vs_oracle"] = float(np.max(np.abs(got - pred_cpu)) / np.max(np.abs(pred_cpu)))
     return out
+
+
+def run_fit_bench(args, w, rank, world, local_rank, backend):
+    """BASELINE cfg5: GPCSD1D hyper-parameter fit, 24 x 500 x 200 trials resident on every GPU, 32 restarts sharded over the
+    GPUs.  The unit of work is one objective + analytic-gradient evaluation of one restart (what L-BFGS-B asks for); a step
+    evaluates one lock-step batch of B restarts in one chain of launches (gpcsd_loglik_grad_batch).  Reported: evaluations/s
+    through the batched call, the same through one-at-a-time calls (the round-1 path), and a truncated real fit()
+    (SciPy L-BFGS-B chains in lock-step) with restarts/s."""
+    import torch
+    from gpcsd_amd.dist import TrialSharding
+    total_restarts = 32
+    mine = [k for k in range(total_restarts) if k % world == rank]
+    B = args.fit_batch or min(8, len(mine))
+    m = build_model(w, np.zeros((w["nx"], w["nt"], 1)))
+    m.set_device(local_rank)
+    lfp = synth_data(w, m, w["trials_per_gpu"], seed=1000)          # every rank holds the same 200 trials
+    m.update_lfp(lfp, w["t"])
+    if os.environ.get("GPCSD_GRAM_PRECISION") == "32":              # BASELINE cfg5 names "fp32 kernel build + fp64 factor"
+        m.gram_precision = 32
+    ctx = m._sync_device()
+    sharding = TrialSharding() if world > 1 else None
+    if sharding is not None:
+        m.shard_restarts(sharding)
+    # restart k starts from the k-th draw of the default priors (SURVEY 8(d): np.random.seed(k), sampled on the host)
+    starts = []
+    for k in range(total_restarts):
+        np.random.seed(k)
+        starts.append(m._sample_start(False))
+    ng = 1 + m.dim + 2 * len(m.temporal_cov_list) + 1
+
+    def hp_of(tp):
+        m._set_from_tparams(tp, False)
+        return m._hparams(m.JITTER)
+    sets = [hp_of(starts[k]) for k in mine[:B]]
+    hps = [h for h, _ in sets]
+
+    def fence():
+        ctx.synchronize()
+        torch.cuda.synchronize()
+        if world > 1:
+            import torch.distributed as td
+            td.barrier()
+    for _ in range(max(3, min(args.setup_steps, 20))):
+        ctx.loglik_grad_batch(hps, ng)
+    for _ in range(args.warmup):
+        ctx.loglik_grad_batch(hps, ng)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        sumlog, quad, grad, st = ctx.loglik_grad_batch(hps, ng)
+    fence()
+    elapsed = time.perf_counter() - t0
+    # one at a time (what a chain on its own costs; fit(workers=1) of round 1)
+    nseq = max(8, min(args.steps, 40))
+    for _ in range(3):
+        ctx.loglik_grad(hps[0], ng)
+    ctx.synchronize()
+    t1 = time.perf_counter()
+    for i in range(nseq):
+        ctx.loglik_grad(hps[i % len(hps)], ng)
+    ctx.synchronize()
+    seq_s = (time.perf_counter() - t1) / nseq
+    if world > 1:
+        import torch.distributed as td
+        tt = torch.tensor([elapsed, seq_s], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+        td.all_reduce(tt, op=td.ReduceOp.MAX)
+        elapsed, seq_s = (float(v) for v in tt.cpu())
+    # profiled pass of the batched step
+    ctx.prof_reset()
+    ctx.prof_enable(True)
+    for _ in range(3):
+        ctx.loglik_grad_batch(hps, ng)
+    ctx.prof_enable(False)
+    prof = ctx.prof_all()
+    # a truncated real fit: lock-step SciPy chains, all of this rank's restarts
+    opts = {"maxiter": args.fit_maxiter, "disp": False, "gtol": 1e-5, "ftol": 1e7 * np.finfo(float).eps}
+    tf = time.perf_counter()
+    m.fit(n_restarts=total_restarts, options=opts, starts=starts, batch=B)
+    fit_s = time.perf_counter() - tf
+    nb, npts = getattr(m, "fit_batches_", (0, 0))
+    if rank != 0:
+        return None
+    n_eval = B * world * args.steps
+    gemm_flops = sum(v["flops"] for k, v in prof.items() if k.startswith("gemm_")) / 3.0
+    tail = prof.get("sytrd_rtail")
+    eig_flops = 4.0 * tail["flops"] / 3.0 if tail else 0.0           # tridiagonalisation + 3x for the back-transformation
+    step_s = elapsed / args.steps
+    return {
+        "metric": "gpcsd_fit_loglik_grad_evals_per_sec",
+        "value": n_eval / elapsed, "unit": "evals/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "setup_steps": max(3, min(args.setup_steps, 20)),
+        "ms_per_step": 1e3 * step_s, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "f64" if m.gram_precision == 64 else "f32 Gram build + f64", "data": "synthetic",
+        "config": {"workload": w["label"], "n_elec": w["nx"], "n_t": w["nt"], "trials_per_gpu": w["trials_per_gpu"],
+                   "restarts_total": total_restarts, "restarts_per_gpu": len(mine), "lockstep_batch": B,
+                   "parallelism": "restart-sharded x%d, %d restarts per lock-step batch" % (world, B)},
+        "evals_per_sec_one_at_a_time_per_gpu": 1.0 / seq_s,
+        "batched_over_sequential": (B / step_s) / (1.0 / seq_s),
+        "fit": {"restarts": total_restarts, "maxiter": args.fit_maxiter, "seconds": fit_s,
+                "restarts_per_sec": total_restarts / fit_s, "evals": int(npts) * world, "batched_calls": int(nb),
+                "evals_per_sec_through_scipy": npts * world / fit_s, "best_nll": float(np.min(m.fit_nll_values_))},
+        "roofline": {"bound": "mfma", "unit": "TFLOP/s", "peak": FP64_MFMA_SPEC_TFLOPS,
+                     "achieved": (gemm_flops + eig_flops) / step_s / 1e12,
+                     "frac": (gemm_flops + eig_flops) / step_s / 1e12 / FP64_MFMA_SPEC_TFLOPS,
+                     "scope": "one step = %d objective+gradient evaluations in one chain of launches; flops actually launched" % B,
+                     "executed_gflop_per_step": (gemm_flops + eig_flops) / 1e9, "traffic": None,
+                     "dominant_kernel": None if not tail else {
+                         "kernel": "sytrd_rtail_kernel", "avg_launch_ms": tail["ms"] / tail["count"],
+                         "launches_per_step": tail["count"] / 3.0, "workgroups_per_launch": "%d (one per half problem and set)" % (2 * B),
+                         "share_of_step_wall": tail["ms"] / 3.0 / (1e3 * step_s)},
+                     "per_kernel_ms_per_step": {k: v["ms"] / 3.0 for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])[:16]}},
+    }
 
 
 if __name__ == "__main__":

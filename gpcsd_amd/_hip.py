@@ -83,6 +83,7 @@ SIGNATURES = {
     "gpcsd_loglik": (_I, [_P, ctypes.POINTER(HParams), _DP]),
     "gpcsd_loglik_parts": (_I, [_P, ctypes.POINTER(HParams), _DP]),
     "gpcsd_loglik_grad": (_I, [_P, ctypes.POINTER(HParams), _DP, _DP, _I]),
+    "gpcsd_loglik_grad_batch": (_I, [_P, ctypes.POINTER(HParams), _I, _DP, _DP, _I, ctypes.POINTER(_I)]),
     "gpcsd_predict": (_I, [_P, ctypes.POINTER(HParams), _DP, _I, _DP, _I, _I, _DP, _DP, _DP, _DP]),
     "gpcsd_predict_resident": (_I, [_P, ctypes.POINTER(HParams), _DP, _I, _DP, _I, _I, _I]),
     "gpcsd_fetch": (_I, [_P, ctypes.c_char_p, _DP, _L]),
@@ -462,6 +463,18 @@ class Context:
         g = np.empty(ngrad)
         self._check(self._lib.gpcsd_loglik_grad(self._h, ctypes.byref(hp), _ptr(out), _ptr(g), int(ngrad)))
         return float(out[0]), float(out[1]), g
+
+    def loglik_grad_batch(self, hps, ngrad):
+        """hps: list of HParams (same kernel kinds, scalar noise).  One shared chain of launches for all of them.
+        Returns (sumlog (B,), quad (B,), grad (B, ngrad), status (B,)); status[i] > 0: set i failed numerically."""
+        B = len(hps)
+        arr = (HParams * B)(*hps)
+        out = np.empty((B, 2))
+        g = np.empty((B, ngrad))
+        st = np.zeros(B, dtype=np.int32)
+        self._check(self._lib.gpcsd_loglik_grad_batch(self._h, arr, B, _ptr(out), _ptr(g), int(ngrad),
+                                                      st.ctypes.data_as(ctypes.POINTER(ctypes.c_int))))
+        return out[:, 0].copy(), out[:, 1].copy(), g, st
 
     def predict(self, hp, z, tstar, type_code, shape, want_lists=True):
         """shape = (nz, ntstar, ntrials).  Returns dict of arrays for the requested type."""

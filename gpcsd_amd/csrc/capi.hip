@@ -1567,80 +1567,169 @@ static bool env_flag_off(const char *name) {       // NAME=0 switches a term off
     return v && v[0] == '0';
 }
 
-extern "C" int gpcsd_loglik_grad(gpcsd_ctx *c, const gpcsd_hparams *hp, double *out2, double *grad, int ngrad) {
-    GP_API_BEGIN(c)
-    GP_REQUIRE(out2 && grad && hp, -3, "loglik_grad: null argument");
-    // every argument check comes before any work is queued (front_half launches on two streams and uploads hp->sig2n)
+// ---- log-likelihood + analytic gradient for B hyper-parameter sets in ONE chain of launches ---------------------------------
+// fit() restarts are independent optimiser chains (gpcsd1d.py:193-220) whose evaluations are latency-bound: ~100 dependent
+// launches in which the longest kernel occupies one workgroup per eigenproblem.  B sets evaluated together share every launch:
+// the Gram builders and derivative kernels take the set index as a grid dimension (scalars from a device table of
+// hyper-parameters), the eigensolver runs B replicas of each problem class, every GEMM gets an outer batch level.  Each set
+// executes exactly the arithmetic of an evaluation on its own (same kernels, same tile configurations, same reduction
+// order), so its results do not depend on B.
+static HpDev hp_image(const gpcsd_hparams *hp) {
+    HpDev h{};
+    h.R = hp->R; h.eps = hp->eps; h.ell_s[0] = hp->ell_s[0]; h.ell_s[1] = hp->ell_s[1];
+    h.ncomp = hp->n_temporal;
+    for (int i = 0; i < hp->n_temporal; ++i) {
+        h.kind[i] = hp->kind[i];
+        h.ell_t[i] = hp->ell_t[i];
+        h.sigma2_t[i] = hp->sigma2_t[i];
+    }
+    h.sig2n = hp->sig2n[0];
+    h.jitter = hp->jitter;
+    return h;
+}
+
+// out2: (B, 2) = (sum log D, quad) per set; grad: (B, ngrad); status: (B) -- 0 ok, > 0 numerical failure of that set alone.
+static int loglik_grad_impl(gpcsd_ctx *c, const gpcsd_hparams *hps, int B, double *out2, double *grad, int ngrad, int *status) {
+    GP_REQUIRE(out2 && grad && hps && B >= 1, -3, "loglik_grad: null argument");
+    // every argument check comes before any work is queued (the front half launches on two streams)
     const Geo g = resident_geo(c);
     GP_REQUIRE(c->d_lfp != nullptr, -4, "lfp not set (call gpcsd_set_lfp)");
-    check_hp(c, hp, c->nx);
-    GP_REQUIRE(!uses_host_kt(hp), -3, "loglik_grad: no analytic gradient for user-defined temporal covariances "
-                                      "(their derivative is not known to the library; use finite differences of gpcsd_loglik)");
-    const int nx = c->nx, nt = c->nt, R = c->ntrials, C = hp->n_temporal, G = g.G();
+    GP_REQUIRE(c->time_nt == c->nt, -4, "time grid has %d points but lfp has nt=%d", c->time_nt, c->nt);
+    GP_REQUIRE(g.nx == c->nx, -4, "geometry has %d electrodes but lfp has nx=%d", g.nx, c->nx);
+    const int nx = c->nx, nt = c->nt, R = c->ntrials, C = hps[0].n_temporal, G = g.G();
+    const int nsig = hps[0].n_sig2n;
+    for (int b = 0; b < B; ++b) {
+        check_hp(c, &hps[b], nx);
+        GP_REQUIRE(!uses_host_kt(&hps[b]), -3, "loglik_grad: no analytic gradient for user-defined temporal covariances "
+                                              "(their derivative is not known to the library; use finite differences of gpcsd_loglik)");
+        GP_REQUIRE(hps[b].n_temporal == C && hps[b].n_sig2n == nsig, -3,
+                   "loglik_grad_batch: every hyper-parameter set must have the same number of temporal components and noise entries");
+        for (int i = 0; i < C; ++i)
+            GP_REQUIRE(hps[b].kind[i] == hps[0].kind[i], -3, "loglik_grad_batch: temporal kernel kinds differ between sets");
+    }
     // scalar sig2n: one trailing entry; per-electrode list (indexed by eigen-row like the reference's D): nx entries
-    const int nsig = hp->n_sig2n;
     GP_REQUIRE(nsig == 1 || nsig == nx, -3, "loglik_grad: sig2n must be a scalar or a list of nx=%d values (got %d)", nx, nsig);
+    GP_REQUIRE(nsig == 1 || B == 1, -3, "loglik_grad_batch: per-electrode noise lists are evaluated one set at a time");
     const int nhead = 1 + g.dim + 2 * C;
     GP_REQUIRE(ngrad == nhead + nsig, -3, "loglik_grad: ngrad=%d, expected %d", ngrad, nhead + nsig);
-    EigState e = front_half(c, hp, hp->jitter);        // leaves A, Kgl, T = A Kgl in the ks_* buffers
-    const long RT = (long)R * nt;
-    hipStream_t s = c->stream;
-    const double *A = (const double *)c->bufs["ks_A"].p, *Kgl = (const double *)c->bufs["ks_Kgl"].p,
-                 *T = (const double *)c->bufs["ks_T"].p;
-    double *W = c->buf<double>("proj_W", (size_t)nx * RT);
-    double *Bm = c->buf<double>("pred_B", (size_t)nx * RT);
-    double *Bet = c->buf<double>("grad_Bet", (size_t)nx * RT);
-    double *Bes = c->buf<double>("grad_Bes", (size_t)nx * RT);
-    double *gdev = c->buf<double>("grad_out", 64);
-    GemmDesc g1;                          // W = Qs^T Y
+    const long RT = (long)R * nt, nxx = (long)nx * nx, ntt = (long)nt * nt, nD = (long)nx * nt, nxRT = (long)nx * RT;
+    const long nxG = (long)nx * G, GG = (long)G * G;
+    hipStream_t s = c->stream, s2 = c->stream2;
+
+    // ---- device table of the hyper-parameter sets
+    std::vector<HpDev> himg(B);
+    for (int b = 0; b < B; ++b) himg[b] = hp_image(&hps[b]);
+    const HpDev *tab = c->upload_cached<HpDev>("b_hp_tab", himg.data(), B);
+    const double *d_siglist = nsig > 1 ? c->upload_cached<double>("sig2n", hps[0].sig2n, nsig) : nullptr;
+
+    double *Ks = c->buf<double>("b_Ks", nxx * B), *Kt = c->buf<double>("b_Kt", ntt * B);
+    double *Qs = c->buf<double>("b_Qs", nxx * B), *Qt = c->buf<double>("b_Qt", ntt * B);
+    double *es = c->buf<double>("b_es", (size_t)nx * B), *et = c->buf<double>("b_et", (size_t)nt * B);
+    double *D = c->buf<double>("b_D", nD * B), *Dinv = c->buf<double>("b_Dinv", nD * B);
+    constexpr int NS = 8;                                     // scalars per set: sumlog, quad, sum B^2, sum 1/D
+    double *scal = c->buf<double>("b_scal", (size_t)NS * B);
+    int *st = c->buf<int>("b_status", (size_t)2 * B);        // [0, B): spatial chains, [B, 2B): temporal chains
+    double *A = c->buf<double>("b_ks_A", nxG * B), *Kgl = c->buf<double>("b_ks_Kgl", GG * B), *T = c->buf<double>("b_ks_T", nxG * B);
+    double *W = c->buf<double>("b_W", nxRT * B), *Bm = c->buf<double>("b_Bm", nxRT * B);
+    double *Bet = c->buf<double>("b_Bet", nxRT * B), *Bes = c->buf<double>("b_Bes", nxRT * B);
+    double *gdev = c->buf<double>("b_grad_out", (size_t)64 * B);
+    const double *t = (const double *)c->bufs["time_t"].p;
+    const SymDev *sym_s = c->sym_s.ns > 0 ? &c->sym_s : nullptr, *sym_t = c->sym_t.ns > 0 ? &c->sym_t : nullptr;
+
+    // ---- front half: temporal chain on stream2 (queued first: the critical path), spatial chain on the main stream
+    GP_HIP(hipMemsetAsync(st, 0, (size_t)2 * B * sizeof(int), s));
+    GP_HIP(hipEventRecord(c->ev_fork, s));
+    GP_HIP(hipStreamWaitEvent(s2, c->ev_fork, 0));
+    k_temporal_gram(c, C, nullptr, nullptr, nullptr, t, nt, t, nt, Kt, s2, tab, B, ntt);
+    {
+        ProfScope ps(c, "eigh_temporal", 9.0 * (double)nt * nt * nt * B, s2);
+        eigh_pair_device(c, nullptr, 0, nullptr, nullptr, nullptr, Kt, nt, et, Qt, sym_t, st + B, s2, true, B, 1);
+    }
+    GP_HIP(hipEventRecord(c->ev_join, s2));
+    // Ks_b = A_b Kgl_b A_b^T + jitter_b I                     covariances.py:74-96 / :204-232
+    if (g.dim == 1) {
+        k_fwd_weights_1d(c, g.x, nx, g.gx1, g.gw1, g.ngl1, 0.0, A, s, tab, B, nxG);
+        k_se_1d(c, g.gx1, G, g.gx1, G, 0.0, Kgl, s, tab, B, GG);
+    } else {
+        k_fwd_weights_2d(c, g.x, nx, g.gx1, g.gw1, g.ngl1, g.gx2, g.gw2, g.ngl2, 0.0, 0.0, A, s, tab, B, nxG);
+        k_se_2d(c, g.gx1, g.gx2, G, g.ngl2, g.gx1, g.gx2, G, g.ngl2, 0.0, 0.0, Kgl, s, tab, B, GG);
+    }
+    {
+        GemmDesc d1;                                   // T = A Kgl
+        d1.M = nx; d1.N = G; d1.K = G;
+        d1.A = A; d1.lda = G; d1.B = Kgl; d1.ldb = G; d1.C = T; d1.ldc = G;
+        d1.batch2 = B; d1.sA2 = nxG; d1.sB2 = GG; d1.sC2 = nxG;
+        d1.prof_name = "gemm_Ks_AKgl";
+        gemm_f64(c, d1, s);
+        GemmDesc d2;                                   // Ks = T A^T
+        d2.M = nx; d2.N = nx; d2.K = G;
+        d2.A = T; d2.lda = G; d2.B = A; d2.ldb = G; d2.transB = true; d2.C = Ks; d2.ldc = nx;
+        d2.batch2 = B; d2.sA2 = nxG; d2.sB2 = nxG; d2.sC2 = nxx;
+        d2.prof_name = "gemm_Ks_TAt";
+        gemm_f64(c, d2, s);
+        k_add_diag(c, Ks, nx, 0.0, s, tab, B, nxx);
+    }
+    {
+        ProfScope ps(c, "eigh_spatial", 9.0 * (double)nx * nx * nx * B, s);
+        eigh_pair_device(c, Ks, nx, es, Qs, sym_s, nullptr, 0, nullptr, nullptr, nullptr, st, s, true, B, 1);
+    }
+    GemmDesc g1;                          // W_b = Qs_b^T Y          (gpcsd1d.py:125 inner dot; the data is shared)
     g1.M = nx; g1.N = (int)RT; g1.K = nx;
-    g1.A = e.Qs; g1.lda = nx; g1.transA = true; g1.B = c->d_lfp; g1.ldb = RT; g1.C = W; g1.ldc = RT;
+    g1.A = Qs; g1.lda = nx; g1.transA = true; g1.B = c->d_lfp; g1.ldb = RT; g1.C = W; g1.ldc = RT;
+    g1.batch2 = B; g1.sA2 = nxx; g1.sB2 = 0; g1.sC2 = nxRT;
     g1.prof_name = "gemm_proj_spatial";
     gemm_f64(c, g1, s);
-    join_temporal(c, e);
+    GP_HIP(hipStreamWaitEvent(s, c->ev_join, 0));
+    // D_b = es_b (x) et_b + sig2n_b, sum log D_b -> scal[b][0]
+    if (nsig == 1) k_build_D(c, es, nx, et, nt, nullptr, 1, D, Dinv, scal, s, tab, B, NS);
+    else k_build_D(c, es, nx, et, nt, d_siglist, nsig, D, Dinv, scal, s);
     GemmDesc g2;                          // alpha = W Qt;  B = alpha / D, B*et, B*es;  sum alpha*B, sum B^2
     g2.M = nx * R; g2.N = nt; g2.K = nt;
-    g2.A = W; g2.lda = nt; g2.B = e.Qt; g2.ldb = nt; g2.C = Bm; g2.ldc = nt; g2.C2 = Bet; g2.C3 = Bes;
-    g2.epi = EPI_GRAD; g2.D = e.Dinv; g2.rdiv = R; g2.ldd = nt; g2.colscale = e.et; g2.rowscale = e.es;
-    g2.quad_out = e.scal + 1;             // scal[1] = quad, scal[2] = sum B^2
+    g2.A = W; g2.lda = nt; g2.B = Qt; g2.ldb = nt; g2.C = Bm; g2.ldc = nt; g2.C2 = Bet; g2.C3 = Bes;
+    g2.epi = EPI_GRAD; g2.D = Dinv; g2.rdiv = R; g2.ldd = nt; g2.colscale = et; g2.rowscale = es;
+    g2.quad_out = scal + 1;               // scal[b][1] = quad, scal[b][2] = sum B^2
+    g2.batch2 = B; g2.sA2 = nxRT; g2.sB2 = ntt; g2.sC2 = nxRT; g2.sD2 = nD; g2.sColscale2 = nt; g2.sRowscale2 = nx; g2.sQuad2 = NS;
     g2.prof_name = "gemm_grad_temporal";
     gemm_f64(c, g2, s);
-    double *av = c->buf<double>("grad_a", nx), *bv = c->buf<double>("grad_b", nt);
-    k_D_sums(c, e.D, e.es, e.et, nx, nt, av, bv, e.scal + 3, s);          // scal[3] = sum 1/D
+    double *av = c->buf<double>("b_grad_a", (size_t)nx * B), *bv = c->buf<double>("b_grad_b", (size_t)nt * B);
+    k_D_sums(c, D, es, et, nx, nt, av, bv, scal + 3, s, B, NS);           // scal[b][3] = sum 1/D
 
     // Ghat_s = 1/2 sum_r (B_r et) B_r^T - R/2 diag(a)      (one GEMM per trial, batched; then a fixed-order sum)
-    double *Cs = c->buf<double>("grad_Cs", (size_t)R * nx * nx);
+    const long sCs = (long)R * nxx;
+    double *Cs = c->buf<double>("b_grad_Cs", (size_t)sCs * B);
     GemmDesc gs;
     gs.M = nx; gs.N = nx; gs.K = nt;
     gs.A = Bet; gs.lda = RT; gs.B = Bm; gs.ldb = RT; gs.transB = true; gs.C = Cs; gs.ldc = nx;
-    gs.batch = R; gs.sA = nt; gs.sB = nt; gs.sC = (long)nx * nx;
+    gs.batch = R; gs.sA = nt; gs.sB = nt; gs.sC = nxx;
+    gs.batch2 = B; gs.sA2 = nxRT; gs.sB2 = nxRT; gs.sC2 = sCs;
     gs.prof_name = "gemm_grad_Gs";
     gemm_f64(c, gs, s);
-    double *Ghs = c->buf<double>("grad_Ghs", (size_t)nx * nx);
-    k_batch_reduce(c, Cs, R, (long)nx * nx, nx, 0.5, av, -0.5 * R, Ghs, s);
+    double *Ghs = c->buf<double>("b_grad_Ghs", nxx * B);
+    k_batch_reduce(c, Cs, R, nxx, nx, 0.5, av, -0.5 * R, Ghs, s, B, sCs);
     if (nsig > 1 && !env_flag_off("GPCSD_SIGLIST_EIGVEC_TERM")) {
         // noise tied to the eigen-index: eigenvector-rotation term, S = sum_r B_r B_r^T (see grad.hip)
         GemmDesc g3 = gs;
         g3.A = Bm;
         g3.prof_name = "gemm_grad_BBt";
         gemm_f64(c, g3, s);
-        double *Ssum = c->buf<double>("grad_Ssum", (size_t)nx * nx);
+        double *Ssum = c->buf<double>("grad_Ssum", (size_t)nxx);
         double *zero = c->buf<double>("grad_zero", nx);
         k_fill(c, zero, nx, 0.0, s);
-        k_batch_reduce(c, Cs, R, (long)nx * nx, nx, 1.0, zero, 0.0, Ssum, s);
-        double *dsig = c->upload<double>("grad_sig", hp->sig2n, nx);
-        k_siglist_eigvec_term(c, Ghs, Ssum, e.es, dsig, nx, 0.0, s);
+        k_batch_reduce(c, Cs, R, nxx, nx, 1.0, zero, 0.0, Ssum, s);
+        k_siglist_eigvec_term(c, Ghs, Ssum, es, d_siglist, nx, 0.0, s);
     }
     // Ghat_t = 1/2 sum_{(x,r)} (B es)^T B - R/2 diag(b)    (row chunks of 512, batched; remainder separately)
     const long rows = (long)nx * R;
     const int CH = 512;
     const int nfull = (int)(rows / CH), rem = (int)(rows % CH);
-    double *Ct = c->buf<double>("grad_Ct", (size_t)(nfull + 1) * nt * nt);
+    const long sCt = (long)(nfull + 1) * ntt;
+    double *Ct = c->buf<double>("b_grad_Ct", (size_t)sCt * B);
     if (nfull > 0) {
         GemmDesc gt;
         gt.M = nt; gt.N = nt; gt.K = CH;
         gt.A = Bes; gt.lda = nt; gt.transA = true; gt.B = Bm; gt.ldb = nt; gt.C = Ct; gt.ldc = nt;
-        gt.batch = nfull; gt.sA = (long)CH * nt; gt.sB = (long)CH * nt; gt.sC = (long)nt * nt;
+        gt.batch = nfull; gt.sA = (long)CH * nt; gt.sB = (long)CH * nt; gt.sC = ntt;
+        gt.batch2 = B; gt.sA2 = nxRT; gt.sB2 = nxRT; gt.sC2 = sCt;
         gt.prof_name = "gemm_grad_Gt";
         gemm_f64(c, gt, s);
     }
@@ -1648,49 +1737,53 @@ extern "C" int gpcsd_loglik_grad(gpcsd_ctx *c, const gpcsd_hparams *hp, double *
         GemmDesc gt;
         gt.M = nt; gt.N = nt; gt.K = rem;
         gt.A = Bes + (long)nfull * CH * nt; gt.lda = nt; gt.transA = true; gt.B = Bm + (long)nfull * CH * nt; gt.ldb = nt;
-        gt.C = Ct + (long)nfull * nt * nt; gt.ldc = nt;
+        gt.C = Ct + (long)nfull * ntt; gt.ldc = nt;
+        gt.batch2 = B; gt.sA2 = nxRT; gt.sB2 = nxRT; gt.sC2 = sCt;
         gt.prof_name = "gemm_grad_Gt";
         gemm_f64(c, gt, s);
     }
-    double *Ght = c->buf<double>("grad_Ght", (size_t)nt * nt);
-    k_batch_reduce(c, Ct, nfull + (rem > 0 ? 1 : 0), (long)nt * nt, nt, 0.5, bv, -0.5 * R, Ght, s);
+    double *Ght = c->buf<double>("b_grad_Ght", ntt * B);
+    k_batch_reduce(c, Ct, nfull + (rem > 0 ? 1 : 0), ntt, nt, 0.5, bv, -0.5 * R, Ght, s, B, sCt);
     // back to the original bases: Gs = Qs Ghat_s Qs^T, Gt = Qt Ghat_t Qt^T
-    double *T1 = c->buf<double>("grad_T1", (size_t)std::max(nx, nt) * std::max(nx, nt));
-    double *Gs = c->buf<double>("grad_Gs", (size_t)nx * nx), *Gt = c->buf<double>("grad_Gt", (size_t)nt * nt);
+    const long nmx = (long)std::max(nx, nt) * std::max(nx, nt);
+    double *T1 = c->buf<double>("b_grad_T1", (size_t)nmx * B);
+    double *Gs = c->buf<double>("b_grad_Gs", nxx * B), *Gt = c->buf<double>("b_grad_Gt", ntt * B);
     auto sandwich = [&](const double *Q, const double *H, int n, double *out) {
+        const long nn = (long)n * n;
         GemmDesc a;
         a.M = n; a.N = n; a.K = n; a.A = Q; a.lda = n; a.B = H; a.ldb = n; a.C = T1; a.ldc = n;
+        a.batch2 = B; a.sA2 = nn; a.sB2 = nn; a.sC2 = nmx;
         a.prof_name = "gemm_grad_sandwich";
         gemm_f64(c, a, s);
-        GemmDesc b;
-        b.M = n; b.N = n; b.K = n; b.A = T1; b.lda = n; b.B = Q; b.ldb = n; b.transB = true; b.C = out; b.ldc = n;
-        b.prof_name = "gemm_grad_sandwich";
-        gemm_f64(c, b, s);
+        GemmDesc bq;
+        bq.M = n; bq.N = n; bq.K = n; bq.A = T1; bq.lda = n; bq.B = Q; bq.ldb = n; bq.transB = true; bq.C = out; bq.ldc = n;
+        bq.batch2 = B; bq.sA2 = nmx; bq.sB2 = nn; bq.sC2 = nn;
+        bq.prof_name = "gemm_grad_sandwich";
+        gemm_f64(c, bq, s);
     };
-    sandwich(e.Qs, Ghs, nx, Gs);
-    sandwich(e.Qt, Ght, nt, Gt);
-    // natural-parameter order: [R, ell_s (dim), (ell_t, sigma2_t) per component, sig2n]
-    const double *t = (const double *)c->bufs["time_t"].p;
-    k_temporal_grad(c, hp, Gt, t, nt, gdev + 1 + g.dim, s);
-    double *P = c->buf<double>("grad_P", (size_t)nx * G);
-    double *Mg = c->buf<double>("grad_M", (size_t)G * G);
+    sandwich(Qs, Ghs, nx, Gs);
+    sandwich(Qt, Ght, nt, Gt);
+    // natural-parameter order: [R, ell_s (dim), (ell_t, sigma2_t) per component, sig2n]; 64 slots per set
+    k_temporal_grad(c, &hps[0], Gt, t, nt, gdev + 1 + g.dim, s, tab, B, 64);
+    double *P = c->buf<double>("b_grad_P", nxG * B);
+    double *Mg = c->buf<double>("b_grad_M", GG * B);
     GemmDesc gp;                          // P = Gs A
     gp.M = nx; gp.N = G; gp.K = nx; gp.A = Gs; gp.lda = nx; gp.B = A; gp.ldb = G; gp.C = P; gp.ldc = G;
+    gp.batch2 = B; gp.sA2 = nxx; gp.sB2 = nxG; gp.sC2 = nxG;
     gp.prof_name = "gemm_grad_GsA";
     gemm_f64(c, gp, s);
     GemmDesc gm;                          // M = A^T P
     gm.M = G; gm.N = G; gm.K = nx; gm.A = A; gm.lda = G; gm.transA = true; gm.B = P; gm.ldb = G; gm.C = Mg; gm.ldc = G;
+    gm.batch2 = B; gm.sA2 = nxG; gm.sB2 = nxG; gm.sC2 = GG;
     gm.prof_name = "gemm_grad_AtP";
     gemm_f64(c, gm, s);
-    double *ellg = c->buf<double>("grad_ell", 2);
-    k_kgl_grad(c, Mg, Kgl, g.gx1, g.gx2, G, g.dim == 2 ? g.ngl2 : 0, hp->ell_s[0], hp->ell_s[1], ellg, s);
-    GP_HIP(hipMemcpyAsync(gdev + 1, ellg, g.dim * sizeof(double), hipMemcpyDeviceToDevice, s));
+    k_kgl_grad(c, Mg, Kgl, g.gx1, g.gx2, G, g.dim == 2 ? g.ngl2 : 0, 0.0, 0.0, gdev + 1, s, tab, B, 64);
     GemmDesc gr;                          // S = Gs T  (T = A Kgl from the forward pass)
     gr.M = nx; gr.N = G; gr.K = nx; gr.A = Gs; gr.lda = nx; gr.B = T; gr.ldb = G; gr.C = P; gr.ldc = G;
+    gr.batch2 = B; gr.sA2 = nxx; gr.sB2 = nxG; gr.sC2 = nxG;
     gr.prof_name = "gemm_grad_GsT";
     gemm_f64(c, gr, s);
-    k_fwdR_grad(c, P, g.x, nx, g.gx1, g.gw1, g.gx2, g.gw2, G, g.dim == 2 ? g.ngl2 : 0, hp->R, hp->eps, gdev, s);
-    double hs[4], hg[64];
+    k_fwdR_grad(c, P, g.x, nx, g.gx1, g.gw1, g.gx2, g.gw2, G, g.dim == 2 ? g.ngl2 : 0, 0.0, 0.0, gdev, s, tab, B, 64);
     std::vector<double> hb2, hinv;
     if (nsig > 1) {                       // d/d sig2n_x = -R/2 sum_i 1/D_xi + 1/2 sum_{r,i} B_{(x,r),i}^2
         double *b2row = c->buf<double>("grad_b2row", nx);
@@ -1700,16 +1793,49 @@ extern "C" int gpcsd_loglik_grad(gpcsd_ctx *c, const gpcsd_hparams *hp, double *
         c->download(hb2.data(), b2row, nx * sizeof(double));
         c->download(hinv.data(), c->bufs["grad_s1row"].p, nx * sizeof(double));   // written by k_D_sums
     }
-    c->download(hs, e.scal, 4 * sizeof(double));
-    c->download(hg, gdev, nhead * sizeof(double));
-    const int rc = finish_status(c, e.status);
-    out2[0] = hs[0];
-    out2[1] = hs[1];
-    for (int k = 0; k < nhead; ++k) grad[k] = hg[k];
-    if (nsig == 1) grad[nhead] = -0.5 * R * hs[3] + 0.5 * hs[2];
-    else
-        for (int x = 0; x < nx; ++x) grad[nhead + x] = -0.5 * R * hinv[x] + 0.5 * hb2[x];
-    return rc;
+    std::vector<double> hs((size_t)NS * B), hg((size_t)64 * B);
+    std::vector<int> hst((size_t)2 * B);
+    c->download(hs.data(), scal, hs.size() * sizeof(double));
+    c->download(hg.data(), gdev, hg.size() * sizeof(double));
+    c->download(hst.data(), st, hst.size() * sizeof(int));
+    GP_HIP(hipStreamSynchronize(s2));
+    c->sync();
+    if (c->prof_on) c->prof_collect();
+    int worst = 0;
+    for (int b = 0; b < B; ++b) {
+        out2[2 * b] = hs[(size_t)NS * b];
+        out2[2 * b + 1] = hs[(size_t)NS * b + 1];
+        double *gb = grad + (size_t)b * ngrad;
+        for (int k = 0; k < nhead; ++k) gb[k] = hg[(size_t)64 * b + k];
+        if (nsig == 1) gb[nhead] = -0.5 * R * hs[(size_t)NS * b + 3] + 0.5 * hs[(size_t)NS * b + 2];
+        else
+            for (int x = 0; x < nx; ++x) gb[nhead + x] = -0.5 * R * hinv[x] + 0.5 * hb2[x];
+        int stb = hst[b] != 0 ? hst[b] : hst[B + b];
+        if (stb < 0) stb = 1;
+        if (status) status[b] = stb;
+        worst = std::max(worst, stb);
+    }
+    if (worst != 0) {
+        char msg[160];
+        snprintf(msg, sizeof(msg), "numerical failure (status %d): eigensolver did not converge or matrix not positive definite", worst);
+        c->last_error = msg;
+    }
+    return worst;
+}
+
+extern "C" int gpcsd_loglik_grad(gpcsd_ctx *c, const gpcsd_hparams *hp, double *out2, double *grad, int ngrad) {
+    GP_API_BEGIN(c)
+    GP_REQUIRE(hp != nullptr, -3, "loglik_grad: null hparams");
+    return loglik_grad_impl(c, hp, 1, out2, grad, ngrad, nullptr);
+    GP_API_END(c)
+}
+
+extern "C" int gpcsd_loglik_grad_batch(gpcsd_ctx *c, const gpcsd_hparams *hps, int nsets, double *out2, double *grad, int ngrad,
+                                       int *status) {
+    GP_API_BEGIN(c)
+    GP_REQUIRE(hps && nsets >= 1 && status, -3, "loglik_grad_batch: bad arguments");
+    (void)loglik_grad_impl(c, hps, nsets, out2, grad, ngrad, status);   // per-set failures are reported in status[], not as rc
+    return 0;
     GP_API_END(c)
 }
 

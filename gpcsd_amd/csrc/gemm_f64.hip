@@ -509,7 +509,9 @@ void gemm_f64(gpcsd_ctx *c, const GemmDesc &g, hipStream_t s) {
     static const int CFG_BM[6] = {0, 128, 64, 64, 0, 32}, CFG_BN[6] = {0, 128, 64, 64, 0, 32};
     int cfg = g.cfg;
     if (cfg != 1 && cfg != 2 && cfg != 3 && cfg != 5) {
-        auto tiles = [&](int bm, int bn) { return (long)ceil_div(g.M, bm) * ceil_div(g.N, bn) * g.batch * batch2; };
+        // the outer batch level (hyper-parameter sets) does NOT enter the choice: a set must run the same tile configuration --
+        // hence the same summation order of the fused reductions -- whether it is evaluated alone or in a batch
+        auto tiles = [&](int bm, int bn) { return (long)ceil_div(g.M, bm) * ceil_div(g.N, bn) * g.batch; };
         // measured on MI355X (tools/gemm_sweep.py): 64x64 tiles reach the same ~40 TF/s as 128x128 on the large
         // flat GEMMs and balance the tail better; everything smaller is latency-bound and wants 32x32 / BK64
         // short K (the folded GEMMs: 192 / 250): the same tile with BK 8 -- half the pipeline fill per tile and half the LDS,

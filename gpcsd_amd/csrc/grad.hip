@@ -27,8 +27,12 @@ __device__ __forceinline__ void block_partials(double (&v)[NV], double *partials
 }
 
 // out[v] = scale[v-th] * sum_b partials[v*nblocks + b]; one workgroup per value
-__global__ __launch_bounds__(256) void final_sums_kernel(const double *__restrict__ partials, int nblocks, double *out) {
+// blockIdx.y = hyper-parameter set of a batched evaluation (partials pstride apart, outputs ostride apart)
+__global__ __launch_bounds__(256) void final_sums_kernel(const double *__restrict__ partials, int nblocks, double *out,
+                                                         long pstride = 0, long ostride = 0) {
     __shared__ double red[4];
+    partials += blockIdx.y * pstride;
+    out += blockIdx.y * ostride;
     const int v = blockIdx.x;
     double s = 0.0;
     for (int b = threadIdx.x; b < nblocks; b += 256) s += partials[(long)v * nblocks + b];
@@ -40,6 +44,10 @@ __global__ __launch_bounds__(256) void final_sums_kernel(const double *__restric
 __global__ __launch_bounds__(256) void d_rowsums_kernel(const double *__restrict__ D, const double *__restrict__ et, int nt,
                                                         double *__restrict__ a, double *__restrict__ s1row) {
     __shared__ double red[4];
+    {                                           // blockIdx.y = hyper-parameter set (gridDim.x = nx rows each)
+        const long b = blockIdx.y, nx = gridDim.x;
+        D += b * nx * nt; et += b * nt; a += b * nx; s1row += b * nx;
+    }
     const int x = blockIdx.x;
     double sa = 0.0, s1 = 0.0;
     for (int i = threadIdx.x; i < nt; i += 256) {
@@ -58,6 +66,10 @@ __global__ __launch_bounds__(256) void d_rowsums_kernel(const double *__restrict
 // b_i = sum_x es_x / D_xi; one thread per eigen-column i (coalesced across i)
 __global__ __launch_bounds__(256) void d_colsums_kernel(const double *__restrict__ D, const double *__restrict__ es, int nx,
                                                         int nt, double *__restrict__ b) {
+    {                                           // blockIdx.y = hyper-parameter set
+        const long q = blockIdx.y;
+        D += q * nx * nt; es += q * nx; b += q * nt;
+    }
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= nt) return;
     double s = 0.0;
@@ -66,18 +78,21 @@ __global__ __launch_bounds__(256) void d_colsums_kernel(const double *__restrict
 }
 
 void k_D_sums(gpcsd_ctx *c, const double *D, const double *es, const double *et, int nx, int nt, double *a, double *b,
-              double *s1_out, hipStream_t s) {
-    double *s1row = c->buf<double>("grad_s1row", nx);
-    hipLaunchKernelGGL(d_rowsums_kernel, dim3(nx), dim3(256), 0, s, D, et, nt, a, s1row);
-    hipLaunchKernelGGL(d_colsums_kernel, dim3(ceil_div(nt, 256)), dim3(256), 0, s, D, es, nx, nt, b);
-    hipLaunchKernelGGL(final_sums_kernel, dim3(1), dim3(256), 0, s, (const double *)s1row, nx, s1_out);
+              double *s1_out, hipStream_t s, int B, long s_s1) {
+    double *s1row = c->buf<double>("grad_s1row", (size_t)nx * B);
+    hipLaunchKernelGGL(d_rowsums_kernel, dim3(nx, B), dim3(256), 0, s, D, et, nt, a, s1row);
+    hipLaunchKernelGGL(d_colsums_kernel, dim3(ceil_div(nt, 256), B), dim3(256), 0, s, D, es, nx, nt, b);
+    hipLaunchKernelGGL(final_sums_kernel, dim3(1, B), dim3(256), 0, s, (const double *)s1row, nx, s1_out, (long)nx, s_s1);
     GP_HIP(hipGetLastError());
 }
 
 // out[e] = scale * sum_b in[b*stride + e]  (+ dscale * dvec[i] on the diagonal of the n x n output)
 __global__ __launch_bounds__(256) void batch_reduce_kernel(const double *__restrict__ in, int nb, long stride, int n, double scale,
                                                            const double *__restrict__ dvec, double dscale,
-                                                           double *__restrict__ out) {
+                                                           double *__restrict__ out, long s_in) {
+    in += blockIdx.y * s_in;                    // blockIdx.y = hyper-parameter set: inputs s_in apart, dvec n apart, out n*n apart
+    dvec += (long)blockIdx.y * n;
+    out += (long)blockIdx.y * n * n;
     const long e = blockIdx.x * 256L + threadIdx.x;
     if (e >= (long)n * n) return;
     double s = 0.0;
@@ -89,9 +104,9 @@ __global__ __launch_bounds__(256) void batch_reduce_kernel(const double *__restr
 }
 
 void k_batch_reduce(gpcsd_ctx *c, const double *in, int nb, long stride, int n, double scale, const double *dvec, double dscale,
-                    double *out, hipStream_t s) {
-    hipLaunchKernelGGL(batch_reduce_kernel, dim3(ceil_div((long)n * n, 256)), dim3(256), 0, s, in, nb, stride, n, scale, dvec,
-                       dscale, out);
+                    double *out, hipStream_t s, int B, long s_in) {
+    hipLaunchKernelGGL(batch_reduce_kernel, dim3(ceil_div((long)n * n, 256), B), dim3(256), 0, s, in, nb, stride, n, scale, dvec,
+                       dscale, out, s_in);
     GP_HIP(hipGetLastError());
 }
 
@@ -104,7 +119,20 @@ struct TGradParams {
 };
 
 __global__ __launch_bounds__(256) void temporal_grad_kernel(TGradParams p, const double *__restrict__ Gt,
-                                                            const double *__restrict__ t, int nt, double *partials) {
+                                                            const double *__restrict__ t, int nt, double *partials,
+                                                            const HpDev *__restrict__ tab) {
+    if (tab) {                                  // blockIdx.y = hyper-parameter set: Gt nt*nt apart, partials GR_MAXV*1024 apart
+        const HpDev &h = tab[blockIdx.y];
+        p.ncomp = h.ncomp;
+#pragma unroll
+        for (int cc = 0; cc < GPCSD_MAX_TEMPORAL; ++cc) {
+            p.kind[cc] = h.kind[cc];
+            p.ell[cc] = h.ell_t[cc];
+            p.sigma2[cc] = h.sigma2_t[cc];
+        }
+        Gt += (long)blockIdx.y * nt * nt;
+        partials += (long)blockIdx.y * GR_MAXV * 1024;
+    }
     double v[GR_MAXV];
 #pragma unroll
     for (int q = 0; q < GR_MAXV; ++q) v[q] = 0.0;
@@ -135,27 +163,35 @@ __global__ __launch_bounds__(256) void temporal_grad_kernel(TGradParams p, const
 }
 
 void k_temporal_grad(gpcsd_ctx *c, const gpcsd_hparams *hp, const double *Gt, const double *t, int nt, double *out2C,
-                     hipStream_t s) {
-    TGradParams p;
+                     hipStream_t s, const HpDev *tab, int B, long s_out) {
+    TGradParams p{};
     p.ncomp = hp->n_temporal;
     for (int i = 0; i < hp->n_temporal; ++i) {
         p.kind[i] = hp->kind[i];
         p.ell[i] = hp->ell_t[i];
         p.sigma2[i] = hp->sigma2_t[i];
     }
-    const int nblocks = 256;
-    double *part = c->buf<double>("grad_partials", (size_t)GR_MAXV * 1024);
-    double *tmp = c->buf<double>("grad_tmp", GR_MAXV);
-    hipLaunchKernelGGL(temporal_grad_kernel, dim3(nblocks), dim3(256), 0, s, p, Gt, t, nt, part);
-    hipLaunchKernelGGL(final_sums_kernel, dim3(2 * hp->n_temporal), dim3(256), 0, s, (const double *)part, nblocks, tmp);
-    GP_HIP(hipMemcpyAsync(out2C, tmp, 2 * hp->n_temporal * sizeof(double), hipMemcpyDeviceToDevice, s));
+    const int nblocks = 256, nb = tab ? B : 1;
+    double *part = c->buf<double>("grad_partials", (size_t)GR_MAXV * 1024 * nb);
+    // the sums land directly in the caller's gradient vector(s): 2 * n_temporal values per set, s_out apart
+    hipLaunchKernelGGL(temporal_grad_kernel, dim3(nblocks, nb), dim3(256), 0, s, p, Gt, t, nt, part, tab);
+    hipLaunchKernelGGL(final_sums_kernel, dim3(2 * hp->n_temporal, nb), dim3(256), 0, s, (const double *)part, nblocks, out2C,
+                       (long)GR_MAXV * 1024, s_out);
     GP_HIP(hipGetLastError());
 }
 
 // ---- spatial length scales: sum_gh M_gh Kgl_gh d_gh^2 / ell^3       (covariances.py:89, :216)
 __global__ __launch_bounds__(256) void kgl_grad_kernel(const double *__restrict__ M, const double *__restrict__ Kgl,
                                                        const double *__restrict__ gx1, const double *__restrict__ gx2, int G,
-                                                       int ngl2, double ell1, double ell2, double *partials) {
+                                                       int ngl2, double ell1, double ell2, double *partials,
+                                                       const HpDev *__restrict__ tab) {
+    if (tab) {                                  // blockIdx.y = hyper-parameter set: M, Kgl G*G apart, partials GR_MAXV*1024 apart
+        ell1 = tab[blockIdx.y].ell_s[0];
+        ell2 = tab[blockIdx.y].ell_s[1];
+        M += (long)blockIdx.y * G * G;
+        Kgl += (long)blockIdx.y * G * G;
+        partials += (long)blockIdx.y * GR_MAXV * 1024;
+    }
     double v[2] = {0.0, 0.0};
     const long n2 = (long)G * G;
     for (long e = blockIdx.x * 256L + threadIdx.x; e < n2; e += (long)gridDim.x * 256) {
@@ -174,11 +210,12 @@ __global__ __launch_bounds__(256) void kgl_grad_kernel(const double *__restrict_
 }
 
 void k_kgl_grad(gpcsd_ctx *c, const double *M, const double *Kgl, const double *gx1, const double *gx2, int G, int ngl2,
-                double ell1, double ell2, double *out2, hipStream_t s) {
-    const int nblocks = 512;
-    double *part = c->buf<double>("grad_partials", (size_t)GR_MAXV * 1024);
-    hipLaunchKernelGGL(kgl_grad_kernel, dim3(nblocks), dim3(256), 0, s, M, Kgl, gx1, gx2, G, ngl2, ell1, ell2, part);
-    hipLaunchKernelGGL(final_sums_kernel, dim3(2), dim3(256), 0, s, (const double *)part, nblocks, out2);
+                double ell1, double ell2, double *out2, hipStream_t s, const HpDev *tab, int B, long s_out) {
+    const int nblocks = 512, nb = tab ? B : 1;
+    double *part = c->buf<double>("grad_partials", (size_t)GR_MAXV * 1024 * nb);
+    hipLaunchKernelGGL(kgl_grad_kernel, dim3(nblocks, nb), dim3(256), 0, s, M, Kgl, gx1, gx2, G, ngl2, ell1, ell2, part, tab);
+    hipLaunchKernelGGL(final_sums_kernel, dim3(ngl2 > 0 ? 2 : 1, nb), dim3(256), 0, s, (const double *)part, nblocks, out2,
+                       (long)GR_MAXV * 1024, s_out);
     GP_HIP(hipGetLastError());
 }
 
@@ -188,7 +225,14 @@ void k_kgl_grad(gpcsd_ctx *c, const double *M, const double *Kgl, const double *
 __global__ __launch_bounds__(256) void fwdR_grad_kernel(const double *__restrict__ S, const double *__restrict__ x, int nx,
                                                         const double *__restrict__ gx1, const double *__restrict__ gw1,
                                                         const double *__restrict__ gx2, const double *__restrict__ gw2, int G,
-                                                        int ngl2, double R, double eps, double *partials) {
+                                                        int ngl2, double R, double eps, double *partials,
+                                                        const HpDev *__restrict__ tab) {
+    if (tab) {                                  // blockIdx.y = hyper-parameter set: S nx*G apart, partials GR_MAXV*1024 apart
+        R = tab[blockIdx.y].R;
+        eps = tab[blockIdx.y].eps;
+        S += (long)blockIdx.y * nx * G;
+        partials += (long)blockIdx.y * GR_MAXV * 1024;
+    }
     double v[1] = {0.0};
     const long n2 = (long)nx * G;
     for (long e = blockIdx.x * 256L + threadIdx.x; e < n2; e += (long)gridDim.x * 256) {
@@ -210,11 +254,14 @@ __global__ __launch_bounds__(256) void fwdR_grad_kernel(const double *__restrict
 }
 
 void k_fwdR_grad(gpcsd_ctx *c, const double *S, const double *x, int nx, const double *gx1, const double *gw1, const double *gx2,
-                 const double *gw2, int G, int ngl2, double R, double eps, double *out1, hipStream_t s) {
-    const int nblocks = 256;
-    double *part = c->buf<double>("grad_partials", (size_t)GR_MAXV * 1024);
-    hipLaunchKernelGGL(fwdR_grad_kernel, dim3(nblocks), dim3(256), 0, s, S, x, nx, gx1, gw1, gx2, gw2, G, ngl2, R, eps, part);
-    hipLaunchKernelGGL(final_sums_kernel, dim3(1), dim3(256), 0, s, (const double *)part, nblocks, out1);
+                 const double *gw2, int G, int ngl2, double R, double eps, double *out1, hipStream_t s, const HpDev *tab, int B,
+                 long s_out) {
+    const int nblocks = 256, nb = tab ? B : 1;
+    double *part = c->buf<double>("grad_partials", (size_t)GR_MAXV * 1024 * nb);
+    hipLaunchKernelGGL(fwdR_grad_kernel, dim3(nblocks, nb), dim3(256), 0, s, S, x, nx, gx1, gw1, gx2, gw2, G, ngl2, R, eps, part,
+                       tab);
+    hipLaunchKernelGGL(final_sums_kernel, dim3(1, nb), dim3(256), 0, s, (const double *)part, nblocks, out1,
+                       (long)GR_MAXV * 1024, s_out);
     GP_HIP(hipGetLastError());
 }
 

@@ -68,9 +68,23 @@ struct TemporalParams {
     double sigma2[GPCSD_MAX_TEMPORAL];
 };
 
+// tab != nullptr: blockIdx.z = hyper-parameter set of a batched evaluation: the kernel parameters come from tab[z] and the
+// output is the z-th matrix (s_out apart).  Same arithmetic, so each set gets the bits of a launch of its own.
 template <typename T>
 __global__ __launch_bounds__(256) void temporal_gram_kernel(TemporalParams p, const double *__restrict__ t, int n,
-                                                            const double *__restrict__ tp, int m, double *__restrict__ out) {
+                                                            const double *__restrict__ tp, int m, double *__restrict__ out,
+                                                            const HpDev *__restrict__ tab, long s_out) {
+    if (tab) {
+        const HpDev &h = tab[blockIdx.z];
+        p.ncomp = h.ncomp;
+#pragma unroll
+        for (int cc = 0; cc < GPCSD_MAX_TEMPORAL; ++cc) {
+            p.kind[cc] = h.kind[cc];
+            p.ell[cc] = h.ell_t[cc];
+            p.sigma2[cc] = h.sigma2_t[cc];
+        }
+        out += blockIdx.z * s_out;
+    }
     __shared__ T st[PT_ROWS], stp[PT_COLS];
     const int c0 = blockIdx.x * PT_COLS, r0 = blockIdx.y * PT_ROWS;
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
@@ -103,20 +117,22 @@ __global__ __launch_bounds__(256) void temporal_gram_kernel(TemporalParams p, co
 }
 
 void k_temporal_gram(gpcsd_ctx *c, int ncomp, const int *kind, const double *ell, const double *sigma2, const double *t, int n,
-                     const double *tp, int m, double *out, hipStream_t s) {
-    GP_REQUIRE(ncomp >= 1 && ncomp <= GPCSD_MAX_TEMPORAL, -3, "temporal gram: %d components (max %d)", ncomp,
-               GPCSD_MAX_TEMPORAL);
-    TemporalParams p;
-    p.ncomp = ncomp;
-    for (int i = 0; i < ncomp; ++i) {
-        p.kind[i] = kind[i];
-        p.ell[i] = ell[i];
-        p.sigma2[i] = sigma2[i];
+                     const double *tp, int m, double *out, hipStream_t s, const HpDev *tab, int B, long s_out) {
+    TemporalParams p{};
+    if (!tab) {
+        GP_REQUIRE(ncomp >= 1 && ncomp <= GPCSD_MAX_TEMPORAL, -3, "temporal gram: %d components (max %d)", ncomp,
+                   GPCSD_MAX_TEMPORAL);
+        p.ncomp = ncomp;
+        for (int i = 0; i < ncomp; ++i) {
+            p.kind[i] = kind[i];
+            p.ell[i] = ell[i];
+            p.sigma2[i] = sigma2[i];
+        }
     }
-    dim3 grid(ceil_div(m, PT_COLS), ceil_div(n, PT_ROWS));
+    dim3 grid(ceil_div(m, PT_COLS), ceil_div(n, PT_ROWS), tab ? B : 1);
     ProfScope ps(c, "gram_temporal", 0.0, s);
-    if (c->gram_fp32) hipLaunchKernelGGL(temporal_gram_kernel<float>, grid, dim3(256), 0, s, p, t, n, tp, m, out);
-    else hipLaunchKernelGGL(temporal_gram_kernel<double>, grid, dim3(256), 0, s, p, t, n, tp, m, out);
+    if (c->gram_fp32) hipLaunchKernelGGL(temporal_gram_kernel<float>, grid, dim3(256), 0, s, p, t, n, tp, m, out, tab, s_out);
+    else hipLaunchKernelGGL(temporal_gram_kernel<double>, grid, dim3(256), 0, s, p, t, n, tp, m, out, tab, s_out);
     GP_HIP(hipGetLastError());
 }
 
@@ -125,7 +141,11 @@ template <typename T>
 __global__ __launch_bounds__(256) void fwd_weights_1d_kernel(const double *__restrict__ x, int nx,
                                                              const double *__restrict__ gl_x,
                                                              const double *__restrict__ gl_w, int ngl, double R,
-                                                             double *__restrict__ A) {
+                                                             double *__restrict__ A, const HpDev *__restrict__ tab, long s_out) {
+    if (tab) {
+        R = tab[blockIdx.z].R;
+        A += blockIdx.z * s_out;
+    }
     const long n = (long)nx * ngl;
     for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) {
         const int i = (int)(e / ngl), g = (int)(e % ngl);
@@ -134,11 +154,12 @@ __global__ __launch_bounds__(256) void fwd_weights_1d_kernel(const double *__res
 }
 
 void k_fwd_weights_1d(gpcsd_ctx *c, const double *x, int nx, const double *gl_x, const double *gl_w, int ngl, double R,
-                      double *A, hipStream_t s) {
+                      double *A, hipStream_t s, const HpDev *tab, int B, long s_out) {
+    const dim3 grid(ew_grid((long)nx * ngl), 1, tab ? B : 1);
     if (c->gram_fp32)
-        hipLaunchKernelGGL(fwd_weights_1d_kernel<float>, dim3(ew_grid((long)nx * ngl)), dim3(256), 0, s, x, nx, gl_x, gl_w, ngl, R, A);
+        hipLaunchKernelGGL(fwd_weights_1d_kernel<float>, grid, dim3(256), 0, s, x, nx, gl_x, gl_w, ngl, R, A, tab, s_out);
     else
-        hipLaunchKernelGGL(fwd_weights_1d_kernel<double>, dim3(ew_grid((long)nx * ngl)), dim3(256), 0, s, x, nx, gl_x, gl_w, ngl, R, A);
+        hipLaunchKernelGGL(fwd_weights_1d_kernel<double>, grid, dim3(256), 0, s, x, nx, gl_x, gl_w, ngl, R, A, tab, s_out);
     GP_HIP(hipGetLastError());
 }
 
@@ -150,7 +171,12 @@ __global__ __launch_bounds__(256) void fwd_weights_2d_kernel(const double *__res
                                                              const double *__restrict__ gw1, int ngl1,
                                                              const double *__restrict__ gx2,
                                                              const double *__restrict__ gw2, int ngl2, double R, double eps,
-                                                             double *__restrict__ A) {
+                                                             double *__restrict__ A, const HpDev *__restrict__ tab, long s_out) {
+    if (tab) {
+        R = tab[blockIdx.z].R;
+        eps = tab[blockIdx.z].eps;
+        A += blockIdx.z * s_out;
+    }
     const int G = ngl1 * ngl2;
     const int i = blockIdx.y;
     const T x1 = T(xy[2 * i]), x2 = T(xy[2 * i + 1]);
@@ -163,21 +189,29 @@ __global__ __launch_bounds__(256) void fwd_weights_2d_kernel(const double *__res
 }
 
 void k_fwd_weights_2d(gpcsd_ctx *c, const double *xy, int nx, const double *gx1, const double *gw1, int ngl1, const double *gx2,
-                      const double *gw2, int ngl2, double R, double eps, double *A, hipStream_t s) {
+                      const double *gw2, int ngl2, double R, double eps, double *A, hipStream_t s, const HpDev *tab, int B,
+                      long s_out) {
     const int G = ngl1 * ngl2;
-    dim3 grid(ceil_div(G, 256), nx);
+    dim3 grid(ceil_div(G, 256), nx, tab ? B : 1);
     ProfScope ps(c, "fwd_weights_2d", 0.0, s);
     if (c->gram_fp32)
-        hipLaunchKernelGGL(fwd_weights_2d_kernel<float>, grid, dim3(256), 0, s, xy, nx, gx1, gw1, ngl1, gx2, gw2, ngl2, R, eps, A);
+        hipLaunchKernelGGL(fwd_weights_2d_kernel<float>, grid, dim3(256), 0, s, xy, nx, gx1, gw1, ngl1, gx2, gw2, ngl2, R, eps, A,
+                           tab, s_out);
     else
-        hipLaunchKernelGGL(fwd_weights_2d_kernel<double>, grid, dim3(256), 0, s, xy, nx, gx1, gw1, ngl1, gx2, gw2, ngl2, R, eps, A);
+        hipLaunchKernelGGL(fwd_weights_2d_kernel<double>, grid, dim3(256), 0, s, xy, nx, gx1, gw1, ngl1, gx2, gw2, ngl2, R, eps, A,
+                           tab, s_out);
     GP_HIP(hipGetLastError());
 }
 
 // out(n,m) = exp(-0.5 ((a_i - b_j)/ell)^2)      covariances.py:55, :67, :89
 template <typename T>
 __global__ __launch_bounds__(256) void se_1d_kernel(const double *__restrict__ a, int n, const double *__restrict__ b, int m,
-                                                    double ell, double *__restrict__ out) {
+                                                    double ell, double *__restrict__ out, const HpDev *__restrict__ tab,
+                                                    long s_out) {
+    if (tab) {
+        ell = tab[blockIdx.z].ell_s[0];
+        out += blockIdx.z * s_out;
+    }
     __shared__ T sa[PT_ROWS], sb[PT_COLS];
     const int c0 = blockIdx.x * PT_COLS, r0 = blockIdx.y * PT_ROWS;
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
@@ -198,10 +232,11 @@ __global__ __launch_bounds__(256) void se_1d_kernel(const double *__restrict__ a
     }
 }
 
-void k_se_1d(gpcsd_ctx *c, const double *a, int n, const double *b, int m, double ell, double *out, hipStream_t s) {
-    dim3 grid(ceil_div(m, PT_COLS), ceil_div(n, PT_ROWS));
-    if (c->gram_fp32) hipLaunchKernelGGL(se_1d_kernel<float>, grid, dim3(256), 0, s, a, n, b, m, ell, out);
-    else hipLaunchKernelGGL(se_1d_kernel<double>, grid, dim3(256), 0, s, a, n, b, m, ell, out);
+void k_se_1d(gpcsd_ctx *c, const double *a, int n, const double *b, int m, double ell, double *out, hipStream_t s,
+             const HpDev *tab, int B, long s_out) {
+    dim3 grid(ceil_div(m, PT_COLS), ceil_div(n, PT_ROWS), tab ? B : 1);
+    if (c->gram_fp32) hipLaunchKernelGGL(se_1d_kernel<float>, grid, dim3(256), 0, s, a, n, b, m, ell, out, tab, s_out);
+    else hipLaunchKernelGGL(se_1d_kernel<double>, grid, dim3(256), 0, s, a, n, b, m, ell, out, tab, s_out);
     GP_HIP(hipGetLastError());
 }
 
@@ -212,7 +247,13 @@ void k_se_1d(gpcsd_ctx *c, const double *a, int n, const double *b, int m, doubl
 template <typename T>
 __global__ __launch_bounds__(256) void se_2d_kernel(const double *__restrict__ a1, const double *__restrict__ a2, int na,
                                                     int na2, const double *__restrict__ b1, const double *__restrict__ b2,
-                                                    int nb, int nb2, double ell1d, double ell2d, double *__restrict__ out) {
+                                                    int nb, int nb2, double ell1d, double ell2d, double *__restrict__ out,
+                                                    const HpDev *__restrict__ tab, long s_out) {
+    if (tab) {
+        ell1d = tab[blockIdx.z].ell_s[0];
+        ell2d = tab[blockIdx.z].ell_s[1];
+        out += blockIdx.z * s_out;
+    }
     __shared__ T sa[2][PT_ROWS], sb[2][PT_COLS];
     const T ell1 = T(ell1d), ell2 = T(ell2d);
     const int c0 = blockIdx.x * PT_COLS, r0 = blockIdx.y * PT_ROWS;
@@ -256,20 +297,27 @@ __global__ __launch_bounds__(256) void se_2d_kernel(const double *__restrict__ a
 }
 
 void k_se_2d(gpcsd_ctx *c, const double *a1, const double *a2, int na, int na2, const double *b1, const double *b2, int nb,
-             int nb2, double ell1, double ell2, double *out, hipStream_t s) {
-    dim3 grid(ceil_div(nb, PT_COLS), ceil_div(na, PT_ROWS));
+             int nb2, double ell1, double ell2, double *out, hipStream_t s, const HpDev *tab, int B, long s_out) {
+    dim3 grid(ceil_div(nb, PT_COLS), ceil_div(na, PT_ROWS), tab ? B : 1);
     ProfScope ps(c, "gram_se_2d", 0.0, s);
-    if (c->gram_fp32) hipLaunchKernelGGL(se_2d_kernel<float>, grid, dim3(256), 0, s, a1, a2, na, na2, b1, b2, nb, nb2, ell1, ell2, out);
-    else hipLaunchKernelGGL(se_2d_kernel<double>, grid, dim3(256), 0, s, a1, a2, na, na2, b1, b2, nb, nb2, ell1, ell2, out);
+    if (c->gram_fp32)
+        hipLaunchKernelGGL(se_2d_kernel<float>, grid, dim3(256), 0, s, a1, a2, na, na2, b1, b2, nb, nb2, ell1, ell2, out, tab, s_out);
+    else
+        hipLaunchKernelGGL(se_2d_kernel<double>, grid, dim3(256), 0, s, a1, a2, na, na2, b1, b2, nb, nb2, ell1, ell2, out, tab, s_out);
     GP_HIP(hipGetLastError());
 }
 
-__global__ void add_diag_kernel(double *A, int n, double v) {
+__global__ void add_diag_kernel(double *A, int n, double v, const HpDev *__restrict__ tab, long s_out) {
+    if (tab) {
+        v = tab[blockIdx.z].jitter;
+        A += blockIdx.z * s_out;
+        if (v == 0.0) return;
+    }
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) A[(long)i * n + i] += v;
 }
-void k_add_diag(gpcsd_ctx *c, double *A, int n, double v, hipStream_t s) {
-    hipLaunchKernelGGL(add_diag_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, s, A, n, v);
+void k_add_diag(gpcsd_ctx *c, double *A, int n, double v, hipStream_t s, const HpDev *tab, int B, long s_out) {
+    hipLaunchKernelGGL(add_diag_kernel, dim3(ceil_div(n, 256), 1, tab ? B : 1), dim3(256), 0, s, A, n, v, tab, s_out);
     GP_HIP(hipGetLastError());
 }
 
@@ -287,8 +335,18 @@ void k_fill(gpcsd_ctx *c, double *p, long n, double v, hipStream_t s) {
 __global__ __launch_bounds__(256) void build_D_kernel(const double *__restrict__ es, int nx, const double *__restrict__ et,
                                                       int nt, const double *__restrict__ sig, int nsig,
                                                       double *__restrict__ D, double *__restrict__ Dinv,
-                                                      double *__restrict__ partials) {
+                                                      double *__restrict__ partials, const HpDev *__restrict__ tab) {
     const long n = (long)nx * nt;
+    if (tab) {                       // blockIdx.y = hyper-parameter set: spectra nx / nt apart, D n apart, scalar noise from tab
+        const long b = blockIdx.y;
+        es += b * nx;
+        et += b * nt;
+        sig = &tab[b].sig2n;
+        nsig = 1;
+        D += b * n;
+        if (Dinv) Dinv += b * n;
+        partials += b * 256;
+    }
     double s = 0.0;
     for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) {
         const int x = (int)(e / nt), i = (int)(e % nt);
@@ -307,7 +365,10 @@ __global__ __launch_bounds__(256) void build_D_kernel(const double *__restrict__
     if (threadIdx.x == 0) partials[blockIdx.x] = sh[0];
 }
 
-__global__ __launch_bounds__(256) void sum_small_kernel(const double *__restrict__ p, int n, double *out) {
+// blockIdx.x = segment: p 256 apart, out ostride apart
+__global__ __launch_bounds__(256) void sum_small_kernel(const double *__restrict__ p, int n, double *out, long ostride = 0) {
+    p += blockIdx.x * 256L;
+    out += blockIdx.x * ostride;
     __shared__ double sh[256];
     double s = 0.0;
     for (int i = threadIdx.x; i < n; i += 256) s += p[i];
@@ -321,15 +382,17 @@ __global__ __launch_bounds__(256) void sum_small_kernel(const double *__restrict
 }
 
 int k_build_D(gpcsd_ctx *c, const double *es, int nx, const double *et, int nt, const double *sig, int nsig, double *D,
-              double *Dinv, double *sumlog_out, hipStream_t s) {
+              double *Dinv, double *sumlog_out, hipStream_t s, const HpDev *tab, int B, long s_sumlog) {
     const long n = (long)nx * nt;
     int blocks = (int)((n + 1023) / 1024);
     if (blocks > 256) blocks = 256;
     if (blocks < 1) blocks = 1;
-    double *part = c->buf<double>("buildD_partials", 256);
+    const int nb = tab ? B : 1;
+    double *part = c->buf<double>("buildD_partials", (size_t)256 * nb);
     ProfScope ps(c, "build_D_logdet", 0.0, s);
-    hipLaunchKernelGGL(build_D_kernel, dim3(blocks), dim3(256), 0, s, es, nx, et, nt, sig, nsig, D, Dinv, part);
-    if (sumlog_out) hipLaunchKernelGGL(sum_small_kernel, dim3(1), dim3(256), 0, s, (const double *)part, blocks, sumlog_out);
+    hipLaunchKernelGGL(build_D_kernel, dim3(blocks, nb), dim3(256), 0, s, es, nx, et, nt, sig, nsig, D, Dinv, part, tab);
+    if (sumlog_out)
+        hipLaunchKernelGGL(sum_small_kernel, dim3(nb), dim3(256), 0, s, (const double *)part, blocks, sumlog_out, s_sumlog);
     GP_HIP(hipGetLastError());
     return blocks;
 }

@@ -52,31 +52,47 @@ struct GemmDesc {
 
 void gemm_f64(gpcsd_ctx *c, const GemmDesc &g, hipStream_t s = nullptr);
 
+// ---------------------------------------------------------------- batched hyper-parameter sets
+// Device image of gpcsd_hparams for batched evaluations (gpcsd_loglik_grad_batch): one entry per hyper-parameter set.  The
+// Gram builders / derivative kernels take an optional table: with `tab` they run once for all B sets (the set index is a grid
+// dimension, scalars come from tab[set], outputs are `s_out` apart), without it they are the single-set kernels as before.
+struct HpDev {
+    double R, eps, ell_s[2];
+    int ncomp;
+    int kind[GPCSD_MAX_TEMPORAL];
+    double ell_t[GPCSD_MAX_TEMPORAL], sigma2_t[GPCSD_MAX_TEMPORAL];
+    double sig2n, jitter;
+};
+
 // ---------------------------------------------------------------- elementwise / Gram builders (gram.hip)
 void k_b_fwd_1d(gpcsd_ctx *c, const double *r, long n, double R, double *out, hipStream_t s);
 void k_b_fwd_2d(gpcsd_ctx *c, const double *d1, const double *d2, const double *w, long n, double R, double eps,
                 double *out, hipStream_t s);
 // out(n,m) = sum_c sigma2_c k_c(t_i - tp_j); ncomp components fused (K1-K3 of SURVEY 2a)
 void k_temporal_gram(gpcsd_ctx *c, int ncomp, const int *kind, const double *ell, const double *sigma2,
-                     const double *t, int n, const double *tp, int m, double *out, hipStream_t s);
+                     const double *t, int n, const double *tp, int m, double *out, hipStream_t s, const HpDev *tab = nullptr,
+                     int B = 1, long s_out = 0);
 // A(nx, G) = gl_w[g] * b_fwd_1d(gl_x[g] - x[i], R)
 void k_fwd_weights_1d(gpcsd_ctx *c, const double *x, int nx, const double *gl_x, const double *gl_w, int ngl, double R,
-                      double *A, hipStream_t s);
+                      double *A, hipStream_t s, const HpDev *tab = nullptr, int B = 1, long s_out = 0);
 // A(nx, G=ngl1*ngl2) = w1[g1] w2[g2] * b_fwd_2d(|gl - x|)
 void k_fwd_weights_2d(gpcsd_ctx *c, const double *xy, int nx, const double *gx1, const double *gw1, int ngl1,
-                      const double *gx2, const double *gw2, int ngl2, double R, double eps, double *A, hipStream_t s);
+                      const double *gx2, const double *gw2, int ngl2, double R, double eps, double *A, hipStream_t s,
+                      const HpDev *tab = nullptr, int B = 1, long s_out = 0);
 // SE kernel between two 1D point sets: out(n,m) = exp(-0.5 ((a_i - b_j)/ell)^2)
-void k_se_1d(gpcsd_ctx *c, const double *a, int n, const double *b, int m, double ell, double *out, hipStream_t s);
+void k_se_1d(gpcsd_ctx *c, const double *a, int n, const double *b, int m, double ell, double *out, hipStream_t s,
+             const HpDev *tab = nullptr, int B = 1, long s_out = 0);
 // anisotropic SE between two 2D point sets given as separate coordinate generators:
 // point i of set A = (a1[i / na2], a2[i % na2]) if na2 > 0 (tensor grid) else (a[2i], a[2i+1]) (explicit list)
 void k_se_2d(gpcsd_ctx *c, const double *a1, const double *a2, int na, int na2, const double *b1, const double *b2,
-             int nb, int nb2, double ell1, double ell2, double *out, hipStream_t s);
-void k_add_diag(gpcsd_ctx *c, double *A, int n, double v, hipStream_t s);
+             int nb, int nb2, double ell1, double ell2, double *out, hipStream_t s, const HpDev *tab = nullptr, int B = 1,
+             long s_out = 0);
+void k_add_diag(gpcsd_ctx *c, double *A, int n, double v, hipStream_t s, const HpDev *tab = nullptr, int B = 1, long s_out = 0);
 // D[x*nt + i] = es[x]*et[i] + sig[x or 0]; also sumlog -> *sumlog_out (deterministic)
 // Dinv (optional) = 1/D elementwise.  sumlog_out == nullptr: no final sum; the per-block partials stay in the ctx buffer
 // "buildD_partials" and the return value is their count (a later launch may fold the sum in, or nobody needs it)
 int k_build_D(gpcsd_ctx *c, const double *es, int nx, const double *et, int nt, const double *sig, int nsig, double *D,
-              double *Dinv, double *sumlog_out, hipStream_t s);
+              double *Dinv, double *sumlog_out, hipStream_t s, const HpDev *tab = nullptr, int B = 1, long s_sumlog = 0);
 // lfp host layout [x][t][r] -> device layout [x][r][t] (and back for predictions [z][r][t] -> [z][t][r])
 void k_swap_last2(gpcsd_ctx *c, const double *in, double *out, int n0, int n1, int n2, hipStream_t s);
 void k_fill(gpcsd_ctx *c, double *p, long n, double v, hipStream_t s);
@@ -168,8 +184,9 @@ void stedc_device(gpcsd_ctx *c, const double *d, const double *e, int n, double 
 
 // ---------------------------------------------------------------- analytic gradient pieces (grad.hip)
 // a_x = sum_i et_i/D_xi, b_i = sum_x es_x/D_xi, s1 = sum 1/D
+// B > 1: B hyper-parameter sets, every array contiguous per set (D nx*nt, es nx, et nt, a nx, b nt apart), s1 s_s1 apart
 void k_D_sums(gpcsd_ctx *c, const double *D, const double *es, const double *et, int nx, int nt, double *a, double *b,
-              double *s1_out, hipStream_t s);
+              double *s1_out, hipStream_t s, int B = 1, long s_s1 = 0);
 // Ghs[y][x] += -1/2 (sig_y - sig_x)/(es_x - es_y) Ssum[x][y] for x != y, |es_x - es_y| > tiny
 void k_siglist_eigvec_term(gpcsd_ctx *c, double *Ghs, const double *Ssum, const double *es, const double *sig, int nx,
                            double tiny, hipStream_t s);
@@ -178,17 +195,20 @@ void k_per_trial_quad(gpcsd_ctx *c, const double *alpha, const double *D, int nx
 // out[x] = sum_k B[x*rowlen + k]^2
 void k_rowgroup_sumsq(gpcsd_ctx *c, const double *B, int nrows, long rowlen, double *out, hipStream_t s);
 // out (n,n) = scale * sum_b in[b*stride + e] + dscale * diag(dvec)
+// B > 1: per hyper-parameter set, inputs s_in apart, dvec n apart, out n*n apart
 void k_batch_reduce(gpcsd_ctx *c, const double *in, int nb, long stride, int n, double scale, const double *dvec, double dscale,
-                    double *out, hipStream_t s);
+                    double *out, hipStream_t s, int B = 1, long s_in = 0);
 // out[2c] = <Gt, dKt/d ell_c>, out[2c+1] = <Gt, dKt/d sigma2_c>
+// with a table: B sets (Gt nt*nt apart, outputs s_out apart); hp still supplies n_temporal
 void k_temporal_grad(gpcsd_ctx *c, const gpcsd_hparams *hp, const double *Gt, const double *t, int nt, double *out2C,
-                     hipStream_t s);
+                     hipStream_t s, const HpDev *tab = nullptr, int B = 1, long s_out = 0);
 // out[0..1] = <M, dKgl/d ell_1>, <M, dKgl/d ell_2>   (ngl2 == 0: 1D, only out[0] meaningful)
 void k_kgl_grad(gpcsd_ctx *c, const double *M, const double *Kgl, const double *gx1, const double *gx2, int G, int ngl2,
-                double ell1, double ell2, double *out2, hipStream_t s);
+                double ell1, double ell2, double *out2, hipStream_t s, const HpDev *tab = nullptr, int B = 1, long s_out = 0);
 // out[0] = 2 <S, dA/dR>
 void k_fwdR_grad(gpcsd_ctx *c, const double *S, const double *x, int nx, const double *gx1, const double *gw1, const double *gx2,
-                 const double *gw2, int G, int ngl2, double R, double eps, double *out1, hipStream_t s);
+                 const double *gw2, int G, int ngl2, double R, double eps, double *out1, hipStream_t s, const HpDev *tab = nullptr,
+                 int B = 1, long s_out = 0);
 
 // ---------------------------------------------------------------- Cholesky (chol.hip)
 // In-place lower Cholesky of A (n,n) row-major; strictly-upper part zeroed.  d_status: 0 ok, k+1 = pivot k <= 0.

@@ -80,7 +80,7 @@ class GPCSD2D(GPCSDModel):
             return -np.inf
 
     def fit(self, n_restarts=10, method="L-BFGS-B", fix_R=False, verbose=False, profile=False,
-            options={"maxiter": 500, "disp": False, "gtol": 1e-5, "ftol": 1e7 * np.finfo(float).eps}, starts=None, workers=1):
+            options={"maxiter": 500, "disp": False, "gtol": 1e-5, "ftol": 1e7 * np.finfo(float).eps}, starts=None, workers=1, batch=1):
         """Multi-restart MAP estimate.  profile=True times one objective and one gradient evaluation per GPU kernel
         (the reference cProfiles them) and returns the table without optimising."""
         if profile:
@@ -95,7 +95,7 @@ class GPCSD2D(GPCSDModel):
             grad = ctx.prof_all()
             ctx.prof_enable(False)
             return {"objective": obj, "gradient": grad}
-        return self._fit(n_restarts, method, fix_R, verbose, options, starts=starts, workers=workers)
+        return self._fit(n_restarts, method, fix_R, verbose, options, starts=starts, workers=workers, batch=batch)
 
     def sample_prior(self, ntrials, type="csd", seed=1):
         """Prior draws of CSD and/or LFP; returns (csd, lfp) with NaN for the part not requested."""

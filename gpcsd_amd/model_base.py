@@ -226,6 +226,27 @@ class GPCSDModel:
             ll, g = float(red[0]), red[1:]
         return ll, g
 
+    def _loglik_and_grad_natural_batch(self, hps):
+        """[(loglik, gradient) or LinAlgError] for a list of hyper-parameter structs: one shared chain of launches
+        (gpcsd_loglik_grad_batch); shards combine with ONE all-reduce for the whole batch."""
+        ctx = self._sync_device()
+        ng = 1 + self.dim + 2 * len(self.temporal_cov_list) + 1
+        sumlog, quad, g, st = ctx.loglik_grad_batch(hps, ng)
+        r_local = self._local_lfp().shape[2]
+        ll = -0.5 * r_local * sumlog - 0.5 * quad
+        sh = getattr(self, "_sharding", None)
+        if sh is not None:                       # both pieces are additive over shards; a set that failed anywhere fails everywhere
+            red = sh.allreduce_sum(np.concatenate([ll, g.ravel(), (st != 0).astype(np.float64)]))
+            B = len(hps)
+            ll, g, st = red[:B], red[B:B + B * ng].reshape(B, ng), red[B + B * ng:]
+        out = []
+        for b in range(len(hps)):
+            if st[b] != 0:
+                out.append(np.linalg.LinAlgError("numerical failure in the eigensolver (hyper-parameter set %d of the batch)" % b))
+            else:
+                out.append((float(ll[b]), np.array(g[b])))
+        return out
+
     # ------------------------------------------------------------------ fit
     def _param_slots(self):
         """[(getter, setter, prior, (min, max), scale)] in the reference's log-parameter order."""
@@ -380,10 +401,38 @@ class GPCSDModel:
         m._resident = {}
         return m
 
-    def _run_restart(self, tparams0, method, fix_R, options, bounds):
+    def _batch_can_evaluate(self):
+        return (getattr(self, "_use_analytic_grad", True) and self._sig2n_is_scalar() and not self._uses_host_kt())
+
+    def _objective_and_grad_batch(self, items, fix_R):
+        """{key: (objective, gradient) or exception} for [(key, tparams)]: the lock-step evaluation behind fit(batch=k).
+        Runs single-threaded (every optimiser chain is blocked on its result), so walking the shared param dicts is safe."""
+        with np.errstate(all="ignore"):
+            hps, keep, lps, tps = [], [], [], []
+            for _, tp in items:
+                tp = np.asarray(tp, dtype=np.float64)
+                self._set_from_tparams(tp, fix_R)
+                lps.append(self._log_prior())
+                hp, k = self._hparams(self.JITTER)
+                hps.append(hp)
+                keep.append(k)
+                tps.append(tp)
+            res = self._loglik_and_grad_natural_batch(hps)
+            out = {}
+            for (key, _), tp, lp, r in zip(items, tps, lps, res):
+                if isinstance(r, Exception):
+                    out[key] = r
+                    continue
+                ll, g_nat = r
+                self._set_from_tparams(tp, fix_R)            # the chain rule reads the values back from the dicts
+                out[key] = (-1.0 * (ll + lp), self._chain_rule(tp, g_nat, fix_R))
+            return out
+
+    def _run_restart(self, tparams0, method, fix_R, options, bounds, evaluate=None):
+        """One L-BFGS-B chain.  evaluate: callback x -> (objective, gradient) of a lock-step batch; default: this model."""
+        fun = evaluate if evaluate is not None else (lambda tp: self._objective_and_grad(tp, fix_R))
         try:
-            res = scipy.optimize.minimize(lambda tp: self._objective_and_grad(tp, fix_R), tparams0, method=method,
-                                          options=options, bounds=bounds, jac=True)
+            res = scipy.optimize.minimize(fun, tparams0, method=method, options=options, bounds=bounds, jac=True)
             return res.fun, res.x, res.message
         except (ValueError, np.linalg.LinAlgError) as e:
             print(e)
@@ -391,7 +440,7 @@ class GPCSDModel:
                 print("\nrestarting optimization...")
             return None
 
-    def _fit(self, n_restarts, method, fix_R, verbose, options, starts=None, workers=1):
+    def _fit(self, n_restarts, method, fix_R, verbose, options, starts=None, workers=1, batch=1):
         bounds = self._bounds()
         # starting points are drawn up front, in the order the sequential loop of the reference consumes the RNG
         # (the optimiser itself draws nothing), so results do not depend on `workers` or on the number of ranks
@@ -413,7 +462,20 @@ class GPCSDModel:
         mine = [k for k in range(n_restarts) if rs is None or k % rs.world_size == rs.rank]
         results = {}
         workers = max(1, min(int(workers), len(mine)))
-        if workers == 1:
+        batch = max(1, min(int(batch), len(mine)))
+        if batch > 1 and self._batch_can_evaluate():
+            # lock-step restarts: `batch` SciPy chains alive at a time, their evaluations served by ONE batched device call
+            from .lockstep import run_chains
+            out, ev = run_chains([starts[k] for k in mine],
+                                 lambda s0, evaluate: self._run_restart(s0, method, fix_R, options, bounds, evaluate),
+                                 lambda items: self._objective_and_grad_batch(items, fix_R), batch)
+            for i, k in enumerate(mine):
+                r = out[i]
+                if isinstance(r, Exception):
+                    raise r
+                results[k] = r
+            self.fit_batches_ = (ev.batches, ev.points)
+        elif workers == 1:
             for k in tqdm(mine, desc="Restarts"):
                 results[k] = self._run_restart(starts[k], method, fix_R, options, bounds)
         else:

@@ -169,6 +169,13 @@ int gpcsd_loglik_parts(gpcsd_ctx *ctx, const gpcsd_hparams *hp, double *out2);
  * Replaces the autograd tape of gpcsd1d.py:211 / gpcsd2d.py:250.  Both L_loc and grad are sums over trials plus a
  * term linear in the resident trial count, so shards combine by plain summation over ranks. */
 int gpcsd_loglik_grad(gpcsd_ctx *ctx, const gpcsd_hparams *hp, double *out2, double *grad, int ngrad);
+/* The same evaluation for `nsets` hyper-parameter sets in ONE chain of launches -- the restarts of fit() (gpcsd1d.py:193-220,
+ * gpcsd2d.py:230-262) are independent optimiser chains whose evaluations are latency-bound, so sets evaluated together
+ * share every launch.  out2 is (nsets, 2), grad (nsets, ngrad); status[i] > 0 reports a numerical failure of set i alone
+ * (the others are valid).  Every set gets exactly the bits a gpcsd_loglik_grad call of its own returns.  All sets must have
+ * the same temporal kernel kinds and a scalar sig2n (per-electrode lists: nsets == 1). */
+int gpcsd_loglik_grad_batch(gpcsd_ctx *ctx, const gpcsd_hparams *hp, int nsets, double *out2, double *grad, int ngrad,
+                            int *status);
 /* GPCSD{1,2}D.predict(z, t, type) gpcsd1d.py:248-293 / gpcsd2d.py:289-334.
  * z (nz, dim), tstar (ntstar) with ntstar == nt (the reference raises ValueError otherwise -> rc -22).
  * Outputs (any may be NULL): *_list is (n_temporal, nz, ntstar, ntrials), sums are (nz, ntstar, ntrials). */

@@ -304,3 +304,38 @@ def test_hip_path_trial_sharding_world2_one_gpu(case):
         assert abs(ll2 - ll_ref) / abs(ll_ref) < 1e-6
         assert shape[2] == (5 if case.startswith("1d_odd") else 3) and perr < 1e-6
     assert np.allclose(res[0][3], res[1][3], rtol=1e-12, atol=0)      # the reduced gradient is identical on both ranks
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# lock-step evaluation of optimiser chains (host logic of fit(batch=k); no device needed)
+# ---------------------------------------------------------------------------------------------------------------------
+def test_lockstep_chains_match_independent_runs():
+    import scipy.optimize
+    from gpcsd_amd.lockstep import run_chains
+
+    def fg(x):
+        return float((x[0] ** 2 - 1.0) ** 2 + 0.3 * x[0] + (x[1] - 0.5) ** 2), np.array([4 * x[0] * (x[0] ** 2 - 1) + 0.3,
+                                                                                           2 * (x[1] - 0.5)])
+    sizes = []
+
+    def batch_fn(items):
+        sizes.append(len(items))
+        out = {}
+        for k, x in items:
+            out[k] = ValueError("poisoned start") if abs(x[0] - 7.0) < 1e-12 else fg(x)
+        return out
+
+    def chain(x0, evaluate):
+        try:
+            r = scipy.optimize.minimize(evaluate, x0, jac=True, method="L-BFGS-B", options={"maxiter": 100})
+            return r.fun, r.x, r.nit
+        except ValueError:
+            return None
+    starts = [np.array([s0, -s0]) for s0 in np.linspace(-2.0, 2.0, 9)] + [np.array([7.0, 0.0])]
+    out, ev = run_chains(starts, chain, batch_fn, width=4)
+    assert out[9] is None                                        # the failing chain ends alone, the others go on
+    for i, s0 in enumerate(starts[:9]):
+        ref = scipy.optimize.minimize(fg, s0, jac=True, method="L-BFGS-B", options={"maxiter": 100})
+        assert out[i][0] == ref.fun and np.array_equal(out[i][1], ref.x)
+    assert max(sizes) == 4 and ev.points == sum(sizes) and ev.batches == len(sizes)
+    assert sum(1 for n in sizes if n == 4) > len(sizes) // 2      # most evaluations really were batched four wide

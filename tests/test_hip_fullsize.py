@@ -202,6 +202,63 @@ def test_cfg5_shape_fit_two_restarts_vs_scipy_on_oracle(gram_precision):
     assert np.all(dev < (2e-3 if gram_precision == 64 else 5e-2))
 
 
+# ------------------------------------------------------------------------------------------------ batched evaluations (N2)
+@pytest.mark.parametrize("name", ["cfg2s_1d_24x500x8", "2d_npx_96x120x3", "1d_odd_17x37x5", "cfg3s_2d_384x500x2"])
+def test_loglik_grad_batch_is_bitwise_the_sequential_evaluation(name):
+    """gpcsd_loglik_grad_batch: B hyper-parameter sets through one chain of launches.  Every set must get exactly the bits
+    of a gpcsd_loglik_grad call of its own (same kernels, tile configurations and reduction order), and one failing set
+    must not take the others down."""
+    c, g, geom, hp, lfp = load_model_case(name)
+    m = _model_from_case(c, g, lfp)
+    ctx = m._sync_device()
+    rs = np.random.RandomState(5)
+    tp0 = m._current_tparams()
+    B = 5 if c["x"].shape[0] < 200 else 3
+    tps = [tp0 + 0.08 * rs.standard_normal(tp0.size) for _ in range(B)]
+    hps, keep, seq = [], [], []
+    ng = 1 + m.dim + 2 * len(m.temporal_cov_list) + 1
+    for tp in tps:
+        m._set_from_tparams(tp, False)
+        h, k = m._hparams(m.JITTER)
+        hps.append(h)
+        keep.append(k)
+        seq.append(ctx.loglik_grad(h, ng))
+    sumlog, quad, grad, st = ctx.loglik_grad_batch(hps, ng)
+    assert np.all(st == 0)
+    for b in range(B):
+        assert sumlog[b] == seq[b][0] and quad[b] == seq[b][1]
+        assert np.array_equal(grad[b], seq[b][2])
+    # against the oracle as well (first set): value and central-difference gradient in log-parameters
+    m._set_from_tparams(tps[0], False)
+    val, gr = m._objective_and_grad(tps[0], False)
+    out = m._objective_and_grad_batch([(7, tps[0])], False)
+    assert out[7][0] == val and np.array_equal(out[7][1], gr)
+    # a non-finite set fails alone
+    m._set_from_tparams(tps[1], False)
+    m.R["value"] = float("nan")
+    hbad, kbad = m._hparams(m.JITTER)
+    s2, q2, g2, st2 = ctx.loglik_grad_batch([hps[0], hbad, hps[2]], ng)
+    assert st2[1] != 0 and st2[0] == 0 and st2[2] == 0
+    assert s2[0] == seq[0][0] and q2[2] == seq[2][1] and np.array_equal(g2[2], seq[2][2])
+
+
+def test_fit_lockstep_batch_equals_sequential_restarts():
+    """fit(batch=k): k SciPy chains advance in lock-step on batched evaluations; since every evaluation is bitwise the one a
+    chain on its own would get, the optima are identical to the sequential loop's."""
+    m1, c, geom, lfp = _cfg5_model()
+    m2, *_ = _cfg5_model()
+    np.random.seed(3)
+    starts = [m1._sample_start(False) for _ in range(5)]
+    opts = {"maxiter": 6, "disp": False, "gtol": 1e-5, "ftol": 1e7 * np.finfo(float).eps}
+    m1.fit(n_restarts=5, options=opts, starts=starts)
+    m2.fit(n_restarts=5, options=opts, starts=starts, batch=4)
+    assert np.array_equal(np.asarray(m1.fit_nll_values_), np.asarray(m2.fit_nll_values_))
+    assert all(np.array_equal(a, b) for a, b in zip(m1.fit_params_, m2.fit_params_))
+    assert m1.R["value"] == m2.R["value"]
+    nb, npts = m2.fit_batches_
+    assert npts > nb                                             # evaluations really shared launches
+
+
 # ------------------------------------------------------------------------------------------------ contract edges
 class _RationalQuadraticCov:
     """A user-defined temporal covariance (covariances.py:235-238 lets any object with compute_Kt in): not stationary-in-
@@ -259,6 +316,7 @@ def test_user_defined_temporal_covariance(trend):
     e[2] = 1e-4                                # (differences of a 1e-10-accurate objective: only a coarse cross-check)
     assert np.all(np.isfinite(g0)) and np.isfinite(f0)
     assert abs((m._objective(tp + e, False) - m._objective(tp - e, False)) / 2e-4 - g0[2]) <= 2e-2 * max(1.0, abs(g0[2]))
+    m._set_from_tparams(tp, False)             # (the differences left perturbed values in the param dicts)
     # switching back to built-in kernels on the same context drops the host Gram
     m.temporal_cov_list = [se]
     hp1 = O.make_hparams(110.0, (210.0,), [(O.SE, 9.0, 0.6)], 0.07, jitter=1e-8)
