@@ -90,6 +90,7 @@ SIGNATURES = {
     "gpcsd_sample_prior": (_I, [_P, ctypes.POINTER(HParams), _I, _DP, _I, _DP]),
     "gpcsd_set_gram_precision": (_I, [_P, _I]),
     "gpcsd_fold_gemm": (_I, [_P, _I, ctypes.POINTER(_L)]),
+    "gpcsd_decomposition_cache": (_I, [_P, _I, ctypes.POINTER(_L)]),
     "gpcsd_prof_enable": (_I, [_P, _I]),
     "gpcsd_prof_reset": (_I, [_P]),
     "gpcsd_prof_get": (_I, [_P, ctypes.c_char_p, _DP, ctypes.POINTER(_L), _DP]),
@@ -528,6 +529,13 @@ class Context:
         """Switch (True/False) or query (None) the folded-basis GEMM path; returns the number of folded calls so far."""
         n = _L(0)
         self._check(self._lib.gpcsd_fold_gemm(self._h, -1 if on is None else int(bool(on)), ctypes.byref(n)))
+        return int(n.value)
+
+    def decomposition_cache(self, on=None):
+        """Switch (True/False) or query (None) the reuse of an unchanged side's eigendecomposition between consecutive
+        fused calls; returns the number of sides reused so far."""
+        n = _L(0)
+        self._check(self._lib.gpcsd_decomposition_cache(self._h, -1 if on is None else int(bool(on)), ctypes.byref(n)))
         return int(n.value)
 
     def prof_enable(self, on=True):

@@ -32,6 +32,7 @@ static void drain_after_failure(gpcsd_ctx *c) {
     if (c->stream2) (void)hipStreamSynchronize(c->stream2);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     c->status_zeroed = false;
+    c->decomp_gen[0] = c->decomp_gen[1] = -1;   // whatever the failed call left behind is not reused
 }
 
 void gpcsd_ctx::prof_collect() {
@@ -272,10 +273,25 @@ struct EigState {
     int *status;
     // two-stream front half: the temporal chain (Kt, its eigen-decomposition) runs on stream2 and has not been waited
     // for yet; join_temporal() makes Qt / et / D available on the main stream
-    bool pending = false;
+    bool pending = false;          // D has not been formed yet (two-stream front half: join_temporal does it)
+    bool wait_temporal = false;    // the temporal chain was queued on stream2 in this call: the main stream must wait for it
     const double *d_sig = nullptr;
     int nsig = 0;
 };
+
+// Decomposition cache: true when side `slot` (0 spatial, 1 temporal) was left in the context's buffers by the previous
+// front half with the same key and nothing has used that solver slot since.  Records the key for the next call otherwise.
+static bool decomp_cached(gpcsd_ctx *c, int slot, const void *key, size_t bytes) {
+    std::vector<unsigned char> &k = c->decomp_key[slot];
+    const bool hit = c->decomp_cache_on && c->decomp_gen[slot] == c->eig_gen[slot] && k.size() == bytes &&
+                     memcmp(k.data(), key, bytes) == 0;
+    if (hit) {
+        ++c->decomp_cache_hits;
+        return true;
+    }
+    k.assign((const unsigned char *)key, (const unsigned char *)key + bytes);
+    return false;
+}
 
 static bool two_stream_front() {            // GPCSD_TWO_STREAM=0: single batched chain (A/B comparisons)
     static const bool off = getenv("GPCSD_TWO_STREAM") && getenv("GPCSD_TWO_STREAM")[0] == '0';
@@ -344,19 +360,48 @@ EigState front_half(gpcsd_ctx *c, const gpcsd_hparams *hp, double jitter, bool n
     // this one; only a call that did not end that way (first call, an exception in between) clears them here.
     if (!c->status_zeroed) GP_HIP(hipMemsetAsync(e.status, 0, 4 * sizeof(int), s));
     c->status_zeroed = false;
-    GP_HIP(hipEventRecord(c->ev_fork, s));
-    GP_HIP(hipStreamWaitEvent(s2, c->ev_fork, 0));
-    make_kt(s2);
-    {
-        ProfScope ps(c, "eigh_temporal", 9.0 * (double)nt * nt * nt, s2);
-        eigh_pair_device(c, nullptr, 0, nullptr, nullptr, nullptr, Kt, nt, e.et, e.Qt, sym_t, e.status + 1, s2, need_merged);
+    struct {                                   // everything the temporal side's result depends on
+        long epoch;
+        int nt, ncomp, kind[GPCSD_MAX_TEMPORAL], merged, fold, host;
+        double ell[GPCSD_MAX_TEMPORAL], s2[GPCSD_MAX_TEMPORAL];
+    } kt_key;
+    memset(&kt_key, 0, sizeof(kt_key));
+    kt_key.epoch = c->grid_epoch; kt_key.nt = nt; kt_key.ncomp = hp->n_temporal; kt_key.merged = need_merged;
+    kt_key.fold = sym_t != nullptr; kt_key.host = host_kt;
+    for (int i = 0; i < hp->n_temporal; ++i) {
+        kt_key.kind[i] = hp->kind[i];
+        kt_key.ell[i] = hp->ell_t[i];
+        kt_key.s2[i] = hp->sigma2_t[i];
     }
-    GP_HIP(hipEventRecord(c->ev_join, s2));
+    if (!decomp_cached(c, 1, &kt_key, sizeof(kt_key))) {
+        GP_HIP(hipEventRecord(c->ev_fork, s));
+        GP_HIP(hipStreamWaitEvent(s2, c->ev_fork, 0));
+        make_kt(s2);
+        {
+            ProfScope ps(c, "eigh_temporal", 9.0 * (double)nt * nt * nt, s2);
+            eigh_pair_device(c, nullptr, 0, nullptr, nullptr, nullptr, Kt, nt, e.et, e.Qt, sym_t, e.status + 1, s2, need_merged);
+        }
+        GP_HIP(hipEventRecord(c->ev_join, s2));
+        c->decomp_gen[1] = c->eig_gen[1];
+        e.wait_temporal = true;
+    }
     double *d_sig = c->upload_cached<double>("sig2n", hp->sig2n, hp->n_sig2n);
-    build_kphi(c, g, hp->R, hp->eps, hp->ell_s, nullptr, 0, jitter, Ks, s);
-    {
-        ProfScope ps(c, "eigh_spatial", 9.0 * (double)nx * nx * nx, s);
-        eigh_pair_device(c, Ks, nx, e.es, e.Qs, sym_s, nullptr, 0, nullptr, nullptr, nullptr, e.status, s, need_merged);
+    struct {
+        long epoch;
+        int nx, merged, fold;
+        double R, eps, ell[2], jitter;
+    } ks_key;
+    memset(&ks_key, 0, sizeof(ks_key));
+    ks_key.epoch = c->grid_epoch; ks_key.nx = nx; ks_key.merged = need_merged; ks_key.fold = sym_s != nullptr;
+    ks_key.R = hp->R; ks_key.eps = g.dim == 2 ? hp->eps : 0.0; ks_key.ell[0] = hp->ell_s[0];
+    ks_key.ell[1] = g.dim == 2 ? hp->ell_s[1] : 0.0; ks_key.jitter = jitter;
+    if (!decomp_cached(c, 0, &ks_key, sizeof(ks_key))) {
+        build_kphi(c, g, hp->R, hp->eps, hp->ell_s, nullptr, 0, jitter, Ks, s);
+        {
+            ProfScope ps(c, "eigh_spatial", 9.0 * (double)nx * nx * nx, s);
+            eigh_pair_device(c, Ks, nx, e.es, e.Qs, sym_s, nullptr, 0, nullptr, nullptr, nullptr, e.status, s, need_merged);
+        }
+        c->decomp_gen[0] = c->eig_gen[0];
     }
     e.pending = true;
     e.d_sig = d_sig;
@@ -483,7 +528,8 @@ static void fold_proj_spatial(gpcsd_ctx *c, const FoldView &fs, const double *in
 // sumlog = false: the caller either does not need sum(log D) (predict) or folds the final sum of the partials into a later
 // launch (loglik: the reduce of the quadratic form); returns the number of partials left in "buildD_partials" (0: none built).
 int join_temporal(gpcsd_ctx *c, EigState &e, const FoldMode *fm = nullptr, bool sumlog = true) {
-    if (e.pending) GP_HIP(hipStreamWaitEvent(c->stream, c->ev_join, 0));
+    if (e.wait_temporal) GP_HIP(hipStreamWaitEvent(c->stream, c->ev_join, 0));
+    e.wait_temporal = false;
     double *out = sumlog ? e.scal : nullptr;
     int np = 0;
     if (fm && fm->on) np = k_build_D(c, fm->fs.w, c->nx, fm->ft.w, c->nt, e.d_sig, e.nsig, e.D, e.Dinv, out, c->stream);
@@ -508,6 +554,7 @@ int finish_call(gpcsd_ctx *c, const EigState &e, double *scal_out, int nscal) {
         char b[128];
         snprintf(b, sizeof(b), "numerical failure (status %d): eigensolver did not converge or matrix not positive definite", st[0]);
         c->last_error = b;
+        c->decomp_gen[0] = c->decomp_gen[1] = -1;     // a failed decomposition is never reused
         return st[0] > 0 ? st[0] : 1;
     }
     return 0;
@@ -648,6 +695,7 @@ extern "C" int gpcsd_set_geometry_1d(gpcsd_ctx *c, const double *x, int nx, cons
     c->upload<double>("geo_gw1", gl_w, ngl);
     c->sync();
     c->dim = 1; c->geo_nx = nx; c->ngl1 = ngl; c->ngl2 = 0;
+    ++c->grid_epoch;
     // electrodes mirror-symmetric about the centre of a symmetric quadrature rule -> Ks commutes with the reflection
     c->sym_s = SymDev();
     c->sym_z = SymDev();
@@ -676,6 +724,7 @@ extern "C" int gpcsd_set_geometry_2d(gpcsd_ctx *c, const double *xy, int nx, con
     c->upload<double>("geo_gw2", gl_w2, ngl2);
     c->sync();
     c->dim = 2; c->geo_nx = nx; c->ngl1 = ngl1; c->ngl2 = ngl2;
+    ++c->grid_epoch;
     // reflections about the centre of the (symmetric) tensor quadrature rule that map the electrode set onto itself:
     // point reflection first (the Neuropixels checkerboard has it), then single-axis mirrors
     c->sym_s = SymDev();
@@ -702,6 +751,7 @@ extern "C" int gpcsd_set_time(gpcsd_ctx *c, const double *t, int nt) {
     c->upload<double>("time_t", t, nt);
     c->sync();
     c->time_nt = nt;
+    ++c->grid_epoch;
     c->time_host.assign(t, t + nt);
     c->lfp_fold_sig = 0;
     // a time grid symmetric about its midpoint (any uniform grid) makes every stationary Kt centro-symmetric
@@ -1146,6 +1196,7 @@ extern "C" int gpcsd_loglik_dense_chol(gpcsd_ctx *c, const double *Ks, int nx, c
 extern "C" int gpcsd_set_host_temporal_gram(gpcsd_ctx *c, const double *Kt, int nt, const double *Kt_cross, int ncomp,
                                             int ntstar) {
     GP_API_BEGIN(c)
+    ++c->grid_epoch;                            // a new host Gram is a new temporal problem
     if (!Kt) {                                  // back to the built-in SE / Matern builders
         c->host_kt_on = false;
         c->host_kt.clear();
@@ -1174,7 +1225,19 @@ extern "C" int gpcsd_set_host_temporal_gram(gpcsd_ctx *c, const double *Kt, int 
 extern "C" int gpcsd_set_gram_precision(gpcsd_ctx *c, int bits) {
     GP_API_BEGIN(c)
     GP_REQUIRE(bits == 32 || bits == 64, -3, "gram precision must be 32 or 64 bits (got %d)", bits);
+    if (c->gram_fp32 != (bits == 32)) ++c->grid_epoch;
     c->gram_fp32 = bits == 32;
+    return 0;
+    GP_API_END(c)
+}
+
+extern "C" int gpcsd_decomposition_cache(gpcsd_ctx *c, int on, long *hits) {
+    GP_API_BEGIN(c)
+    if (on >= 0) {
+        c->decomp_cache_on = on != 0;
+        c->decomp_gen[0] = c->decomp_gen[1] = -1;
+    }
+    if (hits) *hits = c->decomp_cache_hits;
     return 0;
     GP_API_END(c)
 }

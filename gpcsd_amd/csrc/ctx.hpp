@@ -101,6 +101,17 @@ struct gpcsd_ctx {
     bool gram_fp32 = false;                 // gpcsd_set_gram_precision(): Gram builders evaluate in float (cfg5 variant)
     bool fold_gemm_on = true;               // gpcsd_fold_gemm()
     long fold_gemm_calls = 0;
+    // Decomposition cache (capi.hip::front_half): predict() right after loglik() / fit() with the same hyper-parameters
+    // (neuropixels/fit_gpcsd2d.py:101-107) decomposes the very same Kt again, repeated predict() calls the same Ks as well.
+    // The kernels are deterministic, so reusing what the previous call left in the context's buffers gives the same bits.
+    // A side is reused when its key (hyper-parameters of that side, grids, precision, output form) matches and nothing has
+    // run on that solver slot since (eig_gen counts every eigh_pair_device use of a slot).
+    bool decomp_cache_on = true;
+    long decomp_cache_hits = 0;
+    long eig_gen[2] = {0, 0};
+    std::vector<unsigned char> decomp_key[2];
+    long decomp_gen[2] = {-1, -1};
+    long grid_epoch = 0;                    // bumped by set_geometry / set_time / set_host_temporal_gram / set_gram_precision
     // user-defined temporal covariances (covariances.py:235-238: any object with compute_Kt): the caller evaluates the
     // Gram matrices on the host and hands them over (gpcsd_set_host_temporal_gram); the fused calls then upload them
     // instead of running the SE / Matern builders.  Copies: no host pointer outlives the setter.

@@ -250,6 +250,8 @@ void eigh_pair_device(gpcsd_ctx *c, double *A0, int n0, double *w0, double *Z0, 
                       double *w1, double *Z1, const SymDev *sym1, int *d_status, hipStream_t s, bool need_merged, int count,
                       int status_stride) {
     if (count < 1) count = 1;
+    if (n0 > 0) ++c->eig_gen[0];               // whatever a previous call left in this slot's outputs is about to be replaced
+    if (n1 > 0) ++c->eig_gen[1];
     // the limit applies to what the solver actually factorises: a symmetry-folded problem is two half-size ones
     const int m0 = fold_applies(sym0, n0) ? std::max(sym0->ns, sym0->na) : n0;
     const int m1 = fold_applies(sym1, n1) ? std::max(sym1->ns, sym1->na) : n1;

@@ -185,12 +185,17 @@ __global__ __launch_bounds__(RT_NTH) void sytrd_rtail_kernel(SytrdBatch b) {
             const double dk = row[k], alpha = row[k + 1];
             double r, u1, beta;
             rt_house(alpha, xnorm2, true, r, u1, beta);
+            double *__restrict__ vrow = P.V + (long)(k0 + k) * n + k0;      // reflector k (zeros up to k, u_1 at k+1)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int c = lane + 64 * q;
                 double t = (c > k + 1) ? x[q] : 0.0;
                 t = (c == k + 1) ? u1 : t;
-                if (c < T) sv[c] = (r != 0.0 || c == k + 1) ? t : 0.0;
+                t = (r != 0.0 || c == k + 1) ? t : 0.0;
+                if (c < T) {
+                    sv[c] = t;
+                    vrow[c] = t;                                             // fire and forget: the barriers wait for LDS only
+                }
             }
             if (lane == 0) {
                 sd[OFF + k] = dk;
@@ -202,7 +207,6 @@ __global__ __launch_bounds__(RT_NTH) void sytrd_rtail_kernel(SytrdBatch b) {
         }
         __syncthreads();                                             // ---- A: v, scalars published
         const double rr = s_r, au = s_u1;
-        if (tid < T) P.V[(long)(k0 + k) * n + k0 + tid] = sv[tid];   // reflector k (zeros up to k, u_1 at k+1)
         const double tau = rr * fast_rcp(au);
         if (tid == 0) {
             st[OFF + k] = tau;
@@ -362,12 +366,17 @@ __global__ __launch_bounds__(RT_NTH) void sytrd_rtail_kernel(SytrdBatch b) {
             const double dk = sx[kk], alpha = sx[kk + 1];
             double r, u1, beta;
             rt_house(alpha, xnorm2, TB - kk - 1 >= 2, r, u1, beta);
+            // reflector S + kk goes to global memory from here (zero over the strip and up to kk: the rows were cleared by
+            // the scaling pass) -- written by the wave that holds it instead of by every thread after the barrier
+            double *__restrict__ vrow = P.V + (long)(k0 + S + kk) * n + k0 + S;
 #pragma unroll
             for (int q = 0; q < 3; ++q) {
                 const int c = 64 * q + lane;
                 double t = (c > kk + 1) ? x[q] : 0.0;
                 t = (c == kk + 1) ? u1 : t;
-                svb[c] = (r != 0.0 || c == kk + 1) ? t : 0.0;
+                t = (r != 0.0 || c == kk + 1) ? t : 0.0;
+                svb[c] = t;
+                if (c < TB) vrow[c] = t;
             }
             if (lane == 0) {
                 sdb[kk] = dk;
@@ -379,7 +388,6 @@ __global__ __launch_bounds__(RT_NTH) void sytrd_rtail_kernel(SytrdBatch b) {
         }
         __syncthreads();                                             // ---- A: v, scalars published
         const double rr = s_r, au = s_u1;
-        if (tid < T) P.V[(long)(k0 + S + kk) * n + k0 + tid] = svb[tid - S];   // reflector S + kk (zeros up to it, u_1 next)
         const bool live = (16 * wid + 15 > kk) && (rr != 0.0);       // wave-uniform: still owns a row > kk
         double tau;
         // v is re-read from LDS pair by pair in both phases (6 ds_read_b128 each) instead of being held in 24 VGPRs:

@@ -213,6 +213,11 @@ int gpcsd_set_gram_precision(gpcsd_ctx *ctx, int bits);
  * results to rounding, half the flops.  on = 0 / 1 switches the path for this context (default 1; GPCSD_NO_FOLD_GEMM=1 in
  * the environment disables it process-wide), on < 0 only queries.  *calls (optional) receives how many loglik / predict
  * calls of this context have taken the folded path so far. */
+/* Decomposition cache: a fused call whose spatial and / or temporal hyper-parameters, grids and precision equal those of
+ * the previous fused call on this context reuses that side's eigendecomposition instead of repeating it (predict() right
+ * after loglik() / fit(): neuropixels/fit_gpcsd2d.py:101-107; repeated predict() calls).  Kernels are deterministic, so the
+ * results are bit-identical either way.  on = 1 / 0 switches it (default on), -1 only queries; *hits counts reused sides. */
+int gpcsd_decomposition_cache(gpcsd_ctx *ctx, int on, long *hits);
 int gpcsd_fold_gemm(gpcsd_ctx *ctx, int on, long *calls);
 
 /* ---- measurement --------------------------------------------------------------- */

@@ -373,6 +373,38 @@ def test_shift_objective_fixture_whitened_quadratic_forms():
     assert np.allclose(0.5 * q2 + prior[None, :], g["nll"], rtol=1e-7, atol=0)
 
 
+def test_decomposition_cache_reuses_unchanged_sides_bitwise():
+    """predict() right after loglik() with the same hyper-parameters reuses the temporal decomposition (Ks differs by the
+    jitter), a second predict() reuses both sides; results are the bits of a cold evaluation, any change of a side's
+    hyper-parameters, of the grids or an unrelated eigensolve in between invalidates it."""
+    c, g, geom, hp, lfp = load_model_case("2d_npx_96x120x3")
+    m = _model_from_case(c, g, lfp)
+    ctx = m._sync_device()
+    ctx.decomposition_cache(False)
+    ll_cold = m.loglik()
+    m.predict(c["x"], c["t"], type="csd")
+    cold = m.csd_pred.copy()
+    ctx.decomposition_cache(True)
+    h0 = ctx.decomposition_cache()
+    assert m.loglik() == ll_cold
+    m.predict(c["x"], c["t"], type="csd")                        # temporal side reused, spatial recomputed (no jitter)
+    h1 = ctx.decomposition_cache()
+    assert h1 - h0 == 1 and np.array_equal(m.csd_pred, cold)
+    m.predict(c["x"][::2], c["t"], type="csd")                    # both sides reused
+    assert ctx.decomposition_cache() - h1 == 2
+    assert relerr(m.csd_pred, O.predict(geom, hp, lfp, c["x"][::2], c["t"], type="csd")["csd"]) < GATE
+    ctx.eigh(np.eye(70) + 0.01)                                   # an unrelated solve on the same context: nothing is reused after it
+    h2 = ctx.decomposition_cache()
+    m.predict(c["x"], c["t"], type="csd")
+    assert ctx.decomposition_cache() == h2 and np.array_equal(m.csd_pred, cold)
+    m.temporal_cov_list[0].params["ell"]["value"] *= 1.01         # temporal side changes, spatial is reused
+    m.predict(c["x"], c["t"], type="csd")
+    assert ctx.decomposition_cache() - h2 == 1
+    hp2 = dict(hp)
+    hp2["temporal"] = [(k, ell * (1.01 if i == 0 else 1.0), s2) for i, (k, ell, s2) in enumerate(hp["temporal"])]
+    assert relerr(m.csd_pred, O.predict(geom, hp2, lfp, c["x"], c["t"], type="csd")["csd"]) < GATE
+
+
 def test_predict_returns_pinned_arrays_that_are_not_overwritten():
     """predict() lands its host arrays in recycled page-locked blocks; arrays a caller keeps must survive later calls."""
     c, g, geom, hp, lfp = load_model_case("2d_npx_96x120x3")
