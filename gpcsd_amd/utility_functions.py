@@ -56,3 +56,48 @@ def whitened_quadratic_forms(evec_s, evec_t, Dvec, resid):
     batched over trials on the GPU."""
     from . import _hip
     return _hip.default_context().whitened_quad(evec_s, evec_t, Dvec, resid)
+
+
+def fit_trial_shifts(evec_s, evec_t, Dvec, lfp_trials, mu_lfp, t, tau0=None, mutau=0.0, sigtau=10.0, width=None,
+                     options=None):
+    """Per-trial time shifts of the evoked components: the optimisation loop of auditory_lfp/fit_mean_function.py:299-335
+    (one L-BFGS-B per trial over `tau`, objective = 0.5 * whitened quadratic form of `lfp_trial - mean(tau)` + Gaussian
+    prior on the shifts), with every trial's optimiser running in lock-step so that ONE batched GPU call
+    (`whitened_quadratic_forms`) evaluates the objectives all chains are waiting for -- the reference spreads the trials
+    over CPU processes with joblib instead.
+
+    evec_s, evec_t, Dvec: outputs of `comp_eig_D`;  lfp_trials (nx, nt, ntrials);  mu_lfp (nx, nt, nseg + 1): background in
+    [..., 0], component means in [..., 1:];  t (nt,) or (nt, 1).  Returns (tau_hat (ntrials, nseg), success, messages)."""
+    import numpy as np
+    import scipy.interpolate
+    import scipy.optimize
+    from .lockstep import run_chains
+    lfp_trials = np.atleast_3d(np.asarray(lfp_trials, dtype=np.float64))
+    nx, nt, ntrials = lfp_trials.shape
+    nseg = mu_lfp.shape[2] - 1
+    tt = np.asarray(t, dtype=np.float64).reshape(-1)
+    mu_f = [scipy.interpolate.interp1d(tt, mu_lfp[:, :, i], axis=1, fill_value="extrapolate") for i in range(1, nseg + 1)]
+    tau0 = np.zeros(nseg) if tau0 is None else np.asarray(tau0, dtype=np.float64)
+
+    def batch_fn(items):                     # items: [(trial, tau)] -> {trial: objective}
+        resid = np.empty((nx, nt, len(items)))
+        for j, (ti, tau) in enumerate(items):
+            mu = np.array(mu_lfp[:, :, 0], dtype=np.float64, copy=True)
+            for i in range(nseg):
+                mu += mu_f[i](tt + tau[i])
+            resid[:, :, j] = lfp_trials[:, :, ti] - mu
+        quad = whitened_quadratic_forms(evec_s, evec_t, Dvec, resid)
+        return {ti: float(0.5 * quad[j] + 0.5 * np.sum(np.square((np.asarray(tau) - mutau) / sigtau)))
+                for j, (ti, tau) in enumerate(items)}
+
+    def chain(ti, evaluate):
+        # keyed by the trial: the evaluator hands every chain the value of ITS point of the batch
+        return scipy.optimize.minimize(lambda tau: evaluate(np.array(tau, copy=True)), tau0, method="l-bfgs-b",
+                                       options=options or {})
+    out, _ev = run_chains(list(range(ntrials)), chain, lambda items: batch_fn([(k, x) for k, x in items]),
+                          width or ntrials)
+    for r in out.values():
+        if isinstance(r, Exception):
+            raise r
+    tau_hat = np.array([out[i].x for i in range(ntrials)])
+    return tau_hat, np.array([bool(out[i].success) for i in range(ntrials)]), [out[i].message for i in range(ntrials)]

@@ -373,6 +373,35 @@ def test_shift_objective_fixture_whitened_quadratic_forms():
     assert np.allclose(0.5 * q2 + prior[None, :], g["nll"], rtol=1e-7, atol=0)
 
 
+def test_trial_shift_fits_in_lockstep_match_per_trial_scipy_on_the_oracle():
+    """N4: the per-trial shift optimisation of auditory_lfp/fit_mean_function.py:299-335 with all trials' L-BFGS-B chains
+    in lock-step on batched GPU quadratic forms, against one SciPy run per trial on the oracle objective."""
+    import scipy.optimize
+    from gpcsd_amd.utility_functions import fit_trial_shifts
+    g = golden("shift_objective")
+    rs = np.random.RandomState(3)
+    true_tau = rs.uniform(-4.0, 4.0, (5, 2))
+    import scipy.interpolate
+    tt = g["t"].reshape(-1)
+    lfp = np.empty_like(g["lfp"])
+    for ti in range(5):                          # trials = shifted mean + small noise, so the optimum is well defined
+        mu = g["mu_lfp"][:, :, 0].copy()
+        for i in (1, 2):
+            mu += scipy.interpolate.interp1d(tt, g["mu_lfp"][:, :, i], axis=1, fill_value="extrapolate")(tt + true_tau[ti, i - 1])
+        lfp[:, :, ti] = mu + 0.02 * g["lfp"][:, :, ti]
+    tau_hat, ok, msgs = fit_trial_shifts(g["Qs"], g["Qt"], g["Dvec"], lfp, g["mu_lfp"], g["t"], mutau=float(g["mutau"]),
+                                         sigtau=float(g["sigtau"]))
+    assert tau_hat.shape == (5, 2)
+    for ti in range(5):
+        ref = scipy.optimize.minimize(lambda tau: O.shift_objective(g["Qs"], g["Qt"], g["Dvec"], lfp[:, :, ti], g["mu_lfp"], g["t"],
+                                                                    tau, float(g["mutau"]), float(g["sigtau"])),
+                                      np.zeros(2), method="l-bfgs-b")
+        assert np.allclose(tau_hat[ti], ref.x, atol=2e-3), (ti, tau_hat[ti], ref.x)
+        f_hat = O.shift_objective(g["Qs"], g["Qt"], g["Dvec"], lfp[:, :, ti], g["mu_lfp"], g["t"], tau_hat[ti],
+                                  float(g["mutau"]), float(g["sigtau"]))
+        assert f_hat <= ref.fun * (1 + 1e-6) + 1e-9
+
+
 def test_decomposition_cache_reuses_unchanged_sides_bitwise():
     """predict() right after loglik() with the same hyper-parameters reuses the temporal decomposition (Ks differs by the
     jitter), a second predict() reuses both sides; results are the bits of a cold evaluation, any change of a side's
@@ -390,8 +419,12 @@ def test_decomposition_cache_reuses_unchanged_sides_bitwise():
     m.predict(c["x"], c["t"], type="csd")                        # temporal side reused, spatial recomputed (no jitter)
     h1 = ctx.decomposition_cache()
     assert h1 - h0 == 1 and np.array_equal(m.csd_pred, cold)
-    m.predict(c["x"][::2], c["t"], type="csd")                    # both sides reused
+    m.predict(c["x"], c["t"], type="lfp")                         # both sides reused (same path: folded basis, t* = t)
     assert ctx.decomposition_cache() - h1 == 2
+    assert relerr(m.lfp_pred, O.predict(geom, hp, lfp, c["x"], c["t"], type="lfp")["lfp"]) < GATE
+    m.predict(c["x"][::2], c["t"], type="csd")                    # other sites break the site symmetry: the full-size path needs
+    h1b = ctx.decomposition_cache()                               # the merged eigenvectors, which the folded calls never formed
+    assert h1b - h1 == 2
     assert relerr(m.csd_pred, O.predict(geom, hp, lfp, c["x"][::2], c["t"], type="csd")["csd"]) < GATE
     ctx.eigh(np.eye(70) + 0.01)                                   # an unrelated solve on the same context: nothing is reused after it
     h2 = ctx.decomposition_cache()
