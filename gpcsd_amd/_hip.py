@@ -91,6 +91,8 @@ SIGNATURES = {
     "gpcsd_set_gram_precision": (_I, [_P, _I]),
     "gpcsd_fold_gemm": (_I, [_P, _I, ctypes.POINTER(_L)]),
     "gpcsd_decomposition_cache": (_I, [_P, _I, ctypes.POINTER(_L)]),
+    "gpcsd_shard_block": (_I, [_I, _I, _I, ctypes.POINTER(_I), ctypes.POINTER(_I)]),
+    "gpcsd_combine_loglik": (_I, [_I, _D, _D, _DP]),
     "gpcsd_prof_enable": (_I, [_P, _I]),
     "gpcsd_prof_reset": (_I, [_P]),
     "gpcsd_prof_get": (_I, [_P, ctypes.c_char_p, _DP, ctypes.POINTER(_L), _DP]),

@@ -1231,6 +1231,25 @@ extern "C" int gpcsd_set_gram_precision(gpcsd_ctx *c, int bits) {
     GP_API_END(c)
 }
 
+// ---- multi-GPU without Python (one process per GPU, any launcher): trials are independent, so a rank needs nothing but its
+// block of trials and a sum of one double per evaluation.  Contiguous blocks, the first (ntrials mod world) ranks get one
+// extra trial -- the partition of gpcsd_amd.dist.TrialSharding.block.
+extern "C" int gpcsd_shard_block(int ntrials, int rank, int world, int *first, int *count) {
+    if (!first || !count || ntrials < 0 || world < 1 || rank < 0 || rank >= world) return -3;
+    const int base = ntrials / world, extra = ntrials % world;
+    *first = rank * base + (rank < extra ? rank : extra);
+    *count = base + (rank < extra ? 1 : 0);
+    return 0;
+}
+
+// loglik of ALL trials from the pieces gpcsd_loglik_parts returns on each rank: sum log D (identical on every rank: the
+// decompositions are deterministic replicas) and the sum over ranks of the partial quadratic terms.   gpcsd1d.py:122,127-128
+extern "C" int gpcsd_combine_loglik(int ntrials_total, double sumlog, double quad_sum_over_ranks, double *out) {
+    if (!out) return -3;
+    *out = -0.5 * (double)ntrials_total * sumlog - 0.5 * quad_sum_over_ranks;
+    return 0;
+}
+
 extern "C" int gpcsd_decomposition_cache(gpcsd_ctx *c, int on, long *hits) {
     GP_API_BEGIN(c)
     if (on >= 0) {

@@ -213,6 +213,15 @@ int gpcsd_set_gram_precision(gpcsd_ctx *ctx, int bits);
  * results to rounding, half the flops.  on = 0 / 1 switches the path for this context (default 1; GPCSD_NO_FOLD_GEMM=1 in
  * the environment disables it process-wide), on < 0 only queries.  *calls (optional) receives how many loglik / predict
  * calls of this context have taken the folded path so far. */
+/* Multi-GPU from C (one process per GPU): trials are independent, every rank recomputes the (deterministic)
+ * decompositions and owns a contiguous block of trials.  gpcsd_shard_block gives rank `rank` of `world` its block
+ * [first, first+count) of `ntrials`; the rank uploads lfp[:, :, first:first+count] with gpcsd_set_lfp, calls
+ * gpcsd_loglik_parts -> (sum log D, partial quad), sums the partial quad over ranks with the collective of its choice
+ * (RCCL / MPI all-reduce of one double) and gpcsd_combine_loglik forms -R/2 sum log D - 1/2 quad (gpcsd1d.py:122,127-128).
+ * predict / gpcsd_loglik_grad work on the rank's block the same way (gradient entries and L_loc add over ranks). */
+int gpcsd_shard_block(int ntrials, int rank, int world, int *first, int *count);
+int gpcsd_combine_loglik(int ntrials_total, double sumlog, double quad_sum_over_ranks, double *out);
+
 /* Decomposition cache: a fused call whose spatial and / or temporal hyper-parameters, grids and precision equal those of
  * the previous fused call on this context reuses that side's eigendecomposition instead of repeating it (predict() right
  * after loglik() / fit(): neuropixels/fit_gpcsd2d.py:101-107; repeated predict() calls).  Kernels are deterministic, so the

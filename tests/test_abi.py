@@ -111,3 +111,21 @@ def test_model_construction_and_param_surface_cpu():
     m3 = GPCSD1D(np.zeros((24, 50, 2)), x, t, sig2n_prior=[GPCSDHalfNormalPrior(0.1) for _ in range(24)])
     assert m3.sig2n["value"].shape == (24,) and len(m3._bounds()) == 6 + 24
     assert m2.spatial_cov.gl_x_grid.shape == (1200, 2) and m2.spatial_cov.delta_w.shape == (48, 1200)
+
+
+def test_shard_block_matches_the_python_partition():
+    """gpcsd_shard_block (the C-side partition for binders without Python) == TrialSharding.block; no GPU needed."""
+    import ctypes
+    from gpcsd_amd import _hip
+    from gpcsd_amd.dist import TrialSharding
+    lib = _hip.load_library()
+    for n, w in [(400, 8), (5, 2), (3, 4), (50, 1), (0, 3)]:
+        for r in range(w):
+            a, c = ctypes.c_int(), ctypes.c_int()
+            assert lib.gpcsd_shard_block(n, r, w, ctypes.byref(a), ctypes.byref(c)) == 0
+            lo, hi = TrialSharding.block(n, r, w)
+            assert (a.value, a.value + c.value) == (lo, hi)
+    a, c = ctypes.c_int(), ctypes.c_int()
+    assert lib.gpcsd_shard_block(10, 3, 3, ctypes.byref(a), ctypes.byref(c)) == -3
+    out = ctypes.c_double()
+    assert lib.gpcsd_combine_loglik(4, 2.0, 3.0, ctypes.byref(out)) == 0 and out.value == -0.5 * 4 * 2.0 - 0.5 * 3.0
