@@ -297,6 +297,7 @@ def main():
     ap.add_argument("--cpu-budget-s", type=float, default=45.0)
     ap.add_argument("--fit-batch", type=int, default=None, help="cfg5: restarts evaluated per lock-step batch")
     ap.add_argument("--fit-maxiter", type=int, default=15)
+    ap.add_argument("--fit-groups", type=int, default=2, help="cfg5: lock-step groups running side by side on one GPU")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -565,16 +566,51 @@ def run_fit_bench(args, w, rank, world, local_rank, backend):
         if world > 1:
             import torch.distributed as td
             td.barrier()
-    for _ in range(max(3, min(args.setup_steps, 20))):
-        ctx.loglik_grad_batch(hps, ng)
-    for _ in range(args.warmup):
-        ctx.loglik_grad_batch(hps, ng)
+    # G lock-step groups side by side, each with its own context (what fit(batch=B, workers=G) does): a step is one batched
+    # evaluation of EVERY group, i.e. G * B objective+gradient evaluations
+    G = max(1, args.fit_groups)
+    ctxs, group_hps = [ctx], [hps]
+    for gi in range(1, G):
+        mg = m._clone_for_worker()
+        mg.set_device(local_rank)
+        cg = mg._sync_device()
+        ks = mine[gi * B:(gi + 1) * B] or mine[:B]
+        gh = []
+        for k in ks:
+            mg._set_from_tparams(starts[k], False)
+            gh.append(mg._hparams(mg.JITTER))
+        ctxs.append(cg)
+        group_hps.append([h for h, _ in gh])
+        sets.extend(gh)                                          # keep the sig2n arrays alive
+
+    def run_groups(nsteps):
+        if G == 1:
+            for _ in range(nsteps):
+                ctx.loglik_grad_batch(hps, ng)
+            return
+        import threading
+        ths = [threading.Thread(target=lambda c=c, h=h: [c.loglik_grad_batch(h, ng) for _ in range(nsteps)])
+               for c, h in zip(ctxs, group_hps)]
+        for th in ths:
+            th.start()
+        for th in ths:
+            th.join()
+    run_groups(max(3, min(args.setup_steps, 20)))
+    run_groups(args.warmup)
     fence()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        sumlog, quad, grad, st = ctx.loglik_grad_batch(hps, ng)
+    run_groups(args.steps)
+    for cg in ctxs:
+        cg.synchronize()
     fence()
     elapsed = time.perf_counter() - t0
+    # one group alone, for reference
+    fence()
+    t0g = time.perf_counter()
+    for _ in range(args.steps):
+        sumlog, quad, grad, st = ctx.loglik_grad_batch(hps, ng)
+    ctx.synchronize()
+    one_group_s = (time.perf_counter() - t0g) / args.steps
     # one at a time (what a chain on its own costs; fit(workers=1) of round 1)
     nseq = max(8, min(args.steps, 40))
     for _ in range(3):
@@ -600,12 +636,12 @@ def run_fit_bench(args, w, rank, world, local_rank, backend):
     # a truncated real fit: lock-step SciPy chains, all of this rank's restarts
     opts = {"maxiter": args.fit_maxiter, "disp": False, "gtol": 1e-5, "ftol": 1e7 * np.finfo(float).eps}
     tf = time.perf_counter()
-    m.fit(n_restarts=total_restarts, options=opts, starts=starts, batch=B)
+    m.fit(n_restarts=total_restarts, options=opts, starts=starts, batch=B, workers=G)
     fit_s = time.perf_counter() - tf
     nb, npts = getattr(m, "fit_batches_", (0, 0))
     if rank != 0:
         return None
-    n_eval = B * world * args.steps
+    n_eval = G * B * world * args.steps
     gemm_flops = sum(v["flops"] for k, v in prof.items() if k.startswith("gemm_")) / 3.0
     tail = prof.get("sytrd_rtail")
     eig_flops = 4.0 * tail["flops"] / 3.0 if tail else 0.0           # tridiagonalisation + 3x for the back-transformation
@@ -617,18 +653,21 @@ def run_fit_bench(args, w, rank, world, local_rank, backend):
         "ms_per_step": 1e3 * step_s, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": "f64" if m.gram_precision == 64 else "f32 Gram build + f64", "data": "synthetic",
         "config": {"workload": w["label"], "n_elec": w["nx"], "n_t": w["nt"], "trials_per_gpu": w["trials_per_gpu"],
-                   "restarts_total": total_restarts, "restarts_per_gpu": len(mine), "lockstep_batch": B,
-                   "parallelism": "restart-sharded x%d, %d restarts per lock-step batch" % (world, B)},
+                   "restarts_total": total_restarts, "restarts_per_gpu": len(mine), "lockstep_batch": B, "lockstep_groups": G,
+                   "parallelism": "restart-sharded x%d, %d lock-step groups of %d restarts per GPU" % (world, G, B)},
         "evals_per_sec_one_at_a_time_per_gpu": 1.0 / seq_s,
-        "batched_over_sequential": (B / step_s) / (1.0 / seq_s),
+        "evals_per_sec_one_group_per_gpu": B / one_group_s,
+        "batched_over_sequential": (B / one_group_s) / (1.0 / seq_s),
+        "all_groups_over_sequential": (G * B / step_s) / (1.0 / seq_s),
         "fit": {"restarts": total_restarts, "maxiter": args.fit_maxiter, "seconds": fit_s,
                 "restarts_per_sec": total_restarts / fit_s, "evals": int(npts) * world, "batched_calls": int(nb),
                 "evals_per_sec_through_scipy": npts * world / fit_s, "best_nll": float(np.min(m.fit_nll_values_))},
         "roofline": {"bound": "mfma", "unit": "TFLOP/s", "peak": FP64_MFMA_SPEC_TFLOPS,
-                     "achieved": (gemm_flops + eig_flops) / step_s / 1e12,
-                     "frac": (gemm_flops + eig_flops) / step_s / 1e12 / FP64_MFMA_SPEC_TFLOPS,
-                     "scope": "one step = %d objective+gradient evaluations in one chain of launches; flops actually launched" % B,
-                     "executed_gflop_per_step": (gemm_flops + eig_flops) / 1e9, "traffic": None,
+                     "achieved": G * (gemm_flops + eig_flops) / step_s / 1e12,
+                     "frac": G * (gemm_flops + eig_flops) / step_s / 1e12 / FP64_MFMA_SPEC_TFLOPS,
+                     "scope": "one step = %d lock-step group(s) x %d objective+gradient evaluations, each group one chain of launches; "
+                              "flops actually launched (profiled on one group)" % (G, B),
+                     "executed_gflop_per_step": G * (gemm_flops + eig_flops) / 1e9, "traffic": None,
                      "dominant_kernel": None if not tail else {
                          "kernel": "sytrd_rtail_kernel", "avg_launch_ms": tail["ms"] / tail["count"],
                          "launches_per_step": tail["count"] / 3.0, "workgroups_per_launch": "%d (one per half problem and set)" % (2 * B),

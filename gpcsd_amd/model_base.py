@@ -464,17 +464,36 @@ class GPCSDModel:
         workers = max(1, min(int(workers), len(mine)))
         batch = max(1, min(int(batch), len(mine)))
         if batch > 1 and self._batch_can_evaluate():
-            # lock-step restarts: `batch` SciPy chains alive at a time, their evaluations served by ONE batched device call
+            # lock-step restarts: `batch` SciPy chains alive at a time, their evaluations served by ONE batched device call.
+            # workers > 1: that many such groups side by side, each on its own context (= own streams and buffers).  A batched
+            # evaluation is a latency-bound eigen phase (a few CUs) followed by a throughput-bound GEMM phase (all CUs); two
+            # groups drift out of phase and one's eigen chains run under the other's GEMMs.  Not under trial sharding: the
+            # groups' all-reduces would interleave differently on different ranks.
             from .lockstep import run_chains
-            out, ev = run_chains([starts[k] for k in mine],
-                                 lambda s0, evaluate: self._run_restart(s0, method, fix_R, options, bounds, evaluate),
-                                 lambda items: self._objective_and_grad_batch(items, fix_R), batch)
-            for i, k in enumerate(mine):
-                r = out[i]
-                if isinstance(r, Exception):
-                    raise r
-                results[k] = r
-            self.fit_batches_ = (ev.batches, ev.points)
+            ngroups = 1 if getattr(self, "_sharding", None) is not None else max(1, min(workers, len(mine) // 2))
+            parts = [mine[gi::ngroups] for gi in range(ngroups)]
+
+            def run_group(model, ks):
+                return run_chains([starts[k] for k in ks],
+                                  lambda s0, evaluate: model._run_restart(s0, method, fix_R, options, bounds, evaluate),
+                                  lambda items: model._objective_and_grad_batch(items, fix_R), min(batch, len(ks)))
+            if ngroups == 1:
+                outs = [run_group(self, parts[0])]
+            else:
+                from concurrent.futures import ThreadPoolExecutor
+                models = [self] + [self._clone_for_worker() for _ in range(ngroups - 1)]
+                with ThreadPoolExecutor(max_workers=ngroups) as ex:
+                    outs = list(ex.map(lambda a: run_group(*a), zip(models, parts)))
+            nb = npts = 0
+            for ks, (out, ev) in zip(parts, outs):
+                for i, k in enumerate(ks):
+                    r = out[i]
+                    if isinstance(r, Exception):
+                        raise r
+                    results[k] = r
+                nb += ev.batches
+                npts += ev.points
+            self.fit_batches_ = (nb, npts)
         elif workers == 1:
             for k in tqdm(mine, desc="Restarts"):
                 results[k] = self._run_restart(starts[k], method, fix_R, options, bounds)

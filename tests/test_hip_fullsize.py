@@ -257,6 +257,11 @@ def test_fit_lockstep_batch_equals_sequential_restarts():
     assert m1.R["value"] == m2.R["value"]
     nb, npts = m2.fit_batches_
     assert npts > nb                                             # evaluations really shared launches
+    # two lock-step groups side by side, each on its own context: still the same optima
+    m3, *_ = _cfg5_model()
+    m3.fit(n_restarts=5, options=opts, starts=starts, batch=2, workers=2)
+    assert np.array_equal(np.asarray(m1.fit_nll_values_), np.asarray(m3.fit_nll_values_))
+    assert all(np.array_equal(a, b) for a, b in zip(m1.fit_params_, m3.fit_params_))
 
 
 # ------------------------------------------------------------------------------------------------ contract edges
