@@ -167,6 +167,9 @@ __global__ __launch_bounds__(RT_NTH) void sytrd_rtail_kernel(SytrdBatch b) {
     // ------------------------------------------------------------------------------------------------------------
     // strip columns k = 0 .. S-1: every block row is live, the matrix is strip rows (k, S) + the block
     // ------------------------------------------------------------------------------------------------------------
+    // strip rows: lane l covers the tail-global columns (2l, 2l + 1) and (128 + 2l, 129 + 2l), one 16-byte LDS access each
+    const int cA = 2 * lane, cB = 128 + 2 * lane;
+    const bool okB = cB < T;                                         // (cA < 128 < T whenever there is a strip)
     for (int k = 0; k < S; ++k) {
         double *sv = sv2[k & 1] + OFF;                               // tail-global view of the vectors in this phase
         double *syg = sy + OFF;
@@ -174,10 +177,14 @@ __global__ __launch_bounds__(RT_NTH) void sytrd_rtail_kernel(SytrdBatch b) {
             __builtin_amdgcn_s_setprio(3);
             const double *__restrict__ row = strip + k * LDT;
             double x[4], part = 0.0;
+            {
+                const double2 xa = *reinterpret_cast<const double2 *>(row + cA);          // cA < 128 <= T always
+                const double2 xb = okB ? *reinterpret_cast<const double2 *>(row + cB) : double2{0.0, 0.0};
+                x[0] = xa.x; x[1] = xa.y; x[2] = xb.x; x[3] = xb.y;
+            }
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const int c = lane + 64 * q;
-                x[q] = (c < T) ? row[c] : 0.0;
+                const int c = ((q & 2) ? cB : cA) + (q & 1);
                 const double m = (c >= k + 2) ? x[q] : 0.0;
                 part = fma(m, m, part);
             }
@@ -186,17 +193,17 @@ __global__ __launch_bounds__(RT_NTH) void sytrd_rtail_kernel(SytrdBatch b) {
             double r, u1, beta;
             rt_house(alpha, xnorm2, true, r, u1, beta);
             double *__restrict__ vrow = P.V + (long)(k0 + k) * n + k0;      // reflector k (zeros up to k, u_1 at k+1)
+            double tv[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const int c = lane + 64 * q;
-                double t = (c > k + 1) ? x[q] : 0.0;
+                const int c = ((q & 2) ? cB : cA) + (q & 1);
+                double t = (c > k + 1) ? x[q] : 0.0;                       // (a pad column c == T reads 0 and stays 0)
                 t = (c == k + 1) ? u1 : t;
-                t = (r != 0.0 || c == k + 1) ? t : 0.0;
-                if (c < T) {
-                    sv[c] = t;
-                    vrow[c] = t;                                             // fire and forget: the barriers wait for LDS only
-                }
+                tv[q] = (r != 0.0 || c == k + 1) ? t : 0.0;
+                if (c < T) vrow[c] = tv[q];                                // fire and forget: the barriers wait for LDS only
             }
+            *reinterpret_cast<double2 *>(sv + cA) = double2{tv[0], tv[1]};
+            if (okB) *reinterpret_cast<double2 *>(sv + cB) = double2{tv[2], tv[3]};
             if (lane == 0) {
                 sd[OFF + k] = dk;
                 se[OFF + k] = beta;
@@ -216,17 +223,14 @@ __global__ __launch_bounds__(RT_NTH) void sytrd_rtail_kernel(SytrdBatch b) {
         const int rfirst = k + 1 + (wid - (k + 1) % RT_NW + RT_NW) % RT_NW;   // this wave's first strip row > k
         if (live) {
             // strip rows of this wave: y_r = strip[r][:] . v
-            double vq[4], dps = 0.0;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) vq[q] = (lane + 64 * q < T) ? sv[lane + 64 * q] : 0.0;
+            double dps = 0.0;
+            const double2 va = *reinterpret_cast<const double2 *>(sv + cA);
+            const double2 vb = okB ? *reinterpret_cast<const double2 *>(sv + cB) : double2{0.0, 0.0};
             for (int r = rfirst; r < S; r += RT_NW) {
                 const double *__restrict__ row = strip + r * LDT;
-                double p = 0.0;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int c = lane + 64 * q;
-                    p = fma((c < T) ? row[c] : 0.0, vq[q], p);
-                }
+                const double2 ra = *reinterpret_cast<const double2 *>(row + cA);
+                const double2 rb = okB ? *reinterpret_cast<const double2 *>(row + cB) : double2{0.0, 0.0};
+                const double p = fma(rb.y, vb.y, fma(rb.x, vb.x, fma(ra.y, va.y, ra.x * va.x)));
                 const double yr = wave_sum(p);
                 if (lane == 0) syg[r] = yr;
                 dps = fma(sv[r], yr, dps);
@@ -272,20 +276,26 @@ __global__ __launch_bounds__(RT_NTH) void sytrd_rtail_kernel(SytrdBatch b) {
             const double cc = htt * dot;
             // strip rows of this wave (row k+1 first when it is ours: its owner generates the next reflector from it)
             if (rfirst < S) {
-                double vq[4], wq[4];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int c = lane + 64 * q;
-                    vq[q] = (c < T) ? sv[c] : 0.0;
-                    wq[q] = (c < T) ? tau * syg[c] - cc * vq[q] : 0.0;
-                }
+                // two adjacent columns per 16-byte LDS access (half the LDS instructions of one column per access); a pad
+                // column (index T when T is odd) has v = w = 0 and is written back unchanged
+                const double2 va = *reinterpret_cast<const double2 *>(sv + cA);
+                const double2 vb = okB ? *reinterpret_cast<const double2 *>(sv + cB) : double2{0.0, 0.0};
+                const double2 ya = *reinterpret_cast<const double2 *>(syg + cA);
+                const double2 yb = okB ? *reinterpret_cast<const double2 *>(syg + cB) : double2{0.0, 0.0};
+                const double wa0 = tau * ya.x - cc * va.x, wa1 = (cA + 1 < T) ? tau * ya.y - cc * va.y : 0.0;
+                const double wb0 = okB ? tau * yb.x - cc * vb.x : 0.0, wb1 = (cB + 1 < T) ? tau * yb.y - cc * vb.y : 0.0;
                 for (int r = rfirst; r < S; r += RT_NW) {
                     double *__restrict__ row = strip + r * LDT;
                     const double vr = sv[r], wr = tau * syg[r] - cc * vr;
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const int c = lane + 64 * q;
-                        if (c < T) row[c] = fma(-wr, vq[q], fma(-vr, wq[q], row[c]));
+                    double2 ra = *reinterpret_cast<const double2 *>(row + cA);
+                    ra.x = fma(-wr, va.x, fma(-vr, wa0, ra.x));
+                    ra.y = fma(-wr, va.y, fma(-vr, wa1, ra.y));
+                    *reinterpret_cast<double2 *>(row + cA) = ra;
+                    if (okB) {
+                        double2 rb = *reinterpret_cast<const double2 *>(row + cB);
+                        rb.x = fma(-wr, vb.x, fma(-vr, wb0, rb.x));
+                        rb.y = fma(-wr, vb.y, fma(-vr, wb1, rb.y));
+                        *reinterpret_cast<double2 *>(row + cB) = rb;
                     }
                 }
             }
