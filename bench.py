@@ -116,7 +116,9 @@ def algorithmic_flops(w, R, nz, C):
     """flops of the reference's (Kronecker-structured) algorithm per loglik evaluation / predict call."""
     nx, nt = w["nx"], w["nt"]
     G = w["ngl"] if w["dim"] == 1 else w["ngl1"] * w["ngl2"]
-    f_spatial = 2.0 * nx * G * G + 2.0 * nx * nx * G
+    # SURVEY 8(d): a build that exploits Kgl = K1 (x) K2 on the 2D tensor grid must count the reduced product it executes
+    f_akgl = 2.0 * nx * G * G if w["dim"] == 1 else 2.0 * nx * G * (w["ngl1"] + w["ngl2"])
+    f_spatial = f_akgl + 2.0 * nx * nx * G
     f_eig = 9.0 * (nx ** 3 + nt ** 3)
     f_proj = 2.0 * nx * nx * nt + 2.0 * nx * nt * nt
     loglik = f_spatial + f_eig + R * f_proj

@@ -11,8 +11,9 @@ from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-OBJDIR = os.path.join(CSRC, "_build")
-LIB = os.path.join(HERE, "libgpcsd_hip.so")
+OBJDIR = os.path.join(CSRC, os.environ.get("GPCSD_BUILD_OBJDIR", "_build"))
+# developer knobs for A/B experiments (tools/ab_bench.py, tools/sytrd_time.py): another output name and extra compiler flags
+LIB = os.environ.get("GPCSD_BUILD_LIB") or os.path.join(HERE, "libgpcsd_hip.so")
 SOURCES = ["capi.hip", "gemm_f64.hip", "gram.hip", "eigh.hip", "eigh_dc.hip", "stedc.hip", "wy.hip", "grad.hip", "chol.hip"]
 ARCH = "gfx950"
 # -amdgpu-mfma-vgpr-form: keep MFMA accumulators in VGPRs; the default AGPR form made hipcc copy all of them AGPR<->VGPR
@@ -52,7 +53,7 @@ def build(force=False, verbose=True):
 
     def compile_one(job):
         s, o = job
-        cmd = [hipcc] + FLAGS + EXTRA.get(os.path.basename(s), []) + ["-c", s, "-o", o]
+        cmd = [hipcc] + FLAGS + EXTRA.get(os.path.basename(s), []) + os.environ.get("GPCSD_CXXFLAGS", "").split() + ["-c", s, "-o", o]
         if verbose:
             print("[gpcsd_amd.build]", " ".join(cmd), flush=True)
         r = subprocess.run(cmd, capture_output=True, text=True)

@@ -96,16 +96,38 @@ void build_kphi(gpcsd_ctx *c, const Geo &g, double R, double eps, const double *
                 double *out, hipStream_t s) {
     const int G = g.G();
     double *A = c->buf<double>("ks_A", (size_t)g.nx * G);
-    double *Kgl = c->buf<double>("ks_Kgl", (size_t)G * G);
     double *T = c->buf<double>("ks_T", (size_t)g.nx * G);
     fwd_weights(c, g, g.x, g.nx, R, eps, A, s);
-    if (g.dim == 1) k_se_1d(c, g.gx1, G, g.gx1, G, ell[0], Kgl, s);
-    else k_se_2d(c, g.gx1, g.gx2, G, g.ngl2, g.gx1, g.gx2, G, g.ngl2, ell[0], ell[1], Kgl, s);
-    GemmDesc d1;                                   // T = A Kgl
-    d1.M = g.nx; d1.N = G; d1.K = G;
-    d1.A = A; d1.lda = G; d1.B = Kgl; d1.ldb = G; d1.C = T; d1.ldc = G;
-    d1.prof_name = "gemm_Ks_AKgl";
-    gemm_f64(c, d1, s);
+    if (g.dim == 1) {
+        double *Kgl = c->buf<double>("ks_Kgl", (size_t)G * G);
+        k_se_1d(c, g.gx1, G, g.gx1, G, ell[0], Kgl, s);
+        GemmDesc d1;                               // T = A Kgl
+        d1.M = g.nx; d1.N = G; d1.K = G;
+        d1.A = A; d1.lda = G; d1.B = Kgl; d1.ldb = G; d1.C = T; d1.ldc = G;
+        d1.prof_name = "gemm_Ks_AKgl";
+        gemm_f64(c, d1, s);
+    } else {
+        // On the GL tensor grid Kgl = K1 (x) K2 (covariances.py:216: a product of one factor per axis), so
+        //   T[x][(h1,h2)] = sum_{g1} K1[g1][h1] ( sum_{g2} A[x][(g1,g2)] K2[g2][h2] ):
+        // two small products (2 nx G (ngl1 + ngl2) flops: 74 MF at 384 x 20 x 60) instead of the 2 nx G^2 = 1.1 GF flat one,
+        // and Kgl (1200^2 exponentials) is never formed.  Same sums re-associated: agrees with the flat product to rounding.
+        const int n1 = g.ngl1, n2 = g.ngl2;
+        double *K1 = c->buf<double>("ks_K1", (size_t)n1 * n1), *K2 = c->buf<double>("ks_K2", (size_t)n2 * n2);
+        double *U = c->buf<double>("ks_U", (size_t)g.nx * G);
+        k_se_axis(c, g.gx1, n1, ell[0], K1, s);
+        k_se_axis(c, g.gx2, n2, ell[1], K2, s);
+        GemmDesc u;                                // U[(x,g1)][h2] = sum_g2 A[(x,g1)][g2] K2[g2][h2]
+        u.M = g.nx * n1; u.N = n2; u.K = n2;
+        u.A = A; u.lda = n2; u.B = K2; u.ldb = n2; u.C = U; u.ldc = n2;
+        u.prof_name = "gemm_Ks_AK2";
+        gemm_f64(c, u, s);
+        GemmDesc v;                                // T_x (n1 x n2) = K1^T U_x, one small product per electrode
+        v.M = n1; v.N = n2; v.K = n1;
+        v.A = K1; v.lda = n1; v.transA = true; v.B = U; v.ldb = n2; v.C = T; v.ldc = n2;
+        v.batch = g.nx; v.sA = 0; v.sB = G; v.sC = G;
+        v.prof_name = "gemm_Ks_K1U";
+        gemm_f64(c, v, s);
+    }
     const double *Axp = A;
     int n2 = g.nx;
     if (xp) {

@@ -307,6 +307,23 @@ void k_se_2d(gpcsd_ctx *c, const double *a1, const double *a2, int na, int na2, 
     GP_HIP(hipGetLastError());
 }
 
+// One factor of the tensor-grid SE kernel: out(n,n) = exp(-0.5 (a_i - a_j)^2 / ell^2), the per-axis term of the grid form of
+// se_2d_kernel (covariances.py:216: Kgl = exp(-0.5 d1^2/ell1^2) * exp(-0.5 d2^2/ell2^2) = K1 (x) K2 on the GL tensor grid).
+template <typename T>
+__global__ __launch_bounds__(256) void se_axis_kernel(const double *__restrict__ a, int n, double elld, double *__restrict__ out) {
+    const T ell = T(elld);
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < n * n; e += gridDim.x * 256) {
+        const T d = T(a[e / n]) - T(a[e % n]);
+        out[e] = (double)exp(T(-0.5) * (d * d) / (ell * ell));
+    }
+}
+void k_se_axis(gpcsd_ctx *c, const double *a, int n, double ell, double *out, hipStream_t s) {
+    const int grid = ceil_div((long)n * n, 256);
+    if (c->gram_fp32) hipLaunchKernelGGL(se_axis_kernel<float>, dim3(grid), dim3(256), 0, s, a, n, ell, out);
+    else hipLaunchKernelGGL(se_axis_kernel<double>, dim3(grid), dim3(256), 0, s, a, n, ell, out);
+    GP_HIP(hipGetLastError());
+}
+
 __global__ void add_diag_kernel(double *A, int n, double v, const HpDev *__restrict__ tab, long s_out) {
     if (tab) {
         v = tab[blockIdx.z].jitter;

@@ -87,6 +87,8 @@ void k_se_1d(gpcsd_ctx *c, const double *a, int n, const double *b, int m, doubl
 void k_se_2d(gpcsd_ctx *c, const double *a1, const double *a2, int na, int na2, const double *b1, const double *b2,
              int nb, int nb2, double ell1, double ell2, double *out, hipStream_t s, const HpDev *tab = nullptr, int B = 1,
              long s_out = 0);
+// one axis factor of the tensor-grid SE kernel: out(n,n) = exp(-0.5 (a_i - a_j)^2 / ell^2)
+void k_se_axis(gpcsd_ctx *c, const double *a, int n, double ell, double *out, hipStream_t s);
 void k_add_diag(gpcsd_ctx *c, double *A, int n, double v, hipStream_t s, const HpDev *tab = nullptr, int B = 1, long s_out = 0);
 // D[x*nt + i] = es[x]*et[i] + sig[x or 0]; also sumlog -> *sumlog_out (deterministic)
 // Dinv (optional) = 1/D elementwise.  sumlog_out == nullptr: no final sum; the per-block partials stay in the ctx buffer
