@@ -15,7 +15,7 @@ MAX_TEMPORAL = 8
 KIND_SE, KIND_MATERN, KIND_HOST = 0, 1, 2
 ERR_CAPACITY = -7
 MAX_EIG_N = 1024                 # GPCSD_MAX_EIG_N: rows of one eigenproblem (after symmetry folding)
-MAX_GEMM_OPERAND = 1 << 28       # GPCSD_MAX_GEMM_OPERAND: doubles in one flat GEMM operand (nx * ntrials * nt)
+MAX_GEMM_LD_KMAJOR = 1 << 23     # GPCSD_MAX_GEMM_LD_KMAJOR: ntrials * nt of one resident block of trials
 PRED_CSD, PRED_LFP, PRED_BOTH = 1, 2, 3
 
 _c_double_p = ctypes.POINTER(ctypes.c_double)
@@ -34,7 +34,7 @@ class HipUnavailable(RuntimeError):
 
 
 class GPCSDCapacityError(RuntimeError):
-    """A problem exceeds a capacity limit of this build (include/gpcsd_hip.h: GPCSD_MAX_EIG_N, GPCSD_MAX_GEMM_OPERAND).
+    """A problem exceeds a capacity limit of this build (include/gpcsd_hip.h: GPCSD_MAX_EIG_N, GPCSD_MAX_GEMM_LD_KMAJOR).
     Deliberately not a ValueError / LinAlgError: fit() must not treat it as a failed restart and carry on."""
 
 

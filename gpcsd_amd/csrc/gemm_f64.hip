@@ -94,12 +94,17 @@ struct Tile {
             k = tid % BK;
         }
     }
-    // wave-uniform buffer resource over the operand, based at the tile's first outer row/column (raw buffer, no bounds)
-    __device__ static __forceinline__ __amdgpu_buffer_rsrc_t rsrc(const double *p, long ld, int o0) {
-        const double *b = p + (KMAJOR ? (long)o0 : (long)o0 * ld);
+    // wave-uniform base of the tile's first outer row/column, and the buffer resource of K tile t over it (raw buffer, no
+    // bounds).  The resource is re-based per K tile with 64-bit scalar arithmetic, so the only 32-bit quantities are the
+    // per-thread offsets INSIDE one K tile -- an operand may be as large as memory (a K-major operand of ld = ntrials * nt
+    // was limited to 2^28 elements while the K offset travelled in the 32-bit soffset).
+    __device__ static __forceinline__ const double *tile_base(const double *p, long ld, int o0) {
+        return p + (KMAJOR ? (long)o0 : (long)o0 * ld);
+    }
+    __device__ static __forceinline__ __amdgpu_buffer_rsrc_t rsrc(const double *tile0, long ld, int t) {
+        const double *b = tile0 + (long)t * (KMAJOR ? (long)BK * ld : (long)BK);
         return __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(b), 0, 0xFFFFFFFF, 0x00020000);
     }
-    __device__ static __forceinline__ long step_bytes(long ld) { return 8 * (KMAJOR ? (long)BK * ld : (long)BK); }
     // byte offsets of this thread's slots from the tile base (host side checks they fit 32 bits)
     __device__ static __forceinline__ void setup(unsigned (&off)[PER_THREAD], long ld, int o0, int Olim, int tid) {
         int o, k;
@@ -210,8 +215,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f64_kernel(GemmK g) {
     unsigned offA[TileA::PER_THREAD], offB[TileB::PER_THREAD];
     TileA::setup(offA, g.lda, m0, g.M, tid);
     TileB::setup(offB, g.ldb, n0, g.N, tid);
-    const __amdgpu_buffer_rsrc_t rsA = TileA::rsrc(A, g.lda, m0), rsB = TileB::rsrc(B, g.ldb, n0);   // wave-uniform
-    const int stepA = (int)TileA::step_bytes(g.lda), stepB = (int)TileB::step_bytes(g.ldb);
+    const double *const baseA = TileA::tile_base(A, g.lda, m0), *const baseB = TileB::tile_base(B, g.ldb, n0);   // wave-uniform
     const int nk = (g.K + BK - 1) / BK;
     const int nfull = g.K / BK;                  // tiles [0, nfull) are complete
 
@@ -227,15 +231,15 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f64_kernel(GemmK g) {
     using Buf1 = std::integral_constant<int, 1>;
 
     auto load_full = [&](int t) {
-        TileA::gload(ra, rsA, t * stepA, offA);
-        TileB::gload(rb, rsB, t * stepB, offB);
+        TileA::gload(ra, TileA::rsrc(baseA, g.lda, t), 0, offA);
+        TileB::gload(rb, TileB::rsrc(baseB, g.ldb, t), 0, offB);
     };
     auto load_any = [&](int t) {
         if (t < nfull) {
             load_full(t);
         } else {
-            TileA::gload_tail(ra, rsA, t * stepA, g.lda, m0, g.M, g.K - t * BK, tid);
-            TileB::gload_tail(rb, rsB, t * stepB, g.ldb, n0, g.N, g.K - t * BK, tid);
+            TileA::gload_tail(ra, TileA::rsrc(baseA, g.lda, t), 0, g.lda, m0, g.M, g.K - t * BK, tid);
+            TileB::gload_tail(rb, TileB::rsrc(baseB, g.ldb, t), 0, g.ldb, n0, g.N, g.K - t * BK, tid);
         }
     };
     auto store_full = [&](auto bufc) {
@@ -483,12 +487,14 @@ void gemm_f64(gpcsd_ctx *c, const GemmDesc &g, hipStream_t s) {
     if (!s) s = c->stream;
     GP_REQUIRE(g.M > 0 && g.N > 0 && g.K > 0, -3, "gemm_f64: empty problem %dx%dx%d", g.M, g.N, g.K);
     // 32-bit byte offsets inside one batch entry's operand (buffer_load voffset + soffset)
-    GP_REQUIRE((g.transA ? (long)g.K : (long)g.M) * g.lda < (1L << 28) && (g.transB ? (long)g.N : (long)g.K) * g.ldb < (1L << 28),
-               GPCSD_ERR_CAPACITY,
-               "gemm_f64: operand of %ld x %ld doubles exceeds the 2^28-element capacity of one flat GEMM operand "
-               "(GPCSD_MAX_GEMM_OPERAND; e.g. nx * ntrials * nt per resident block of trials)",
-               (g.transA ? (long)g.K : (long)g.M) * g.lda >= (1L << 28) ? (g.transA ? (long)g.K : (long)g.M) : (g.transB ? (long)g.N : (long)g.K),
-               (g.transA ? (long)g.K : (long)g.M) * g.lda >= (1L << 28) ? g.lda : g.ldb);
+    // 32-bit byte offsets exist only inside one K tile of one block tile: (rows of the tile) x (leading dimension).  The
+    // widest tile has 128 outer rows / 64 K rows, so a leading dimension below 2^22 doubles is always safe; K-major operands
+    // (the flat projections: ld = ntrials * nt) only span BK <= 64 rows per tile and get 2^23
+    const long ld_lim_a = g.transA ? GPCSD_MAX_GEMM_LD_KMAJOR : (1L << 22), ld_lim_b = g.transB ? (1L << 22) : GPCSD_MAX_GEMM_LD_KMAJOR;
+    GP_REQUIRE(g.lda < ld_lim_a && g.ldb < ld_lim_b, GPCSD_ERR_CAPACITY,
+               "gemm_f64: leading dimension %ld exceeds the capacity of one flat GEMM operand row (%ld doubles; "
+               "GPCSD_MAX_GEMM_LD_KMAJOR: ntrials * nt of a resident block of trials)",
+               g.lda >= ld_lim_a ? g.lda : g.ldb, g.lda >= ld_lim_a ? ld_lim_a : ld_lim_b);
     GemmK k;
     k.M = g.M; k.N = g.N; k.K = g.K;
     k.A = g.A; k.lda = g.lda; k.B = g.B; k.ldb = g.ldb; k.C = g.C; k.ldc = g.ldc; k.C2 = g.C2; k.C3 = g.C3;

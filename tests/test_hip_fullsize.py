@@ -363,6 +363,31 @@ def test_time_grid_beyond_1024_points_and_capacity_error():
     assert not issubclass(gpcsd_amd.GPCSDCapacityError, (ValueError, np.linalg.LinAlgError))
 
 
+@pytest.mark.timeout(900)
+def test_trial_block_beyond_2p28_elements():
+    """384 x 500 x 1500 trials = 288 M doubles per operand of the flat projections (round 1 refused operands of 2^28
+    elements: the K offset of a K-major operand travelled in a 32-bit field; it is 64-bit scalar arithmetic now).  loglik
+    against the oracle, and the new limit -- one operand row of ntrials * nt >= 2^23 doubles -- raises the capacity error."""
+    import gpcsd_amd
+    c, g, geom, hp, _ = load_model_case("cfg3s_2d_384x500x2")
+    R = 1500
+    rs = np.random.RandomState(77)
+    lfp = rs.standard_normal((384, 500, R))
+    assert lfp.size > (1 << 28)
+    m = _model_from_case(c, g, lfp)
+    ll = m.loglik()
+    ref = O.loglik(geom, with_jitter(hp, 1e-7), lfp)
+    assert abs(ll - ref) / abs(ref) < 1e-9
+    m._ctx.close()
+    del m, lfp
+    # 24 electrodes x 500 samples x 17000 trials: ntrials * nt = 8.5 M >= 2^23
+    from gpcsd_amd.gpcsd1d import GPCSD1D
+    big = np.zeros((24, 500, 17000))
+    m2 = GPCSD1D(big, np.linspace(0, 2300, 24)[:, None], np.arange(500.0)[:, None], a=0.0, b=2300.0, ngl=50)
+    with pytest.raises(gpcsd_amd.GPCSDCapacityError):
+        m2.loglik()
+
+
 def test_shift_objective_fixture_whitened_quadratic_forms():
     """N4: the per-trial quadratic form behind the trial-shift objective (auditory_lfp/fit_mean_function.py:311-321), against
     the fixture produced with the reference's own comp_eig_D, and end to end through the library's comp_eig_D."""
