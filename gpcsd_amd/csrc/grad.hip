@@ -89,10 +89,10 @@ void k_D_sums(gpcsd_ctx *c, const double *D, const double *es, const double *et,
 // out[e] = scale * sum_b in[b*stride + e]  (+ dscale * dvec[i] on the diagonal of the n x n output)
 __global__ __launch_bounds__(256) void batch_reduce_kernel(const double *__restrict__ in, int nb, long stride, int n, double scale,
                                                            const double *__restrict__ dvec, double dscale,
-                                                           double *__restrict__ out, long s_in) {
-    in += blockIdx.y * s_in;                    // blockIdx.y = hyper-parameter set: inputs s_in apart, dvec n apart, out n*n apart
-    dvec += (long)blockIdx.y * n;
-    out += (long)blockIdx.y * n * n;
+                                                           double *__restrict__ out, long s_in, long s_dvec, long s_out) {
+    in += blockIdx.y * s_in;                    // blockIdx.y = hyper-parameter set
+    dvec += blockIdx.y * s_dvec;
+    out += blockIdx.y * s_out;
     const long e = blockIdx.x * 256L + threadIdx.x;
     if (e >= (long)n * n) return;
     double s = 0.0;
@@ -104,9 +104,11 @@ __global__ __launch_bounds__(256) void batch_reduce_kernel(const double *__restr
 }
 
 void k_batch_reduce(gpcsd_ctx *c, const double *in, int nb, long stride, int n, double scale, const double *dvec, double dscale,
-                    double *out, hipStream_t s, int B, long s_in) {
+                    double *out, hipStream_t s, int B, long s_in, long s_dvec, long s_out) {
+    if (s_dvec < 0) s_dvec = n;
+    if (s_out < 0) s_out = (long)n * n;
     hipLaunchKernelGGL(batch_reduce_kernel, dim3(ceil_div((long)n * n, 256), B), dim3(256), 0, s, in, nb, stride, n, scale, dvec,
-                       dscale, out, s_in);
+                       dscale, out, s_in, s_dvec, s_out);
     GP_HIP(hipGetLastError());
 }
 

@@ -531,6 +531,27 @@ void k_sym_fold_rect(gpcsd_ctx *c, const double *K, long ldk, const SymDev &rs, 
     GP_HIP(hipGetLastError());
 }
 
+// Inverse of the fold for a matrix that is block diagonal in the folded basis: G = F^T diag(Gss, Gaa) F, i.e.
+//   G[i][j] = w_i w_j Gss[orb_i][orb_j] + (sgn_i sgn_j / 2) Gaa[orb_i][orb_j]      (w = 1/sqrt2 for pair members, 1 for fixed points)
+// blockIdx.y = hyper-parameter set: inputs s_in apart (Gaa follows Gss), outputs n*n apart.
+__global__ __launch_bounds__(256) void sym_unfold_mat_kernel(const double *__restrict__ Gf, long s_in, SymDev sy, int n,
+                                                             double *__restrict__ out) {
+    const long e = blockIdx.x * 256L + threadIdx.x;
+    if (e >= (long)n * n) return;
+    const double *__restrict__ Gss = Gf + blockIdx.y * s_in, *__restrict__ Gaa = Gss + (long)sy.ns * sy.ns;
+    const int i = (int)(e / n), j = (int)(e % n);
+    const int a = sy.orb[i], b = sy.orb[j], si = sy.sgn[i], sj = sy.sgn[j];
+    const double isq2 = 0.70710678118654752440;
+    double v = ((si == 0) ? 1.0 : isq2) * ((sj == 0) ? 1.0 : isq2) * Gss[(long)a * sy.ns + b];
+    if (si != 0 && sj != 0) v += 0.5 * (double)(si * sj) * Gaa[(long)a * sy.na + b];
+    out[blockIdx.y * (long)n * n + e] = v;
+}
+void k_sym_unfold_mat(gpcsd_ctx *c, const double *Gf, long s_in, const SymDev &sy, int n, double *out, hipStream_t s, int B) {
+    (void)c;
+    hipLaunchKernelGGL(sym_unfold_mat_kernel, dim3(ceil_div((long)n * n, 256), B), dim3(256), 0, s, Gf, s_in, sy, n, out);
+    GP_HIP(hipGetLastError());
+}
+
 // Y[x][r][t] -> out[q][r][b], q / b = fold index of the electrode / the time point
 __global__ __launch_bounds__(256) void fold_lfp_kernel(const double *__restrict__ Y, int nx, int R, int nt, SymDev ss, SymDev st,
                                                        double *__restrict__ out) {

@@ -107,6 +107,8 @@ void k_swap_last2_sum(gpcsd_ctx *c, const double *in, int C, double *list, long 
 // final pass of a folded prediction (unfold in site and time, (r, t) -> (t, r), sum over components)
 void k_sym_fold_rect(gpcsd_ctx *c, const double *K, long ldk, const SymDev &rs, const SymDev &cs, double *out_ss, double *out_aa,
                      hipStream_t s);
+// G (n,n) = F^T diag(Gss, Gaa) F for B sets (inputs s_in apart: Gss (ns,ns) followed by Gaa (na,na); outputs n*n apart)
+void k_sym_unfold_mat(gpcsd_ctx *c, const double *Gf, long s_in, const SymDev &sy, int n, double *out, hipStream_t s, int B = 1);
 void k_fold_lfp(gpcsd_ctx *c, const double *Y, int nx, int R, int nt, const SymDev &ss, const SymDev &st, double *out,
                 hipStream_t s);
 void k_unfold_swap_sum(gpcsd_ctx *c, const double *in, int C, double *list, long list_stride, double *sum, int R, int nt,
@@ -197,9 +199,9 @@ void k_per_trial_quad(gpcsd_ctx *c, const double *alpha, const double *D, int nx
 // out[x] = sum_k B[x*rowlen + k]^2
 void k_rowgroup_sumsq(gpcsd_ctx *c, const double *B, int nrows, long rowlen, double *out, hipStream_t s);
 // out (n,n) = scale * sum_b in[b*stride + e] + dscale * diag(dvec)
-// B > 1: per hyper-parameter set, inputs s_in apart, dvec n apart, out n*n apart
+// B > 1: per hyper-parameter set, inputs s_in apart, dvec s_dvec apart (default n), out s_out apart (default n*n)
 void k_batch_reduce(gpcsd_ctx *c, const double *in, int nb, long stride, int n, double scale, const double *dvec, double dscale,
-                    double *out, hipStream_t s, int B = 1, long s_in = 0);
+                    double *out, hipStream_t s, int B = 1, long s_in = 0, long s_dvec = -1, long s_out = -1);
 // out[2c] = <Gt, dKt/d ell_c>, out[2c+1] = <Gt, dKt/d sigma2_c>
 // with a table: B sets (Gt nt*nt apart, outputs s_out apart); hp still supplies n_temporal
 void k_temporal_grad(gpcsd_ctx *c, const gpcsd_hparams *hp, const double *Gt, const double *t, int nt, double *out2C,
