@@ -311,8 +311,14 @@ def main():
         local_rank = int(os.environ["GPCSD_DEVICE"])
     import torch
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    # GPCSD_BENCH_FORCE_DIST=1: initialise the process group and shard even with one rank -- the only way to drive the RCCL
+    # code path (device tensors, broadcast, async all-reduce, barrier) on a one-GPU box
+    force_dist = os.environ.get("GPCSD_BENCH_FORCE_DIST") == "1"
+    if world > 1 or force_dist:
         import torch.distributed as td
+        os.environ.setdefault("MASTER_PORT", "29511")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
             td.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
@@ -334,7 +340,7 @@ def run_step_bench(args, w, rank, world, local_rank, backend):
     from gpcsd_amd.dist import TrialSharding
     n_gpus = world
     R_local = args.trials_per_gpu or w["trials_per_gpu"]
-    sharding = TrialSharding() if world > 1 else None
+    sharding = TrialSharding() if (world > 1 or os.environ.get("GPCSD_BENCH_FORCE_DIST") == "1") else None
 
     # ---- synthetic resident data (each rank draws its own block of trials) ----
     m = build_model(w, np.zeros((w["nx"], w["nt"], 1)))
@@ -349,18 +355,16 @@ def run_step_bench(args, w, rank, world, local_rank, backend):
     C = len(m.temporal_cov_list)
     R_total = R_local * n_gpus
 
+    # Hyper-parameters originate on rank 0: ONE broadcast before the loop (what fit() does -- every rank then walks the same
+    # deterministic optimiser trajectory, no per-evaluation broadcast is needed); every rank re-assembles Ks / Kt and their
+    # decompositions itself (deterministic kernels: bit-identical replicas).  Per step the only collective is the sum
+    # all-reduce of the partial quadratic term (one double over RCCL).
+    if sharding is not None:
+        m._set_from_tparams(sharding.broadcast(m._current_tparams(), src=0), False)
+
     def one_step():
-        # hyper-parameters originate on rank 0 (tiny broadcast), every rank re-assembles Ks/Kt/eig deterministically
         hp, keep = m._hparams(m.JITTER)
         hp0, keep0 = m._hparams(0.0)
-        if sharding is not None:
-            vec = np.array([hp.R, hp.eps, hp.ell_s[0], hp.ell_s[1]] + [hp.ell_t[i] for i in range(C)]
-                           + [hp.sigma2_t[i] for i in range(C)] + [float(keep[0])])
-            vec = sharding.broadcast(vec, src=0)
-            kinds = [hp.kind[i] for i in range(C)]
-            temporal = [(kinds[i], vec[4 + i], vec[4 + C + i]) for i in range(C)]
-            hp, keep = ctx.make_hparams(vec[0], vec[1], vec[2:4], temporal, vec[4 + 2 * C], m.JITTER)
-            hp0, keep0 = ctx.make_hparams(vec[0], vec[1], vec[2:4], temporal, vec[4 + 2 * C], 0.0)
         ta = time.perf_counter()
         sumlog, quad = ctx.loglik_parts(hp)
         pending = sharding.allreduce_sum_async(np.array([quad])) if sharding is not None else None
@@ -375,7 +379,7 @@ def run_step_bench(args, w, rank, world, local_rank, backend):
     def fence():
         ctx.synchronize()
         torch.cuda.synchronize()
-        if world > 1:
+        if sharding is not None:
             import torch.distributed as td
             td.barrier()
 
@@ -397,7 +401,7 @@ def run_step_bench(args, w, rank, world, local_rank, backend):
         t_pr += b
     fence()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if sharding is not None:
         import torch.distributed as td
         tt = torch.tensor([elapsed, t_ll, t_pr], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         td.all_reduce(tt, op=td.ReduceOp.MAX)
@@ -546,7 +550,7 @@ def run_fit_bench(args, w, rank, world, local_rank, backend):
     if os.environ.get("GPCSD_GRAM_PRECISION") == "32":              # BASELINE cfg5 names "fp32 kernel build + fp64 factor"
         m.gram_precision = 32
     ctx = m._sync_device()
-    sharding = TrialSharding() if world > 1 else None
+    sharding = TrialSharding() if (world > 1 or os.environ.get("GPCSD_BENCH_FORCE_DIST") == "1") else None
     if sharding is not None:
         m.shard_restarts(sharding)
     # restart k starts from the k-th draw of the default priors (np.random.seed(k), sampled on the host)
@@ -565,7 +569,7 @@ def run_fit_bench(args, w, rank, world, local_rank, backend):
     def fence():
         ctx.synchronize()
         torch.cuda.synchronize()
-        if world > 1:
+        if sharding is not None:
             import torch.distributed as td
             td.barrier()
     # G lock-step groups side by side, each with its own context (what fit(batch=B, workers=G) does): a step is one batched
@@ -623,7 +627,7 @@ def run_fit_bench(args, w, rank, world, local_rank, backend):
         ctx.loglik_grad(hps[i % len(hps)], ng)
     ctx.synchronize()
     seq_s = (time.perf_counter() - t1) / nseq
-    if world > 1:
+    if sharding is not None:
         import torch.distributed as td
         tt = torch.tensor([elapsed, seq_s], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         td.all_reduce(tt, op=td.ReduceOp.MAX)

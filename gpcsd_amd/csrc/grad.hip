@@ -87,16 +87,25 @@ void k_D_sums(gpcsd_ctx *c, const double *D, const double *es, const double *et,
 }
 
 // out[e] = scale * sum_b in[b*stride + e]  (+ dscale * dvec[i] on the diagonal of the n x n output)
+// LPE lanes share one output element: lane g adds the terms b = g, g + LPE, ... in order, the partial sums are combined in a
+// fixed xor tree.  With one lane per element a long sum (one term per trial: 200 at cfg5) is 200 dependent loads per
+// thread on a handful of workgroups -- 80 us for a 24 x 24 output; eight lanes per element bring it to ~10 us.
+template <int LPE>
 __global__ __launch_bounds__(256) void batch_reduce_kernel(const double *__restrict__ in, int nb, long stride, int n, double scale,
                                                            const double *__restrict__ dvec, double dscale,
                                                            double *__restrict__ out, long s_in, long s_dvec, long s_out) {
     in += blockIdx.y * s_in;                    // blockIdx.y = hyper-parameter set
     dvec += blockIdx.y * s_dvec;
     out += blockIdx.y * s_out;
-    const long e = blockIdx.x * 256L + threadIdx.x;
-    if (e >= (long)n * n) return;
+    const long e = (blockIdx.x * 256L + threadIdx.x) / LPE;
+    const int g = threadIdx.x % LPE;
+    const bool ok = e < (long)n * n;
     double s = 0.0;
-    for (int b = 0; b < nb; ++b) s += in[b * stride + e];
+    if (ok)
+        for (int b = g; b < nb; b += LPE) s += in[b * stride + e];
+#pragma unroll
+    for (int off = LPE / 2; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);   // (LPE lanes of an element sit in one wave)
+    if (!ok || g != 0) return;
     s *= scale;
     const int i = (int)(e / n), j = (int)(e % n);
     if (i == j) s += dscale * dvec[i];
@@ -107,8 +116,13 @@ void k_batch_reduce(gpcsd_ctx *c, const double *in, int nb, long stride, int n, 
                     double *out, hipStream_t s, int B, long s_in, long s_dvec, long s_out) {
     if (s_dvec < 0) s_dvec = n;
     if (s_out < 0) s_out = (long)n * n;
-    hipLaunchKernelGGL(batch_reduce_kernel, dim3(ceil_div((long)n * n, 256), B), dim3(256), 0, s, in, nb, stride, n, scale, dvec,
-                       dscale, out, s_in, s_dvec, s_out);
+    // the split depends on the sum's length only (never on B): a set is reduced the same way alone or in a batch
+    if (nb >= 32)
+        hipLaunchKernelGGL(batch_reduce_kernel<8>, dim3(ceil_div((long)n * n * 8, 256), B), dim3(256), 0, s, in, nb, stride, n, scale,
+                           dvec, dscale, out, s_in, s_dvec, s_out);
+    else
+        hipLaunchKernelGGL(batch_reduce_kernel<1>, dim3(ceil_div((long)n * n, 256), B), dim3(256), 0, s, in, nb, stride, n, scale,
+                           dvec, dscale, out, s_in, s_dvec, s_out);
     GP_HIP(hipGetLastError());
 }
 

@@ -45,13 +45,35 @@ class TrialSharding:
 
     def allreduce_sum_async(self, values):
         """Start the sum all-reduce and return a callable that waits for it and yields the NumPy result: the caller can
-        queue independent GPU work (e.g. predict after loglik) while the collective is in flight."""
-        t = self._tensor(values)
-        work = self._td.all_reduce(t, op=self._td.ReduceOp.SUM, group=self._group, async_op=True)
+        queue independent GPU work (e.g. predict after loglik) while the collective is in flight.  The message is a few
+        doubles, so what it costs is host latency: the staging tensors (pinned host + device) are allocated once per size
+        and both copies are non-blocking on a side stream; only the final read waits."""
+        values = np.ascontiguousarray(values, dtype=np.float64)
+        if self._device.type != "cuda":
+            t = self._tensor(values)
+            work = self._td.all_reduce(t, op=self._td.ReduceOp.SUM, group=self._group, async_op=True)
+
+            def result_cpu():
+                work.wait()
+                return t.numpy().copy()
+            return result_cpu
+        torch = self._torch
+        key = values.size
+        cache = self.__dict__.setdefault("_staging", {})
+        if key not in cache:
+            cache[key] = (torch.empty(key, dtype=torch.float64).pin_memory(), torch.empty(key, dtype=torch.float64, device=self._device),
+                          torch.cuda.Stream(device=self._device), torch.cuda.Event())
+        host, dev, stream, done = cache[key]
+        host.numpy()[:] = values
+        with torch.cuda.stream(stream):
+            dev.copy_(host, non_blocking=True)
+            self._td.all_reduce(dev, op=self._td.ReduceOp.SUM, group=self._group)      # enqueued on `stream`, returns at once
+            host.copy_(dev, non_blocking=True)
+            done.record(stream)
 
         def result():
-            work.wait()
-            return t.cpu().numpy()
+            done.synchronize()
+            return host.numpy().copy()
         return result
 
     def broadcast(self, values, src=0):
