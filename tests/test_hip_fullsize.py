@@ -511,3 +511,18 @@ def test_bench_step_two_ranks_gloo_on_one_gpu():
     m.update_lfp(np.concatenate(blocks, axis=2), w["t"])
     ll = float(m.loglik())
     assert abs(ll - two["loglik"]) / abs(ll) < 1e-10
+
+
+@pytest.mark.timeout(900)
+def test_bench_cfg5_two_ranks_restart_sharding_over_the_hip_objective():
+    """bench.py --workload cfg5 with two ranks sharing the one GPU (gloo): restarts are sharded over the ranks, every rank's
+    lock-step groups run the real HIP objective, and the combined fit equals the single-process fit of all 32 restarts."""
+    env = dict(os.environ, GPCSD_BENCH_BACKEND="gloo", GPCSD_DEVICE="0", MASTER_ADDR="127.0.0.1")
+    port = 29900 + os.getpid() % 400
+    common = ["--workload", "cfg5", "--steps", "3", "--warmup", "1", "--fit-maxiter", "4"]
+    two = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                "127.0.0.1", "--master-port", str(port), "bench.py", "--gpus", "2"] + common, env)
+    one = _run([sys.executable, "bench.py", "--gpus", "1"] + common, dict(os.environ))
+    assert two["n_gpus"] == 2 and two["config"]["restarts_per_gpu"] == 16 and two["value"] > 0
+    assert two["fit"]["restarts"] == 32 and one["fit"]["restarts"] == 32
+    assert two["fit"]["best_nll"] == one["fit"]["best_nll"]           # same starts, bitwise-equal evaluations, same optimum
