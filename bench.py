@@ -667,7 +667,8 @@ def run_fit_bench(args, w, rank, world, local_rank, backend):
         "all_groups_over_sequential": (G * B / step_s) / (1.0 / seq_s),
         "fit": {"restarts": total_restarts, "maxiter": args.fit_maxiter, "seconds": fit_s,
                 "restarts_per_sec": total_restarts / fit_s, "evals": int(npts) * world, "batched_calls": int(nb),
-                "evals_per_sec_through_scipy": npts * world / fit_s, "best_nll": float(np.min(m.fit_nll_values_))},
+                "evals_per_sec_through_scipy": npts * world / fit_s, "best_nll": float(np.min(m.fit_nll_values_)),
+                "nll_values": [float(v) for v in np.asarray(m.fit_nll_values_)]},
         "roofline": {"bound": "mfma", "unit": "TFLOP/s", "peak": FP64_MFMA_SPEC_TFLOPS,
                      "achieved": G * (gemm_flops + eig_flops) / step_s / 1e12,
                      "frac": G * (gemm_flops + eig_flops) / step_s / 1e12 / FP64_MFMA_SPEC_TFLOPS,

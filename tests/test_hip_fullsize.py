@@ -522,7 +522,10 @@ def test_bench_cfg5_two_ranks_restart_sharding_over_the_hip_objective():
     common = ["--workload", "cfg5", "--steps", "3", "--warmup", "1", "--fit-maxiter", "4"]
     two = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
                 "127.0.0.1", "--master-port", str(port), "bench.py", "--gpus", "2"] + common, env)
-    one = _run([sys.executable, "bench.py", "--gpus", "1"] + common, dict(os.environ))
+    # torch.distributed.run pins OMP_NUM_THREADS=1 in its workers; the synthetic data come out of NumPy matmuls whose rounding
+    # depends on the BLAS thread count, and truncated optimisations from wild prior draws amplify a last-bit change of the
+    # data -- the single-process reference must generate its data the same way
+    one = _run([sys.executable, "bench.py", "--gpus", "1"] + common, dict(os.environ, OMP_NUM_THREADS="1"))
     assert two["n_gpus"] == 2 and two["config"]["restarts_per_gpu"] == 16 and two["value"] > 0
     assert two["fit"]["restarts"] == 32 and one["fit"]["restarts"] == 32
-    assert two["fit"]["best_nll"] == one["fit"]["best_nll"]           # same starts, bitwise-equal evaluations, same optimum
+    assert two["fit"]["nll_values"] == one["fit"]["nll_values"]       # same starts, bitwise-equal evaluations, same optima
