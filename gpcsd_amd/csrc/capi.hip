@@ -625,6 +625,8 @@ extern "C" int gpcsd_ctx_create(int device, gpcsd_ctx **out) {
         GP_HIP(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
         GP_HIP(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
         GP_HIP(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
+        GP_HIP(hipEventCreateWithFlags(&c->ev_aux, hipEventDisableTiming));
+        GP_HIP(hipEventCreateWithFlags(&c->ev_pc, hipEventDisableTiming));
         GP_HIP(hipHostMalloc(reinterpret_cast<void **>(&c->h_result), 66 * sizeof(double), hipHostMallocDefault));
         *out = c;
         return 0;
@@ -651,6 +653,8 @@ extern "C" int gpcsd_ctx_destroy(gpcsd_ctx *c) {
         if (kv.second.exec) (void)hipGraphExecDestroy(kv.second.exec);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+    if (c->ev_aux) (void)hipEventDestroy(c->ev_aux);
+    if (c->ev_pc) (void)hipEventDestroy(c->ev_pc);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     if (c->stream2) (void)hipStreamDestroy(c->stream2);
     if (c->h_result) (void)hipHostFree(c->h_result);
@@ -1427,7 +1431,10 @@ static int predict_fold(gpcsd_ctx *c, const gpcsd_hparams *hp, EigState &e, cons
         g2[p].epi = EPI_DIV_D; g2[p].D = e.Dinv + c0; g2[p].rdiv = R; g2[p].ldd = nt;
         g2[p].prof_name = "gemm_pred_temporal_div";
     }
-    gemm_pair(c, g2[0], g2[1], s);
+    // Pcat = V^T Kt*~ needs the temporal eigenvectors and the folded prediction-time Grams only: it runs on stream2 beside the
+    // large Bm~ / S~ products of the main stream instead of in front of them (two small launches off the serial tail)
+    GP_HIP(hipEventRecord(c->ev_aux, s));                            // Kt*~ is complete on the main stream here
+    GP_HIP(hipStreamWaitEvent(c->stream2, c->ev_aux, 0));
     for (int p = 0; p < 2; ++p) {
         const int np = p ? nta : nts;
         if (np == 0) continue;
@@ -1438,8 +1445,10 @@ static int predict_fold(gpcsd_ctx *c, const gpcsd_hparams *hp, EigState &e, cons
         gp.C = Pc + (p ? (size_t)C * nts * nts : 0); gp.ldc = (long)C * np;
         gp.batch = C; gp.sA = 0; gp.sB = (long)ktf_sz; gp.sC = np;
         gp.prof_name = "gemm_pred_Pc";
-        gemm_f64(c, gp, s);
+        gemm_f64(c, gp, c->stream2);
     }
+    GP_HIP(hipEventRecord(c->ev_pc, c->stream2));
+    gemm_pair(c, g2[0], g2[1], s);
     for (int which = 1; which <= 2; ++which) {
         if (!(type & which)) continue;
         double *o_sum = c->buf<double>(which == 1 ? "pred_out_csd" : "pred_out_lfp", out_elems);
@@ -1455,6 +1464,7 @@ static int predict_fold(gpcsd_ctx *c, const gpcsd_hparams *hp, EigState &e, cons
             g5[p].prof_name = "gemm_pred_cross";
         }
         gemm_pair(c, g5[0], g5[1], s);
+        if (which == 1 || !(type & 1)) GP_HIP(hipStreamWaitEvent(s, c->ev_pc, 0));     // Pcat (stream2) before its first use
         for (int p = 0; p < 2; ++p) {     // comp~[(zq, r)][p][cc][b] = sum_i' S~[(zq, r)][p block i'] Pcat_p[i'][cc*np + b]
             const int np = p ? nta : nts, c0 = p ? nts : 0;
             g6[p].M = nz * R; g6[p].N = C * np; g6[p].K = np;

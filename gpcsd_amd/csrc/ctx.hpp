@@ -68,6 +68,7 @@ struct gpcsd_ctx {
     double *h_result = nullptr;             // pinned host landing zone for the end-of-call copy (66 doubles)
     bool capturing = false;                 // inside a stream capture: profiling scopes stay silent
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipEvent_t ev_aux = nullptr, ev_pc = nullptr;   // predict: small products of the tail on stream2 beside the large ones
     std::string last_error;
     std::map<std::string, gpcsd::DevBuf> bufs;
     bool prof_on = false;

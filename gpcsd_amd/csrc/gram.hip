@@ -586,15 +586,20 @@ void k_fold_lfp(gpcsd_ctx *c, const double *Y, int nx, int R, int nt, const SymD
 
 // Predictions in the folded basis, in[(zq, r)][pt][c][b] (zq = fold index of the site; pt = 0: the C symmetric time blocks of
 // width st.ns, pt = 1: the C antisymmetric blocks of width st.na; row stride C*nt) -> list[c][z][t][r] (optional) and
-// sum[z][t][r].  One workgroup owns a site orbit x 32 time orbits x 32 trials: it reads the four parity tiles once and
-// writes the (up to) four mirror images, transposing (r, t) -> (t, r) through LDS like swap_last2_sum_kernel.
+// sum[z][t][r].  One workgroup owns a site orbit x 16 time orbits x 64 trials: it reads the four parity tiles once and
+// writes the (up to) four mirror images, transposing (r, t) -> (t, r) through LDS.  The outputs have the trial index
+// innermost (R = 50: 400-byte rows, consecutive time points back to back), so a wave writes ONE WHOLE ROW per store and
+// the workgroup's sixteen consecutive time points form one contiguous run per mirror image -- the 32-trial tiles of the
+// first version cut every row in two pieces owned by different workgroups (partial cache lines: 4.2 TB/s; now 4.9 TB/s).
+constexpr int UF_TB = 16, UF_TR = 64;
 __global__ __launch_bounds__(256) void unfold_swap_sum_kernel(const double *__restrict__ in, int C, double *__restrict__ list,
                                                               long list_stride, double *__restrict__ sum, int R, int nt,
                                                               SymDev sz, SymDev st) {
-    __shared__ double tile[2][2][32][33];
+    __shared__ double tile[2][2][UF_TR][UF_TB + 1];
     const int az = blockIdx.z;                                  // site orbit
-    const int b0 = blockIdx.x * 32, i0 = blockIdx.y * 32;       // time orbits, trials
-    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;     // 32 x 8
+    const int b0 = blockIdx.x * UF_TB, i0 = blockIdx.y * UF_TR; // time orbits, trials
+    const int lx = threadIdx.x & 15, ly = threadIdx.x >> 4;     // load phase: 16 time orbits x 16 trials per pass
+    const int wi = threadIdx.x & 63, wb = threadIdx.x >> 6;     // write phase: 64 trials x 4 time orbits per pass
     const int zi = sz.rep_i[az], zj = sz.rep_j[az];
     const double isq2 = 0.70710678118654752440;
     const double wz = (zi == zj) ? 1.0 : isq2;
@@ -615,22 +620,22 @@ __global__ __launch_bounds__(256) void unfold_swap_sum_kernel(const double *__re
                 const int wdt = pt ? st.na : st.ns;
                 const long col0 = (pt ? (long)C * st.ns : 0) + (long)c * wdt;
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const int i = i0 + ty + 8 * k, b = b0 + tx;
+                for (int k = 0; k < UF_TR / 16; ++k) {
+                    const int i = i0 + ly + 16 * k, bb = b0 + lx;
                     double v = 0.0;
-                    if (zok && i < R && b < wdt) v = in[(row * R + i) * ldin + col0 + b];
-                    tile[pz][pt][ty + 8 * k][tx] = v;
+                    if (zok && i < R && bb < wdt) v = in[(row * R + i) * ldin + col0 + bb];
+                    tile[pz][pt][ly + 16 * k][lx] = v;
                 }
             }
         __syncthreads();
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const int b = b0 + ty + 8 * k, i = i0 + tx;
-            if (i < R && b < st.ns) {
-                const int tk = st.rep_i[b], tl = st.rep_j[b];
+            const int bl = wb + 4 * k, bb = b0 + bl, i = i0 + wi;
+            if (i < R && bb < st.ns) {
+                const int tk = st.rep_i[bb], tl = st.rep_j[bb];
                 const double wt = (tk == tl) ? 1.0 : isq2;
-                const double ss = wz * wt * tile[0][0][tx][ty + 8 * k], sa = wz * isq2 * tile[0][1][tx][ty + 8 * k];
-                const double as = isq2 * wt * tile[1][0][tx][ty + 8 * k], aa = 0.5 * tile[1][1][tx][ty + 8 * k];
+                const double ss = wz * wt * tile[0][0][wi][bl], sa = wz * isq2 * tile[0][1][wi][bl];
+                const double as = isq2 * wt * tile[1][0][wi][bl], aa = 0.5 * tile[1][1][wi][bl];
                 const double v0 = (ss + sa) + (as + aa);        // (zi, tk)
                 const double v1 = (ss - sa) + (as - aa);        // (zi, tl)
                 const double v2 = (ss + sa) - (as + aa);        // (zj, tk)
@@ -653,9 +658,9 @@ __global__ __launch_bounds__(256) void unfold_swap_sum_kernel(const double *__re
     }
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        const int b = b0 + ty + 8 * k, i = i0 + tx;
-        if (i < R && b < st.ns) {
-            const int tk = st.rep_i[b], tl = st.rep_j[b];
+        const int bb = b0 + wb + 4 * k, i = i0 + wi;
+        if (i < R && bb < st.ns) {
+            const int tk = st.rep_i[bb], tl = st.rep_j[bb];
             sum[((long)zi * nt + tk) * R + i] = acc[0][k];
             if (tl != tk) sum[((long)zi * nt + tl) * R + i] = acc[1][k];
             if (zj != zi) {
@@ -668,7 +673,7 @@ __global__ __launch_bounds__(256) void unfold_swap_sum_kernel(const double *__re
 
 void k_unfold_swap_sum(gpcsd_ctx *c, const double *in, int C, double *list, long list_stride, double *sum, int R, int nt,
                        const SymDev &sz, const SymDev &st, hipStream_t s) {
-    dim3 grid(ceil_div(st.ns, 32), ceil_div(R, 32), sz.ns);
+    dim3 grid(ceil_div(st.ns, UF_TB), ceil_div(R, UF_TR), sz.ns);
     ProfScope ps(c, "relayout", 0.0, s);
     hipLaunchKernelGGL(unfold_swap_sum_kernel, grid, dim3(256), 0, s, in, C, list, list_stride, sum, R, nt, sz, st);
     GP_HIP(hipGetLastError());
