@@ -19,7 +19,8 @@ static int fail(gpcsd_ctx *c, const HipError &e) {
 #define GP_API_BEGIN(ctx)                                                                      \
     if (!(ctx)) return fail(nullptr, HipError{-1, "null context"});                            \
     try {                                                                                      \
-        GP_HIP(hipSetDevice((ctx)->device));
+        GP_HIP(hipSetDevice((ctx)->device));                                                   \
+        ++(ctx)->api_seq;
 #define GP_API_END(ctx)                                                                        \
     }                                                                                          \
     catch (const HipError &e) { drain_after_failure(ctx); return fail((ctx), e); }             \
@@ -32,7 +33,19 @@ static void drain_after_failure(gpcsd_ctx *c) {
     if (c->stream2) (void)hipStreamSynchronize(c->stream2);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     c->status_zeroed = false;
+    c->async_pending = c->fork_recorded = false;   // everything is drained: no deferred status, no early fork point
     c->decomp_gen[0] = c->decomp_gen[1] = -1;   // whatever the failed call left behind is not reused
+}
+
+static int drain_async(gpcsd_ctx *c);
+
+// stream2 may start a temporal chain once the main stream has finished with Kt / Qt / et: normally "now" in main-stream
+// order.  Right behind an asynchronous predict that point was already recorded behind its last reader of those buffers,
+// i.e. in front of its GEMM tail (valid for the very next API call only: any call in between may have queued new readers).
+static void fork_temporal_chain(gpcsd_ctx *c, hipStream_t s) {
+    if (!(c->fork_recorded && c->api_seq == c->fork_seq + 1)) GP_HIP(hipEventRecord(c->ev_fork, s));
+    c->fork_recorded = false;
+    GP_HIP(hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
 }
 
 void gpcsd_ctx::prof_collect() {
@@ -363,7 +376,7 @@ EigState front_half(gpcsd_ctx *c, const gpcsd_hparams *hp, double jitter, bool n
     };
     if (!two_stream_front()) {
         double *d_sig = c->upload_cached<double>("sig2n", hp->sig2n, hp->n_sig2n);
-        if (!c->status_zeroed) GP_HIP(hipMemsetAsync(e.status, 0, 4 * sizeof(int), s));
+        if (!c->status_zeroed && !c->async_pending) GP_HIP(hipMemsetAsync(e.status, 0, 4 * sizeof(int), s));
         c->status_zeroed = false;
         build_kphi(c, g, hp->R, hp->eps, hp->ell_s, nullptr, 0, jitter, Ks, s);
         make_kt(s);
@@ -380,7 +393,7 @@ EigState front_half(gpcsd_ctx *c, const gpcsd_hparams *hp, double jitter, bool n
     hipStream_t s2 = c->stream2;
     // The status words are zeroed at the END of the previous call (finish_call / finish_status), off the critical path of
     // this one; only a call that did not end that way (first call, an exception in between) clears them here.
-    if (!c->status_zeroed) GP_HIP(hipMemsetAsync(e.status, 0, 4 * sizeof(int), s));
+    if (!c->status_zeroed && !c->async_pending) GP_HIP(hipMemsetAsync(e.status, 0, 4 * sizeof(int), s));
     c->status_zeroed = false;
     struct {                                   // everything the temporal side's result depends on
         long epoch;
@@ -396,8 +409,7 @@ EigState front_half(gpcsd_ctx *c, const gpcsd_hparams *hp, double jitter, bool n
         kt_key.s2[i] = hp->sigma2_t[i];
     }
     if (!decomp_cached(c, 1, &kt_key, sizeof(kt_key))) {
-        GP_HIP(hipEventRecord(c->ev_fork, s));
-        GP_HIP(hipStreamWaitEvent(s2, c->ev_fork, 0));
+        fork_temporal_chain(c, s);
         make_kt(s2);
         {
             ProfScope ps(c, "eigh_temporal", 9.0 * (double)nt * nt * nt, s2);
@@ -567,6 +579,7 @@ int finish_call(gpcsd_ctx *c, const EigState &e, double *scal_out, int nscal) {
     GP_HIP(hipMemsetAsync(e.status, 0, 4 * sizeof(int), c->stream));   // clean status words for the next call, after the copy
     c->sync();
     c->status_zeroed = true;
+    c->async_pending = false;              // whatever an asynchronous predict left in the status words has been collected now
     if (c->prof_on) c->prof_collect();
     for (int i = 0; i < nscal; ++i) scal_out[i] = host[i];
     int st[4];
@@ -687,7 +700,7 @@ extern "C" int gpcsd_device_synchronize(gpcsd_ctx *c) {
     GP_API_BEGIN(c)
     GP_HIP(hipStreamSynchronize(c->stream2));
     c->sync();
-    return 0;
+    return drain_async(c);
     GP_API_END(c)
 }
 
@@ -1375,7 +1388,7 @@ static const SymDev &site_symmetry(gpcsd_ctx *c, const double *z, int nz, int di
 //   out_c = Fz^T [ diag_p( (Kc_pp^T U_p) ) Bm~ diag_q( V_q^T Kt*_c,qq ) ] Ft   with Bm~ = (diag(U)^T Y~ diag(V)) / D~ ,
 // every flat GEMM split in its two parity blocks; the last pass unfolds sites and times while it transposes.
 static int predict_fold(gpcsd_ctx *c, const gpcsd_hparams *hp, EigState &e, const FoldMode &fm, const double *Yf, const SymDev &sz,
-                        const double *dz, int nz, const double *dts, int type, bool want_lists) {
+                        const double *dz, int nz, const double *dts, int type, bool want_lists, bool async) {
     const Geo g = resident_geo(c);
     const int nx = c->nx, nt = c->nt, R = c->ntrials, C = hp->n_temporal;
     const long RT = (long)R * nt;
@@ -1449,6 +1462,11 @@ static int predict_fold(gpcsd_ctx *c, const gpcsd_hparams *hp, EigState &e, cons
     }
     GP_HIP(hipEventRecord(c->ev_pc, c->stream2));
     gemm_pair(c, g2[0], g2[1], s);
+    if (async) {                          // last main-stream reader of the temporal buffers: the next call's stream2 may go
+        GP_HIP(hipEventRecord(c->ev_fork, s));
+        c->fork_recorded = true;
+        c->fork_seq = c->api_seq;
+    }
     for (int which = 1; which <= 2; ++which) {
         if (!(type & which)) continue;
         double *o_sum = c->buf<double>(which == 1 ? "pred_out_csd" : "pred_out_lfp", out_elems);
@@ -1476,6 +1494,11 @@ static int predict_fold(gpcsd_ctx *c, const gpcsd_hparams *hp, EigState &e, cons
         gemm_pair(c, g6[0], g6[1], s);
         k_unfold_swap_sum(c, comp, C, o_list, (long)out_elems, o_sum, R, nt, sz, fm.sym_t, s);
     }
+    if (async && !c->prof_on) {           // results stay on the device: return with the tail still in flight
+        c->async_pending = true;
+        c->status_zeroed = false;
+        return 0;
+    }
     return finish_call(c, e, nullptr, 0);
 }
 
@@ -1483,7 +1506,7 @@ static int predict_fold(gpcsd_ctx *c, const gpcsd_hparams *hp, EigState &e, cons
 //   pred_out_csd / pred_out_lfp            (nz, ntstar, R)
 //   pred_out_csd_list / pred_out_lfp_list  (C, nz, ntstar, R)     when want_lists
 static int predict_impl(gpcsd_ctx *c, const gpcsd_hparams *hp, const double *z, int nz, const double *tstar, int ntstar,
-                        int type, bool want_lists) {
+                        int type, bool want_lists, bool async = false) {
     GP_REQUIRE(z && tstar && nz > 0 && ntstar > 0, -3, "predict: bad arguments");
     GP_REQUIRE(type >= 1 && type <= 3, -3, "predict: type must be CSD(1), LFP(2) or BOTH(3)");
     GP_REQUIRE(c->nt > 0 && ntstar == c->nt, -22,
@@ -1504,7 +1527,7 @@ static int predict_impl(gpcsd_ctx *c, const gpcsd_hparams *hp, const double *z, 
             double *dzf = c->upload_cached<double>("pred_z", z, (size_t)nz * c->dim);
             double *dtf = c->upload_cached<double>("pred_tstar", tstar, ntstar);
             EigState ef = front_half(c, hp, 0.0, false);  // no jitter in predict (gpcsd1d.py:258)
-            return predict_fold(c, hp, ef, fm, Yf, sz, dzf, nz, dtf, type, want_lists);
+            return predict_fold(c, hp, ef, fm, Yf, sz, dzf, nz, dtf, type, want_lists, async);
         }
     }
     EigState e = front_half(c, hp, 0.0);           // no jitter in predict (gpcsd1d.py:258)
@@ -1589,10 +1612,20 @@ static int predict_impl(gpcsd_ctx *c, const gpcsd_hparams *hp, const double *z, 
     return finish_call(c, e, nullptr, 0);
 }
 
+// Collect the status words of an asynchronous predict (see gpcsd_ctx::async_pending): drains the streams.
+static int drain_async(gpcsd_ctx *c) {
+    if (!c->async_pending) return 0;
+    c->async_pending = false;
+    int *st = reinterpret_cast<int *>(c->buf<double>("scal_status", 64 + 2) + 64);
+    GP_HIP(hipStreamSynchronize(c->stream2));
+    return finish_status(c, st);          // downloads + synchronises; the words are cleared by the next call's front half
+}
+
 extern "C" int gpcsd_predict_resident(gpcsd_ctx *c, const gpcsd_hparams *hp, const double *z, int nz, const double *tstar,
                                       int ntstar, int type, int want_lists) {
     GP_API_BEGIN(c)
-    return predict_impl(c, hp, z, nz, tstar, ntstar, type, want_lists != 0);
+    static const bool fenced = getenv("GPCSD_SYNC_PREDICT") && getenv("GPCSD_SYNC_PREDICT")[0] == '1';   // A/B switch
+    return predict_impl(c, hp, z, nz, tstar, ntstar, type, want_lists != 0, /*async=*/!fenced);
     GP_API_END(c)
 }
 
@@ -1605,7 +1638,7 @@ extern "C" int gpcsd_fetch(gpcsd_ctx *c, const char *name, double *host, long co
                it->second.bytes, count);
     c->download(host, it->second.p, (size_t)count * sizeof(double));
     c->sync();
-    return 0;
+    return drain_async(c);                // a numerical failure of a preceding asynchronous predict surfaces here
     GP_API_END(c)
 }
 
@@ -1759,8 +1792,7 @@ static int loglik_grad_impl(gpcsd_ctx *c, const gpcsd_hparams *hps, int B, doubl
 
     // ---- front half: temporal chain on stream2 (queued first: the critical path), spatial chain on the main stream
     GP_HIP(hipMemsetAsync(st, 0, (size_t)2 * B * sizeof(int), s));
-    GP_HIP(hipEventRecord(c->ev_fork, s));
-    GP_HIP(hipStreamWaitEvent(s2, c->ev_fork, 0));
+    fork_temporal_chain(c, s);
     k_temporal_gram(c, C, nullptr, nullptr, nullptr, t, nt, t, nt, Kt, s2, tab, B, ntt);
     {
         ProfScope ps(c, "eigh_temporal", 9.0 * (double)nt * nt * nt * B, s2);
@@ -2095,6 +2127,7 @@ static int loglik_grad_impl(gpcsd_ctx *c, const gpcsd_hparams *hps, int B, doubl
 extern "C" int gpcsd_loglik_grad(gpcsd_ctx *c, const gpcsd_hparams *hp, double *out2, double *grad, int ngrad) {
     GP_API_BEGIN(c)
     GP_REQUIRE(hp != nullptr, -3, "loglik_grad: null hparams");
+    if (int rc = drain_async(c)) return rc;      // (this path keeps its own status words)
     return loglik_grad_impl(c, hp, 1, out2, grad, ngrad, nullptr);
     GP_API_END(c)
 }
@@ -2103,6 +2136,7 @@ extern "C" int gpcsd_loglik_grad_batch(gpcsd_ctx *c, const gpcsd_hparams *hps, i
                                        int *status) {
     GP_API_BEGIN(c)
     GP_REQUIRE(hps && nsets >= 1 && status, -3, "loglik_grad_batch: bad arguments");
+    if (int rc = drain_async(c)) return rc;
     (void)loglik_grad_impl(c, hps, nsets, out2, grad, ngrad, status);   // per-set failures are reported in status[], not as rc
     return 0;
     GP_API_END(c)

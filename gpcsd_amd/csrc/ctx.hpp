@@ -68,6 +68,14 @@ struct gpcsd_ctx {
     double *h_result = nullptr;             // pinned host landing zone for the end-of-call copy (66 doubles)
     bool capturing = false;                 // inside a stream capture: profiling scopes stay silent
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    // gpcsd_predict_resident returns once its work is queued (the results stay on the device anyway): the next call's
+    // temporal chain then runs under this call's GEMM tail instead of after it.  fork_recorded: ev_fork was recorded by the
+    // previous call right after its last read of the temporal buffers (instead of by the next call at its start);
+    // async_pending: the status words of that call have not been collected yet -- the next synchronising call
+    // (gpcsd_fetch, gpcsd_device_synchronize, any call that returns values) reports them.
+    bool fork_recorded = false;
+    long api_seq = 0, fork_seq = -1;       // API calls entered so far / the call that recorded the early fork point
+    bool async_pending = false;
     hipEvent_t ev_aux = nullptr, ev_pc = nullptr;   // predict: small products of the tail on stream2 beside the large ones
     std::string last_error;
     std::map<std::string, gpcsd::DevBuf> bufs;

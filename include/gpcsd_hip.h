@@ -74,6 +74,7 @@ int  gpcsd_ctx_create(int device, gpcsd_ctx **out);
 int  gpcsd_ctx_destroy(gpcsd_ctx *ctx);
 const char *gpcsd_last_error(gpcsd_ctx *ctx);     /* ctx may be NULL: last global error */
 int  gpcsd_version(void);
+/* waits for everything queued on the context; also reports (rc > 0) a pending asynchronous gpcsd_predict_resident's failure */
 int  gpcsd_device_synchronize(gpcsd_ctx *ctx);
 /* Page-locked host blocks for result arrays (gpcsd2d.py:328-334 returns host arrays of (1+C)*nz*nt*ntrials doubles: 231 MB
  * at 384 x 500 x 50).  Outputs handed to gpcsd_predict / gpcsd_fetch / gpcsd_sample_prior may live in such a block, in which
@@ -186,10 +187,16 @@ int gpcsd_predict(gpcsd_ctx *ctx, const gpcsd_hparams *hp, const double *z, int 
                   double *csd_list, double *csd, double *lfp_list, double *lfp);
 /* Same computation, results left in ctx-owned device buffers in the output layout (z, t, trial); nothing crosses
  * PCIe.  Buffers: "pred_out_csd", "pred_out_lfp" (nz*ntstar*ntrials) and, when want_lists,
- * "pred_out_csd_list", "pred_out_lfp_list" (n_temporal times that).  Read them back with gpcsd_fetch. */
+ * "pred_out_csd_list", "pred_out_lfp_list" (n_temporal times that).  Read them back with gpcsd_fetch.
+ * ASYNCHRONOUS on the symmetric-grid (folded) path: the call validates its arguments, queues the work and returns 0 with
+ * the GEMM tail still in flight; any later call on the context is ordered behind it (the next call's temporal
+ * eigen-chain runs beside that tail, which is the point).  A numerical failure (rc > 0) of such a call is reported by the
+ * next call on the context that synchronises: gpcsd_fetch, gpcsd_device_synchronize, or any call that returns values
+ * (gpcsd_loglik*, gpcsd_predict, ...).  Argument errors (rc < 0) are still reported by the call itself. */
 int gpcsd_predict_resident(gpcsd_ctx *ctx, const gpcsd_hparams *hp, const double *z, int nz,
                            const double *tstar, int ntstar, int type, int want_lists);
-/* copy `count` doubles of the named ctx-owned device buffer to host; rc -2 if the name is unknown */
+/* copy `count` doubles of the named ctx-owned device buffer to host; rc -2 if the name is unknown; rc > 0 if the
+ * asynchronous gpcsd_predict_resident that produced the buffer failed numerically */
 int gpcsd_fetch(gpcsd_ctx *ctx, const char *name, double *host, long count);
 /* sample_prior with host-supplied standard normals (nx, nt, ntrials): Ls Z_r Lt^T
  * gpcsd1d.py:295-309 / gpcsd2d.py:336-360.  which: GPCSD_PRED_CSD (compute_Ks) or GPCSD_PRED_LFP (compKphi) */

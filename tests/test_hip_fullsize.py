@@ -468,6 +468,66 @@ def test_decomposition_cache_reuses_unchanged_sides_bitwise():
     assert relerr(m.csd_pred, O.predict(geom, hp2, lfp, c["x"], c["t"], type="csd")["csd"]) < GATE
 
 
+def test_predict_resident_is_asynchronous_and_changes_no_bits():
+    """gpcsd_predict_resident returns with its GEMM tail in flight; the next call's temporal eigen-chain runs beside that
+    tail.  A loglik -> predict_resident loop (changing hyper-parameters every step) gives the bits of the same calls fenced
+    one by one; a numerical failure of an asynchronous predict surfaces at the next synchronising call, and the context
+    stays usable."""
+    from gpcsd_amd import _hip
+    c, g, geom, hp, lfp = load_model_case("2d_npx_96x120x3")
+    m = _model_from_case(c, g, lfp)
+    ctx = m._sync_device()
+    ctx.decomposition_cache(False)
+    z, t = np.ascontiguousarray(c["x"]), c["t"]
+    shape = (z.shape[0], t.shape[0], lfp.shape[2])
+    ells = [m.temporal_cov_list[0].params["ell"]["value"] * f for f in (1.0, 1.1, 0.9, 1.05, 1.0)]
+
+    def run(fenced):
+        out = []
+        for ell in ells:
+            m.temporal_cov_list[0].params["ell"]["value"] = ell
+            hp1, keep1 = m._hparams(m.JITTER)
+            hp0, keep0 = m._hparams(0.0)
+            parts = ctx.loglik_parts(hp1)
+            ctx.predict_resident(hp0, z, t, _hip.PRED_CSD, want_lists=True)
+            if fenced:
+                ctx.synchronize()
+            out.append(parts)
+        out.append(ctx.fetch("pred_out_csd", shape).copy())
+        out.append(ctx.fetch("pred_out_csd_list", (len(m.temporal_cov_list),) + shape).copy())
+        return out
+
+    ref = run(True)
+    got = run(False)
+    for a, b in zip(ref[:-2], got[:-2]):
+        assert a == b
+    assert np.array_equal(ref[-2], got[-2]) and np.array_equal(ref[-1], got[-1])
+    # asynchronous predict, then the gradient path (which keeps status words of its own) and the batch path
+    hp1, keep1 = m._hparams(m.JITTER)
+    hp0, keep0 = m._hparams(0.0)
+    ll_ref = m.loglik()
+    f_ref, g_ref = m._loglik_and_grad_natural()
+    ctx.predict_resident(hp0, z, t, _hip.PRED_CSD, want_lists=False)
+    f1, g1 = m._loglik_and_grad_natural()
+    assert f1 == f_ref and np.array_equal(g1, g_ref)
+    # deferred failure: NaN hyper-parameter -> the call itself returns, the next synchronising call reports it
+    good = m.temporal_cov_list[0].params["ell"]["value"]
+    m.temporal_cov_list[0].params["ell"]["value"] = float("nan")
+    hp_bad, keep_bad = m._hparams(0.0)
+    m.temporal_cov_list[0].params["ell"]["value"] = good
+    ctx.predict_resident(hp_bad, z, t, _hip.PRED_CSD, want_lists=False)
+    with pytest.raises(np.linalg.LinAlgError):
+        ctx.synchronize()
+    ctx.synchronize()                                             # reported once
+    assert m.loglik() == ll_ref
+    ctx.predict_resident(hp_bad, z, t, _hip.PRED_CSD, want_lists=False)
+    with pytest.raises(np.linalg.LinAlgError):                    # ... or by the next call that returns values
+        ctx.loglik_parts(hp1)
+    assert m.loglik() == ll_ref
+    ctx.predict_resident(hp0, z, t, _hip.PRED_CSD, want_lists=True)
+    assert np.array_equal(ctx.fetch("pred_out_csd", shape), ref[-2])
+
+
 def test_predict_returns_pinned_arrays_that_are_not_overwritten():
     """predict() lands its host arrays in recycled page-locked blocks; arrays a caller keeps must survive later calls."""
     c, g, geom, hp, lfp = load_model_case("2d_npx_96x120x3")
