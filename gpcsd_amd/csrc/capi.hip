@@ -19,8 +19,7 @@ static int fail(gpcsd_ctx *c, const HipError &e) {
 #define GP_API_BEGIN(ctx)                                                                      \
     if (!(ctx)) return fail(nullptr, HipError{-1, "null context"});                            \
     try {                                                                                      \
-        GP_HIP(hipSetDevice((ctx)->device));                                                   \
-        ++(ctx)->api_seq;
+        GP_HIP(hipSetDevice((ctx)->device));
 #define GP_API_END(ctx)                                                                        \
     }                                                                                          \
     catch (const HipError &e) { drain_after_failure(ctx); return fail((ctx), e); }             \
@@ -31,21 +30,41 @@ static int fail(gpcsd_ctx *c, const HipError &e) {
 static void drain_after_failure(gpcsd_ctx *c) {
     if (!c) return;
     if (c->stream2) (void)hipStreamSynchronize(c->stream2);
+    if (c->stream3) (void)hipStreamSynchronize(c->stream3);
+    if (c->stream4) (void)hipStreamSynchronize(c->stream4);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     c->status_zeroed = false;
-    c->async_pending = c->fork_recorded = false;   // everything is drained: no deferred status, no early fork point
+    c->async_pending = false;                   // everything is drained: no deferred status
     c->decomp_gen[0] = c->decomp_gen[1] = -1;   // whatever the failed call left behind is not reused
 }
 
 static int drain_async(gpcsd_ctx *c);
 
-// stream2 may start a temporal chain once the main stream has finished with Kt / Qt / et: normally "now" in main-stream
-// order.  Right behind an asynchronous predict that point was already recorded behind its last reader of those buffers,
-// i.e. in front of its GEMM tail (valid for the very next API call only: any call in between may have queued new readers).
-static void fork_temporal_chain(gpcsd_ctx *c, hipStream_t s) {
-    if (!(c->fork_recorded && c->api_seq == c->fork_seq + 1)) GP_HIP(hipEventRecord(c->ev_fork, s));
-    c->fork_recorded = false;
-    GP_HIP(hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
+// Start the next generation of side's decomposition (0 spatial, 1 temporal) on `chain`: see gpcsd_ctx::par.  Flips the
+// current generation -- callers fetch output buffers and fold views AFTER this -- and orders the chain behind every reader
+// of the generation it is about to overwrite.  after_main_now: the chain also needs something queued on the main stream
+// just now (an upload of this call, cleared status words): wait for the main stream's current position instead.
+static void begin_generation(gpcsd_ctx *c, int side, hipStream_t chain, bool after_main_now) {
+    const int p = (c->par[side] ^= 1);
+    GP_HIP(hipEventRecord(c->ev_mark[side][p], c->stream));
+    if (chain != c->stream) GP_HIP(hipStreamWaitEvent(chain, c->ev_mark[side][after_main_now ? p : (p ^ 1)], 0));
+}
+
+// name of a per-generation output buffer of `side`
+static std::string gen_name(const gpcsd_ctx *c, int side, const char *base) { return std::string(base) + (c->par[side] ? "#1" : "#0"); }
+
+void gpcsd_ctx::timeline_dump() {
+    if (timeline.empty()) return;
+    // keep the last ~4 calls' worth of marks
+    const size_t keep = 64, n0 = timeline.size() > keep ? timeline.size() - keep : 0;
+    for (size_t i = 0; i < timeline.size(); ++i) (void)hipEventSynchronize(timeline[i].second);
+    for (size_t i = n0; i < timeline.size(); ++i) {
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, timeline[n0].second, timeline[i].second);
+        fprintf(stderr, "[timeline] %9.1f us  %s\n", 1e3 * ms, timeline[i].first.c_str());
+    }
+    for (auto &kv : timeline) event_pool.push_back(kv.second);
+    timeline.clear();
 }
 
 void gpcsd_ctx::prof_collect() {
@@ -105,14 +124,17 @@ void fwd_weights(gpcsd_ctx *c, const Geo &g, const double *pts, int n, double R,
 }
 
 // Kphi(nx, nxp) = A Kgl Axp^T (+ jitter I when square and jitter != 0)     covariances.py:74-96 / :204-232
+// pfx names the scratch buffers: the spatial chain ("ks_", on its own stream) and the cross-covariance builds of predict
+// ("kx_", main stream) run concurrently and must not share them.
 void build_kphi(gpcsd_ctx *c, const Geo &g, double R, double eps, const double *ell, const double *xp, int nxp, double jitter,
-                double *out, hipStream_t s) {
+                double *out, hipStream_t s, const char *pfx = "kx_") {
     const int G = g.G();
-    double *A = c->buf<double>("ks_A", (size_t)g.nx * G);
-    double *T = c->buf<double>("ks_T", (size_t)g.nx * G);
+    const std::string P(pfx);
+    double *A = c->buf<double>(P + "A", (size_t)g.nx * G);
+    double *T = c->buf<double>(P + "T", (size_t)g.nx * G);
     fwd_weights(c, g, g.x, g.nx, R, eps, A, s);
     if (g.dim == 1) {
-        double *Kgl = c->buf<double>("ks_Kgl", (size_t)G * G);
+        double *Kgl = c->buf<double>(P + "Kgl", (size_t)G * G);
         k_se_1d(c, g.gx1, G, g.gx1, G, ell[0], Kgl, s);
         GemmDesc d1;                               // T = A Kgl
         d1.M = g.nx; d1.N = G; d1.K = G;
@@ -125,8 +147,8 @@ void build_kphi(gpcsd_ctx *c, const Geo &g, double R, double eps, const double *
         // two small products (2 nx G (ngl1 + ngl2) flops: 74 MF at 384 x 20 x 60) instead of the 2 nx G^2 = 1.1 GF flat one,
         // and Kgl (1200^2 exponentials) is never formed.  Same sums re-associated: agrees with the flat product to rounding.
         const int n1 = g.ngl1, n2 = g.ngl2;
-        double *K1 = c->buf<double>("ks_K1", (size_t)n1 * n1), *K2 = c->buf<double>("ks_K2", (size_t)n2 * n2);
-        double *U = c->buf<double>("ks_U", (size_t)g.nx * G);
+        double *K1 = c->buf<double>(P + "K1", (size_t)n1 * n1), *K2 = c->buf<double>(P + "K2", (size_t)n2 * n2);
+        double *U = c->buf<double>(P + "U", (size_t)g.nx * G);
         k_se_axis(c, g.gx1, n1, ell[0], K1, s);
         k_se_axis(c, g.gx2, n2, ell[1], K2, s);
         GemmDesc u;                                // U[(x,g1)][h2] = sum_g2 A[(x,g1)][g2] K2[g2][h2]
@@ -144,7 +166,7 @@ void build_kphi(gpcsd_ctx *c, const Geo &g, double R, double eps, const double *
     const double *Axp = A;
     int n2 = g.nx;
     if (xp) {
-        double *A2 = c->buf<double>("ks_Axp", (size_t)nxp * G);
+        double *A2 = c->buf<double>(P + "Axp", (size_t)nxp * G);
         fwd_weights(c, g, xp, nxp, R, eps, A2, s);
         Axp = A2;
         n2 = nxp;
@@ -161,8 +183,8 @@ void build_kphi(gpcsd_ctx *c, const Geo &g, double R, double eps, const double *
 void build_kphig(gpcsd_ctx *c, const Geo &g, double R, double eps, const double *ell, const double *z, int nz, double *out,
                  hipStream_t s) {
     const int G = g.G();
-    double *A = c->buf<double>("ks_A", (size_t)g.nx * G);
-    double *Kc = c->buf<double>("ks_Kcross", (size_t)G * nz);
+    double *A = c->buf<double>("kx_A", (size_t)g.nx * G);
+    double *Kc = c->buf<double>("kx_Kcross", (size_t)G * nz);
     fwd_weights(c, g, g.x, g.nx, R, eps, A, s);
     if (g.dim == 1) k_se_1d(c, g.gx1, G, z, nz, ell[0], Kc, s);
     else k_se_2d(c, g.gx1, g.gx2, G, g.ngl2, z, nullptr, nz, 0, ell[0], ell[1], Kc, s);
@@ -310,9 +332,20 @@ struct EigState {
     // for yet; join_temporal() makes Qt / et / D available on the main stream
     bool pending = false;          // D has not been formed yet (two-stream front half: join_temporal does it)
     bool wait_temporal = false;    // the temporal chain was queued on stream2 in this call: the main stream must wait for it
+    bool wait_spatial = false;     // the spatial chain was queued on stream3 in this call: join_spatial() before using Qs / es
     const double *d_sig = nullptr;
     int nsig = 0;
 };
+
+// Main stream waits for the spatial chain of this call (no-op when it was reused from the cache or already joined).
+static void join_spatial(gpcsd_ctx *c, EigState &e) {
+    if (e.wait_spatial) {
+        c->tl("main before join S", c->stream);
+        GP_HIP(hipStreamWaitEvent(c->stream, c->ev_sjoin, 0));
+        c->tl("main after join S", c->stream);
+    }
+    e.wait_spatial = false;
+}
 
 // Decomposition cache: true when side `slot` (0 spatial, 1 temporal) was left in the context's buffers by the previous
 // front half with the same key and nothing has used that solver slot since.  Records the key for the next call otherwise.
@@ -336,14 +369,16 @@ static bool two_stream_front() {            // GPCSD_TWO_STREAM=0: single batche
 // Shared front half of loglik / predict: Ks (+jitter), Kt, eigen-decompositions, D.
 //
 // The spatial and the temporal side are independent until D = es (x) et + sig2n, and both are chains of small
-// latency-bound launches.  They run on two streams: stream2 builds Kt and decomposes it, the main stream assembles Ks
-// (three GEMMs, ~0.2 ms at 384 electrodes) and decomposes it; the caller then keeps working on the main stream with Qs
-// alone (the spatial projection W = Qs^T Y, ~0.15 ms) and calls join_temporal() right before the first use of
-// Qt / et / D.  At cfg3 the temporal chain (1.2 ms) is the critical path and everything spatial hides behind it.
+// latency-bound launches.  Each runs on a stream of its own: stream2 builds Kt and decomposes it, stream3 assembles Ks
+// (three GEMMs, ~0.1 ms at 384 electrodes) and decomposes it.  The caller works on the main stream: whatever needs neither
+// side first (cross-covariances of predict), join_spatial() before the first use of Qs / es, join_temporal() right before
+// the first use of Qt / et / D.  The outputs of both chains are double-buffered (gpcsd_ctx::par), so behind a call that
+// returned with work in flight (gpcsd_predict_resident) the chains of this call start at once, beside that call's GEMM tail.
 // need_merged = false: the caller runs the folded-basis GEMMs and never reads the merged Qs / Qt / es / et of a folded side
 // (one small launch less at the end of each chain).  NOTE: D from the single-stream front half is then in merged order of
 // stale spectra -- such callers rebuild it in fold order (join_temporal with a FoldMode).
-EigState front_half(gpcsd_ctx *c, const gpcsd_hparams *hp, double jitter, bool need_merged = true) {
+// join_s = false: the caller calls join_spatial() itself.  Fold views (fold_mode) must be taken AFTER this returns.
+EigState front_half(gpcsd_ctx *c, const gpcsd_hparams *hp, double jitter, bool need_merged = true, bool join_s = true) {
     const Geo g = resident_geo(c);
     GP_REQUIRE(c->d_lfp != nullptr, -4, "lfp not set (call gpcsd_set_lfp)");
     GP_REQUIRE(c->time_nt == c->nt, -4, "time grid has %d points but lfp has nt=%d", c->time_nt, c->nt);
@@ -352,12 +387,14 @@ EigState front_half(gpcsd_ctx *c, const gpcsd_hparams *hp, double jitter, bool n
     const int nx = c->nx, nt = c->nt;
     hipStream_t s = c->stream;
     EigState e;
-    double *Ks = c->buf<double>("Ks", (size_t)nx * nx);
+    double *Ks = c->buf<double>("Ks", (size_t)nx * nx);          // chain-private inputs (destroyed by the solver)
     double *Kt = c->buf<double>("Kt", (size_t)nt * nt);
-    e.Qs = c->buf<double>("Qs", (size_t)nx * nx);
-    e.Qt = c->buf<double>("Qt", (size_t)nt * nt);
-    e.es = c->buf<double>("es", nx);
-    e.et = c->buf<double>("et", nt);
+    auto outputs = [&]() {                                        // of the current generations
+        e.Qs = c->buf<double>(gen_name(c, 0, "Qs"), (size_t)nx * nx);
+        e.es = c->buf<double>(gen_name(c, 0, "es"), nx);
+        e.Qt = c->buf<double>(gen_name(c, 1, "Qt"), (size_t)nt * nt);
+        e.et = c->buf<double>(gen_name(c, 1, "et"), nt);
+    };
     e.D = c->buf<double>("D", (size_t)nx * nt);
     e.Dinv = c->buf<double>("Dinv", (size_t)nx * nt);
     // scalars and status words share one allocation so that a call ends with ONE small device-to-host copy
@@ -374,11 +411,17 @@ EigState front_half(gpcsd_ctx *c, const gpcsd_hparams *hp, double jitter, bool n
         if (host_kt) GP_HIP(hipMemcpyAsync(Kt, c->host_kt.data(), (size_t)nt * nt * sizeof(double), hipMemcpyHostToDevice, st));
         else build_kt(c, hp, t, nt, t, nt, Kt, st);
     };
+    // The status words are zeroed at the END of the previous call (finish_call / finish_status), off the critical path of
+    // this one; only a call that did not end that way (first call, an exception in between) clears them here -- and then the
+    // chains, which report into them, have to be ordered behind that.  (Behind an asynchronous predict they hold its
+    // uncollected status and stay as they are.)
+    const bool clear_now = !c->status_zeroed && !c->async_pending;
+    if (clear_now) GP_HIP(hipMemsetAsync(e.status, 0, 4 * sizeof(int), s));
+    c->status_zeroed = false;
     if (!two_stream_front()) {
         double *d_sig = c->upload_cached<double>("sig2n", hp->sig2n, hp->n_sig2n);
-        if (!c->status_zeroed && !c->async_pending) GP_HIP(hipMemsetAsync(e.status, 0, 4 * sizeof(int), s));
-        c->status_zeroed = false;
-        build_kphi(c, g, hp->R, hp->eps, hp->ell_s, nullptr, 0, jitter, Ks, s);
+        outputs();
+        build_kphi(c, g, hp->R, hp->eps, hp->ell_s, nullptr, 0, jitter, Ks, s, "ks_");
         make_kt(s);
         // the symmetries come from the resident geometry / time grid, so they hold for the Grams built from them
         eig_pair_D(c, Ks, nx, Kt, nt, d_sig, hp->n_sig2n, e.Qs, e.es, e.Qt, e.et, e.D, e.Dinv, e.scal, e.status, sym_s, sym_t,
@@ -387,14 +430,10 @@ EigState front_half(gpcsd_ctx *c, const gpcsd_hparams *hp, double jitter, bool n
         e.nsig = hp->n_sig2n;
         return e;
     }
-    // The temporal chain is the critical path: it is queued first, before any upload of this call.  It needs nothing
-    // from the main stream except that the previous call has finished with Kt / Qt (ev_fork), and reports numerical
-    // failure in its own status word (status[1]; the spatial chain uses status[0]).
-    hipStream_t s2 = c->stream2;
-    // The status words are zeroed at the END of the previous call (finish_call / finish_status), off the critical path of
-    // this one; only a call that did not end that way (first call, an exception in between) clears them here.
-    if (!c->status_zeroed && !c->async_pending) GP_HIP(hipMemsetAsync(e.status, 0, 4 * sizeof(int), s));
-    c->status_zeroed = false;
+    // The temporal chain is the critical path: it is queued first, before any upload of this call.  It takes its
+    // hyper-parameters by value and reports numerical failure in its own status word (status[1]; the spatial chain uses
+    // status[0]).
+    hipStream_t s2 = c->stream2, s3 = c->stream3;
     struct {                                   // everything the temporal side's result depends on
         long epoch;
         int nt, ncomp, kind[GPCSD_MAX_TEMPORAL], merged, fold, host;
@@ -408,18 +447,7 @@ EigState front_half(gpcsd_ctx *c, const gpcsd_hparams *hp, double jitter, bool n
         kt_key.ell[i] = hp->ell_t[i];
         kt_key.s2[i] = hp->sigma2_t[i];
     }
-    if (!decomp_cached(c, 1, &kt_key, sizeof(kt_key))) {
-        fork_temporal_chain(c, s);
-        make_kt(s2);
-        {
-            ProfScope ps(c, "eigh_temporal", 9.0 * (double)nt * nt * nt, s2);
-            eigh_pair_device(c, nullptr, 0, nullptr, nullptr, nullptr, Kt, nt, e.et, e.Qt, sym_t, e.status + 1, s2, need_merged);
-        }
-        GP_HIP(hipEventRecord(c->ev_join, s2));
-        c->decomp_gen[1] = c->eig_gen[1];
-        e.wait_temporal = true;
-    }
-    double *d_sig = c->upload_cached<double>("sig2n", hp->sig2n, hp->n_sig2n);
+    const bool run_t = !decomp_cached(c, 1, &kt_key, sizeof(kt_key));
     struct {
         long epoch;
         int nx, merged, fold;
@@ -429,17 +457,39 @@ EigState front_half(gpcsd_ctx *c, const gpcsd_hparams *hp, double jitter, bool n
     ks_key.epoch = c->grid_epoch; ks_key.nx = nx; ks_key.merged = need_merged; ks_key.fold = sym_s != nullptr;
     ks_key.R = hp->R; ks_key.eps = g.dim == 2 ? hp->eps : 0.0; ks_key.ell[0] = hp->ell_s[0];
     ks_key.ell[1] = g.dim == 2 ? hp->ell_s[1] : 0.0; ks_key.jitter = jitter;
-    if (!decomp_cached(c, 0, &ks_key, sizeof(ks_key))) {
-        build_kphi(c, g, hp->R, hp->eps, hp->ell_s, nullptr, 0, jitter, Ks, s);
+    const bool run_s = !decomp_cached(c, 0, &ks_key, sizeof(ks_key));
+    if (run_t) begin_generation(c, 1, s2, clear_now);
+    if (run_s) begin_generation(c, 0, s3, clear_now);
+    outputs();
+    c->tl("call start (main)", s);
+    if (run_t) {
+        c->tl("T chain start (s2)", s2);
+        make_kt(s2);
         {
-            ProfScope ps(c, "eigh_spatial", 9.0 * (double)nx * nx * nx, s);
-            eigh_pair_device(c, Ks, nx, e.es, e.Qs, sym_s, nullptr, 0, nullptr, nullptr, nullptr, e.status, s, need_merged);
+            ProfScope ps(c, "eigh_temporal", 9.0 * (double)nt * nt * nt, s2);
+            eigh_pair_device(c, nullptr, 0, nullptr, nullptr, nullptr, Kt, nt, e.et, e.Qt, sym_t, e.status + 1, s2, need_merged);
         }
-        c->decomp_gen[0] = c->eig_gen[0];
+        GP_HIP(hipEventRecord(c->ev_join, s2));
+        c->tl("T chain end (s2)", s2);
+        c->decomp_gen[1] = c->eig_gen[1];
+        e.wait_temporal = true;
     }
-    e.pending = true;
-    e.d_sig = d_sig;
+    if (run_s) {
+        c->tl("S chain start (s3)", s3);
+        build_kphi(c, g, hp->R, hp->eps, hp->ell_s, nullptr, 0, jitter, Ks, s3, "ks_");
+        {
+            ProfScope ps(c, "eigh_spatial", 9.0 * (double)nx * nx * nx, s3);
+            eigh_pair_device(c, Ks, nx, e.es, e.Qs, sym_s, nullptr, 0, nullptr, nullptr, nullptr, e.status, s3, need_merged);
+        }
+        GP_HIP(hipEventRecord(c->ev_sjoin, s3));
+        c->tl("S chain end (s3)", s3);
+        c->decomp_gen[0] = c->eig_gen[0];
+        e.wait_spatial = true;
+    }
+    e.d_sig = c->upload_cached<double>("sig2n", hp->sig2n, hp->n_sig2n);
     e.nsig = hp->n_sig2n;
+    e.pending = true;
+    if (join_s) join_spatial(c, e);
     return e;
 }
 
@@ -497,15 +547,15 @@ static FoldMode fold_mode(gpcsd_ctx *c, const gpcsd_hparams *hp) {
     else {
         fm.sym_s = identity_sym(c, c->nx);
         fm.fs.ns = c->nx; fm.fs.na = 0;
-        fm.fs.w = c->buf<double>("es", c->nx);                       // front_half's buffers: merged spectrum / full eigenvectors
-        fm.fs.U = c->buf<double>("Qs", (size_t)c->nx * c->nx);
+        fm.fs.w = c->buf<double>(gen_name(c, 0, "es"), c->nx);       // front_half's buffers: merged spectrum / full eigenvectors
+        fm.fs.U = c->buf<double>(gen_name(c, 0, "Qs"), (size_t)c->nx * c->nx);
     }
     if (fm.ft.on) fm.sym_t = c->sym_t;
     else {
         fm.sym_t = identity_sym(c, c->nt);
         fm.ft.ns = c->nt; fm.ft.na = 0;
-        fm.ft.w = c->buf<double>("et", c->nt);
-        fm.ft.U = c->buf<double>("Qt", (size_t)c->nt * c->nt);
+        fm.ft.w = c->buf<double>(gen_name(c, 1, "et"), c->nt);
+        fm.ft.U = c->buf<double>(gen_name(c, 1, "Qt"), (size_t)c->nt * c->nt);
     }
     return fm;
 }
@@ -562,7 +612,12 @@ static void fold_proj_spatial(gpcsd_ctx *c, const FoldView &fs, const double *in
 // sumlog = false: the caller either does not need sum(log D) (predict) or folds the final sum of the partials into a later
 // launch (loglik: the reduce of the quadratic form); returns the number of partials left in "buildD_partials" (0: none built).
 int join_temporal(gpcsd_ctx *c, EigState &e, const FoldMode *fm = nullptr, bool sumlog = true) {
-    if (e.wait_temporal) GP_HIP(hipStreamWaitEvent(c->stream, c->ev_join, 0));
+    join_spatial(c, e);
+    if (e.wait_temporal) {
+        c->tl("main before join T", c->stream);
+        GP_HIP(hipStreamWaitEvent(c->stream, c->ev_join, 0));
+        c->tl("main after join T", c->stream);
+    }
     e.wait_temporal = false;
     double *out = sumlog ? e.scal : nullptr;
     int np = 0;
@@ -575,6 +630,7 @@ int join_temporal(gpcsd_ctx *c, EigState &e, const FoldMode *fm = nullptr, bool 
 // End of a fused call: one copy brings back the leading `nscal` scalars and the status words, then the stream is drained.
 int finish_call(gpcsd_ctx *c, const EigState &e, double *scal_out, int nscal) {
     double *host = c->h_result;                        // pinned: a true asynchronous copy, no staging
+    c->tl("sync call end (main)", c->stream);
     c->download(host, e.scal, 66 * sizeof(double));
     GP_HIP(hipMemsetAsync(e.status, 0, 4 * sizeof(int), c->stream));   // clean status words for the next call, after the copy
     c->sync();
@@ -634,9 +690,19 @@ extern "C" int gpcsd_ctx_create(int device, gpcsd_ctx **out) {
         GP_HIP(hipSetDevice(device));
         c = new gpcsd_ctx();
         c->device = device;
+        c->timeline_on = getenv("GPCSD_TIMELINE") && getenv("GPCSD_TIMELINE")[0] == '1';
         GP_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-        GP_HIP(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
-        GP_HIP(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+        // The two chains are the critical path and made of small launches; when they run beside another call's GEMM tail
+        // (thousands of workgroups) each of those launches would otherwise queue behind the tiles: high priority.
+        int prio_least = 0, prio_greatest = 0;
+        GP_HIP(hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
+        const char *pe = getenv("GPCSD_CHAIN_PRIORITY");
+        const int prio = (pe && pe[0] == '0') ? prio_least : prio_greatest;
+        GP_HIP(hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, prio));
+        GP_HIP(hipStreamCreateWithPriority(&c->stream3, hipStreamNonBlocking, prio));
+        GP_HIP(hipStreamCreateWithFlags(&c->stream4, hipStreamNonBlocking));
+        GP_HIP(hipEventCreateWithFlags(&c->ev_sjoin, hipEventDisableTiming));
+        for (int i = 0; i < 4; ++i) GP_HIP(hipEventCreateWithFlags(&c->ev_mark[i / 2][i % 2], hipEventDisableTiming));
         GP_HIP(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
         GP_HIP(hipEventCreateWithFlags(&c->ev_aux, hipEventDisableTiming));
         GP_HIP(hipEventCreateWithFlags(&c->ev_pc, hipEventDisableTiming));
@@ -664,7 +730,11 @@ extern "C" int gpcsd_ctx_destroy(gpcsd_ctx *c) {
     for (auto e : c->event_pool) (void)hipEventDestroy(e);
     for (auto &kv : c->graphs)
         if (kv.second.exec) (void)hipGraphExecDestroy(kv.second.exec);
-    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    if (c->ev_sjoin) (void)hipEventDestroy(c->ev_sjoin);
+    for (int i = 0; i < 4; ++i)
+        if (c->ev_mark[i / 2][i % 2]) (void)hipEventDestroy(c->ev_mark[i / 2][i % 2]);
+    if (c->stream3) (void)hipStreamDestroy(c->stream3);
+    if (c->stream4) (void)hipStreamDestroy(c->stream4);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     if (c->ev_aux) (void)hipEventDestroy(c->ev_aux);
     if (c->ev_pc) (void)hipEventDestroy(c->ev_pc);
@@ -699,7 +769,9 @@ extern "C" int gpcsd_host_free(void *p) {
 extern "C" int gpcsd_device_synchronize(gpcsd_ctx *c) {
     GP_API_BEGIN(c)
     GP_HIP(hipStreamSynchronize(c->stream2));
+    GP_HIP(hipStreamSynchronize(c->stream3));
     c->sync();
+    c->timeline_dump();
     return drain_async(c);
     GP_API_END(c)
 }
@@ -1315,9 +1387,10 @@ extern "C" int gpcsd_loglik_parts(gpcsd_ctx *c, const gpcsd_hparams *hp, double 
     GP_API_BEGIN(c)
     GP_REQUIRE(out2 != nullptr, -3, "null output");
     GP_REQUIRE(c->d_lfp != nullptr, -4, "lfp not set (call gpcsd_set_lfp)");
-    const FoldMode fm = fold_mode(c, hp);                           // before the front half: first use allocates
-    const double *Yf = fm.on ? folded_lfp(c, fm) : nullptr;
-    EigState e = front_half(c, hp, hp->jitter, !fm.on);
+    const FoldMode fm0 = fold_mode(c, hp);                          // the decision; its views are of the previous generation
+    const double *Yf = fm0.on ? folded_lfp(c, fm0) : nullptr;
+    EigState e = front_half(c, hp, hp->jitter, !fm0.on);
+    const FoldMode fm = fold_mode(c, hp);                           // views of the generation the front half just launched
     const int nx = c->nx, nt = c->nt, R = c->ntrials;
     hipStream_t s = c->stream;
     double *W = c->buf<double>("proj_W", (size_t)nx * R * nt);
@@ -1398,7 +1471,8 @@ static int predict_fold(gpcsd_ctx *c, const gpcsd_hparams *hp, EigState &e, cons
     double *Bm = c->buf<double>("pred_B", (size_t)nx * RT);
     const double *t = (const double *)c->bufs["time_t"].p;
     double *Kc = c->buf<double>("pred_Kcross", (size_t)nx * nz);
-    double *Kcf = c->buf<double>("pred_Kcross_fold", (size_t)ns * nzs + (size_t)na * nza);
+    const size_t kcf_sz = (size_t)ns * nzs + (size_t)na * nza;
+    double *Kcf = c->buf<double>("pred_Kcross_fold", 2 * kcf_sz);
     double *S = c->buf<double>("pred_S", (size_t)nz * RT);
     double *comp = c->buf<double>("pred_comp", (size_t)C * nz * RT);
     double *Kts = c->buf<double>("pred_Ktstar", (size_t)C * nt * nt);
@@ -1409,29 +1483,37 @@ static int predict_fold(gpcsd_ctx *c, const gpcsd_hparams *hp, EigState &e, cons
     double *Pc = c->buf<double>("pred_Pc", std::max((size_t)C * ktf_sz, (size_t)C * nt * nt));
     const size_t out_elems = (size_t)nz * RT;
     ++c->fold_gemm_calls;
-    fold_proj_spatial(c, fm.fs, Yf, W, RT, s);                      // W~ = diag(U)^T Y~
-    // everything that needs only the spatial eigenvectors runs beside the temporal eigensolver
+    // what needs neither decomposition runs first, beside both chains: the cross-covariances and the prediction-time Grams,
+    // folded
     for (int which = 1; which <= 2; ++which) {
         if (!(type & which)) continue;
+        double *kf = Kcf + (size_t)(which - 1) * kcf_sz;
         if (which == 1) build_kphig(c, g, hp->R, hp->eps, hp->ell_s, dz, nz, Kc, s);        // gpcsd1d.py:273
         else build_kphi(c, g, hp->R, hp->eps, hp->ell_s, dz, nz, 0.0, Kc, s);               // gpcsd1d.py:275
-        k_sym_fold_rect(c, Kc, nz, fm.sym_s, sz, Kcf, Kcf + (size_t)ns * nzs, s);
-        for (int p = 0; p < 2; ++p) {
-            const int np = p ? na : ns, nzp = p ? nza : nzs;
-            if (np == 0 || nzp == 0) continue;
-            GemmDesc gm;                  // M1_p[zq][x'] = sum_xq Kc~_pp[xq][zq] U_p[xq][x']
-            gm.M = nzp; gm.N = np; gm.K = np;
-            gm.A = Kcf + (p ? (size_t)ns * nzs : 0); gm.lda = nzp; gm.transA = true;
-            gm.B = fm.fs.U + (p ? (size_t)ns * ns : 0); gm.ldb = np;
-            gm.C = M1 + (size_t)(which - 1) * m1_sz + (p ? (size_t)nzs * ns : 0); gm.ldc = np;
-            gm.prof_name = "gemm_pred_M1";
-            gemm_f64(c, gm, s);
-        }
+        k_sym_fold_rect(c, Kc, nz, fm.sym_s, sz, kf, kf + (size_t)ns * nzs, s);
     }
     for (int cc = 0; cc < C; ++cc) {
         temporal_cross_gram(c, hp, cc, dts, nt, t, nt, Kts + (size_t)cc * nt * nt, s);
         k_sym_fold_rect(c, Kts + (size_t)cc * nt * nt, nt, fm.sym_t, fm.sym_t, Ktf + cc * ktf_sz,
                         Ktf + cc * ktf_sz + (size_t)nts * nts, s);
+    }
+    // then everything that needs only the spatial eigenvectors, beside the temporal eigensolver
+    join_spatial(c, e);
+    fold_proj_spatial(c, fm.fs, Yf, W, RT, s);                      // W~ = diag(U)^T Y~
+    for (int which = 1; which <= 2; ++which) {
+        if (!(type & which)) continue;
+        const double *kf = Kcf + (size_t)(which - 1) * kcf_sz;
+        for (int p = 0; p < 2; ++p) {
+            const int np = p ? na : ns, nzp = p ? nza : nzs;
+            if (np == 0 || nzp == 0) continue;
+            GemmDesc gm;                  // M1_p[zq][x'] = sum_xq Kc~_pp[xq][zq] U_p[xq][x']
+            gm.M = nzp; gm.N = np; gm.K = np;
+            gm.A = kf + (p ? (size_t)ns * nzs : 0); gm.lda = nzp; gm.transA = true;
+            gm.B = fm.fs.U + (p ? (size_t)ns * ns : 0); gm.ldb = np;
+            gm.C = M1 + (size_t)(which - 1) * m1_sz + (p ? (size_t)nzs * ns : 0); gm.ldc = np;
+            gm.prof_name = "gemm_pred_M1";
+            gemm_f64(c, gm, s);
+        }
     }
     join_temporal(c, e, &fm, false);      // predict never reads sum(log D)
     GemmDesc g2[2];                       // Bm~[:, p block] = (W~[:, p block] V_p) / D~
@@ -1444,10 +1526,11 @@ static int predict_fold(gpcsd_ctx *c, const gpcsd_hparams *hp, EigState &e, cons
         g2[p].epi = EPI_DIV_D; g2[p].D = e.Dinv + c0; g2[p].rdiv = R; g2[p].ldd = nt;
         g2[p].prof_name = "gemm_pred_temporal_div";
     }
-    // Pcat = V^T Kt*~ needs the temporal eigenvectors and the folded prediction-time Grams only: it runs on stream2 beside the
-    // large Bm~ / S~ products of the main stream instead of in front of them (two small launches off the serial tail)
-    GP_HIP(hipEventRecord(c->ev_aux, s));                            // Kt*~ is complete on the main stream here
-    GP_HIP(hipStreamWaitEvent(c->stream2, c->ev_aux, 0));
+    // Pcat = V^T Kt*~ needs the temporal eigenvectors and the folded prediction-time Grams only: it runs on a stream of its
+    // own beside the large Bm~ / S~ products of the main stream instead of in front of them (two small launches off the
+    // serial tail) -- not on stream2, where it would sit between this call's temporal chain and the next call's
+    GP_HIP(hipEventRecord(c->ev_aux, s));                            // Kt*~ and the temporal eigenvectors are complete here
+    GP_HIP(hipStreamWaitEvent(c->stream4, c->ev_aux, 0));
     for (int p = 0; p < 2; ++p) {
         const int np = p ? nta : nts;
         if (np == 0) continue;
@@ -1458,15 +1541,11 @@ static int predict_fold(gpcsd_ctx *c, const gpcsd_hparams *hp, EigState &e, cons
         gp.C = Pc + (p ? (size_t)C * nts * nts : 0); gp.ldc = (long)C * np;
         gp.batch = C; gp.sA = 0; gp.sB = (long)ktf_sz; gp.sC = np;
         gp.prof_name = "gemm_pred_Pc";
-        gemm_f64(c, gp, c->stream2);
+        gemm_f64(c, gp, c->stream4);
     }
-    GP_HIP(hipEventRecord(c->ev_pc, c->stream2));
+    GP_HIP(hipEventRecord(c->ev_pc, c->stream4));
+    c->tl("Pc end (s4)", c->stream4);
     gemm_pair(c, g2[0], g2[1], s);
-    if (async) {                          // last main-stream reader of the temporal buffers: the next call's stream2 may go
-        GP_HIP(hipEventRecord(c->ev_fork, s));
-        c->fork_recorded = true;
-        c->fork_seq = c->api_seq;
-    }
     for (int which = 1; which <= 2; ++which) {
         if (!(type & which)) continue;
         double *o_sum = c->buf<double>(which == 1 ? "pred_out_csd" : "pred_out_lfp", out_elems);
@@ -1482,7 +1561,7 @@ static int predict_fold(gpcsd_ctx *c, const gpcsd_hparams *hp, EigState &e, cons
             g5[p].prof_name = "gemm_pred_cross";
         }
         gemm_pair(c, g5[0], g5[1], s);
-        if (which == 1 || !(type & 1)) GP_HIP(hipStreamWaitEvent(s, c->ev_pc, 0));     // Pcat (stream2) before its first use
+        if (which == 1 || !(type & 1)) GP_HIP(hipStreamWaitEvent(s, c->ev_pc, 0));     // Pcat (stream4) before its first use
         for (int p = 0; p < 2; ++p) {     // comp~[(zq, r)][p][cc][b] = sum_i' S~[(zq, r)][p block i'] Pcat_p[i'][cc*np + b]
             const int np = p ? nta : nts, c0 = p ? nts : 0;
             g6[p].M = nz * R; g6[p].N = C * np; g6[p].K = np;
@@ -1494,6 +1573,7 @@ static int predict_fold(gpcsd_ctx *c, const gpcsd_hparams *hp, EigState &e, cons
         gemm_pair(c, g6[0], g6[1], s);
         k_unfold_swap_sum(c, comp, C, o_list, (long)out_elems, o_sum, R, nt, sz, fm.sym_t, s);
     }
+    c->tl("predict end (main)", s);
     if (async && !c->prof_on) {           // results stay on the device: return with the tail still in flight
         c->async_pending = true;
         c->status_zeroed = false;
@@ -1514,19 +1594,21 @@ static int predict_impl(gpcsd_ctx *c, const gpcsd_hparams *hp, const double *z, 
                ntstar, c->nt);
     GP_REQUIRE(c->d_lfp != nullptr, -4, "lfp not set (call gpcsd_set_lfp)");
     // folded basis when the grids, the prediction sites and the prediction times all share the reflection symmetries
-    const FoldMode fm = fold_mode(c, hp);
+    const FoldMode fm0 = fold_mode(c, hp);         // the decision only: views are taken after the front half
     // a folded side needs its outputs on a grid with the same symmetry (t* = t; mirror-symmetric sites); an unfolded side
     // takes any sites / times
-    const bool t_ok = fm.on && ntstar == c->nt &&
-                      (!fm.ft.on || ((int)c->time_host.size() == c->nt &&
-                                     memcmp(c->time_host.data(), tstar, (size_t)ntstar * sizeof(double)) == 0));
+    const bool t_ok = fm0.on && ntstar == c->nt &&
+                      (!fm0.ft.on || ((int)c->time_host.size() == c->nt &&
+                                      memcmp(c->time_host.data(), tstar, (size_t)ntstar * sizeof(double)) == 0));
     if (t_ok) {
-        const SymDev sz = fm.fs.on ? site_symmetry(c, z, nz, c->dim) : identity_sym(c, nz);
+        const SymDev sz = fm0.fs.on ? site_symmetry(c, z, nz, c->dim) : identity_sym(c, nz);
         if (sz.ns > 0 && sz.ns + sz.na == nz) {
+            // the chains go first (they need no upload of this call), then the host-side uploads
+            EigState ef = front_half(c, hp, 0.0, false, /*join_s=*/false);  // no jitter in predict (gpcsd1d.py:258)
+            const FoldMode fm = fold_mode(c, hp);
             const double *Yf = folded_lfp(c, fm);
             double *dzf = c->upload_cached<double>("pred_z", z, (size_t)nz * c->dim);
             double *dtf = c->upload_cached<double>("pred_tstar", tstar, ntstar);
-            EigState ef = front_half(c, hp, 0.0, false);  // no jitter in predict (gpcsd1d.py:258)
             return predict_fold(c, hp, ef, fm, Yf, sz, dzf, nz, dtf, type, want_lists, async);
         }
     }
@@ -1618,6 +1700,7 @@ static int drain_async(gpcsd_ctx *c) {
     c->async_pending = false;
     int *st = reinterpret_cast<int *>(c->buf<double>("scal_status", 64 + 2) + 64);
     GP_HIP(hipStreamSynchronize(c->stream2));
+    GP_HIP(hipStreamSynchronize(c->stream3));
     return finish_status(c, st);          // downloads + synchronises; the words are cleared by the next call's front half
 }
 
@@ -1786,13 +1869,15 @@ static int loglik_grad_impl(gpcsd_ctx *c, const gpcsd_hparams *hps, int B, doubl
     // of the symmetry-folded eigensolver -- projections, the Ghat_s / Ghat_t sums and the back-rotations are each two
     // half-size products.  The cross-parity blocks of Ghat are never needed: dKs and dKt commute with the reflections, so
     // <G, dK> only sees the parity-diagonal blocks.  Half the GEMM flops of the full-size path below.
+    // ---- front half: temporal chain on stream2 (queued first: the critical path), spatial chain on the main stream.  Both
+    // read the hyper-parameter table uploaded above and report into the status words cleared here: they start behind the
+    // main stream's current position (this call returns values, so nothing of it outlives it anyway).
+    GP_HIP(hipMemsetAsync(st, 0, (size_t)2 * B * sizeof(int), s));
+    begin_generation(c, 1, s2, true);
+    begin_generation(c, 0, s, true);
     const FoldMode fm = fold_mode(c, &hps[0]);
     const bool fold = fm.on;
     const double *Yf = fold ? folded_lfp(c, fm) : nullptr;
-
-    // ---- front half: temporal chain on stream2 (queued first: the critical path), spatial chain on the main stream
-    GP_HIP(hipMemsetAsync(st, 0, (size_t)2 * B * sizeof(int), s));
-    fork_temporal_chain(c, s);
     k_temporal_gram(c, C, nullptr, nullptr, nullptr, t, nt, t, nt, Kt, s2, tab, B, ntt);
     {
         ProfScope ps(c, "eigh_temporal", 9.0 * (double)nt * nt * nt * B, s2);

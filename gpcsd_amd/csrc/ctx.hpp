@@ -64,17 +64,24 @@ struct SymDev {
 struct gpcsd_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
-    hipStream_t stream2 = nullptr;          // second stream: the two eigenproblems are independent
+    hipStream_t stream2 = nullptr;          // temporal chain (Kt, its eigen-decomposition)
+    hipStream_t stream3 = nullptr;          // spatial chain (Ks assembly, its eigen-decomposition)
+    hipStream_t stream4 = nullptr;          // predict: the small Pcat products, beside the large GEMMs of the main stream
     double *h_result = nullptr;             // pinned host landing zone for the end-of-call copy (66 doubles)
     bool capturing = false;                 // inside a stream capture: profiling scopes stay silent
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-    // gpcsd_predict_resident returns once its work is queued (the results stay on the device anyway): the next call's
-    // temporal chain then runs under this call's GEMM tail instead of after it.  fork_recorded: ev_fork was recorded by the
-    // previous call right after its last read of the temporal buffers (instead of by the next call at its start);
-    // async_pending: the status words of that call have not been collected yet -- the next synchronising call
+    hipEvent_t ev_join = nullptr, ev_sjoin = nullptr;      // temporal / spatial chain finished (recorded on stream2 / stream3)
+    // Software pipeline across calls.  The outputs of a side's decomposition (eigenvector blocks, spectra) exist in two
+    // generations, used alternately (par[side] = the current one, 0 spatial / 1 temporal): the chain of call N+1 writes the
+    // buffers call N-1 read, so it does not have to wait for call N's GEMM tail, which still reads generation N.  What it does
+    // have to wait for is every reader of generation N-1; those were all queued on the main stream before chain N was launched,
+    // and ev_mark[side][N % 2] was recorded there at that moment.  Chain N+1 therefore waits for ev_mark[side][N % 2] and then
+    // records ev_mark[side][(N+1) % 2].  Everything else a chain touches (Gram assembly scratch, solver workspaces) is
+    // private to the chain's stream.  Synchronous calls gain nothing from this (the host waits for the end of the call), but
+    // gpcsd_predict_resident returns with its GEMM tail in flight, and the next call's two chains then run beside that tail.
+    // async_pending: the status words of such a call have not been collected yet -- the next synchronising call
     // (gpcsd_fetch, gpcsd_device_synchronize, any call that returns values) reports them.
-    bool fork_recorded = false;
-    long api_seq = 0, fork_seq = -1;       // API calls entered so far / the call that recorded the early fork point
+    int par[2] = {0, 0};
+    hipEvent_t ev_mark[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
     bool async_pending = false;
     hipEvent_t ev_aux = nullptr, ev_pc = nullptr;   // predict: small products of the tail on stream2 beside the large ones
     std::string last_error;
@@ -181,6 +188,19 @@ struct gpcsd_ctx {
         return e;
     }
     void prof_collect();
+
+    // Stream timeline (GPCSD_TIMELINE=1, a measurement aid): timestamped events at the phase boundaries of the fused calls on
+    // the streams they run on -- unlike the profiling scopes it leaves the asynchronous behaviour alone, unlike a profiler's
+    // kernel trace it adds no host time per launch.  Dumped (relative times, stderr) by gpcsd_device_synchronize.
+    bool timeline_on = false;
+    std::vector<std::pair<std::string, hipEvent_t>> timeline;
+    void tl(const char *label, hipStream_t s) {
+        if (!timeline_on || capturing) return;
+        hipEvent_t e = get_event();
+        (void)hipEventRecord(e, s);
+        timeline.emplace_back(label, e);
+    }
+    void timeline_dump();
 };
 
 namespace gpcsd {

@@ -181,8 +181,10 @@ FoldView eigh_fold_view(gpcsd_ctx *c, int slot, const SymDev *sy, int n, int cou
     v.na = sy->na;
     v.sw = n;
     v.sU = (long)v.ns * v.ns + (long)v.na * v.na;
-    v.w = c->buf<double>(T + "w", (size_t)n * count);
-    v.U = c->buf<double>(T + "U", (size_t)v.sU * count);
+    // outputs: one set per generation of the slot (gpcsd_ctx::par) -- the solver writes, and callers read, the current one
+    const char *gen = c->par[slot ? 1 : 0] ? "#1" : "#0";
+    v.w = c->buf<double>(T + "w" + gen, (size_t)n * count);
+    v.U = c->buf<double>(T + "U" + gen, (size_t)v.sU * count);
     return v;
 }
 
@@ -265,11 +267,12 @@ void eigh_pair_device(gpcsd_ctx *c, double *A0, int n0, double *w0, double *Z0, 
         eigh_pair_enqueue(c, A0, n0, w0, Z0, sym0, A1, n1, w1, Z1, sym1, d_status, s, need_merged, count, status_stride);
         return;
     }
-    char key[320];
-    snprintf(key, sizeof(key), "eigh|%p|%d|%p|%p|%p|%d|%p|%d|%p|%p|%p|%d|%p|%p|%d|%d|%d", (void *)A0, n0, (void *)w0, (void *)Z0,
+    // (the generation of each slot picks the fold-order output buffers, which are not among the arguments)
+    char key[352];
+    snprintf(key, sizeof(key), "eigh|%p|%d|%p|%p|%p|%d|%p|%d|%p|%p|%p|%d|%p|%p|%d|%d|%d|%d%d", (void *)A0, n0, (void *)w0, (void *)Z0,
              (void *)(sym0 ? sym0->rep_i : nullptr), sym0 ? sym0->ns : 0, (void *)A1, n1, (void *)w1, (void *)Z1,
              (void *)(sym1 ? sym1->rep_i : nullptr), sym1 ? sym1->ns : 0, (void *)d_status, (void *)s, (int)need_merged, count,
-             status_stride);
+             status_stride, c->par[0], c->par[1]);
     gpcsd_ctx::GraphSlot &g = c->graphs[key];
     if (g.exec && g.epoch == c->alloc_epoch) {
         GP_HIP(hipGraphLaunch(g.exec, s));
