@@ -82,6 +82,8 @@ SIGNATURES = {
     "gpcsd_loglik_dense_chol": (_I, [_P, _DP, _I, _DP, _I, _D, _DP, _I, _DP]),
     "gpcsd_loglik": (_I, [_P, ctypes.POINTER(HParams), _DP]),
     "gpcsd_loglik_parts": (_I, [_P, ctypes.POINTER(HParams), _DP]),
+    "gpcsd_loglik_parts_async": (_I, [_P, ctypes.POINTER(HParams)]),
+    "gpcsd_loglik_parts_wait": (_I, [_P, _DP]),
     "gpcsd_loglik_grad": (_I, [_P, ctypes.POINTER(HParams), _DP, _DP, _I]),
     "gpcsd_loglik_grad_batch": (_I, [_P, ctypes.POINTER(HParams), _I, _DP, _DP, _I, ctypes.POINTER(_I)]),
     "gpcsd_predict": (_I, [_P, ctypes.POINTER(HParams), _DP, _I, _DP, _I, _I, _DP, _DP, _DP, _DP]),
@@ -458,6 +460,16 @@ class Context:
     def loglik_parts(self, hp):
         out = np.empty(2)
         self._check(self._lib.gpcsd_loglik_parts(self._h, ctypes.byref(hp), _ptr(out)))
+        return float(out[0]), float(out[1])
+
+    def loglik_parts_async(self, hp):
+        """Queue loglik_parts(hp) and return; collect with loglik_parts_wait().  Calls queued in between (predict_resident)
+        overlap with this evaluation's tail."""
+        self._check(self._lib.gpcsd_loglik_parts_async(self._h, ctypes.byref(hp)))
+
+    def loglik_parts_wait(self):
+        out = np.empty(2)
+        self._check(self._lib.gpcsd_loglik_parts_wait(self._h, _ptr(out)))
         return float(out[0]), float(out[1])
 
     def loglik_grad(self, hp, ngrad):

@@ -35,6 +35,7 @@ static void drain_after_failure(gpcsd_ctx *c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     c->status_zeroed = false;
     c->async_pending = false;                   // everything is drained: no deferred status
+    // (an outstanding asynchronous loglik stays collectable: its result has landed by now)
     c->decomp_gen[0] = c->decomp_gen[1] = -1;   // whatever the failed call left behind is not reused
 }
 
@@ -707,6 +708,8 @@ extern "C" int gpcsd_ctx_create(int device, gpcsd_ctx **out) {
         GP_HIP(hipEventCreateWithFlags(&c->ev_aux, hipEventDisableTiming));
         GP_HIP(hipEventCreateWithFlags(&c->ev_pc, hipEventDisableTiming));
         GP_HIP(hipHostMalloc(reinterpret_cast<void **>(&c->h_result), 66 * sizeof(double), hipHostMallocDefault));
+        GP_HIP(hipHostMalloc(reinterpret_cast<void **>(&c->h_ll), 66 * sizeof(double), hipHostMallocDefault));
+        GP_HIP(hipEventCreateWithFlags(&c->ev_ll, hipEventDisableTiming));
         *out = c;
         return 0;
     } catch (const HipError &e) {
@@ -741,6 +744,9 @@ extern "C" int gpcsd_ctx_destroy(gpcsd_ctx *c) {
     if (c->stream) (void)hipStreamDestroy(c->stream);
     if (c->stream2) (void)hipStreamDestroy(c->stream2);
     if (c->h_result) (void)hipHostFree(c->h_result);
+    if (c->h_ll) (void)hipHostFree(c->h_ll);
+    if (c->stage_ring) (void)hipHostFree(c->stage_ring);
+    if (c->ev_ll) (void)hipEventDestroy(c->ev_ll);
     delete c;
     return 0;
 }
@@ -1383,10 +1389,26 @@ extern "C" int gpcsd_fold_gemm(gpcsd_ctx *c, int on, long *calls) {
 // ------------------------------------------------------------------------------------------------
 // fused hot calls
 // ------------------------------------------------------------------------------------------------
-extern "C" int gpcsd_loglik_parts(gpcsd_ctx *c, const gpcsd_hparams *hp, double *out2) {
-    GP_API_BEGIN(c)
-    GP_REQUIRE(out2 != nullptr, -3, "null output");
+// End of an asynchronous loglik: the scalars and status words go to the pinned block behind an event; nothing is waited for
+// and the status words are left alone (the chains of later calls may already be reporting into them).
+static int finish_loglik_async(gpcsd_ctx *c, const EigState &e, bool two) {
+    GP_HIP(hipMemcpyAsync(c->h_ll, e.scal, 66 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    GP_HIP(hipEventRecord(c->ev_ll, c->stream));
+    c->ll_pending = true;
+    c->ll_done = false;
+    c->ll_two = two;
+    c->async_pending = true;
+    c->status_zeroed = false;
+    return 0;
+}
+
+static int loglik_parts_impl(gpcsd_ctx *c, const gpcsd_hparams *hp, double *out2, bool async) {
     GP_REQUIRE(c->d_lfp != nullptr, -4, "lfp not set (call gpcsd_set_lfp)");
+    if (async && c->prof_on) {            // profiling scopes need fenced calls: evaluate now, hand the result over at the wait
+        c->ll_rc = loglik_parts_impl(c, hp, c->ll_out, false);
+        c->ll_pending = c->ll_done = true;
+        return 0;
+    }
     const FoldMode fm0 = fold_mode(c, hp);                          // the decision; its views are of the previous generation
     const double *Yf = fm0.on ? folded_lfp(c, fm0) : nullptr;
     EigState e = front_half(c, hp, hp->jitter, !fm0.on);
@@ -1412,6 +1434,7 @@ extern "C" int gpcsd_loglik_parts(gpcsd_ctx *c, const gpcsd_hparams *hp, double 
             g2[p].prof_name = "gemm_proj_temporal_quad";
         }
         const bool batched = gemm_pair(c, g2[0], g2[1], s);
+        if (async) return finish_loglik_async(c, e, !batched);
         double h3[3] = {0.0, 0.0, 0.0};
         const int rc = finish_call(c, e, h3, 3);
         out2[0] = h3[0];
@@ -1433,7 +1456,51 @@ extern "C" int gpcsd_loglik_parts(gpcsd_ctx *c, const gpcsd_hparams *hp, double 
     g2.epi = EPI_QUAD; g2.D = e.Dinv; g2.rdiv = R; g2.ldd = nt; g2.quad_out = e.scal + 1;
     g2.prof_name = "gemm_proj_temporal_quad";
     gemm_f64(c, g2, s);
+    if (async) return finish_loglik_async(c, e, false);
     return finish_call(c, e, out2, 2);
+}
+
+extern "C" int gpcsd_loglik_parts(gpcsd_ctx *c, const gpcsd_hparams *hp, double *out2) {
+    GP_API_BEGIN(c)
+    GP_REQUIRE(out2 != nullptr, -3, "null output");
+    return loglik_parts_impl(c, hp, out2, false);
+    GP_API_END(c)
+}
+
+extern "C" int gpcsd_loglik_parts_async(gpcsd_ctx *c, const gpcsd_hparams *hp) {
+    if (c && c->ll_pending)               // refused before anything is touched: the outstanding evaluation stays collectable
+        return fail(c, HipError{-3, "loglik_parts_async: the previous asynchronous evaluation has not been collected "
+                                    "(gpcsd_loglik_parts_wait)"});
+    GP_API_BEGIN(c)
+    return loglik_parts_impl(c, hp, nullptr, true);
+    GP_API_END(c)
+}
+
+extern "C" int gpcsd_loglik_parts_wait(gpcsd_ctx *c, double *out2) {
+    if (c && (!out2 || !c->ll_pending))
+        return fail(c, HipError{-3, out2 ? "loglik_parts_wait: no asynchronous evaluation pending" : "null output"});
+    GP_API_BEGIN(c)
+    c->ll_pending = false;
+    if (c->ll_done) {
+        out2[0] = c->ll_out[0];
+        out2[1] = c->ll_out[1];
+        return c->ll_rc;
+    }
+    GP_HIP(hipEventSynchronize(c->ev_ll));
+    const double *host = c->h_ll;
+    out2[0] = host[0];
+    out2[1] = c->ll_two ? host[1] + host[2] : host[1];
+    int st[4];
+    memcpy(st, host + 64, sizeof(st));
+    if (st[0] == 0 && st[1] != 0) st[0] = st[1];
+    if (st[0] != 0) {                     // this evaluation's, or an earlier asynchronous call's that nobody collected yet
+        char b[160];
+        snprintf(b, sizeof(b), "numerical failure (status %d): eigensolver did not converge or matrix not positive definite", st[0]);
+        c->last_error = b;
+        c->decomp_gen[0] = c->decomp_gen[1] = -1;
+        return st[0] > 0 ? st[0] : 1;
+    }
+    return 0;
     GP_API_END(c)
 }
 

@@ -83,6 +83,13 @@ struct gpcsd_ctx {
     int par[2] = {0, 0};
     hipEvent_t ev_mark[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
     bool async_pending = false;
+    // gpcsd_loglik_parts_async: the result lands in h_ll (pinned, 66 doubles like h_result) behind ev_ll; ll_pending until
+    // gpcsd_loglik_parts_wait collects it.  ll_two: the quadratic form came back as two partial sums.
+    double *h_ll = nullptr;
+    hipEvent_t ev_ll = nullptr;
+    bool ll_pending = false, ll_two = false, ll_done = false;
+    double ll_out[2] = {0.0, 0.0};
+    int ll_rc = 0;
     hipEvent_t ev_aux = nullptr, ev_pc = nullptr;   // predict: small products of the tail on stream2 beside the large ones
     std::string last_error;
     std::map<std::string, gpcsd::DevBuf> bufs;
@@ -168,9 +175,32 @@ struct gpcsd_ctx {
         const long epoch_before = alloc_epoch;
         T *d = buf<T>(name, count);
         if (alloc_epoch == epoch_before && sh.size() == bytes && bytes > 0 && memcmp(sh.data(), host, bytes) == 0) return d;
-        if (count) GP_HIP(hipMemcpyAsync(d, host, bytes, hipMemcpyHostToDevice, stream));
+        if (count) GP_HIP(hipMemcpyAsync(d, stage_small(host, bytes), bytes, hipMemcpyHostToDevice, stream));
         sh.assign(reinterpret_cast<const unsigned char *>(host), reinterpret_cast<const unsigned char *>(host) + bytes);
         return d;
+    }
+    // Small uploads go through a ring of pinned slots: a host-to-device copy from pageable memory makes the host wait for
+    // everything queued on the stream before it, which would serialise a caller that changes hyper-parameters every call
+    // against the previous call's GEMM tail.  The ring is fenced once per lap (every STAGE_SLOTS small uploads).
+    static constexpr size_t STAGE_SLOT = 8192, STAGE_SLOTS = 128;
+    unsigned char *stage_ring = nullptr;
+    size_t stage_next = 0;
+    const void *stage_small(const void *host, size_t bytes) {
+        if (bytes > STAGE_SLOT) return host;
+        if (!stage_ring) {
+            if (hipHostMalloc(reinterpret_cast<void **>(&stage_ring), STAGE_SLOT * STAGE_SLOTS, hipHostMallocDefault) != hipSuccess) {
+                (void)hipGetLastError();
+                stage_ring = nullptr;
+                return host;
+            }
+        }
+        if (stage_next == STAGE_SLOTS) {
+            GP_HIP(hipStreamSynchronize(stream));
+            stage_next = 0;
+        }
+        unsigned char *slot = stage_ring + STAGE_SLOT * stage_next++;
+        memcpy(slot, host, bytes);
+        return slot;
     }
     void download(void *host, const void *dev, size_t bytes) {
         GP_HIP(hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, stream));

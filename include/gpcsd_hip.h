@@ -165,6 +165,15 @@ int gpcsd_loglik(gpcsd_ctx *ctx, const gpcsd_hparams *hp, double *out);
 /* Sharded form: out[0] = sum(log D) (identical on every shard), out[1] = sum_r sum alpha^2/D over the
  * resident trials; loglik = -0.5*R_total*out[0] - 0.5*sum_over_shards(out[1]) */
 int gpcsd_loglik_parts(gpcsd_ctx *ctx, const gpcsd_hparams *hp, double *out2);
+/* The same evaluation split in two: _async validates its arguments, queues the work and returns; _wait blocks until that
+ * evaluation (and only that: not whatever was queued behind it) has finished and returns its out2 / rc.  Between the two
+ * the caller may queue further calls on the context -- a gpcsd_predict_resident at the same hyper-parameters, say -- whose
+ * eigen-chains then run beside this evaluation's GEMMs instead of after the host has come back for the result.  One
+ * evaluation may be outstanding per context (rc -3 otherwise).  hp is read during the _async call only.  rc > 0 from _wait:
+ * numerical failure of this evaluation or of an earlier asynchronous call nobody has collected yet (status is sticky until
+ * a synchronising call -- gpcsd_device_synchronize, any call that returns values -- has reported it). */
+int gpcsd_loglik_parts_async(gpcsd_ctx *ctx, const gpcsd_hparams *hp);
+int gpcsd_loglik_parts_wait(gpcsd_ctx *ctx, double *out2);
 /* Local log-likelihood pieces and the gradient of  L_loc = -0.5*ntrials_resident*out2[0] - 0.5*out2[1]  with respect
  * to the natural hyper-parameters [R, ell_s (dim), (ell_t, sigma2_t) per component, sig2n]; with a per-electrode
  * noise list (hp->n_sig2n == nx, indexed by eigen-row as utility_functions.py:54-63) the tail holds nx entries and the

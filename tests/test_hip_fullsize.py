@@ -502,6 +502,31 @@ def test_predict_resident_is_asynchronous_and_changes_no_bits():
     for a, b in zip(ref[:-2], got[:-2]):
         assert a == b
     assert np.array_equal(ref[-2], got[-2]) and np.array_equal(ref[-1], got[-1])
+    # the fully queued step: loglik_async -> predict_resident -> wait, hyper-parameters changing every step
+    def run_queued():
+        out = []
+        for ell in ells:
+            m.temporal_cov_list[0].params["ell"]["value"] = ell
+            hp1, keep1 = m._hparams(m.JITTER)
+            hp0, keep0 = m._hparams(0.0)
+            ctx.loglik_parts_async(hp1)
+            ctx.predict_resident(hp0, z, t, _hip.PRED_CSD, want_lists=True)
+            out.append(ctx.loglik_parts_wait())
+        out.append(ctx.fetch("pred_out_csd", shape).copy())
+        out.append(ctx.fetch("pred_out_csd_list", (len(m.temporal_cov_list),) + shape).copy())
+        return out
+
+    got = run_queued()
+    for a, b in zip(ref[:-2], got[:-2]):
+        assert a == b
+    assert np.array_equal(ref[-2], got[-2]) and np.array_equal(ref[-1], got[-1])
+    with pytest.raises(ValueError):
+        ctx.loglik_parts_wait()                                   # nothing outstanding
+    hp1, keep1 = m._hparams(m.JITTER)
+    ctx.loglik_parts_async(hp1)
+    with pytest.raises(ValueError):
+        ctx.loglik_parts_async(hp1)                               # one outstanding evaluation per context
+    assert ctx.loglik_parts_wait() == ref[len(ells) - 1]
     # asynchronous predict, then the gradient path (which keeps status words of its own) and the batch path
     hp1, keep1 = m._hparams(m.JITTER)
     hp0, keep0 = m._hparams(0.0)

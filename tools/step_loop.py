@@ -28,24 +28,26 @@ def main():
     hp, keep = m._hparams(m.JITTER)
     hp0, keep0 = m._hparams(0.0)
 
+    sync_ll = os.environ.get("STEP_SYNC_LOGLIK") == "1"
+
     def step():
-        ctx.loglik_parts(hp)
-        ctx.predict_resident(hp0, z, w["t"], _hip.PRED_CSD, want_lists=True)
+        if sync_ll:
+            ctx.loglik_parts(hp)
+            ctx.predict_resident(hp0, z, w["t"], _hip.PRED_CSD, want_lists=True)
+        else:
+            ctx.loglik_parts_async(hp)
+            ctx.predict_resident(hp0, z, w["t"], _hip.PRED_CSD, want_lists=True)
+            ctx.loglik_parts_wait()
 
     for _ in range(setup):
         step()
     ctx.synchronize()
     t0 = time.perf_counter()
-    th = 0.0
     for _ in range(steps):
-        a = time.perf_counter()
-        ctx.loglik_parts(hp)
-        b = time.perf_counter()
-        ctx.predict_resident(hp0, z, w["t"], _hip.PRED_CSD, want_lists=True)
-        th += time.perf_counter() - b
+        step()
     ctx.synchronize()
     dt = time.perf_counter() - t0
-    print("steps %d  %.3f ms/step  host time inside predict_resident %.3f ms/step" % (steps, 1e3 * dt / steps, 1e3 * th / steps))
+    print("steps %d  %.3f ms/step  (%s loglik)" % (steps, 1e3 * dt / steps, "synchronous" if sync_ll else "asynchronous"))
 
 
 if __name__ == "__main__":
