@@ -7,6 +7,10 @@ import weakref
 
 import numpy as np
 
+# A context uses four streams; a process that also runs torch / RCCL streams should give the HIP runtime more than its
+# default 4 hardware queues, or streams that share a queue serialise.  Only effective if HIP is not initialised yet.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # GPCSD_LIB_PATH: developer knob for A/B timing of two builds in one session (tools/ab_bench.py); the default is the in-tree build
 LIB_PATH = os.environ.get("GPCSD_LIB_PATH") or os.path.join(_HERE, "libgpcsd_hip.so")
