@@ -304,7 +304,9 @@ def main():
     ap.add_argument("--cpu-budget-s", type=float, default=45.0)
     ap.add_argument("--fit-batch", type=int, default=None, help="cfg5: restarts evaluated per lock-step batch")
     ap.add_argument("--fit-maxiter", type=int, default=15)
-    ap.add_argument("--fit-groups", type=int, default=2, help="cfg5: lock-step groups running side by side on one GPU")
+    ap.add_argument("--fit-groups", type=int, default=1,
+                    help="cfg5: lock-step groups running side by side on one GPU, each on its own context and host thread "
+                         "(measured: one large batch beats several groups -- 7.5 k evals/s at 1 x 32 against 6.3 k at 2 x 16)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -569,7 +571,7 @@ def run_fit_bench(args, w, rank, world, local_rank, backend):
     from gpcsd_amd.dist import TrialSharding
     total_restarts = 32
     mine = [k for k in range(total_restarts) if k % world == rank]
-    B = args.fit_batch or min(8, len(mine))
+    B = args.fit_batch or min(32, len(mine))                        # all of this rank's restarts advance in one lock-step batch
     m = build_model(w, np.zeros((w["nx"], w["nt"], 1)))
     m.set_device(local_rank)
     lfp = synth_data(w, m, w["trials_per_gpu"], seed=1000)          # every rank holds the same 200 trials

@@ -692,15 +692,35 @@ extern "C" int gpcsd_ctx_create(int device, gpcsd_ctx **out) {
         c = new gpcsd_ctx();
         c->device = device;
         c->timeline_on = getenv("GPCSD_TIMELINE") && getenv("GPCSD_TIMELINE")[0] == '1';
-        GP_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+        // GPCSD_RESERVE_CUS=k (experiment): the main stream -- every machine-filling GEMM -- leaves k CUs alone, so that the
+        // chains' whole-CU workgroups (768 threads, 116 KB of LDS) never wait for a GEMM grid to drain
+        {
+            const char *re = getenv("GPCSD_RESERVE_CUS");
+            const int k = re ? atoi(re) : 0;
+            hipDeviceProp_t prop;
+            GP_HIP(hipGetDeviceProperties(&prop, device));
+            const int ncu = prop.multiProcessorCount;
+            if (k > 0 && k < ncu) {
+                std::vector<uint32_t> mask((ncu + 31) / 32, 0xFFFFFFFFu);
+                if (ncu % 32) mask.back() = (1u << (ncu % 32)) - 1u;
+                const int stride = ncu / k + 1;                   // spread over the bit range whatever the XCD interleave is
+                for (int i = 0; i < k; ++i) {
+                    const int b = (i * stride) % ncu;
+                    mask[b / 32] &= ~(1u << (b % 32));
+                }
+                GP_HIP(hipExtStreamCreateWithCUMask(&c->stream, (uint32_t)mask.size(), mask.data()));
+            }
+        }
+        if (!c->stream) GP_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
         // The two chains are the critical path and made of small launches; when they run beside another call's GEMM tail
         // (thousands of workgroups) each of those launches would otherwise queue behind the tiles: high priority.
         int prio_least = 0, prio_greatest = 0;
         GP_HIP(hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
         const char *pe = getenv("GPCSD_CHAIN_PRIORITY");
         const int prio = (pe && pe[0] == '0') ? prio_least : prio_greatest;
+        const int prio_s = (pe && pe[0] == '2') ? prio_least : prio;       // '2': only the temporal chain is raised (A/B)
         GP_HIP(hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, prio));
-        GP_HIP(hipStreamCreateWithPriority(&c->stream3, hipStreamNonBlocking, prio));
+        GP_HIP(hipStreamCreateWithPriority(&c->stream3, hipStreamNonBlocking, prio_s));
         GP_HIP(hipStreamCreateWithFlags(&c->stream4, hipStreamNonBlocking));
         GP_HIP(hipEventCreateWithFlags(&c->ev_sjoin, hipEventDisableTiming));
         for (int i = 0; i < 4; ++i) GP_HIP(hipEventCreateWithFlags(&c->ev_mark[i / 2][i % 2], hipEventDisableTiming));

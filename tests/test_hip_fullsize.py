@@ -468,13 +468,15 @@ def test_decomposition_cache_reuses_unchanged_sides_bitwise():
     assert relerr(m.csd_pred, O.predict(geom, hp2, lfp, c["x"], c["t"], type="csd")["csd"]) < GATE
 
 
-def test_predict_resident_is_asynchronous_and_changes_no_bits():
-    """gpcsd_predict_resident returns with its GEMM tail in flight; the next call's temporal eigen-chain runs beside that
-    tail.  A loglik -> predict_resident loop (changing hyper-parameters every step) gives the bits of the same calls fenced
-    one by one; a numerical failure of an asynchronous predict surfaces at the next synchronising call, and the context
-    stays usable."""
+@pytest.mark.parametrize("name", ["2d_npx_96x120x3", "cfg2s_1d_24x500x8", "1d_odd_17x37x5", "cfg3s_2d_384x500x2"])
+def test_predict_resident_is_asynchronous_and_changes_no_bits(name):
+    """Queued calls: gpcsd_predict_resident returns with its GEMM tail in flight and gpcsd_loglik_parts_async /
+    _wait split the log-likelihood, so the eigen-chains of a call run beside the GEMMs of the call in front of it (two
+    generations of chain outputs).  A loglik -> predict loop that changes hyper-parameters every step gives the bits of the
+    same calls fenced one by one -- both sides folded, one side folded, nothing folded, full size; a numerical failure of a
+    queued call surfaces at the next synchronising call, and the context stays usable."""
     from gpcsd_amd import _hip
-    c, g, geom, hp, lfp = load_model_case("2d_npx_96x120x3")
+    c, g, geom, hp, lfp = load_model_case(name)
     m = _model_from_case(c, g, lfp)
     ctx = m._sync_device()
     ctx.decomposition_cache(False)
@@ -540,14 +542,18 @@ def test_predict_resident_is_asynchronous_and_changes_no_bits():
     m.temporal_cov_list[0].params["ell"]["value"] = float("nan")
     hp_bad, keep_bad = m._hparams(0.0)
     m.temporal_cov_list[0].params["ell"]["value"] = good
-    ctx.predict_resident(hp_bad, z, t, _hip.PRED_CSD, want_lists=False)
-    with pytest.raises(np.linalg.LinAlgError):
-        ctx.synchronize()
+    def bad_predict_then(collect):
+        try:
+            ctx.predict_resident(hp_bad, z, t, _hip.PRED_CSD, want_lists=False)
+        except np.linalg.LinAlgError:
+            return                                                # the unfolded path is synchronous: the call itself reports
+        with pytest.raises(np.linalg.LinAlgError):
+            collect()
+
+    bad_predict_then(ctx.synchronize)
     ctx.synchronize()                                             # reported once
     assert m.loglik() == ll_ref
-    ctx.predict_resident(hp_bad, z, t, _hip.PRED_CSD, want_lists=False)
-    with pytest.raises(np.linalg.LinAlgError):                    # ... or by the next call that returns values
-        ctx.loglik_parts(hp1)
+    bad_predict_then(lambda: ctx.loglik_parts(hp1))               # ... or by the next call that returns values
     assert m.loglik() == ll_ref
     ctx.predict_resident(hp0, z, t, _hip.PRED_CSD, want_lists=True)
     assert np.array_equal(ctx.fetch("pred_out_csd", shape), ref[-2])
