@@ -65,6 +65,7 @@ SIGNATURES = {
     "gpcsd_set_time": (_I, [_P, _DP, _I]),
     "gpcsd_set_host_temporal_gram": (_I, [_P, _DP, _I, _DP, _I, _I]),
     "gpcsd_b_fwd_1d": (_I, [_P, _DP, _L, _D, _DP]),
+    "gpcsd_trad_csd": (_I, [_P, _DP, _L, _L, _L, _I, _DP]),
     "gpcsd_b_fwd_2d": (_I, [_P, _DP, _DP, _DP, _L, _D, _D, _DP]),
     "gpcsd_gram_temporal": (_I, [_P, _I, _DP, _I, _DP, _I, _D, _D, _DP]),
     "gpcsd_ks_csd_1d": (_I, [_P, _DP, _I, _D, _DP]),
@@ -292,6 +293,15 @@ class Context:
         r = _arr(r)
         out = np.empty_like(r)
         self._check(self._lib.gpcsd_b_fwd_1d(self._h, _ptr(r), r.size, float(R), _ptr(out)))
+        return out
+
+    def trad_csd(self, lfp, axis, edge_nan):
+        """minus the second difference of lfp along `axis`; the two end positions are -0.0 or NaN (predict_csd.py)"""
+        lfp = _arr(lfp)
+        out = np.empty_like(lfp)
+        n_outer = int(np.prod(lfp.shape[:axis], dtype=np.int64))
+        n_inner = int(np.prod(lfp.shape[axis + 1:], dtype=np.int64))
+        self._check(self._lib.gpcsd_trad_csd(self._h, _ptr(lfp), n_outer, lfp.shape[axis], n_inner, int(bool(edge_nan)), _ptr(out)))
         return out
 
     def b_fwd_2d(self, d1, d2, R, eps, w=None):

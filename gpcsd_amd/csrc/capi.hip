@@ -919,6 +919,21 @@ extern "C" int gpcsd_b_fwd_1d(gpcsd_ctx *c, const double *r, long n, double R, d
     GP_API_END(c)
 }
 
+extern "C" int gpcsd_trad_csd(gpcsd_ctx *c, const double *lfp, long n_outer, long n_axis, long n_inner, int edge_nan, double *out) {
+    GP_API_BEGIN(c)
+    GP_REQUIRE(n_outer >= 0 && n_axis >= 0 && n_inner >= 0, -3, "trad_csd: negative extent");
+    const long n = n_outer * n_axis * n_inner;
+    if (n == 0) return 0;
+    GP_REQUIRE(lfp && out, -3, "trad_csd: null array");
+    double *d = c->upload<double>("op_in0", lfp, n);
+    double *o = c->buf<double>("op_out", n);
+    k_second_diff(c, d, n_outer, n_axis, n_inner, edge_nan ? -__builtin_nan("") : -0.0, o, c->stream);
+    c->download(out, o, n * sizeof(double));
+    c->sync();
+    return 0;
+    GP_API_END(c)
+}
+
 extern "C" int gpcsd_b_fwd_2d(gpcsd_ctx *c, const double *d1, const double *d2, const double *w, long n, double R, double eps,
                               double *out) {
     GP_API_BEGIN(c)

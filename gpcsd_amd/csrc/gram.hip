@@ -45,6 +45,23 @@ static inline int ew_grid(long n) {
     return (int)(b < 1 ? 1 : (b > 2048 ? 2048 : b));
 }
 
+// Traditional CSD estimator (predict_csd.py:3-31): minus the second difference along the electrode axis of data laid out as
+// (outer, axis, inner); the first and last position of the axis get `edge` (-0.0 in 1-D, NaN in 2-D).  HBM-bound: one read
+// of three neighbouring planes (two of them cache hits) and one write per element.
+__global__ void second_diff_kernel(const double *__restrict__ in, long n_axis, long n_inner, long total, double edge,
+                                   double *__restrict__ out) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long a = (i / n_inner) % n_axis;
+        out[i] = (a == 0 || a == n_axis - 1) ? edge : -(in[i + n_inner] + in[i - n_inner] - 2.0 * in[i]);
+    }
+}
+
+void k_second_diff(gpcsd_ctx *c, const double *in, long n_outer, long n_axis, long n_inner, double edge, double *out, hipStream_t s) {
+    const long total = n_outer * n_axis * n_inner;
+    hipLaunchKernelGGL(second_diff_kernel, dim3(ew_grid(total)), dim3(256), 0, s, in, n_axis, n_inner, total, edge, out);
+    GP_HIP(hipGetLastError());
+}
+
 void k_b_fwd_1d(gpcsd_ctx *c, const double *r, long n, double R, double *out, hipStream_t s) {
     hipLaunchKernelGGL(b_fwd_1d_kernel, dim3(ew_grid(n)), dim3(256), 0, s, r, n, R, out);
     GP_HIP(hipGetLastError());

@@ -66,6 +66,7 @@ struct HpDev {
 
 // ---------------------------------------------------------------- elementwise / Gram builders (gram.hip)
 void k_b_fwd_1d(gpcsd_ctx *c, const double *r, long n, double R, double *out, hipStream_t s);
+void k_second_diff(gpcsd_ctx *c, const double *in, long n_outer, long n_axis, long n_inner, double edge, double *out, hipStream_t s);
 void k_b_fwd_2d(gpcsd_ctx *c, const double *d1, const double *d2, const double *w, long n, double R, double eps,
                 double *out, hipStream_t s);
 // out(n,m) = sum_c sigma2_c k_c(t_i - tp_j); ncomp components fused (K1-K3 of SURVEY 2a)

@@ -105,6 +105,10 @@ int gpcsd_set_host_temporal_gram(gpcsd_ctx *ctx, const double *Kt, int nt, const
 /* ---- operator surface (stand-alone; host in / host out) ------------------------- */
 /* b_fwd_1d(r, R)                        forward_models.py:9-17   (elementwise, n values) */
 int gpcsd_b_fwd_1d(gpcsd_ctx *ctx, const double *r, long n, double R, double *out);
+/* predictcsd_trad_1d / _2d  predict_csd.py:3-16 / :19-31: minus the second difference along the electrode axis of host data
+ * viewed as (n_outer, n_axis, n_inner) -- 1-D: (1, nx, nt*ntrials), ends of the axis -0.0 (edge_nan = 0); 2-D, column-wise on
+ * gridded data: (nx1, nx2, nt*ntrials), first and last column NaN (edge_nan = 1).  out has the shape of lfp. */
+int gpcsd_trad_csd(gpcsd_ctx *ctx, const double *lfp, long n_outer, long n_axis, long n_inner, int edge_nan, double *out);
 /* b_fwd_2d(delta1, delta2, R, eps, w)   forward_models.py:42-54  (w != NULL -> d1,d2 ignored) */
 int gpcsd_b_fwd_2d(gpcsd_ctx *ctx, const double *d1, const double *d2, const double *w, long n,
                    double R, double eps, double *out);

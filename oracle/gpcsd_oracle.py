@@ -483,3 +483,19 @@ def fwd_model_2d(arr, x1, x2, z, R, eps, varsigma=1.0):
     d2 = z[:, 1][:, None, None] - x2[None, None, :]
     W = b_fwd_2d(d1, d2, R, eps) * w1[None, :, None] * w2[None, None, :]   # (nz, nx1, nx2)
     return np.tensordot(W, arr, axes=([1, 2], [0, 1]))
+
+
+def trad_csd_1d(lfp):
+    """predictcsd_trad_1d (predict_csd.py:3-16): minus the second difference over electrodes, zero at the two ends."""
+    lfp = np.asarray(lfp, dtype=np.float64)
+    csd = np.zeros_like(lfp)
+    csd[1:-1] = lfp[2:] + lfp[:-2] - 2.0 * lfp[1:-1]
+    return -csd
+
+
+def trad_csd_2d(lfp):
+    """predictcsd_trad_2d (predict_csd.py:19-31): column-wise on gridded data (nx1, nx2, nt, ntrials), NaN on the end columns."""
+    lfp = np.asarray(lfp, dtype=np.float64)
+    csd = np.full(lfp.shape, np.nan)
+    csd[:, 1:-1] = lfp[:, 2:] + lfp[:, :-2] - 2.0 * lfp[:, 1:-1]
+    return -csd

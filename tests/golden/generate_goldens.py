@@ -312,8 +312,23 @@ def gen_shift_objective():
     print("wrote shift_objective")
 
 
+def gen_trad_csd():
+    """Traditional second-difference CSD estimators (predict_csd.py), the comparison baseline of the simulation studies
+    (sim_from_gp_1D.py:88, sim_from_gp_2D.py:141) and of the auditory analysis (fit_gpcsd_baseline.py:106,147)."""
+    from gpcsd import predict_csd as rpc
+    out = dict(META)
+    rs = np.random.RandomState(7)
+    lfp1 = rs.standard_normal((24, 50, 6))
+    lfp1e = rs.standard_normal((2, 5, 3))                    # no interior electrode at all
+    lfp2 = rs.standard_normal((5, 9, 20, 4))
+    out.update(lfp1=lfp1, csd1=rpc.predictcsd_trad_1d(lfp1), lfp1e=lfp1e, csd1e=rpc.predictcsd_trad_1d(lfp1e),
+               lfp2=lfp2, csd2=rpc.predictcsd_trad_2d(lfp2))
+    np.savez_compressed(os.path.join(HERE, "trad_csd.npz"), **out)
+    print("wrote trad_csd")
+
+
 if __name__ == "__main__":
-    gen_shift_objective()
-    gen_ops()
-    gen_sample_prior()
-    gen_models()
+    which = sys.argv[1:] or ["shift_objective", "ops", "sample_prior", "models", "trad_csd"]
+    for name in which:                                       # a subset regenerates only those fixtures
+        {"shift_objective": gen_shift_objective, "ops": gen_ops, "sample_prior": gen_sample_prior, "models": gen_models,
+         "trad_csd": gen_trad_csd}[name]()

@@ -49,6 +49,23 @@ def test_fwd_models():
     assert relerr(F.fwd_model_2d(g["fm2_arr"], g["fm2_x1"], g["fm2_x2"], g["fm2_z"], 60.0, 20.0), g["fm2_out"]) < 1e-12
 
 
+def test_traditional_csd_estimators_bitwise():
+    """predictcsd_trad_1d / _2d (predict_csd.py:3-31) on the device: the reference's outputs bit for bit, the oracle at a
+    cfg2-sized block, and the degenerate shapes."""
+    from gpcsd_amd import predict_csd
+    g = golden("trad_csd")
+    np.testing.assert_array_equal(predict_csd.predictcsd_trad_1d(g["lfp1"]), g["csd1"])
+    np.testing.assert_array_equal(predict_csd.predictcsd_trad_1d(g["lfp1e"]), g["csd1e"])
+    np.testing.assert_array_equal(predict_csd.predictcsd_trad_2d(g["lfp2"]), g["csd2"])
+    big = np.random.RandomState(3).standard_normal((24, 500, 200))
+    np.testing.assert_array_equal(predict_csd.predictcsd_trad_1d(big), O.trad_csd_1d(big))
+    assert predict_csd.predictcsd_trad_1d(np.zeros((0, 4, 2))).shape == (0, 4, 2)
+    one = predict_csd.predictcsd_trad_2d(np.ones((3, 1, 4, 2)))
+    assert one.shape == (3, 1, 4, 2) and np.all(np.isnan(one))
+    with pytest.raises(ValueError):
+        predict_csd.predictcsd_trad_1d(np.zeros((4, 5)))
+
+
 def test_temporal_cov_classes():
     from gpcsd_amd.covariances import GPCSDTemporalCovSE, GPCSDTemporalCovMatern
     g = golden("ops")

@@ -169,3 +169,10 @@ def test_shift_objective_vs_reference_pieces():
     q = O.whitened_quad(g["Qs"], g["Qt"], g["Dvec"], g["resid"][:, :, :, 1])
     prior = 0.5 * np.sum(np.square((g["taus"][1] - g["mutau"]) / g["sigtau"]))
     assert np.allclose(0.5 * q + prior, g["nll"][:, 1], rtol=1e-11, atol=0)
+
+
+def test_traditional_csd_estimators_vs_reference():
+    g = golden("trad_csd")
+    np.testing.assert_array_equal(O.trad_csd_1d(g["lfp1"]), g["csd1"])
+    np.testing.assert_array_equal(O.trad_csd_1d(g["lfp1e"]), g["csd1e"])
+    np.testing.assert_array_equal(O.trad_csd_2d(g["lfp2"]), g["csd2"])
