@@ -369,20 +369,45 @@ def run_step_bench(args, w, rank, world, local_rank, backend):
     if sharding is not None:
         m._set_from_tparams(sharding.broadcast(m._current_tparams(), src=0), False)
 
+    paired = os.environ.get("GPCSD_BENCH_UNPAIRED") != "1"
+
     def one_step():
         hp, keep = m._hparams(m.JITTER)
         hp0, keep0 = m._hparams(0.0)
-        # queue both calls, then come back for the log-likelihood: predict's eigen-chains run beside the log-likelihood's
-        # GEMMs, and the next step's beside predict's (gpcsd_loglik_parts_async / _wait, gpcsd_predict_resident)
-        ctx.loglik_parts_async(hp)
-        ctx.predict_resident(hp0, z, w["t"], _hip.PRED_CSD, want_lists=True)
+        # queue both calls, then come back for the log-likelihood.  As one paired call (gpcsd_loglik_predict_async) the two
+        # temporal and the two spatial eigenproblems of the step share one chain of launches as replicas -- every one of them
+        # is solved, the results are the bits of the two calls made separately -- and the next step's chain runs beside this
+        # step's predict GEMMs.  GPCSD_BENCH_UNPAIRED=1: the same as two queued calls (four chains per step).
+        if paired:
+            ctx.loglik_predict_async(hp, hp0, z, w["t"], _hip.PRED_CSD, want_lists=True)
+        else:
+            ctx.loglik_parts_async(hp)
+            ctx.predict_resident(hp0, z, w["t"], _hip.PRED_CSD, want_lists=True)
+        if sharding is None:
+            sumlog, quad = ctx.loglik_parts_wait()
+            return -0.5 * R_total * sumlog - 0.5 * quad, 0.0, 0.0
+        # Multi-rank: the only collective of a step is one double summed over the ranks (RCCL).  A rank has its partial sum
+        # when its log-likelihood comes back; the host then queues the next step FIRST and runs the all-reduce of the step
+        # before behind that queueing -- while the GPU works on the next step's eigen-chain and the host would be idle
+        # anyway (issuing it in front of the queueing costs 0.25 ms of host time per step on the critical path).  The global
+        # log-likelihood of step k is therefore complete during step k+1 (the last one before the final fence).
+        ll_prev = flush()
         sumlog, quad = ctx.loglik_parts_wait()
-        if sharding is not None:                 # the only collective of the step: one double summed over the ranks
-            quad = float(sharding.allreduce_sum_async(np.array([quad]))()[0])
-        ll = -0.5 * R_total * sumlog - 0.5 * quad
-        return ll, 0.0, 0.0
+        state["partial"] = (sumlog, quad)
+        return ll_prev, 0.0, 0.0
+
+    state = {}
+
+    def flush():
+        prev = state.pop("partial", None)
+        if prev is None or sharding is None:
+            return None
+        return -0.5 * R_total * prev[0] - 0.5 * float(sharding.allreduce_sum_async(np.array([prev[1]]))()[0])
 
     def fence():
+        last = flush()
+        if last is not None:
+            state["ll"] = last
         ctx.synchronize()
         torch.cuda.synchronize()
         if sharding is not None:
@@ -404,6 +429,8 @@ def run_step_bench(args, w, rank, world, local_rank, backend):
         ll, _a, _b = one_step()
     fence()
     elapsed = time.perf_counter() - t0
+    if sharding is not None:
+        ll = state["ll"]                          # the last step's global log-likelihood, collected inside the timed region
     if sharding is not None:
         import torch.distributed as td
         tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
@@ -438,6 +465,7 @@ def run_step_bench(args, w, rank, world, local_rank, backend):
     n_cached = max(10, min(args.steps, 50))
     for _ in range(n_cached):
         one_step()
+    flush()
     ctx.synchronize()
     cached_ms = 1e3 * (time.perf_counter() - tc0) / n_cached
     ctx.decomposition_cache(False)
@@ -458,6 +486,7 @@ def run_step_bench(args, w, rank, world, local_rank, backend):
     ctx.prof_enable(True)
     for _ in range(n_prof):
         one_step()
+    flush()
     ctx.prof_enable(False)
     prof = ctx.prof_all()
     if rank != 0:
@@ -533,10 +562,15 @@ def run_step_bench(args, w, rank, world, local_rank, backend):
         "config": {"workload": w["label"], "n_elec": w["nx"], "n_t": w["nt"], "trials_per_gpu": R_local,
                    "total_trials": R_total, "predict": "z=electrodes, t*=t, type=csd, %d temporal components" % C,
                    "parallelism": "trial-sharded x%d" % n_gpus},
-        "pipelining": "a step queues loglik (gpcsd_loglik_parts_async) and predict (gpcsd_predict_resident, results stay in "
-                      "HBM), then waits for the log-likelihood: the eigen-chains of a call (two streams, double-buffered "
-                      "outputs) run beside the GEMMs of the call in front of it.  Every step's log-likelihood is returned "
-                      "to the host inside the step; the timed region ends with a full device fence.",
+        "pipelining": "a step queues loglik + predict as one paired call (gpcsd_loglik_predict_async: the four eigenproblems of "
+                      "the step -- Kt and Ks with jitter for loglik, Kt and Ks without for predict, each solved, none reused -- "
+                      "go through one chain of launches as replicas; results stay in HBM), then waits for the log-likelihood; "
+                      "the next step's chain runs beside this step's predict GEMMs (double-buffered chain outputs).  Every "
+                      "step's log-likelihood is returned to the host inside the step; the timed region ends with a full "
+                      "device fence.  Same bits as the two calls made separately (fenced_calls)."
+                      + ("  N > 1: a rank's partial sum is back inside the step; the 8-byte RCCL all-reduce that completes the "
+                         "global log-likelihood of step k runs behind the queueing of step k+1 (the last one before the final "
+                         "fence)." if n_gpus > 1 or sharding is not None else ""),
         "fenced_calls": {"loglik_ms": 1e3 * t_ll, "predict_resident_ms": 1e3 * t_pr, "sum_ms": 1e3 * (t_ll + t_pr),
                          "loglik_evals_per_sec_per_gpu": 1.0 / t_ll, "loglik_trial_evals_per_sec_per_gpu": R_local / t_ll,
                          "predict_trials_per_sec_per_gpu": R_local / t_pr,

@@ -89,6 +89,7 @@ SIGNATURES = {
     "gpcsd_loglik_parts": (_I, [_P, ctypes.POINTER(HParams), _DP]),
     "gpcsd_loglik_parts_async": (_I, [_P, ctypes.POINTER(HParams)]),
     "gpcsd_loglik_parts_wait": (_I, [_P, _DP]),
+    "gpcsd_loglik_predict_async": (_I, [_P, ctypes.POINTER(HParams), ctypes.POINTER(HParams), _DP, _I, _DP, _I, _I, _I]),
     "gpcsd_loglik_grad": (_I, [_P, ctypes.POINTER(HParams), _DP, _DP, _I]),
     "gpcsd_loglik_grad_batch": (_I, [_P, ctypes.POINTER(HParams), _I, _DP, _DP, _I, ctypes.POINTER(_I)]),
     "gpcsd_predict": (_I, [_P, ctypes.POINTER(HParams), _DP, _I, _DP, _I, _I, _DP, _DP, _DP, _DP]),
@@ -485,6 +486,14 @@ class Context:
         out = np.empty(2)
         self._check(self._lib.gpcsd_loglik_parts_wait(self._h, _ptr(out)))
         return float(out[0]), float(out[1])
+
+    def loglik_predict_async(self, hp_loglik, hp_predict, z, tstar, type_code, want_lists=True):
+        """loglik_parts_async(hp_loglik) + predict_resident(hp_predict, ...) as one queued call with the decompositions of the
+        two batched (same bits); collect with loglik_parts_wait() and fetch()."""
+        z = _arr(z)
+        tstar = _arr(tstar).reshape(-1)
+        self._check(self._lib.gpcsd_loglik_predict_async(self._h, ctypes.byref(hp_loglik), ctypes.byref(hp_predict), _ptr(z),
+                                                         z.shape[0], _ptr(tstar), tstar.size, int(type_code), int(bool(want_lists))))
 
     def loglik_grad(self, hp, ngrad):
         """(sum log D, local quad, d L_loc / d natural params) with L_loc = -0.5*R_resident*sumlog - 0.5*quad."""

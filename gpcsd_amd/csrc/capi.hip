@@ -1,8 +1,10 @@
 // extern "C" surface of libgpcsd_hip.so (include/gpcsd_hip.h) and the host-side orchestration of the hot path.
+#include <functional>
 #include <cmath>
 #include <mutex>
 
 #include "kernels.hpp"
+#include "jacobi.hpp"
 
 using namespace gpcsd;
 
@@ -476,6 +478,10 @@ EigState front_half(gpcsd_ctx *c, const gpcsd_hparams *hp, double jitter, bool n
         e.wait_temporal = true;
     }
     if (run_s) {
+        if (c->slot0_on_s2) {             // a paired call ran the spatial problems inside its one chain on stream2: same workspaces
+            GP_HIP(hipStreamWaitEvent(s3, c->ev_join, 0));
+            c->slot0_on_s2 = false;
+        }
         c->tl("S chain start (s3)", s3);
         build_kphi(c, g, hp->R, hp->eps, hp->ell_s, nullptr, 0, jitter, Ks, s3, "ks_");
         {
@@ -641,7 +647,7 @@ int finish_call(gpcsd_ctx *c, const EigState &e, double *scal_out, int nscal) {
     for (int i = 0; i < nscal; ++i) scal_out[i] = host[i];
     int st[4];
     memcpy(st, host + 64, sizeof(st));
-    if (st[0] == 0 && st[1] != 0) st[0] = st[1];      // status[1]: the temporal chain of the two-stream front half
+    for (int i = 1; i < 4 && st[0] == 0; ++i) st[0] = st[i];   // [1]: temporal chain; [2], [3]: second replica of a paired call
     if (st[0] != 0) {
         char b[128];
         snprintf(b, sizeof(b), "numerical failure (status %d): eigensolver did not converge or matrix not positive definite", st[0]);
@@ -657,7 +663,7 @@ int finish_status(gpcsd_ctx *c, const int *d_status) {
     c->download(st, d_status, sizeof(st));
     c->sync();
     if (c->prof_on) c->prof_collect();
-    if (st[0] == 0 && st[1] != 0) st[0] = st[1];      // status[1]: the temporal chain of the two-stream front half
+    for (int i = 1; i < 4 && st[0] == 0; ++i) st[0] = st[i];   // [1]: temporal chain; [2], [3]: second replica of a paired call
     if (st[0] != 0) {
         char b[128];
         snprintf(b, sizeof(b), "numerical failure (status %d): eigensolver did not converge or matrix not positive definite", st[0]);
@@ -1437,6 +1443,29 @@ static int finish_loglik_async(gpcsd_ctx *c, const EigState &e, bool two) {
     return 0;
 }
 
+// Folded-basis tail of the log-likelihood: the two projections as 2 + 2 half-size GEMMs, the quadratic form as two partial
+// sums (one when the parity blocks went out as one batched launch: returns true), sum(log D) folded into the reduce launch.
+static bool loglik_fold_tail(gpcsd_ctx *c, EigState &e, const FoldMode &fm, const double *Yf, double *W) {
+    const int nx = c->nx, nt = c->nt, R = c->ntrials;
+    hipStream_t s = c->stream;
+    ++c->fold_gemm_calls;
+    fold_proj_spatial(c, fm.fs, Yf, W, (long)R * nt, s);
+    const int nparts = join_temporal(c, e, &fm, false);         // sum(log D): summed by the reduce launch of the GEMM below
+    GemmDesc g2[2];
+    g2[0].extra_sum_in = c->buf<double>("buildD_partials", 256);
+    g2[0].extra_sum_n = nparts;
+    g2[0].extra_sum_out = e.scal;
+    for (int p = 0; p < 2; ++p) {
+        const int np = p ? fm.ft.na : fm.ft.ns, c0 = p ? fm.ft.ns : 0;
+        g2[p].M = nx * R; g2[p].N = np; g2[p].K = np;
+        g2[p].A = W + c0; g2[p].lda = nt;
+        g2[p].B = fm.ft.U + (p ? (size_t)fm.ft.ns * fm.ft.ns : 0); g2[p].ldb = np;
+        g2[p].epi = EPI_QUAD; g2[p].D = e.Dinv + c0; g2[p].rdiv = R; g2[p].ldd = nt; g2[p].quad_out = e.scal + 1 + p;
+        g2[p].prof_name = "gemm_proj_temporal_quad";
+    }
+    return gemm_pair(c, g2[0], g2[1], s);
+}
+
 static int loglik_parts_impl(gpcsd_ctx *c, const gpcsd_hparams *hp, double *out2, bool async) {
     GP_REQUIRE(c->d_lfp != nullptr, -4, "lfp not set (call gpcsd_set_lfp)");
     if (async && c->prof_on) {            // profiling scopes need fenced calls: evaluate now, hand the result over at the wait
@@ -1452,23 +1481,7 @@ static int loglik_parts_impl(gpcsd_ctx *c, const gpcsd_hparams *hp, double *out2
     hipStream_t s = c->stream;
     double *W = c->buf<double>("proj_W", (size_t)nx * R * nt);
     if (fm.on) {
-        // the same two projections in the folded basis: 2 + 2 half-size GEMMs, the quadratic form as two partial sums
-        ++c->fold_gemm_calls;
-        fold_proj_spatial(c, fm.fs, Yf, W, (long)R * nt, s);
-        const int nparts = join_temporal(c, e, &fm, false);         // sum(log D): summed by the reduce launch of the GEMM below
-        GemmDesc g2[2];
-        g2[0].extra_sum_in = c->buf<double>("buildD_partials", 256);
-        g2[0].extra_sum_n = nparts;
-        g2[0].extra_sum_out = e.scal;
-        for (int p = 0; p < 2; ++p) {
-            const int np = p ? fm.ft.na : fm.ft.ns, c0 = p ? fm.ft.ns : 0;
-            g2[p].M = nx * R; g2[p].N = np; g2[p].K = np;
-            g2[p].A = W + c0; g2[p].lda = nt;
-            g2[p].B = fm.ft.U + (p ? (size_t)fm.ft.ns * fm.ft.ns : 0); g2[p].ldb = np;
-            g2[p].epi = EPI_QUAD; g2[p].D = e.Dinv + c0; g2[p].rdiv = R; g2[p].ldd = nt; g2[p].quad_out = e.scal + 1 + p;
-            g2[p].prof_name = "gemm_proj_temporal_quad";
-        }
-        const bool batched = gemm_pair(c, g2[0], g2[1], s);
+        const bool batched = loglik_fold_tail(c, e, fm, Yf, W);
         if (async) return finish_loglik_async(c, e, !batched);
         double h3[3] = {0.0, 0.0, 0.0};
         const int rc = finish_call(c, e, h3, 3);
@@ -1527,7 +1540,7 @@ extern "C" int gpcsd_loglik_parts_wait(gpcsd_ctx *c, double *out2) {
     out2[1] = c->ll_two ? host[1] + host[2] : host[1];
     int st[4];
     memcpy(st, host + 64, sizeof(st));
-    if (st[0] == 0 && st[1] != 0) st[0] = st[1];
+    for (int i = 1; i < 4 && st[0] == 0; ++i) st[0] = st[i];
     if (st[0] != 0) {                     // this evaluation's, or an earlier asynchronous call's that nobody collected yet
         char b[160];
         snprintf(b, sizeof(b), "numerical failure (status %d): eigensolver did not converge or matrix not positive definite", st[0]);
@@ -1563,7 +1576,8 @@ static const SymDev &site_symmetry(gpcsd_ctx *c, const double *z, int nz, int di
 //   out_c = Fz^T [ diag_p( (Kc_pp^T U_p) ) Bm~ diag_q( V_q^T Kt*_c,qq ) ] Ft   with Bm~ = (diag(U)^T Y~ diag(V)) / D~ ,
 // every flat GEMM split in its two parity blocks; the last pass unfolds sites and times while it transposes.
 static int predict_fold(gpcsd_ctx *c, const gpcsd_hparams *hp, EigState &e, const FoldMode &fm, const double *Yf, const SymDev &sz,
-                        const double *dz, int nz, const double *dts, int type, bool want_lists, bool async) {
+                        const double *dz, int nz, const double *dts, int type, bool want_lists, bool async,
+                        const std::function<void()> *after_spatial_join = nullptr) {
     const Geo g = resident_geo(c);
     const int nx = c->nx, nt = c->nt, R = c->ntrials, C = hp->n_temporal;
     const long RT = (long)R * nt;
@@ -1601,6 +1615,9 @@ static int predict_fold(gpcsd_ctx *c, const gpcsd_hparams *hp, EigState &e, cons
     }
     // then everything that needs only the spatial eigenvectors, beside the temporal eigensolver
     join_spatial(c, e);
+    // gpcsd_loglik_predict_async: the log-likelihood's whole tail goes here, in front of everything of predict that needs a
+    // decomposition -- it is what the caller waits for
+    if (after_spatial_join) (*after_spatial_join)();
     fold_proj_spatial(c, fm.fs, Yf, W, RT, s);                      // W~ = diag(U)^T Y~
     for (int which = 1; which <= 2; ++which) {
         if (!(type & which)) continue;
@@ -1796,6 +1813,126 @@ static int predict_impl(gpcsd_ctx *c, const gpcsd_hparams *hp, const double *z, 
     return finish_call(c, e, nullptr, 0);
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// loglik + predict as ONE queued call with the four decompositions batched two by two.
+//
+// Chains of small dependent launches do not overlap on this part (1.4x at best, however many queues), but
+// replicas inside one chain are nearly free (gpcsd_eigh_batch: 8 problems in 1.09 ms against 0.93 ms for one).  So when a
+// caller wants the log-likelihood at one hyper-parameter set and the prediction at another (the same set without jitter, in
+// practice), the two temporal problems go through ONE chain as two replicas and the two spatial problems through another:
+// two chains per pair of calls instead of four.  Every problem is still solved (nothing is reused between the two unless the
+// decomposition cache is on and the temporal hyper-parameters coincide: then that side is solved once, as the cache would).
+// Results: the bits of the two calls made separately.
+struct PairFront {
+    EigState e[2];
+    FoldMode fm[2];
+};
+
+static bool same_temporal(const gpcsd_hparams *a, const gpcsd_hparams *b) {
+    if (a->n_temporal != b->n_temporal) return false;
+    for (int i = 0; i < a->n_temporal; ++i)
+        if (a->kind[i] != b->kind[i] || a->ell_t[i] != b->ell_t[i] || a->sigma2_t[i] != b->sigma2_t[i]) return false;
+    return true;
+}
+
+// Both sets decomposed, set b's results at replica b of the generation just started (folded-basis callers only).
+static void front_half_pair(gpcsd_ctx *c, const gpcsd_hparams *const hp[2], const double jitter[2], PairFront &out) {
+    const Geo g = resident_geo(c);
+    const int nx = c->nx, nt = c->nt;
+    const long nxx = (long)nx * nx, ntt = (long)nt * nt;
+    hipStream_t s = c->stream, s2 = c->stream2, s3 = c->stream3;
+    const SymDev *sym_s = c->sym_s.ns > 0 ? &c->sym_s : nullptr, *sym_t = c->sym_t.ns > 0 ? &c->sym_t : nullptr;
+    const double *t = (const double *)c->bufs["time_t"].p;
+    const int nT = (c->decomp_cache_on && same_temporal(hp[0], hp[1])) ? 1 : 2;      // replicas of the temporal problem
+    double *scal = c->buf<double>("scal_status", 64 + 2);
+    int *status = reinterpret_cast<int *>(scal + 64);
+    const bool clear_now = !c->status_zeroed && !c->async_pending;
+    if (clear_now) GP_HIP(hipMemsetAsync(status, 0, 4 * sizeof(int), s));
+    c->status_zeroed = false;
+    begin_generation(c, 1, s2, clear_now);
+    begin_generation(c, 0, s3, clear_now);
+    // inputs and outputs (of the generations just started), two replicas each.  The inputs have names of their own: the
+    // one-chain form below reads them on stream2, the separate calls' spatial chain writes "Ks" on stream3.
+    double *Ks = c->buf<double>("Ks_pair", (size_t)nxx * 2), *Kt = c->buf<double>("Kt_pair", (size_t)ntt * 2);
+    double *Qs = c->buf<double>(gen_name(c, 0, "Qs"), (size_t)nxx * 2), *es = c->buf<double>(gen_name(c, 0, "es"), (size_t)nx * 2);
+    double *Qt = c->buf<double>(gen_name(c, 1, "Qt"), (size_t)ntt * 2), *et = c->buf<double>(gen_name(c, 1, "et"), (size_t)nt * 2);
+    const FoldView vs = sym_s ? eigh_fold_view(c, 0, sym_s, nx, 2) : FoldView(), vt = sym_t ? eigh_fold_view(c, 1, sym_t, nt, 2) : FoldView();
+    c->tl("call start (main)", s);
+    // Gram matrices.  Temporal (stream2): replica b = Kt(hp[b]).  Spatial (stream3): replica b = Ks(hp[b]) + jitter[b] I; with
+    // equal spatial hyper-parameters -- the usual pair -- the two differ by the diagonal shift only, so the matrix is
+    // assembled once and copied (the same GEMM output plus the same diagonal add: the same bits).
+    c->tl("T chain start (s2)", s2);
+    for (int b = 0; b < nT; ++b) build_kt(c, hp[b], t, nt, t, nt, Kt + b * ntt, s2);
+    GP_HIP(hipStreamWaitEvent(s3, c->ev_join, 0));      // the previous chain on stream2 may have been reading Ks_pair
+    c->tl("S chain start (s3)", s3);
+    const bool same_ks = hp[0]->R == hp[1]->R && hp[0]->ell_s[0] == hp[1]->ell_s[0] &&
+                         (g.dim == 1 || (hp[0]->eps == hp[1]->eps && hp[0]->ell_s[1] == hp[1]->ell_s[1]));
+    if (same_ks) {
+        const int lo = jitter[0] == 0.0 ? 0 : 1, hi = 1 - lo;           // assemble the one without a shift (if any) first
+        build_kphi(c, g, hp[lo]->R, hp[lo]->eps, hp[lo]->ell_s, nullptr, 0, 0.0, Ks + lo * nxx, s3, "ks_");
+        GP_HIP(hipMemcpyAsync(Ks + hi * nxx, Ks + lo * nxx, (size_t)nxx * sizeof(double), hipMemcpyDeviceToDevice, s3));
+        if (jitter[lo] != 0.0) k_add_diag(c, Ks + lo * nxx, nx, jitter[lo], s3);
+        if (jitter[hi] != 0.0) k_add_diag(c, Ks + hi * nxx, nx, jitter[hi], s3);
+    } else {
+        for (int b = 0; b < 2; ++b) build_kphi(c, g, hp[b]->R, hp[b]->eps, hp[b]->ell_s, nullptr, 0, jitter[b], Ks + b * nxx, s3, "ks_");
+    }
+    // (a Jacobi-sized problem is solved by another algorithm next to a large one than alone -- it rides in the large one's
+    // launches -- so it keeps a chain of its own: every problem gets the bits of a separate call)
+    const bool one_chain = nT == 2 && nx > JACOBI_LDS_MAX && nt > JACOBI_LDS_MAX;
+    if (one_chain) {
+        // ONE chain for all four problems (stream2; status words [0] and [2]): two chains side by side slow each other down
+        // by more than the shorter one is worth
+        GP_HIP(hipEventRecord(c->ev_aux, s3));
+        GP_HIP(hipStreamWaitEvent(s2, c->ev_aux, 0));              // the Gram matrices of stream3
+        GP_HIP(hipStreamWaitEvent(s2, c->ev_sjoin, 0));            // the last chain on stream3 used the spatial workspaces
+        {
+            ProfScope ps(c, "eigh_pair", 9.0 * ((double)nt * nt * nt + (double)nx * nx * nx) * 2, s2);
+            eigh_pair_device(c, Ks, nx, es, Qs, sym_s, Kt, nt, et, Qt, sym_t, status, s2, false, 2, 2);
+        }
+        GP_HIP(hipEventRecord(c->ev_join, s2));
+        GP_HIP(hipEventRecord(c->ev_sjoin, s2));
+        c->slot0_on_s2 = true;
+        c->tl("pair chain end (s2)", s2);
+    } else {
+        // two chains: the temporal problem(s) on stream2 (one replica when it is shared -- decomposition cache on, equal temporal
+        // hyper-parameters; status words [1], [3]), two replicas of the spatial problem on stream3 (status words [0], [2])
+        {
+            ProfScope ps(c, "eigh_temporal", 9.0 * (double)nt * nt * nt * nT, s2);
+            eigh_pair_device(c, nullptr, 0, nullptr, nullptr, nullptr, Kt, nt, et, Qt, sym_t, status + 1, s2, false, nT, 2);
+        }
+        GP_HIP(hipEventRecord(c->ev_join, s2));
+        c->tl("T chain end (s2)", s2);
+        if (c->slot0_on_s2) c->slot0_on_s2 = false;                 // (ordered behind stream2's last chain by the wait above)
+        {
+            ProfScope ps(c, "eigh_spatial", 9.0 * (double)nx * nx * nx * 2, s3);
+            eigh_pair_device(c, Ks, nx, es, Qs, sym_s, nullptr, 0, nullptr, nullptr, nullptr, status, s3, false, 2, 2);
+        }
+        GP_HIP(hipEventRecord(c->ev_sjoin, s3));
+        c->tl("S chain end (s3)", s3);
+    }
+    c->decomp_gen[0] = c->decomp_gen[1] = -1;          // replicas are not what the separate calls' cache looks for
+    const double *d_sig[2] = {c->upload_cached<double>("sig2n", hp[0]->sig2n, 1), c->upload_cached<double>("sig2n_pair", hp[1]->sig2n, 1)};
+    for (int b = 0; b < 2; ++b) {
+        const int bt = nT == 2 ? b : 0;
+        EigState &e = out.e[b];
+        e.Qs = Qs + b * nxx; e.es = es + (long)b * nx; e.Qt = Qt + bt * ntt; e.et = et + (long)bt * nt;
+        e.D = c->buf<double>("D", (size_t)nx * nt);
+        e.Dinv = c->buf<double>("Dinv", (size_t)nx * nt);
+        e.scal = scal;
+        e.status = status;
+        e.pending = true;
+        e.wait_temporal = e.wait_spatial = true;
+        e.d_sig = d_sig[b];
+        e.nsig = 1;
+        FoldMode &fm = out.fm[b];
+        fm = fold_mode(c, hp[b]);                       // replica 0 of the generations just started ...
+        if (fm.fs.on) { fm.fs.w += (long)b * vs.sw; fm.fs.U += (long)b * vs.sU; }       // ... moved to replica b
+        else { fm.fs.w += (long)b * nx; fm.fs.U += b * nxx; }
+        if (fm.ft.on) { fm.ft.w += (long)bt * vt.sw; fm.ft.U += (long)bt * vt.sU; }
+        else { fm.ft.w += (long)bt * nt; fm.ft.U += bt * ntt; }
+    }
+}
+
 // Collect the status words of an asynchronous predict (see gpcsd_ctx::async_pending): drains the streams.
 static int drain_async(gpcsd_ctx *c) {
     if (!c->async_pending) return 0;
@@ -1811,6 +1948,60 @@ extern "C" int gpcsd_predict_resident(gpcsd_ctx *c, const gpcsd_hparams *hp, con
     GP_API_BEGIN(c)
     static const bool fenced = getenv("GPCSD_SYNC_PREDICT") && getenv("GPCSD_SYNC_PREDICT")[0] == '1';   // A/B switch
     return predict_impl(c, hp, z, nz, tstar, ntstar, type, want_lists != 0, /*async=*/!fenced);
+    GP_API_END(c)
+}
+
+extern "C" int gpcsd_loglik_predict_async(gpcsd_ctx *c, const gpcsd_hparams *hp_ll, const gpcsd_hparams *hp_pr, const double *z, int nz,
+                                          const double *tstar, int ntstar, int type, int want_lists) {
+    if (c && c->ll_pending)
+        return fail(c, HipError{-3, "loglik_predict_async: the previous asynchronous log-likelihood has not been collected "
+                                    "(gpcsd_loglik_parts_wait)"});
+    GP_API_BEGIN(c)
+    GP_REQUIRE(hp_ll && hp_pr, -3, "loglik_predict_async: null hparams");
+    GP_REQUIRE(z && tstar && nz > 0 && ntstar > 0, -3, "predict: bad arguments");
+    GP_REQUIRE(type >= 1 && type <= 3, -3, "predict: type must be CSD(1), LFP(2) or BOTH(3)");
+    GP_REQUIRE(c->nt > 0 && ntstar == c->nt, -22,
+               "predict: len(t)=%d must equal the training nt=%d (the reference's reshape raises ValueError, gpcsd1d.py:279)",
+               ntstar, c->nt);
+    GP_REQUIRE(c->d_lfp != nullptr, -4, "lfp not set (call gpcsd_set_lfp)");
+    static const bool unpaired = getenv("GPCSD_NO_PAIR") && getenv("GPCSD_NO_PAIR")[0] == '1';     // A/B switch
+    // the paired front half serves the folded-basis tails only; anything else is the two calls one after the other
+    bool pair = !unpaired && two_stream_front() && !c->prof_on && !uses_host_kt(hp_ll) && !uses_host_kt(hp_pr) &&
+                hp_ll->n_sig2n == 1 && hp_pr->n_sig2n == 1;
+    FoldMode fm0;
+    SymDev sz;
+    if (pair) {
+        fm0 = fold_mode(c, hp_ll);
+        pair = fm0.on && fold_mode(c, hp_pr).on &&
+               (!fm0.ft.on || ((int)c->time_host.size() == c->nt &&
+                               memcmp(c->time_host.data(), tstar, (size_t)ntstar * sizeof(double)) == 0));
+    }
+    if (pair) {
+        sz = fm0.fs.on ? site_symmetry(c, z, nz, c->dim) : identity_sym(c, nz);
+        pair = sz.ns > 0 && sz.ns + sz.na == nz;
+    }
+    if (!pair) {
+        const int rc = loglik_parts_impl(c, hp_ll, nullptr, true);
+        if (rc != 0) return rc;
+        return predict_impl(c, hp_pr, z, nz, tstar, ntstar, type, want_lists != 0, true);
+    }
+    GP_REQUIRE(c->time_nt == c->nt, -4, "time grid has %d points but lfp has nt=%d", c->time_nt, c->nt);
+    GP_REQUIRE(resident_geo(c).nx == c->nx, -4, "geometry has %d electrodes but lfp has nx=%d", resident_geo(c).nx, c->nx);
+    check_hp(c, hp_ll, c->nx);
+    check_hp(c, hp_pr, c->nx);
+    const gpcsd_hparams *hps[2] = {hp_ll, hp_pr};
+    const double jit[2] = {hp_ll->jitter, 0.0};          // no jitter in predict (gpcsd1d.py:258)
+    PairFront pf;
+    front_half_pair(c, hps, jit, pf);
+    const double *Yf = folded_lfp(c, pf.fm[1]);
+    double *dzf = c->upload_cached<double>("pred_z", z, (size_t)nz * c->dim);
+    double *dtf = c->upload_cached<double>("pred_tstar", tstar, ntstar);
+    const std::function<void()> ll_tail = [&]() {
+        double *Wll = c->buf<double>("proj_W_ll", (size_t)c->nx * c->ntrials * c->nt);
+        const bool batched = loglik_fold_tail(c, pf.e[0], pf.fm[0], Yf, Wll);
+        (void)finish_loglik_async(c, pf.e[0], !batched);
+    };
+    return predict_fold(c, hp_pr, pf.e[1], pf.fm[1], Yf, sz, dzf, nz, dtf, type, want_lists != 0, true, &ll_tail);
     GP_API_END(c)
 }
 

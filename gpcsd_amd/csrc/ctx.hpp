@@ -83,6 +83,7 @@ struct gpcsd_ctx {
     int par[2] = {0, 0};
     hipEvent_t ev_mark[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
     bool async_pending = false;
+    bool slot0_on_s2 = false;               // the last chain that used the spatial solver workspaces ran on stream2 (paired call)
     // gpcsd_loglik_parts_async: the result lands in h_ll (pinned, 66 doubles like h_result) behind ev_ll; ll_pending until
     // gpcsd_loglik_parts_wait collects it.  ll_two: the quadratic form came back as two partial sums.
     double *h_ll = nullptr;

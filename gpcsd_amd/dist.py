@@ -62,7 +62,7 @@ class TrialSharding:
         cache = self.__dict__.setdefault("_staging", {})
         if key not in cache:
             cache[key] = (torch.empty(key, dtype=torch.float64).pin_memory(), torch.empty(key, dtype=torch.float64, device=self._device),
-                          torch.cuda.Stream(device=self._device), torch.cuda.Event())
+                          torch.cuda.Stream(device=self._device, priority=-1), torch.cuda.Event())
         host, dev, stream, done = cache[key]
         host.numpy()[:] = values
         with torch.cuda.stream(stream):

@@ -178,6 +178,17 @@ int gpcsd_loglik_parts(gpcsd_ctx *ctx, const gpcsd_hparams *hp, double *out2);
  * a synchronising call -- gpcsd_device_synchronize, any call that returns values -- has reported it). */
 int gpcsd_loglik_parts_async(gpcsd_ctx *ctx, const gpcsd_hparams *hp);
 int gpcsd_loglik_parts_wait(gpcsd_ctx *ctx, double *out2);
+/* gpcsd_loglik_parts_async(hp_loglik) followed by gpcsd_predict_resident(hp_predict, ...) as ONE queued call: same results
+ * bit for bit, collected the same way (gpcsd_loglik_parts_wait, gpcsd_fetch), but the two temporal eigenproblems go through
+ * one chain of launches as two replicas and the two spatial ones through another -- replicas inside a chain are nearly free
+ * on this GPU, independent chains are not.  The usual pair is one hyper-parameter set with and without the
+ * jitter (GPCSD1D.loglik gpcsd1d.py:113-128 adds it, predict gpcsd1d.py:258 does not); any two sets are accepted.  Every
+ * decomposition is still computed, unless the decomposition cache is on and the temporal hyper-parameters of the two sets
+ * coincide: then that side is solved once, exactly as the cache would serve the second of two separate calls.  Falls back
+ * to the two calls in sequence where the folded-basis path does not apply (per-electrode noise lists, user-defined temporal
+ * covariances, grids or prediction sites without the mirror symmetry). */
+int gpcsd_loglik_predict_async(gpcsd_ctx *ctx, const gpcsd_hparams *hp_loglik, const gpcsd_hparams *hp_predict,
+                               const double *z, int nz, const double *tstar, int ntstar, int type, int want_lists);
 /* Local log-likelihood pieces and the gradient of  L_loc = -0.5*ntrials_resident*out2[0] - 0.5*out2[1]  with respect
  * to the natural hyper-parameters [R, ell_s (dim), (ell_t, sigma2_t) per component, sig2n]; with a per-electrode
  * noise list (hp->n_sig2n == nx, indexed by eigen-row as utility_functions.py:54-63) the tail holds nx entries and the

@@ -522,6 +522,38 @@ def test_predict_resident_is_asynchronous_and_changes_no_bits(name):
     for a, b in zip(ref[:-2], got[:-2]):
         assert a == b
     assert np.array_equal(ref[-2], got[-2]) and np.array_equal(ref[-1], got[-1])
+
+    # ... and as ONE paired call per step: the two temporal problems are two replicas of one chain, the two spatial ones of
+    # another (with the decomposition cache on, equal temporal hyper-parameters are solved once)
+    def run_paired(cache, other_temporal):
+        ctx.decomposition_cache(cache)
+        out = []
+        for ell in ells:
+            m.temporal_cov_list[0].params["ell"]["value"] = ell
+            hp1, keep1 = m._hparams(m.JITTER)
+            if other_temporal:                                    # predict at other temporal hyper-parameters than loglik
+                m.temporal_cov_list[0].params["ell"]["value"] = ells[0] * 1.02
+            hp0, keep0 = m._hparams(0.0)
+            ctx.loglik_predict_async(hp1, hp0, z, t, _hip.PRED_CSD, want_lists=True)
+            out.append(ctx.loglik_parts_wait())
+        out.append(ctx.fetch("pred_out_csd", shape).copy())
+        out.append(ctx.fetch("pred_out_csd_list", (len(m.temporal_cov_list),) + shape).copy())
+        ctx.decomposition_cache(False)
+        return out
+
+    for cache in (False, True):
+        got = run_paired(cache, False)
+        for a, b in zip(ref[:-2], got[:-2]):
+            assert a == b
+        assert np.array_equal(ref[-2], got[-2]) and np.array_equal(ref[-1], got[-1])
+    got = run_paired(False, True)
+    for a, b in zip(ref[:-2], got[:-2]):
+        assert a == b                                             # the log-likelihoods do not depend on predict's set
+    m.temporal_cov_list[0].params["ell"]["value"] = ells[0] * 1.02
+    hp0x, keep0x = m._hparams(0.0)
+    ctx.predict_resident(hp0x, z, t, _hip.PRED_CSD, want_lists=True)
+    assert np.array_equal(ctx.fetch("pred_out_csd", shape), got[-2])
+    m.temporal_cov_list[0].params["ell"]["value"] = ells[-1]
     with pytest.raises(ValueError):
         ctx.loglik_parts_wait()                                   # nothing outstanding
     hp1, keep1 = m._hparams(m.JITTER)

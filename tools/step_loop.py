@@ -30,8 +30,13 @@ def main():
 
     sync_ll = os.environ.get("STEP_SYNC_LOGLIK") == "1"
 
+    paired = os.environ.get("STEP_PAIRED", "1") == "1"
+
     def step():
-        if sync_ll:
+        if paired and not sync_ll:
+            ctx.loglik_predict_async(hp, hp0, z, w["t"], _hip.PRED_CSD, want_lists=True)
+            ctx.loglik_parts_wait()
+        elif sync_ll:
             ctx.loglik_parts(hp)
             ctx.predict_resident(hp0, z, w["t"], _hip.PRED_CSD, want_lists=True)
         else:
@@ -47,7 +52,7 @@ def main():
         step()
     ctx.synchronize()
     dt = time.perf_counter() - t0
-    print("steps %d  %.3f ms/step  (%s loglik)" % (steps, 1e3 * dt / steps, "synchronous" if sync_ll else "asynchronous"))
+    print("steps %d  %.3f ms/step  (%s loglik)" % (steps, 1e3 * dt / steps, "synchronous" if sync_ll else ("paired" if paired else "asynchronous")))
 
 
 if __name__ == "__main__":
