@@ -529,10 +529,11 @@ def run_step_bench(args, w, rank, world, local_rank, backend):
             "achieved": per_launch / (avg * 1e-3) / 1e12, "frac": per_launch / (avg * 1e-3) / 1e12 / FP64_MFMA_SPEC_TFLOPS,
             "workgroups_per_launch": 2, "cus_busy": "2 of %d (one 768-thread workgroup per half problem)" % N_CUS,
             "bound": "latency: ~250 dependent Householder columns per launch, two workgroup barriers each",
-            "launch_time_sum_over_step_wall": (tail["count"] / n_prof) * avg / ms_per_step,
-            "note": "the four launches of a step overlap (spatial beside temporal chain, and the chains of one call beside "
-                    "the GEMMs of the call in front of it), so their summed duration is not a share of the wall time; the "
-                    "two temporal launches (2 x ~0.55 ms) are on the critical path of the pipelined step",
+            "note": "measured in the profiled pass, where the library's event profiler runs loglik and predict as two fenced "
+                    "calls: four launches per step (one per eigenproblem, two half problems each).  In the timed paired step "
+                    "the four eigenproblems share ONE launch of 8 workgroups (8 of %d CUs) whose duration is that of its "
+                    "longest half problem (~0.55 ms, on the critical path: it is 40 %% of the step's wall time)" % N_CUS,
+            "paired_step": {"launches_per_step": 1, "workgroups_per_launch": 8, "cus_busy": "8 of %d" % N_CUS},
         }
     if gemms:
         name = max(gemms, key=lambda k: gemms[k]["ms"])
