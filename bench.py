@@ -456,6 +456,28 @@ def run_step_bench(args, w, rank, world, local_rank, backend):
         ctx.synchronize()
     t_pr = (time.perf_counter() - ts0) / n_sub
 
+    # ---- the same steps with the host loop two steps deep: step k+1 is queued before step k's log-likelihood is collected, so
+    # the chains of consecutive steps run back to back (rank-local, no collective; never part of `value`, whose steps each
+    # return their result before the next one is queued) ----
+    deep_ms = None
+    if paired:
+        hp_d, keep_d = m._hparams(m.JITTER)
+        hp0_d, keep0_d = m._hparams(0.0)
+
+        def run_deep(n):
+            ctx.loglik_predict_async(hp_d, hp0_d, z, w["t"], _hip.PRED_CSD, want_lists=True)
+            for _ in range(n - 1):
+                ctx.loglik_predict_async(hp_d, hp0_d, z, w["t"], _hip.PRED_CSD, want_lists=True)
+                ctx.loglik_parts_wait()
+            return ctx.loglik_parts_wait()
+        run_deep(10)
+        ctx.synchronize()
+        td0 = time.perf_counter()
+        n_deep = max(10, min(args.steps, 100))
+        run_deep(n_deep)
+        ctx.synchronize()
+        deep_ms = 1e3 * (time.perf_counter() - td0) / n_deep
+
     # ---- same step with the decomposition cache on (a user's loglik -> predict sequence; never part of `value`) ----
     ctx.decomposition_cache(True)
     for _ in range(5):
@@ -576,6 +598,11 @@ def run_step_bench(args, w, rank, world, local_rank, backend):
                          "loglik_evals_per_sec_per_gpu": 1.0 / t_ll, "loglik_trial_evals_per_sec_per_gpu": R_local / t_ll,
                          "predict_trials_per_sec_per_gpu": R_local / t_pr,
                          "note": "each call alone, device fenced after every call (rank-local, no collective)"},
+        "two_steps_in_flight": None if deep_ms is None else {
+            "ms_per_step": deep_ms, "trials_per_sec_per_gpu": R_local / (deep_ms * 1e-3),
+            "note": "host loop two steps deep (step k+1 queued before step k's log-likelihood is collected; up to four "
+                    "evaluations may be outstanding per context): the chains of consecutive steps run back to back.  NOT "
+                    "part of value, whose steps each hand their result back before the next step is queued"},
         "with_decomposition_cache": {"ms_per_step": cached_ms, "trials_per_sec_per_gpu": R_local / (cached_ms * 1e-3),
                                      "note": "library default for users (predict after loglik reuses the unchanged temporal "
                                              "eigendecomposition, bit-identical); NOT part of value"},

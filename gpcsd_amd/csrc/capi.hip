@@ -734,8 +734,8 @@ extern "C" int gpcsd_ctx_create(int device, gpcsd_ctx **out) {
         GP_HIP(hipEventCreateWithFlags(&c->ev_aux, hipEventDisableTiming));
         GP_HIP(hipEventCreateWithFlags(&c->ev_pc, hipEventDisableTiming));
         GP_HIP(hipHostMalloc(reinterpret_cast<void **>(&c->h_result), 66 * sizeof(double), hipHostMallocDefault));
-        GP_HIP(hipHostMalloc(reinterpret_cast<void **>(&c->h_ll), 66 * sizeof(double), hipHostMallocDefault));
-        GP_HIP(hipEventCreateWithFlags(&c->ev_ll, hipEventDisableTiming));
+        GP_HIP(hipHostMalloc(reinterpret_cast<void **>(&c->h_ll), gpcsd_ctx::LL_SLOTS * 66 * sizeof(double), hipHostMallocDefault));
+        for (auto &sl : c->ll_slot) GP_HIP(hipEventCreateWithFlags(&sl.ev, hipEventDisableTiming));
         *out = c;
         return 0;
     } catch (const HipError &e) {
@@ -772,7 +772,8 @@ extern "C" int gpcsd_ctx_destroy(gpcsd_ctx *c) {
     if (c->h_result) (void)hipHostFree(c->h_result);
     if (c->h_ll) (void)hipHostFree(c->h_ll);
     if (c->stage_ring) (void)hipHostFree(c->stage_ring);
-    if (c->ev_ll) (void)hipEventDestroy(c->ev_ll);
+    for (auto &sl : c->ll_slot)
+        if (sl.ev) (void)hipEventDestroy(sl.ev);
     delete c;
     return 0;
 }
@@ -1433,11 +1434,13 @@ extern "C" int gpcsd_fold_gemm(gpcsd_ctx *c, int on, long *calls) {
 // End of an asynchronous loglik: the scalars and status words go to the pinned block behind an event; nothing is waited for
 // and the status words are left alone (the chains of later calls may already be reporting into them).
 static int finish_loglik_async(gpcsd_ctx *c, const EigState &e, bool two) {
-    GP_HIP(hipMemcpyAsync(c->h_ll, e.scal, 66 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    GP_HIP(hipEventRecord(c->ev_ll, c->stream));
-    c->ll_pending = true;
-    c->ll_done = false;
-    c->ll_two = two;
+    const int k = (c->ll_head + c->ll_count) % gpcsd_ctx::LL_SLOTS;       // callers have checked that a slot is free
+    gpcsd_ctx::LlSlot &sl = c->ll_slot[k];
+    GP_HIP(hipMemcpyAsync(c->h_ll + 66 * k, e.scal, 66 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    GP_HIP(hipEventRecord(sl.ev, c->stream));
+    ++c->ll_count;
+    sl.done = false;
+    sl.two = two;
     c->async_pending = true;
     c->status_zeroed = false;
     return 0;
@@ -1469,8 +1472,10 @@ static bool loglik_fold_tail(gpcsd_ctx *c, EigState &e, const FoldMode &fm, cons
 static int loglik_parts_impl(gpcsd_ctx *c, const gpcsd_hparams *hp, double *out2, bool async) {
     GP_REQUIRE(c->d_lfp != nullptr, -4, "lfp not set (call gpcsd_set_lfp)");
     if (async && c->prof_on) {            // profiling scopes need fenced calls: evaluate now, hand the result over at the wait
-        c->ll_rc = loglik_parts_impl(c, hp, c->ll_out, false);
-        c->ll_pending = c->ll_done = true;
+        gpcsd_ctx::LlSlot &sl = c->ll_slot[(c->ll_head + c->ll_count) % gpcsd_ctx::LL_SLOTS];
+        sl.rc = loglik_parts_impl(c, hp, sl.out, false);
+        sl.done = true;
+        ++c->ll_count;
         return 0;
     }
     const FoldMode fm0 = fold_mode(c, hp);                          // the decision; its views are of the previous generation
@@ -1516,28 +1521,31 @@ extern "C" int gpcsd_loglik_parts(gpcsd_ctx *c, const gpcsd_hparams *hp, double 
 }
 
 extern "C" int gpcsd_loglik_parts_async(gpcsd_ctx *c, const gpcsd_hparams *hp) {
-    if (c && c->ll_pending)               // refused before anything is touched: the outstanding evaluation stays collectable
-        return fail(c, HipError{-3, "loglik_parts_async: the previous asynchronous evaluation has not been collected "
-                                    "(gpcsd_loglik_parts_wait)"});
+    if (c && c->ll_count >= gpcsd_ctx::LL_SLOTS)   // refused before anything is touched: the outstanding ones stay collectable
+        return fail(c, HipError{-3, "loglik_parts_async: too many asynchronous evaluations outstanding (collect with "
+                                    "gpcsd_loglik_parts_wait)"});
     GP_API_BEGIN(c)
     return loglik_parts_impl(c, hp, nullptr, true);
     GP_API_END(c)
 }
 
 extern "C" int gpcsd_loglik_parts_wait(gpcsd_ctx *c, double *out2) {
-    if (c && (!out2 || !c->ll_pending))
+    if (c && (!out2 || c->ll_count == 0))
         return fail(c, HipError{-3, out2 ? "loglik_parts_wait: no asynchronous evaluation pending" : "null output"});
     GP_API_BEGIN(c)
-    c->ll_pending = false;
-    if (c->ll_done) {
-        out2[0] = c->ll_out[0];
-        out2[1] = c->ll_out[1];
-        return c->ll_rc;
+    const int k = c->ll_head;
+    gpcsd_ctx::LlSlot &sl = c->ll_slot[k];
+    c->ll_head = (k + 1) % gpcsd_ctx::LL_SLOTS;
+    --c->ll_count;
+    if (sl.done) {
+        out2[0] = sl.out[0];
+        out2[1] = sl.out[1];
+        return sl.rc;
     }
-    GP_HIP(hipEventSynchronize(c->ev_ll));
-    const double *host = c->h_ll;
+    GP_HIP(hipEventSynchronize(sl.ev));
+    const double *host = c->h_ll + 66 * k;
     out2[0] = host[0];
-    out2[1] = c->ll_two ? host[1] + host[2] : host[1];
+    out2[1] = sl.two ? host[1] + host[2] : host[1];
     int st[4];
     memcpy(st, host + 64, sizeof(st));
     for (int i = 1; i < 4 && st[0] == 0; ++i) st[0] = st[i];
@@ -1953,9 +1961,9 @@ extern "C" int gpcsd_predict_resident(gpcsd_ctx *c, const gpcsd_hparams *hp, con
 
 extern "C" int gpcsd_loglik_predict_async(gpcsd_ctx *c, const gpcsd_hparams *hp_ll, const gpcsd_hparams *hp_pr, const double *z, int nz,
                                           const double *tstar, int ntstar, int type, int want_lists) {
-    if (c && c->ll_pending)
-        return fail(c, HipError{-3, "loglik_predict_async: the previous asynchronous log-likelihood has not been collected "
-                                    "(gpcsd_loglik_parts_wait)"});
+    if (c && c->ll_count >= gpcsd_ctx::LL_SLOTS)
+        return fail(c, HipError{-3, "loglik_predict_async: too many asynchronous evaluations outstanding (collect with "
+                                    "gpcsd_loglik_parts_wait)"});
     GP_API_BEGIN(c)
     GP_REQUIRE(hp_ll && hp_pr, -3, "loglik_predict_async: null hparams");
     GP_REQUIRE(z && tstar && nz > 0 && ntstar > 0, -3, "predict: bad arguments");

@@ -84,13 +84,19 @@ struct gpcsd_ctx {
     hipEvent_t ev_mark[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
     bool async_pending = false;
     bool slot0_on_s2 = false;               // the last chain that used the spatial solver workspaces ran on stream2 (paired call)
-    // gpcsd_loglik_parts_async: the result lands in h_ll (pinned, 66 doubles like h_result) behind ev_ll; ll_pending until
-    // gpcsd_loglik_parts_wait collects it.  ll_two: the quadratic form came back as two partial sums.
-    double *h_ll = nullptr;
-    hipEvent_t ev_ll = nullptr;
-    bool ll_pending = false, ll_two = false, ll_done = false;
-    double ll_out[2] = {0.0, 0.0};
-    int ll_rc = 0;
+    // gpcsd_loglik_parts_async / gpcsd_loglik_predict_async: a result lands in a slot of h_ll (pinned, 66 doubles like
+    // h_result) behind that slot's event; up to LL_SLOTS evaluations may be outstanding, gpcsd_loglik_parts_wait collects
+    // them oldest first.  two: the quadratic form came back as two partial sums; done: evaluated at once (profiling on).
+    static constexpr int LL_SLOTS = 4;
+    struct LlSlot {
+        hipEvent_t ev = nullptr;
+        bool two = false, done = false;
+        double out[2] = {0.0, 0.0};
+        int rc = 0;
+    };
+    double *h_ll = nullptr;                 // LL_SLOTS x 66 doubles
+    LlSlot ll_slot[LL_SLOTS];
+    int ll_head = 0, ll_count = 0;          // oldest outstanding slot, number outstanding
     hipEvent_t ev_aux = nullptr, ev_pc = nullptr;   // predict: small products of the tail on stream2 beside the large ones
     std::string last_error;
     std::map<std::string, gpcsd::DevBuf> bufs;

@@ -172,8 +172,9 @@ int gpcsd_loglik_parts(gpcsd_ctx *ctx, const gpcsd_hparams *hp, double *out2);
 /* The same evaluation split in two: _async validates its arguments, queues the work and returns; _wait blocks until that
  * evaluation (and only that: not whatever was queued behind it) has finished and returns its out2 / rc.  Between the two
  * the caller may queue further calls on the context -- a gpcsd_predict_resident at the same hyper-parameters, say -- whose
- * eigen-chains then run beside this evaluation's GEMMs instead of after the host has come back for the result.  One
- * evaluation may be outstanding per context (rc -3 otherwise).  hp is read during the _async call only.  rc > 0 from _wait:
+ * eigen-chains then run beside this evaluation's GEMMs instead of after the host has come back for the result.  Up to
+ * four evaluations may be outstanding per context (rc -3 beyond that); _wait collects them oldest first.  hp is read during
+ * the _async call only.  rc > 0 from _wait:
  * numerical failure of this evaluation or of an earlier asynchronous call nobody has collected yet (status is sticky until
  * a synchronising call -- gpcsd_device_synchronize, any call that returns values -- has reported it). */
 int gpcsd_loglik_parts_async(gpcsd_ctx *ctx, const gpcsd_hparams *hp);

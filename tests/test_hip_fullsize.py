@@ -556,10 +556,19 @@ def test_predict_resident_is_asynchronous_and_changes_no_bits(name):
     m.temporal_cov_list[0].params["ell"]["value"] = ells[-1]
     with pytest.raises(ValueError):
         ctx.loglik_parts_wait()                                   # nothing outstanding
+    # up to four evaluations outstanding, collected oldest first (a deeper host loop: queue step k+1, then collect step k)
+    hps = []
+    for ell in ells[:4]:
+        m.temporal_cov_list[0].params["ell"]["value"] = ell
+        hps.append(m._hparams(m.JITTER))
+        hp0, keep0 = m._hparams(0.0)
+        ctx.loglik_predict_async(hps[-1][0], hp0, z, t, _hip.PRED_CSD, want_lists=True)
+    with pytest.raises(ValueError):
+        ctx.loglik_parts_async(hps[0][0])                         # a fifth is refused, the four stay collectable
+    assert [ctx.loglik_parts_wait() for _ in range(4)] == ref[:4]
+    m.temporal_cov_list[0].params["ell"]["value"] = ells[-1]
     hp1, keep1 = m._hparams(m.JITTER)
     ctx.loglik_parts_async(hp1)
-    with pytest.raises(ValueError):
-        ctx.loglik_parts_async(hp1)                               # one outstanding evaluation per context
     assert ctx.loglik_parts_wait() == ref[len(ells) - 1]
     # asynchronous predict, then the gradient path (which keeps status words of its own) and the batch path
     hp1, keep1 = m._hparams(m.JITTER)

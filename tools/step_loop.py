@@ -44,6 +44,21 @@ def main():
             ctx.predict_resident(hp0, z, w["t"], _hip.PRED_CSD, want_lists=True)
             ctx.loglik_parts_wait()
 
+    depth = int(os.environ.get("STEP_DEPTH", "1"))        # 2: queue step k+1 before collecting step k's log-likelihood
+    if depth == 2 and paired and not sync_ll:
+        def run(n):
+            ctx.loglik_predict_async(hp, hp0, z, w["t"], _hip.PRED_CSD, want_lists=True)
+            for _ in range(n - 1):
+                ctx.loglik_predict_async(hp, hp0, z, w["t"], _hip.PRED_CSD, want_lists=True)
+                ctx.loglik_parts_wait()
+            ctx.loglik_parts_wait()
+        run(setup)
+        ctx.synchronize()
+        t0 = time.perf_counter()
+        run(steps)
+        ctx.synchronize()
+        print("steps %d  %.3f ms/step  (paired, host loop two steps deep)" % (steps, 1e3 * (time.perf_counter() - t0) / steps))
+        return
     for _ in range(setup):
         step()
     ctx.synchronize()
