@@ -983,8 +983,8 @@ __global__ __launch_bounds__(NT_SMALL) void dc_small_level_kernel(DcLevel L) {
     __shared__ SetupShared S;
     __shared__ SmallShared Q;
     __shared__ double Q2s[DC_SMALL * Q2_LD];
-    const int lo = sg.lo, hi = sg.hi, n = w.n, N = hi - lo;
-    const int tid = threadIdx.x, wid = tid >> 6;
+    const int lo = sg.lo, hi = sg.hi;
+    const int tid = threadIdx.x;
     dc_setup_body<NW>(w, sg, m, S);
     __syncthreads();
     const int K = S.K, nrot = S.nrot;
