@@ -78,10 +78,12 @@ class GPCSD1D(GPCSDModel):
         self.lfp = new_lfp
 
     def fit(self, n_restarts=10, method="L-BFGS-B", fix_R=False, verbose=False,
-            options={"maxiter": 1000, "disp": False, "gtol": 1e-5, "ftol": 1e7 * np.finfo(float).eps}, starts=None, workers=1, batch=1):
+            options={"maxiter": 1000, "disp": False, "gtol": 1e-5, "ftol": 1e7 * np.finfo(float).eps}, starts=None, workers=1, batch=None):
         """Multi-restart MAP estimate of the hyper-parameters (`starts`: optional explicit log-parameter starts;
         `workers`: restarts run concurrently on this GPU, each on its own context / HIP stream; `batch`: that many
-        restarts advance in lock-step, every objective + gradient evaluation of theirs served by one batched device call)."""
+        restarts advance in lock-step, every objective + gradient evaluation of theirs served by one batched device call --
+        default: all of them (within a memory budget); every restart walks the trajectory it walks on its own, bit for bit;
+        batch=1: one restart after the other, like the reference's loop)."""
         return self._fit(n_restarts, method, fix_R, verbose, options, starts=starts, workers=workers, batch=batch)
 
     def sample_prior(self, ntrials):

@@ -80,7 +80,7 @@ class GPCSD2D(GPCSDModel):
             return -np.inf
 
     def fit(self, n_restarts=10, method="L-BFGS-B", fix_R=False, verbose=False, profile=False,
-            options={"maxiter": 500, "disp": False, "gtol": 1e-5, "ftol": 1e7 * np.finfo(float).eps}, starts=None, workers=1, batch=1):
+            options={"maxiter": 500, "disp": False, "gtol": 1e-5, "ftol": 1e7 * np.finfo(float).eps}, starts=None, workers=1, batch=None):
         """Multi-restart MAP estimate.  profile=True times one objective and one gradient evaluation per GPU kernel
         (the reference cProfiles them) and returns the table without optimising."""
         if profile:

@@ -402,7 +402,12 @@ class GPCSDModel:
         return m
 
     def _batch_can_evaluate(self):
-        return (getattr(self, "_use_analytic_grad", True) and self._sig2n_is_scalar() and not self._uses_host_kt())
+        # (a subclass that brings its own objective is evaluated through it, one point at a time)
+        cls = type(self)
+        own = (cls._loglik_and_grad_natural_batch is not GPCSDModel._loglik_and_grad_natural_batch or
+               (cls._objective_and_grad is GPCSDModel._objective_and_grad and
+                cls._loglik_and_grad_natural is GPCSDModel._loglik_and_grad_natural))
+        return (own and getattr(self, "_use_analytic_grad", True) and self._sig2n_is_scalar() and not self._uses_host_kt())
 
     def _objective_and_grad_batch(self, items, fix_R):
         """{key: (objective, gradient) or exception} for [(key, tparams)]: the lock-step evaluation behind fit(batch=k).
@@ -440,7 +445,16 @@ class GPCSDModel:
                 print("\nrestarting optimization...")
             return None
 
-    def _fit(self, n_restarts, method, fix_R, verbose, options, starts=None, workers=1, batch=1):
+    # device memory a lock-step batch may take for its per-set arrays (five of nx * ntrials * nt doubles per set)
+    FIT_BATCH_BYTES = 32 << 30
+
+    def _auto_batch(self, n):
+        """Default lock-step width of fit(): all restarts of this rank, capped at 32 and by FIT_BATCH_BYTES."""
+        lfp = self._local_lfp()
+        per_set = 5 * 8 * lfp.shape[0] * lfp.shape[1] * lfp.shape[2]
+        return int(max(1, min(n, 32, self.FIT_BATCH_BYTES // max(per_set, 1))))
+
+    def _fit(self, n_restarts, method, fix_R, verbose, options, starts=None, workers=1, batch=None):
         bounds = self._bounds()
         # starting points are drawn up front, in the order the sequential loop of the reference consumes the RNG
         # (the optimiser itself draws nothing), so results do not depend on `workers` or on the number of ranks
@@ -462,7 +476,11 @@ class GPCSDModel:
         mine = [k for k in range(n_restarts) if rs is None or k % rs.world_size == rs.rank]
         results = {}
         workers = max(1, min(int(workers), len(mine)))
-        batch = max(1, min(int(batch), len(mine)))
+        # Replicas in one chain of launches are nearly free on the GPU and each restart gets the bits of a run of its own, so
+        # by default all of this rank's restarts advance in lock-step
+        if batch is None:
+            batch = self._auto_batch(len(mine)) if (len(mine) > 1 and self._batch_can_evaluate()) else 1
+        batch = max(1, min(int(batch), max(len(mine), 1)))
         if batch > 1 and self._batch_can_evaluate():
             # lock-step restarts: `batch` SciPy chains alive at a time, their evaluations served by ONE batched device call.
             # workers > 1: that many such groups side by side, each on its own context (= own streams and buffers).  A batched

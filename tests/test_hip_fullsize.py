@@ -250,7 +250,7 @@ def test_fit_lockstep_batch_equals_sequential_restarts():
     np.random.seed(3)
     starts = [m1._sample_start(False) for _ in range(5)]
     opts = {"maxiter": 6, "disp": False, "gtol": 1e-5, "ftol": 1e7 * np.finfo(float).eps}
-    m1.fit(n_restarts=5, options=opts, starts=starts)
+    m1.fit(n_restarts=5, options=opts, starts=starts, batch=1)      # one restart after the other, like the reference's loop
     m2.fit(n_restarts=5, options=opts, starts=starts, batch=4)
     assert np.array_equal(np.asarray(m1.fit_nll_values_), np.asarray(m2.fit_nll_values_))
     assert all(np.array_equal(a, b) for a, b in zip(m1.fit_params_, m2.fit_params_))
@@ -262,6 +262,12 @@ def test_fit_lockstep_batch_equals_sequential_restarts():
     m3.fit(n_restarts=5, options=opts, starts=starts, batch=2, workers=2)
     assert np.array_equal(np.asarray(m1.fit_nll_values_), np.asarray(m3.fit_nll_values_))
     assert all(np.array_equal(a, b) for a, b in zip(m1.fit_params_, m3.fit_params_))
+    # the default: all restarts in one lock-step batch
+    m4, *_ = _cfg5_model()
+    m4.fit(n_restarts=5, options=opts, starts=starts)
+    assert m4.fit_batches_[1] > m4.fit_batches_[0] and m4._auto_batch(5) == 5
+    assert np.array_equal(np.asarray(m1.fit_nll_values_), np.asarray(m4.fit_nll_values_))
+    assert all(np.array_equal(a, b) for a, b in zip(m1.fit_params_, m4.fit_params_))
 
 
 # ------------------------------------------------------------------------------------------------ contract edges

@@ -540,8 +540,8 @@ def test_fit_concurrent_restarts_match_sequential():
     np.random.seed(11)
     starts = [m1._sample_start(False) for _ in range(4)]
     opts = {"maxiter": 25, "disp": False, "gtol": 1e-5, "ftol": 1e7 * np.finfo(float).eps}
-    m1.fit(n_restarts=4, options=opts, starts=starts, workers=1)
-    m2.fit(n_restarts=4, options=opts, starts=starts, workers=3)
+    m1.fit(n_restarts=4, options=opts, starts=starts, workers=1, batch=1)
+    m2.fit(n_restarts=4, options=opts, starts=starts, workers=3, batch=1)
     assert np.allclose(m1.fit_nll_values_, m2.fit_nll_values_, rtol=1e-10, atol=0)
     assert abs(m1.R["value"] - m2.R["value"]) <= 1e-9 * abs(m1.R["value"])
     assert abs(m1.loglik() - m2.loglik()) <= 1e-9 * abs(m1.loglik())
