@@ -606,6 +606,17 @@ def test_predict_resident_is_asynchronous_and_changes_no_bits(name):
     assert np.array_equal(ctx.fetch("pred_out_csd", shape), ref[-2])
 
 
+@pytest.mark.parametrize("name", ["cfg3", "cfg2"])
+def test_queued_call_forms_mixed_at_random_soak(name):
+    """tools/soak_paired.py: 80 steps at the bench geometry with hyper-parameters changing every step, the call forms
+    (fenced / two queued calls / paired / paired with two steps in flight) mixed at random, decomposition cache off and on:
+    every log-likelihood and the final predictions are the bits of the same calls fenced one by one."""
+    import subprocess
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "soak_paired.py"), name, "80"], capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0 and "soak ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
 def test_predict_returns_pinned_arrays_that_are_not_overwritten():
     """predict() lands its host arrays in recycled page-locked blocks; arrays a caller keeps must survive later calls."""
     c, g, geom, hp, lfp = load_model_case("2d_npx_96x120x3")

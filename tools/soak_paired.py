@@ -1,0 +1,76 @@
+"""Soak of the queued call forms: N steps with hyper-parameters that change every step, the paired / queued / two-deep forms
+against the same calls fenced one by one -- every log-likelihood and the final predictions bit for bit.  Mixes the forms at
+random, so generations, chain streams and the result ring see every hand-over.   python tools/soak_paired.py [cfg3|cfg2] [N]"""
+import os, sys
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench
+from gpcsd_amd import _hip
+
+name = sys.argv[1] if len(sys.argv) > 1 else "cfg3"
+N = int(sys.argv[2]) if len(sys.argv) > 2 else 200
+w = bench.workload(name)
+m = bench.build_model(w, np.zeros((w["nx"], w["nt"], 1)))
+R = 6
+lfp = bench.synth_data(w, m, R, seed=5)
+m.update_lfp(lfp, w["t"])
+ctx = m._sync_device()
+z = np.ascontiguousarray(w["x"])
+shape = (z.shape[0], w["nt"], R)
+rs = np.random.RandomState(0)
+base_ell = m.temporal_cov_list[0].params["ell"]["value"]
+base_R = m.R["value"]
+thetas = [(base_ell * rs.uniform(0.8, 1.25), base_R * rs.uniform(0.9, 1.1), bool(rs.rand() < 0.3)) for _ in range(N)]
+
+
+def hps(k):
+    ell, Rv, other = thetas[k]
+    m.temporal_cov_list[0].params["ell"]["value"] = ell
+    m.R["value"] = Rv
+    h1 = m._hparams(m.JITTER)
+    if other:                                   # predict at another spatial set than loglik: no shared Gram assembly
+        m.R["value"] = Rv * 1.01
+    h0 = m._hparams(0.0)
+    return h1, h0
+
+
+ctx.decomposition_cache(False)
+ref_ll, ref_pred = [], None
+for k in range(N):
+    h1, h0 = hps(k)
+    ref_ll.append(ctx.loglik_parts(h1[0]))
+    ctx.predict_resident(h0[0], z, w["t"], _hip.PRED_CSD, want_lists=True)
+    ctx.synchronize()
+ref_pred = ctx.fetch("pred_out_csd", shape).copy()
+
+for cache in (False, True):
+    ctx.decomposition_cache(cache)
+    got, outstanding, keep = [], 0, []
+    for k in range(N):
+        h1, h0 = hps(k)
+        keep.append((h1, h0))
+        form = rs.randint(4)
+        if form == 0:                           # fenced
+            while outstanding:
+                got.append(ctx.loglik_parts_wait()); outstanding -= 1
+            got.append(ctx.loglik_parts(h1[0]))
+            ctx.predict_resident(h0[0], z, w["t"], _hip.PRED_CSD, want_lists=True)
+            if rs.rand() < 0.5:
+                ctx.synchronize()
+        elif form == 1:                         # two queued calls
+            ctx.loglik_parts_async(h1[0]); outstanding += 1
+            ctx.predict_resident(h0[0], z, w["t"], _hip.PRED_CSD, want_lists=True)
+        else:                                   # paired call
+            ctx.loglik_predict_async(h1[0], h0[0], z, w["t"], _hip.PRED_CSD, want_lists=True); outstanding += 1
+        while outstanding > (2 if form == 3 else 0) or outstanding >= 4:      # form 3 leaves up to two outstanding
+            got.append(ctx.loglik_parts_wait()); outstanding -= 1
+    while outstanding:
+        got.append(ctx.loglik_parts_wait()); outstanding -= 1
+    pred = ctx.fetch("pred_out_csd", shape)
+    bad = [k for k in range(N) if got[k] != ref_ll[k]]
+    print("%s cache=%s: %d steps, log-likelihood mismatches %d, predictions %s" % (
+        name, cache, N, len(bad), "identical" if np.array_equal(pred, ref_pred) else "DIFFER"), flush=True)
+    if bad or not np.array_equal(pred, ref_pred):
+        print("first mismatches:", bad[:5])
+        sys.exit(1)
+print("soak ok")
