@@ -553,9 +553,9 @@ def run_step_bench(args, w, rank, world, local_rank, backend):
             "bound": "latency: ~250 dependent Householder columns per launch, two workgroup barriers each",
             "note": "measured in the profiled pass, where the library's event profiler runs loglik and predict as two fenced "
                     "calls: four launches per step (one per eigenproblem, two half problems each).  In the timed paired step "
-                    "the four eigenproblems share ONE launch of 8 workgroups (8 of %d CUs) whose duration is that of its "
-                    "longest half problem (~0.55 ms, on the critical path: it is 40 %% of the step's wall time)" % N_CUS,
-            "paired_step": {"launches_per_step": 1, "workgroups_per_launch": 8, "cus_busy": "8 of %d" % N_CUS},
+                    "the two temporal problems share one launch of 4 workgroups (~0.55 ms, on the critical path: almost half "
+                    "of the step's wall time) and the two spatial ones another (~0.33 ms, beside it): 8 of %d CUs" % N_CUS,
+            "paired_step": {"launches_per_step": 2, "workgroups_per_launch": 4, "cus_busy": "8 of %d" % N_CUS},
         }
     if gemms:
         name = max(gemms, key=lambda k: gemms[k]["ms"])
@@ -587,8 +587,9 @@ def run_step_bench(args, w, rank, world, local_rank, backend):
                    "parallelism": "trial-sharded x%d" % n_gpus},
         "pipelining": "a step queues loglik + predict as one paired call (gpcsd_loglik_predict_async: the four eigenproblems of "
                       "the step -- Kt and Ks with jitter for loglik, Kt and Ks without for predict, each solved, none reused -- "
-                      "go through one chain of launches as replicas; results stay in HBM), then waits for the log-likelihood; "
-                      "the next step's chain runs beside this step's predict GEMMs (double-buffered chain outputs).  Every "
+                      "share launches two by two as replicas: one temporal chain, one spatial chain; results stay in HBM), then "
+                      "waits for the log-likelihood; the next step's chains run beside this step's predict GEMMs "
+                      "(double-buffered chain outputs).  Every "
                       "step's log-likelihood is returned to the host inside the step; the timed region ends with a full "
                       "device fence.  Same bits as the two calls made separately (fenced_calls)."
                       + ("  N > 1: a rank's partial sum is back inside the step; the 8-byte RCCL all-reduce that completes the "

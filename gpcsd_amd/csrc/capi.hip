@@ -1884,26 +1884,31 @@ static void front_half_pair(gpcsd_ctx *c, const gpcsd_hparams *const hp[2], cons
     } else {
         for (int b = 0; b < 2; ++b) build_kphi(c, g, hp[b]->R, hp[b]->eps, hp[b]->ell_s, nullptr, 0, jitter[b], Ks + b * nxx, s3, "ks_");
     }
-    // (a Jacobi-sized problem is solved by another algorithm next to a large one than alone -- it rides in the large one's
-    // launches -- so it keeps a chain of its own: every problem gets the bits of a separate call)
-    const bool one_chain = nT == 2 && nx > JACOBI_LDS_MAX && nt > JACOBI_LDS_MAX;
+    // (in the one-chain form a Jacobi-sized problem would be solved by another algorithm than alone -- it rides in the large
+    // one's launches -- and lose the bits of a separate call: such a pair always takes two chains)
+    // GPCSD_PAIR_CHAINS=1 (A/B): everything in ONE chain on stream2.  Measured slower than two: 1.38 against 1.18 ms per cfg3
+    // step -- with two chains the spatial one is done first (0.83 against 1.0 ms) and the log-likelihood's spatial projection
+    // runs under the end of the temporal one, while one chain makes everybody wait for its last launch.
+    static const bool want_one = getenv("GPCSD_PAIR_CHAINS") && getenv("GPCSD_PAIR_CHAINS")[0] == '1';
+    const bool one_chain = want_one && nx > JACOBI_LDS_MAX && nt > JACOBI_LDS_MAX;
     if (one_chain) {
-        // ONE chain for all four problems (stream2; status words [0] and [2]): two chains side by side slow each other down
-        // by more than the shorter one is worth
+        // ONE chain for all the problems (stream2; status words [0] and [2]; the temporal problem has one replica when it is
+        // shared -- decomposition cache on, equal temporal hyper-parameters)
         GP_HIP(hipEventRecord(c->ev_aux, s3));
         GP_HIP(hipStreamWaitEvent(s2, c->ev_aux, 0));              // the Gram matrices of stream3
         GP_HIP(hipStreamWaitEvent(s2, c->ev_sjoin, 0));            // the last chain on stream3 used the spatial workspaces
         {
-            ProfScope ps(c, "eigh_pair", 9.0 * ((double)nt * nt * nt + (double)nx * nx * nx) * 2, s2);
-            eigh_pair_device(c, Ks, nx, es, Qs, sym_s, Kt, nt, et, Qt, sym_t, status, s2, false, 2, 2);
+            ProfScope ps(c, "eigh_pair", 9.0 * ((double)nt * nt * nt * nT + (double)nx * nx * nx * 2), s2);
+            eigh_pair_device(c, Ks, nx, es, Qs, sym_s, Kt, nt, et, Qt, sym_t, status, s2, false, 2, 2, nT);
         }
         GP_HIP(hipEventRecord(c->ev_join, s2));
         GP_HIP(hipEventRecord(c->ev_sjoin, s2));
         c->slot0_on_s2 = true;
         c->tl("pair chain end (s2)", s2);
     } else {
-        // two chains: the temporal problem(s) on stream2 (one replica when it is shared -- decomposition cache on, equal temporal
-        // hyper-parameters; status words [1], [3]), two replicas of the spatial problem on stream3 (status words [0], [2])
+        // two chains: the temporal problem(s) on stream2 (status words [1], [3]; one replica when the problem is shared --
+        // decomposition cache on, equal temporal hyper-parameters), two replicas of the spatial problem on stream3 (status
+        // words [0], [2])
         {
             ProfScope ps(c, "eigh_temporal", 9.0 * (double)nt * nt * nt * nT, s2);
             eigh_pair_device(c, nullptr, 0, nullptr, nullptr, nullptr, Kt, nt, et, Qt, sym_t, status + 1, s2, false, nT, 2);

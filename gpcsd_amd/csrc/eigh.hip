@@ -194,7 +194,8 @@ __global__ void dummy_probe_kernel(int *p) {
 
 static void eigh_pair_enqueue(gpcsd_ctx *c, double *A0, int n0, double *w0, double *Z0, const SymDev *sym0, double *A1, int n1,
                               double *w1, double *Z1, const SymDev *sym1, int *d_status, hipStream_t s, bool need_merged,
-                              int count, int status_stride) {
+                              int count, int status_stride, int count1) {
+    const int cnt[2] = {count, count1 > 0 ? count1 : count};      // replicas of problem 0 / problem 1
     {   // GPCSD_DUMMY_LAUNCHES=k (measurement only): k empty dependent launches in front of every chain -- what one more
         // kernel boundary costs the chain and the whole step
         static const int ndummy = getenv("GPCSD_DUMMY_LAUNCHES") ? atoi(getenv("GPCSD_DUMMY_LAUNCHES")) : 0;
@@ -213,11 +214,11 @@ static void eigh_pair_enqueue(gpcsd_ctx *c, double *A0, int n0, double *w0, doub
     // A small problem next to a large one rides along in the large problem's launches for free (GPCSD1D: 24 electrodes
     // next to 500 time points), instead of a serial 250 us single-workgroup Jacobi in front of them.
     const bool pair_has_large = !force_jacobi() && (n0 > JACOBI_LDS_MAX || n1 > JACOBI_LDS_MAX);
-    auto submit = [&](double *Am, int nm, double *wm, double *Zm, const char *tag, long sA, long sw, long sZ) {
+    auto submit = [&](double *Am, int nm, double *wm, double *Zm, const char *tag, long sA, long sw, long sZ, int nrep) {
         if (nm <= 0) return;
         EigReq q;
         q.A = Am; q.n = nm; q.w = wm; q.Z = Zm; q.tag = tag;
-        q.count = count; q.sA = sA; q.sw = sw; q.sZ = sZ;
+        q.count = nrep; q.sA = sA; q.sw = sw; q.sZ = sZ;
         const bool small = nm <= JACOBI_LDS_MAX && !(pair_has_large && nm >= EIG_BATCH_MIN_N);
         if (small || force_jacobi()) eigh_jacobi(c, q, d_status, status_stride, s);
         else large[nlarge++] = q;
@@ -229,27 +230,27 @@ static void eigh_pair_enqueue(gpcsd_ctx *c, double *A0, int n0, double *w0, doub
         if (fold_applies(sy, n[p])) {
             const int ns = sy->ns, na = sy->na;
             const std::string T = std::string("fold_") + tags[p][0] + "_";
-            double *Ks = c->buf<double>(T + "Ks", (size_t)ns * ns * count),
-                   *Ka = c->buf<double>(T + "Ka", (size_t)std::max(na, 1) * na * count);
-            const FoldView fv = eigh_fold_view(c, p, sy, n[p], count);
+            double *Ks = c->buf<double>(T + "Ks", (size_t)ns * ns * cnt[p]),
+                   *Ka = c->buf<double>(T + "Ka", (size_t)std::max(na, 1) * na * cnt[p]);
+            const FoldView fv = eigh_fold_view(c, p, sy, n[p], cnt[p]);
             fold[p].on = true;
             fold[p].ws = fv.w;
             fold[p].Us = fv.U;
             fold[p].wa = fv.w + ns;
             fold[p].Ua = fv.U + (size_t)ns * ns;
-            hipLaunchKernelGGL(sym_fold_kernel, dim3(ceil_div((long)ns * ns, 256), count), dim3(256), 0, s, (const double *)A[p],
+            hipLaunchKernelGGL(sym_fold_kernel, dim3(ceil_div((long)ns * ns, 256), cnt[p]), dim3(256), 0, s, (const double *)A[p],
                                n[p], *sy, Ks, Ka);
-            submit(Ks, ns, fold[p].ws, fold[p].Us, tags[p][1], (long)ns * ns, fv.sw, fv.sU);
-            submit(Ka, na, fold[p].wa, fold[p].Ua, tags[p][2], (long)na * na, fv.sw, fv.sU);
+            submit(Ks, ns, fold[p].ws, fold[p].Us, tags[p][1], (long)ns * ns, fv.sw, fv.sU, cnt[p]);
+            submit(Ka, na, fold[p].wa, fold[p].Ua, tags[p][2], (long)na * na, fv.sw, fv.sU, cnt[p]);
         } else {
-            submit(A[p], n[p], w[p], Z[p], tags[p][0], nn, n[p], nn);
+            submit(A[p], n[p], w[p], Z[p], tags[p][0], nn, n[p], nn, cnt[p]);
         }
     }
     if (nlarge) eigh_large_multi(c, large, nlarge, d_status, status_stride, s);
     // need_merged == false: the caller stays in the folded basis (eigh_fold_view) and never reads w / Z of a folded problem
     for (int p = 0; p < 2; ++p)
         if (fold[p].on && need_merged)
-            hipLaunchKernelGGL(sym_unfold_kernel, dim3(n[p], count), dim3(256), 0, s, n[p], *sym[p], (const double *)fold[p].ws,
+            hipLaunchKernelGGL(sym_unfold_kernel, dim3(n[p], cnt[p]), dim3(256), 0, s, n[p], *sym[p], (const double *)fold[p].ws,
                                (const double *)fold[p].Us, (const double *)fold[p].wa, (const double *)fold[p].Ua, w[p], Z[p]);
     GP_HIP(hipGetLastError());
 }
@@ -259,8 +260,9 @@ static void eigh_pair_enqueue(gpcsd_ctx *c, double *A0, int n0, double *w0, doub
 // replayed.  A graph is retired whenever any context buffer is (re)allocated, since it holds raw device pointers.
 void eigh_pair_device(gpcsd_ctx *c, double *A0, int n0, double *w0, double *Z0, const SymDev *sym0, double *A1, int n1,
                       double *w1, double *Z1, const SymDev *sym1, int *d_status, hipStream_t s, bool need_merged, int count,
-                      int status_stride) {
+                      int status_stride, int count1) {
     if (count < 1) count = 1;
+    if (count1 < 1) count1 = count;
     if (n0 > 0) ++c->eig_gen[0];               // whatever a previous call left in this slot's outputs is about to be replaced
     if (n1 > 0) ++c->eig_gen[1];
     // the limit applies to what the solver actually factorises: a symmetry-folded problem is two half-size ones
@@ -273,15 +275,15 @@ void eigh_pair_device(gpcsd_ctx *c, double *A0, int n0, double *w0, double *Z0, 
     // GPCSD_PROF_GRAPH=1: keep replaying graphs while profiling, so the outer scopes time the chains as they run in production
     static const bool prof_graph = getenv("GPCSD_PROF_GRAPH") != nullptr;
     if (!any_large || (c->prof_on && !prof_graph) || !graphs_enabled()) {
-        eigh_pair_enqueue(c, A0, n0, w0, Z0, sym0, A1, n1, w1, Z1, sym1, d_status, s, need_merged, count, status_stride);
+        eigh_pair_enqueue(c, A0, n0, w0, Z0, sym0, A1, n1, w1, Z1, sym1, d_status, s, need_merged, count, status_stride, count1);
         return;
     }
     // (the generation of each slot picks the fold-order output buffers, which are not among the arguments)
     char key[352];
-    snprintf(key, sizeof(key), "eigh|%p|%d|%p|%p|%p|%d|%p|%d|%p|%p|%p|%d|%p|%p|%d|%d|%d|%d%d", (void *)A0, n0, (void *)w0, (void *)Z0,
+    snprintf(key, sizeof(key), "eigh|%p|%d|%p|%p|%p|%d|%p|%d|%p|%p|%p|%d|%p|%p|%d|%d|%d|%d%d|%d", (void *)A0, n0, (void *)w0, (void *)Z0,
              (void *)(sym0 ? sym0->rep_i : nullptr), sym0 ? sym0->ns : 0, (void *)A1, n1, (void *)w1, (void *)Z1,
              (void *)(sym1 ? sym1->rep_i : nullptr), sym1 ? sym1->ns : 0, (void *)d_status, (void *)s, (int)need_merged, count,
-             status_stride, c->par[0], c->par[1]);
+             status_stride, c->par[0], c->par[1], count1);
     gpcsd_ctx::GraphSlot &g = c->graphs[key];
     if (g.exec && g.epoch == c->alloc_epoch) {
         GP_HIP(hipGraphLaunch(g.exec, s));
@@ -296,7 +298,7 @@ void eigh_pair_device(gpcsd_ctx *c, double *A0, int n0, double *w0, double *Z0, 
         GP_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
         c->capturing = true;
         try {
-            eigh_pair_enqueue(c, A0, n0, w0, Z0, sym0, A1, n1, w1, Z1, sym1, d_status, s, need_merged, count, status_stride);
+            eigh_pair_enqueue(c, A0, n0, w0, Z0, sym0, A1, n1, w1, Z1, sym1, d_status, s, need_merged, count, status_stride, count1);
         } catch (...) {
             c->capturing = false;
             (void)hipStreamEndCapture(s, &graph);
@@ -315,7 +317,7 @@ void eigh_pair_device(gpcsd_ctx *c, double *A0, int n0, double *w0, double *Z0, 
             return;
         }
     }
-    eigh_pair_enqueue(c, A0, n0, w0, Z0, sym0, A1, n1, w1, Z1, sym1, d_status, s, need_merged, count, status_stride);
+    eigh_pair_enqueue(c, A0, n0, w0, Z0, sym0, A1, n1, w1, Z1, sym1, d_status, s, need_merged, count, status_stride, count1);
     g.seen_epoch = c->alloc_epoch;
 }
 

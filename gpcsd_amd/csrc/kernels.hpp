@@ -146,7 +146,7 @@ __device__ __forceinline__ void class_of(const int *start, int g, int &cls, int 
 // reports numerical failure in d_status[r * status_stride] (status_stride 0: one shared word)
 void eigh_pair_device(gpcsd_ctx *c, double *A0, int n0, double *w0, double *Z0, const SymDev *sym0, double *A1, int n1,
                       double *w1, double *Z1, const SymDev *sym1, int *d_status, hipStream_t s, bool need_merged = true,
-                      int count = 1, int status_stride = 0);
+                      int count = 1, int status_stride = 0, int count1 = -1);   // count1 > 0: replicas of problem 1 (else = count)
 // Half-size results of a symmetry-folded problem, in fold order (see eigh.hip); on == false: the problem is not folded.
 struct FoldView {
     bool on = false;
