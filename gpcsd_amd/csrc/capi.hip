@@ -1872,6 +1872,21 @@ static void front_half_pair(gpcsd_ctx *c, const gpcsd_hparams *const hp[2], cons
     c->tl("T chain start (s2)", s2);
     for (int b = 0; b < nT; ++b) build_kt(c, hp[b], t, nt, t, nt, Kt + b * ntt, s2);
     GP_HIP(hipStreamWaitEvent(s3, c->ev_join, 0));      // the previous chain on stream2 may have been reading Ks_pair
+    // (one chain wanted: decided below; a Jacobi-sized problem next to a large one would be solved by another algorithm than
+    // alone -- it rides in the large one's launches -- and lose the bits of a separate call: such a pair takes two chains)
+    static const bool want_one = getenv("GPCSD_PAIR_CHAINS") && getenv("GPCSD_PAIR_CHAINS")[0] == '1';
+    const bool one_chain = want_one && nx > JACOBI_LDS_MAX && nt > JACOBI_LDS_MAX;
+    if (!one_chain) {
+        // the temporal chain is the critical path of the call: it is queued before the host spends its time on the dozen
+        // launches of the spatial Gram assembly (status words [1], [3]; one replica when the problem is shared --
+        // decomposition cache on, equal temporal hyper-parameters)
+        {
+            ProfScope ps(c, "eigh_temporal", 9.0 * (double)nt * nt * nt * nT, s2);
+            eigh_pair_device(c, nullptr, 0, nullptr, nullptr, nullptr, Kt, nt, et, Qt, sym_t, status + 1, s2, false, nT, 2);
+        }
+        GP_HIP(hipEventRecord(c->ev_join, s2));
+        c->tl("T chain end (s2)", s2);
+    }
     c->tl("S chain start (s3)", s3);
     const bool same_ks = hp[0]->R == hp[1]->R && hp[0]->ell_s[0] == hp[1]->ell_s[0] &&
                          (g.dim == 1 || (hp[0]->eps == hp[1]->eps && hp[0]->ell_s[1] == hp[1]->ell_s[1]));
@@ -1884,13 +1899,9 @@ static void front_half_pair(gpcsd_ctx *c, const gpcsd_hparams *const hp[2], cons
     } else {
         for (int b = 0; b < 2; ++b) build_kphi(c, g, hp[b]->R, hp[b]->eps, hp[b]->ell_s, nullptr, 0, jitter[b], Ks + b * nxx, s3, "ks_");
     }
-    // (in the one-chain form a Jacobi-sized problem would be solved by another algorithm than alone -- it rides in the large
-    // one's launches -- and lose the bits of a separate call: such a pair always takes two chains)
     // GPCSD_PAIR_CHAINS=1 (A/B): everything in ONE chain on stream2.  Measured slower than two: 1.38 against 1.18 ms per cfg3
-    // step -- with two chains the spatial one is done first (0.83 against 1.0 ms) and the log-likelihood's spatial projection
+    // step -- with two chains the spatial one is done first (0.89 against 1.0 ms) and the log-likelihood's spatial projection
     // runs under the end of the temporal one, while one chain makes everybody wait for its last launch.
-    static const bool want_one = getenv("GPCSD_PAIR_CHAINS") && getenv("GPCSD_PAIR_CHAINS")[0] == '1';
-    const bool one_chain = want_one && nx > JACOBI_LDS_MAX && nt > JACOBI_LDS_MAX;
     if (one_chain) {
         // ONE chain for all the problems (stream2; status words [0] and [2]; the temporal problem has one replica when it is
         // shared -- decomposition cache on, equal temporal hyper-parameters)
@@ -1906,15 +1917,7 @@ static void front_half_pair(gpcsd_ctx *c, const gpcsd_hparams *const hp[2], cons
         c->slot0_on_s2 = true;
         c->tl("pair chain end (s2)", s2);
     } else {
-        // two chains: the temporal problem(s) on stream2 (status words [1], [3]; one replica when the problem is shared --
-        // decomposition cache on, equal temporal hyper-parameters), two replicas of the spatial problem on stream3 (status
-        // words [0], [2])
-        {
-            ProfScope ps(c, "eigh_temporal", 9.0 * (double)nt * nt * nt * nT, s2);
-            eigh_pair_device(c, nullptr, 0, nullptr, nullptr, nullptr, Kt, nt, et, Qt, sym_t, status + 1, s2, false, nT, 2);
-        }
-        GP_HIP(hipEventRecord(c->ev_join, s2));
-        c->tl("T chain end (s2)", s2);
+        // two chains: the temporal one is queued above; two replicas of the spatial problem on stream3 (status words [0], [2])
         if (c->slot0_on_s2) c->slot0_on_s2 = false;                 // (ordered behind stream2's last chain by the wait above)
         {
             ProfScope ps(c, "eigh_spatial", 9.0 * (double)nx * nx * nx * 2, s3);
