@@ -21,6 +21,8 @@ rs = np.random.RandomState(0)
 base_ell = m.temporal_cov_list[0].params["ell"]["value"]
 base_R = m.R["value"]
 thetas = [(base_ell * rs.uniform(0.8, 1.25), base_R * rs.uniform(0.9, 1.1), bool(rs.rand() < 0.3)) for _ in range(N)]
+kinds = [(int(rs.choice([_hip.PRED_CSD, _hip.PRED_BOTH, _hip.PRED_LFP])), bool(rs.rand() < 0.7)) for _ in range(N)]   # (type, lists)
+kinds[-1] = (_hip.PRED_BOTH, True)               # the last step leaves every output buffer for the final comparison
 
 
 def hps(k):
@@ -39,9 +41,11 @@ ref_ll, ref_pred = [], None
 for k in range(N):
     h1, h0 = hps(k)
     ref_ll.append(ctx.loglik_parts(h1[0]))
-    ctx.predict_resident(h0[0], z, w["t"], _hip.PRED_CSD, want_lists=True)
+    ctx.predict_resident(h0[0], z, w["t"], kinds[k][0], want_lists=kinds[k][1])
     ctx.synchronize()
-ref_pred = ctx.fetch("pred_out_csd", shape).copy()
+C = len(m.temporal_cov_list)
+outs = [("pred_out_csd", shape), ("pred_out_lfp", shape), ("pred_out_csd_list", (C,) + shape), ("pred_out_lfp_list", (C,) + shape)]
+ref_pred = [ctx.fetch(nm, sh).copy() for nm, sh in outs]
 
 for cache in (False, True):
     ctx.decomposition_cache(cache)
@@ -54,23 +58,24 @@ for cache in (False, True):
             while outstanding:
                 got.append(ctx.loglik_parts_wait()); outstanding -= 1
             got.append(ctx.loglik_parts(h1[0]))
-            ctx.predict_resident(h0[0], z, w["t"], _hip.PRED_CSD, want_lists=True)
+            ctx.predict_resident(h0[0], z, w["t"], kinds[k][0], want_lists=kinds[k][1])
             if rs.rand() < 0.5:
                 ctx.synchronize()
         elif form == 1:                         # two queued calls
             ctx.loglik_parts_async(h1[0]); outstanding += 1
-            ctx.predict_resident(h0[0], z, w["t"], _hip.PRED_CSD, want_lists=True)
+            ctx.predict_resident(h0[0], z, w["t"], kinds[k][0], want_lists=kinds[k][1])
         else:                                   # paired call
-            ctx.loglik_predict_async(h1[0], h0[0], z, w["t"], _hip.PRED_CSD, want_lists=True); outstanding += 1
+            ctx.loglik_predict_async(h1[0], h0[0], z, w["t"], kinds[k][0], want_lists=kinds[k][1]); outstanding += 1
         while outstanding > (2 if form == 3 else 0) or outstanding >= 4:      # form 3 leaves up to two outstanding
             got.append(ctx.loglik_parts_wait()); outstanding -= 1
     while outstanding:
         got.append(ctx.loglik_parts_wait()); outstanding -= 1
-    pred = ctx.fetch("pred_out_csd", shape)
+    pred = [ctx.fetch(nm, sh) for nm, sh in outs]
+    same = all(np.array_equal(a, b) for a, b in zip(pred, ref_pred))
     bad = [k for k in range(N) if got[k] != ref_ll[k]]
-    print("%s cache=%s: %d steps, log-likelihood mismatches %d, predictions %s" % (
-        name, cache, N, len(bad), "identical" if np.array_equal(pred, ref_pred) else "DIFFER"), flush=True)
-    if bad or not np.array_equal(pred, ref_pred):
+    print("%s cache=%s: %d steps, log-likelihood mismatches %d, predictions (csd, lfp, both lists) %s" % (
+        name, cache, N, len(bad), "identical" if same else "DIFFER"), flush=True)
+    if bad or not same:
         print("first mismatches:", bad[:5])
         sys.exit(1)
 print("soak ok")
