@@ -668,6 +668,7 @@ int finish_status(gpcsd_ctx *c, const int *d_status) {
         char b[128];
         snprintf(b, sizeof(b), "numerical failure (status %d): eigensolver did not converge or matrix not positive definite", st[0]);
         c->last_error = b;
+        c->decomp_gen[0] = c->decomp_gen[1] = -1;     // a failed decomposition is never reused (a retry with the same hp re-solves)
         return st[0] > 0 ? st[0] : 1;
     }
     return 0;
@@ -1553,7 +1554,16 @@ extern "C" int gpcsd_loglik_parts_wait(gpcsd_ctx *c, double *out2) {
         char b[160];
         snprintf(b, sizeof(b), "numerical failure (status %d): eigensolver did not converge or matrix not positive definite", st[0]);
         c->last_error = b;
-        c->decomp_gen[0] = c->decomp_gen[1] = -1;
+        // The status words are sticky while asynchronous work is outstanding (nobody may clear them under a running chain).
+        // Now that a failure has been reported: drain everything and clear them, so that evaluations queued from here on
+        // start clean.  Evaluations that were ALREADY outstanding copied the words as they stood and report the failure too
+        // (a failed wait poisons the ones queued before it returned; documented in gpcsd_hip.h).
+        drain_after_failure(c);
+        if (int *dst = reinterpret_cast<int *>(c->buf<double>("scal_status", 64 + 2) + 64)) {
+            GP_HIP(hipMemsetAsync(dst, 0, 4 * sizeof(int), c->stream));
+            GP_HIP(hipStreamSynchronize(c->stream));
+            c->status_zeroed = true;
+        }
         return st[0] > 0 ? st[0] : 1;
     }
     return 0;

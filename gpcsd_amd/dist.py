@@ -10,6 +10,8 @@ import numpy as np
 
 
 class TrialSharding:
+    STAGING_RING = 4            # outstanding asynchronous all-reduces of one message size before the oldest is waited for
+
     def __init__(self, group=None, gather_predictions=False, device=None):
         import torch
         import torch.distributed as td
@@ -59,21 +61,33 @@ class TrialSharding:
             return result_cpu
         torch = self._torch
         key = values.size
+        # a small ring of staging tuples per message size: several collectives of one size may be outstanding (the docstring
+        # invites queueing work in between), and a tuple is refilled only after its previous `done` event has completed
         cache = self.__dict__.setdefault("_staging", {})
-        if key not in cache:
-            cache[key] = (torch.empty(key, dtype=torch.float64).pin_memory(), torch.empty(key, dtype=torch.float64, device=self._device),
-                          torch.cuda.Stream(device=self._device, priority=-1), torch.cuda.Event())
-        host, dev, stream, done = cache[key]
+        ring = cache.setdefault(key, {"slots": [], "next": 0, "stream": torch.cuda.Stream(device=self._device, priority=-1)})
+        if len(ring["slots"]) < self.STAGING_RING:
+            ring["slots"].append((torch.empty(key, dtype=torch.float64).pin_memory(),
+                                  torch.empty(key, dtype=torch.float64, device=self._device), torch.cuda.Event()))
+            host, dev, done = ring["slots"][-1]
+        else:
+            host, dev, done = ring["slots"][ring["next"] % self.STAGING_RING]
+            done.synchronize()          # the oldest collective of this size: its copies have landed before the block is refilled
+        ring["next"] += 1
+        stream = ring["stream"]
         host.numpy()[:] = values
         with torch.cuda.stream(stream):
             dev.copy_(host, non_blocking=True)
             self._td.all_reduce(dev, op=self._td.ReduceOp.SUM, group=self._group)      # enqueued on `stream`, returns at once
             host.copy_(dev, non_blocking=True)
             done.record(stream)
+        taken = []
 
         def result():
-            done.synchronize()
-            return host.numpy().copy()
+            # the value is copied out at the first read, behind the event: a later refill of the block cannot change it
+            if not taken:
+                done.synchronize()
+                taken.append(host.numpy().copy())
+            return taken[0]
         return result
 
     def broadcast(self, values, src=0):

@@ -35,7 +35,10 @@ class LockstepEvaluator:
         # called with the lock held; the chains that submitted are all blocked in evaluate(), so running the batch here --
         # on whichever thread completed the rendezvous -- is single-threaded with respect to the model state
         if self._pending and len(self._pending) >= self._live:
-            items = list(self._pending.items())
+            # sorted by key: the SET of keys in a batch is deterministic, the order in which the optimiser threads arrived is
+            # not -- and under trial sharding every rank all-reduces the batch element-wise, so slot b must mean the same
+            # restart on every rank (and a given restart's position must not depend on thread timing)
+            items = sorted(self._pending.items(), key=lambda kv: kv[0])
             self._pending = {}
             try:
                 res = self._fn(items)

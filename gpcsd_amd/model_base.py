@@ -226,21 +226,28 @@ class GPCSDModel:
             ll, g = float(red[0]), red[1:]
         return ll, g
 
-    def _loglik_and_grad_natural_batch(self, hps):
-        """[(loglik, gradient) or LinAlgError] for a list of hyper-parameter structs: one shared chain of launches
-        (gpcsd_loglik_grad_batch); shards combine with ONE all-reduce for the whole batch."""
+    def _eval_batch_local(self, hps):
+        """(loglik of the LOCAL trials [B], natural gradient [B, ng], status [B]) for a list of hyper-parameter structs: one
+        shared chain of launches (gpcsd_loglik_grad_batch)."""
         ctx = self._sync_device()
         ng = 1 + self.dim + 2 * len(self.temporal_cov_list) + 1
         sumlog, quad, g, st = ctx.loglik_grad_batch(hps, ng)
         r_local = self._local_lfp().shape[2]
-        ll = -0.5 * r_local * sumlog - 0.5 * quad
+        return -0.5 * r_local * sumlog - 0.5 * quad, g, st
+
+    def _loglik_and_grad_natural_batch(self, hps):
+        """[(loglik, gradient) or LinAlgError] for a list of hyper-parameter structs; shards combine with ONE all-reduce for
+        the whole batch.  Slot b of the list must mean the same hyper-parameter set on every rank (the lock-step evaluator
+        hands its batches over sorted by restart index for exactly this reason)."""
+        ll, g, st = self._eval_batch_local(hps)
+        ll, g, st = np.asarray(ll, dtype=np.float64), np.asarray(g, dtype=np.float64), np.asarray(st)
+        B, ng = g.shape
         sh = getattr(self, "_sharding", None)
         if sh is not None:                       # both pieces are additive over shards; a set that failed anywhere fails everywhere
             red = sh.allreduce_sum(np.concatenate([ll, g.ravel(), (st != 0).astype(np.float64)]))
-            B = len(hps)
             ll, g, st = red[:B], red[B:B + B * ng].reshape(B, ng), red[B + B * ng:]
         out = []
-        for b in range(len(hps)):
+        for b in range(B):
             if st[b] != 0:
                 out.append(np.linalg.LinAlgError("numerical failure in the eigensolver (hyper-parameter set %d of the batch)" % b))
             else:
@@ -405,6 +412,7 @@ class GPCSDModel:
         # (a subclass that brings its own objective is evaluated through it, one point at a time)
         cls = type(self)
         own = (cls._loglik_and_grad_natural_batch is not GPCSDModel._loglik_and_grad_natural_batch or
+               cls._eval_batch_local is not GPCSDModel._eval_batch_local or
                (cls._objective_and_grad is GPCSDModel._objective_and_grad and
                 cls._loglik_and_grad_natural is GPCSDModel._loglik_and_grad_natural))
         return (own and getattr(self, "_use_analytic_grad", True) and self._sig2n_is_scalar() and not self._uses_host_kt())

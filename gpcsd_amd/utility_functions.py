@@ -67,7 +67,8 @@ def fit_trial_shifts(evec_s, evec_t, Dvec, lfp_trials, mu_lfp, t, tau0=None, mut
     over CPU processes with joblib instead.
 
     evec_s, evec_t, Dvec: outputs of `comp_eig_D`;  lfp_trials (nx, nt, ntrials);  mu_lfp (nx, nt, nseg + 1): background in
-    [..., 0], component means in [..., 1:];  t (nt,) or (nt, 1).  Returns (tau_hat (ntrials, nseg), success, messages)."""
+    [..., 0], component means in [..., 1:];  t (nt,) or (nt, 1);  width: chains alive at a time (default min(ntrials, 128),
+    memory-capped).  Returns (tau_hat (ntrials, nseg), success, messages)."""
     import numpy as np
     import scipy.interpolate
     import scipy.optimize
@@ -94,8 +95,11 @@ def fit_trial_shifts(evec_s, evec_t, Dvec, lfp_trials, mu_lfp, t, tau0=None, mut
         # keyed by the trial: the evaluator hands every chain the value of ITS point of the batch
         return scipy.optimize.minimize(lambda tau: evaluate(np.array(tau, copy=True)), tau0, method="l-bfgs-b",
                                        options=options or {})
-    out, _ev = run_chains(list(range(ntrials)), chain, lambda items: batch_fn([(k, x) for k, x in items]),
-                          width or ntrials)
+    if width is None:
+        # one OS thread and one (nx, nt) residual per live chain: at most 128 chains, within a 1 GiB budget for the batch's
+        # residuals; the remaining trials wait in run_chains' queue and take the slot of a chain that converges
+        width = int(max(1, min(ntrials, 128, (1 << 30) // max(8 * nx * nt, 1))))
+    out, _ev = run_chains(list(range(ntrials)), chain, lambda items: batch_fn([(k, x) for k, x in items]), width)
     for r in out.values():
         if isinstance(r, Exception):
             raise r

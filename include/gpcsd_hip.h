@@ -176,7 +176,10 @@ int gpcsd_loglik_parts(gpcsd_ctx *ctx, const gpcsd_hparams *hp, double *out2);
  * four evaluations may be outstanding per context (rc -3 beyond that); _wait collects them oldest first.  hp is read during
  * the _async call only.  rc > 0 from _wait:
  * numerical failure of this evaluation or of an earlier asynchronous call nobody has collected yet (status is sticky until
- * a synchronising call -- gpcsd_device_synchronize, any call that returns values -- has reported it). */
+ * a synchronising call -- gpcsd_device_synchronize, any call that returns values -- has reported it).  A _wait that reports
+ * a failure drains the context and clears the status, so evaluations queued AFTER it returned start clean; evaluations that
+ * were already outstanding copied the status as it stood and report the failure too (a failed wait poisons those), and
+ * the decomposition cache forgets both sides (a retry with the same hp re-solves). */
 int gpcsd_loglik_parts_async(gpcsd_ctx *ctx, const gpcsd_hparams *hp);
 int gpcsd_loglik_parts_wait(gpcsd_ctx *ctx, double *out2);
 /* gpcsd_loglik_parts_async(hp_loglik) followed by gpcsd_predict_resident(hp_predict, ...) as ONE queued call: same results

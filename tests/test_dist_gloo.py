@@ -261,6 +261,100 @@ def test_fit_with_unseeded_ranks_is_synchronised_world2():
 
 
 # ---------------------------------------------------------------------------------------------------------------------
+# fit(batch=k) under trial sharding goes through the REAL lock-step batch path: the whole batch's partial sums travel in one
+# element-wise all-reduce, so slot b must be the same restart on every rank (the batch used to come out in
+# thread-arrival order, which differs between ranks and between runs).
+# ---------------------------------------------------------------------------------------------------------------------
+def _batched_oracle_model(seed):
+    m, cls = _oracle_backed_model(seed)
+    from oracle import gpcsd_oracle as O
+    geom = O.Geometry1D(m.x, m.t, a=0.0, b=1100.0, ngl=30)
+
+    class BatchedOracle(cls):
+        """The per-rank device evaluation of a batch is the oracle on the local block of trials; hyper-parameter structs
+        are natural-parameter vectors (no device context on the CPU)."""
+        batch_orders = []
+
+        def _hparams(self, jitter, tstar=None):
+            tc = self.temporal_cov_list[0]
+            return np.array([self.R["value"], self.spatial_cov.params["ell"]["value"], tc.params["ell"]["value"],
+                             tc.params["sigma2"]["value"], self.sig2n["value"]], dtype=np.float64), None
+
+        def _local_ll_grad(self, v0):
+            local = self._local_lfp()
+            ll = O.loglik(geom, self._natural_hp(v0), local)
+            g = np.zeros(5)
+            for i in range(5):
+                h = 1e-6 * abs(v0[i])
+                vp, vm = v0.copy(), v0.copy()
+                vp[i] += h
+                vm[i] -= h
+                g[i] = (O.loglik(geom, self._natural_hp(vp), local) - O.loglik(geom, self._natural_hp(vm), local)) / (2 * h)
+            return ll, g
+
+        def _eval_batch_local(self, hps):
+            res = [self._local_ll_grad(v) for v in hps]
+            return np.array([r[0] for r in res]), np.stack([r[1] for r in res]), np.zeros(len(hps))
+
+        def _loglik_and_grad_natural(self):          # batch=1 path: the same numbers, one point at a time
+            ll, g = self._local_ll_grad(self._hparams(0.0)[0])
+            sh = getattr(self, "_sharding", None)
+            if sh is not None:
+                red = sh.allreduce_sum(np.concatenate([[ll], g]))
+                ll, g = float(red[0]), red[1:]
+            return ll, g
+
+        def _objective_and_grad_batch(self, items, fix_R):
+            BatchedOracle.batch_orders.append([k for k, _ in items])
+            return super()._objective_and_grad_batch(items, fix_R)
+
+    m.__class__ = BatchedOracle
+    return m, BatchedOracle
+
+
+def _batched_fit_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as td
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    td.init_process_group("gloo", rank=rank, world_size=world)
+    from gpcsd_amd.dist import TrialSharding
+    out = []
+    for batch in (None, 1):
+        m, cls = _batched_oracle_model(seed=7)
+        assert m._batch_can_evaluate()
+        m.shard_trials(TrialSharding())
+        np.random.seed(11)
+        m.fit(n_restarts=5, batch=batch, options={"maxiter": 5, "disp": False, "gtol": 1e-5, "ftol": 1e-9})
+        out.append((np.asarray(m.fit_nll_values_).tolist(), [p.tolist() for p in m.fit_params_],
+                    getattr(m, "fit_batches_", None), list(cls.batch_orders)))
+    q.put((rank, out))
+    td.destroy_process_group()
+
+
+@pytest.mark.timeout(900)
+def test_fit_lockstep_batch_under_trial_sharding_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_batched_fit_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=800) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, (b0, s0)), (_, (b1, s1)) = res
+    # the lock-step run really batched, in sorted slot order, identically on both ranks
+    assert b0[2] is not None and b0[2][1] > b0[2][0]
+    assert all(o == sorted(o) for o in b0[3]) and b0[3] == b1[3]
+    # both ranks end with identical optima ...
+    assert b0[0] == b1[0] and b0[1] == b1[1]
+    # ... and they are the optima of the one-after-the-other loop, bit for bit (the batch adds the same numbers slot by slot)
+    assert b0[0] == s0[0] and b0[1] == s0[1] and s0[0] == s1[0]
+
+
+# ---------------------------------------------------------------------------------------------------------------------
 # the same sharding layer over the HIP path: two ranks share the one GPU of the test box (gloo for the tiny collectives)
 # ---------------------------------------------------------------------------------------------------------------------
 def _gpu_shard_worker(rank, world, port, q, case="1d_odd_17x37x5"):

@@ -1,0 +1,331 @@
+"""GPU parity of GPCSD2D.fit() and of the 2D analytic gradient on the production path (-m gpu).
+
+north_star names GPCSD2D.fit(); the reference's own callers are neuropixels/fit_gpcsd2d.py:101 and
+simulation_studies/sim_from_gp_2D.py:133.  The reference's fit cannot run here (it needs autograd), so the
+checker is SciPy's L-BFGS-B on the ORACLE objective (central differences for its gradient), from the same starts.
+
+  * gradient vs central differences of the oracle where both sides go through the symmetry-folded sytrd + divide & conquer
+    eigensolver and the Kronecker Ks assembly: 192 x 200 (96 / 100-row halves) and 384 x 500 (192 / 250-row halves) --
+    the 48 x 40 golden case of test_hip_parity stays inside the <= 64-row Jacobi path;
+  * fit() end to end: explicit starts, prior-drawn starts (seeded; the draw order of gpcsd2d.py:223-238 is restated here),
+    fix_R=True, verbose=True, profile=True;
+  * a start whose factorisation fails: objective +inf (gpcsd2d.py:213-218), restart skipped (gpcsd2d.py:249-260).
+"""
+import numpy as np
+import pytest
+import scipy.optimize
+
+import cases as C
+from helpers import load_model_case
+from oracle import gpcsd_oracle as O
+
+pytestmark = pytest.mark.gpu
+GATE = 1e-6
+JITTER_2D = 1e-7                                        # gpcsd2d.py:16
+OPTS = {"maxiter": 8, "disp": False, "gtol": 1e-5, "ftol": 1e7 * np.finfo(float).eps}
+
+
+def _draw_from_model(geom, hp, ntrials, seed, noise_var):
+    """(nx, nt, R) data with the model's own structure (unit standard deviation + white noise), so that the optimiser has
+    something to find."""
+    rs = np.random.RandomState(seed)
+    es, Qs = np.linalg.eigh(O.spatial_kphi(geom, hp))
+    et, Qt = np.linalg.eigh(O.temporal_sum(hp["temporal"], geom.t))
+    Ls, Lt = Qs * np.sqrt(np.maximum(es, 0.0)), Qt * np.sqrt(np.maximum(et, 0.0))
+    nx, nt = Ls.shape[0], Lt.shape[0]
+    Y = np.matmul(np.matmul(Ls, rs.standard_normal((ntrials, nx, nt))), Lt.T)
+    Y = Y / Y.std() + np.sqrt(noise_var) * rs.standard_normal(Y.shape)
+    return np.ascontiguousarray(np.moveaxis(Y, 0, 2))
+
+
+def _model_2d(x, t, ngl1, ngl2, eps, lfp, R, ell_s, temporal, sig2n):
+    from gpcsd_amd.gpcsd2d import GPCSD2D
+    from gpcsd_amd.covariances import GPCSDTemporalCovSE, GPCSDTemporalCovMatern
+    np.random.seed(0)
+    tcl = []
+    for kind, ell, s2 in temporal:
+        tc = GPCSDTemporalCovSE(t) if kind == C.SE else GPCSDTemporalCovMatern(t)
+        tc.params["ell"]["value"], tc.params["sigma2"]["value"] = float(ell), float(s2)
+        tcl.append(tc)
+    m = GPCSD2D(lfp, x, t, ngl1=ngl1, ngl2=ngl2, temporal_cov_list=tcl, eps=eps)
+    m.spatial_cov.params["ell1"]["value"], m.spatial_cov.params["ell2"]["value"] = ell_s
+    m.R["value"] = R
+    m.sig2n["value"] = sig2n
+    return m
+
+
+def _case_2d(name, ntrials=None, structured=True, seed=77):
+    """(model, oracle geometry, lfp, kinds, eps) of a golden 2D case (its geometry and hyper-parameters; optionally data drawn
+    from the model instead of the fixture's white noise)."""
+    c, g, geom, hp, lfp = load_model_case(name)
+    if structured:
+        lfp = _draw_from_model(geom, hp, ntrials or c["R_trials"], seed, 0.05)
+    m = _model_2d(c["x"], c["t"], c["ngl1"], c["ngl2"], c["eps"], lfp, c["R"], c["ell_s"], hp["temporal"], c["sig2n"])
+    return m, geom, lfp, [k for k, _, _ in hp["temporal"]], c["eps"]
+
+
+def _npx_case(nchan, nt, ntrials, seed=31):
+    """An ad-hoc Neuropixels-shaped case between the golden sizes: nchan channels x nt samples at 2.5 kHz."""
+    x, t = C.neuropixels_xy(nchan), 0.4 * np.arange(float(nt))[:, None]
+    geom = O.Geometry2D(x, t, ngl1=12, ngl2=40)
+    hp = O.make_hparams(100.0, (40.0, 150.0), [(O.SE, 20.0, 1.0), (O.MATERN, 5.0, 1.0)], 0.05, eps=80.0)
+    scale = float(np.mean(np.diag(O.spatial_kphi(geom, hp))))           # temporal variances relative to mean diag(Ks)
+    temporal = [(O.SE, 20.0, 0.5 / scale), (O.MATERN, 5.0, 0.7 / scale)]
+    hp = O.make_hparams(100.0, (40.0, 150.0), temporal, 0.05, eps=80.0)
+    lfp = _draw_from_model(geom, hp, ntrials, seed, 0.05)
+    m = _model_2d(x, t, 12, 40, 80.0, lfp, 100.0, (40.0, 150.0), temporal, 0.05)
+    return m, geom, lfp, [O.SE, O.MATERN], 80.0
+
+
+def _cpu_objective_2d(m, geom, lfp, kinds, eps, n_sig=1, R_fixed=None):
+    """-(oracle loglik + log prior) over the log-parameter vector of gpcsd2d.py:196-211, and its central-difference
+    gradient.  The priors are the model's own objects (priors.py is host arithmetic on both sides)."""
+    def lp_of(hp):
+        lp = m.R["prior"].lpdf(hp["R"])
+        lp += m.spatial_cov.params["ell1"]["prior"].lpdf(hp["ell_s"][0]) + m.spatial_cov.params["ell2"]["prior"].lpdf(hp["ell_s"][1])
+        for tc, (_, ell, s2) in zip(m.temporal_cov_list, hp["temporal"]):
+            lp += tc.params["ell"]["prior"].lpdf(ell) + tc.params["sigma2"]["prior"].lpdf(s2)
+        if n_sig == 1:
+            return lp + m.sig2n["prior"].lpdf(hp["sig2n"])
+        return lp + sum(pr.lpdf(v) for pr, v in zip(m.sig2n["prior"], hp["sig2n"]))
+
+    def f(tp):
+        hp = O.hparams_from_tparams(tp, 2, kinds, n_sig, eps=eps, jitter=JITTER_2D, R_fixed=R_fixed)
+        return -(O.loglik(geom, hp, lfp) + lp_of(hp))
+
+    def fg(tp, h=1e-5, only=None):
+        g = np.zeros_like(tp)
+        for i in (range(tp.size) if only is None else only):
+            if i == 0 and R_fixed is not None:
+                continue
+            e = np.zeros_like(tp)
+            e[i] = h
+            g[i] = (f(tp + e) - f(tp - e)) / (2 * h)
+        return f(tp), g
+    return f, fg
+
+
+def _folded_calls(m):
+    return m._sync_device().fold_gemm(None)
+
+
+# ------------------------------------------------------------------------------------------------ gradient
+@pytest.mark.parametrize("shape", ["npx_192x200x2", "cfg3s_384x500x2", "npx_96x120x3"])
+def test_2d_gradient_on_the_folded_dc_path_vs_oracle_finite_differences(shape):
+    """Objective and gradient of GPCSD2D's fit (log-parameters, priors included) against the oracle's objective and its central
+    differences, at sizes where Ks (Kronecker assembly forward, flat Kgl in the gradient) and Kt are decomposed through the
+    folded sytrd + D&C chain and the folded parity-block Ghat rotations of DESIGN 4.5."""
+    if shape == "npx_192x200x2":
+        m, geom, lfp, kinds, eps = _npx_case(192, 200, 2)
+    elif shape == "cfg3s_384x500x2":
+        m, geom, lfp, kinds, eps = _case_2d("cfg3s_2d_384x500x2", structured=True)
+    else:
+        m, geom, lfp, kinds, eps = _case_2d("2d_npx_96x120x3", structured=False)
+    f, fg = _cpu_objective_2d(m, geom, lfp, kinds, eps)
+    tp = m._current_tparams()
+    calls0 = _folded_calls(m)
+    val, grad = m._objective_and_grad(tp, False)
+    assert _folded_calls(m) > calls0                     # the folded-basis path is the one that ran
+    fval, fgrad = fg(tp)
+    assert abs(val - fval) / abs(fval) < 1e-9
+    err = np.max(np.abs(grad - fgrad)) / np.max(np.abs(fgrad))
+    print("2D %s gradient vs oracle central differences: %.2e of the largest component; grad %s" % (shape, err, grad))
+    assert err < 2e-5, (grad, fgrad)
+    # a second point away from the generating hyper-parameters (every parameter moved, R and eps-coupled terms included)
+    tp2 = tp + 0.2 * np.array([1, -1, 1, -1, 1, 1, -1, 1.0])
+    val2, grad2 = m._objective_and_grad(tp2, False)
+    fval2, fgrad2 = fg(tp2)
+    assert abs(val2 - fval2) / abs(fval2) < 1e-9
+    assert np.max(np.abs(grad2 - fgrad2)) / np.max(np.abs(fgrad2)) < 2e-5, (grad2, fgrad2)
+    # fix_R: the R entry is held (gpcsd2d.py:196-197), the others unchanged
+    val3, grad3 = m._objective_and_grad(tp2, True)
+    assert grad3[0] == 0.0 and np.array_equal(grad3[1:], grad2[1:])
+
+
+def test_2d_gradient_with_per_electrode_noise_list_vs_oracle():
+    """GPCSD2D with a per-electrode noise list (gpcsd2d.py:72-79, indexed by eigen-RANK as utility_functions.py:54-63): 192 + 7
+    gradient entries, the spatial ones with the eigenvector-rotation term, against central differences of the oracle.  192
+    channels x 100 samples: 96-row spatial halves through sytrd + D&C, merged eigen-order on the unfolded GEMM path.
+    The hyper-parameters keep Ks full rank (short length scales, narrow forward model): where Ks is numerically
+    rank-deficient the ranks of its rounding-noise eigenvalues -- and with them the reference's noise assignment -- depend on
+    the LAPACK driver ('noise lists'), and no gradient is defined to better than that."""
+    from gpcsd_amd.priors import GPCSDHalfNormalPrior
+    nx = 192
+    x, t = C.neuropixels_xy(nx), 0.4 * np.arange(100.0)[:, None]
+    geom = O.Geometry2D(x, t, ngl1=16, ngl2=120)
+    R, eps, ell_s = 10.0, 5.0, (10.0, 12.0)
+    hp = O.make_hparams(R, ell_s, [(O.SE, 20.0, 1.0), (O.MATERN, 5.0, 1.0)], 0.05, eps=eps)
+    Ks = O.spatial_kphi(geom, hp)
+    w = np.linalg.eigvalsh(Ks)
+    assert w[0] > 1e-8 * w[-1]                           # full rank: eigen-ranks are well defined
+    scale = float(np.mean(np.diag(Ks)))
+    temporal = [(O.SE, 20.0, 0.5 / scale), (O.MATERN, 5.0, 0.7 / scale)]
+    hp = O.make_hparams(R, ell_s, temporal, 0.05, eps=eps)
+    lfp = _draw_from_model(geom, hp, 3, 5, 0.05)
+    m = _model_2d(x, t, 16, 120, eps, lfp, R, ell_s, temporal, 0.05)
+    sig = np.linspace(0.02, 0.3, nx)
+    m.sig2n = {"value": sig.copy(), "prior": [GPCSDHalfNormalPrior(1.0) for _ in range(nx)], "min": [1e-8] * nx, "max": [10.0] * nx}
+    f, fg = _cpu_objective_2d(m, geom, lfp, [O.SE, O.MATERN], eps, n_sig=nx)
+    tp = m._current_tparams()
+    assert tp.shape == (7 + nx,)
+    val, grad = m._objective_and_grad(tp, False)
+    only = list(range(7)) + [7, 8, 7 + nx // 2, 7 + nx - 2, 7 + nx - 1]
+    fval, fgrad = fg(tp, only=only)
+    assert abs(val - fval) / abs(fval) < 1e-8
+    err = np.max(np.abs(grad[only] - fgrad[only])) / np.max(np.abs(fgrad[only]))
+    print("2D noise-list gradient vs oracle central differences: %.2e of the largest component" % err)
+    assert err < 1e-5, (grad[only], fgrad[only])
+    # ... and a truncated fit with the list (one restart, 4 iterations) lands where SciPy on the oracle objective lands
+    s0 = tp + 0.05 * np.cos(np.arange(tp.size))
+    opts = dict(OPTS, maxiter=4)
+    m.fit(n_restarts=1, options=opts, starts=[s0])
+    got = float(m.fit_nll_values_[0])
+    at_opt = f(np.asarray(m.fit_params_[0]))
+    assert got < f(s0) and abs(at_opt - got) / abs(at_opt) < 1e-7
+    assert np.shape(m.sig2n["value"]) == (nx,)
+
+
+# ------------------------------------------------------------------------------------------------ fit
+@pytest.mark.parametrize("name,ntrials,batch", [("2d_grid_48x40x2", 4, None), ("2d_npx_96x120x3", 4, None), ("2d_npx_96x120x3", 4, 1)])
+def test_gpcsd2d_fit_two_restarts_vs_scipy_on_oracle(name, ntrials, batch):
+    """GPCSD2D.fit() (gpcsd2d.py:153-287) through the HIP objective + analytic gradient: 2 restarts x <= 8 iterations against
+    SciPy L-BFGS-B on the oracle objective from the same starts; lock-step batch (the default) and the reference's
+    one-after-the-other loop."""
+    m, geom, lfp, kinds, eps = _case_2d(name, ntrials=ntrials)
+    f, fg = _cpu_objective_2d(m, geom, lfp, kinds, eps)
+    tp0 = m._current_tparams()
+    assert tp0.shape == (8,)
+    starts = [tp0 + 0.15 * np.array([1, -1, 1, 1, -1, 1, -1, 1.0]), tp0 - 0.1 * np.array([1, 1, -1, -1, 1, -1, 1, 1.0])]
+    nll_start = [f(s0) for s0 in starts]
+    m.fit(n_restarts=2, options=OPTS, starts=starts, batch=batch)
+    got = np.asarray(m.fit_nll_values_)
+    assert got.shape == (2,) and np.all(got < np.asarray(nll_start))
+    for k in range(2):                                   # the value reported at the optimum is the oracle's objective there
+        at_opt = f(np.asarray(m.fit_params_[k]))
+        assert abs(at_opt - got[k]) / abs(at_opt) < 1e-8, (k, at_opt, got[k])
+    ref = [scipy.optimize.minimize(fg, s0, jac=True, method="L-BFGS-B", bounds=m._bounds(), options=OPTS) for s0 in starts]
+    dev = np.abs(got - np.array([r.fun for r in ref])) / np.abs([r.fun for r in ref])
+    print("2D fit %s batch=%s: nll GPU %s  SciPy-on-oracle %s  rel dev %s" % (name, batch, got, [r.fun for r in ref], dev))
+    assert np.all(dev < 2e-3)
+    # the model holds the best restart's hyper-parameters, written back as gpcsd2d.py:273-287 does
+    best = np.asarray(m.fit_params_[int(np.argmin(got))])
+    assert np.isclose(m.R["value"], np.exp(best[0]) * 100) and np.isclose(m.spatial_cov.params["ell1"]["value"], np.exp(best[1]) * 100)
+    assert np.isclose(m.spatial_cov.params["ell2"]["value"], np.exp(best[2]) * 100)
+    assert np.isclose(m.temporal_cov_list[1].params["sigma2"]["value"], np.exp(best[6])) and np.isclose(m.sig2n["value"], np.exp(best[7]))
+    assert m.R["min"] <= m.R["value"] <= m.R["max"]
+    if batch is None:
+        nb, npts = m.fit_batches_
+        assert npts > nb                                 # evaluations really were served two at a time
+
+
+def test_gpcsd2d_fit_on_the_cfg3_geometry_vs_scipy_on_oracle():
+    """One restart x 3 iterations at 384 x 500 (the folded sytrd + D&C path) against SciPy on the oracle objective."""
+    m, geom, lfp, kinds, eps = _case_2d("cfg3s_2d_384x500x2", structured=True)
+    f, fg = _cpu_objective_2d(m, geom, lfp, kinds, eps)
+    s0 = m._current_tparams() + 0.1 * np.array([1, -1, 1, 1, -1, 1, -1, 1.0])
+    opts = dict(OPTS, maxiter=3)
+    m.fit(n_restarts=1, options=opts, starts=[s0])
+    got = float(m.fit_nll_values_[0])
+    assert got < f(s0)
+    at_opt = f(np.asarray(m.fit_params_[0]))
+    assert abs(at_opt - got) / abs(at_opt) < 1e-8
+    ref = scipy.optimize.minimize(fg, s0, jac=True, method="L-BFGS-B", bounds=m._bounds(), options=opts)
+    print("2D fit cfg3 geometry: nll GPU %.6f  SciPy-on-oracle %.6f" % (got, ref.fun))
+    assert abs(got - ref.fun) / abs(ref.fun) < 2e-3
+
+
+def _reference_draw_order(m, fix_R):
+    """Starting point of one restart, drawn in the order of gpcsd2d.py:223-238."""
+    tp = [np.log(m.R["value"]) - np.log(100) if fix_R else np.log(m.R["prior"].sample()) - np.log(100)]
+    tp.append(np.log(m.spatial_cov.params["ell1"]["prior"].sample()) - np.log(100))
+    tp.append(np.log(m.spatial_cov.params["ell2"]["prior"].sample()) - np.log(100))
+    for tc in m.temporal_cov_list:
+        tp.append(np.log(tc.params["ell"]["prior"].sample()))
+        tp.append(np.log(tc.params["sigma2"]["prior"].sample()))
+    tp.append(np.log(m.sig2n["prior"].sample()))
+    return np.array(tp)
+
+
+@pytest.mark.parametrize("fix_R", [False, True])
+def test_gpcsd2d_fit_prior_drawn_starts_fix_R_and_verbose(fix_R, capsys):
+    """starts=None: restarts start at prior draws consumed from NumPy's global stream in the reference's order; fix_R=True holds
+    R at its current value (gpcsd2d.py:196-197, 224-225, 273-274); verbose=True prints the reference's summary."""
+    m, geom, lfp, kinds, eps = _case_2d("2d_grid_48x40x2", ntrials=4)
+    # HalfNormal(1) draws of the temporal variances are ~1e8 x the data's scale on this geometry (Ks is O(1e8)); give the
+    # variances priors at the data's scale so that prior-drawn starts are meaningful for a truncated fit
+    from gpcsd_amd.priors import GPCSDHalfNormalPrior
+    for tc in m.temporal_cov_list:
+        tc.params["sigma2"]["prior"] = GPCSDHalfNormalPrior(2.0 * tc.params["sigma2"]["value"])
+    R_before = m.R["value"]
+    np.random.seed(123)
+    expect = [_reference_draw_order(m, fix_R) for _ in range(2)]
+    np.random.seed(123)
+    m.fit(n_restarts=2, fix_R=fix_R, verbose=True, options=OPTS)
+    out = capsys.readouterr().out
+    assert "Neg log lik values across different initializations:" in out and "Best index termination message" in out
+    assert np.array_equal(np.array(m.fit_starts_), np.array(expect))
+    f, fg = _cpu_objective_2d(m, geom, lfp, kinds, eps, R_fixed=R_before if fix_R else None)
+    got = np.asarray(m.fit_nll_values_)
+    ref = np.array([scipy.optimize.minimize(fg, s0, jac=True, method="L-BFGS-B", bounds=m._bounds(), options=OPTS).fun for s0 in expect])
+    assert got.shape == (2,) and np.all(np.isfinite(got)) and np.all(np.isfinite(ref))
+    dev = np.abs(got - ref) / np.abs(ref)
+    print("2D fit prior-drawn starts fix_R=%s: nll GPU %s  SciPy-on-oracle %s" % (fix_R, got, ref))
+    assert np.all(dev < 5e-3)
+    if fix_R:
+        assert m.R["value"] == R_before
+        assert all(p[0] == e[0] for p, e in zip(m.fit_params_, expect))       # zero gradient entry: R's slot never moves
+    else:
+        assert m.R["value"] != R_before
+
+
+def test_gpcsd2d_fit_profile_returns_the_per_kernel_table():
+    """profile=True (the reference cProfiles one objective and one gradient evaluation and returns, gpcsd2d.py:241-246): here
+    the per-kernel device times of one objective and one objective + gradient evaluation."""
+    m, geom, lfp, kinds, eps = _case_2d("2d_npx_96x120x3", ntrials=3)
+    before = m.extract_model_params()
+    np.random.seed(5)
+    tab = m.fit(n_restarts=3, profile=True)
+    assert set(tab) == {"objective", "gradient"}
+    for part in ("objective", "gradient"):
+        assert len(tab[part]) > 0
+        assert all(v["count"] >= 1 and v["ms"] >= 0.0 for v in tab[part].values())
+    assert any("eigh" in k for k in tab["objective"]) and any("gemm" in k for k in tab["gradient"])
+    assert not hasattr(m, "fit_nll_values_")             # nothing was optimised
+    assert m.extract_model_params()["eps"] == before["eps"]
+
+
+# ------------------------------------------------------------------------------------------------ failing factorisation
+@pytest.mark.parametrize("batch", [None, 1])
+def test_gpcsd2d_failed_factorisation_is_plus_inf_and_the_restart_is_skipped(batch, capsys):
+    """gpcsd2d.py:213-218: a LinAlgError inside loglik makes the objective +inf; gpcsd2d.py:249-260: a restart whose optimiser
+    raises is reported and skipped, the others decide the result."""
+    m, geom, lfp, kinds, eps = _case_2d("2d_npx_96x120x3", ntrials=3)
+    tp0 = m._current_tparams()
+    good = [tp0 + 0.1 * np.array([1, -1, 1, 1, -1, 1, -1, 1.0]), tp0 - 0.1 * np.array([1, 1, -1, -1, 1, -1, 1, 1.0])]
+    bad = tp0.copy()
+    bad[4] = 710.0                                       # exp() overflows: the SE variance is inf, Kt is not finite
+    assert m._bounds()[4][1] == np.inf                   # (the reference leaves sigma2 unbounded above, covariances.py:254)
+    assert m._objective(bad, False) == np.inf
+    with pytest.raises(np.linalg.LinAlgError):
+        m._objective_and_grad(bad, False)
+    f, fg = _cpu_objective_2d(m, geom, lfp, kinds, eps)
+    m.fit(n_restarts=3, options=OPTS, starts=[good[0], bad, good[1]], batch=batch)
+    out = capsys.readouterr().out
+    assert "restarting optimization..." in out
+    got = np.asarray(m.fit_nll_values_)
+    assert got.shape == (2,) and np.all(np.isfinite(got))
+    ref = [scipy.optimize.minimize(fg, s0, jac=True, method="L-BFGS-B", bounds=m._bounds(), options=OPTS).fun for s0 in good]
+    assert np.all(np.abs(got - np.asarray(ref)) / np.abs(ref) < 2e-3)
+    # the context is clean afterwards: the next evaluation is the oracle's value again
+    val = m._objective(good[0], False)
+    assert abs(val - f(good[0])) / abs(val) < 1e-9
+    # every restart failing: "problem with optimization!", hyper-parameters left alone
+    keep = m.extract_model_params()
+    m.eps = float("nan")                                 # eps is not optimised: every evaluation now fails
+    assert m._objective(good[0], False) == np.inf
+    m.eps = keep["eps"]
+    m.restore_model_params(keep)
+    m2, *_ = _case_2d("2d_npx_96x120x3", ntrials=3)
+    m2.eps = float("nan")
+    assert m2.fit(n_restarts=2, options=OPTS, starts=good, batch=batch) is None
+    assert "problem with optimization!" in capsys.readouterr().out
