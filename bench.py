@@ -12,13 +12,19 @@ predict(z = electrodes, t, type="csd") of every resident trial, inputs resident 
         bench.py --gpus N --steps K --warmup W
     python bench.py --workload cfg2          # GPCSD1D 24 x 500 x 200 trials (BASELINE configs[1]), same step
     python bench.py --workload cfg5          # GPCSD1D fit: restarts evaluated in lock-step batches (BASELINE configs[4])
+    python bench.py --only-value             # setup + warm-up + timed loop and nothing else: the command the rocprofv3 kernel
+                                             # stats / PMC passes under profiles/ are taken over (tools/profile_r03.sh)
+The default cfg3 line at N=1 also carries compact cfg2 and cfg5 sub-results (`sub_results`, a few seconds) so that the driver's
+record holds them; --no-sub-results skips them.
 
 Rank 0 prints ONE JSON line.
   roofline      step level, as SURVEY 8(d) specifies: flops per step / ms_per_step against the fp64 MFMA peak, once in flops
                 actually launched (folded basis, symmetry-folded eigensolver) and once in flops of the reference's algorithm;
                 beside it the kernel with the largest share of GPU time (the single-workgroup tridiagonalisation tail) with
                 its own launch time, rate and CU occupancy, and the largest GEMM launch.  Launch times are HIP events on the
-                library's own streams in a separate profiled pass of the same step.
+                library's own streams around the kernels of the SAME paired, queued step the timed loop runs (asynchronous
+                scopes, gpcsd_prof_enable mode 2: chains launched eagerly so that the scopes inside them record; mode 3: chains
+                replayed as hipGraphs as in the timed loop, chain-level scopes).
   cpu_baseline  the NumPy oracle (a port: the Python reference cannot travel to the GPU box) on the SAME number of trials
                 as the GPU step, BLAS threads swept, >= 20 loglik / >= 3 predict repetitions at the best setting, plus the
                 single-thread figure and the reference's strided per-trial layout priced next to the contiguous one.
@@ -198,21 +204,26 @@ def cpu_baseline(w, m, lfp, budget_s=45.0):
             ll_ts += more
         pr_ts, pred = t_predict(3)
     with threadpool_limits(limits=1):
-        ll1_ts, _ = t_loglik(2 if time.perf_counter() - t_begin < 0.7 * budget_s else 1)
-        pr1_ts, _ = t_predict(1)
-    # the reference projects trial by trial on strided slices lfp[:, :, r] (gpcsd2d.py:147-148); the oracle uses contiguous
-    # trials and one batched matmul (the "fair" flavour of SURVEY 8(d)).  Price the reference's access pattern too
-    # (bounded: at most 8 trials, scaled).
+        ll1_ts, _ = t_loglik(3 if time.perf_counter() - t_begin < 0.7 * budget_s else 1)
+        pr1_ts, _ = t_predict(2 if time.perf_counter() - t_begin < 0.8 * budget_s else 1)
+    # The reference projects trial by trial on strided slices lfp[:, :, r] of the (nx, nt, R) array (gpcsd2d.py:147-148); the
+    # oracle uses contiguous trials and one batched matmul (the "fair" flavour of SURVEY 8(d)).  The reference's loglik is
+    # timed directly, piece by piece, in its own order: covariance assembly, comp_eig_D, then its per-trial loop on at most 8
+    # trials (scaled to R; the loop is R independent, identical iterations).
     nxs = lfp.shape[0]
-    Ks = O.spatial_kphi(geom, hp) + hp["jitter"] * np.eye(nxs)
-    Kt = O.temporal_sum(hp["temporal"], geom.t)
     with threadpool_limits(limits=best):
+        t0 = time.perf_counter()
+        Ks = O.spatial_kphi(geom, hp) + hp["jitter"] * np.eye(nxs)
+        Kt = O.temporal_sum(hp["temporal"], geom.t)
+        t_assembly = time.perf_counter() - t0
         t0 = time.perf_counter()
         Qs, Qt, D = O.eig_D(Ks, Kt, hp["sig2n"])
         t_eig = time.perf_counter() - t0
         nf = min(8, R)
-        t0 = time.perf_counter()
         quad = 0.0
+        for r in range(min(2, nf)):                                # warm the strided access path
+            alpha = np.reshape(np.dot(np.dot(Qs.T, lfp[:, :, r]), Qt), (nxs * lfp.shape[1]))
+        t0 = time.perf_counter()
         for r in range(nf):
             alpha = np.reshape(np.dot(np.dot(Qs.T, lfp[:, :, r]), Qt), (nxs * lfp.shape[1]))
             quad += np.sum(np.square(alpha) / D)
@@ -225,70 +236,71 @@ def cpu_baseline(w, m, lfp, budget_s=45.0):
         contiguous_ms = (time.perf_counter() - t0) * 1e3 / nf
     med = lambda v: float(np.median(v))
     t_ll, t_pr = med(ll_ts), med(pr_ts)
-    faithful_ll_s = med(ll_ts) - R * contiguous_ms * 1e-3 + R * strided_ms * 1e-3
+    faithful_ll_s = t_assembly + t_eig + R * strided_ms * 1e-3
+    host_cpus = os.cpu_count() or affinity
     rep = {
-        "value": R / (t_ll + t_pr), "unit": "trials/s", "cores": int(best), "kind": "port",
+        "value": R / (t_ll + t_pr), "unit": "trials/s", "cores": int(best), "blas_threads": int(best), "host_cpus": int(host_cpus),
+        "kind": "port",
         "sample": "oracle loglik x%d + predict(csd) x%d on the bench's own %d trials at the bench geometry (median times; "
-                  "NumPy %s; BLAS threads: best of sweep %s = %d; host affinity %d cpus, BLAS max %d)"
-                  % (len(ll_ts), len(pr_ts), R, np.__version__, sorted(sweep), best, affinity, blas_max),
+                  "NumPy %s; `cores` = BLAS threads actually used: best of sweep %s = %d; host has %d cpus, affinity %d, BLAS "
+                  "max %d)" % (len(ll_ts), len(pr_ts), R, np.__version__, sorted(sweep), best, host_cpus, affinity, blas_max),
         "loglik_evals_per_sec": 1.0 / t_ll, "predict_trials_per_sec": R / t_pr,
         "single_thread": {"value": R / (med(ll1_ts) + med(pr1_ts)), "loglik_evals_per_sec": 1.0 / med(ll1_ts),
                           "predict_trials_per_sec": R / med(pr1_ts), "reps": [len(ll1_ts), len(pr1_ts)]},
         "thread_sweep_loglik_s": {str(k): v for k, v in sorted(sweep.items())},
-        "faithful_layout": {"loglik_evals_per_sec": 1.0 / max(faithful_ll_s, 1e-9),
+        "faithful_layout": {"loglik_evals_per_sec": 1.0 / faithful_ll_s, "loglik_s": faithful_ll_s,
+                            "assembly_s": t_assembly, "eig_pair_s": t_eig,
                             "projection_ms_per_trial_reference_layout": strided_ms,
-                            "projection_ms_per_trial_contiguous": contiguous_ms, "eig_pair_s": t_eig,
-                            "note": "the reference's per-trial loop on strided slices lfp[:, :, r] (gpcsd2d.py:147-148) "
-                                    "timed on %d trials and scaled to %d; its predict is dense (2 x 295 GB at 384 x 500) and "
-                                    "cannot run at this size, so predict is the structured form in both flavours" % (nf, R)},
+                            "projection_ms_per_trial_contiguous": contiguous_ms,
+                            "note": "the reference's loglik timed directly in its own order: covariance assembly + comp_eig_D + "
+                                    "its per-trial loop on strided slices lfp[:, :, r] (gpcsd2d.py:147-148), the loop timed on %d "
+                                    "trials and scaled to %d; its predict is dense (2 x 295 GB at 384 x 500) and cannot run at "
+                                    "this size, so predict is the structured form in both flavours" % (nf, R)},
         "seconds_spent": time.perf_counter() - t_begin,
     }
     return rep, ll, pred
 
 
 # ------------------------------------------------------------------------------------------------------- committed profiles
-def _profile(name_r02, name_r01):
-    for n in (name_r02, name_r01):
-        p = os.path.join(ROOT, "profiles", n)
-        if os.path.exists(p):
-            return p
-    return None
+# rocprofv3 summaries of `bench.py --only-value [--workload W]` (tools/profile_r03.sh), one set per workload: a line never
+# inherits another workload's numbers (no file for the workload, or a non-default trial count: null).
+PROFILE_ROUND = "r03"
 
 
-def pmc_step_traffic():
-    """HBM bytes per step from the committed rocprofv3 --pmc passes over this same bench command (FETCH_SIZE x2 on gfx950 +
-    WRITE_SIZE, separate passes; tools/pmc_summary.py).  None if no profile is committed."""
-    path = _profile("r02_pmc_traffic.json", "r01_pmc_traffic.json")
+def _profile(kind, wl, ext):
+    p = os.path.join(ROOT, "profiles", "%s_%s_%s.%s" % (PROFILE_ROUND, kind, wl, ext))
+    return p if os.path.exists(p) else None
+
+
+def pmc_step_traffic(wl):
+    """HBM bytes per step from the committed rocprofv3 --pmc passes over `bench.py --only-value` for this workload (FETCH_SIZE
+    x2 on gfx950 + WRITE_SIZE, separate passes; tools/pmc_summary.py).  (None, None) if no profile is committed for it."""
+    path = _profile("pmc_traffic", wl, "json")
     if path is None:
         return None, None
     with open(path) as fh:
         d = json.load(fh)
     per_step = d.get("hbm_traffic_bytes_per_step")
-    if per_step is None:                      # older summaries: per-launch rows + launch counts; steps = launches of a
-        steps = None                          # kernel that runs exactly once per step (the final pass of predict)
-        for r in d.get("rows", []):
-            if r["kernel"].startswith(("unfold_swap_sum_kernel", "swap_last2_sum_kernel")):
-                steps = (steps or 0) + r.get("launches", 0)
-        tot = sum(r.get("hbm_traffic_bytes_per_launch", 0.0) * r.get("launches", 0) for r in d.get("rows", []))
-        per_step = tot / steps if steps else None
     top = sorted((r for r in d.get("rows", []) if "hbm_traffic_bytes_per_launch" in r),
                  key=lambda r: -r["hbm_traffic_bytes_per_launch"] * r.get("launches", 1))[:4]
-    return per_step, {"source": "profiles/" + os.path.basename(path),
+    return per_step, {"source": "profiles/" + os.path.basename(path), "steps_in_profile": d.get("steps"),
                       "largest": [{"kernel": r["kernel"][:60], "bytes_per_launch": r["hbm_traffic_bytes_per_launch"],
-                                   "launches": r.get("launches")} for r in top]}
+                                   "launches_per_step": r.get("launches_per_step")} for r in top]}
 
 
-def rocprof_share(kernel_substr):
-    """Share of GPU time of a kernel in the committed `rocprofv3 --kernel-trace --stats` summary of this bench command."""
+def rocprof_kernel(wl, kernel_substr):
+    """(share of GPU time, average launch ms, launches, source) of a kernel in the committed `rocprofv3 --kernel-trace --stats`
+    summary of `bench.py --only-value` for this workload; Nones if no profile is committed for it."""
     import csv
-    path = _profile("r02_kernel_stats.csv", "r01_t_kernel_stats.csv")
+    path = _profile("kernel_stats", wl, "csv")
     if path is None:
-        return None, None
+        return None, None, None, None
     with open(path) as fh:
         for row in csv.DictReader(fh):
             if kernel_substr in row.get("Name", ""):
-                return float(row["Percentage"]) / 100.0, "profiles/" + os.path.basename(path)
-    return None, "profiles/" + os.path.basename(path)
+                return (float(row["Percentage"]) / 100.0, float(row["AverageNs"]) * 1e-6, int(row["Calls"]),
+                        "profiles/" + os.path.basename(path))
+    return None, None, None, "profiles/" + os.path.basename(path)
 
 
 # ------------------------------------------------------------------------------------------------------- main
@@ -301,6 +313,9 @@ def main():
     ap.add_argument("--trials-per-gpu", type=int, default=None)
     ap.add_argument("--setup-steps", type=int, default=150)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--only-value", action="store_true",
+                    help="setup + warm-up + timed loop, then print value / ms_per_step and exit: the command profiled under profiles/")
+    ap.add_argument("--no-sub-results", action="store_true", help="skip the compact cfg2 / cfg5 sub-results of the default line")
     ap.add_argument("--cpu-budget-s", type=float, default=45.0)
     ap.add_argument("--fit-batch", type=int, default=None, help="cfg5: restarts evaluated per lock-step batch")
     ap.add_argument("--fit-maxiter", type=int, default=15)
@@ -337,11 +352,43 @@ def main():
         out = run_fit_bench(args, w, rank, world, local_rank, backend)
     else:
         out = run_step_bench(args, w, rank, world, local_rank, backend)
+    # the driver runs `bench.py --gpus 1` only: carry compact cfg2 / cfg5 results in that line (N=1, a few seconds)
+    if (rank == 0 and out is not None and world == 1 and args.workload == "cfg3" and args.trials_per_gpu is None
+            and not args.only_value and not args.no_sub_results):
+        out["sub_results"] = sub_results(args, local_rank, backend)
     if rank == 0 and out is not None:
         print(json.dumps(out))
 
 
-def run_step_bench(args, w, rank, world, local_rank, backend):
+def sub_results(args, local_rank, backend):
+    """Compact cfg2 (BASELINE configs[1]) and cfg5 (configs[4], this GPU's share at N=1: all 32 restarts) results with a parity
+    spot check each, measured by the same functions `--workload cfg2` / `--workload cfg5` run."""
+    import copy
+    out = {}
+    t0 = time.perf_counter()
+    a2 = copy.copy(args)
+    a2.workload, a2.steps, a2.warmup, a2.setup_steps, a2.no_cpu_baseline, a2.trials_per_gpu = "cfg2", 100, 5, 60, True, None
+    try:
+        r = run_step_bench(a2, workload("cfg2"), 0, 1, local_rank, backend, compact=True)
+        out["cfg2"] = {k: r[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "config", "parity_rel_err_loglik_vs_oracle",
+                                          "parity_rel_err_predict_vs_oracle", "loglik") if k in r}
+        out["cfg2"]["roofline_frac_step_executed"] = r["roofline"]["frac"]
+        out["cfg2"]["fenced_calls_ms"] = [r["fenced_calls"]["loglik_ms"], r["fenced_calls"]["predict_resident_ms"]]
+    except Exception as e:                                   # a sub-result must never take the headline down
+        out["cfg2"] = {"error": repr(e)}
+    a5 = copy.copy(args)
+    a5.workload, a5.steps, a5.warmup, a5.setup_steps, a5.fit_batch, a5.fit_groups = "cfg5", 20, 3, 10, None, 1
+    try:
+        r = run_fit_bench(a5, workload("cfg5"), 0, 1, local_rank, backend, compact=True)
+        out["cfg5"] = {k: r[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "config", "evals_per_sec_one_at_a_time_per_gpu",
+                                          "batched_over_sequential", "fit", "fit_vectorised", "parity") if k in r}
+    except Exception as e:
+        out["cfg5"] = {"error": repr(e)}
+    out["seconds_spent"] = time.perf_counter() - t0
+    return out
+
+
+def run_step_bench(args, w, rank, world, local_rank, backend, compact=False):
     import torch
     from gpcsd_amd import _hip
     from gpcsd_amd.dist import TrialSharding
@@ -437,6 +484,16 @@ def run_step_bench(args, w, rank, world, local_rank, backend):
         td.all_reduce(tt, op=td.ReduceOp.MAX)
         elapsed = float(tt.cpu()[0])
     ms_per_step = 1e3 * elapsed / args.steps
+    if args.only_value:
+        if rank != 0:
+            return None
+        return {"metric": "gpcsd_loglik_plus_predict_trials_per_sec", "value": R_total * args.steps / elapsed, "unit": "trials/s",
+                "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup, "setup_steps": args.setup_steps,
+                "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+                "data": "synthetic", "loglik": float(ll),
+                "config": {"workload": w["label"], "n_elec": w["nx"], "n_t": w["nt"], "trials_per_gpu": R_local,
+                           "total_trials": R_total, "parallelism": "trial-sharded x%d" % n_gpus},
+                "only_value": "setup + warm-up + timed loop only (the command profiled under profiles/)"}
 
     # ---- the two halves on their own (rank-local, every call fenced: nothing of one call overlaps the next) ----
     # In the step loop above predict_resident returns with its GEMM tail in flight (its results stay on the device) and
@@ -502,30 +559,46 @@ def run_step_bench(args, w, rank, world, local_rank, backend):
     pcie_predict = R_local * n_pcie / (time.perf_counter() - t1)
     out_bytes = (1 + C) * z.shape[0] * w["nt"] * R_local * 8
 
-    # ---- roofline: profiled pass (HIP events on the library's streams, per named scope) ----
-    n_prof = 3
-    ctx.prof_reset()
-    ctx.prof_enable(True)
-    for _ in range(n_prof):
-        one_step()
-    flush()
-    ctx.prof_enable(False)
-    prof = ctx.prof_all()
+    # ---- roofline: HIP events around the kernels of the SAME paired, queued step the timed loop runs ----
+    # mode 2: asynchronous scopes, chains launched eagerly so the scopes inside them record (per-kernel launch times);
+    # mode 3: asynchronous scopes with the chains replayed as hipGraphs exactly as in the timed loop (chain-level scopes)
+    def profiled_pass(mode, n):
+        flush()
+        ctx.synchronize()
+        ctx.prof_reset()
+        ctx.prof_enable(mode)
+        for _ in range(3):
+            one_step()
+        flush()
+        ctx.synchronize()
+        ctx.prof_reset()
+        tp0 = time.perf_counter()
+        for _ in range(n):
+            one_step()
+        flush()
+        ctx.synchronize()
+        dt = (time.perf_counter() - tp0) / n
+        ctx.prof_enable(0)
+        return ctx.prof_all(), 1e3 * dt
+    n_prof = max(10, min(args.steps, 40))
+    prof, eager_ms = profiled_pass(2, n_prof)
+    prof_graph, graph_ms = profiled_pass(3, n_prof)
     if rank != 0:
         return None
 
     f_ll, f_pred, f_pred_trial = algorithmic_flops(w, R_local, z.shape[0], C)
     ref_flops = f_ll + f_pred
-    gemms = {k: v for k, v in prof.items() if k.startswith("gemm_") and v["count"] > 0}
+    gemms = {k: v for k, v in prof_graph.items() if k.startswith("gemm_") and v["count"] > 0}
     # flops actually launched per step: every GEMM launch as recorded by the library (2 M N K per launch, batch included:
     # folded-basis projections, Gram assembly, D&C merge products), the tridiagonalisations ((4/3) n^3 per half problem) and
     # the compact-WY back-transformations (4 n^3 per half problem: V Z, T W, V^T W per panel of 64 reflectors)
-    gemm_flops = sum(v["flops"] for v in gemms.values()) / n_prof
+    gemm_flops = sum(v["flops"] for k, v in prof.items() if k.startswith("gemm_")) / n_prof       # (incl. the D&C merge products)
     tail = prof.get("sytrd_rtail")
     tail_flops = tail["flops"] / n_prof if tail else 0.0
     wy_flops = 3.0 * tail_flops                                  # 4 n^3 = 3 x (4/3) n^3 for the same half problems
     exec_flops = gemm_flops + tail_flops + wy_flops
     step_s = ms_per_step * 1e-3
+    wl = args.workload if (args.trials_per_gpu is None and n_gpus == 1) else "none"
     roof = {
         "bound": "mfma", "unit": "TFLOP/s", "peak": FP64_MFMA_SPEC_TFLOPS,
         "achieved": exec_flops / step_s / 1e12, "frac": exec_flops / step_s / 1e12 / FP64_MFMA_SPEC_TFLOPS,
@@ -539,23 +612,27 @@ def run_step_bench(args, w, rank, world, local_rank, backend):
                                 "note": "SURVEY 8(d) unit: F_spatial + F_eig + R F_proj (+ predict); the library executes "
                                         "about half of its GEMM part and a quarter of its eigensolver part"},
         "measured_mfma_f64_peak_tflops": ctx.mfma_f64_peak(),
+        "profiled_passes": {"steps": n_prof, "eager_chains_ms_per_step": eager_ms, "graph_chains_ms_per_step": graph_ms,
+                            "note": "the timed step re-run with event scopes on the library's streams: chains eager (per-kernel "
+                                    "scopes below) and chains as hipGraphs (chain-level scopes); both leave the step queued and paired"},
     }
     if tail and tail["count"]:
         avg = tail["ms"] / tail["count"]
         per_launch = tail["flops"] / tail["count"]
-        share, src = rocprof_share("sytrd_rtail_kernel")
+        share, rp_avg, rp_calls, src = rocprof_kernel(wl, "sytrd_rtail_kernel")
+        lps = tail["count"] / n_prof
         roof["dominant_kernel"] = {
-            "kernel": "sytrd_rtail_kernel", "why": "largest share of GPU time in the rocprofv3 kernel stats of this command",
-            "share_of_gpu_time_rocprof": share, "rocprof_source": src,
-            "avg_launch_ms": avg, "launches_per_step": tail["count"] / n_prof, "flops_per_launch": per_launch,
+            "kernel": "sytrd_rtail_kernel", "why": "largest share of GPU time in the rocprofv3 kernel stats of `bench.py --only-value`",
+            "share_of_gpu_time_rocprof": share, "rocprof_avg_launch_ms": rp_avg, "rocprof_launches": rp_calls, "rocprof_source": src,
+            "avg_launch_ms": avg, "launches_per_step": lps, "ms_per_step": avg * lps, "flops_per_launch": per_launch,
             "achieved": per_launch / (avg * 1e-3) / 1e12, "frac": per_launch / (avg * 1e-3) / 1e12 / FP64_MFMA_SPEC_TFLOPS,
-            "workgroups_per_launch": 2, "cus_busy": "2 of %d (one 768-thread workgroup per half problem)" % N_CUS,
+            "workgroups_per_launch": 4 if paired else 2,
+            "cus_busy": "%d of %d (one 768-thread workgroup per half problem)" % (4 if paired else 2, N_CUS),
             "bound": "latency: ~250 dependent Householder columns per launch, two workgroup barriers each",
-            "note": "measured in the profiled pass, where the library's event profiler runs loglik and predict as two fenced "
-                    "calls: four launches per step (one per eigenproblem, two half problems each).  In the timed paired step "
-                    "the two temporal problems share one launch of 4 workgroups (~0.55 ms, on the critical path: almost half "
-                    "of the step's wall time) and the two spatial ones another (~0.33 ms, beside it): 8 of %d CUs" % N_CUS,
-            "paired_step": {"launches_per_step": 2, "workgroups_per_launch": 4, "cus_busy": "8 of %d" % N_CUS},
+            "note": "HIP events around the launches of the timed paired step itself (asynchronous scopes): one launch per chain "
+                    "per step, each with the two replicas' half problems as workgroups -- the temporal chain's (4 x 250 rows, "
+                    "on the critical path) and the spatial chain's (4 x 192 rows, beside it); the two overlap in time, so "
+                    "their sum is not a share of the step's wall time",
         }
     if gemms:
         name = max(gemms, key=lambda k: gemms[k]["ms"])
@@ -566,13 +643,16 @@ def run_step_bench(args, w, rank, world, local_rank, backend):
             "kernel": "gemm_f64_kernel [" + name + "]", "avg_launch_ms": avg_ms, "flops_per_launch": g["flops"] / g["count"],
             "achieved": ach, "frac": ach / FP64_MFMA_SPEC_TFLOPS, "share_of_step_wall": (g["count"] / n_prof) * avg_ms / ms_per_step,
             "all_gemm_tflops": sum(v["flops"] for v in gemms.values()) / (sum(v["ms"] for v in gemms.values()) * 1e-3) / 1e12}
-    traffic, tdetail = pmc_step_traffic()
+    traffic, tdetail = pmc_step_traffic(wl)
     alg_bytes = 2 * w["nx"] * w["nt"] * R_local * 8 + out_bytes          # lfp read once per call + predict outputs written once
     roof["traffic"] = traffic
-    roof["traffic_unit"] = "HBM bytes per step (rocprofv3 --pmc, corrected as the gfx950 guide prescribes)"
+    roof["traffic_unit"] = "HBM bytes per step (rocprofv3 --pmc over `bench.py --only-value`, corrected as the gfx950 guide prescribes)"
     roof["traffic_detail"] = tdetail
     roof["algorithmic_bytes_per_step"] = alg_bytes
     roof["per_kernel_ms_per_step"] = {k: v["ms"] / n_prof for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])}
+    roof["per_kernel_launches_per_step"] = {k: v["count"] / n_prof for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])}
+    roof["chains_ms_per_step_graph_replay"] = {k: v["ms"] / n_prof for k, v in sorted(prof_graph.items(), key=lambda kv: -kv[1]["ms"])
+                                               if v["count"] > 0}
 
     out = {
         "metric": "gpcsd_loglik_plus_predict_trials_per_sec",
@@ -621,10 +701,19 @@ def run_step_bench(args, w, rank, world, local_rank, backend):
         ctx.predict_resident(hp0, z, w["t"], _hip.PRED_CSD, want_lists=True)
         got = ctx.fetch("pred_out_csd", (z.shape[0], w["nt"], R_local))
         out["parity_rel_err_predict_vs_oracle"] = float(np.max(np.abs(got - pred_cpu)) / np.max(np.abs(pred_cpu)))
+    elif compact:                                    # sub-result of the default line: parity spot check without the timing legs
+        O, geom, hpo, hpo0 = oracle_setup(w, m)
+        ll_cpu = O.loglik(geom, hpo, lfp)
+        pred_cpu = O.predict(geom, hpo0, lfp, z, w["t"], type="csd")["csd"]
+        out["parity_rel_err_loglik_vs_oracle"] = abs(float(ll) - ll_cpu) / abs(ll_cpu)
+        hp0, _k = m._hparams(0.0)
+        ctx.predict_resident(hp0, z, w["t"], _hip.PRED_CSD, want_lists=True)
+        got = ctx.fetch("pred_out_csd", (z.shape[0], w["nt"], R_local))
+        out["parity_rel_err_predict_vs_oracle"] = float(np.max(np.abs(got - pred_cpu)) / np.max(np.abs(pred_cpu)))
     return out
 
 
-def run_fit_bench(args, w, rank, world, local_rank, backend):
+def run_fit_bench(args, w, rank, world, local_rank, backend, compact=False):
     """BASELINE cfg5: GPCSD1D hyper-parameter fit, 24 x 500 x 200 trials resident on every GPU, 32 restarts sharded over the
     GPUs.  The unit of work is one objective + analytic-gradient evaluation of one restart (what L-BFGS-B asks for); a step
     evaluates one lock-step batch of B restarts in one chain of launches (gpcsd_loglik_grad_batch).  Reported: evaluations/s
@@ -740,6 +829,35 @@ def run_fit_bench(args, w, rank, world, local_rank, backend):
     if rank != 0:
         return None
     n_eval = G * B * world * args.steps
+    # parity spot check beside the numbers: the HIP objective and analytic gradient at restart 0's start against the oracle
+    # objective and its central differences (checker code; 2 p + 1 oracle evaluations)
+    parity = None
+    if world == 1:
+        O, geom, hpo, _hpo0 = oracle_setup(w, m)
+        kinds = [k for k, _, _ in w["temporal"]]
+
+        def cpu_obj(tp):
+            hh = O.hparams_from_tparams(tp, 1, kinds, 1, jitter=1e-8)
+            lp = m.R["prior"].lpdf(hh["R"]) + m.spatial_cov.params["ell"]["prior"].lpdf(hh["ell_s"][0]) + m.sig2n["prior"].lpdf(hh["sig2n"])
+            for tc, (_, ell, s2) in zip(m.temporal_cov_list, hh["temporal"]):
+                lp += tc.params["ell"]["prior"].lpdf(ell) + tc.params["sigma2"]["prior"].lpdf(s2)
+            return -(O.loglik(geom, hh, lfp) + lp)
+        # at the hyper-parameters the data were drawn from (a well-scaled point: central differences of a prior-drawn start,
+        # where the objective is ~1e7 and dominated by one term, only measure the differences' own rounding)
+        m.R["value"], m.sig2n["value"] = w["R"], w["sig2n"]
+        m.spatial_cov.params["ell"]["value"] = w["ell_s"][0]
+        for tc, (_, ell, s2) in zip(m.temporal_cov_list, w["temporal"]):
+            tc.params["ell"]["value"], tc.params["sigma2"]["value"] = ell, s2
+        tp0 = m._current_tparams()
+        f_gpu, g_gpu = m._objective_and_grad(tp0, False)
+        f_cpu = cpu_obj(tp0)
+        g_cpu = np.zeros_like(tp0)
+        for i in range(tp0.size):
+            e = np.zeros_like(tp0)
+            e[i] = 1e-5
+            g_cpu[i] = (cpu_obj(tp0 + e) - cpu_obj(tp0 - e)) / 2e-5
+        parity = {"objective_rel_err_vs_oracle": abs(f_gpu - f_cpu) / abs(f_cpu),
+                  "gradient_max_err_over_max_component_vs_oracle_fd": float(np.max(np.abs(g_gpu - g_cpu)) / np.max(np.abs(g_cpu)))}
     gemm_flops = sum(v["flops"] for k, v in prof.items() if k.startswith("gemm_")) / 3.0
     tail = prof.get("sytrd_rtail")
     eig_flops = 4.0 * tail["flops"] / 3.0 if tail else 0.0           # tridiagonalisation + 3x for the back-transformation
@@ -756,6 +874,7 @@ def run_fit_bench(args, w, rank, world, local_rank, backend):
         "evals_per_sec_one_at_a_time_per_gpu": 1.0 / seq_s,
         "evals_per_sec_one_group_per_gpu": B / one_group_s,
         "batched_over_sequential": (B / one_group_s) / (1.0 / seq_s),
+        "parity": parity,
         "all_groups_over_sequential": (G * B / step_s) / (1.0 / seq_s),
         "fit": {"restarts": total_restarts, "maxiter": args.fit_maxiter, "seconds": fit_s,
                 "restarts_per_sec": total_restarts / fit_s, "evals": int(npts) * world, "batched_calls": int(nb),

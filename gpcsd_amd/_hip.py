@@ -611,7 +611,9 @@ class Context:
         return int(n.value)
 
     def prof_enable(self, on=True):
-        self._check(self._lib.gpcsd_prof_enable(self._h, int(bool(on))))
+        """False / 0 off; True / 1 fenced scopes; 2 asynchronous scopes (queued and paired calls stay queued, eager chains);
+        3 asynchronous scopes with the chains replayed as hipGraphs (chain-level scopes only)."""
+        self._check(self._lib.gpcsd_prof_enable(self._h, int(on)))
 
     def prof_reset(self):
         self._check(self._lib.gpcsd_prof_reset(self._h))

@@ -643,7 +643,7 @@ int finish_call(gpcsd_ctx *c, const EigState &e, double *scal_out, int nscal) {
     c->sync();
     c->status_zeroed = true;
     c->async_pending = false;              // whatever an asynchronous predict left in the status words has been collected now
-    if (c->prof_on) c->prof_collect();
+    if (c->prof_mode == 1) c->prof_collect();
     for (int i = 0; i < nscal; ++i) scal_out[i] = host[i];
     int st[4];
     memcpy(st, host + 64, sizeof(st));
@@ -662,7 +662,7 @@ int finish_status(gpcsd_ctx *c, const int *d_status) {
     int st[4];
     c->download(st, d_status, sizeof(st));
     c->sync();
-    if (c->prof_on) c->prof_collect();
+    if (c->prof_mode == 1) c->prof_collect();
     for (int i = 1; i < 4 && st[0] == 0; ++i) st[0] = st[i];   // [1]: temporal chain; [2], [3]: second replica of a paired call
     if (st[0] != 0) {
         char b[128];
@@ -1121,7 +1121,7 @@ extern "C" int gpcsd_eigh_batch(gpcsd_ctx *c, const double *A, int n, int count,
     c->download(evecs, dV, nn * count * sizeof(double));
     c->download(status, st, (size_t)count * sizeof(int));
     c->sync();
-    if (c->prof_on) c->prof_collect();
+    if (c->prof_mode == 1) c->prof_collect();
     return 0;
     GP_API_END(c)
 }
@@ -1245,7 +1245,7 @@ extern "C" int gpcsd_trsm_lower(gpcsd_ctx *c, const double *L, int n, const doub
     trsm_lower_device(c, dL, n, dB, nrhs, c->stream);
     c->download(X, dB, (size_t)n * nrhs * sizeof(double));
     c->sync();
-    if (c->prof_on) c->prof_collect();
+    if (c->prof_mode == 1) c->prof_collect();
     return 0;
     GP_API_END(c)
 }
@@ -1265,7 +1265,7 @@ extern "C" int gpcsd_gemm(gpcsd_ctx *c, int transA, int transB, int M, int N, in
     gemm_f64(c, g, c->stream);
     c->download(C, dC, (size_t)M * N * sizeof(double));
     c->sync();
-    if (c->prof_on) c->prof_collect();
+    if (c->prof_mode == 1) c->prof_collect();
     return 0;
     GP_API_END(c)
 }
@@ -1472,7 +1472,7 @@ static bool loglik_fold_tail(gpcsd_ctx *c, EigState &e, const FoldMode &fm, cons
 
 static int loglik_parts_impl(gpcsd_ctx *c, const gpcsd_hparams *hp, double *out2, bool async) {
     GP_REQUIRE(c->d_lfp != nullptr, -4, "lfp not set (call gpcsd_set_lfp)");
-    if (async && c->prof_on) {            // profiling scopes need fenced calls: evaluate now, hand the result over at the wait
+    if (async && c->prof_mode == 1) {     // fenced profiling (mode 1): evaluate now, hand the result over at the wait
         gpcsd_ctx::LlSlot &sl = c->ll_slot[(c->ll_head + c->ll_count) % gpcsd_ctx::LL_SLOTS];
         sl.rc = loglik_parts_impl(c, hp, sl.out, false);
         sl.done = true;
@@ -1711,7 +1711,7 @@ static int predict_fold(gpcsd_ctx *c, const gpcsd_hparams *hp, EigState &e, cons
         k_unfold_swap_sum(c, comp, C, o_list, (long)out_elems, o_sum, R, nt, sz, fm.sym_t, s);
     }
     c->tl("predict end (main)", s);
-    if (async && !c->prof_on) {           // results stay on the device: return with the tail still in flight
+    if (async && c->prof_mode != 1) {     // results stay on the device: return with the tail still in flight
         c->async_pending = true;
         c->status_zeroed = false;
         return 0;
@@ -1992,7 +1992,7 @@ extern "C" int gpcsd_loglik_predict_async(gpcsd_ctx *c, const gpcsd_hparams *hp_
     GP_REQUIRE(c->d_lfp != nullptr, -4, "lfp not set (call gpcsd_set_lfp)");
     static const bool unpaired = getenv("GPCSD_NO_PAIR") && getenv("GPCSD_NO_PAIR")[0] == '1';     // A/B switch
     // the paired front half serves the folded-basis tails only; anything else is the two calls one after the other
-    bool pair = !unpaired && two_stream_front() && !c->prof_on && !uses_host_kt(hp_ll) && !uses_host_kt(hp_pr) &&
+    bool pair = !unpaired && two_stream_front() && c->prof_mode != 1 && !uses_host_kt(hp_ll) && !uses_host_kt(hp_pr) &&
                 hp_ll->n_sig2n == 1 && hp_pr->n_sig2n == 1;
     FoldMode fm0;
     SymDev sz;
@@ -2504,7 +2504,7 @@ static int loglik_grad_impl(gpcsd_ctx *c, const gpcsd_hparams *hps, int B, doubl
     c->download(hst.data(), st, hst.size() * sizeof(int));
     GP_HIP(hipStreamSynchronize(s2));
     c->sync();
-    if (c->prof_on) c->prof_collect();
+    if (c->prof_mode == 1) c->prof_collect();
     int worst = 0;
     for (int b = 0; b < B; ++b) {
         out2[2 * b] = hs[(size_t)NS * b];
@@ -2551,6 +2551,14 @@ extern "C" int gpcsd_loglik_grad_batch(gpcsd_ctx *c, const gpcsd_hparams *hps, i
 // ------------------------------------------------------------------------------------------------
 extern "C" int gpcsd_prof_enable(gpcsd_ctx *c, int on) {
     GP_API_BEGIN(c)
+    // 0 off.  1: fenced -- every fused call synchronises and collects its scopes, asynchronous calls are evaluated at once,
+    // chains run eagerly (one scope per kernel family).  2: asynchronous -- scopes record their events on the streams they run
+    // on and nothing else changes: queued and paired calls stay queued and paired; chains run eagerly so that the scopes inside
+    // them (sytrd_rtail, eigh_stedc, ...) see their kernels.  3: as 2 with the chains replayed as hipGraphs, as in production:
+    // only the scopes around whole chains and the GEMM tails record.  Modes 2 / 3 are collected by gpcsd_prof_get (which waits
+    // for the recorded events).
+    GP_REQUIRE(on >= 0 && on <= 3, -3, "prof_enable: mode must be 0..3");
+    c->prof_mode = on;
     c->prof_on = (on != 0);
     return 0;
     GP_API_END(c)

@@ -101,6 +101,7 @@ struct gpcsd_ctx {
     std::string last_error;
     std::map<std::string, gpcsd::DevBuf> bufs;
     bool prof_on = false;
+    int prof_mode = 0;                      // gpcsd_prof_enable: 0 off, 1 fenced, 2 asynchronous (eager chains), 3 asynchronous (graph chains)
     std::map<std::string, gpcsd::ProfEntry> prof;
     std::vector<hipEvent_t> event_pool;
     std::map<std::string, int> int_cache;

@@ -273,7 +273,8 @@ void eigh_pair_device(gpcsd_ctx *c, double *A0, int n0, double *w0, double *Z0, 
                "(GPCSD_MAX_EIG_N)", n0, n1, m0, m1, JACOBI_MAX_N);
     const bool any_large = !force_jacobi() && (n0 > JACOBI_LDS_MAX || n1 > JACOBI_LDS_MAX);
     // GPCSD_PROF_GRAPH=1: keep replaying graphs while profiling, so the outer scopes time the chains as they run in production
-    static const bool prof_graph = getenv("GPCSD_PROF_GRAPH") != nullptr;
+    static const bool prof_graph_env = getenv("GPCSD_PROF_GRAPH") != nullptr;
+    const bool prof_graph = prof_graph_env || c->prof_mode == 3;
     if (!any_large || (c->prof_on && !prof_graph) || !graphs_enabled()) {
         eigh_pair_enqueue(c, A0, n0, w0, Z0, sym0, A1, n1, w1, Z1, sym1, d_status, s, need_merged, count, status_stride, count1);
         return;

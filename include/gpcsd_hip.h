@@ -267,7 +267,11 @@ int gpcsd_decomposition_cache(gpcsd_ctx *ctx, int on, long *hits);
 int gpcsd_fold_gemm(gpcsd_ctx *ctx, int on, long *calls);
 
 /* ---- measurement --------------------------------------------------------------- */
-/* When enabled, every launch of a named hot kernel is bracketed by hipEvents on the ctx stream. */
+/* When enabled, every launch of a named hot kernel (or kernel family) is bracketed by hipEvents on the stream it runs on.
+ * on = 0 off; 1 fenced: every fused call synchronises, asynchronous / paired calls are evaluated one by one, chains run
+ * eagerly; 2 asynchronous: events only, queued and paired calls stay queued and paired (what bench.py's timed step does),
+ * chains run eagerly so the scopes inside them see their kernels; 3 as 2 with the chains replayed as hipGraphs (only the
+ * scopes around whole chains and the GEMMs record).  gpcsd_prof_get waits for the recorded events. */
 int gpcsd_prof_enable(gpcsd_ctx *ctx, int on);
 int gpcsd_prof_reset(gpcsd_ctx *ctx);
 /* total ms, launch count and algorithmic flops accumulated under `name`; rc -2 if unknown */

@@ -474,6 +474,59 @@ def test_decomposition_cache_reuses_unchanged_sides_bitwise():
     assert relerr(m.csd_pred, O.predict(geom, hp2, lfp, c["x"], c["t"], type="csd")["csd"]) < GATE
 
 
+@pytest.mark.parametrize("name", ["2d_npx_96x120x3", "cfg2s_1d_24x500x8"])
+def test_failed_asynchronous_call_is_never_served_from_the_decomposition_cache(name):
+    """a predict_resident whose eigensolver fails reports through the next synchronising call (gpcsd_fetch); a retry
+    with the SAME hyper-parameters must solve again and fail again -- with the decomposition cache on (the default) both
+    sides' keys match the failed call's, and the retry used to return success on the failed decomposition's eigenvectors.
+    Same for the asynchronous log-likelihood; and once a failure has been reported, later evaluations start clean."""
+    from gpcsd_amd import _hip
+    c, g, geom, hp, lfp = load_model_case(name)
+    m = _model_from_case(c, g, lfp)
+    ctx = m._sync_device()
+    ctx.decomposition_cache(True)
+    z, t = np.ascontiguousarray(c["x"], dtype=np.float64).reshape(c["x"].shape[0], -1), c["t"]
+    shape = (z.shape[0], t.shape[0], lfp.shape[2])
+    ll_ref = m.loglik()
+    m.predict(c["x"], c["t"], type="csd")
+    pred_ref = m.csd_pred.copy()
+    good = m.temporal_cov_list[0].params["ell"]["value"]
+    m.temporal_cov_list[0].params["ell"]["value"] = float("nan")
+    hp_bad, keep_bad = m._hparams(0.0)
+    hp_bad1, keep_bad1 = m._hparams(m.JITTER)
+    m.temporal_cov_list[0].params["ell"]["value"] = good
+    hp0, keep0 = m._hparams(0.0)
+    hp1, keep1 = m._hparams(m.JITTER)
+    for attempt in range(3):                              # every retry with the same bad hp fails: nothing is reused
+        with pytest.raises(np.linalg.LinAlgError):
+            ctx.predict_resident(hp_bad, z, t, _hip.PRED_CSD, want_lists=False)
+            ctx.fetch("pred_out_csd", shape)
+    ctx.predict_resident(hp0, z, t, _hip.PRED_CSD, want_lists=False)
+    assert np.array_equal(ctx.fetch("pred_out_csd", shape), pred_ref)
+    for attempt in range(3):
+        ctx.loglik_parts_async(hp_bad1)
+        with pytest.raises(np.linalg.LinAlgError):
+            ctx.loglik_parts_wait()
+        # the failed wait cleared the sticky status: an evaluation queued after it is clean (ADVICE r2, low)
+        ctx.loglik_parts_async(hp1)
+        sumlog, quad = ctx.loglik_parts_wait()
+        assert -0.5 * lfp.shape[2] * sumlog - 0.5 * quad == ll_ref
+    # a failure followed by a good evaluation, both outstanding: the second copied the sticky status and reports it too
+    # (documented in gpcsd_hip.h: a failed wait poisons the evaluations queued before it returned) -- then clean again
+    ctx.loglik_parts_async(hp_bad1)
+    ctx.loglik_parts_async(hp1)
+    with pytest.raises(np.linalg.LinAlgError):
+        ctx.loglik_parts_wait()
+    try:
+        ctx.loglik_parts_wait()
+    except np.linalg.LinAlgError:
+        pass
+    assert m.loglik() == ll_ref
+    ctx.loglik_parts_async(hp1)
+    sumlog, quad = ctx.loglik_parts_wait()
+    assert -0.5 * lfp.shape[2] * sumlog - 0.5 * quad == ll_ref
+
+
 @pytest.mark.parametrize("name", ["2d_npx_96x120x3", "cfg2s_1d_24x500x8", "1d_odd_17x37x5", "cfg3s_2d_384x500x2"])
 def test_predict_resident_is_asynchronous_and_changes_no_bits(name):
     """Queued calls: gpcsd_predict_resident returns with its GEMM tail in flight and gpcsd_loglik_parts_async /
@@ -678,3 +731,23 @@ def test_bench_cfg5_two_ranks_restart_sharding_over_the_hip_objective():
     assert two["n_gpus"] == 2 and two["config"]["restarts_per_gpu"] == 16 and two["value"] > 0
     assert two["fit"]["restarts"] == 32 and one["fit"]["restarts"] == 32
     assert two["fit"]["nll_values"] == one["fit"]["nll_values"]       # same starts, bitwise-equal evaluations, same optima
+
+
+@pytest.mark.timeout(900)
+def test_bench_step_over_rccl_with_one_rank_matches_the_plain_run():
+    """RCCL readiness on the driver's box: bench.py --gpus 1 with GPCSD_BENCH_FORCE_DIST=1 initialises the `nccl` (= RCCL)
+    process group with one rank in a fresh child process (before any GPU call of its own), so the hyper-parameter broadcast,
+    the side-stream all-reduce of the partial quadratic term and the barrier of the N > 1 step all execute on the RCCL code
+    path.  The log-likelihood is the plain run's to rounding (a one-rank sum adds nothing) and the step costs the same."""
+    common = ["--steps", "40", "--warmup", "5", "--setup-steps", "60", "--no-cpu-baseline", "--only-value"]
+    port = 30300 + os.getpid() % 400
+    plain = _run([sys.executable, "bench.py", "--gpus", "1"] + common, dict(os.environ))
+    rccl = _run([sys.executable, "bench.py", "--gpus", "1"] + common,
+                dict(os.environ, GPCSD_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0",
+                     WORLD_SIZE="1", LOCAL_RANK="0"))
+    # (not bit for bit: the sharded step first broadcasts rank 0's LOG-parameters, as fit() does, and exp(log(v)) moves a
+    # hyper-parameter by a rounding error)
+    assert rccl["n_gpus"] == 1 and abs(rccl["loglik"] - plain["loglik"]) <= 1e-12 * abs(plain["loglik"])
+    ratio = rccl["ms_per_step"] / plain["ms_per_step"]
+    print("bench step over RCCL (1 rank): %.4f ms  plain: %.4f ms  ratio %.3f" % (rccl["ms_per_step"], plain["ms_per_step"], ratio))
+    assert ratio < 1.10        # (measured ~1.00; 5 % is the target, 10 % the gate: two fresh processes on a shared box)

@@ -82,9 +82,12 @@ def main():
     per_step = total / steps if steps else None
     if per_step:
         print("steps profiled: %d   HBM traffic per step: %.1f MB" % (steps, per_step / 1e6))
+    if steps:
+        for r in rows:
+            r["launches_per_step"] = r.get("launches", 0) / steps
     if args.out:
         with open(args.out, "w") as fh:
-            json.dump({"unit_bytes": args.unit_bytes, "fetch_correction": 2.0, "steps_profiled": steps,
+            json.dump({"unit_bytes": args.unit_bytes, "fetch_correction": 2.0, "steps_profiled": steps, "steps": steps,
                        "hbm_traffic_bytes_per_step": per_step, "rows": rows}, fh, indent=1)
 
 
