@@ -208,6 +208,44 @@ void build_kt(gpcsd_ctx *c, const gpcsd_hparams *hp, const double *t, int n, con
     k_temporal_gram(c, hp->n_temporal, hp->kind, hp->ell_t, hp->sigma2_t, t, n, tp, m, out, s);
 }
 
+// The temporal chain's input in one launch (k_temporal_fold_fill): applies when the time grid's reflection symmetry folds the
+// eigenproblem and the library's own Gram builders evaluate the kernels.  GPCSD_TFILL=0: the separate Gram -> fold ->
+// absmax -> scale launches (A/B).
+static bool temporal_fill_applies(gpcsd_ctx *c, const SymDev *sym_t, int nt, bool host_kt) {
+    static const bool off = getenv("GPCSD_TFILL") && getenv("GPCSD_TFILL")[0] == '0';
+    return !off && sym_t && !host_kt && eigh_fold_view(c, 1, sym_t, nt).on;
+}
+static void temporal_fill(gpcsd_ctx *c, const gpcsd_hparams *const *hps, int nrep, const double *t, int nt, const SymDev &sy,
+                          int *status, int status_stride, hipStream_t s) {
+    TemporalSet sets[2];
+    for (int r = 0; r < nrep; ++r) {
+        sets[r].ncomp = hps[r]->n_temporal;
+        for (int i = 0; i < GPCSD_MAX_TEMPORAL; ++i) {
+            const bool on = i < hps[r]->n_temporal;
+            sets[r].kind[i] = on ? hps[r]->kind[i] : 0;
+            sets[r].ell[i] = on ? hps[r]->ell_t[i] : 1.0;
+            sets[r].sigma2[i] = on ? hps[r]->sigma2_t[i] : 0.0;
+        }
+    }
+    const char *const *tg = eigh_fold_tags(1);
+    const EigArenaView as = eigh_arena_view(c, tg[0], sy.ns, nrep), aa = eigh_arena_view(c, tg[1], sy.na, nrep);
+    k_temporal_fold_fill(c, sets, nrep, t, nt, sy, as, aa, status, status_stride, s);
+}
+
+// The spatial chain's input the same way (k_psd_fold_fill): Ks is assembled WITHOUT the jitter, which the fill adds to the
+// folded blocks' diagonals -- the paired call's two replicas (Ks + jitter I, Ks) then need no copy of Ks.  GPCSD_SFILL=0: the
+// separate add_diag -> fold -> absmax -> scale launches (A/B).
+static bool spatial_fill_applies(gpcsd_ctx *c, const SymDev *sym_s, int nx) {
+    static const bool off = getenv("GPCSD_SFILL") && getenv("GPCSD_SFILL")[0] == '0';
+    return !off && sym_s && eigh_fold_view(c, 0, sym_s, nx).on;
+}
+static void spatial_fill(gpcsd_ctx *c, const double *Ks, int nx, long sK, int nrep, const double *jitter, const SymDev &sy,
+                         int *status, int status_stride, hipStream_t s) {
+    const char *const *tg = eigh_fold_tags(0);
+    const EigArenaView as = eigh_arena_view(c, tg[0], sy.ns, nrep), aa = eigh_arena_view(c, tg[1], sy.na, nrep);
+    k_psd_fold_fill(c, Ks, nx, sK, nrep, jitter, sy, as, aa, status, status_stride, s);
+}
+
 bool uses_host_kt(const gpcsd_hparams *hp);
 
 // Kt*_c = cov_c.compute_Kt(tstar) (ntstar, nt) of component cc (gpcsd1d.py:277): built on the device for SE / Matern, copied
@@ -467,10 +505,13 @@ EigState front_half(gpcsd_ctx *c, const gpcsd_hparams *hp, double jitter, bool n
     c->tl("call start (main)", s);
     if (run_t) {
         c->tl("T chain start (s2)", s2);
-        make_kt(s2);
+        const bool tfill = temporal_fill_applies(c, sym_t, nt, host_kt);
+        if (tfill) temporal_fill(c, &hp, 1, t, nt, *sym_t, e.status + 1, 0, s2);
+        else make_kt(s2);
         {
             ProfScope ps(c, "eigh_temporal", 9.0 * (double)nt * nt * nt, s2);
-            eigh_pair_device(c, nullptr, 0, nullptr, nullptr, nullptr, Kt, nt, e.et, e.Qt, sym_t, e.status + 1, s2, need_merged);
+            eigh_pair_device(c, nullptr, 0, nullptr, nullptr, nullptr, Kt, nt, e.et, e.Qt, sym_t, e.status + 1, s2, need_merged, 1, 0,
+                             -1, tfill ? 2 : 0);
         }
         GP_HIP(hipEventRecord(c->ev_join, s2));
         c->tl("T chain end (s2)", s2);
@@ -483,10 +524,13 @@ EigState front_half(gpcsd_ctx *c, const gpcsd_hparams *hp, double jitter, bool n
             c->slot0_on_s2 = false;
         }
         c->tl("S chain start (s3)", s3);
-        build_kphi(c, g, hp->R, hp->eps, hp->ell_s, nullptr, 0, jitter, Ks, s3, "ks_");
+        const bool sfill = spatial_fill_applies(c, sym_s, nx);
+        build_kphi(c, g, hp->R, hp->eps, hp->ell_s, nullptr, 0, sfill ? 0.0 : jitter, Ks, s3, "ks_");
+        if (sfill) spatial_fill(c, Ks, nx, 0, 1, &jitter, *sym_s, e.status, 0, s3);
         {
             ProfScope ps(c, "eigh_spatial", 9.0 * (double)nx * nx * nx, s3);
-            eigh_pair_device(c, Ks, nx, e.es, e.Qs, sym_s, nullptr, 0, nullptr, nullptr, nullptr, e.status, s3, need_merged);
+            eigh_pair_device(c, Ks, nx, e.es, e.Qs, sym_s, nullptr, 0, nullptr, nullptr, nullptr, e.status, s3, need_merged, 1, 0, -1,
+                             sfill ? 1 : 0);
         }
         GP_HIP(hipEventRecord(c->ev_sjoin, s3));
         c->tl("S chain end (s3)", s3);
@@ -1880,7 +1924,9 @@ static void front_half_pair(gpcsd_ctx *c, const gpcsd_hparams *const hp[2], cons
     // equal spatial hyper-parameters -- the usual pair -- the two differ by the diagonal shift only, so the matrix is
     // assembled once and copied (the same GEMM output plus the same diagonal add: the same bits).
     c->tl("T chain start (s2)", s2);
-    for (int b = 0; b < nT; ++b) build_kt(c, hp[b], t, nt, t, nt, Kt + b * ntt, s2);
+    const bool tfill = temporal_fill_applies(c, sym_t, nt, false);       // (the paired call is refused for host temporal Grams)
+    if (tfill) temporal_fill(c, hp, nT, t, nt, *sym_t, status + 1, 2, s2);
+    else for (int b = 0; b < nT; ++b) build_kt(c, hp[b], t, nt, t, nt, Kt + b * ntt, s2);
     GP_HIP(hipStreamWaitEvent(s3, c->ev_join, 0));      // the previous chain on stream2 may have been reading Ks_pair
     // (one chain wanted: decided below; a Jacobi-sized problem next to a large one would be solved by another algorithm than
     // alone -- it rides in the large one's launches -- and lose the bits of a separate call: such a pair takes two chains)
@@ -1892,7 +1938,8 @@ static void front_half_pair(gpcsd_ctx *c, const gpcsd_hparams *const hp[2], cons
         // decomposition cache on, equal temporal hyper-parameters)
         {
             ProfScope ps(c, "eigh_temporal", 9.0 * (double)nt * nt * nt * nT, s2);
-            eigh_pair_device(c, nullptr, 0, nullptr, nullptr, nullptr, Kt, nt, et, Qt, sym_t, status + 1, s2, false, nT, 2);
+            eigh_pair_device(c, nullptr, 0, nullptr, nullptr, nullptr, Kt, nt, et, Qt, sym_t, status + 1, s2, false, nT, 2, -1,
+                             tfill ? 2 : 0);
         }
         GP_HIP(hipEventRecord(c->ev_join, s2));
         c->tl("T chain end (s2)", s2);
@@ -1900,7 +1947,13 @@ static void front_half_pair(gpcsd_ctx *c, const gpcsd_hparams *const hp[2], cons
     c->tl("S chain start (s3)", s3);
     const bool same_ks = hp[0]->R == hp[1]->R && hp[0]->ell_s[0] == hp[1]->ell_s[0] &&
                          (g.dim == 1 || (hp[0]->eps == hp[1]->eps && hp[0]->ell_s[1] == hp[1]->ell_s[1]));
-    if (same_ks) {
+    const bool sfill = spatial_fill_applies(c, sym_s, nx);
+    if (sfill) {
+        // the fill folds Ks and adds each replica's jitter to the folded diagonals: one assembly, no copy, no diagonal pass
+        if (same_ks) build_kphi(c, g, hp[0]->R, hp[0]->eps, hp[0]->ell_s, nullptr, 0, 0.0, Ks, s3, "ks_");
+        else for (int b = 0; b < 2; ++b) build_kphi(c, g, hp[b]->R, hp[b]->eps, hp[b]->ell_s, nullptr, 0, 0.0, Ks + b * nxx, s3, "ks_");
+        spatial_fill(c, Ks, nx, same_ks ? 0 : nxx, 2, jitter, *sym_s, status, 2, s3);   // (one chain: stream2 waits for stream3 below)
+    } else if (same_ks) {
         const int lo = jitter[0] == 0.0 ? 0 : 1, hi = 1 - lo;           // assemble the one without a shift (if any) first
         build_kphi(c, g, hp[lo]->R, hp[lo]->eps, hp[lo]->ell_s, nullptr, 0, 0.0, Ks + lo * nxx, s3, "ks_");
         GP_HIP(hipMemcpyAsync(Ks + hi * nxx, Ks + lo * nxx, (size_t)nxx * sizeof(double), hipMemcpyDeviceToDevice, s3));
@@ -1920,7 +1973,8 @@ static void front_half_pair(gpcsd_ctx *c, const gpcsd_hparams *const hp[2], cons
         GP_HIP(hipStreamWaitEvent(s2, c->ev_sjoin, 0));            // the last chain on stream3 used the spatial workspaces
         {
             ProfScope ps(c, "eigh_pair", 9.0 * ((double)nt * nt * nt * nT + (double)nx * nx * nx * 2), s2);
-            eigh_pair_device(c, Ks, nx, es, Qs, sym_s, Kt, nt, et, Qt, sym_t, status, s2, false, 2, 2, nT);
+            eigh_pair_device(c, Ks, nx, es, Qs, sym_s, Kt, nt, et, Qt, sym_t, status, s2, false, 2, 2, nT,
+                             (tfill ? 2 : 0) | (sfill ? 1 : 0));
         }
         GP_HIP(hipEventRecord(c->ev_join, s2));
         GP_HIP(hipEventRecord(c->ev_sjoin, s2));
@@ -1931,7 +1985,8 @@ static void front_half_pair(gpcsd_ctx *c, const gpcsd_hparams *const hp[2], cons
         if (c->slot0_on_s2) c->slot0_on_s2 = false;                 // (ordered behind stream2's last chain by the wait above)
         {
             ProfScope ps(c, "eigh_spatial", 9.0 * (double)nx * nx * nx * 2, s3);
-            eigh_pair_device(c, Ks, nx, es, Qs, sym_s, nullptr, 0, nullptr, nullptr, nullptr, status, s3, false, 2, 2);
+            eigh_pair_device(c, Ks, nx, es, Qs, sym_s, nullptr, 0, nullptr, nullptr, nullptr, status, s3, false, 2, 2, -1,
+                             sfill ? 1 : 0);
         }
         GP_HIP(hipEventRecord(c->ev_sjoin, s3));
         c->tl("S chain end (s3)", s3);

@@ -14,6 +14,7 @@
 #include <algorithm>
 #include <cstdlib>
 
+#include "devutil.hpp"
 #include "jacobi.hpp"
 #include "kernels.hpp"
 
@@ -125,6 +126,128 @@ __global__ __launch_bounds__(256) void sym_fold_kernel(const double *__restrict_
     if (a < na && b < na) Kanti[(long)a * na + b] = 0.5 * asum;
 }
 
+// The same fold for a positive semi-definite K (a covariance matrix), with everything the tridiagonalisation's preparation
+// launches do fused in: replica r folds K + r * sK (sK = 0: one source), adds shift[r] to both blocks' diagonals (F (K + s I)
+// F^T = F K F^T + s I: the jitter of the log-likelihood's Ks needs no copy of Ks), divides each block by a power of two >=
+// its largest entry and writes it where the tridiagonalisation reads it (EigArenaView), reflector storage zeroed, *amax set.
+// The largest entry of a PSD block is on its diagonal, so the scale comes from ns (na) diagonal entries that every workgroup
+// evaluates for itself -- no absmax pass, no second launch.  (A block that is rounding noise next to the other one -- its
+// diagonal may then be exceeded by its off-diagonal noise -- is scaled by at least 2^-30 of the larger block's scale.)
+// Replaces copy -> add_diag -> fold -> absmax -> scale/copy/zero.  Non-finite entries are zeroed and reported (status 4).
+struct PsdFoldFillArgs {
+    const double *K;
+    long sK;
+    int n;
+    double shift[2];
+    SymDev sy;
+    double *A0s, *A0a, *Vs, *Va, *taus, *taua, *amaxs, *amaxa;
+    long blks, blka;
+    int *status;
+    int status_stride;
+    int elem_blocks;
+};
+__device__ __forceinline__ double pow2_at_least(double b) {
+    if (!(b > 0.0 && b <= 1.7e308)) return 1.0;
+    int ex = 0;
+    (void)frexp(b, &ex);                       // b = f 2^ex, f in [0.5, 1)
+    const double m = ldexp(1.0, ex);
+    return (m <= 1.7e308) ? m : b;
+}
+__global__ __launch_bounds__(256) void psd_fold_fill_kernel(PsdFoldFillArgs g) {
+    const int rep = blockIdx.y;
+    const SymDev sy = g.sy;
+    const int ns = sy.ns, na = sy.na, n = g.n;
+    const double *__restrict__ K = g.K + rep * g.sK;
+    const double shift = g.shift[rep];
+    __shared__ double red[4];
+    // scales: largest diagonal entry of each block (every workgroup for itself: <= 4 orbits per thread, L2 hits)
+    const double isq2 = 0.70710678118654752440;
+    double ds = 0.0, da = 0.0;
+    for (int a = threadIdx.x; a < ns; a += 256) {
+        const int i = sy.rep_i[a], j = sy.rep_j[a];
+        const double kii = K[(long)i * n + i];
+        if (i == j) ds = fmax(ds, fabs(kii + shift));
+        else {
+            const double kij = K[(long)i * n + j], kji = K[(long)j * n + i], kjj = K[(long)j * n + j];
+            ds = fmax(ds, fabs(0.5 * (((kii + kij) + kji) + kjj) + shift));
+            da = fmax(da, fabs(0.5 * (((kii - kij) - kji) + kjj) + shift));
+        }
+    }
+    ds = block_max256(ds, red);
+    __syncthreads();
+    da = block_max256(da, red);
+    const double big = fmax(ds, da);
+    const double m_s = pow2_at_least(fmax(ds, big * 9.3132257461547852e-10));
+    const double m_a = pow2_at_least(fmax(da, big * 9.3132257461547852e-10));
+    if ((int)blockIdx.x >= g.elem_blocks) {
+        const long i0 = ((long)blockIdx.x - g.elem_blocks) * 256 + threadIdx.x, stride = ((long)gridDim.x - g.elem_blocks) * 256;
+        double *Vs = g.Vs + rep * g.blks, *Va = g.Va + rep * g.blka, *ts = g.taus + rep * g.blks, *ta = g.taua + rep * g.blka;
+        const long nvs = (long)(ns + 64) * ns, nva = (long)(na + 64) * na;
+        for (long i = i0; i < nvs; i += stride) Vs[i] = 0.0;
+        for (long i = i0; i < nva; i += stride) Va[i] = 0.0;
+        for (long i = i0; i < ns + 64; i += stride) ts[i] = 0.0;
+        for (long i = i0; i < na + 64; i += stride) ta[i] = 0.0;
+        if (blockIdx.x == g.elem_blocks && threadIdx.x == 0) {
+            g.amaxs[rep * g.blks] = m_s;
+            g.amaxa[rep * g.blka] = m_a;
+        }
+        return;
+    }
+    const long e = blockIdx.x * 256L + threadIdx.x;
+    if (e >= (long)ns * ns) return;
+    const int a = (int)(e / ns), b = (int)(e % ns);
+    const int i = sy.rep_i[a], j = sy.rep_j[a], k = sy.rep_i[b], l = sy.rep_j[b];
+    const double kik = K[(long)i * n + k];
+    double ssum = kik, asum = kik;
+    if (l != k) {
+        const double v = K[(long)i * n + l];
+        ssum += v;
+        asum -= v;
+    }
+    if (j != i) {
+        const double v = K[(long)j * n + k];
+        ssum += v;
+        asum -= v;
+        if (l != k) {
+            const double v2 = K[(long)j * n + l];
+            ssum += v2;
+            asum += v2;
+        }
+    }
+    const double wa = (i == j) ? 1.0 : isq2, wb = (k == l) ? 1.0 : isq2;
+    bool bad = false;
+    auto scaled = [&](double x, double m) {
+        x = (m > 1e300) ? x / m : x * (1.0 / m);
+        if (!(fabs(x) <= 2.0)) {
+            x = 0.0;
+            bad = true;
+        }
+        return x;
+    };
+    const double dshift = (a == b) ? shift : 0.0;
+    g.A0s[rep * g.blks + e] = scaled(wa * wb * ssum + dshift, m_s);
+    if (a < na && b < na) g.A0a[rep * g.blka + (long)a * na + b] = scaled(0.5 * asum + dshift, m_a);
+    if (bad && g.status) atomicMax(g.status + (long)rep * g.status_stride, 4);
+}
+
+void k_psd_fold_fill(gpcsd_ctx *c, const double *K, int n, long sK, int nrep, const double *shift, const SymDev &sy,
+                     const EigArenaView &as, const EigArenaView &aa, int *status, int status_stride, hipStream_t s) {
+    GP_REQUIRE(nrep >= 1 && nrep <= 2, -3, "psd fold fill: %d replicas (1 or 2)", nrep);
+    GP_REQUIRE(sy.ns > 0 && sy.ns + sy.na == n, -3, "psd fold fill: the symmetry does not cover the %d points", n);
+    PsdFoldFillArgs g{};
+    g.K = K; g.sK = sK; g.n = n;
+    for (int r = 0; r < nrep; ++r) g.shift[r] = shift ? shift[r] : 0.0;
+    g.sy = sy;
+    g.A0s = as.A0; g.A0a = aa.A0; g.Vs = as.V; g.Va = aa.V; g.taus = as.tau; g.taua = aa.tau; g.amaxs = as.amax; g.amaxa = aa.amax;
+    g.blks = as.blk; g.blka = aa.blk;
+    g.status = status;
+    g.status_stride = status_stride;
+    g.elem_blocks = ceil_div((long)sy.ns * sy.ns, 256);
+    ProfScope ps(c, "psd_fold_fill", 0.0, s);
+    hipLaunchKernelGGL(psd_fold_fill_kernel, dim3(g.elem_blocks + 48, nrep), dim3(256), 0, s, g);
+    GP_HIP(hipGetLastError());
+}
+
 // merge the two ascending spectra and expand the half-size eigenvectors: Z[:, rank] from (Us | Ua)
 __global__ __launch_bounds__(256) void sym_unfold_kernel(int n, SymDev sy, const double *__restrict__ ws,
                                                          const double *__restrict__ Us, const double *__restrict__ wa,
@@ -192,9 +315,12 @@ __global__ void dummy_probe_kernel(int *p) {
     if (p && threadIdx.x == 1234567) *p = 0;
 }
 
+static const char *const FOLD_TAGS[2][3] = {{"p0", "p0s", "p0a"}, {"p1", "p1s", "p1a"}};
+const char *const *eigh_fold_tags(int slot) { return &FOLD_TAGS[slot ? 1 : 0][1]; }
+
 static void eigh_pair_enqueue(gpcsd_ctx *c, double *A0, int n0, double *w0, double *Z0, const SymDev *sym0, double *A1, int n1,
                               double *w1, double *Z1, const SymDev *sym1, int *d_status, hipStream_t s, bool need_merged,
-                              int count, int status_stride, int count1) {
+                              int count, int status_stride, int count1, int prefolded_mask) {
     const int cnt[2] = {count, count1 > 0 ? count1 : count};      // replicas of problem 0 / problem 1
     {   // GPCSD_DUMMY_LAUNCHES=k (measurement only): k empty dependent launches in front of every chain -- what one more
         // kernel boundary costs the chain and the whole step
@@ -210,16 +336,19 @@ static void eigh_pair_enqueue(gpcsd_ctx *c, double *A0, int n0, double *w0, doub
         bool on = false;
         double *ws, *Us, *wa, *Ua;
     } fold[2];
-    static const char *tags[2][3] = {{"p0", "p0s", "p0a"}, {"p1", "p1s", "p1a"}};
+    const char *const (*tags)[3] = FOLD_TAGS;
     // A small problem next to a large one rides along in the large problem's launches for free (GPCSD1D: 24 electrodes
     // next to 500 time points), instead of a serial 250 us single-workgroup Jacobi in front of them.
     const bool pair_has_large = !force_jacobi() && (n0 > JACOBI_LDS_MAX || n1 > JACOBI_LDS_MAX);
-    auto submit = [&](double *Am, int nm, double *wm, double *Zm, const char *tag, long sA, long sw, long sZ, int nrep) {
+    auto submit = [&](double *Am, int nm, double *wm, double *Zm, const char *tag, long sA, long sw, long sZ, int nrep,
+                      bool prefilled = false) {
         if (nm <= 0) return;
         EigReq q;
         q.A = Am; q.n = nm; q.w = wm; q.Z = Zm; q.tag = tag;
         q.count = nrep; q.sA = sA; q.sw = sw; q.sZ = sZ;
+        q.prefilled = prefilled;
         const bool small = nm <= JACOBI_LDS_MAX && !(pair_has_large && nm >= EIG_BATCH_MIN_N);
+        GP_REQUIRE(!prefilled || !(small || force_jacobi()), -3, "eigh: a prefilled class must take the tridiagonalisation path (n=%d)", nm);
         if (small || force_jacobi()) eigh_jacobi(c, q, d_status, status_stride, s);
         else large[nlarge++] = q;
     };
@@ -238,11 +367,14 @@ static void eigh_pair_enqueue(gpcsd_ctx *c, double *A0, int n0, double *w0, doub
             fold[p].Us = fv.U;
             fold[p].wa = fv.w + ns;
             fold[p].Ua = fv.U + (size_t)ns * ns;
-            hipLaunchKernelGGL(sym_fold_kernel, dim3(ceil_div((long)ns * ns, 256), cnt[p]), dim3(256), 0, s, (const double *)A[p],
-                               n[p], *sy, Ks, Ka);
-            submit(Ks, ns, fold[p].ws, fold[p].Us, tags[p][1], (long)ns * ns, fv.sw, fv.sU, cnt[p]);
-            submit(Ka, na, fold[p].wa, fold[p].Ua, tags[p][2], (long)na * na, fv.sw, fv.sU, cnt[p]);
+            const bool pre = (prefolded_mask >> p) & 1;     // the caller wrote the scaled halves into the class arenas itself
+            if (!pre)
+                hipLaunchKernelGGL(sym_fold_kernel, dim3(ceil_div((long)ns * ns, 256), cnt[p]), dim3(256), 0, s, (const double *)A[p],
+                                   n[p], *sy, Ks, Ka);
+            submit(Ks, ns, fold[p].ws, fold[p].Us, tags[p][1], (long)ns * ns, fv.sw, fv.sU, cnt[p], pre);
+            submit(Ka, na, fold[p].wa, fold[p].Ua, tags[p][2], (long)na * na, fv.sw, fv.sU, cnt[p], pre);
         } else {
+            GP_REQUIRE(!((prefolded_mask >> p) & 1), -3, "eigh: problem %d was announced as prefolded but symmetry folding does not apply", p);
             submit(A[p], n[p], w[p], Z[p], tags[p][0], nn, n[p], nn, cnt[p]);
         }
     }
@@ -260,7 +392,7 @@ static void eigh_pair_enqueue(gpcsd_ctx *c, double *A0, int n0, double *w0, doub
 // replayed.  A graph is retired whenever any context buffer is (re)allocated, since it holds raw device pointers.
 void eigh_pair_device(gpcsd_ctx *c, double *A0, int n0, double *w0, double *Z0, const SymDev *sym0, double *A1, int n1,
                       double *w1, double *Z1, const SymDev *sym1, int *d_status, hipStream_t s, bool need_merged, int count,
-                      int status_stride, int count1) {
+                      int status_stride, int count1, int prefolded_mask) {
     if (count < 1) count = 1;
     if (count1 < 1) count1 = count;
     if (n0 > 0) ++c->eig_gen[0];               // whatever a previous call left in this slot's outputs is about to be replaced
@@ -276,15 +408,15 @@ void eigh_pair_device(gpcsd_ctx *c, double *A0, int n0, double *w0, double *Z0, 
     static const bool prof_graph_env = getenv("GPCSD_PROF_GRAPH") != nullptr;
     const bool prof_graph = prof_graph_env || c->prof_mode == 3;
     if (!any_large || (c->prof_on && !prof_graph) || !graphs_enabled()) {
-        eigh_pair_enqueue(c, A0, n0, w0, Z0, sym0, A1, n1, w1, Z1, sym1, d_status, s, need_merged, count, status_stride, count1);
+        eigh_pair_enqueue(c, A0, n0, w0, Z0, sym0, A1, n1, w1, Z1, sym1, d_status, s, need_merged, count, status_stride, count1, prefolded_mask);
         return;
     }
     // (the generation of each slot picks the fold-order output buffers, which are not among the arguments)
     char key[352];
-    snprintf(key, sizeof(key), "eigh|%p|%d|%p|%p|%p|%d|%p|%d|%p|%p|%p|%d|%p|%p|%d|%d|%d|%d%d|%d", (void *)A0, n0, (void *)w0, (void *)Z0,
+    snprintf(key, sizeof(key), "eigh|%p|%d|%p|%p|%p|%d|%p|%d|%p|%p|%p|%d|%p|%p|%d|%d|%d|%d%d|%d|%d", (void *)A0, n0, (void *)w0, (void *)Z0,
              (void *)(sym0 ? sym0->rep_i : nullptr), sym0 ? sym0->ns : 0, (void *)A1, n1, (void *)w1, (void *)Z1,
              (void *)(sym1 ? sym1->rep_i : nullptr), sym1 ? sym1->ns : 0, (void *)d_status, (void *)s, (int)need_merged, count,
-             status_stride, c->par[0], c->par[1], count1);
+             status_stride, c->par[0], c->par[1], count1, prefolded_mask);
     gpcsd_ctx::GraphSlot &g = c->graphs[key];
     if (g.exec && g.epoch == c->alloc_epoch) {
         GP_HIP(hipGraphLaunch(g.exec, s));
@@ -299,7 +431,7 @@ void eigh_pair_device(gpcsd_ctx *c, double *A0, int n0, double *w0, double *Z0, 
         GP_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
         c->capturing = true;
         try {
-            eigh_pair_enqueue(c, A0, n0, w0, Z0, sym0, A1, n1, w1, Z1, sym1, d_status, s, need_merged, count, status_stride, count1);
+            eigh_pair_enqueue(c, A0, n0, w0, Z0, sym0, A1, n1, w1, Z1, sym1, d_status, s, need_merged, count, status_stride, count1, prefolded_mask);
         } catch (...) {
             c->capturing = false;
             (void)hipStreamEndCapture(s, &graph);
@@ -318,7 +450,7 @@ void eigh_pair_device(gpcsd_ctx *c, double *A0, int n0, double *w0, double *Z0, 
             return;
         }
     }
-    eigh_pair_enqueue(c, A0, n0, w0, Z0, sym0, A1, n1, w1, Z1, sym1, d_status, s, need_merged, count, status_stride, count1);
+    eigh_pair_enqueue(c, A0, n0, w0, Z0, sym0, A1, n1, w1, Z1, sym1, d_status, s, need_merged, count, status_stride, count1, prefolded_mask);
     g.seen_epoch = c->alloc_epoch;
 }
 
@@ -328,7 +460,7 @@ void eigh_device(gpcsd_ctx *c, double *A, int n, double *evals, double *evecs, i
     GP_REQUIRE(n <= JACOBI_MAX_N, GPCSD_ERR_CAPACITY, "eigh: matrix order %d exceeds the eigensolver's capacity of %d rows (GPCSD_MAX_EIG_N)", n,
                JACOBI_MAX_N);
     (void)tag;
-    eigh_pair_device(c, A, n, evals, evecs, nullptr, nullptr, 0, nullptr, nullptr, nullptr, d_status, s, true, 1, 0);
+    eigh_pair_device(c, A, n, evals, evecs, nullptr, nullptr, 0, nullptr, nullptr, nullptr, d_status, s, true, 1, 0, -1, 0);
 }
 
 }  // namespace gpcsd

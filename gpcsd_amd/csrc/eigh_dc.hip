@@ -371,6 +371,7 @@ struct EigProb {                 // one class: `count` replicas, inputs / output
     std::string tag;
     int count = 1;
     long sA = 0, sw = 0, sZ = 0;
+    bool prefilled = false;      // EigReq::prefilled
     double *amax;                // 2 + AMAX_PARTS doubles per replica (in the arena)
     double *wyT;                 // T factors of the compact-WY panels (in the arena)
     SytrdProb sp;
@@ -387,27 +388,39 @@ struct ArenaLayout {
     }
 };
 
+// the class arena (grow-only: the same (tag, n, count) always maps to the same slices)
+static void layout_arena(gpcsd_ctx *c, const std::string &tag, int n, int count, SytrdProb &sp, double *&amax, double *&wyT) {
+    const size_t nn = (size_t)n * n;
+    const std::string T = "eig_" + tag + "_";
+    const int npanels = std::max(1, ceil_div(std::max(n - 2, 1), WY_NB));
+    ArenaLayout L;
+    const size_t oA0 = L.take(nn), oA1 = L.take(nn), oV = L.take((size_t)(n + WY_NB) * n), otau = L.take(n + WY_NB);
+    const size_t od = L.take(n), oe = L.take(n), oy0 = L.take(n), oy1 = L.take(n), oamax = L.take(2 + AMAX_PARTS);
+    const size_t oT = L.take((size_t)npanels * WY_NB * WY_NB);
+    double *base = c->buf<double>(T + "arena", L.off * (size_t)std::max(count, 1));
+    sp.blk = (long)L.off;
+    sp.A0 = base + oA0; sp.A1 = base + oA1; sp.V = base + oV; sp.tau = base + otau;
+    sp.d = base + od; sp.e = base + oe; sp.y0 = base + oy0; sp.y1 = base + oy1;
+    amax = base + oamax;
+    wyT = base + oT;
+}
+
+EigArenaView eigh_arena_view(gpcsd_ctx *c, const char *tag, int n, int count) {
+    SytrdProb sp{};
+    double *amax = nullptr, *wyT = nullptr;
+    layout_arena(c, tag, n, count, sp, amax, wyT);
+    return EigArenaView{sp.A0, sp.V, sp.tau, amax, sp.blk};
+}
+
 static void prep_problem(gpcsd_ctx *c, EigProb &p, hipStream_t s) {
     const int n = p.n;
-    const size_t nn = (size_t)n * n;
-    const std::string T = "eig_" + p.tag + "_";
     p.sp.n = n;
     {
         static const bool no_tail = getenv("GPCSD_NO_TAIL") && getenv("GPCSD_NO_TAIL")[0] == '1';
         // the trailing block finishes inside one workgroup (192 rows in registers + up to 64 strip rows in LDS)
         p.sp.k_tail = no_tail ? n - 1 : std::max(0, n - sy_regtail_rows());
     }
-    const int npanels = std::max(1, ceil_div(std::max(n - 2, 1), WY_NB));
-    ArenaLayout L;
-    const size_t oA0 = L.take(nn), oA1 = L.take(nn), oV = L.take((size_t)(n + WY_NB) * n), otau = L.take(n + WY_NB);
-    const size_t od = L.take(n), oe = L.take(n), oy0 = L.take(n), oy1 = L.take(n), oamax = L.take(2 + AMAX_PARTS);
-    const size_t oT = L.take((size_t)npanels * WY_NB * WY_NB);
-    double *base = c->buf<double>(T + "arena", L.off * (size_t)std::max(p.count, 1));
-    p.sp.blk = (long)L.off;
-    p.sp.A0 = base + oA0; p.sp.A1 = base + oA1; p.sp.V = base + oV; p.sp.tau = base + otau;
-    p.sp.d = base + od; p.sp.e = base + oe; p.sp.y0 = base + oy0; p.sp.y1 = base + oy1;
-    p.amax = base + oamax;
-    p.wyT = base + oT;
+    layout_arena(c, p.tag, n, p.count, p.sp, p.amax, p.wyT);
     (void)s;
 }
 
@@ -420,6 +433,7 @@ struct PrepBatch {
     double *w[MAX_BATCH];       // eigenvalue outputs (for the final rescale)
     long sw[MAX_BATCH];
     int start[MAX_BATCH + 1];
+    int skip[MAX_BATCH];        // the class is prefilled (EigReq::prefilled): its arena already holds the scaled matrix
     int *status;                // numerical-failure words of the call (non-finite input is reported there) ...
     int status_stride;          // ... one per replica index when != 0
 };
@@ -428,6 +442,7 @@ struct PrepView {
     double *amax, *w;
     SytrdProb P;
     int *status;
+    bool skip;
 };
 __device__ __forceinline__ PrepView prep_resolve(const PrepBatch &b, int g) {
     int cls, rep;
@@ -440,11 +455,13 @@ __device__ __forceinline__ PrepView prep_resolve(const PrepBatch &b, int g) {
     v.amax = b.amax[cls] + o;
     v.w = b.w[cls] ? b.w[cls] + rep * b.sw[cls] : nullptr;
     v.status = b.status ? b.status + (long)rep * b.status_stride : nullptr;
+    v.skip = b.skip[cls] != 0;
     return v;
 }
 __global__ __launch_bounds__(256) void absmax_partial_batch_kernel(PrepBatch b) {
     __shared__ double red[4];
     const PrepView v = prep_resolve(b, blockIdx.y);
+    if (v.skip) return;
     const long n2 = (long)v.P.n * v.P.n;
     const double *__restrict__ A = v.A;
     double m = 0.0;
@@ -454,6 +471,7 @@ __global__ __launch_bounds__(256) void absmax_partial_batch_kernel(PrepBatch b) 
 }
 __global__ __launch_bounds__(256) void scale_copy_zero_batch_kernel(PrepBatch b) {
     const PrepView v = prep_resolve(b, blockIdx.y);
+    if (v.skip) return;
     const SytrdProb &P = v.P;
     const long n = P.n, n2 = n * n;
     double *amax = v.amax;
@@ -497,12 +515,17 @@ static PrepBatch prep_batch_launch(gpcsd_ctx *c, EigProb *probs, int nclass, hip
         pb.sp[i] = probs[i].sp;
         pb.w[i] = probs[i].w;
         pb.sw[i] = probs[i].sw;
+        pb.skip[i] = probs[i].prefilled ? 1 : 0;
         total += std::max(probs[i].count, 1);
     }
     pb.start[MAX_BATCH] = total;
-    hipLaunchKernelGGL(absmax_partial_batch_kernel, dim3(AMAX_PARTS, total), dim3(256), 0, s, pb);
-    hipLaunchKernelGGL(scale_copy_zero_batch_kernel, dim3(128, total), dim3(256), 0, s, pb);
-    GP_HIP(hipGetLastError());
+    bool any = false;
+    for (int i = 0; i < nclass; ++i) any = any || !probs[i].prefilled;
+    if (any) {                                  // (every class prefilled: the chain starts at the tridiagonalisation)
+        hipLaunchKernelGGL(absmax_partial_batch_kernel, dim3(AMAX_PARTS, total), dim3(256), 0, s, pb);
+        hipLaunchKernelGGL(scale_copy_zero_batch_kernel, dim3(128, total), dim3(256), 0, s, pb);
+        GP_HIP(hipGetLastError());
+    }
     return pb;
 }
 
@@ -597,6 +620,7 @@ void eigh_large_multi(gpcsd_ctx *c, const EigReq *reqs, int nclass, int *d_statu
         probs[i].tag = reqs[i].tag;
         probs[i].count = std::max(reqs[i].count, 1);
         probs[i].sA = reqs[i].sA; probs[i].sw = reqs[i].sw; probs[i].sZ = reqs[i].sZ;
+        probs[i].prefilled = reqs[i].prefilled;
     }
     eigh_large_batch(c, probs, nclass, d_status, status_stride, s);
 }

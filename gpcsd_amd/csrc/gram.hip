@@ -153,6 +153,140 @@ void k_temporal_gram(gpcsd_ctx *c, int ncomp, const int *kind, const double *ell
     GP_HIP(hipGetLastError());
 }
 
+// ------------------------------------------------------------------------------------------------
+// temporal chain input in one launch (see kernels.hpp: k_temporal_fold_fill)
+// ------------------------------------------------------------------------------------------------
+struct TFoldFillArgs {
+    TemporalSet set[2];          // hyper-parameters of replica 0 / 1
+    double inv_m[2], m[2];       // scale of replica r: entries are multiplied by inv_m = 1 / m (m a power of two)
+    SymDev sy;
+    const double *t;
+    int n;
+    double *A0s, *A0a, *Vs, *Va, *taus, *taua, *amaxs, *amaxa;
+    long blks, blka;
+    int *status;
+    int status_stride;
+    int elem_blocks;
+};
+
+template <typename T>
+__device__ __forceinline__ double tset_eval(const TemporalSet &p, const T ti, const T tj) {
+    const T d = ti - tj;
+    T acc = T(0);                                                      // Kt = zeros; Kt = Kt + K_c (gpcsd1d.py:118-120)
+    for (int cc = 0; cc < p.ncomp; ++cc) {
+        const T ell = T(p.ell[cc]), s2 = T(p.sigma2[cc]);
+        T v;
+        if (p.kind[cc] == GPCSD_KIND_SE)
+            v = s2 * exp(T(-0.5) * (d * d) / (ell * ell));             // covariances.py:270
+        else
+            v = s2 * exp(-sqrt(d * d) / ell);                          // covariances.py:304
+        acc = acc + v;
+    }
+    return (double)acc;
+}
+
+// blockIdx.y = replica.  Blocks [0, elem_blocks): one entry (a, b) of the symmetric block per thread (and of the
+// antisymmetric block when a, b < na), the four Kt entries of the two orbits evaluated in place and combined exactly as
+// sym_fold_kernel combines them.  Blocks beyond: zero-fill of the reflector storage of both classes.
+template <typename T>
+__global__ __launch_bounds__(256) void temporal_fold_fill_kernel(TFoldFillArgs g) {
+    const int rep = blockIdx.y;
+    const SymDev sy = g.sy;
+    const int ns = sy.ns, na = sy.na;
+    if ((int)blockIdx.x >= g.elem_blocks) {
+        const long i0 = ((long)blockIdx.x - g.elem_blocks) * 256 + threadIdx.x, stride = ((long)gridDim.x - g.elem_blocks) * 256;
+        double *Vs = g.Vs + rep * g.blks, *Va = g.Va + rep * g.blka, *ts = g.taus + rep * g.blks, *ta = g.taua + rep * g.blka;
+        const long nvs = (long)(ns + 64) * ns, nva = (long)(na + 64) * na;
+        for (long i = i0; i < nvs; i += stride) Vs[i] = 0.0;
+        for (long i = i0; i < nva; i += stride) Va[i] = 0.0;
+        for (long i = i0; i < ns + 64; i += stride) ts[i] = 0.0;
+        for (long i = i0; i < na + 64; i += stride) ta[i] = 0.0;
+        if (blockIdx.x == g.elem_blocks && threadIdx.x == 0) {
+            g.amaxs[rep * g.blks] = g.m[rep];
+            g.amaxa[rep * g.blka] = g.m[rep];
+        }
+        return;
+    }
+    const long e = blockIdx.x * 256L + threadIdx.x;
+    if (e >= (long)ns * ns) return;
+    const TemporalSet &p = g.set[rep];
+    const int a = (int)(e / ns), b = (int)(e % ns);
+    const int i = sy.rep_i[a], j = sy.rep_j[a], k = sy.rep_i[b], l = sy.rep_j[b];
+    const T ti = T(g.t[i]), tj = T(g.t[j]), tk = T(g.t[k]), tl = T(g.t[l]);
+    const double kik = tset_eval<T>(p, ti, tk);
+    double ssum = kik, asum = kik;
+    if (l != k) {
+        const double v = tset_eval<T>(p, ti, tl);
+        ssum += v;
+        asum -= v;
+    }
+    if (j != i) {
+        const double v = tset_eval<T>(p, tj, tk);
+        ssum += v;
+        asum -= v;
+        if (l != k) {
+            const double v2 = tset_eval<T>(p, tj, tl);
+            ssum += v2;
+            asum += v2;
+        }
+    }
+    const double isq2 = 0.70710678118654752440;
+    const double wa = (i == j) ? 1.0 : isq2, wb = (k == l) ? 1.0 : isq2;
+    const double m = g.m[rep], inv = g.inv_m[rep];
+    bool bad = false;
+    auto scaled = [&](double x) {
+        x = (m > 1e300) ? x / m : x * inv;          // 1 / m is subnormal beyond 1e300
+        if (!(fabs(x) <= 2.0)) {                    // non-finite (a NaN / inf hyper-parameter): never reaches the solver
+            x = 0.0;
+            bad = true;
+        }
+        return x;
+    };
+    g.A0s[rep * g.blks + e] = scaled(wa * wb * ssum);
+    if (a < na && b < na) g.A0a[rep * g.blka + (long)a * na + b] = scaled(0.5 * asum);
+    if (bad && g.status) atomicMax(g.status + (long)rep * g.status_stride, 4);
+}
+
+void k_temporal_fold_fill(gpcsd_ctx *c, const TemporalSet *sets, int nrep, const double *t, int n, const SymDev &sy,
+                          const EigArenaView &as, const EigArenaView &aa, int *status, int status_stride, hipStream_t s) {
+    GP_REQUIRE(nrep >= 1 && nrep <= 2, -3, "temporal fold fill: %d replicas (1 or 2)", nrep);
+    GP_REQUIRE(sy.ns > 0 && sy.ns + sy.na == n, -3, "temporal fold fill: the symmetry does not cover the %d time points", n);
+    TFoldFillArgs g{};
+    for (int r = 0; r < nrep; ++r) {
+        g.set[r] = sets[r];
+        GP_REQUIRE(sets[r].ncomp >= 1 && sets[r].ncomp <= GPCSD_MAX_TEMPORAL, -3, "temporal gram: %d components (max %d)",
+                   sets[r].ncomp, GPCSD_MAX_TEMPORAL);
+        // every entry of either block is a signed combination of four kernel values with weights summing to at most 2
+        double bound = 0.0;
+        for (int cc = 0; cc < sets[r].ncomp; ++cc) bound += fabs(sets[r].sigma2[cc]);
+        bound *= 2.0;
+        double m = 1.0;
+        if (bound > 0.0 && bound <= 1.7e308) {
+            int ex = 0;
+            (void)frexp(bound, &ex);                // bound = f * 2^ex, f in [0.5, 1)
+            m = ldexp(1.0, ex);
+            if (!(m <= 1.7e308)) m = bound;         // 2^1024 overflows: fall back to the bound itself
+        }
+        g.m[r] = m;
+        g.inv_m[r] = 1.0 / m;
+    }
+    g.sy = sy;
+    g.t = t;
+    g.n = n;
+    g.A0s = as.A0; g.A0a = aa.A0; g.Vs = as.V; g.Va = aa.V; g.taus = as.tau; g.taua = aa.tau; g.amaxs = as.amax; g.amaxa = aa.amax;
+    g.blks = as.blk; g.blka = aa.blk;
+    g.status = status;
+    g.status_stride = status_stride;
+    g.elem_blocks = ceil_div((long)sy.ns * sy.ns, 256);
+    const int zero_blocks = 64;
+    ProfScope ps(c, "gram_temporal_fold_fill", 0.0, s);
+    if (c->gram_fp32)
+        hipLaunchKernelGGL(temporal_fold_fill_kernel<float>, dim3(g.elem_blocks + zero_blocks, nrep), dim3(256), 0, s, g);
+    else
+        hipLaunchKernelGGL(temporal_fold_fill_kernel<double>, dim3(g.elem_blocks + zero_blocks, nrep), dim3(256), 0, s, g);
+    GP_HIP(hipGetLastError());
+}
+
 // A(nx, ngl) = gl_w[g] * b_fwd_1d(gl_x[g] - x[i], R)                      covariances.py:86-88
 template <typename T>
 __global__ __launch_bounds__(256) void fwd_weights_1d_kernel(const double *__restrict__ x, int nx,

@@ -133,7 +133,35 @@ struct EigReq {
     const char *tag;
     int count = 1;
     long sA = 0, sw = 0, sZ = 0;
+    bool prefilled = false;      // the scaled matrix is already in the class arena (eigh_arena_view): no scaling / copy pass
 };
+// Where the tridiagonalisation of class `tag` (order n, `count` replicas) expects its input: A0 = the matrix divided by
+// *amax (replica r at A0 + r*blk, *amax at amax + r*blk), with the reflector storage V ((n + 64) x n) and tau (n + 64) zeroed.
+// A caller that can generate the scaled matrix itself (k_temporal_fold_fill) writes it there and submits the class as
+// `prefilled`, which takes the fold / absmax / scale launches out of the dependent chain.
+struct EigArenaView {
+    double *A0, *V, *tau, *amax;
+    long blk;
+};
+EigArenaView eigh_arena_view(gpcsd_ctx *c, const char *tag, int n, int count);
+// tags of the two half-size classes of problem `slot` (0 / 1) of eigh_pair_device: [0] symmetric, [1] antisymmetric
+const char *const *eigh_fold_tags(int slot);
+// fold of a PSD matrix (+ diagonal shift per replica) straight into the class arenas, scaled: see eigh.hip
+void k_psd_fold_fill(gpcsd_ctx *c, const double *K, int n, long sK, int nrep, const double *shift, const SymDev &sy,
+                     const EigArenaView &as, const EigArenaView &aa, int *status, int status_stride, hipStream_t s);
+// The temporal chain's input in ONE launch: the symmetric / antisymmetric fold of Kt = sum_c sigma2_c k_c(t_i - t_j) for
+// `nrep` hyper-parameter sets, evaluated entry by entry from the time grid (the same expressions, in the same order, as
+// k_temporal_gram followed by the eigensolver's fold), divided by a power of two >= 2 sum_c sigma2_c (>= every entry of
+// either block) and written where the tridiagonalisation reads it (eigh_arena_view of the two half-size classes), reflector
+// storage zeroed, *amax set.  Replaces temporal Gram -> fold -> absmax -> scale/copy/zero (five dependent launches).
+// Non-finite entries are zeroed and reported in status[r * status_stride] (4), as the scaling pass does.
+struct TemporalSet {
+    int ncomp;
+    int kind[GPCSD_MAX_TEMPORAL];
+    double ell[GPCSD_MAX_TEMPORAL], sigma2[GPCSD_MAX_TEMPORAL];
+};
+void k_temporal_fold_fill(gpcsd_ctx *c, const TemporalSet *sets, int nrep, const double *t, int n, const SymDev &sy,
+                          const EigArenaView &as, const EigArenaView &aa, int *status, int status_stride, hipStream_t s);
 // flat problem index g -> (class, replica) from the prefix sums start[0..MAX_EIG_BATCH] (unused classes repeat the total)
 __device__ __forceinline__ void class_of(const int *start, int g, int &cls, int &rep) {
     cls = (g >= start[1]) + (g >= start[2]) + (g >= start[3]);
@@ -144,9 +172,12 @@ __device__ __forceinline__ void class_of(const int *start, int g, int &cls, int 
 // need_merged = false: a caller that stays in the folded basis (eigh_fold_view) skips the unfold + rank merge of folded problems
 // count > 1: `count` replicas of both problems (inputs n*n apart, eigenvalues n apart, eigenvectors n*n apart); replica r
 // reports numerical failure in d_status[r * status_stride] (status_stride 0: one shared word)
+// prefolded_mask bit p: the folded halves of problem p are already in their class arenas, scaled (see EigArenaView); A_p is
+// then not read (symmetry folding must apply to that problem: eigh_fold_view(...).on)
 void eigh_pair_device(gpcsd_ctx *c, double *A0, int n0, double *w0, double *Z0, const SymDev *sym0, double *A1, int n1,
                       double *w1, double *Z1, const SymDev *sym1, int *d_status, hipStream_t s, bool need_merged = true,
-                      int count = 1, int status_stride = 0, int count1 = -1);   // count1 > 0: replicas of problem 1 (else = count)
+                      int count = 1, int status_stride = 0, int count1 = -1,   // count1 > 0: replicas of problem 1 (else = count)
+                      int prefolded_mask = 0);
 // Half-size results of a symmetry-folded problem, in fold order (see eigh.hip); on == false: the problem is not folded.
 struct FoldView {
     bool on = false;
