@@ -68,6 +68,47 @@ class HParams(ctypes.Structure):
                 ("n_sig2n", ctypes.c_int), ("sig2n", _c_double_p), ("jitter", ctypes.c_double)]
 
 
+# the same struct as a NumPy record: a whole batch of hyper-parameter sets is filled column by column
+HPARAMS_DTYPE = np.dtype({"names": ["R", "eps", "ell_s", "n_temporal", "kind", "ell_t", "sigma2_t", "n_sig2n", "sig2n", "jitter"],
+                          "formats": ["f8", "f8", ("f8", (2,)), "i4", ("i4", (MAX_TEMPORAL,)), ("f8", (MAX_TEMPORAL,)),
+                                      ("f8", (MAX_TEMPORAL,)), "i4", "u8", "f8"],
+                          "offsets": [getattr(HParams, n).offset for n, _ in HParams._fields_],
+                          "itemsize": ctypes.sizeof(HParams)})
+
+
+class HParamsBatch:
+    """B hyper-parameter structs in one contiguous block (what gpcsd_loglik_grad_batch takes), with the scalar noise variances
+    they point to; built from arrays without a Python loop over the sets."""
+
+    def __init__(self, R, eps, ell_s, kinds, ell_t, sigma2_t, sig2n, jitter):
+        R = np.asarray(R, dtype=np.float64)
+        B = R.shape[0]
+        C = len(kinds)
+        if not (1 <= C <= MAX_TEMPORAL):
+            raise ValueError("between 1 and %d temporal covariance components are supported" % MAX_TEMPORAL)
+        rec = np.zeros(B, dtype=HPARAMS_DTYPE)
+        rec["R"] = R
+        rec["eps"] = eps if eps is not None else 0.0
+        ell_s = np.asarray(ell_s, dtype=np.float64).reshape(B, -1)
+        rec["ell_s"][:, :ell_s.shape[1]] = ell_s
+        rec["n_temporal"] = C
+        rec["kind"][:, :C] = np.asarray(kinds, dtype=np.int32)[None, :]
+        rec["ell_t"][:, :C] = np.asarray(ell_t, dtype=np.float64).reshape(B, C)
+        rec["sigma2_t"][:, :C] = np.asarray(sigma2_t, dtype=np.float64).reshape(B, C)
+        self.sig = np.ascontiguousarray(np.asarray(sig2n, dtype=np.float64).reshape(B))
+        rec["n_sig2n"] = 1
+        rec["sig2n"] = self.sig.ctypes.data + 8 * np.arange(B, dtype=np.uint64)
+        rec["jitter"] = jitter
+        self.rec = rec
+        self.B = B
+
+    def __len__(self):
+        return self.B
+
+    def pointer(self):
+        return ctypes.cast(self.rec.ctypes.data, ctypes.POINTER(HParams))
+
+
 class HipUnavailable(RuntimeError):
     pass
 
@@ -541,7 +582,7 @@ class Context:
         """hps: list of HParams (same kernel kinds, scalar noise).  One shared chain of launches for all of them.
         Returns (sumlog (B,), quad (B,), grad (B, ngrad), status (B,)); status[i] > 0: set i failed numerically."""
         B = len(hps)
-        arr = (HParams * B)(*hps)
+        arr = hps.pointer() if isinstance(hps, HParamsBatch) else (HParams * B)(*hps)
         out = np.empty((B, 2))
         g = np.empty((B, ngrad))
         st = np.zeros(B, dtype=np.int32)

@@ -235,10 +235,10 @@ class GPCSDModel:
         r_local = self._local_lfp().shape[2]
         return -0.5 * r_local * sumlog - 0.5 * quad, g, st
 
-    def _loglik_and_grad_natural_batch(self, hps):
-        """[(loglik, gradient) or LinAlgError] for a list of hyper-parameter structs; shards combine with ONE all-reduce for
-        the whole batch.  Slot b of the list must mean the same hyper-parameter set on every rank (the lock-step evaluator
-        hands its batches over sorted by restart index for exactly this reason)."""
+    def _eval_batch_reduced(self, hps):
+        """(loglik [B], natural gradient [B, ng], failed [B]) of a batch over ALL trials: the local evaluation, and under trial
+        sharding ONE all-reduce for the whole batch.  Slot b must mean the same hyper-parameter set on every rank (the
+        lock-step drivers hand their batches over sorted by restart index for exactly this reason)."""
         ll, g, st = self._eval_batch_local(hps)
         ll, g, st = np.asarray(ll, dtype=np.float64), np.asarray(g, dtype=np.float64), np.asarray(st)
         B, ng = g.shape
@@ -246,13 +246,16 @@ class GPCSDModel:
         if sh is not None:                       # both pieces are additive over shards; a set that failed anywhere fails everywhere
             red = sh.allreduce_sum(np.concatenate([ll, g.ravel(), (st != 0).astype(np.float64)]))
             ll, g, st = red[:B], red[B:B + B * ng].reshape(B, ng), red[B + B * ng:]
-        out = []
-        for b in range(B):
-            if st[b] != 0:
-                out.append(np.linalg.LinAlgError("numerical failure in the eigensolver (hyper-parameter set %d of the batch)" % b))
-            else:
-                out.append((float(ll[b]), np.array(g[b])))
-        return out
+        return ll, g, st != 0
+
+    @staticmethod
+    def _batch_failure(b):
+        return np.linalg.LinAlgError("numerical failure in the eigensolver (hyper-parameter set %d of the batch)" % b)
+
+    def _loglik_and_grad_natural_batch(self, hps):
+        """[(loglik, gradient) or LinAlgError] for a batch of hyper-parameter structs."""
+        ll, g, failed = self._eval_batch_reduced(hps)
+        return [self._batch_failure(b) if failed[b] else (float(ll[b]), np.array(g[b])) for b in range(len(ll))]
 
     # ------------------------------------------------------------------ fit
     def _param_slots(self):
@@ -345,6 +348,13 @@ class GPCSDModel:
         with np.errstate(all="ignore"):          # the reference runs under np.seterr(all='ignore') (gpcsd1d.py:7)
             tparams = np.asarray(tparams, dtype=np.float64)
             if getattr(self, "_use_analytic_grad", True) and not self._uses_host_kt():
+                if self._batch_can_evaluate() and self._vector_glue_applies():
+                    # the batch of one: the same array expressions (and the same device code, gpcsd_loglik_grad is the B = 1 case
+                    # of gpcsd_loglik_grad_batch), so a restart gets the same bits alone and in a lock-step batch
+                    r = self._objective_and_grad_batch([(0, tparams)], fix_R)[0]
+                    if isinstance(r, Exception):
+                        raise r
+                    return r
                 self._set_from_tparams(tparams, fix_R)
                 lp = self._log_prior()
                 ll, g_nat = self._loglik_and_grad_natural()
@@ -417,9 +427,56 @@ class GPCSDModel:
                 cls._loglik_and_grad_natural is GPCSDModel._loglik_and_grad_natural))
         return (own and getattr(self, "_use_analytic_grad", True) and self._sig2n_is_scalar() and not self._uses_host_kt())
 
+    def _vector_glue_applies(self):
+        """The hyper-parameters of a batch can be unpacked, their priors evaluated and the chain rule applied as array
+        operations: scalar noise, the library's own temporal kernels, priors that offer lpdf_many / dlpdf_many."""
+        if not (self._sig2n_is_scalar() and not self._uses_host_kt()):
+            return False
+        priors = [sl[2] for sl in self._param_slots()] + [self.sig2n["prior"]]
+        return all(callable(getattr(pr, "lpdf_many", None)) and callable(getattr(pr, "dlpdf_many", None)) for pr in priors)
+
     def _objective_and_grad_batch(self, items, fix_R):
         """{key: (objective, gradient) or exception} for [(key, tparams)]: the lock-step evaluation behind fit(batch=k).
-        Runs single-threaded (every optimiser chain is blocked on its result), so walking the shared param dicts is safe."""
+        Runs single-threaded (every optimiser chain is waiting for its result), so walking the shared param dicts is safe.
+        With the library's own priors and kernels the host side of a batch is array arithmetic (B x p): per tick of a 32-restart
+        fit the Python loop below it cost about as much as a quarter of the device evaluation."""
+        if not self._vector_glue_applies():
+            return self._objective_and_grad_batch_loop(items, fix_R)
+        with np.errstate(all="ignore"):
+            slots = self._param_slots()
+            p = len(slots)
+            tps = np.stack([np.asarray(tp, dtype=np.float64) for _, tp in items])                 # (B, p + 1)
+            scales = np.array([sl[4] for sl in slots] + [1.0])
+            nat = np.exp(tps) * scales                                                            # natural values, slot order
+            if fix_R:
+                nat[:, 0] = slots[0][0]()
+            priors = [sl[2] for sl in slots] + [self.sig2n["prior"]]
+            lp = np.zeros(len(items))
+            for i, pr in enumerate(priors):                                                       # same order as _log_prior
+                lp = lp + pr.lpdf_many(nat[:, i])
+            ns = len(self._spatial_names)
+            C = len(self.temporal_cov_list)
+            kinds = [k for k, _, _ in self._temporal_triplets()]
+            tcols = nat[:, 1 + ns:1 + ns + 2 * C]
+            hps = _hip.HParamsBatch(nat[:, 0], getattr(self, "eps", 0.0), nat[:, 1:1 + ns], kinds, tcols[:, 0::2], tcols[:, 1::2],
+                                    nat[:, p], self.JITTER)
+            if getattr(self, "_resident", {}).get("host_kt"):
+                self._context().set_host_temporal_gram(None)
+                self._resident["host_kt"] = False
+            ll, g_nat, failed = self._eval_batch_reduced(hps)
+            dlp = np.stack([pr.dlpdf_many(nat[:, i]) for i, pr in enumerate(priors)], axis=1)
+            G = -(g_nat + dlp) * nat                                                              # d/dlog(v) = v d/dv
+            if fix_R:
+                G[:, 0] = 0.0
+            F = -1.0 * (ll + lp)
+            out = {}
+            for b, (key, _) in enumerate(items):
+                out[key] = self._batch_failure(b) if failed[b] else (F[b], G[b])
+            self._set_from_tparams(tps[-1], fix_R)       # the param dicts hold the last point evaluated, as after a scalar call
+            return out
+
+    def _objective_and_grad_batch_loop(self, items, fix_R):
+        """The same, one hyper-parameter set at a time through the param dicts (user-defined priors without array methods)."""
         with np.errstate(all="ignore"):
             hps, keep, lps, tps = [], [], [], []
             for _, tp in items:
@@ -455,6 +512,8 @@ class GPCSDModel:
 
     # device memory a lock-step batch may take for its per-set arrays (five of nx * ntrials * nt doubles per set)
     FIT_BATCH_BYTES = 32 << 30
+    # "auto" | "setulb" | "threads": who steps the restarts' optimisers between batched evaluations (see _fit)
+    fit_driver = "auto"
 
     def _auto_batch(self, n):
         """Default lock-step width of fit(): all restarts of this rank, capped at 32 and by FIT_BATCH_BYTES."""
@@ -496,13 +555,42 @@ class GPCSDModel:
             # groups drift out of phase and one's eigen chains run under the other's GEMMs.  Not under trial sharding: the
             # groups' all-reduces would interleave differently on different ranks.
             from .lockstep import run_chains
+            from . import lbfgsb_lockstep
             ngroups = 1 if getattr(self, "_sharding", None) is not None else max(1, min(workers, len(mine) // 2))
             parts = [mine[gi::ngroups] for gi in range(ngroups)]
+            # Who steps the optimisers between the batched evaluations.  "setulb" (the default where this SciPy has it): ONE
+            # driver steps every chain's L-BFGS-B state through SciPy's reverse-communication entry point -- the same compiled
+            # optimiser scipy.optimize.minimize runs, the same trajectories bit for bit, without a thread, two condition-variable
+            # hand-offs and a GIL switch per chain and evaluation.  "threads": unmodified minimize() calls on threads that
+            # rendezvous in their objective callbacks (round 2; any `method`).
+            driver = getattr(self, "fit_driver", "auto")
+            use_setulb = (method == "L-BFGS-B" and driver in ("auto", "setulb") and lbfgsb_lockstep.available())
+            if driver == "setulb" and not use_setulb:
+                raise RuntimeError("fit_driver='setulb' needs method='L-BFGS-B' and scipy.optimize._lbfgsb.setulb")
+            self.fit_driver_used_ = "setulb" if use_setulb else "threads"
+
+            class _Stats:
+                batches = points = 0
 
             def run_group(model, ks):
-                return run_chains([starts[k] for k in ks],
-                                  lambda s0, evaluate: model._run_restart(s0, method, fix_R, options, bounds, evaluate),
-                                  lambda items: model._objective_and_grad_batch(items, fix_R), min(batch, len(ks)))
+                if not use_setulb:
+                    return run_chains([starts[k] for k in ks],
+                                      lambda s0, evaluate: model._run_restart(s0, method, fix_R, options, bounds, evaluate),
+                                      lambda items: model._objective_and_grad_batch(items, fix_R), min(batch, len(ks)))
+                res, st = lbfgsb_lockstep.minimize_many(lambda items: model._objective_and_grad_batch(items, fix_R),
+                                                        [starts[k] for k in ks], bounds, options, min(batch, len(ks)))
+                out = {}
+                for i in range(len(ks)):
+                    r = res[i]
+                    if isinstance(r, Exception):          # what _run_restart does with a failed restart (gpcsd1d.py:219, gpcsd2d.py:258-260)
+                        print(r)
+                        if model.dim == 2:
+                            print("\nrestarting optimization...")
+                        r = None
+                    out[i] = r
+                ev = _Stats()
+                ev.batches, ev.points = st["batches"], st["points"]
+                return out, ev
             if ngroups == 1:
                 outs = [run_group(self, parts[0])]
             else:

@@ -2,7 +2,8 @@
 
 Mirrors src/gpcsd/priors.py of the reference: `GPCSDInvGammaPrior` (lpdf :23-28, set_params :30-32,
 sample :34-35) and `GPCSDHalfNormalPrior` (lpdf :46-51, sample :53-54).  `dlpdf` (derivative of lpdf) is an
-addition used by the analytic gradient that replaces the reference's autograd tape.
+addition used by the analytic gradient that replaces the reference's autograd tape; `lpdf_many` / `dlpdf_many` are the same
+expressions on arrays (all restarts of a lock-step fit at once).
 """
 import numpy as np
 from scipy import stats as _stats
@@ -40,6 +41,17 @@ class GPCSDInvGammaPrior(GPCSDPrior):
     def dlpdf(self, x):
         return -(self.alpha + 1.0) / x + self.beta / (x * x)
 
+    # the same two expressions elementwise on an array of values (the lock-step fit evaluates all restarts' priors at once)
+    def lpdf_many(self, x):
+        x = np.asarray(x, dtype=np.float64)
+        with np.errstate(all="ignore"):
+            return np.where(x <= 0, -np.inf, -(self.alpha + 1.0) * np.log(x) - self.beta / x)
+
+    def dlpdf_many(self, x):
+        x = np.asarray(x, dtype=np.float64)
+        with np.errstate(all="ignore"):
+            return -(self.alpha + 1.0) / x + self.beta / (x * x)
+
     def set_params(self, l, u):
         """Shape/scale so that most of the mass lies in [l, u] (same rule as the reference)."""
         ratio = (l + u) / (u - l)
@@ -66,6 +78,15 @@ class GPCSDHalfNormalPrior(GPCSDPrior):
         return -0.5 * np.square(x / self.sd)
 
     def dlpdf(self, x):
+        return -x / (self.sd * self.sd)
+
+    def lpdf_many(self, x):
+        x = np.asarray(x, dtype=np.float64)
+        with np.errstate(all="ignore"):
+            return np.where(x <= 0, -np.inf, -0.5 * np.square(x / self.sd))
+
+    def dlpdf_many(self, x):
+        x = np.asarray(x, dtype=np.float64)
         return -x / (self.sd * self.sd)
 
     def sample(self):
