@@ -140,6 +140,7 @@ SIGNATURES = {
     "gpcsd_set_geometry_2d": (_I, [_P, _DP, _I, _DP, _DP, _I, _DP, _DP, _I]),
     "gpcsd_set_time": (_I, [_P, _DP, _I]),
     "gpcsd_set_host_temporal_gram": (_I, [_P, _DP, _I, _DP, _I, _I]),
+    "gpcsd_set_host_temporal_dgram": (_I, [_P, _DP, _I, _I]),
     "gpcsd_b_fwd_1d": (_I, [_P, _DP, _L, _D, _DP]),
     "gpcsd_trad_csd": (_I, [_P, _DP, _L, _L, _L, _I, _DP]),
     "gpcsd_b_fwd_2d": (_I, [_P, _DP, _DP, _DP, _L, _D, _D, _DP]),
@@ -366,6 +367,17 @@ class Context:
                                                            Kt_cross.shape[1]))
 
     # ---- operators ----
+    def set_host_temporal_dgram(self, dKt):
+        """Derivatives of the host temporal Gram handed over last: (2 * n_temporal, nt, nt), ordered (d/d ell_c, d/d sigma2_c)
+        per component; None clears."""
+        if dKt is None:
+            self._check(self._lib.gpcsd_set_host_temporal_dgram(self._h, None, 0, 0))
+            return
+        dKt = _arr(dKt)
+        if dKt.ndim != 3 or dKt.shape[1] != dKt.shape[2]:
+            raise ValueError("dKt must have shape (n_matrices, nt, nt)")
+        self._check(self._lib.gpcsd_set_host_temporal_dgram(self._h, _ptr(dKt), dKt.shape[1], dKt.shape[0]))
+
     def b_fwd_1d(self, r, R):
         r = _arr(r)
         out = np.empty_like(r)

@@ -185,6 +185,30 @@ class _StationaryTemporalCov(GPCSDTemporalCov):
                                                     self.params["sigma2"]["value"])
 
 
+    def compute_dKt(self, name):
+        """d Kt / d params[name] on this object's own time grid (name: "ell" or "sigma2"): what fit()'s analytic gradient needs
+        from a temporal covariance the library does not evaluate itself.  Any GPCSDTemporalCov subclass with a `compute_Kt` may
+        be put in a model (the reference traces it with autograd, covariances.py:235-238, gpcsd1d.py:211); one that also offers
+        `compute_dKt(name)` keeps the fit at one device evaluation per optimiser step instead of 2p + 1 (central differences).
+        Host NumPy: this is the contract's default implementation for the two stationary kernels, used when they sit next to a
+        user-defined component (alone, the library differentiates them on the device)."""
+        ts = np.asarray(self.t, dtype=np.float64).reshape(-1)
+        d = ts[:, None] - ts[None, :]
+        ell, s2 = float(self.params["ell"]["value"]), float(self.params["sigma2"]["value"])
+        if self.kind == _hip.KIND_SE:
+            k = np.exp(-0.5 * np.square(d) / (ell * ell))
+            dk = k * np.square(d) / (ell * ell * ell)
+        else:
+            ad = np.abs(d)
+            k = np.exp(-ad / ell)
+            dk = k * ad / (ell * ell)
+        if name == "ell":
+            return s2 * dk
+        if name == "sigma2":
+            return k
+        raise KeyError(name)
+
+
 class GPCSDTemporalCovSE(_StationaryTemporalCov):
     """sigma2 * exp(-(t-t')^2 / (2 ell^2))   (reference: covariances.py:239-271)."""
     kind = _hip.KIND_SE

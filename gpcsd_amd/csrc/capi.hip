@@ -1406,8 +1406,12 @@ extern "C" int gpcsd_set_host_temporal_gram(gpcsd_ctx *c, const double *Kt, int 
         c->host_kt.clear();
         c->host_kt_cross.clear();
         c->host_kt_nt = c->host_kt_C = c->host_kt_ntstar = 0;
+        c->host_dkt.clear();
+        c->host_dkt_n = 0;
         return 0;
     }
+    c->host_dkt.clear();                        // derivatives belong to the Gram they were handed over with
+    c->host_dkt_n = 0;
     GP_REQUIRE(nt > 0, -3, "set_host_temporal_gram: nt must be positive");
     GP_REQUIRE(!Kt_cross || (ncomp >= 1 && ncomp <= GPCSD_MAX_TEMPORAL && ntstar > 0), -3,
                "set_host_temporal_gram: bad cross-Gram shape (%d, %d, %d)", ncomp, ntstar, nt);
@@ -1422,6 +1426,24 @@ extern "C" int gpcsd_set_host_temporal_gram(gpcsd_ctx *c, const double *Kt, int 
         c->host_kt_C = c->host_kt_ntstar = 0;
     }
     c->host_kt_on = true;
+    return 0;
+    GP_API_END(c)
+}
+
+extern "C" int gpcsd_set_host_temporal_dgram(gpcsd_ctx *c, const double *dKt, int nt, int nmat) {
+    GP_API_BEGIN(c)
+    if (!dKt) {
+        c->host_dkt.clear();
+        c->host_dkt_n = 0;
+        return 0;
+    }
+    GP_REQUIRE(c->host_kt_on && nt == c->host_kt_nt, -3,
+               "set_host_temporal_dgram: hand the Gram matrix over first (gpcsd_set_host_temporal_gram) -- nt=%d, Gram nt=%d", nt,
+               c->host_kt_nt);
+    GP_REQUIRE(nmat >= 1 && nmat <= 2 * GPCSD_MAX_TEMPORAL, -3, "set_host_temporal_dgram: %d derivative matrices (1..%d)", nmat,
+               2 * GPCSD_MAX_TEMPORAL);
+    c->host_dkt.assign(dKt, dKt + (size_t)nmat * nt * nt);
+    c->host_dkt_n = nmat;
     return 0;
     GP_API_END(c)
 }
@@ -2204,8 +2226,11 @@ static int loglik_grad_impl(gpcsd_ctx *c, const gpcsd_hparams *hps, int B, doubl
     const int nsig = hps[0].n_sig2n;
     for (int b = 0; b < B; ++b) {
         check_hp(c, &hps[b], nx);
-        GP_REQUIRE(!uses_host_kt(&hps[b]), -3, "loglik_grad: no analytic gradient for user-defined temporal covariances "
-                                              "(their derivative is not known to the library; use finite differences of gpcsd_loglik)");
+        // user-defined temporal covariances: the caller supplies d Kt / d theta_k (gpcsd_set_host_temporal_dgram), one set at a time
+        GP_REQUIRE(!uses_host_kt(&hps[b]) || (B == 1 && c->host_kt_on && c->host_kt_nt == nt && c->host_dkt_n == 2 * C &&
+                                              c->host_dkt.size() == (size_t)2 * C * nt * nt), -3,
+                   "loglik_grad: user-defined temporal covariances need their Gram matrix and the %d derivative matrices "
+                   "d Kt / d (ell_c, sigma2_c) (gpcsd_set_host_temporal_gram + gpcsd_set_host_temporal_dgram), one set per call", 2 * C);
         GP_REQUIRE(hps[b].n_temporal == C && hps[b].n_sig2n == nsig, -3,
                    "loglik_grad_batch: every hyper-parameter set must have the same number of temporal components and noise entries");
         for (int i = 0; i < C; ++i)
@@ -2238,7 +2263,9 @@ static int loglik_grad_impl(gpcsd_ctx *c, const gpcsd_hparams *hps, int B, doubl
     double *Bet = c->buf<double>("b_Bet", nxRT * B), *Bes = c->buf<double>("b_Bes", nxRT * B);
     double *gdev = c->buf<double>("b_grad_out", (size_t)64 * B);
     const double *t = (const double *)c->bufs["time_t"].p;
-    const SymDev *sym_s = c->sym_s.ns > 0 ? &c->sym_s : nullptr, *sym_t = c->sym_t.ns > 0 ? &c->sym_t : nullptr;
+    const bool host_kt = uses_host_kt(&hps[0]);
+    // (a caller-supplied Gram need not commute with the reflection of the time grid: that side is not folded, cf. front_half)
+    const SymDev *sym_s = c->sym_s.ns > 0 ? &c->sym_s : nullptr, *sym_t = (c->sym_t.ns > 0 && !host_kt) ? &c->sym_t : nullptr;
     // Folded basis (see FoldMode): with a scalar noise variance the whole evaluation runs on the half-size eigenvector blocks
     // of the symmetry-folded eigensolver -- projections, the Ghat_s / Ghat_t sums and the back-rotations are each two
     // half-size products.  The cross-parity blocks of Ghat are never needed: dKs and dKt commute with the reflections, so
@@ -2252,7 +2279,8 @@ static int loglik_grad_impl(gpcsd_ctx *c, const gpcsd_hparams *hps, int B, doubl
     const FoldMode fm = fold_mode(c, &hps[0]);
     const bool fold = fm.on;
     const double *Yf = fold ? folded_lfp(c, fm) : nullptr;
-    k_temporal_gram(c, C, nullptr, nullptr, nullptr, t, nt, t, nt, Kt, s2, tab, B, ntt);
+    if (host_kt) GP_HIP(hipMemcpyAsync(Kt, c->host_kt.data(), (size_t)ntt * sizeof(double), hipMemcpyHostToDevice, s2));
+    else k_temporal_gram(c, C, nullptr, nullptr, nullptr, t, nt, t, nt, Kt, s2, tab, B, ntt);
     {
         ProfScope ps(c, "eigh_temporal", 9.0 * (double)nt * nt * nt * B, s2);
         eigh_pair_device(c, nullptr, 0, nullptr, nullptr, nullptr, Kt, nt, et, Qt, sym_t, st + B, s2, !fold, B, 1);
@@ -2523,7 +2551,12 @@ static int loglik_grad_impl(gpcsd_ctx *c, const gpcsd_hparams *hps, int B, doubl
         sandwich(Qt, Ght, nt, Gt);
     }
     // natural-parameter order: [R, ell_s (dim), (ell_t, sigma2_t) per component, sig2n]; 64 slots per set
-    k_temporal_grad(c, &hps[0], Gt, t, nt, gdev + 1 + g.dim, s, tab, B, 64);
+    if (host_kt) {                        // <Gt, d Kt / d theta_k> with the caller's derivative matrices
+        double *dK = c->upload<double>("b_host_dkt", c->host_dkt.data(), (size_t)2 * C * ntt);
+        k_frob_inner(c, Gt, dK, ntt, 2 * C, gdev + 1 + g.dim, s);
+    } else {
+        k_temporal_grad(c, &hps[0], Gt, t, nt, gdev + 1 + g.dim, s, tab, B, 64);
+    }
     double *P = c->buf<double>("b_grad_P", nxG * B);
     double *Mg = c->buf<double>("b_grad_M", GG * B);
     GemmDesc gp;                          // P = Gs A

@@ -149,6 +149,8 @@ struct gpcsd_ctx {
     bool host_kt_on = false;
     std::vector<double> host_kt, host_kt_cross;   // (nt, nt) sum over components; (C, ntstar, nt) per component or empty
     int host_kt_nt = 0, host_kt_C = 0, host_kt_ntstar = 0;
+    std::vector<double> host_dkt;           // (nmat, nt, nt): d Kt / d theta_k from the objects' compute_dKt (gpcsd_set_host_temporal_dgram)
+    int host_dkt_n = 0;
 
     // ---- device buffers: grow-only, keyed by name, freed in destroy ----
     template <typename T = double>

@@ -196,6 +196,31 @@ void k_temporal_grad(gpcsd_ctx *c, const gpcsd_hparams *hp, const double *Gt, co
     GP_HIP(hipGetLastError());
 }
 
+// ---- temporal, user-defined covariances: out[k] = sum_ij Gt_ij dK_k,ij for nm caller-supplied derivative matrices
+// (dK_k = d Kt / d theta_k evaluated by the covariance object's own compute_dKt; nm <= 2 * GPCSD_MAX_TEMPORAL)
+__global__ __launch_bounds__(256) void frob_inner_kernel(const double *__restrict__ Gt, const double *__restrict__ dK, long n2, int nm,
+                                                         double *partials) {
+    double v[GR_MAXV];
+#pragma unroll
+    for (int q = 0; q < GR_MAXV; ++q) v[q] = 0.0;
+    for (long e = blockIdx.x * 256L + threadIdx.x; e < n2; e += (long)gridDim.x * 256) {
+        const double g = Gt[e];
+#pragma unroll
+        for (int q = 0; q < GR_MAXV; ++q)
+            if (q < nm) v[q] += g * dK[(long)q * n2 + e];
+    }
+    block_partials<GR_MAXV>(v, partials, gridDim.x, blockIdx.x);
+}
+
+void k_frob_inner(gpcsd_ctx *c, const double *Gt, const double *dK, long n2, int nm, double *out, hipStream_t s) {
+    GP_REQUIRE(nm >= 1 && nm <= GR_MAXV, -3, "frob_inner: %d matrices (max %d)", nm, GR_MAXV);
+    const int nblocks = 256;
+    double *part = c->buf<double>("grad_partials", (size_t)GR_MAXV * 1024);
+    hipLaunchKernelGGL(frob_inner_kernel, dim3(nblocks), dim3(256), 0, s, Gt, dK, n2, nm, part);
+    hipLaunchKernelGGL(final_sums_kernel, dim3(nm, 1), dim3(256), 0, s, (const double *)part, nblocks, out, (long)GR_MAXV * 1024, 0L);
+    GP_HIP(hipGetLastError());
+}
+
 // ---- spatial length scales: sum_gh M_gh Kgl_gh d_gh^2 / ell^3       (covariances.py:89, :216)
 __global__ __launch_bounds__(256) void kgl_grad_kernel(const double *__restrict__ M, const double *__restrict__ Kgl,
                                                        const double *__restrict__ gx1, const double *__restrict__ gx2, int G,

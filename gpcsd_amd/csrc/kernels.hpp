@@ -238,6 +238,8 @@ void k_batch_reduce(gpcsd_ctx *c, const double *in, int nb, long stride, int n, 
 // with a table: B sets (Gt nt*nt apart, outputs s_out apart); hp still supplies n_temporal
 void k_temporal_grad(gpcsd_ctx *c, const gpcsd_hparams *hp, const double *Gt, const double *t, int nt, double *out2C,
                      hipStream_t s, const HpDev *tab = nullptr, int B = 1, long s_out = 0);
+// out[k] = <Gt, dK_k> for nm matrices dK_k (n2 doubles each, contiguous): user-defined temporal covariances
+void k_frob_inner(gpcsd_ctx *c, const double *Gt, const double *dK, long n2, int nm, double *out, hipStream_t s);
 // out[0..1] = <M, dKgl/d ell_1>, <M, dKgl/d ell_2>   (ngl2 == 0: 1D, only out[0] meaningful)
 void k_kgl_grad(gpcsd_ctx *c, const double *M, const double *Kgl, const double *gx1, const double *gx2, int G, int ngl2,
                 double ell1, double ell2, double *out2, hipStream_t s, const HpDev *tab = nullptr, int B = 1, long s_out = 0);

@@ -124,7 +124,11 @@ class GPCSDModel:
     def _uses_host_kt(self):
         return any(k == _hip.KIND_HOST for k, _, _ in self._temporal_triplets())
 
-    def _hparams(self, jitter, tstar=None):
+    def _host_kt_is_differentiable(self):
+        """Every temporal component of a model with user-defined covariances offers compute_dKt(name)."""
+        return all(callable(getattr(tc, "compute_dKt", None)) for tc in self.temporal_cov_list)
+
+    def _hparams(self, jitter, tstar=None, want_dkt=False):
         ell_s = [self.spatial_cov.params[n]["value"] for n in self._spatial_names]
         eps = getattr(self, "eps", 0.0)
         ctx = self._context()
@@ -137,6 +141,9 @@ class GPCSDModel:
             if tstar is not None:
                 cross = np.stack([np.asarray(tc.compute_Kt(tstar), dtype=np.float64) for tc in self.temporal_cov_list])
             ctx.set_host_temporal_gram(Kt, cross)
+            if want_dkt:                             # d Kt / d (ell_c, sigma2_c) per component, from the objects themselves
+                ctx.set_host_temporal_dgram(np.stack([np.asarray(tc.compute_dKt(nm), dtype=np.float64)
+                                                      for tc in self.temporal_cov_list for nm in ("ell", "sigma2")]))
             self._resident["host_kt"] = True
         elif self._resident.get("host_kt"):
             ctx.set_host_temporal_gram(None)
@@ -211,10 +218,11 @@ class GPCSDModel:
 
     def _loglik_and_grad_natural(self):
         """(loglik, d loglik / d[R, ell_s.., (ell_t, sigma2_t).., sig2n or sig2n_0..sig2n_{nx-1}]) on the GPU."""
-        if self._uses_host_kt():
-            raise NotImplementedError("no analytic gradient for user-defined temporal covariances")
+        host = self._uses_host_kt()
+        if host and not self._host_kt_is_differentiable():
+            raise NotImplementedError("no analytic gradient for user-defined temporal covariances without compute_dKt(name)")
         ctx = self._sync_device()
-        hp, _keep = self._hparams(self.JITTER)
+        hp, _keep = self._hparams(self.JITTER, want_dkt=host)
         nsig = 1 if self._sig2n_is_scalar() else len(self.sig2n["value"])
         ng = 1 + self.dim + 2 * len(self.temporal_cov_list) + nsig
         sumlog, quad, g = ctx.loglik_grad(hp, ng)
@@ -347,7 +355,7 @@ class GPCSDModel:
         does (gpcsd1d.py:219, gpcsd2d.py:258)."""
         with np.errstate(all="ignore"):          # the reference runs under np.seterr(all='ignore') (gpcsd1d.py:7)
             tparams = np.asarray(tparams, dtype=np.float64)
-            if getattr(self, "_use_analytic_grad", True) and not self._uses_host_kt():
+            if getattr(self, "_use_analytic_grad", True) and (not self._uses_host_kt() or self._host_kt_is_differentiable()):
                 if self._batch_can_evaluate() and self._vector_glue_applies():
                     # the batch of one: the same array expressions (and the same device code, gpcsd_loglik_grad is the B = 1 case
                     # of gpcsd_loglik_grad_batch), so a restart gets the same bits alone and in a lock-step batch
@@ -359,7 +367,7 @@ class GPCSDModel:
                 lp = self._log_prior()
                 ll, g_nat = self._loglik_and_grad_natural()
                 return -1.0 * (ll + lp), self._chain_rule(tparams, g_nat, fix_R)
-            # finite differences of the objective (user-defined temporal covariances; diagnostics)
+            # finite differences of the objective (user-defined temporal covariances without compute_dKt; diagnostics)
             f = self._objective(tparams, fix_R)
             g = np.zeros_like(tparams)
             for i in range(tparams.size):

@@ -99,8 +99,15 @@ int gpcsd_set_time(gpcsd_ctx *ctx, const double *t, int nt);   /* GPCSDTemporalC
  * may be NULL for loglik), evaluated by the caller.  Copied; used by every later fused call whose hparams carry a
  * component of kind GPCSD_KIND_HOST, in place of the built-in Gram builders (the eigensolver, projections and predict
  * chain are unchanged; the reflection fold of the time axis is skipped since such a kernel need not be stationary).
- * Kt == NULL clears it.  gpcsd_loglik_grad refuses such hparams (-3): the library cannot differentiate a host kernel. */
+ * Kt == NULL clears it.  gpcsd_loglik_grad needs the derivatives of such a Gram as well (gpcsd_set_host_temporal_dgram); without
+ * them it refuses such hparams (-3). */
 int gpcsd_set_host_temporal_gram(gpcsd_ctx *ctx, const double *Kt, int nt, const double *Kt_cross, int ncomp, int ntstar);
+/* Derivatives of that Gram matrix with respect to the natural temporal hyper-parameters, evaluated by the caller (the
+ * reference differentiates any GPCSDTemporalCov subclass by tracing it with autograd, gpcsd1d.py:211; here the class offers
+ * compute_dKt(name)): dKt is (nmat, nt, nt) with nmat = 2 * n_temporal, ordered (d/d ell_c, d/d sigma2_c) per component.
+ * Copied; belongs to the Gram handed over last (a new gpcsd_set_host_temporal_gram clears it).  With it gpcsd_loglik_grad
+ * accepts GPCSD_KIND_HOST components: its temporal entries are <Gt, dKt_k>, one evaluation per gradient.  dKt == NULL clears. */
+int gpcsd_set_host_temporal_dgram(gpcsd_ctx *ctx, const double *dKt, int nt, int nmat);
 
 /* ---- operator surface (stand-alone; host in / host out) ------------------------- */
 /* b_fwd_1d(r, R)                        forward_models.py:9-17   (elementwise, n values) */
