@@ -1674,13 +1674,20 @@ static int predict_fold(gpcsd_ctx *c, const gpcsd_hparams *hp, EigState &e, cons
     const size_t kcf_sz = (size_t)ns * nzs + (size_t)na * nza;
     double *Kcf = c->buf<double>("pred_Kcross_fold", 2 * kcf_sz);
     double *S = c->buf<double>("pred_S", (size_t)nz * RT);
-    double *comp = c->buf<double>("pred_comp", (size_t)C * nz * RT);
+    // comp~ and Pcat keep every (parity, component) block of columns on a 128-byte boundary (block widths padded to a multiple
+    // of 16 doubles): the final relayout pass reads comp~ in 16-column pieces per trial row, and unaligned blocks (250 columns)
+    // made every piece straddle two cache lines -- 291 MB fetched for 154 MB of comp~ per cfg3 step
+    const int ntsP = (nts + 15) & ~15, ntaP = (nta + 15) & ~15;
+    // (+16: a row stride that is a power of two -- 1024 doubles at nt = 500 -- walks the same HBM channels row after row)
+    const long ldcomp = (long)C * (ntsP + ntaP) + 16;
+    double *comp = c->buf<double>("pred_comp", std::max((size_t)C * nz * RT, (size_t)nz * R * ldcomp));
     double *Kts = c->buf<double>("pred_Ktstar", (size_t)C * nt * nt);
     const size_t ktf_sz = (size_t)nts * nts + (size_t)nta * nta;
     double *Ktf = c->buf<double>("pred_Ktstar_fold", (size_t)C * ktf_sz);
     const size_t m1_sz = (size_t)nzs * ns + (size_t)nza * na;
     double *M1 = c->buf<double>("pred_M1", 2 * std::max(m1_sz, (size_t)nz * nx));
-    double *Pc = c->buf<double>("pred_Pc", std::max((size_t)C * ktf_sz, (size_t)C * nt * nt));
+    const size_t pc_s = (size_t)nts * C * ntsP;                     // Pcat_sym: nts rows of C * ntsP columns; Pcat_anti follows
+    double *Pc = c->buf<double>("pred_Pc", std::max(pc_s + (size_t)nta * C * ntaP, (size_t)C * nt * nt));
     const size_t out_elems = (size_t)nz * RT;
     ++c->fold_gemm_calls;
     // what needs neither decomposition runs first, beside both chains: the cross-covariances and the prediction-time Grams,
@@ -1735,14 +1742,14 @@ static int predict_fold(gpcsd_ctx *c, const gpcsd_hparams *hp, EigState &e, cons
     GP_HIP(hipEventRecord(c->ev_aux, s));                            // Kt*~ and the temporal eigenvectors are complete here
     GP_HIP(hipStreamWaitEvent(c->stream4, c->ev_aux, 0));
     for (int p = 0; p < 2; ++p) {
-        const int np = p ? nta : nts;
+        const int np = p ? nta : nts, npP = p ? ntaP : ntsP;
         if (np == 0) continue;
-        GemmDesc gp;                      // Pcat_p[i'][cc*np + b] = sum_j V_p[j][i'] Kt*~_cc,pp[j][b], all components batched
+        GemmDesc gp;                      // Pcat_p[i'][cc*npP + b] = sum_j V_p[j][i'] Kt*~_cc,pp[j][b], all components batched
         gp.M = np; gp.N = np; gp.K = np;
         gp.A = fm.ft.U + (p ? (size_t)nts * nts : 0); gp.lda = np; gp.transA = true;
         gp.B = Ktf + (p ? (size_t)nts * nts : 0); gp.ldb = np;
-        gp.C = Pc + (p ? (size_t)C * nts * nts : 0); gp.ldc = (long)C * np;
-        gp.batch = C; gp.sA = 0; gp.sB = (long)ktf_sz; gp.sC = np;
+        gp.C = Pc + (p ? pc_s : 0); gp.ldc = (long)C * npP;
+        gp.batch = C; gp.sA = 0; gp.sB = (long)ktf_sz; gp.sC = npP;
         gp.prof_name = "gemm_pred_Pc";
         gemm_f64(c, gp, c->stream4);
     }
@@ -1765,16 +1772,36 @@ static int predict_fold(gpcsd_ctx *c, const gpcsd_hparams *hp, EigState &e, cons
         }
         gemm_pair(c, g5[0], g5[1], s);
         if (which == 1 || !(type & 1)) GP_HIP(hipStreamWaitEvent(s, c->ev_pc, 0));     // Pcat (stream4) before its first use
-        for (int p = 0; p < 2; ++p) {     // comp~[(zq, r)][p][cc][b] = sum_i' S~[(zq, r)][p block i'] Pcat_p[i'][cc*np + b]
-            const int np = p ? nta : nts, c0 = p ? nts : 0;
-            g6[p].M = nz * R; g6[p].N = C * np; g6[p].K = np;
+        for (int p = 0; p < 2; ++p) {     // comp~[(zq, r)][p][cc][b] = sum_i' S~[(zq, r)][p block i'] Pcat_p[i'][cc*npP + b]
+            const int np = p ? nta : nts, npP = p ? ntaP : ntsP, c0 = p ? nts : 0;
+            // (the padding columns between two components are computed along -- whatever Pcat holds there only reaches comp~'s
+            // own padding columns, which nobody reads; the last component's padding is left out)
+            g6[p].M = nz * R; g6[p].N = (C - 1) * npP + np; g6[p].K = np;
             g6[p].A = S + c0; g6[p].lda = nt;
-            g6[p].B = Pc + (p ? (size_t)C * nts * nts : 0); g6[p].ldb = (long)C * np;
-            g6[p].C = comp + (p ? (size_t)C * nts : 0); g6[p].ldc = (long)C * nt;
+            g6[p].B = Pc + (p ? pc_s : 0); g6[p].ldb = (long)C * npP;
+            g6[p].C = comp + (p ? (size_t)C * ntsP : 0); g6[p].ldc = ldcomp;
             g6[p].prof_name = "gemm_pred_tstar";
         }
-        gemm_pair(c, g6[0], g6[1], s);
-        k_unfold_swap_sum(c, comp, C, o_list, (long)out_elems, o_sum, R, nt, sz, fm.sym_t, s);
+        if (gemm_pred_unfold_supported(C, (long)nz * R, nt)) {
+            // ... as ONE launch whose epilogue unfolds in site and time, turns (r, t) into (t, r) and sums the components:
+            // comp~ is never written (gemm_f64.hip: gemm_pred_unfold_kernel)
+            PredUnfoldDesc pu{};
+            pu.S = S; pu.lds = nt;
+            pu.Pc[0] = Pc; pu.Pc[1] = Pc + pc_s;
+            pu.ldp[0] = (long)C * ntsP; pu.ldp[1] = (long)C * ntaP;
+            pu.npP[0] = ntsP; pu.npP[1] = ntaP;
+            pu.K[0] = nts; pu.K[1] = nta;
+            pu.kcol0[0] = 0; pu.kcol0[1] = nts;
+            pu.nb = nts; pu.nba = nta;
+            pu.ncolS = (long)nzs * R; pu.ncolA = (long)nza * R; pu.anti_row0 = (long)nzs * R;
+            pu.R = R; pu.nt = nt; pu.C = C;
+            pu.sz = sz; pu.st = fm.sym_t;
+            pu.list = o_list; pu.list_stride = (long)out_elems; pu.sum = o_sum;
+            gemm_pred_unfold(c, pu, s);
+        } else {
+            gemm_pair(c, g6[0], g6[1], s);
+            k_unfold_swap_sum(c, comp, C, o_list, (long)out_elems, o_sum, R, nt, sz, fm.sym_t, s, ntsP, ntaP, ldcomp);
+        }
     }
     c->tl("predict end (main)", s);
     if (async && c->prof_mode != 1) {     // results stay on the device: return with the tail still in flight

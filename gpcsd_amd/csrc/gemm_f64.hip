@@ -434,6 +434,283 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f64_kernel(GemmK g) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Last product of a folded prediction with the unfold fused in (replaces gemm_pred_tstar + unfold_swap_sum_kernel).
+//
+//   comp~[(zq, r)][tp][cc][b] = sum_i' S~[(zq, r)][tp block i'] Pcat_tp[i'][cc * npP + b]        (the GEMM, K = nts / nta)
+//   out[cc][z][t][r] = sum over the site parity sp of zq and the time parity tp of b of (+-) weights * comp~   (the unfold)
+//
+// Every output element combines FOUR entries of comp~ -- (site-symmetric, site-antisymmetric row) x (time-symmetric,
+// time-antisymmetric column block) of one (site orbit a, trial r, time orbit b) -- and yields the four mirror images
+// (z_i | z_j) x (t_k | t_l).  The kernel computes the transposed product, rows = (cc, b), columns = (a, r), so that the lanes
+// of a wave run along r, the innermost index of the outputs: a workgroup owns 32 time orbits b (all CC components of them:
+// fragment i of a wave = component i, so the sum over components is a register add) x 32 columns (a, r) in BOTH site parities
+// (fragment j = 0 the symmetric row of S~, j = 1 the antisymmetric one), runs the K loop once per time parity with its own
+// accumulators, and then holds ss / as / sa / aa of the same (b, a, r) in one lane: the unfold is register arithmetic and every
+// store instruction writes 16 consecutive trials (128 bytes) of four output rows.  comp~ (154 MB at 384 x 500 x 50) is never
+// written or read, and the relayout launch is gone.
+template <int CC>
+struct PredUnfoldK {
+    const double *S;             // S~ [(zq, r)][nt] row-major
+    long lds;
+    const double *Pc[2];         // Pcat_tp [K_tp][C * npP_tp]
+    long ldp[2];
+    int npP[2], K[2], kcol0[2];
+    int nb, nba;                 // time orbits; those below nba have an antisymmetric partner
+    long ncolS, ncolA, anti_row0;   // columns (a, r) of the symmetric site block, of the antisymmetric one, its first row in S~
+    int R, nt;
+    SymDev sz, st;
+    double *list;                // [cc][z][t][r] (nullptr: sums only)
+    long list_stride;
+    double *sum;                 // [z][t][r]
+    int tiles_b;
+};
+
+template <int CC>
+__global__ __launch_bounds__(256) void gemm_pred_unfold_kernel(PredUnfoldK<CC> g) {
+    constexpr int NT = 256, BK = 8, BM = 32 * CC, BN = 64;
+    using TileA = Tile<BM, true, NT, BK>;     // Pcat: global [K][rows]
+    using TileB = Tile<BN, false, NT, BK>;    // S~: global [cols][K]
+    __shared__ double lds[2 * (TileA::LDS_ELEMS + TileB::LDS_ELEMS)];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wr = wid >> 1, wc = wid & 1;
+    // XCD-aware order as in gemm_f64_kernel: consecutive logical tiles share the S~ panel (the long dimension)
+    int L = blockIdx.x;
+    {
+        const int total = gridDim.x;
+        if (total >= 64) {
+            const int x = L & 7, q = total >> 3, r = total & 7;
+            L = x * q + (x < r ? x : r) + (L >> 3);
+        }
+    }
+    const int tile_b = L % g.tiles_b;
+    const long tile_c = L / g.tiles_b;
+    const int b0 = tile_b * 32;
+    const long n0 = tile_c * 32;
+    const int fr = lane & 15, fq = lane >> 4;
+
+    d4 acc[2][CC][2];
+#pragma unroll
+    for (int tp = 0; tp < 2; ++tp)
+#pragma unroll
+        for (int i = 0; i < CC; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[tp][i][j] = d4{0.0, 0.0, 0.0, 0.0};
+
+    int oa0, ka0, ob0, kb0;
+    TileA::slot0(tid, oa0, ka0);
+    TileB::slot0(tid, ob0, kb0);
+    double *const swA = lds + TileA::lds_index(oa0, ka0);
+    double *const swB = lds + 2 * TileA::LDS_ELEMS + TileB::lds_index(ob0, kb0);
+    using Buf0 = std::integral_constant<int, 0>;
+    using Buf1 = std::integral_constant<int, 1>;
+
+#pragma unroll
+    for (int tp = 0; tp < 2; ++tp) {
+        const int K = g.K[tp];
+        if (K <= 0) continue;                                  // (no antisymmetric time block: wave-uniform)
+        const int nbt = tp ? g.nba : g.nb;                     // valid b of this parity
+        // per-thread slots: A' slot i = (row o = oa0 [+ 0], k = ka0 + DK i), row o -> component o / 32, time orbit b0 + o % 32
+        unsigned offA[TileA::PER_THREAD], offB[TileB::PER_THREAD];
+        int colA;
+        {
+            const int cc = oa0 >> 5, bb = b0 + (oa0 & 31);
+            colA = cc * g.npP[tp] + (bb < nbt ? bb : nbt - 1);
+#pragma unroll
+            for (int i = 0; i < TileA::PER_THREAD; ++i) offA[i] = (unsigned)(((long)(ka0 + TileA::DK * i) * g.ldp[tp] + colA) * 8);
+        }
+        long rowB[TileB::PER_THREAD];
+#pragma unroll
+        for (int i = 0; i < TileB::PER_THREAD; ++i) {          // slot 0: symmetric row n0 + o, slot 1 (o + 32): its antisymmetric row
+            const int o = ob0 + TileB::DO * i;
+            const long c = n0 + (o & 31);
+            if (o < 32) rowB[i] = c < g.ncolS ? c : g.ncolS - 1;
+            else rowB[i] = g.anti_row0 + (c < g.ncolA ? c : (g.ncolA > 0 ? g.ncolA - 1 : -g.anti_row0));
+            offB[i] = (unsigned)((rowB[i] * g.lds + kb0) * 8);
+        }
+        const double *const baseA = g.Pc[tp];
+        const double *const baseB = g.S + g.kcol0[tp];
+        const int nk = (K + BK - 1) / BK, nfull = K / BK;
+        double ra[TileA::PER_THREAD], rb[TileB::PER_THREAD];
+        const double *const srA = lds + TileA::lds_index(wr * 16 + fr, fq);
+        const double *const srB = lds + 2 * TileA::LDS_ELEMS + TileB::lds_index(wc * 16 + fr, fq);
+
+        auto load_full = [&](int t) {
+            TileA::gload(ra, TileA::rsrc(baseA, g.ldp[tp], t), 0, offA);
+            TileB::gload(rb, TileB::rsrc(baseB, g.lds, t), 0, offB);
+        };
+        auto load_any = [&](int t) {
+            if (t < nfull) {
+                load_full(t);
+            } else {                                           // partial K tile: out-of-range k reads the last valid one
+                const int kleft = K - t * BK;
+                const __amdgpu_buffer_rsrc_t rsa = TileA::rsrc(baseA, g.ldp[tp], t), rsb = TileB::rsrc(baseB, g.lds, t);
+#pragma unroll
+                for (int i = 0; i < TileA::PER_THREAD; ++i) {
+                    const int kk = ka0 + TileA::DK * i, kc = kk < kleft ? kk : kleft - 1;
+                    ra[i] = TileA::bload(rsa, (unsigned)(((long)kc * g.ldp[tp] + colA) * 8), 0);
+                }
+                const int kc = kb0 < kleft ? kb0 : kleft - 1;
+#pragma unroll
+                for (int i = 0; i < TileB::PER_THREAD; ++i) rb[i] = TileB::bload(rsb, (unsigned)((rowB[i] * g.lds + kc) * 8), 0);
+            }
+        };
+        auto store_any = [&](auto bufc, int t) {
+            constexpr int buf = decltype(bufc)::value;
+            if (t < nfull) {
+                TileA::template sstore<false>(ra, swA + buf * TileA::LDS_ELEMS, 0, 0);
+                TileB::template sstore<false>(rb, swB + buf * TileB::LDS_ELEMS, 0, 0);
+            } else {
+                TileA::template sstore<true>(ra, swA + buf * TileA::LDS_ELEMS, ka0, K - t * BK);
+                TileB::template sstore<true>(rb, swB + buf * TileB::LDS_ELEMS, kb0, K - t * BK);
+            }
+        };
+        const int last_steps = (nk > nfull) ? (K - nfull * BK + 3) / 4 : BK / 4;
+        auto mma = [&](auto bufc, int steps) {
+            constexpr int buf = decltype(bufc)::value;
+            const double *sa = srA + buf * TileA::LDS_ELEMS;
+            const double *sb = srB + buf * TileB::LDS_ELEMS;
+#pragma unroll
+            for (int kk = 0; kk < BK / 4; ++kk) {
+                if (kk < steps) {                              // wave-uniform
+                    double a[CC], b[2];
+#pragma unroll
+                    for (int i = 0; i < CC; ++i) a[i] = LDS_FRAG(sa + TileA::lds_index(i * 32, kk * 4));
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) b[j] = LDS_FRAG(sb + TileB::lds_index(j * 32, kk * 4));
+#pragma unroll
+                    for (int i = 0; i < CC; ++i)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j)
+                            acc[tp][i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[tp][i][j], 0, 0, 0);
+                }
+            }
+        };
+        __syncthreads();                                       // the previous parity's last fragment reads are done
+        load_any(0);
+        store_any(Buf0{}, 0);
+        __syncthreads();
+        int kt = 0;
+        for (; kt + 2 < nfull; kt += 2) {
+            load_full(kt + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            mma(Buf0{}, BK / 4);
+            __builtin_amdgcn_sched_barrier(0);
+            store_any(Buf1{}, kt + 1);
+            __syncthreads();
+            load_full(kt + 2);
+            __builtin_amdgcn_sched_barrier(0);
+            mma(Buf1{}, BK / 4);
+            __builtin_amdgcn_sched_barrier(0);
+            store_any(Buf0{}, kt + 2);
+            __syncthreads();
+        }
+        if (kt + 1 < nk) {
+            load_any(kt + 1);
+            mma(Buf0{}, BK / 4);
+            store_any(Buf1{}, kt + 1);
+            __syncthreads();
+            if (kt + 2 < nk) {
+                load_any(kt + 2);
+                mma(Buf1{}, BK / 4);
+                store_any(Buf0{}, kt + 2);
+                __syncthreads();
+                mma(Buf0{}, last_steps);
+            } else {
+                mma(Buf1{}, last_steps);
+            }
+        } else {
+            mma(Buf0{}, last_steps);
+        }
+    }
+
+    // ---- epilogue: unfold in site and time, sum over components, the (up to) four mirror images of every (b, a, r) ----
+    const long rho = n0 + wc * 16 + fr;                        // this lane's column (a, r) of the symmetric site block
+    if (rho >= g.ncolS) return;
+    const int a = (int)(rho / g.R), rr = (int)(rho - (long)a * g.R);
+    const int zi = g.sz.rep_i[a], zj = g.sz.rep_j[a];
+    const double isq2 = 0.70710678118654752440;
+    const double wz = (zi == zj) ? 1.0 : isq2;
+    const bool has_za = (zi != zj) && rho < g.ncolA;
+    const long rowlen = (long)g.nt * g.R;
+    double *const sum_i = g.sum + (long)zi * rowlen + rr, *const sum_j = g.sum + (long)zj * rowlen + rr;
+#pragma unroll
+    for (int r4 = 0; r4 < 4; ++r4) {
+        const int bb = b0 + wr * 16 + fq + 4 * r4;
+        if (bb >= g.nb) continue;
+        const int tk = g.st.rep_i[bb], tl = g.st.rep_j[bb];
+        const double wt = (tk == tl) ? 1.0 : isq2;
+        const bool has_ta = (tk != tl) && bb < g.nba;
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+#pragma unroll
+        for (int cc = 0; cc < CC; ++cc) {
+            const double ss = wz * wt * acc[0][cc][0][r4];
+            const double sa = has_ta ? wz * isq2 * acc[1][cc][0][r4] : 0.0;
+            const double as = has_za ? isq2 * wt * acc[0][cc][1][r4] : 0.0;
+            const double aa = (has_za && has_ta) ? 0.5 * acc[1][cc][1][r4] : 0.0;
+            const double v0 = (ss + sa) + (as + aa);           // (zi, tk)
+            const double v1 = (ss - sa) + (as - aa);           // (zi, tl)
+            const double v2 = (ss + sa) - (as + aa);           // (zj, tk)
+            const double v3 = (ss - sa) - (as - aa);           // (zj, tl)
+            s0 += v0;                                          // components summed in index order, as the reference does
+            s1 += v1;
+            s2 += v2;
+            s3 += v3;
+            if (g.list) {
+                double *const li = g.list + (long)cc * g.list_stride + (long)zi * rowlen + rr;
+                double *const lj = g.list + (long)cc * g.list_stride + (long)zj * rowlen + rr;
+                li[(long)tk * g.R] = v0;
+                if (tl != tk) li[(long)tl * g.R] = v1;
+                if (zj != zi) {
+                    lj[(long)tk * g.R] = v2;
+                    if (tl != tk) lj[(long)tl * g.R] = v3;
+                }
+            }
+        }
+        sum_i[(long)tk * g.R] = s0;
+        if (tl != tk) sum_i[(long)tl * g.R] = s1;
+        if (zj != zi) {
+            sum_j[(long)tk * g.R] = s2;
+            if (tl != tk) sum_j[(long)tl * g.R] = s3;
+        }
+    }
+}
+
+bool gemm_pred_unfold_supported(int C, long nrows_S, int nt) {
+    static const bool off = getenv("GPCSD_FUSED_UNFOLD") && getenv("GPCSD_FUSED_UNFOLD")[0] == '0';      // A/B switch
+    // 32-bit byte offsets span all rows of S~ (symmetric and antisymmetric halves are addressed from one base)
+    return !off && (C == 1 || C == 2) && nrows_S * (long)nt * 8 < (1L << 32);
+}
+
+void gemm_pred_unfold(gpcsd_ctx *c, const PredUnfoldDesc &d, hipStream_t s) {
+    GP_REQUIRE(gemm_pred_unfold_supported(d.C, d.anti_row0 + d.ncolA, d.nt), -3, "gemm_pred_unfold: unsupported shape");
+    const int tiles_b = ceil_div(d.nb, 32);
+    const long tiles_c = (d.ncolS + 31) / 32;
+    const long nblocks = tiles_b * tiles_c;
+    GP_REQUIRE(nblocks < (1L << 31), GPCSD_ERR_CAPACITY, "gemm_pred_unfold: too many tiles");
+    const double flops = 2.0 * (double)(d.ncolS + d.ncolA) * d.C * ((double)d.nb * d.K[0] + (double)d.nba * d.K[1]);
+    ProfScope ps(c, "gemm_pred_tstar_unfold", flops, s);
+    auto fill = [&](auto &k) {
+        k.S = d.S; k.lds = d.lds;
+        for (int tp = 0; tp < 2; ++tp) {
+            k.Pc[tp] = d.Pc[tp]; k.ldp[tp] = d.ldp[tp]; k.npP[tp] = d.npP[tp]; k.K[tp] = d.K[tp]; k.kcol0[tp] = d.kcol0[tp];
+        }
+        k.nb = d.nb; k.nba = d.nba; k.ncolS = d.ncolS; k.ncolA = d.ncolA; k.anti_row0 = d.anti_row0;
+        k.R = d.R; k.nt = d.nt; k.sz = d.sz; k.st = d.st; k.list = d.list; k.list_stride = d.list_stride; k.sum = d.sum;
+        k.tiles_b = tiles_b;
+    };
+    if (d.C == 1) {
+        PredUnfoldK<1> k;
+        fill(k);
+        hipLaunchKernelGGL(gemm_pred_unfold_kernel<1>, dim3((unsigned)nblocks), dim3(256), 0, s, k);
+    } else {
+        PredUnfoldK<2> k;
+        fill(k);
+        hipLaunchKernelGGL(gemm_pred_unfold_kernel<2>, dim3((unsigned)nblocks), dim3(256), 0, s, k);
+    }
+    GP_HIP(hipGetLastError());
+}
+
 // Deterministic final reduction of per-block partials (single workgroup, fixed tree).
 // A second workgroup may carry an unrelated reduction of the same shape (p2, n2 -> out2: the sum of log D partials of the
 // likelihood, which would otherwise be a launch of its own in the dependent tail of the call).

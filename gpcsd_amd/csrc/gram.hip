@@ -745,7 +745,7 @@ void k_fold_lfp(gpcsd_ctx *c, const double *Y, int nx, int R, int nt, const SymD
 constexpr int UF_TB = 16, UF_TR = 64;
 __global__ __launch_bounds__(256) void unfold_swap_sum_kernel(const double *__restrict__ in, int C, double *__restrict__ list,
                                                               long list_stride, double *__restrict__ sum, int R, int nt,
-                                                              SymDev sz, SymDev st) {
+                                                              SymDev sz, SymDev st, int nsP, int naP, long ldin) {
     __shared__ double tile[2][2][UF_TR][UF_TB + 1];
     const int az = blockIdx.z;                                  // site orbit
     const int b0 = blockIdx.x * UF_TB, i0 = blockIdx.y * UF_TR; // time orbits, trials
@@ -754,7 +754,7 @@ __global__ __launch_bounds__(256) void unfold_swap_sum_kernel(const double *__re
     const int zi = sz.rep_i[az], zj = sz.rep_j[az];
     const double isq2 = 0.70710678118654752440;
     const double wz = (zi == zj) ? 1.0 : isq2;
-    const long ldin = (long)C * nt;
+    // (column blocks padded to nsP / naP columns -- 128-byte aligned blocks --, rows ldin apart)
     double acc[4][4];
 #pragma unroll
     for (int m = 0; m < 4; ++m)
@@ -769,7 +769,7 @@ __global__ __launch_bounds__(256) void unfold_swap_sum_kernel(const double *__re
                 const bool zok = pz == 0 || az < sz.na;
                 const long row = pz ? (long)sz.ns + az : az;
                 const int wdt = pt ? st.na : st.ns;
-                const long col0 = (pt ? (long)C * st.ns : 0) + (long)c * wdt;
+                const long col0 = (pt ? (long)C * nsP : 0) + (long)c * (pt ? naP : nsP);
 #pragma unroll
                 for (int k = 0; k < UF_TR / 16; ++k) {
                     const int i = i0 + ly + 16 * k, bb = b0 + lx;
@@ -823,10 +823,13 @@ __global__ __launch_bounds__(256) void unfold_swap_sum_kernel(const double *__re
 }
 
 void k_unfold_swap_sum(gpcsd_ctx *c, const double *in, int C, double *list, long list_stride, double *sum, int R, int nt,
-                       const SymDev &sz, const SymDev &st, hipStream_t s) {
+                       const SymDev &sz, const SymDev &st, hipStream_t s, int nsP, int naP, long ldin) {
+    if (nsP <= 0) nsP = st.ns;                                  // unpadded input: blocks of st.ns / st.na columns
+    if (naP <= 0) naP = st.na;
+    if (ldin <= 0) ldin = (long)C * (nsP + naP);
     dim3 grid(ceil_div(st.ns, UF_TB), ceil_div(R, UF_TR), sz.ns);
     ProfScope ps(c, "relayout", 0.0, s);
-    hipLaunchKernelGGL(unfold_swap_sum_kernel, grid, dim3(256), 0, s, in, C, list, list_stride, sum, R, nt, sz, st);
+    hipLaunchKernelGGL(unfold_swap_sum_kernel, grid, dim3(256), 0, s, in, C, list, list_stride, sum, R, nt, sz, st, nsP, naP, ldin);
     GP_HIP(hipGetLastError());
 }
 

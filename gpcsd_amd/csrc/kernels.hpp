@@ -52,6 +52,25 @@ struct GemmDesc {
 
 void gemm_f64(gpcsd_ctx *c, const GemmDesc &g, hipStream_t s = nullptr);
 
+// Last product of a folded prediction with the unfold, the (r, t) -> (t, r) relayout and the sum over components fused into
+// its epilogue (gemm_f64.hip: gemm_pred_unfold_kernel).  S~ [(zq, r)][nt]; Pcat_tp [K_tp][C * npP_tp], tp = time parity.
+struct PredUnfoldDesc {
+    const double *S;
+    long lds;
+    const double *Pc[2];
+    long ldp[2];
+    int npP[2], K[2], kcol0[2];
+    int nb, nba;                    // time orbits (symmetric block); those with an antisymmetric partner
+    long ncolS, ncolA, anti_row0;   // (site orbit, trial) columns of the symmetric / antisymmetric site block; first anti row of S~
+    int R, nt, C;
+    SymDev sz, st;
+    double *list;
+    long list_stride;
+    double *sum;
+};
+bool gemm_pred_unfold_supported(int C, long nrows_S, int nt);
+void gemm_pred_unfold(gpcsd_ctx *c, const PredUnfoldDesc &d, hipStream_t s);
+
 // ---------------------------------------------------------------- batched hyper-parameter sets
 // Device image of gpcsd_hparams for batched evaluations (gpcsd_loglik_grad_batch): one entry per hyper-parameter set.  The
 // Gram builders / derivative kernels take an optional table: with `tab` they run once for all B sets (the set index is a grid
@@ -112,8 +131,9 @@ void k_sym_fold_rect(gpcsd_ctx *c, const double *K, long ldk, const SymDev &rs, 
 void k_sym_unfold_mat(gpcsd_ctx *c, const double *Gf, long s_in, const SymDev &sy, int n, double *out, hipStream_t s, int B = 1);
 void k_fold_lfp(gpcsd_ctx *c, const double *Y, int nx, int R, int nt, const SymDev &ss, const SymDev &st, double *out,
                 hipStream_t s);
+// nsP / naP > 0: the (parity, component) column blocks of `in` are padded to that many columns (128-byte aligned blocks)
 void k_unfold_swap_sum(gpcsd_ctx *c, const double *in, int C, double *list, long list_stride, double *sum, int R, int nt,
-                       const SymDev &sz, const SymDev &st, hipStream_t s);
+                       const SymDev &sz, const SymDev &st, hipStream_t s, int nsP = 0, int naP = 0, long ldin = 0);
 
 // ---------------------------------------------------------------- eigensolver (eigh.hip)
 // Symmetric eigendecomposition of A (n,n) on device.  evals ascending; evecs (n,n) row-major with

@@ -51,8 +51,9 @@ def main():
     ap.add_argument("dirs", nargs="+")
     ap.add_argument("--out", default=None)
     ap.add_argument("--unit-bytes", type=float, default=1024.0, help="bytes per FETCH_SIZE/WRITE_SIZE unit")
-    ap.add_argument("--per-step-kernel", default="unfold_swap_sum_kernel",
-                    help="a kernel launched exactly once per bench step: its launch count is the number of steps profiled")
+    ap.add_argument("--per-step-kernel", default="gemm_pred_unfold_kernel,unfold_swap_sum_kernel,swap_last2_sum_kernel",
+                    help="kernels launched exactly once per bench step (first one present wins): its launch count is the number "
+                         "of steps profiled")
     args = ap.parse_args()
     merged = defaultdict(dict)
     for d in args.dirs:
@@ -77,7 +78,11 @@ def main():
         print("%-70s grid %9d x%-5d n=%4d  read %10.3f MB  write %10.3f MB" % (
             r["kernel"][:70], r["grid"], r["workgroup"], r.get("launches", 0),
             r.get("hbm_read_bytes_per_launch", float("nan")) / 1e6, r.get("hbm_write_bytes_per_launch", float("nan")) / 1e6))
-    steps = sum(r.get("launches", 0) for r in rows if r["kernel"].startswith(args.per_step_kernel))
+    steps = 0
+    for cand in args.per_step_kernel.split(","):
+        steps = sum(r.get("launches", 0) for r in rows if r["kernel"].startswith(cand))
+        if steps:
+            break
     total = sum(r.get("hbm_traffic_bytes_per_launch", 0.0) * r.get("launches", 0) for r in rows)
     per_step = total / steps if steps else None
     if per_step:

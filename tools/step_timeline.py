@@ -23,8 +23,8 @@ def short(name):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("trace")
-    ap.add_argument("--step-kernel", default="unfold_swap_sum_kernel")
-    ap.add_argument("--alt-step-kernel", default="swap_last2_sum_kernel")
+    ap.add_argument("--step-kernel", default="gemm_pred_unfold_kernel,unfold_swap_sum_kernel,swap_last2_sum_kernel",
+                    help="kernels that run exactly once per step, first one present in the trace wins")
     ap.add_argument("--from-end", type=int, default=10)
     args = ap.parse_args()
     rows = []
@@ -33,9 +33,12 @@ def main():
             stream = r.get("Stream_Id") or r.get("Queue_Id") or "?"
             rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), stream, r["Kernel_Name"]))
     rows.sort()
-    marks = [i for i, r in enumerate(rows) if args.step_kernel in r[3]]
-    if len(marks) < 3:
-        marks = [i for i, r in enumerate(rows) if args.alt_step_kernel in r[3]]
+    marks = []
+    for cand in args.step_kernel.split(","):
+        marks = [i for i, r in enumerate(rows) if cand in r[3]]
+        if len(marks) >= 3:
+            args.step_kernel = cand
+            break
     if len(marks) < args.from_end + 2:
         raise SystemExit("trace holds %d steps only" % len(marks))
     # steady-state statistics over the last (up to) 50 steps
