@@ -179,6 +179,7 @@ SIGNATURES = {
     "gpcsd_shard_block": (_I, [_I, _I, _I, ctypes.POINTER(_I), ctypes.POINTER(_I)]),
     "gpcsd_combine_loglik": (_I, [_I, _D, _D, _DP]),
     "gpcsd_prof_enable": (_I, [_P, _I]),
+    "gpcsd_prof_tail_clock": (_I, [_P, _I, _DP, ctypes.POINTER(ctypes.c_int), _DP]),
     "gpcsd_prof_reset": (_I, [_P]),
     "gpcsd_prof_get": (_I, [_P, ctypes.c_char_p, _DP, ctypes.POINTER(_L), _DP]),
     "gpcsd_prof_names": (_I, [_P, ctypes.c_char_p, _I]),
@@ -667,6 +668,13 @@ class Context:
         """False / 0 off; True / 1 fenced scopes; 2 asynchronous scopes (queued and paired calls stay queued, eager chains);
         3 asynchronous scopes with the chains replayed as hipGraphs (chain-level scopes only)."""
         self._check(self._lib.gpcsd_prof_enable(self._h, int(on)))
+
+    def prof_tail_clock(self, region):
+        """(ms, workgroups, flops) of the last tridiagonalisation-tail launch of a chain (0 temporal, 1 spatial, 2 other),
+        from the workgroups' own wall-clock stamps; profiling modes 2 / 3, after the chain has finished."""
+        ms, fl, n = ctypes.c_double(), ctypes.c_double(), ctypes.c_int()
+        self._check(self._lib.gpcsd_prof_tail_clock(self._h, int(region), ctypes.byref(ms), ctypes.byref(n), ctypes.byref(fl)))
+        return ms.value, n.value, fl.value
 
     def prof_reset(self):
         self._check(self._lib.gpcsd_prof_reset(self._h))

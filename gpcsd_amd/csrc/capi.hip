@@ -817,6 +817,7 @@ extern "C" int gpcsd_ctx_destroy(gpcsd_ctx *c) {
     if (c->h_result) (void)hipHostFree(c->h_result);
     if (c->h_ll) (void)hipHostFree(c->h_ll);
     if (c->stage_ring) (void)hipHostFree(c->stage_ring);
+    if (c->tail_clk_host) (void)hipHostFree(c->tail_clk_host);
     for (auto &sl : c->ll_slot)
         if (sl.ev) (void)hipEventDestroy(sl.ev);
     delete c;
@@ -2673,8 +2674,39 @@ extern "C" int gpcsd_prof_enable(gpcsd_ctx *c, int on) {
     // only the scopes around whole chains and the GEMM tails record.  Modes 2 / 3 are collected by gpcsd_prof_get (which waits
     // for the recorded events).
     GP_REQUIRE(on >= 0 && on <= 3, -3, "prof_enable: mode must be 0..3");
+    if (on >= 2 && !c->tail_clk_host) {
+        const size_t bytes = (size_t)3 * 2 * gpcsd_ctx::TAIL_CLK_WGS * sizeof(unsigned long long);
+        GP_HIP(hipHostMalloc(reinterpret_cast<void **>(&c->tail_clk_host), bytes, hipHostMallocMapped));
+        memset(c->tail_clk_host, 0, bytes);
+        GP_HIP(hipHostGetDevicePointer(reinterpret_cast<void **>(&c->tail_clk_dev), c->tail_clk_host, 0));
+    }
     c->prof_mode = on;
     c->prof_on = (on != 0);
+    return 0;
+    GP_API_END(c)
+}
+
+// Duration of the last tridiagonalisation-tail launch of a chain from the workgroups' own wall-clock stamps (region 0: temporal
+// chain, 1: spatial chain, 2: other): last end - first start over its workgroups, in ms; *nwg = workgroups, *flops = the (4/3)
+// T^3 count of the launch.  Valid once the chain has finished (e.g. after gpcsd_loglik_parts_wait); profiling modes 2 / 3.
+extern "C" int gpcsd_prof_tail_clock(gpcsd_ctx *c, int region, double *ms, int *nwg, double *flops) {
+    GP_API_BEGIN(c)
+    GP_REQUIRE(region >= 0 && region < 3 && ms, -3, "prof_tail_clock: bad arguments");
+    GP_REQUIRE(c->tail_clk_host != nullptr, -4, "prof_tail_clock: profiling mode 2 / 3 has not been enabled on this context");
+    int rate_khz = 0;
+    GP_HIP(hipDeviceGetAttribute(&rate_khz, hipDeviceAttributeWallClockRate, c->device));
+    GP_REQUIRE(rate_khz > 0, -5, "prof_tail_clock: the device reports no wall clock rate");
+    const int n = c->tail_clk_count[region];
+    const volatile unsigned long long *p = c->tail_clk_host + (size_t)region * 2 * gpcsd_ctx::TAIL_CLK_WGS;
+    unsigned long long t0 = ~0ull, t1 = 0ull;
+    for (int i = 0; i < n; ++i) {
+        if (p[2 * i] == 0 || p[2 * i + 1] == 0) continue;          // (a workgroup that returned early stamps nothing)
+        t0 = p[2 * i] < t0 ? p[2 * i] : t0;
+        t1 = p[2 * i + 1] > t1 ? p[2 * i + 1] : t1;
+    }
+    *ms = (t1 > t0 && t0 != ~0ull) ? (double)(t1 - t0) / (double)rate_khz : 0.0;
+    if (nwg) *nwg = n;
+    if (flops) *flops = c->tail_clk_flops[region];
     return 0;
     GP_API_END(c)
 }

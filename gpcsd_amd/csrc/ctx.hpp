@@ -101,6 +101,12 @@ struct gpcsd_ctx {
     std::string last_error;
     std::map<std::string, gpcsd::DevBuf> bufs;
     bool prof_on = false;
+    // wall-clock stamps of the tridiagonalisation tail's workgroups (SytrdBatch::clk): three regions (temporal chain, spatial
+    // chain, other) of TAIL_CLK_WGS (start, end) pairs in host-mapped memory, allocated when profiling mode 2 / 3 is switched on
+    static constexpr int TAIL_CLK_WGS = 64;
+    unsigned long long *tail_clk_host = nullptr, *tail_clk_dev = nullptr;
+    int tail_clk_count[3] = {0, 0, 0};
+    double tail_clk_flops[3] = {0.0, 0.0, 0.0};
     int prof_mode = 0;                      // gpcsd_prof_enable: 0 off, 1 fenced, 2 asynchronous (eager chains), 3 asynchronous (graph chains)
     std::map<std::string, gpcsd::ProfEntry> prof;
     std::vector<hipEvent_t> event_pool;

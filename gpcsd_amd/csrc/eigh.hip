@@ -413,10 +413,10 @@ void eigh_pair_device(gpcsd_ctx *c, double *A0, int n0, double *w0, double *Z0, 
     }
     // (the generation of each slot picks the fold-order output buffers, which are not among the arguments)
     char key[352];
-    snprintf(key, sizeof(key), "eigh|%p|%d|%p|%p|%p|%d|%p|%d|%p|%p|%p|%d|%p|%p|%d|%d|%d|%d%d|%d|%d", (void *)A0, n0, (void *)w0, (void *)Z0,
+    snprintf(key, sizeof(key), "eigh|%p|%d|%p|%p|%p|%d|%p|%d|%p|%p|%p|%d|%p|%p|%d|%d|%d|%d%d|%d|%d|%d", (void *)A0, n0, (void *)w0, (void *)Z0,
              (void *)(sym0 ? sym0->rep_i : nullptr), sym0 ? sym0->ns : 0, (void *)A1, n1, (void *)w1, (void *)Z1,
              (void *)(sym1 ? sym1->rep_i : nullptr), sym1 ? sym1->ns : 0, (void *)d_status, (void *)s, (int)need_merged, count,
-             status_stride, c->par[0], c->par[1], count1, prefolded_mask);
+             status_stride, c->par[0], c->par[1], count1, prefolded_mask, (int)(c->prof_mode == 3));   // (mode 3 graphs carry clock stamps)
     gpcsd_ctx::GraphSlot &g = c->graphs[key];
     if (g.exec && g.epoch == c->alloc_epoch) {
         GP_HIP(hipGraphLaunch(g.exec, s));

@@ -81,6 +81,10 @@ struct SytrdProb {
 struct SytrdBatch {
     SytrdProb p[MAX_BATCH];
     int start[MAX_BATCH + 1];
+    // measurement (gpcsd_prof_enable modes 2 / 3): workgroup g of the single-workgroup tail stamps the device's wall clock at
+    // its start and end into clk[2 g], clk[2 g + 1] (host-mapped memory) -- the one way to time this kernel inside a replayed
+    // hipGraph, where event scopes cannot record.  nullptr: off.
+    unsigned long long *clk;
 };
 __device__ __forceinline__ SytrdProb sy_resolve(const SytrdBatch &b, int g) {
     int cls, rep;
@@ -285,7 +289,15 @@ static void sytrd_batch_launch(gpcsd_ctx *c, const SytrdBatch &b, int nclass, in
             if (b.p[i].k_tail < b.p[i].n - 1) fl += 4.0 / 3.0 * T * T * T * (b.start[i + 1] - b.start[i]);
         }
         ProfScope ps(c, "sytrd_rtail", fl, s);
-        hipLaunchKernelGGL(sytrd_rtail_kernel, dim3(count), dim3(RT_NTH), sh, s, b);
+        SytrdBatch bt = b;
+        bt.clk = nullptr;
+        if (c->prof_mode >= 2 && c->tail_clk_dev && count <= gpcsd_ctx::TAIL_CLK_WGS) {
+            const int region = (s == c->stream2) ? 0 : (s == c->stream3) ? 1 : 2;      // temporal chain, spatial chain, other
+            bt.clk = c->tail_clk_dev + (size_t)region * 2 * gpcsd_ctx::TAIL_CLK_WGS;
+            c->tail_clk_count[region] = count;
+            c->tail_clk_flops[region] = fl;
+        }
+        hipLaunchKernelGGL(sytrd_rtail_kernel, dim3(count), dim3(RT_NTH), sh, s, bt);
     }
     if (!all_tail) hipLaunchKernelGGL(sytrd_last_diag_kernel, dim3(count), dim3(64), 0, s, b);
     GP_HIP(hipGetLastError());
@@ -531,6 +543,7 @@ static PrepBatch prep_batch_launch(gpcsd_ctx *c, EigProb *probs, int nclass, hip
 
 static SytrdBatch sytrd_batch_of(const PrepBatch &pb) {
     SytrdBatch b{};
+    b.clk = nullptr;
     for (int i = 0; i < MAX_BATCH; ++i) b.p[i] = pb.sp[i];
     for (int i = 0; i <= MAX_BATCH; ++i) b.start[i] = pb.start[i];
     return b;

@@ -79,6 +79,7 @@ __global__ __launch_bounds__(RT_NTH) void sytrd_rtail_kernel(SytrdBatch b) {
     const SytrdProb P = sy_resolve(b, blockIdx.x);
     const int n = P.n, k0 = P.k_tail;
     if (k0 >= n - 1) return;
+    if (b.clk && threadIdx.x == 0) b.clk[2 * blockIdx.x] = wall_clock64();      // (measurement only: see SytrdBatch::clk)
     const int T = n - k0;                          // rows / columns k0 .. n-1, T <= RT_TMAX
     const int S = rt_strip_rows(T), LDT = rt_strip_ld(T);
     const int TB = T - S;                          // live rows of the register block, <= RT_T
@@ -484,6 +485,7 @@ __global__ __launch_bounds__(RT_NTH) void sytrd_rtail_kernel(SytrdBatch b) {
         P.e[k0 + kk] = se[OFF + kk];
         P.tau[k0 + kk] = st[OFF + kk];
     }
+    if (b.clk && threadIdx.x == 0) b.clk[2 * blockIdx.x + 1] = wall_clock64();
 }
 
 }  // namespace gpcsd

@@ -280,6 +280,10 @@ int gpcsd_fold_gemm(gpcsd_ctx *ctx, int on, long *calls);
  * chains run eagerly so the scopes inside them see their kernels; 3 as 2 with the chains replayed as hipGraphs (only the
  * scopes around whole chains and the GEMMs record).  gpcsd_prof_get waits for the recorded events. */
 int gpcsd_prof_enable(gpcsd_ctx *ctx, int on);
+/* Modes 2 / 3: duration (ms) of the last launch of the single-workgroup tridiagonalisation tail -- the kernel with the
+ * largest share of GPU time -- in a chain (region 0: temporal, 1: spatial, 2: other), from wall-clock stamps its workgroups
+ * write themselves: the one way to time it inside a replayed hipGraph.  Valid once that chain has finished. */
+int gpcsd_prof_tail_clock(gpcsd_ctx *ctx, int region, double *ms, int *nwg, double *flops);
 int gpcsd_prof_reset(gpcsd_ctx *ctx);
 /* total ms, launch count and algorithmic flops accumulated under `name`; rc -2 if unknown */
 int gpcsd_prof_get(gpcsd_ctx *ctx, const char *name, double *ms, long *count, double *flops);
