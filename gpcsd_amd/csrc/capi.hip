@@ -519,10 +519,6 @@ EigState front_half(gpcsd_ctx *c, const gpcsd_hparams *hp, double jitter, bool n
         e.wait_temporal = true;
     }
     if (run_s) {
-        if (c->slot0_on_s2) {             // a paired call ran the spatial problems inside its one chain on stream2: same workspaces
-            GP_HIP(hipStreamWaitEvent(s3, c->ev_join, 0));
-            c->slot0_on_s2 = false;
-        }
         c->tl("S chain start (s3)", s3);
         const bool sfill = spatial_fill_applies(c, sym_s, nx);
         build_kphi(c, g, hp->R, hp->eps, hp->ell_s, nullptr, 0, sfill ? 0.0 : jitter, Ks, s3, "ks_");
@@ -743,35 +739,13 @@ extern "C" int gpcsd_ctx_create(int device, gpcsd_ctx **out) {
         c = new gpcsd_ctx();
         c->device = device;
         c->timeline_on = getenv("GPCSD_TIMELINE") && getenv("GPCSD_TIMELINE")[0] == '1';
-        // GPCSD_RESERVE_CUS=k (experiment): the main stream -- every machine-filling GEMM -- leaves k CUs alone, so that the
-        // chains' whole-CU workgroups (768 threads, 116 KB of LDS) never wait for a GEMM grid to drain
-        {
-            const char *re = getenv("GPCSD_RESERVE_CUS");
-            const int k = re ? atoi(re) : 0;
-            hipDeviceProp_t prop;
-            GP_HIP(hipGetDeviceProperties(&prop, device));
-            const int ncu = prop.multiProcessorCount;
-            if (k > 0 && k < ncu) {
-                std::vector<uint32_t> mask((ncu + 31) / 32, 0xFFFFFFFFu);
-                if (ncu % 32) mask.back() = (1u << (ncu % 32)) - 1u;
-                const int stride = ncu / k + 1;                   // spread over the bit range whatever the XCD interleave is
-                for (int i = 0; i < k; ++i) {
-                    const int b = (i * stride) % ncu;
-                    mask[b / 32] &= ~(1u << (b % 32));
-                }
-                GP_HIP(hipExtStreamCreateWithCUMask(&c->stream, (uint32_t)mask.size(), mask.data()));
-            }
-        }
-        if (!c->stream) GP_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+        GP_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
         // The two chains are the critical path and made of small launches; when they run beside another call's GEMM tail
         // (thousands of workgroups) each of those launches would otherwise queue behind the tiles: high priority.
         int prio_least = 0, prio_greatest = 0;
         GP_HIP(hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
-        const char *pe = getenv("GPCSD_CHAIN_PRIORITY");
-        const int prio = (pe && pe[0] == '0') ? prio_least : prio_greatest;
-        const int prio_s = (pe && pe[0] == '2') ? prio_least : prio;       // '2': only the temporal chain is raised (A/B)
-        GP_HIP(hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, prio));
-        GP_HIP(hipStreamCreateWithPriority(&c->stream3, hipStreamNonBlocking, prio_s));
+        GP_HIP(hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, prio_greatest));
+        GP_HIP(hipStreamCreateWithPriority(&c->stream3, hipStreamNonBlocking, prio_greatest));
         GP_HIP(hipStreamCreateWithFlags(&c->stream4, hipStreamNonBlocking));
         GP_HIP(hipEventCreateWithFlags(&c->ev_sjoin, hipEventDisableTiming));
         for (int i = 0; i < 4; ++i) GP_HIP(hipEventCreateWithFlags(&c->ev_mark[i / 2][i % 2], hipEventDisableTiming));
@@ -1977,23 +1951,17 @@ static void front_half_pair(gpcsd_ctx *c, const gpcsd_hparams *const hp[2], cons
     const bool tfill = temporal_fill_applies(c, sym_t, nt, false);       // (the paired call is refused for host temporal Grams)
     if (tfill) temporal_fill(c, hp, nT, t, nt, *sym_t, status + 1, 2, s2);
     else for (int b = 0; b < nT; ++b) build_kt(c, hp[b], t, nt, t, nt, Kt + b * ntt, s2);
-    GP_HIP(hipStreamWaitEvent(s3, c->ev_join, 0));      // the previous chain on stream2 may have been reading Ks_pair
-    // (one chain wanted: decided below; a Jacobi-sized problem next to a large one would be solved by another algorithm than
-    // alone -- it rides in the large one's launches -- and lose the bits of a separate call: such a pair takes two chains)
-    static const bool want_one = getenv("GPCSD_PAIR_CHAINS") && getenv("GPCSD_PAIR_CHAINS")[0] == '1';
-    const bool one_chain = want_one && nx > JACOBI_LDS_MAX && nt > JACOBI_LDS_MAX;
-    if (!one_chain) {
-        // the temporal chain is the critical path of the call: it is queued before the host spends its time on the dozen
-        // launches of the spatial Gram assembly (status words [1], [3]; one replica when the problem is shared --
-        // decomposition cache on, equal temporal hyper-parameters)
-        {
-            ProfScope ps(c, "eigh_temporal", 9.0 * (double)nt * nt * nt * nT, s2);
-            eigh_pair_device(c, nullptr, 0, nullptr, nullptr, nullptr, Kt, nt, et, Qt, sym_t, status + 1, s2, false, nT, 2, -1,
-                             tfill ? 2 : 0);
-        }
-        GP_HIP(hipEventRecord(c->ev_join, s2));
-        c->tl("T chain end (s2)", s2);
+    // the temporal chain is the critical path of the call: it is queued before the host spends its time on the launches of the
+    // spatial Gram assembly (status words [1], [3]; one replica when the problem is shared -- decomposition cache on, equal
+    // temporal hyper-parameters).  (All four problems in ONE chain was measured slower, 1.38 against 1.18 ms per cfg3 step: with
+    // two chains the log-likelihood's spatial projection runs under the end of the temporal one.)
+    {
+        ProfScope ps(c, "eigh_temporal", 9.0 * (double)nt * nt * nt * nT, s2);
+        eigh_pair_device(c, nullptr, 0, nullptr, nullptr, nullptr, Kt, nt, et, Qt, sym_t, status + 1, s2, false, nT, 2, -1,
+                         tfill ? 2 : 0);
     }
+    GP_HIP(hipEventRecord(c->ev_join, s2));
+    c->tl("T chain end (s2)", s2);
     c->tl("S chain start (s3)", s3);
     const bool same_ks = hp[0]->R == hp[1]->R && hp[0]->ell_s[0] == hp[1]->ell_s[0] &&
                          (g.dim == 1 || (hp[0]->eps == hp[1]->eps && hp[0]->ell_s[1] == hp[1]->ell_s[1]));
@@ -2002,7 +1970,7 @@ static void front_half_pair(gpcsd_ctx *c, const gpcsd_hparams *const hp[2], cons
         // the fill folds Ks and adds each replica's jitter to the folded diagonals: one assembly, no copy, no diagonal pass
         if (same_ks) build_kphi(c, g, hp[0]->R, hp[0]->eps, hp[0]->ell_s, nullptr, 0, 0.0, Ks, s3, "ks_");
         else for (int b = 0; b < 2; ++b) build_kphi(c, g, hp[b]->R, hp[b]->eps, hp[b]->ell_s, nullptr, 0, 0.0, Ks + b * nxx, s3, "ks_");
-        spatial_fill(c, Ks, nx, same_ks ? 0 : nxx, 2, jitter, *sym_s, status, 2, s3);   // (one chain: stream2 waits for stream3 below)
+        spatial_fill(c, Ks, nx, same_ks ? 0 : nxx, 2, jitter, *sym_s, status, 2, s3);
     } else if (same_ks) {
         const int lo = jitter[0] == 0.0 ? 0 : 1, hi = 1 - lo;           // assemble the one without a shift (if any) first
         build_kphi(c, g, hp[lo]->R, hp[lo]->eps, hp[lo]->ell_s, nullptr, 0, 0.0, Ks + lo * nxx, s3, "ks_");
@@ -2012,35 +1980,14 @@ static void front_half_pair(gpcsd_ctx *c, const gpcsd_hparams *const hp[2], cons
     } else {
         for (int b = 0; b < 2; ++b) build_kphi(c, g, hp[b]->R, hp[b]->eps, hp[b]->ell_s, nullptr, 0, jitter[b], Ks + b * nxx, s3, "ks_");
     }
-    // GPCSD_PAIR_CHAINS=1 (A/B): everything in ONE chain on stream2.  Measured slower than two: 1.38 against 1.18 ms per cfg3
-    // step -- with two chains the spatial one is done first (0.89 against 1.0 ms) and the log-likelihood's spatial projection
-    // runs under the end of the temporal one, while one chain makes everybody wait for its last launch.
-    if (one_chain) {
-        // ONE chain for all the problems (stream2; status words [0] and [2]; the temporal problem has one replica when it is
-        // shared -- decomposition cache on, equal temporal hyper-parameters)
-        GP_HIP(hipEventRecord(c->ev_aux, s3));
-        GP_HIP(hipStreamWaitEvent(s2, c->ev_aux, 0));              // the Gram matrices of stream3
-        GP_HIP(hipStreamWaitEvent(s2, c->ev_sjoin, 0));            // the last chain on stream3 used the spatial workspaces
-        {
-            ProfScope ps(c, "eigh_pair", 9.0 * ((double)nt * nt * nt * nT + (double)nx * nx * nx * 2), s2);
-            eigh_pair_device(c, Ks, nx, es, Qs, sym_s, Kt, nt, et, Qt, sym_t, status, s2, false, 2, 2, nT,
-                             (tfill ? 2 : 0) | (sfill ? 1 : 0));
-        }
-        GP_HIP(hipEventRecord(c->ev_join, s2));
-        GP_HIP(hipEventRecord(c->ev_sjoin, s2));
-        c->slot0_on_s2 = true;
-        c->tl("pair chain end (s2)", s2);
-    } else {
-        // two chains: the temporal one is queued above; two replicas of the spatial problem on stream3 (status words [0], [2])
-        if (c->slot0_on_s2) c->slot0_on_s2 = false;                 // (ordered behind stream2's last chain by the wait above)
-        {
-            ProfScope ps(c, "eigh_spatial", 9.0 * (double)nx * nx * nx * 2, s3);
-            eigh_pair_device(c, Ks, nx, es, Qs, sym_s, nullptr, 0, nullptr, nullptr, nullptr, status, s3, false, 2, 2, -1,
-                             sfill ? 1 : 0);
-        }
-        GP_HIP(hipEventRecord(c->ev_sjoin, s3));
-        c->tl("S chain end (s3)", s3);
+    // two replicas of the spatial problem on stream3 (status words [0], [2])
+    {
+        ProfScope ps(c, "eigh_spatial", 9.0 * (double)nx * nx * nx * 2, s3);
+        eigh_pair_device(c, Ks, nx, es, Qs, sym_s, nullptr, 0, nullptr, nullptr, nullptr, status, s3, false, 2, 2, -1,
+                         sfill ? 1 : 0);
     }
+    GP_HIP(hipEventRecord(c->ev_sjoin, s3));
+    c->tl("S chain end (s3)", s3);
     c->decomp_gen[0] = c->decomp_gen[1] = -1;          // replicas are not what the separate calls' cache looks for
     const double *d_sig[2] = {c->upload_cached<double>("sig2n", hp[0]->sig2n, 1), c->upload_cached<double>("sig2n_pair", hp[1]->sig2n, 1)};
     for (int b = 0; b < 2; ++b) {
@@ -2077,8 +2024,7 @@ static int drain_async(gpcsd_ctx *c) {
 extern "C" int gpcsd_predict_resident(gpcsd_ctx *c, const gpcsd_hparams *hp, const double *z, int nz, const double *tstar,
                                       int ntstar, int type, int want_lists) {
     GP_API_BEGIN(c)
-    static const bool fenced = getenv("GPCSD_SYNC_PREDICT") && getenv("GPCSD_SYNC_PREDICT")[0] == '1';   // A/B switch
-    return predict_impl(c, hp, z, nz, tstar, ntstar, type, want_lists != 0, /*async=*/!fenced);
+    return predict_impl(c, hp, z, nz, tstar, ntstar, type, want_lists != 0, /*async=*/true);
     GP_API_END(c)
 }
 
@@ -2095,9 +2041,8 @@ extern "C" int gpcsd_loglik_predict_async(gpcsd_ctx *c, const gpcsd_hparams *hp_
                "predict: len(t)=%d must equal the training nt=%d (the reference's reshape raises ValueError, gpcsd1d.py:279)",
                ntstar, c->nt);
     GP_REQUIRE(c->d_lfp != nullptr, -4, "lfp not set (call gpcsd_set_lfp)");
-    static const bool unpaired = getenv("GPCSD_NO_PAIR") && getenv("GPCSD_NO_PAIR")[0] == '1';     // A/B switch
     // the paired front half serves the folded-basis tails only; anything else is the two calls one after the other
-    bool pair = !unpaired && two_stream_front() && c->prof_mode != 1 && !uses_host_kt(hp_ll) && !uses_host_kt(hp_pr) &&
+    bool pair = two_stream_front() && c->prof_mode != 1 && !uses_host_kt(hp_ll) && !uses_host_kt(hp_pr) &&
                 hp_ll->n_sig2n == 1 && hp_pr->n_sig2n == 1;
     FoldMode fm0;
     SymDev sz;
@@ -2214,11 +2159,6 @@ extern "C" int gpcsd_sample_prior(gpcsd_ctx *c, const gpcsd_hparams *hp, int whi
     c->download(out, stage, (size_t)nx * RT * sizeof(double));
     return finish_status(c, st);
     GP_API_END(c)
-}
-
-static bool env_flag_off(const char *name) {       // NAME=0 switches a term off (diagnostics)
-    const char *v = getenv(name);
-    return v && v[0] == '0';
 }
 
 // ---- log-likelihood + analytic gradient for B hyper-parameter sets in ONE chain of launches ---------------------------------
@@ -2524,7 +2464,7 @@ static int loglik_grad_impl(gpcsd_ctx *c, const gpcsd_hparams *hps, int B, doubl
         gemm_f64(c, gs, s);
         double *Ghs = c->buf<double>("b_grad_Ghs", nxx * B);
         k_batch_reduce(c, Cs, R, nxx, nx, 0.5, av, -0.5 * R, Ghs, s, B, sCs);
-        if (nsig > 1 && !env_flag_off("GPCSD_SIGLIST_EIGVEC_TERM")) {
+        if (nsig > 1) {
             // noise tied to the eigen-index: eigenvector-rotation term, S = sum_r B_r B_r^T (see grad.hip)
             GemmDesc g3 = gs;
             g3.A = Bm;

@@ -83,7 +83,6 @@ struct gpcsd_ctx {
     int par[2] = {0, 0};
     hipEvent_t ev_mark[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
     bool async_pending = false;
-    bool slot0_on_s2 = false;               // the last chain that used the spatial solver workspaces ran on stream2 (paired call)
     // gpcsd_loglik_parts_async / gpcsd_loglik_predict_async: a result lands in a slot of h_ll (pinned, 66 doubles like
     // h_result) behind that slot's event; up to LL_SLOTS evaluations may be outstanding, gpcsd_loglik_parts_wait collects
     // them oldest first.  two: the quadratic form came back as two partial sums; done: evaluated at once (profiling on).

@@ -311,10 +311,6 @@ FoldView eigh_fold_view(gpcsd_ctx *c, int slot, const SymDev *sy, int n, int cou
     return v;
 }
 
-__global__ void dummy_probe_kernel(int *p) {
-    if (p && threadIdx.x == 1234567) *p = 0;
-}
-
 static const char *const FOLD_TAGS[2][3] = {{"p0", "p0s", "p0a"}, {"p1", "p1s", "p1a"}};
 const char *const *eigh_fold_tags(int slot) { return &FOLD_TAGS[slot ? 1 : 0][1]; }
 
@@ -322,11 +318,6 @@ static void eigh_pair_enqueue(gpcsd_ctx *c, double *A0, int n0, double *w0, doub
                               double *w1, double *Z1, const SymDev *sym1, int *d_status, hipStream_t s, bool need_merged,
                               int count, int status_stride, int count1, int prefolded_mask) {
     const int cnt[2] = {count, count1 > 0 ? count1 : count};      // replicas of problem 0 / problem 1
-    {   // GPCSD_DUMMY_LAUNCHES=k (measurement only): k empty dependent launches in front of every chain -- what one more
-        // kernel boundary costs the chain and the whole step
-        static const int ndummy = getenv("GPCSD_DUMMY_LAUNCHES") ? atoi(getenv("GPCSD_DUMMY_LAUNCHES")) : 0;
-        for (int i = 0; i < ndummy; ++i) hipLaunchKernelGGL(dummy_probe_kernel, dim3(1), dim3(64), 0, s, (int *)nullptr);
-    }
     double *A[2] = {A0, A1}, *w[2] = {w0, w1}, *Z[2] = {Z0, Z1};
     const int n[2] = {n0, n1};
     const SymDev *sym[2] = {sym0, sym1};
@@ -404,9 +395,8 @@ void eigh_pair_device(gpcsd_ctx *c, double *A0, int n0, double *w0, double *Z0, 
                "eigh: matrix order %d / %d (after symmetry folding: %d / %d) exceeds the eigensolver's capacity of %d rows "
                "(GPCSD_MAX_EIG_N)", n0, n1, m0, m1, JACOBI_MAX_N);
     const bool any_large = !force_jacobi() && (n0 > JACOBI_LDS_MAX || n1 > JACOBI_LDS_MAX);
-    // GPCSD_PROF_GRAPH=1: keep replaying graphs while profiling, so the outer scopes time the chains as they run in production
-    static const bool prof_graph_env = getenv("GPCSD_PROF_GRAPH") != nullptr;
-    const bool prof_graph = prof_graph_env || c->prof_mode == 3;
+    // profiling mode 3 keeps replaying graphs, so the outer scopes time the chains as they run in production
+    const bool prof_graph = c->prof_mode == 3;
     if (!any_large || (c->prof_on && !prof_graph) || !graphs_enabled()) {
         eigh_pair_enqueue(c, A0, n0, w0, Z0, sym0, A1, n1, w1, Z1, sym1, d_status, s, need_merged, count, status_stride, count1, prefolded_mask);
         return;

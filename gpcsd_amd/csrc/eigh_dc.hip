@@ -249,11 +249,7 @@ __global__ void sytrd_last_diag_kernel(SytrdBatch b) {
 }
 
 // rows the single-workgroup tail (sytrd_regtail.hpp) can hold: 192 in registers + up to 64 strip rows in LDS
-// (GPCSD_TAIL_STRIP=0: registers only, the leading rows go through per-column launches)
-static int sy_regtail_rows() {
-    static const bool nostrip = getenv("GPCSD_TAIL_STRIP") && getenv("GPCSD_TAIL_STRIP")[0] == '0';
-    return nostrip ? RT_T : RT_TMAX;
-}
+static int sy_regtail_rows() { return RT_TMAX; }
 
 static void sytrd_batch_launch(gpcsd_ctx *c, const SytrdBatch &b, int nclass, int nmax, hipStream_t s) {
     int klast = -1;                                        // last column handled by per-column launches
@@ -428,9 +424,8 @@ static void prep_problem(gpcsd_ctx *c, EigProb &p, hipStream_t s) {
     const int n = p.n;
     p.sp.n = n;
     {
-        static const bool no_tail = getenv("GPCSD_NO_TAIL") && getenv("GPCSD_NO_TAIL")[0] == '1';
         // the trailing block finishes inside one workgroup (192 rows in registers + up to 64 strip rows in LDS)
-        p.sp.k_tail = no_tail ? n - 1 : std::max(0, n - sy_regtail_rows());
+        p.sp.k_tail = std::max(0, n - sy_regtail_rows());
     }
     layout_arena(c, p.tag, n, p.count, p.sp, p.amax, p.wyT);
     (void)s;
@@ -582,7 +577,6 @@ void eigh_large_batch(gpcsd_ctx *c, EigProb *probs, int nclass, int *d_status, i
     const bool wy_fused = wy_fused_supported(nmax);
     GP_REQUIRE(wy_fused || !replicated, GPCSD_ERR_CAPACITY,
                "eigh: replicated (batched) problems need the fused back-transformation, n=%d is too large for it", nmax);
-    static const bool wy_in_leaf = !(getenv("GPCSD_WY_IN_LEAF") && getenv("GPCSD_WY_IN_LEAF")[0] == '0');
     WyBatch wb{};
     for (int i = 0; i <= MAX_BATCH; ++i) wb.start[i] = pb.start[i];
     if (wy_fused)
@@ -606,8 +600,7 @@ void eigh_large_batch(gpcsd_ctx *c, EigProb *probs, int nclass, int *d_status, i
             sp[i].s_in = probs[i].sp.blk; sp[i].sw = probs[i].sw; sp[i].sZ = probs[i].sZ;
         }
         // the T factors of the back-transformation need the reflectors only: they ride in the leaf launch of the D&C stage
-        // (GPCSD_WY_IN_LEAF=0: their own launch after it)
-        prep_done = wy_fused && wy_in_leaf;
+        prep_done = wy_fused;
         stedc_batch_device(c, sp, nclass, d_status, status_stride, s, prep_done ? &wb : nullptr);
     }
     if (wy_fused) {

@@ -799,8 +799,7 @@ void gemm_f64(gpcsd_ctx *c, const GemmDesc &g, hipStream_t s) {
         // flat GEMMs and balance the tail better; everything smaller is latency-bound and wants 32x32 / BK64
         // short K (the folded GEMMs: 192 / 250): the same tile with BK 8 -- half the pipeline fill per tile and half the LDS,
         // 46-48 TF/s against 40-41 with BK 16 at 192x25000x192 / 19200x250x250; equal from K = 500 up
-        static const bool bk8 = !(getenv("GPCSD_GEMM_BK8") && getenv("GPCSD_GEMM_BK8")[0] == '0');
-        cfg = (tiles(64, 64) >= 512) ? ((bk8 && g.K <= 320) ? 2 : 3) : 5;
+        cfg = (tiles(64, 64) >= 512) ? ((g.K <= 320) ? 2 : 3) : 5;
     }
     const int bm = CFG_BM[cfg], bn = CFG_BN[cfg];
     const int tm = ceil_div(g.M, bm), tn = ceil_div(g.N, bn);
