@@ -4,7 +4,7 @@
 
 namespace gpcsd {
 
-constexpr int EIG_MAXN = 1024;                       // LDS vectors of the eigensolver are sized for this
+constexpr int EIG_MAXN = 2048;                       // LDS vectors of the eigensolver are sized for this (= GPCSD_MAX_EIG_N)
 constexpr int MAX_BATCH = 4;                         // independent eigenproblems sharing launches
 constexpr double EPS_U = 1.1102230246251565e-16;     // unit roundoff (LAPACK dlamch('E'))
 

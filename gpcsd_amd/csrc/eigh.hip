@@ -391,9 +391,11 @@ void eigh_pair_device(gpcsd_ctx *c, double *A0, int n0, double *w0, double *Z0, 
     // the limit applies to what the solver actually factorises: a symmetry-folded problem is two half-size ones
     const int m0 = fold_applies(sym0, n0) ? std::max(sym0->ns, sym0->na) : n0;
     const int m1 = fold_applies(sym1, n1) ? std::max(sym1->ns, sym1->na) : n1;
-    GP_REQUIRE(m0 <= JACOBI_MAX_N && m1 <= JACOBI_MAX_N, GPCSD_ERR_CAPACITY,
+    // (GPCSD_EIGH=jacobi, the single-workgroup cross-check, keeps its own smaller limit)
+    const int cap = force_jacobi() ? JACOBI_MAX_N : EIG_MAXN;
+    GP_REQUIRE(m0 <= cap && m1 <= cap, GPCSD_ERR_CAPACITY,
                "eigh: matrix order %d / %d (after symmetry folding: %d / %d) exceeds the eigensolver's capacity of %d rows "
-               "(GPCSD_MAX_EIG_N)", n0, n1, m0, m1, JACOBI_MAX_N);
+               "(GPCSD_MAX_EIG_N)", n0, n1, m0, m1, cap);
     const bool any_large = !force_jacobi() && (n0 > JACOBI_LDS_MAX || n1 > JACOBI_LDS_MAX);
     // profiling mode 3 keeps replaying graphs, so the outer scopes time the chains as they run in production
     const bool prof_graph = c->prof_mode == 3;
@@ -447,8 +449,9 @@ void eigh_pair_device(gpcsd_ctx *c, double *A0, int n0, double *w0, double *Z0, 
 void eigh_device(gpcsd_ctx *c, double *A, int n, double *evals, double *evecs, int *d_status, hipStream_t s,
                  const char *tag) {
     GP_REQUIRE(n >= 1, -3, "eigh: n=%d must be positive", n);
-    GP_REQUIRE(n <= JACOBI_MAX_N, GPCSD_ERR_CAPACITY, "eigh: matrix order %d exceeds the eigensolver's capacity of %d rows (GPCSD_MAX_EIG_N)", n,
-               JACOBI_MAX_N);
+    GP_REQUIRE(n <= (force_jacobi() ? JACOBI_MAX_N : EIG_MAXN), GPCSD_ERR_CAPACITY,
+               "eigh: matrix order %d exceeds the eigensolver's capacity of %d rows (GPCSD_MAX_EIG_N)", n,
+               force_jacobi() ? JACOBI_MAX_N : EIG_MAXN);
     (void)tag;
     eigh_pair_device(c, A, n, evals, evecs, nullptr, nullptr, 0, nullptr, nullptr, nullptr, d_status, s, true, 1, 0, -1, 0);
 }

@@ -99,7 +99,7 @@ __device__ __forceinline__ SytrdProb sy_resolve(const SytrdBatch &b, int g) {
 #include "sytrd_regtail.hpp"
 namespace gpcsd {
 
-// JQ = ceil(trailing columns / 64) this launch may need (2, 4, 8 or 16).  Every global load of the step -- the slab
+// JQ = ceil(trailing columns / 64) this launch may need (2, 4, 8, 16 or 32).  Every global load of the step -- the slab
 // rows, the pivot row, the previous reflector and its y -- is issued before the first barrier, so a step costs one
 // L2/Infinity-Cache round trip plus LDS reductions instead of a chain of dependent loads.
 template <int JQ>
@@ -265,7 +265,8 @@ static void sytrd_batch_launch(gpcsd_ctx *c, const SytrdBatch &b, int nclass, in
         if (m <= 128) hipLaunchKernelGGL(sytrd_step_kernel<2>, grid, dim3(256), 0, s, b, k);
         else if (m <= 256) hipLaunchKernelGGL(sytrd_step_kernel<4>, grid, dim3(256), 0, s, b, k);
         else if (m <= 512) hipLaunchKernelGGL(sytrd_step_kernel<8>, grid, dim3(256), 0, s, b, k);
-        else hipLaunchKernelGGL(sytrd_step_kernel<16>, grid, dim3(256), 0, s, b, k);
+        else if (m <= 1024) hipLaunchKernelGGL(sytrd_step_kernel<16>, grid, dim3(256), 0, s, b, k);
+        else hipLaunchKernelGGL(sytrd_step_kernel<32>, grid, dim3(256), 0, s, b, k);
     }
     if (any_tail) {
         size_t sh = 0;
@@ -575,8 +576,7 @@ void eigh_large_batch(gpcsd_ctx *c, EigProb *probs, int nclass, int *d_status, i
         sytrd_batch_launch(c, sytrd_batch_of(pb), nclass, nmax, s);
     }
     const bool wy_fused = wy_fused_supported(nmax);
-    GP_REQUIRE(wy_fused || !replicated, GPCSD_ERR_CAPACITY,
-               "eigh: replicated (batched) problems need the fused back-transformation, n=%d is too large for it", nmax);
+    (void)replicated;
     WyBatch wb{};
     for (int i = 0; i <= MAX_BATCH; ++i) wb.start[i] = pb.start[i];
     if (wy_fused)
@@ -608,10 +608,15 @@ void eigh_large_batch(gpcsd_ctx *c, EigProb *probs, int nclass, int *d_status, i
         wy_batch_device(c, wb, nclass, s, prep_done);
     } else {                                   // n too large for the LDS-resident apply kernel: GEMM chain per panel
         ProfScope ps(c, "eigh_backtransform", 0.0, s);
+        // (replicas one after the other: the panel workspaces of a class are shared)
         for (int i = 0; i < nclass; ++i) {
             EigProb &p = probs[i];
-            ormtr_device(c, p.sp.V, p.sp.tau, p.n, p.Z, s, "eig_" + p.tag + "_");
-            hipLaunchKernelGGL(scale_vec_kernel, dim3(ceil_div(p.n, 256)), dim3(256), 0, s, p.w, p.n, (const double *)p.amax);
+            for (int r = 0; r < std::max(p.count, 1); ++r) {
+                const long o = (long)r * p.sp.blk;
+                ormtr_device(c, p.sp.V + o, p.sp.tau + o, p.n, p.Z + r * p.sZ, s, "eig_" + p.tag + "_");
+                hipLaunchKernelGGL(scale_vec_kernel, dim3(ceil_div(p.n, 256)), dim3(256), 0, s, p.w + r * p.sw, p.n,
+                                   (const double *)(p.amax + o));
+            }
         }
     }
     GP_HIP(hipGetLastError());

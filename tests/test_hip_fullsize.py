@@ -411,10 +411,12 @@ def test_user_defined_temporal_covariance(trend):
     assert abs(m.loglik() - O.loglik(geom, hp1, lfp)) / abs(ll_ref) < 1e-9
 
 
-def test_time_grid_beyond_1024_points_and_capacity_error():
-    """nt = 1400 on a uniform grid: the eigensolver's limit applies to the symmetry-folded halves (700 rows each).  A grid
-    with no reflection symmetry of that length exceeds the capacity and raises GPCSDCapacityError, which fit() does not
-    swallow (it is not a ValueError / LinAlgError)."""
+def test_time_grids_beyond_1024_points_and_capacity_error():
+    """nt = 1400 on a uniform grid: the eigensolver's limit (GPCSD_MAX_EIG_N = 2048 rows) applies to the symmetry-folded halves
+    (700 rows each).  The same length WITHOUT a reflection symmetry is one 1400-row problem: per-column tridiagonalisation
+    launches in front of the register tail, five large divide & conquer levels, the GEMM-chain back-transformation (the fused one
+    holds n <= 1009 rows in LDS) -- round 2 raised GPCSDCapacityError there.  A 2100-point grid without symmetry still exceeds the
+    capacity and raises GPCSDCapacityError, which fit() does not swallow (it is not a ValueError / LinAlgError)."""
     import gpcsd_amd
     from gpcsd_amd.gpcsd1d import GPCSD1D
     from gpcsd_amd.covariances import GPCSDTemporalCovSE, GPCSDTemporalCovMatern
@@ -422,23 +424,37 @@ def test_time_grid_beyond_1024_points_and_capacity_error():
     t = 0.5 * np.arange(1400.0)[:, None]
     lfp = C.synth_lfp(271, 24, 1400, 2)
 
-    def build(tgrid):
+    def build(tgrid, data):
         np.random.seed(0)
         tcl = [GPCSDTemporalCovSE(tgrid), GPCSDTemporalCovMatern(tgrid)]
         tcl[0].params["ell"]["value"], tcl[0].params["sigma2"]["value"] = 12.0, 0.5
         tcl[1].params["ell"]["value"], tcl[1].params["sigma2"]["value"] = 4.0, 0.7
-        mm = GPCSD1D(lfp, x, tgrid, a=0.0, b=2300.0, ngl=100, temporal_cov_list=tcl)
+        mm = GPCSD1D(data, x, tgrid, a=0.0, b=2300.0, ngl=100, temporal_cov_list=tcl)
         mm.R["value"], mm.sig2n["value"] = 100.0, 0.05
         mm.spatial_cov.params["ell"]["value"] = 200.0
         return mm
-    m = build(t)
-    geom = O.Geometry1D(x, t, a=0.0, b=2300.0, ngl=100)
     hp = O.make_hparams(100.0, (200.0,), [(O.SE, 12.0, 0.5), (O.MATERN, 4.0, 0.7)], 0.05, jitter=1e-8)
+    m = build(t, lfp)
     ll = m.loglik()
-    assert abs(ll - O.loglik(geom, hp, lfp)) / abs(ll) < 1e-8
-    t_bad = t.copy()
-    t_bad[-1, 0] += 0.123                                         # breaks the mirror symmetry of the grid
-    mb = build(t_bad)
+    assert abs(ll - O.loglik(O.Geometry1D(x, t, a=0.0, b=2300.0, ngl=100), hp, lfp)) / abs(ll) < 1e-8
+    # no mirror symmetry: one 1400-row temporal eigenproblem (loglik, the gradient's batched path with one set, predict)
+    t_asym = t.copy()
+    t_asym[-1, 0] += 0.123
+    ma = build(t_asym, lfp)
+    geom_a = O.Geometry1D(x, t_asym, a=0.0, b=2300.0, ngl=100)
+    lla = ma.loglik()
+    assert abs(lla - O.loglik(geom_a, hp, lfp)) / abs(lla) < 1e-8
+    f0, g0 = ma._objective_and_grad(ma._current_tparams(), False)
+    assert np.isfinite(f0) and np.all(np.isfinite(g0))
+    ma.predict(x, t_asym, type="csd")
+    hp0 = dict(hp)
+    hp0["jitter"] = 0.0
+    ref = O.predict(geom_a, hp0, lfp, x, t_asym, type="csd")["csd"]
+    assert relerr(ma.csd_pred, ref) < GATE
+    # beyond the capacity
+    t_big = 0.5 * np.arange(2100.0)[:, None]
+    t_big[-1, 0] += 0.123
+    mb = build(t_big, C.synth_lfp(272, 24, 2100, 1))
     with pytest.raises(gpcsd_amd.GPCSDCapacityError):
         mb.loglik()
     with pytest.raises(gpcsd_amd.GPCSDCapacityError):

@@ -392,6 +392,27 @@ def test_stedc_stage_hard_cases(ctx):
     run(np.full(90, 3.0), np.full(89, -0.5))                         # negative off-diagonals
 
 
+@pytest.mark.parametrize("n", [1100, 1400, 2048])
+def test_eigh_beyond_1024_rows(ctx, n):
+    """Round 3: one eigenproblem may have up to GPCSD_MAX_EIG_N = 2048 rows (per-column tridiagonalisation launches with 32
+    column chunks per thread, divide & conquer workspaces of 2048 entries in LDS, GEMM-chain back-transformation).  A GP
+    covariance (clustered, rank-deficient spectrum) and a random symmetric matrix against LAPACK: eigenvalues to n eps ||A||,
+    orthogonality and residual to 1e-13 n."""
+    rs = np.random.RandomState(n)
+    tt = np.sort(rs.uniform(0, 0.4 * n, n))
+    gp = 0.5 * np.exp(-0.5 * (tt[:, None] - tt[None, :]) ** 2 / 20.0 ** 2) + 0.7 * np.exp(-np.abs(tt[:, None] - tt[None, :]) / 5.0)
+    B = rs.standard_normal((n, n))
+    for A in (gp, 0.5 * (B + B.T)):
+        w, Z = ctx.eigh(A)
+        wr = np.linalg.eigvalsh(A)
+        nrm = np.max(np.abs(wr))
+        assert np.max(np.abs(w - wr)) < 4 * n * np.finfo(float).eps * nrm
+        assert np.max(np.abs(Z.T @ Z - np.eye(n))) < 1e-13 * n
+        assert np.max(np.abs(A @ Z - Z * w[None, :])) < 1e-13 * n * nrm
+    with pytest.raises(RuntimeError):
+        ctx.eigh(np.eye(2049))
+
+
 @pytest.mark.parametrize("n", [100, 384, 500])
 def test_eigh_gpcsd_shaped(ctx, n):
     """The actual Gram matrices of the hot path: numerically rank-deficient Ks, slowly decaying Kt."""
