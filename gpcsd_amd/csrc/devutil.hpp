@@ -4,7 +4,10 @@
 
 namespace gpcsd {
 
-constexpr int EIG_MAXN = 2048;                       // LDS vectors of the eigensolver are sized for this (= GPCSD_MAX_EIG_N)
+#ifndef GPCSD_EIG_MAXN_BUILD                          // (A/B builds only: -DGPCSD_EIG_MAXN_BUILD=1024 through GPCSD_CXXFLAGS)
+#define GPCSD_EIG_MAXN_BUILD 2048
+#endif
+constexpr int EIG_MAXN = GPCSD_EIG_MAXN_BUILD;       // LDS vectors of the eigensolver are sized for this (= GPCSD_MAX_EIG_N)
 constexpr int MAX_BATCH = 4;                         // independent eigenproblems sharing launches
 constexpr double EPS_U = 1.1102230246251565e-16;     // unit roundoff (LAPACK dlamch('E'))
 

@@ -13,7 +13,7 @@ for r in range(rounds):
         env = dict(os.environ, GPCSD_LIB_PATH=os.path.abspath(path))
         for kv in filter(None, extra.split(",")):
             env[kv.split("=", 1)[0]] = kv.split("=", 1)[1]
-        out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--no-cpu-baseline", "--steps", steps, "--warmup", "5"],
+        out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--only-value", "--steps", steps, "--warmup", "5"],
                              env=env, capture_output=True, text=True)
         if out.returncode != 0:
             print(out.stderr[-2000:])
