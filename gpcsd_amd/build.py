@@ -32,7 +32,7 @@ def _hipcc():
 
 
 def _deps():
-    hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hpp")]
+    hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hpp", ".inl"))]
     hdrs.append(os.path.join(os.path.dirname(HERE), "include", "gpcsd_hip.h"))
     hdrs.append(os.path.abspath(__file__))
     return max(os.path.getmtime(h) for h in hdrs)

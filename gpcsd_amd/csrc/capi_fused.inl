@@ -1,0 +1,693 @@
+// Part of capi.hip (included there: one translation unit, so the file-local helpers of capi.hip are in scope) --
+// fused hot calls on resident data: loglik (synchronous, queued), predict (folded / full-size, resident), the paired call, sample_prior.
+
+// ------------------------------------------------------------------------------------------------
+// fused hot calls
+// ------------------------------------------------------------------------------------------------
+// End of an asynchronous loglik: the scalars and status words go to the pinned block behind an event; nothing is waited for
+// and the status words are left alone (the chains of later calls may already be reporting into them).
+static int finish_loglik_async(gpcsd_ctx *c, const EigState &e, bool two) {
+    const int k = (c->ll_head + c->ll_count) % gpcsd_ctx::LL_SLOTS;       // callers have checked that a slot is free
+    gpcsd_ctx::LlSlot &sl = c->ll_slot[k];
+    GP_HIP(hipMemcpyAsync(c->h_ll + 66 * k, e.scal, 66 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    GP_HIP(hipEventRecord(sl.ev, c->stream));
+    ++c->ll_count;
+    sl.done = false;
+    sl.two = two;
+    c->async_pending = true;
+    c->status_zeroed = false;
+    return 0;
+}
+
+// Folded-basis tail of the log-likelihood: the two projections as 2 + 2 half-size GEMMs, the quadratic form as two partial
+// sums (one when the parity blocks went out as one batched launch: returns true), sum(log D) folded into the reduce launch.
+static bool loglik_fold_tail(gpcsd_ctx *c, EigState &e, const FoldMode &fm, const double *Yf, double *W) {
+    const int nx = c->nx, nt = c->nt, R = c->ntrials;
+    hipStream_t s = c->stream;
+    ++c->fold_gemm_calls;
+    fold_proj_spatial(c, fm.fs, Yf, W, (long)R * nt, s);
+    const int nparts = join_temporal(c, e, &fm, false);         // sum(log D): summed by the reduce launch of the GEMM below
+    GemmDesc g2[2];
+    g2[0].extra_sum_in = c->buf<double>("buildD_partials", 256);
+    g2[0].extra_sum_n = nparts;
+    g2[0].extra_sum_out = e.scal;
+    for (int p = 0; p < 2; ++p) {
+        const int np = p ? fm.ft.na : fm.ft.ns, c0 = p ? fm.ft.ns : 0;
+        g2[p].M = nx * R; g2[p].N = np; g2[p].K = np;
+        g2[p].A = W + c0; g2[p].lda = nt;
+        g2[p].B = fm.ft.U + (p ? (size_t)fm.ft.ns * fm.ft.ns : 0); g2[p].ldb = np;
+        g2[p].epi = EPI_QUAD; g2[p].D = e.Dinv + c0; g2[p].rdiv = R; g2[p].ldd = nt; g2[p].quad_out = e.scal + 1 + p;
+        g2[p].prof_name = "gemm_proj_temporal_quad";
+    }
+    return gemm_pair(c, g2[0], g2[1], s);
+}
+
+static int loglik_parts_impl(gpcsd_ctx *c, const gpcsd_hparams *hp, double *out2, bool async) {
+    GP_REQUIRE(c->d_lfp != nullptr, -4, "lfp not set (call gpcsd_set_lfp)");
+    if (async && c->prof_mode == 1) {     // fenced profiling (mode 1): evaluate now, hand the result over at the wait
+        gpcsd_ctx::LlSlot &sl = c->ll_slot[(c->ll_head + c->ll_count) % gpcsd_ctx::LL_SLOTS];
+        sl.rc = loglik_parts_impl(c, hp, sl.out, false);
+        sl.done = true;
+        ++c->ll_count;
+        return 0;
+    }
+    const FoldMode fm0 = fold_mode(c, hp);                          // the decision; its views are of the previous generation
+    const double *Yf = fm0.on ? folded_lfp(c, fm0) : nullptr;
+    EigState e = front_half(c, hp, hp->jitter, !fm0.on);
+    const FoldMode fm = fold_mode(c, hp);                           // views of the generation the front half just launched
+    const int nx = c->nx, nt = c->nt, R = c->ntrials;
+    hipStream_t s = c->stream;
+    double *W = c->buf<double>("proj_W", (size_t)nx * R * nt);
+    if (fm.on) {
+        const bool batched = loglik_fold_tail(c, e, fm, Yf, W);
+        if (async) return finish_loglik_async(c, e, !batched);
+        double h3[3] = {0.0, 0.0, 0.0};
+        const int rc = finish_call(c, e, h3, 3);
+        out2[0] = h3[0];
+        out2[1] = batched ? h3[1] : h3[1] + h3[2];
+        return rc;
+    }
+    GemmDesc g1;                          // W[x'][(r,t)] = sum_x Qs[x][x'] Y[x][(r,t)]        (gpcsd1d.py:125 inner dot)
+    g1.M = nx; g1.N = R * nt; g1.K = nx;
+    g1.A = e.Qs; g1.lda = nx; g1.transA = true;
+    g1.B = c->d_lfp; g1.ldb = (long)R * nt;
+    g1.C = W; g1.ldc = (long)R * nt;
+    g1.prof_name = "gemm_proj_spatial";
+    gemm_f64(c, g1, s);
+    join_temporal(c, e);
+    GemmDesc g2;                          // alpha[(x',r)][i'] = sum_t W[(x',r)][t] Qt[t][i'];  quad = sum alpha^2 / D
+    g2.M = nx * R; g2.N = nt; g2.K = nt;
+    g2.A = W; g2.lda = nt;
+    g2.B = e.Qt; g2.ldb = nt;
+    g2.epi = EPI_QUAD; g2.D = e.Dinv; g2.rdiv = R; g2.ldd = nt; g2.quad_out = e.scal + 1;
+    g2.prof_name = "gemm_proj_temporal_quad";
+    gemm_f64(c, g2, s);
+    if (async) return finish_loglik_async(c, e, false);
+    return finish_call(c, e, out2, 2);
+}
+
+extern "C" int gpcsd_loglik_parts(gpcsd_ctx *c, const gpcsd_hparams *hp, double *out2) {
+    GP_API_BEGIN(c)
+    GP_REQUIRE(out2 != nullptr, -3, "null output");
+    return loglik_parts_impl(c, hp, out2, false);
+    GP_API_END(c)
+}
+
+extern "C" int gpcsd_loglik_parts_async(gpcsd_ctx *c, const gpcsd_hparams *hp) {
+    if (c && c->ll_count >= gpcsd_ctx::LL_SLOTS)   // refused before anything is touched: the outstanding ones stay collectable
+        return fail(c, HipError{-3, "loglik_parts_async: too many asynchronous evaluations outstanding (collect with "
+                                    "gpcsd_loglik_parts_wait)"});
+    GP_API_BEGIN(c)
+    return loglik_parts_impl(c, hp, nullptr, true);
+    GP_API_END(c)
+}
+
+extern "C" int gpcsd_loglik_parts_wait(gpcsd_ctx *c, double *out2) {
+    if (c && (!out2 || c->ll_count == 0))
+        return fail(c, HipError{-3, out2 ? "loglik_parts_wait: no asynchronous evaluation pending" : "null output"});
+    GP_API_BEGIN(c)
+    const int k = c->ll_head;
+    gpcsd_ctx::LlSlot &sl = c->ll_slot[k];
+    c->ll_head = (k + 1) % gpcsd_ctx::LL_SLOTS;
+    --c->ll_count;
+    if (sl.done) {
+        out2[0] = sl.out[0];
+        out2[1] = sl.out[1];
+        return sl.rc;
+    }
+    GP_HIP(hipEventSynchronize(sl.ev));
+    const double *host = c->h_ll + 66 * k;
+    out2[0] = host[0];
+    out2[1] = sl.two ? host[1] + host[2] : host[1];
+    int st[4];
+    memcpy(st, host + 64, sizeof(st));
+    for (int i = 1; i < 4 && st[0] == 0; ++i) st[0] = st[i];
+    if (st[0] != 0) {                     // this evaluation's, or an earlier asynchronous call's that nobody collected yet
+        char b[160];
+        snprintf(b, sizeof(b), "numerical failure (status %d): eigensolver did not converge or matrix not positive definite", st[0]);
+        c->last_error = b;
+        // The status words are sticky while asynchronous work is outstanding (nobody may clear them under a running chain).
+        // Now that a failure has been reported: drain everything and clear them, so that evaluations queued from here on
+        // start clean.  Evaluations that were ALREADY outstanding copied the words as they stood and report the failure too
+        // (a failed wait poisons the ones queued before it returned; documented in gpcsd_hip.h).
+        drain_after_failure(c);
+        if (int *dst = reinterpret_cast<int *>(c->buf<double>("scal_status", 64 + 2) + 64)) {
+            GP_HIP(hipMemsetAsync(dst, 0, 4 * sizeof(int), c->stream));
+            GP_HIP(hipStreamSynchronize(c->stream));
+            c->status_zeroed = true;
+        }
+        return st[0] > 0 ? st[0] : 1;
+    }
+    return 0;
+    GP_API_END(c)
+}
+
+extern "C" int gpcsd_loglik(gpcsd_ctx *c, const gpcsd_hparams *hp, double *out) {
+    if (!out) return fail(c, HipError{-3, "null output"});
+    double p[2] = {0.0, 0.0};
+    int rc = gpcsd_loglik_parts(c, hp, p);
+    if (rc < 0) return rc;
+    *out = -0.5 * (double)c->ntrials * p[0] - 0.5 * p[1];      // gpcsd1d.py:122,127-128
+    return rc;
+}
+
+// Reflection symmetry of the prediction sites under the SAME reflection as the electrodes (then the cross-covariances
+// commute with the pair of involutions and fold as well).  Cached on the site coordinates; ns == 0: none.
+static const SymDev &site_symmetry(gpcsd_ctx *c, const double *z, int nz, int dim) {
+    const size_t cnt = (size_t)nz * dim;
+    if (c->sym_z_pts.size() == cnt && memcmp(c->sym_z_pts.data(), z, cnt * sizeof(double)) == 0) return c->sym_z;
+    c->sym_z_pts.assign(z, z + cnt);
+    if (c->geo_host.size() == cnt && memcmp(c->geo_host.data(), z, cnt * sizeof(double)) == 0) c->sym_z = c->sym_s;
+    else c->sym_z = find_symmetry(c, "sym_z_tbl", z, nz, dim, c->sym_s_ctr, c->sym_s_refl);
+    return c->sym_z;
+}
+
+// predict_impl in the folded basis (see FoldMode).  Prediction sites and times must share the symmetry of the grids:
+//   out_c = Fz^T [ diag_p( (Kc_pp^T U_p) ) Bm~ diag_q( V_q^T Kt*_c,qq ) ] Ft   with Bm~ = (diag(U)^T Y~ diag(V)) / D~ ,
+// every flat GEMM split in its two parity blocks; the last pass unfolds sites and times while it transposes.
+static int predict_fold(gpcsd_ctx *c, const gpcsd_hparams *hp, EigState &e, const FoldMode &fm, const double *Yf, const SymDev &sz,
+                        const double *dz, int nz, const double *dts, int type, bool want_lists, bool async,
+                        const std::function<void()> *after_spatial_join = nullptr) {
+    const Geo g = resident_geo(c);
+    const int nx = c->nx, nt = c->nt, R = c->ntrials, C = hp->n_temporal;
+    const long RT = (long)R * nt;
+    const int ns = fm.fs.ns, na = fm.fs.na, nts = fm.ft.ns, nta = fm.ft.na, nzs = sz.ns, nza = sz.na;
+    hipStream_t s = c->stream;
+    double *W = c->buf<double>("proj_W", (size_t)nx * RT);
+    double *Bm = c->buf<double>("pred_B", (size_t)nx * RT);
+    const double *t = (const double *)c->bufs["time_t"].p;
+    double *Kc = c->buf<double>("pred_Kcross", (size_t)nx * nz);
+    const size_t kcf_sz = (size_t)ns * nzs + (size_t)na * nza;
+    double *Kcf = c->buf<double>("pred_Kcross_fold", 2 * kcf_sz);
+    double *S = c->buf<double>("pred_S", (size_t)nz * RT);
+    // comp~ and Pcat keep every (parity, component) block of columns on a 128-byte boundary (block widths padded to a multiple
+    // of 16 doubles): the final relayout pass reads comp~ in 16-column pieces per trial row, and unaligned blocks (250 columns)
+    // made every piece straddle two cache lines -- 291 MB fetched for 154 MB of comp~ per cfg3 step
+    const int ntsP = (nts + 15) & ~15, ntaP = (nta + 15) & ~15;
+    // (+16: a row stride that is a power of two -- 1024 doubles at nt = 500 -- walks the same HBM channels row after row)
+    const long ldcomp = (long)C * (ntsP + ntaP) + 16;
+    double *comp = c->buf<double>("pred_comp", std::max((size_t)C * nz * RT, (size_t)nz * R * ldcomp));
+    double *Kts = c->buf<double>("pred_Ktstar", (size_t)C * nt * nt);
+    const size_t ktf_sz = (size_t)nts * nts + (size_t)nta * nta;
+    double *Ktf = c->buf<double>("pred_Ktstar_fold", (size_t)C * ktf_sz);
+    const size_t m1_sz = (size_t)nzs * ns + (size_t)nza * na;
+    double *M1 = c->buf<double>("pred_M1", 2 * std::max(m1_sz, (size_t)nz * nx));
+    const size_t pc_s = (size_t)nts * C * ntsP;                     // Pcat_sym: nts rows of C * ntsP columns; Pcat_anti follows
+    double *Pc = c->buf<double>("pred_Pc", std::max(pc_s + (size_t)nta * C * ntaP, (size_t)C * nt * nt));
+    const size_t out_elems = (size_t)nz * RT;
+    ++c->fold_gemm_calls;
+    // what needs neither decomposition runs first, beside both chains: the cross-covariances and the prediction-time Grams,
+    // folded
+    for (int which = 1; which <= 2; ++which) {
+        if (!(type & which)) continue;
+        double *kf = Kcf + (size_t)(which - 1) * kcf_sz;
+        if (which == 1) build_kphig(c, g, hp->R, hp->eps, hp->ell_s, dz, nz, Kc, s);        // gpcsd1d.py:273
+        else build_kphi(c, g, hp->R, hp->eps, hp->ell_s, dz, nz, 0.0, Kc, s);               // gpcsd1d.py:275
+        k_sym_fold_rect(c, Kc, nz, fm.sym_s, sz, kf, kf + (size_t)ns * nzs, s);
+    }
+    for (int cc = 0; cc < C; ++cc) {
+        temporal_cross_gram(c, hp, cc, dts, nt, t, nt, Kts + (size_t)cc * nt * nt, s);
+        k_sym_fold_rect(c, Kts + (size_t)cc * nt * nt, nt, fm.sym_t, fm.sym_t, Ktf + cc * ktf_sz,
+                        Ktf + cc * ktf_sz + (size_t)nts * nts, s);
+    }
+    // then everything that needs only the spatial eigenvectors, beside the temporal eigensolver
+    join_spatial(c, e);
+    // gpcsd_loglik_predict_async: the log-likelihood's whole tail goes here, in front of everything of predict that needs a
+    // decomposition -- it is what the caller waits for
+    if (after_spatial_join) (*after_spatial_join)();
+    fold_proj_spatial(c, fm.fs, Yf, W, RT, s);                      // W~ = diag(U)^T Y~
+    for (int which = 1; which <= 2; ++which) {
+        if (!(type & which)) continue;
+        const double *kf = Kcf + (size_t)(which - 1) * kcf_sz;
+        for (int p = 0; p < 2; ++p) {
+            const int np = p ? na : ns, nzp = p ? nza : nzs;
+            if (np == 0 || nzp == 0) continue;
+            GemmDesc gm;                  // M1_p[zq][x'] = sum_xq Kc~_pp[xq][zq] U_p[xq][x']
+            gm.M = nzp; gm.N = np; gm.K = np;
+            gm.A = kf + (p ? (size_t)ns * nzs : 0); gm.lda = nzp; gm.transA = true;
+            gm.B = fm.fs.U + (p ? (size_t)ns * ns : 0); gm.ldb = np;
+            gm.C = M1 + (size_t)(which - 1) * m1_sz + (p ? (size_t)nzs * ns : 0); gm.ldc = np;
+            gm.prof_name = "gemm_pred_M1";
+            gemm_f64(c, gm, s);
+        }
+    }
+    join_temporal(c, e, &fm, false);      // predict never reads sum(log D)
+    GemmDesc g2[2];                       // Bm~[:, p block] = (W~[:, p block] V_p) / D~
+    for (int p = 0; p < 2; ++p) {
+        const int np = p ? nta : nts, c0 = p ? nts : 0;
+        g2[p].M = nx * R; g2[p].N = np; g2[p].K = np;
+        g2[p].A = W + c0; g2[p].lda = nt;
+        g2[p].B = fm.ft.U + (p ? (size_t)nts * nts : 0); g2[p].ldb = np;
+        g2[p].C = Bm + c0; g2[p].ldc = nt;
+        g2[p].epi = EPI_DIV_D; g2[p].D = e.Dinv + c0; g2[p].rdiv = R; g2[p].ldd = nt;
+        g2[p].prof_name = "gemm_pred_temporal_div";
+    }
+    // Pcat = V^T Kt*~ needs the temporal eigenvectors and the folded prediction-time Grams only: it runs on a stream of its
+    // own beside the large Bm~ / S~ products of the main stream instead of in front of them (two small launches off the
+    // serial tail) -- not on stream2, where it would sit between this call's temporal chain and the next call's
+    GP_HIP(hipEventRecord(c->ev_aux, s));                            // Kt*~ and the temporal eigenvectors are complete here
+    GP_HIP(hipStreamWaitEvent(c->stream4, c->ev_aux, 0));
+    for (int p = 0; p < 2; ++p) {
+        const int np = p ? nta : nts, npP = p ? ntaP : ntsP;
+        if (np == 0) continue;
+        GemmDesc gp;                      // Pcat_p[i'][cc*npP + b] = sum_j V_p[j][i'] Kt*~_cc,pp[j][b], all components batched
+        gp.M = np; gp.N = np; gp.K = np;
+        gp.A = fm.ft.U + (p ? (size_t)nts * nts : 0); gp.lda = np; gp.transA = true;
+        gp.B = Ktf + (p ? (size_t)nts * nts : 0); gp.ldb = np;
+        gp.C = Pc + (p ? pc_s : 0); gp.ldc = (long)C * npP;
+        gp.batch = C; gp.sA = 0; gp.sB = (long)ktf_sz; gp.sC = npP;
+        gp.prof_name = "gemm_pred_Pc";
+        gemm_f64(c, gp, c->stream4);
+    }
+    GP_HIP(hipEventRecord(c->ev_pc, c->stream4));
+    c->tl("Pc end (s4)", c->stream4);
+    gemm_pair(c, g2[0], g2[1], s);
+    for (int which = 1; which <= 2; ++which) {
+        if (!(type & which)) continue;
+        double *o_sum = c->buf<double>(which == 1 ? "pred_out_csd" : "pred_out_lfp", out_elems);
+        double *o_list = want_lists ? c->buf<double>(which == 1 ? "pred_out_csd_list" : "pred_out_lfp_list", out_elems * C)
+                                    : nullptr;
+        GemmDesc g5[2], g6[2];
+        for (int p = 0; p < 2; ++p) {     // S~[p rows] = M1_p Bm~[p rows]
+            const int np = p ? na : ns, nzp = p ? nza : nzs;
+            g5[p].M = nzp; g5[p].N = (int)RT; g5[p].K = np;
+            g5[p].A = M1 + (size_t)(which - 1) * m1_sz + (p ? (size_t)nzs * ns : 0); g5[p].lda = np;
+            g5[p].B = Bm + (p ? (size_t)ns * RT : 0); g5[p].ldb = RT;
+            g5[p].C = S + (p ? (size_t)nzs * RT : 0); g5[p].ldc = RT;
+            g5[p].prof_name = "gemm_pred_cross";
+        }
+        gemm_pair(c, g5[0], g5[1], s);
+        if (which == 1 || !(type & 1)) GP_HIP(hipStreamWaitEvent(s, c->ev_pc, 0));     // Pcat (stream4) before its first use
+        for (int p = 0; p < 2; ++p) {     // comp~[(zq, r)][p][cc][b] = sum_i' S~[(zq, r)][p block i'] Pcat_p[i'][cc*npP + b]
+            const int np = p ? nta : nts, npP = p ? ntaP : ntsP, c0 = p ? nts : 0;
+            // (the padding columns between two components are computed along -- whatever Pcat holds there only reaches comp~'s
+            // own padding columns, which nobody reads; the last component's padding is left out)
+            g6[p].M = nz * R; g6[p].N = (C - 1) * npP + np; g6[p].K = np;
+            g6[p].A = S + c0; g6[p].lda = nt;
+            g6[p].B = Pc + (p ? pc_s : 0); g6[p].ldb = (long)C * npP;
+            g6[p].C = comp + (p ? (size_t)C * ntsP : 0); g6[p].ldc = ldcomp;
+            g6[p].prof_name = "gemm_pred_tstar";
+        }
+        if (gemm_pred_unfold_supported(C, (long)nz * R, nt)) {
+            // ... as ONE launch whose epilogue unfolds in site and time, turns (r, t) into (t, r) and sums the components:
+            // comp~ is never written (gemm_f64.hip: gemm_pred_unfold_kernel)
+            PredUnfoldDesc pu{};
+            pu.S = S; pu.lds = nt;
+            pu.Pc[0] = Pc; pu.Pc[1] = Pc + pc_s;
+            pu.ldp[0] = (long)C * ntsP; pu.ldp[1] = (long)C * ntaP;
+            pu.npP[0] = ntsP; pu.npP[1] = ntaP;
+            pu.K[0] = nts; pu.K[1] = nta;
+            pu.kcol0[0] = 0; pu.kcol0[1] = nts;
+            pu.nb = nts; pu.nba = nta;
+            pu.ncolS = (long)nzs * R; pu.ncolA = (long)nza * R; pu.anti_row0 = (long)nzs * R;
+            pu.R = R; pu.nt = nt; pu.C = C;
+            pu.sz = sz; pu.st = fm.sym_t;
+            pu.list = o_list; pu.list_stride = (long)out_elems; pu.sum = o_sum;
+            gemm_pred_unfold(c, pu, s);
+        } else {
+            gemm_pair(c, g6[0], g6[1], s);
+            k_unfold_swap_sum(c, comp, C, o_list, (long)out_elems, o_sum, R, nt, sz, fm.sym_t, s, ntsP, ntaP, ldcomp);
+        }
+    }
+    c->tl("predict end (main)", s);
+    if (async && c->prof_mode != 1) {     // results stay on the device: return with the tail still in flight
+        c->async_pending = true;
+        c->status_zeroed = false;
+        return 0;
+    }
+    return finish_call(c, e, nullptr, 0);
+}
+
+// Posterior mean into ctx-owned device buffers, already in the reference's output layout (z, t, trial):
+//   pred_out_csd / pred_out_lfp            (nz, ntstar, R)
+//   pred_out_csd_list / pred_out_lfp_list  (C, nz, ntstar, R)     when want_lists
+static int predict_impl(gpcsd_ctx *c, const gpcsd_hparams *hp, const double *z, int nz, const double *tstar, int ntstar,
+                        int type, bool want_lists, bool async = false) {
+    GP_REQUIRE(z && tstar && nz > 0 && ntstar > 0, -3, "predict: bad arguments");
+    GP_REQUIRE(type >= 1 && type <= 3, -3, "predict: type must be CSD(1), LFP(2) or BOTH(3)");
+    GP_REQUIRE(c->nt > 0 && ntstar == c->nt, -22,
+               "predict: len(t)=%d must equal the training nt=%d (the reference's reshape raises ValueError, gpcsd1d.py:279)",
+               ntstar, c->nt);
+    GP_REQUIRE(c->d_lfp != nullptr, -4, "lfp not set (call gpcsd_set_lfp)");
+    // folded basis when the grids, the prediction sites and the prediction times all share the reflection symmetries
+    const FoldMode fm0 = fold_mode(c, hp);         // the decision only: views are taken after the front half
+    // a folded side needs its outputs on a grid with the same symmetry (t* = t; mirror-symmetric sites); an unfolded side
+    // takes any sites / times
+    const bool t_ok = fm0.on && ntstar == c->nt &&
+                      (!fm0.ft.on || ((int)c->time_host.size() == c->nt &&
+                                      memcmp(c->time_host.data(), tstar, (size_t)ntstar * sizeof(double)) == 0));
+    if (t_ok) {
+        const SymDev sz = fm0.fs.on ? site_symmetry(c, z, nz, c->dim) : identity_sym(c, nz);
+        if (sz.ns > 0 && sz.ns + sz.na == nz) {
+            // the chains go first (they need no upload of this call), then the host-side uploads
+            EigState ef = front_half(c, hp, 0.0, false, /*join_s=*/false);  // no jitter in predict (gpcsd1d.py:258)
+            const FoldMode fm = fold_mode(c, hp);
+            const double *Yf = folded_lfp(c, fm);
+            double *dzf = c->upload_cached<double>("pred_z", z, (size_t)nz * c->dim);
+            double *dtf = c->upload_cached<double>("pred_tstar", tstar, ntstar);
+            return predict_fold(c, hp, ef, fm, Yf, sz, dzf, nz, dtf, type, want_lists, async);
+        }
+    }
+    EigState e = front_half(c, hp, 0.0);           // no jitter in predict (gpcsd1d.py:258)
+    const Geo g = resident_geo(c);
+    const int nx = c->nx, nt = c->nt, R = c->ntrials, C = hp->n_temporal;
+    const long RT = (long)R * nt;
+    hipStream_t s = c->stream;
+    double *W = c->buf<double>("proj_W", (size_t)nx * RT);
+    double *Bm = c->buf<double>("pred_B", (size_t)nx * RT);
+    GemmDesc g1;                          // W = Qs^T Y
+    g1.M = nx; g1.N = (int)RT; g1.K = nx;
+    g1.A = e.Qs; g1.lda = nx; g1.transA = true;
+    g1.B = c->d_lfp; g1.ldb = RT; g1.C = W; g1.ldc = RT;
+    g1.prof_name = "gemm_proj_spatial";
+    gemm_f64(c, g1, s);
+    // invy = (Qs (x) Qt) vec(Bm) (gpcsd1d.py:262-265) is never formed: the cross-covariance contraction
+    //   out_c = Kc^T Qs Bm Qt^T Kt*_c  is re-associated as  (Kc^T Qs) Bm (Qt^T Kt*_c),
+    // i.e. two small (n^3) products M1, Pc and two flat GEMMs, instead of back-projecting to the original bases first
+    // (saves 2 nx^2 nt + 2 nx nt^2 flops per trial; identical up to rounding).
+    double *dz = c->upload_cached<double>("pred_z", z, (size_t)nz * g.dim);
+    double *dts = c->upload_cached<double>("pred_tstar", tstar, ntstar);
+    const double *t = (const double *)c->bufs["time_t"].p;
+    double *Kc = c->buf<double>("pred_Kcross", (size_t)nx * nz);
+    double *S = c->buf<double>("pred_S", (size_t)nz * RT);
+    double *comp = c->buf<double>("pred_comp", (size_t)C * nz * RT);
+    double *Kts = c->buf<double>("pred_Ktstar", (size_t)C * ntstar * nt);
+    double *M1 = c->buf<double>("pred_M1", (size_t)2 * nz * nx);
+    double *Pc = c->buf<double>("pred_Pc", (size_t)C * nt * nt);
+    const size_t out_elems = (size_t)nz * RT;
+    // Everything that needs only Qs is queued before the join, i.e. it runs beside the temporal eigensolver:
+    // cross-covariances Kc, M1 = Kc^T Qs for the requested outputs, and the prediction-time temporal Grams.
+    for (int which = 1; which <= 2; ++which) {
+        if (!(type & which)) continue;
+        if (which == 1) build_kphig(c, g, hp->R, hp->eps, hp->ell_s, dz, nz, Kc, s);        // gpcsd1d.py:273
+        else build_kphi(c, g, hp->R, hp->eps, hp->ell_s, dz, nz, 0.0, Kc, s);               // gpcsd1d.py:275
+        GemmDesc gm;                      // M1[z][x'] = sum_x Kc[x][z] Qs[x][x']
+        gm.M = nz; gm.N = nx; gm.K = nx;
+        gm.A = Kc; gm.lda = nz; gm.transA = true; gm.B = e.Qs; gm.ldb = nx; gm.C = M1 + (size_t)(which - 1) * nz * nx; gm.ldc = nx;
+        gm.prof_name = "gemm_pred_M1";
+        gemm_f64(c, gm, s);
+    }
+    for (int cc = 0; cc < C; ++cc) {
+        // Ktstar_c = cov_c.compute_Kt(tstar): (ntstar, nt); its FIRST axis is contracted with the training
+        // time index (reference quirk when tstar != t)      gpcsd1d.py:277-279
+        temporal_cross_gram(c, hp, cc, dts, ntstar, t, nt, Kts + (size_t)cc * ntstar * nt, s);
+    }
+    join_temporal(c, e, nullptr, false);      // predict never reads sum(log D)
+    GemmDesc g2;                          // Bm = (W Qt) / D
+    g2.M = nx * R; g2.N = nt; g2.K = nt;
+    g2.A = W; g2.lda = nt; g2.B = e.Qt; g2.ldb = nt; g2.C = Bm; g2.ldc = nt;
+    g2.epi = EPI_DIV_D; g2.D = e.Dinv; g2.rdiv = R; g2.ldd = nt;
+    g2.prof_name = "gemm_pred_temporal_div";
+    gemm_f64(c, g2, s);
+    for (int which = 1; which <= 2; ++which) {
+        if (!(type & which)) continue;
+        double *o_sum = c->buf<double>(which == 1 ? "pred_out_csd" : "pred_out_lfp", out_elems);
+        double *o_list = want_lists ? c->buf<double>(which == 1 ? "pred_out_csd_list" : "pred_out_lfp_list", out_elems * C)
+                                    : nullptr;
+        GemmDesc g5;                      // S[z][(r,i')] = sum_x' M1[z][x'] Bm[x'][(r,i')]
+        g5.M = nz; g5.N = (int)RT; g5.K = nx;
+        g5.A = M1 + (size_t)(which - 1) * nz * nx; g5.lda = nx; g5.B = Bm; g5.ldb = RT; g5.C = S; g5.ldc = RT;
+        g5.prof_name = "gemm_pred_cross";
+        gemm_f64(c, g5, s);
+        for (int cc = 0; cc < C; ++cc) {
+            GemmDesc gp;                  // Pcat[i'][cc*nt + t'] = sum_j Qt[j][i'] Ktstar_cc[j][t']
+            gp.M = nt; gp.N = nt; gp.K = ntstar;
+            gp.A = e.Qt; gp.lda = nt; gp.transA = true; gp.B = Kts + (size_t)cc * ntstar * nt; gp.ldb = nt;
+            gp.C = Pc + (size_t)cc * nt; gp.ldc = (long)C * nt;
+            gp.prof_name = "gemm_pred_Pc";
+            gemm_f64(c, gp, s);
+        }
+        // All temporal components in ONE flat GEMM: out[(z,r)][cc*nt + t'] = sum_i' S[(z,r)][i'] Pcat[i'][cc*nt + t'],
+        // then one pass writes every component in the reference's (z, t, r) layout plus their sum (no read-modify-write
+        // epilogue, one launch instead of C, a single relayout pass instead of C + 1).
+        GemmDesc g6;
+        g6.M = nz * R; g6.N = C * nt; g6.K = nt;
+        g6.A = S; g6.lda = nt; g6.B = Pc; g6.ldb = (long)C * nt; g6.C = comp; g6.ldc = (long)C * nt;
+        g6.prof_name = "gemm_pred_tstar";
+        gemm_f64(c, g6, s);
+        k_swap_last2_sum(c, comp, C, o_list, (long)out_elems, o_sum, nz, R, nt, s);     // (z,r,c,t) -> (c,z,t,r), sum over c
+    }
+    return finish_call(c, e, nullptr, 0);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// loglik + predict as ONE queued call with the four decompositions batched two by two.
+//
+// Chains of small dependent launches do not overlap on this part (1.4x at best, however many queues), but
+// replicas inside one chain are nearly free (gpcsd_eigh_batch: 8 problems in 1.09 ms against 0.93 ms for one).  So when a
+// caller wants the log-likelihood at one hyper-parameter set and the prediction at another (the same set without jitter, in
+// practice), the two temporal problems go through ONE chain as two replicas and the two spatial problems through another:
+// two chains per pair of calls instead of four.  Every problem is still solved (nothing is reused between the two unless the
+// decomposition cache is on and the temporal hyper-parameters coincide: then that side is solved once, as the cache would).
+// Results: the bits of the two calls made separately.
+struct PairFront {
+    EigState e[2];
+    FoldMode fm[2];
+};
+
+static bool same_temporal(const gpcsd_hparams *a, const gpcsd_hparams *b) {
+    if (a->n_temporal != b->n_temporal) return false;
+    for (int i = 0; i < a->n_temporal; ++i)
+        if (a->kind[i] != b->kind[i] || a->ell_t[i] != b->ell_t[i] || a->sigma2_t[i] != b->sigma2_t[i]) return false;
+    return true;
+}
+
+// Both sets decomposed, set b's results at replica b of the generation just started (folded-basis callers only).
+static void front_half_pair(gpcsd_ctx *c, const gpcsd_hparams *const hp[2], const double jitter[2], PairFront &out) {
+    const Geo g = resident_geo(c);
+    const int nx = c->nx, nt = c->nt;
+    const long nxx = (long)nx * nx, ntt = (long)nt * nt;
+    hipStream_t s = c->stream, s2 = c->stream2, s3 = c->stream3;
+    const SymDev *sym_s = c->sym_s.ns > 0 ? &c->sym_s : nullptr, *sym_t = c->sym_t.ns > 0 ? &c->sym_t : nullptr;
+    const double *t = (const double *)c->bufs["time_t"].p;
+    const int nT = (c->decomp_cache_on && same_temporal(hp[0], hp[1])) ? 1 : 2;      // replicas of the temporal problem
+    double *scal = c->buf<double>("scal_status", 64 + 2);
+    int *status = reinterpret_cast<int *>(scal + 64);
+    const bool clear_now = !c->status_zeroed && !c->async_pending;
+    if (clear_now) GP_HIP(hipMemsetAsync(status, 0, 4 * sizeof(int), s));
+    c->status_zeroed = false;
+    begin_generation(c, 1, s2, clear_now);
+    begin_generation(c, 0, s3, clear_now);
+    // inputs and outputs (of the generations just started), two replicas each.  The inputs have names of their own: the
+    // one-chain form below reads them on stream2, the separate calls' spatial chain writes "Ks" on stream3.
+    double *Ks = c->buf<double>("Ks_pair", (size_t)nxx * 2), *Kt = c->buf<double>("Kt_pair", (size_t)ntt * 2);
+    double *Qs = c->buf<double>(gen_name(c, 0, "Qs"), (size_t)nxx * 2), *es = c->buf<double>(gen_name(c, 0, "es"), (size_t)nx * 2);
+    double *Qt = c->buf<double>(gen_name(c, 1, "Qt"), (size_t)ntt * 2), *et = c->buf<double>(gen_name(c, 1, "et"), (size_t)nt * 2);
+    const FoldView vs = sym_s ? eigh_fold_view(c, 0, sym_s, nx, 2) : FoldView(), vt = sym_t ? eigh_fold_view(c, 1, sym_t, nt, 2) : FoldView();
+    c->tl("call start (main)", s);
+    // Gram matrices.  Temporal (stream2): replica b = Kt(hp[b]).  Spatial (stream3): replica b = Ks(hp[b]) + jitter[b] I; with
+    // equal spatial hyper-parameters -- the usual pair -- the two differ by the diagonal shift only, so the matrix is
+    // assembled once and copied (the same GEMM output plus the same diagonal add: the same bits).
+    c->tl("T chain start (s2)", s2);
+    const bool tfill = temporal_fill_applies(c, sym_t, nt, false);       // (the paired call is refused for host temporal Grams)
+    if (tfill) temporal_fill(c, hp, nT, t, nt, *sym_t, status + 1, 2, s2);
+    else for (int b = 0; b < nT; ++b) build_kt(c, hp[b], t, nt, t, nt, Kt + b * ntt, s2);
+    // the temporal chain is the critical path of the call: it is queued before the host spends its time on the launches of the
+    // spatial Gram assembly (status words [1], [3]; one replica when the problem is shared -- decomposition cache on, equal
+    // temporal hyper-parameters).  (All four problems in ONE chain was measured slower, 1.38 against 1.18 ms per cfg3 step: with
+    // two chains the log-likelihood's spatial projection runs under the end of the temporal one.)
+    {
+        ProfScope ps(c, "eigh_temporal", 9.0 * (double)nt * nt * nt * nT, s2);
+        eigh_pair_device(c, nullptr, 0, nullptr, nullptr, nullptr, Kt, nt, et, Qt, sym_t, status + 1, s2, false, nT, 2, -1,
+                         tfill ? 2 : 0);
+    }
+    GP_HIP(hipEventRecord(c->ev_join, s2));
+    c->tl("T chain end (s2)", s2);
+    c->tl("S chain start (s3)", s3);
+    const bool same_ks = hp[0]->R == hp[1]->R && hp[0]->ell_s[0] == hp[1]->ell_s[0] &&
+                         (g.dim == 1 || (hp[0]->eps == hp[1]->eps && hp[0]->ell_s[1] == hp[1]->ell_s[1]));
+    const bool sfill = spatial_fill_applies(c, sym_s, nx);
+    if (sfill) {
+        // the fill folds Ks and adds each replica's jitter to the folded diagonals: one assembly, no copy, no diagonal pass
+        if (same_ks) build_kphi(c, g, hp[0]->R, hp[0]->eps, hp[0]->ell_s, nullptr, 0, 0.0, Ks, s3, "ks_");
+        else for (int b = 0; b < 2; ++b) build_kphi(c, g, hp[b]->R, hp[b]->eps, hp[b]->ell_s, nullptr, 0, 0.0, Ks + b * nxx, s3, "ks_");
+        spatial_fill(c, Ks, nx, same_ks ? 0 : nxx, 2, jitter, *sym_s, status, 2, s3);
+    } else if (same_ks) {
+        const int lo = jitter[0] == 0.0 ? 0 : 1, hi = 1 - lo;           // assemble the one without a shift (if any) first
+        build_kphi(c, g, hp[lo]->R, hp[lo]->eps, hp[lo]->ell_s, nullptr, 0, 0.0, Ks + lo * nxx, s3, "ks_");
+        GP_HIP(hipMemcpyAsync(Ks + hi * nxx, Ks + lo * nxx, (size_t)nxx * sizeof(double), hipMemcpyDeviceToDevice, s3));
+        if (jitter[lo] != 0.0) k_add_diag(c, Ks + lo * nxx, nx, jitter[lo], s3);
+        if (jitter[hi] != 0.0) k_add_diag(c, Ks + hi * nxx, nx, jitter[hi], s3);
+    } else {
+        for (int b = 0; b < 2; ++b) build_kphi(c, g, hp[b]->R, hp[b]->eps, hp[b]->ell_s, nullptr, 0, jitter[b], Ks + b * nxx, s3, "ks_");
+    }
+    // two replicas of the spatial problem on stream3 (status words [0], [2])
+    {
+        ProfScope ps(c, "eigh_spatial", 9.0 * (double)nx * nx * nx * 2, s3);
+        eigh_pair_device(c, Ks, nx, es, Qs, sym_s, nullptr, 0, nullptr, nullptr, nullptr, status, s3, false, 2, 2, -1,
+                         sfill ? 1 : 0);
+    }
+    GP_HIP(hipEventRecord(c->ev_sjoin, s3));
+    c->tl("S chain end (s3)", s3);
+    c->decomp_gen[0] = c->decomp_gen[1] = -1;          // replicas are not what the separate calls' cache looks for
+    const double *d_sig[2] = {c->upload_cached<double>("sig2n", hp[0]->sig2n, 1), c->upload_cached<double>("sig2n_pair", hp[1]->sig2n, 1)};
+    for (int b = 0; b < 2; ++b) {
+        const int bt = nT == 2 ? b : 0;
+        EigState &e = out.e[b];
+        e.Qs = Qs + b * nxx; e.es = es + (long)b * nx; e.Qt = Qt + bt * ntt; e.et = et + (long)bt * nt;
+        e.D = c->buf<double>("D", (size_t)nx * nt);
+        e.Dinv = c->buf<double>("Dinv", (size_t)nx * nt);
+        e.scal = scal;
+        e.status = status;
+        e.pending = true;
+        e.wait_temporal = e.wait_spatial = true;
+        e.d_sig = d_sig[b];
+        e.nsig = 1;
+        FoldMode &fm = out.fm[b];
+        fm = fold_mode(c, hp[b]);                       // replica 0 of the generations just started ...
+        if (fm.fs.on) { fm.fs.w += (long)b * vs.sw; fm.fs.U += (long)b * vs.sU; }       // ... moved to replica b
+        else { fm.fs.w += (long)b * nx; fm.fs.U += b * nxx; }
+        if (fm.ft.on) { fm.ft.w += (long)bt * vt.sw; fm.ft.U += (long)bt * vt.sU; }
+        else { fm.ft.w += (long)bt * nt; fm.ft.U += bt * ntt; }
+    }
+}
+
+// Collect the status words of an asynchronous predict (see gpcsd_ctx::async_pending): drains the streams.
+static int drain_async(gpcsd_ctx *c) {
+    if (!c->async_pending) return 0;
+    c->async_pending = false;
+    int *st = reinterpret_cast<int *>(c->buf<double>("scal_status", 64 + 2) + 64);
+    GP_HIP(hipStreamSynchronize(c->stream2));
+    GP_HIP(hipStreamSynchronize(c->stream3));
+    return finish_status(c, st);          // downloads + synchronises; the words are cleared by the next call's front half
+}
+
+extern "C" int gpcsd_predict_resident(gpcsd_ctx *c, const gpcsd_hparams *hp, const double *z, int nz, const double *tstar,
+                                      int ntstar, int type, int want_lists) {
+    GP_API_BEGIN(c)
+    return predict_impl(c, hp, z, nz, tstar, ntstar, type, want_lists != 0, /*async=*/true);
+    GP_API_END(c)
+}
+
+extern "C" int gpcsd_loglik_predict_async(gpcsd_ctx *c, const gpcsd_hparams *hp_ll, const gpcsd_hparams *hp_pr, const double *z, int nz,
+                                          const double *tstar, int ntstar, int type, int want_lists) {
+    if (c && c->ll_count >= gpcsd_ctx::LL_SLOTS)
+        return fail(c, HipError{-3, "loglik_predict_async: too many asynchronous evaluations outstanding (collect with "
+                                    "gpcsd_loglik_parts_wait)"});
+    GP_API_BEGIN(c)
+    GP_REQUIRE(hp_ll && hp_pr, -3, "loglik_predict_async: null hparams");
+    GP_REQUIRE(z && tstar && nz > 0 && ntstar > 0, -3, "predict: bad arguments");
+    GP_REQUIRE(type >= 1 && type <= 3, -3, "predict: type must be CSD(1), LFP(2) or BOTH(3)");
+    GP_REQUIRE(c->nt > 0 && ntstar == c->nt, -22,
+               "predict: len(t)=%d must equal the training nt=%d (the reference's reshape raises ValueError, gpcsd1d.py:279)",
+               ntstar, c->nt);
+    GP_REQUIRE(c->d_lfp != nullptr, -4, "lfp not set (call gpcsd_set_lfp)");
+    // the paired front half serves the folded-basis tails only; anything else is the two calls one after the other
+    bool pair = two_stream_front() && c->prof_mode != 1 && !uses_host_kt(hp_ll) && !uses_host_kt(hp_pr) &&
+                hp_ll->n_sig2n == 1 && hp_pr->n_sig2n == 1;
+    FoldMode fm0;
+    SymDev sz;
+    if (pair) {
+        fm0 = fold_mode(c, hp_ll);
+        pair = fm0.on && fold_mode(c, hp_pr).on &&
+               (!fm0.ft.on || ((int)c->time_host.size() == c->nt &&
+                               memcmp(c->time_host.data(), tstar, (size_t)ntstar * sizeof(double)) == 0));
+    }
+    if (pair) {
+        sz = fm0.fs.on ? site_symmetry(c, z, nz, c->dim) : identity_sym(c, nz);
+        pair = sz.ns > 0 && sz.ns + sz.na == nz;
+    }
+    if (!pair) {
+        const int rc = loglik_parts_impl(c, hp_ll, nullptr, true);
+        if (rc != 0) return rc;
+        return predict_impl(c, hp_pr, z, nz, tstar, ntstar, type, want_lists != 0, true);
+    }
+    GP_REQUIRE(c->time_nt == c->nt, -4, "time grid has %d points but lfp has nt=%d", c->time_nt, c->nt);
+    GP_REQUIRE(resident_geo(c).nx == c->nx, -4, "geometry has %d electrodes but lfp has nx=%d", resident_geo(c).nx, c->nx);
+    check_hp(c, hp_ll, c->nx);
+    check_hp(c, hp_pr, c->nx);
+    const gpcsd_hparams *hps[2] = {hp_ll, hp_pr};
+    const double jit[2] = {hp_ll->jitter, 0.0};          // no jitter in predict (gpcsd1d.py:258)
+    PairFront pf;
+    front_half_pair(c, hps, jit, pf);
+    const double *Yf = folded_lfp(c, pf.fm[1]);
+    double *dzf = c->upload_cached<double>("pred_z", z, (size_t)nz * c->dim);
+    double *dtf = c->upload_cached<double>("pred_tstar", tstar, ntstar);
+    const std::function<void()> ll_tail = [&]() {
+        double *Wll = c->buf<double>("proj_W_ll", (size_t)c->nx * c->ntrials * c->nt);
+        const bool batched = loglik_fold_tail(c, pf.e[0], pf.fm[0], Yf, Wll);
+        (void)finish_loglik_async(c, pf.e[0], !batched);
+    };
+    return predict_fold(c, hp_pr, pf.e[1], pf.fm[1], Yf, sz, dzf, nz, dtf, type, want_lists != 0, true, &ll_tail);
+    GP_API_END(c)
+}
+
+extern "C" int gpcsd_fetch(gpcsd_ctx *c, const char *name, double *host, long count) {
+    GP_API_BEGIN(c)
+    GP_REQUIRE(name && host && count > 0, -3, "fetch: bad arguments");
+    auto it = c->bufs.find(name);
+    GP_REQUIRE(it != c->bufs.end() && it->second.p, -2, "fetch: no device buffer named '%s'", name);
+    GP_REQUIRE((size_t)count * sizeof(double) <= it->second.bytes, -3, "fetch: '%s' holds %zu bytes, asked for %ld doubles", name,
+               it->second.bytes, count);
+    c->download(host, it->second.p, (size_t)count * sizeof(double));
+    c->sync();
+    return drain_async(c);                // a numerical failure of a preceding asynchronous predict surfaces here
+    GP_API_END(c)
+}
+
+extern "C" int gpcsd_predict(gpcsd_ctx *c, const gpcsd_hparams *hp, const double *z, int nz, const double *tstar, int ntstar,
+                             int type, double *csd_list, double *csd, double *lfp_list, double *lfp) {
+    GP_API_BEGIN(c)
+    const bool want_lists = (csd_list != nullptr) || (lfp_list != nullptr);
+    int rc = predict_impl(c, hp, z, nz, tstar, ntstar, type, want_lists);
+    if (rc < 0) return rc;
+    const size_t out_elems = (size_t)nz * ntstar * c->ntrials;
+    const int C = hp->n_temporal;
+    if ((type & 1) && csd) c->download(csd, c->bufs["pred_out_csd"].p, out_elems * sizeof(double));
+    if ((type & 1) && csd_list) c->download(csd_list, c->bufs["pred_out_csd_list"].p, out_elems * C * sizeof(double));
+    if ((type & 2) && lfp) c->download(lfp, c->bufs["pred_out_lfp"].p, out_elems * sizeof(double));
+    if ((type & 2) && lfp_list) c->download(lfp_list, c->bufs["pred_out_lfp_list"].p, out_elems * C * sizeof(double));
+    c->sync();
+    return rc;
+    GP_API_END(c)
+}
+
+extern "C" int gpcsd_sample_prior(gpcsd_ctx *c, const gpcsd_hparams *hp, int which, const double *normals, int ntrials,
+                                  double *out) {
+    GP_API_BEGIN(c)
+    const Geo g = resident_geo(c);
+    GP_REQUIRE(normals && out && ntrials > 0, -3, "sample_prior: bad arguments");
+    GP_REQUIRE(which == GPCSD_PRED_CSD || which == GPCSD_PRED_LFP, -3, "sample_prior: which must be CSD(1) or LFP(2)");
+    GP_REQUIRE(c->time_nt > 0, -4, "time grid not set");
+    check_hp(c, hp, g.nx);
+    const int nx = g.nx, nt = c->time_nt, R = ntrials;
+    const long RT = (long)R * nt;
+    hipStream_t s = c->stream;
+    double *Ks = c->buf<double>("Ks", (size_t)nx * nx);
+    double *Kt = c->buf<double>("Kt", (size_t)nt * nt);
+    int *st = c->buf<int>("status", 4);
+    GP_HIP(hipMemsetAsync(st, 0, 4 * sizeof(int), s));
+    const double *t = (const double *)c->bufs["time_t"].p;
+    if (which == GPCSD_PRED_CSD) {
+        build_ks_csd(c, g, hp->ell_s, Ks, s);                                      // gpcsd1d.py:298
+        k_add_diag(c, Ks, nx, hp->jitter, s);
+    } else {
+        build_kphi(c, g, hp->R, hp->eps, hp->ell_s, nullptr, 0, hp->jitter, Ks, s);   // gpcsd2d.py:346-347
+    }
+    if (uses_host_kt(hp)) {
+        GP_REQUIRE(c->host_kt_nt == nt && (int)c->host_kt.size() == nt * nt, -3, "host temporal Gram does not match nt=%d", nt);
+        GP_HIP(hipMemcpyAsync(Kt, c->host_kt.data(), (size_t)nt * nt * sizeof(double), hipMemcpyHostToDevice, s));
+    } else {
+        build_kt(c, hp, t, nt, t, nt, Kt, s);
+    }
+    potrf_device(c, Kt, nt, st, s);                                                 // Lt
+    potrf_device(c, Ks, nx, st, s);                                                 // Ls
+    double *stage = c->upload<double>("sp_stage", normals, (size_t)nx * RT);
+    double *Z = c->buf<double>("sp_Z", (size_t)nx * RT);
+    double *T1 = c->buf<double>("sp_T1", (size_t)nx * RT);
+    k_swap_last2(c, stage, Z, nx, nt, R, s);                                        // (x,t,r) -> (x,r,t)
+    GemmDesc g1;                          // T1[x'][(r,t)] = sum_x Ls[x'][x] Z[x][(r,t)]
+    g1.M = nx; g1.N = (int)RT; g1.K = nx;
+    g1.A = Ks; g1.lda = nx; g1.B = Z; g1.ldb = RT; g1.C = T1; g1.ldc = RT;
+    g1.prof_name = "gemm_sample_spatial";
+    gemm_f64(c, g1, s);
+    GemmDesc g2;                          // out[(x',r)][t'] = sum_t T1[(x',r)][t] Lt[t'][t]
+    g2.M = nx * R; g2.N = nt; g2.K = nt;
+    g2.A = T1; g2.lda = nt; g2.B = Kt; g2.ldb = nt; g2.transB = true; g2.C = Z; g2.ldc = nt;
+    g2.prof_name = "gemm_sample_temporal";
+    gemm_f64(c, g2, s);
+    k_swap_last2(c, Z, stage, nx, R, nt, s);                                        // (x,r,t) -> (x,t,r)
+    c->download(out, stage, (size_t)nx * RT * sizeof(double));
+    return finish_status(c, st);
+    GP_API_END(c)
+}

@@ -26,21 +26,21 @@ except Exception:                             # pragma: no cover - depends on th
 _TASK_START, _TASK_NEW_X, _TASK_FG, _TASK_CONVERGENCE, _TASK_STOP = 0, 1, 3, 4, 5
 
 
+_probed = None                                # available(): None = not probed yet
+
+
 def available():
     """True when SciPy's compiled L-BFGS-B exposes the reverse-communication entry point with the 1.15 `task` arrays."""
-    if _slb is None or not hasattr(_slb, "setulb"):
-        return False
     global _probed
-    try:
-        return _probed
-    except NameError:
-        pass
-    try:                                      # one tiny minimisation through the driver itself
-        out, _ = minimize_many(lambda items: {k: (float(x @ x), 2.0 * x) for k, x in items}, [np.array([1.0, -2.0])],
-                               [(-5.0, 5.0), (None, None)], {"maxiter": 5}, width=1)
-        _probed = out[0] is not None and np.isfinite(out[0][0])
-    except Exception:
+    if _probed is None:
         _probed = False
+        if _slb is not None and hasattr(_slb, "setulb"):
+            try:                              # one tiny minimisation through the driver itself
+                out, _ = minimize_many(lambda items: {k: (float(x @ x), 2.0 * x) for k, x in items}, [np.array([1.0, -2.0])],
+                                       [(-5.0, 5.0), (None, None)], {"maxiter": 5}, width=1)
+                _probed = (not isinstance(out[0], Exception)) and bool(np.isfinite(out[0][0]))
+            except Exception:
+                _probed = False
     return _probed
 
 

@@ -639,25 +639,31 @@ def test_folded_gemm_falls_back_when_symmetry_is_missing():
     assert ctx.fold_gemm() == n2 and np.isfinite(ll)
 
 
-def test_folded_gemm_1d_odd_sizes_vs_oracle():
+@pytest.mark.parametrize("ncomp,R", [(2, 3), (1, 21), (3, 5)])
+def test_folded_gemm_1d_odd_sizes_vs_oracle(ncomp, R):
     """GPCSD1D with an odd number of electrodes and time points (fixed points of both reflections, ns != na), folded path
-    against the oracle: loglik, predictions at the electrodes and at a symmetric subset of sites."""
+    against the oracle: loglik, predictions at the electrodes and at a symmetric subset of sites.  One and two temporal
+    components go through the fused last product (unfold in its epilogue; partial tiles in every dimension: 36 / 35 time
+    orbits, 41 / 40 site orbits, 3 or 21 trials), three through the GEMM + relayout pair with padded column blocks."""
     from gpcsd_amd.gpcsd1d import GPCSD1D
     from gpcsd_amd.covariances import GPCSDTemporalCovSE, GPCSDTemporalCovMatern
     rs = np.random.RandomState(5)
-    nx, nt, R = 81, 71, 3
+    nx, nt = 81, 71
     x = np.linspace(0.0, 2400.0, nx).reshape(-1, 1)
     t = np.linspace(0.0, 70.0, nt).reshape(-1, 1)
     lfp = rs.standard_normal((nx, nt, R))
-    tse, tma = GPCSDTemporalCovSE(t), GPCSDTemporalCovMatern(t)
-    tse.params["ell"]["value"], tse.params["sigma2"]["value"] = 9.0, 0.8
-    tma.params["ell"]["value"], tma.params["sigma2"]["value"] = 4.0, 0.3
-    m = GPCSD1D(lfp, x, t, a=0.0, b=2400.0, ngl=60, temporal_cov_list=[tse, tma])
+    spec = [(C.SE, 9.0, 0.8), (C.MATERN, 4.0, 0.3), (C.SE, 2.5, 0.2)][:ncomp]
+    tcl = []
+    for kind, ell, s2 in spec:
+        tc = GPCSDTemporalCovSE(t) if kind == C.SE else GPCSDTemporalCovMatern(t)
+        tc.params["ell"]["value"], tc.params["sigma2"]["value"] = ell, s2
+        tcl.append(tc)
+    m = GPCSD1D(lfp, x, t, a=0.0, b=2400.0, ngl=60, temporal_cov_list=tcl)
     m.spatial_cov.params["ell"]["value"] = 180.0
     m.R["value"] = 120.0
     m.sig2n["value"] = 0.07
     geom = O.Geometry1D(x, t, a=0.0, b=2400.0, ngl=60)
-    hp = O.make_hparams(120.0, (180.0,), [(C.SE, 9.0, 0.8), (C.MATERN, 4.0, 0.3)], 0.07)
+    hp = O.make_hparams(120.0, (180.0,), spec, 0.07)
     ctx = m._context()
     n0 = ctx.fold_gemm(True)
     ll = float(m.loglik())
