@@ -178,6 +178,19 @@ SIGNATURES = {
     "gpcsd_decomposition_cache": (_I, [_P, _I, ctypes.POINTER(_L)]),
     "gpcsd_shard_block": (_I, [_I, _I, _I, ctypes.POINTER(_I), ctypes.POINTER(_I)]),
     "gpcsd_combine_loglik": (_I, [_I, _D, _D, _DP]),
+    "gpcsd_dist_create": (_I, [_I, ctypes.POINTER(_I), ctypes.POINTER(_P)]),
+    "gpcsd_dist_destroy": (_I, [_P]),
+    "gpcsd_dist_size": (_I, [_P]),
+    "gpcsd_dist_ctx": (_I, [_P, _I, ctypes.POINTER(_P)]),
+    "gpcsd_dist_last_error": (ctypes.c_char_p, [_P]),
+    "gpcsd_dist_set_geometry_1d": (_I, [_P, _DP, _I, _DP, _DP, _I]),
+    "gpcsd_dist_set_geometry_2d": (_I, [_P, _DP, _I, _DP, _DP, _I, _DP, _DP, _I]),
+    "gpcsd_dist_set_time": (_I, [_P, _DP, _I]),
+    "gpcsd_dist_set_lfp": (_I, [_P, _DP, _I, _I, _I, _I]),
+    "gpcsd_dist_loglik": (_I, [_P, ctypes.POINTER(HParams), _DP]),
+    "gpcsd_dist_loglik_grad": (_I, [_P, ctypes.POINTER(HParams), _DP, _DP, _I]),
+    "gpcsd_dist_loglik_grad_batch": (_I, [_P, ctypes.POINTER(HParams), _I, _DP, _DP, _I, ctypes.POINTER(_I)]),
+    "gpcsd_dist_predict": (_I, [_P, ctypes.POINTER(HParams), _DP, _I, _DP, _I, _I, _DP, _DP, _DP, _DP]),
     "gpcsd_prof_enable": (_I, [_P, _I]),
     "gpcsd_prof_tail_clock": (_I, [_P, _I, _DP, ctypes.POINTER(ctypes.c_int), _DP]),
     "gpcsd_prof_reset": (_I, [_P]),
@@ -713,6 +726,96 @@ class Context:
         out = ctypes.c_double()
         self._check(self._lib.gpcsd_hbm_copy_peak(self._h, int(nbytes), ctypes.byref(out)))
         return out.value
+
+
+class Dist:
+    """Several devices driven by ONE process through the C ABI's gpcsd_dist_* entry points (a binder without Python's
+    one-process-per-GPU launcher; the class API shards through gpcsd_amd.dist.TrialSharding instead).  devices: ordinals, which
+    may repeat (two contexts on one GPU)."""
+
+    def __init__(self, devices):
+        self._lib = load_library()
+        devs = (ctypes.c_int * len(devices))(*[int(d) for d in devices])
+        h = ctypes.c_void_p()
+        rc = self._lib.gpcsd_dist_create(len(devices), devs, ctypes.byref(h))
+        if rc != 0:
+            raise HipUnavailable("gpcsd_dist_create failed (%d): %s" % (rc, (self._lib.gpcsd_last_error(None) or b"").decode()))
+        self._h = h
+        self.ndev = len(devices)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.gpcsd_dist_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc == 0:
+            return
+        msg = (self._lib.gpcsd_dist_last_error(self._h) or b"").decode()
+        if rc > 0:
+            raise np.linalg.LinAlgError(msg or "numerical failure (status %d)" % rc)
+        if rc == ERR_CAPACITY:
+            raise GPCSDCapacityError(msg)
+        if rc in (-3, -22):
+            raise ValueError(msg or "bad arguments")
+        raise RuntimeError("libgpcsd_hip error %d: %s" % (rc, msg))
+
+    def set_geometry_1d(self, x, gl_x, gl_w):
+        x, gl_x, gl_w = _arr(x).reshape(-1), _arr(gl_x).reshape(-1), _arr(gl_w).reshape(-1)
+        self._check(self._lib.gpcsd_dist_set_geometry_1d(self._h, _ptr(x), x.size, _ptr(gl_x), _ptr(gl_w), gl_x.size))
+
+    def set_geometry_2d(self, xy, gl_x1, gl_w1, gl_x2, gl_w2):
+        xy, g1, w1, g2, w2 = _arr(xy), _arr(gl_x1).reshape(-1), _arr(gl_w1).reshape(-1), _arr(gl_x2).reshape(-1), _arr(gl_w2).reshape(-1)
+        self._check(self._lib.gpcsd_dist_set_geometry_2d(self._h, _ptr(xy), xy.shape[0], _ptr(g1), _ptr(w1), g1.size, _ptr(g2),
+                                                         _ptr(w2), g2.size))
+
+    def set_time(self, t):
+        t = _arr(t).reshape(-1)
+        self._check(self._lib.gpcsd_dist_set_time(self._h, _ptr(t), t.size))
+
+    def set_lfp(self, lfp, replicate=False):
+        lfp = _arr(lfp)
+        self._check(self._lib.gpcsd_dist_set_lfp(self._h, _ptr(lfp), lfp.shape[0], lfp.shape[1], lfp.shape[2], int(bool(replicate))))
+        self._shape = lfp.shape
+
+    def loglik(self, hp):
+        out = ctypes.c_double()
+        self._check(self._lib.gpcsd_dist_loglik(self._h, ctypes.byref(hp), ctypes.byref(out)))
+        return out.value
+
+    def loglik_grad(self, hp, ngrad):
+        out, g = np.empty(2), np.empty(ngrad)
+        self._check(self._lib.gpcsd_dist_loglik_grad(self._h, ctypes.byref(hp), _ptr(out), _ptr(g), int(ngrad)))
+        return float(out[0]), float(out[1]), g
+
+    def loglik_grad_batch(self, hps, ngrad):
+        B = len(hps)
+        arr = (HParams * B)(*hps)
+        out, g, st = np.empty((B, 2)), np.empty((B, ngrad)), np.zeros(B, dtype=np.int32)
+        self._check(self._lib.gpcsd_dist_loglik_grad_batch(self._h, arr, B, _ptr(out), _ptr(g), int(ngrad),
+                                                           st.ctypes.data_as(ctypes.POINTER(ctypes.c_int))))
+        return out[:, 0].copy(), out[:, 1].copy(), g, st
+
+    def predict(self, hp, z, tstar, type_code, want_lists=True):
+        z, tstar = _arr(z), _arr(tstar).reshape(-1)
+        z = z.reshape(z.shape[0], -1)
+        nz, nts, R, C = z.shape[0], tstar.size, self._shape[2], hp.n_temporal
+        res = {}
+        ptrs = []
+        for name, bit in (("csd", PRED_CSD), ("lfp", PRED_LFP)):
+            if type_code & bit:
+                res[name] = np.empty((nz, nts, R))
+                res[name + "_list"] = np.empty((C, nz, nts, R)) if want_lists else None
+            ptrs += [(_ptr(res[name + "_list"]) if res.get(name + "_list") is not None else None),
+                     (_ptr(res[name]) if name in res else None)]
+        self._check(self._lib.gpcsd_dist_predict(self._h, ctypes.byref(hp), _ptr(z), nz, _ptr(tstar), nts, int(type_code), *ptrs))
+        return {k: v for k, v in res.items() if v is not None}
 
 
 _default_ctx = None

@@ -937,3 +937,4 @@ extern "C" int gpcsd_set_time(gpcsd_ctx *c, const double *t, int nt) {
 #include "capi_fused.inl"
 #include "capi_grad.inl"
 #include "capi_measure.inl"
+#include "capi_dist.inl"

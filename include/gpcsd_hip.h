@@ -273,6 +273,37 @@ int gpcsd_combine_loglik(int ntrials_total, double sumlog, double quad_sum_over_
 int gpcsd_decomposition_cache(gpcsd_ctx *ctx, int on, long *hits);
 int gpcsd_fold_gemm(gpcsd_ctx *ctx, int on, long *calls);
 
+/* ---- several devices from ONE process ------------------------------------------------------- */
+/* SURVEY 8(b)'s gpcsd_dist_*: one context per device, driven by one host process (the Python layer uses one process per GPU
+ * over torch.distributed / RCCL instead: gpcsd_amd/dist.py).  The path has no device-to-device exchange: trials
+ * are independent, every device recomputes the deterministic decompositions, and what is combined is one double per device --
+ * summed on the host in device order.  devices == NULL: ordinals 0..ndev-1 (an ordinal may repeat: two contexts on one GPU). */
+typedef struct gpcsd_dist gpcsd_dist;
+int gpcsd_dist_create(int ndev, const int *devices, gpcsd_dist **out);
+int gpcsd_dist_destroy(gpcsd_dist *dist);
+int gpcsd_dist_size(gpcsd_dist *dist);
+int gpcsd_dist_ctx(gpcsd_dist *dist, int i, gpcsd_ctx **ctx);          /* the i-th context, for the per-context knobs */
+const char *gpcsd_dist_last_error(gpcsd_dist *dist);
+/* the gpcsd_set_* calls on every device */
+int gpcsd_dist_set_geometry_1d(gpcsd_dist *dist, const double *x, int nx, const double *gl_x, const double *gl_w, int ngl);
+int gpcsd_dist_set_geometry_2d(gpcsd_dist *dist, const double *xy, int nx, const double *gl_x1, const double *gl_w1, int ngl1,
+                               const double *gl_x2, const double *gl_w2, int ngl2);
+int gpcsd_dist_set_time(gpcsd_dist *dist, const double *t, int nt);
+/* lfp (nx, nt, ntrials).  replicate = 0: device i gets the block of trials gpcsd_shard_block gives rank i (trial sharding,
+ * BASELINE cfg4); replicate = 1: every device gets all trials (restart sharding, BASELINE cfg5) */
+int gpcsd_dist_set_lfp(gpcsd_dist *dist, const double *lfp, int nx, int nt, int ntrials, int replicate);
+/* loglik() over all trials  gpcsd1d.py:113-128 / gpcsd2d.py:136-151: queued on every device, partial sums added in device order */
+int gpcsd_dist_loglik(gpcsd_dist *dist, const gpcsd_hparams *hp, double *out);
+/* as gpcsd_loglik_grad, summed over the devices' blocks of trials */
+int gpcsd_dist_loglik_grad(gpcsd_dist *dist, const gpcsd_hparams *hp, double *out2, double *grad, int ngrad);
+/* the restarts of fit()  gpcsd1d.py:193-220: set k evaluated on device k mod ndev (needs replicate = 1); arguments as
+ * gpcsd_loglik_grad_batch */
+int gpcsd_dist_loglik_grad_batch(gpcsd_dist *dist, const gpcsd_hparams *hps, int nsets, double *out2, double *grad, int ngrad,
+                                 int *status);
+/* predict() over all trials  gpcsd1d.py:248-293 / gpcsd2d.py:289-334: outputs as gpcsd_predict, assembled from the devices' blocks */
+int gpcsd_dist_predict(gpcsd_dist *dist, const gpcsd_hparams *hp, const double *z, int nz, const double *tstar, int ntstar,
+                       int type, double *csd_list, double *csd, double *lfp_list, double *lfp);
+
 /* ---- measurement --------------------------------------------------------------- */
 /* When enabled, every launch of a named hot kernel (or kernel family) is bracketed by hipEvents on the stream it runs on.
  * on = 0 off; 1 fenced: every fused call synchronises, asynchronous / paired calls are evaluated one by one, chains run

@@ -846,3 +846,58 @@ def test_bench_step_over_rccl_with_one_rank_matches_the_plain_run():
     # measured 1.00-1.11 (two fresh processes on a shared box differ by +-5 % by themselves; the 8-byte all-reduce kernel on its
     # side stream competes with the chains' single-workgroup launches for dispatch): 5 % is the target, 25 % the gate
     assert ratio < 1.25
+
+
+@pytest.mark.parametrize("name,devices", [("2d_npx_96x120x3", [0, 0]), ("cfg2s_1d_24x500x8", [0, 0, 0]), ("1d_odd_17x37x5", [0])])
+def test_c_abi_multi_device_entry_points(name, devices):
+    """gpcsd_dist_* (SURVEY 8(b)): one process driving one context per device -- here several contexts on the one GPU of the
+    test box.  Trial sharding: loglik, gradient and predictions of all trials equal the single-context evaluation (to the
+    rounding of a sum taken in another association); restart sharding: hyper-parameter sets dealt to the devices, each with
+    the bits of a single evaluation."""
+    from gpcsd_amd import _hip
+    import test_hip_parity as T
+    m, c, g, geom, hp, lfp = T._build_model(name)
+    ll_ref = float(m.loglik())
+    f_ref, g_ref = m._loglik_and_grad_natural()
+    m.predict(c["x"], c["t"], type="both")
+    sc = m.spatial_cov
+    d = _hip.Dist(devices)
+    try:
+        if c["dim"] == 1:
+            d.set_geometry_1d(sc.x, sc.gl_x, sc.gl_w)
+        else:
+            d.set_geometry_2d(sc.x, sc.gl_x1, sc.gl_w1, sc.gl_x2, sc.gl_w2)
+        d.set_time(c["t"])
+        d.set_lfp(lfp)
+        hp1, keep1 = m._hparams(m.JITTER)
+        hp0, keep0 = m._hparams(0.0)
+        ll = d.loglik(hp1)
+        assert abs(ll - ll_ref) <= 1e-12 * abs(ll_ref)
+        ng = g_ref.size
+        sumlog, quad, grad = d.loglik_grad(hp1, ng)
+        assert abs((-0.5 * lfp.shape[2] * sumlog - 0.5 * quad) - f_ref) <= 1e-12 * abs(f_ref)
+        assert np.max(np.abs(grad - g_ref)) <= 1e-10 * np.max(np.abs(g_ref))
+        res = d.predict(hp0, c["x"], c["t"], _hip.PRED_BOTH)
+        assert relerr(res["csd"], m.csd_pred) < 1e-10 and relerr(res["lfp"], m.lfp_pred) < 1e-10
+        for k in range(len(m.csd_pred_list)):
+            assert relerr(res["csd_list"][k], m.csd_pred_list[k]) < 1e-10
+        assert relerr(res["csd"], g["csd_pred"]) < GATE
+        # restart sharding: every device holds all trials, sets are dealt out
+        d.set_lfp(lfp, replicate=True)
+        hps, keep = [], []
+        for k in range(5):
+            m.temporal_cov_list[0].params["ell"]["value"] *= 1.03
+            h, kk = m._hparams(m.JITTER)
+            hps.append(h)
+            keep.append(kk)
+        sl, qd, gb, st = d.loglik_grad_batch(hps, ng)
+        assert np.all(st == 0)
+        ctx = m._sync_device()
+        for k in range(5):
+            s1, q1, g1 = ctx.loglik_grad(hps[k], ng)
+            assert s1 == sl[k] and q1 == qd[k] and np.array_equal(g1, gb[k])
+        with pytest.raises(ValueError):
+            d.set_lfp(lfp)                                   # back to blocks of trials ...
+            d.loglik_grad_batch(hps, ng)                     # ... which the batch entry refuses
+    finally:
+        d.close()
