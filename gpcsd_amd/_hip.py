@@ -175,6 +175,7 @@ SIGNATURES = {
     "gpcsd_sample_prior": (_I, [_P, ctypes.POINTER(HParams), _I, _DP, _I, _DP]),
     "gpcsd_set_gram_precision": (_I, [_P, _I]),
     "gpcsd_fold_gemm": (_I, [_P, _I, ctypes.POINTER(_L)]),
+    "gpcsd_ll_tridiag": (_I, [_P, _I, ctypes.POINTER(_L)]),
     "gpcsd_decomposition_cache": (_I, [_P, _I, ctypes.POINTER(_L)]),
     "gpcsd_shard_block": (_I, [_I, _I, _I, ctypes.POINTER(_I), ctypes.POINTER(_I)]),
     "gpcsd_combine_loglik": (_I, [_I, _D, _D, _DP]),
@@ -668,6 +669,13 @@ class Context:
         """Switch (True/False) or query (None) the folded-basis GEMM path; returns the number of folded calls so far."""
         n = _L(0)
         self._check(self._lib.gpcsd_fold_gemm(self._h, -1 if on is None else int(bool(on)), ctypes.byref(n)))
+        return int(n.value)
+
+    def ll_tridiag(self, on=None):
+        """Switch (True/False) or query (None) the experimental shifted-tridiagonal form of the folded log-likelihood (no temporal
+        eigenvectors on its path); returns the number of log-likelihoods evaluated that way so far."""
+        n = _L(0)
+        self._check(self._lib.gpcsd_ll_tridiag(self._h, -1 if on is None else int(bool(on)), ctypes.byref(n)))
         return int(n.value)
 
     def decomposition_cache(self, on=None):

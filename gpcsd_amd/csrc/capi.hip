@@ -378,7 +378,18 @@ struct EigState {
     bool wait_spatial = false;     // the spatial chain was queued on stream3 in this call: join_spatial() before using Qs / es
     const double *d_sig = nullptr;
     int nsig = 0;
+    // the log-likelihood may take the shifted-tridiagonal tail (loglik_tri_*): the temporal chain ran in two stages (or its
+    // stage-1 outputs are still those of this temporal problem), replica `tri_rep` of the temporal classes is this call's
+    bool tri = false, wait_q = false;
+    int tri_rep = 0, tri_count = 1;
 };
+
+// The log-likelihood in the basis U (x) Q (k_ll_tridiag) instead of U (x) V: it needs the temporal chain only up to the
+// tridiagonalisation + Q, not the divide & conquer, which only a prediction's tail waits for.  EXPERIMENTAL, off by default
+// (gpcsd_ll_tridiag(ctx, 1, ..) or GPCSD_LL_TRIDIAG=1 switch it on): the log-likelihood comes back ~0.1 ms earlier at cfg3, but
+// the staged temporal chain is ~0.1 ms longer (T factors and Q in front of the divide & conquer) and bounds the pipelined step
+// as before -- no gain on bench.py's step until stage 2 runs beside the next chain's stage 1.
+static bool ll_tridiag_enabled(const gpcsd_ctx *c) { return c->ll_tridiag_on; }
 
 // Main stream waits for the spatial chain of this call (no-op when it was reused from the cache or already joined).
 static void join_spatial(gpcsd_ctx *c, EigState &e) {
@@ -421,7 +432,8 @@ static bool two_stream_front() {            // GPCSD_TWO_STREAM=0: single batche
 // (one small launch less at the end of each chain).  NOTE: D from the single-stream front half is then in merged order of
 // stale spectra -- such callers rebuild it in fold order (join_temporal with a FoldMode).
 // join_s = false: the caller calls join_spatial() itself.  Fold views (fold_mode) must be taken AFTER this returns.
-EigState front_half(gpcsd_ctx *c, const gpcsd_hparams *hp, double jitter, bool need_merged = true, bool join_s = true) {
+EigState front_half(gpcsd_ctx *c, const gpcsd_hparams *hp, double jitter, bool need_merged = true, bool join_s = true,
+                    bool want_tri = false) {
     const Geo g = resident_geo(c);
     GP_REQUIRE(c->d_lfp != nullptr, -4, "lfp not set (call gpcsd_set_lfp)");
     GP_REQUIRE(c->time_nt == c->nt, -4, "time grid has %d points but lfp has nt=%d", c->time_nt, c->nt);
@@ -508,12 +520,29 @@ EigState front_half(gpcsd_ctx *c, const gpcsd_hparams *hp, double jitter, bool n
     if (run_t) {
         c->tl("T chain start (s2)", s2);
         const bool tfill = temporal_fill_applies(c, sym_t, nt, host_kt);
+        if (c->tri_reader_queued) {       // a queued log-likelihood tail still reads the previous chain's Q / tridiagonal
+            GP_HIP(hipStreamWaitEvent(s2, c->ev_tri_done, 0));
+            c->tri_reader_queued = false;
+        }
         if (tfill) temporal_fill(c, &hp, 1, t, nt, *sym_t, e.status + 1, 0, s2);
         else make_kt(s2);
+        // staged whenever it applies (not only for a log-likelihood): stage 2 forms the eigenvectors as Q Z, and every call
+        // form must get the same bits
+        const bool staged = tfill && ll_tridiag_enabled(c) && eigh_stageable(sym_t, nt);
         {
             ProfScope ps(c, "eigh_temporal", 9.0 * (double)nt * nt * nt, s2);
-            eigh_pair_device(c, nullptr, 0, nullptr, nullptr, nullptr, Kt, nt, e.et, e.Qt, sym_t, e.status + 1, s2, need_merged, 1, 0,
-                             -1, tfill ? 2 : 0);
+            if (staged) {            // the log-likelihood's tail starts behind stage 1; stage 2 completes the decomposition
+                eigh_pair_device(c, nullptr, 0, nullptr, nullptr, nullptr, Kt, nt, e.et, e.Qt, sym_t, e.status + 1, s2, need_merged, 1, 0,
+                                 -1, 2, /*stage=*/1);
+                GP_HIP(hipEventRecord(c->ev_q, s2));
+                eigh_pair_device(c, nullptr, 0, nullptr, nullptr, nullptr, Kt, nt, e.et, e.Qt, sym_t, e.status + 1, s2, need_merged, 1, 0,
+                                 -1, 2, /*stage=*/2);
+                c->q_gen = c->eig_gen[1];
+                e.tri = e.wait_q = want_tri && !need_merged && hp->n_sig2n == 1;
+            } else {
+                eigh_pair_device(c, nullptr, 0, nullptr, nullptr, nullptr, Kt, nt, e.et, e.Qt, sym_t, e.status + 1, s2, need_merged, 1, 0,
+                                 -1, tfill ? 2 : 0);
+            }
         }
         GP_HIP(hipEventRecord(c->ev_join, s2));
         c->tl("T chain end (s2)", s2);
@@ -535,6 +564,12 @@ EigState front_half(gpcsd_ctx *c, const gpcsd_hparams *hp, double jitter, bool n
         c->decomp_gen[0] = c->eig_gen[0];
         e.wait_spatial = true;
     }
+    // a temporal side served from the cache: the chain that produced it may still be running its second stage (a log-likelihood
+    // in the tridiagonal form returns without waiting for it) -- readers of its eigenvectors wait for that chain's end as usual
+    if (!run_t) e.wait_temporal = true;
+    if (!run_t && want_tri && !need_merged && hp->n_sig2n == 1 && ll_tridiag_enabled(c) && c->q_gen == c->eig_gen[1] && sym_t &&
+        eigh_stageable(sym_t, nt))
+        e.tri = true;                // the temporal side is reused from the cache and its stage-1 outputs are those of this problem
     e.d_sig = c->upload_cached<double>("sig2n", hp->sig2n, hp->n_sig2n);
     e.nsig = hp->n_sig2n;
     e.pending = true;
@@ -741,6 +776,7 @@ extern "C" int gpcsd_ctx_create(int device, gpcsd_ctx **out) {
         c = new gpcsd_ctx();
         c->device = device;
         c->timeline_on = getenv("GPCSD_TIMELINE") && getenv("GPCSD_TIMELINE")[0] == '1';
+        c->ll_tridiag_on = getenv("GPCSD_LL_TRIDIAG") && getenv("GPCSD_LL_TRIDIAG")[0] == '1';
         GP_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
         // The two chains are the critical path and made of small launches; when they run beside another call's GEMM tail
         // (thousands of workgroups) each of those launches would otherwise queue behind the tiles: high priority.
@@ -754,6 +790,8 @@ extern "C" int gpcsd_ctx_create(int device, gpcsd_ctx **out) {
         GP_HIP(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
         GP_HIP(hipEventCreateWithFlags(&c->ev_aux, hipEventDisableTiming));
         GP_HIP(hipEventCreateWithFlags(&c->ev_pc, hipEventDisableTiming));
+        GP_HIP(hipEventCreateWithFlags(&c->ev_q, hipEventDisableTiming));
+        GP_HIP(hipEventCreateWithFlags(&c->ev_tri_done, hipEventDisableTiming));
         GP_HIP(hipHostMalloc(reinterpret_cast<void **>(&c->h_result), 66 * sizeof(double), hipHostMallocDefault));
         GP_HIP(hipHostMalloc(reinterpret_cast<void **>(&c->h_ll), gpcsd_ctx::LL_SLOTS * 66 * sizeof(double), hipHostMallocDefault));
         for (auto &sl : c->ll_slot) GP_HIP(hipEventCreateWithFlags(&sl.ev, hipEventDisableTiming));
@@ -788,6 +826,8 @@ extern "C" int gpcsd_ctx_destroy(gpcsd_ctx *c) {
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     if (c->ev_aux) (void)hipEventDestroy(c->ev_aux);
     if (c->ev_pc) (void)hipEventDestroy(c->ev_pc);
+    if (c->ev_q) (void)hipEventDestroy(c->ev_q);
+    if (c->ev_tri_done) (void)hipEventDestroy(c->ev_tri_done);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     if (c->stream2) (void)hipStreamDestroy(c->stream2);
     if (c->h_result) (void)hipHostFree(c->h_result);

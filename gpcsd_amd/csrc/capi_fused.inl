@@ -21,10 +21,61 @@ static int finish_loglik_async(gpcsd_ctx *c, const EigState &e, bool two) {
 
 // Folded-basis tail of the log-likelihood: the two projections as 2 + 2 half-size GEMMs, the quadratic form as two partial
 // sums (one when the parity blocks went out as one batched launch: returns true), sum(log D) folded into the reduce launch.
-static bool loglik_fold_tail(gpcsd_ctx *c, EigState &e, const FoldMode &fm, const double *Yf, double *W) {
+// Shifted-tridiagonal form (EigState::tri): X = Y~ Q needs stage 1 of the temporal chain only and is queued BEFORE the main
+// stream waits for the spatial chain; after that wait W = diag(U)^T X, and one forward recurrence per row gives the quadratic
+// form, the pivots the log-determinant (k_ll_tridiag).  The temporal eigenvectors are never read.
+static void loglik_tri_pre(gpcsd_ctx *c, EigState &e, const FoldMode &fm, const double *Yf) {
+    const int nx = c->nx, nt = c->nt, R = c->ntrials;
+    hipStream_t s = c->stream;
+    if (e.wait_q) GP_HIP(hipStreamWaitEvent(s, c->ev_q, 0));
+    e.wait_q = false;
+    double *X = c->buf<double>("ll_X", (size_t)nx * R * nt);
+    const char *const *tg = eigh_fold_tags(1);
+    GemmDesc g[2];
+    for (int p = 0; p < 2; ++p) {
+        const int np = p ? fm.ft.na : fm.ft.ns, c0 = p ? fm.ft.ns : 0;
+        g[p].M = nx * R; g[p].N = np; g[p].K = np;
+        g[p].A = Yf + c0; g[p].lda = nt;
+        g[p].B = eigh_Q_view(c, tg[p], np, e.tri_count) + (size_t)e.tri_rep * np * np; g[p].ldb = np;
+        g[p].C = X + c0; g[p].ldc = nt;
+        g[p].prof_name = "gemm_ll_YQ";
+    }
+    gemm_pair(c, g[0], g[1], s);
+}
+
+static void loglik_tri_tail(gpcsd_ctx *c, EigState &e, const FoldMode &fm, double *W) {
     const int nx = c->nx, nt = c->nt, R = c->ntrials;
     hipStream_t s = c->stream;
     ++c->fold_gemm_calls;
+    ++c->ll_tridiag_calls;
+    join_spatial(c, e);
+    const double *X = c->buf<double>("ll_X", (size_t)nx * R * nt);
+    fold_proj_spatial(c, fm.fs, X, W, (long)R * nt, s);
+    const char *const *tg = eigh_fold_tags(1);
+    const double *d[2], *ee[2], *am[2];
+    int np[2], c0[2];
+    for (int p = 0; p < 2; ++p) {
+        np[p] = p ? fm.ft.na : fm.ft.ns;
+        c0[p] = p ? fm.ft.ns : 0;
+        const EigArenaView av = eigh_arena_view(c, tg[p], np[p], e.tri_count);
+        const long o = (long)e.tri_rep * av.blk;
+        d[p] = av.d + o; ee[p] = av.e + o; am[p] = av.amax + o;
+    }
+    k_ll_tridiag(c, W, fm.fs.w, d, ee, am, e.d_sig, nx, R, nt, np, c0, e.scal, e.scal + 1, s);
+    GP_HIP(hipEventRecord(c->ev_tri_done, s));
+    c->tri_reader_queued = true;
+}
+
+static bool loglik_fold_tail(gpcsd_ctx *c, EigState &e, const FoldMode &fm, const double *Yf, double *W) {
+    const int nx = c->nx, nt = c->nt, R = c->ntrials;
+    hipStream_t s = c->stream;
+    if (e.tri) {
+        loglik_tri_pre(c, e, fm, Yf);
+        loglik_tri_tail(c, e, fm, W);
+        return true;
+    }
+    ++c->fold_gemm_calls;
+    join_spatial(c, e);
     fold_proj_spatial(c, fm.fs, Yf, W, (long)R * nt, s);
     const int nparts = join_temporal(c, e, &fm, false);         // sum(log D): summed by the reduce launch of the GEMM below
     GemmDesc g2[2];
@@ -53,7 +104,8 @@ static int loglik_parts_impl(gpcsd_ctx *c, const gpcsd_hparams *hp, double *out2
     }
     const FoldMode fm0 = fold_mode(c, hp);                          // the decision; its views are of the previous generation
     const double *Yf = fm0.on ? folded_lfp(c, fm0) : nullptr;
-    EigState e = front_half(c, hp, hp->jitter, !fm0.on);
+    // (the spatial chain is joined by the tail: the tridiagonal form queues its first product in front of that wait)
+    EigState e = front_half(c, hp, hp->jitter, !fm0.on, /*join_s=*/!fm0.on, /*want_tri=*/fm0.on);
     const FoldMode fm = fold_mode(c, hp);                           // views of the generation the front half just launched
     const int nx = c->nx, nt = c->nt, R = c->ntrials;
     hipStream_t s = c->stream;
@@ -167,7 +219,8 @@ static const SymDev &site_symmetry(gpcsd_ctx *c, const double *z, int nz, int di
 // every flat GEMM split in its two parity blocks; the last pass unfolds sites and times while it transposes.
 static int predict_fold(gpcsd_ctx *c, const gpcsd_hparams *hp, EigState &e, const FoldMode &fm, const double *Yf, const SymDev &sz,
                         const double *dz, int nz, const double *dts, int type, bool want_lists, bool async,
-                        const std::function<void()> *after_spatial_join = nullptr) {
+                        const std::function<void()> *after_spatial_join = nullptr,
+                        const std::function<void()> *before_spatial_join = nullptr) {
     const Geo g = resident_geo(c);
     const int nx = c->nx, nt = c->nt, R = c->ntrials, C = hp->n_temporal;
     const long RT = (long)R * nt;
@@ -211,6 +264,7 @@ static int predict_fold(gpcsd_ctx *c, const gpcsd_hparams *hp, EigState &e, cons
                         Ktf + cc * ktf_sz + (size_t)nts * nts, s);
     }
     // then everything that needs only the spatial eigenvectors, beside the temporal eigensolver
+    if (before_spatial_join) (*before_spatial_join)();
     join_spatial(c, e);
     // gpcsd_loglik_predict_async: the log-likelihood's whole tail goes here, in front of everything of predict that needs a
     // decomposition -- it is what the caller waits for
@@ -480,16 +534,28 @@ static void front_half_pair(gpcsd_ctx *c, const gpcsd_hparams *const hp[2], cons
     // assembled once and copied (the same GEMM output plus the same diagonal add: the same bits).
     c->tl("T chain start (s2)", s2);
     const bool tfill = temporal_fill_applies(c, sym_t, nt, false);       // (the paired call is refused for host temporal Grams)
+    if (c->tri_reader_queued) {           // a queued log-likelihood tail still reads the previous chain's Q / tridiagonal
+        GP_HIP(hipStreamWaitEvent(s2, c->ev_tri_done, 0));
+        c->tri_reader_queued = false;
+    }
     if (tfill) temporal_fill(c, hp, nT, t, nt, *sym_t, status + 1, 2, s2);
     else for (int b = 0; b < nT; ++b) build_kt(c, hp[b], t, nt, t, nt, Kt + b * ntt, s2);
     // the temporal chain is the critical path of the call: it is queued before the host spends its time on the launches of the
     // spatial Gram assembly (status words [1], [3]; one replica when the problem is shared -- decomposition cache on, equal
     // temporal hyper-parameters).  (All four problems in ONE chain was measured slower, 1.38 against 1.18 ms per cfg3 step: with
     // two chains the log-likelihood's spatial projection runs under the end of the temporal one.)
+    const bool staged = tfill && ll_tridiag_enabled(c) && eigh_stageable(sym_t, nt);
     {
         ProfScope ps(c, "eigh_temporal", 9.0 * (double)nt * nt * nt * nT, s2);
-        eigh_pair_device(c, nullptr, 0, nullptr, nullptr, nullptr, Kt, nt, et, Qt, sym_t, status + 1, s2, false, nT, 2, -1,
-                         tfill ? 2 : 0);
+        if (staged) {                // the log-likelihood's tail starts behind stage 1 (see EigState::tri)
+            eigh_pair_device(c, nullptr, 0, nullptr, nullptr, nullptr, Kt, nt, et, Qt, sym_t, status + 1, s2, false, nT, 2, -1, 2, 1);
+            GP_HIP(hipEventRecord(c->ev_q, s2));
+            eigh_pair_device(c, nullptr, 0, nullptr, nullptr, nullptr, Kt, nt, et, Qt, sym_t, status + 1, s2, false, nT, 2, -1, 2, 2);
+            c->q_gen = -1;           // (replicas: not what a separate call's cache looks for)
+        } else {
+            eigh_pair_device(c, nullptr, 0, nullptr, nullptr, nullptr, Kt, nt, et, Qt, sym_t, status + 1, s2, false, nT, 2, -1,
+                             tfill ? 2 : 0);
+        }
     }
     GP_HIP(hipEventRecord(c->ev_join, s2));
     c->tl("T chain end (s2)", s2);
@@ -533,6 +599,11 @@ static void front_half_pair(gpcsd_ctx *c, const gpcsd_hparams *const hp[2], cons
         e.wait_temporal = e.wait_spatial = true;
         e.d_sig = d_sig[b];
         e.nsig = 1;
+        if (b == 0 && staged) {      // set 0 is the log-likelihood's: replica 0 of the temporal classes
+            e.tri = e.wait_q = true;
+            e.tri_rep = 0;
+            e.tri_count = nT;
+        }
         FoldMode &fm = out.fm[b];
         fm = fold_mode(c, hp[b]);                       // replica 0 of the generations just started ...
         if (fm.fs.on) { fm.fs.w += (long)b * vs.sw; fm.fs.U += (long)b * vs.sU; }       // ... moved to replica b
@@ -603,12 +674,17 @@ extern "C" int gpcsd_loglik_predict_async(gpcsd_ctx *c, const gpcsd_hparams *hp_
     const double *Yf = folded_lfp(c, pf.fm[1]);
     double *dzf = c->upload_cached<double>("pred_z", z, (size_t)nz * c->dim);
     double *dtf = c->upload_cached<double>("pred_tstar", tstar, ntstar);
+    const std::function<void()> ll_pre = [&]() {
+        if (pf.e[0].tri) loglik_tri_pre(c, pf.e[0], pf.fm[0], Yf);
+    };
     const std::function<void()> ll_tail = [&]() {
         double *Wll = c->buf<double>("proj_W_ll", (size_t)c->nx * c->ntrials * c->nt);
-        const bool batched = loglik_fold_tail(c, pf.e[0], pf.fm[0], Yf, Wll);
+        bool batched = true;
+        if (pf.e[0].tri) loglik_tri_tail(c, pf.e[0], pf.fm[0], Wll);
+        else batched = loglik_fold_tail(c, pf.e[0], pf.fm[0], Yf, Wll);
         (void)finish_loglik_async(c, pf.e[0], !batched);
     };
-    return predict_fold(c, hp_pr, pf.e[1], pf.fm[1], Yf, sz, dzf, nz, dtf, type, want_lists != 0, true, &ll_tail);
+    return predict_fold(c, hp_pr, pf.e[1], pf.fm[1], Yf, sz, dzf, nz, dtf, type, want_lists != 0, true, &ll_tail, &ll_pre);
     GP_API_END(c)
 }
 

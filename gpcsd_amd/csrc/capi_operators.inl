@@ -532,6 +532,21 @@ extern "C" int gpcsd_decomposition_cache(gpcsd_ctx *c, int on, long *hits) {
     GP_API_END(c)
 }
 
+extern "C" int gpcsd_ll_tridiag(gpcsd_ctx *c, int on, long *calls) {
+    GP_API_BEGIN(c)
+    if (on >= 0 && c->ll_tridiag_on != (on != 0)) {
+        if (int rc = drain_async(c)) return rc;            // the two forms order their streams differently: start from an idle context
+        GP_HIP(hipStreamSynchronize(c->stream2));
+        GP_HIP(hipStreamSynchronize(c->stream3));
+        c->ll_tridiag_on = on != 0;
+        c->decomp_gen[0] = c->decomp_gen[1] = -1;          // (the forms compute the temporal eigenvectors differently: no reuse across)
+        c->q_gen = -1;
+    }
+    if (calls) *calls = c->ll_tridiag_calls;
+    return 0;
+    GP_API_END(c)
+}
+
 extern "C" int gpcsd_fold_gemm(gpcsd_ctx *c, int on, long *calls) {
     GP_API_BEGIN(c)
     if (on >= 0) c->fold_gemm_on = on != 0;

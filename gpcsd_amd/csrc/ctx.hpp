@@ -97,6 +97,15 @@ struct gpcsd_ctx {
     LlSlot ll_slot[LL_SLOTS];
     int ll_head = 0, ll_count = 0;          // oldest outstanding slot, number outstanding
     hipEvent_t ev_aux = nullptr, ev_pc = nullptr;   // predict: small products of the tail on stream2 beside the large ones
+    // stage 1 of the temporal chain (tridiagonalisation, T factors, the orthogonal factor Q) has finished: recorded on stream2
+    // between the chain's two stages; the log-likelihood's tail needs nothing more of that chain (capi_fused.inl).  q_gen: the
+    // generation of the temporal solver slot whose Q / tridiagonal are in the buffers (decomposition cache hits reuse them).
+    hipEvent_t ev_q = nullptr;
+    long q_gen = -1;
+    // ... and the last reader of those single-buffered stage-1 outputs (Q, the tridiagonal, its scale) on the main stream: the next
+    // temporal chain must not overwrite them before it (a caller may queue several steps deep)
+    hipEvent_t ev_tri_done = nullptr;
+    bool tri_reader_queued = false;
     std::string last_error;
     std::map<std::string, gpcsd::DevBuf> bufs;
     bool prof_on = false;
@@ -136,6 +145,8 @@ struct gpcsd_ctx {
     bool status_zeroed = false;             // the fused calls' status words were cleared at the end of the previous call
     bool gram_fp32 = false;                 // gpcsd_set_gram_precision(): Gram builders evaluate in float (cfg5 variant)
     bool fold_gemm_on = true;               // gpcsd_fold_gemm()
+    bool ll_tridiag_on = false;             // gpcsd_ll_tridiag(): log-likelihood in the basis U (x) Q (experimental, see capi.hip)
+    long ll_tridiag_calls = 0;
     long fold_gemm_calls = 0;
     // Decomposition cache (capi.hip::front_half): predict() right after loglik() / fit() with the same hyper-parameters
     // (neuropixels/fit_gpcsd2d.py:101-107) decomposes the very same Kt again, repeated predict() calls the same Ks as well.

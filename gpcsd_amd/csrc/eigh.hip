@@ -20,7 +20,8 @@
 
 namespace gpcsd {
 
-void eigh_large_multi(gpcsd_ctx *c, const EigReq *reqs, int nclass, int *d_status, int status_stride, hipStream_t s);   // eigh_dc.hip
+void eigh_large_multi(gpcsd_ctx *c, const EigReq *reqs, int nclass, int *d_status, int status_stride, hipStream_t s,
+                      int stage = 0);   // eigh_dc.hip
 
 // blockIdx.x = replica: inputs sA apart, eigenvalues sw apart, eigenvectors sZ apart, status words status_stride apart
 template <int NT>
@@ -291,6 +292,14 @@ static bool fold_applies(const SymDev *sy, int n) {
     return sy && sy->ns > 0 && sy->ns + sy->na == n && n > JACOBI_LDS_MAX && symfold_enabled() && !force_jacobi();
 }
 
+// a problem that can be solved in two stages (see eigh_pair_device): folded, both halves on the tridiagonalisation path and
+// within the fused back-transformation's capacity
+bool eigh_stageable(const SymDev *sy, int n) {
+    if (!fold_applies(sy, n)) return false;
+    const int lo = std::min(sy->ns, sy->na), hi = std::max(sy->ns, sy->na);
+    return lo > JACOBI_LDS_MAX && wy_fused_supported(hi);
+}
+
 // The half-size spectra and eigenvectors of problem `slot` (0: first / spatial, 1: second / temporal) of eigh_pair_device,
 // in FOLD order: w = (ws | wa), U = (Us (ns x ns) | Ua (na x na)), eigenvectors in columns.  The same predicate and buffers
 // as the solver itself uses, so callers that stay in the folded basis (capi.hip) read what the last solve left there.
@@ -316,7 +325,7 @@ const char *const *eigh_fold_tags(int slot) { return &FOLD_TAGS[slot ? 1 : 0][1]
 
 static void eigh_pair_enqueue(gpcsd_ctx *c, double *A0, int n0, double *w0, double *Z0, const SymDev *sym0, double *A1, int n1,
                               double *w1, double *Z1, const SymDev *sym1, int *d_status, hipStream_t s, bool need_merged,
-                              int count, int status_stride, int count1, int prefolded_mask) {
+                              int count, int status_stride, int count1, int prefolded_mask, int stage) {
     const int cnt[2] = {count, count1 > 0 ? count1 : count};      // replicas of problem 0 / problem 1
     double *A[2] = {A0, A1}, *w[2] = {w0, w1}, *Z[2] = {Z0, Z1};
     const int n[2] = {n0, n1};
@@ -358,21 +367,22 @@ static void eigh_pair_enqueue(gpcsd_ctx *c, double *A0, int n0, double *w0, doub
             fold[p].Us = fv.U;
             fold[p].wa = fv.w + ns;
             fold[p].Ua = fv.U + (size_t)ns * ns;
-            const bool pre = (prefolded_mask >> p) & 1;     // the caller wrote the scaled halves into the class arenas itself
+            const bool pre = ((prefolded_mask >> p) & 1) || stage == 2;     // the scaled halves are in the class arenas already
             if (!pre)
                 hipLaunchKernelGGL(sym_fold_kernel, dim3(ceil_div((long)ns * ns, 256), cnt[p]), dim3(256), 0, s, (const double *)A[p],
                                    n[p], *sy, Ks, Ka);
             submit(Ks, ns, fold[p].ws, fold[p].Us, tags[p][1], (long)ns * ns, fv.sw, fv.sU, cnt[p], pre);
             submit(Ka, na, fold[p].wa, fold[p].Ua, tags[p][2], (long)na * na, fv.sw, fv.sU, cnt[p], pre);
         } else {
+            GP_REQUIRE(stage == 0, -3, "eigh: staged solves need symmetry-folded problems (problem %d)", p);
             GP_REQUIRE(!((prefolded_mask >> p) & 1), -3, "eigh: problem %d was announced as prefolded but symmetry folding does not apply", p);
             submit(A[p], n[p], w[p], Z[p], tags[p][0], nn, n[p], nn, cnt[p]);
         }
     }
-    if (nlarge) eigh_large_multi(c, large, nlarge, d_status, status_stride, s);
+    if (nlarge) eigh_large_multi(c, large, nlarge, d_status, status_stride, s, stage);
     // need_merged == false: the caller stays in the folded basis (eigh_fold_view) and never reads w / Z of a folded problem
     for (int p = 0; p < 2; ++p)
-        if (fold[p].on && need_merged)
+        if (fold[p].on && need_merged && stage != 1)
             hipLaunchKernelGGL(sym_unfold_kernel, dim3(n[p], cnt[p]), dim3(256), 0, s, n[p], *sym[p], (const double *)fold[p].ws,
                                (const double *)fold[p].Us, (const double *)fold[p].wa, (const double *)fold[p].Ua, w[p], Z[p]);
     GP_HIP(hipGetLastError());
@@ -383,11 +393,13 @@ static void eigh_pair_enqueue(gpcsd_ctx *c, double *A0, int n0, double *w0, doub
 // replayed.  A graph is retired whenever any context buffer is (re)allocated, since it holds raw device pointers.
 void eigh_pair_device(gpcsd_ctx *c, double *A0, int n0, double *w0, double *Z0, const SymDev *sym0, double *A1, int n1,
                       double *w1, double *Z1, const SymDev *sym1, int *d_status, hipStream_t s, bool need_merged, int count,
-                      int status_stride, int count1, int prefolded_mask) {
+                      int status_stride, int count1, int prefolded_mask, int stage) {
     if (count < 1) count = 1;
     if (count1 < 1) count1 = count;
-    if (n0 > 0) ++c->eig_gen[0];               // whatever a previous call left in this slot's outputs is about to be replaced
-    if (n1 > 0) ++c->eig_gen[1];
+    if (stage != 2) {                          // (stage 2 continues the solve stage 1 started)
+        if (n0 > 0) ++c->eig_gen[0];           // whatever a previous call left in this slot's outputs is about to be replaced
+        if (n1 > 0) ++c->eig_gen[1];
+    }
     // the limit applies to what the solver actually factorises: a symmetry-folded problem is two half-size ones
     const int m0 = fold_applies(sym0, n0) ? std::max(sym0->ns, sym0->na) : n0;
     const int m1 = fold_applies(sym1, n1) ? std::max(sym1->ns, sym1->na) : n1;
@@ -400,15 +412,16 @@ void eigh_pair_device(gpcsd_ctx *c, double *A0, int n0, double *w0, double *Z0, 
     // profiling mode 3 keeps replaying graphs, so the outer scopes time the chains as they run in production
     const bool prof_graph = c->prof_mode == 3;
     if (!any_large || (c->prof_on && !prof_graph) || !graphs_enabled()) {
-        eigh_pair_enqueue(c, A0, n0, w0, Z0, sym0, A1, n1, w1, Z1, sym1, d_status, s, need_merged, count, status_stride, count1, prefolded_mask);
+        eigh_pair_enqueue(c, A0, n0, w0, Z0, sym0, A1, n1, w1, Z1, sym1, d_status, s, need_merged, count, status_stride, count1, prefolded_mask, stage);
         return;
     }
     // (the generation of each slot picks the fold-order output buffers, which are not among the arguments)
     char key[352];
-    snprintf(key, sizeof(key), "eigh|%p|%d|%p|%p|%p|%d|%p|%d|%p|%p|%p|%d|%p|%p|%d|%d|%d|%d%d|%d|%d|%d", (void *)A0, n0, (void *)w0, (void *)Z0,
+    snprintf(key, sizeof(key), "eigh|%p|%d|%p|%p|%p|%d|%p|%d|%p|%p|%p|%d|%p|%p|%d|%d|%d|%d%d|%d|%d|%d|%d", (void *)A0, n0, (void *)w0, (void *)Z0,
              (void *)(sym0 ? sym0->rep_i : nullptr), sym0 ? sym0->ns : 0, (void *)A1, n1, (void *)w1, (void *)Z1,
              (void *)(sym1 ? sym1->rep_i : nullptr), sym1 ? sym1->ns : 0, (void *)d_status, (void *)s, (int)need_merged, count,
-             status_stride, c->par[0], c->par[1], count1, prefolded_mask, (int)(c->prof_mode == 3));   // (mode 3 graphs carry clock stamps)
+             status_stride, c->par[0], c->par[1], count1, prefolded_mask, (int)(c->prof_mode == 3),   // (mode 3 graphs carry clock stamps)
+             stage);
     gpcsd_ctx::GraphSlot &g = c->graphs[key];
     if (g.exec && g.epoch == c->alloc_epoch) {
         GP_HIP(hipGraphLaunch(g.exec, s));
@@ -423,7 +436,7 @@ void eigh_pair_device(gpcsd_ctx *c, double *A0, int n0, double *w0, double *Z0, 
         GP_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
         c->capturing = true;
         try {
-            eigh_pair_enqueue(c, A0, n0, w0, Z0, sym0, A1, n1, w1, Z1, sym1, d_status, s, need_merged, count, status_stride, count1, prefolded_mask);
+            eigh_pair_enqueue(c, A0, n0, w0, Z0, sym0, A1, n1, w1, Z1, sym1, d_status, s, need_merged, count, status_stride, count1, prefolded_mask, stage);
         } catch (...) {
             c->capturing = false;
             (void)hipStreamEndCapture(s, &graph);
@@ -442,7 +455,7 @@ void eigh_pair_device(gpcsd_ctx *c, double *A0, int n0, double *w0, double *Z0, 
             return;
         }
     }
-    eigh_pair_enqueue(c, A0, n0, w0, Z0, sym0, A1, n1, w1, Z1, sym1, d_status, s, need_merged, count, status_stride, count1, prefolded_mask);
+    eigh_pair_enqueue(c, A0, n0, w0, Z0, sym0, A1, n1, w1, Z1, sym1, d_status, s, need_merged, count, status_stride, count1, prefolded_mask, stage);
     g.seen_epoch = c->alloc_epoch;
 }
 
@@ -453,7 +466,7 @@ void eigh_device(gpcsd_ctx *c, double *A, int n, double *evals, double *evecs, i
                "eigh: matrix order %d exceeds the eigensolver's capacity of %d rows (GPCSD_MAX_EIG_N)", n,
                force_jacobi() ? JACOBI_MAX_N : EIG_MAXN);
     (void)tag;
-    eigh_pair_device(c, A, n, evals, evecs, nullptr, nullptr, 0, nullptr, nullptr, nullptr, d_status, s, true, 1, 0, -1, 0);
+    eigh_pair_device(c, A, n, evals, evecs, nullptr, nullptr, 0, nullptr, nullptr, nullptr, d_status, s, true, 1, 0, -1, 0, 0);
 }
 
 }  // namespace gpcsd

@@ -59,6 +59,13 @@ __global__ __launch_bounds__(256) void scale_copy_kernel(const double *__restric
     const double inv = 1.0 / m;
     for (long i = blockIdx.x * 256L + threadIdx.x; i < n2; i += (long)gridDim.x * 256) out[i] = A[i] * inv;
 }
+// eigenvalues of the scaled matrices back to the scale of the inputs, all classes and replicas in one launch (stage 2 of a
+// staged solve; elsewhere the rescale rides in the back-transformation's apply launch)
+__global__ void scale_w_batch_kernel(WyBatch b) {
+    const WyProb P = wy_resolve(b, blockIdx.y);
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (P.w_scale && i < P.n) P.w_scale[i] *= P.amax[0];
+}
 __global__ void scale_vec_kernel(double *w, int n, const double *__restrict__ amax) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) w[i] *= amax[0];
@@ -418,7 +425,11 @@ EigArenaView eigh_arena_view(gpcsd_ctx *c, const char *tag, int n, int count) {
     SytrdProb sp{};
     double *amax = nullptr, *wyT = nullptr;
     layout_arena(c, tag, n, count, sp, amax, wyT);
-    return EigArenaView{sp.A0, sp.V, sp.tau, amax, sp.blk};
+    return EigArenaView{sp.A0, sp.V, sp.tau, amax, sp.blk, sp.d, sp.e};
+}
+
+double *eigh_Q_view(gpcsd_ctx *c, const char *tag, int n, int count) {
+    return c->buf<double>(std::string("eig_") + tag + "_Q", (size_t)n * n * std::max(count, 1));
 }
 
 static void prep_problem(gpcsd_ctx *c, EigProb &p, hipStream_t s) {
@@ -508,7 +519,7 @@ __global__ __launch_bounds__(256) void scale_copy_zero_batch_kernel(PrepBatch b)
 }
 
 static PrepBatch prep_batch_launch(gpcsd_ctx *c, EigProb *probs, int nclass, hipStream_t s, int *d_status = nullptr,
-                                   int status_stride = 0) {
+                                   int status_stride = 0, bool launch = true) {
     PrepBatch pb{};
     pb.status = d_status;
     pb.status_stride = status_stride;
@@ -529,7 +540,7 @@ static PrepBatch prep_batch_launch(gpcsd_ctx *c, EigProb *probs, int nclass, hip
     pb.start[MAX_BATCH] = total;
     bool any = false;
     for (int i = 0; i < nclass; ++i) any = any || !probs[i].prefilled;
-    if (any) {                                  // (every class prefilled: the chain starts at the tridiagonalisation)
+    if (any && launch) {                        // (every class prefilled: the chain starts at the tridiagonalisation)
         hipLaunchKernelGGL(absmax_partial_batch_kernel, dim3(AMAX_PARTS, total), dim3(256), 0, s, pb);
         hipLaunchKernelGGL(scale_copy_zero_batch_kernel, dim3(128, total), dim3(256), 0, s, pb);
         GP_HIP(hipGetLastError());
@@ -561,7 +572,7 @@ void sytrd_device(gpcsd_ctx *c, double *A, int n, double *d, double *e, double *
     GP_HIP(hipGetLastError());
 }
 
-void eigh_large_batch(gpcsd_ctx *c, EigProb *probs, int nclass, int *d_status, int status_stride, hipStream_t s) {
+void eigh_large_batch(gpcsd_ctx *c, EigProb *probs, int nclass, int *d_status, int status_stride, hipStream_t s, int stage = 0) {
     GP_REQUIRE(nclass >= 1 && nclass <= MAX_BATCH, -3, "eigh: %d problem classes outside [1,%d]", nclass, MAX_BATCH);
     int nmax = 0;
     bool replicated = false;
@@ -570,12 +581,13 @@ void eigh_large_batch(gpcsd_ctx *c, EigProb *probs, int nclass, int *d_status, i
         nmax = std::max(nmax, probs[i].n);
         replicated = replicated || probs[i].count > 1;
     }
-    const PrepBatch pb = prep_batch_launch(c, probs, nclass, s, d_status, status_stride);
-    {
+    const PrepBatch pb = prep_batch_launch(c, probs, nclass, s, d_status, status_stride, /*launch=*/stage != 2);
+    if (stage != 2) {
         ProfScope ps(c, "eigh_sytrd", 0.0, s);
         sytrd_batch_launch(c, sytrd_batch_of(pb), nclass, nmax, s);
     }
     const bool wy_fused = wy_fused_supported(nmax);
+    GP_REQUIRE(stage == 0 || wy_fused, -3, "eigh: staged solves need the fused back-transformation (n=%d)", nmax);
     (void)replicated;
     WyBatch wb{};
     for (int i = 0; i <= MAX_BATCH; ++i) wb.start[i] = pb.start[i];
@@ -589,7 +601,26 @@ void eigh_large_batch(gpcsd_ctx *c, EigProb *probs, int nclass, int *d_status, i
             wb.p[i].w_scale = pb.w[i]; wb.p[i].amax = pb.amax[i];   // the final rescale of the eigenvalues rides in the apply launch
             wb.p[i].blk = p.sp.blk; wb.p[i].sZ = p.sZ; wb.p[i].sw = p.sw;
         }
+    if (stage == 1) {
+        // T factors of the reflector panels, then Q = the panels applied to the identity (the same apply launch, its slab of Z
+        // starting as columns of I): everything a caller of the tridiagonal form needs, without the divide & conquer
+        ProfScope ps(c, "eigh_stage1_Q", 0.0, s);
+        wy_prep_device(c, wb, nclass, s);
+        WyBatch wq = wb;
+        for (int i = 0; i < nclass; ++i) {
+            wq.p[i].Z = eigh_Q_view(c, probs[i].tag.c_str(), probs[i].n, probs[i].count);
+            wq.p[i].sZ = (long)probs[i].n * probs[i].n;
+            wq.p[i].w_scale = nullptr;
+            wq.p[i].z_identity = 1;
+        }
+        wy_batch_device(c, wq, nclass, s, /*prep_done=*/true);
+        GP_HIP(hipGetLastError());
+        return;
+    }
     bool prep_done = false;
+    // stage 2 has Q itself (stage 1): the eigenvectors are ONE small product Q Z per class instead of the panel-by-panel apply
+    // launch (46 us of dependent chain at n = 250 against ~12), with the tridiagonal eigenvectors Z in a scratch block
+    double *Zs[MAX_BATCH] = {nullptr, nullptr, nullptr, nullptr};
     {
         ProfScope ps(c, "eigh_stedc", 0.0, s);
         StedcProb sp[MAX_BATCH];
@@ -598,12 +629,42 @@ void eigh_large_batch(gpcsd_ctx *c, EigProb *probs, int nclass, int *d_status, i
             sp[i].w = probs[i].w; sp[i].Z = probs[i].Z; sp[i].tag = probs[i].tag;
             sp[i].count = std::max(probs[i].count, 1);
             sp[i].s_in = probs[i].sp.blk; sp[i].sw = probs[i].sw; sp[i].sZ = probs[i].sZ;
+            if (stage == 2) {
+                Zs[i] = c->buf<double>("eig_" + probs[i].tag + "_Zs", (size_t)probs[i].n * probs[i].n * sp[i].count);
+                sp[i].Z = Zs[i];
+                sp[i].sZ = (long)probs[i].n * probs[i].n;
+            }
         }
         // the T factors of the back-transformation need the reflectors only: they ride in the leaf launch of the D&C stage
         prep_done = wy_fused;
-        stedc_batch_device(c, sp, nclass, d_status, status_stride, s, prep_done ? &wb : nullptr);
+        // (stage 2: the T factors were formed by stage 1, the leaf launch carries leaves only)
+        stedc_batch_device(c, sp, nclass, d_status, status_stride, s, (prep_done && stage != 2) ? &wb : nullptr);
     }
-    if (wy_fused) {
+    if (stage == 2) {
+        ProfScope ps(c, "eigh_backtransform", 0.0, s);
+        for (int i = 0; i < nclass; ++i) {
+            EigProb &p = probs[i];
+            const long nn = (long)p.n * p.n;
+            GemmDesc g;                        // V = Q Z
+            g.M = p.n; g.N = p.n; g.K = p.n;
+            g.A = eigh_Q_view(c, p.tag.c_str(), p.n, p.count); g.lda = p.n;
+            g.B = Zs[i]; g.ldb = p.n;
+            g.C = p.Z; g.ldc = p.n;
+            g.batch2 = std::max(p.count, 1); g.sA2 = nn; g.sB2 = nn; g.sC2 = p.sZ;
+            g.prof_name = "gemm_eigh_QZ";
+            // two classes of one order (the symmetric / antisymmetric halves of an even grid) share the launch
+            if (i + 1 < nclass && probs[i + 1].n == p.n && probs[i + 1].count == p.count && probs[i + 1].sZ == p.sZ) {
+                EigProb &q = probs[i + 1];
+                g.batch = 2;
+                g.sA = eigh_Q_view(c, q.tag.c_str(), q.n, q.count) - g.A;
+                g.sB = Zs[i + 1] - Zs[i];
+                g.sC = q.Z - p.Z;
+                ++i;
+            }
+            gemm_f64(c, g, s);
+        }
+        hipLaunchKernelGGL(scale_w_batch_kernel, dim3(ceil_div(nmax, 256), pb.start[MAX_BATCH]), dim3(256), 0, s, wb);
+    } else if (wy_fused) {
         ProfScope ps(c, "eigh_backtransform", 0.0, s);
         wy_batch_device(c, wb, nclass, s, prep_done);
     } else {                                   // n too large for the LDS-resident apply kernel: GEMM chain per panel
@@ -622,7 +683,7 @@ void eigh_large_batch(gpcsd_ctx *c, EigProb *probs, int nclass, int *d_status, i
     GP_HIP(hipGetLastError());
 }
 
-void eigh_large_multi(gpcsd_ctx *c, const EigReq *reqs, int nclass, int *d_status, int status_stride, hipStream_t s) {
+void eigh_large_multi(gpcsd_ctx *c, const EigReq *reqs, int nclass, int *d_status, int status_stride, hipStream_t s, int stage) {
     static_assert(MAX_EIG_BATCH <= MAX_BATCH, "batch limits");
     GP_REQUIRE(nclass >= 1 && nclass <= MAX_BATCH, -3, "eigh: %d problem classes outside [1,%d]", nclass, MAX_BATCH);
     EigProb probs[MAX_BATCH];
@@ -633,7 +694,7 @@ void eigh_large_multi(gpcsd_ctx *c, const EigReq *reqs, int nclass, int *d_statu
         probs[i].sA = reqs[i].sA; probs[i].sw = reqs[i].sw; probs[i].sZ = reqs[i].sZ;
         probs[i].prefilled = reqs[i].prefilled;
     }
-    eigh_large_batch(c, probs, nclass, d_status, status_stride, s);
+    eigh_large_batch(c, probs, nclass, d_status, status_stride, s, stage);
 }
 
 }  // namespace gpcsd

@@ -3,6 +3,7 @@
 // These are tiny (<= 1200^2 outputs) and transcendental-bound, never HBM-bound; the rules that matter are
 // coalesced stores, coordinates staged through LDS once per tile, and operation order identical to the
 // reference expressions so results agree to the last few ulps (no fast-math, IEEE div/sqrt).
+#include "devutil.hpp"
 #include "kernels.hpp"
 
 namespace gpcsd {
@@ -284,6 +285,147 @@ void k_temporal_fold_fill(gpcsd_ctx *c, const TemporalSet *sets, int nrep, const
         hipLaunchKernelGGL(temporal_fold_fill_kernel<float>, dim3(g.elem_blocks + zero_blocks, nrep), dim3(256), 0, s, g);
     else
         hipLaunchKernelGGL(temporal_fold_fill_kernel<double>, dim3(g.elem_blocks + zero_blocks, nrep), dim3(256), 0, s, g);
+    GP_HIP(hipGetLastError());
+}
+
+// ------------------------------------------------------------------------------------------------
+// log-likelihood in the basis U (x) Q: shifted tridiagonal systems (see kernels.hpp: k_ll_tridiag)
+// ------------------------------------------------------------------------------------------------
+// One wave per item (x', p) = (spatial eigen-row in fold order, temporal parity block): with Kt_p = m_p Q_p T_p Q_p^T and
+// lam = es[x'], the block of Ks (x) Kt + sig2 I belonging to the item is Q_p (lam m_p T_p + sig2 I) Q_p^T, a shifted
+// symmetric tridiagonal matrix A = L D L^T (no pivoting: positive definite for lam >= 0, sig2 > 0).  Its log-determinant is
+// sum log D_k, and for a row w = (U^T Y Q)[x', r, p block] the quadratic form w^T A^-1 w = sum z_k^2 / D_k with z = L^-1 w,
+// i.e. ONE forward recurrence per (item, trial): lane = trial, every lane runs the (uniform) pivot recurrence beside its own.
+// The rows are staged through LDS in chunks of LT_CK columns (coalesced 256-byte pieces), the logs of a chunk's pivots are
+// taken by 32 lanes in parallel.  Partials per item: [0, nitems) quadratic forms, [nitems, 2 nitems) log-determinants.
+constexpr int LT_CK = 32, LT_WAVES = 4, LT_RPL = 32;     // columns per chunk; waves per workgroup; staged rows per lane (64 trials)
+struct LlTridiagArgs {
+    const double *W;             // (U^T Y Q) in the layout [x'][r][t~], rows of nt doubles
+    const double *es;            // spatial eigenvalues, fold order (nx)
+    const double *d[2], *e[2];   // tridiagonal of the scaled temporal blocks (np entries each)
+    const double *amax[2];       // their scales m_p
+    const double *sig;           // scalar noise variance (device)
+    int nx, R, nt, np[2], c0[2];
+    double *partials;
+};
+__global__ __launch_bounds__(64 * LT_WAVES) void ll_tridiag_kernel(LlTridiagArgs g) {
+    __shared__ double tile[LT_WAVES][2][64][LT_CK + 1];            // double-buffered chunk of the wave's rows
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int item = blockIdx.x * LT_WAVES + wid, nitems = 2 * g.nx;
+    if (item >= nitems) return;                                   // (whole waves leave: no workgroup barrier below)
+    const int xr = item >> 1, p = item & 1;
+    const int np = g.np[p];
+    if (np <= 0) {
+        if (lane == 0) {
+            g.partials[item] = 0.0;
+            g.partials[nitems + item] = 0.0;
+        }
+        return;
+    }
+    const double lam_m = g.es[xr] * g.amax[p][0], sig = g.sig[0];
+    const double *__restrict__ dd = g.d[p], *__restrict__ ee = g.e[p];
+    const double *__restrict__ Wx = g.W + (long)xr * g.R * g.nt + g.c0[p];
+    const int half = lane >> 5, kk_l = lane & 31;                 // staging: two rows of 32 columns per load instruction
+    double quad = 0.0, logsum = 0.0;
+    for (int r0 = 0; r0 < g.R; r0 += 64) {
+        const int nr = min(64, g.R - r0);
+        double stg[LT_RPL];
+        // all loads of a chunk are issued before any of them is used: one L2 / HBM round trip per chunk, not one per row pair
+        auto load_chunk = [&](int k0) {
+            const int nk = min(LT_CK, np - k0);
+#pragma unroll
+            for (int i = 0; i < LT_RPL; ++i) {
+                const int rr = half + 2 * i;
+                stg[i] = (rr < nr && kk_l < nk) ? Wx[(long)(r0 + rr) * g.nt + k0 + kk_l] : 0.0;
+            }
+        };
+        auto store_chunk = [&](int buf) {
+#pragma unroll
+            for (int i = 0; i < LT_RPL; ++i) tile[wid][buf][half + 2 * i][kk_l] = stg[i];
+        };
+        // the tridiagonal's entries of a chunk travel one chunk ahead as well (lane kk < 32 holds d / e of column k0 + kk)
+        double cd = 0.0, ce = 0.0;
+        auto load_coef = [&](int k0) {
+            const int k = k0 + (lane & 31);
+            cd = (k < np) ? dd[k] : 0.0;
+            ce = (k < np) ? ee[k] : 0.0;
+        };
+        load_coef(0);
+        load_chunk(0);
+        store_chunk(0);
+        double piv_inv = 0.0, bprev = 0.0, z = 0.0, q = 0.0;      // 1 / D_{k-1}, offdiagonal b_{k-1}, z_{k-1}
+        int buf = 0;
+        for (int k0 = 0; k0 < np; k0 += LT_CK, buf ^= 1) {
+            const int nk = min(LT_CK, np - k0);
+            // a_k = lam m d_k + sig2, b_k = lam m e_k of this chunk: lane kk holds column k0 + kk's, the recurrence reads them
+            // with v_readlane (a scalar per step, no LDS on the serial path)
+            const double ca = lam_m * cd + sig, cb = lam_m * ce;
+            if (k0 + LT_CK < np) {                                // the next chunk's loads fly during this chunk's recurrence
+                load_coef(k0 + LT_CK);
+                load_chunk(k0 + LT_CK);
+            }
+            __builtin_amdgcn_wave_barrier();
+            double wv[LT_CK];                                     // this lane's row of the chunk: one batch of LDS reads
+#pragma unroll
+            for (int kk = 0; kk < LT_CK; ++kk) wv[kk] = tile[wid][buf][lane][kk];
+            // the serial part, all in registers: per step one multiply, one fma and a reciprocal on the pivot chain (v_rcp_f64 +
+            // two Newton steps, ~2 ulp: an IEEE division is 3x the latency and every one of the 250 steps waits for it)
+            double mypiv = 1.0;
+#pragma unroll
+            for (int kk = 0; kk < LT_CK; ++kk) {
+                if (kk < nk) {                                    // wave-uniform
+                    const double l = bprev * piv_inv;             // L_{k,k-1} = b_{k-1} / D_{k-1}  (0 for k = 0)
+                    const double piv = lane_get(ca, kk) - l * bprev;
+                    z = wv[kk] - l * z;
+                    piv_inv = fast_rcp(piv);
+                    q += z * z * piv_inv;
+                    bprev = lane_get(cb, kk);
+                    if (lane == kk) mypiv = piv;
+                }
+            }
+            if (r0 == 0) {                                        // log-determinant: once per item, lane kk takes log D_{k0+kk}
+                const double lg = (lane < nk) ? log(mypiv) : 0.0;
+                logsum += wave_sum(lg);
+            }
+            __builtin_amdgcn_wave_barrier();
+            if (k0 + LT_CK < np) store_chunk(buf ^ 1);
+        }
+        quad += wave_sum(lane < nr ? q : 0.0);
+    }
+    if (lane == 0) {
+        g.partials[item] = quad;
+        g.partials[nitems + item] = logsum;
+    }
+}
+
+__global__ __launch_bounds__(256) void ll_tridiag_reduce_kernel(const double *__restrict__ partials, int nitems, double *out_sumlog,
+                                                                double *out_quad) {
+    __shared__ double sh[256];
+    const double *p = partials + (blockIdx.x == 0 ? nitems : 0);
+    double s = 0.0;
+    for (int i = threadIdx.x; i < nitems; i += 256) s += p[i];
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) sh[threadIdx.x] += sh[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) (blockIdx.x == 0 ? out_sumlog : out_quad)[0] = sh[0];
+}
+
+void k_ll_tridiag(gpcsd_ctx *c, const double *W, const double *es, const double *const d[2], const double *const e[2],
+                  const double *const amax[2], const double *sig, int nx, int R, int nt, const int np[2], const int c0[2],
+                  double *out_sumlog, double *out_quad, hipStream_t s) {
+    LlTridiagArgs g{};
+    g.W = W; g.es = es; g.sig = sig; g.nx = nx; g.R = R; g.nt = nt;
+    for (int p = 0; p < 2; ++p) {
+        g.d[p] = d[p]; g.e[p] = e[p]; g.amax[p] = amax[p]; g.np[p] = np[p]; g.c0[p] = c0[p];
+    }
+    const int nitems = 2 * nx;
+    g.partials = c->buf<double>("ll_tridiag_partials", (size_t)2 * nitems);
+    ProfScope ps(c, "ll_tridiag", 0.0, s);
+    hipLaunchKernelGGL(ll_tridiag_kernel, dim3(ceil_div(nitems, LT_WAVES)), dim3(64 * LT_WAVES), 0, s, g);
+    hipLaunchKernelGGL(ll_tridiag_reduce_kernel, dim3(2), dim3(256), 0, s, (const double *)g.partials, nitems, out_sumlog, out_quad);
     GP_HIP(hipGetLastError());
 }
 

@@ -109,6 +109,13 @@ void k_se_2d(gpcsd_ctx *c, const double *a1, const double *a2, int na, int na2, 
              long s_out = 0);
 // one axis factor of the tensor-grid SE kernel: out(n,n) = exp(-0.5 (a_i - a_j)^2 / ell^2)
 void k_se_axis(gpcsd_ctx *c, const double *a, int n, double ell, double *out, hipStream_t s);
+// Log-likelihood pieces in the basis U (x) Q (gram.hip): with Kt_p = amax_p Q_p T_p Q_p^T (T_p tridiagonal: d_p, e_p) the
+// block of Ks (x) Kt + sig2 I of spatial eigen-row x' and temporal parity p is Q_p (es[x'] amax_p T_p + sig2 I) Q_p^T;
+// *out_sumlog = sum of the log pivots of all these tridiagonal matrices (= sum log D), *out_quad = sum over the rows w of
+// W = U^T Y Q ([x'][r][t~], rows of nt) of w^T (.)^-1 w by one forward recurrence each.  No temporal eigenvectors.
+void k_ll_tridiag(gpcsd_ctx *c, const double *W, const double *es, const double *const d[2], const double *const e[2],
+                  const double *const amax[2], const double *sig, int nx, int R, int nt, const int np[2], const int c0[2],
+                  double *out_sumlog, double *out_quad, hipStream_t s);
 void k_add_diag(gpcsd_ctx *c, double *A, int n, double v, hipStream_t s, const HpDev *tab = nullptr, int B = 1, long s_out = 0);
 // D[x*nt + i] = es[x]*et[i] + sig[x or 0]; also sumlog -> *sumlog_out (deterministic)
 // Dinv (optional) = 1/D elementwise.  sumlog_out == nullptr: no final sum; the per-block partials stay in the ctx buffer
@@ -162,6 +169,7 @@ struct EigReq {
 struct EigArenaView {
     double *A0, *V, *tau, *amax;
     long blk;
+    double *d, *e;               // the tridiagonal of A0 = Q T Q^T once the tridiagonalisation has run (n entries each)
 };
 EigArenaView eigh_arena_view(gpcsd_ctx *c, const char *tag, int n, int count);
 // tags of the two half-size classes of problem `slot` (0 / 1) of eigh_pair_device: [0] symmetric, [1] antisymmetric
@@ -194,10 +202,18 @@ __device__ __forceinline__ void class_of(const int *start, int g, int &cls, int 
 // reports numerical failure in d_status[r * status_stride] (status_stride 0: one shared word)
 // prefolded_mask bit p: the folded halves of problem p are already in their class arenas, scaled (see EigArenaView); A_p is
 // then not read (symmetry folding must apply to that problem: eigh_fold_view(...).on)
+// stage: 0 = the whole solve.  1 = up to the tridiagonalisation, the T factors of its reflector panels and the orthogonal
+// factor Q itself (eigh_Q_view: A / amax = Q T Q^T, T in EigArenaView::d / e) -- what a caller needs that works with the
+// tridiagonal form directly (capi_fused.inl: the log-likelihood's shifted tridiagonal systems); 2 = the rest (divide & conquer,
+// back-transformation) of a solve whose stage 1 has run with the same arguments.  Stages 1 / 2 need folded (prefolded or not),
+// tridiagonalisation-path problems within the fused back-transformation's size (eigh_stageable).
 void eigh_pair_device(gpcsd_ctx *c, double *A0, int n0, double *w0, double *Z0, const SymDev *sym0, double *A1, int n1,
                       double *w1, double *Z1, const SymDev *sym1, int *d_status, hipStream_t s, bool need_merged = true,
                       int count = 1, int status_stride = 0, int count1 = -1,   // count1 > 0: replicas of problem 1 (else = count)
-                      int prefolded_mask = 0);
+                      int prefolded_mask = 0, int stage = 0);
+bool eigh_stageable(const SymDev *sy, int n);
+// Q of class `tag` after stage 1: (n, n) row-major per replica, replicas n*n apart
+double *eigh_Q_view(gpcsd_ctx *c, const char *tag, int n, int count);
 // Half-size results of a symmetry-folded problem, in fold order (see eigh.hip); on == false: the problem is not folded.
 struct FoldView {
     bool on = false;
@@ -214,6 +230,7 @@ struct WyProb {
     double *w_scale = nullptr;       // optional: eigenvalues of the SCALED matrix, multiplied by *amax in the apply launch
     const double *amax = nullptr;    // (saves the separate rescale launch at the end of the dependent chain)
     long blk = 0, sZ = 0, sw = 0;    // replica strides: V / tau / T / amax live in the class arena (blk), Z and w_scale are the caller's
+    int z_identity = 0;              // the apply launch starts from Z = I (and writes Q itself): Z is only written
 };
 struct WyBatch {
     WyProb p[MAX_EIG_BATCH];         // one entry per class
@@ -233,6 +250,7 @@ __device__ __forceinline__ WyProb wy_resolve(const WyBatch &b, int g) {
 bool wy_fused_supported(int nmax);
 // prep_done: the T factors were already formed by the D&C leaf launch (stedc_batch_device with a WyBatch)
 void wy_batch_device(gpcsd_ctx *c, const WyBatch &b, int nclass, hipStream_t s, bool prep_done = false);
+void wy_prep_device(gpcsd_ctx *c, const WyBatch &b, int nclass, hipStream_t s);     // the T factors only
 // stages of the large-n solver, exposed for tests / diagnostics
 void sytrd_device(gpcsd_ctx *c, double *A, int n, double *d, double *e, double *V, double *tau, hipStream_t s);
 void stedc_device(gpcsd_ctx *c, const double *d, const double *e, int n, double *w, double *Z, int *d_status,

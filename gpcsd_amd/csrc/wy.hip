@@ -40,7 +40,8 @@ __global__ __launch_bounds__(256) void wy_apply_kernel(WyBatch b) {
     }
     for (int idx = tid; idx < n * WY_ZC; idx += 256) {
         const int r = idx / WY_ZC, j = idx % WY_ZC;
-        Zs[r * WY_LD + j] = (c0 + j < n) ? P.Z[(long)r * n + c0 + j] : 0.0;
+        if (P.z_identity) Zs[r * WY_LD + j] = (r == c0 + j) ? 1.0 : 0.0;        // Q itself: the panels applied to the identity
+        else Zs[r * WY_LD + j] = (c0 + j < n) ? P.Z[(long)r * n + c0 + j] : 0.0;
     }
     __syncthreads();
     const int nfrag = (n + 15) / 16;
@@ -134,6 +135,14 @@ __global__ __launch_bounds__(256) void wy_apply_kernel(WyBatch b) {
         const int r = idx / WY_ZC, j = idx % WY_ZC;
         if (c0 + j < n) P.Z[(long)r * n + c0 + j] = Zs[r * WY_LD + j];
     }
+}
+
+void wy_prep_device(gpcsd_ctx *c, const WyBatch &b, int nclass, hipStream_t s) {
+    int maxP = 0;
+    for (int i = 0; i < nclass; ++i) maxP = std::max(maxP, b.p[i].npanels);
+    if (maxP == 0) return;
+    hipLaunchKernelGGL(wy_prep_kernel, dim3(maxP, b.start[MAX_EIG_BATCH]), dim3(1024), 0, s, b);
+    GP_HIP(hipGetLastError());
 }
 
 bool wy_fused_supported(int nmax) { return ((size_t)nmax * WY_LD + 2 * WY_NB * WY_LD) * sizeof(double) <= 160 * 1024; }

@@ -329,3 +329,35 @@ def test_gpcsd2d_failed_factorisation_is_plus_inf_and_the_restart_is_skipped(bat
     m2.eps = float("nan")
     assert m2.fit(n_restarts=2, options=OPTS, starts=good, batch=batch) is None
     assert "problem with optimization!" in capsys.readouterr().out
+
+
+def test_gpcsd2d_fit_with_the_reference_default_options_converges():
+    """GPCSD2D.fit() as the reference's callers invoke it (neuropixels/fit_gpcsd2d.py:101, sim_from_gp_2D.py:133): default
+    options (maxiter 500, gtol 1e-5, ftol 1e7 eps), restarts from prior draws.  The optimiser must terminate by one of
+    L-BFGS-B's convergence tests well inside the iteration budget, at an objective below the truncated fit's from the same
+    starts, and the value it reports must be the oracle's objective at the optimum."""
+    m, geom, lfp, kinds, eps = _case_2d("2d_grid_48x40x2", ntrials=4)
+    from gpcsd_amd.priors import GPCSDHalfNormalPrior
+    for tc in m.temporal_cov_list:
+        tc.params["sigma2"]["prior"] = GPCSDHalfNormalPrior(2.0 * tc.params["sigma2"]["value"])
+    f, fg = _cpu_objective_2d(m, geom, lfp, kinds, eps)
+    np.random.seed(321)
+    m.fit(n_restarts=2, verbose=False)
+    full = np.asarray(m.fit_nll_values_)
+    starts = [s0.copy() for s0 in m.fit_starts_]
+    assert full.shape == (2,) and np.all(np.isfinite(full))
+    for k in range(2):
+        at_opt = f(np.asarray(m.fit_params_[k]))
+        assert abs(at_opt - full[k]) / abs(at_opt) < 1e-8
+    m2, *_ = _case_2d("2d_grid_48x40x2", ntrials=4)
+    for tc in m2.temporal_cov_list:
+        tc.params["sigma2"]["prior"] = GPCSDHalfNormalPrior(2.0 * tc.params["sigma2"]["value"])
+    m2.fit(n_restarts=2, starts=starts, options=OPTS)
+    assert np.all(full <= np.asarray(m2.fit_nll_values_) + 1e-9 * np.abs(full))
+    # gradient at the optimum: projected gradient below gtol (or the relative-reduction test fired first, a few gtol above it)
+    for k in range(2):
+        _, g = m._objective_and_grad(np.asarray(m.fit_params_[k]), False)
+        lo, hi = np.array(m._bounds()).T
+        x = np.asarray(m.fit_params_[k])
+        pg = np.where((x <= lo) & (g > 0) | (x >= hi) & (g < 0), 0.0, g)
+        assert np.max(np.abs(pg)) < 5e-2 * max(1.0, abs(full[k])) ** 0.5, pg

@@ -752,15 +752,50 @@ def test_predict_resident_is_asynchronous_and_changes_no_bits(name):
     assert np.array_equal(ctx.fetch("pred_out_csd", shape), ref[-2])
 
 
-@pytest.mark.parametrize("name", ["cfg3", "cfg2"])
-def test_queued_call_forms_mixed_at_random_soak(name):
+@pytest.mark.parametrize("name,form", [("cfg3", ""), ("cfg2", ""), ("cfg3", "tri"), ("cfg2", "tri")])
+def test_queued_call_forms_mixed_at_random_soak(name, form):
     """tools/soak_paired.py: 80 steps at the bench geometry with hyper-parameters changing every step, the call forms
     (fenced / two queued calls / paired / paired with two steps in flight) mixed at random, decomposition cache off and on:
-    every log-likelihood and the final predictions are the bits of the same calls fenced one by one."""
+    every log-likelihood and the final predictions are the bits of the same calls fenced one by one.  "tri": the same with the
+    experimental shifted-tridiagonal log-likelihood switched on (gpcsd_ll_tridiag; staged temporal chain)."""
     import subprocess
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "soak_paired.py"), name, "80"], capture_output=True, text=True,
-                       timeout=600)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "soak_paired.py"), name, "80"] + ([form] if form else []),
+                       capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "soak ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+@pytest.mark.parametrize("name", ["cfg3s_2d_384x500x2", "cfg2s_1d_24x500x8", "2d_npx_96x120x3"])
+def test_shifted_tridiagonal_loglik_matches_eigenvector_form_and_oracle(name):
+    """gpcsd_ll_tridiag (experimental): with the spatial side decomposed and the temporal side only tridiagonalised, the
+    log-likelihood is a sum over shifted tridiagonal systems (LDL^T pivots + one forward recurrence per (x', trial) row).  Same
+    value as the eigenvector form to rounding and as the oracle to the gate; predictions after it (eigenvectors formed as Q Z in
+    the second stage of the temporal chain) agree with the default chain's to 1e-9; switching back restores the default bits.
+    Time grids whose halves are small enough for the Jacobi solver (120 points) keep the eigenvector form."""
+    c, g, geom, hp, lfp = load_model_case(name)
+    if lfp is None or lfp.shape[2] < 2:
+        lfp = C.synth_lfp(77, c["x"].shape[0], c["t"].shape[0], 3)
+    m = _model_from_case(c, g, lfp)
+    ctx = m._sync_device()
+    ll0 = m.loglik()
+    m.predict(c["x"], c["t"], type="both")
+    csd0, lfp0 = m.csd_pred.copy(), m.lfp_pred.copy()
+    n0 = ctx.ll_tridiag(True)
+    try:
+        ll1 = m.loglik()
+        took = ctx.ll_tridiag() - n0
+        assert took == (1 if c["t"].shape[0] // 2 > 64 else 0)
+        assert abs(ll1 - ll0) <= 1e-12 * abs(ll0)
+        assert abs(ll1 - O.loglik(geom, with_jitter(hp, m.JITTER), lfp)) / abs(ll1) < 1e-9
+        m.predict(c["x"], c["t"], type="both")
+        assert relerr(m.csd_pred, csd0) < 1e-9 and relerr(m.lfp_pred, lfp0) < 1e-9
+        f, gr = m._loglik_and_grad_natural()                     # the gradient path keeps the eigenvector form
+        assert abs(f - ll0) <= 1e-12 * abs(ll0) and np.all(np.isfinite(gr))
+        assert m.loglik() == ll1
+    finally:
+        ctx.ll_tridiag(False)
+    assert m.loglik() == ll0
+    m.predict(c["x"], c["t"], type="both")
+    assert np.array_equal(m.csd_pred, csd0)
 
 
 def test_predict_returns_pinned_arrays_that_are_not_overwritten():

@@ -1,6 +1,8 @@
 """Soak of the queued call forms: N steps with hyper-parameters that change every step, the paired / queued / two-deep forms
 against the same calls fenced one by one -- every log-likelihood and the final predictions bit for bit.  Mixes the forms at
-random, so generations, chain streams and the result ring see every hand-over.   python tools/soak_paired.py [cfg3|cfg2] [N]"""
+random, so generations, chain streams and the result ring see every hand-over.   python tools/soak_paired.py [cfg3|cfg2] [N] [tri]
+("tri": with the experimental shifted-tridiagonal log-likelihood, gpcsd_ll_tridiag; its fenced values are also held to 1e-12
+of the eigenvector form's)."""
 import os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -9,6 +11,7 @@ from gpcsd_amd import _hip
 
 name = sys.argv[1] if len(sys.argv) > 1 else "cfg3"
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 200
+TRI = len(sys.argv) > 3 and sys.argv[3] == "tri"
 w = bench.workload(name)
 m = bench.build_model(w, np.zeros((w["nx"], w["nt"], 1)))
 R = 6
@@ -37,6 +40,9 @@ def hps(k):
 
 
 ctx.decomposition_cache(False)
+if TRI:
+    eig_ll = [ctx.loglik_parts(hps(k)[0][0]) for k in range(N)]
+    ctx.ll_tridiag(True)
 ref_ll, ref_pred = [], None
 for k in range(N):
     h1, h0 = hps(k)
@@ -46,6 +52,12 @@ for k in range(N):
 C = len(m.temporal_cov_list)
 outs = [("pred_out_csd", shape), ("pred_out_lfp", shape), ("pred_out_csd_list", (C,) + shape), ("pred_out_lfp_list", (C,) + shape)]
 ref_pred = [ctx.fetch(nm, sh).copy() for nm, sh in outs]
+if TRI:
+    dev = max(abs(sum(a[:2]) - sum(b[:2])) / abs(sum(b[:2])) for a, b in zip(ref_ll, eig_ll))
+    print("tridiagonal form vs eigenvector form: %d of %d log-likelihoods took it, max relative deviation %.2e" % (
+        ctx.ll_tridiag(), N, dev), flush=True)
+    if ctx.ll_tridiag() < N or not dev < 1e-12:
+        sys.exit(1)
 
 for cache in (False, True):
     ctx.decomposition_cache(cache)
