@@ -333,6 +333,14 @@ def main():
         local_rank = int(os.environ["GPCSD_DEVICE"])
     import torch
     torch.cuda.set_device(local_rank)
+    # keep this rank's host threads (those running now; RCCL's and the library's inherit) on the CPUs of its GPU's NUMA node: a
+    # host process that migrates between the sockets runs the same queued step at 1.12 .. 1.25 ms from run to run, a bound one
+    # at 1.13 (GPCSD_BENCH_NUMA_BIND=0 leaves the affinity alone).  After torch has initialised HIP: torch's
+    # bundled runtime does not come up once another copy of the runtime (the library's) has been initialised first.
+    host_numa = None
+    if os.environ.get("GPCSD_BENCH_NUMA_BIND", "1") != "0":
+        from gpcsd_amd import _hip as _hip_mod
+        host_numa = _hip_mod.bind_host_to_device_numa(local_rank)
     # GPCSD_BENCH_FORCE_DIST=1: initialise the process group and shard even with one rank -- the only way to drive the RCCL
     # code path (device tensors, broadcast, async all-reduce, barrier) on a one-GPU box
     force_dist = os.environ.get("GPCSD_BENCH_FORCE_DIST") == "1"
@@ -357,6 +365,8 @@ def main():
             and not args.only_value and not args.no_sub_results):
         out["sub_results"] = sub_results(args, local_rank, backend)
     if rank == 0 and out is not None:
+        out["host_affinity"] = ({"bound_to_numa_node": host_numa["node"], "cpus": host_numa["cpus"], "device_pci": host_numa["pci"]}
+                                if host_numa else {"bound_to_numa_node": None, "cpus": len(os.sched_getaffinity(0))})
         print(json.dumps(out))
 
 

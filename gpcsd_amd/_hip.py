@@ -135,6 +135,7 @@ SIGNATURES = {
     "gpcsd_device_synchronize": (_I, [_P]),
     "gpcsd_host_alloc": (_I, [ctypes.c_size_t, ctypes.POINTER(_P)]),
     "gpcsd_host_free": (_I, [_P]),
+    "gpcsd_device_pci_bus_id": (_I, [_I, ctypes.c_char_p, _I]),
     "gpcsd_set_lfp": (_I, [_P, _DP, _I, _I, _I]),
     "gpcsd_set_geometry_1d": (_I, [_P, _DP, _I, _DP, _DP, _I]),
     "gpcsd_set_geometry_2d": (_I, [_P, _DP, _I, _DP, _DP, _I, _DP, _DP, _I]),
@@ -219,6 +220,57 @@ def load_library():
             fn.argtypes = args
         _lib = lib
         return lib
+
+
+def _parse_cpulist(text):
+    """'0-3,8,10-11' (the kernel's cpulist format) -> set of ints."""
+    out = set()
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        lo, _, hi = part.partition("-")
+        out.update(range(int(lo), int(hi or lo) + 1))
+    return out
+
+
+def bind_host_to_device_numa(device=0):
+    """Keep every thread of this process on the CPUs of the NUMA node device `device` hangs off (sched_setaffinity on all
+    threads, intersected with the affinity the process already has).  Returns {"node", "cpus", "pci"}, or None when the node
+    cannot be told (no sysfs, one node only, no permission) -- then nothing is changed.
+
+    Why: on a two-socket host a process the scheduler may move between the sockets runs the latency-bound queued step of
+    bench.py at 1.12 .. 1.25 ms from one run to the next; bound to one socket's CPUs it stays at 1.13 (either socket: it is
+    the migration that costs; `taskset -c <node cpulist>` from outside does the same).  Opt-in -- a library does not change
+    its host's affinity on its own: bench.py calls it, a multi-rank launcher calls it per rank with LOCAL_RANK."""
+    try:
+        lib = load_library()
+        buf = ctypes.create_string_buffer(64)
+        if lib.gpcsd_device_pci_bus_id(int(device), buf, 64) != 0:
+            return None
+        pci = buf.value.decode().lower()
+        nodes = sorted(int(d[4:]) for d in os.listdir("/sys/devices/system/node") if d.startswith("node") and d[4:].isdigit())
+        if len(nodes) < 2:
+            return None
+        node = -1
+        try:
+            node = int(open("/sys/bus/pci/devices/%s/numa_node" % pci).read())
+        except (OSError, ValueError):
+            pass
+        lists = {nd: _parse_cpulist(open("/sys/devices/system/node/node%d/cpulist" % nd).read()) for nd in nodes}
+        if node not in lists:                      # unknown to the kernel: the node most of the present affinity lies on
+            have = os.sched_getaffinity(0)
+            node = max(nodes, key=lambda nd: len(lists[nd] & have))
+        cpus = lists[node] & os.sched_getaffinity(0)
+        if not cpus:
+            return None
+        for tid in os.listdir("/proc/self/task"):
+            try:
+                os.sched_setaffinity(int(tid), cpus)
+            except (OSError, ValueError):
+                pass
+        return {"node": node, "cpus": len(cpus), "pci": pci}
+    except (OSError, HipUnavailable):
+        return None
 
 
 def _arr(a, shape=None, name="array"):

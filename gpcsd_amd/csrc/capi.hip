@@ -856,6 +856,20 @@ extern "C" int gpcsd_host_alloc(size_t bytes, void **out) {
     return 0;
 }
 
+// PCI address of a device ("0000:c5:00.0"), for a host that wants to place itself on the device's NUMA node
+// (/sys/bus/pci/devices/<address>/numa_node): no context needed.
+extern "C" int gpcsd_device_pci_bus_id(int device, char *buf, int len) {
+    if (!buf || len < 16) return -3;
+    buf[0] = 0;
+    const hipError_t e = hipDeviceGetPCIBusId(buf, len, device);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        fail(nullptr, HipError{-100 - (int)e, std::string("hipDeviceGetPCIBusId: ") + hipGetErrorString(e)});
+        return -100 - (int)e;
+    }
+    return 0;
+}
+
 extern "C" int gpcsd_host_free(void *p) {
     if (!p) return 0;
     return hipHostFree(p) == hipSuccess ? 0 : -1;

@@ -81,6 +81,12 @@ int  gpcsd_device_synchronize(gpcsd_ctx *ctx);
  * case the device-to-host copy is a single DMA at link speed; any other host pointer still works (staged, slower). */
 int  gpcsd_host_alloc(size_t bytes, void **out);
 int  gpcsd_host_free(void *p);
+/* PCI address of device `device` ("0000:c5:00.0", NUL-terminated into buf[len], len >= 16): what a host needs to find the
+ * device's NUMA node (/sys/bus/pci/devices/<address>/numa_node) and keep its threads there.  On the two-socket hosts of the
+ * MI355X pool a host process free to migrate between the sockets ran the queued step of bench.py at 1.12 .. 1.25 ms from run to
+ * run, one kept on either socket's CPUs at 1.13 (gpcsd_amd._hip.bind_host_to_device_numa; `numactl`/`taskset` do the same from
+ * outside).  No context needed. */
+int  gpcsd_device_pci_bus_id(int device, char *buf, int len);
 
 /* ---- resident data (copied; re-laid-out on device) ----------------------------- */
 /* lfp is (nx, nt, ntrials) C-order as held by GPCSD{1,2}D.lfp (gpcsd1d.py:34, gpcsd2d.py:36);

@@ -128,3 +128,16 @@ def test_shard_block_matches_the_python_partition():
     assert lib.gpcsd_shard_block(10, 3, 3, ctypes.byref(a), ctypes.byref(c)) == -3
     out = ctypes.c_double()
     assert lib.gpcsd_combine_loglik(4, 2.0, 3.0, ctypes.byref(out)) == 0 and out.value == -0.5 * 4 * 2.0 - 0.5 * 3.0
+
+
+def test_cpulist_parser_and_numa_binding_is_a_noop_without_a_gpu():
+    """bind_host_to_device_numa: the kernel's cpulist format, and no change of affinity when the device cannot be asked."""
+    import os
+    from gpcsd_amd import _hip
+    assert _hip._parse_cpulist("0-3,8,10-11\n") == {0, 1, 2, 3, 8, 10, 11}
+    assert _hip._parse_cpulist("") == set() and _hip._parse_cpulist("5") == {5}
+    before = os.sched_getaffinity(0)
+    import torch
+    if not torch.cuda.is_available():
+        assert _hip.bind_host_to_device_numa(0) is None
+        assert os.sched_getaffinity(0) == before

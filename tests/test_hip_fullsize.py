@@ -936,3 +936,34 @@ def test_c_abi_multi_device_entry_points(name, devices):
             d.loglik_grad_batch(hps, ng)                     # ... which the batch entry refuses
     finally:
         d.close()
+
+
+def test_host_numa_binding_in_a_child_process():
+    """gpcsd_device_pci_bus_id + bind_host_to_device_numa (what bench.py does at start-up): the device's PCI address comes back,
+    every thread of the process ends up on CPUs of ONE node that were in its affinity before, and a log-likelihood evaluated
+    afterwards is the one evaluated before.  In a child: the test process keeps its own affinity."""
+    import subprocess
+    code = (
+        "import os, sys, json\n"
+        "sys.path.insert(0, %r)\n"
+        "sys.path.insert(0, os.path.join(%r, 'tests'))\n"
+        "sys.path.insert(0, os.path.join(%r, 'tests', 'golden'))\n"
+        "import numpy as np\n"
+        "from gpcsd_amd import _hip\n"
+        "from helpers import load_model_case\n"
+        "import test_hip_fullsize as T\n"
+        "c, g, geom, hp, lfp = load_model_case('2d_npx_96x120x3')\n"
+        "m = T._model_from_case(c, g, lfp)\n"
+        "ll0 = m.loglik()\n"
+        "before = os.sched_getaffinity(0)\n"
+        "r = _hip.bind_host_to_device_numa(0)\n"
+        "after = [os.sched_getaffinity(int(t)) for t in os.listdir('/proc/self/task')]\n"
+        "print(json.dumps({'r': r, 'subset': all(a <= before for a in after), 'same': len({tuple(sorted(a)) for a in after}) == 1,\n"
+        "                  'n_after': len(after[0]), 'n_before': len(before), 'll_same': bool(m.loglik() == ll0)}))\n") % (ROOT, ROOT, ROOT)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    assert out["ll_same"] and out["subset"]
+    if out["r"] is not None:                                      # a host with one node (or no sysfs) is left alone
+        assert out["same"] and out["n_after"] == out["r"]["cpus"] <= out["n_before"]
+        assert len(out["r"]["pci"].split(":")) == 3
