@@ -723,11 +723,11 @@ class Context:
         self._check(self._lib.gpcsd_fold_gemm(self._h, -1 if on is None else int(bool(on)), ctypes.byref(n)))
         return int(n.value)
 
-    def ll_tridiag(self, on=None):
-        """Switch (True/False) or query (None) the experimental shifted-tridiagonal form of the folded log-likelihood (no temporal
-        eigenvectors on its path); returns the number of log-likelihoods evaluated that way so far."""
+    def ll_tridiag(self, mode=None):
+        """Set (0 / False: off, 1 / True: on, 2: by size -- the default) or query (None) the shifted-tridiagonal form of the
+        folded log-likelihood (no temporal eigenvectors on its path); returns the number of log-likelihoods evaluated that way."""
         n = _L(0)
-        self._check(self._lib.gpcsd_ll_tridiag(self._h, -1 if on is None else int(bool(on)), ctypes.byref(n)))
+        self._check(self._lib.gpcsd_ll_tridiag(self._h, -1 if mode is None else int(mode), ctypes.byref(n)))
         return int(n.value)
 
     def decomposition_cache(self, on=None):

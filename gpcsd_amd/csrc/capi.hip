@@ -385,11 +385,29 @@ struct EigState {
 };
 
 // The log-likelihood in the basis U (x) Q (k_ll_tridiag) instead of U (x) V: it needs the temporal chain only up to the
-// tridiagonalisation + Q, not the divide & conquer, which only a prediction's tail waits for.  EXPERIMENTAL, off by default
-// (gpcsd_ll_tridiag(ctx, 1, ..) or GPCSD_LL_TRIDIAG=1 switch it on): the log-likelihood comes back ~0.1 ms earlier at cfg3, but
-// the staged temporal chain is ~0.1 ms longer (T factors and Q in front of the divide & conquer) and bounds the pipelined step
-// as before -- no gain on bench.py's step until stage 2 runs beside the next chain's stage 1.
-static bool ll_tridiag_enabled(const gpcsd_ctx *c) { return c->ll_tridiag_on; }
+// tridiagonalisation + Q, not the divide & conquer and the back-transformation, which only a prediction's tail waits for.  The
+// temporal chain then runs in stages (eigh_pair_device): 1 and 2 on stream2, 3 (Q) beside 2 on stream4.  Measured:
+// the paired step 1.134 -> 1.101 ms at cfg3 (50 trials), 0.969 -> 0.929 ms at cfg2; with 400 resident trials the step is bound by
+// its GEMMs and the extra pass over W costs 3 % (5.08 against 4.92 ms).  Hence mode 2 (the default): on while the resident block
+// is small enough for the step to be latency-bound.  gpcsd_ll_tridiag(ctx, 0 | 1 | 2, ..) / GPCSD_LL_TRIDIAG=0 | 1 force it.
+static constexpr long LL_TRI_AUTO_MAX = 1L << 24;      // nx * nt * ntrials (384 x 500: up to 87 trials)
+static bool ll_tridiag_enabled(const gpcsd_ctx *c) {
+    return c->ll_tridiag_mode == 1 || (c->ll_tridiag_mode == 2 && (long)c->nx * c->nt * c->ntrials <= LL_TRI_AUTO_MAX);
+}
+
+// Before a temporal chain overwrites the single-buffered outputs of a staged predecessor (reflectors, T factors, the
+// tridiagonal and its scale, Q): wait on its stream for the readers beside the chain -- the log-likelihood tail on the main
+// stream (X = Y~ Q, the recurrences) and stage 3 on stream4 (reads reflectors and T factors, writes Q).
+static void staged_chain_guard(gpcsd_ctx *c, hipStream_t s2) {
+    if (c->tri_reader_queued) {
+        GP_HIP(hipStreamWaitEvent(s2, c->ev_tri_done, 0));
+        c->tri_reader_queued = false;
+    }
+    if (c->q_queued) {
+        GP_HIP(hipStreamWaitEvent(s2, c->ev_q, 0));
+        c->q_queued = false;
+    }
+}
 
 // Main stream waits for the spatial chain of this call (no-op when it was reused from the cache or already joined).
 static void join_spatial(gpcsd_ctx *c, EigState &e) {
@@ -520,25 +538,35 @@ EigState front_half(gpcsd_ctx *c, const gpcsd_hparams *hp, double jitter, bool n
     if (run_t) {
         c->tl("T chain start (s2)", s2);
         const bool tfill = temporal_fill_applies(c, sym_t, nt, host_kt);
-        if (c->tri_reader_queued) {       // a queued log-likelihood tail still reads the previous chain's Q / tridiagonal
-            GP_HIP(hipStreamWaitEvent(s2, c->ev_tri_done, 0));
-            c->tri_reader_queued = false;
-        }
+        staged_chain_guard(c, s2);
         if (tfill) temporal_fill(c, &hp, 1, t, nt, *sym_t, e.status + 1, 0, s2);
         else make_kt(s2);
-        // staged whenever it applies (not only for a log-likelihood): stage 2 forms the eigenvectors as Q Z, and every call
-        // form must get the same bits
+        // staged whenever it applies (not only for a log-likelihood): the T factors are then a launch of their own instead of
+        // riding in the leaf launch -- same bits either way, but every call form takes the same launches
         const bool staged = tfill && ll_tridiag_enabled(c) && eigh_stageable(sym_t, nt);
         {
             ProfScope ps(c, "eigh_temporal", 9.0 * (double)nt * nt * nt, s2);
-            if (staged) {            // the log-likelihood's tail starts behind stage 1; stage 2 completes the decomposition
+            if (staged) {
+                // stage 1 (tridiagonalisation, T factors), then on this stream stage 2 (divide & conquer, back-transformation)
+                // and BESIDE it, on stream4, stage 3 (Q) when a log-likelihood wants the tridiagonal form: its tail starts
+                // behind stage 3 and never waits for stage 2
+                const bool tri = want_tri && !need_merged && hp->n_sig2n == 1;
                 eigh_pair_device(c, nullptr, 0, nullptr, nullptr, nullptr, Kt, nt, e.et, e.Qt, sym_t, e.status + 1, s2, need_merged, 1, 0,
                                  -1, 2, /*stage=*/1);
-                GP_HIP(hipEventRecord(c->ev_q, s2));
+                if (tri) GP_HIP(hipEventRecord(c->ev_t1, s2));
                 eigh_pair_device(c, nullptr, 0, nullptr, nullptr, nullptr, Kt, nt, e.et, e.Qt, sym_t, e.status + 1, s2, need_merged, 1, 0,
                                  -1, 2, /*stage=*/2);
-                c->q_gen = c->eig_gen[1];
-                e.tri = e.wait_q = want_tri && !need_merged && hp->n_sig2n == 1;
+                if (tri) {
+                    GP_HIP(hipStreamWaitEvent(c->stream4, c->ev_t1, 0));
+                    eigh_pair_device(c, nullptr, 0, nullptr, nullptr, nullptr, Kt, nt, e.et, e.Qt, sym_t, e.status + 1, c->stream4,
+                                     need_merged, 1, 0, -1, 2, /*stage=*/3);
+                    GP_HIP(hipEventRecord(c->ev_q, c->stream4));
+                    c->q_queued = true;
+                    c->q_gen = c->eig_gen[1];
+                } else {
+                    c->q_gen = -1;
+                }
+                e.tri = e.wait_q = tri;
             } else {
                 eigh_pair_device(c, nullptr, 0, nullptr, nullptr, nullptr, Kt, nt, e.et, e.Qt, sym_t, e.status + 1, s2, need_merged, 1, 0,
                                  -1, tfill ? 2 : 0);
@@ -776,7 +804,7 @@ extern "C" int gpcsd_ctx_create(int device, gpcsd_ctx **out) {
         c = new gpcsd_ctx();
         c->device = device;
         c->timeline_on = getenv("GPCSD_TIMELINE") && getenv("GPCSD_TIMELINE")[0] == '1';
-        c->ll_tridiag_on = getenv("GPCSD_LL_TRIDIAG") && getenv("GPCSD_LL_TRIDIAG")[0] == '1';
+        if (const char *ev = getenv("GPCSD_LL_TRIDIAG")) c->ll_tridiag_mode = ev[0] == '0' ? 0 : ev[0] == '1' ? 1 : 2;
         GP_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
         // The two chains are the critical path and made of small launches; when they run beside another call's GEMM tail
         // (thousands of workgroups) each of those launches would otherwise queue behind the tiles: high priority.
@@ -791,6 +819,7 @@ extern "C" int gpcsd_ctx_create(int device, gpcsd_ctx **out) {
         GP_HIP(hipEventCreateWithFlags(&c->ev_aux, hipEventDisableTiming));
         GP_HIP(hipEventCreateWithFlags(&c->ev_pc, hipEventDisableTiming));
         GP_HIP(hipEventCreateWithFlags(&c->ev_q, hipEventDisableTiming));
+        GP_HIP(hipEventCreateWithFlags(&c->ev_t1, hipEventDisableTiming));
         GP_HIP(hipEventCreateWithFlags(&c->ev_tri_done, hipEventDisableTiming));
         GP_HIP(hipHostMalloc(reinterpret_cast<void **>(&c->h_result), 66 * sizeof(double), hipHostMallocDefault));
         GP_HIP(hipHostMalloc(reinterpret_cast<void **>(&c->h_ll), gpcsd_ctx::LL_SLOTS * 66 * sizeof(double), hipHostMallocDefault));
@@ -827,6 +856,7 @@ extern "C" int gpcsd_ctx_destroy(gpcsd_ctx *c) {
     if (c->ev_aux) (void)hipEventDestroy(c->ev_aux);
     if (c->ev_pc) (void)hipEventDestroy(c->ev_pc);
     if (c->ev_q) (void)hipEventDestroy(c->ev_q);
+    if (c->ev_t1) (void)hipEventDestroy(c->ev_t1);
     if (c->ev_tri_done) (void)hipEventDestroy(c->ev_tri_done);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     if (c->stream2) (void)hipStreamDestroy(c->stream2);

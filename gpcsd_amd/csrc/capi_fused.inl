@@ -532,59 +532,75 @@ static void front_half_pair(gpcsd_ctx *c, const gpcsd_hparams *const hp[2], cons
     // Gram matrices.  Temporal (stream2): replica b = Kt(hp[b]).  Spatial (stream3): replica b = Ks(hp[b]) + jitter[b] I; with
     // equal spatial hyper-parameters -- the usual pair -- the two differ by the diagonal shift only, so the matrix is
     // assembled once and copied (the same GEMM output plus the same diagonal add: the same bits).
-    c->tl("T chain start (s2)", s2);
     const bool tfill = temporal_fill_applies(c, sym_t, nt, false);       // (the paired call is refused for host temporal Grams)
-    if (c->tri_reader_queued) {           // a queued log-likelihood tail still reads the previous chain's Q / tridiagonal
-        GP_HIP(hipStreamWaitEvent(s2, c->ev_tri_done, 0));
-        c->tri_reader_queued = false;
-    }
-    if (tfill) temporal_fill(c, hp, nT, t, nt, *sym_t, status + 1, 2, s2);
-    else for (int b = 0; b < nT; ++b) build_kt(c, hp[b], t, nt, t, nt, Kt + b * ntt, s2);
-    // the temporal chain is the critical path of the call: it is queued before the host spends its time on the launches of the
-    // spatial Gram assembly (status words [1], [3]; one replica when the problem is shared -- decomposition cache on, equal
-    // temporal hyper-parameters).  (All four problems in ONE chain was measured slower, 1.38 against 1.18 ms per cfg3 step: with
-    // two chains the log-likelihood's spatial projection runs under the end of the temporal one.)
     const bool staged = tfill && ll_tridiag_enabled(c) && eigh_stageable(sym_t, nt);
-    {
-        ProfScope ps(c, "eigh_temporal", 9.0 * (double)nt * nt * nt * nT, s2);
-        if (staged) {                // the log-likelihood's tail starts behind stage 1 (see EigState::tri)
-            eigh_pair_device(c, nullptr, 0, nullptr, nullptr, nullptr, Kt, nt, et, Qt, sym_t, status + 1, s2, false, nT, 2, -1, 2, 1);
-            GP_HIP(hipEventRecord(c->ev_q, s2));
-            eigh_pair_device(c, nullptr, 0, nullptr, nullptr, nullptr, Kt, nt, et, Qt, sym_t, status + 1, s2, false, nT, 2, -1, 2, 2);
-            c->q_gen = -1;           // (replicas: not what a separate call's cache looks for)
-        } else {
-            eigh_pair_device(c, nullptr, 0, nullptr, nullptr, nullptr, Kt, nt, et, Qt, sym_t, status + 1, s2, false, nT, 2, -1,
-                             tfill ? 2 : 0);
+    // part 1: the inputs and (staged) stage 1, or the whole chain; part 2 (staged only): stage 2, and stage 3 beside it
+    auto run_T = [&](int part) {
+        if (part == 1) {
+            c->tl("T chain start (s2)", s2);
+            staged_chain_guard(c, s2);
+            if (tfill) temporal_fill(c, hp, nT, t, nt, *sym_t, status + 1, 2, s2);
+            else for (int b = 0; b < nT; ++b) build_kt(c, hp[b], t, nt, t, nt, Kt + b * ntt, s2);
         }
-    }
-    GP_HIP(hipEventRecord(c->ev_join, s2));
-    c->tl("T chain end (s2)", s2);
-    c->tl("S chain start (s3)", s3);
-    const bool same_ks = hp[0]->R == hp[1]->R && hp[0]->ell_s[0] == hp[1]->ell_s[0] &&
-                         (g.dim == 1 || (hp[0]->eps == hp[1]->eps && hp[0]->ell_s[1] == hp[1]->ell_s[1]));
-    const bool sfill = spatial_fill_applies(c, sym_s, nx);
-    if (sfill) {
-        // the fill folds Ks and adds each replica's jitter to the folded diagonals: one assembly, no copy, no diagonal pass
-        if (same_ks) build_kphi(c, g, hp[0]->R, hp[0]->eps, hp[0]->ell_s, nullptr, 0, 0.0, Ks, s3, "ks_");
-        else for (int b = 0; b < 2; ++b) build_kphi(c, g, hp[b]->R, hp[b]->eps, hp[b]->ell_s, nullptr, 0, 0.0, Ks + b * nxx, s3, "ks_");
-        spatial_fill(c, Ks, nx, same_ks ? 0 : nxx, 2, jitter, *sym_s, status, 2, s3);
-    } else if (same_ks) {
-        const int lo = jitter[0] == 0.0 ? 0 : 1, hi = 1 - lo;           // assemble the one without a shift (if any) first
-        build_kphi(c, g, hp[lo]->R, hp[lo]->eps, hp[lo]->ell_s, nullptr, 0, 0.0, Ks + lo * nxx, s3, "ks_");
-        GP_HIP(hipMemcpyAsync(Ks + hi * nxx, Ks + lo * nxx, (size_t)nxx * sizeof(double), hipMemcpyDeviceToDevice, s3));
-        if (jitter[lo] != 0.0) k_add_diag(c, Ks + lo * nxx, nx, jitter[lo], s3);
-        if (jitter[hi] != 0.0) k_add_diag(c, Ks + hi * nxx, nx, jitter[hi], s3);
-    } else {
-        for (int b = 0; b < 2; ++b) build_kphi(c, g, hp[b]->R, hp[b]->eps, hp[b]->ell_s, nullptr, 0, jitter[b], Ks + b * nxx, s3, "ks_");
-    }
-    // two replicas of the spatial problem on stream3 (status words [0], [2])
-    {
-        ProfScope ps(c, "eigh_spatial", 9.0 * (double)nx * nx * nx * 2, s3);
-        eigh_pair_device(c, Ks, nx, es, Qs, sym_s, nullptr, 0, nullptr, nullptr, nullptr, status, s3, false, 2, 2, -1,
-                         sfill ? 1 : 0);
-    }
-    GP_HIP(hipEventRecord(c->ev_sjoin, s3));
-    c->tl("S chain end (s3)", s3);
+        // the temporal chain is the critical path of the call: it is queued before the host spends its time on the launches of the
+        // spatial Gram assembly (status words [1], [3]; one replica when the problem is shared -- decomposition cache on, equal
+        // temporal hyper-parameters).  (All four problems in ONE chain was measured slower, 1.38 against 1.18 ms per cfg3 step: with
+        // two chains the log-likelihood's spatial projection runs under the end of the temporal one.)
+        {
+            ProfScope ps(c, part == 2 ? "eigh_temporal_stage2" : "eigh_temporal", part == 2 ? 0.0 : 9.0 * (double)nt * nt * nt * nT, s2);
+            if (staged && part == 1) {   // the log-likelihood's tail starts behind stages 1 + 3 (see front_half, EigState::tri)
+                eigh_pair_device(c, nullptr, 0, nullptr, nullptr, nullptr, Kt, nt, et, Qt, sym_t, status + 1, s2, false, nT, 2, -1, 2, 1);
+                GP_HIP(hipEventRecord(c->ev_t1, s2));
+                return;
+            }
+            if (staged) {
+                eigh_pair_device(c, nullptr, 0, nullptr, nullptr, nullptr, Kt, nt, et, Qt, sym_t, status + 1, s2, false, nT, 2, -1, 2, 2);
+                GP_HIP(hipStreamWaitEvent(c->stream4, c->ev_t1, 0));
+                eigh_pair_device(c, nullptr, 0, nullptr, nullptr, nullptr, Kt, nt, et, Qt, sym_t, status + 1, c->stream4, false, nT, 2, -1, 2, 3);
+                GP_HIP(hipEventRecord(c->ev_q, c->stream4));
+                c->q_queued = true;
+                c->q_gen = -1;           // (replicas: not what a separate call's cache looks for)
+            } else {
+                eigh_pair_device(c, nullptr, 0, nullptr, nullptr, nullptr, Kt, nt, et, Qt, sym_t, status + 1, s2, false, nT, 2, -1,
+                                 tfill ? 2 : 0);
+            }
+        }
+        GP_HIP(hipEventRecord(c->ev_join, s2));
+        c->tl("T chain end (s2)", s2);
+    };
+    auto run_S = [&]() {
+        c->tl("S chain start (s3)", s3);
+        const bool same_ks = hp[0]->R == hp[1]->R && hp[0]->ell_s[0] == hp[1]->ell_s[0] &&
+                             (g.dim == 1 || (hp[0]->eps == hp[1]->eps && hp[0]->ell_s[1] == hp[1]->ell_s[1]));
+        const bool sfill = spatial_fill_applies(c, sym_s, nx);
+        if (sfill) {
+            // the fill folds Ks and adds each replica's jitter to the folded diagonals: one assembly, no copy, no diagonal pass
+            if (same_ks) build_kphi(c, g, hp[0]->R, hp[0]->eps, hp[0]->ell_s, nullptr, 0, 0.0, Ks, s3, "ks_");
+            else for (int b = 0; b < 2; ++b) build_kphi(c, g, hp[b]->R, hp[b]->eps, hp[b]->ell_s, nullptr, 0, 0.0, Ks + b * nxx, s3, "ks_");
+            spatial_fill(c, Ks, nx, same_ks ? 0 : nxx, 2, jitter, *sym_s, status, 2, s3);
+        } else if (same_ks) {
+            const int lo = jitter[0] == 0.0 ? 0 : 1, hi = 1 - lo;           // assemble the one without a shift (if any) first
+            build_kphi(c, g, hp[lo]->R, hp[lo]->eps, hp[lo]->ell_s, nullptr, 0, 0.0, Ks + lo * nxx, s3, "ks_");
+            GP_HIP(hipMemcpyAsync(Ks + hi * nxx, Ks + lo * nxx, (size_t)nxx * sizeof(double), hipMemcpyDeviceToDevice, s3));
+            if (jitter[lo] != 0.0) k_add_diag(c, Ks + lo * nxx, nx, jitter[lo], s3);
+            if (jitter[hi] != 0.0) k_add_diag(c, Ks + hi * nxx, nx, jitter[hi], s3);
+        } else {
+            for (int b = 0; b < 2; ++b) build_kphi(c, g, hp[b]->R, hp[b]->eps, hp[b]->ell_s, nullptr, 0, jitter[b], Ks + b * nxx, s3, "ks_");
+        }
+        // two replicas of the spatial problem on stream3 (status words [0], [2])
+        {
+            ProfScope ps(c, "eigh_spatial", 9.0 * (double)nx * nx * nx * 2, s3);
+            eigh_pair_device(c, Ks, nx, es, Qs, sym_s, nullptr, 0, nullptr, nullptr, nullptr, status, s3, false, 2, 2, -1,
+                             sfill ? 1 : 0);
+        }
+        GP_HIP(hipEventRecord(c->ev_sjoin, s3));
+        c->tl("S chain end (s3)", s3);
+    };
+    // The temporal chain's long first kernels go first; staged, the host queues the spatial chain (~0.1 ms of launches) before
+    // it comes back for the temporal chain's second stage -- stage 1 runs half a millisecond, the queue is never empty
+    run_T(1);
+    run_S();
+    if (staged) run_T(2);
     c->decomp_gen[0] = c->decomp_gen[1] = -1;          // replicas are not what the separate calls' cache looks for
     const double *d_sig[2] = {c->upload_cached<double>("sig2n", hp[0]->sig2n, 1), c->upload_cached<double>("sig2n_pair", hp[1]->sig2n, 1)};
     for (int b = 0; b < 2; ++b) {

@@ -534,11 +534,13 @@ extern "C" int gpcsd_decomposition_cache(gpcsd_ctx *c, int on, long *hits) {
 
 extern "C" int gpcsd_ll_tridiag(gpcsd_ctx *c, int on, long *calls) {
     GP_API_BEGIN(c)
-    if (on >= 0 && c->ll_tridiag_on != (on != 0)) {
+    GP_REQUIRE(on <= 2, -3, "ll_tridiag: mode must be 0 (off), 1 (on), 2 (by size) or negative (query)");
+    if (on >= 0 && c->ll_tridiag_mode != on) {
         if (int rc = drain_async(c)) return rc;            // the two forms order their streams differently: start from an idle context
         GP_HIP(hipStreamSynchronize(c->stream2));
         GP_HIP(hipStreamSynchronize(c->stream3));
-        c->ll_tridiag_on = on != 0;
+        GP_HIP(hipStreamSynchronize(c->stream4));
+        c->ll_tridiag_mode = on;
         c->decomp_gen[0] = c->decomp_gen[1] = -1;          // (the forms compute the temporal eigenvectors differently: no reuse across)
         c->q_gen = -1;
     }

@@ -102,6 +102,8 @@ struct gpcsd_ctx {
     // generation of the temporal solver slot whose Q / tridiagonal are in the buffers (decomposition cache hits reuse them).
     hipEvent_t ev_q = nullptr;
     long q_gen = -1;
+    hipEvent_t ev_t1 = nullptr;             // stage 1 done (stream2): stage 3 (Q, on stream4) starts behind it
+    bool q_queued = false;                  // a stage 3 has been queued since the last temporal chain started (staged_chain_guard)
     // ... and the last reader of those single-buffered stage-1 outputs (Q, the tridiagonal, its scale) on the main stream: the next
     // temporal chain must not overwrite them before it (a caller may queue several steps deep)
     hipEvent_t ev_tri_done = nullptr;
@@ -145,7 +147,7 @@ struct gpcsd_ctx {
     bool status_zeroed = false;             // the fused calls' status words were cleared at the end of the previous call
     bool gram_fp32 = false;                 // gpcsd_set_gram_precision(): Gram builders evaluate in float (cfg5 variant)
     bool fold_gemm_on = true;               // gpcsd_fold_gemm()
-    bool ll_tridiag_on = false;             // gpcsd_ll_tridiag(): log-likelihood in the basis U (x) Q (experimental, see capi.hip)
+    int ll_tridiag_mode = 2;                // gpcsd_ll_tridiag(): log-likelihood in the basis U (x) Q -- 0 off, 1 on, 2 by size (capi.hip)
     long ll_tridiag_calls = 0;
     long fold_gemm_calls = 0;
     // Decomposition cache (capi.hip::front_half): predict() right after loglik() / fit() with the same hyper-parameters

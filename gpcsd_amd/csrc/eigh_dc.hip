@@ -581,8 +581,8 @@ void eigh_large_batch(gpcsd_ctx *c, EigProb *probs, int nclass, int *d_status, i
         nmax = std::max(nmax, probs[i].n);
         replicated = replicated || probs[i].count > 1;
     }
-    const PrepBatch pb = prep_batch_launch(c, probs, nclass, s, d_status, status_stride, /*launch=*/stage != 2);
-    if (stage != 2) {
+    const PrepBatch pb = prep_batch_launch(c, probs, nclass, s, d_status, status_stride, /*launch=*/stage < 2);
+    if (stage < 2) {
         ProfScope ps(c, "eigh_sytrd", 0.0, s);
         sytrd_batch_launch(c, sytrd_batch_of(pb), nclass, nmax, s);
     }
@@ -602,10 +602,16 @@ void eigh_large_batch(gpcsd_ctx *c, EigProb *probs, int nclass, int *d_status, i
             wb.p[i].blk = p.sp.blk; wb.p[i].sZ = p.sZ; wb.p[i].sw = p.sw;
         }
     if (stage == 1) {
-        // T factors of the reflector panels, then Q = the panels applied to the identity (the same apply launch, its slab of Z
-        // starting as columns of I): everything a caller of the tridiagonal form needs, without the divide & conquer
-        ProfScope ps(c, "eigh_stage1_Q", 0.0, s);
+        // T factors of the reflector panels as a launch of their own (stage 3 needs them beside stage 2's leaf launch, which
+        // carries them in an unstaged solve)
+        ProfScope ps(c, "eigh_stage1_T", 0.0, s);
         wy_prep_device(c, wb, nclass, s);
+        GP_HIP(hipGetLastError());
+        return;
+    }
+    if (stage == 3) {
+        // Q = the panels applied to the identity (the back-transformation's apply launch, its slab of Z starting as columns of I)
+        ProfScope ps(c, "eigh_stage3_Q", 0.0, s);
         WyBatch wq = wb;
         for (int i = 0; i < nclass; ++i) {
             wq.p[i].Z = eigh_Q_view(c, probs[i].tag.c_str(), probs[i].n, probs[i].count);
@@ -618,9 +624,6 @@ void eigh_large_batch(gpcsd_ctx *c, EigProb *probs, int nclass, int *d_status, i
         return;
     }
     bool prep_done = false;
-    // stage 2 has Q itself (stage 1): the eigenvectors are ONE small product Q Z per class instead of the panel-by-panel apply
-    // launch (46 us of dependent chain at n = 250 against ~12), with the tridiagonal eigenvectors Z in a scratch block
-    double *Zs[MAX_BATCH] = {nullptr, nullptr, nullptr, nullptr};
     {
         ProfScope ps(c, "eigh_stedc", 0.0, s);
         StedcProb sp[MAX_BATCH];
@@ -629,42 +632,13 @@ void eigh_large_batch(gpcsd_ctx *c, EigProb *probs, int nclass, int *d_status, i
             sp[i].w = probs[i].w; sp[i].Z = probs[i].Z; sp[i].tag = probs[i].tag;
             sp[i].count = std::max(probs[i].count, 1);
             sp[i].s_in = probs[i].sp.blk; sp[i].sw = probs[i].sw; sp[i].sZ = probs[i].sZ;
-            if (stage == 2) {
-                Zs[i] = c->buf<double>("eig_" + probs[i].tag + "_Zs", (size_t)probs[i].n * probs[i].n * sp[i].count);
-                sp[i].Z = Zs[i];
-                sp[i].sZ = (long)probs[i].n * probs[i].n;
-            }
         }
         // the T factors of the back-transformation need the reflectors only: they ride in the leaf launch of the D&C stage
         prep_done = wy_fused;
         // (stage 2: the T factors were formed by stage 1, the leaf launch carries leaves only)
         stedc_batch_device(c, sp, nclass, d_status, status_stride, s, (prep_done && stage != 2) ? &wb : nullptr);
     }
-    if (stage == 2) {
-        ProfScope ps(c, "eigh_backtransform", 0.0, s);
-        for (int i = 0; i < nclass; ++i) {
-            EigProb &p = probs[i];
-            const long nn = (long)p.n * p.n;
-            GemmDesc g;                        // V = Q Z
-            g.M = p.n; g.N = p.n; g.K = p.n;
-            g.A = eigh_Q_view(c, p.tag.c_str(), p.n, p.count); g.lda = p.n;
-            g.B = Zs[i]; g.ldb = p.n;
-            g.C = p.Z; g.ldc = p.n;
-            g.batch2 = std::max(p.count, 1); g.sA2 = nn; g.sB2 = nn; g.sC2 = p.sZ;
-            g.prof_name = "gemm_eigh_QZ";
-            // two classes of one order (the symmetric / antisymmetric halves of an even grid) share the launch
-            if (i + 1 < nclass && probs[i + 1].n == p.n && probs[i + 1].count == p.count && probs[i + 1].sZ == p.sZ) {
-                EigProb &q = probs[i + 1];
-                g.batch = 2;
-                g.sA = eigh_Q_view(c, q.tag.c_str(), q.n, q.count) - g.A;
-                g.sB = Zs[i + 1] - Zs[i];
-                g.sC = q.Z - p.Z;
-                ++i;
-            }
-            gemm_f64(c, g, s);
-        }
-        hipLaunchKernelGGL(scale_w_batch_kernel, dim3(ceil_div(nmax, 256), pb.start[MAX_BATCH]), dim3(256), 0, s, wb);
-    } else if (wy_fused) {
+    if (wy_fused) {
         ProfScope ps(c, "eigh_backtransform", 0.0, s);
         wy_batch_device(c, wb, nclass, s, prep_done);
     } else {                                   // n too large for the LDS-resident apply kernel: GEMM chain per panel

@@ -278,14 +278,16 @@ int gpcsd_combine_loglik(int ntrials_total, double sumlog, double quad_sum_over_
  * results are bit-identical either way.  on = 1 / 0 switches it (default on), -1 only queries; *hits counts reused sides. */
 int gpcsd_decomposition_cache(gpcsd_ctx *ctx, int on, long *hits);
 int gpcsd_fold_gemm(gpcsd_ctx *ctx, int on, long *calls);
-/* EXPERIMENTAL (off by default; GPCSD_LL_TRIDIAG=1 in the environment switches it on for new contexts): the log-likelihood of
- * the folded path in the basis U (x) Q instead of U (x) V.  With Kt = m Q T Q^T from the tridiagonalisation alone (Q orthogonal,
- * T tridiagonal) and the spatial side fully decomposed, Ks (x) Kt + sig2 I is a set of SHIFTED TRIDIAGONAL matrices
- * es[x'] m T + sig2 I: sum log D is the sum of the logs of their LDL^T pivots and the quadratic form one forward recurrence per
- * (x', trial) row of U^T Y Q -- exact algebra (gpcsd1d.py:113-128), no temporal eigenvectors, so the log-likelihood does not wait
- * for the temporal divide & conquer.  The temporal chain then runs in two stages and forms its eigenvectors as Q Z.  Same
- * results to rounding (1e-15 relative on the log-likelihood at 384 x 500).  on = 1 / 0, < 0 only queries; *calls counts the
- * log-likelihoods evaluated this way.  See DESIGN.md 9 for why it is not the default. */
+/* The log-likelihood of the folded path in the basis U (x) Q instead of U (x) V.  With Kt = m Q T Q^T from the
+ * tridiagonalisation alone (Q orthogonal, T tridiagonal) and the spatial side fully decomposed, Ks (x) Kt + sig2 I is a set of
+ * SHIFTED TRIDIAGONAL matrices es[x'] m T + sig2 I: sum log D is the sum of the logs of their LDL^T pivots and the quadratic
+ * form one forward recurrence per (x', trial) row of U^T Y Q -- exact algebra (gpcsd1d.py:113-128), no temporal eigenvectors, so
+ * the log-likelihood does not wait for the temporal divide & conquer (which a prediction still needs and the chain still runs).
+ * Same results to rounding (1e-15 relative on the log-likelihood at 384 x 500).  mode: 0 = off (the eigenvector form always),
+ * 1 = on wherever it applies (mirror-symmetric time grid with halves beyond the Jacobi size, scalar noise, folded path),
+ * 2 = on while nx * nt * ntrials <= 2^24 (the default: above that the step is bound by its GEMMs and the form costs 3 %),
+ * < 0 only queries; GPCSD_LL_TRIDIAG=0|1|2 sets the mode of new contexts.  *calls counts the log-likelihoods evaluated this
+ * way.  DESIGN.md 9. */
 int gpcsd_ll_tridiag(gpcsd_ctx *ctx, int on, long *calls);
 
 /* ---- several devices from ONE process ------------------------------------------------------- */

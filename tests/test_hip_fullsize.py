@@ -757,7 +757,7 @@ def test_queued_call_forms_mixed_at_random_soak(name, form):
     """tools/soak_paired.py: 80 steps at the bench geometry with hyper-parameters changing every step, the call forms
     (fenced / two queued calls / paired / paired with two steps in flight) mixed at random, decomposition cache off and on:
     every log-likelihood and the final predictions are the bits of the same calls fenced one by one.  "tri": the same with the
-    experimental shifted-tridiagonal log-likelihood switched on (gpcsd_ll_tridiag; staged temporal chain)."""
+    shifted-tridiagonal log-likelihood forced on (gpcsd_ll_tridiag mode 1; staged temporal chain), "": forced off."""
     import subprocess
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "soak_paired.py"), name, "80"] + ([form] if form else []),
                        capture_output=True, text=True, timeout=600)
@@ -766,7 +766,7 @@ def test_queued_call_forms_mixed_at_random_soak(name, form):
 
 @pytest.mark.parametrize("name", ["cfg3s_2d_384x500x2", "cfg2s_1d_24x500x8", "2d_npx_96x120x3"])
 def test_shifted_tridiagonal_loglik_matches_eigenvector_form_and_oracle(name):
-    """gpcsd_ll_tridiag (experimental): with the spatial side decomposed and the temporal side only tridiagonalised, the
+    """gpcsd_ll_tridiag: with the spatial side decomposed and the temporal side only tridiagonalised, the
     log-likelihood is a sum over shifted tridiagonal systems (LDL^T pivots + one forward recurrence per (x', trial) row).  Same
     value as the eigenvector form to rounding and as the oracle to the gate; predictions after it (eigenvectors formed as Q Z in
     the second stage of the temporal chain) agree with the default chain's to 1e-9; switching back restores the default bits.
@@ -776,10 +776,11 @@ def test_shifted_tridiagonal_loglik_matches_eigenvector_form_and_oracle(name):
         lfp = C.synth_lfp(77, c["x"].shape[0], c["t"].shape[0], 3)
     m = _model_from_case(c, g, lfp)
     ctx = m._sync_device()
+    ctx.ll_tridiag(0)                                             # the eigenvector form (the default chooses by size)
     ll0 = m.loglik()
     m.predict(c["x"], c["t"], type="both")
     csd0, lfp0 = m.csd_pred.copy(), m.lfp_pred.copy()
-    n0 = ctx.ll_tridiag(True)
+    n0 = ctx.ll_tridiag(1)
     try:
         ll1 = m.loglik()
         took = ctx.ll_tridiag() - n0
@@ -792,10 +793,12 @@ def test_shifted_tridiagonal_loglik_matches_eigenvector_form_and_oracle(name):
         assert abs(f - ll0) <= 1e-12 * abs(ll0) and np.all(np.isfinite(gr))
         assert m.loglik() == ll1
     finally:
-        ctx.ll_tridiag(False)
+        ctx.ll_tridiag(0)
     assert m.loglik() == ll0
     m.predict(c["x"], c["t"], type="both")
     assert np.array_equal(m.csd_pred, csd0)
+    n1 = ctx.ll_tridiag(2)                                        # by size: these cases are far below the threshold
+    assert abs(m.loglik() - ll0) <= 1e-12 * abs(ll0) and ctx.ll_tridiag() - n1 == (1 if c["t"].shape[0] // 2 > 64 else 0)
 
 
 def test_predict_returns_pinned_arrays_that_are_not_overwritten():

@@ -1,8 +1,8 @@
 """Soak of the queued call forms: N steps with hyper-parameters that change every step, the paired / queued / two-deep forms
 against the same calls fenced one by one -- every log-likelihood and the final predictions bit for bit.  Mixes the forms at
 random, so generations, chain streams and the result ring see every hand-over.   python tools/soak_paired.py [cfg3|cfg2] [N] [tri]
-("tri": with the experimental shifted-tridiagonal log-likelihood, gpcsd_ll_tridiag; its fenced values are also held to 1e-12
-of the eigenvector form's)."""
+("tri": with the shifted-tridiagonal log-likelihood forced on, gpcsd_ll_tridiag mode 1 -- its fenced values are also held to
+1e-12 of the eigenvector form's; without it the eigenvector form is forced)."""
 import os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -40,9 +40,10 @@ def hps(k):
 
 
 ctx.decomposition_cache(False)
+ctx.ll_tridiag(0)
 if TRI:
     eig_ll = [ctx.loglik_parts(hps(k)[0][0]) for k in range(N)]
-    ctx.ll_tridiag(True)
+    ctx.ll_tridiag(1)
 ref_ll, ref_pred = [], None
 for k in range(N):
     h1, h0 = hps(k)
