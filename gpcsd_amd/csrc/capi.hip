@@ -557,10 +557,11 @@ EigState front_half(gpcsd_ctx *c, const gpcsd_hparams *hp, double jitter, bool n
                 eigh_pair_device(c, nullptr, 0, nullptr, nullptr, nullptr, Kt, nt, e.et, e.Qt, sym_t, e.status + 1, s2, need_merged, 1, 0,
                                  -1, 2, /*stage=*/2);
                 if (tri) {
-                    GP_HIP(hipStreamWaitEvent(c->stream4, c->ev_t1, 0));
-                    eigh_pair_device(c, nullptr, 0, nullptr, nullptr, nullptr, Kt, nt, e.et, e.Qt, sym_t, e.status + 1, c->stream4,
+                    hipStream_t sq = c->stream4;
+                    GP_HIP(hipStreamWaitEvent(sq, c->ev_t1, 0));
+                    eigh_pair_device(c, nullptr, 0, nullptr, nullptr, nullptr, Kt, nt, e.et, e.Qt, sym_t, e.status + 1, sq,
                                      need_merged, 1, 0, -1, 2, /*stage=*/3);
-                    GP_HIP(hipEventRecord(c->ev_q, c->stream4));
+                    GP_HIP(hipEventRecord(c->ev_q, sq));
                     c->q_queued = true;
                     c->q_gen = c->eig_gen[1];
                 } else {
