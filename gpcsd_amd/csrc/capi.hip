@@ -547,16 +547,16 @@ EigState front_half(gpcsd_ctx *c, const gpcsd_hparams *hp, double jitter, bool n
         {
             ProfScope ps(c, "eigh_temporal", 9.0 * (double)nt * nt * nt, s2);
             if (staged) {
-                // stage 1 (tridiagonalisation, T factors), then on this stream stage 2 (divide & conquer, back-transformation)
-                // and BESIDE it, on stream4, stage 3 (Q) when a log-likelihood wants the tridiagonal form: its tail starts
-                // behind stage 3 and never waits for stage 2
+                // stage 1 (tridiagonalisation), then on this stream stage 2 (divide & conquer) and BESIDE it, on stream4, stage 3
+                // (T factors, Q), then stage 4 (back-transformation) behind both.  A log-likelihood in the tridiagonal form
+                // starts its tail behind stage 3 and never waits for stages 2 and 4.
                 const bool tri = want_tri && !need_merged && hp->n_sig2n == 1;
                 eigh_pair_device(c, nullptr, 0, nullptr, nullptr, nullptr, Kt, nt, e.et, e.Qt, sym_t, e.status + 1, s2, need_merged, 1, 0,
                                  -1, 2, /*stage=*/1);
-                if (tri) GP_HIP(hipEventRecord(c->ev_t1, s2));
+                GP_HIP(hipEventRecord(c->ev_t1, s2));
                 eigh_pair_device(c, nullptr, 0, nullptr, nullptr, nullptr, Kt, nt, e.et, e.Qt, sym_t, e.status + 1, s2, need_merged, 1, 0,
                                  -1, 2, /*stage=*/2);
-                if (tri) {
+                {
                     hipStream_t sq = c->stream4;
                     GP_HIP(hipStreamWaitEvent(sq, c->ev_t1, 0));
                     eigh_pair_device(c, nullptr, 0, nullptr, nullptr, nullptr, Kt, nt, e.et, e.Qt, sym_t, e.status + 1, sq,
@@ -564,9 +564,10 @@ EigState front_half(gpcsd_ctx *c, const gpcsd_hparams *hp, double jitter, bool n
                     GP_HIP(hipEventRecord(c->ev_q, sq));
                     c->q_queued = true;
                     c->q_gen = c->eig_gen[1];
-                } else {
-                    c->q_gen = -1;
                 }
+                GP_HIP(hipStreamWaitEvent(s2, c->ev_q, 0));
+                eigh_pair_device(c, nullptr, 0, nullptr, nullptr, nullptr, Kt, nt, e.et, e.Qt, sym_t, e.status + 1, s2, need_merged, 1, 0,
+                                 -1, 2, /*stage=*/4);
                 e.tri = e.wait_q = tri;
             } else {
                 eigh_pair_device(c, nullptr, 0, nullptr, nullptr, nullptr, Kt, nt, e.et, e.Qt, sym_t, e.status + 1, s2, need_merged, 1, 0,

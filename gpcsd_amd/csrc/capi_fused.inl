@@ -555,14 +555,19 @@ static void front_half_pair(gpcsd_ctx *c, const gpcsd_hparams *const hp[2], cons
                 return;
             }
             if (staged) {
+                // stage 2 (divide & conquer) on the chain's stream; beside it, on stream4, stage 3 (T factors, Q); stage 4
+                // (back-transformation) behind both.  (Stage 3 on the main stream, in front of X: 1.14 against 1.10 ms -- the
+                // main stream is rarely idle when stage 1 ends.)
                 eigh_pair_device(c, nullptr, 0, nullptr, nullptr, nullptr, Kt, nt, et, Qt, sym_t, status + 1, s2, false, nT, 2, -1, 2, 2);
-                hipStream_t sq = c->stream4;     // (on the main stream, in front of X: 1.14 against 1.10 ms -- it is rarely idle then)
+                hipStream_t sq = c->stream4;
                 GP_HIP(hipStreamWaitEvent(sq, c->ev_t1, 0));
                 eigh_pair_device(c, nullptr, 0, nullptr, nullptr, nullptr, Kt, nt, et, Qt, sym_t, status + 1, sq, false, nT, 2, -1, 2, 3);
                 GP_HIP(hipEventRecord(c->ev_q, sq));
                 c->tl("Q end", sq);
                 c->q_queued = true;
                 c->q_gen = -1;           // (replicas: not what a separate call's cache looks for)
+                GP_HIP(hipStreamWaitEvent(s2, c->ev_q, 0));
+                eigh_pair_device(c, nullptr, 0, nullptr, nullptr, nullptr, Kt, nt, et, Qt, sym_t, status + 1, s2, false, nT, 2, -1, 2, 4);
             } else {
                 eigh_pair_device(c, nullptr, 0, nullptr, nullptr, nullptr, Kt, nt, et, Qt, sym_t, status + 1, s2, false, nT, 2, -1,
                                  tfill ? 2 : 0);

@@ -382,7 +382,7 @@ static void eigh_pair_enqueue(gpcsd_ctx *c, double *A0, int n0, double *w0, doub
     if (nlarge) eigh_large_multi(c, large, nlarge, d_status, status_stride, s, stage);
     // need_merged == false: the caller stays in the folded basis (eigh_fold_view) and never reads w / Z of a folded problem
     for (int p = 0; p < 2; ++p)
-        if (fold[p].on && need_merged && (stage == 0 || stage == 2))
+        if (fold[p].on && need_merged && (stage == 0 || stage == 4))
             hipLaunchKernelGGL(sym_unfold_kernel, dim3(n[p], cnt[p]), dim3(256), 0, s, n[p], *sym[p], (const double *)fold[p].ws,
                                (const double *)fold[p].Us, (const double *)fold[p].wa, (const double *)fold[p].Ua, w[p], Z[p]);
     GP_HIP(hipGetLastError());
@@ -396,7 +396,7 @@ void eigh_pair_device(gpcsd_ctx *c, double *A0, int n0, double *w0, double *Z0, 
                       int status_stride, int count1, int prefolded_mask, int stage) {
     if (count < 1) count = 1;
     if (count1 < 1) count1 = count;
-    if (stage < 2) {                           // (stages 2 and 3 continue the solve stage 1 started)
+    if (stage < 2) {                           // (stages 2, 3 and 4 continue the solve stage 1 started)
         if (n0 > 0) ++c->eig_gen[0];           // whatever a previous call left in this slot's outputs is about to be replaced
         if (n1 > 0) ++c->eig_gen[1];
     }

@@ -601,17 +601,13 @@ void eigh_large_batch(gpcsd_ctx *c, EigProb *probs, int nclass, int *d_status, i
             wb.p[i].w_scale = pb.w[i]; wb.p[i].amax = pb.amax[i];   // the final rescale of the eigenvalues rides in the apply launch
             wb.p[i].blk = p.sp.blk; wb.p[i].sZ = p.sZ; wb.p[i].sw = p.sw;
         }
-    if (stage == 1) {
-        // T factors of the reflector panels as a launch of their own (stage 3 needs them beside stage 2's leaf launch, which
-        // carries them in an unstaged solve)
-        ProfScope ps(c, "eigh_stage1_T", 0.0, s);
-        wy_prep_device(c, wb, nclass, s);
-        GP_HIP(hipGetLastError());
-        return;
-    }
+    if (stage == 1) return;                    // the tridiagonalisation alone
     if (stage == 3) {
-        // Q = the panels applied to the identity (the back-transformation's apply launch, its slab of Z starting as columns of I)
-        ProfScope ps(c, "eigh_stage3_Q", 0.0, s);
+        // T factors of the reflector panels as a launch of their own (unstaged they ride in the divide & conquer's leaf launch),
+        // then Q = the panels applied to the identity (the back-transformation's apply launch, its slab of Z starting as
+        // columns of I).  Off the chain's own stream: stage 2 needs neither, stage 4 the T factors.
+        ProfScope ps(c, "eigh_stage3_TQ", 0.0, s);
+        wy_prep_device(c, wb, nclass, s);
         WyBatch wq = wb;
         for (int i = 0; i < nclass; ++i) {
             wq.p[i].Z = eigh_Q_view(c, probs[i].tag.c_str(), probs[i].n, probs[i].count);
@@ -624,7 +620,7 @@ void eigh_large_batch(gpcsd_ctx *c, EigProb *probs, int nclass, int *d_status, i
         return;
     }
     bool prep_done = false;
-    {
+    if (stage != 4) {
         ProfScope ps(c, "eigh_stedc", 0.0, s);
         StedcProb sp[MAX_BATCH];
         for (int i = 0; i < nclass; ++i) {
@@ -638,6 +634,8 @@ void eigh_large_batch(gpcsd_ctx *c, EigProb *probs, int nclass, int *d_status, i
         // (stage 2: the T factors were formed by stage 1, the leaf launch carries leaves only)
         stedc_batch_device(c, sp, nclass, d_status, status_stride, s, (prep_done && stage != 2) ? &wb : nullptr);
     }
+    if (stage == 2) return;                    // the divide & conquer alone: stage 4 finishes behind stage 3's T factors
+    if (stage == 4) prep_done = true;
     if (wy_fused) {
         ProfScope ps(c, "eigh_backtransform", 0.0, s);
         wy_batch_device(c, wb, nclass, s, prep_done);

@@ -203,11 +203,14 @@ __device__ __forceinline__ void class_of(const int *start, int g, int &cls, int 
 // prefolded_mask bit p: the folded halves of problem p are already in their class arenas, scaled (see EigArenaView); A_p is
 // then not read (symmetry folding must apply to that problem: eigh_fold_view(...).on)
 // stage: 0 = the whole solve.  Staged (capi_fused.inl: the log-likelihood's shifted tridiagonal systems need the temporal side
-// only as far as A / amax = Q T Q^T): 1 = tridiagonalisation + the T factors of its reflector panels; 2 = the rest of that solve
-// (divide & conquer, back-transformation), same arguments, same stream; 3 = the orthogonal factor Q itself (eigh_Q_view; T in
-// EigArenaView::d / e), same arguments, on ANY stream behind stage 1 -- it only reads what stage 1 wrote and stage 2 leaves
-// alone (reflectors, T factors), so it runs beside stage 2.  Staged solves need folded (prefolded or not),
-// tridiagonalisation-path problems within the fused back-transformation's size (eigh_stageable).
+// only as far as A / amax = Q T Q^T), same arguments every time:
+//   1 = the tridiagonalisation (chain stream);
+//   3 = the T factors of its reflector panels and the orthogonal factor Q itself (eigh_Q_view; T in EigArenaView::d / e) -- on
+//       ANY stream behind stage 1: it reads the reflectors, which stages 2 and 4 leave alone;
+//   2 = the divide & conquer of the tridiagonal matrix (chain stream, behind stage 1);
+//   4 = the back-transformation (chain stream, behind stage 2 AND stage 3: it needs the T factors).
+// Staged solves need folded (prefolded or not), tridiagonalisation-path problems within the fused back-transformation's size
+// (eigh_stageable).
 void eigh_pair_device(gpcsd_ctx *c, double *A0, int n0, double *w0, double *Z0, const SymDev *sym0, double *A1, int n1,
                       double *w1, double *Z1, const SymDev *sym1, int *d_status, hipStream_t s, bool need_merged = true,
                       int count = 1, int status_stride = 0, int count1 = -1,   // count1 > 0: replicas of problem 1 (else = count)
