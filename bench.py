@@ -544,6 +544,17 @@ def run_step_bench(args, w, rank, world, local_rank, backend, compact=False):
         run_deep(n_deep)
         ctx.synchronize()
         deep_ms = 1e3 * (time.perf_counter() - td0) / n_deep
+        # ... and the same with the eigenvector form of the log-likelihood forced (gpcsd_ll_tridiag mode 0): the tridiagonal form
+        # (the default at this size) makes the next temporal chain wait for the previous log-likelihood's tail, which is what a
+        # two-deep loop would overlap -- DESIGN 4.9
+        ctx.ll_tridiag(0)
+        run_deep(10)
+        ctx.synchronize()
+        td1 = time.perf_counter()
+        run_deep(n_deep)
+        ctx.synchronize()
+        deep_ms_eig = 1e3 * (time.perf_counter() - td1) / n_deep
+        ctx.ll_tridiag(int(os.environ.get("GPCSD_LL_TRIDIAG", "2")[:1] or 2))      # back to the mode this context was created with
 
     # ---- same step with the decomposition cache on (a user's loglik -> predict sequence; never part of `value`) ----
     ctx.decomposition_cache(True)
@@ -717,9 +728,13 @@ def run_step_bench(args, w, rank, world, local_rank, backend, compact=False):
                          "note": "each call alone, device fenced after every call (rank-local, no collective)"},
         "two_steps_in_flight": None if deep_ms is None else {
             "ms_per_step": deep_ms, "trials_per_sec_per_gpu": R_local / (deep_ms * 1e-3),
+            "ms_per_step_eigenvector_form": deep_ms_eig,
             "note": "host loop two steps deep (step k+1 queued before step k's log-likelihood is collected; up to four "
                     "evaluations may be outstanding per context): the chains of consecutive steps run back to back.  NOT "
-                    "part of value, whose steps each hand their result back before the next step is queued"},
+                    "part of value, whose steps each hand their result back before the next step is queued.  With the "
+                    "log-likelihood's tridiagonal form (the default at this size, built for the one-deep loop) the next "
+                    "temporal chain waits for the previous log-likelihood's tail; ms_per_step_eigenvector_form is the same "
+                    "loop with gpcsd_ll_tridiag mode 0"},
         "with_decomposition_cache": {"ms_per_step": cached_ms, "trials_per_sec_per_gpu": R_local / (cached_ms * 1e-3),
                                      "note": "library default for users (predict after loglik reuses the unchanged temporal "
                                              "eigendecomposition, bit-identical); NOT part of value"},
