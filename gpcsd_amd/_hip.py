@@ -53,7 +53,7 @@ LIB_PATH = os.environ.get("GPCSD_LIB_PATH") or os.path.join(_HERE, "libgpcsd_hip
 MAX_TEMPORAL = 8
 KIND_SE, KIND_MATERN, KIND_HOST = 0, 1, 2
 ERR_CAPACITY = -7
-MAX_EIG_N = 2048                 # GPCSD_MAX_EIG_N: rows of one eigenproblem (after symmetry folding)
+MAX_EIG_N = 4096                 # GPCSD_MAX_EIG_N: rows of one eigenproblem (after symmetry folding)
 MAX_GEMM_LD_KMAJOR = 1 << 23     # GPCSD_MAX_GEMM_LD_KMAJOR: ntrials * nt of one resident block of trials
 PRED_CSD, PRED_LFP, PRED_BOTH = 1, 2, 3
 

@@ -5,7 +5,7 @@
 namespace gpcsd {
 
 #ifndef GPCSD_EIG_MAXN_BUILD                          // (A/B builds only: -DGPCSD_EIG_MAXN_BUILD=1024 through GPCSD_CXXFLAGS)
-#define GPCSD_EIG_MAXN_BUILD 2048
+#define GPCSD_EIG_MAXN_BUILD 4096
 #endif
 constexpr int EIG_MAXN = GPCSD_EIG_MAXN_BUILD;       // LDS vectors of the eigensolver are sized for this (= GPCSD_MAX_EIG_N)
 constexpr int MAX_BATCH = 4;                         // independent eigenproblems sharing launches

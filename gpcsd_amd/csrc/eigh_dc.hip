@@ -106,7 +106,7 @@ __device__ __forceinline__ SytrdProb sy_resolve(const SytrdBatch &b, int g) {
 #include "sytrd_regtail.hpp"
 namespace gpcsd {
 
-// JQ = ceil(trailing columns / 64) this launch may need (2, 4, 8, 16 or 32).  Every global load of the step -- the slab
+// JQ = ceil(trailing columns / 64) this launch may need (2, 4, 8, 16, 32 or 64).  Every global load of the step -- the slab
 // rows, the pivot row, the previous reflector and its y -- is issued before the first barrier, so a step costs one
 // L2/Infinity-Cache round trip plus LDS reductions instead of a chain of dependent loads.
 template <int JQ>
@@ -273,8 +273,10 @@ static void sytrd_batch_launch(gpcsd_ctx *c, const SytrdBatch &b, int nclass, in
         else if (m <= 256) hipLaunchKernelGGL(sytrd_step_kernel<4>, grid, dim3(256), 0, s, b, k);
         else if (m <= 512) hipLaunchKernelGGL(sytrd_step_kernel<8>, grid, dim3(256), 0, s, b, k);
         else if (m <= 1024) hipLaunchKernelGGL(sytrd_step_kernel<16>, grid, dim3(256), 0, s, b, k);
-        else hipLaunchKernelGGL(sytrd_step_kernel<32>, grid, dim3(256), 0, s, b, k);
+        else if (m <= 2048) hipLaunchKernelGGL(sytrd_step_kernel<32>, grid, dim3(256), 0, s, b, k);
+        else hipLaunchKernelGGL(sytrd_step_kernel<64>, grid, dim3(256), 0, s, b, k);
     }
+    static_assert(EIG_MAXN <= 64 * 64, "the widest step kernel covers 64 column chunks of 64");
     if (any_tail) {
         size_t sh = 0;
         for (int i = 0; i < nclass; ++i)

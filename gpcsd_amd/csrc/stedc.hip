@@ -239,19 +239,27 @@ __global__ __launch_bounds__(1024) void dc_leaf_wyprep_kernel(DcLevel L, int *st
 // ------------------------------------------------------------------------------------------------------------------
 // merge phases as device functions (called by the per-phase kernels and by the fused small-level kernel)
 // ------------------------------------------------------------------------------------------------------------------
-struct SetupShared {
-    double sd[EIG_MAXN], sz[EIG_MAXN];   // by local index
-    double ds[EIG_MAXN], zs[EIG_MAXN];   // in merged ascending order
-    double cd[EIG_MAXN], cz[EIG_MAXN];   // survivors of the negligible-weight test, merged order
-    int sperm[EIG_MAXN], cidx[EIG_MAXN];
-    unsigned char sdefl[EIG_MAXN];
+// 37 bytes of LDS per row of the merge (57 until round 3: a merge of 4096 rows now fits the 160 KB of a CU): the survivors of
+// the negligible-weight test are compacted IN PLACE (cd = ds, cz = zs: the compaction only moves entries towards the front,
+// one wave, chunk after chunk, every lane's reads in front of the chunk's writes), and their local indices take the storage of
+// sz, which is dead once the merged order has been formed.
+template <int CAP>
+struct SetupSharedT {
+    double sd[CAP], sz[CAP];             // by local index (sz: until the merge ranks; then cidx())
+    double ds[CAP], zs[CAP];             // in merged ascending order; from the compaction on: the survivors, merged order
+    int sperm[CAP];
+    unsigned char sdefl[CAP];
     double red[16];
     int K, nrot, nsurv, close_pairs;
+    __device__ __forceinline__ int *cidx() { return reinterpret_cast<int *>(sz); }
 };
+using SetupShared = SetupSharedT<EIG_MAXN>;
+// the fused small-level kernel merges at most DC_SMALL rows and reuses sd | sz | ds | zs as its 64 x 64 U tile
+using SetupSharedSmall = SetupSharedT<1024>;
 
 // z, merged order, deflation scan, compacted poles.  Whole workgroup (NW waves).
-template <int NW>
-__device__ void dc_setup_body(const DcWork &w, const Seg sg, const int m, SetupShared &S) {
+template <int NW, class SS>
+__device__ void dc_setup_body(const DcWork &w, const Seg sg, const int m, SS &S) {
     constexpr int NT = 64 * NW;
     const int lo = sg.lo, mid = sg.mid, hi = sg.hi, n = w.n;
     const int N = hi - lo, n1 = mid - lo;
@@ -305,17 +313,20 @@ __device__ void dc_setup_body(const DcWork &w, const Seg sg, const int m, SetupS
     for (int jj = tid; jj < N; jj += NT)
         if (all_defl || rho * fabs(S.zs[jj]) <= tol) S.sdefl[S.sperm[jj]] = 1;
     __syncthreads();
-    if (tid < 64) {                      // wave 0: stable compaction of the survivors by ballot prefix
+    if (tid < 64) {                      // wave 0: stable compaction of the survivors by ballot prefix, in place
+        int *const cidx = S.cidx();
         int base = 0;
         for (int j0 = 0; j0 < N; j0 += 64) {
             const int jj = j0 + tid;
-            const bool keep = (jj < N) && !S.sdefl[S.sperm[jj]];
+            const int sp = (jj < N) ? S.sperm[jj] : 0;
+            const double dv = (jj < N) ? S.ds[jj] : 0.0, zv = (jj < N) ? S.zs[jj] : 0.0;   // the chunk is read ...
+            const bool keep = (jj < N) && !S.sdefl[sp];
             const unsigned long long mask = __ballot(keep);
-            if (keep) {
-                const int pos = base + __popcll(mask & ((1ull << tid) - 1ull));
-                S.cidx[pos] = S.sperm[jj];
-                S.cd[pos] = S.ds[jj];
-                S.cz[pos] = S.zs[jj];
+            if (keep) {                                                                  // ... before any of it is overwritten
+                const int pos = base + __popcll(mask & ((1ull << tid) - 1ull));          // pos <= jj
+                cidx[pos] = sp;
+                S.ds[pos] = dv;
+                S.zs[pos] = zv;
             }
             base += __popcll(mask);
         }
@@ -332,16 +343,16 @@ __device__ void dc_setup_body(const DcWork &w, const Seg sg, const int m, SetupS
         __syncthreads();
         bool hit = false;
         for (int p = 1 + tid; p < ns; p += NT) {
-            const double t = S.cd[p] - S.cd[p - 1], zp = S.cz[p - 1], zn = S.cz[p];
+            const double t = S.ds[p] - S.ds[p - 1], zp = S.zs[p - 1], zn = S.zs[p];
             hit |= fabs(t) * fabs(zp * zn) <= tol * (zp * zp + zn * zn) * (1.0 + 1e-10);
         }
         if (hit) S.close_pairs = 1;                 // benign race: every writer stores 1
         __syncthreads();
         if (!S.close_pairs) {
             for (int p = tid; p < ns; p += NT) {
-                w.ndidx[lo + p] = S.cidx[p];
-                w.dk[lo + p] = S.cd[p];
-                w.zk[lo + p] = S.cz[p];
+                w.ndidx[lo + p] = S.cidx()[p];
+                w.dk[lo + p] = S.ds[p];
+                w.zk[lo + p] = S.zs[p];
             }
             if (tid == 0) {
                 S.K = ns;
@@ -358,17 +369,18 @@ __device__ void dc_setup_body(const DcWork &w, const Seg sg, const int m, SetupS
         const int ns = S.nsurv;
         int K = 0, nrot = 0;
         if (ns > 0) {
-            int pj = S.cidx[0];
-            double dpj = S.cd[0], zpj = S.cz[0];
-            int nidx = ns > 1 ? S.cidx[1] : 0;
-            double nd = ns > 1 ? S.cd[1] : 0.0, nz = ns > 1 ? S.cz[1] : 0.0;
+            const int *const cidx = S.cidx();
+            int pj = cidx[0];
+            double dpj = S.ds[0], zpj = S.zs[0];
+            int nidx = ns > 1 ? cidx[1] : 0;
+            double nd = ns > 1 ? S.ds[1] : 0.0, nz = ns > 1 ? S.zs[1] : 0.0;
             for (int p = 1; p < ns; ++p) {
                 const int idx = nidx;
                 double dn = nd, zn = nz;
                 if (p + 1 < ns) {
-                    nidx = S.cidx[p + 1];
-                    nd = S.cd[p + 1];
-                    nz = S.cz[p + 1];
+                    nidx = cidx[p + 1];
+                    nd = S.ds[p + 1];
+                    nz = S.zs[p + 1];
                 }
                 const double t = dn - dpj;
                 bool merged = false;
@@ -896,7 +908,7 @@ constexpr int Q2_LD = DC_SMALL + 1;
 
 // Everything after the deflation scan of a small merge, on LDS-resident data: roots (8 lanes each), z-hat (8 lanes per
 // pole), U with normalised columns, W = Q2 U on fp64 MFMA 16x16x4 (operands from LDS), rank sort, placement.
-__device__ void dc_small_tail(const DcWork &w, const Seg sg, SetupShared &S, SmallShared &Q, double *Q2s, const int K,
+__device__ void dc_small_tail(const DcWork &w, const Seg sg, SetupSharedSmall &S, SmallShared &Q, double *Q2s, const int K,
                               const double rho) {
     const int lo = sg.lo, hi = sg.hi, n = w.n, N = hi - lo;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -919,7 +931,7 @@ __device__ void dc_small_tail(const DcWork &w, const Seg sg, SetupShared &S, Sma
         }
     }
     __syncthreads();
-    double *U = S.sd;                                     // sd | sz | ds | zs: 4 * EIG_MAXN doubles >= 64 x 64
+    double *U = S.sd;                                     // sd | sz | ds | zs: 4 * 1024 doubles = 64 x 64
     {                                                     // column o of U, rows s, s+8, ...; zero padded to 64 x 64
         double u[8], ss = 0.0;
         const bool colok = o < K;
@@ -980,7 +992,7 @@ __global__ __launch_bounds__(NT_SMALL) void dc_small_level_kernel(DcLevel L) {
     if (m >= L.nseg[cls]) return;
     const Seg sg = load_seg(w, L.seg_off[cls], m);
     constexpr int NW = NT_SMALL / 64;
-    __shared__ SetupShared S;
+    __shared__ SetupSharedSmall S;
     __shared__ SmallShared Q;
     __shared__ double Q2s[DC_SMALL * Q2_LD];
     const int lo = sg.lo, hi = sg.hi;
@@ -997,7 +1009,8 @@ __global__ __launch_bounds__(NT_SMALL) void dc_small_level_kernel(DcLevel L) {
     __syncthreads();
     dc_small_tail(w, sg, S, Q, Q2s, K, rho);
 }
-static_assert(4 * EIG_MAXN >= DC_SMALL * DC_SMALL, "U tile must fit the reused setup arrays");
+static_assert(4 * 1024 >= DC_SMALL * DC_SMALL && offsetof(SetupSharedSmall, zs) == 3 * 1024 * sizeof(double),
+              "U tile must fit the reused, contiguous setup arrays");
 
 __global__ void copy_vec_kernel(const double *__restrict__ a, double *__restrict__ b, long n) {
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) b[i] = a[i];

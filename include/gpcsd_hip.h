@@ -40,11 +40,11 @@ extern "C" {
  * returns GPCSD_ERR_CAPACITY (-7), which the Python layer raises as gpcsd_amd.GPCSDCapacityError -- a RuntimeError, so
  * that fit()'s LinAlgError / ValueError handlers (gpcsd1d.py:219, gpcsd2d.py:217,258) do not swallow it.
  *   GPCSD_MAX_EIG_N           rows of one symmetric eigenproblem after symmetry folding (a mirror-symmetric grid of up
- *                           to 4096 points): nx and nt of the fused calls, n of gpcsd_eigh / gpcsd_eig_D
+ *                           to 8192 points): nx and nt of the fused calls, n of gpcsd_eigh / gpcsd_eig_D
  *   GPCSD_MAX_GEMM_LD_KMAJOR  doubles in one row of a flat GEMM operand whose rows are the contracted index: ntrials * nt
  *                           of the resident block of trials (8.4 M: 16 777 trials of 500 samples, 25 GB of fp64 at 384
  *                           electrodes; shard trials over ranks beyond that)                                          */
-#define GPCSD_MAX_EIG_N           2048
+#define GPCSD_MAX_EIG_N           4096
 #define GPCSD_MAX_GEMM_LD_KMAJOR  (1L << 23)
 #define GPCSD_ERR_CAPACITY      (-7)
 

@@ -412,10 +412,10 @@ def test_user_defined_temporal_covariance(trend):
 
 
 def test_time_grids_beyond_1024_points_and_capacity_error():
-    """nt = 1400 on a uniform grid: the eigensolver's limit (GPCSD_MAX_EIG_N = 2048 rows) applies to the symmetry-folded halves
+    """nt = 1400 on a uniform grid: the eigensolver's limit (GPCSD_MAX_EIG_N = 4096 rows) applies to the symmetry-folded halves
     (700 rows each).  The same length WITHOUT a reflection symmetry is one 1400-row problem: per-column tridiagonalisation
     launches in front of the register tail, five large divide & conquer levels, the GEMM-chain back-transformation (the fused one
-    holds n <= 1009 rows in LDS) -- round 2 raised GPCSDCapacityError there.  A 2100-point grid without symmetry still exceeds the
+    holds n <= 1009 rows in LDS) -- round 2 raised GPCSDCapacityError there.  A 4200-point grid without symmetry exceeds the
     capacity and raises GPCSDCapacityError, which fit() does not swallow (it is not a ValueError / LinAlgError)."""
     import gpcsd_amd
     from gpcsd_amd.gpcsd1d import GPCSD1D
@@ -452,9 +452,9 @@ def test_time_grids_beyond_1024_points_and_capacity_error():
     ref = O.predict(geom_a, hp0, lfp, x, t_asym, type="csd")["csd"]
     assert relerr(ma.csd_pred, ref) < GATE
     # beyond the capacity
-    t_big = 0.5 * np.arange(2100.0)[:, None]
+    t_big = 0.5 * np.arange(4200.0)[:, None]
     t_big[-1, 0] += 0.123
-    mb = build(t_big, C.synth_lfp(272, 24, 2100, 1))
+    mb = build(t_big, C.synth_lfp(272, 24, 4200, 1))
     with pytest.raises(gpcsd_amd.GPCSDCapacityError):
         mb.loglik()
     with pytest.raises(gpcsd_amd.GPCSDCapacityError):

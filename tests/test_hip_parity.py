@@ -392,10 +392,11 @@ def test_stedc_stage_hard_cases(ctx):
     run(np.full(90, 3.0), np.full(89, -0.5))                         # negative off-diagonals
 
 
-@pytest.mark.parametrize("n", [1100, 1400, 2048])
+@pytest.mark.parametrize("n", [1100, 1400, 2048, 2049, 4096])
 def test_eigh_beyond_1024_rows(ctx, n):
-    """Round 3: one eigenproblem may have up to GPCSD_MAX_EIG_N = 2048 rows (per-column tridiagonalisation launches with 32
-    column chunks per thread, divide & conquer workspaces of 2048 entries in LDS, GEMM-chain back-transformation).  A GP
+    """Round 3: one eigenproblem may have up to GPCSD_MAX_EIG_N = 4096 rows (per-column tridiagonalisation launches with up to
+    64 column chunks per thread, the merge set-up of the divide & conquer at 37 bytes of LDS per row, GEMM-chain
+    back-transformation; the reference takes any n, utility_functions.py:58-59 -- 0.13 s here at 4096 rows).  A GP
     covariance (clustered, rank-deficient spectrum) and a random symmetric matrix against LAPACK: eigenvalues to n eps ||A||,
     orthogonality and residual to 1e-13 n."""
     rs = np.random.RandomState(n)
@@ -410,7 +411,7 @@ def test_eigh_beyond_1024_rows(ctx, n):
         assert np.max(np.abs(Z.T @ Z - np.eye(n))) < 1e-13 * n
         assert np.max(np.abs(A @ Z - Z * w[None, :])) < 1e-13 * n * nrm
     with pytest.raises(RuntimeError):
-        ctx.eigh(np.eye(2049))
+        ctx.eigh(np.eye(4097))
 
 
 @pytest.mark.parametrize("n", [100, 384, 500])
