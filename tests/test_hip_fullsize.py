@@ -451,6 +451,13 @@ def test_time_grids_beyond_1024_points_and_capacity_error():
     hp0["jitter"] = 0.0
     ref = O.predict(geom_a, hp0, lfp, x, t_asym, type="csd")["csd"]
     assert relerr(ma.csd_pred, ref) < GATE
+    # ... and one 2600-row temporal eigenproblem (beyond round 2's and this round's first limit): loglik against the oracle
+    t26 = 0.5 * np.arange(2600.0)[:, None]
+    t26[-1, 0] += 0.123
+    lfp26 = C.synth_lfp(273, 24, 2600, 1)
+    m26 = build(t26, lfp26)
+    ll26 = m26.loglik()
+    assert abs(ll26 - O.loglik(O.Geometry1D(x, t26, a=0.0, b=2300.0, ngl=100), hp, lfp26)) / abs(ll26) < 1e-8
     # beyond the capacity
     t_big = 0.5 * np.arange(4200.0)[:, None]
     t_big[-1, 0] += 0.123
