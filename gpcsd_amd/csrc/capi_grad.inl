@@ -68,7 +68,6 @@ static int loglik_grad_impl(gpcsd_ctx *c, const gpcsd_hparams *hps, int B, doubl
     int *st = c->buf<int>("b_status", (size_t)2 * B);        // [0, B): spatial chains, [B, 2B): temporal chains
     double *A = c->buf<double>("b_ks_A", nxG * B), *Kgl = c->buf<double>("b_ks_Kgl", GG * B), *T = c->buf<double>("b_ks_T", nxG * B);
     double *W = c->buf<double>("b_W", nxRT * B), *Bm = c->buf<double>("b_Bm", nxRT * B);
-    double *Bet = c->buf<double>("b_Bet", nxRT * B), *Bes = c->buf<double>("b_Bes", nxRT * B);
     double *gdev = c->buf<double>("b_grad_out", (size_t)64 * B);
     const double *t = (const double *)c->bufs["time_t"].p;
     const bool host_kt = uses_host_kt(&hps[0]);
@@ -173,7 +172,9 @@ static int loglik_grad_impl(gpcsd_ctx *c, const gpcsd_hparams *hps, int B, doubl
                 const int nq = q ? T_.na : T_.ns, c0 = q ? T_.ns : 0;
                 gq[q].M = nx * R; gq[q].N = nq; gq[q].K = nq;
                 gq[q].A = W + c0; gq[q].lda = nt; gq[q].B = T_.U + (q ? (long)T_.ns * T_.ns : 0); gq[q].ldb = nq;
-                gq[q].C = Bm + c0; gq[q].ldc = nt; gq[q].C2 = Bet + c0; gq[q].C3 = Bes + c0;
+                // (no B~ wt / B~ ws copies: the two products below scale B~ along their contracted index as they load it --
+                // GemmDesc::kscale -- the same rounded products, without 2 x 0.6 GB written and read back per 32-set batch)
+                gq[q].C = Bm + c0; gq[q].ldc = nt; gq[q].C2 = nullptr; gq[q].C3 = nullptr;
                 gq[q].epi = EPI_GRAD; gq[q].D = Dinv + c0; gq[q].rdiv = R; gq[q].ldd = nt;
                 gq[q].colscale = T_.w + c0; gq[q].rowscale = S_.w;
                 gq[q].quad_out = scal + 1 + 3 * q;        // scal[b][1], [2] (first block or both), scal[b][4], [5] (second block)
@@ -205,7 +206,8 @@ static int loglik_grad_impl(gpcsd_ctx *c, const gpcsd_hparams *hps, int B, doubl
             if (np == 0) continue;
             GemmDesc gs;
             gs.M = np; gs.N = np; gs.K = nt;
-            gs.A = Bet + r0 * RT; gs.lda = RT; gs.B = Bm + r0 * RT; gs.ldb = RT; gs.transB = true; gs.C = Cs + o_in; gs.ldc = np;
+            gs.A = Bm + r0 * RT; gs.lda = RT; gs.B = Bm + r0 * RT; gs.ldb = RT; gs.transB = true; gs.C = Cs + o_in; gs.ldc = np;
+            gs.kscale = T_.w; gs.sKscale = 0; gs.sKscale2 = nt;           // (B~ wt) B~^T: the factor runs along the contracted t'
             gs.batch = R; gs.sA = nt; gs.sB = nt; gs.sC = (long)np * np;
             gs.batch2 = B; gs.sA2 = nxRT; gs.sB2 = nxRT; gs.sC2 = sCs;
             // the tile configuration must not depend on B (a set has to run the same tiles alone or in a batch): these
@@ -217,6 +219,8 @@ static int loglik_grad_impl(gpcsd_ctx *c, const gpcsd_hparams *hps, int B, doubl
         }
         // Ghat_t~ parity blocks: 1/2 sum_{(x,r)} (B~ ws)[:, q]^T B~[:, q] - R/2 diag(b[q block])   (row chunks, then a fixed-order sum)
         const long rows = (long)nx * R;
+        double *wsr = c->buf<double>("b_grad_ws_rows", (size_t)rows * B);        // ws spread over the (x', r) rows
+        k_repeat_rows(c, S_.w, nx, nx, R, B, wsr, s);
         const int nfull = (int)(rows / CH), rem = (int)(rows % CH), nchunk = nfull + (rem > 0 ? 1 : 0);
         const long sCt = (long)nchunk * sUt;
         double *Ct = c->buf<double>("b_grad_Ct", (size_t)sCt * B);
@@ -228,7 +232,8 @@ static int loglik_grad_impl(gpcsd_ctx *c, const gpcsd_hparams *hps, int B, doubl
             if (nfull > 0) {
                 GemmDesc gt;
                 gt.M = nq; gt.N = nq; gt.K = CH;
-                gt.A = Bes + c0; gt.lda = nt; gt.transA = true; gt.B = Bm + c0; gt.ldb = nt; gt.C = Ct + o_in; gt.ldc = nq;
+                gt.A = Bm + c0; gt.lda = nt; gt.transA = true; gt.B = Bm + c0; gt.ldb = nt; gt.C = Ct + o_in; gt.ldc = nq;
+                gt.kscale = wsr; gt.sKscale = CH; gt.sKscale2 = rows;         // (B~ ws)^T B~: the factor runs along the contracted row
                 gt.batch = nfull; gt.sA = (long)CH * nt; gt.sB = (long)CH * nt; gt.sC = nqq;
                 gt.batch2 = B; gt.sA2 = nxRT; gt.sB2 = nxRT; gt.sC2 = sCt;
                 if (nq >= 64) gt.cfg = 3;
@@ -239,7 +244,8 @@ static int loglik_grad_impl(gpcsd_ctx *c, const gpcsd_hparams *hps, int B, doubl
                 GemmDesc gt;
                 gt.M = nq; gt.N = nq; gt.K = rem;
                 if (nq >= 64) gt.cfg = 3;
-                gt.A = Bes + (long)nfull * CH * nt + c0; gt.lda = nt; gt.transA = true; gt.B = Bm + (long)nfull * CH * nt + c0; gt.ldb = nt;
+                gt.A = Bm + (long)nfull * CH * nt + c0; gt.lda = nt; gt.transA = true; gt.B = Bm + (long)nfull * CH * nt + c0; gt.ldb = nt;
+                gt.kscale = wsr + (long)nfull * CH; gt.sKscale2 = rows;
                 gt.C = Ct + o_in + (long)nfull * nqq; gt.ldc = nq;
                 gt.batch2 = B; gt.sA2 = nxRT; gt.sB2 = nxRT; gt.sC2 = sCt;
                 gt.prof_name = "gemm_grad_Gt";
@@ -284,7 +290,7 @@ static int loglik_grad_impl(gpcsd_ctx *c, const gpcsd_hparams *hps, int B, doubl
         else k_build_D(c, es, nx, et, nt, d_siglist, nsig, D, Dinv, scal, s);
         GemmDesc g2;                          // alpha = W Qt;  B = alpha / D, B*et, B*es;  sum alpha*B, sum B^2
         g2.M = nx * R; g2.N = nt; g2.K = nt;
-        g2.A = W; g2.lda = nt; g2.B = Qt; g2.ldb = nt; g2.C = Bm; g2.ldc = nt; g2.C2 = Bet; g2.C3 = Bes;
+        g2.A = W; g2.lda = nt; g2.B = Qt; g2.ldb = nt; g2.C = Bm; g2.ldc = nt; g2.C2 = nullptr; g2.C3 = nullptr;   // (see the folded path)
         g2.epi = EPI_GRAD; g2.D = Dinv; g2.rdiv = R; g2.ldd = nt; g2.colscale = et; g2.rowscale = es;
         g2.quad_out = scal + 1;               // scal[b][1] = quad, scal[b][2] = sum B^2
         g2.batch2 = B; g2.sA2 = nxRT; g2.sB2 = ntt; g2.sC2 = nxRT; g2.sD2 = nD; g2.sColscale2 = nt; g2.sRowscale2 = nx; g2.sQuad2 = NS;
@@ -297,7 +303,8 @@ static int loglik_grad_impl(gpcsd_ctx *c, const gpcsd_hparams *hps, int B, doubl
         double *Cs = c->buf<double>("b_grad_Cs", (size_t)sCs * B);
         GemmDesc gs;
         gs.M = nx; gs.N = nx; gs.K = nt;
-        gs.A = Bet; gs.lda = RT; gs.B = Bm; gs.ldb = RT; gs.transB = true; gs.C = Cs; gs.ldc = nx;
+        gs.A = Bm; gs.lda = RT; gs.B = Bm; gs.ldb = RT; gs.transB = true; gs.C = Cs; gs.ldc = nx;
+        gs.kscale = et; gs.sKscale = 0; gs.sKscale2 = nt;
         gs.batch = R; gs.sA = nt; gs.sB = nt; gs.sC = nxx;
         gs.batch2 = B; gs.sA2 = nxRT; gs.sB2 = nxRT; gs.sC2 = sCs;
         gs.prof_name = "gemm_grad_Gs";
@@ -308,6 +315,7 @@ static int loglik_grad_impl(gpcsd_ctx *c, const gpcsd_hparams *hps, int B, doubl
             // noise tied to the eigen-index: eigenvector-rotation term, S = sum_r B_r B_r^T (see grad.hip)
             GemmDesc g3 = gs;
             g3.A = Bm;
+            g3.kscale = nullptr;
             g3.prof_name = "gemm_grad_BBt";
             gemm_f64(c, g3, s);
             double *Ssum = c->buf<double>("grad_Ssum", (size_t)nxx);
@@ -318,13 +326,16 @@ static int loglik_grad_impl(gpcsd_ctx *c, const gpcsd_hparams *hps, int B, doubl
         }
         // Ghat_t = 1/2 sum_{(x,r)} (B es)^T B - R/2 diag(b)    (row chunks of 512, batched; remainder separately)
         const long rows = (long)nx * R;
+        double *wsr = c->buf<double>("b_grad_ws_rows", (size_t)rows * B);        // es spread over the (x, r) rows
+        k_repeat_rows(c, es, nx, nx, R, B, wsr, s);
         const int nfull = (int)(rows / CH), rem = (int)(rows % CH);
         const long sCt = (long)(nfull + 1) * ntt;
         double *Ct = c->buf<double>("b_grad_Ct", (size_t)sCt * B);
         if (nfull > 0) {
             GemmDesc gt;
             gt.M = nt; gt.N = nt; gt.K = CH;
-            gt.A = Bes; gt.lda = nt; gt.transA = true; gt.B = Bm; gt.ldb = nt; gt.C = Ct; gt.ldc = nt;
+            gt.A = Bm; gt.lda = nt; gt.transA = true; gt.B = Bm; gt.ldb = nt; gt.C = Ct; gt.ldc = nt;
+            gt.kscale = wsr; gt.sKscale = CH; gt.sKscale2 = rows;
             gt.batch = nfull; gt.sA = (long)CH * nt; gt.sB = (long)CH * nt; gt.sC = ntt;
             gt.batch2 = B; gt.sA2 = nxRT; gt.sB2 = nxRT; gt.sC2 = sCt;
             gt.prof_name = "gemm_grad_Gt";
@@ -333,7 +344,8 @@ static int loglik_grad_impl(gpcsd_ctx *c, const gpcsd_hparams *hps, int B, doubl
         if (rem > 0) {
             GemmDesc gt;
             gt.M = nt; gt.N = nt; gt.K = rem;
-            gt.A = Bes + (long)nfull * CH * nt; gt.lda = nt; gt.transA = true; gt.B = Bm + (long)nfull * CH * nt; gt.ldb = nt;
+            gt.A = Bm + (long)nfull * CH * nt; gt.lda = nt; gt.transA = true; gt.B = Bm + (long)nfull * CH * nt; gt.ldb = nt;
+            gt.kscale = wsr + (long)nfull * CH; gt.sKscale2 = rows;
             gt.C = Ct + (long)nfull * ntt; gt.ldc = nt;
             gt.batch2 = B; gt.sA2 = nxRT; gt.sB2 = nxRT; gt.sC2 = sCt;
             gt.prof_name = "gemm_grad_Gt";

@@ -55,6 +55,8 @@ struct GemmK {
     int m_fastest;      // logical tile order: 1 = tile_m varies fastest (few row tiles, many column tiles)
     int n_group;        // otherwise: n-tiles per sweep over the row panels
     const int *dyn;     // optional device scalar: effective N and K (= *dyn) of this launch (D&C merge GEMMs)
+    const double *kscale;   // optional: A's element at contracted index k is multiplied by kscale[k] on its way to LDS
+    long sKscale, sKscale2;
     // outer batch level (GemmDesc::batch2): grid z = z2 * batch1 + z1
     int batch1;
     long sA2, sB2, sC2, sD2, sColscale2, sRowscale2, sDyn2;
@@ -230,9 +232,30 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f64_kernel(GemmK g) {
     using Buf0 = std::integral_constant<int, 0>;
     using Buf1 = std::integral_constant<int, 1>;
 
+    // optional scaling of A along K (GemmDesc::kscale): the factors of a thread's slots travel with the tile's loads and are
+    // applied right before the LDS store, i.e. behind the MFMA block like the store itself (wave-uniform branch; launches
+    // without kscale execute none of it)
+    const double *__restrict__ ksc = g.kscale ? g.kscale + z1 * g.sKscale + z2 * g.sKscale2 : nullptr;
+    double rk[TileA::PER_THREAD];
+    auto load_ks = [&](int t) {
+        if (ksc) {
+#pragma unroll
+            for (int i = 0; i < TileA::PER_THREAD; ++i) {
+                const int kk = t * BK + ka0 + TileA::DK * i;
+                rk[i] = ksc[kk < g.K ? kk : g.K - 1];
+            }
+        }
+    };
+    auto apply_ks = [&]() {
+        if (ksc) {
+#pragma unroll
+            for (int i = 0; i < TileA::PER_THREAD; ++i) ra[i] *= rk[i];
+        }
+    };
     auto load_full = [&](int t) {
         TileA::gload(ra, TileA::rsrc(baseA, g.lda, t), 0, offA);
         TileB::gload(rb, TileB::rsrc(baseB, g.ldb, t), 0, offB);
+        load_ks(t);
     };
     auto load_any = [&](int t) {
         if (t < nfull) {
@@ -240,10 +263,12 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f64_kernel(GemmK g) {
         } else {
             TileA::gload_tail(ra, TileA::rsrc(baseA, g.lda, t), 0, g.lda, m0, g.M, g.K - t * BK, tid);
             TileB::gload_tail(rb, TileB::rsrc(baseB, g.ldb, t), 0, g.ldb, n0, g.N, g.K - t * BK, tid);
+            load_ks(t);
         }
     };
     auto store_full = [&](auto bufc) {
         constexpr int buf = decltype(bufc)::value;
+        apply_ks();
         TileA::template sstore<false>(ra, swA + buf * TileA::LDS_ELEMS, 0, 0);
         TileB::template sstore<false>(rb, swB + buf * TileB::LDS_ELEMS, 0, 0);
     };
@@ -252,6 +277,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f64_kernel(GemmK g) {
         if (t < nfull) {
             store_full(bufc);
         } else {
+            apply_ks();
             TileA::template sstore<true>(ra, swA + buf * TileA::LDS_ELEMS, ka0, g.K - t * BK);
             TileB::template sstore<true>(rb, swB + buf * TileB::LDS_ELEMS, kb0, g.K - t * BK);
         }
@@ -341,8 +367,8 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f64_kernel(GemmK g) {
     const long offC = z1 * g.sC + z2 * g.sC2;
     double *__restrict__ C = (EPI == EPI_QUAD) ? nullptr : g.C + offC;
     const double *__restrict__ Dz = g.D + z1 * g.sD + z2 * g.sD2;
-    double *__restrict__ C2 = (EPI == EPI_GRAD) ? g.C2 + offC : nullptr;
-    double *__restrict__ C3 = (EPI == EPI_GRAD) ? g.C3 + offC : nullptr;
+    double *__restrict__ C2 = (EPI == EPI_GRAD && g.C2) ? g.C2 + offC : nullptr;      // (optional: callers that scale at the
+    double *__restrict__ C3 = (EPI == EPI_GRAD && g.C3) ? g.C3 + offC : nullptr;      //  consumer's load -- kscale -- skip the copies)
     const double *__restrict__ colscale = g.colscale ? g.colscale + z1 * g.sColscale + z2 * g.sColscale2 : nullptr;
     const double *__restrict__ rowscale = (EPI == EPI_GRAD) ? g.rowscale + z2 * g.sRowscale2 : nullptr;
     if (EPI == EPI_STORE) {
@@ -397,8 +423,8 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f64_kernel(GemmK g) {
                     // b = alpha / D; also b * et[col], b * es[row / rdiv]; partial sums of alpha*b and b*b
                     const double bq = v * Dz[drow + col];
                     C[(long)row * g.ldc + col] = bq;
-                    C2[(long)row * g.ldc + col] = bq * colscale[col];
-                    C3[(long)row * g.ldc + col] = bq * rsc;
+                    if (C2) C2[(long)row * g.ldc + col] = bq * colscale[col];        // wave-uniform
+                    if (C3) C3[(long)row * g.ldc + col] = bq * rsc;
                     qsum += v * bq;
                     qsum2 += bq * bq;
                 } else {
@@ -780,6 +806,7 @@ void gemm_f64(gpcsd_ctx *c, const GemmDesc &g, hipStream_t s) {
     k.alpha = g.alpha; k.D = g.D; k.rdiv = g.rdiv > 0 ? g.rdiv : 1; k.ldd = g.ldd; k.sD = g.sD;
     k.partials = nullptr;
     k.dyn = g.dyn;
+    k.kscale = g.kscale; k.sKscale = g.sKscale; k.sKscale2 = g.sKscale2;
     const int batch2 = g.batch2 > 1 ? g.batch2 : 1;
     k.batch1 = batch2 > 1 ? g.batch : 0;
     k.sA2 = g.sA2; k.sB2 = g.sB2; k.sC2 = g.sC2; k.sD2 = g.sD2; k.sColscale2 = g.sColscale2; k.sRowscale2 = g.sRowscale2;

@@ -198,6 +198,20 @@ void k_temporal_grad(gpcsd_ctx *c, const gpcsd_hparams *hp, const double *Gt, co
 
 // ---- temporal, user-defined covariances: out[k] = sum_ij Gt_ij dK_k,ij for nm caller-supplied derivative matrices
 // (dK_k = d Kt / d theta_k evaluated by the covariance object's own compute_dKt; nm <= 2 * GPCSD_MAX_TEMPORAL)
+// out[b][i * R + r] = in[b * s_in + i]: a per-row factor spread over the (row, trial) index of the flat layout, so that a GEMM
+// contracting over that index can scale its operand on the way (GemmDesc::kscale) instead of reading a pre-scaled copy
+__global__ __launch_bounds__(256) void repeat_rows_kernel(const double *__restrict__ in, long s_in, long nR, int R,
+                                                           double *__restrict__ out) {
+    const long i = blockIdx.x * 256L + threadIdx.x;
+    if (i < nR) out[blockIdx.y * nR + i] = in[blockIdx.y * s_in + i / R];
+}
+
+void k_repeat_rows(gpcsd_ctx *c, const double *in, long s_in, int n, int R, int B, double *out, hipStream_t s) {
+    const long nR = (long)n * R;
+    hipLaunchKernelGGL(repeat_rows_kernel, dim3((unsigned)((nR + 255) / 256), B), dim3(256), 0, s, in, s_in, nR, R, out);
+    GP_HIP(hipGetLastError());
+}
+
 __global__ __launch_bounds__(256) void frob_inner_kernel(const double *__restrict__ Gt, const double *__restrict__ dK, long n2, int nm,
                                                          double *partials) {
     double v[GR_MAXV];

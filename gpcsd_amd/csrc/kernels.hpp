@@ -28,6 +28,10 @@ struct GemmDesc {
     double *C3 = nullptr;  // EPI_GRAD
     const double *colscale = nullptr, *rowscale = nullptr;   // EPI_GRAD; EPI_STORE: optional C = alpha*acc*colscale[col]
     long sColscale = 0;                                      // batch stride of colscale (EPI_STORE)
+    // optional scaling of operand A along the contracted index: C = (A diag(kscale)) B, applied to A's tile on its way to LDS
+    // (one rounded product per element: the same bits as a pre-scaled copy of A, without writing and re-reading that copy)
+    const double *kscale = nullptr;
+    long sKscale = 0, sKscale2 = 0;                          // batch strides
     int batch = 1;
     long sA = 0, sB = 0, sC = 0;
     // second (outer) batch level: entry z = z2 * batch + z1 adds z2 * s?2 to the operand bases.  Used to run the same
@@ -280,6 +284,8 @@ void k_batch_reduce(gpcsd_ctx *c, const double *in, int nb, long stride, int n, 
 // with a table: B sets (Gt nt*nt apart, outputs s_out apart); hp still supplies n_temporal
 void k_temporal_grad(gpcsd_ctx *c, const gpcsd_hparams *hp, const double *Gt, const double *t, int nt, double *out2C,
                      hipStream_t s, const HpDev *tab = nullptr, int B = 1, long s_out = 0);
+// out[b][i * R + r] = in[b * s_in + i], i < n, r < R, b < B
+void k_repeat_rows(gpcsd_ctx *c, const double *in, long s_in, int n, int R, int B, double *out, hipStream_t s);
 // out[k] = <Gt, dK_k> for nm matrices dK_k (n2 doubles each, contiguous): user-defined temporal covariances
 void k_frob_inner(gpcsd_ctx *c, const double *Gt, const double *dK, long n2, int nm, double *out, hipStream_t s);
 // out[0..1] = <M, dKgl/d ell_1>, <M, dKgl/d ell_2>   (ngl2 == 0: 1D, only out[0] meaningful)
