@@ -147,7 +147,7 @@ struct Tile {
     }
 };
 
-template <int WM, int WN, int FM, int FN, int BK, bool TA, bool TB, int EPI>
+template <int WM, int WN, int FM, int FN, int BK, bool TA, bool TB, int EPI, bool KS = false>
 __global__ __launch_bounds__(64 * WM * WN) void gemm_f64_kernel(GemmK g) {
     constexpr int NT = 64 * WM * WN;
     constexpr int BM = 16 * FM * WM, BN = 16 * FN * WN;
@@ -232,13 +232,13 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f64_kernel(GemmK g) {
     using Buf0 = std::integral_constant<int, 0>;
     using Buf1 = std::integral_constant<int, 1>;
 
-    // optional scaling of A along K (GemmDesc::kscale): the factors of a thread's slots travel with the tile's loads and are
-    // applied right before the LDS store, i.e. behind the MFMA block like the store itself (wave-uniform branch; launches
-    // without kscale execute none of it)
-    const double *__restrict__ ksc = g.kscale ? g.kscale + z1 * g.sKscale + z2 * g.sKscale2 : nullptr;
-    double rk[TileA::PER_THREAD];
+    // optional scaling of A along K (GemmDesc::kscale; instantiations with KS only -- as a run-time branch in every
+    // instantiation it cost the cfg3 step 1.6 %): the factors of a thread's slots travel with the tile's loads and are applied
+    // right before the LDS store, i.e. behind the MFMA block like the store itself
+    const double *__restrict__ ksc = KS ? g.kscale + z1 * g.sKscale + z2 * g.sKscale2 : nullptr;
+    double rk[KS ? TileA::PER_THREAD : 1];
     auto load_ks = [&](int t) {
-        if (ksc) {
+        if constexpr (KS) {
 #pragma unroll
             for (int i = 0; i < TileA::PER_THREAD; ++i) {
                 const int kk = t * BK + ka0 + TileA::DK * i;
@@ -247,7 +247,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f64_kernel(GemmK g) {
         }
     };
     auto apply_ks = [&]() {
-        if (ksc) {
+        if constexpr (KS) {
 #pragma unroll
             for (int i = 0; i < TileA::PER_THREAD; ++i) ra[i] *= rk[i];
         }
@@ -778,6 +778,15 @@ static void launch_epi(const GemmK &k, int epi, dim3 grid, hipStream_t s) {
     }
 }
 
+// operand A scaled along K (GemmDesc::kscale): plain-store epilogue, the two operand layouts the gradient sums use
+template <int WM, int WN, int FM, int FN, int BK>
+static void launch_kscale(const GemmK &k, bool ta, bool tb, int epi, dim3 grid, hipStream_t s) {
+    const dim3 blk(64 * WM * WN);
+    if (epi != EPI_STORE || ta == tb) throw HipError{-3, "gemm_f64: kscale is implemented for the plain-store epilogue with exactly one transposed operand"};
+    if (ta) hipLaunchKernelGGL((gemm_f64_kernel<WM, WN, FM, FN, BK, true, false, EPI_STORE, true>), grid, blk, 0, s, k);
+    else hipLaunchKernelGGL((gemm_f64_kernel<WM, WN, FM, FN, BK, false, true, EPI_STORE, true>), grid, blk, 0, s, k);
+}
+
 template <int WM, int WN, int FM, int FN, int BK>
 static void launch_trans(const GemmK &k, bool ta, bool tb, int epi, dim3 grid, hipStream_t s) {
     if (!ta && !tb) launch_epi<WM, WN, FM, FN, BK, false, false>(k, epi, grid, s);
@@ -828,6 +837,7 @@ void gemm_f64(gpcsd_ctx *c, const GemmDesc &g, hipStream_t s) {
         // 46-48 TF/s against 40-41 with BK 16 at 192x25000x192 / 19200x250x250; equal from K = 500 up
         cfg = (tiles(64, 64) >= 512) ? ((g.K <= 320) ? 2 : 3) : 5;
     }
+    if (g.kscale && (cfg == 1 || cfg == 2)) cfg = 3;           // (the K-scaled variant exists for configurations 3 and 5)
     const int bm = CFG_BM[cfg], bn = CFG_BN[cfg];
     const int tm = ceil_div(g.M, bm), tn = ceil_div(g.N, bn);
     k.tiles_n = tn;
@@ -846,7 +856,13 @@ void gemm_f64(gpcsd_ctx *c, const GemmDesc &g, hipStream_t s) {
     const double flops = 2.0 * g.M * (double)g.N * g.K * g.batch * batch2;
     {
         ProfScope ps(c, g.prof_name, flops, s);
-        switch (cfg) {
+        if (k.kscale) {
+            switch (cfg) {
+                case 3: launch_kscale<2, 2, 2, 2, 16>(k, g.transA, g.transB, g.epi, grid, s); break;
+                case 5: launch_kscale<2, 2, 1, 1, 64>(k, g.transA, g.transB, g.epi, grid, s); break;
+                default: throw HipError{-3, "gemm_f64: kscale is implemented for tile configurations 3 and 5"};
+            }
+        } else switch (cfg) {
             case 1: launch_trans<4, 2, 2, 4, 16>(k, g.transA, g.transB, g.epi, grid, s); break;
             case 2: launch_trans<2, 2, 2, 2, 8>(k, g.transA, g.transB, g.epi, grid, s); break;
             case 3: launch_trans<2, 2, 2, 2, 16>(k, g.transA, g.transB, g.epi, grid, s); break;
