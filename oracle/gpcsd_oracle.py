@@ -317,6 +317,39 @@ def loglik(geom, hp, lfp):
     return loglik_from_K(lfp, Ks, Kt, hp["sig2n"])
 
 
+def loglik_tridiagonal(geom, hp, lfp):
+    """The same log-likelihood WITHOUT the temporal eigenvectors (what gpcsd_amd's staged path evaluates): with
+    Ks = Qs diag(es) Qs^T (comp_eig_D's spatial half, gpcsd1d.py:113-116) and only Kt = Q T Q^T, T tridiagonal (Householder),
+    (Ks (x) Kt + sig2n I) is in the basis Qs (x) Q the block-diagonal set of shifted tridiagonal matrices es[x] T + sig2n I.
+    sum log D = sum of the logs of their LDL^T pivots, the quadratic form (gpcsd1d.py:124-127) one forward substitution per
+    (x, trial) row of Qs^T Y Q.  Scalar noise only (a list ties the noise to the eigen-rank, utility_functions.py:54-63).
+    Checker code: a NumPy/SciPy cross-check of the algebra, independent of the device kernels."""
+    import scipy.linalg as sla
+    lfp = np.atleast_3d(lfp)
+    nx, nt, R = lfp.shape
+    assert np.ndim(hp["sig2n"]) == 0
+    Ks = spatial_kphi(geom, hp) + hp["jitter"] * np.eye(nx)
+    Kt = temporal_sum(hp["temporal"], geom.t)
+    es, Qs = np.linalg.eigh(Ks)
+    T, Q = sla.hessenberg(Kt, calc_q=True)            # symmetric input: T is tridiagonal up to rounding
+    d, e = np.diag(T).copy(), np.diag(T, -1).copy()
+    sig2 = float(hp["sig2n"])
+    W = np.einsum("xa,xtr,tb->arb", Qs, lfp, Q)      # (x', r, t')
+    sumlog, quad = 0.0, 0.0
+    for a in range(nx):
+        lam = es[a]
+        piv = np.empty(nt)
+        y = W[a].copy()                               # (R, nt): forward substitution L z = y in place
+        piv[0] = lam * d[0] + sig2
+        for k in range(1, nt):
+            l = lam * e[k - 1] / piv[k - 1]
+            piv[k] = lam * d[k] + sig2 - l * lam * e[k - 1]
+            y[:, k] -= l * y[:, k - 1]
+        sumlog += np.sum(np.log(piv))
+        quad += np.sum(y * y / piv[None, :])
+    return -0.5 * R * sumlog - 0.5 * quad
+
+
 def predict(geom, hp, lfp, z, tstar, type="csd"):
     """Posterior mean, structured form of gpcsd1d.py:248-293 / gpcsd2d.py:289-334.
 

@@ -107,6 +107,20 @@ def test_model_loglik(name):
         assert relerr(D, g["Dvec"]) < 1e-10
 
 
+@pytest.mark.parametrize("name", [n for n in MODEL_CASES if np.ndim(C.model_cases()[n]["sig2n"]) == 0
+                                  and C.model_cases()[n]["x"].shape[0] * C.model_cases()[n]["t"].shape[0] <= 24 * 500])
+def test_model_loglik_tridiagonal_form(name):
+    """The log-likelihood without the temporal eigenvectors -- Ks decomposed, Kt only tridiagonalised, shifted tridiagonal
+    LDL^T per spatial eigen-row (what the device's staged path evaluates) -- restated in NumPy/SciPy: equal to
+    the eigen form (gpcsd1d.py:113-128) to the rounding both carry and to the reference's golden value."""
+    c, g, geom, hp, lfp = load_model_case(name)
+    hpj = with_jitter(hp, float(g["jitter"]))
+    ll_tri = O.loglik_tridiagonal(geom, hpj, lfp)
+    ll = O.loglik(geom, hpj, lfp)
+    assert abs(ll_tri - ll) <= 2e-9 * abs(ll)          # (both forms carry the conditioning of a numerically singular Ks)
+    assert abs(ll_tri - float(g["loglik"])) / abs(float(g["loglik"])) < 1e-9
+
+
 @pytest.mark.parametrize("name", [n for n in MODEL_CASES if not C.model_cases()[n].get("loglik_only")])
 def test_model_predict(name):
     c, g, geom, hp, lfp = load_model_case(name)
