@@ -378,7 +378,7 @@ struct EigState {
     bool wait_spatial = false;     // the spatial chain was queued on stream3 in this call: join_spatial() before using Qs / es
     const double *d_sig = nullptr;
     int nsig = 0;
-    // the log-likelihood may take the shifted-tridiagonal tail (loglik_tri_*): the temporal chain ran in two stages (or its
+    // the log-likelihood may take the shifted-tridiagonal tail (loglik_tri_*): the temporal chain ran in stages (or its
     // stage-1 outputs are still those of this temporal problem), replica `tri_rep` of the temporal classes is this call's
     bool tri = false, wait_q = false;
     int tri_rep = 0, tri_count = 1;
@@ -386,7 +386,8 @@ struct EigState {
 
 // The log-likelihood in the basis U (x) Q (k_ll_tridiag) instead of U (x) V: it needs the temporal chain only up to the
 // tridiagonalisation + Q, not the divide & conquer and the back-transformation, which only a prediction's tail waits for.  The
-// temporal chain then runs in stages (eigh_pair_device): 1 and 2 on stream2, 3 (Q) beside 2 on stream4.  Measured:
+// temporal chain then runs in stages (eigh_pair_device): 1, 2, 4 on stream2, 3 (T factors, Q) beside 2 on stream4.  Measured
+// (DESIGN 4.9):
 // the paired step 1.134 -> 1.101 ms at cfg3 (50 trials), 0.969 -> 0.929 ms at cfg2; with 400 resident trials the step is bound by
 // its GEMMs and the extra pass over W costs 3 % (5.08 against 4.92 ms).  Hence mode 2 (the default): on while the resident block
 // is small enough for the step to be latency-bound.  gpcsd_ll_tridiag(ctx, 0 | 1 | 2, ..) / GPCSD_LL_TRIDIAG=0 | 1 force it.
@@ -397,7 +398,7 @@ static bool ll_tridiag_enabled(const gpcsd_ctx *c) {
 
 // Before a temporal chain overwrites the single-buffered outputs of a staged predecessor (reflectors, T factors, the
 // tridiagonal and its scale, Q): wait on its stream for the readers beside the chain -- the log-likelihood tail on the main
-// stream (X = Y~ Q, the recurrences) and stage 3 on stream4 (reads reflectors and T factors, writes Q).
+// stream (X = Y~ Q, the recurrences) and stage 3 on stream4 (reads reflectors, writes T factors and Q).
 static void staged_chain_guard(gpcsd_ctx *c, hipStream_t s2) {
     if (c->tri_reader_queued) {
         GP_HIP(hipStreamWaitEvent(s2, c->ev_tri_done, 0));

@@ -97,12 +97,13 @@ struct gpcsd_ctx {
     LlSlot ll_slot[LL_SLOTS];
     int ll_head = 0, ll_count = 0;          // oldest outstanding slot, number outstanding
     hipEvent_t ev_aux = nullptr, ev_pc = nullptr;   // predict: small products of the tail on stream2 beside the large ones
-    // stage 1 of the temporal chain (tridiagonalisation, T factors, the orthogonal factor Q) has finished: recorded on stream2
-    // between the chain's two stages; the log-likelihood's tail needs nothing more of that chain (capi_fused.inl).  q_gen: the
-    // generation of the temporal solver slot whose Q / tridiagonal are in the buffers (decomposition cache hits reuse them).
+    // staged temporal chain (capi.hip front_half): ev_t1 = stage 1 (tridiagonalisation) done, recorded on stream2; ev_q = stage 3
+    // (T factors and the orthogonal factor Q, on stream4 behind ev_t1) done -- the log-likelihood's tail needs nothing more of
+    // that chain, its stage 4 waits for it too.  q_gen: the generation of the temporal solver slot whose Q / tridiagonal are in
+    // the buffers (decomposition cache hits reuse them).
     hipEvent_t ev_q = nullptr;
     long q_gen = -1;
-    hipEvent_t ev_t1 = nullptr;             // stage 1 done (stream2): stage 3 (Q, on stream4) starts behind it
+    hipEvent_t ev_t1 = nullptr;
     bool q_queued = false;                  // a stage 3 has been queued since the last temporal chain started (staged_chain_guard)
     // ... and the last reader of those single-buffered stage-1 outputs (Q, the tridiagonal, its scale) on the main stream: the next
     // temporal chain must not overwrite them before it (a caller may queue several steps deep)

@@ -292,7 +292,7 @@ static bool fold_applies(const SymDev *sy, int n) {
     return sy && sy->ns > 0 && sy->ns + sy->na == n && n > JACOBI_LDS_MAX && symfold_enabled() && !force_jacobi();
 }
 
-// a problem that can be solved in two stages (see eigh_pair_device): folded, both halves on the tridiagonalisation path and
+// a problem that can be solved in stages (see eigh_pair_device): folded, both halves on the tridiagonalisation path and
 // within the fused back-transformation's capacity
 bool eigh_stageable(const SymDev *sy, int n) {
     if (!fold_applies(sy, n)) return false;
