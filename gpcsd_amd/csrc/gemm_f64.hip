@@ -494,7 +494,7 @@ struct PredUnfoldK {
 
 template <int CC>
 __global__ __launch_bounds__(256) void gemm_pred_unfold_kernel(PredUnfoldK<CC> g) {
-    constexpr int NT = 256, BK = 8, BM = 32 * CC, BN = 64;
+    constexpr int NT = 256, BK = 16, BM = 32 * CC, BN = 64;
     using TileA = Tile<BM, true, NT, BK>;     // Pcat: global [K][rows]
     using TileB = Tile<BN, false, NT, BK>;    // S~: global [cols][K]
     __shared__ double lds[2 * (TileA::LDS_ELEMS + TileB::LDS_ELEMS)];
