@@ -86,11 +86,22 @@ static int loglik_grad_impl(gpcsd_ctx *c, const gpcsd_hparams *hps, int B, doubl
     const FoldMode fm = fold_mode(c, &hps[0]);
     const bool fold = fm.on;
     const double *Yf = fold ? folded_lfp(c, fm) : nullptr;
-    if (host_kt) GP_HIP(hipMemcpyAsync(Kt, c->host_kt.data(), (size_t)ntt * sizeof(double), hipMemcpyHostToDevice, s2));
-    else k_temporal_gram(c, C, nullptr, nullptr, nullptr, t, nt, t, nt, Kt, s2, tab, B, ntt);
+    // the temporal chain's input as one launch straight from t and the hyper-parameter table (folded, scaled blocks in the class
+    // arenas: capi.hip temporal_fill) instead of Gram -> fold -> absmax -> scale, as in the fused calls
+    const bool tfill = temporal_fill_applies(c, sym_t, nt, host_kt);
+    staged_chain_guard(c, s2);            // (a queued staged chain's side-stream readers of the class arenas)
+    if (tfill) {
+        const char *const *tg = eigh_fold_tags(1);
+        const EigArenaView as = eigh_arena_view(c, tg[0], sym_t->ns, B), aa = eigh_arena_view(c, tg[1], sym_t->na, B);
+        k_temporal_fold_fill_tab(c, tab, B, t, nt, *sym_t, as, aa, st + B, 1, s2);
+    } else if (host_kt) {
+        GP_HIP(hipMemcpyAsync(Kt, c->host_kt.data(), (size_t)ntt * sizeof(double), hipMemcpyHostToDevice, s2));
+    } else {
+        k_temporal_gram(c, C, nullptr, nullptr, nullptr, t, nt, t, nt, Kt, s2, tab, B, ntt);
+    }
     {
         ProfScope ps(c, "eigh_temporal", 9.0 * (double)nt * nt * nt * B, s2);
-        eigh_pair_device(c, nullptr, 0, nullptr, nullptr, nullptr, Kt, nt, et, Qt, sym_t, st + B, s2, !fold, B, 1);
+        eigh_pair_device(c, nullptr, 0, nullptr, nullptr, nullptr, Kt, nt, et, Qt, sym_t, st + B, s2, !fold, B, 1, -1, tfill ? 2 : 0);
     }
     GP_HIP(hipEventRecord(c->ev_join, s2));
     // Ks_b = A_b Kgl_b A_b^T + jitter_b I                     covariances.py:74-96 / :204-232

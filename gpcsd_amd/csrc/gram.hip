@@ -168,14 +168,32 @@ struct TFoldFillArgs {
     int *status;
     int status_stride;
     int elem_blocks;
+    const HpDev *tab;            // non-null: replica r takes its hyper-parameters from tab[r] (any number of replicas: the batched
+                                 // evaluations of fit) and forms its scale on the device by the same rule
 };
 
-template <typename T>
-__device__ __forceinline__ double tset_eval(const TemporalSet &p, const T ti, const T tj) {
+// power of two >= 2 sum |sigma2_c|: every entry of either folded block is a signed combination of four kernel values with
+// weights summing to at most 2 (host and device form it by the same rule: a set gets the same scale either way)
+__host__ __device__ inline double tfold_scale(const double *sigma2, int ncomp) {
+    double bound = 0.0;
+    for (int cc = 0; cc < ncomp; ++cc) bound += fabs(sigma2[cc]);
+    bound *= 2.0;
+    double m = 1.0;
+    if (bound > 0.0 && bound <= 1.7e308) {
+        int ex = 0;
+        (void)frexp(bound, &ex);                // bound = f * 2^ex, f in [0.5, 1)
+        m = ldexp(1.0, ex);
+        if (!(m <= 1.7e308)) m = bound;         // 2^1024 overflows: fall back to the bound itself
+    }
+    return m;
+}
+
+template <typename T, class P>
+__device__ __forceinline__ double tset_eval(const P &p, const T ti, const T tj) {
     const T d = ti - tj;
     T acc = T(0);                                                      // Kt = zeros; Kt = Kt + K_c (gpcsd1d.py:118-120)
     for (int cc = 0; cc < p.ncomp; ++cc) {
-        const T ell = T(p.ell[cc]), s2 = T(p.sigma2[cc]);
+        const T ell = T(p.ell_of(cc)), s2 = T(p.sigma2_of(cc));
         T v;
         if (p.kind[cc] == GPCSD_KIND_SE)
             v = s2 * exp(T(-0.5) * (d * d) / (ell * ell));             // covariances.py:270
@@ -185,6 +203,9 @@ __device__ __forceinline__ double tset_eval(const TemporalSet &p, const T ti, co
     }
     return (double)acc;
 }
+
+template <typename T, class P>
+__device__ __forceinline__ void fold_fill_entry(const TFoldFillArgs &g, const P &p, const double m, const int rep, const long e);
 
 // blockIdx.y = replica.  Blocks [0, elem_blocks): one entry (a, b) of the symmetric block per thread (and of the
 // antisymmetric block when a, b < na), the four Kt entries of the two orbits evaluated in place and combined exactly as
@@ -203,14 +224,23 @@ __global__ __launch_bounds__(256) void temporal_fold_fill_kernel(TFoldFillArgs g
         for (long i = i0; i < ns + 64; i += stride) ts[i] = 0.0;
         for (long i = i0; i < na + 64; i += stride) ta[i] = 0.0;
         if (blockIdx.x == g.elem_blocks && threadIdx.x == 0) {
-            g.amaxs[rep * g.blks] = g.m[rep];
-            g.amaxa[rep * g.blka] = g.m[rep];
+            const double mr = g.tab ? tfold_scale(g.tab[rep].sigma2_t, g.tab[rep].ncomp) : g.m[rep];
+            g.amaxs[rep * g.blks] = mr;
+            g.amaxa[rep * g.blka] = mr;
         }
         return;
     }
     const long e = blockIdx.x * 256L + threadIdx.x;
     if (e >= (long)ns * ns) return;
-    const TemporalSet &p = g.set[rep];
+    if (g.tab) fold_fill_entry<T>(g, g.tab[rep], tfold_scale(g.tab[rep].sigma2_t, g.tab[rep].ncomp), rep, e);
+    else fold_fill_entry<T>(g, g.set[rep], g.m[rep], rep, e);
+}
+
+// one entry (a, b) of the symmetric block (and of the antisymmetric one) of replica rep, hyper-parameters from p, scale m
+template <typename T, class P>
+__device__ __forceinline__ void fold_fill_entry(const TFoldFillArgs &g, const P &p, const double m, const int rep, const long e) {
+    const SymDev &sy = g.sy;
+    const int ns = sy.ns, na = sy.na;
     const int a = (int)(e / ns), b = (int)(e % ns);
     const int i = sy.rep_i[a], j = sy.rep_j[a], k = sy.rep_i[b], l = sy.rep_j[b];
     const T ti = T(g.t[i]), tj = T(g.t[j]), tk = T(g.t[k]), tl = T(g.t[l]);
@@ -233,7 +263,7 @@ __global__ __launch_bounds__(256) void temporal_fold_fill_kernel(TFoldFillArgs g
     }
     const double isq2 = 0.70710678118654752440;
     const double wa = (i == j) ? 1.0 : isq2, wb = (k == l) ? 1.0 : isq2;
-    const double m = g.m[rep], inv = g.inv_m[rep];
+    const double inv = 1.0 / m;                      // (m is a power of two: exact)
     bool bad = false;
     auto scaled = [&](double x) {
         x = (m > 1e300) ? x / m : x * inv;          // 1 / m is subnormal beyond 1e300
@@ -257,19 +287,8 @@ void k_temporal_fold_fill(gpcsd_ctx *c, const TemporalSet *sets, int nrep, const
         g.set[r] = sets[r];
         GP_REQUIRE(sets[r].ncomp >= 1 && sets[r].ncomp <= GPCSD_MAX_TEMPORAL, -3, "temporal gram: %d components (max %d)",
                    sets[r].ncomp, GPCSD_MAX_TEMPORAL);
-        // every entry of either block is a signed combination of four kernel values with weights summing to at most 2
-        double bound = 0.0;
-        for (int cc = 0; cc < sets[r].ncomp; ++cc) bound += fabs(sets[r].sigma2[cc]);
-        bound *= 2.0;
-        double m = 1.0;
-        if (bound > 0.0 && bound <= 1.7e308) {
-            int ex = 0;
-            (void)frexp(bound, &ex);                // bound = f * 2^ex, f in [0.5, 1)
-            m = ldexp(1.0, ex);
-            if (!(m <= 1.7e308)) m = bound;         // 2^1024 overflows: fall back to the bound itself
-        }
-        g.m[r] = m;
-        g.inv_m[r] = 1.0 / m;
+        g.m[r] = tfold_scale(sets[r].sigma2, sets[r].ncomp);
+        g.inv_m[r] = 1.0 / g.m[r];
     }
     g.sy = sy;
     g.t = t;
@@ -285,6 +304,30 @@ void k_temporal_fold_fill(gpcsd_ctx *c, const TemporalSet *sets, int nrep, const
         hipLaunchKernelGGL(temporal_fold_fill_kernel<float>, dim3(g.elem_blocks + zero_blocks, nrep), dim3(256), 0, s, g);
     else
         hipLaunchKernelGGL(temporal_fold_fill_kernel<double>, dim3(g.elem_blocks + zero_blocks, nrep), dim3(256), 0, s, g);
+    GP_HIP(hipGetLastError());
+}
+
+// the same for B sets whose hyper-parameters sit in a device table (the lock-step batches of fit)
+void k_temporal_fold_fill_tab(gpcsd_ctx *c, const HpDev *tab, int B, const double *t, int n, const SymDev &sy,
+                              const EigArenaView &as, const EigArenaView &aa, int *status, int status_stride, hipStream_t s) {
+    GP_REQUIRE(tab && B >= 1, -3, "temporal fold fill: no hyper-parameter table");
+    GP_REQUIRE(sy.ns > 0 && sy.ns + sy.na == n, -3, "temporal fold fill: the symmetry does not cover the %d time points", n);
+    TFoldFillArgs g{};
+    g.tab = tab;
+    g.sy = sy;
+    g.t = t;
+    g.n = n;
+    g.A0s = as.A0; g.A0a = aa.A0; g.Vs = as.V; g.Va = aa.V; g.taus = as.tau; g.taua = aa.tau; g.amaxs = as.amax; g.amaxa = aa.amax;
+    g.blks = as.blk; g.blka = aa.blk;
+    g.status = status;
+    g.status_stride = status_stride;
+    g.elem_blocks = ceil_div((long)sy.ns * sy.ns, 256);
+    const int zero_blocks = 64;
+    ProfScope ps(c, "gram_temporal_fold_fill", 0.0, s);
+    if (c->gram_fp32)
+        hipLaunchKernelGGL(temporal_fold_fill_kernel<float>, dim3(g.elem_blocks + zero_blocks, B), dim3(256), 0, s, g);
+    else
+        hipLaunchKernelGGL(temporal_fold_fill_kernel<double>, dim3(g.elem_blocks + zero_blocks, B), dim3(256), 0, s, g);
     GP_HIP(hipGetLastError());
 }
 

@@ -85,6 +85,8 @@ struct HpDev {
     int kind[GPCSD_MAX_TEMPORAL];
     double ell_t[GPCSD_MAX_TEMPORAL], sigma2_t[GPCSD_MAX_TEMPORAL];
     double sig2n, jitter;
+    __host__ __device__ double ell_of(int c) const { return ell_t[c]; }          // (the accessors TemporalSet has too: kernels
+    __host__ __device__ double sigma2_of(int c) const { return sigma2_t[c]; }    //  templated on the parameter source)
 };
 
 // ---------------------------------------------------------------- elementwise / Gram builders (gram.hip)
@@ -191,9 +193,14 @@ struct TemporalSet {
     int ncomp;
     int kind[GPCSD_MAX_TEMPORAL];
     double ell[GPCSD_MAX_TEMPORAL], sigma2[GPCSD_MAX_TEMPORAL];
+    __host__ __device__ double ell_of(int c) const { return ell[c]; }
+    __host__ __device__ double sigma2_of(int c) const { return sigma2[c]; }
 };
 void k_temporal_fold_fill(gpcsd_ctx *c, const TemporalSet *sets, int nrep, const double *t, int n, const SymDev &sy,
                           const EigArenaView &as, const EigArenaView &aa, int *status, int status_stride, hipStream_t s);
+// ... for B sets from a device table of hyper-parameters (scale formed on the device by the same rule)
+void k_temporal_fold_fill_tab(gpcsd_ctx *c, const HpDev *tab, int B, const double *t, int n, const SymDev &sy,
+                              const EigArenaView &as, const EigArenaView &aa, int *status, int status_stride, hipStream_t s);
 // flat problem index g -> (class, replica) from the prefix sums start[0..MAX_EIG_BATCH] (unused classes repeat the total)
 __device__ __forceinline__ void class_of(const int *start, int g, int &cls, int &rep) {
     cls = (g >= start[1]) + (g >= start[2]) + (g >= start[3]);
