@@ -391,9 +391,13 @@ struct EigState {
 // the paired step 1.134 -> 1.101 ms at cfg3 (50 trials), 0.969 -> 0.929 ms at cfg2; with 400 resident trials the step is bound by
 // its GEMMs and the extra pass over W costs 3 % (5.08 against 4.92 ms).  Hence mode 2 (the default): on while the resident block
 // is small enough for the step to be latency-bound.  gpcsd_ll_tridiag(ctx, 0 | 1 | 2, ..) / GPCSD_LL_TRIDIAG=0 | 1 force it.
-static constexpr long LL_TRI_AUTO_MAX = 1L << 24;      // nx * nt * ntrials (384 x 500: up to 87 trials)
+// Where the forms cross over (alternating runs, ms per paired step, eigenvector | tridiagonal form): 384 x 500 with 50 trials
+// 1.13 | 1.09, with 75 trials 1.358 | 1.390; 24 x 500 with 200 trials 0.98 | 0.94, with 400 trials 0.975 | 1.085 -- the
+// measure max(nx, 64) * nt * ntrials separates the four at 11 M.
+static constexpr long LL_TRI_AUTO_MAX = 11L << 20;
 static bool ll_tridiag_enabled(const gpcsd_ctx *c) {
-    return c->ll_tridiag_mode == 1 || (c->ll_tridiag_mode == 2 && (long)c->nx * c->nt * c->ntrials <= LL_TRI_AUTO_MAX);
+    return c->ll_tridiag_mode == 1 ||
+           (c->ll_tridiag_mode == 2 && (long)std::max(c->nx, 64) * c->nt * c->ntrials <= LL_TRI_AUTO_MAX);
 }
 
 // Before a temporal chain overwrites the single-buffered outputs of a staged predecessor (reflectors, T factors, the

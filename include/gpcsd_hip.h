@@ -285,7 +285,8 @@ int gpcsd_fold_gemm(gpcsd_ctx *ctx, int on, long *calls);
  * the log-likelihood does not wait for the temporal divide & conquer (which a prediction still needs and the chain still runs).
  * Same results to rounding (1e-15 relative on the log-likelihood at 384 x 500).  mode: 0 = off (the eigenvector form always),
  * 1 = on wherever it applies (mirror-symmetric time grid with halves beyond the Jacobi size, scalar noise, folded path),
- * 2 = on while nx * nt * ntrials <= 2^24 (the default: above that the step is bound by its GEMMs and the form costs 3 %),
+ * 2 = on while max(nx, 64) * nt * ntrials <= 11 * 2^20 (the default: above that the step is bound by its GEMMs and the form
+ *     costs 2-10 %),
  * < 0 only queries; GPCSD_LL_TRIDIAG=0|1|2 sets the mode of new contexts.  *calls counts the log-likelihoods evaluated this
  * way.  DESIGN.md 9. */
 int gpcsd_ll_tridiag(gpcsd_ctx *ctx, int on, long *calls);
