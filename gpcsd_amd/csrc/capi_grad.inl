@@ -125,11 +125,19 @@ static int loglik_grad_impl(gpcsd_ctx *c, const gpcsd_hparams *hps, int B, doubl
         d2.batch2 = B; d2.sA2 = nxG; d2.sB2 = nxG; d2.sC2 = nxx;
         d2.prof_name = "gemm_Ks_TAt";
         gemm_f64(c, d2, s);
-        k_add_diag(c, Ks, nx, 0.0, s, tab, B, nxx);
     }
     {
+        // the spatial chain's input the same way (psd fold fill: fold + jitter on the folded diagonals + scale in one launch)
+        const bool sfill = spatial_fill_applies(c, sym_s, nx);
+        if (sfill) {
+            const char *const *tg = eigh_fold_tags(0);
+            const EigArenaView as = eigh_arena_view(c, tg[0], sym_s->ns, B), aa = eigh_arena_view(c, tg[1], sym_s->na, B);
+            k_psd_fold_fill(c, Ks, nx, nxx, B, nullptr, *sym_s, as, aa, st, 1, s, tab);
+        } else {
+            k_add_diag(c, Ks, nx, 0.0, s, tab, B, nxx);
+        }
         ProfScope ps(c, "eigh_spatial", 9.0 * (double)nx * nx * nx * B, s);
-        eigh_pair_device(c, Ks, nx, es, Qs, sym_s, nullptr, 0, nullptr, nullptr, nullptr, st, s, !fold, B, 1);
+        eigh_pair_device(c, Ks, nx, es, Qs, sym_s, nullptr, 0, nullptr, nullptr, nullptr, st, s, !fold, B, 1, -1, sfill ? 1 : 0);
     }
     double *av = c->buf<double>("b_grad_a", (size_t)nx * B), *bv = c->buf<double>("b_grad_b", (size_t)nt * B);
     double *Gs = c->buf<double>("b_grad_Gs", nxx * B), *Gt = c->buf<double>("b_grad_Gt", ntt * B);

@@ -140,6 +140,7 @@ struct PsdFoldFillArgs {
     long sK;
     int n;
     double shift[2];
+    const HpDev *tab;            // non-null: replica r adds tab[r].jitter (any number of replicas: the batched evaluations of fit)
     SymDev sy;
     double *A0s, *A0a, *Vs, *Va, *taus, *taua, *amaxs, *amaxa;
     long blks, blka;
@@ -159,7 +160,7 @@ __global__ __launch_bounds__(256) void psd_fold_fill_kernel(PsdFoldFillArgs g) {
     const SymDev sy = g.sy;
     const int ns = sy.ns, na = sy.na, n = g.n;
     const double *__restrict__ K = g.K + rep * g.sK;
-    const double shift = g.shift[rep];
+    const double shift = g.tab ? g.tab[rep].jitter : g.shift[rep];
     __shared__ double red[4];
     // scales: largest diagonal entry of each block (every workgroup for itself: <= 4 orbits per thread, L2 hits)
     const double isq2 = 0.70710678118654752440;
@@ -232,12 +233,14 @@ __global__ __launch_bounds__(256) void psd_fold_fill_kernel(PsdFoldFillArgs g) {
 }
 
 void k_psd_fold_fill(gpcsd_ctx *c, const double *K, int n, long sK, int nrep, const double *shift, const SymDev &sy,
-                     const EigArenaView &as, const EigArenaView &aa, int *status, int status_stride, hipStream_t s) {
-    GP_REQUIRE(nrep >= 1 && nrep <= 2, -3, "psd fold fill: %d replicas (1 or 2)", nrep);
+                     const EigArenaView &as, const EigArenaView &aa, int *status, int status_stride, hipStream_t s,
+                     const HpDev *tab) {
+    GP_REQUIRE(nrep >= 1 && (tab || nrep <= 2), -3, "psd fold fill: %d replicas (1 or 2 without a hyper-parameter table)", nrep);
     GP_REQUIRE(sy.ns > 0 && sy.ns + sy.na == n, -3, "psd fold fill: the symmetry does not cover the %d points", n);
     PsdFoldFillArgs g{};
     g.K = K; g.sK = sK; g.n = n;
-    for (int r = 0; r < nrep; ++r) g.shift[r] = shift ? shift[r] : 0.0;
+    for (int r = 0; r < nrep && r < 2; ++r) g.shift[r] = shift ? shift[r] : 0.0;
+    g.tab = tab;
     g.sy = sy;
     g.A0s = as.A0; g.A0a = aa.A0; g.Vs = as.V; g.Va = aa.V; g.taus = as.tau; g.taua = aa.tau; g.amaxs = as.amax; g.amaxa = aa.amax;
     g.blks = as.blk; g.blka = aa.blk;

@@ -182,7 +182,8 @@ EigArenaView eigh_arena_view(gpcsd_ctx *c, const char *tag, int n, int count);
 const char *const *eigh_fold_tags(int slot);
 // fold of a PSD matrix (+ diagonal shift per replica) straight into the class arenas, scaled: see eigh.hip
 void k_psd_fold_fill(gpcsd_ctx *c, const double *K, int n, long sK, int nrep, const double *shift, const SymDev &sy,
-                     const EigArenaView &as, const EigArenaView &aa, int *status, int status_stride, hipStream_t s);
+                     const EigArenaView &as, const EigArenaView &aa, int *status, int status_stride, hipStream_t s,
+                     const HpDev *tab = nullptr);       // tab: replica r adds tab[r].jitter instead of shift[r] (any nrep)
 // The temporal chain's input in ONE launch: the symmetric / antisymmetric fold of Kt = sum_c sigma2_c k_c(t_i - t_j) for
 // `nrep` hyper-parameter sets, evaluated entry by entry from the time grid (the same expressions, in the same order, as
 // k_temporal_gram followed by the eigensolver's fold), divided by a power of two >= 2 sum_c sigma2_c (>= every entry of
