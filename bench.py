@@ -303,6 +303,41 @@ def rocprof_kernel(wl, kernel_substr):
     return None, None, None, "profiles/" + os.path.basename(path)
 
 
+# ------------------------------------------------------------------------------------------------------- launcher
+def launch_ranks(n, argv):
+    """Start `python -m torch.distributed.run --nnodes=1 --nproc-per-node n bench.py <argv>` as a child process (one rank per
+    GPU, rendezvous on 127.0.0.1 at a free port), pass its output through and return its exit code.  The caller is a process
+    that has made no GPU call; nothing is exec'ed and nothing is retried."""
+    import socket
+    import subprocess
+    backend = os.environ.get("GPCSD_BENCH_BACKEND", "nccl")
+    if backend == "nccl" and "GPCSD_DEVICE" not in os.environ:
+        import torch                                   # device_count() does not initialise the runtime on this image
+        have = torch.cuda.device_count()
+        if have < n:
+            print("bench.py: --gpus %d but this node shows %d GPU(s); one rank per GPU over RCCL needs %d (rehearsal on fewer "
+                  "cards: GPCSD_BENCH_BACKEND=gloo GPCSD_DEVICE=0)" % (n, have, n), file=sys.stderr)
+            return 2
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    other = [ln for ln in r.stdout.splitlines() if not ln.startswith("{")]
+    if other:
+        print("\n".join(other), file=sys.stderr)
+    if lines:
+        print(lines[-1], flush=True)
+    elif r.returncode == 0:
+        print("bench.py: the ranks exited 0 without a result line", file=sys.stderr)
+        return 1
+    return r.returncode
+
+
 # ------------------------------------------------------------------------------------------------------- main
 def main():
     ap = argparse.ArgumentParser()
@@ -322,10 +357,20 @@ def main():
     ap.add_argument("--fit-groups", type=int, default=1,
                     help="cfg5: lock-step groups running side by side on one GPU, each on its own context and host thread "
                          "(measured: one large batch beats several groups -- 7.5 k evals/s at 1 x 32 against 6.3 k at 2 x 16)")
+    ap.add_argument("--n1-value", type=float, default=None,
+                    help="N > 1: the N = 1 `value` of this workload (trials/s) to quote scaling_efficiency against; without it the "
+                         "efficiency is quoted against the ranks' own rates without collectives, measured in the same processes")
     args = ap.parse_args()
 
+    # `python bench.py --gpus N` (no launcher): start the N ranks ourselves.  This process has not touched the GPU (torch is not
+    # even imported yet) and never will: the ranks are a fresh `torch.distributed.run` child, whose rank 0 prints the line.
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks: they must agree (run "
+                         "`python bench.py --gpus N` and let it start the ranks, or launch N ranks with --gpus N)" % (args.gpus, world))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     # rehearsal knobs (one-GPU box): GPCSD_BENCH_BACKEND=gloo + GPCSD_DEVICE=0 run N ranks on one card
     backend = os.environ.get("GPCSD_BENCH_BACKEND", "nccl")
@@ -363,7 +408,16 @@ def main():
     # the driver runs `bench.py --gpus 1` only: carry compact cfg2 / cfg5 results in that line (N=1, a few seconds)
     if (rank == 0 and out is not None and world == 1 and args.workload == "cfg3" and args.trials_per_gpu is None
             and not args.only_value and not args.no_sub_results):
-        out["sub_results"] = sub_results(args, local_rank, backend)
+        out["sub_results"] = sub = sub_results(args, local_rank, backend)
+        # ... and their headline scalars inside `config` (kept by a record that drops nested results)
+        out["config"]["cfg2_trials_per_sec"] = sub.get("cfg2", {}).get("value")
+        out["config"]["cfg2_ms_per_step"] = sub.get("cfg2", {}).get("ms_per_step")
+        out["config"]["cfg5_evals_per_sec"] = sub.get("cfg5", {}).get("value")
+        out["config"]["cfg5_fit_evals_per_sec"] = (sub.get("cfg5", {}).get("fit") or {}).get("evals_per_sec")
+        for k in ("potrf", "npx69"):
+            if isinstance(sub.get(k), dict):
+                for kk, vv in sub[k].get("headline", {}).items():
+                    out["config"]["%s_%s" % (k, kk)] = vv
     if rank == 0 and out is not None:
         out["host_affinity"] = ({"bound_to_numa_node": host_numa["node"], "cpus": host_numa["cpus"], "device_pci": host_numa["pci"]}
                                 if host_numa else {"bound_to_numa_node": None, "cpus": len(os.sched_getaffinity(0))})
@@ -453,6 +507,12 @@ def run_step_bench(args, w, rank, world, local_rank, backend, compact=False):
         state["partial"] = (sumlog, quad)
         return ll_prev, 0.0, 0.0
 
+    def solo_step():
+        hp, keep = m._hparams(m.JITTER)
+        hp0, keep0 = m._hparams(0.0)
+        ctx.loglik_predict_async(hp, hp0, z, w["t"], _hip.PRED_CSD, want_lists=True)
+        return ctx.loglik_parts_wait()
+
     state = {}
 
     def flush():
@@ -488,11 +548,39 @@ def run_step_bench(args, w, rank, world, local_rank, backend, compact=False):
     elapsed = time.perf_counter() - t0
     if sharding is not None:
         ll = state["ll"]                          # the last step's global log-likelihood, collected inside the timed region
+    dist_info = None
     if sharding is not None:
         import torch.distributed as td
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+        # the same steps on every rank WITHOUT the collective (each rank alone with its card, as an N = 1 run): what the
+        # sharded job's rate is quoted against when no N = 1 figure is handed in (--n1-value)
+        for _ in range(min(args.warmup, 3)):
+            solo_step()
+        ctx.synchronize()
+        tsolo = time.perf_counter()
+        for _ in range(args.steps):
+            solo_step()
+        ctx.synchronize()
+        solo = time.perf_counter() - tsolo
+        dev = "cuda" if backend == "nccl" else "cpu"
+        per_rank = torch.zeros(2 * world, dtype=torch.float64, device=dev)
+        per_rank[rank], per_rank[world + rank] = elapsed, solo
+        td.all_reduce(per_rank, op=td.ReduceOp.SUM)
+        per_rank = per_rank.cpu().numpy()
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         td.all_reduce(tt, op=td.ReduceOp.MAX)
         elapsed = float(tt.cpu()[0])
+        unsharded_rate = float(np.sum(R_local * args.steps / per_rank[world:]))
+        value_now = R_total * args.steps / elapsed
+        dist_info = {
+            "collective_backend": td.get_backend(), "rccl_ranks": td.get_world_size() if td.get_backend() == "nccl" else 0,
+            "ranks": td.get_world_size(),
+            "per_rank_ms_per_step": [1e3 * float(v) / args.steps for v in per_rank[:world]],
+            "per_rank_ms_per_step_without_collectives": [1e3 * float(v) / args.steps for v in per_rank[world:]],
+            "efficiency_vs_ranks_without_collectives": value_now / unsharded_rate,
+            "scaling_efficiency": (value_now / (world * args.n1_value)) if args.n1_value else value_now / unsharded_rate,
+            "scaling_efficiency_against": ("--n1-value %.6g trials/s" % args.n1_value) if args.n1_value else
+                                          "sum of the ranks' own rates over the same steps without the all-reduce (same processes)",
+        }
     ms_per_step = 1e3 * elapsed / args.steps
     if args.only_value:
         if rank != 0:
@@ -503,7 +591,7 @@ def run_step_bench(args, w, rank, world, local_rank, backend, compact=False):
                 "data": "synthetic", "loglik": float(ll),
                 "config": {"workload": w["label"], "n_elec": w["nx"], "n_t": w["nt"], "trials_per_gpu": R_local,
                            "total_trials": R_total, "parallelism": "trial-sharded x%d" % n_gpus},
-                "only_value": "setup + warm-up + timed loop only (the command profiled under profiles/)"}
+                "only_value": "setup + warm-up + timed loop only (the command profiled under profiles/)", "distributed": dist_info}
 
     # ---- the two halves on their own (rank-local, every call fenced: nothing of one call overlaps the next) ----
     # In the step loop above predict_resident returns with its GEMM tail in flight (its results stay on the device) and
@@ -701,6 +789,20 @@ def run_step_bench(args, w, rank, world, local_rank, backend, compact=False):
     roof["chains_ms_per_step_graph_replay"] = {k: v["ms"] / n_prof for k, v in sorted(prof_graph.items(), key=lambda kv: -kv[1]["ms"])
                                                if v["count"] > 0}
 
+    # scalars of the nested reports once more at the first level of `roofline` (a record that keeps scalars only keeps these)
+    dk, lg = roof.get("dominant_kernel"), roof.get("largest_gemm")
+    if dk:
+        roof["dominant_kernel_name"] = dk["kernel"]
+        roof["dominant_kernel_frac"] = dk["frac"]
+        roof["dominant_kernel_avg_ms"] = dk["avg_launch_ms"]
+        roof["dominant_kernel_share"] = dk["share_of_gpu_time_rocprof"]
+    if lg:
+        roof["largest_gemm_frac"] = lg["frac"]
+        roof["largest_gemm_avg_ms"] = lg["avg_launch_ms"]
+        roof["all_gemm_frac"] = lg["all_gemm_tflops"] / FP64_MFMA_SPEC_TFLOPS
+    roof["traffic_over_algorithmic"] = (traffic / alg_bytes) if traffic else None
+    roof["reference_algorithm_frac"] = roof["reference_algorithm"]["frac"]
+
     out = {
         "metric": "gpcsd_loglik_plus_predict_trials_per_sec",
         "value": R_total * args.steps / elapsed,
@@ -741,11 +843,14 @@ def run_step_bench(args, w, rank, world, local_rank, backend, compact=False):
         "class_api_predict_trials_per_sec_per_gpu_pcie_inclusive": pcie_predict,
         "class_api_predict_host_gb_per_sec": pcie_predict / R_local * out_bytes / 1e9,
         "loglik": float(ll),
+        "distributed": dist_info,
         "roofline": roof,
     }
     if not args.no_cpu_baseline and world == 1:      # the CPU baseline is reported at N=1 only
         cb, ll_cpu, pred_cpu = cpu_baseline(w, m, lfp, args.cpu_budget_s)
         out["cpu_baseline"] = cb
+        cb["reference_layout_loglik_evals_per_sec"] = cb["faithful_layout"]["loglik_evals_per_sec"]
+        cb["single_thread_trials_per_sec"] = cb["single_thread"]["value"]
         # parity spot check beside the numbers: the GPU step's own outputs vs the oracle on the same trials
         out["parity_rel_err_loglik_vs_oracle"] = abs(float(ll) - ll_cpu) / abs(ll_cpu)
         hp0, _k = m._hparams(0.0)

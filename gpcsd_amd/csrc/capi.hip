@@ -38,6 +38,7 @@ static void drain_after_failure(gpcsd_ctx *c) {
     if (c->stream4) (void)hipStreamSynchronize(c->stream4);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     c->status_zeroed = false;
+    c->late_dirty = false;                      // (status_zeroed = false: the next front half clears every word)
     c->async_pending = false;                   // everything is drained: no deferred status
     // (an outstanding asynchronous loglik stays collectable: its result has landed by now)
     c->decomp_gen[0] = c->decomp_gen[1] = -1;   // whatever the failed call left behind is not reused
@@ -414,6 +415,17 @@ static void staged_chain_guard(gpcsd_ctx *c, hipStream_t s2) {
     }
 }
 
+// A staged temporal chain is about to start on s2: the late status words (stages 2 and 4 of its predecessor on this stream,
+// gpcsd_ctx::STATUS_LATE) are cleared there, behind that predecessor -- unless asynchronous work is outstanding, whose status
+// stays sticky until a synchronising call has collected it.  A synchronous log-likelihood in the tridiagonal form returns while
+// those stages are still running: whatever they report concerns results nobody has read, and must not be charged to the next
+// call.
+static void clear_late_status(gpcsd_ctx *c, int *status, hipStream_t s2, bool staged) {
+    if (c->async_pending || !(staged || c->late_dirty)) return;
+    c->late_dirty = false;
+    GP_HIP(hipMemsetAsync(status + gpcsd_ctx::STATUS_LATE, 0, (gpcsd_ctx::STATUS_N - gpcsd_ctx::STATUS_LATE) * sizeof(int), s2));
+}
+
 // Main stream waits for the spatial chain of this call (no-op when it was reused from the cache or already joined).
 static void join_spatial(gpcsd_ctx *c, EigState &e) {
     if (e.wait_spatial) {
@@ -476,8 +488,8 @@ EigState front_half(gpcsd_ctx *c, const gpcsd_hparams *hp, double jitter, bool n
     e.D = c->buf<double>("D", (size_t)nx * nt);
     e.Dinv = c->buf<double>("Dinv", (size_t)nx * nt);
     // scalars and status words share one allocation so that a call ends with ONE small device-to-host copy
-    e.scal = c->buf<double>("scal_status", 64 + 2);
-    e.status = reinterpret_cast<int *>(e.scal + 64);
+    e.scal = c->buf<double>("scal_status", gpcsd_ctx::RESULT_DOUBLES);
+    e.status = reinterpret_cast<int *>(e.scal + gpcsd_ctx::SCAL_N);
     const double *t = (const double *)c->bufs["time_t"].p;
     const bool host_kt = uses_host_kt(hp);
     if (host_kt)
@@ -494,7 +506,7 @@ EigState front_half(gpcsd_ctx *c, const gpcsd_hparams *hp, double jitter, bool n
     // chains, which report into them, have to be ordered behind that.  (Behind an asynchronous predict they hold its
     // uncollected status and stay as they are.)
     const bool clear_now = !c->status_zeroed && !c->async_pending;
-    if (clear_now) GP_HIP(hipMemsetAsync(e.status, 0, 4 * sizeof(int), s));
+    if (clear_now) GP_HIP(hipMemsetAsync(e.status, 0, gpcsd_ctx::STATUS_N * sizeof(int), s));
     c->status_zeroed = false;
     if (!two_stream_front()) {
         double *d_sig = c->upload_cached<double>("sig2n", hp->sig2n, hp->n_sig2n);
@@ -549,6 +561,7 @@ EigState front_half(gpcsd_ctx *c, const gpcsd_hparams *hp, double jitter, bool n
         // staged whenever it applies (not only for a log-likelihood): the T factors are then a launch of their own instead of
         // riding in the leaf launch -- same bits either way, but every call form takes the same launches
         const bool staged = tfill && ll_tridiag_enabled(c) && eigh_stageable(sym_t, nt);
+        clear_late_status(c, e.status, s2, staged);
         {
             ProfScope ps(c, "eigh_temporal", 9.0 * (double)nt * nt * nt, s2);
             if (staged) {
@@ -556,10 +569,11 @@ EigState front_half(gpcsd_ctx *c, const gpcsd_hparams *hp, double jitter, bool n
                 // (T factors, Q), then stage 4 (back-transformation) behind both.  A log-likelihood in the tridiagonal form
                 // starts its tail behind stage 3 and never waits for stages 2 and 4.
                 const bool tri = want_tri && !need_merged && hp->n_sig2n == 1;
+                int *late = e.status + gpcsd_ctx::STATUS_LATE;    // stages 2 and 4 report here (gpcsd_ctx::STATUS_LATE)
                 eigh_pair_device(c, nullptr, 0, nullptr, nullptr, nullptr, Kt, nt, e.et, e.Qt, sym_t, e.status + 1, s2, need_merged, 1, 0,
                                  -1, 2, /*stage=*/1);
                 GP_HIP(hipEventRecord(c->ev_t1, s2));
-                eigh_pair_device(c, nullptr, 0, nullptr, nullptr, nullptr, Kt, nt, e.et, e.Qt, sym_t, e.status + 1, s2, need_merged, 1, 0,
+                eigh_pair_device(c, nullptr, 0, nullptr, nullptr, nullptr, Kt, nt, e.et, e.Qt, sym_t, late + 1, s2, need_merged, 1, 0,
                                  -1, 2, /*stage=*/2);
                 {
                     hipStream_t sq = c->stream4;
@@ -571,7 +585,7 @@ EigState front_half(gpcsd_ctx *c, const gpcsd_hparams *hp, double jitter, bool n
                     c->q_gen = c->eig_gen[1];
                 }
                 GP_HIP(hipStreamWaitEvent(s2, c->ev_q, 0));
-                eigh_pair_device(c, nullptr, 0, nullptr, nullptr, nullptr, Kt, nt, e.et, e.Qt, sym_t, e.status + 1, s2, need_merged, 1, 0,
+                eigh_pair_device(c, nullptr, 0, nullptr, nullptr, nullptr, Kt, nt, e.et, e.Qt, sym_t, late + 1, s2, need_merged, 1, 0,
                                  -1, 2, /*stage=*/4);
                 e.tri = e.wait_q = tri;
             } else {
@@ -746,42 +760,57 @@ int join_temporal(gpcsd_ctx *c, EigState &e, const FoldMode *fm = nullptr, bool 
     return np;
 }
 
+// Fold the status words of a fused call into one code (0: fine).  late: the call joined the whole temporal chain, so the words of
+// its stages 2 and 4 are complete and count as well.
+static int fold_status(const int *st, bool late) {
+    int r = 0;
+    const int n = late ? gpcsd_ctx::STATUS_N : gpcsd_ctx::STATUS_LATE;
+    for (int i = 0; i < n && r == 0; ++i) r = st[i];   // [0]/[2] spatial, [1]/[3] temporal, [4..7] late stages of the temporal chain
+    return r;
+}
+
 // End of a fused call: one copy brings back the leading `nscal` scalars and the status words, then the stream is drained.
+// A log-likelihood in the tridiagonal form (e.tri) has not waited for stages 2 and 4 of its temporal chain and does not use
+// their results: it neither reads nor clears their status words (see gpcsd_ctx::STATUS_LATE), and stream2 may still be running
+// them when it returns -- every later use of that chain's outputs is ordered behind ev_join as usual.
 int finish_call(gpcsd_ctx *c, const EigState &e, double *scal_out, int nscal) {
     double *host = c->h_result;                        // pinned: a true asynchronous copy, no staging
+    const bool late = !e.tri;
     c->tl("sync call end (main)", c->stream);
-    c->download(host, e.scal, 66 * sizeof(double));
-    GP_HIP(hipMemsetAsync(e.status, 0, 4 * sizeof(int), c->stream));   // clean status words for the next call, after the copy
+    c->download(host, e.scal, gpcsd_ctx::RESULT_DOUBLES * sizeof(double));
+    // clean status words for the next call, after the copy
+    GP_HIP(hipMemsetAsync(e.status, 0, (late ? gpcsd_ctx::STATUS_N : gpcsd_ctx::STATUS_LATE) * sizeof(int), c->stream));
     c->sync();
     c->status_zeroed = true;
+    c->late_dirty = !late;
     c->async_pending = false;              // whatever an asynchronous predict left in the status words has been collected now
     if (c->prof_mode == 1) c->prof_collect();
     for (int i = 0; i < nscal; ++i) scal_out[i] = host[i];
-    int st[4];
-    memcpy(st, host + 64, sizeof(st));
-    for (int i = 1; i < 4 && st[0] == 0; ++i) st[0] = st[i];   // [1]: temporal chain; [2], [3]: second replica of a paired call
-    if (st[0] != 0) {
+    int st[gpcsd_ctx::STATUS_N];
+    memcpy(st, host + gpcsd_ctx::SCAL_N, sizeof(st));
+    const int bad = fold_status(st, late);
+    if (bad != 0) {
         char b[128];
-        snprintf(b, sizeof(b), "numerical failure (status %d): eigensolver did not converge or matrix not positive definite", st[0]);
+        snprintf(b, sizeof(b), "numerical failure (status %d): eigensolver did not converge or matrix not positive definite", bad);
         c->last_error = b;
         c->decomp_gen[0] = c->decomp_gen[1] = -1;     // a failed decomposition is never reused
-        return st[0] > 0 ? st[0] : 1;
+        return bad > 0 ? bad : 1;
     }
     return 0;
 }
 
-int finish_status(gpcsd_ctx *c, const int *d_status) {
-    int st[4];
-    c->download(st, d_status, sizeof(st));
+int finish_status(gpcsd_ctx *c, const int *d_status, int nwords = 4) {
+    int st[gpcsd_ctx::STATUS_N] = {0, 0, 0, 0, 0, 0, 0, 0};
+    c->download(st, d_status, nwords * sizeof(int));
     c->sync();
     if (c->prof_mode == 1) c->prof_collect();
-    for (int i = 1; i < 4 && st[0] == 0; ++i) st[0] = st[i];   // [1]: temporal chain; [2], [3]: second replica of a paired call
-    if (st[0] != 0) {
+    const int bad = fold_status(st, true);     // (words beyond nwords are zero)
+    if (bad != 0) {
         char b[128];
-        snprintf(b, sizeof(b), "numerical failure (status %d): eigensolver did not converge or matrix not positive definite", st[0]);
+        snprintf(b, sizeof(b), "numerical failure (status %d): eigensolver did not converge or matrix not positive definite", bad);
         c->last_error = b;
         c->decomp_gen[0] = c->decomp_gen[1] = -1;     // a failed decomposition is never reused (a retry with the same hp re-solves)
-        return st[0] > 0 ? st[0] : 1;
+        return bad > 0 ? bad : 1;
     }
     return 0;
 }
@@ -828,8 +857,9 @@ extern "C" int gpcsd_ctx_create(int device, gpcsd_ctx **out) {
         GP_HIP(hipEventCreateWithFlags(&c->ev_q, hipEventDisableTiming));
         GP_HIP(hipEventCreateWithFlags(&c->ev_t1, hipEventDisableTiming));
         GP_HIP(hipEventCreateWithFlags(&c->ev_tri_done, hipEventDisableTiming));
-        GP_HIP(hipHostMalloc(reinterpret_cast<void **>(&c->h_result), 66 * sizeof(double), hipHostMallocDefault));
-        GP_HIP(hipHostMalloc(reinterpret_cast<void **>(&c->h_ll), gpcsd_ctx::LL_SLOTS * 66 * sizeof(double), hipHostMallocDefault));
+        GP_HIP(hipHostMalloc(reinterpret_cast<void **>(&c->h_result), gpcsd_ctx::RESULT_DOUBLES * sizeof(double), hipHostMallocDefault));
+        GP_HIP(hipHostMalloc(reinterpret_cast<void **>(&c->h_ll), gpcsd_ctx::LL_SLOTS * gpcsd_ctx::RESULT_DOUBLES * sizeof(double),
+                             hipHostMallocDefault));
         for (auto &sl : c->ll_slot) GP_HIP(hipEventCreateWithFlags(&sl.ev, hipEventDisableTiming));
         *out = c;
         return 0;

@@ -96,30 +96,45 @@ extern "C" int gpcsd_dist_set_time(gpcsd_dist *d, const double *t, int nt) {
 extern "C" int gpcsd_dist_set_lfp(gpcsd_dist *d, const double *lfp, int nx, int nt, int ntrials, int replicate) {
     if (!d || !lfp || nx < 1 || nt < 1 || ntrials < 1) return -3;
     const int n = (int)d->ctx.size();
-    d->nx = nx; d->nt = nt; d->ntrials = ntrials; d->replicated = replicate != 0;
-    d->first.assign(n, 0);
-    d->count.assign(n, ntrials);
-    if (!d->replicated) {
+    // validate and partition into locals first: a rejected or failed call must not leave the handle describing data the
+    // contexts do not hold (gpcsd_dist_loglik / _predict combine and scatter by first / count / ntrials)
+    const bool repl = replicate != 0;
+    std::vector<int> first(n, 0), count(n, ntrials);
+    if (!repl) {
         if (ntrials < n) {
             d->last_error = "fewer trials than devices";
             return -3;
         }
-        for (int i = 0; i < n; ++i) (void)gpcsd_shard_block(ntrials, i, n, &d->first[i], &d->count[i]);
+        for (int i = 0; i < n; ++i) (void)gpcsd_shard_block(ntrials, i, n, &first[i], &count[i]);
     }
-    return dist_parallel(d, [&](int i) {
-        if (d->replicated || n == 1) return gpcsd_set_lfp(d->ctx[i], lfp, nx, nt, ntrials);
+    const int rc = dist_parallel(d, [&](int i) {
+        if (repl || n == 1) return gpcsd_set_lfp(d->ctx[i], lfp, nx, nt, ntrials);
         // the trial index is innermost: a block of trials is a strided slice, packed here
-        const int f = d->first[i], cnt = d->count[i];
+        const int f = first[i], cnt = count[i];
         std::vector<double> blk((size_t)nx * nt * cnt);
         for (long r = 0; r < (long)nx * nt; ++r) memcpy(&blk[(size_t)r * cnt], lfp + (size_t)r * ntrials + f, (size_t)cnt * sizeof(double));
         return gpcsd_set_lfp(d->ctx[i], blk.data(), nx, nt, cnt);
     });
+    if (rc != 0) {                       // some contexts may hold the new data, some the old: the handle holds none
+        d->nx = d->nt = d->ntrials = 0;
+        d->first.assign(n, 0);
+        d->count.assign(n, 0);
+        return rc;
+    }
+    d->nx = nx; d->nt = nt; d->ntrials = ntrials; d->replicated = repl;
+    d->first = first;
+    d->count = count;
+    return 0;
 }
 
 // GPCSD1D/2D.loglik over all trials (gpcsd1d.py:113-128): every device queues its partial evaluation, then the partial quadratic
 // terms are collected and summed in device order
 extern "C" int gpcsd_dist_loglik(gpcsd_dist *d, const gpcsd_hparams *hp, double *out) {
     if (!d || !hp || !out) return -3;
+    if (d->ntrials <= 0) {
+        d->last_error = "no data on the devices (gpcsd_dist_set_lfp has not succeeded)";
+        return -4;
+    }
     if (d->replicated) return dist_fail(d, gpcsd_loglik(d->ctx[0], hp, out), 0);
     const int n = (int)d->ctx.size();
     for (int i = 0; i < n; ++i) {                         // asynchronous: the devices work side by side without host threads
@@ -152,6 +167,10 @@ extern "C" int gpcsd_dist_loglik(gpcsd_dist *d, const gpcsd_hparams *hp, double 
 // of the devices' gradients of L_loc (see gpcsd_loglik_grad: both are sums over trials plus a term linear in the trial count)
 extern "C" int gpcsd_dist_loglik_grad(gpcsd_dist *d, const gpcsd_hparams *hp, double *out2, double *grad, int ngrad) {
     if (!d || !hp || !out2 || !grad || ngrad < 1) return -3;
+    if (d->ntrials <= 0) {
+        d->last_error = "no data on the devices (gpcsd_dist_set_lfp has not succeeded)";
+        return -4;
+    }
     if (d->replicated) return dist_fail(d, gpcsd_loglik_grad(d->ctx[0], hp, out2, grad, ngrad), 0);
     const int n = (int)d->ctx.size();
     std::vector<double> o2((size_t)2 * n), g((size_t)ngrad * n);
@@ -173,6 +192,10 @@ extern "C" int gpcsd_dist_loglik_grad(gpcsd_dist *d, const gpcsd_hparams *hp, do
 extern "C" int gpcsd_dist_loglik_grad_batch(gpcsd_dist *d, const gpcsd_hparams *hps, int nsets, double *out2, double *grad, int ngrad,
                                             int *status) {
     if (!d || !hps || nsets < 1 || !out2 || !grad || !status || ngrad < 1) return -3;
+    if (d->ntrials <= 0) {
+        d->last_error = "no data on the devices (gpcsd_dist_set_lfp has not succeeded)";
+        return -4;
+    }
     if (!d->replicated) {
         d->last_error = "gpcsd_dist_loglik_grad_batch needs every device to hold all trials (gpcsd_dist_set_lfp with replicate = 1)";
         return -3;
@@ -206,6 +229,10 @@ extern "C" int gpcsd_dist_loglik_grad_batch(gpcsd_dist *d, const gpcsd_hparams *
 extern "C" int gpcsd_dist_predict(gpcsd_dist *d, const gpcsd_hparams *hp, const double *z, int nz, const double *tstar, int ntstar,
                                   int type, double *csd_list, double *csd, double *lfp_list, double *lfp) {
     if (!d || !hp || !z || !tstar || nz < 1 || ntstar < 1) return -3;
+    if (d->ntrials <= 0) {
+        d->last_error = "no data on the devices (gpcsd_dist_set_lfp has not succeeded)";
+        return -4;
+    }
     const int n = (int)d->ctx.size();
     if (d->replicated || n == 1)
         return dist_fail(d, gpcsd_predict(d->ctx[0], hp, z, nz, tstar, ntstar, type, csd_list, csd, lfp_list, lfp), 0);

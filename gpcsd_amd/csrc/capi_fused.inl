@@ -9,7 +9,8 @@
 static int finish_loglik_async(gpcsd_ctx *c, const EigState &e, bool two) {
     const int k = (c->ll_head + c->ll_count) % gpcsd_ctx::LL_SLOTS;       // callers have checked that a slot is free
     gpcsd_ctx::LlSlot &sl = c->ll_slot[k];
-    GP_HIP(hipMemcpyAsync(c->h_ll + 66 * k, e.scal, 66 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    GP_HIP(hipMemcpyAsync(c->h_ll + gpcsd_ctx::RESULT_DOUBLES * k, e.scal, gpcsd_ctx::RESULT_DOUBLES * sizeof(double),
+                          hipMemcpyDeviceToHost, c->stream));
     GP_HIP(hipEventRecord(sl.ev, c->stream));
     ++c->ll_count;
     sl.done = false;
@@ -168,27 +169,28 @@ extern "C" int gpcsd_loglik_parts_wait(gpcsd_ctx *c, double *out2) {
         return sl.rc;
     }
     GP_HIP(hipEventSynchronize(sl.ev));
-    const double *host = c->h_ll + 66 * k;
+    const double *host = c->h_ll + gpcsd_ctx::RESULT_DOUBLES * k;
     out2[0] = host[0];
     out2[1] = sl.two ? host[1] + host[2] : host[1];
-    int st[4];
-    memcpy(st, host + 64, sizeof(st));
-    for (int i = 1; i < 4 && st[0] == 0; ++i) st[0] = st[i];
-    if (st[0] != 0) {                     // this evaluation's, or an earlier asynchronous call's that nobody collected yet
+    int st[gpcsd_ctx::STATUS_N];
+    memcpy(st, host + gpcsd_ctx::SCAL_N, sizeof(st));
+    // (asynchronous calls: every word as it stood when this evaluation's copy ran, the late stages' of EARLIER chains included)
+    const int bad = fold_status(st, true);
+    if (bad != 0) {                       // this evaluation's, or an earlier asynchronous call's that nobody collected yet
         char b[160];
-        snprintf(b, sizeof(b), "numerical failure (status %d): eigensolver did not converge or matrix not positive definite", st[0]);
+        snprintf(b, sizeof(b), "numerical failure (status %d): eigensolver did not converge or matrix not positive definite", bad);
         c->last_error = b;
         // The status words are sticky while asynchronous work is outstanding (nobody may clear them under a running chain).
         // Now that a failure has been reported: drain everything and clear them, so that evaluations queued from here on
         // start clean.  Evaluations that were ALREADY outstanding copied the words as they stood and report the failure too
         // (a failed wait poisons the ones queued before it returned; documented in gpcsd_hip.h).
         drain_after_failure(c);
-        if (int *dst = reinterpret_cast<int *>(c->buf<double>("scal_status", 64 + 2) + 64)) {
-            GP_HIP(hipMemsetAsync(dst, 0, 4 * sizeof(int), c->stream));
+        if (int *dst = reinterpret_cast<int *>(c->buf<double>("scal_status", gpcsd_ctx::RESULT_DOUBLES) + gpcsd_ctx::SCAL_N)) {
+            GP_HIP(hipMemsetAsync(dst, 0, gpcsd_ctx::STATUS_N * sizeof(int), c->stream));
             GP_HIP(hipStreamSynchronize(c->stream));
             c->status_zeroed = true;
         }
-        return st[0] > 0 ? st[0] : 1;
+        return bad > 0 ? bad : 1;
     }
     return 0;
     GP_API_END(c)
@@ -515,10 +517,11 @@ static void front_half_pair(gpcsd_ctx *c, const gpcsd_hparams *const hp[2], cons
     const SymDev *sym_s = c->sym_s.ns > 0 ? &c->sym_s : nullptr, *sym_t = c->sym_t.ns > 0 ? &c->sym_t : nullptr;
     const double *t = (const double *)c->bufs["time_t"].p;
     const int nT = (c->decomp_cache_on && same_temporal(hp[0], hp[1])) ? 1 : 2;      // replicas of the temporal problem
-    double *scal = c->buf<double>("scal_status", 64 + 2);
-    int *status = reinterpret_cast<int *>(scal + 64);
+    double *scal = c->buf<double>("scal_status", gpcsd_ctx::RESULT_DOUBLES);
+    int *status = reinterpret_cast<int *>(scal + gpcsd_ctx::SCAL_N);
+    int *late = status + gpcsd_ctx::STATUS_LATE;           // stages 2 and 4 of a staged temporal chain report here
     const bool clear_now = !c->status_zeroed && !c->async_pending;
-    if (clear_now) GP_HIP(hipMemsetAsync(status, 0, 4 * sizeof(int), s));
+    if (clear_now) GP_HIP(hipMemsetAsync(status, 0, gpcsd_ctx::STATUS_N * sizeof(int), s));
     c->status_zeroed = false;
     begin_generation(c, 1, s2, clear_now);
     begin_generation(c, 0, s3, clear_now);
@@ -539,6 +542,7 @@ static void front_half_pair(gpcsd_ctx *c, const gpcsd_hparams *const hp[2], cons
         if (part == 1) {
             c->tl("T chain start (s2)", s2);
             staged_chain_guard(c, s2);
+            clear_late_status(c, status, s2, staged);
             if (tfill) temporal_fill(c, hp, nT, t, nt, *sym_t, status + 1, 2, s2);
             else for (int b = 0; b < nT; ++b) build_kt(c, hp[b], t, nt, t, nt, Kt + b * ntt, s2);
         }
@@ -558,7 +562,7 @@ static void front_half_pair(gpcsd_ctx *c, const gpcsd_hparams *const hp[2], cons
                 // stage 2 (divide & conquer) on the chain's stream; beside it, on stream4, stage 3 (T factors, Q); stage 4
                 // (back-transformation) behind both.  (Stage 3 on the main stream, in front of X: 1.14 against 1.10 ms -- the
                 // main stream is rarely idle when stage 1 ends.)
-                eigh_pair_device(c, nullptr, 0, nullptr, nullptr, nullptr, Kt, nt, et, Qt, sym_t, status + 1, s2, false, nT, 2, -1, 2, 2);
+                eigh_pair_device(c, nullptr, 0, nullptr, nullptr, nullptr, Kt, nt, et, Qt, sym_t, late + 1, s2, false, nT, 2, -1, 2, 2);
                 hipStream_t sq = c->stream4;
                 GP_HIP(hipStreamWaitEvent(sq, c->ev_t1, 0));
                 eigh_pair_device(c, nullptr, 0, nullptr, nullptr, nullptr, Kt, nt, et, Qt, sym_t, status + 1, sq, false, nT, 2, -1, 2, 3);
@@ -567,7 +571,7 @@ static void front_half_pair(gpcsd_ctx *c, const gpcsd_hparams *const hp[2], cons
                 c->q_queued = true;
                 c->q_gen = -1;           // (replicas: not what a separate call's cache looks for)
                 GP_HIP(hipStreamWaitEvent(s2, c->ev_q, 0));
-                eigh_pair_device(c, nullptr, 0, nullptr, nullptr, nullptr, Kt, nt, et, Qt, sym_t, status + 1, s2, false, nT, 2, -1, 2, 4);
+                eigh_pair_device(c, nullptr, 0, nullptr, nullptr, nullptr, Kt, nt, et, Qt, sym_t, late + 1, s2, false, nT, 2, -1, 2, 4);
             } else {
                 eigh_pair_device(c, nullptr, 0, nullptr, nullptr, nullptr, Kt, nt, et, Qt, sym_t, status + 1, s2, false, nT, 2, -1,
                                  tfill ? 2 : 0);
@@ -641,10 +645,10 @@ static void front_half_pair(gpcsd_ctx *c, const gpcsd_hparams *const hp[2], cons
 static int drain_async(gpcsd_ctx *c) {
     if (!c->async_pending) return 0;
     c->async_pending = false;
-    int *st = reinterpret_cast<int *>(c->buf<double>("scal_status", 64 + 2) + 64);
+    int *st = reinterpret_cast<int *>(c->buf<double>("scal_status", gpcsd_ctx::RESULT_DOUBLES) + gpcsd_ctx::SCAL_N);
     GP_HIP(hipStreamSynchronize(c->stream2));
     GP_HIP(hipStreamSynchronize(c->stream3));
-    return finish_status(c, st);          // downloads + synchronises; the words are cleared by the next call's front half
+    return finish_status(c, st, gpcsd_ctx::STATUS_N);          // downloads + synchronises; the words are cleared by the next call's front half
 }
 
 extern "C" int gpcsd_predict_resident(gpcsd_ctx *c, const gpcsd_hparams *hp, const double *z, int nz, const double *tstar,

@@ -67,7 +67,15 @@ struct gpcsd_ctx {
     hipStream_t stream2 = nullptr;          // temporal chain (Kt, its eigen-decomposition)
     hipStream_t stream3 = nullptr;          // spatial chain (Ks assembly, its eigen-decomposition)
     hipStream_t stream4 = nullptr;          // predict: the small Pcat products, beside the large GEMMs of the main stream
-    double *h_result = nullptr;             // pinned host landing zone for the end-of-call copy (66 doubles)
+    // Scalars and status words of the fused calls share one device allocation ("scal_status") and travel in one copy:
+    // SCAL_N doubles, then STATUS_N ints.  Words [0..3]: the spatial chain ([0], second replica [2]) and the temporal chain
+    // ([1], [3]) up to and including what a log-likelihood in the tridiagonal form consumes (stages 1 and 3 of a staged chain,
+    // everything of an unstaged one).  Words [4..7] ("late"): stages 2 and 4 of a staged temporal chain (divide & conquer,
+    // back-transformation), which such a log-likelihood neither reads nor waits for -- only calls that join the whole chain
+    // (ev_join) collect them, and the next staged chain clears them on its own stream when nothing asynchronous is pending.
+    static constexpr int SCAL_N = 64, STATUS_N = 8, STATUS_LATE = 4;
+    static constexpr int RESULT_DOUBLES = SCAL_N + STATUS_N / 2;
+    double *h_result = nullptr;             // pinned host landing zone for the end-of-call copy (RESULT_DOUBLES)
     bool capturing = false;                 // inside a stream capture: profiling scopes stay silent
     hipEvent_t ev_join = nullptr, ev_sjoin = nullptr;      // temporal / spatial chain finished (recorded on stream2 / stream3)
     // Software pipeline across calls.  The outputs of a side's decomposition (eigenvector blocks, spectra) exist in two
@@ -83,7 +91,7 @@ struct gpcsd_ctx {
     int par[2] = {0, 0};
     hipEvent_t ev_mark[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
     bool async_pending = false;
-    // gpcsd_loglik_parts_async / gpcsd_loglik_predict_async: a result lands in a slot of h_ll (pinned, 66 doubles like
+    // gpcsd_loglik_parts_async / gpcsd_loglik_predict_async: a result lands in a slot of h_ll (pinned, RESULT_DOUBLES like
     // h_result) behind that slot's event; up to LL_SLOTS evaluations may be outstanding, gpcsd_loglik_parts_wait collects
     // them oldest first.  two: the quadratic form came back as two partial sums; done: evaluated at once (profiling on).
     static constexpr int LL_SLOTS = 4;
@@ -93,7 +101,7 @@ struct gpcsd_ctx {
         double out[2] = {0.0, 0.0};
         int rc = 0;
     };
-    double *h_ll = nullptr;                 // LL_SLOTS x 66 doubles
+    double *h_ll = nullptr;                 // LL_SLOTS x RESULT_DOUBLES
     LlSlot ll_slot[LL_SLOTS];
     int ll_head = 0, ll_count = 0;          // oldest outstanding slot, number outstanding
     hipEvent_t ev_aux = nullptr, ev_pc = nullptr;   // predict: small products of the tail on stream2 beside the large ones
@@ -146,6 +154,7 @@ struct gpcsd_ctx {
     gpcsd::SymDev sym_z;
     int lfp_fold_sig = 0;                   // 0: the folded copy of the data is stale; else FoldMode::sig() it was built for
     bool status_zeroed = false;             // the fused calls' status words were cleared at the end of the previous call
+    bool late_dirty = false;                // ... except the late words: a tridiagonal-form log-likelihood returned under its chain's stages 2 / 4
     bool gram_fp32 = false;                 // gpcsd_set_gram_precision(): Gram builders evaluate in float (cfg5 variant)
     bool fold_gemm_on = true;               // gpcsd_fold_gemm()
     int ll_tridiag_mode = 2;                // gpcsd_ll_tridiag(): log-likelihood in the basis U (x) Q -- 0 off, 1 on, 2 by size (capi.hip)

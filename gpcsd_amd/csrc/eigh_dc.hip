@@ -574,6 +574,17 @@ void sytrd_device(gpcsd_ctx *c, double *A, int n, double *d, double *e, double *
     GP_HIP(hipGetLastError());
 }
 
+// Test aid (GPCSD_FAULT_STAGE2=1 in the environment, read once): the divide & conquer stage of a STAGED solve reports failure 3
+// for every replica -- which call surfaces a failure of a stage that a tridiagonal-form log-likelihood does not wait for
+// (tests/test_hip_fullsize.py::test_late_stage_failure_is_reported_by_the_call_that_joins_the_chain).
+__global__ void fault_status_kernel(int *status, int stride, int count) {
+    for (int r = threadIdx.x; r < count; r += blockDim.x) atomicMax(status + (long)r * stride, 3);
+}
+static bool fault_stage2() {
+    static const bool on = getenv("GPCSD_FAULT_STAGE2") && getenv("GPCSD_FAULT_STAGE2")[0] == '1';
+    return on;
+}
+
 void eigh_large_batch(gpcsd_ctx *c, EigProb *probs, int nclass, int *d_status, int status_stride, hipStream_t s, int stage = 0) {
     GP_REQUIRE(nclass >= 1 && nclass <= MAX_BATCH, -3, "eigh: %d problem classes outside [1,%d]", nclass, MAX_BATCH);
     int nmax = 0;
@@ -635,6 +646,11 @@ void eigh_large_batch(gpcsd_ctx *c, EigProb *probs, int nclass, int *d_status, i
         prep_done = wy_fused;
         // (stage 2: the T factors were formed by stage 1, the leaf launch carries leaves only)
         stedc_batch_device(c, sp, nclass, d_status, status_stride, s, (prep_done && stage != 2) ? &wb : nullptr);
+    }
+    if (stage == 2 && fault_stage2() && d_status) {
+        int nrep = 1;
+        for (int i = 0; i < nclass; ++i) nrep = std::max(nrep, probs[i].count);
+        hipLaunchKernelGGL(fault_status_kernel, dim3(1), dim3(64), 0, s, d_status, std::max(status_stride, 1), nrep);
     }
     if (stage == 2) return;                    // the divide & conquer alone: stage 4 finishes behind stage 3's T factors
     if (stage == 4) prep_done = true;

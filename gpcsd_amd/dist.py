@@ -66,12 +66,17 @@ class TrialSharding:
         cache = self.__dict__.setdefault("_staging", {})
         ring = cache.setdefault(key, {"slots": [], "next": 0, "stream": torch.cuda.Stream(device=self._device, priority=-1)})
         if len(ring["slots"]) < self.STAGING_RING:
-            ring["slots"].append((torch.empty(key, dtype=torch.float64).pin_memory(),
-                                  torch.empty(key, dtype=torch.float64, device=self._device), torch.cuda.Event()))
-            host, dev, done = ring["slots"][-1]
+            ring["slots"].append([torch.empty(key, dtype=torch.float64).pin_memory(),
+                                  torch.empty(key, dtype=torch.float64, device=self._device), torch.cuda.Event(), None])
+            slot = ring["slots"][-1]
         else:
-            host, dev, done = ring["slots"][ring["next"] % self.STAGING_RING]
-            done.synchronize()          # the oldest collective of this size: its copies have landed before the block is refilled
+            slot = ring["slots"][ring["next"] % self.STAGING_RING]
+            # the oldest collective of this size: its copies have landed before the block is refilled -- and if its result has
+            # not been read yet, it is copied out for its owner now (an unread closure must never see a later collective's data)
+            slot[2].synchronize()
+            if slot[3] is not None and not slot[3]:
+                slot[3].append(slot[0].numpy().copy())
+        host, dev, done = slot[0], slot[1], slot[2]
         ring["next"] += 1
         stream = ring["stream"]
         host.numpy()[:] = values
@@ -81,9 +86,10 @@ class TrialSharding:
             host.copy_(dev, non_blocking=True)
             done.record(stream)
         taken = []
+        slot[3] = taken                      # the owner of the block's present contents
 
         def result():
-            # the value is copied out at the first read, behind the event: a later refill of the block cannot change it
+            # the value is copied out at the first read, behind the event -- or by the refill of the block, whichever is first
             if not taken:
                 done.synchronize()
                 taken.append(host.numpy().copy())

@@ -29,16 +29,37 @@ _TASK_START, _TASK_NEW_X, _TASK_FG, _TASK_CONVERGENCE, _TASK_STOP = 0, 1, 3, 4, 
 _probed = None                                # available(): None = not probed yet
 
 
+def _probe_problem():
+    """A small bounded problem whose L-BFGS-B run takes several iterations, a line search with more than one evaluation and
+    an active bound: what a change of SciPy's `task` codes or argument semantics would disturb."""
+    A = np.array([[3.0, 0.6, 0.0], [0.6, 2.0, -0.4], [0.0, -0.4, 1.5]])
+    b = np.array([1.0, -2.0, 0.5])
+
+    def fg(x):
+        r = A @ x - b
+        f = 0.5 * float(r @ r) + 0.1 * float(np.sum(x ** 4))
+        return f, A.T @ r + 0.4 * x ** 3
+    return fg, np.array([2.0, 1.5, 1.0]), [(-5.0, 5.0), (None, None), (0.3, None)], {"maxiter": 50}
+
+
 def available():
-    """True when SciPy's compiled L-BFGS-B exposes the reverse-communication entry point with the 1.15 `task` arrays."""
+    """True when SciPy's compiled L-BFGS-B exposes the reverse-communication entry point AND stepping it through this driver
+    reproduces `scipy.optimize.minimize(method="L-BFGS-B")` on a probe problem exactly -- x, fun, message and the iteration /
+    evaluation counts.  A SciPy that keeps the private name but changes the protocol fails the comparison and fit() falls back
+    (with a RuntimeWarning) to the thread rendezvous around unmodified minimize() calls."""
     global _probed
     if _probed is None:
         _probed = False
         if _slb is not None and hasattr(_slb, "setulb"):
-            try:                              # one tiny minimisation through the driver itself
-                out, _ = minimize_many(lambda items: {k: (float(x @ x), 2.0 * x) for k, x in items}, [np.array([1.0, -2.0])],
-                                       [(-5.0, 5.0), (None, None)], {"maxiter": 5}, width=1)
-                _probed = (not isinstance(out[0], Exception)) and bool(np.isfinite(out[0][0]))
+            try:
+                from scipy.optimize import minimize
+                fg, x0, bounds, opts = _probe_problem()
+                ref = minimize(fg, x0, jac=True, method="L-BFGS-B", bounds=bounds, options=opts)
+                out, stats = minimize_many(lambda items: {k: fg(x) for k, x in items}, [x0], bounds, opts, width=1)
+                got = out[0]
+                msg = ref.message if isinstance(ref.message, str) else ref.message.decode()
+                _probed = (not isinstance(got, Exception) and got[0] == ref.fun and np.array_equal(got[1], ref.x)
+                           and got[2] == msg and stats["points"] == ref.nfev)
             except Exception:
                 _probed = False
     return _probed

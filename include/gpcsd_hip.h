@@ -289,6 +289,12 @@ int gpcsd_fold_gemm(gpcsd_ctx *ctx, int on, long *calls);
  *     costs 2-10 %),
  * < 0 only queries; GPCSD_LL_TRIDIAG=0|1|2 sets the mode of new contexts.  *calls counts the log-likelihoods evaluated this
  * way.  DESIGN.md 9. */
+/* Status of the stages such a log-likelihood does not wait for: the temporal chain's divide & conquer and back-transformation
+ * keep running on the chain's stream when a synchronous gpcsd_loglik / gpcsd_loglik_parts in this form returns (the one case in
+ * which the context is not idle behind a value-returning call; every later call is ordered behind them as usual).  They report
+ * into status words of their own, which only a call that JOINS that chain collects -- a prediction reusing it through the
+ * decomposition cache, or any call in the eigenvector form: a failure there is that call's rc > 0, never this log-likelihood's
+ * (whose value does not depend on them) and never an unrelated later call's. */
 int gpcsd_ll_tridiag(gpcsd_ctx *ctx, int on, long *calls);
 
 /* ---- several devices from ONE process ------------------------------------------------------- */

@@ -141,3 +141,19 @@ def test_cpulist_parser_and_numa_binding_is_a_noop_without_a_gpu():
     if not torch.cuda.is_available():
         assert _hip.bind_host_to_device_numa(0) is None
         assert os.sched_getaffinity(0) == before
+
+
+def test_bench_gpus_flag_is_honoured_without_a_gpu():
+    """`bench.py --gpus N` must mean N ranks: under a launcher whose WORLD_SIZE differs it refuses; without a launcher it starts
+    the ranks itself -- here, with no GPU, that stops at the device count with exit code 2 (nothing is launched)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "GPCSD_DEVICE", "GPCSD_BENCH_BACKEND")}
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "4"], cwd=root, env=dict(env, WORLD_SIZE="2", RANK="0"),
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "--gpus 4" in r.stderr and "WORLD_SIZE=2" in r.stderr
+    import torch
+    if torch.cuda.device_count() < 2:
+        r = subprocess.run([sys.executable, "bench.py", "--gpus", "2"], cwd=root, env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 2 and "one rank per GPU" in r.stderr and not r.stdout.strip()

@@ -838,11 +838,22 @@ def test_bench_step_two_ranks_gloo_on_one_gpu():
     rehearsed with two ranks sharing the one GPU of the test box over gloo: the global log-likelihood the two ranks report
     equals the single-process evaluation of the same 2 x 4 trials."""
     env = dict(os.environ, GPCSD_BENCH_BACKEND="gloo", GPCSD_DEVICE="0", MASTER_ADDR="127.0.0.1")
-    port = 29500 + os.getpid() % 400
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
     common = ["--steps", "2", "--warmup", "1", "--setup-steps", "3", "--trials-per-gpu", "4", "--no-cpu-baseline"]
-    two = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-                "127.0.0.1", "--master-port", str(port), "bench.py", "--gpus", "2"] + common, env)
+    # the driver's own command form: no launcher in front -- bench.py starts its two ranks itself (a fresh torch.distributed.run
+    # child of a parent that never touched the GPU) and relays rank 0's line
+    two = _run([sys.executable, "bench.py", "--gpus", "2"] + common, env)
     assert two["n_gpus"] == 2 and two["config"]["total_trials"] == 8 and two["value"] > 0 and two["setup_steps"] == 3
+    d = two["distributed"]
+    assert d["ranks"] == 2 and d["collective_backend"] == "gloo" and d["rccl_ranks"] == 0 and len(d["per_rank_ms_per_step"]) == 2
+    assert all(v > 0 for v in d["per_rank_ms_per_step"] + d["per_rank_ms_per_step_without_collectives"])
+    assert 0.0 < d["scaling_efficiency"] < 1.5
+    # ... and under an explicit launcher (how the driver starts N > 1) the same line comes back
+    port = 29500 + os.getpid() % 400
+    again = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                  "127.0.0.1", "--master-port", str(port), "bench.py", "--gpus", "2"] + common + ["--only-value"], env)
+    assert again["n_gpus"] == 2 and again["loglik"] == two["loglik"]
     sys.path.insert(0, ROOT)
     import bench
     w = bench.workload("cfg3")
@@ -977,3 +988,97 @@ def test_host_numa_binding_in_a_child_process():
     if out["r"] is not None:                                      # a host with one node (or no sysfs) is left alone
         assert out["same"] and out["n_after"] == out["r"]["cpus"] <= out["n_before"]
         assert len(out["r"]["pci"].split(":")) == 3
+
+
+_LATE_STATUS_PROBE = r'''
+import json, sys
+import numpy as np
+sys.path.insert(0, "tests"); sys.path.insert(0, "tests/golden")
+import cases as C
+from helpers import load_model_case
+import test_hip_fullsize as T
+from gpcsd_amd import _hip
+c, g, geom, hp, _ = load_model_case("cfg3s_2d_384x500x2")
+lfp = C.synth_lfp(77, 384, 500, 2)
+m = T._model_from_case(c, g, lfp)
+ctx = m._sync_device()
+ctx.ll_tridiag(1)
+h1, k1 = m._hparams(m.JITTER)
+h0, k0 = m._hparams(0.0)
+res = {}
+def attempt(name, fn):
+    try:
+        fn(); res[name] = "ok"
+    except np.linalg.LinAlgError:
+        res[name] = "LinAlgError"
+ctx.decomposition_cache(False)
+n0 = ctx.ll_tridiag()
+attempt("tri_loglik_1", lambda: ctx.loglik_parts(h1))
+attempt("tri_loglik_2", lambda: ctx.loglik_parts(h1))
+res["tri_calls"] = ctx.ll_tridiag() - n0
+attempt("sync_predict", lambda: m.predict(c["x"], c["t"], type="csd"))
+attempt("tri_loglik_3", lambda: ctx.loglik_parts(h1))
+def queued():
+    ctx.predict_resident(h0, c["x"], c["t"], _hip.PRED_CSD)
+    ctx.synchronize()
+attempt("queued_predict_then_synchronize", queued)
+attempt("tri_loglik_4", lambda: ctx.loglik_parts(h1))
+ctx.ll_tridiag(0)                       # the eigenvector form right behind a tridiagonal-form call: unstaged chain, clean words
+attempt("eig_loglik_after_tri", lambda: ctx.loglik_parts(h1))
+ctx.ll_tridiag(1)
+ctx.decomposition_cache(True)           # predict reusing the temporal chain of the log-likelihood before it: that chain's late failure
+m.temporal_cov_list[0].params["ell"]["value"] *= 1.01      # a temporal problem no earlier call has left in the cache
+h1, k1 = m._hparams(m.JITTER)
+hits0 = ctx.decomposition_cache()
+attempt("tri_loglik_5", lambda: ctx.loglik_parts(h1))
+res["tri_calls_5"] = ctx.ll_tridiag() - n0
+attempt("sync_predict_on_cached_chain", lambda: m.predict(c["x"], c["t"], type="csd"))
+res["cache_hits_of_the_last_predict"] = ctx.decomposition_cache() - hits0
+print(json.dumps(res))
+'''
+
+
+@pytest.mark.timeout(600)
+def test_late_stage_failure_is_reported_by_the_call_that_joins_the_chain():
+    """ADVICE r3: a synchronous log-likelihood in the tridiagonal form returns while stages 2 and 4 of its temporal chain (divide
+    & conquer, back-transformation) are still running.  A failure of those stages (injected: GPCSD_FAULT_STAGE2=1) concerns
+    results that call never read: it must neither fail that call nor be charged to the next one -- it belongs to the call that
+    joins the chain (a prediction), and only to that one."""
+    r = subprocess.run([sys.executable, "-c", _LATE_STATUS_PROBE], cwd=ROOT, env=dict(os.environ, GPCSD_FAULT_STAGE2="1"),
+                       capture_output=True, text=True, timeout=500)
+    assert r.returncode == 0, r.stderr[-3000:]
+    res = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    print(res)
+    assert res["tri_calls"] == 2 and res["tri_calls_5"] == 5 and res["cache_hits_of_the_last_predict"] >= 1
+    for k in ("tri_loglik_1", "tri_loglik_2", "tri_loglik_3", "tri_loglik_4", "tri_loglik_5", "eig_loglik_after_tri"):
+        assert res[k] == "ok", (k, res)
+    for k in ("sync_predict", "queued_predict_then_synchronize", "sync_predict_on_cached_chain"):
+        assert res[k] == "LinAlgError", (k, res)
+
+
+_RING_PROBE = r'''
+import os, json
+os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "%d")
+os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
+import numpy as np, torch, torch.distributed as td
+torch.cuda.set_device(0)
+td.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+from gpcsd_amd.dist import TrialSharding
+sh = TrialSharding()
+n = 3 * TrialSharding.STAGING_RING + 1
+pending = [sh.allreduce_sum_async(np.array([float(i), -2.0 * i])) for i in range(n)]      # none read before all are issued
+got = [p().tolist() for p in pending]
+print(json.dumps({"got": got, "again": pending[0]().tolist()}))
+td.destroy_process_group()
+'''
+
+
+@pytest.mark.timeout(600)
+def test_async_allreduce_ring_keeps_unread_results_apart():
+    """ADVICE r3 (dist.py): more asynchronous all-reduces of one size outstanding than the staging ring has slots, none read
+    until all are issued -- every closure still returns its own collective's sum (one RCCL rank: the sum is the input)."""
+    r = subprocess.run([sys.executable, "-c", _RING_PROBE % (31000 + os.getpid() % 400)], cwd=ROOT, env=dict(os.environ),
+                       capture_output=True, text=True, timeout=500)
+    assert r.returncode == 0, r.stderr[-3000:]
+    res = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert res["got"] == [[float(i), -2.0 * i] for i in range(len(res["got"]))] and res["again"] == [0.0, 0.0]
