@@ -400,6 +400,10 @@ def main():
         else:
             td.init_process_group(backend, rank=rank, world_size=world)
 
+    if args.workload == "potrf":                      # the dense Cholesky path on its own (the command profiled as r04_*_potrf)
+        if rank == 0:
+            print(json.dumps(potrf_bench()))
+        return
     w = workload(args.workload)
     if args.workload == "cfg5":
         out = run_fit_bench(args, w, rank, world, local_rank, backend)
@@ -422,6 +426,34 @@ def main():
         out["host_affinity"] = ({"bound_to_numa_node": host_numa["node"], "cpus": host_numa["cpus"], "device_pci": host_numa["pci"]}
                                 if host_numa else {"bound_to_numa_node": None, "cpus": len(os.sched_getaffinity(0))})
         print(json.dumps(out))
+
+
+def potrf_bench(n=12000, reps=3):
+    """The dense Cholesky path (north_star: "(Ks (x) Kt + sig2 I) Cholesky factor, log-det and triangular solves") at the one size of
+    BASELINE's configurations where the dense matrix fits one GPU -- cfg2's N = 24 x 500 = 12 000 (1.15 GB): the blocked factorisation
+    on a device-resident SPD matrix (gpcsd_potrf_bench: HIP events on the library's stream around the factorisation alone), n^3 / 3
+    flops against the fp64 MFMA peak, with the event-scope split of one profiled factorisation."""
+    from gpcsd_amd import _hip
+    ctx = _hip.default_context()
+    ms, tf = ctx.potrf_bench(n, reps=reps)
+    ctx.prof_reset()
+    ctx.prof_enable(1)
+    ctx.potrf_bench(n, reps=1)
+    ctx.prof_enable(0)
+    prof = {k: v for k, v in ctx.prof_all().items() if k.startswith("potrf") and v["count"]}
+    # (the profiled call factors twice: one untimed repetition + one)
+    split = {k: {"ms": v["ms"] / 2.0, "launches": v["count"] // 2,
+                 "tflops": ((v["flops"] / 2.0) / (v["ms"] / 2.0 * 1e-3) / 1e12) if (v["ms"] and v["flops"]) else None} for k, v in prof.items()}
+    tu = split.get("potrf_syrk", {})
+    out = {"metric": "gpcsd_dense_cholesky_factorisations_per_sec", "value": 1e3 / ms, "unit": "factorisations/s", "n": n, "ms": ms,
+           "dtype": "f64", "flops": n ** 3 / 3.0, "tflops": tf, "frac_of_fp64_mfma_peak": tf / FP64_MFMA_SPEC_TFLOPS,
+           "trailing_update": {"kernel": "gemm_f64_kernel<EPI_SUB, lower> [potrf_syrk]: rank-256 update A22 -= L21 L21^T, tiles on or "
+                                         "below the diagonal", "ms": tu.get("ms"), "launches": tu.get("launches"),
+                               "tflops": tu.get("tflops"), "frac": (tu.get("tflops") or 0.0) / FP64_MFMA_SPEC_TFLOPS},
+           "scopes": split, "diag128_phases_us": ctx.potrf_diag_probe(),
+           "config": {"workload": "blocked Cholesky of a %d x %d SPD matrix resident in HBM (N of BASELINE cfg2: 24 x 500)" % (n, n)}}
+    out["headline"] = {"ms": ms, "frac": out["frac_of_fp64_mfma_peak"], "trailing_update_frac": out["trailing_update"]["frac"]}
+    return out
 
 
 def sub_results(args, local_rank, backend):
@@ -448,6 +480,10 @@ def sub_results(args, local_rank, backend):
                                           "batched_over_sequential", "fit", "fit_threads_driver", "parity") if k in r}
     except Exception as e:
         out["cfg5"] = {"error": repr(e)}
+    try:
+        out["potrf"] = potrf_bench()
+    except Exception as e:
+        out["potrf"] = {"error": repr(e)}
     out["seconds_spent"] = time.perf_counter() - t0
     return out
 

@@ -201,6 +201,8 @@ SIGNATURES = {
     "gpcsd_mfma_f64_peak": (_I, [_P, _DP]),
     "gpcsd_hbm_copy_peak": (_I, [_P, _L, _DP]),
     "gpcsd_gemm_bench": (_I, [_P, _I, _I, _I, _I, _I, _I, _I, _DP]),
+    "gpcsd_potrf_bench": (_I, [_P, _I, _I, _DP]),
+    "gpcsd_potrf_diag_probe": (_I, [_P, _DP]),
 }
 
 
@@ -781,6 +783,19 @@ class Context:
         self._check(self._lib.gpcsd_gemm_bench(self._h, int(transA), int(transB), int(M), int(N), int(K), int(cfg), int(reps),
                                                ctypes.byref(out)))
         return out.value, 2.0 * M * N * K / (out.value * 1e-3) / 1e12
+
+    def potrf_bench(self, n, reps=3):
+        """(ms per factorisation, TFLOP/s in n^3 / 3 flops) of the blocked Cholesky on a device-resident SPD matrix of order n."""
+        out = ctypes.c_double()
+        self._check(self._lib.gpcsd_potrf_bench(self._h, int(n), int(reps), ctypes.byref(out)))
+        return out.value, (n ** 3 / 3.0) / (out.value * 1e-3) / 1e12
+
+    def potrf_diag_probe(self):
+        """Phase split (us) of the 128 x 128 factor + invert workgroup of the blocked Cholesky."""
+        out = np.zeros(10)
+        self._check(self._lib.gpcsd_potrf_diag_probe(self._h, _ptr(out)))
+        return dict(zip(["load", "serial_panels", "rank16_updates", "store_L", "diag_inverses", "level16", "level32", "level64",
+                         "store_X", "total"], out.tolist()))
 
     def hbm_copy_peak(self, nbytes=1 << 30):
         out = ctypes.c_double()

@@ -854,6 +854,8 @@ extern "C" int gpcsd_ctx_create(int device, gpcsd_ctx **out) {
         GP_HIP(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
         GP_HIP(hipEventCreateWithFlags(&c->ev_aux, hipEventDisableTiming));
         GP_HIP(hipEventCreateWithFlags(&c->ev_pc, hipEventDisableTiming));
+        GP_HIP(hipEventCreateWithFlags(&c->ev_chol_a, hipEventDisableTiming));
+        GP_HIP(hipEventCreateWithFlags(&c->ev_chol_d, hipEventDisableTiming));
         GP_HIP(hipEventCreateWithFlags(&c->ev_q, hipEventDisableTiming));
         GP_HIP(hipEventCreateWithFlags(&c->ev_t1, hipEventDisableTiming));
         GP_HIP(hipEventCreateWithFlags(&c->ev_tri_done, hipEventDisableTiming));
@@ -892,6 +894,8 @@ extern "C" int gpcsd_ctx_destroy(gpcsd_ctx *c) {
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     if (c->ev_aux) (void)hipEventDestroy(c->ev_aux);
     if (c->ev_pc) (void)hipEventDestroy(c->ev_pc);
+    if (c->ev_chol_a) (void)hipEventDestroy(c->ev_chol_a);
+    if (c->ev_chol_d) (void)hipEventDestroy(c->ev_chol_d);
     if (c->ev_q) (void)hipEventDestroy(c->ev_q);
     if (c->ev_t1) (void)hipEventDestroy(c->ev_t1);
     if (c->ev_tri_done) (void)hipEventDestroy(c->ev_tri_done);

@@ -148,3 +148,80 @@ extern "C" int gpcsd_hbm_copy_peak(gpcsd_ctx *c, long bytes, double *gbs) {
     return 0;
     GP_API_END(c)
 }
+
+
+// Device-resident timing of the blocked Cholesky (chol.hip) at order n: a well-conditioned SPD test matrix is generated on the
+// device before every repetition (A_ij = exp(-|i - j| / 64) + [i == j]: an exponential-kernel Gram matrix plus a unit nugget),
+// HIP events on the call's stream bracket potrf_device alone.  ms_out: mean over reps (after one untimed repetition).  With
+// profiling enabled (gpcsd_prof_enable(ctx, 1)) the scopes potrf_diag_block / potrf_panel / potrf_syrk* / potrf_inv split it.
+__global__ void spd_test_matrix_kernel(double *A, int n) {
+    const long e = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (e < (long)n * n) {
+        const int i = (int)(e / n), j = (int)(e % n);
+        const double d = (double)(i > j ? i - j : j - i);
+        A[e] = exp(-d / 64.0) + (i == j ? 1.0 : 0.0);
+    }
+}
+
+extern "C" int gpcsd_potrf_bench(gpcsd_ctx *c, int n, int reps, double *ms_out) {
+    GP_API_BEGIN(c)
+    GP_REQUIRE(ms_out != nullptr && n >= 1 && n <= 32768 && reps >= 1, -3, "potrf_bench: bad arguments");
+    double *A = c->buf<double>("dense_K", (size_t)n * n);
+    int *st = c->buf<int>("status", 4);
+    hipStream_t s = c->stream;
+    GP_HIP(hipMemsetAsync(st, 0, 4 * sizeof(int), s));
+    hipEvent_t e0 = c->get_event(), e1 = c->get_event();
+    double total = 0.0;
+    for (int r = 0; r <= reps; ++r) {
+        hipLaunchKernelGGL(spd_test_matrix_kernel, dim3(ceil_div((long)n * n, 256)), dim3(256), 0, s, A, n);
+        GP_HIP(hipEventRecord(e0, s));
+        potrf_device(c, A, n, st, s);
+        GP_HIP(hipEventRecord(e1, s));
+        GP_HIP(hipEventSynchronize(e1));
+        float ms = 0.f;
+        GP_HIP(hipEventElapsedTime(&ms, e0, e1));
+        if (r > 0) total += ms;
+    }
+    c->event_pool.push_back(e0);
+    c->event_pool.push_back(e1);
+    *ms_out = total / reps;
+    return finish_status(c, st);
+    GP_API_END(c)
+}
+
+// Phase split of the 128 x 128 factor + invert workgroup (chol.hip: diag128_kernel) on the leading block of the SPD test matrix:
+// out10 = {load, serial panels, rank-16 updates, store L, diagonal inverses, level 16, level 32, level 64, store X, total} in us.
+extern "C" int gpcsd_potrf_diag_probe(gpcsd_ctx *c, double *out10) {
+    GP_API_BEGIN(c)
+    GP_REQUIRE(out10 != nullptr, -3, "null output");
+    const int n = 128;
+    double *A = c->buf<double>("dense_K", (size_t)n * n);
+    double *X = c->buf<double>("chol_Linv", (size_t)256 * 256);
+    int *st = c->buf<int>("status", 4);
+    unsigned long long *clk = c->buf<unsigned long long>("diag_clk", 16);
+    hipStream_t s = c->stream;
+    GP_HIP(hipMemsetAsync(st, 0, 4 * sizeof(int), s));
+    unsigned long long h[16];
+    for (int rep = 0; rep < 3; ++rep) {
+        hipLaunchKernelGGL(spd_test_matrix_kernel, dim3(ceil_div((long)n * n, 256)), dim3(256), 0, s, A, n);
+        GP_HIP(hipMemsetAsync(clk, 0, 16 * sizeof(unsigned long long), s));
+        potrf_diag128_probe(c, A, n, X, st, clk, s);
+        c->download(h, clk, sizeof(h));
+        c->sync();
+    }
+    int rate_khz = 0;
+    GP_HIP(hipDeviceGetAttribute(&rate_khz, hipDeviceAttributeWallClockRate, c->device));
+    const double us = 1e3 / (double)rate_khz;
+    out10[0] = (h[1] - h[0]) * us;
+    out10[1] = h[2] * us;
+    out10[2] = h[3] * us;
+    out10[3] = (h[4] - h[1]) * us - out10[1] - out10[2];
+    out10[4] = (h[5] - h[4]) * us;
+    out10[5] = (h[6] - h[5]) * us;
+    out10[6] = (h[7] - h[6]) * us;
+    out10[7] = (h[8] - h[7]) * us;
+    out10[8] = (h[9] - h[8]) * us;
+    out10[9] = (h[9] - h[0]) * us;
+    return finish_status(c, st);
+    GP_API_END(c)
+}

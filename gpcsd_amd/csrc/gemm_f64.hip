@@ -55,6 +55,7 @@ struct GemmK {
     int m_fastest;      // logical tile order: 1 = tile_m varies fastest (few row tiles, many column tiles)
     int n_group;        // otherwise: n-tiles per sweep over the row panels
     const int *dyn;     // optional device scalar: effective N and K (= *dyn) of this launch (D&C merge GEMMs)
+    int lower;          // 1: tiles strictly above the diagonal of C are skipped (symmetric rank-k update, lower triangle wanted)
     const double *kscale;   // optional: A's element at contracted index k is multiplied by kscale[k] on its way to LDS
     long sKscale, sKscale2;
     // outer batch level (GemmDesc::batch2): grid z = z2 * batch1 + z1
@@ -167,12 +168,21 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f64_kernel(GemmK g) {
     long bz = blockIdx.z;
     {
         const int total = gridDim.x * gridDim.z;
-        if (total >= 64) {
+        if (total >= 64 && !g.lower) {
             const int L = blockIdx.z * gridDim.x + blockIdx.x;
             const int x = L & 7, q = total >> 3, r = total & 7;
             const int logical = x * q + (x < r ? x : r) + (L >> 3);
             bz = logical / gridDim.x;
             bx = logical % gridDim.x;
+        } else if (total >= 64) {
+            // lower-triangular update: the tiles above the diagonal exit at once, and they are not spread evenly over the logical
+            // order (the first n-groups run nearly all their tiles, the last ones nearly none) -- one contiguous range per XCD
+            // left XCD 0 with twice the average work and XCD 7 with none (31 TF/s).  Chunks of one row panel's n-group (the
+            // tiles that share an A panel) are dealt round-robin to the XCDs instead.
+            const int L = blockIdx.x;                        // (within one batch entry: blockIdx.z stays)
+            const int x = L & 7, slot = L >> 3, ch = g.n_group;
+            const int full = ((int)gridDim.x >> 3) / ch * ch * 8;     // tiles covered by whole rounds of 8 chunks
+            if (L < full) bx = ((slot / ch) * 8 + x) * ch + slot % ch;
         }
     }
     // consecutive logical tiles share the operand panel of the LONGER tile dimension, so that panel is fetched from HBM
@@ -192,6 +202,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f64_kernel(GemmK g) {
         tile_n = n_first + rem - tile_m * ng;
     }
     const int m0 = tile_m * BM, n0 = tile_n * BN;
+    if (g.lower && n0 > m0 + BM - 1) return;      // wave-uniform: no entry of this tile lies on or below the diagonal
     // two batch levels: z1 the inner entry (stride s?), z2 the outer one (stride s?2; replicas of a hyper-parameter batch)
     long z1 = bz, z2 = 0;
     if (g.batch1 > 0) {                 // wave-uniform; only launches with an outer level pay the division
@@ -212,6 +223,22 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f64_kernel(GemmK g) {
     for (int i = 0; i < FM; ++i)
 #pragma unroll
         for (int j = 0; j < FN; ++j) acc[i][j] = d4{0.0, 0.0, 0.0, 0.0};
+
+    if (EPI == EPI_SUB) {                 // accumulators start as -C: issued in front of the first operand tile's loads
+        const double *__restrict__ Cin = g.C + z1 * g.sC + z2 * g.sC2;
+        const int colb = n0 + wc * 16 * FN + (lane & 15), rowb = m0 + wr * 16 * FM + (lane >> 4);
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = rowb + 16 * i + 4 * r;
+#pragma unroll
+                for (int j = 0; j < FN; ++j) {
+                    const int col = colb + 16 * j;
+                    if (row < g.M && col < g.N) acc[i][j][r] = -Cin[(long)row * g.ldc + col];
+                }
+            }
+    }
 
     double ra[TileA::PER_THREAD], rb[TileB::PER_THREAD];
     unsigned offA[TileA::PER_THREAD], offB[TileB::PER_THREAD];
@@ -365,13 +392,13 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f64_kernel(GemmK g) {
     // ---- epilogue ----
     double qsum = 0.0, qsum2 = 0.0;
     const long offC = z1 * g.sC + z2 * g.sC2;
-    double *__restrict__ C = (EPI == EPI_QUAD) ? nullptr : g.C + offC;
+    double *C = (EPI == EPI_QUAD) ? nullptr : g.C + offC;
     const double *__restrict__ Dz = g.D + z1 * g.sD + z2 * g.sD2;
     double *__restrict__ C2 = (EPI == EPI_GRAD && g.C2) ? g.C2 + offC : nullptr;      // (optional: callers that scale at the
     double *__restrict__ C3 = (EPI == EPI_GRAD && g.C3) ? g.C3 + offC : nullptr;      //  consumer's load -- kscale -- skip the copies)
     const double *__restrict__ colscale = g.colscale ? g.colscale + z1 * g.sColscale + z2 * g.sColscale2 : nullptr;
     const double *__restrict__ rowscale = (EPI == EPI_GRAD) ? g.rowscale + z2 * g.sRowscale2 : nullptr;
-    if (EPI == EPI_STORE) {
+    if (EPI == EPI_STORE || EPI == EPI_SUB) {
         // The plain store is the hot epilogue: every VALU instruction here is taken from the MFMAs of the workgroups that
         // share the SIMD, so the per-column factor (alpha, optional column scale) and the validity of the FN columns are
         // formed once, rows advance by pointer increments, and the FN stores of a row use immediate offsets.
@@ -774,6 +801,13 @@ static void launch_epi(const GemmK &k, int epi, dim3 grid, hipStream_t s) {
         case EPI_QUAD: hipLaunchKernelGGL((gemm_f64_kernel<WM, WN, FM, FN, BK, TA, TB, EPI_QUAD>), grid, blk, 0, s, k); break;
         case EPI_ACCUM: hipLaunchKernelGGL((gemm_f64_kernel<WM, WN, FM, FN, BK, TA, TB, EPI_ACCUM>), grid, blk, 0, s, k); break;
         case EPI_GRAD: hipLaunchKernelGGL((gemm_f64_kernel<WM, WN, FM, FN, BK, TA, TB, EPI_GRAD>), grid, blk, 0, s, k); break;
+        case EPI_SUB:
+            if constexpr (!TA && TB) {
+                hipLaunchKernelGGL((gemm_f64_kernel<WM, WN, FM, FN, BK, TA, TB, EPI_SUB>), grid, blk, 0, s, k);
+                break;
+            } else {
+                throw HipError{-3, "gemm_f64: EPI_SUB is instantiated for A (M,K), B (N,K) only"};
+            }
         default: throw HipError{-3, "gemm_f64: bad epilogue"};
     }
 }
@@ -812,9 +846,10 @@ void gemm_f64(gpcsd_ctx *c, const GemmDesc &g, hipStream_t s) {
     k.A = g.A; k.lda = g.lda; k.B = g.B; k.ldb = g.ldb; k.C = g.C; k.ldc = g.ldc; k.C2 = g.C2; k.C3 = g.C3;
     k.colscale = g.colscale; k.rowscale = g.rowscale; k.sColscale = g.sColscale;
     k.sA = g.sA; k.sB = g.sB; k.sC = g.sC;
-    k.alpha = g.alpha; k.D = g.D; k.rdiv = g.rdiv > 0 ? g.rdiv : 1; k.ldd = g.ldd; k.sD = g.sD;
+    k.alpha = g.epi == EPI_SUB ? -1.0 : g.alpha; k.D = g.D; k.rdiv = g.rdiv > 0 ? g.rdiv : 1; k.ldd = g.ldd; k.sD = g.sD;
     k.partials = nullptr;
     k.dyn = g.dyn;
+    k.lower = g.lower ? 1 : 0;
     k.kscale = g.kscale; k.sKscale = g.sKscale; k.sKscale2 = g.sKscale2;
     const int batch2 = g.batch2 > 1 ? g.batch2 : 1;
     k.batch1 = batch2 > 1 ? g.batch : 0;
@@ -853,7 +888,12 @@ void gemm_f64(gpcsd_ctx *c, const GemmDesc &g, hipStream_t s) {
     const long nblocks = (long)tm * tn * g.batch * batch2;
     if (g.epi == EPI_QUAD || g.epi == EPI_GRAD) k.partials = c->buf<double>("gemm_partials", 2 * nblocks);
 
-    const double flops = 2.0 * g.M * (double)g.N * g.K * g.batch * batch2;
+    double flops = 2.0 * g.M * (double)g.N * g.K * g.batch * batch2;
+    if (g.lower) {                                  // count the tiles that run (on or below the diagonal), whole tiles
+        long run = 0;
+        for (int i = 0; i < tm; ++i) run += std::min<long>(tn, ((long)i * bm + bm - 1) / bn + 1);
+        flops = 2.0 * (double)run * bm * bn * g.K * g.batch * batch2;
+    }
     {
         ProfScope ps(c, g.prof_name, flops, s);
         if (k.kscale) {

@@ -11,7 +11,10 @@ enum Epi : int {
     EPI_QUAD = 2,    // no store; partial sums of acc^2 * D[...] (reciprocals; deterministic two-stage reduce)
     EPI_ACCUM = 3,   // C += alpha * acc
     EPI_GRAD = 4,    // b = acc * D (reciprocals): C = b, C2 = b*colscale[col], C3 = b*rowscale[row/rdiv]; sums of acc*b and b*b
-    EPI_DUAL_INIT = 6  // C = alpha*acc and C2 = alpha*acc (first term of a running sum: no read, no zero fill)
+    EPI_DUAL_INIT = 6, // C = alpha*acc and C2 = alpha*acc (first term of a running sum: no read, no zero fill)
+    EPI_SUB = 7        // C = C - acc with C read at the START of the tile (accumulators initialised to -C, plain-store epilogue with
+                       // alpha = -1): the rank-k trailing updates of the Cholesky -- EPI_ACCUM's read-modify-write sits at the end
+                       // of a tile, where nothing hides its latency.  A (M,K) row-major, B stored (N,K) only.
 };
 
 struct GemmDesc {
@@ -50,6 +53,7 @@ struct GemmDesc {
     int extra_sum_n = 0;                     //   (sum_small_kernel's association: bit-identical to k_build_D's own sum)
     double *extra_sum_out = nullptr;
     const int *dyn = nullptr;     // device int per batch entry: effective N = K = dyn[batch] (tiles beyond it exit)
+    bool lower = false;           // square symmetric update (C and its mirror image equal): tiles strictly above the diagonal exit at once
     int cfg = 0;                  // 0 = choose the tile configuration automatically, 1 / 2 / 3 / 5 = force (see gemm_f64.hip)
     const char *prof_name = "gemm_f64";
 };
@@ -307,6 +311,7 @@ void k_fwdR_grad(gpcsd_ctx *c, const double *S, const double *x, int nx, const d
 // ---------------------------------------------------------------- Cholesky (chol.hip)
 // In-place lower Cholesky of A (n,n) row-major; strictly-upper part zeroed.  d_status: 0 ok, k+1 = pivot k <= 0.
 void potrf_device(gpcsd_ctx *c, double *A, int n, int *d_status, hipStream_t s);
+void potrf_diag128_probe(gpcsd_ctx *c, double *A, int n, double *X, int *d_status, unsigned long long *clk_dev, hipStream_t s);
 // X = L^{-1} B in place (B (n,nrhs) row-major)
 void trsm_lower_device(gpcsd_ctx *c, const double *L, int n, double *B, int nrhs, hipStream_t s);
 void logdet_chol_device(gpcsd_ctx *c, const double *L, int n, double *out, hipStream_t s);

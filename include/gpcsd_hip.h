@@ -349,6 +349,13 @@ int gpcsd_mfma_f64_peak(gpcsd_ctx *ctx, double *tflops);
 /* average ms per launch of the fp64 MFMA GEMM on device-resident pseudo-random operands; cfg 0 = automatic tile
  * configuration, 1..6 = forced (tuning aid) */
 int gpcsd_gemm_bench(gpcsd_ctx *ctx, int transA, int transB, int M, int N, int K, int cfg, int reps, double *ms_out);
+/* average ms of the blocked Cholesky (numpy.linalg.cholesky of gpcsd1d.py:303-304 / gpcsd2d.py:343-350; the dense cross-check's
+ * factor at N = nx * nt) on a device-resident, device-generated SPD test matrix of order n; events on the call's own stream
+ * around the factorisation alone.  Kernel split through the profiling scopes (potrf_*). */
+int gpcsd_potrf_bench(gpcsd_ctx *ctx, int n, int reps, double *ms_out);
+/* phase split (us) of the one-workgroup 128 x 128 factor + invert launch inside that Cholesky: {load, serial panels, rank-16
+ * MFMA updates, store L, diagonal-block inverses, doubling levels 16 / 32 / 64, store X, total} -- a tuning aid */
+int gpcsd_potrf_diag_probe(gpcsd_ctx *ctx, double *out10);
 /* streaming copy microbenchmark over `bytes` bytes: measured GB/s (read+write counted) */
 int gpcsd_hbm_copy_peak(gpcsd_ctx *ctx, long bytes, double *gbs);
 

@@ -1082,3 +1082,47 @@ def test_async_allreduce_ring_keeps_unread_results_apart():
     assert r.returncode == 0, r.stderr[-3000:]
     res = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     assert res["got"] == [[float(i), -2.0 * i] for i in range(len(res["got"]))] and res["again"] == [0.0, 0.0]
+
+
+# ------------------------------------------------------------------------------------------------ dense Cholesky path at N = 12 000
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("n", [4096, 12000])
+def test_potrf_large_vs_numpy(n):
+    """the blocked Cholesky (two block levels, look-ahead; chol.hip) at the sizes the dense cross-check runs at,
+    against numpy.linalg.cholesky (LAPACK dpotrf): 1e-11 of the largest entry, exact zeros above the diagonal, log-determinant."""
+    from gpcsd_amd import _hip
+    ctx = _hip.default_context()
+    i = np.arange(n)
+    A = np.exp(-np.abs(i[:, None] - i[None, :]) / 64.0)               # the bench's test matrix (gpcsd_potrf_bench)
+    A[i, i] += 1.0
+    L = ctx.potrf(A)
+    Lr = np.linalg.cholesky(A)
+    err = float(np.max(np.abs(L - Lr)) / np.max(np.abs(Lr)))
+    print("potrf n=%d: max |L - L_lapack| / max |L| = %.2e" % (n, err))
+    assert err < 1e-11
+    assert np.all(np.triu(L, 1) == 0.0)
+    assert abs(ctx.logdet_chol(L) - 2.0 * np.sum(np.log(np.diag(Lr)))) < 1e-9 * n
+    ms, tf = ctx.potrf_bench(n, reps=2)
+    print("potrf n=%d: %.2f ms, %.1f TF/s (n^3/3 flops) = %.2f of the fp64 MFMA peak" % (n, ms, tf, tf / 78.6))
+
+
+@pytest.mark.timeout(900)
+def test_dense_cholesky_loglik_at_cfg2_geometry_N12000():
+    """The north-star's "(Ks (x) Kt + sig2 I) Cholesky factor, log-det and triangular solves" at the one size of BASELINE's
+    configurations where the dense matrix fits (cfg2: 24 x 500, N = 12 000; 1.15 GB): gpcsd_loglik_dense_chol on the 8 golden
+    trials of cfg2s_1d_24x500x8 = the Kronecker-eigen log-likelihood of the library = the oracle = the reference's golden value,
+    1e-9 relative (gpcsd1d.py:113-128; the dense form is the textbook GP marginal likelihood the reference's identity replaces)."""
+    import test_hip_parity as T
+    m, c, g, geom, hp, lfp = T._build_model("cfg2s_1d_24x500x8")
+    assert lfp.shape == (24, 500, 8)
+    ctx = m._sync_device()
+    Ks = m.spatial_cov.compKphi_1d(m.R["value"]) + m.JITTER * np.eye(24)
+    Kt = sum(tc.compute_Kt() for tc in m.temporal_cov_list)
+    ll_dense = ctx.loglik_dense_chol(Ks, Kt, float(m.sig2n["value"]), lfp)
+    ll_kron = float(m.loglik())
+    ll_oracle = O.loglik(geom, with_jitter(hp, 1e-8), lfp)
+    print("N = 12000 dense Cholesky loglik %.10f  Kronecker-eigen %.10f  oracle %.10f  golden %.10f"
+          % (ll_dense, ll_kron, ll_oracle, float(g["loglik"])))
+    assert abs(ll_dense - ll_kron) <= 1e-9 * abs(ll_kron)
+    assert abs(ll_dense - ll_oracle) <= 1e-9 * abs(ll_oracle)
+    assert abs(ll_dense - float(g["loglik"])) <= 1e-9 * abs(float(g["loglik"]))

@@ -172,7 +172,7 @@ def test_comp_eig_D():
     assert relerr(comp_eig_D(g["eig_Ks"], g["eig_Kt"], g["eig_siglist"])[2], g["eig_D_list"]) < 1e-12
 
 
-@pytest.mark.parametrize("n", [1, 5, 64, 65, 130, 300])
+@pytest.mark.parametrize("n", [1, 5, 64, 65, 130, 255, 256, 257, 300, 513, 700, 1100])
 def test_potrf_trsm_logdet(ctx, n):
     rs = np.random.RandomState(n)
     M = rs.standard_normal((n, n))
