@@ -71,6 +71,32 @@ def workload(name):
                           "32 restarts over 8 GPUs = 4 per GPU)")
             w["restarts_per_gpu"] = 4
         return w
+    if name == "npx69fit":
+        w = workload("npx69")
+        w["label"] = "GPCSD2D fit, " + w["label"] + ": 20 restarts in lock-step"
+        return w
+    if name in ("npx69", "npx72sym"):
+        # The reference's own 2D workload (neuropixels/fit_gpcsd2d.py:36-41,86-90,101,107): the 69 V1 channels of one probe (a slice of
+        # the checkerboard without its two reference channels: NO mirror symmetry), 376 samples at 2.5 kHz (-40 .. 110 ms), 150
+        # trials, ngl 30 x 120, eps = 1, integration limits widened by 16 / 100 um, fit(n_restarts=20), then predict at four
+        # off-grid depths.  "npx72sym": the control -- 72 channels of the same probe that ARE point-symmetric (212 .. 283).
+        if name == "npx69":
+            chans = np.array([c for c in range(213, 284) if c not in (227, 264)])
+        else:
+            chans = np.arange(212, 284)
+        x = neuropixels_xy(384)[chans]
+        t = (-40.0 + 0.4 * np.arange(376.0))[:, None]
+        return dict(dim=2, nx=len(chans), nt=376, x=x, t=t, ngl1=30, ngl2=120, R=100.0, eps=1.0, ell_s=(40.0, 150.0),
+                    temporal=[(0, 20.0, 0.5), (1, 5.0, 0.7)], sig2n=0.05, trials_per_gpu=150,
+                    limits=dict(a1=float(x[:, 0].min()) - 16.0, b1=float(x[:, 0].max()) + 16.0, a2=float(x[:, 1].min()) - 100.0,
+                                b2=float(x[:, 1].max()) + 100.0),
+                    # npx69: the script's four depths.  The control predicts at four sites that share ITS electrodes' point symmetry
+                    # (centre (24, 2470)): both then run the paired, folded step and the comparison is of the spatial side alone
+                    z=(np.stack([24.0 * np.ones(4), np.array([2260.0, 2450.0, 2650.0, 2785.0])]).T if name == "npx69" else
+                       np.stack([24.0 * np.ones(4), np.array([2260.0, 2400.0, 2540.0, 2680.0])]).T), restarts=20,
+                    label="GPCSD2D %d ch%s x 376t x 150 trials/GPU, fp64, ngl 30x120, eps 1, predict at 4 off-grid sites "
+                          "(neuropixels/fit_gpcsd2d.py%s)" % (len(chans), " (no mirror symmetry)" if name == "npx69" else " (point-symmetric control)",
+                                                              "" if name == "npx69" else "'s shape"))
     raise SystemExit("unknown workload %r" % name)
 
 
@@ -88,7 +114,7 @@ def build_model(w, lfp):
         m = GPCSD1D(lfp, w["x"], w["t"], a=0.0, b=2300.0, ngl=w["ngl"], temporal_cov_list=tcl)
         m.spatial_cov.params["ell"]["value"] = w["ell_s"][0]
     else:
-        m = GPCSD2D(lfp, w["x"], w["t"], ngl1=w["ngl1"], ngl2=w["ngl2"], temporal_cov_list=tcl, eps=w["eps"])
+        m = GPCSD2D(lfp, w["x"], w["t"], ngl1=w["ngl1"], ngl2=w["ngl2"], temporal_cov_list=tcl, eps=w["eps"], **w.get("limits", {}))
         m.spatial_cov.params["ell1"]["value"], m.spatial_cov.params["ell2"]["value"] = w["ell_s"]
     m.R["value"] = w["R"]
     m.sig2n["value"] = w["sig2n"]
@@ -146,7 +172,7 @@ def oracle_setup(w, m):
         geom = O.Geometry1D(w["x"], w["t"], a=0.0, b=2300.0, ngl=w["ngl"])
         jit = 1e-8
     else:
-        geom = O.Geometry2D(w["x"], w["t"], ngl1=w["ngl1"], ngl2=w["ngl2"])
+        geom = O.Geometry2D(w["x"], w["t"], ngl1=w["ngl1"], ngl2=w["ngl2"], **w.get("limits", {}))
         jit = 1e-7
     hp = O.make_hparams(w["R"], w["ell_s"], temporal, w["sig2n"], eps=w["eps"], jitter=jit)
     hp0 = dict(hp)
@@ -167,7 +193,7 @@ def cpu_baseline(w, m, lfp, budget_s=45.0):
     except Exception:
         affinity = os.cpu_count() or 1
     cand = sorted({n for n in (1, 8, 16, 32, 64, affinity, blas_max) if 1 <= n <= blas_max})
-    z, t = w["x"], w["t"]
+    z, t = w.get("z", w["x"]), w["t"]
 
     def t_loglik(reps):
         ts, ll = [], None
@@ -405,7 +431,7 @@ def main():
             print(json.dumps(potrf_bench()))
         return
     w = workload(args.workload)
-    if args.workload == "cfg5":
+    if args.workload in ("cfg5", "npx69fit"):
         out = run_fit_bench(args, w, rank, world, local_rank, backend)
     else:
         out = run_step_bench(args, w, rank, world, local_rank, backend)
@@ -484,6 +510,31 @@ def sub_results(args, local_rank, backend):
         out["potrf"] = potrf_bench()
     except Exception as e:
         out["potrf"] = {"error": repr(e)}
+    # the reference's own 2D workload shape (69 channels without mirror symmetry) beside a point-symmetric control
+    try:
+        res = {}
+        for name in ("npx69", "npx72sym"):
+            a = copy.copy(args)
+            a.workload, a.steps, a.warmup, a.setup_steps, a.no_cpu_baseline, a.trials_per_gpu = name, 100, 5, 60, True, None
+            r = run_step_bench(a, workload(name), 0, 1, local_rank, backend, compact=True)
+            res[name] = {k: r[k] for k in ("value", "unit", "ms_per_step", "steps", "config", "parity_rel_err_loglik_vs_oracle",
+                                           "parity_rel_err_predict_vs_oracle", "loglik") if k in r}
+            res[name]["fenced_calls_ms"] = [r["fenced_calls"]["loglik_ms"], r["fenced_calls"]["predict_resident_ms"]]
+            res[name]["loglik_evals_per_sec"] = r["fenced_calls"]["loglik_evals_per_sec_per_gpu"]
+            res[name]["predict_trials_per_sec"] = r["fenced_calls"]["predict_trials_per_sec_per_gpu"]
+        af = copy.copy(args)
+        af.workload, af.steps, af.warmup, af.setup_steps, af.fit_batch, af.fit_groups = "npx69fit", 20, 3, 10, None, 1
+        rf = run_fit_bench(af, workload("npx69fit"), 0, 1, local_rank, backend, compact=True)
+        res["npx69"]["fit"] = {k: rf[k] for k in ("value", "unit", "ms_per_step", "evals_per_sec_one_at_a_time_per_gpu", "parity") if k in rf}
+        res["npx69"]["fit"]["truncated_fit"] = {k: v for k, v in rf["fit"].items() if k != "nll_values"}
+        out["npx69"] = res["npx69"]
+        out["npx69"]["symmetric_control_72ch"] = res["npx72sym"]
+        out["npx69"]["step_over_symmetric_control"] = res["npx69"]["ms_per_step"] / res["npx72sym"]["ms_per_step"]
+        out["npx69"]["headline"] = {"trials_per_sec": res["npx69"]["value"], "ms_per_step": res["npx69"]["ms_per_step"],
+                                    "loglik_evals_per_sec": res["npx69"]["loglik_evals_per_sec"],
+                                    "fit_evals_per_sec": rf["value"], "step_over_symmetric_control": out["npx69"]["step_over_symmetric_control"]}
+    except Exception as e:
+        out["npx69"] = {"error": repr(e)}
     out["seconds_spent"] = time.perf_counter() - t0
     return out
 
@@ -505,7 +556,7 @@ def run_step_bench(args, w, rank, world, local_rank, backend, compact=False):
     # `value` is measured with every call doing its own decompositions: the library's decomposition cache (predict right
     # after loglik reuses the unchanged temporal side) is switched off here and reported as a separate line below
     ctx.decomposition_cache(False)
-    z = w["x"]
+    z = w.get("z", w["x"])
     C = len(m.temporal_cov_list)
     R_total = R_local * n_gpus
 
@@ -703,6 +754,17 @@ def run_step_bench(args, w, rank, world, local_rank, backend, compact=False):
         m.predict(z, w["t"], type="csd")
     pcie_predict = R_local * n_pcie / (time.perf_counter() - t1)
     out_bytes = (1 + C) * z.shape[0] * w["nt"] * R_local * 8
+    # ... and with the decomposition cache on, the library's default: what predict() costs right after fit() / loglik() at the
+    # fitted hyper-parameters (neuropixels/fit_gpcsd2d.py:101-107) -- both decompositions are reused, the call is its GEMM tail
+    # and the copy
+    ctx.decomposition_cache(True)
+    for _ in range(3):
+        m.predict(z, w["t"], type="csd")
+    t1 = time.perf_counter()
+    for _ in range(n_pcie):
+        m.predict(z, w["t"], type="csd")
+    pcie_predict_cached = R_local * n_pcie / (time.perf_counter() - t1)
+    ctx.decomposition_cache(False)
 
     # ---- roofline: HIP events around the kernels of the SAME paired, queued step the timed loop runs ----
     # mode 2: asynchronous scopes, chains launched eagerly so the scopes inside them record (per-kernel launch times);
@@ -848,8 +910,11 @@ def run_step_bench(args, w, rank, world, local_rank, backend, compact=False):
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
         "config": {"workload": w["label"], "n_elec": w["nx"], "n_t": w["nt"], "trials_per_gpu": R_local,
-                   "total_trials": R_total, "predict": "z=electrodes, t*=t, type=csd, %d temporal components" % C,
-                   "parallelism": "trial-sharded x%d" % n_gpus},
+                   "total_trials": R_total, "predict": "z=%s, t*=t, type=csd, %d temporal components" % ("electrodes" if "z" not in w else "%d sites" % len(z), C),
+                   "parallelism": "trial-sharded x%d" % n_gpus,
+                   "class_api_predict_trials_per_sec": pcie_predict, "class_api_predict_host_gb_per_sec": pcie_predict / R_local * out_bytes / 1e9,
+                   "class_api_predict_cached_trials_per_sec": pcie_predict_cached,
+                   "class_api_predict_cached_host_gb_per_sec": pcie_predict_cached / R_local * out_bytes / 1e9},
         "pipelining": "a step queues loglik + predict as one paired call (gpcsd_loglik_predict_async: the four eigenproblems of "
                       "the step -- Kt and Ks with jitter for loglik, Kt and Ks without for predict, each solved, none reused -- "
                       "share launches two by two as replicas: one temporal chain, one spatial chain; results stay in HBM), then "
@@ -878,6 +943,11 @@ def run_step_bench(args, w, rank, world, local_rank, backend, compact=False):
                                              "eigendecomposition, bit-identical); NOT part of value"},
         "class_api_predict_trials_per_sec_per_gpu_pcie_inclusive": pcie_predict,
         "class_api_predict_host_gb_per_sec": pcie_predict / R_local * out_bytes / 1e9,
+        "class_api_predict_cached_trials_per_sec_per_gpu_pcie_inclusive": pcie_predict_cached,
+        "class_api_predict_cached_host_gb_per_sec": pcie_predict_cached / R_local * out_bytes / 1e9,
+        "class_api_predict_note": "predict() returns host arrays: device time + one PCIe copy of (1 + C) nz nt R doubles into pinned "
+                                  "blocks.  First pair: every call decomposes both sides (cache off, as `value`); `cached`: the "
+                                  "library default, unchanged hyper-parameters reuse both decompositions",
         "loglik": float(ll),
         "distributed": dist_info,
         "roofline": roof,
@@ -913,12 +983,13 @@ def run_fit_bench(args, w, rank, world, local_rank, backend, compact=False):
     (SciPy L-BFGS-B chains in lock-step) with restarts/s."""
     import torch
     from gpcsd_amd.dist import TrialSharding
-    total_restarts = 32
+    total_restarts = int(w.get("restarts", 32))
     mine = [k for k in range(total_restarts) if k % world == rank]
     B = args.fit_batch or min(32, len(mine))                        # all of this rank's restarts advance in one lock-step batch
     m = build_model(w, np.zeros((w["nx"], w["nt"], 1)))
     m.set_device(local_rank)
-    lfp = synth_data(w, m, w["trials_per_gpu"], seed=1000)          # every rank holds the same 200 trials
+    lfp = synth_data(w, m, w["trials_per_gpu"], seed=1000)          # every rank holds the same trials
+    data_sigma2 = [float(tc.params["sigma2"]["value"]) for tc in m.temporal_cov_list]   # (2D: rescaled by 1 / mean diag Ks)
     m.update_lfp(lfp, w["t"])
     if os.environ.get("GPCSD_GRAM_PRECISION") == "32":              # BASELINE cfg5 names "fp32 kernel build + fp64 factor"
         m.gram_precision = 32
@@ -1041,17 +1112,22 @@ def run_fit_bench(args, w, rank, world, local_rank, backend, compact=False):
         O, geom, hpo, _hpo0 = oracle_setup(w, m)
         kinds = [k for k, _, _ in w["temporal"]]
 
+        snames = ("ell",) if w["dim"] == 1 else ("ell1", "ell2")
+
         def cpu_obj(tp):
-            hh = O.hparams_from_tparams(tp, 1, kinds, 1, jitter=1e-8)
-            lp = m.R["prior"].lpdf(hh["R"]) + m.spatial_cov.params["ell"]["prior"].lpdf(hh["ell_s"][0]) + m.sig2n["prior"].lpdf(hh["sig2n"])
+            hh = O.hparams_from_tparams(tp, w["dim"], kinds, 1, eps=w["eps"], jitter=m.JITTER)
+            lp = m.R["prior"].lpdf(hh["R"]) + m.sig2n["prior"].lpdf(hh["sig2n"])
+            for nm, v in zip(snames, hh["ell_s"]):
+                lp += m.spatial_cov.params[nm]["prior"].lpdf(v)
             for tc, (_, ell, s2) in zip(m.temporal_cov_list, hh["temporal"]):
                 lp += tc.params["ell"]["prior"].lpdf(ell) + tc.params["sigma2"]["prior"].lpdf(s2)
             return -(O.loglik(geom, hh, lfp) + lp)
         # at the hyper-parameters the data were drawn from (a well-scaled point: central differences of a prior-drawn start,
         # where the objective is ~1e7 and dominated by one term, only measure the differences' own rounding)
         m.R["value"], m.sig2n["value"] = w["R"], w["sig2n"]
-        m.spatial_cov.params["ell"]["value"] = w["ell_s"][0]
-        for tc, (_, ell, s2) in zip(m.temporal_cov_list, w["temporal"]):
+        for nm, v in zip(snames, w["ell_s"]):
+            m.spatial_cov.params[nm]["value"] = v
+        for tc, (_, ell, _s2), s2 in zip(m.temporal_cov_list, w["temporal"], data_sigma2):
             tc.params["ell"]["value"], tc.params["sigma2"]["value"] = ell, s2
         tp0 = m._current_tparams()
         f_gpu, g_gpu = m._objective_and_grad(tp0, False)
