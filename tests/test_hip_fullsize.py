@@ -1126,3 +1126,37 @@ def test_dense_cholesky_loglik_at_cfg2_geometry_N12000():
     assert abs(ll_dense - ll_kron) <= 1e-9 * abs(ll_kron)
     assert abs(ll_dense - ll_oracle) <= 1e-9 * abs(ll_oracle)
     assert abs(ll_dense - float(g["loglik"])) <= 1e-9 * abs(float(g["loglik"]))
+
+
+# ------------------------------------------------------------------------------------------------ cfg3 at its own trial count
+@pytest.mark.timeout(900)
+def test_cfg3_at_50_trials_paired_step_vs_oracle():
+    """BASELINE configs[2] as `bench.py` runs it -- GPCSD2D 384 x 500 with 50 trials drawn from the model, one paired queued step
+    (gpcsd_loglik_predict_async) -- against the oracle on the same 50 trials: log-likelihood 1e-9, posterior mean (z = electrodes,
+    type csd, both per-component lists) 1e-6 (north_star's gate; observed ~5e-12).  The bench's own spot check, as a test."""
+    from gpcsd_amd import _hip
+    import bench
+    w = bench.workload("cfg3")
+    m = bench.build_model(w, np.zeros((w["nx"], w["nt"], 1)))
+    lfp = bench.synth_data(w, m, 50, seed=1000)
+    m.update_lfp(lfp, w["t"])
+    assert lfp.shape == (384, 500, 50)
+    ctx = m._sync_device()
+    ctx.decomposition_cache(False)
+    O_, geom, hp, hp0 = bench.oracle_setup(w, m)
+    h1, k1 = m._hparams(m.JITTER)
+    h0, k0 = m._hparams(0.0)
+    for _ in range(3):
+        ctx.loglik_predict_async(h1, h0, w["x"], w["t"], _hip.PRED_CSD, want_lists=True)
+        sumlog, quad = ctx.loglik_parts_wait()
+    ll = -0.5 * 50 * sumlog - 0.5 * quad
+    ll_ref = O.loglik(geom, hp, lfp)
+    ref = O.predict(geom, hp0, lfp, w["x"], w["t"], type="csd")
+    got = ctx.fetch("pred_out_csd", (384, 500, 50))
+    got_list = ctx.fetch("pred_out_csd_list", (2, 384, 500, 50))
+    e_ll = abs(ll - ll_ref) / abs(ll_ref)
+    e_pr = relerr(got, ref["csd"])
+    e_l = max(relerr(got_list[i], ref["csd_list"][i]) for i in range(2))
+    print("cfg3 R=50: loglik rel err %.2e, predict %.2e, per-component %.2e" % (e_ll, e_pr, e_l))
+    assert e_ll < 1e-9 and e_pr < GATE and e_l < GATE
+    assert float(m.loglik()) == ll                                 # the class API's synchronous call: the same bits
