@@ -230,7 +230,7 @@ static void temporal_fill(gpcsd_ctx *c, const gpcsd_hparams *const *hps, int nre
             sets[r].sigma2[i] = on ? hps[r]->sigma2_t[i] : 0.0;
         }
     }
-    const char *const *tg = eigh_fold_tags(1);
+    const char *const *tg = eigh_fold_tags(c, 1);
     const EigArenaView as = eigh_arena_view(c, tg[0], sy.ns, nrep), aa = eigh_arena_view(c, tg[1], sy.na, nrep);
     k_temporal_fold_fill(c, sets, nrep, t, nt, sy, as, aa, status, status_stride, s);
 }
@@ -244,7 +244,7 @@ static bool spatial_fill_applies(gpcsd_ctx *c, const SymDev *sym_s, int nx) {
 }
 static void spatial_fill(gpcsd_ctx *c, const double *Ks, int nx, long sK, int nrep, const double *jitter, const SymDev &sy,
                          int *status, int status_stride, hipStream_t s) {
-    const char *const *tg = eigh_fold_tags(0);
+    const char *const *tg = eigh_fold_tags(c, 0);
     const EigArenaView as = eigh_arena_view(c, tg[0], sy.ns, nrep), aa = eigh_arena_view(c, tg[1], sy.na, nrep);
     k_psd_fold_fill(c, Ks, nx, sK, nrep, jitter, sy, as, aa, status, status_stride, s);
 }
@@ -383,7 +383,17 @@ struct EigState {
     // stage-1 outputs are still those of this temporal problem), replica `tri_rep` of the temporal classes is this call's
     bool tri = false, wait_q = false;
     int tri_rep = 0, tri_count = 1;
+    bool late_stages = false;      // stages 2 and 4 of a staged temporal chain were queued although this call does not wait for them
 };
+
+// The prediction in the basis U (x) Q as well (k_tridiag_solve instead of (W V) / D): with it NO consumer of a staged temporal
+// chain reads the spectrum or the eigenvectors, and the chain ends at the tridiagonalisation + Q -- divide & conquer and
+// back-transformation (~25 dependent launches, 0.3-0.5 ms beside the GEMM tails at 250-row halves) are not queued at all.
+// GPCSD_PRED_TRIDIAG=0: the eigenvector form of the prediction (A/B).
+static bool predict_tridiag_applies(int np_s, int np_a, int R) {
+    static const bool off = getenv("GPCSD_PRED_TRIDIAG") && getenv("GPCSD_PRED_TRIDIAG")[0] == '0';
+    return !off && k_tridiag_solve_pass(std::max(np_s, np_a), R) > 0;
+}
 
 // The log-likelihood in the basis U (x) Q (k_ll_tridiag) instead of U (x) V: it needs the temporal chain only up to the
 // tridiagonalisation + Q, not the divide & conquer and the back-transformation, which only a prediction's tail waits for.  The
@@ -405,13 +415,13 @@ static bool ll_tridiag_enabled(const gpcsd_ctx *c) {
 // tridiagonal and its scale, Q): wait on its stream for the readers beside the chain -- the log-likelihood tail on the main
 // stream (X = Y~ Q, the recurrences) and stage 3 on stream4 (reads reflectors, writes T factors and Q).
 static void staged_chain_guard(gpcsd_ctx *c, hipStream_t s2) {
-    if (c->tri_reader_queued) {
-        GP_HIP(hipStreamWaitEvent(s2, c->ev_tri_done, 0));
-        c->tri_reader_queued = false;
+    if (c->tri_reader_queued[c->tgen]) {
+        GP_HIP(hipStreamWaitEvent(s2, c->ev_tri_done[c->tgen], 0));
+        c->tri_reader_queued[c->tgen] = false;
     }
-    if (c->q_queued) {
-        GP_HIP(hipStreamWaitEvent(s2, c->ev_q, 0));
-        c->q_queued = false;
+    if (c->q_queued[c->tgen]) {
+        GP_HIP(hipStreamWaitEvent(s2, c->ev_q[c->tgen], 0));
+        c->q_queued[c->tgen] = false;
     }
 }
 
@@ -467,6 +477,7 @@ static bool two_stream_front() {            // GPCSD_TWO_STREAM=0: single batche
 // (one small launch less at the end of each chain).  NOTE: D from the single-stream front half is then in merged order of
 // stale spectra -- such callers rebuild it in fold order (join_temporal with a FoldMode).
 // join_s = false: the caller calls join_spatial() itself.  Fold views (fold_mode) must be taken AFTER this returns.
+// want_tri: the caller's tail works from the temporal tridiagonalisation + Q alone (EigState::tri tells it whether it may).
 EigState front_half(gpcsd_ctx *c, const gpcsd_hparams *hp, double jitter, bool need_merged = true, bool join_s = true,
                     bool want_tri = false) {
     const Geo g = resident_geo(c);
@@ -537,7 +548,20 @@ EigState front_half(gpcsd_ctx *c, const gpcsd_hparams *hp, double jitter, bool n
         kt_key.ell[i] = hp->ell_t[i];
         kt_key.s2[i] = hp->sigma2_t[i];
     }
-    const bool run_t = !decomp_cached(c, 1, &kt_key, sizeof(kt_key));
+    // can this call's consumer take the tridiagonal form?  (decided before the cache is asked: a cached side that stopped at the
+    // tridiagonalisation only serves such consumers)
+    const bool tfill0 = temporal_fill_applies(c, sym_t, nt, host_kt);
+    const bool staged0 = tfill0 && ll_tridiag_enabled(c) && eigh_stageable(sym_t, nt);
+    const bool tri_consumer = staged0 && want_tri && !need_merged && hp->n_sig2n == 1;
+    bool run_t = !decomp_cached(c, 1, &kt_key, sizeof(kt_key));
+    if (!run_t && !tri_consumer && !c->decomp_t_full) {      // cached, but only as far as a tridiagonal-form consumer needs
+        run_t = true;
+        --c->decomp_cache_hits;
+    }
+    if (!run_t && tri_consumer && c->q_gen != c->eig_gen[1]) {   // cached by an unstaged chain: no Q / tridiagonal in the buffers
+        run_t = true;
+        --c->decomp_cache_hits;
+    }
     struct {
         long epoch;
         int nx, merged, fold;
@@ -554,43 +578,49 @@ EigState front_half(gpcsd_ctx *c, const gpcsd_hparams *hp, double jitter, bool n
     c->tl("call start (main)", s);
     if (run_t) {
         c->tl("T chain start (s2)", s2);
-        const bool tfill = temporal_fill_applies(c, sym_t, nt, host_kt);
+        const bool tfill = tfill0;
+        c->tgen ^= 1;                        // the other generation of the temporal class arenas (gpcsd_ctx::tgen)
         staged_chain_guard(c, s2);
         if (tfill) temporal_fill(c, &hp, 1, t, nt, *sym_t, e.status + 1, 0, s2);
         else make_kt(s2);
-        // staged whenever it applies (not only for a log-likelihood): the T factors are then a launch of their own instead of
-        // riding in the leaf launch -- same bits either way, but every call form takes the same launches
-        const bool staged = tfill && ll_tridiag_enabled(c) && eigh_stageable(sym_t, nt);
-        clear_late_status(c, e.status, s2, staged);
+        // staged whenever it applies: the T factors are then a launch of their own instead of riding in the leaf launch (same
+        // bits either way).  A consumer in the tridiagonal form gets stages 1 and 3 only; anybody else all four.
+        const bool staged = staged0;
+        clear_late_status(c, e.status, s2, staged && !tri_consumer);
         {
             ProfScope ps(c, "eigh_temporal", 9.0 * (double)nt * nt * nt, s2);
             if (staged) {
                 // stage 1 (tridiagonalisation), then on this stream stage 2 (divide & conquer) and BESIDE it, on stream4, stage 3
                 // (T factors, Q), then stage 4 (back-transformation) behind both.  A log-likelihood in the tridiagonal form
                 // starts its tail behind stage 3 and never waits for stages 2 and 4.
-                const bool tri = want_tri && !need_merged && hp->n_sig2n == 1;
+                const bool tri = tri_consumer;
                 int *late = e.status + gpcsd_ctx::STATUS_LATE;    // stages 2 and 4 report here (gpcsd_ctx::STATUS_LATE)
                 eigh_pair_device(c, nullptr, 0, nullptr, nullptr, nullptr, Kt, nt, e.et, e.Qt, sym_t, e.status + 1, s2, need_merged, 1, 0,
                                  -1, 2, /*stage=*/1);
                 GP_HIP(hipEventRecord(c->ev_t1, s2));
-                eigh_pair_device(c, nullptr, 0, nullptr, nullptr, nullptr, Kt, nt, e.et, e.Qt, sym_t, late + 1, s2, need_merged, 1, 0,
-                                 -1, 2, /*stage=*/2);
+                if (!tri)
+                    eigh_pair_device(c, nullptr, 0, nullptr, nullptr, nullptr, Kt, nt, e.et, e.Qt, sym_t, late + 1, s2, need_merged, 1, 0,
+                                     -1, 2, /*stage=*/2);
                 {
                     hipStream_t sq = c->stream4;
                     GP_HIP(hipStreamWaitEvent(sq, c->ev_t1, 0));
                     eigh_pair_device(c, nullptr, 0, nullptr, nullptr, nullptr, Kt, nt, e.et, e.Qt, sym_t, e.status + 1, sq,
                                      need_merged, 1, 0, -1, 2, /*stage=*/3);
-                    GP_HIP(hipEventRecord(c->ev_q, sq));
-                    c->q_queued = true;
+                    GP_HIP(hipEventRecord(c->ev_q[c->tgen], sq));
+                    c->q_queued[c->tgen] = true;
                     c->q_gen = c->eig_gen[1];
                 }
-                GP_HIP(hipStreamWaitEvent(s2, c->ev_q, 0));
-                eigh_pair_device(c, nullptr, 0, nullptr, nullptr, nullptr, Kt, nt, e.et, e.Qt, sym_t, late + 1, s2, need_merged, 1, 0,
-                                 -1, 2, /*stage=*/4);
+                if (!tri) {
+                    GP_HIP(hipStreamWaitEvent(s2, c->ev_q[c->tgen], 0));
+                    eigh_pair_device(c, nullptr, 0, nullptr, nullptr, nullptr, Kt, nt, e.et, e.Qt, sym_t, late + 1, s2, need_merged, 1, 0,
+                                     -1, 2, /*stage=*/4);
+                }
                 e.tri = e.wait_q = tri;
+                c->decomp_t_full = !tri;
             } else {
                 eigh_pair_device(c, nullptr, 0, nullptr, nullptr, nullptr, Kt, nt, e.et, e.Qt, sym_t, e.status + 1, s2, need_merged, 1, 0,
                                  -1, tfill ? 2 : 0);
+                c->decomp_t_full = true;
             }
         }
         GP_HIP(hipEventRecord(c->ev_join, s2));
@@ -616,9 +646,10 @@ EigState front_half(gpcsd_ctx *c, const gpcsd_hparams *hp, double jitter, bool n
     // a temporal side served from the cache: the chain that produced it may still be running its second stage (a log-likelihood
     // in the tridiagonal form returns without waiting for it) -- readers of its eigenvectors wait for that chain's end as usual
     if (!run_t) e.wait_temporal = true;
-    if (!run_t && want_tri && !need_merged && hp->n_sig2n == 1 && ll_tridiag_enabled(c) && c->q_gen == c->eig_gen[1] && sym_t &&
-        eigh_stageable(sym_t, nt))
-        e.tri = true;                // the temporal side is reused from the cache and its stage-1 outputs are those of this problem
+    if (!run_t && tri_consumer) {    // the temporal side is reused from the cache and its stage-1 outputs are those of this problem
+        e.tri = true;
+        e.wait_q = c->q_queued[c->tgen];      // (the stage 3 that left Q there may still be running)
+    }
     e.d_sig = c->upload_cached<double>("sig2n", hp->sig2n, hp->n_sig2n);
     e.nsig = hp->n_sig2n;
     e.pending = true;
@@ -782,7 +813,7 @@ int finish_call(gpcsd_ctx *c, const EigState &e, double *scal_out, int nscal) {
     GP_HIP(hipMemsetAsync(e.status, 0, (late ? gpcsd_ctx::STATUS_N : gpcsd_ctx::STATUS_LATE) * sizeof(int), c->stream));
     c->sync();
     c->status_zeroed = true;
-    c->late_dirty = !late;
+    c->late_dirty = !late && e.late_stages;
     c->async_pending = false;              // whatever an asynchronous predict left in the status words has been collected now
     if (c->prof_mode == 1) c->prof_collect();
     for (int i = 0; i < nscal; ++i) scal_out[i] = host[i];
@@ -856,9 +887,9 @@ extern "C" int gpcsd_ctx_create(int device, gpcsd_ctx **out) {
         GP_HIP(hipEventCreateWithFlags(&c->ev_pc, hipEventDisableTiming));
         GP_HIP(hipEventCreateWithFlags(&c->ev_chol_a, hipEventDisableTiming));
         GP_HIP(hipEventCreateWithFlags(&c->ev_chol_d, hipEventDisableTiming));
-        GP_HIP(hipEventCreateWithFlags(&c->ev_q, hipEventDisableTiming));
+        for (int i = 0; i < 2; ++i) GP_HIP(hipEventCreateWithFlags(&c->ev_q[i], hipEventDisableTiming));
         GP_HIP(hipEventCreateWithFlags(&c->ev_t1, hipEventDisableTiming));
-        GP_HIP(hipEventCreateWithFlags(&c->ev_tri_done, hipEventDisableTiming));
+        for (int i = 0; i < 2; ++i) GP_HIP(hipEventCreateWithFlags(&c->ev_tri_done[i], hipEventDisableTiming));
         GP_HIP(hipHostMalloc(reinterpret_cast<void **>(&c->h_result), gpcsd_ctx::RESULT_DOUBLES * sizeof(double), hipHostMallocDefault));
         GP_HIP(hipHostMalloc(reinterpret_cast<void **>(&c->h_ll), gpcsd_ctx::LL_SLOTS * gpcsd_ctx::RESULT_DOUBLES * sizeof(double),
                              hipHostMallocDefault));
@@ -896,9 +927,11 @@ extern "C" int gpcsd_ctx_destroy(gpcsd_ctx *c) {
     if (c->ev_pc) (void)hipEventDestroy(c->ev_pc);
     if (c->ev_chol_a) (void)hipEventDestroy(c->ev_chol_a);
     if (c->ev_chol_d) (void)hipEventDestroy(c->ev_chol_d);
-    if (c->ev_q) (void)hipEventDestroy(c->ev_q);
+    for (int i = 0; i < 2; ++i)
+        if (c->ev_q[i]) (void)hipEventDestroy(c->ev_q[i]);
     if (c->ev_t1) (void)hipEventDestroy(c->ev_t1);
-    if (c->ev_tri_done) (void)hipEventDestroy(c->ev_tri_done);
+    for (int i = 0; i < 2; ++i)
+        if (c->ev_tri_done[i]) (void)hipEventDestroy(c->ev_tri_done[i]);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     if (c->stream2) (void)hipStreamDestroy(c->stream2);
     if (c->h_result) (void)hipHostFree(c->h_result);

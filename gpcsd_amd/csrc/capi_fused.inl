@@ -25,13 +25,14 @@ static int finish_loglik_async(gpcsd_ctx *c, const EigState &e, bool two) {
 // Shifted-tridiagonal form (EigState::tri): X = Y~ Q needs stage 1 of the temporal chain only and is queued BEFORE the main
 // stream waits for the spatial chain; after that wait W = diag(U)^T X, and one forward recurrence per row gives the quadratic
 // form, the pivots the log-determinant (k_ll_tridiag).  The temporal eigenvectors are never read.
-static void loglik_tri_pre(gpcsd_ctx *c, EigState &e, const FoldMode &fm, const double *Yf) {
+static void loglik_tri_pre(gpcsd_ctx *c, EigState &e, const FoldMode &fm, const double *Yf, const char *xname = "ll_X",
+                           const char *prof = "gemm_ll_YQ") {
     const int nx = c->nx, nt = c->nt, R = c->ntrials;
     hipStream_t s = c->stream;
-    if (e.wait_q) GP_HIP(hipStreamWaitEvent(s, c->ev_q, 0));
+    if (e.wait_q) GP_HIP(hipStreamWaitEvent(s, c->ev_q[c->tgen], 0));
     e.wait_q = false;
-    double *X = c->buf<double>("ll_X", (size_t)nx * R * nt);
-    const char *const *tg = eigh_fold_tags(1);
+    double *X = c->buf<double>(xname, (size_t)nx * R * nt);
+    const char *const *tg = eigh_fold_tags(c, 1);
     GemmDesc g[2];
     for (int p = 0; p < 2; ++p) {
         const int np = p ? fm.ft.na : fm.ft.ns, c0 = p ? fm.ft.ns : 0;
@@ -39,7 +40,7 @@ static void loglik_tri_pre(gpcsd_ctx *c, EigState &e, const FoldMode &fm, const 
         g[p].A = Yf + c0; g[p].lda = nt;
         g[p].B = eigh_Q_view(c, tg[p], np, e.tri_count) + (size_t)e.tri_rep * np * np; g[p].ldb = np;
         g[p].C = X + c0; g[p].ldc = nt;
-        g[p].prof_name = "gemm_ll_YQ";
+        g[p].prof_name = prof;
     }
     gemm_pair(c, g[0], g[1], s);
 }
@@ -52,7 +53,7 @@ static void loglik_tri_tail(gpcsd_ctx *c, EigState &e, const FoldMode &fm, doubl
     join_spatial(c, e);
     const double *X = c->buf<double>("ll_X", (size_t)nx * R * nt);
     fold_proj_spatial(c, fm.fs, X, W, (long)R * nt, s);
-    const char *const *tg = eigh_fold_tags(1);
+    const char *const *tg = eigh_fold_tags(c, 1);
     const double *d[2], *ee[2], *am[2];
     int np[2], c0[2];
     for (int p = 0; p < 2; ++p) {
@@ -63,8 +64,8 @@ static void loglik_tri_tail(gpcsd_ctx *c, EigState &e, const FoldMode &fm, doubl
         d[p] = av.d + o; ee[p] = av.e + o; am[p] = av.amax + o;
     }
     k_ll_tridiag(c, W, fm.fs.w, d, ee, am, e.d_sig, nx, R, nt, np, c0, e.scal, e.scal + 1, s);
-    GP_HIP(hipEventRecord(c->ev_tri_done, s));
-    c->tri_reader_queued = true;
+    GP_HIP(hipEventRecord(c->ev_tri_done[c->tgen], s));
+    c->tri_reader_queued[c->tgen] = true;
 }
 
 static bool loglik_fold_tail(gpcsd_ctx *c, EigState &e, const FoldMode &fm, const double *Yf, double *W) {
@@ -267,11 +268,17 @@ static int predict_fold(gpcsd_ctx *c, const gpcsd_hparams *hp, EigState &e, cons
     }
     // then everything that needs only the spatial eigenvectors, beside the temporal eigensolver
     if (before_spatial_join) (*before_spatial_join)();
+    // tridiagonal form (EigState::tri): X = Y~ Q needs the temporal tridiagonalisation + Q only and is queued in front of the wait
+    // for the spatial chain, exactly as the log-likelihood's
+    // (a call of its own: in front of the wait for the spatial chain; in the paired call: behind the log-likelihood's tail -- in
+    // front of it the product delays the result the caller is waiting for by its 0.09 ms)
+    if (e.tri && !after_spatial_join) loglik_tri_pre(c, e, fm, Yf, "pred_X", "gemm_pred_YQ");
     join_spatial(c, e);
     // gpcsd_loglik_predict_async: the log-likelihood's whole tail goes here, in front of everything of predict that needs a
     // decomposition -- it is what the caller waits for
     if (after_spatial_join) (*after_spatial_join)();
-    fold_proj_spatial(c, fm.fs, Yf, W, RT, s);                      // W~ = diag(U)^T Y~
+    if (e.tri && after_spatial_join) loglik_tri_pre(c, e, fm, Yf, "pred_X", "gemm_pred_YQ");
+    fold_proj_spatial(c, fm.fs, e.tri ? c->buf<double>("pred_X", (size_t)nx * RT) : Yf, W, RT, s);   // W~ = diag(U)^T Y~ (or of Y~ Q)
     for (int which = 1; which <= 2; ++which) {
         if (!(type & which)) continue;
         const double *kf = Kcf + (size_t)(which - 1) * kcf_sz;
@@ -287,13 +294,24 @@ static int predict_fold(gpcsd_ctx *c, const gpcsd_hparams *hp, EigState &e, cons
             gemm_f64(c, gm, s);
         }
     }
-    join_temporal(c, e, &fm, false);      // predict never reads sum(log D)
+    // the temporal basis of everything below: the eigenvectors V_p (blocks of fm.ft.U), or in the tridiagonal form the orthogonal
+    // factors Q_p of the tridiagonalisation (replica e.tri_rep of the temporal classes)
+    const double *Tb[2] = {fm.ft.U, fm.ft.U + (size_t)nts * nts};
+    if (e.tri) {
+        const char *const *tg = eigh_fold_tags(c, 1);
+        for (int p = 0; p < 2; ++p) {
+            const int np = p ? nta : nts;
+            Tb[p] = np > 0 ? eigh_Q_view(c, tg[p], np, e.tri_count) + (size_t)e.tri_rep * np * np : nullptr;
+        }
+    } else {
+        join_temporal(c, e, &fm, false);  // predict never reads sum(log D)
+    }
     GemmDesc g2[2];                       // Bm~[:, p block] = (W~[:, p block] V_p) / D~
     for (int p = 0; p < 2; ++p) {
         const int np = p ? nta : nts, c0 = p ? nts : 0;
         g2[p].M = nx * R; g2[p].N = np; g2[p].K = np;
         g2[p].A = W + c0; g2[p].lda = nt;
-        g2[p].B = fm.ft.U + (p ? (size_t)nts * nts : 0); g2[p].ldb = np;
+        g2[p].B = Tb[p]; g2[p].ldb = np;
         g2[p].C = Bm + c0; g2[p].ldc = nt;
         g2[p].epi = EPI_DIV_D; g2[p].D = e.Dinv + c0; g2[p].rdiv = R; g2[p].ldd = nt;
         g2[p].prof_name = "gemm_pred_temporal_div";
@@ -308,7 +326,7 @@ static int predict_fold(gpcsd_ctx *c, const gpcsd_hparams *hp, EigState &e, cons
         if (np == 0) continue;
         GemmDesc gp;                      // Pcat_p[i'][cc*npP + b] = sum_j V_p[j][i'] Kt*~_cc,pp[j][b], all components batched
         gp.M = np; gp.N = np; gp.K = np;
-        gp.A = fm.ft.U + (p ? (size_t)nts * nts : 0); gp.lda = np; gp.transA = true;
+        gp.A = Tb[p]; gp.lda = np; gp.transA = true;
         gp.B = Ktf + (p ? (size_t)nts * nts : 0); gp.ldb = np;
         gp.C = Pc + (p ? pc_s : 0); gp.ldc = (long)C * npP;
         gp.batch = C; gp.sA = 0; gp.sB = (long)ktf_sz; gp.sC = npP;
@@ -317,7 +335,24 @@ static int predict_fold(gpcsd_ctx *c, const gpcsd_hparams *hp, EigState &e, cons
     }
     GP_HIP(hipEventRecord(c->ev_pc, c->stream4));
     c->tl("Pc end (s4)", c->stream4);
-    gemm_pair(c, g2[0], g2[1], s);
+    if (e.tri) {
+        // Bm~ = the solutions of the shifted tridiagonal systems (es[x'] m T_p + sig2 I) b = w, row by row of W~ = diag(U)^T Y~ Q
+        const char *const *tg = eigh_fold_tags(c, 1);
+        const double *d[2], *ee[2], *am[2];
+        int np[2], c0[2];
+        for (int p = 0; p < 2; ++p) {
+            np[p] = p ? nta : nts;
+            c0[p] = p ? nts : 0;
+            const EigArenaView av = eigh_arena_view(c, tg[p], np[p], e.tri_count);
+            const long o = (long)e.tri_rep * av.blk;
+            d[p] = av.d + o; ee[p] = av.e + o; am[p] = av.amax + o;
+        }
+        k_tridiag_solve(c, W, Bm, fm.fs.w, d, ee, am, e.d_sig, nx, R, nt, np, c0, s);
+        GP_HIP(hipEventRecord(c->ev_tri_done[c->tgen], s));     // the last reader of Q / the tridiagonal on this stream
+        c->tri_reader_queued[c->tgen] = true;
+    } else {
+        gemm_pair(c, g2[0], g2[1], s);
+    }
     for (int which = 1; which <= 2; ++which) {
         if (!(type & which)) continue;
         double *o_sum = c->buf<double>(which == 1 ? "pred_out_csd" : "pred_out_lfp", out_elems);
@@ -396,7 +431,8 @@ static int predict_impl(gpcsd_ctx *c, const gpcsd_hparams *hp, const double *z, 
         const SymDev sz = fm0.fs.on ? site_symmetry(c, z, nz, c->dim) : identity_sym(c, nz);
         if (sz.ns > 0 && sz.ns + sz.na == nz) {
             // the chains go first (they need no upload of this call), then the host-side uploads
-            EigState ef = front_half(c, hp, 0.0, false, /*join_s=*/false);  // no jitter in predict (gpcsd1d.py:258)
+            const bool ptri = fm0.ft.on && predict_tridiag_applies(fm0.ft.ns, fm0.ft.na, c->ntrials);
+            EigState ef = front_half(c, hp, 0.0, false, /*join_s=*/false, /*want_tri=*/ptri);  // no jitter in predict (gpcsd1d.py:258)
             const FoldMode fm = fold_mode(c, hp);
             const double *Yf = folded_lfp(c, fm);
             double *dzf = c->upload_cached<double>("pred_z", z, (size_t)nz * c->dim);
@@ -509,7 +545,9 @@ static bool same_temporal(const gpcsd_hparams *a, const gpcsd_hparams *b) {
 }
 
 // Both sets decomposed, set b's results at replica b of the generation just started (folded-basis callers only).
-static void front_half_pair(gpcsd_ctx *c, const gpcsd_hparams *const hp[2], const double jitter[2], PairFront &out) {
+// pred_tri: the prediction (set 1) takes the tridiagonal form too, so that nobody reads the temporal spectrum or eigenvectors: the
+// staged temporal chain then stops behind stages 1 and 3.
+static void front_half_pair(gpcsd_ctx *c, const gpcsd_hparams *const hp[2], const double jitter[2], PairFront &out, bool pred_tri) {
     const Geo g = resident_geo(c);
     const int nx = c->nx, nt = c->nt;
     const long nxx = (long)nx * nx, ntt = (long)nt * nt;
@@ -541,8 +579,9 @@ static void front_half_pair(gpcsd_ctx *c, const gpcsd_hparams *const hp[2], cons
     auto run_T = [&](int part) {
         if (part == 1) {
             c->tl("T chain start (s2)", s2);
+            c->tgen ^= 1;                    // the other generation of the temporal class arenas (gpcsd_ctx::tgen)
             staged_chain_guard(c, s2);
-            clear_late_status(c, status, s2, staged);
+            clear_late_status(c, status, s2, staged && !pred_tri);
             if (tfill) temporal_fill(c, hp, nT, t, nt, *sym_t, status + 1, 2, s2);
             else for (int b = 0; b < nT; ++b) build_kt(c, hp[b], t, nt, t, nt, Kt + b * ntt, s2);
         }
@@ -561,17 +600,20 @@ static void front_half_pair(gpcsd_ctx *c, const gpcsd_hparams *const hp[2], cons
             if (staged) {
                 // stage 2 (divide & conquer) on the chain's stream; beside it, on stream4, stage 3 (T factors, Q); stage 4
                 // (back-transformation) behind both.  (Stage 3 on the main stream, in front of X: 1.14 against 1.10 ms -- the
-                // main stream is rarely idle when stage 1 ends.)
-                eigh_pair_device(c, nullptr, 0, nullptr, nullptr, nullptr, Kt, nt, et, Qt, sym_t, late + 1, s2, false, nT, 2, -1, 2, 2);
+                // main stream is rarely idle when stage 1 ends.)  With the prediction in the tridiagonal form as well: stage 3 alone.
+                if (!pred_tri)
+                    eigh_pair_device(c, nullptr, 0, nullptr, nullptr, nullptr, Kt, nt, et, Qt, sym_t, late + 1, s2, false, nT, 2, -1, 2, 2);
                 hipStream_t sq = c->stream4;
                 GP_HIP(hipStreamWaitEvent(sq, c->ev_t1, 0));
                 eigh_pair_device(c, nullptr, 0, nullptr, nullptr, nullptr, Kt, nt, et, Qt, sym_t, status + 1, sq, false, nT, 2, -1, 2, 3);
-                GP_HIP(hipEventRecord(c->ev_q, sq));
+                GP_HIP(hipEventRecord(c->ev_q[c->tgen], sq));
                 c->tl("Q end", sq);
-                c->q_queued = true;
+                c->q_queued[c->tgen] = true;
                 c->q_gen = -1;           // (replicas: not what a separate call's cache looks for)
-                GP_HIP(hipStreamWaitEvent(s2, c->ev_q, 0));
-                eigh_pair_device(c, nullptr, 0, nullptr, nullptr, nullptr, Kt, nt, et, Qt, sym_t, late + 1, s2, false, nT, 2, -1, 2, 4);
+                if (!pred_tri) {
+                    GP_HIP(hipStreamWaitEvent(s2, c->ev_q[c->tgen], 0));
+                    eigh_pair_device(c, nullptr, 0, nullptr, nullptr, nullptr, Kt, nt, et, Qt, sym_t, late + 1, s2, false, nT, 2, -1, 2, 4);
+                }
             } else {
                 eigh_pair_device(c, nullptr, 0, nullptr, nullptr, nullptr, Kt, nt, et, Qt, sym_t, status + 1, s2, false, nT, 2, -1,
                                  tfill ? 2 : 0);
@@ -627,10 +669,11 @@ static void front_half_pair(gpcsd_ctx *c, const gpcsd_hparams *const hp[2], cons
         e.wait_temporal = e.wait_spatial = true;
         e.d_sig = d_sig[b];
         e.nsig = 1;
-        if (b == 0 && staged) {      // set 0 is the log-likelihood's: replica 0 of the temporal classes
+        if (staged && (b == 0 || pred_tri)) {      // set 0 is the log-likelihood's: replica 0 of the temporal classes
             e.tri = e.wait_q = true;
-            e.tri_rep = 0;
+            e.tri_rep = bt;
             e.tri_count = nT;
+            e.late_stages = !pred_tri;
         }
         FoldMode &fm = out.fm[b];
         fm = fold_mode(c, hp[b]);                       // replica 0 of the generations just started ...
@@ -698,7 +741,9 @@ extern "C" int gpcsd_loglik_predict_async(gpcsd_ctx *c, const gpcsd_hparams *hp_
     const gpcsd_hparams *hps[2] = {hp_ll, hp_pr};
     const double jit[2] = {hp_ll->jitter, 0.0};          // no jitter in predict (gpcsd1d.py:258)
     PairFront pf;
-    front_half_pair(c, hps, jit, pf);
+    // (decided here, where the fold sizes are known: does the prediction take the tridiagonal form too?)
+    const bool pred_tri = fm0.ft.on && predict_tridiag_applies(fm0.ft.ns, fm0.ft.na, c->ntrials);
+    front_half_pair(c, hps, jit, pf, pred_tri);
     const double *Yf = folded_lfp(c, pf.fm[1]);
     double *dzf = c->upload_cached<double>("pred_z", z, (size_t)nz * c->dim);
     double *dtf = c->upload_cached<double>("pred_tstar", tstar, ntstar);

@@ -91,7 +91,7 @@ static int loglik_grad_impl(gpcsd_ctx *c, const gpcsd_hparams *hps, int B, doubl
     const bool tfill = temporal_fill_applies(c, sym_t, nt, host_kt);
     staged_chain_guard(c, s2);            // (a queued staged chain's side-stream readers of the class arenas)
     if (tfill) {
-        const char *const *tg = eigh_fold_tags(1);
+        const char *const *tg = eigh_fold_tags(c, 1);
         const EigArenaView as = eigh_arena_view(c, tg[0], sym_t->ns, B), aa = eigh_arena_view(c, tg[1], sym_t->na, B);
         k_temporal_fold_fill_tab(c, tab, B, t, nt, *sym_t, as, aa, st + B, 1, s2);
     } else if (host_kt) {
@@ -130,7 +130,7 @@ static int loglik_grad_impl(gpcsd_ctx *c, const gpcsd_hparams *hps, int B, doubl
         // the spatial chain's input the same way (psd fold fill: fold + jitter on the folded diagonals + scale in one launch)
         const bool sfill = spatial_fill_applies(c, sym_s, nx);
         if (sfill) {
-            const char *const *tg = eigh_fold_tags(0);
+            const char *const *tg = eigh_fold_tags(c, 0);
             const EigArenaView as = eigh_arena_view(c, tg[0], sym_s->ns, B), aa = eigh_arena_view(c, tg[1], sym_s->na, B);
             k_psd_fold_fill(c, Ks, nx, nxx, B, nullptr, *sym_s, as, aa, st, 1, s, tab);
         } else {

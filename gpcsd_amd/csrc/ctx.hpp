@@ -110,14 +110,20 @@ struct gpcsd_ctx {
     // (T factors and the orthogonal factor Q, on stream4 behind ev_t1) done -- the log-likelihood's tail needs nothing more of
     // that chain, its stage 4 waits for it too.  q_gen: the generation of the temporal solver slot whose Q / tridiagonal are in
     // the buffers (decomposition cache hits reuse them).
-    hipEvent_t ev_q = nullptr;
+    hipEvent_t ev_q[2] = {nullptr, nullptr};
     long q_gen = -1;
+    // Those stage-1 / stage-3 outputs (reflectors, T factors, the tridiagonal and its scale, Q: the class arenas of the temporal
+    // halves) exist in TWO generations, used alternately by successive temporal chains (tgen = the current one: it selects the
+    // arena tag set, eigh_fold_tags): chain N + 1 overwrites what chain N - 1 left, whose readers -- a log-likelihood's or a
+    // prediction's tail in the tridiagonal form, which may sit late in a queued GEMM tail -- were queued a whole call earlier.
+    // Single-buffered, the next step's tridiagonalisation waited for the previous prediction's solve (0.3 ms per step).
+    int tgen = 0;
     hipEvent_t ev_t1 = nullptr;
-    bool q_queued = false;                  // a stage 3 has been queued since the last temporal chain started (staged_chain_guard)
+    bool q_queued[2] = {false, false};      // a stage 3 has been queued on this generation since its last temporal chain started (staged_chain_guard)
     // ... and the last reader of those single-buffered stage-1 outputs (Q, the tridiagonal, its scale) on the main stream: the next
     // temporal chain must not overwrite them before it (a caller may queue several steps deep)
-    hipEvent_t ev_tri_done = nullptr;
-    bool tri_reader_queued = false;
+    hipEvent_t ev_tri_done[2] = {nullptr, nullptr};
+    bool tri_reader_queued[2] = {false, false};
     std::string last_error;
     std::map<std::string, gpcsd::DevBuf> bufs;
     bool prof_on = false;
@@ -171,6 +177,8 @@ struct gpcsd_ctx {
     long eig_gen[2] = {0, 0};
     std::vector<unsigned char> decomp_key[2];
     long decomp_gen[2] = {-1, -1};
+    bool decomp_t_full = false;             // the cached temporal side went through all stages (spectrum and eigenvectors exist),
+                                            // not only the tridiagonalisation + Q a tridiagonal-form consumer needs
     long grid_epoch = 0;                    // bumped by set_geometry / set_time / set_host_temporal_gram / set_gram_precision
     // user-defined temporal covariances (covariances.py:235-238: any object with compute_Kt): the caller evaluates the
     // Gram matrices on the host and hands them over (gpcsd_set_host_temporal_gram); the fused calls then upload them

@@ -323,8 +323,9 @@ FoldView eigh_fold_view(gpcsd_ctx *c, int slot, const SymDev *sy, int n, int cou
     return v;
 }
 
-static const char *const FOLD_TAGS[2][3] = {{"p0", "p0s", "p0a"}, {"p1", "p1s", "p1a"}};
-const char *const *eigh_fold_tags(int slot) { return &FOLD_TAGS[slot ? 1 : 0][1]; }
+// [slot][generation]: the temporal classes exist twice (gpcsd_ctx::tgen)
+static const char *const FOLD_TAGS[2][2][3] = {{{"p0", "p0s", "p0a"}, {"p0", "p0s", "p0a"}}, {{"p1", "p1s", "p1a"}, {"p1g", "p1gs", "p1ga"}}};
+const char *const *eigh_fold_tags(const gpcsd_ctx *c, int slot) { return &FOLD_TAGS[slot ? 1 : 0][slot ? (c->tgen & 1) : 0][1]; }
 
 static void eigh_pair_enqueue(gpcsd_ctx *c, double *A0, int n0, double *w0, double *Z0, const SymDev *sym0, double *A1, int n1,
                               double *w1, double *Z1, const SymDev *sym1, int *d_status, hipStream_t s, bool need_merged,
@@ -339,7 +340,7 @@ static void eigh_pair_enqueue(gpcsd_ctx *c, double *A0, int n0, double *w0, doub
         bool on = false;
         double *ws, *Us, *wa, *Ua;
     } fold[2];
-    const char *const (*tags)[3] = FOLD_TAGS;
+    const char *const *tags[2] = {FOLD_TAGS[0][0], FOLD_TAGS[1][c->tgen & 1]};     // [problem] -> {whole, symmetric, antisymmetric}
     // A small problem next to a large one rides along in the large problem's launches for free (GPCSD1D: 24 electrodes
     // next to 500 time points), instead of a serial 250 us single-workgroup Jacobi in front of them.
     const bool pair_has_large = !force_jacobi() && (n0 > JACOBI_LDS_MAX || n1 > JACOBI_LDS_MAX);
@@ -424,7 +425,7 @@ void eigh_pair_device(gpcsd_ctx *c, double *A0, int n0, double *w0, double *Z0, 
              (void *)(sym0 ? sym0->rep_i : nullptr), sym0 ? sym0->ns : 0, (void *)A1, n1, (void *)w1, (void *)Z1,
              (void *)(sym1 ? sym1->rep_i : nullptr), sym1 ? sym1->ns : 0, (void *)d_status, (void *)s, (int)need_merged, count,
              status_stride, c->par[0], c->par[1], count1, prefolded_mask, (int)(c->prof_mode == 3),   // (mode 3 graphs carry clock stamps)
-             stage);
+             stage + 8 * (c->tgen & 1));                                              // (the generation picks the temporal arenas)
     gpcsd_ctx::GraphSlot &g = c->graphs[key];
     if (g.exec && g.epoch == c->alloc_epoch) {
         GP_HIP(hipGraphLaunch(g.exec, s));

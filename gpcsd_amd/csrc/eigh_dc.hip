@@ -83,6 +83,7 @@ struct SytrdProb {
     double *y0, *y1;      // ping-pong A v products
     int n;
     int k_tail;           // first column handled by the in-LDS tail kernel (n - 1: no tail)
+    int psd;              // the matrix is a Gram matrix (positive semi-definite up to rounding): the tail may stop early (sytrd_regtail.hpp)
     long blk;             // replica stride of the arena, in doubles
 };
 struct SytrdBatch {
@@ -285,6 +286,10 @@ static void sytrd_batch_launch(gpcsd_ctx *c, const SytrdBatch &b, int nclass, in
         if (!rt_attr_set) {
             GP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(sytrd_rtail_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)rt_strip_bytes(RT_TMAX)));
+            if (getenv("GPCSD_TAIL_EARLY_EXIT") && getenv("GPCSD_TAIL_EARLY_EXIT")[0] == '0') {     // every column step (A/B, cross-check)
+                const int off = 0;
+                GP_HIP(hipMemcpyToSymbol(HIP_SYMBOL(rt_early_exit_enabled), &off, sizeof(int)));
+            }
             rt_attr_set = true;
         }
         // profiled on its own: this single launch (one workgroup per problem) is the largest share of the GPU time of an
@@ -442,6 +447,7 @@ static void prep_problem(gpcsd_ctx *c, EigProb &p, hipStream_t s) {
         p.sp.k_tail = std::max(0, n - sy_regtail_rows());
     }
     layout_arena(c, p.tag, n, p.count, p.sp, p.amax, p.wyT);
+    p.sp.psd = p.prefilled ? 1 : 0;     // (prefilled classes come from the fused calls' fold fills: Ks and Kt of the model)
     (void)s;
 }
 

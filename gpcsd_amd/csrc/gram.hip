@@ -472,6 +472,261 @@ void k_ll_tridiag(gpcsd_ctx *c, const double *W, const double *es, const double 
     GP_HIP(hipGetLastError());
 }
 
+// ------------------------------------------------------------------------------------------------
+// posterior mean in the basis U (x) Q: the same shifted tridiagonal systems, SOLVED (kernels.hpp: k_tridiag_solve)
+// ------------------------------------------------------------------------------------------------
+// predict needs B = (Ks (x) Kt + sig2 I)^-1 y in a basis in which the remaining products are plain GEMMs.  In the basis U (x) Q
+// that is, per item (x', p) and trial, one solve with A = lam m T_p + sig2 I = L D L^T: forward z_k = w_k - l_k z_{k-1}, backward
+// x_k = z_k / D_k - l_{k+1} x_{k+1}.  One wave per item and workgroup; lane = trial; the item's z (np x trials) stays in LDS between
+// the two sweeps (k-major: conflict-free), so the rows travel through HBM once in and once out -- the traffic of the GEMM
+// (W V) / D this replaces, without its operand V: the temporal divide & conquer and back-transformation are then on nobody's
+// path.  Pivots and multipliers are formed once per item (first pass over the trials) and kept in LDS, a lane per column of a chunk
+// holds them during a sweep and the serial chain reads them with v_readlane.
+// Per item: the rows come into LDS in one burst (64 loads per lane in flight at a time; 16-column pieces of a row = one 128-byte
+// line, written transposed), and the item's 250 pivots -- a serial chain of ~56 cycles per column that every lane would otherwise
+// drag through its own sweep -- are formed in the shadow of those loads.  The sweeps then run in place in LDS, 64 columns per
+// batch: 64 reads up front, one dependent FMA per column with the multiplier from an SGPR (v_readlane), 64 writes.  (A first
+// version streamed 16-column chunks one ahead through a staging tile and formed the pivots inside the forward sweep, as the
+// log-likelihood's kernel does: 83 us per item against ~15 -- and with 122 KB of LDS per item only one item runs per CU, three
+// rounds per launch.)
+constexpr int TS_BATCH = 64;                    // columns per batch of the sweeps / of the load burst
+constexpr int TS_P = 64;                        // LDS row of a column: one entry per lane (trial) of the pass
+struct TriSolveArgs {
+    const double *W;             // (U^T Y Q) in the layout [x'][r][t~], rows of nt doubles
+    double *B;                   // the solutions, same layout (may be W)
+    const double *es;
+    const double *d[2], *e[2], *amax[2];
+    const double *sig;
+    int nx, R, nt, np[2], c0[2];
+    int npad;                    // column capacity of the LDS block: max(np) rounded up to TS_BATCH
+    unsigned long long *clk;     // measurement aid (GPCSD_TS_CLK=1): wall-clock stamps of workgroup 0 at the phase boundaries
+};
+// Written for the scalar unit as much as for the vector one: NO per-element predicate inside the unrolled batches (a first version
+// guarded every LDS access with `column < np && lane < P`: the compiler turned each into an exec-mask save / restore with scalar
+// compares, ran out of SGPRs and spilled them to VGPR lanes -- 200 cycles per column step).  Instead the LDS block is padded to
+// whole batches with zero columns whose multipliers are zero (the recurrences pass through them unchanged), every lane owns a
+// row of the block (trials beyond the pass are duplicate rows nobody stores), and the global accesses of a piece are classified
+// wave-uniformly as whole, partial or absent.
+// Four waves per item: each brings in and takes out one batch of 64 columns (all of an item's ~200 loads in flight at once: with
+// one wave the four batches queued behind each other, 26 us), wave 0 forms the pivots meanwhile and runs both sweeps.  The
+// coefficients of a sweep are LDS broadcast reads into VGPRs, 32 columns ahead -- as v_readlane operands (SGPRs) they cost
+// ~40 cycles per column step against the 8 of the dependent FMA itself.
+constexpr int TS_HB = 32;                       // columns per half batch of a sweep (registers: 32 values + 2 x 32 coefficients)
+constexpr int TS_KMAX = 256;                    // columns of a block at most: one per thread of the pivot scan, one batch per wave
+__global__ __launch_bounds__(256) void tridiag_solve_kernel(TriSolveArgs g) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    double *zbuf = smem;                               // [npad / 2][64][2]: w, then z, then x, in place -- two consecutive columns of
+                                                       // a lane side by side (one 16-byte LDS access per two column steps)
+    double *pinv = zbuf + (long)g.npad * TS_P;         // [TS_KMAX + TS_BATCH]: 1 / D_k
+    double *lmul = pinv + TS_KMAX + TS_BATCH;          // [TS_KMAX + TS_BATCH]: l_k = b_{k-1} / D_{k-1} (0 for k = 0 and k >= np)
+    double *scan = lmul + TS_KMAX + TS_BATCH;          // [2][256][4]: the 2 x 2 prefix products of the pivot scan (pass 0)
+    auto stamp = [&](int k) { if (g.clk && blockIdx.x == 0 && threadIdx.x == 0) g.clk[k] = wall_clock64(); };
+    stamp(0);
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    // A workgroup takes the items blockIdx.x, blockIdx.x + gridDim.x, ..: the grid is capped below the CU count (k_tridiag_solve) so
+    // that this kernel -- one workgroup per CU, 140 KB of LDS and 280 VGPRs each, several rounds back to back -- never holds every
+    // CU: the next call's eigen-chains start beside it, and their one-workgroup tridiagonalisation needs a whole CU's registers
+    // (with 768 workgroups on all 256 CUs the spatial chain of the next step waited ~0.1 ms for one).
+  for (int item = blockIdx.x; item < 2 * g.nx; item += gridDim.x) {
+    const int xr = item >> 1, p = item & 1;
+    const int np = g.np[p];
+    if (np <= 0) continue;                             // (the whole workgroup: no barrier is skipped by part of it)
+    const int nbatch = (np + TS_BATCH - 1) / TS_BATCH, npad = nbatch * TS_BATCH;
+    const double lam_m = g.es[xr] * g.amax[p][0], sig = g.sig[0];
+    const double *__restrict__ dd = g.d[p], *__restrict__ ee = g.e[p];
+    const long rowbase = (long)xr * g.R * g.nt + g.c0[p];
+    const int quarter = lane >> 4, kk_l = lane & 15;   // a global access: four rows of 16 columns
+    for (int r0 = 0; r0 < g.R; r0 += TS_P) {
+        const int nr = min(TS_P, g.R - r0);
+        const bool first = r0 == 0;
+        const double *const wl = g.W + rowbase + (long)(r0 + quarter) * g.nt + kk_l;     // this lane's corner of a piece
+        // ---- the rows of this pass into LDS: wave w takes batch w (npad <= 256: at most four batches, one per wave); the loads
+        // are issued first and land while the pivots are formed
+        const int b0 = wid * TS_BATCH;
+        double stg[4][16];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int kq = b0 + 16 * q;                              // wave-uniform classification of the piece's columns
+            // rows beyond the pass and columns beyond the block read a clamped (legal) address and are NOT zeroed: a duplicate
+            // row is a lane whose results are never stored, a duplicate column feeds a padding column that nothing reads back
+            // (its multipliers are zero) -- and 64 loop-invariant lane masks would live in SGPRs the kernel does not have
+            const int kc = min(kk_l, max(np - 1 - kq, 0));
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                double v = 0.0;
+                if (4 * i < nr && kq < np) {                         // wave-uniform: some row / column of the piece exists
+                    const int rc = min(quarter + 4 * i, nr - 1) - quarter;
+                    v = wl[(long)rc * g.nt + kq + (kc - kk_l)];
+                }
+                stg[q][i] = v;
+            }
+        }
+        if (first) {
+            // The pivots D_k = a_k - b_{k-1}^2 / D_{k-1} of the item, once: as a serial chain they are 250 x 7 dependent fp64
+            // operations (~175 cycles per column: 18 us, with three of the four waves waiting).  D_k is the ratio theta_k /
+            // theta_{k-1} of leading principal minors, and (theta_k, theta_{k-1})^T = M_k (theta_{k-1}, theta_{k-2})^T with
+            // M_k = [[a_k, -b_{k-1}^2], [1, 0]]: an inclusive scan over 2 x 2 matrix products, thread = column, eight doubling
+            // steps.  A prefix product may be scaled by any factor without changing the ratio: every product is renormalised by a
+            // power of two (positive definite blocks: all minors positive).
+            const int k = tid;
+            const bool real = k < np;
+            const double ak = real ? lam_m * dd[k] + sig : 1.0;
+            const double bkm = (k >= 1 && k < np) ? lam_m * ee[k - 1] : 0.0;
+            double m00 = ak, m01 = -bkm * bkm, m10 = 1.0, m11 = 0.0;
+            double *buf = scan;
+#pragma unroll 1
+            for (int dlt = 1; dlt < 256; dlt <<= 1, buf = (buf == scan) ? scan + 1024 : scan) {
+                buf[4 * k + 0] = m00; buf[4 * k + 1] = m01; buf[4 * k + 2] = m10; buf[4 * k + 3] = m11;
+                __syncthreads();
+                if (k >= dlt) {                                      // P <- P (later) x P_{k - dlt} (earlier)
+                    const double e00 = buf[4 * (k - dlt) + 0], e01 = buf[4 * (k - dlt) + 1], e10 = buf[4 * (k - dlt) + 2],
+                                 e11 = buf[4 * (k - dlt) + 3];
+                    const double n00 = m00 * e00 + m01 * e10, n01 = m00 * e01 + m01 * e11;
+                    const double n10 = m10 * e00 + m11 * e10, n11 = m10 * e01 + m11 * e11;
+                    const double big = fmax(fmax(fabs(n00), fabs(n01)), fmax(fabs(n10), fabs(n11)));
+                    int ex;
+                    (void)frexp(big, &ex);
+                    m00 = ldexp(n00, -ex); m01 = ldexp(n01, -ex); m10 = ldexp(n10, -ex); m11 = ldexp(n11, -ex);
+                }
+            }
+            // first column of the prefix product = (theta_k, theta_{k-1}) up to a common factor
+            const double pk = m10 / m00;                             // 1 / D_k
+            pinv[k] = real ? pk : 1.0;
+            buf[k] = pk;
+            __syncthreads();
+            lmul[k] = (k >= 1 && real) ? bkm * buf[k - 1] : 0.0;     // l_k = b_{k-1} / D_{k-1}; zero through the padding columns
+            if (k < TS_BATCH) {
+                pinv[TS_KMAX + k] = 1.0;
+                lmul[TS_KMAX + k] = 0.0;
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int i = 0; i < 16; ++i)
+                if (b0 < npad) zbuf[((b0 + 16 * q + kk_l) >> 1) * (2 * TS_P) + (quarter + 4 * i) * 2 + (kk_l & 1)] = stg[q][i];
+        __syncthreads();
+        stamp(1);
+        if (wid == 0) {
+            typedef double dbl2 __attribute__((ext_vector_type(2)));
+            dbl2 *const zl = reinterpret_cast<dbl2 *>(zbuf) + lane;  // this lane's row of the block: columns 2j, 2j + 1 at zl[j * 64]
+            // ---- forward sweep in place: z_k = w_k - l_k z_{k-1}
+            double z = 0.0;
+            for (int h0 = 0; h0 < npad; h0 += TS_HB) {
+                dbl2 *const zb = zl + (h0 >> 1) * TS_P;
+                const dbl2 *const lc = reinterpret_cast<const dbl2 *>(lmul + h0);
+                dbl2 v[TS_HB / 2], cl[TS_HB / 2];
+#pragma unroll
+                for (int j = 0; j < TS_HB / 2; ++j) {
+                    v[j] = zb[j * TS_P];
+                    cl[j] = lc[j];
+                }
+#pragma unroll
+                for (int j = 0; j < TS_HB / 2; ++j) {
+                    z = fma(-cl[j].x, z, v[j].x);
+                    v[j].x = z;
+                    z = fma(-cl[j].y, z, v[j].y);
+                    v[j].y = z;
+                }
+#pragma unroll
+                for (int j = 0; j < TS_HB / 2; ++j) zb[j * TS_P] = v[j];
+            }
+            stamp(2);
+            // ---- backward sweep in place: x_k = z_k / D_k - l_{k+1} x_{k+1}
+            double x = 0.0;
+            for (int h0 = npad - TS_HB; h0 >= 0; h0 -= TS_HB) {
+                dbl2 *const zb = zl + (h0 >> 1) * TS_P;
+                const dbl2 *const pc = reinterpret_cast<const dbl2 *>(pinv + h0);
+                double cl[TS_HB + 1];                                // l_{h0 + 1} .. l_{h0 + 32}: an odd offset, read singly
+                dbl2 v[TS_HB / 2], cp[TS_HB / 2];
+#pragma unroll
+                for (int j = 0; j < TS_HB / 2; ++j) {
+                    v[j] = zb[j * TS_P];
+                    cp[j] = pc[j];
+                }
+#pragma unroll
+                for (int kk = 0; kk < TS_HB; ++kk) cl[kk] = lmul[h0 + kk + 1];
+#pragma unroll
+                for (int j = TS_HB / 2 - 1; j >= 0; --j) {
+                    x = fma(v[j].y, cp[j].y, -cl[2 * j + 1] * x);
+                    v[j].y = x;
+                    x = fma(v[j].x, cp[j].x, -cl[2 * j] * x);
+                    v[j].x = x;
+                }
+#pragma unroll
+                for (int j = 0; j < TS_HB / 2; ++j) zb[j * TS_P] = v[j];
+            }
+        }
+        __syncthreads();
+        stamp(3);
+        // ---- the solutions out: 16-column pieces of a row, read transposed; wave w its batches
+        double *const bl = g.B + rowbase + (long)(r0 + quarter) * g.nt + kk_l;
+        for (int bi = wid; bi < nbatch; bi += 4) {
+            const int b0 = bi * TS_BATCH;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int kq = b0 + 16 * q;
+                if (kq >= np) continue;                              // wave-uniform
+                const bool kfull = kq + 15 < np, kok = kq + kk_l < np;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    if (4 * i >= nr) continue;                       // wave-uniform
+                    const double v = zbuf[((kq + kk_l) >> 1) * (2 * TS_P) + (quarter + 4 * i) * 2 + (kk_l & 1)];
+                    if (kfull && 4 * i + 3 < nr) bl[(long)(4 * i) * g.nt + kq] = v;      // whole piece: no lane mask
+                    else if (kok && quarter + 4 * i < nr) bl[(long)(4 * i) * g.nt + kq] = v;
+                }
+            }
+        }
+        __syncthreads();                                             // the block is free for the next pass
+        stamp(4);
+    }
+  }
+}
+
+static int tridiag_solve_npad(int npmax) { return (npmax + TS_BATCH - 1) / TS_BATCH * TS_BATCH; }
+static size_t tridiag_solve_lds(int npmax) {
+    const int npad = tridiag_solve_npad(npmax);
+    return ((size_t)npad * TS_P + 2 * (size_t)(256 + TS_BATCH) + 2 * 256 * 4) * sizeof(double);
+}
+// trials per pass (64: a lane each) if column blocks of up to npmax fit the kernel's LDS block, else 0 (not supported: the caller keeps
+// the eigenvector form).  R < 16 leaves most of the wave's lanes idle: the GEMM form is the better one there.
+int k_tridiag_solve_pass(int npmax, int R) {
+    return (R >= 16 && npmax <= 256 && tridiag_solve_lds(npmax) <= (size_t)150 * 1024) ? TS_P : 0;
+}
+
+void k_tridiag_solve(gpcsd_ctx *c, const double *W, double *B, const double *es, const double *const d[2], const double *const e[2],
+                     const double *const amax[2], const double *sig, int nx, int R, int nt, const int np[2], const int c0[2],
+                     hipStream_t s) {
+    TriSolveArgs g{};
+    g.W = W; g.B = B; g.es = es; g.sig = sig; g.nx = nx; g.R = R; g.nt = nt;
+    for (int p = 0; p < 2; ++p) {
+        g.d[p] = d[p]; g.e[p] = e[p]; g.amax[p] = amax[p]; g.np[p] = np[p]; g.c0[p] = c0[p];
+    }
+    const int npmax = std::max(np[0], np[1]);
+    GP_REQUIRE(k_tridiag_solve_pass(npmax, R) > 0, -3, "tridiag_solve: temporal blocks of %d columns do not fit the solve kernel", npmax);
+    g.npad = tridiag_solve_npad(npmax);
+    const size_t lds = tridiag_solve_lds(npmax);
+    static size_t attr = 0;
+    if (lds > attr) {
+        GP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(tridiag_solve_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr = lds;
+    }
+    static const bool clk_on = getenv("GPCSD_TS_CLK") && getenv("GPCSD_TS_CLK")[0] == '1';
+    g.clk = clk_on ? c->buf<unsigned long long>("ts_clk", 8) : nullptr;
+    ProfScope ps(c, "tridiag_solve", 6.0 * nx * (double)R * nt, s);
+    static const int grid_cap = getenv("GPCSD_TS_GRID") ? atoi(getenv("GPCSD_TS_GRID")) : 192;     // (A/B: 0 = one workgroup per item)
+    const int grid = grid_cap > 0 ? std::min(2 * nx, grid_cap) : 2 * nx;
+    hipLaunchKernelGGL(tridiag_solve_kernel, dim3(grid), dim3(256), lds, s, g);
+    GP_HIP(hipGetLastError());
+    if (clk_on) {
+        unsigned long long h[8];
+        GP_HIP(hipMemcpyAsync(h, g.clk, sizeof(h), hipMemcpyDeviceToHost, s));
+        GP_HIP(hipStreamSynchronize(s));
+        fprintf(stderr, "[tridiag_solve] item 0 (10 ns ticks): load+pivots %llu  forward %llu  backward %llu  store %llu\n", h[1] - h[0],
+                h[2] - h[1], h[3] - h[2], h[4] - h[3]);
+    }
+}
+
 // A(nx, ngl) = gl_w[g] * b_fwd_1d(gl_x[g] - x[i], R)                      covariances.py:86-88
 template <typename T>
 __global__ __launch_bounds__(256) void fwd_weights_1d_kernel(const double *__restrict__ x, int nx,

@@ -126,6 +126,13 @@ void k_se_axis(gpcsd_ctx *c, const double *a, int n, double ell, double *out, hi
 void k_ll_tridiag(gpcsd_ctx *c, const double *W, const double *es, const double *const d[2], const double *const e[2],
                   const double *const amax[2], const double *sig, int nx, int R, int nt, const int np[2], const int c0[2],
                   double *out_sumlog, double *out_quad, hipStream_t s);
+// The same systems solved: B[x'][r][p block] = (es[x'] amax_p T_p + sig2 I)^-1 W[x'][r][p block] (B may be W).  The posterior mean
+// in the basis U (x) Q -- what (W V) / D is in the basis U (x) V -- without the temporal eigenvectors.
+// k_tridiag_solve_pass: trials per pass of the kernel for column blocks of up to npmax (its z lives in LDS); 0 = unsupported.
+int k_tridiag_solve_pass(int npmax, int R);
+void k_tridiag_solve(gpcsd_ctx *c, const double *W, double *B, const double *es, const double *const d[2], const double *const e[2],
+                     const double *const amax[2], const double *sig, int nx, int R, int nt, const int np[2], const int c0[2],
+                     hipStream_t s);
 void k_add_diag(gpcsd_ctx *c, double *A, int n, double v, hipStream_t s, const HpDev *tab = nullptr, int B = 1, long s_out = 0);
 // D[x*nt + i] = es[x]*et[i] + sig[x or 0]; also sumlog -> *sumlog_out (deterministic)
 // Dinv (optional) = 1/D elementwise.  sumlog_out == nullptr: no final sum; the per-block partials stay in the ctx buffer
@@ -183,7 +190,7 @@ struct EigArenaView {
 };
 EigArenaView eigh_arena_view(gpcsd_ctx *c, const char *tag, int n, int count);
 // tags of the two half-size classes of problem `slot` (0 / 1) of eigh_pair_device: [0] symmetric, [1] antisymmetric
-const char *const *eigh_fold_tags(int slot);
+const char *const *eigh_fold_tags(const gpcsd_ctx *c, int slot);     // (slot 1: the tag set of the context's current generation, gpcsd_ctx::tgen)
 // fold of a PSD matrix (+ diagonal shift per replica) straight into the class arenas, scaled: see eigh.hip
 void k_psd_fold_fill(gpcsd_ctx *c, const double *K, int n, long sK, int nrep, const double *shift, const SymDev &sy,
                      const EigArenaView &as, const EigArenaView &aa, int *status, int status_stride, hipStream_t s,

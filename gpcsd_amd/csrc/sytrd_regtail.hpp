@@ -75,6 +75,16 @@ __device__ __forceinline__ void rt_house(double alpha, double xnorm2, bool ok, d
     }
 }
 
+// Early exit for positive semi-definite inputs (SytrdProb::psd: the Gram matrices of the fused calls).  A Householder step is a
+// similarity transformation, so the block still to be reduced stays PSD and its trace -- trace(A) minus the diagonal entries
+// already produced, one scalar kept by the generating wave -- bounds its norm.  Once that trace has dropped below 64 unit roundoffs
+// of trace(A) the rest of the block is rounding noise of the part already reduced: the remaining reflectors are left out (H = I:
+// tau = 0) and the tridiagonal ends with the block's diagonal.  Backward error <= the dropped trace, inside the n eps ||A||
+// the reduction itself commits.  The Gram matrices of smooth kernels are numerically low-rank: the 192-row halves of the
+// 384-channel Ks have ~58 eigenvalues above 1e-13 of the largest, and two thirds of the serial column steps of their tails
+// multiplied noise.  GPCSD_TAIL_EARLY_EXIT=0 keeps every column step (A/B, cross-check).
+__device__ int rt_early_exit_enabled = 1;
+
 __global__ __launch_bounds__(RT_NTH) void sytrd_rtail_kernel(SytrdBatch b) {
     const SytrdProb P = sy_resolve(b, blockIdx.x);
     const int n = P.n, k0 = P.k_tail;
@@ -89,6 +99,8 @@ __global__ __launch_bounds__(RT_NTH) void sytrd_rtail_kernel(SytrdBatch b) {
     __shared__ __attribute__((aligned(16))) double red[RT_NW];
     __shared__ double sd[RT_TMAX], se[RT_TMAX], st[RT_TMAX];
     __shared__ double s_r, s_u1;                   // 1 / ||column|| (0: H = I) and |u_1| of the current reflector
+    __shared__ double s_trace, s_ttol;             // early exit (below): trace still to be reduced, and the threshold
+    __shared__ int s_exit_at;                      // first block column left out (-1: none)
     // v is double-buffered: the wave generating reflector kk+1 writes it while slower waves still read v of column kk
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int gg = lane >> 4, h = lane & 15;       // row group inside the wave, column part
@@ -147,7 +159,31 @@ __global__ __launch_bounds__(RT_NTH) void sytrd_rtail_kernel(SytrdBatch b) {
             strip[idx] = v;
         }
     }
+    {
+        // trace of the register block as loaded (one entry per thread at most lies on the diagonal... up to RT_R of them)
+        double tr = 0.0;
+#pragma unroll
+        for (int r = 0; r < RT_R; ++r)
+#pragma unroll
+            for (int j = 0; j < RT_C; ++j) tr += (row0 + r == c0 + j) ? a[r][j] : 0.0;
+        tr = wave_sum(tr);
+        if (lane == 0) red[wid] = tr;
+    }
     __syncthreads();
+    if (tid == 0) {
+        double tot = 0.0;
+#pragma unroll
+        for (int q = 0; q < RT_NW; ++q) tot += red[q];
+        s_trace = tot;
+        // (strip rows in front of the block, S > 0: their diagonal is not counted -- the check then only starts once the
+        // strip is done, with the block's own trace at that point taken below)
+        // 64 unit roundoffs of the trace: what the running difference itself can be off by after a few hundred subtractions, and
+        // a dropped PSD block moves no eigenvalue by more than its trace (Weyl) -- the few-eps-||A|| any solver leaves in the
+        // small eigenvalues.  (4 n eps, the reduction's own backward-error scale, showed in a log-likelihood: 1D models multiply
+        // the temporal spectrum by spatial eigenvalues of 1e8, and 1.2e-9 of it moved.)
+        s_ttol = (P.psd && rt_early_exit_enabled && S == 0) ? 64.0 * EPS_U * tot : -1.0;
+        s_exit_at = -1;
+    }
     if (tid < RT_TMAX) sy[tid] = 0.0;              // from here on sy is y = A v: zero on dead rows and beyond T
     __syncthreads();
 
@@ -394,6 +430,9 @@ __global__ __launch_bounds__(RT_NTH) void sytrd_rtail_kernel(SytrdBatch b) {
                 seb[kk] = beta;
                 s_r = r;
                 s_u1 = fabs(u1);
+                const double rem = s_trace - dk;                     // trace of the block behind column kk
+                s_trace = rem;
+                if (s_ttol >= 0.0 && rem <= s_ttol && s_exit_at < 0) s_exit_at = kk + 1;     // (s_ttol < 0: the check is off)
             }
             __builtin_amdgcn_s_setprio(0);
         }
@@ -464,11 +503,30 @@ __global__ __launch_bounds__(RT_NTH) void sytrd_rtail_kernel(SytrdBatch b) {
             }
         }
     };
-    for (int kb = 0; kb < TB - 1; kb += 4) {                         // TB is the same for every thread: uniform control flow
+    int exit_at = -1, kb = 0;
+    for (; kb < TB - 1; kb += 4) {                                   // TB is the same for every thread: uniform control flow
         column(kb, std::integral_constant<int, 0>{});
         if (kb + 1 < TB - 1) column(kb + 1, std::integral_constant<int, 1>{});
         if (kb + 2 < TB - 1) column(kb + 2, std::integral_constant<int, 2>{});
         if (kb + 3 < TB - 1) column(kb + 3, std::integral_constant<int, 3>{});
+        // (read behind the last column's barrier B: the flag was set in front of one of this group's barriers A)
+        exit_at = s_exit_at;                                         // uniform: every thread reads the same LDS word
+        if (exit_at >= 0) break;
+    }
+    if (exit_at >= 0) {
+        // Columns exit_at .. kb + 3 of the group were still reduced (harmless: noise); from kb + 4 on the block is left as it
+        // is -- d = its diagonal, e = tau = 0, the reflector rows stay as the scaling pass cleared them (H = I).
+        const int kfirst = min(kb + 4, TB - 1);
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < RT_R; ++r)
+#pragma unroll
+            for (int j = 0; j < RT_C; ++j)
+                if (row0 + r == c0 + j && row0 + r >= kfirst && row0 + r < TB) sdb[row0 + r] = a[r][j];
+        if (tid >= kfirst && tid < TB) {
+            seb[tid] = 0.0;
+            stb[tid] = 0.0;
+        }
     }
     // last diagonal element a[TB-1][TB-1]
     if (wid == ((TB - 1) >> 4)) {
