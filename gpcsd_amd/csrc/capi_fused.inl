@@ -12,6 +12,7 @@ static int finish_loglik_async(gpcsd_ctx *c, const EigState &e, bool two) {
     GP_HIP(hipMemcpyAsync(c->h_ll + gpcsd_ctx::RESULT_DOUBLES * k, e.scal, gpcsd_ctx::RESULT_DOUBLES * sizeof(double),
                           hipMemcpyDeviceToHost, c->stream));
     GP_HIP(hipEventRecord(sl.ev, c->stream));
+    c->tl("loglik result copied (main)", c->stream);
     ++c->ll_count;
     sl.done = false;
     sl.two = two;
