@@ -478,8 +478,10 @@ static bool two_stream_front() {            // GPCSD_TWO_STREAM=0: single batche
 // stale spectra -- such callers rebuild it in fold order (join_temporal with a FoldMode).
 // join_s = false: the caller calls join_spatial() itself.  Fold views (fold_mode) must be taken AFTER this returns.
 // want_tri: the caller's tail works from the temporal tridiagonalisation + Q alone (EigState::tri tells it whether it may).
+// merged_s: the spatial side's merged spectrum and eigenvectors are wanted although the temporal side's are not (-1: as need_merged).
 EigState front_half(gpcsd_ctx *c, const gpcsd_hparams *hp, double jitter, bool need_merged = true, bool join_s = true,
-                    bool want_tri = false) {
+                    bool want_tri = false, int merged_s = -1) {
+    const bool need_merged_s = merged_s < 0 ? need_merged : merged_s != 0;
     const Geo g = resident_geo(c);
     GP_REQUIRE(c->d_lfp != nullptr, -4, "lfp not set (call gpcsd_set_lfp)");
     GP_REQUIRE(c->time_nt == c->nt, -4, "time grid has %d points but lfp has nt=%d", c->time_nt, c->nt);
@@ -526,7 +528,7 @@ EigState front_half(gpcsd_ctx *c, const gpcsd_hparams *hp, double jitter, bool n
         make_kt(s);
         // the symmetries come from the resident geometry / time grid, so they hold for the Grams built from them
         eig_pair_D(c, Ks, nx, Kt, nt, d_sig, hp->n_sig2n, e.Qs, e.es, e.Qt, e.et, e.D, e.Dinv, e.scal, e.status, sym_s, sym_t,
-                   need_merged);
+                   need_merged || need_merged_s);
         e.d_sig = d_sig;
         e.nsig = hp->n_sig2n;
         return e;
@@ -568,7 +570,7 @@ EigState front_half(gpcsd_ctx *c, const gpcsd_hparams *hp, double jitter, bool n
         double R, eps, ell[2], jitter;
     } ks_key;
     memset(&ks_key, 0, sizeof(ks_key));
-    ks_key.epoch = c->grid_epoch; ks_key.nx = nx; ks_key.merged = need_merged; ks_key.fold = sym_s != nullptr;
+    ks_key.epoch = c->grid_epoch; ks_key.nx = nx; ks_key.merged = need_merged_s; ks_key.fold = sym_s != nullptr;
     ks_key.R = hp->R; ks_key.eps = g.dim == 2 ? hp->eps : 0.0; ks_key.ell[0] = hp->ell_s[0];
     ks_key.ell[1] = g.dim == 2 ? hp->ell_s[1] : 0.0; ks_key.jitter = jitter;
     const bool run_s = !decomp_cached(c, 0, &ks_key, sizeof(ks_key));
@@ -635,7 +637,7 @@ EigState front_half(gpcsd_ctx *c, const gpcsd_hparams *hp, double jitter, bool n
         if (sfill) spatial_fill(c, Ks, nx, 0, 1, &jitter, *sym_s, e.status, 0, s3);
         {
             ProfScope ps(c, "eigh_spatial", 9.0 * (double)nx * nx * nx, s3);
-            eigh_pair_device(c, Ks, nx, e.es, e.Qs, sym_s, nullptr, 0, nullptr, nullptr, nullptr, e.status, s3, need_merged, 1, 0, -1,
+            eigh_pair_device(c, Ks, nx, e.es, e.Qs, sym_s, nullptr, 0, nullptr, nullptr, nullptr, e.status, s3, need_merged_s, 1, 0, -1,
                              sfill ? 1 : 0);
         }
         GP_HIP(hipEventRecord(c->ev_sjoin, s3));
@@ -699,11 +701,14 @@ static SymDev identity_sym(gpcsd_ctx *c, int n) {
     return sy;
 }
 
-static FoldMode fold_mode(gpcsd_ctx *c, const gpcsd_hparams *hp) {
+// fold_spatial = false: the spatial side takes part unfolded (one full-size block, merged eigenvectors) although the electrodes have
+// a reflection symmetry -- for prediction sites that do not share it (the cross-covariances then do not commute with the pair of
+// reflections, but everything on the temporal side still folds).
+static FoldMode fold_mode(gpcsd_ctx *c, const gpcsd_hparams *hp, bool fold_spatial = true) {
     static const bool off = getenv("GPCSD_NO_FOLD_GEMM") && getenv("GPCSD_NO_FOLD_GEMM")[0] == '1';
     FoldMode fm;
     if (off || !c->fold_gemm_on || hp->n_sig2n != 1 || c->nx <= 0 || c->nt <= 0) return fm;
-    if (c->sym_s.ns > 0) fm.fs = eigh_fold_view(c, 0, &c->sym_s, c->nx);
+    if (c->sym_s.ns > 0 && fold_spatial) fm.fs = eigh_fold_view(c, 0, &c->sym_s, c->nx);
     if (c->sym_t.ns > 0 && !uses_host_kt(hp)) fm.ft = eigh_fold_view(c, 1, &c->sym_t, c->nt);
     if (!fm.fs.on && !fm.ft.on) return fm;
     fm.on = true;
@@ -726,10 +731,13 @@ static FoldMode fold_mode(gpcsd_ctx *c, const gpcsd_hparams *hp) {
 
 // Fs Y Ft^T in the layout of the resident data ([fold x][r][fold t]); rebuilt when data, geometry or time grid change
 static const double *folded_lfp(gpcsd_ctx *c, const FoldMode &fm) {
-    double *Yf = c->buf<double>("lfp_fold", (size_t)c->nx * c->ntrials * c->nt);
-    if (c->lfp_fold_sig != fm.sig()) {                               // 0: invalid; else which sides the resident copy folds
+    // one copy per combination of folded sides (a model whose prediction sites do not share the electrodes' symmetry alternates
+    // between "both sides folded" for loglik and "time only" for predict: neither evicts the other)
+    const int sig = fm.sig();
+    double *Yf = c->buf<double>("lfp_fold" + std::to_string(sig), (size_t)c->nx * c->ntrials * c->nt);
+    if (!(c->lfp_fold_sig & (1 << sig))) {
         k_fold_lfp(c, c->d_lfp, c->nx, c->ntrials, c->nt, fm.sym_s, fm.sym_t, Yf, c->stream);
-        c->lfp_fold_sig = fm.sig();
+        c->lfp_fold_sig |= 1 << sig;
     }
     return Yf;
 }

@@ -429,12 +429,19 @@ static int predict_impl(gpcsd_ctx *c, const gpcsd_hparams *hp, const double *z, 
                       (!fm0.ft.on || ((int)c->time_host.size() == c->nt &&
                                       memcmp(c->time_host.data(), tstar, (size_t)ntstar * sizeof(double)) == 0));
     if (t_ok) {
-        const SymDev sz = fm0.fs.on ? site_symmetry(c, z, nz, c->dim) : identity_sym(c, nz);
+        SymDev sz = fm0.fs.on ? site_symmetry(c, z, nz, c->dim) : identity_sym(c, nz);
+        // sites without the electrodes' symmetry (the reference's own use: four off-grid depths): the spatial side unfolded, the
+        // temporal side folded as ever -- not the full-size path
+        bool fold_s = true;
+        if (!(sz.ns > 0 && sz.ns + sz.na == nz) && fm0.fs.on && fm0.ft.on) {
+            fold_s = false;
+            sz = identity_sym(c, nz);
+        }
         if (sz.ns > 0 && sz.ns + sz.na == nz) {
             // the chains go first (they need no upload of this call), then the host-side uploads
             const bool ptri = fm0.ft.on && predict_tridiag_applies(fm0.ft.ns, fm0.ft.na, c->ntrials);
-            EigState ef = front_half(c, hp, 0.0, false, /*join_s=*/false, /*want_tri=*/ptri);  // no jitter in predict (gpcsd1d.py:258)
-            const FoldMode fm = fold_mode(c, hp);
+            EigState ef = front_half(c, hp, 0.0, false, /*join_s=*/false, /*want_tri=*/ptri, fold_s ? -1 : 1);  // no jitter in predict (gpcsd1d.py:258)
+            const FoldMode fm = fold_mode(c, hp, fold_s);
             const double *Yf = folded_lfp(c, fm);
             double *dzf = c->upload_cached<double>("pred_z", z, (size_t)nz * c->dim);
             double *dtf = c->upload_cached<double>("pred_tstar", tstar, ntstar);
@@ -548,7 +555,9 @@ static bool same_temporal(const gpcsd_hparams *a, const gpcsd_hparams *b) {
 // Both sets decomposed, set b's results at replica b of the generation just started (folded-basis callers only).
 // pred_tri: the prediction (set 1) takes the tridiagonal form too, so that nobody reads the temporal spectrum or eigenvectors: the
 // staged temporal chain then stops behind stages 1 and 3.
-static void front_half_pair(gpcsd_ctx *c, const gpcsd_hparams *const hp[2], const double jitter[2], PairFront &out, bool pred_tri) {
+// fold_s = false: the tails take the spatial side unfolded (merged eigenvectors; the eigensolver still folds it internally).
+static void front_half_pair(gpcsd_ctx *c, const gpcsd_hparams *const hp[2], const double jitter[2], PairFront &out, bool pred_tri,
+                            bool fold_s = true) {
     const Geo g = resident_geo(c);
     const int nx = c->nx, nt = c->nt;
     const long nxx = (long)nx * nx, ntt = (long)nt * nt;
@@ -645,7 +654,7 @@ static void front_half_pair(gpcsd_ctx *c, const gpcsd_hparams *const hp[2], cons
         // two replicas of the spatial problem on stream3 (status words [0], [2])
         {
             ProfScope ps(c, "eigh_spatial", 9.0 * (double)nx * nx * nx * 2, s3);
-            eigh_pair_device(c, Ks, nx, es, Qs, sym_s, nullptr, 0, nullptr, nullptr, nullptr, status, s3, false, 2, 2, -1,
+            eigh_pair_device(c, Ks, nx, es, Qs, sym_s, nullptr, 0, nullptr, nullptr, nullptr, status, s3, /*need_merged=*/!fold_s, 2, 2, -1,
                              sfill ? 1 : 0);
         }
         GP_HIP(hipEventRecord(c->ev_sjoin, s3));
@@ -677,7 +686,7 @@ static void front_half_pair(gpcsd_ctx *c, const gpcsd_hparams *const hp[2], cons
             e.late_stages = !pred_tri;
         }
         FoldMode &fm = out.fm[b];
-        fm = fold_mode(c, hp[b]);                       // replica 0 of the generations just started ...
+        fm = fold_mode(c, hp[b], fold_s);               // replica 0 of the generations just started ...
         if (fm.fs.on) { fm.fs.w += (long)b * vs.sw; fm.fs.U += (long)b * vs.sU; }       // ... moved to replica b
         else { fm.fs.w += (long)b * nx; fm.fs.U += b * nxx; }
         if (fm.ft.on) { fm.ft.w += (long)bt * vt.sw; fm.ft.U += (long)bt * vt.sU; }
@@ -726,8 +735,14 @@ extern "C" int gpcsd_loglik_predict_async(gpcsd_ctx *c, const gpcsd_hparams *hp_
                (!fm0.ft.on || ((int)c->time_host.size() == c->nt &&
                                memcmp(c->time_host.data(), tstar, (size_t)ntstar * sizeof(double)) == 0));
     }
+    bool fold_s = true;
     if (pair) {
         sz = fm0.fs.on ? site_symmetry(c, z, nz, c->dim) : identity_sym(c, nz);
+        if (!(sz.ns > 0 && sz.ns + sz.na == nz) && fm0.fs.on && fm0.ft.on) {      // sites without the electrodes' symmetry: spatial
+            fold_s = false;                                                          // side unfolded for BOTH sets (see predict_impl)
+            sz = identity_sym(c, nz);
+            fm0 = fold_mode(c, hp_ll, false);
+        }
         pair = sz.ns > 0 && sz.ns + sz.na == nz;
     }
     if (!pair) {
@@ -744,7 +759,7 @@ extern "C" int gpcsd_loglik_predict_async(gpcsd_ctx *c, const gpcsd_hparams *hp_
     PairFront pf;
     // (decided here, where the fold sizes are known: does the prediction take the tridiagonal form too?)
     const bool pred_tri = fm0.ft.on && predict_tridiag_applies(fm0.ft.ns, fm0.ft.na, c->ntrials);
-    front_half_pair(c, hps, jit, pf, pred_tri);
+    front_half_pair(c, hps, jit, pf, pred_tri, fold_s);
     const double *Yf = folded_lfp(c, pf.fm[1]);
     double *dzf = c->upload_cached<double>("pred_z", z, (size_t)nz * c->dim);
     double *dtf = c->upload_cached<double>("pred_tstar", tstar, ntstar);

@@ -159,7 +159,7 @@ struct gpcsd_ctx {
     bool sym_s_refl[2] = {false, false};
     std::vector<double> geo_host, time_host, sym_z_pts;
     gpcsd::SymDev sym_z;
-    int lfp_fold_sig = 0;                   // 0: the folded copy of the data is stale; else FoldMode::sig() it was built for
+    int lfp_fold_sig = 0;                   // bit k set: the folded copy of the data for FoldMode::sig() == k is current (0: none is)
     bool status_zeroed = false;             // the fused calls' status words were cleared at the end of the previous call
     bool late_dirty = false;                // ... except the late words: a tridiagonal-form log-likelihood returned under its chain's stages 2 / 4
     bool gram_fp32 = false;                 // gpcsd_set_gram_precision(): Gram builders evaluate in float (cfg5 variant)

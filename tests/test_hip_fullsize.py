@@ -1164,3 +1164,43 @@ def test_cfg3_at_50_trials_paired_step_vs_oracle():
     print("cfg3 R=50: loglik rel err %.2e, predict %.2e, per-component %.2e" % (e_ll, e_pr, e_l))
     assert e_ll < 1e-9 and e_pr < GATE and e_l < GATE
     assert float(m.loglik()) == ll                                 # the class API's synchronous call: the same bits
+
+
+def test_asymmetric_prediction_sites_on_a_symmetric_probe_keep_the_folded_temporal_path():
+    """Prediction sites that do not share the electrodes' reflection symmetry (the reference's own use: four off-grid depths,
+    neuropixels/fit_gpcsd2d.py:46,107) used to drop predict -- and the paired call -- to the full-size path.  Now only the spatial
+    side is taken unfolded (merged eigenvectors), the temporal side stays folded: same results (1e-6 gate vs the oracle; 1e-10 vs
+    the full-size path), the folded-path counter moves, and the paired queued call returns the bits of the two calls."""
+    from gpcsd_amd import _hip
+    c, g, geom, hp, _ = load_model_case("cfg3s_2d_384x500x2")
+    lfp = C.synth_lfp(233, 384, 500, 3)
+    m = _model_from_case(c, g, lfp)
+    ctx = m._sync_device()
+    z = np.stack([24.0 * np.ones(4), np.array([2260.0, 2450.0, 2650.0, 2785.0])]).T
+    n0 = ctx.fold_gemm()
+    m.predict(z, c["t"], type="both")
+    assert ctx.fold_gemm() > n0                                    # folded-basis tail, not the full-size fallback
+    ref = O.predict(geom, hp, lfp, z, c["t"], type="both")
+    assert relerr(m.csd_pred, ref["csd"]) < GATE and relerr(m.lfp_pred, ref["lfp"]) < GATE
+    folded = m.csd_pred.copy()
+    ctx.fold_gemm(False)
+    m.predict(z, c["t"], type="csd")
+    ctx.fold_gemm(True)
+    assert relerr(folded, m.csd_pred) < 1e-9
+    # paired call at these sites: bits of the separate calls
+    h1, k1 = m._hparams(m.JITTER)
+    h0, k0 = m._hparams(0.0)
+    ctx.decomposition_cache(False)
+    sl0, q0 = ctx.loglik_parts(h1)
+    ctx.predict_resident(h0, z, c["t"], _hip.PRED_CSD, want_lists=True)
+    bits = ctx.fetch("pred_out_csd", (4, 500, 3)).copy()
+    for _ in range(3):
+        ctx.loglik_predict_async(h1, h0, z, c["t"], _hip.PRED_CSD, want_lists=True)
+        sl, q = ctx.loglik_parts_wait()
+    # (the paired call takes the log-likelihood's spatial side unfolded as well: equal to the folded evaluation to rounding)
+    assert abs(sl - sl0) <= 1e-12 * abs(sl0) and abs(q - q0) <= 1e-10 * abs(q0)
+    assert np.array_equal(ctx.fetch("pred_out_csd", (4, 500, 3)), bits)
+    # and loglik / predict alternate without evicting each other's folded copy of the data
+    ll1 = float(m.loglik())
+    m.predict(z, c["t"], type="csd")
+    assert float(m.loglik()) == ll1
