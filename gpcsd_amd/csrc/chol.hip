@@ -65,6 +65,8 @@ __device__ __forceinline__ double readlane_d(double v, int lane) {       // lane
 // Fragment maps (cdna_hip_programming.md section 3): A lane l holds A[l & 15][l >> 4], B lane l holds B[l >> 4][l & 15], C lane l
 // register r holds C[(l >> 4) + 4 r][l & 15].
 constexpr int DN = 128, DLD = 130, LPLD = 17;
+constexpr int DNT = 512, DNW = DNT / 64;      // threads / waves of the workgroup: 8 waves keep 256 VGPRs each (with 16 waves and 128
+                                              // registers the panel arrays and the inverse's operand strips spilled to scratch)
 constexpr size_t DIAG_LDS_BYTES = ((size_t)DN * DLD + (size_t)DN * LPLD + DN) * sizeof(double);
 
 template <int H>
@@ -72,7 +74,7 @@ __device__ __forceinline__ void inverse_level(double *As, int wid, int lane) {
     constexpr int NF = H / 16, NPAIR = 64 / H;
     const int fr = lane & 15, fq = lane >> 4;
     // product 1: T = B X_A, fragment (fi, fj) of pair q; count = NPAIR * NF * NF = H / 4
-    for (int t = wid; t < NPAIR * NF * NF; t += 16) {
+    for (int t = wid; t < NPAIR * NF * NF; t += DNW) {
         const int q = t / (NF * NF), rem = t % (NF * NF), fi = rem / NF, fj = rem % NF;
         const int o = 2 * H * q;
         d4 acc = {0.0, 0.0, 0.0, 0.0};
@@ -133,7 +135,7 @@ __device__ __forceinline__ void inverse_level(double *As, int wid, int lane) {
 // Xout (lower; leading dimension ldx).  !FACTOR: the block already is a Cholesky factor: inverse only.
 // status: first failing pivot + 1 (global index pivot_base + j).  Blocks smaller than 128 are padded with the identity.
 template <bool FACTOR>
-__global__ __launch_bounds__(1024) void diag128_kernel(double *Ablk, long lda, int nb, double *Xout, long ldx, int *status,
+__global__ __launch_bounds__(DNT) void diag128_kernel(double *Ablk, long lda, int nb, double *Xout, long ldx, int *status,
                                                        int pivot_base, unsigned long long *clk) {
     // clk (measurement aid, normally null): wall-clock stamps (100 MHz) at the phase boundaries -- [0] start, [1] block loaded,
     // [2] / [3] ticks spent in the serial panels / the rank-16 updates, [4] L stored, [5] diagonal inverses, [6..8] doubling levels,
@@ -148,15 +150,16 @@ __global__ __launch_bounds__(1024) void diag128_kernel(double *Ablk, long lda, i
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int fr = lane & 15, fq = lane >> 4;
     {   // all sixteen loads of a thread in flight before the first LDS store (interleaved, each store waited for its load: 10 us)
-        double v[16];
+        constexpr int NL = DN * DN / DNT;
+        double v[NL];
 #pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            const int e = tid + 1024 * k, i = e >> 7, c = e & 127;
+        for (int k = 0; k < NL; ++k) {
+            const int e = tid + DNT * k, i = e >> 7, c = e & 127;
             v[k] = (i < nb && c < nb) ? (c <= i ? Ablk[(long)i * lda + c] : 0.0) : (i == c ? 1.0 : 0.0);
         }
 #pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            const int e = tid + 1024 * k;
+        for (int k = 0; k < NL; ++k) {
+            const int e = tid + DNT * k;
             As[(e >> 7) * DLD + (e & 127)] = v[k];
         }
     }
@@ -186,6 +189,8 @@ __global__ __launch_bounds__(1024) void diag128_kernel(double *Ablk, long lda, i
                     p1[jj] *= rinv;
 #pragma unroll
                     for (int cc = jj + 1; cc < 16; ++cc) {
+                        // (the multipliers through LDS instead -- written by the diagonal block's lanes, read back as broadcasts -- or
+                        // through ds_bpermute: no faster; a column step is its ~11 levels of dependent fp64 operations, ~25 cycles each)
                         const double lc = readlane_d(p0[jj], cc);
                         p0[cc] = fma(-p0[jj], lc, p0[cc]);
                         p1[cc] = fma(-p1[jj], lc, p1[cc]);
@@ -208,7 +213,7 @@ __global__ __launch_bounds__(1024) void diag128_kernel(double *Ablk, long lda, i
             if (clk) { const unsigned long long t = wall_clock64(); t_f1 += t - t_last; t_last = t; }
             // rank-16 update of the fragments (fi, fc), pb < fc <= fi <= 7
             const int m = 7 - pb, count = m * (m + 1) / 2;
-            for (int t = wid; t < count; t += 16) {
+            for (int t = wid; t < count; t += DNW) {
                 int ri = 0;
                 while ((ri + 1) * (ri + 2) / 2 <= t) ++ri;
                 const int rc = t - ri * (ri + 1) / 2;
@@ -229,7 +234,7 @@ __global__ __launch_bounds__(1024) void diag128_kernel(double *Ablk, long lda, i
             if (clk) { const unsigned long long t = wall_clock64(); t_f2 += t - t_last; t_last = t; }
         }
         if (clk && tid == 0) { clk[2] = t_f1; clk[3] = t_f2; }
-        for (int e = tid; e < DN * DN; e += 1024) {
+        for (int e = tid; e < DN * DN; e += DNT) {
             const int i = e >> 7, c = e & 127;
             if (i < nb && c < nb) Ablk[(long)i * lda + c] = c <= i ? As[i * DLD + c] : 0.0;           // L in place, upper part zeroed
         }
@@ -248,6 +253,7 @@ __global__ __launch_bounds__(1024) void diag128_kernel(double *Ablk, long lda, i
 #pragma unroll
             for (int k = 0; k < i; ++k) sacc = fma(-As[(b0 + i) * DLD + b0 + k], x[k], sacc);
             x[i] = sacc * dinv[b0 + i];
+            __builtin_amdgcn_sched_barrier(0);             // (keeps the 120 LDS reads of the block from being hoisted into 240 registers)
         }
         if (lane < 16) {
 #pragma unroll
@@ -263,7 +269,7 @@ __global__ __launch_bounds__(1024) void diag128_kernel(double *Ablk, long lda, i
     stamp(7);
     inverse_level<64>(As, wid, lane);
     stamp(8);
-    for (int e = tid; e < DN * DN; e += 1024) {
+    for (int e = tid; e < DN * DN; e += DNT) {
         const int i = e >> 7, c = e & 127;
         if (i < nb && c < nb) Xout[(long)i * ldx + c] = c <= i ? As[c * DLD + i + 1] : 0.0;
     }
@@ -280,8 +286,8 @@ static void launch_diag(double *Ablk, long lda, int nb, double *Xout, long ldx, 
                                    (int)DIAG_LDS_BYTES));
         attr_done = true;
     }
-    if (factor) hipLaunchKernelGGL(diag128_kernel<true>, dim3(1), dim3(1024), DIAG_LDS_BYTES, s, Ablk, lda, nb, Xout, ldx, status, pivot_base, clk);
-    else hipLaunchKernelGGL(diag128_kernel<false>, dim3(1), dim3(1024), DIAG_LDS_BYTES, s, Ablk, lda, nb, Xout, ldx, status, pivot_base, clk);
+    if (factor) hipLaunchKernelGGL(diag128_kernel<true>, dim3(1), dim3(DNT), DIAG_LDS_BYTES, s, Ablk, lda, nb, Xout, ldx, status, pivot_base, clk);
+    else hipLaunchKernelGGL(diag128_kernel<false>, dim3(1), dim3(DNT), DIAG_LDS_BYTES, s, Ablk, lda, nb, Xout, ldx, status, pivot_base, clk);
 }
 
 __global__ void copy2d_kernel(const double *__restrict__ src, long lds_, double *__restrict__ dst, long ldd, int rows, int cols) {
