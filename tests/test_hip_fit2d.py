@@ -452,3 +452,22 @@ def test_npx69_fit_twenty_restarts_runs_in_lockstep_and_matches_scipy_on_the_ora
     f0 = obj(tp_best)
     print("npx69 fit: best nll %.6f, oracle objective at the fitted parameters %.6f (rel %.2e)" % (best, f0, abs(f0 - best) / abs(best)))
     assert abs(f0 - best) <= 1e-5 * abs(best), (f0, best)
+
+
+@pytest.mark.parametrize("ntrials", [16, 70])
+def test_npx69_prediction_in_the_tridiagonal_form_vs_oracle_and_vs_the_eigenvector_form(ntrials):
+    """The prediction's tridiagonal form (k_tridiag_solve: per (spatial eigen-row, time parity) one L D L^T solve per trial instead of
+    (W V) / D) needs >= 16 resident trials; temporal halves of 188 columns (not a multiple of the kernel's 64-column batches), 16
+    trials (one partial pass) and 70 (a full pass of 64 lanes + 6): against the oracle, and against the eigenvector form of the
+    same call (gpcsd_ll_tridiag mode 0) to 1e-10."""
+    w, m, lfp, geom, hp, hp0 = _npx69(ntrials, seed=9)
+    ctx = m._sync_device()
+    ctx.ll_tridiag(1)
+    m.predict(w["z"], w["t"], type="both")
+    tri = [m.csd_pred.copy(), m.lfp_pred.copy(), m.csd_pred_list[1].copy()]
+    ref = O.predict(geom, hp0, lfp, w["z"], w["t"], type="both")
+    assert _rel(tri[0], ref["csd"]) < GATE and _rel(tri[1], ref["lfp"]) < GATE and _rel(tri[2], ref["csd_list"][1]) < GATE
+    ctx.ll_tridiag(0)
+    m.predict(w["z"], w["t"], type="both")
+    assert _rel(tri[0], m.csd_pred) < 1e-10 and _rel(tri[1], m.lfp_pred) < 1e-10
+    ctx.ll_tridiag(2)
