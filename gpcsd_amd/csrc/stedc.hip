@@ -228,7 +228,7 @@ __global__ __launch_bounds__(64) void dc_leaf_reg_kernel(DcLevel L, int *status,
 __global__ __launch_bounds__(1024) void dc_leaf_wyprep_kernel(DcLevel L, int *status, int nleaf_max, int nunits, WyBatch wb,
                                                               int nprep) {
     if ((int)blockIdx.x < nprep) {
-        wy_prep_body(wy_resolve(wb, blockIdx.y), (int)blockIdx.x, (int)threadIdx.x);
+        wy_prep_role(wy_resolve(wb, blockIdx.y), (int)blockIdx.x, (int)threadIdx.x);
         return;
     }
     const int bx = ((int)blockIdx.x - nprep) * 16 + ((int)threadIdx.x >> 6);

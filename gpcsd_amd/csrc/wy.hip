@@ -20,25 +20,37 @@ constexpr int WY_ZC = 16;             // columns of Z per workgroup (one MFMA fr
 constexpr int WY_LD = WY_ZC + 2;      // LDS row stride: 18*i mod 32 gives distinct even slots for the b64 fragment reads
 
 // G = V_p V_p^T (16 waves, one 16x16 fragment each), then T by back substitution (4 columns per wave): wy_prep.hpp
-__global__ __launch_bounds__(1024) void wy_prep_kernel(WyBatch b) { wy_prep_body(wy_resolve(b, blockIdx.y), blockIdx.x, threadIdx.x); }
+__global__ __launch_bounds__(1024) void wy_prep_kernel(WyBatch b) {
+    extern __shared__ double psm[];
+    double *vs = psm, *st = psm + WY_NB * (WY_PREP_KC + 2);
+    wy_prep_body<WY_PREP_KC>(wy_resolve(b, blockIdx.y), blockIdx.x, threadIdx.x, vs, /*g on the chunk's storage*/ vs, st);
+}
 
-// one workgroup = 16 columns of Z resident in LDS, all panels applied in sequence
-__global__ __launch_bounds__(256) void wy_apply_kernel(WyBatch b) {
+constexpr int WY_NT = 1024;           // threads of an apply workgroup
+constexpr int WY_KS = 4;              // the K range of W1 = V_p Zc split over this many wave groups
+
+// one workgroup = 16 columns of Z resident in LDS, all panels applied in sequence.  Sixteen waves: the 64 x 16 product
+// W1 = V_p Zc has four fragments only, so its K range is split four ways (partial sums in LDS, added up by the readers);
+// the update of Zc has one row fragment per wave at 250 rows.  (Four waves, each walking the whole K range and four row
+// fragments: 47 us per launch at 4 x 250 rows, this form 1/3 less; the launch forms Q on the critical path of the
+// log-likelihood's tridiagonal form)  KS = 1 when the partial sums would not fit beside a long slab.
+template <int KS>
+__global__ __launch_bounds__(WY_NT) void wy_apply_kernel(WyBatch b) {
     const WyProb P = wy_resolve(b, blockIdx.y);
     const int n = P.n;
     const int c0 = blockIdx.x * WY_ZC;
     if (c0 >= n) return;
     extern __shared__ double smem[];
     double *Zs = smem;                         // [n][WY_LD]
-    double *W1 = Zs + (size_t)n * WY_LD;       // [64][WY_LD]
-    double *W2 = W1 + WY_NB * WY_LD;           // [64][WY_LD]
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    double *W1 = Zs + (size_t)n * WY_LD;       // [KS][64][WY_LD]
+    double *W2 = W1 + KS * WY_NB * WY_LD;      // [64][WY_LD]
+    const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int fr = lane & 15, fq = lane >> 4;
     if (blockIdx.x == 0 && P.w_scale) {        // eigenvalues back to the scale of the input matrix (nobody reads them here)
         const double m = P.amax[0];
-        for (int i = tid; i < n; i += 256) P.w_scale[i] *= m;
+        for (int i = tid; i < n; i += WY_NT) P.w_scale[i] *= m;
     }
-    for (int idx = tid; idx < n * WY_ZC; idx += 256) {
+    for (int idx = tid; idx < n * WY_ZC; idx += WY_NT) {
         const int r = idx / WY_ZC, j = idx % WY_ZC;
         if (P.z_identity) Zs[r * WY_LD + j] = (r == c0 + j) ? 1.0 : 0.0;        // Q itself: the panels applied to the identity
         else Zs[r * WY_LD + j] = (c0 + j < n) ? P.Z[(long)r * n + c0 + j] : 0.0;
@@ -49,9 +61,12 @@ __global__ __launch_bounds__(256) void wy_apply_kernel(WyBatch b) {
         const double *__restrict__ Vp = P.V + (long)p * WY_NB * n;
         const double *__restrict__ Tp = P.T + (long)p * WY_NB * WY_NB;
         const int kstart = (p * WY_NB) & ~3;
-        // W1 = V_p Zc : wave w owns panel rows 16w .. 16w+15
-        {
-            const double *__restrict__ ra = Vp + (long)(16 * wid + fr) * n;
+        // W1 = V_p Zc : wave (ks, fa) owns panel rows 16 fa .. 16 fa + 15 over the ks-th part of the K range
+        if (wid < 4 * KS) {
+            const int fa = wid & 3, ks = wid >> 2;
+            const int klen = (((n - kstart + KS - 1) / KS) + 3) & ~3;
+            const int kb = kstart + ks * klen, ke = min(n, kb + klen);
+            const double *__restrict__ ra = Vp + (long)(16 * fa + fr) * n;
             d4 acc = {0.0, 0.0, 0.0, 0.0};
             // the panel rows come straight from L2: batches of eight clamped (branch-free) loads, the NEXT batch issued
             // before the MFMAs of the current one, so the chain never waits for a full L2 round trip
@@ -60,92 +75,106 @@ __global__ __launch_bounds__(256) void wy_apply_kernel(WyBatch b) {
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
                     const int k = k0 + 4 * u + fq;
-                    dst[u] = ra[k < n ? k : n - 1];
+                    dst[u] = ra[k < ke ? k : n - 1];
                 }
             };
             auto mma8 = [&](const double (&src)[8], int k0) {
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
                     const int k = k0 + 4 * u + fq;
-                    const double bb = Zs[(k < n ? k : n - 1) * WY_LD + fr];
-                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(k < n ? src[u] : 0.0, bb, acc, 0, 0, 0);
+                    const double bb = Zs[(k < ke ? k : n - 1) * WY_LD + fr];
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(k < ke ? src[u] : 0.0, bb, acc, 0, 0, 0);
                 }
             };
-            load8(a8, kstart);
-            for (int k0 = kstart; k0 < n; k0 += 64) {
-                if (k0 + 32 < n) load8(b8, k0 + 32);
+            if (kb < ke) load8(a8, kb);
+            for (int k0 = kb; k0 < ke; k0 += 64) {
+                if (k0 + 32 < ke) load8(b8, k0 + 32);
                 mma8(a8, k0);
-                if (k0 + 32 < n) {
-                    if (k0 + 64 < n) load8(a8, k0 + 64);
+                if (k0 + 32 < ke) {
+                    if (k0 + 64 < ke) load8(a8, k0 + 64);
                     mma8(b8, k0 + 32);
                 }
             }
 #pragma unroll
-            for (int r = 0; r < 4; ++r) W1[(16 * wid + fq + 4 * r) * WY_LD + fr] = acc[r];
+            for (int r = 0; r < 4; ++r) W1[(ks * WY_NB + 16 * fa + fq + 4 * r) * WY_LD + fr] = acc[r];
         }
         __syncthreads();
-        // W2 = T_p W1
-        {
+        // W2 = T_p W1 (four waves; the others go on to the loads of the update)
+        if (wid < 4) {
             const double *__restrict__ ta = Tp + (long)(16 * wid + fr) * WY_NB;
             d4 acc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
             for (int k0 = 0; k0 < WY_NB; k0 += 4) {
                 const int k = k0 + fq;
-                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ta[k], W1[k * WY_LD + fr], acc, 0, 0, 0);
+                double w = W1[k * WY_LD + fr];
+#pragma unroll
+                for (int q = 1; q < KS; ++q) w += W1[(q * WY_NB + k) * WY_LD + fr];
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ta[k], w, acc, 0, 0, 0);
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) W2[(16 * wid + fq + 4 * r) * WY_LD + fr] = acc[r];
         }
-        __syncthreads();
-        // Zc -= V_p^T W2 : rows below the panel's first reflector only
+        // Zc -= V_p^T W2 : rows below the panel's first reflector only, a row fragment in two halves of eight MFMA steps:
+        // the loads of the next half are issued before the MFMAs of the current one, the first before the barrier that
+        // publishes W2.
         {
-            // the sixteen V_p^T loads of the NEXT row fragment are issued before the MFMAs of the current one
-            double a16[16], b16[16];
-            auto loadf = [&](double (&dst)[16], int fm) {
+            double a8[8], b8[8];
+            auto loadh = [&](double (&dst)[8], int fm, int h) {
                 const int m = 16 * fm + fr;
-                const double *__restrict__ vm = Vp + (m < n ? m : n - 1);   // clamped column: rows >= n are never stored
+                const double *__restrict__ vm = Vp + (m < n ? m : n - 1) + (long)(32 * h + fq) * n;   // clamped column
 #pragma unroll
-                for (int u = 0; u < 16; ++u) dst[u] = vm[(long)(4 * u + fq) * n];
+                for (int u = 0; u < 8; ++u) dst[u] = vm[(long)(4 * u) * n];
             };
-            auto applyf = [&](const double (&src)[16], int fm) {
-                d4 acc = {0.0, 0.0, 0.0, 0.0};
+            auto mmah = [&](const double (&src)[8], int h, d4 &acc) {
 #pragma unroll
-                for (int u = 0; u < 16; ++u)
-                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(src[u], W2[(4 * u + fq) * WY_LD + fr], acc, 0, 0, 0);
+                for (int u = 0; u < 8; ++u)
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(src[u], W2[(32 * h + 4 * u + fq) * WY_LD + fr], acc, 0, 0, 0);
+            };
+            constexpr int NW = WY_NT / 64;
+            int fm = (p * WY_NB) / 16 + wid;
+            if (fm < nfrag) loadh(a8, fm, 0);
+            __syncthreads();
+            for (; fm < nfrag; fm += NW) {
+                d4 acc = {0.0, 0.0, 0.0, 0.0};
+                loadh(b8, fm, 1);
+                mmah(a8, 0, acc);
+                if (fm + NW < nfrag) loadh(a8, fm + NW, 0);
+                mmah(b8, 1, acc);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int row = 16 * fm + fq + 4 * r;
                     if (row < n) Zs[row * WY_LD + fr] -= acc[r];
                 }
-            };
-            int fm = (p * WY_NB) / 16 + wid;
-            if (fm < nfrag) loadf(a16, fm);
-            for (; fm < nfrag; fm += 8) {
-                if (fm + 4 < nfrag) loadf(b16, fm + 4);
-                applyf(a16, fm);
-                if (fm + 4 < nfrag) {
-                    if (fm + 8 < nfrag) loadf(a16, fm + 8);
-                    applyf(b16, fm + 4);
-                }
             }
         }
         __syncthreads();
     }
-    for (int idx = tid; idx < n * WY_ZC; idx += 256) {
+    for (int idx = tid; idx < n * WY_ZC; idx += WY_NT) {
         const int r = idx / WY_ZC, j = idx % WY_ZC;
         if (c0 + j < n) P.Z[(long)r * n + c0 + j] = Zs[r * WY_LD + j];
     }
+}
+
+static void wy_prep_launch(const WyBatch &b, int maxP, int count, hipStream_t s) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        GP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(wy_prep_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)WY_PREP_LDS));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(wy_prep_kernel, dim3(maxP, count), dim3(1024), WY_PREP_LDS, s, b);
 }
 
 void wy_prep_device(gpcsd_ctx *c, const WyBatch &b, int nclass, hipStream_t s) {
     int maxP = 0;
     for (int i = 0; i < nclass; ++i) maxP = std::max(maxP, b.p[i].npanels);
     if (maxP == 0) return;
-    hipLaunchKernelGGL(wy_prep_kernel, dim3(maxP, b.start[MAX_EIG_BATCH]), dim3(1024), 0, s, b);
+    wy_prep_launch(b, maxP, b.start[MAX_EIG_BATCH], s);
     GP_HIP(hipGetLastError());
 }
 
-bool wy_fused_supported(int nmax) { return ((size_t)nmax * WY_LD + 2 * WY_NB * WY_LD) * sizeof(double) <= 160 * 1024; }
+static size_t wy_apply_lds(int nmax, int ks) { return ((size_t)nmax * WY_LD + (size_t)(ks + 1) * WY_NB * WY_LD) * sizeof(double); }
+bool wy_fused_supported(int nmax) { return wy_apply_lds(nmax, 1) <= 160 * 1024; }
 
 void wy_batch_device(gpcsd_ctx *c, const WyBatch &b, int nclass, hipStream_t s, bool prep_done) {
     int maxP = 0, nmax = 0;
@@ -155,15 +184,19 @@ void wy_batch_device(gpcsd_ctx *c, const WyBatch &b, int nclass, hipStream_t s, 
     }
     if (maxP == 0) return;
     const int count = b.start[MAX_EIG_BATCH];          // all replicas of all classes
-    const size_t sh = ((size_t)nmax * WY_LD + 2 * WY_NB * WY_LD) * sizeof(double);
+    const bool split = wy_apply_lds(nmax, WY_KS) <= 160 * 1024;
+    const size_t sh = wy_apply_lds(nmax, split ? WY_KS : 1);
     static bool attr_set = false;
     if (!attr_set) {
-        GP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(wy_apply_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+        GP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(wy_apply_kernel<WY_KS>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        GP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(wy_apply_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                    160 * 1024));
         attr_set = true;
     }
-    if (!prep_done) hipLaunchKernelGGL(wy_prep_kernel, dim3(maxP, count), dim3(1024), 0, s, b);
-    hipLaunchKernelGGL(wy_apply_kernel, dim3(ceil_div(nmax, WY_ZC), count), dim3(256), sh, s, b);
+    if (!prep_done) wy_prep_launch(b, maxP, count, s);
+    if (split) hipLaunchKernelGGL(wy_apply_kernel<WY_KS>, dim3(ceil_div(nmax, WY_ZC), count), dim3(WY_NT), sh, s, b);
+    else hipLaunchKernelGGL(wy_apply_kernel<1>, dim3(ceil_div(nmax, WY_ZC), count), dim3(WY_NT), sh, s, b);
     GP_HIP(hipGetLastError());
 }
 

@@ -558,14 +558,15 @@ def test_decomposition_cache_reuses_unchanged_sides_bitwise():
     m.predict(c["x"], c["t"], type="lfp")                         # both sides reused (same path: folded basis, t* = t)
     assert ctx.decomposition_cache() - h1 == 2
     assert relerr(m.lfp_pred, O.predict(geom, hp, lfp, c["x"], c["t"], type="lfp")["lfp"]) < GATE
-    m.predict(c["x"][::2], c["t"], type="csd")                    # other sites break the site symmetry: the full-size path needs
-    h1b = ctx.decomposition_cache()                               # the merged eigenvectors, which the folded calls never formed
-    assert h1b - h1 == 2
+    m.predict(c["x"][::2], c["t"], type="csd")                    # other sites break the site symmetry: the spatial side is solved
+    h1b = ctx.decomposition_cache()                               # again, unfolded; the temporal side keeps its folded form and is
+    assert h1b - h1 == 3                                          # reused (round 4; before, the whole call ran full-size: no reuse)
     assert relerr(m.csd_pred, O.predict(geom, hp, lfp, c["x"][::2], c["t"], type="csd")["csd"]) < GATE
-    ctx.eigh(np.eye(70) + 0.01)                                   # an unrelated solve on the same context: nothing is reused after it
-    h2 = ctx.decomposition_cache()
-    m.predict(c["x"], c["t"], type="csd")
-    assert ctx.decomposition_cache() == h2 and np.array_equal(m.csd_pred, cold)
+    ctx.eigh(np.eye(70) + 0.01)                                   # an unrelated solve on the same context runs in the spatial
+    h2 = ctx.decomposition_cache()                                # side's slot: that side is solved again, the temporal one (its
+    m.predict(c["x"], c["t"], type="csd")                         # key unchanged since the folded calls above) is reused
+    assert np.array_equal(m.csd_pred, cold)
+    assert ctx.decomposition_cache() - h2 == 1
     m.temporal_cov_list[0].params["ell"]["value"] *= 1.01         # temporal side changes, spatial is reused
     m.predict(c["x"], c["t"], type="csd")
     assert ctx.decomposition_cache() - h2 == 1

@@ -605,8 +605,9 @@ def test_folded_gemm_path_matches_unfolded(name):
 
 
 def test_folded_gemm_falls_back_when_symmetry_is_missing():
-    """Prediction sites without the electrodes' mirror symmetry, prediction times other than the training grid, or a
-    per-electrode noise list (indexed by eigen-rank in the reference) take the full-size path; results agree with it."""
+    """Prediction times other than the training grid, or a per-electrode noise list (indexed by eigen-rank in the reference),
+    take the full-size path; prediction sites without the electrodes' mirror symmetry keep the folded TEMPORAL side and
+    unfold only the spatial one (round 4); results agree with the full-size path."""
     name = "2d_npx_96x120x3"                                          # both sides folded: both output grids are constrained
     m, c, g, geom, hp, lfp = _build_model(name)
     ctx = m._context()
@@ -615,11 +616,16 @@ def test_folded_gemm_falls_back_when_symmetry_is_missing():
     z_asym = np.array(x[: x.shape[0] - 3], dtype=np.float64)          # drop three sites: no longer mirror-symmetric
     n0 = ctx.fold_gemm()
     m.predict(z_asym, t, type="csd")
-    assert ctx.fold_gemm() == n0
+    assert ctx.fold_gemm() == n0 + 1                                  # folded in time, full-size in space
     p_asym = m.csd_pred.copy()
     m.predict(x, t, type="csd")
-    assert ctx.fold_gemm() == n0 + 1
+    assert ctx.fold_gemm() == n0 + 2
     assert relerr(p_asym, m.csd_pred[: z_asym.shape[0]]) < 1e-10      # same sites, either path
+    ctx.fold_gemm(False)
+    m.predict(z_asym, t, type="csd")
+    assert relerr(p_asym, m.csd_pred) < 1e-10                         # and against the full-size path on the same sites
+    ctx.fold_gemm(True)
+    n0 += 1
     t_shift = t + 0.37 * (t[1] - t[0])
     m.predict(x, t_shift, type="csd")
     assert ctx.fold_gemm() == n0 + 1
