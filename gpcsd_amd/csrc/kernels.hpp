@@ -262,6 +262,7 @@ struct WyProb {
 struct WyBatch {
     WyProb p[MAX_EIG_BATCH];         // one entry per class
     int start[MAX_EIG_BATCH + 1];    // prefix sums of the replica counts (see class_of)
+    unsigned long long *clk = nullptr;   // measurement aid (GPCSD_WY_CLK=1): wall-clock stamps of workgroup (0, 0) at its phase boundaries
 };
 __device__ __forceinline__ WyProb wy_resolve(const WyBatch &b, int g) {
     int cls, rep;

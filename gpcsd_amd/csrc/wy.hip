@@ -23,7 +23,8 @@ constexpr int WY_LD = WY_ZC + 2;      // LDS row stride: 18*i mod 32 gives disti
 __global__ __launch_bounds__(1024) void wy_prep_kernel(WyBatch b) {
     extern __shared__ double psm[];
     double *vs = psm, *st = psm + WY_NB * (WY_PREP_KC + 2);
-    wy_prep_body<WY_PREP_KC>(wy_resolve(b, blockIdx.y), blockIdx.x, threadIdx.x, vs, /*g on the chunk's storage*/ vs, st);
+    wy_prep_body<WY_PREP_KC>(wy_resolve(b, blockIdx.y), blockIdx.x, threadIdx.x, vs, /*g, tl, pl on the chunk's storage*/ vs,
+                             vs + WY_NB * WY_LDG, vs + 2 * WY_NB * WY_LDG, st, (blockIdx.x == 0 && blockIdx.y == 0) ? b.clk : nullptr);
 }
 
 constexpr int WY_NT = 1024;           // threads of an apply workgroup
@@ -46,6 +47,10 @@ __global__ __launch_bounds__(WY_NT) void wy_apply_kernel(WyBatch b) {
     double *W2 = W1 + KS * WY_NB * WY_LD;      // [64][WY_LD]
     const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int fr = lane & 15, fq = lane >> 4;
+    const bool stamping = b.clk && blockIdx.y == 0 && blockIdx.x == gridDim.x - 1 && tid == 0;
+    int nstamp = 8;
+    auto stamp = [&]() { if (stamping && nstamp < 32) b.clk[nstamp++] = wall_clock64(); };
+    stamp();
     if (blockIdx.x == 0 && P.w_scale) {        // eigenvalues back to the scale of the input matrix (nobody reads them here)
         const double m = P.amax[0];
         for (int i = tid; i < n; i += WY_NT) P.w_scale[i] *= m;
@@ -56,6 +61,7 @@ __global__ __launch_bounds__(WY_NT) void wy_apply_kernel(WyBatch b) {
         else Zs[r * WY_LD + j] = (c0 + j < n) ? P.Z[(long)r * n + c0 + j] : 0.0;
     }
     __syncthreads();
+    stamp();
     const int nfrag = (n + 15) / 16;
     for (int p = P.npanels - 1; p >= 0; --p) {
         const double *__restrict__ Vp = P.V + (long)p * WY_NB * n;
@@ -99,6 +105,7 @@ __global__ __launch_bounds__(WY_NT) void wy_apply_kernel(WyBatch b) {
             for (int r = 0; r < 4; ++r) W1[(ks * WY_NB + 16 * fa + fq + 4 * r) * WY_LD + fr] = acc[r];
         }
         __syncthreads();
+        stamp();
         // W2 = T_p W1 (four waves; the others go on to the loads of the update)
         if (wid < 4) {
             const double *__restrict__ ta = Tp + (long)(16 * wid + fr) * WY_NB;
@@ -134,6 +141,7 @@ __global__ __launch_bounds__(WY_NT) void wy_apply_kernel(WyBatch b) {
             int fm = (p * WY_NB) / 16 + wid;
             if (fm < nfrag) loadh(a8, fm, 0);
             __syncthreads();
+            stamp();
             for (; fm < nfrag; fm += NW) {
                 d4 acc = {0.0, 0.0, 0.0, 0.0};
                 loadh(b8, fm, 1);
@@ -148,11 +156,26 @@ __global__ __launch_bounds__(WY_NT) void wy_apply_kernel(WyBatch b) {
             }
         }
         __syncthreads();
+        stamp();
     }
     for (int idx = tid; idx < n * WY_ZC; idx += WY_NT) {
         const int r = idx / WY_ZC, j = idx % WY_ZC;
         if (c0 + j < n) P.Z[(long)r * n + c0 + j] = Zs[r * WY_LD + j];
     }
+    stamp();
+}
+
+static bool wy_clk_on() {
+    static const bool on = getenv("GPCSD_WY_CLK") && getenv("GPCSD_WY_CLK")[0] == '1';
+    return on;
+}
+static void wy_clk_print(gpcsd_ctx *c, unsigned long long *d, const char *what, int first, int n, hipStream_t s) {
+    unsigned long long h[32];
+    GP_HIP(hipMemcpyAsync(h, d, sizeof(h), hipMemcpyDeviceToHost, s));
+    GP_HIP(hipStreamSynchronize(s));
+    fprintf(stderr, "[%s] phases (10 ns ticks):", what);
+    for (int i = first + 1; i < first + n; ++i) fprintf(stderr, " %llu", h[i] >= h[i - 1] ? h[i] - h[i - 1] : 0ull);
+    fprintf(stderr, "\n");
 }
 
 static void wy_prep_launch(const WyBatch &b, int maxP, int count, hipStream_t s) {
@@ -164,12 +187,22 @@ static void wy_prep_launch(const WyBatch &b, int maxP, int count, hipStream_t s)
     }
     hipLaunchKernelGGL(wy_prep_kernel, dim3(maxP, count), dim3(1024), WY_PREP_LDS, s, b);
 }
+static WyBatch wy_with_clk(gpcsd_ctx *c, const WyBatch &b, hipStream_t s) {
+    WyBatch w = b;
+    if (wy_clk_on()) {
+        w.clk = c->buf<unsigned long long>("wy_clk", 32);
+        GP_HIP(hipMemsetAsync(w.clk, 0, 32 * sizeof(unsigned long long), s));
+    }
+    return w;
+}
 
 void wy_prep_device(gpcsd_ctx *c, const WyBatch &b, int nclass, hipStream_t s) {
     int maxP = 0;
     for (int i = 0; i < nclass; ++i) maxP = std::max(maxP, b.p[i].npanels);
     if (maxP == 0) return;
-    wy_prep_launch(b, maxP, b.start[MAX_EIG_BATCH], s);
+    const WyBatch w = wy_with_clk(c, b, s);
+    wy_prep_launch(w, maxP, b.start[MAX_EIG_BATCH], s);
+    if (w.clk) wy_clk_print(c, w.clk, "wy_prep: load, G, back substitution", 0, 4, s);
     GP_HIP(hipGetLastError());
 }
 
@@ -194,9 +227,11 @@ void wy_batch_device(gpcsd_ctx *c, const WyBatch &b, int nclass, hipStream_t s, 
                                    160 * 1024));
         attr_set = true;
     }
-    if (!prep_done) wy_prep_launch(b, maxP, count, s);
-    if (split) hipLaunchKernelGGL(wy_apply_kernel<WY_KS>, dim3(ceil_div(nmax, WY_ZC), count), dim3(WY_NT), sh, s, b);
-    else hipLaunchKernelGGL(wy_apply_kernel<1>, dim3(ceil_div(nmax, WY_ZC), count), dim3(WY_NT), sh, s, b);
+    const WyBatch w = wy_with_clk(c, b, s);
+    if (!prep_done) wy_prep_launch(w, maxP, count, s);
+    if (split) hipLaunchKernelGGL(wy_apply_kernel<WY_KS>, dim3(ceil_div(nmax, WY_ZC), count), dim3(WY_NT), sh, s, w);
+    else hipLaunchKernelGGL(wy_apply_kernel<1>, dim3(ceil_div(nmax, WY_ZC), count), dim3(WY_NT), sh, s, w);
+    if (w.clk) wy_clk_print(c, w.clk, "wy_apply, last column block: init, then per panel W1 | W2 + loads | update, store", 8, 2 + 3 * maxP + 1, s);
     GP_HIP(hipGetLastError());
 }
 

@@ -569,7 +569,7 @@ def test_decomposition_cache_reuses_unchanged_sides_bitwise():
     assert ctx.decomposition_cache() - h2 == 1
     m.temporal_cov_list[0].params["ell"]["value"] *= 1.01         # temporal side changes, spatial is reused
     m.predict(c["x"], c["t"], type="csd")
-    assert ctx.decomposition_cache() - h2 == 1
+    assert ctx.decomposition_cache() - h2 == 2
     hp2 = dict(hp)
     hp2["temporal"] = [(k, ell * (1.01 if i == 0 else 1.0), s2) for i, (k, ell, s2) in enumerate(hp["temporal"])]
     assert relerr(m.csd_pred, O.predict(geom, hp2, lfp, c["x"], c["t"], type="csd")["csd"]) < GATE
