@@ -181,7 +181,25 @@ void build_kphi(gpcsd_ctx *c, const Geo &g, double R, double eps, const double *
     d2.M = g.nx; d2.N = n2; d2.K = G;
     d2.A = T; d2.lda = G; d2.B = Axp; d2.ldb = G; d2.transB = true; d2.C = out; d2.ldc = n2;
     d2.prof_name = "gemm_Ks_TAt";
-    gemm_f64(c, d2, s);
+    // Few output tiles over a long contraction (384 x 384 over the 1200 quadrature nodes: 36 workgroups walking 150 K tiles each,
+    // 67 us at the head of the spatial chain): the K range in `parts` batches of one launch into partial products, then one
+    // fixed-order sum.
+    int parts = 1;
+    static const bool splitk = !(getenv("GPCSD_KS_SPLITK") && getenv("GPCSD_KS_SPLITK")[0] == '0');
+    if (splitk && (long)ceil_div(g.nx, 64) * ceil_div(n2, 64) <= 64 && G >= 512)
+        for (int q : {8, 6, 5, 4, 3, 2})
+            if (G % q == 0 && G / q >= 128) { parts = q; break; }
+    if (parts > 1) {
+        const long nn = (long)g.nx * n2;
+        double *Pp = c->buf<double>(P + "TAt_parts", (size_t)nn * parts);
+        d2.K = G / parts;
+        d2.batch = parts; d2.sA = d2.K; d2.sB = d2.K; d2.sC = nn;
+        d2.C = Pp;
+        gemm_f64(c, d2, s);
+        k_sum_partials(c, out, Pp, nn, parts, s);
+    } else {
+        gemm_f64(c, d2, s);
+    }
     if (jitter != 0.0 && n2 == g.nx) k_add_diag(c, out, g.nx, jitter, s);
 }
 

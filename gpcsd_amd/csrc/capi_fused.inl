@@ -26,34 +26,52 @@ static int finish_loglik_async(gpcsd_ctx *c, const EigState &e, bool two) {
 // Shifted-tridiagonal form (EigState::tri): X = Y~ Q needs stage 1 of the temporal chain only and is queued BEFORE the main
 // stream waits for the spatial chain; after that wait W = diag(U)^T X, and one forward recurrence per row gives the quadratic
 // form, the pivots the log-determinant (k_ll_tridiag).  The temporal eigenvectors are never read.
-static void loglik_tri_pre(gpcsd_ctx *c, EigState &e, const FoldMode &fm, const double *Yf, const char *xname = "ll_X",
-                           const char *prof = "gemm_ll_YQ") {
+// Order of the log-likelihood's two products: X = Y~ Q then W = U^T X (0: the temporal product first, behind Q and in front of the
+// wait for the spatial chain), or W0 = U^T Y~ then W = W0 Q (1: the spatial product first, behind the spatial chain and in front
+// of the wait for Q).  Same flops, same shapes; whichever chain ends first should have its product first.  GPCSD_LL_ORDER.
+static int ll_order() {
+    static const int o = getenv("GPCSD_LL_ORDER") ? atoi(getenv("GPCSD_LL_ORDER")) : 0;
+    return o;
+}
+
+// out[(x, r)][t~ block p] = in[(x, r)][t~ block p] Q_p, both parity blocks in one launch (Q of replica e.tri_rep; waits for stage 3)
+static void tri_times_Q(gpcsd_ctx *c, EigState &e, const FoldMode &fm, const double *in, double *out, const char *prof) {
     const int nx = c->nx, nt = c->nt, R = c->ntrials;
     hipStream_t s = c->stream;
     if (e.wait_q) GP_HIP(hipStreamWaitEvent(s, c->ev_q[c->tgen], 0));
     e.wait_q = false;
-    double *X = c->buf<double>(xname, (size_t)nx * R * nt);
     const char *const *tg = eigh_fold_tags(c, 1);
     GemmDesc g[2];
     for (int p = 0; p < 2; ++p) {
         const int np = p ? fm.ft.na : fm.ft.ns, c0 = p ? fm.ft.ns : 0;
         g[p].M = nx * R; g[p].N = np; g[p].K = np;
-        g[p].A = Yf + c0; g[p].lda = nt;
+        g[p].A = in + c0; g[p].lda = nt;
         g[p].B = eigh_Q_view(c, tg[p], np, e.tri_count) + (size_t)e.tri_rep * np * np; g[p].ldb = np;
-        g[p].C = X + c0; g[p].ldc = nt;
+        g[p].C = out + c0; g[p].ldc = nt;
         g[p].prof_name = prof;
     }
     gemm_pair(c, g[0], g[1], s);
 }
 
-static void loglik_tri_tail(gpcsd_ctx *c, EigState &e, const FoldMode &fm, double *W) {
+static void loglik_tri_pre(gpcsd_ctx *c, EigState &e, const FoldMode &fm, const double *Yf, const char *xname = "ll_X",
+                           const char *prof = "gemm_ll_YQ", bool is_ll = true) {
+    if (is_ll && ll_order() == 1) return;              // spatial product first: everything happens in the tail
+    tri_times_Q(c, e, fm, Yf, c->buf<double>(xname, (size_t)c->nx * c->ntrials * c->nt), prof);
+}
+
+static void loglik_tri_tail(gpcsd_ctx *c, EigState &e, const FoldMode &fm, const double *Yf, double *W) {
     const int nx = c->nx, nt = c->nt, R = c->ntrials;
     hipStream_t s = c->stream;
     ++c->fold_gemm_calls;
     ++c->ll_tridiag_calls;
     join_spatial(c, e);
-    const double *X = c->buf<double>("ll_X", (size_t)nx * R * nt);
-    fold_proj_spatial(c, fm.fs, X, W, (long)R * nt, s);
+    double *X = c->buf<double>("ll_X", (size_t)nx * R * nt);
+    if (ll_order() == 1) {
+        fold_proj_spatial(c, fm.fs, Yf, X, (long)R * nt, s);
+        tri_times_Q(c, e, fm, X, W, "gemm_ll_WQ");
+    } else {
+        fold_proj_spatial(c, fm.fs, X, W, (long)R * nt, s);
+    }
     const char *const *tg = eigh_fold_tags(c, 1);
     const double *d[2], *ee[2], *am[2];
     int np[2], c0[2];
@@ -74,7 +92,7 @@ static bool loglik_fold_tail(gpcsd_ctx *c, EigState &e, const FoldMode &fm, cons
     hipStream_t s = c->stream;
     if (e.tri) {
         loglik_tri_pre(c, e, fm, Yf);
-        loglik_tri_tail(c, e, fm, W);
+        loglik_tri_tail(c, e, fm, Yf, W);
         return true;
     }
     ++c->fold_gemm_calls;
@@ -273,12 +291,12 @@ static int predict_fold(gpcsd_ctx *c, const gpcsd_hparams *hp, EigState &e, cons
     // for the spatial chain, exactly as the log-likelihood's
     // (a call of its own: in front of the wait for the spatial chain; in the paired call: behind the log-likelihood's tail -- in
     // front of it the product delays the result the caller is waiting for by its 0.09 ms)
-    if (e.tri && !after_spatial_join) loglik_tri_pre(c, e, fm, Yf, "pred_X", "gemm_pred_YQ");
+    if (e.tri && !after_spatial_join) loglik_tri_pre(c, e, fm, Yf, "pred_X", "gemm_pred_YQ", false);
     join_spatial(c, e);
     // gpcsd_loglik_predict_async: the log-likelihood's whole tail goes here, in front of everything of predict that needs a
     // decomposition -- it is what the caller waits for
     if (after_spatial_join) (*after_spatial_join)();
-    if (e.tri && after_spatial_join) loglik_tri_pre(c, e, fm, Yf, "pred_X", "gemm_pred_YQ");
+    if (e.tri && after_spatial_join) loglik_tri_pre(c, e, fm, Yf, "pred_X", "gemm_pred_YQ", false);
     fold_proj_spatial(c, fm.fs, e.tri ? c->buf<double>("pred_X", (size_t)nx * RT) : Yf, W, RT, s);   // W~ = diag(U)^T Y~ (or of Y~ Q)
     for (int which = 1; which <= 2; ++which) {
         if (!(type & which)) continue;
@@ -769,7 +787,7 @@ extern "C" int gpcsd_loglik_predict_async(gpcsd_ctx *c, const gpcsd_hparams *hp_
     const std::function<void()> ll_tail = [&]() {
         double *Wll = c->buf<double>("proj_W_ll", (size_t)c->nx * c->ntrials * c->nt);
         bool batched = true;
-        if (pf.e[0].tri) loglik_tri_tail(c, pf.e[0], pf.fm[0], Wll);
+        if (pf.e[0].tri) loglik_tri_tail(c, pf.e[0], pf.fm[0], Yf, Wll);
         else batched = loglik_fold_tail(c, pf.e[0], pf.fm[0], Yf, Wll);
         (void)finish_loglik_async(c, pf.e[0], !batched);
     };

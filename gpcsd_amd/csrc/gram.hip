@@ -441,6 +441,167 @@ __global__ __launch_bounds__(64 * LT_WAVES) void ll_tridiag_kernel(LlTridiagArgs
     }
 }
 
+// The same with the pivots off the serial path (blocks of at most 64 * LS_CPL columns).  In the kernel above every column step
+// waits for a chain of ~8 dependent fp64 operations -- multiplier, pivot, reciprocal with its Newton steps -- that all lanes
+// walk in lock-step: 250 x ~200 cycles = 21 us of its 38.  The pivots D_k = a_k - b_{k-1}^2 / D_{k-1} are ratios theta_k /
+// theta_{k-1} of leading principal minors, (theta_k, theta_{k-1})^T = M_k (theta_{k-1}, theta_{k-2})^T with M_k = [[a_k,
+// -b_{k-1}^2], [1, 0]]: lane j multiplies the M_k of its LS_CPL consecutive columns, a wave scan (six shuffle steps, every
+// product renormalised by a power of two: positive definite, all minors positive) gives each lane the product of everything
+// in front of it, and a second walk over its own columns the pivots themselves.  One step of the exact recurrence from the
+// neighbour's pivot (D_k = a_k - b_{k-1}^2 / D_{k-1}, all columns at once) then removes what the re-associated products
+// lost: a relative error delta in D_{k-1} reaches D_k multiplied by b^2 / (D_{k-1} D_k) < 1.  Multipliers and reciprocal
+// pivots go to LDS as pairs; a column step of the sweep is ONE dependent FMA (z) plus one on a rotating accumulator (q),
+// coefficients by LDS broadcast reads a chunk ahead of their use.
+constexpr int LS_CPL = 4;                                           // columns per lane in the scan: blocks of up to 256 columns
+typedef double dbl2_t __attribute__((ext_vector_type(2)));
+__global__ __launch_bounds__(64 * LT_WAVES) void ll_tridiag_scan_kernel(LlTridiagArgs g) {
+    __shared__ double tile[LT_WAVES][2][64][LT_CK + 1];            // double-buffered chunk of the wave's rows
+    __shared__ dbl2_t coef[LT_WAVES][64 * LS_CPL + LT_CK];          // (l_k, 1 / D_k); zero beyond the block
+    __shared__ double pexc[LT_WAVES][64 * LS_CPL + 1];              // pivot reciprocals on their way between lanes
+    const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int item = blockIdx.x * LT_WAVES + wid, nitems = 2 * g.nx;
+    if (item >= nitems) return;                                   // (whole waves leave: no workgroup barrier below)
+    const int xr = item >> 1, p = item & 1;
+    const int np = g.np[p];
+    if (np <= 0) {
+        if (lane == 0) {
+            g.partials[item] = 0.0;
+            g.partials[nitems + item] = 0.0;
+        }
+        return;
+    }
+    const double lam_m = g.es[xr] * g.amax[p][0], sig = g.sig[0];
+    const double *__restrict__ dd = g.d[p], *__restrict__ ee = g.e[p];
+    const double *__restrict__ Wx = g.W + (long)xr * g.R * g.nt + g.c0[p];
+    const int half = lane >> 5, kk_l = lane & 31;                 // staging: two rows of 32 columns per load instruction
+    double stg[LT_RPL];
+    auto load_chunk = [&](int r0, int nr, int k0) {               // all loads of a chunk are issued before any of them is used
+        const int nk = min(LT_CK, np - k0);
+#pragma unroll
+        for (int i = 0; i < LT_RPL; ++i) {
+            const int rr = half + 2 * i;
+            stg[i] = (rr < nr && kk_l < nk) ? Wx[(long)(r0 + rr) * g.nt + k0 + kk_l] : 0.0;
+        }
+    };
+    auto store_chunk = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < LT_RPL; ++i) tile[wid][buf][half + 2 * i][kk_l] = stg[i];
+    };
+    load_chunk(0, min(64, g.R), 0);                               // the first chunk's rows fly while the pivots are formed
+    // ---- pivots of the item
+    double logsum;
+    {
+        double a[LS_CPL], b2[LS_CPL], bb[LS_CPL];
+#pragma unroll
+        for (int cc = 0; cc < LS_CPL; ++cc) {
+            const int k = lane * LS_CPL + cc;
+            a[cc] = (k < np) ? lam_m * dd[k] + sig : 1.0;
+            bb[cc] = (k >= 1 && k < np) ? lam_m * ee[k - 1] : 0.0;
+            b2[cc] = bb[cc] * bb[cc];
+        }
+        auto renorm = [](double &x0, double &x1, double &x2, double &x3) {
+            const double big = fmax(fmax(fabs(x0), fabs(x1)), fmax(fabs(x2), fabs(x3)));
+            int ex;
+            (void)frexp(big, &ex);
+            x0 = ldexp(x0, -ex); x1 = ldexp(x1, -ex); x2 = ldexp(x2, -ex); x3 = ldexp(x3, -ex);
+        };
+        // the lane's own product M_last .. M_first
+        double m00 = a[0], m01 = -b2[0], m10 = 1.0, m11 = 0.0;
+#pragma unroll
+        for (int cc = 1; cc < LS_CPL; ++cc) {                      // M_k P: rows (a P0 - b2 P1, P0)
+            const double n00 = a[cc] * m00 - b2[cc] * m10, n01 = a[cc] * m01 - b2[cc] * m11;
+            m10 = m00; m11 = m01; m00 = n00; m01 = n01;
+        }
+        renorm(m00, m01, m10, m11);
+        // inclusive scan over the lanes: P_j <- P_j P_{j - dlt}
+#pragma unroll
+        for (int dlt = 1; dlt < 64; dlt <<= 1) {
+            const double e00 = __shfl_up(m00, dlt), e01 = __shfl_up(m01, dlt), e10 = __shfl_up(m10, dlt), e11 = __shfl_up(m11, dlt);
+            if (lane >= dlt) {
+                double n00 = m00 * e00 + m01 * e10, n01 = m00 * e01 + m01 * e11;
+                double n10 = m10 * e00 + m11 * e10, n11 = m10 * e01 + m11 * e11;
+                renorm(n00, n01, n10, n11);
+                m00 = n00; m01 = n01; m10 = n10; m11 = n11;
+            }
+        }
+        // (theta, theta') in front of this lane's columns: first column of the product of the lanes before it
+        double t0 = __shfl_up(m00, 1), t1 = __shfl_up(m10, 1);
+        if (lane == 0) { t0 = 1.0; t1 = 0.0; }
+        double pv[LS_CPL];                                         // 1 / D_k from the products
+#pragma unroll
+        for (int cc = 0; cc < LS_CPL; ++cc) {
+            const double tn = a[cc] * t0 - b2[cc] * t1;
+            pv[cc] = t0 / tn;
+            t1 = t0; t0 = tn;
+            if (cc == 1) {                                         // keep the pair in range (a ratio is all that is used)
+                int ex;
+                (void)frexp(t0, &ex);
+                t0 = ldexp(t0, -ex); t1 = ldexp(t1, -ex);
+            }
+        }
+#pragma unroll
+        for (int cc = 0; cc < LS_CPL; ++cc) pexc[wid][lane * LS_CPL + cc + 1] = pv[cc];
+        if (lane == 0) pexc[wid][0] = 0.0;
+        __builtin_amdgcn_wave_barrier();
+        // one step of the exact recurrence, every column from its left neighbour's reciprocal pivot
+        double dk[LS_CPL], lg = 0.0;
+#pragma unroll
+        for (int cc = 0; cc < LS_CPL; ++cc) {
+            const int k = lane * LS_CPL + cc;
+            dk[cc] = a[cc] - b2[cc] * pexc[wid][k];
+            pv[cc] = 1.0 / dk[cc];
+            if (k < np) lg += log(dk[cc]);
+        }
+        logsum = wave_sum(lg);
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int cc = 0; cc < LS_CPL; ++cc) pexc[wid][lane * LS_CPL + cc + 1] = pv[cc];
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int cc = 0; cc < LS_CPL; ++cc) {
+            const int k = lane * LS_CPL + cc;
+            dbl2_t cf;
+            cf.x = (k < np) ? bb[cc] * pexc[wid][k] : 0.0;         // l_k = b_{k-1} / D_{k-1}
+            cf.y = (k < np) ? pv[cc] : 0.0;
+            coef[wid][k] = cf;
+        }
+        if (lane < LT_CK) coef[wid][64 * LS_CPL + lane] = dbl2_t{0.0, 0.0};
+    }
+    // ---- the sweeps: the item's rows in passes of 64, chunks of LT_CK columns
+    double quad = 0.0;
+    for (int r0 = 0; r0 < g.R; r0 += 64) {
+        const int nr = min(64, g.R - r0);
+        if (r0 > 0) load_chunk(r0, nr, 0);
+        __builtin_amdgcn_wave_barrier();
+        store_chunk(0);
+        double z = 0.0, q[4] = {0.0, 0.0, 0.0, 0.0};
+        int buf = 0;
+        for (int k0 = 0; k0 < np; k0 += LT_CK, buf ^= 1) {
+            if (k0 + LT_CK < np) load_chunk(r0, nr, k0 + LT_CK);  // the next chunk's loads fly during this chunk's recurrence
+            __builtin_amdgcn_wave_barrier();
+            double wv[LT_CK];                                     // this lane's row of the chunk: one batch of LDS reads
+            dbl2_t cf[LT_CK];
+#pragma unroll
+            for (int kk = 0; kk < LT_CK; ++kk) {
+                wv[kk] = tile[wid][buf][lane][kk];
+                cf[kk] = coef[wid][k0 + kk];
+            }
+#pragma unroll
+            for (int kk = 0; kk < LT_CK; ++kk) {                  // (columns beyond the block: w = 0, l = 0, 1 / D = 0)
+                z = fma(-cf[kk].x, z, wv[kk]);
+                q[kk & 3] = fma(z * z, cf[kk].y, q[kk & 3]);
+            }
+            __builtin_amdgcn_wave_barrier();
+            if (k0 + LT_CK < np) store_chunk(buf ^ 1);
+        }
+        quad += wave_sum(lane < nr ? (q[0] + q[1]) + (q[2] + q[3]) : 0.0);
+    }
+    if (lane == 0) {
+        g.partials[item] = quad;
+        g.partials[nitems + item] = logsum;
+    }
+}
+
 __global__ __launch_bounds__(256) void ll_tridiag_reduce_kernel(const double *__restrict__ partials, int nitems, double *out_sumlog,
                                                                 double *out_quad) {
     __shared__ double sh[256];
@@ -467,7 +628,11 @@ void k_ll_tridiag(gpcsd_ctx *c, const double *W, const double *es, const double 
     const int nitems = 2 * nx;
     g.partials = c->buf<double>("ll_tridiag_partials", (size_t)2 * nitems);
     ProfScope ps(c, "ll_tridiag", 0.0, s);
-    hipLaunchKernelGGL(ll_tridiag_kernel, dim3(ceil_div(nitems, LT_WAVES)), dim3(64 * LT_WAVES), 0, s, g);
+    static const bool serial = getenv("GPCSD_LL_PIVOT_SCAN") && getenv("GPCSD_LL_PIVOT_SCAN")[0] == '0';
+    if (!serial && std::max(np[0], np[1]) <= 64 * LS_CPL)
+        hipLaunchKernelGGL(ll_tridiag_scan_kernel, dim3(ceil_div(nitems, LT_WAVES)), dim3(64 * LT_WAVES), 0, s, g);
+    else
+        hipLaunchKernelGGL(ll_tridiag_kernel, dim3(ceil_div(nitems, LT_WAVES)), dim3(64 * LT_WAVES), 0, s, g);
     hipLaunchKernelGGL(ll_tridiag_reduce_kernel, dim3(2), dim3(256), 0, s, (const double *)g.partials, nitems, out_sumlog, out_quad);
     GP_HIP(hipGetLastError());
 }
@@ -926,6 +1091,19 @@ __global__ void add_diag_kernel(double *A, int n, double v, const HpDev *__restr
 }
 void k_add_diag(gpcsd_ctx *c, double *A, int n, double v, hipStream_t s, const HpDev *tab, int B, long s_out) {
     hipLaunchKernelGGL(add_diag_kernel, dim3(ceil_div(n, 256), 1, tab ? B : 1), dim3(256), 0, s, A, n, v, tab, s_out);
+    GP_HIP(hipGetLastError());
+}
+
+// out[i] = ((P_0[i] + P_1[i]) + P_2[i]) + ..: the partial products of a GEMM whose K range was split over workgroups (fixed order)
+__global__ __launch_bounds__(256) void sum_partials_kernel(double *__restrict__ out, const double *__restrict__ P, long n, int parts) {
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        double acc = P[i];
+        for (int q = 1; q < parts; ++q) acc += P[q * n + i];
+        out[i] = acc;
+    }
+}
+void k_sum_partials(gpcsd_ctx *c, double *out, const double *P, long n, int parts, hipStream_t s) {
+    hipLaunchKernelGGL(sum_partials_kernel, dim3((int)std::min<long>(ceil_div(n, 256L), 1024)), dim3(256), 0, s, out, P, n, parts);
     GP_HIP(hipGetLastError());
 }
 

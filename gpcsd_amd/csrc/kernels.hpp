@@ -134,6 +134,7 @@ void k_tridiag_solve(gpcsd_ctx *c, const double *W, double *B, const double *es,
                      const double *const amax[2], const double *sig, int nx, int R, int nt, const int np[2], const int c0[2],
                      hipStream_t s);
 void k_add_diag(gpcsd_ctx *c, double *A, int n, double v, hipStream_t s, const HpDev *tab = nullptr, int B = 1, long s_out = 0);
+void k_sum_partials(gpcsd_ctx *c, double *out, const double *P, long n, int parts, hipStream_t s);
 // D[x*nt + i] = es[x]*et[i] + sig[x or 0]; also sumlog -> *sumlog_out (deterministic)
 // Dinv (optional) = 1/D elementwise.  sumlog_out == nullptr: no final sum; the per-block partials stay in the ctx buffer
 // "buildD_partials" and the return value is their count (a later launch may fold the sum in, or nobody needs it)
