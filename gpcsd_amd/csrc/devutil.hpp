@@ -32,6 +32,12 @@ __device__ __forceinline__ double dpp_mov(double v) {
     hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, true);
     return __hiloint2double(hi, lo);
 }
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() waits for EVERY outstanding memory operation of the wave,
+// so a global load issued in front of it as a prefetch has landed before the barrier lets anybody through; here the loads stay
+// in flight (the compiler still waits for them where their registers are first used).  For phases that communicate through
+// LDS alone.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 __device__ __forceinline__ double lane_get(double v, int l) {
     const int lo = __builtin_amdgcn_readlane(__double2loint(v), l), hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
     return __hiloint2double(hi, lo);

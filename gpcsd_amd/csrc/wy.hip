@@ -29,6 +29,7 @@ __global__ __launch_bounds__(1024) void wy_prep_kernel(WyBatch b) {
 
 constexpr int WY_NT = 1024;           // threads of an apply workgroup
 constexpr int WY_KS = 4;              // the K range of W1 = V_p Zc split over this many wave groups
+constexpr int WY_LDT = WY_NB + 1;     // LDS row stride of T_p
 
 // one workgroup = 16 columns of Z resident in LDS, all panels applied in sequence.  Sixteen waves: the 64 x 16 product
 // W1 = V_p Zc has four fragments only, so its K range is split four ways (partial sums in LDS, added up by the readers);
@@ -45,6 +46,7 @@ __global__ __launch_bounds__(WY_NT) void wy_apply_kernel(WyBatch b) {
     double *Zs = smem;                         // [n][WY_LD]
     double *W1 = Zs + (size_t)n * WY_LD;       // [KS][64][WY_LD]
     double *W2 = W1 + KS * WY_NB * WY_LD;      // [64][WY_LD]
+    double *Ts = W2 + WY_NB * WY_LD;           // [64][WY_LDT]: T_p (KS > 1 only)
     const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int fr = lane & 15, fq = lane >> 4;
     const bool stamping = b.clk && blockIdx.y == 0 && blockIdx.x == gridDim.x - 1 && tid == 0;
@@ -63,60 +65,89 @@ __global__ __launch_bounds__(WY_NT) void wy_apply_kernel(WyBatch b) {
     __syncthreads();
     stamp();
     const int nfrag = (n + 15) / 16;
+    struct W1Range { int fa, ks, kb, ke; };
+    auto w1_range = [&](int p) {
+        const int kstart = (p * WY_NB) & ~3;
+        const int klen = (((n - kstart + KS - 1) / KS) + 3) & ~3;
+        W1Range w;
+        w.fa = wid & 3; w.ks = wid >> 2;
+        w.kb = kstart + w.ks * klen; w.ke = min(n, w.kb + klen);
+        return w;
+    };
+    auto load8 = [&](double (&dst)[8], const double *__restrict__ ra, int k0, int ke) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int k = k0 + 4 * u + fq;
+            dst[u] = ra[k < ke ? k : n - 1];
+        }
+    };
+    double a8[8];                              // first batch of the W1 operand of the panel about to be applied
+    auto preload_w1 = [&](int p) {
+        if (wid < 4 * KS) {
+            const W1Range w = w1_range(p);
+            if (w.kb < w.ke) load8(a8, P.V + (long)p * WY_NB * n + (long)(16 * w.fa + fr) * n, w.kb, w.ke);
+        }
+    };
+    if (P.npanels > 0) preload_w1(P.npanels - 1);
     for (int p = P.npanels - 1; p >= 0; --p) {
         const double *__restrict__ Vp = P.V + (long)p * WY_NB * n;
         const double *__restrict__ Tp = P.T + (long)p * WY_NB * WY_NB;
         const int kstart = (p * WY_NB) & ~3;
-        // W1 = V_p Zc : wave (ks, fa) owns panel rows 16 fa .. 16 fa + 15 over the ks-th part of the K range
-        if (wid < 4 * KS) {
-            const int fa = wid & 3, ks = wid >> 2;
-            const int klen = (((n - kstart + KS - 1) / KS) + 3) & ~3;
-            const int kb = kstart + ks * klen, ke = min(n, kb + klen);
-            const double *__restrict__ ra = Vp + (long)(16 * fa + fr) * n;
-            d4 acc = {0.0, 0.0, 0.0, 0.0};
-            // the panel rows come straight from L2: batches of eight clamped (branch-free) loads, the NEXT batch issued
-            // before the MFMAs of the current one, so the chain never waits for a full L2 round trip
-            double a8[8], b8[8];
-            auto load8 = [&](double (&dst)[8], int k0) {
+        // T_p on its way to LDS (KS > 1: there is room): four coalesced loads per thread issued here, in front of the W1 product
+        // they do not depend on -- as strided fragment loads in the W2 phase they were a 2 us round trip per panel
+        double tl4[4];
+        if (KS > 1) {
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const int k = k0 + 4 * u + fq;
-                    dst[u] = ra[k < ke ? k : n - 1];
-                }
-            };
+            for (int u = 0; u < 4; ++u) tl4[u] = Tp[tid + WY_NT * u];
+        }
+        // W1 = V_p Zc : wave (ks, fa) owns panel rows 16 fa .. 16 fa + 15 over the ks-th part of the K range.  The panel rows come
+        // straight from L2: batches of eight clamped (branch-free) loads, the NEXT batch issued before the MFMAs of the current
+        // one; the first batch of a panel was issued before the previous panel's update phase (a8 is carried across panels).
+        if (wid < 4 * KS) {
+            const W1Range w = w1_range(p);
+            const double *__restrict__ ra = Vp + (long)(16 * w.fa + fr) * n;
+            d4 acc = {0.0, 0.0, 0.0, 0.0};
+            double b8[8];
             auto mma8 = [&](const double (&src)[8], int k0) {
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
                     const int k = k0 + 4 * u + fq;
-                    const double bb = Zs[(k < ke ? k : n - 1) * WY_LD + fr];
-                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(k < ke ? src[u] : 0.0, bb, acc, 0, 0, 0);
+                    const double bb = Zs[(k < w.ke ? k : n - 1) * WY_LD + fr];
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(k < w.ke ? src[u] : 0.0, bb, acc, 0, 0, 0);
                 }
             };
-            if (kb < ke) load8(a8, kb);
-            for (int k0 = kb; k0 < ke; k0 += 64) {
-                if (k0 + 32 < ke) load8(b8, k0 + 32);
+            for (int k0 = w.kb; k0 < w.ke; k0 += 64) {
+                if (k0 + 32 < w.ke) load8(b8, ra, k0 + 32, w.ke);
                 mma8(a8, k0);
-                if (k0 + 32 < ke) {
-                    if (k0 + 64 < ke) load8(a8, k0 + 64);
+                if (k0 + 32 < w.ke) {
+                    if (k0 + 64 < w.ke) load8(a8, ra, k0 + 64, w.ke);
                     mma8(b8, k0 + 32);
                 }
             }
 #pragma unroll
-            for (int r = 0; r < 4; ++r) W1[(ks * WY_NB + 16 * fa + fq + 4 * r) * WY_LD + fr] = acc[r];
+            for (int r = 0; r < 4; ++r) W1[(w.ks * WY_NB + 16 * w.fa + fq + 4 * r) * WY_LD + fr] = acc[r];
         }
-        __syncthreads();
+        if (KS > 1) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int idx = tid + WY_NT * u;
+                Ts[(idx >> 6) * WY_LDT + (idx & 63)] = tl4[u];
+            }
+        }
+        lds_barrier();
         stamp();
         // W2 = T_p W1 (four waves; the others go on to the loads of the update)
         if (wid < 4) {
             const double *__restrict__ ta = Tp + (long)(16 * wid + fr) * WY_NB;
             d4 acc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-            for (int k0 = 0; k0 < WY_NB; k0 += 4) {
-                const int k = k0 + fq;
+            for (int u = 0; u < 16; ++u) {
+                const int k = 4 * u + fq;
                 double w = W1[k * WY_LD + fr];
 #pragma unroll
                 for (int q = 1; q < KS; ++q) w += W1[(q * WY_NB + k) * WY_LD + fr];
-                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ta[k], w, acc, 0, 0, 0);
+                const double tv = (KS > 1) ? Ts[(16 * wid + fr) * WY_LDT + k] : ta[k];
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(tv, w, acc, 0, 0, 0);
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) W2[(16 * wid + fq + 4 * r) * WY_LD + fr] = acc[r];
@@ -125,7 +156,7 @@ __global__ __launch_bounds__(WY_NT) void wy_apply_kernel(WyBatch b) {
         // the loads of the next half are issued before the MFMAs of the current one, the first before the barrier that
         // publishes W2.
         {
-            double a8[8], b8[8];
+            double ua[8], ub[8];
             auto loadh = [&](double (&dst)[8], int fm, int h) {
                 const int m = 16 * fm + fr;
                 const double *__restrict__ vm = Vp + (m < n ? m : n - 1) + (long)(32 * h + fq) * n;   // clamped column
@@ -139,15 +170,16 @@ __global__ __launch_bounds__(WY_NT) void wy_apply_kernel(WyBatch b) {
             };
             constexpr int NW = WY_NT / 64;
             int fm = (p * WY_NB) / 16 + wid;
-            if (fm < nfrag) loadh(a8, fm, 0);
-            __syncthreads();
+            if (fm < nfrag) loadh(ua, fm, 0);
+            if (p > 0) preload_w1(p - 1);                     // (reads V only: independent of this panel's update)
+            lds_barrier();
             stamp();
             for (; fm < nfrag; fm += NW) {
                 d4 acc = {0.0, 0.0, 0.0, 0.0};
-                loadh(b8, fm, 1);
-                mmah(a8, 0, acc);
-                if (fm + NW < nfrag) loadh(a8, fm + NW, 0);
-                mmah(b8, 1, acc);
+                loadh(ub, fm, 1);
+                mmah(ua, 0, acc);
+                if (fm + NW < nfrag) loadh(ua, fm + NW, 0);
+                mmah(ub, 1, acc);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int row = 16 * fm + fq + 4 * r;
@@ -155,7 +187,7 @@ __global__ __launch_bounds__(WY_NT) void wy_apply_kernel(WyBatch b) {
                 }
             }
         }
-        __syncthreads();
+        lds_barrier();
         stamp();
     }
     for (int idx = tid; idx < n * WY_ZC; idx += WY_NT) {
@@ -206,7 +238,9 @@ void wy_prep_device(gpcsd_ctx *c, const WyBatch &b, int nclass, hipStream_t s) {
     GP_HIP(hipGetLastError());
 }
 
-static size_t wy_apply_lds(int nmax, int ks) { return ((size_t)nmax * WY_LD + (size_t)(ks + 1) * WY_NB * WY_LD) * sizeof(double); }
+static size_t wy_apply_lds(int nmax, int ks) {
+    return ((size_t)nmax * WY_LD + (size_t)(ks + 1) * WY_NB * WY_LD + (ks > 1 ? (size_t)WY_NB * WY_LDT : 0)) * sizeof(double);
+}
 bool wy_fused_supported(int nmax) { return wy_apply_lds(nmax, 1) <= 160 * 1024; }
 
 void wy_batch_device(gpcsd_ctx *c, const WyBatch &b, int nclass, hipStream_t s, bool prep_done) {
