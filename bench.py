@@ -543,7 +543,7 @@ def sub_results(args, local_rank, backend):
         res = {}
         for name in ("npx69", "npx72sym"):
             a = copy.copy(args)
-            a.workload, a.steps, a.warmup, a.setup_steps, a.no_cpu_baseline, a.trials_per_gpu = name, 100, 5, 60, True, None
+            a.workload, a.steps, a.warmup, a.setup_steps, a.no_cpu_baseline, a.trials_per_gpu = name, 200, 5, 150, True, None
             r = run_step_bench(a, workload(name), 0, 1, local_rank, backend, compact=True)
             res[name] = {k: r[k] for k in ("value", "unit", "ms_per_step", "steps", "config", "parity_rel_err_loglik_vs_oracle",
                                            "parity_rel_err_predict_vs_oracle", "loglik") if k in r}
