@@ -6,11 +6,15 @@
 // ------------------------------------------------------------------------------------------------
 // End of an asynchronous loglik: the scalars and status words go to the pinned block behind an event; nothing is waited for
 // and the status words are left alone (the chains of later calls may already be reporting into them).
-static int finish_loglik_async(gpcsd_ctx *c, const EigState &e, bool two) {
+// the pinned slot the next asynchronous log-likelihood lands in (the tail's last launch may write it itself: k_ll_tridiag)
+static double *next_ll_slot(gpcsd_ctx *c) { return c->h_ll + gpcsd_ctx::RESULT_DOUBLES * ((c->ll_head + c->ll_count) % gpcsd_ctx::LL_SLOTS); }
+
+static int finish_loglik_async(gpcsd_ctx *c, const EigState &e, bool two, bool slot_written = false) {
     const int k = (c->ll_head + c->ll_count) % gpcsd_ctx::LL_SLOTS;       // callers have checked that a slot is free
     gpcsd_ctx::LlSlot &sl = c->ll_slot[k];
-    GP_HIP(hipMemcpyAsync(c->h_ll + gpcsd_ctx::RESULT_DOUBLES * k, e.scal, gpcsd_ctx::RESULT_DOUBLES * sizeof(double),
-                          hipMemcpyDeviceToHost, c->stream));
+    if (!slot_written)
+        GP_HIP(hipMemcpyAsync(c->h_ll + gpcsd_ctx::RESULT_DOUBLES * k, e.scal, gpcsd_ctx::RESULT_DOUBLES * sizeof(double),
+                              hipMemcpyDeviceToHost, c->stream));
     GP_HIP(hipEventRecord(sl.ev, c->stream));
     c->tl("loglik result copied (main)", c->stream);
     ++c->ll_count;
@@ -59,7 +63,8 @@ static void loglik_tri_pre(gpcsd_ctx *c, EigState &e, const FoldMode &fm, const 
     tri_times_Q(c, e, fm, Yf, c->buf<double>(xname, (size_t)c->nx * c->ntrials * c->nt), prof);
 }
 
-static void loglik_tri_tail(gpcsd_ctx *c, EigState &e, const FoldMode &fm, const double *Yf, double *W) {
+// host_slot: the caller's pinned result slot when the evaluation is asynchronous (else null); returns true when the tail wrote it
+static bool loglik_tri_tail(gpcsd_ctx *c, EigState &e, const FoldMode &fm, const double *Yf, double *W, double *host_slot = nullptr) {
     const int nx = c->nx, nt = c->nt, R = c->ntrials;
     hipStream_t s = c->stream;
     ++c->fold_gemm_calls;
@@ -82,17 +87,21 @@ static void loglik_tri_tail(gpcsd_ctx *c, EigState &e, const FoldMode &fm, const
         const long o = (long)e.tri_rep * av.blk;
         d[p] = av.d + o; ee[p] = av.e + o; am[p] = av.amax + o;
     }
-    k_ll_tridiag(c, W, fm.fs.w, d, ee, am, e.d_sig, nx, R, nt, np, c0, e.scal, e.scal + 1, s);
+    const bool wrote = k_ll_tridiag(c, W, fm.fs.w, d, ee, am, e.d_sig, nx, R, nt, np, c0, e.scal, e.scal + 1, s, host_slot,
+                                    e.scal + gpcsd_ctx::SCAL_N, gpcsd_ctx::SCAL_N, gpcsd_ctx::RESULT_DOUBLES - gpcsd_ctx::SCAL_N);
     GP_HIP(hipEventRecord(c->ev_tri_done[c->tgen], s));
     c->tri_reader_queued[c->tgen] = true;
+    return wrote;
 }
 
-static bool loglik_fold_tail(gpcsd_ctx *c, EigState &e, const FoldMode &fm, const double *Yf, double *W) {
+static bool loglik_fold_tail(gpcsd_ctx *c, EigState &e, const FoldMode &fm, const double *Yf, double *W, double *host_slot = nullptr,
+                             bool *slot_written = nullptr) {
     const int nx = c->nx, nt = c->nt, R = c->ntrials;
     hipStream_t s = c->stream;
     if (e.tri) {
         loglik_tri_pre(c, e, fm, Yf);
-        loglik_tri_tail(c, e, fm, Yf, W);
+        const bool wrote = loglik_tri_tail(c, e, fm, Yf, W, host_slot);
+        if (slot_written) *slot_written = wrote;
         return true;
     }
     ++c->fold_gemm_calls;
@@ -132,8 +141,9 @@ static int loglik_parts_impl(gpcsd_ctx *c, const gpcsd_hparams *hp, double *out2
     hipStream_t s = c->stream;
     double *W = c->buf<double>("proj_W", (size_t)nx * R * nt);
     if (fm.on) {
-        const bool batched = loglik_fold_tail(c, e, fm, Yf, W);
-        if (async) return finish_loglik_async(c, e, !batched);
+        bool wrote = false;
+        const bool batched = loglik_fold_tail(c, e, fm, Yf, W, async ? next_ll_slot(c) : nullptr, &wrote);
+        if (async) return finish_loglik_async(c, e, !batched, wrote);
         double h3[3] = {0.0, 0.0, 0.0};
         const int rc = finish_call(c, e, h3, 3);
         out2[0] = h3[0];
@@ -787,9 +797,10 @@ extern "C" int gpcsd_loglik_predict_async(gpcsd_ctx *c, const gpcsd_hparams *hp_
     const std::function<void()> ll_tail = [&]() {
         double *Wll = c->buf<double>("proj_W_ll", (size_t)c->nx * c->ntrials * c->nt);
         bool batched = true;
-        if (pf.e[0].tri) loglik_tri_tail(c, pf.e[0], pf.fm[0], Yf, Wll);
+        bool wrote = false;
+        if (pf.e[0].tri) wrote = loglik_tri_tail(c, pf.e[0], pf.fm[0], Yf, Wll, next_ll_slot(c));
         else batched = loglik_fold_tail(c, pf.e[0], pf.fm[0], Yf, Wll);
-        (void)finish_loglik_async(c, pf.e[0], !batched);
+        (void)finish_loglik_async(c, pf.e[0], !batched, wrote);
     };
     return predict_fold(c, hp_pr, pf.e[1], pf.fm[1], Yf, sz, dzf, nz, dtf, type, want_lists != 0, true, &ll_tail, &ll_pre);
     GP_API_END(c)

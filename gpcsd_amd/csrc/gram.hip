@@ -602,8 +602,13 @@ __global__ __launch_bounds__(64 * LT_WAVES) void ll_tridiag_scan_kernel(LlTridia
     }
 }
 
+// host_slot != null: the two sums also go straight into the caller's pinned result slot (device-accessible host memory:
+// host_slot[0] = sum log D, host_slot[1] = quadratic form) together with the status words (status_doubles doubles from
+// status_src to host_slot + status_at) -- the launch is the last of the evaluation, its results are visible to the host when
+// the event behind it completes, and the separate device-to-host copy (a 4 us blit kernel behind a 6 us gap) is not queued.
 __global__ __launch_bounds__(256) void ll_tridiag_reduce_kernel(const double *__restrict__ partials, int nitems, double *out_sumlog,
-                                                                double *out_quad) {
+                                                                double *out_quad, double *host_slot, const double *status_src,
+                                                                int status_at, int status_doubles) {
     __shared__ double sh[256];
     const double *p = partials + (blockIdx.x == 0 ? nitems : 0);
     double s = 0.0;
@@ -614,12 +619,17 @@ __global__ __launch_bounds__(256) void ll_tridiag_reduce_kernel(const double *__
         if ((int)threadIdx.x < w) sh[threadIdx.x] += sh[threadIdx.x + w];
         __syncthreads();
     }
-    if (threadIdx.x == 0) (blockIdx.x == 0 ? out_sumlog : out_quad)[0] = sh[0];
+    if (threadIdx.x == 0) {
+        (blockIdx.x == 0 ? out_sumlog : out_quad)[0] = sh[0];
+        if (host_slot) host_slot[blockIdx.x == 0 ? 0 : 1] = sh[0];
+    }
+    if (host_slot && blockIdx.x == 0 && (int)threadIdx.x < status_doubles) host_slot[status_at + threadIdx.x] = status_src[threadIdx.x];
 }
 
-void k_ll_tridiag(gpcsd_ctx *c, const double *W, const double *es, const double *const d[2], const double *const e[2],
+bool k_ll_tridiag(gpcsd_ctx *c, const double *W, const double *es, const double *const d[2], const double *const e[2],
                   const double *const amax[2], const double *sig, int nx, int R, int nt, const int np[2], const int c0[2],
-                  double *out_sumlog, double *out_quad, hipStream_t s) {
+                  double *out_sumlog, double *out_quad, hipStream_t s, double *host_slot, const double *status_src, int status_at,
+                  int status_doubles) {
     LlTridiagArgs g{};
     g.W = W; g.es = es; g.sig = sig; g.nx = nx; g.R = R; g.nt = nt;
     for (int p = 0; p < 2; ++p) {
@@ -633,8 +643,12 @@ void k_ll_tridiag(gpcsd_ctx *c, const double *W, const double *es, const double 
         hipLaunchKernelGGL(ll_tridiag_scan_kernel, dim3(ceil_div(nitems, LT_WAVES)), dim3(64 * LT_WAVES), 0, s, g);
     else
         hipLaunchKernelGGL(ll_tridiag_kernel, dim3(ceil_div(nitems, LT_WAVES)), dim3(64 * LT_WAVES), 0, s, g);
-    hipLaunchKernelGGL(ll_tridiag_reduce_kernel, dim3(2), dim3(256), 0, s, (const double *)g.partials, nitems, out_sumlog, out_quad);
+    static const bool direct = !(getenv("GPCSD_LL_HOST_WRITE") && getenv("GPCSD_LL_HOST_WRITE")[0] == '0');
+    if (!direct || status_doubles > 256) host_slot = nullptr;
+    hipLaunchKernelGGL(ll_tridiag_reduce_kernel, dim3(2), dim3(256), 0, s, (const double *)g.partials, nitems, out_sumlog, out_quad,
+                       host_slot, status_src, status_at, host_slot ? status_doubles : 0);
     GP_HIP(hipGetLastError());
+    return host_slot != nullptr;
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -123,9 +123,12 @@ void k_se_axis(gpcsd_ctx *c, const double *a, int n, double ell, double *out, hi
 // block of Ks (x) Kt + sig2 I of spatial eigen-row x' and temporal parity p is Q_p (es[x'] amax_p T_p + sig2 I) Q_p^T;
 // *out_sumlog = sum of the log pivots of all these tridiagonal matrices (= sum log D), *out_quad = sum over the rows w of
 // W = U^T Y Q ([x'][r][t~], rows of nt) of w^T (.)^-1 w by one forward recurrence each.  No temporal eigenvectors.
-void k_ll_tridiag(gpcsd_ctx *c, const double *W, const double *es, const double *const d[2], const double *const e[2],
+// host_slot (pinned, device-accessible) != null: the final sums' launch also writes {sum log D, quadratic form} to host_slot[0..1]
+// and the status_doubles doubles at status_src to host_slot + status_at -- returns true when it did (the caller then skips its copy)
+bool k_ll_tridiag(gpcsd_ctx *c, const double *W, const double *es, const double *const d[2], const double *const e[2],
                   const double *const amax[2], const double *sig, int nx, int R, int nt, const int np[2], const int c0[2],
-                  double *out_sumlog, double *out_quad, hipStream_t s);
+                  double *out_sumlog, double *out_quad, hipStream_t s, double *host_slot = nullptr, const double *status_src = nullptr,
+                  int status_at = 0, int status_doubles = 0);
 // The same systems solved: B[x'][r][p block] = (es[x'] amax_p T_p + sig2 I)^-1 W[x'][r][p block] (B may be W).  The posterior mean
 // in the basis U (x) Q -- what (W V) / D is in the basis U (x) V -- without the temporal eigenvectors.
 // k_tridiag_solve_pass: trials per pass of the kernel for column blocks of up to npmax (its z lives in LDS); 0 = unsupported.
