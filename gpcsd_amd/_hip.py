@@ -640,17 +640,31 @@ class Context:
         self._check(self._lib.gpcsd_loglik_parts_async(self._h, ctypes.byref(hp)))
 
     def loglik_parts_wait(self):
-        out = np.empty(2)
-        self._check(self._lib.gpcsd_loglik_parts_wait(self._h, _ptr(out)))
-        return float(out[0]), float(out[1])
+        # (the queued forms are called a thousand times a second: their wrappers keep what does not change from call to call)
+        w = getattr(self, "_wait_out", None)
+        if w is None:
+            out = np.empty(2)
+            w = self._wait_out = (out, _ptr(out))
+        rc = self._lib.gpcsd_loglik_parts_wait(self._h, w[1])
+        if rc:
+            self._check(rc)
+        return float(w[0][0]), float(w[0][1])
 
     def loglik_predict_async(self, hp_loglik, hp_predict, z, tstar, type_code, want_lists=True):
         """loglik_parts_async(hp_loglik) + predict_resident(hp_predict, ...) as one queued call with the decompositions of the
         two batched (same bits); collect with loglik_parts_wait() and fetch()."""
-        z = _arr(z)
-        tstar = _arr(tstar).reshape(-1)
-        self._check(self._lib.gpcsd_loglik_predict_async(self._h, ctypes.byref(hp_loglik), ctypes.byref(hp_predict), _ptr(z),
-                                                         z.shape[0], _ptr(tstar), tstar.size, int(type_code), int(bool(want_lists))))
+        k = getattr(self, "_lpa_args", None)
+        if k is None or k[0] is not z or k[1] is not tstar:
+            za = _arr(z)
+            ta = _arr(tstar).reshape(-1)
+            k = (z, tstar, za, ta, _ptr(za), za.shape[0], _ptr(ta), ta.size)
+            # the pointers are kept only when they point into the caller's own arrays (no contiguous copy was made): an in-place
+            # edit of z / tstar between calls is then seen, as without the cache
+            self._lpa_args = k if (za is z and (ta is tstar or ta.base is tstar)) else None
+        rc = self._lib.gpcsd_loglik_predict_async(self._h, ctypes.byref(hp_loglik), ctypes.byref(hp_predict), k[4], k[5], k[6], k[7],
+                                                  int(type_code), 1 if want_lists else 0)
+        if rc:
+            self._check(rc)
 
     def loglik_grad(self, hp, ngrad):
         """(sum log D, local quad, d L_loc / d natural params) with L_loc = -0.5*R_resident*sumlog - 0.5*quad."""
