@@ -134,9 +134,14 @@ __device__ __forceinline__ void inverse_level(double *As, int wid, int lane) {
 // FACTOR: Cholesky of the nb x nb (<= 128) block at Ablk (in: its lower part; out: L in place, upper part zeroed), then inv(L) to
 // Xout (lower; leading dimension ldx).  !FACTOR: the block already is a Cholesky factor: inverse only.
 // status: first failing pivot + 1 (global index pivot_base + j).  Blocks smaller than 128 are padded with the identity.
+// started (pinned host word, may be null): stamped with `token` as soon as the workgroup runs -- it then HAS its CU; potrf's gate
+// launches poll the word before they let the trailing update's tiles take every other one (see potrf_device).
 template <bool FACTOR>
 __global__ __launch_bounds__(DNT) void diag128_kernel(double *Ablk, long lda, int nb, double *Xout, long ldx, int *status,
-                                                       int pivot_base, unsigned long long *clk) {
+                                                       int pivot_base, unsigned long long *clk, unsigned int *started,
+                                                       unsigned int token) {
+    __builtin_amdgcn_s_setprio(3);
+    if (started && threadIdx.x == 0) __atomic_store_n(started, token, __ATOMIC_RELAXED);
     // clk (measurement aid, normally null): wall-clock stamps (100 MHz) at the phase boundaries -- [0] start, [1] block loaded,
     // [2] / [3] ticks spent in the serial panels / the rank-16 updates, [4] L stored, [5] diagonal inverses, [6..8] doubling levels,
     // [9] X stored
@@ -277,7 +282,7 @@ __global__ __launch_bounds__(DNT) void diag128_kernel(double *Ablk, long lda, in
 }
 
 static void launch_diag(double *Ablk, long lda, int nb, double *Xout, long ldx, int *status, int pivot_base, bool factor,
-                        hipStream_t s, unsigned long long *clk = nullptr) {
+                        hipStream_t s, unsigned long long *clk = nullptr, unsigned int *started = nullptr, unsigned int token = 0) {
     static bool attr_done = false;
     if (!attr_done) {
         GP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(diag128_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -286,8 +291,12 @@ static void launch_diag(double *Ablk, long lda, int nb, double *Xout, long ldx, 
                                    (int)DIAG_LDS_BYTES));
         attr_done = true;
     }
-    if (factor) hipLaunchKernelGGL(diag128_kernel<true>, dim3(1), dim3(DNT), DIAG_LDS_BYTES, s, Ablk, lda, nb, Xout, ldx, status, pivot_base, clk);
-    else hipLaunchKernelGGL(diag128_kernel<false>, dim3(1), dim3(DNT), DIAG_LDS_BYTES, s, Ablk, lda, nb, Xout, ldx, status, pivot_base, clk);
+    if (factor)
+        hipLaunchKernelGGL(diag128_kernel<true>, dim3(1), dim3(DNT), DIAG_LDS_BYTES, s, Ablk, lda, nb, Xout, ldx, status, pivot_base, clk,
+                           started, token);
+    else
+        hipLaunchKernelGGL(diag128_kernel<false>, dim3(1), dim3(DNT), DIAG_LDS_BYTES, s, Ablk, lda, nb, Xout, ldx, status, pivot_base, clk,
+                           started, token);
 }
 
 __global__ void copy2d_kernel(const double *__restrict__ src, long lds_, double *__restrict__ dst, long ldd, int rows, int cols) {
@@ -306,6 +315,16 @@ __global__ void zero_upper_kernel(double *A, int n) {
     }
 }
 
+// Tile configuration of the diagonal chain's small products.  On their own the 32 x 32 tiles with deep K slabs are fastest; beside
+// the trailing update a workgroup of that configuration (64 KB of LDS, more registers than an update tile) only finds room on a CU
+// when TWO update tiles have retired there -- the products then took 58 us on average, up to 500.  The update's own 64 x 64
+// configuration fits wherever one of its tiles retires.
+static thread_local bool g_chain_under_update = false;      // set by potrf_device around a chain that runs beside a long update
+static int small_cfg() {
+    static const int v = getenv("GPCSD_POTRF_SMALL_CFG") ? atoi(getenv("GPCSD_POTRF_SMALL_CFG")) : 2;
+    return g_chain_under_update ? v : 0;
+}
+
 static void small_gemm(gpcsd_ctx *c, int M, int N, int K, const double *A, long lda, const double *B, long ldb, bool tb, double *C,
                        long ldc, double alpha, int epi, const char *name, hipStream_t s) {
     if (M <= 0 || N <= 0 || K <= 0) return;
@@ -313,6 +332,8 @@ static void small_gemm(gpcsd_ctx *c, int M, int N, int K, const double *A, long 
     g.M = M; g.N = N; g.K = K;
     g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.transB = tb; g.C = C; g.ldc = ldc;
     g.alpha = alpha; g.epi = epi;
+    g.prio = 1;
+    g.cfg = small_cfg();
     g.prof_name = name;
     gemm_f64(c, g, s);
 }
@@ -339,13 +360,23 @@ static void assemble_block_inverse(gpcsd_ctx *c, const double *Lblk, long ld, in
 // D of the header: factor the nb x nb (<= NBO) diagonal block at Ablk in place and leave its inverse in X (NBO x NBO buffer).
 // Dependent launches at nb = 256: factor + invert the upper 128 block, panel product, rank-128 update, factor + invert the lower
 // block, copy, two products for the lower-left block of the inverse.
+// One wave that waits (bounded) until *flag has reached token: placed in front of a machine-filling launch, it holds that launch
+// back until a workgroup of another stream that needs a whole CU is resident.  Steers the order of execution only: every data
+// dependence is an event; when the time is up the stream simply goes on.
+__global__ __launch_bounds__(64) void gate_kernel(const unsigned int *flag, unsigned int token, unsigned int max_ticks) {
+    const unsigned long long t0 = wall_clock64();
+    while ((int)(__atomic_load_n(flag, __ATOMIC_RELAXED) - token) < 0 && wall_clock64() - t0 < max_ticks) __builtin_amdgcn_s_sleep(8);
+}
+
+// first_token != 0: the diagonal launches stamp c->h_chol_flag with first_token, first_token + 1, ..
 static void factor_diag_block(gpcsd_ctx *c, double *Ablk, long ld, int nb, double *X, double *tmp, double *Wsub, int *d_status,
-                              int pivot_base, hipStream_t s) {
+                              int pivot_base, hipStream_t s, unsigned int first_token = 0) {
     ProfScope ps(c, "potrf_diag_block", (double)nb * nb * nb * (1.0 / 3.0 + 1.0 / 3.0), s);
     for (int p0 = 0; p0 < nb; p0 += NB) {
         const int b = std::min(NB, nb - p0), rows = nb - (p0 + b);
         double *App = Ablk + (long)p0 * ld + p0;
-        launch_diag(App, ld, b, X + (long)p0 * NBO + p0, (long)NBO, d_status, pivot_base + p0, true, s);
+        launch_diag(App, ld, b, X + (long)p0 * NBO + p0, (long)NBO, d_status, pivot_base + p0, true, s, nullptr,
+                    first_token ? c->h_chol_flag : nullptr, first_token + (unsigned)(p0 / NB));
         if (rows > 0) {
             double *A21 = Ablk + (long)(p0 + b) * ld + p0;
             // L21 = A21 X_pp^T (into Wsub; copied into place below), A22 -= L21 L21^T -- all inside the diagonal block
@@ -354,7 +385,7 @@ static void factor_diag_block(gpcsd_ctx *c, double *Ablk, long ld, int nb, doubl
             g.M = rows; g.N = rows; g.K = b;
             g.A = Wsub; g.lda = LDWS; g.B = Wsub; g.ldb = LDWS; g.transB = true;
             g.C = Ablk + (long)(p0 + b) * ld + (p0 + b); g.ldc = ld;
-            g.epi = EPI_SUB; g.lower = true;
+            g.epi = EPI_SUB; g.lower = true; g.prio = 1; g.cfg = small_cfg();
             g.prof_name = "potrf_blk_syrk";
             gemm_f64(c, g, s);
             if (nb > 2 * NB)             // (more than two sub-blocks: the next sub-step reuses Wsub -- L21 into its place now)
@@ -390,6 +421,7 @@ void potrf_device(gpcsd_ctx *c, double *A, int n, int *d_status, hipStream_t s_i
     static const bool lookahead = potrf_cfg_env("GPCSD_POTRF_LOOKAHEAD", 1) != 0;
     static const int t_cfg = potrf_cfg_env("GPCSD_POTRF_TCFG", 0);      // tile configuration of the trailing update (0: automatic)
     const bool la = lookahead && n > 2 * NBO;
+    static const bool gate_on = potrf_cfg_env("GPCSD_POTRF_GATES", 1) != 0;
     // (tried: two streams with disjoint CU masks, 8 CUs for the side chain -- every GEMM on the CU-restricted main stream ran at
     // a fraction of its rate: 30.3 against 23.4 ms at n = 12 000)
     hipStream_t s = s_in;
@@ -426,20 +458,55 @@ void potrf_device(gpcsd_ctx *c, double *A, int n, int *d_status, hipStream_t s_i
         ta.epi = EPI_SUB; ta.lower = true; ta.cfg = t_cfg;
         ta.prof_name = "potrf_syrk_next_panel";
         gemm_f64(c, ta, s);
-        if (la) {                                                      // D of the next step, beside T_b
+        // D of the next step beside T_b.  Its two factor + invert workgroups need a whole CU each, and under the update's tiles no
+        // CU ever drains (a retiring tile is replaced at once: the chain then only ran when the update was over).  So the update
+        // is held back by gates: T_b1 starts when the first diagonal workgroup is resident, T_b2 -- the rest -- when the second
+        // one is (T_b1 is sized to end about then).  The small products of the chain fit between the tiles anyway.
+        const int mm = m - na;
+        unsigned int tok = 0;
+        const int ndiag = (na + NB - 1) / NB;
+        const double t_update_us = (double)mm * mm * nb / 48e6;            // ~48 TF/s on the tiles that run (mm^2 nb flops)
+        static const double gate_min_us = potrf_cfg_env("GPCSD_POTRF_GATE_MIN_US", 0), tb1_us = potrf_cfg_env("GPCSD_POTRF_TB1_US", 130);
+        const bool gated = la && gate_on && mm > 0 && t_update_us > gate_min_us;
+        if (la) {
             GP_HIP(hipEventRecord(c->ev_chol_a, s));
             GP_HIP(hipStreamWaitEvent(sd, c->ev_chol_a, 0));
-            factor_diag_block(c, A + (long)k1 * n + k1, n, na, X, tmp, Wsub, d_status, k1, sd);
+            if (gated) {
+                tok = c->chol_token + 1;
+                c->chol_token += (unsigned)ndiag;
+            }
+            static const double flood_us = potrf_cfg_env("GPCSD_POTRF_FLOOD_US", 250);
+            g_chain_under_update = gated && t_update_us > flood_us;    // (else the chain is what the main stream waits for: fastest tiles)
+            factor_diag_block(c, A + (long)k1 * n + k1, n, na, X, tmp, Wsub, d_status, k1, sd, tok);
+            g_chain_under_update = false;
             GP_HIP(hipEventRecord(c->ev_chol_d, sd));
         }
-        if (m > na) {                                                  // T_b: everything to the right of the next panel
-            GemmDesc tb;
-            tb.M = m - na; tb.N = m - na; tb.K = nb;
-            tb.A = W + (long)na * LDW; tb.lda = LDW; tb.B = W + (long)na * LDW; tb.ldb = LDW; tb.transB = true;
-            tb.C = A + (long)(k1 + na) * n + (k1 + na); tb.ldc = n;
-            tb.epi = EPI_SUB; tb.lower = true; tb.cfg = t_cfg;
-            tb.prof_name = "potrf_syrk";
-            gemm_f64(c, tb, s);
+        if (mm > 0) {                                                  // T_b: everything to the right of the next panel
+            auto update_rows = [&](int r0, int r1) {                   // rows [r0, r1) of the lower-triangular update
+                GemmDesc tb;
+                tb.M = r1 - r0; tb.N = r1; tb.K = nb;
+                tb.A = W + (long)(na + r0) * LDW; tb.lda = LDW; tb.B = W + (long)na * LDW; tb.ldb = LDW; tb.transB = true;
+                tb.C = A + (long)(k1 + na + r0) * n + (k1 + na); tb.ldc = n;
+                tb.epi = EPI_SUB; tb.lower = true; tb.lower_shift = r0; tb.cfg = t_cfg;
+                tb.prof_name = "potrf_syrk";
+                gemm_f64(c, tb, s);
+            };
+            if (!gated) {
+                update_rows(0, mm);
+            } else {
+                const unsigned int max_ticks = 30000;                  // 300 us
+                hipLaunchKernelGGL(gate_kernel, dim3(1), dim3(64), 0, s, (const unsigned int *)c->h_chol_flag, tok, max_ticks);
+                int r1 = mm;
+                if (ndiag > 1) {                                       // T_b1: ~100 us of tiles (first diagonal launch + the two small products)
+                    const double frac = std::min(0.5, tb1_us / t_update_us);
+                    r1 = std::min(mm, std::max(256, (int)(mm * std::sqrt(frac)) / 64 * 64));
+                }
+                update_rows(0, r1);
+                if (r1 < mm) {
+                    hipLaunchKernelGGL(gate_kernel, dim3(1), dim3(64), 0, s, (const unsigned int *)c->h_chol_flag, tok + 1, max_ticks);
+                    update_rows(r1, mm);
+                }
+            }
         }
         hipLaunchKernelGGL(copy2d_kernel, dim3(ceil_div((long)m * nb, 256)), dim3(256), 0, s, (const double *)W, (long)LDW, A21,
                            (long)n, m, nb);                            // L21 into its place (W is reused by the next step)

@@ -106,6 +106,8 @@ struct gpcsd_ctx {
     int ll_head = 0, ll_count = 0;          // oldest outstanding slot, number outstanding
     hipEvent_t ev_aux = nullptr, ev_pc = nullptr;   // predict: small products of the tail on stream2 beside the large ones
     hipEvent_t ev_chol_a = nullptr, ev_chol_d = nullptr;   // potrf look-ahead (chol.hip): next panel updated / next diagonal block factored
+    unsigned int *h_chol_flag = nullptr;    // pinned word the diagonal kernel stamps when its workgroup is resident (potrf's gates poll it)
+    unsigned int chol_token = 0;            // last token handed out
     // staged temporal chain (capi.hip front_half): ev_t1 = stage 1 (tridiagonalisation) done, recorded on stream2; ev_q = stage 3
     // (T factors and the orthogonal factor Q, on stream4 behind ev_t1) done -- the log-likelihood's tail needs nothing more of
     // that chain, its stage 4 waits for it too.  q_gen: the generation of the temporal solver slot whose Q / tridiagonal are in

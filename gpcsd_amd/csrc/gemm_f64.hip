@@ -56,6 +56,8 @@ struct GemmK {
     int n_group;        // otherwise: n-tiles per sweep over the row panels
     const int *dyn;     // optional device scalar: effective N and K (= *dyn) of this launch (D&C merge GEMMs)
     int lower;          // 1: tiles strictly above the diagonal of C are skipped (symmetric rank-k update, lower triangle wanted)
+    int lower_shift;    // rows of the update in front of this launch's first row
+    int prio;           // > 0: the launch's waves raise their issue priority (a small product on a dependent chain beside a flood of tiles)
     const double *kscale;   // optional: A's element at contracted index k is multiplied by kscale[k] on its way to LDS
     long sKscale, sKscale2;
     // outer batch level (GemmDesc::batch2): grid z = z2 * batch1 + z1
@@ -156,6 +158,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f64_kernel(GemmK g) {
     using TileB = Tile<BN, !TB, NT, BK>;   // !transB: global [K][N]
     __shared__ double lds[2 * (TileA::LDS_ELEMS + TileB::LDS_ELEMS)];
     // operand A buffers at lds + b*TileA::LDS_ELEMS; operand B buffers follow the A buffers
+    if (g.prio) __builtin_amdgcn_s_setprio(3);
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wid = tid >> 6;
@@ -202,7 +205,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f64_kernel(GemmK g) {
         tile_n = n_first + rem - tile_m * ng;
     }
     const int m0 = tile_m * BM, n0 = tile_n * BN;
-    if (g.lower && n0 > m0 + BM - 1) return;      // wave-uniform: no entry of this tile lies on or below the diagonal
+    if (g.lower && n0 > m0 + BM - 1 + g.lower_shift) return;      // wave-uniform: no entry of this tile lies on or below the diagonal
     // two batch levels: z1 the inner entry (stride s?), z2 the outer one (stride s?2; replicas of a hyper-parameter batch)
     long z1 = bz, z2 = 0;
     if (g.batch1 > 0) {                 // wave-uniform; only launches with an outer level pay the division
@@ -850,6 +853,8 @@ void gemm_f64(gpcsd_ctx *c, const GemmDesc &g, hipStream_t s) {
     k.partials = nullptr;
     k.dyn = g.dyn;
     k.lower = g.lower ? 1 : 0;
+    k.lower_shift = g.lower ? g.lower_shift : 0;
+    k.prio = g.prio;
     k.kscale = g.kscale; k.sKscale = g.sKscale; k.sKscale2 = g.sKscale2;
     const int batch2 = g.batch2 > 1 ? g.batch2 : 1;
     k.batch1 = batch2 > 1 ? g.batch : 0;
@@ -891,7 +896,7 @@ void gemm_f64(gpcsd_ctx *c, const GemmDesc &g, hipStream_t s) {
     double flops = 2.0 * g.M * (double)g.N * g.K * g.batch * batch2;
     if (g.lower) {                                  // count the tiles that run (on or below the diagonal), whole tiles
         long run = 0;
-        for (int i = 0; i < tm; ++i) run += std::min<long>(tn, ((long)i * bm + bm - 1) / bn + 1);
+        for (int i = 0; i < tm; ++i) run += std::min<long>(tn, ((long)i * bm + bm - 1 + g.lower_shift) / bn + 1);
         flops = 2.0 * (double)run * bm * bn * g.K * g.batch * batch2;
     }
     {

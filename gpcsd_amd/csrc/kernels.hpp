@@ -54,6 +54,9 @@ struct GemmDesc {
     double *extra_sum_out = nullptr;
     const int *dyn = nullptr;     // device int per batch entry: effective N = K = dyn[batch] (tiles beyond it exit)
     bool lower = false;           // square symmetric update (C and its mirror image equal): tiles strictly above the diagonal exit at once
+    int lower_shift = 0;          // ... of a launch that covers rows lower_shift.. of such an update (row i of C is row lower_shift + i)
+    int prio = 0;                 // 1: the launch's waves run at raised issue priority (small products of a dependent chain that share
+                                  // their CUs with another stream's flood of tiles: Cholesky's diagonal chain)
     int cfg = 0;                  // 0 = choose the tile configuration automatically, 1 / 2 / 3 / 5 = force (see gemm_f64.hip)
     const char *prof_name = "gemm_f64";
 };
