@@ -481,6 +481,10 @@ void potrf_device(gpcsd_ctx *c, double *A, int n, int *d_status, hipStream_t s_i
             g_chain_under_update = false;
             GP_HIP(hipEventRecord(c->ev_chol_d, sd));
         }
+        // L21 into its place (W is reused by the next step): queued here, where the main stream would otherwise only wait for the
+        // next diagonal workgroup to become resident
+        hipLaunchKernelGGL(copy2d_kernel, dim3(ceil_div((long)m * nb, 256)), dim3(256), 0, s, (const double *)W, (long)LDW, A21,
+                           (long)n, m, nb);
         if (mm > 0) {                                                  // T_b: everything to the right of the next panel
             auto update_rows = [&](int r0, int r1) {                   // rows [r0, r1) of the lower-triangular update
                 GemmDesc tb;
@@ -508,8 +512,6 @@ void potrf_device(gpcsd_ctx *c, double *A, int n, int *d_status, hipStream_t s_i
                 }
             }
         }
-        hipLaunchKernelGGL(copy2d_kernel, dim3(ceil_div((long)m * nb, 256)), dim3(256), 0, s, (const double *)W, (long)LDW, A21,
-                           (long)n, m, nb);                            // L21 into its place (W is reused by the next step)
         if (la) GP_HIP(hipStreamWaitEvent(s, c->ev_chol_d, 0));
         else factor_diag_block(c, A + (long)k1 * n + k1, n, na, X, tmp, Wsub, d_status, k1, s);
     }
