@@ -320,10 +320,7 @@ __global__ void zero_upper_kernel(double *A, int n) {
 // when TWO update tiles have retired there -- the products then took 58 us on average, up to 500.  The update's own 64 x 64
 // configuration fits wherever one of its tiles retires.
 static thread_local bool g_chain_under_update = false;      // set by potrf_device around a chain that runs beside a long update
-static int small_cfg() {
-    static const int v = getenv("GPCSD_POTRF_SMALL_CFG") ? atoi(getenv("GPCSD_POTRF_SMALL_CFG")) : 2;
-    return g_chain_under_update ? v : 0;
-}
+static int small_cfg() { return g_chain_under_update ? 2 : 0; }
 
 static void small_gemm(gpcsd_ctx *c, int M, int N, int K, const double *A, long lda, const double *B, long ldb, bool tb, double *C,
                        long ldc, double alpha, int epi, const char *name, hipStream_t s) {
@@ -466,8 +463,10 @@ void potrf_device(gpcsd_ctx *c, double *A, int n, int *d_status, hipStream_t s_i
         unsigned int tok = 0;
         const int ndiag = (na + NB - 1) / NB;
         const double t_update_us = (double)mm * mm * nb / 48e6;            // ~48 TF/s on the tiles that run (mm^2 nb flops)
-        static const double gate_min_us = potrf_cfg_env("GPCSD_POTRF_GATE_MIN_US", 0), tb1_us = potrf_cfg_env("GPCSD_POTRF_TB1_US", 130);
-        const bool gated = la && gate_on && mm > 0 && t_update_us > gate_min_us;
+        // (measured at n = 12 000: gating every update, however short, 18.11 ms; only those above 30 / 60 / 120 us: 18.25 / 18.5 /
+        // 18.8; a first part of 60 / 80 / 100 / 130 / 170 us: 18.55 / 18.27 / 18.36 / 18.19 / 18.32)
+        const double tb1_us = 130.0;
+        const bool gated = la && gate_on && mm > 0;
         if (la) {
             GP_HIP(hipEventRecord(c->ev_chol_a, s));
             GP_HIP(hipStreamWaitEvent(sd, c->ev_chol_a, 0));
@@ -475,8 +474,7 @@ void potrf_device(gpcsd_ctx *c, double *A, int n, int *d_status, hipStream_t s_i
                 tok = c->chol_token + 1;
                 c->chol_token += (unsigned)ndiag;
             }
-            static const double flood_us = potrf_cfg_env("GPCSD_POTRF_FLOOD_US", 250);
-            g_chain_under_update = gated && t_update_us > flood_us;    // (else the chain is what the main stream waits for: fastest tiles)
+            g_chain_under_update = gated && t_update_us > 250.0;       // (else the chain is what the main stream waits for: fastest tiles)
             factor_diag_block(c, A + (long)k1 * n + k1, n, na, X, tmp, Wsub, d_status, k1, sd, tok);
             g_chain_under_update = false;
             GP_HIP(hipEventRecord(c->ev_chol_d, sd));
