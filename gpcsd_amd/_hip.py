@@ -375,23 +375,36 @@ class Context:
         raise RuntimeError("libgpcsd_hip error %d: %s" % (rc, msg))
 
     def make_hparams(self, R, eps, ell_s, temporal, sig2n, jitter):
-        """temporal: list of (kind, ell, sigma2).  Returns (HParams, keepalive)."""
+        """temporal: list of (kind, ell, sigma2).  Returns (HParams, keepalive).  Called once or twice per evaluation on the host's
+        critical path (a queued step is a millisecond): plain Python numbers go straight into the struct, NumPy is only asked when
+        an argument is an array."""
         hp = HParams()
         hp.R = float(R)
         hp.eps = float(eps) if eps is not None else 0.0
-        ell_s = np.atleast_1d(np.asarray(ell_s, dtype=np.float64))
-        hp.ell_s[0] = float(ell_s[0])
-        hp.ell_s[1] = float(ell_s[1]) if ell_s.size > 1 else 0.0
-        if not (1 <= len(temporal) <= MAX_TEMPORAL):
+        if isinstance(ell_s, (list, tuple)):
+            hp.ell_s[0] = float(ell_s[0])
+            hp.ell_s[1] = float(ell_s[1]) if len(ell_s) > 1 else 0.0
+        else:
+            ell_s = np.atleast_1d(np.asarray(ell_s, dtype=np.float64))
+            hp.ell_s[0] = float(ell_s[0])
+            hp.ell_s[1] = float(ell_s[1]) if ell_s.size > 1 else 0.0
+        nt = len(temporal)
+        if not (1 <= nt <= MAX_TEMPORAL):
             raise ValueError("between 1 and %d temporal covariance components are supported" % MAX_TEMPORAL)
-        hp.n_temporal = len(temporal)
+        hp.n_temporal = nt
+        kind, ell_t, s2_t = hp.kind, hp.ell_t, hp.sigma2_t
         for i, (k, ell, s2) in enumerate(temporal):
-            hp.kind[i] = int(k)
-            hp.ell_t[i] = float(ell)
-            hp.sigma2_t[i] = float(s2)
-        sig = np.ascontiguousarray(np.atleast_1d(np.asarray(sig2n, dtype=np.float64)))
-        hp.n_sig2n = int(sig.size)
-        hp.sig2n = _ptr(sig)
+            kind[i] = int(k)
+            ell_t[i] = float(ell)
+            s2_t[i] = float(s2)
+        if isinstance(sig2n, (float, int)) or np.ndim(sig2n) == 0:
+            sig = (ctypes.c_double * 1)(float(sig2n))
+            hp.n_sig2n = 1
+            hp.sig2n = ctypes.cast(sig, _c_double_p)
+        else:
+            sig = np.ascontiguousarray(np.atleast_1d(np.asarray(sig2n, dtype=np.float64)))
+            hp.n_sig2n = int(sig.size)
+            hp.sig2n = _ptr(sig)
         hp.jitter = float(jitter)
         return hp, sig
 
