@@ -1111,6 +1111,33 @@ def test_potrf_large_vs_numpy(n):
     print("potrf n=%d: %.2f ms, %.1f TF/s (n^3/3 flops) = %.2f of the fp64 MFMA peak" % (n, ms, tf, tf / 78.6))
 
 
+_POTRF_SUM_PROBE = r"""
+import hashlib, numpy as np
+from gpcsd_amd import _hip
+ctx = _hip.default_context()
+n = 3000
+i = np.arange(n)
+A = np.exp(-np.abs(i[:, None] - i[None, :]) / 64.0); A[i, i] += 1.0
+L = ctx.potrf(A)
+print("SHA", hashlib.sha256(np.ascontiguousarray(L).tobytes()).hexdigest())
+"""
+
+
+@pytest.mark.timeout(600)
+def test_potrf_gates_and_lookahead_do_not_change_a_bit():
+    """The gate launches of the Cholesky look-ahead (chol.hip: potrf_device) steer the ORDER of execution only -- every data
+    dependence is an event, a gate that times out lets its stream go on -- and the update they split in two covers the same
+    tiles with the same arithmetic: the factor is the same bits with the gates, without them (side stream, no overlap) and
+    without the look-ahead (one stream).  n = 3000: twelve outer blocks, gated and ungated updates, a ragged last block."""
+    digests = {}
+    for tag, env in (("gated", {}), ("no gates", {"GPCSD_POTRF_GATES": "0"}), ("one stream", {"GPCSD_POTRF_LOOKAHEAD": "0"})):
+        r = subprocess.run([sys.executable, "-c", _POTRF_SUM_PROBE], cwd=ROOT, env=dict(os.environ, **env), capture_output=True,
+                           text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        digests[tag] = [ln for ln in r.stdout.splitlines() if ln.startswith("SHA")][-1]
+    assert digests["gated"] == digests["no gates"] == digests["one stream"], digests
+
+
 @pytest.mark.timeout(900)
 def test_dense_cholesky_loglik_at_cfg2_geometry_N12000():
     """The north-star's "(Ks (x) Kt + sig2 I) Cholesky factor, log-det and triangular solves" at the one size of BASELINE's
