@@ -760,14 +760,17 @@ def test_predict_resident_is_asynchronous_and_changes_no_bits(name):
     assert np.array_equal(ctx.fetch("pred_out_csd", shape), ref[-2])
 
 
-@pytest.mark.parametrize("name,form", [("cfg3", ""), ("cfg2", ""), ("cfg3", "tri"), ("cfg2", "tri")])
-def test_queued_call_forms_mixed_at_random_soak(name, form):
+@pytest.mark.parametrize("name,form,R", [("cfg3", "", 6), ("cfg2", "", 6), ("cfg3", "tri", 6), ("cfg2", "tri", 6), ("cfg3", "tri", 50),
+                                         ("cfg2", "tri", 70)])
+def test_queued_call_forms_mixed_at_random_soak(name, form, R):
     """tools/soak_paired.py: 80 steps at the bench geometry with hyper-parameters changing every step, the call forms
     (fenced / two queued calls / paired / paired with two steps in flight) mixed at random, decomposition cache off and on:
     every log-likelihood and the final predictions are the bits of the same calls fenced one by one.  "tri": the same with the
-    shifted-tridiagonal log-likelihood forced on (gpcsd_ll_tridiag mode 1; staged temporal chain), "": forced off."""
+    shifted-tridiagonal log-likelihood forced on (gpcsd_ll_tridiag mode 1; staged temporal chain), "": forced off.  R = 50 / 70
+    resident trials ("soak green at R = 50 as well as R = 6"): from 16 trials on the prediction takes its tridiagonal
+    form too -- solves instead of eigenvectors, temporal arenas in two generations, one or several passes of the solve kernel."""
     import subprocess
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "soak_paired.py"), name, "80"] + ([form] if form else []),
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "soak_paired.py"), name, "80", form or "eig", str(R)],
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "soak ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 

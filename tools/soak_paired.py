@@ -1,6 +1,7 @@
 """Soak of the queued call forms: N steps with hyper-parameters that change every step, the paired / queued / two-deep forms
 against the same calls fenced one by one -- every log-likelihood and the final predictions bit for bit.  Mixes the forms at
-random, so generations, chain streams and the result ring see every hand-over.   python tools/soak_paired.py [cfg3|cfg2] [N] [tri]
+random, so generations, chain streams and the result ring see every hand-over.   python tools/soak_paired.py [cfg3|cfg2] [N] [tri] [R]
+(R resident trials, default 6; from 16 on the prediction takes its tridiagonal form too)
 ("tri": with the shifted-tridiagonal log-likelihood forced on, gpcsd_ll_tridiag mode 1 -- its fenced values are also held to
 1e-12 of the eigenvector form's; without it the eigenvector form is forced)."""
 import os, sys
@@ -14,7 +15,7 @@ N = int(sys.argv[2]) if len(sys.argv) > 2 else 200
 TRI = len(sys.argv) > 3 and sys.argv[3] == "tri"
 w = bench.workload(name)
 m = bench.build_model(w, np.zeros((w["nx"], w["nt"], 1)))
-R = 6
+R = int(sys.argv[4]) if len(sys.argv) > 4 else 6
 lfp = bench.synth_data(w, m, R, seed=5)
 m.update_lfp(lfp, w["t"])
 ctx = m._sync_device()
