@@ -294,10 +294,10 @@ def cpu_baseline(w, m, lfp, budget_s=45.0):
         "value": R / (t_ll + t_pr), "unit": "trials/s", "cores": cores_used, "blas_threads": int(best), "host_cpus": int(host_cpus),
         "host_physical_cores_in_affinity": phys,
         "kind": "port", "loglik_path_used_for_value": ll_path,
-        "sample": "loglik (the faster of the oracle x%d and the reference-layout loop) + oracle predict(csd) x%d on the bench's own %d "
-                  "trials at the bench geometry (median times; NumPy %s; %d BLAS threads = best of sweep %s, on %d physical cores; "
-                  "host has %d cpus, affinity %d, BLAS max %d)" % (len(ll_ts), len(pr_ts), R, np.__version__, best, sorted(sweep),
-                                                                   cores_used, host_cpus, affinity, blas_max),
+        "sample": "oracle loglik x%d (or the reference-layout loop, the faster) + predict(csd) x%d, the bench's own %d trials, medians, "
+                  "%d BLAS threads" % (len(ll_ts), len(pr_ts), R, best),
+        "sample_detail": "bench geometry; NumPy %s; %d BLAS threads = best of sweep %s, on %d physical cores; host has %d cpus, affinity "
+                         "%d, BLAS max %d" % (np.__version__, best, sorted(sweep), cores_used, host_cpus, affinity, blas_max),
         "loglik_evals_per_sec": 1.0 / t_ll, "oracle_loglik_evals_per_sec": 1.0 / t_ll_oracle, "predict_trials_per_sec": R / t_pr,
         "single_thread": {"value": R / (med(ll1_ts) + med(pr1_ts)), "loglik_evals_per_sec": 1.0 / med(ll1_ts),
                           "predict_trials_per_sec": R / med(pr1_ts), "reps": [len(ll1_ts), len(pr1_ts)]},
@@ -456,30 +456,107 @@ def main():
 
     if args.workload == "potrf":                      # the dense Cholesky path on its own (the command profiled as r04_*_potrf)
         if rank == 0:
-            print(json.dumps(potrf_bench()))
+            emit(potrf_bench())
         return
     w = workload(args.workload)
-    if args.workload in ("cfg5", "npx69fit"):
-        out = run_fit_bench(args, w, rank, world, local_rank, backend)
+    # Every GPU measurement of this process runs BEFORE any CPU leg (oracle parity checks, the CPU baseline's BLAS-thread sweep):
+    # the run_* functions append their CPU legs to `cpu_legs` and main() runs them last.  (Round 4's driver record read cfg2 at
+    # 1.12 ms per step for 0.86: its sub-result ran after the CPU baseline, whose OpenBLAS workers were still spinning on the CPUs
+    # the launch thread is bound to.)
+    cpu_legs = []
+    if args.workload in ("cfg5", "npx69fit", "aud24"):
+        out = run_fit_bench(args, w, rank, world, local_rank, backend, cpu_legs=cpu_legs)
     else:
-        out = run_step_bench(args, w, rank, world, local_rank, backend)
-    # the driver runs `bench.py --gpus 1` only: carry compact cfg2 / cfg5 results in that line (N=1, a few seconds)
+        out = run_step_bench(args, w, rank, world, local_rank, backend, cpu_legs=cpu_legs)
+    # the driver runs `bench.py --gpus 1` only: carry compact cfg2 / cfg5 / potrf / npx69 / aud24 results with that run (N=1, a few
+    # seconds each); their headline scalars go into `config` of the line, the full dicts into the detail file
+    sub = None
     if (rank == 0 and out is not None and world == 1 and args.workload == "cfg3" and args.trials_per_gpu is None
             and not args.only_value and not args.no_sub_results):
-        out["sub_results"] = sub = sub_results(args, local_rank, backend)
-        # ... and their headline scalars inside `config` (kept by a record that drops nested results)
-        out["config"]["cfg2_trials_per_sec"] = sub.get("cfg2", {}).get("value")
-        out["config"]["cfg2_ms_per_step"] = sub.get("cfg2", {}).get("ms_per_step")
-        out["config"]["cfg5_evals_per_sec"] = sub.get("cfg5", {}).get("value")
-        out["config"]["cfg5_fit_evals_per_sec"] = (sub.get("cfg5", {}).get("fit") or {}).get("evals_per_sec")
-        for k in ("potrf", "npx69"):
-            if isinstance(sub.get(k), dict):
-                for kk, vv in sub[k].get("headline", {}).items():
-                    out["config"]["%s_%s" % (k, kk)] = vv
+        sub = sub_results(args, local_rank, backend, cpu_legs)
+    for leg in cpu_legs:
+        leg()
+    if sub is not None:
+        out["sub_results"] = sub
+        out["config"].update(sub_headlines(sub))
     if rank == 0 and out is not None:
         out["host_affinity"] = ({"bound_to_numa_node": host_numa["node"], "cpus": host_numa["cpus"], "device_pci": host_numa["pci"]}
                                 if host_numa else {"bound_to_numa_node": None, "cpus": len(os.sched_getaffinity(0))})
-        print(json.dumps(out))
+        emit(out)
+
+
+def sub_headlines(sub):
+    """Headline scalars of the sub-results, flat, for `config` of the compact line."""
+    h = {}
+    g = lambda d, *ks: (g(d.get(ks[0]), *ks[1:]) if len(ks) > 1 else d.get(ks[0])) if isinstance(d, dict) else None
+    h["cfg2_trials_per_sec"] = g(sub, "cfg2", "value")
+    h["cfg2_ms_per_step"] = g(sub, "cfg2", "ms_per_step")
+    h["cfg5_evals_per_sec"] = g(sub, "cfg5", "value")
+    h["cfg5_fit_evals_per_sec"] = g(sub, "cfg5", "fit", "evals_per_sec")
+    for k in ("potrf", "npx69", "aud24"):
+        for kk, vv in (g(sub, k, "headline") or {}).items():
+            h["%s_%s" % (k, kk)] = vv
+    return h
+
+
+# ------------------------------------------------------------------------------------------------------- the printed line
+LINE_LIMIT = 4096          # bytes; the driver keeps an 8 KB stdout tail and parses the last line (round 4's 20 KB line was lost)
+DETAIL_FILE = "bench_detail.json"
+
+_TOP_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "setup_steps", "ms_per_step", "higher_is_better", "scaling",
+             "vs_baseline", "dtype", "data", "loglik", "parity_rel_err_loglik_vs_oracle", "parity_rel_err_predict_vs_oracle",
+             "n", "ms", "tflops", "frac_of_fp64_mfma_peak", "evals_per_sec_one_at_a_time_per_gpu", "batched_over_sequential",
+             "only_value")
+_NESTED_KEYS = {
+    "config": ("workload", "n_elec", "n_t", "trials_per_gpu", "total_trials", "parallelism", "restarts_total", "restarts_per_gpu",
+               "lockstep_batch", "class_api_predict_trials_per_sec", "class_api_predict_host_gb_per_sec",
+               "class_api_predict_cached_trials_per_sec", "fenced_loglik_ms", "fenced_predict_ms", "two_steps_in_flight_ms",
+               "cfg2_trials_per_sec", "cfg2_ms_per_step", "cfg5_evals_per_sec", "cfg5_fit_evals_per_sec",
+               "potrf_ms", "potrf_frac", "potrf_trailing_update_frac", "npx69_trials_per_sec", "npx69_ms_per_step",
+               "npx69_fit_evals_per_sec", "npx69_step_over_symmetric_control", "aud24_evals_per_sec", "aud24_fit_evals_per_sec",
+               "aud24_predict_trials_per_sec", "aud24_grad_err_vs_oracle_fd", "fit_evals_per_sec", "fit_restarts_per_sec"),
+    "roofline": ("bound", "unit", "peak", "achieved", "frac", "executed_gflop_per_step", "dominant_kernel_name",
+                 "dominant_kernel_frac", "dominant_kernel_avg_ms", "dominant_kernel_share", "largest_gemm_frac", "all_gemm_frac",
+                 "traffic", "algorithmic_bytes_per_step", "traffic_over_algorithmic", "measured_mfma_f64_peak_tflops",
+                 "reference_algorithm_frac"),
+    "cpu_baseline": ("value", "unit", "kind", "cores", "blas_threads", "host_cpus", "loglik_evals_per_sec", "predict_trials_per_sec",
+                     "reference_layout_loglik_evals_per_sec", "single_thread_trials_per_sec", "sample"),
+    "distributed": ("ranks", "rccl_ranks", "collective_backend", "scaling_efficiency"),
+}
+
+
+def compact_record(full):
+    """The ONE line bench.py prints: scalars only, one level deep inside config / roofline / cpu_baseline / distributed, a fixed set
+    of keys, at most LINE_LIMIT bytes.  Everything else (notes, per-kernel tables, sub-result dicts) lives in DETAIL_FILE."""
+    def scalar(v):
+        return v is None or isinstance(v, (bool, int, float)) or (isinstance(v, str) and len(v) <= 200)
+    rec = {k: full[k] for k in _TOP_KEYS if k in full and scalar(full[k])}
+    for obj, keys in _NESTED_KEYS.items():
+        src = full.get(obj)
+        if isinstance(src, dict):
+            rec[obj] = {k: src[k] for k in keys if k in src and scalar(src[k])}
+        elif obj in full:
+            rec[obj] = None
+    rec["detail"] = DETAIL_FILE
+    line = json.dumps(rec)
+    if len(line) > LINE_LIMIT:
+        raise AssertionError("bench.py: the result line is %d bytes (limit %d): move keys to the detail file" % (len(line), LINE_LIMIT))
+    return line
+
+
+def emit(full):
+    """Write the full result dict to DETAIL_FILE beside the script (and under gpurun_out/ when that exists, so that a gpurun call
+    brings it home), then print the compact line -- the last thing on stdout."""
+    blob = json.dumps(full, indent=1, default=lambda o: float(o) if isinstance(o, np.floating) else str(o))
+    for d in (ROOT, os.path.join(ROOT, "gpurun_out")):
+        if os.path.isdir(d):
+            try:
+                with open(os.path.join(d, DETAIL_FILE), "w") as fh:
+                    fh.write(blob)
+            except OSError as e:
+                print("bench.py: could not write %s: %s" % (os.path.join(d, DETAIL_FILE), e), file=sys.stderr)
+    sys.stdout.flush()
+    print(compact_record(full), flush=True)
 
 
 def potrf_bench(n=12000, reps=3):
@@ -522,68 +599,62 @@ def _quiesce_host(seconds=0.25):
     time.sleep(seconds)
 
 
-def sub_results(args, local_rank, backend):
-    """Compact cfg2 (BASELINE configs[1]) and cfg5 (configs[4], this GPU's share at N=1: all 32 restarts) results with a parity
-    spot check each, measured by the same functions `--workload cfg2` / `--workload cfg5` run."""
+def sub_results(args, local_rank, backend, cpu_legs):
+    """Compact cfg2 (BASELINE configs[1]), cfg5 (configs[4], this GPU's share at N=1: all 32 restarts), dense Cholesky, npx69 (the
+    reference's 2D script shape) and aud24 (its 1D script shape) results, measured by the same functions `--workload <name>` runs.
+    GPU work only: every parity check against the oracle is appended to `cpu_legs` and runs after the last GPU measurement."""
     import copy
     out = {}
     t0 = time.perf_counter()
-    a2 = copy.copy(args)
-    a2.workload, a2.steps, a2.warmup, a2.setup_steps, a2.no_cpu_baseline, a2.trials_per_gpu = "cfg2", 100, 5, 60, True, None
-    try:
-        _quiesce_host()
-        r = run_step_bench(a2, workload("cfg2"), 0, 1, local_rank, backend, compact=True)
-        out["cfg2"] = {k: r[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "config", "parity_rel_err_loglik_vs_oracle",
-                                          "parity_rel_err_predict_vs_oracle", "loglik") if k in r}
-        out["cfg2"]["roofline_frac_step_executed"] = r["roofline"]["frac"]
-        out["cfg2"]["fenced_calls_ms"] = [r["fenced_calls"]["loglik_ms"], r["fenced_calls"]["predict_resident_ms"]]
-    except Exception as e:                                   # a sub-result must never take the headline down
-        out["cfg2"] = {"error": repr(e)}
-    a5 = copy.copy(args)
-    a5.workload, a5.steps, a5.warmup, a5.setup_steps, a5.fit_batch, a5.fit_groups = "cfg5", 20, 3, 10, None, 1
-    try:
-        _quiesce_host()
-        r = run_fit_bench(a5, workload("cfg5"), 0, 1, local_rank, backend, compact=True)
-        out["cfg5"] = {k: r[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "config", "evals_per_sec_one_at_a_time_per_gpu",
-                                          "batched_over_sequential", "fit", "fit_threads_driver", "parity") if k in r}
-    except Exception as e:
-        out["cfg5"] = {"error": repr(e)}
-    try:
-        out["potrf"] = potrf_bench()
-    except Exception as e:
-        out["potrf"] = {"error": repr(e)}
-    # the reference's own 2D workload shape (69 channels without mirror symmetry) beside a point-symmetric control
-    try:
-        res = {}
-        for name in ("npx69", "npx72sym"):
-            a = copy.copy(args)
-            a.workload, a.steps, a.warmup, a.setup_steps, a.no_cpu_baseline, a.trials_per_gpu = name, 200, 5, 150, True, None
-            _quiesce_host()
-            r = run_step_bench(a, workload(name), 0, 1, local_rank, backend, compact=True)
-            res[name] = {k: r[k] for k in ("value", "unit", "ms_per_step", "steps", "config", "parity_rel_err_loglik_vs_oracle",
-                                           "parity_rel_err_predict_vs_oracle", "loglik") if k in r}
-            res[name]["fenced_calls_ms"] = [r["fenced_calls"]["loglik_ms"], r["fenced_calls"]["predict_resident_ms"]]
-            res[name]["loglik_evals_per_sec"] = r["fenced_calls"]["loglik_evals_per_sec_per_gpu"]
-            res[name]["predict_trials_per_sec"] = r["fenced_calls"]["predict_trials_per_sec_per_gpu"]
-        af = copy.copy(args)
-        af.workload, af.steps, af.warmup, af.setup_steps, af.fit_batch, af.fit_groups = "npx69fit", 20, 3, 10, None, 1
-        _quiesce_host()
-        rf = run_fit_bench(af, workload("npx69fit"), 0, 1, local_rank, backend, compact=True)
-        res["npx69"]["fit"] = {k: rf[k] for k in ("value", "unit", "ms_per_step", "evals_per_sec_one_at_a_time_per_gpu", "parity") if k in rf}
-        res["npx69"]["fit"]["truncated_fit"] = {k: v for k, v in rf["fit"].items() if k != "nll_values"}
-        out["npx69"] = res["npx69"]
-        out["npx69"]["symmetric_control_72ch"] = res["npx72sym"]
-        out["npx69"]["step_over_symmetric_control"] = res["npx69"]["ms_per_step"] / res["npx72sym"]["ms_per_step"]
-        out["npx69"]["headline"] = {"trials_per_sec": res["npx69"]["value"], "ms_per_step": res["npx69"]["ms_per_step"],
-                                    "loglik_evals_per_sec": res["npx69"]["loglik_evals_per_sec"],
-                                    "fit_evals_per_sec": rf["value"], "step_over_symmetric_control": out["npx69"]["step_over_symmetric_control"]}
-    except Exception as e:
-        out["npx69"] = {"error": repr(e)}
-    out["seconds_spent"] = time.perf_counter() - t0
+
+    def step(name, steps, warmup, setup):
+        a = copy.copy(args)
+        a.workload, a.steps, a.warmup, a.setup_steps, a.no_cpu_baseline, a.trials_per_gpu = name, steps, warmup, setup, True, None
+        r = run_step_bench(a, workload(name), 0, 1, local_rank, backend, compact=True, cpu_legs=cpu_legs)
+        r["fenced_calls_ms"] = [r["fenced_calls"]["loglik_ms"], r["fenced_calls"]["predict_resident_ms"]]
+        r["loglik_evals_per_sec"] = r["fenced_calls"]["loglik_evals_per_sec_per_gpu"]
+        r["predict_trials_per_sec"] = r["fenced_calls"]["predict_trials_per_sec_per_gpu"]
+        r["roofline_frac_step_executed"] = r["roofline"]["frac"]
+        for k in ("roofline", "pipelining", "fenced_calls", "two_steps_in_flight", "with_decomposition_cache", "class_api_predict_note"):
+            r.pop(k, None)                                         # (the sub-result keeps its scalars; r is what the CPU leg fills in)
+        return r
+
+    def fit(name):
+        a = copy.copy(args)
+        a.workload, a.steps, a.warmup, a.setup_steps, a.fit_batch, a.fit_groups = name, 20, 3, 10, None, 1
+        r = run_fit_bench(a, workload(name), 0, 1, local_rank, backend, compact=True, cpu_legs=cpu_legs)
+        r.pop("roofline", None)
+        if isinstance(r.get("fit"), dict):
+            r["fit"].pop("nll_values", None)
+        return r
+
+    def guarded(key, fn):                                          # a sub-result must never take the headline down
+        try:
+            out[key] = fn()
+        except Exception as e:
+            out[key] = {"error": repr(e)}
+
+    guarded("cfg2", lambda: step("cfg2", 100, 5, 60))
+    guarded("cfg5", lambda: fit("cfg5"))
+    guarded("potrf", potrf_bench)
+
+    def npx():
+        # the reference's own 2D workload shape (69 channels without mirror symmetry) beside a point-symmetric control
+        r69, r72 = step("npx69", 200, 5, 150), step("npx72sym", 200, 5, 150)
+        rf = fit("npx69fit")
+        r69["fit"] = rf
+        r69["symmetric_control_72ch"] = r72
+        r69["step_over_symmetric_control"] = r69["ms_per_step"] / r72["ms_per_step"]
+        r69["headline"] = {"trials_per_sec": r69["value"], "ms_per_step": r69["ms_per_step"],
+                           "loglik_evals_per_sec": r69["loglik_evals_per_sec"], "fit_evals_per_sec": rf["value"],
+                           "step_over_symmetric_control": r69["step_over_symmetric_control"]}
+        return r69
+    guarded("npx69", npx)
+    out["seconds_spent_gpu_legs"] = time.perf_counter() - t0
     return out
 
 
-def run_step_bench(args, w, rank, world, local_rank, backend, compact=False):
+def run_step_bench(args, w, rank, world, local_rank, backend, compact=False, cpu_legs=None):
     import torch
     from gpcsd_amd import _hip
     from gpcsd_amd.dist import TrialSharding
@@ -996,30 +1067,37 @@ def run_step_bench(args, w, rank, world, local_rank, backend, compact=False):
         "distributed": dist_info,
         "roofline": roof,
     }
-    if not args.no_cpu_baseline and world == 1:      # the CPU baseline is reported at N=1 only
-        cb, ll_cpu, pred_cpu = cpu_baseline(w, m, lfp, args.cpu_budget_s)
-        out["cpu_baseline"] = cb
-        cb["reference_layout_loglik_evals_per_sec"] = cb["faithful_layout"]["loglik_evals_per_sec"]
-        cb["single_thread_trials_per_sec"] = cb["single_thread"]["value"]
-        # parity spot check beside the numbers: the GPU step's own outputs vs the oracle on the same trials
-        out["parity_rel_err_loglik_vs_oracle"] = abs(float(ll) - ll_cpu) / abs(ll_cpu)
+    out["config"]["fenced_loglik_ms"], out["config"]["fenced_predict_ms"] = 1e3 * t_ll, 1e3 * t_pr
+    out["config"]["two_steps_in_flight_ms"] = deep_ms
+    want_baseline = not args.no_cpu_baseline and world == 1       # the CPU baseline is reported at N=1 only
+    if want_baseline or compact:
+        # the GPU half of the parity spot check now (the step's own prediction, fetched); the oracle half is a CPU leg
         hp0, _k = m._hparams(0.0)
         ctx.predict_resident(hp0, z, w["t"], _hip.PRED_CSD, want_lists=True)
         got = ctx.fetch("pred_out_csd", (z.shape[0], w["nt"], R_local))
-        out["parity_rel_err_predict_vs_oracle"] = float(np.max(np.abs(got - pred_cpu)) / np.max(np.abs(pred_cpu)))
-    elif compact:                                    # sub-result of the default line: parity spot check without the timing legs
-        O, geom, hpo, hpo0 = oracle_setup(w, m)
-        ll_cpu = O.loglik(geom, hpo, lfp)
-        pred_cpu = O.predict(geom, hpo0, lfp, z, w["t"], type="csd")["csd"]
-        out["parity_rel_err_loglik_vs_oracle"] = abs(float(ll) - ll_cpu) / abs(ll_cpu)
-        hp0, _k = m._hparams(0.0)
-        ctx.predict_resident(hp0, z, w["t"], _hip.PRED_CSD, want_lists=True)
-        got = ctx.fetch("pred_out_csd", (z.shape[0], w["nt"], R_local))
-        out["parity_rel_err_predict_vs_oracle"] = float(np.max(np.abs(got - pred_cpu)) / np.max(np.abs(pred_cpu)))
+        ll_gpu = float(ll)
+
+        def cpu_leg():
+            if want_baseline:
+                cb, ll_cpu, pred_cpu = cpu_baseline(w, m, lfp, args.cpu_budget_s)
+                out["cpu_baseline"] = cb
+                cb["reference_layout_loglik_evals_per_sec"] = cb["faithful_layout"]["loglik_evals_per_sec"]
+                cb["single_thread_trials_per_sec"] = cb["single_thread"]["value"]
+            else:                                    # sub-result of the default line: parity spot check without the timing legs
+                O, geom, hpo, hpo0 = oracle_setup(w, m)
+                ll_cpu = O.loglik(geom, hpo, lfp)
+                pred_cpu = O.predict(geom, hpo0, lfp, z, w["t"], type="csd")["csd"]
+            # parity spot check beside the numbers: the GPU step's own outputs vs the oracle on the same trials
+            out["parity_rel_err_loglik_vs_oracle"] = abs(ll_gpu - ll_cpu) / abs(ll_cpu)
+            out["parity_rel_err_predict_vs_oracle"] = float(np.max(np.abs(got - pred_cpu)) / np.max(np.abs(pred_cpu)))
+        if cpu_legs is None:
+            cpu_leg()
+        else:
+            cpu_legs.append(cpu_leg)
     return out
 
 
-def run_fit_bench(args, w, rank, world, local_rank, backend, compact=False):
+def run_fit_bench(args, w, rank, world, local_rank, backend, compact=False, cpu_legs=None):
     """BASELINE cfg5: GPCSD1D hyper-parameter fit, 24 x 500 x 200 trials resident on every GPU, 32 restarts sharded over the
     GPUs.  The unit of work is one objective + analytic-gradient evaluation of one restart (what L-BFGS-B asks for); a step
     evaluates one lock-step batch of B restarts in one chain of launches (gpcsd_loglik_grad_batch).  Reported: evaluations/s
@@ -1151,43 +1229,51 @@ def run_fit_bench(args, w, rank, world, local_rank, backend, compact=False):
     n_eval = G * B * world * args.steps
     # parity spot check beside the numbers: the HIP objective and analytic gradient at restart 0's start against the oracle
     # objective and its central differences (checker code; 2 p + 1 oracle evaluations)
-    parity = None
+    cpu_leg = None
     if world == 1:
-        O, geom, hpo, _hpo0 = oracle_setup(w, m)
         kinds = [k for k, _, _ in w["temporal"]]
-
         snames = ("ell",) if w["dim"] == 1 else ("ell1", "ell2")
-
-        def cpu_obj(tp):
-            hh = O.hparams_from_tparams(tp, w["dim"], kinds, 1, eps=w["eps"], jitter=m.JITTER)
-            lp = m.R["prior"].lpdf(hh["R"]) + m.sig2n["prior"].lpdf(hh["sig2n"])
-            for nm, v in zip(snames, hh["ell_s"]):
-                lp += m.spatial_cov.params[nm]["prior"].lpdf(v)
-            for tc, (_, ell, s2) in zip(m.temporal_cov_list, hh["temporal"]):
-                lp += tc.params["ell"]["prior"].lpdf(ell) + tc.params["sigma2"]["prior"].lpdf(s2)
-            return -(O.loglik(geom, hh, lfp) + lp)
+        n_sig = int(np.size(m.sig2n["value"]))
         # at the hyper-parameters the data were drawn from (a well-scaled point: central differences of a prior-drawn start,
         # where the objective is ~1e7 and dominated by one term, only measure the differences' own rounding)
-        m.R["value"], m.sig2n["value"] = w["R"], w["sig2n"]
+        m.R["value"] = w["R"]
+        m.sig2n["value"] = w["sig2n"] if n_sig == 1 else np.array(w["sig2n_list"], dtype=float)
         for nm, v in zip(snames, w["ell_s"]):
             m.spatial_cov.params[nm]["value"] = v
         for tc, (_, ell, _s2), s2 in zip(m.temporal_cov_list, w["temporal"], data_sigma2):
             tc.params["ell"]["value"], tc.params["sigma2"]["value"] = ell, s2
         tp0 = m._current_tparams()
-        f_gpu, g_gpu = m._objective_and_grad(tp0, False)
-        f_cpu = cpu_obj(tp0)
-        g_cpu = np.zeros_like(tp0)
-        for i in range(tp0.size):
-            e = np.zeros_like(tp0)
-            e[i] = 1e-5
-            g_cpu[i] = (cpu_obj(tp0 + e) - cpu_obj(tp0 - e)) / 2e-5
-        parity = {"objective_rel_err_vs_oracle": abs(f_gpu - f_cpu) / abs(f_cpu),
-                  "gradient_max_err_over_max_component_vs_oracle_fd": float(np.max(np.abs(g_gpu - g_cpu)) / np.max(np.abs(g_cpu)))}
+        f_gpu, g_gpu = m._objective_and_grad(tp0, False)          # the GPU half now; the oracle half is a CPU leg
+
+        def cpu_leg():
+            O, geom, hpo, _hpo0 = oracle_setup(w, m)
+
+            def cpu_obj(tp):
+                hh = O.hparams_from_tparams(tp, w["dim"], kinds, n_sig, eps=w["eps"], jitter=m.JITTER)
+                lp = m.R["prior"].lpdf(hh["R"])
+                if n_sig == 1:
+                    lp += m.sig2n["prior"].lpdf(hh["sig2n"])
+                else:
+                    lp += sum(pr.lpdf(v) for pr, v in zip(m.sig2n["prior"], np.atleast_1d(hh["sig2n"])))
+                for nm, v in zip(snames, hh["ell_s"]):
+                    lp += m.spatial_cov.params[nm]["prior"].lpdf(v)
+                for tc, (_, ell, s2) in zip(m.temporal_cov_list, hh["temporal"]):
+                    lp += tc.params["ell"]["prior"].lpdf(ell) + tc.params["sigma2"]["prior"].lpdf(s2)
+                return -(O.loglik(geom, hh, lfp) + lp)
+            f_cpu = cpu_obj(tp0)
+            g_cpu = np.zeros_like(tp0)
+            for i in range(tp0.size):
+                e = np.zeros_like(tp0)
+                e[i] = 1e-5
+                g_cpu[i] = (cpu_obj(tp0 + e) - cpu_obj(tp0 - e)) / 2e-5
+            res["parity"] = {"objective_rel_err_vs_oracle": abs(f_gpu - f_cpu) / abs(f_cpu),
+                             "gradient_max_err_over_max_component_vs_oracle_fd":
+                                 float(np.max(np.abs(g_gpu - g_cpu)) / np.max(np.abs(g_cpu)))}
     gemm_flops = sum(v["flops"] for k, v in prof.items() if k.startswith("gemm_")) / 3.0
     tail = prof.get("sytrd_rtail")
     eig_flops = 4.0 * tail["flops"] / 3.0 if tail else 0.0           # tridiagonalisation + 3x for the back-transformation
     step_s = elapsed / args.steps
-    return {
+    res = {
         "metric": "gpcsd_fit_loglik_grad_evals_per_sec",
         "value": n_eval / elapsed, "unit": "evals/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "setup_steps": max(3, min(args.setup_steps, 20)),
@@ -1199,7 +1285,7 @@ def run_fit_bench(args, w, rank, world, local_rank, backend, compact=False):
         "evals_per_sec_one_at_a_time_per_gpu": 1.0 / seq_s,
         "evals_per_sec_one_group_per_gpu": B / one_group_s,
         "batched_over_sequential": (B / one_group_s) / (1.0 / seq_s),
-        "parity": parity,
+        "parity": None,
         "all_groups_over_sequential": (G * B / step_s) / (1.0 / seq_s),
         "fit": dict(fit_main, evals_per_sec_through_scipy=fit_main["evals_per_sec"],
                     real_fit_over_synthetic_evals_per_sec=fit_main["evals_per_sec"] / (n_eval / elapsed),
@@ -1217,6 +1303,13 @@ def run_fit_bench(args, w, rank, world, local_rank, backend, compact=False):
                          "share_of_step_wall": tail["ms"] / 3.0 / (1e3 * step_s)},
                      "per_kernel_ms_per_step": {k: v["ms"] / 3.0 for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])[:16]}},
     }
+    res["config"]["fit_evals_per_sec"], res["config"]["fit_restarts_per_sec"] = fit_main["evals_per_sec"], fit_main["restarts_per_sec"]
+    if cpu_leg is not None:
+        if cpu_legs is None:
+            cpu_leg()
+        else:
+            cpu_legs.append(cpu_leg)
+    return res
 
 
 if __name__ == "__main__":

@@ -833,7 +833,13 @@ def _run(cmd, env, timeout=600):
     assert r.returncode == 0, "command failed:\n%s\n%s" % (r.stdout[-3000:], r.stderr[-3000:])
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert lines, r.stdout[-2000:]
-    return json.loads(lines[-1])
+    # bench.py prints ONE compact line (<= 4 KB, what the driver parses) and writes the full result dict beside itself
+    assert len(lines[-1]) <= 4096 and r.stdout.rstrip().endswith(lines[-1])
+    rec = json.loads(lines[-1])
+    with open(os.path.join(ROOT, rec["detail"])) as fh:
+        full = json.load(fh)
+    assert all(full[k] == rec[k] for k in ("metric", "value", "ms_per_step", "n_gpus", "steps"))
+    return full
 
 
 @pytest.mark.timeout(900)
