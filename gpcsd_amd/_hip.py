@@ -153,6 +153,7 @@ SIGNATURES = {
     "gpcsd_kphi_2d": (_I, [_P, _DP, _I, _DP, _DP, _I, _DP, _DP, _I, _D, _D, _D, _D, _DP, _I, _DP]),
     "gpcsd_kphig_2d": (_I, [_P, _DP, _I, _DP, _DP, _I, _DP, _DP, _I, _DP, _I, _D, _D, _D, _D, _DP]),
     "gpcsd_eigh": (_I, [_P, _DP, _I, _DP, _DP]),
+    "gpcsd_eigh_psd": (_I, [_P, _DP, _I, _DP, _DP]),
     "gpcsd_eigh_batch": (_I, [_P, _DP, _I, _I, _DP, _DP, ctypes.POINTER(_I)]),
     "gpcsd_eig_D": (_I, [_P, _DP, _I, _DP, _I, _DP, _I, _DP, _DP, _DP]),
     "gpcsd_whitened_quad": (_I, [_P, _DP, _I, _DP, _I, _DP, _DP, _I, _DP]),
@@ -177,6 +178,8 @@ SIGNATURES = {
     "gpcsd_set_gram_precision": (_I, [_P, _I]),
     "gpcsd_fold_gemm": (_I, [_P, _I, ctypes.POINTER(_L)]),
     "gpcsd_ll_tridiag": (_I, [_P, _I, ctypes.POINTER(_L)]),
+    "gpcsd_tail_early_exit": (_I, [_P, _I, ctypes.POINTER(_I)]),
+    "gpcsd_debug_fault_stage2": (_I, [_P, _I]),
     "gpcsd_decomposition_cache": (_I, [_P, _I, ctypes.POINTER(_L)]),
     "gpcsd_shard_block": (_I, [_I, _I, _I, ctypes.POINTER(_I), ctypes.POINTER(_I)]),
     "gpcsd_combine_loglik": (_I, [_I, _D, _D, _DP]),
@@ -543,13 +546,16 @@ class Context:
                                              float(ell2), _ptr(out)))
         return out
 
-    def eigh(self, A):
+    def eigh(self, A, psd=False):
+        """numpy.linalg.eigh; psd=True: the caller vouches that A is positive semi-definite (a Gram matrix), which lets orders
+        <= 192 take the tridiagonalisation's rank-revealing early exit (tail_early_exit)."""
         A = _arr(A)
         n = A.shape[0]
         if A.shape != (n, n):
             raise ValueError("eigh needs a square matrix")
         w, V = np.empty(n), np.empty((n, n))
-        self._check(self._lib.gpcsd_eigh(self._h, _ptr(A), n, _ptr(w), _ptr(V)))
+        fn = self._lib.gpcsd_eigh_psd if psd else self._lib.gpcsd_eigh
+        self._check(fn(self._h, _ptr(A), n, _ptr(w), _ptr(V)))
         return w, V
 
     def eigh_batch(self, A):
@@ -758,6 +764,17 @@ class Context:
         n = _L(0)
         self._check(self._lib.gpcsd_ll_tridiag(self._h, -1 if mode is None else int(mode), ctypes.byref(n)))
         return int(n.value)
+
+    def tail_early_exit(self, on=None):
+        """Switch (True/False) or query (None) the rank-revealing early exit of the tridiagonalisation on positive semi-definite
+        Gram matrices; returns the setting before the call."""
+        prev = _I(0)
+        self._check(self._lib.gpcsd_tail_early_exit(self._h, -1 if on is None else int(bool(on)), ctypes.byref(prev)))
+        return bool(prev.value)
+
+    def debug_fault_stage2(self, on):
+        """Test aid: the divide & conquer stage of a staged temporal chain reports a numerical failure (late status words)."""
+        self._check(self._lib.gpcsd_debug_fault_stage2(self._h, int(bool(on))))
 
     def decomposition_cache(self, on=None):
         """Switch (True/False) or query (None) the reuse of an unchanged side's eigendecomposition between consecutive

@@ -38,7 +38,6 @@ static void drain_after_failure(gpcsd_ctx *c) {
     if (c->stream4) (void)hipStreamSynchronize(c->stream4);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     c->status_zeroed = false;
-    c->late_dirty = false;                      // (status_zeroed = false: the next front half clears every word)
     c->async_pending = false;                   // everything is drained: no deferred status
     // (an outstanding asynchronous loglik stays collectable: its result has landed by now)
     c->decomp_gen[0] = c->decomp_gen[1] = -1;   // whatever the failed call left behind is not reused
@@ -401,7 +400,6 @@ struct EigState {
     // stage-1 outputs are still those of this temporal problem), replica `tri_rep` of the temporal classes is this call's
     bool tri = false, wait_q = false;
     int tri_rep = 0, tri_count = 1;
-    bool late_stages = false;      // stages 2 and 4 of a staged temporal chain were queued although this call does not wait for them
 };
 
 // The prediction in the basis U (x) Q as well (k_tridiag_solve instead of (W V) / D): with it NO consumer of a staged temporal
@@ -443,14 +441,14 @@ static void staged_chain_guard(gpcsd_ctx *c, hipStream_t s2) {
     }
 }
 
-// A staged temporal chain is about to start on s2: the late status words (stages 2 and 4 of its predecessor on this stream,
-// gpcsd_ctx::STATUS_LATE) are cleared there, behind that predecessor -- unless asynchronous work is outstanding, whose status
-// stays sticky until a synchronising call has collected it.  A synchronous log-likelihood in the tridiagonal form returns while
-// those stages are still running: whatever they report concerns results nobody has read, and must not be charged to the next
-// call.
+// A staged temporal chain WITH stages 2 and 4 (a consumer in the eigenvector form) is about to start on s2: the late status words
+// those stages report into (gpcsd_ctx::STATUS_LATE) are cleared there, behind the predecessor on that stream -- unless
+// asynchronous work is outstanding, whose status stays sticky until a synchronising call has collected it.  A chain all of whose
+// consumers take the tridiagonal form queues no such stages (and clears nothing): late words are only ever written by the
+// paired call with an eigenvector-form prediction or by a non-tridiagonal consumer, and are collected by the call that joins
+// that chain.
 static void clear_late_status(gpcsd_ctx *c, int *status, hipStream_t s2, bool staged) {
-    if (c->async_pending || !(staged || c->late_dirty)) return;
-    c->late_dirty = false;
+    if (c->async_pending || !staged) return;
     GP_HIP(hipMemsetAsync(status + gpcsd_ctx::STATUS_LATE, 0, (gpcsd_ctx::STATUS_N - gpcsd_ctx::STATUS_LATE) * sizeof(int), s2));
 }
 
@@ -827,9 +825,9 @@ static int fold_status(const int *st, bool late) {
 }
 
 // End of a fused call: one copy brings back the leading `nscal` scalars and the status words, then the stream is drained.
-// A log-likelihood in the tridiagonal form (e.tri) has not waited for stages 2 and 4 of its temporal chain and does not use
-// their results: it neither reads nor clears their status words (see gpcsd_ctx::STATUS_LATE), and stream2 may still be running
-// them when it returns -- every later use of that chain's outputs is ordered behind ev_join as usual.
+// A log-likelihood in the tridiagonal form (e.tri) has no stages 2 and 4 of its own (front_half does not queue them for such a
+// consumer): it neither reads nor clears the late status words (gpcsd_ctx::STATUS_LATE), which may belong to an earlier paired
+// call's eigenvector-form prediction that nobody has joined yet.
 int finish_call(gpcsd_ctx *c, const EigState &e, double *scal_out, int nscal) {
     double *host = c->h_result;                        // pinned: a true asynchronous copy, no staging
     const bool late = !e.tri;
@@ -839,7 +837,6 @@ int finish_call(gpcsd_ctx *c, const EigState &e, double *scal_out, int nscal) {
     GP_HIP(hipMemsetAsync(e.status, 0, (late ? gpcsd_ctx::STATUS_N : gpcsd_ctx::STATUS_LATE) * sizeof(int), c->stream));
     c->sync();
     c->status_zeroed = true;
-    c->late_dirty = !late && e.late_stages;
     c->async_pending = false;              // whatever an asynchronous predict left in the status words has been collected now
     if (c->prof_mode == 1) c->prof_collect();
     for (int i = 0; i < nscal; ++i) scal_out[i] = host[i];
@@ -898,6 +895,7 @@ extern "C" int gpcsd_ctx_create(int device, gpcsd_ctx **out) {
         c->device = device;
         c->timeline_on = getenv("GPCSD_TIMELINE") && getenv("GPCSD_TIMELINE")[0] == '1';
         if (const char *ev = getenv("GPCSD_LL_TRIDIAG")) c->ll_tridiag_mode = ev[0] == '0' ? 0 : ev[0] == '1' ? 1 : 2;
+        if (const char *ev = getenv("GPCSD_TAIL_EARLY_EXIT")) c->tail_early_exit = ev[0] != '0';
         GP_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
         // The two chains are the critical path and made of small launches; when they run beside another call's GEMM tail
         // (thousands of workgroups) each of those launches would otherwise queue behind the tiles: high priority.

@@ -711,7 +711,6 @@ static void front_half_pair(gpcsd_ctx *c, const gpcsd_hparams *const hp[2], cons
             e.tri = e.wait_q = true;
             e.tri_rep = bt;
             e.tri_count = nT;
-            e.late_stages = !pred_tri;
         }
         FoldMode &fm = out.fm[b];
         fm = fold_mode(c, hp[b], fold_s);               // replica 0 of the generations just started ...

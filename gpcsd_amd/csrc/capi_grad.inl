@@ -89,11 +89,17 @@ static int loglik_grad_impl(gpcsd_ctx *c, const gpcsd_hparams *hps, int B, doubl
     // the temporal chain's input as one launch straight from t and the hyper-parameter table (folded, scaled blocks in the class
     // arenas: capi.hip temporal_fill) instead of Gram -> fold -> absmax -> scale, as in the fused calls
     const bool tfill = temporal_fill_applies(c, sym_t, nt, host_kt);
+    // what the fills may announce as positive semi-definite (EigArenaView::psd): the signs are the host's to check
+    bool variances_nonneg = true, jitters_nonneg = true;
+    for (int b = 0; b < B; ++b) {
+        jitters_nonneg = jitters_nonneg && hps[b].jitter >= 0.0;
+        for (int cc = 0; cc < hps[b].n_temporal; ++cc) variances_nonneg = variances_nonneg && hps[b].sigma2_t[cc] >= 0.0;
+    }
     staged_chain_guard(c, s2);            // (a queued staged chain's side-stream readers of the class arenas)
     if (tfill) {
         const char *const *tg = eigh_fold_tags(c, 1);
         const EigArenaView as = eigh_arena_view(c, tg[0], sym_t->ns, B), aa = eigh_arena_view(c, tg[1], sym_t->na, B);
-        k_temporal_fold_fill_tab(c, tab, B, t, nt, *sym_t, as, aa, st + B, 1, s2);
+        k_temporal_fold_fill_tab(c, tab, B, t, nt, *sym_t, as, aa, st + B, 1, s2, variances_nonneg);
     } else if (host_kt) {
         GP_HIP(hipMemcpyAsync(Kt, c->host_kt.data(), (size_t)ntt * sizeof(double), hipMemcpyHostToDevice, s2));
     } else {
@@ -132,7 +138,7 @@ static int loglik_grad_impl(gpcsd_ctx *c, const gpcsd_hparams *hps, int B, doubl
         if (sfill) {
             const char *const *tg = eigh_fold_tags(c, 0);
             const EigArenaView as = eigh_arena_view(c, tg[0], sym_s->ns, B), aa = eigh_arena_view(c, tg[1], sym_s->na, B);
-            k_psd_fold_fill(c, Ks, nx, nxx, B, nullptr, *sym_s, as, aa, st, 1, s, tab);
+            k_psd_fold_fill(c, Ks, nx, nxx, B, nullptr, *sym_s, as, aa, st, 1, s, tab, jitters_nonneg);
         } else {
             k_add_diag(c, Ks, nx, 0.0, s, tab, B, nxx);
         }

@@ -193,6 +193,18 @@ extern "C" int gpcsd_eigh(gpcsd_ctx *c, const double *A, int n, double *evals, d
     GP_API_END(c)
 }
 
+// numpy.linalg.eigh (utility_functions.py:58-59) of a matrix the CALLER vouches is positive semi-definite (a Gram matrix): the one
+// way a caller's matrix may take the tridiagonalisation's rank-revealing early exit (gpcsd_tail_early_exit; n <= 192 only).
+extern "C" int gpcsd_eigh_psd(gpcsd_ctx *c, const double *A, int n, double *evals, double *evecs) {
+    if (!c) return -3;
+    struct Claim {
+        gpcsd_ctx *c;
+        explicit Claim(gpcsd_ctx *cc) : c(cc) { c->claim_psd = true; }
+        ~Claim() { c->claim_psd = false; }
+    } claim(c);
+    return gpcsd_eigh(c, A, n, evals, evecs);
+}
+
 // `count` independent symmetric matrices of the same order in ONE chain of launches (the replicated-class machinery behind
 // gpcsd_loglik_grad_batch, exposed for tests): A (count, n, n) -> evals (count, n), evecs (count, n, n), status (count):
 // 0 ok, > 0 numerical failure of that matrix alone.
@@ -545,6 +557,35 @@ extern "C" int gpcsd_ll_tridiag(gpcsd_ctx *c, int on, long *calls) {
         c->q_gen = -1;
     }
     if (calls) *calls = c->ll_tridiag_calls;
+    return 0;
+    GP_API_END(c)
+}
+
+extern "C" int gpcsd_tail_early_exit(gpcsd_ctx *c, int on, int *previous) {
+    GP_API_BEGIN(c)
+    if (previous) *previous = c->tail_early_exit ? 1 : 0;
+    if (on >= 0 && c->tail_early_exit != (on != 0)) {
+        if (int rc = drain_async(c)) return rc;            // start from an idle context
+        GP_HIP(hipStreamSynchronize(c->stream2));
+        GP_HIP(hipStreamSynchronize(c->stream3));
+        GP_HIP(hipStreamSynchronize(c->stream4));
+        c->tail_early_exit = on != 0;
+        ++c->alloc_epoch;                                  // captured chains carry the flag in their kernel arguments: retire them
+        c->decomp_gen[0] = c->decomp_gen[1] = -1;          // (and nothing decomposed under the other setting is reused)
+        c->q_gen = -1;
+    }
+    return 0;
+    GP_API_END(c)
+}
+
+extern "C" int gpcsd_debug_fault_stage2(gpcsd_ctx *c, int on) {
+    GP_API_BEGIN(c)
+    if (int rc = drain_async(c)) return rc;
+    GP_HIP(hipStreamSynchronize(c->stream2));
+    GP_HIP(hipStreamSynchronize(c->stream4));
+    c->fault_stage2 = on != 0;
+    ++c->alloc_epoch;                                      // (a captured stage 2 holds or lacks the injected launch)
+    c->decomp_gen[0] = c->decomp_gen[1] = -1;
     return 0;
     GP_API_END(c)
 }

@@ -163,7 +163,14 @@ struct gpcsd_ctx {
     gpcsd::SymDev sym_z;
     int lfp_fold_sig = 0;                   // bit k set: the folded copy of the data for FoldMode::sig() == k is current (0: none is)
     bool status_zeroed = false;             // the fused calls' status words were cleared at the end of the previous call
-    bool late_dirty = false;                // ... except the late words: a tridiagonal-form log-likelihood returned under its chain's stages 2 / 4
+    // Which eigensolver class arenas (by tag) currently hold a POSITIVE SEMI-DEFINITE matrix: set by the fills that know it (the
+    // Gram fills k_psd_fold_fill / k_temporal_fold_fill write true through EigArenaView::psd), cleared whenever the library's own
+    // scaling pass fills the arena from a caller's matrix.  Only such a class may take the tridiagonalisation's rank-revealing early
+    // exit (sytrd_regtail.hpp): the claim comes from the producer of the matrix, not from how the arena happened to be filled.
+    std::map<std::string, bool> arena_psd;
+    bool claim_psd = false;                 // gpcsd_eigh_psd() in progress: the caller vouches that its matrix is positive semi-definite
+    bool tail_early_exit = true;            // gpcsd_tail_early_exit() / GPCSD_TAIL_EARLY_EXIT=0: PSD classes may stop the tridiagonalisation early
+    bool fault_stage2 = false;              // gpcsd_debug_fault_stage2(): test aid, the staged divide & conquer reports status 3
     bool gram_fp32 = false;                 // gpcsd_set_gram_precision(): Gram builders evaluate in float (cfg5 variant)
     bool fold_gemm_on = true;               // gpcsd_fold_gemm()
     int ll_tridiag_mode = 2;                // gpcsd_ll_tridiag(): log-likelihood in the basis U (x) Q -- 0 off, 1 on, 2 by size (capi.hip)

@@ -234,7 +234,7 @@ __global__ __launch_bounds__(256) void psd_fold_fill_kernel(PsdFoldFillArgs g) {
 
 void k_psd_fold_fill(gpcsd_ctx *c, const double *K, int n, long sK, int nrep, const double *shift, const SymDev &sy,
                      const EigArenaView &as, const EigArenaView &aa, int *status, int status_stride, hipStream_t s,
-                     const HpDev *tab) {
+                     const HpDev *tab, bool tab_shifts_nonneg) {
     GP_REQUIRE(nrep >= 1 && (tab || nrep <= 2), -3, "psd fold fill: %d replicas (1 or 2 without a hyper-parameter table)", nrep);
     GP_REQUIRE(sy.ns > 0 && sy.ns + sy.na == n, -3, "psd fold fill: the symmetry does not cover the %d points", n);
     PsdFoldFillArgs g{};
@@ -247,6 +247,11 @@ void k_psd_fold_fill(gpcsd_ctx *c, const double *K, int n, long sK, int nrep, co
     g.status = status;
     g.status_stride = status_stride;
     g.elem_blocks = ceil_div((long)sy.ns * sy.ns, 256);
+    // K is positive semi-definite by this routine's contract and every shift is checked (host-side ones here, a table's by the
+    // callers' hyper-parameter validation): the two arenas are announced as PSD -- only then may the tail stop early
+    bool nonneg = tab ? tab_shifts_nonneg : true;
+    for (int r = 0; r < nrep && r < 2 && !tab; ++r) nonneg = nonneg && g.shift[r] >= 0.0;
+    *as.psd = *aa.psd = nonneg;
     ProfScope ps(c, "psd_fold_fill", 0.0, s);
     hipLaunchKernelGGL(psd_fold_fill_kernel, dim3(g.elem_blocks + 48, nrep), dim3(256), 0, s, g);
     GP_HIP(hipGetLastError());
@@ -420,12 +425,21 @@ void eigh_pair_device(gpcsd_ctx *c, double *A0, int n0, double *w0, double *Z0, 
         return;
     }
     // (the generation of each slot picks the fold-order output buffers, which are not among the arguments)
-    char key[352];
-    snprintf(key, sizeof(key), "eigh|%p|%d|%p|%p|%p|%d|%p|%d|%p|%p|%p|%d|%p|%p|%d|%d|%d|%d%d|%d|%d|%d|%d", (void *)A0, n0, (void *)w0, (void *)Z0,
+    // (... and SytrdProb::psd of the prefilled classes, a kernel argument: what their fills announced, and the context's switch)
+    int psd_sig = (c->tail_early_exit ? 16 : 0) | (c->claim_psd ? 32 : 0);
+    for (int p = 0; p < 2; ++p) {
+        const char *const *tg = eigh_fold_tags(c, p);
+        for (int h = 0; h < 2; ++h) {
+            const auto it = c->arena_psd.find(tg[h]);
+            if (((prefolded_mask >> p) & 1) && it != c->arena_psd.end() && it->second) psd_sig |= 1 << (2 * p + h);
+        }
+    }
+    char key[368];
+    snprintf(key, sizeof(key), "eigh|%p|%d|%p|%p|%p|%d|%p|%d|%p|%p|%p|%d|%p|%p|%d|%d|%d|%d%d|%d|%d|%d|%d|%d", (void *)A0, n0, (void *)w0, (void *)Z0,
              (void *)(sym0 ? sym0->rep_i : nullptr), sym0 ? sym0->ns : 0, (void *)A1, n1, (void *)w1, (void *)Z1,
              (void *)(sym1 ? sym1->rep_i : nullptr), sym1 ? sym1->ns : 0, (void *)d_status, (void *)s, (int)need_merged, count,
              status_stride, c->par[0], c->par[1], count1, prefolded_mask, (int)(c->prof_mode == 3),   // (mode 3 graphs carry clock stamps)
-             stage + 8 * (c->tgen & 1));                                              // (the generation picks the temporal arenas)
+             stage + 8 * (c->tgen & 1), psd_sig);                                     // (the generation picks the temporal arenas)
     gpcsd_ctx::GraphSlot &g = c->graphs[key];
     if (g.exec && g.epoch == c->alloc_epoch) {
         GP_HIP(hipGraphLaunch(g.exec, s));

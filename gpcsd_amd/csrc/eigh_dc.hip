@@ -286,10 +286,6 @@ static void sytrd_batch_launch(gpcsd_ctx *c, const SytrdBatch &b, int nclass, in
         if (!rt_attr_set) {
             GP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(sytrd_rtail_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)rt_strip_bytes(RT_TMAX)));
-            if (getenv("GPCSD_TAIL_EARLY_EXIT") && getenv("GPCSD_TAIL_EARLY_EXIT")[0] == '0') {     // every column step (A/B, cross-check)
-                const int off = 0;
-                GP_HIP(hipMemcpyToSymbol(HIP_SYMBOL(rt_early_exit_enabled), &off, sizeof(int)));
-            }
             rt_attr_set = true;
         }
         // profiled on its own: this single launch (one workgroup per problem) is the largest share of the GPU time of an
@@ -432,7 +428,7 @@ EigArenaView eigh_arena_view(gpcsd_ctx *c, const char *tag, int n, int count) {
     SytrdProb sp{};
     double *amax = nullptr, *wyT = nullptr;
     layout_arena(c, tag, n, count, sp, amax, wyT);
-    return EigArenaView{sp.A0, sp.V, sp.tau, amax, sp.blk, sp.d, sp.e};
+    return EigArenaView{sp.A0, sp.V, sp.tau, amax, sp.blk, sp.d, sp.e, &c->arena_psd[tag]};
 }
 
 double *eigh_Q_view(gpcsd_ctx *c, const char *tag, int n, int count) {
@@ -447,7 +443,11 @@ static void prep_problem(gpcsd_ctx *c, EigProb &p, hipStream_t s) {
         p.sp.k_tail = std::max(0, n - sy_regtail_rows());
     }
     layout_arena(c, p.tag, n, p.count, p.sp, p.amax, p.wyT);
-    p.sp.psd = p.prefilled ? 1 : 0;     // (prefilled classes come from the fused calls' fold fills: Ks and Kt of the model)
+    // positive semi-definite only on the word of whoever filled the arena (EigArenaView::psd); the library's own scaling pass
+    // copies a caller's matrix, about which nothing is known
+    bool &psd = c->arena_psd[p.tag];
+    if (!p.prefilled) psd = c->claim_psd;         // (... unless the caller vouches for it: gpcsd_eigh_psd)
+    p.sp.psd = (psd && c->tail_early_exit) ? 1 : 0;
     (void)s;
 }
 
@@ -580,15 +580,11 @@ void sytrd_device(gpcsd_ctx *c, double *A, int n, double *d, double *e, double *
     GP_HIP(hipGetLastError());
 }
 
-// Test aid (GPCSD_FAULT_STAGE2=1 in the environment, read once): the divide & conquer stage of a STAGED solve reports failure 3
-// for every replica -- which call surfaces a failure of a stage that a tridiagonal-form log-likelihood does not wait for
-// (tests/test_hip_fullsize.py::test_late_stage_failure_is_reported_by_the_call_that_joins_the_chain).
+// Test aid (gpcsd_debug_fault_stage2(ctx, 1): an explicit call on the context, never the environment): the divide & conquer stage
+// of a STAGED solve reports failure 3 for every replica -- which call surfaces a failure of a stage that a tridiagonal-form
+// log-likelihood does not wait for (tests/test_hip_fullsize.py::test_late_stage_failure_is_reported_by_the_call_that_joins_the_chain).
 __global__ void fault_status_kernel(int *status, int stride, int count) {
     for (int r = threadIdx.x; r < count; r += blockDim.x) atomicMax(status + (long)r * stride, 3);
-}
-static bool fault_stage2() {
-    static const bool on = getenv("GPCSD_FAULT_STAGE2") && getenv("GPCSD_FAULT_STAGE2")[0] == '1';
-    return on;
 }
 
 void eigh_large_batch(gpcsd_ctx *c, EigProb *probs, int nclass, int *d_status, int status_stride, hipStream_t s, int stage = 0) {
@@ -653,7 +649,7 @@ void eigh_large_batch(gpcsd_ctx *c, EigProb *probs, int nclass, int *d_status, i
         // (stage 2: the T factors were formed by stage 1, the leaf launch carries leaves only)
         stedc_batch_device(c, sp, nclass, d_status, status_stride, s, (prep_done && stage != 2) ? &wb : nullptr);
     }
-    if (stage == 2 && fault_stage2() && d_status) {
+    if (stage == 2 && c->fault_stage2 && d_status) {
         int nrep = 1;
         for (int i = 0; i < nclass; ++i) nrep = std::max(nrep, probs[i].count);
         hipLaunchKernelGGL(fault_status_kernel, dim3(1), dim3(64), 0, s, d_status, std::max(status_stride, 1), nrep);

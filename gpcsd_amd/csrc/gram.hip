@@ -299,6 +299,11 @@ void k_temporal_fold_fill(gpcsd_ctx *c, const TemporalSet *sets, int nrep, const
     g.status_stride = status_stride;
     g.elem_blocks = ceil_div((long)sy.ns * sy.ns, 256);
     const int zero_blocks = 64;
+    // sums of SE / Matern-1/2 kernels with non-negative variances: positive semi-definite (EigArenaView::psd)
+    bool nonneg = true;
+    for (int r = 0; r < nrep; ++r)
+        for (int cc = 0; cc < sets[r].ncomp; ++cc) nonneg = nonneg && sets[r].sigma2[cc] >= 0.0;
+    *as.psd = *aa.psd = nonneg;
     ProfScope ps(c, "gram_temporal_fold_fill", 0.0, s);
     if (c->gram_fp32)
         hipLaunchKernelGGL(temporal_fold_fill_kernel<float>, dim3(g.elem_blocks + zero_blocks, nrep), dim3(256), 0, s, g);
@@ -309,8 +314,10 @@ void k_temporal_fold_fill(gpcsd_ctx *c, const TemporalSet *sets, int nrep, const
 
 // the same for B sets whose hyper-parameters sit in a device table (the lock-step batches of fit)
 void k_temporal_fold_fill_tab(gpcsd_ctx *c, const HpDev *tab, int B, const double *t, int n, const SymDev &sy,
-                              const EigArenaView &as, const EigArenaView &aa, int *status, int status_stride, hipStream_t s) {
+                              const EigArenaView &as, const EigArenaView &aa, int *status, int status_stride, hipStream_t s,
+                              bool variances_nonneg) {
     GP_REQUIRE(tab && B >= 1, -3, "temporal fold fill: no hyper-parameter table");
+    *as.psd = *aa.psd = variances_nonneg;          // (the table is on the device: its owner vouches for the signs)
     GP_REQUIRE(sy.ns > 0 && sy.ns + sy.na == n, -3, "temporal fold fill: the symmetry does not cover the %d time points", n);
     TFoldFillArgs g{};
     g.tab = tab;

@@ -194,6 +194,7 @@ struct EigArenaView {
     double *A0, *V, *tau, *amax;
     long blk;
     double *d, *e;               // the tridiagonal of A0 = Q T Q^T once the tridiagonalisation has run (n entries each)
+    bool *psd;                   // host flag of the class (gpcsd_ctx::arena_psd): a fill that writes a positive semi-definite matrix sets it
 };
 EigArenaView eigh_arena_view(gpcsd_ctx *c, const char *tag, int n, int count);
 // tags of the two half-size classes of problem `slot` (0 / 1) of eigh_pair_device: [0] symmetric, [1] antisymmetric
@@ -201,7 +202,8 @@ const char *const *eigh_fold_tags(const gpcsd_ctx *c, int slot);     // (slot 1:
 // fold of a PSD matrix (+ diagonal shift per replica) straight into the class arenas, scaled: see eigh.hip
 void k_psd_fold_fill(gpcsd_ctx *c, const double *K, int n, long sK, int nrep, const double *shift, const SymDev &sy,
                      const EigArenaView &as, const EigArenaView &aa, int *status, int status_stride, hipStream_t s,
-                     const HpDev *tab = nullptr);       // tab: replica r adds tab[r].jitter instead of shift[r] (any nrep)
+                     const HpDev *tab = nullptr,        // tab: replica r adds tab[r].jitter instead of shift[r] (any nrep)
+                     bool tab_shifts_nonneg = false);   // ... all of which are >= 0 (the arenas then count as PSD: EigArenaView::psd)
 // The temporal chain's input in ONE launch: the symmetric / antisymmetric fold of Kt = sum_c sigma2_c k_c(t_i - t_j) for
 // `nrep` hyper-parameter sets, evaluated entry by entry from the time grid (the same expressions, in the same order, as
 // k_temporal_gram followed by the eigensolver's fold), divided by a power of two >= 2 sum_c sigma2_c (>= every entry of
@@ -219,7 +221,8 @@ void k_temporal_fold_fill(gpcsd_ctx *c, const TemporalSet *sets, int nrep, const
                           const EigArenaView &as, const EigArenaView &aa, int *status, int status_stride, hipStream_t s);
 // ... for B sets from a device table of hyper-parameters (scale formed on the device by the same rule)
 void k_temporal_fold_fill_tab(gpcsd_ctx *c, const HpDev *tab, int B, const double *t, int n, const SymDev &sy,
-                              const EigArenaView &as, const EigArenaView &aa, int *status, int status_stride, hipStream_t s);
+                              const EigArenaView &as, const EigArenaView &aa, int *status, int status_stride, hipStream_t s,
+                              bool variances_nonneg);   // every sigma2 of the table is >= 0: the blocks are PSD (EigArenaView::psd)
 // flat problem index g -> (class, replica) from the prefix sums start[0..MAX_EIG_BATCH] (unused classes repeat the total)
 __device__ __forceinline__ void class_of(const int *start, int g, int &cls, int &rep) {
     cls = (g >= start[1]) + (g >= start[2]) + (g >= start[3]);

@@ -82,8 +82,8 @@ __device__ __forceinline__ void rt_house(double alpha, double xnorm2, bool ok, d
 // tau = 0) and the tridiagonal ends with the block's diagonal.  Backward error <= the dropped trace, inside the n eps ||A||
 // the reduction itself commits.  The Gram matrices of smooth kernels are numerically low-rank: the 192-row halves of the
 // 384-channel Ks have ~58 eigenvalues above 1e-13 of the largest, and two thirds of the serial column steps of their tails
-// multiplied noise.  GPCSD_TAIL_EARLY_EXIT=0 keeps every column step (A/B, cross-check).
-__device__ int rt_early_exit_enabled = 1;
+// multiplied noise.  gpcsd_tail_early_exit(ctx, 0) / GPCSD_TAIL_EARLY_EXIT=0 keep every column step (the host then never sets
+// SytrdProb::psd): the A/B and the cross-check of tests/test_hip_fullsize.py::test_tail_early_exit_*.
 
 __global__ __launch_bounds__(RT_NTH) void sytrd_rtail_kernel(SytrdBatch b) {
     const SytrdProb P = sy_resolve(b, blockIdx.x);
@@ -181,7 +181,7 @@ __global__ __launch_bounds__(RT_NTH) void sytrd_rtail_kernel(SytrdBatch b) {
         // a dropped PSD block moves no eigenvalue by more than its trace (Weyl) -- the few-eps-||A|| any solver leaves in the
         // small eigenvalues.  (4 n eps, the reduction's own backward-error scale, showed in a log-likelihood: 1D models multiply
         // the temporal spectrum by spatial eigenvalues of 1e8, and 1.2e-9 of it moved.)
-        s_ttol = (P.psd && rt_early_exit_enabled && S == 0) ? 64.0 * EPS_U * tot : -1.0;
+        s_ttol = (P.psd && S == 0) ? 64.0 * EPS_U * tot : -1.0;
         s_exit_at = -1;
     }
     if (tid < RT_TMAX) sy[tid] = 0.0;              // from here on sy is y = A v: zero on dead rows and beyond T

@@ -18,8 +18,10 @@
  *     (gpcsd1d.py:219, gpcsd2d.py:217,258); <0 usage / HIP runtime error.
  *     NaN/Inf in results are returned, not trapped (reference runs under
  *     np.seterr(all='ignore'), gpcsd1d.py:7).
- *   - One ctx = one device + one HIP stream; calls on one ctx must be serialised by
- *     the caller.  Contexts are created lazily by the Python layer (fork safety).
+ *   - One ctx = one device + its four HIP streams (main, temporal chain, spatial
+ *     chain, side products: DESIGN.md 4.8) + the resident data; calls on one ctx must
+ *     be serialised by the caller, different contexts may be used from different
+ *     threads.  Contexts are created lazily by the Python layer (fork safety).
  */
 #ifndef GPCSD_HIP_H
 #define GPCSD_HIP_H
@@ -151,6 +153,9 @@ int gpcsd_kphig_2d(gpcsd_ctx *ctx, const double *xy, int nx,
                    const double *z, int nz, double R, double eps, double ell1, double ell2, double *out);
 /* numpy.linalg.eigh as used by comp_eig_D (utility_functions.py:58-59): ascending evals, evecs in columns */
 int gpcsd_eigh(gpcsd_ctx *ctx, const double *A, int n, double *evals, double *evecs);
+/* the same for a matrix the caller vouches is positive semi-definite (a Gram matrix such as Ks, Kt handed to comp_eig_D,
+ * utility_functions.py:44-64): it may take the rank-revealing early exit of gpcsd_tail_early_exit (orders <= 192) */
+int gpcsd_eigh_psd(gpcsd_ctx *ctx, const double *A, int n, double *evals, double *evecs);
 /* `count` matrices of the same order through one shared chain of launches (batched hyper-parameter evaluations decompose
  * all their Gram matrices this way): A (count,n,n) -> evals (count,n), evecs (count,n,n); status[i] > 0: matrix i failed. */
 int gpcsd_eigh_batch(gpcsd_ctx *ctx, const double *A, int n, int count, double *evals, double *evecs, int *status);
@@ -289,13 +294,26 @@ int gpcsd_fold_gemm(gpcsd_ctx *ctx, int on, long *calls);
  *     costs 2-10 %),
  * < 0 only queries; GPCSD_LL_TRIDIAG=0|1|2 sets the mode of new contexts.  *calls counts the log-likelihoods evaluated this
  * way.  DESIGN.md 9. */
-/* Status of the stages such a log-likelihood does not wait for: the temporal chain's divide & conquer and back-transformation
- * keep running on the chain's stream when a synchronous gpcsd_loglik / gpcsd_loglik_parts in this form returns (the one case in
- * which the context is not idle behind a value-returning call; every later call is ordered behind them as usual).  They report
- * into status words of their own, which only a call that JOINS that chain collects -- a prediction reusing it through the
- * decomposition cache, or any call in the eigenvector form: a failure there is that call's rc > 0, never this log-likelihood's
- * (whose value does not depend on them) and never an unrelated later call's. */
+/* Late status words.  A temporal chain all of whose consumers take the tridiagonal form (a log-likelihood in this form; the
+ * paired call when its prediction is in that form too, the default) runs its tridiagonalisation, T factors and Q only: the
+ * divide & conquer and the back-transformation are not queued, and the context is idle behind every value-returning call.  Only
+ * the paired call gpcsd_loglik_predict_async with an EIGENVECTOR-form prediction (GPCSD_PRED_TRIDIAG=0, or shapes the solve
+ * kernel does not take) queues those two stages behind a log-likelihood that does not wait for them; they report into status
+ * words of their own, which the call that JOINS that chain collects (the prediction's wait / gpcsd_device_synchronize): a failure
+ * there is that call's rc > 0, never the log-likelihood's (whose value does not depend on them) and never an unrelated later
+ * call's. */
 int gpcsd_ll_tridiag(gpcsd_ctx *ctx, int on, long *calls);
+/* Rank-revealing early exit of the tridiagonalisation (no reference counterpart -- numpy.linalg.eigh,
+ * utility_functions.py:58-59, reduces every column): for matrices the LIBRARY's own Gram fills announce as positive
+ * semi-definite (Ks, Kt of the model with non-negative variances and jitter; never a caller's matrix handed to gpcsd_eigh /
+ * gpcsd_eig_D / gpcsd_set_host_temporal_gram) of at most 192 rows after folding, the Householder reduction stops once the trace
+ * still to be reduced is below 64 unit roundoffs of the matrix's trace (backward error <= that trace).  on = 1 / 0 switches it
+ * for this context (default 1; GPCSD_TAIL_EARLY_EXIT=0 for new contexts), < 0 only queries; *previous receives the setting
+ * before the call.  Both settings are tested against each other (tests/test_hip_fullsize.py::test_tail_early_exit_*). */
+int gpcsd_tail_early_exit(gpcsd_ctx *ctx, int on, int *previous);
+/* Test aid, off by default and never read from the environment: with on = 1 the divide & conquer stage of a staged temporal
+ * chain reports numerical failure 3 for every replica (drives the late status words above). */
+int gpcsd_debug_fault_stage2(gpcsd_ctx *ctx, int on);
 
 /* ---- several devices from ONE process ------------------------------------------------------- */
 /* SURVEY 8(b)'s gpcsd_dist_*: one context per device, driven by one host process (the Python layer uses one process per GPU

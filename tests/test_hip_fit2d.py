@@ -446,12 +446,25 @@ def test_npx69_fit_twenty_restarts_runs_in_lockstep_and_matches_scipy_on_the_ora
         for tc, (_, ell, s2) in zip(m.temporal_cov_list, hh["temporal"]):
             lp += tc.params["ell"]["prior"].lpdf(ell) + tc.params["sigma2"]["prior"].lpdf(s2)
         return -(O.loglik(geom, hh, lfp) + lp)
-    # the objective the library reports at its optimum is the ORACLE's objective there (a prior-drawn start leaves a truncated
-    # fit at hyper-parameters nobody scaled: 1e-5 here, not the 1e-9 of the well-scaled point above)
+    # the objective the library reports at its optimum is the ORACLE's objective there.  A prior-drawn start leaves a truncated fit
+    # at hyper-parameters nobody scaled, where equally correct LAPACK drivers disagree about the objective themselves: the gate is
+    # north_star's 1e-6 or three times the measured driver spread at that very point (as test_cfg3_geometry_noise_list_... does),
+    # never a hand-set constant; both are printed.  The same point re-evaluated with the tridiagonalisation's early exit off tells
+    # whether the exit has any part in the deviation.
     tp_best = m._current_tparams()
     f0 = obj(tp_best)
-    print("npx69 fit: best nll %.6f, oracle objective at the fitted parameters %.6f (rel %.2e)" % (best, f0, abs(f0 - best) / abs(best)))
-    assert abs(f0 - best) <= 1e-5 * abs(best), (f0, best)
+    spread = O.driver_spread(lambda: obj(tp_best))
+    gate = max(1e-6, 3.0 * spread)
+    ctx = m._sync_device()
+    f_on, _g = m._objective_and_grad(tp_best, False)
+    ctx.tail_early_exit(False)
+    f_off, _g = m._objective_and_grad(tp_best, False)
+    ctx.tail_early_exit(True)
+    print("npx69 fit: best nll %.6f, library objective at the fitted parameters %.6f (early exit off: %.6f), oracle objective there %.6f "
+          "(rel %.2e); LAPACK driver spread of the oracle objective there %.2e -> gate %.2e"
+          % (best, f_on, f_off, f0, abs(f0 - best) / abs(best), spread, gate))
+    assert abs(f_on - f_off) <= 1e-9 * abs(f_off)
+    assert abs(f0 - best) <= gate * abs(best), (f0, best, spread)
 
 
 @pytest.mark.parametrize("ntrials", [16, 70])

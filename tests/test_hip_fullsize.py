@@ -1013,6 +1013,7 @@ lfp = C.synth_lfp(77, 384, 500, 2)
 m = T._model_from_case(c, g, lfp)
 ctx = m._sync_device()
 ctx.ll_tridiag(1)
+ctx.debug_fault_stage2(True)            # the injection is an explicit call on the context (ADVICE r4), not an environment variable
 h1, k1 = m._hparams(m.JITTER)
 h0, k0 = m._hparams(0.0)
 res = {}
@@ -1051,13 +1052,13 @@ print(json.dumps(res))
 @pytest.mark.timeout(600)
 def test_late_stage_failure_is_reported_by_the_call_that_joins_the_chain():
     """a synchronous log-likelihood in the tridiagonal form returns while stages 2 and 4 of its temporal chain (divide
-    & conquer, back-transformation) are still running.  A failure of those stages (injected: GPCSD_FAULT_STAGE2=1) concerns
+    & conquer, back-transformation) are still running.  A failure of those stages (injected: gpcsd_debug_fault_stage2) concerns
     results that call never read: it must neither fail that call nor be charged to the next one -- it belongs to the call that
     joins the chain (a prediction), and only to that one."""
     # (GPCSD_PRED_TRIDIAG=0: the prediction in the eigenvector form, the one consumer that joins a staged chain's late stages -- with
     # the prediction in the tridiagonal form as well, the default, those stages are not even queued)
     r = subprocess.run([sys.executable, "-c", _LATE_STATUS_PROBE], cwd=ROOT,
-                       env=dict(os.environ, GPCSD_FAULT_STAGE2="1", GPCSD_PRED_TRIDIAG="0"), capture_output=True, text=True, timeout=500)
+                       env=dict(os.environ, GPCSD_PRED_TRIDIAG="0"), capture_output=True, text=True, timeout=500)
     assert r.returncode == 0, r.stderr[-3000:]
     res = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     print(res)
