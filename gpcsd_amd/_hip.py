@@ -178,6 +178,7 @@ SIGNATURES = {
     "gpcsd_set_gram_precision": (_I, [_P, _I]),
     "gpcsd_fold_gemm": (_I, [_P, _I, ctypes.POINTER(_L)]),
     "gpcsd_ll_tridiag": (_I, [_P, _I, ctypes.POINTER(_L)]),
+    "gpcsd_pair_share_x": (_I, [_P, _I, ctypes.POINTER(_L)]),
     "gpcsd_tail_early_exit": (_I, [_P, _I, ctypes.POINTER(_I)]),
     "gpcsd_debug_fault_stage2": (_I, [_P, _I]),
     "gpcsd_decomposition_cache": (_I, [_P, _I, ctypes.POINTER(_L)]),
@@ -763,6 +764,13 @@ class Context:
         folded log-likelihood (no temporal eigenvectors on its path); returns the number of log-likelihoods evaluated that way."""
         n = _L(0)
         self._check(self._lib.gpcsd_ll_tridiag(self._h, -1 if mode is None else int(mode), ctypes.byref(n)))
+        return int(n.value)
+
+    def pair_share_x(self, on=None):
+        """Switch (True/False) or query (None) the paired call's sharing of X = Y~ Q between its log-likelihood and its prediction
+        when their temporal hyper-parameters are equal; returns the number of paired calls that shared it."""
+        n = _L(0)
+        self._check(self._lib.gpcsd_pair_share_x(self._h, -1 if on is None else int(bool(on)), ctypes.byref(n)))
         return int(n.value)
 
     def tail_early_exit(self, on=None):

@@ -252,7 +252,7 @@ static const SymDev &site_symmetry(gpcsd_ctx *c, const double *z, int nz, int di
 static int predict_fold(gpcsd_ctx *c, const gpcsd_hparams *hp, EigState &e, const FoldMode &fm, const double *Yf, const SymDev &sz,
                         const double *dz, int nz, const double *dts, int type, bool want_lists, bool async,
                         const std::function<void()> *after_spatial_join = nullptr,
-                        const std::function<void()> *before_spatial_join = nullptr) {
+                        const std::function<void()> *before_spatial_join = nullptr, const char *shared_x = nullptr) {
     const Geo g = resident_geo(c);
     const int nx = c->nx, nt = c->nt, R = c->ntrials, C = hp->n_temporal;
     const long RT = (long)R * nt;
@@ -301,13 +301,21 @@ static int predict_fold(gpcsd_ctx *c, const gpcsd_hparams *hp, EigState &e, cons
     // for the spatial chain, exactly as the log-likelihood's
     // (a call of its own: in front of the wait for the spatial chain; in the paired call: behind the log-likelihood's tail -- in
     // front of it the product delays the result the caller is waiting for by its 0.09 ms)
-    if (e.tri && !after_spatial_join) loglik_tri_pre(c, e, fm, Yf, "pred_X", "gemm_pred_YQ", false);
+    // shared_x (the paired call with equal temporal hyper-parameters): X = Y~ Q is the log-likelihood's own product -- the two
+    // replicas of the temporal problem are the same matrix, decomposed by the same deterministic launches into the same bits, so
+    // the second product would only recompute `shared_x` (0.1 ms of MFMA time and 154 MB of traffic per cfg3 step)
+    const char *xname = shared_x ? shared_x : "pred_X";
+    if (e.tri && !after_spatial_join && !shared_x) loglik_tri_pre(c, e, fm, Yf, "pred_X", "gemm_pred_YQ", false);
     join_spatial(c, e);
     // gpcsd_loglik_predict_async: the log-likelihood's whole tail goes here, in front of everything of predict that needs a
     // decomposition -- it is what the caller waits for
     if (after_spatial_join) (*after_spatial_join)();
-    if (e.tri && after_spatial_join) loglik_tri_pre(c, e, fm, Yf, "pred_X", "gemm_pred_YQ", false);
-    fold_proj_spatial(c, fm.fs, e.tri ? c->buf<double>("pred_X", (size_t)nx * RT) : Yf, W, RT, s);   // W~ = diag(U)^T Y~ (or of Y~ Q)
+    if (e.tri && after_spatial_join && !shared_x) loglik_tri_pre(c, e, fm, Yf, "pred_X", "gemm_pred_YQ", false);
+    if (e.tri && shared_x) {              // (the wait for Q the skipped product would have queued; the log-likelihood's tail has passed it)
+        if (e.wait_q) GP_HIP(hipStreamWaitEvent(s, c->ev_q[c->tgen], 0));
+        e.wait_q = false;
+    }
+    fold_proj_spatial(c, fm.fs, e.tri ? c->buf<double>(xname, (size_t)nx * RT) : Yf, W, RT, s);   // W~ = diag(U)^T Y~ (or of Y~ Q)
     for (int which = 1; which <= 2; ++which) {
         if (!(type & which)) continue;
         const double *kf = Kcf + (size_t)(which - 1) * kcf_sz;
@@ -801,7 +809,13 @@ extern "C" int gpcsd_loglik_predict_async(gpcsd_ctx *c, const gpcsd_hparams *hp_
         else batched = loglik_fold_tail(c, pf.e[0], pf.fm[0], Yf, Wll);
         (void)finish_loglik_async(c, pf.e[0], !batched, wrote);
     };
-    return predict_fold(c, hp_pr, pf.e[1], pf.fm[1], Yf, sz, dzf, nz, dtf, type, want_lists != 0, true, &ll_tail, &ll_pre);
+    // equal temporal hyper-parameters (every loglik -> predict pair of a fit or a bench step: the jitter is spatial): the prediction
+    // reads the log-likelihood's X = Y~ Q instead of forming its own from the bit-identical second replica
+    // (gpcsd_pair_share_x(ctx, 0, ..) / GPCSD_PAIR_SHARE_X=0: A/B)
+    const bool share_x = c->pair_share_x && pf.e[0].tri && pf.e[1].tri && ll_order() == 0 && same_temporal(hp_ll, hp_pr);
+    if (share_x) ++c->pair_shared_x_calls;
+    return predict_fold(c, hp_pr, pf.e[1], pf.fm[1], Yf, sz, dzf, nz, dtf, type, want_lists != 0, true, &ll_tail, &ll_pre,
+                        share_x ? "ll_X" : nullptr);
     GP_API_END(c)
 }
 

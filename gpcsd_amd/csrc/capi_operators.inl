@@ -590,6 +590,14 @@ extern "C" int gpcsd_debug_fault_stage2(gpcsd_ctx *c, int on) {
     GP_API_END(c)
 }
 
+extern "C" int gpcsd_pair_share_x(gpcsd_ctx *c, int on, long *calls) {
+    GP_API_BEGIN(c)
+    if (on >= 0) c->pair_share_x = on != 0;
+    if (calls) *calls = c->pair_shared_x_calls;
+    return 0;
+    GP_API_END(c)
+}
+
 extern "C" int gpcsd_fold_gemm(gpcsd_ctx *c, int on, long *calls) {
     GP_API_BEGIN(c)
     if (on >= 0) c->fold_gemm_on = on != 0;

@@ -176,6 +176,8 @@ struct gpcsd_ctx {
     int ll_tridiag_mode = 2;                // gpcsd_ll_tridiag(): log-likelihood in the basis U (x) Q -- 0 off, 1 on, 2 by size (capi.hip)
     long ll_tridiag_calls = 0;
     long fold_gemm_calls = 0;
+    bool pair_share_x = true;               // gpcsd_pair_share_x()
+    long pair_shared_x_calls = 0;           // paired calls whose prediction read the log-likelihood's X = Y~ Q (capi_fused.inl)
     // Decomposition cache (capi.hip::front_half): predict() right after loglik() / fit() with the same hyper-parameters
     // (neuropixels/fit_gpcsd2d.py:101-107) decomposes the very same Kt again, repeated predict() calls the same Ks as well.
     // The kernels are deterministic, so reusing what the previous call left in the context's buffers gives the same bits.

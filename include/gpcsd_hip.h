@@ -283,6 +283,13 @@ int gpcsd_combine_loglik(int ntrials_total, double sumlog, double quad_sum_over_
  * results are bit-identical either way.  on = 1 / 0 switches it (default on), -1 only queries; *hits counts reused sides. */
 int gpcsd_decomposition_cache(gpcsd_ctx *ctx, int on, long *hits);
 int gpcsd_fold_gemm(gpcsd_ctx *ctx, int on, long *calls);
+/* The paired call gpcsd_loglik_predict_async (loglik gpcsd2d.py:136-151 + predict :289-334 of one step) with EQUAL temporal
+ * hyper-parameters in both sets -- the case of every loglik -> predict pair, whose only difference is the spatial jitter -- forms
+ * the product X = Y~ Q of the resident data with the temporal basis once and lets the prediction read the log-likelihood's copy:
+ * the two replicas of the temporal problem are the same matrix reduced by the same deterministic launches, so the second product
+ * would recompute the same bits.  on = 1 / 0 switches it (default 1; GPCSD_PAIR_SHARE_X=0 for new contexts), < 0 only queries;
+ * *calls counts the paired calls that shared the product.  Results are bit-identical either way. */
+int gpcsd_pair_share_x(gpcsd_ctx *ctx, int on, long *calls);
 /* The log-likelihood of the folded path in the basis U (x) Q instead of U (x) V.  With Kt = m Q T Q^T from the
  * tridiagonalisation alone (Q orthogonal, T tridiagonal) and the spatial side fully decomposed, Ks (x) Kt + sig2 I is a set of
  * SHIFTED TRIDIAGONAL matrices es[x'] m T + sig2 I: sum log D is the sum of the logs of their LDL^T pivots and the quadratic

@@ -628,6 +628,53 @@ def test_failed_asynchronous_call_is_never_served_from_the_decomposition_cache(n
     assert -0.5 * lfp.shape[2] * sumlog - 0.5 * quad == ll_ref
 
 
+def test_paired_call_shares_the_product_with_the_temporal_basis_and_changes_no_bits():
+    """gpcsd_pair_share_x (round 5): with equal temporal hyper-parameters the paired call's prediction reads the log-likelihood's
+    X = Y~ Q instead of forming it again from the second, bit-identical replica of the temporal problem.  cfg3's geometry with 16
+    trials (the prediction takes the tridiagonal form from 16 trials on): the sharing is counted, and log-likelihood and posterior
+    mean are the bits of the same call with the sharing off and of the two calls fenced one by one; with DIFFERENT temporal
+    hyper-parameters in the two sets nothing is shared."""
+    from gpcsd_amd import _hip
+    c, g, geom, hp, _ = load_model_case("cfg3s_2d_384x500x2")
+    lfp = C.synth_lfp(99, 384, 500, 16)
+    m = _model_from_case(c, g, lfp)
+    ctx = m._sync_device()
+    ctx.decomposition_cache(False)
+    z, t = np.ascontiguousarray(c["x"]), c["t"]
+    h1, k1 = m._hparams(m.JITTER)
+    h0, k0 = m._hparams(0.0)
+
+    def paired(ha, hb):
+        ctx.loglik_predict_async(ha, hb, z, t, _hip.PRED_CSD, want_lists=True)
+        parts = ctx.loglik_parts_wait()
+        return parts, ctx.fetch("pred_out_csd", (384, 500, 16)), ctx.fetch("pred_out_csd_list", (2, 384, 500, 16))
+    assert ctx.pair_share_x(True) >= 0
+    n0 = ctx.pair_share_x()
+    on = paired(h1, h0)
+    assert ctx.pair_share_x() == n0 + 1
+    ctx.pair_share_x(False)
+    off = paired(h1, h0)
+    assert ctx.pair_share_x() == n0 + 1                         # switched off: not counted, not shared
+    ctx.pair_share_x(True)
+    assert on[0] == off[0] and np.array_equal(on[1], off[1]) and np.array_equal(on[2], off[2])
+    fenced_ll = ctx.loglik_parts(h1)
+    ctx.predict_resident(h0, z, t, _hip.PRED_CSD, want_lists=True)
+    ctx.synchronize()
+    assert fenced_ll == on[0] and np.array_equal(ctx.fetch("pred_out_csd", (384, 500, 16)), on[1])
+    ref = O.predict(geom, hp, lfp, z, t, type="csd")["csd"]
+    assert relerr(on[1], ref) < GATE
+    # a prediction at other temporal hyper-parameters than the log-likelihood's: its own product, its own (different) result
+    m.temporal_cov_list[0].params["ell"]["value"] *= 1.05
+    h0b, k0b = m._hparams(0.0)
+    n1 = ctx.pair_share_x()
+    other = paired(h1, h0b)
+    assert ctx.pair_share_x() == n1 and other[0] == on[0] and not np.array_equal(other[1], on[1])
+    ctx.predict_resident(h0b, z, t, _hip.PRED_CSD, want_lists=True)
+    ctx.synchronize()
+    assert np.array_equal(ctx.fetch("pred_out_csd", (384, 500, 16)), other[1])
+    ctx.decomposition_cache(True)
+
+
 @pytest.mark.parametrize("name", ["2d_npx_96x120x3", "cfg2s_1d_24x500x8", "1d_odd_17x37x5", "cfg3s_2d_384x500x2"])
 def test_predict_resident_is_asynchronous_and_changes_no_bits(name):
     """Queued calls: gpcsd_predict_resident returns with its GEMM tail in flight and gpcsd_loglik_parts_async /
