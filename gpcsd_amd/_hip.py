@@ -77,8 +77,8 @@ HPARAMS_DTYPE = np.dtype({"names": ["R", "eps", "ell_s", "n_temporal", "kind", "
 
 
 class HParamsBatch:
-    """B hyper-parameter structs in one contiguous block (what gpcsd_loglik_grad_batch takes), with the scalar noise variances
-    they point to; built from arrays without a Python loop over the sets."""
+    """B hyper-parameter structs in one contiguous block (what gpcsd_loglik_grad_batch takes), with the noise variances they
+    point to (one per set, or one list of nx per set); built from arrays without a Python loop over the sets."""
 
     def __init__(self, R, eps, ell_s, kinds, ell_t, sigma2_t, sig2n, jitter):
         R = np.asarray(R, dtype=np.float64)
@@ -95,9 +95,13 @@ class HParamsBatch:
         rec["kind"][:, :C] = np.asarray(kinds, dtype=np.int32)[None, :]
         rec["ell_t"][:, :C] = np.asarray(ell_t, dtype=np.float64).reshape(B, C)
         rec["sigma2_t"][:, :C] = np.asarray(sigma2_t, dtype=np.float64).reshape(B, C)
-        self.sig = np.ascontiguousarray(np.asarray(sig2n, dtype=np.float64).reshape(B))
-        rec["n_sig2n"] = 1
-        rec["sig2n"] = self.sig.ctypes.data + 8 * np.arange(B, dtype=np.uint64)
+        # scalar noise: sig2n (B,); per-electrode lists: sig2n (B, nx) -- each struct points at its own row
+        self.sig = np.ascontiguousarray(np.asarray(sig2n, dtype=np.float64).reshape(B, -1))
+        nsig = self.sig.shape[1]
+        if nsig == 1:
+            self.sig = self.sig.reshape(B)                   # (scalar noise: one value per set, as before)
+        rec["n_sig2n"] = nsig
+        rec["sig2n"] = self.sig.ctypes.data + 8 * nsig * np.arange(B, dtype=np.uint64)
         rec["jitter"] = jitter
         self.rec = rec
         self.B = B
@@ -694,7 +698,7 @@ class Context:
         return float(out[0]), float(out[1]), g
 
     def loglik_grad_batch(self, hps, ngrad):
-        """hps: list of HParams (same kernel kinds, scalar noise).  One shared chain of launches for all of them.
+        """hps: list of HParams (same kernel kinds, the same number of noise entries).  One shared chain of launches for all of them.
         Returns (sumlog (B,), quad (B,), grad (B, ngrad), status (B,)); status[i] > 0: set i failed numerically."""
         B = len(hps)
         arr = hps.pointer() if isinstance(hps, HParamsBatch) else (HParams * B)(*hps)

@@ -46,7 +46,6 @@ static int loglik_grad_impl(gpcsd_ctx *c, const gpcsd_hparams *hps, int B, doubl
     }
     // scalar sig2n: one trailing entry; per-electrode list (indexed by eigen-row like the reference's D): nx entries
     GP_REQUIRE(nsig == 1 || nsig == nx, -3, "loglik_grad: sig2n must be a scalar or a list of nx=%d values (got %d)", nx, nsig);
-    GP_REQUIRE(nsig == 1 || B == 1, -3, "loglik_grad_batch: per-electrode noise lists are evaluated one set at a time");
     const int nhead = 1 + g.dim + 2 * C;
     GP_REQUIRE(ngrad == nhead + nsig, -3, "loglik_grad: ngrad=%d, expected %d", ngrad, nhead + nsig);
     const long RT = (long)R * nt, nxx = (long)nx * nx, ntt = (long)nt * nt, nD = (long)nx * nt, nxRT = (long)nx * RT;
@@ -57,7 +56,13 @@ static int loglik_grad_impl(gpcsd_ctx *c, const gpcsd_hparams *hps, int B, doubl
     std::vector<HpDev> himg(B);
     for (int b = 0; b < B; ++b) himg[b] = hp_image(&hps[b]);
     const HpDev *tab = c->upload_cached<HpDev>("b_hp_tab", himg.data(), B);
-    const double *d_siglist = nsig > 1 ? c->upload_cached<double>("sig2n", hps[0].sig2n, nsig) : nullptr;
+    // per-electrode noise lists (fit_gpcsd_baseline.py:85-89): set b's nx variances at d_siglist + b * nx
+    const double *d_siglist = nullptr;
+    if (nsig > 1) {
+        std::vector<double> lists((size_t)nsig * B);
+        for (int b = 0; b < B; ++b) memcpy(lists.data() + (size_t)b * nsig, hps[b].sig2n, (size_t)nsig * sizeof(double));
+        d_siglist = c->upload_cached<double>("b_sig2n_lists", lists.data(), lists.size());
+    }
 
     double *Ks = c->buf<double>("b_Ks", nxx * B), *Kt = c->buf<double>("b_Kt", ntt * B);
     double *Qs = c->buf<double>("b_Qs", nxx * B), *Qt = c->buf<double>("b_Qt", ntt * B);
@@ -311,8 +316,7 @@ static int loglik_grad_impl(gpcsd_ctx *c, const gpcsd_hparams *hps, int B, doubl
         gemm_f64(c, g1, s);
         GP_HIP(hipStreamWaitEvent(s, c->ev_join, 0));
         // D_b = es_b (x) et_b + sig2n_b, sum log D_b -> scal[b][0]
-        if (nsig == 1) k_build_D(c, es, nx, et, nt, nullptr, 1, D, Dinv, scal, s, tab, B, NS);
-        else k_build_D(c, es, nx, et, nt, d_siglist, nsig, D, Dinv, scal, s);
+        k_build_D(c, es, nx, et, nt, d_siglist, nsig, D, Dinv, scal, s, tab, B, NS);
         GemmDesc g2;                          // alpha = W Qt;  B = alpha / D, B*et, B*es;  sum alpha*B, sum B^2
         g2.M = nx * R; g2.N = nt; g2.K = nt;
         g2.A = W; g2.lda = nt; g2.B = Qt; g2.ldb = nt; g2.C = Bm; g2.ldc = nt; g2.C2 = nullptr; g2.C3 = nullptr;   // (see the folded path)
@@ -343,11 +347,11 @@ static int loglik_grad_impl(gpcsd_ctx *c, const gpcsd_hparams *hps, int B, doubl
             g3.kscale = nullptr;
             g3.prof_name = "gemm_grad_BBt";
             gemm_f64(c, g3, s);
-            double *Ssum = c->buf<double>("grad_Ssum", (size_t)nxx);
+            double *Ssum = c->buf<double>("grad_Ssum", (size_t)nxx * B);
             double *zero = c->buf<double>("grad_zero", nx);
             k_fill(c, zero, nx, 0.0, s);
-            k_batch_reduce(c, Cs, R, nxx, nx, 1.0, zero, 0.0, Ssum, s);
-            k_siglist_eigvec_term(c, Ghs, Ssum, es, d_siglist, nx, 0.0, s);
+            k_batch_reduce(c, Cs, R, nxx, nx, 1.0, zero, 0.0, Ssum, s, B, sCs, /*s_dvec=*/0, nxx);
+            k_siglist_eigvec_term(c, Ghs, Ssum, es, d_siglist, nx, 0.0, s, B);
         }
         // Ghat_t = 1/2 sum_{(x,r)} (B es)^T B - R/2 diag(b)    (row chunks of 512, batched; remainder separately)
         const long rows = (long)nx * R;
@@ -423,12 +427,12 @@ static int loglik_grad_impl(gpcsd_ctx *c, const gpcsd_hparams *hps, int B, doubl
     k_fwdR_grad(c, P, g.x, nx, g.gx1, g.gw1, g.gx2, g.gw2, G, g.dim == 2 ? g.ngl2 : 0, 0.0, 0.0, gdev, s, tab, B, 64);
     std::vector<double> hb2, hinv;
     if (nsig > 1) {                       // d/d sig2n_x = -R/2 sum_i 1/D_xi + 1/2 sum_{r,i} B_{(x,r),i}^2
-        double *b2row = c->buf<double>("grad_b2row", nx);
-        k_rowgroup_sumsq(c, Bm, nx, RT, b2row, s);
-        hb2.resize(nx);
-        hinv.resize(nx);
-        c->download(hb2.data(), b2row, nx * sizeof(double));
-        c->download(hinv.data(), c->bufs["grad_s1row"].p, nx * sizeof(double));   // written by k_D_sums
+        double *b2row = c->buf<double>("grad_b2row", (size_t)nx * B);               // (Bm is [set][x][r][t]: nx * B rows of R nt)
+        k_rowgroup_sumsq(c, Bm, nx * B, RT, b2row, s);
+        hb2.resize((size_t)nx * B);
+        hinv.resize((size_t)nx * B);
+        c->download(hb2.data(), b2row, hb2.size() * sizeof(double));
+        c->download(hinv.data(), c->bufs["grad_s1row"].p, hinv.size() * sizeof(double));   // written by k_D_sums, [set][x]
     }
     std::vector<double> hs((size_t)NS * B), hg((size_t)64 * B);
     std::vector<int> hst((size_t)2 * B);
@@ -447,7 +451,7 @@ static int loglik_grad_impl(gpcsd_ctx *c, const gpcsd_hparams *hps, int B, doubl
         if (nsig == 1)
             gb[nhead] = -0.5 * R * hs[(size_t)NS * b + 3] + 0.5 * (hs[(size_t)NS * b + 2] + (quad_in_two ? hs[(size_t)NS * b + 5] : 0.0));
         else
-            for (int x = 0; x < nx; ++x) gb[nhead + x] = -0.5 * R * hinv[x] + 0.5 * hb2[x];
+            for (int x = 0; x < nx; ++x) gb[nhead + x] = -0.5 * R * hinv[(size_t)b * nx + x] + 0.5 * hb2[(size_t)b * nx + x];
         int stb = hst[b] != 0 ? hst[b] : hst[B + b];
         if (stb < 0) stb = 1;
         if (status) status[b] = stb;

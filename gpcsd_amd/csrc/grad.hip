@@ -344,6 +344,10 @@ void k_rowgroup_sumsq(gpcsd_ctx *c, const double *B, int nrows, long rowlen, dou
 __global__ __launch_bounds__(256) void siglist_eigvec_term_kernel(double *__restrict__ Ghs, const double *__restrict__ Ssum,
                                                                   const double *__restrict__ es, const double *__restrict__ sig,
                                                                   int nx, double tiny) {
+    {                                           // blockIdx.y = hyper-parameter set
+        const long b = blockIdx.y;
+        Ghs += b * nx * nx; Ssum += b * nx * nx; es += b * nx; sig += b * nx;
+    }
     const long e = blockIdx.x * 256L + threadIdx.x;
     if (e >= (long)nx * nx) return;
     const int y = (int)(e / nx), x = (int)(e % nx);
@@ -354,8 +358,8 @@ __global__ __launch_bounds__(256) void siglist_eigvec_term_kernel(double *__rest
 }
 
 void k_siglist_eigvec_term(gpcsd_ctx *c, double *Ghs, const double *Ssum, const double *es, const double *sig, int nx,
-                           double tiny, hipStream_t s) {
-    hipLaunchKernelGGL(siglist_eigvec_term_kernel, dim3(ceil_div((long)nx * nx, 256)), dim3(256), 0, s, Ghs, Ssum, es, sig, nx, tiny);
+                           double tiny, hipStream_t s, int B) {
+    hipLaunchKernelGGL(siglist_eigvec_term_kernel, dim3(ceil_div((long)nx * nx, 256), B), dim3(256), 0, s, Ghs, Ssum, es, sig, nx, tiny);
     GP_HIP(hipGetLastError());
 }
 

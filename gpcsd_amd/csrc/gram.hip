@@ -1145,11 +1145,11 @@ __global__ __launch_bounds__(256) void build_D_kernel(const double *__restrict__
                                                       double *__restrict__ partials, const HpDev *__restrict__ tab) {
     const long n = (long)nx * nt;
     if (tab) {                       // blockIdx.y = hyper-parameter set: spectra nx / nt apart, D n apart, scalar noise from tab
-        const long b = blockIdx.y;
+        const long b = blockIdx.y;   // (or, with a per-electrode list: set b's nx entries of `sig`)
         es += b * nx;
         et += b * nt;
-        sig = &tab[b].sig2n;
-        nsig = 1;
+        if (nsig == 1) sig = &tab[b].sig2n;
+        else sig += b * nx;
         D += b * n;
         if (Dinv) Dinv += b * n;
         partials += b * 256;

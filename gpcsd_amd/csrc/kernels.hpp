@@ -142,6 +142,7 @@ void k_tridiag_solve(gpcsd_ctx *c, const double *W, double *B, const double *es,
 void k_add_diag(gpcsd_ctx *c, double *A, int n, double v, hipStream_t s, const HpDev *tab = nullptr, int B = 1, long s_out = 0);
 void k_sum_partials(gpcsd_ctx *c, double *out, const double *P, long n, int parts, hipStream_t s);
 // D[x*nt + i] = es[x]*et[i] + sig[x or 0]; also sumlog -> *sumlog_out (deterministic)
+// with a table (B sets): scalar noise from tab[b].sig2n when nsig == 1, else set b's list at sig + b * nx
 // Dinv (optional) = 1/D elementwise.  sumlog_out == nullptr: no final sum; the per-block partials stay in the ctx buffer
 // "buildD_partials" and the return value is their count (a later launch may fold the sum in, or nobody needs it)
 int k_build_D(gpcsd_ctx *c, const double *es, int nx, const double *et, int nt, const double *sig, int nsig, double *D,
@@ -300,8 +301,9 @@ void stedc_device(gpcsd_ctx *c, const double *d, const double *e, int n, double 
 void k_D_sums(gpcsd_ctx *c, const double *D, const double *es, const double *et, int nx, int nt, double *a, double *b,
               double *s1_out, hipStream_t s, int B = 1, long s_s1 = 0);
 // Ghs[y][x] += -1/2 (sig_y - sig_x)/(es_x - es_y) Ssum[x][y] for x != y, |es_x - es_y| > tiny
+// B > 1: per hyper-parameter set (Ghs, Ssum nx*nx apart, es and sig nx apart)
 void k_siglist_eigvec_term(gpcsd_ctx *c, double *Ghs, const double *Ssum, const double *es, const double *sig, int nx,
-                           double tiny, hipStream_t s);
+                           double tiny, hipStream_t s, int B = 1);
 // out[b] = sum_{x,i} alpha[(x*nb + b)*nt + i]^2 / D[x*nt + i]
 void k_per_trial_quad(gpcsd_ctx *c, const double *alpha, const double *D, int nx, int nb, int nt, double *out, hipStream_t s);
 // out[x] = sum_k B[x*rowlen + k]^2

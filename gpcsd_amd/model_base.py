@@ -238,7 +238,8 @@ class GPCSDModel:
         """(loglik of the LOCAL trials [B], natural gradient [B, ng], status [B]) for a list of hyper-parameter structs: one
         shared chain of launches (gpcsd_loglik_grad_batch)."""
         ctx = self._sync_device()
-        ng = 1 + self.dim + 2 * len(self.temporal_cov_list) + 1
+        nsig = 1 if self._sig2n_is_scalar() else len(self.sig2n["value"])
+        ng = 1 + self.dim + 2 * len(self.temporal_cov_list) + nsig
         sumlog, quad, g, st = ctx.loglik_grad_batch(hps, ng)
         r_local = self._local_lfp().shape[2]
         return -0.5 * r_local * sumlog - 0.5 * quad, g, st
@@ -433,15 +434,21 @@ class GPCSDModel:
                cls._eval_batch_local is not GPCSDModel._eval_batch_local or
                (cls._objective_and_grad is GPCSDModel._objective_and_grad and
                 cls._loglik_and_grad_natural is GPCSDModel._loglik_and_grad_natural))
-        return (own and getattr(self, "_use_analytic_grad", True) and self._sig2n_is_scalar() and not self._uses_host_kt())
+        # (scalar noise or a per-electrode list: gpcsd_loglik_grad_batch takes either since round 5)
+        return (own and getattr(self, "_use_analytic_grad", True) and not self._uses_host_kt())
 
     def _vector_glue_applies(self):
         """The hyper-parameters of a batch can be unpacked, their priors evaluated and the chain rule applied as array
-        operations: scalar noise, the library's own temporal kernels, priors that offer lpdf_many / dlpdf_many."""
-        if not (self._sig2n_is_scalar() and not self._uses_host_kt()):
+        operations: the library's own temporal kernels, priors that offer lpdf_many / dlpdf_many (scalar noise or a
+        per-electrode list of priors)."""
+        if self._uses_host_kt():
             return False
-        priors = [sl[2] for sl in self._param_slots()] + [self.sig2n["prior"]]
+        priors = [sl[2] for sl in self._param_slots()] + self._noise_priors()
         return all(callable(getattr(pr, "lpdf_many", None)) and callable(getattr(pr, "dlpdf_many", None)) for pr in priors)
+
+    def _noise_priors(self):
+        """the noise prior(s) as a list: one entry for scalar noise, nx for a per-electrode list (gpcsd1d.py:58-60)"""
+        return [self.sig2n["prior"]] if self._sig2n_is_scalar() else list(self.sig2n["prior"])
 
     def _objective_and_grad_batch(self, items, fix_R):
         """{key: (objective, gradient) or exception} for [(key, tparams)]: the lock-step evaluation behind fit(batch=k).
@@ -453,12 +460,14 @@ class GPCSDModel:
         with np.errstate(all="ignore"):
             slots = self._param_slots()
             p = len(slots)
-            tps = np.stack([np.asarray(tp, dtype=np.float64) for _, tp in items])                 # (B, p + 1)
-            scales = np.array([sl[4] for sl in slots] + [1.0])
+            noise_priors = self._noise_priors()
+            nsig = len(noise_priors)
+            tps = np.stack([np.asarray(tp, dtype=np.float64) for _, tp in items])                 # (B, p + nsig)
+            scales = np.array([sl[4] for sl in slots] + [1.0] * nsig)
             nat = np.exp(tps) * scales                                                            # natural values, slot order
             if fix_R:
                 nat[:, 0] = slots[0][0]()
-            priors = [sl[2] for sl in slots] + [self.sig2n["prior"]]
+            priors = [sl[2] for sl in slots] + noise_priors
             lp = np.zeros(len(items))
             for i, pr in enumerate(priors):                                                       # same order as _log_prior
                 lp = lp + pr.lpdf_many(nat[:, i])
@@ -467,7 +476,7 @@ class GPCSDModel:
             kinds = [k for k, _, _ in self._temporal_triplets()]
             tcols = nat[:, 1 + ns:1 + ns + 2 * C]
             hps = _hip.HParamsBatch(nat[:, 0], getattr(self, "eps", 0.0), nat[:, 1:1 + ns], kinds, tcols[:, 0::2], tcols[:, 1::2],
-                                    nat[:, p], self.JITTER)
+                                    nat[:, p] if self._sig2n_is_scalar() else nat[:, p:], self.JITTER)
             if getattr(self, "_resident", {}).get("host_kt"):
                 self._context().set_host_temporal_gram(None)
                 self._resident["host_kt"] = False

@@ -222,7 +222,9 @@ int gpcsd_loglik_grad(gpcsd_ctx *ctx, const gpcsd_hparams *hp, double *out2, dou
  * gpcsd2d.py:230-262) are independent optimiser chains whose evaluations are latency-bound, so sets evaluated together
  * share every launch.  out2 is (nsets, 2), grad (nsets, ngrad); status[i] > 0 reports a numerical failure of set i alone
  * (the others are valid).  Every set gets exactly the bits a gpcsd_loglik_grad call of its own returns.  All sets must have
- * the same temporal kernel kinds and a scalar sig2n (per-electrode lists: nsets == 1). */
+ * the same temporal kernel kinds and the same number of noise entries: a scalar sig2n each, or (round 5) a per-electrode list
+ * of nx entries each -- the restarts of auditory_lfp/fit_gpcsd_baseline.py:85-101, evaluated on the merged-order path with the
+ * eigenvector-rotation term per set. */
 int gpcsd_loglik_grad_batch(gpcsd_ctx *ctx, const gpcsd_hparams *hp, int nsets, double *out2, double *grad, int ngrad,
                             int *status);
 /* GPCSD{1,2}D.predict(z, t, type) gpcsd1d.py:248-293 / gpcsd2d.py:289-334.
