@@ -659,8 +659,6 @@ def sub_results(args, local_rank, backend, cpu_legs):
             out[key] = {"error": repr(e)}
 
     guarded("cfg2", lambda: step("cfg2", 100, 5, 60))
-    guarded("cfg5", lambda: fit("cfg5"))
-    guarded("potrf", potrf_bench)
 
     def npx():
         # the reference's own 2D workload shape (69 channels without mirror symmetry) beside a point-symmetric control
@@ -673,8 +671,13 @@ def sub_results(args, local_rank, backend, cpu_legs):
                            "loglik_evals_per_sec": r69["loglik_evals_per_sec"], "fit_evals_per_sec": rf["value"],
                            "step_over_symmetric_control": r69["step_over_symmetric_control"]}
         return r69
+    # Order: the latency-bound step loops first, the machine-filling legs last.  The dense Cholesky (18 ms launches at 0.4 of the
+    # MFMA peak) leaves the card's clocks low for the next tenth of a second: the driver's round-5 rehearsal read npx69 at 1.13 ms
+    # per step right behind it against 0.586 ms as a command of its own (and 0.57 for its control, which ran one leg later).
     guarded("npx69", npx)
+    guarded("cfg5", lambda: fit("cfg5"))
     guarded("aud24", lambda: fit("aud24"))            # the reference's 1D script shape: per-electrode noise list (fit_gpcsd_baseline.py:79-105)
+    guarded("potrf", potrf_bench)
     out["seconds_spent_gpu_legs"] = time.perf_counter() - t0
     return out
 

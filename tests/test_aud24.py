@@ -111,7 +111,10 @@ def test_aud24_fit_restarts_run_in_lockstep_and_equal_the_sequential_loop():
     m.fit(n_restarts=6, options=opts, starts=starts)
     nb, npts = m.fit_batches_
     nll_batched = np.array(m.fit_nll_values_, dtype=float)
-    assert m.fit_driver_used_ == "setulb" and nb < npts / 3
+    # (a tick of the lock-step driver serves every live chain once, so the number of batches is the LONGEST chain's evaluation
+    # count: with these wild starts -- objective values of 1e8 -- one chain spends 32 evaluations in its line searches, the six
+    # together 79)
+    assert m.fit_driver_used_ == "setulb" and nb <= npts / 2
     w2, m2, *_ = _aud24(8)
     m2.fit(n_restarts=6, options=opts, starts=starts, batch=1)
     assert np.array_equal(nll_batched, np.array(m2.fit_nll_values_, dtype=float))
