@@ -183,6 +183,8 @@ SIGNATURES = {
     "gpcsd_fold_gemm": (_I, [_P, _I, ctypes.POINTER(_L)]),
     "gpcsd_ll_tridiag": (_I, [_P, _I, ctypes.POINTER(_L)]),
     "gpcsd_pair_share_x": (_I, [_P, _I, ctypes.POINTER(_L)]),
+    "gpcsd_band_tail": (_I, [_P, _I, ctypes.POINTER(_L)]),
+    "gpcsd_debug_sybrd": (_I, [_P, _DP, _I, _DP, _DP, _DP]),
     "gpcsd_tail_early_exit": (_I, [_P, _I, ctypes.POINTER(_I)]),
     "gpcsd_debug_fault_stage2": (_I, [_P, _I]),
     "gpcsd_decomposition_cache": (_I, [_P, _I, ctypes.POINTER(_L)]),
@@ -582,6 +584,14 @@ class Context:
         self._check(self._lib.gpcsd_debug_sytrd(self._h, _ptr(A), n, _ptr(d), _ptr(e), _ptr(V), _ptr(tau)))
         return d, e[:n - 1], V, tau
 
+    def debug_sybrd(self, A):
+        """Band tail on its own: (band (5, n) with band[j, k] = B[k + j, k], reflectors V (n, n) by rows, tau (n)) of A = Q B Q^T."""
+        A = _arr(A)
+        n = A.shape[0]
+        band, tau, V = np.empty((5, n)), np.empty(n), np.empty((n, n))
+        self._check(self._lib.gpcsd_debug_sybrd(self._h, _ptr(A), n, _ptr(band), _ptr(V), _ptr(tau)))
+        return band, V, tau
+
     def debug_stedc(self, d, e):
         d, e = _arr(d).reshape(-1), _arr(e).reshape(-1)
         n = d.size
@@ -775,6 +785,13 @@ class Context:
         when their temporal hyper-parameters are equal; returns the number of paired calls that shared it."""
         n = _L(0)
         self._check(self._lib.gpcsd_pair_share_x(self._h, -1 if on is None else int(bool(on)), ctypes.byref(n)))
+        return int(n.value)
+
+    def band_tail(self, on=None):
+        """Switch (True/False) or query (None) the band form of the temporal side for consumers in the basis U (x) Q (DESIGN 4.11);
+        returns the number of temporal chains that took it."""
+        n = _L(0)
+        self._check(self._lib.gpcsd_band_tail(self._h, -1 if on is None else int(bool(on)), ctypes.byref(n)))
         return int(n.value)
 
     def tail_early_exit(self, on=None):

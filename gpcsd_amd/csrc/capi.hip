@@ -400,7 +400,16 @@ struct EigState {
     // stage-1 outputs are still those of this temporal problem), replica `tri_rep` of the temporal classes is this call's
     bool tri = false, wait_q = false;
     int tri_rep = 0, tri_count = 1;
+    int band = 0;                  // tri: half-bandwidth of what the temporal chain left (0: tridiagonal d / e; 4: EigArenaView::bd)
 };
+
+// May a staged temporal chain whose consumers all take the basis U (x) Q stop at the band form?  Both halves must fit the band tail
+// and the banded solve kernel (the log-likelihood's kernel takes what the tail can hold).  gpcsd_band_tail(ctx, 0) / GPCSD_BAND_TAIL=0.
+static bool band_tail_applies(const gpcsd_ctx *c, const SymDev *sym_t, int R, bool with_predict) {
+    if (!c->band_tail || !sym_t) return false;
+    const int hi = std::max(sym_t->ns, sym_t->na);
+    return hi <= bt_max_rows() && hi > 8 && (!with_predict || k_band_solve_pass(hi, R) > 0);
+}
 
 // The prediction in the basis U (x) Q as well (k_tridiag_solve instead of (W V) / D): with it NO consumer of a staged temporal
 // chain reads the spectrum or the eigenvectors, and the chain ends at the tridiagonalisation + Q -- divide & conquer and
@@ -613,8 +622,13 @@ EigState front_half(gpcsd_ctx *c, const gpcsd_hparams *hp, double jitter, bool n
                 // starts its tail behind stage 3 and never waits for stages 2 and 4.
                 const bool tri = tri_consumer;
                 int *late = e.status + gpcsd_ctx::STATUS_LATE;    // stages 2 and 4 report here (gpcsd_ctx::STATUS_LATE)
+                // a chain that stops behind stages 1 + 3 may stop at the band form (nobody reads the spectrum)
+                c->band_req = (tri && band_tail_applies(c, sym_t, c->ntrials, true)) ? 4 : 0;
+                c->tri_band[c->tgen] = c->band_req;
+                if (c->band_req) ++c->band_tail_calls;
                 eigh_pair_device(c, nullptr, 0, nullptr, nullptr, nullptr, Kt, nt, e.et, e.Qt, sym_t, e.status + 1, s2, need_merged, 1, 0,
                                  -1, 2, /*stage=*/1);
+                c->band_req = 0;
                 GP_HIP(hipEventRecord(c->ev_t1, s2));
                 if (!tri)
                     eigh_pair_device(c, nullptr, 0, nullptr, nullptr, nullptr, Kt, nt, e.et, e.Qt, sym_t, late + 1, s2, need_merged, 1, 0,
@@ -634,6 +648,7 @@ EigState front_half(gpcsd_ctx *c, const gpcsd_hparams *hp, double jitter, bool n
                                      -1, 2, /*stage=*/4);
                 }
                 e.tri = e.wait_q = tri;
+                e.band = tri ? c->tri_band[c->tgen] : 0;
                 c->decomp_t_full = !tri;
             } else {
                 eigh_pair_device(c, nullptr, 0, nullptr, nullptr, nullptr, Kt, nt, e.et, e.Qt, sym_t, e.status + 1, s2, need_merged, 1, 0,
@@ -666,6 +681,7 @@ EigState front_half(gpcsd_ctx *c, const gpcsd_hparams *hp, double jitter, bool n
     if (!run_t) e.wait_temporal = true;
     if (!run_t && tri_consumer) {    // the temporal side is reused from the cache and its stage-1 outputs are those of this problem
         e.tri = true;
+        e.band = c->tri_band[c->tgen];
         e.wait_q = c->q_queued[c->tgen];      // (the stage 3 that left Q there may still be running)
     }
     e.d_sig = c->upload_cached<double>("sig2n", hp->sig2n, hp->n_sig2n);
@@ -897,6 +913,7 @@ extern "C" int gpcsd_ctx_create(int device, gpcsd_ctx **out) {
         if (const char *ev = getenv("GPCSD_LL_TRIDIAG")) c->ll_tridiag_mode = ev[0] == '0' ? 0 : ev[0] == '1' ? 1 : 2;
         if (const char *ev = getenv("GPCSD_TAIL_EARLY_EXIT")) c->tail_early_exit = ev[0] != '0';
         if (const char *ev = getenv("GPCSD_PAIR_SHARE_X")) c->pair_share_x = ev[0] != '0';
+        if (const char *ev = getenv("GPCSD_BAND_TAIL")) c->band_tail = ev[0] != '0';
         GP_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
         // The two chains are the critical path and made of small launches; when they run beside another call's GEMM tail
         // (thousands of workgroups) each of those launches would otherwise queue behind the tiles: high priority.

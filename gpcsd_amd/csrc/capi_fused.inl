@@ -78,17 +78,20 @@ static bool loglik_tri_tail(gpcsd_ctx *c, EigState &e, const FoldMode &fm, const
         fold_proj_spatial(c, fm.fs, X, W, (long)R * nt, s);
     }
     const char *const *tg = eigh_fold_tags(c, 1);
-    const double *d[2], *ee[2], *am[2];
+    const double *d[2], *ee[2], *am[2], *bd[2];
     int np[2], c0[2];
     for (int p = 0; p < 2; ++p) {
         np[p] = p ? fm.ft.na : fm.ft.ns;
         c0[p] = p ? fm.ft.ns : 0;
         const EigArenaView av = eigh_arena_view(c, tg[p], np[p], e.tri_count);
         const long o = (long)e.tri_rep * av.blk;
-        d[p] = av.d + o; ee[p] = av.e + o; am[p] = av.amax + o;
+        d[p] = av.d + o; ee[p] = av.e + o; am[p] = av.amax + o; bd[p] = av.bd + o;
     }
-    const bool wrote = k_ll_tridiag(c, W, fm.fs.w, d, ee, am, e.d_sig, nx, R, nt, np, c0, e.scal, e.scal + 1, s, host_slot,
-                                    e.scal + gpcsd_ctx::SCAL_N, gpcsd_ctx::SCAL_N, gpcsd_ctx::RESULT_DOUBLES - gpcsd_ctx::SCAL_N);
+    const bool wrote = e.band
+        ? k_ll_band(c, W, fm.fs.w, bd, np, am, e.d_sig, nx, R, nt, np, c0, e.scal, e.scal + 1, s, host_slot,
+                    e.scal + gpcsd_ctx::SCAL_N, gpcsd_ctx::SCAL_N, gpcsd_ctx::RESULT_DOUBLES - gpcsd_ctx::SCAL_N)
+        : k_ll_tridiag(c, W, fm.fs.w, d, ee, am, e.d_sig, nx, R, nt, np, c0, e.scal, e.scal + 1, s, host_slot,
+                       e.scal + gpcsd_ctx::SCAL_N, gpcsd_ctx::SCAL_N, gpcsd_ctx::RESULT_DOUBLES - gpcsd_ctx::SCAL_N);
     GP_HIP(hipEventRecord(c->ev_tri_done[c->tgen], s));
     c->tri_reader_queued[c->tgen] = true;
     return wrote;
@@ -375,16 +378,17 @@ static int predict_fold(gpcsd_ctx *c, const gpcsd_hparams *hp, EigState &e, cons
     if (e.tri) {
         // Bm~ = the solutions of the shifted tridiagonal systems (es[x'] m T_p + sig2 I) b = w, row by row of W~ = diag(U)^T Y~ Q
         const char *const *tg = eigh_fold_tags(c, 1);
-        const double *d[2], *ee[2], *am[2];
+        const double *d[2], *ee[2], *am[2], *bd[2];
         int np[2], c0[2];
         for (int p = 0; p < 2; ++p) {
             np[p] = p ? nta : nts;
             c0[p] = p ? nts : 0;
             const EigArenaView av = eigh_arena_view(c, tg[p], np[p], e.tri_count);
             const long o = (long)e.tri_rep * av.blk;
-            d[p] = av.d + o; ee[p] = av.e + o; am[p] = av.amax + o;
+            d[p] = av.d + o; ee[p] = av.e + o; am[p] = av.amax + o; bd[p] = av.bd + o;
         }
-        k_tridiag_solve(c, W, Bm, fm.fs.w, d, ee, am, e.d_sig, nx, R, nt, np, c0, s);
+        if (e.band) k_band_solve(c, W, Bm, fm.fs.w, bd, np, am, e.d_sig, nx, R, nt, np, c0, s);
+        else k_tridiag_solve(c, W, Bm, fm.fs.w, d, ee, am, e.d_sig, nx, R, nt, np, c0, s);
         GP_HIP(hipEventRecord(c->ev_tri_done[c->tgen], s));     // the last reader of Q / the tridiagonal on this stream
         c->tri_reader_queued[c->tgen] = true;
     } else {
@@ -638,7 +642,12 @@ static void front_half_pair(gpcsd_ctx *c, const gpcsd_hparams *const hp[2], cons
         {
             ProfScope ps(c, part == 2 ? "eigh_temporal_stage2" : "eigh_temporal", part == 2 ? 0.0 : 9.0 * (double)nt * nt * nt * nT, s2);
             if (staged && part == 1) {   // the log-likelihood's tail starts behind stages 1 + 3 (see front_half, EigState::tri)
+                // both consumers in the basis U (x) Q: the chain may stop at the band form (capi.hip: band_tail_applies)
+                c->band_req = (pred_tri && band_tail_applies(c, sym_t, c->ntrials, true)) ? 4 : 0;
+                c->tri_band[c->tgen] = c->band_req;
+                if (c->band_req) ++c->band_tail_calls;
                 eigh_pair_device(c, nullptr, 0, nullptr, nullptr, nullptr, Kt, nt, et, Qt, sym_t, status + 1, s2, false, nT, 2, -1, 2, 1);
+                c->band_req = 0;
                 GP_HIP(hipEventRecord(c->ev_t1, s2));
                 c->tl("T stage 1 end (s2)", s2);
                 return;
@@ -719,6 +728,7 @@ static void front_half_pair(gpcsd_ctx *c, const gpcsd_hparams *const hp[2], cons
             e.tri = e.wait_q = true;
             e.tri_rep = bt;
             e.tri_count = nT;
+            e.band = c->tri_band[c->tgen];
         }
         FoldMode &fm = out.fm[b];
         fm = fold_mode(c, hp[b], fold_s);               // replica 0 of the generations just started ...

@@ -176,6 +176,15 @@ struct gpcsd_ctx {
     int ll_tridiag_mode = 2;                // gpcsd_ll_tridiag(): log-likelihood in the basis U (x) Q -- 0 off, 1 on, 2 by size (capi.hip)
     long ll_tridiag_calls = 0;
     long fold_gemm_calls = 0;
+    // Band tail (round 5; sytrd_bandtail.hpp, band.hip): a staged temporal chain none of whose consumers reads the spectrum stops at
+    // HALF-BANDWIDTH 4 instead of a tridiagonal matrix -- one synchronisation per four columns instead of per column.
+    // band_tail: the switch (gpcsd_band_tail() / GPCSD_BAND_TAIL=0).  band_req: set by the front halves around the stage-1 call of
+    // such a chain (read by the eigensolver's problem set-up, part of its graph key).  tri_band[g]: what the last stage 1 of
+    // generation g of the temporal classes left there (0: d / e tridiagonal, 4: the band in EigArenaView::bd).
+    bool band_tail = false;                 // (off until it is the faster form: the first build measured 1.04 ms per 250-row tail against 0.585)
+    int band_req = 0;
+    int tri_band[2] = {0, 0};
+    long band_tail_calls = 0;
     bool pair_share_x = true;               // gpcsd_pair_share_x()
     long pair_shared_x_calls = 0;           // paired calls whose prediction read the log-likelihood's X = Y~ Q (capi_fused.inl)
     // Decomposition cache (capi.hip::front_half): predict() right after loglik() / fit() with the same hyper-parameters

@@ -633,6 +633,17 @@ __global__ __launch_bounds__(256) void ll_tridiag_reduce_kernel(const double *__
     if (host_slot && blockIdx.x == 0 && (int)threadIdx.x < status_doubles) host_slot[status_at + threadIdx.x] = status_src[threadIdx.x];
 }
 
+// the final sums of the per-item partials (shared with the banded form, band.hip)
+void ll_tridiag_reduce_launch(gpcsd_ctx *c, const double *partials, int nitems, double *out_sumlog, double *out_quad, double *host_slot,
+                              const double *status_src, int status_at, int status_doubles, hipStream_t s, bool *wrote) {
+    (void)c;
+    static const bool direct = !(getenv("GPCSD_LL_HOST_WRITE") && getenv("GPCSD_LL_HOST_WRITE")[0] == '0');
+    if (!direct || status_doubles > 256) host_slot = nullptr;
+    hipLaunchKernelGGL(ll_tridiag_reduce_kernel, dim3(2), dim3(256), 0, s, partials, nitems, out_sumlog, out_quad, host_slot, status_src,
+                       status_at, host_slot ? status_doubles : 0);
+    *wrote = host_slot != nullptr;
+}
+
 bool k_ll_tridiag(gpcsd_ctx *c, const double *W, const double *es, const double *const d[2], const double *const e[2],
                   const double *const amax[2], const double *sig, int nx, int R, int nt, const int np[2], const int c0[2],
                   double *out_sumlog, double *out_quad, hipStream_t s, double *host_slot, const double *status_src, int status_at,
@@ -650,12 +661,10 @@ bool k_ll_tridiag(gpcsd_ctx *c, const double *W, const double *es, const double 
         hipLaunchKernelGGL(ll_tridiag_scan_kernel, dim3(ceil_div(nitems, LT_WAVES)), dim3(64 * LT_WAVES), 0, s, g);
     else
         hipLaunchKernelGGL(ll_tridiag_kernel, dim3(ceil_div(nitems, LT_WAVES)), dim3(64 * LT_WAVES), 0, s, g);
-    static const bool direct = !(getenv("GPCSD_LL_HOST_WRITE") && getenv("GPCSD_LL_HOST_WRITE")[0] == '0');
-    if (!direct || status_doubles > 256) host_slot = nullptr;
-    hipLaunchKernelGGL(ll_tridiag_reduce_kernel, dim3(2), dim3(256), 0, s, (const double *)g.partials, nitems, out_sumlog, out_quad,
-                       host_slot, status_src, status_at, host_slot ? status_doubles : 0);
+    bool wrote = false;
+    ll_tridiag_reduce_launch(c, g.partials, nitems, out_sumlog, out_quad, host_slot, status_src, status_at, status_doubles, s, &wrote);
     GP_HIP(hipGetLastError());
-    return host_slot != nullptr;
+    return wrote;
 }
 
 // ------------------------------------------------------------------------------------------------
