@@ -7,21 +7,27 @@
 // and a cross-wave reduction PER COLUMN (2.3 us x 250 columns: the period of the cfg3 step).  Reducing to a band of width 4
 // takes the same flops but synchronises once per PANEL of four columns:
 //
-//   QR   the wave that owns the panel's four rows (= columns, by symmetry) factors the part of the panel below the band by
-//        four Householder reflectors, wave-local (no barrier): V (m x 4), the compact-WY factor T (4 x 4) with
-//        Q_p = I - V T V^T, and the panel's band entries (the 4 x 4 diagonal block and the triangle R);
+//   QR   ONE wave factors the part of the panel below the band by four Householder reflectors, wave-local (no barrier): V (m x 4),
+//        the compact-WY factor T (4 x 4) with Q_p = I - V T V^T, and the panel's band entries (the triangle R);
 //   A    barrier;  X = A22 V  (four matrix-vector products in one pass over the tile: 192 FMAs per thread, one reduce-scatter);
-//   B    barrier;  wave 0: H = V^T X, M = T^T H T;
-//   C    barrier;  thread i: Z_i = X_i T - V_i M / 2;
+//   B    barrier;  wave 0: H = V^T X, M = T^T H T / 2;
+//   C    barrier;  thread i: Z_i = X_i T - V_i M;  the reflectors and the band entries go to global memory; the NEXT panel's
+//        rows are published (as they are before this panel's update);
 //   D    barrier;  A22 -= Z V^T + V Z^T  (rank 8: 384 FMAs per thread).
 //
-// Four barriers and one serial section per four columns instead of eight and four.  The reflectors go to SytrdProb::V / tau in
-// the layout of the tridiagonal tail (row k = reflector k, support from row k + 4 on), so the compact-WY machinery that forms
-// Q (wy.hip) takes them unchanged; the band goes to SytrdProb::bd as bd[j * n + k] = B[k + j][k], j = 0 .. 4.
+// Who factors the panel.  Strip phase: the wave that owns the panel's four strip rows (it wrote them itself).  Block phase: WAVE 0,
+// from the published rows, to which it first applies the previous panel's update itself (a 4 x 192 slice of phase D in the
+// factorisation's own lane layout).  Wave 0 owns block rows 0 .. 15: from the fifth block panel on its tile is dead, it skips
+// phase D and factors panel p + 1 WHILE the other waves update with panel p -- the one serial section of a panel disappears
+// behind the update.
+//
+// Four barriers per four columns instead of eight.  The reflectors go to SytrdProb::V / tau in the layout of the tridiagonal tail
+// (row k = reflector k, support from row k + 4 on), so the compact-WY machinery that forms Q (wy.hip) takes them unchanged; the
+// band goes to SytrdProb::bd as bd[j * n + k] = B[k + j][k], j = 0 .. 4.
 //
 // Data layout as in sytrd_regtail.hpp: the trailing <= 192 rows / columns as 4 x 12 tiles in the registers of 768 threads, the
 // S = T - 192 (rounded up to a multiple of 4) leading rows as a strip in LDS; strip rows are dealt to the waves in GROUPS OF FOUR
-// (group g -> wave g mod 12) so that a panel's four rows belong to one wave.  Only whole problems (k_tail == 0, n <= 256).
+// (group g -> wave g mod 12) so that a panel's four rows belong to one wave.  Only whole problems (k_tail == 0, n <= bt_max_rows()).
 #pragma once
 
 namespace gpcsd {
@@ -30,7 +36,12 @@ constexpr int BT_W = 4;                                             // half-band
 static_assert(BT_W == RT_R, "a panel is one row group of a wave");
 
 __host__ __device__ inline int bt_strip_rows(int T) { return T > RT_T ? ((T - RT_T + 3) & ~3) : 0; }
-inline size_t bt_lds_bytes(int T) { return ((size_t)bt_strip_rows(T) * rt_strip_ld(T) + 8) * sizeof(double); }
+// dynamic LDS: the strip, or (block phase, on the same storage) two generations of the published panel rows
+inline size_t bt_lds_bytes(int T) {
+    const size_t strip = ((size_t)bt_strip_rows(T) * rt_strip_ld(T) + 8) * sizeof(double);
+    const size_t pan = ((size_t)2 * BT_W * RT_T + (size_t)64 * RT_R * RT_C) * sizeof(double);     // (+ a parked tile of wave 0)
+    return strip > pan ? strip : pan;
+}
 
 typedef double bt_d2 __attribute__((ext_vector_type(2)));
 
@@ -54,6 +65,17 @@ __device__ __forceinline__ void bt_reduce16(const double (&v)[16], int h, double
     }
 }
 
+// three wave-wide sums at once (the DPP stages of independent values interleave)
+__device__ __forceinline__ void bt_wave_sum3(double &x, double &y, double &z) {
+    x += dpp_mov<0xB1>(x); y += dpp_mov<0xB1>(y); z += dpp_mov<0xB1>(z);
+    x += dpp_mov<0x4E>(x); y += dpp_mov<0x4E>(y); z += dpp_mov<0x4E>(z);
+    x += dpp_mov<0x141>(x); y += dpp_mov<0x141>(y); z += dpp_mov<0x141>(z);
+    x += dpp_mov<0x140>(x); y += dpp_mov<0x140>(y); z += dpp_mov<0x140>(z);
+    x = (lane_get(x, 0) + lane_get(x, 16)) + (lane_get(x, 32) + lane_get(x, 48));
+    y = (lane_get(y, 0) + lane_get(y, 16)) + (lane_get(y, 32) + lane_get(y, 48));
+    z = (lane_get(z, 0) + lane_get(z, 16)) + (lane_get(z, 32) + lane_get(z, 48));
+}
+
 __global__ __launch_bounds__(RT_NTH) void sybrd_btail_kernel(SytrdBatch b) {
     const SytrdProb P = sy_resolve(b, blockIdx.x);
     const int n = P.n;
@@ -63,18 +85,19 @@ __global__ __launch_bounds__(RT_NTH) void sybrd_btail_kernel(SytrdBatch b) {
     const int S = bt_strip_rows(T), LDT = rt_strip_ld(T);
     const int TB = T - S;                                            // live rows of the register block, <= RT_T
     const int OFF = RT_SMAX - S;                                     // slot of tail-global index 0 in the LDS vectors
-    extern __shared__ __attribute__((aligned(16))) double strip[];   // [S][LDT]
+    extern __shared__ __attribute__((aligned(16))) double strip[];   // [S][LDT]; block phase: panA[2][BT_W][RT_T]
     __shared__ __attribute__((aligned(16))) double sV[2][RT_TMAX][BT_W];      // the panel's reflectors, [slot][j]; double-buffered
     __shared__ __attribute__((aligned(16))) double sX[RT_TMAX][BT_W];         // X = A V, then Z in place
-    __shared__ __attribute__((aligned(16))) double pan[BT_W][RT_TMAX];        // the panel's rows (block phase) / its final values
     __shared__ __attribute__((aligned(16))) double part[RT_NW][4][16];        // cross-row partial sums of a wave's strip groups
     __shared__ __attribute__((aligned(16))) double sT[BT_W][BT_W], sM[BT_W][BT_W], sH[BT_W * BT_W];
+    __shared__ double panb[2][BT_W][BT_W];                           // R of the panel: panb[.][j][i] = R[i][j], i <= j (R[j][j] = beta_j)
     __shared__ double stau[RT_TMAX];
     __shared__ int s_live;                                           // any reflector of the current panel with tau != 0
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int gg = lane >> 4, h = lane & 15;
     const int row0 = 16 * wid + 4 * gg, c0 = RT_C * h;
     const double *__restrict__ Ain = P.A0;
+    double (*const panA)[BT_W][RT_T] = reinterpret_cast<double (*)[BT_W][RT_T]>(strip);
 
     // ---- load: the block into registers, the strip into LDS, vectors cleared
     double a[RT_R][RT_C];
@@ -101,107 +124,100 @@ __global__ __launch_bounds__(RT_NTH) void sybrd_btail_kernel(SytrdBatch b) {
     // ------------------------------------------------------------------------------------------------------------
     // Householder QR of a panel held as w[j][q]: row j of the panel (= matrix column first + j), the lane's NQ entries at the
     // (phase-specific) column indices colq[q]; pv0 = index of the first pivot (first + 4), nlim = columns that exist.  The wave
-    // works alone.  On return: pan[j][slot0 + c] holds the panel's final values up to the pivots (R on and above them), w[j][q] the
-    // reflectors (zero outside their support: the rows' registers are reused), tau[j], and lane 0 has written T to sT.
-    // pick(x, c): the entry at column c, every lane.
+    // works alone.  On return w[j][q] holds the reflectors (zero outside their support: the rows' registers are reused), tau[j];
+    // lane 0 has written T to sT, R to panb[gen] and s_live.  pick(x, c): the entry at column c, every lane (uniform).
+    // Per column: the finished entries left of and at the pivot are read out (R) and zeroed, so the norm and the products below
+    // need no masks; the products with the later columns (for their update) and with the earlier reflectors (for T) are three
+    // values however far the panel is, reduced together.
     // ------------------------------------------------------------------------------------------------------------
-    auto house4 = [&](auto &w, double (&tau)[BT_W], const auto &colq, auto NQc, int pv0, int nlim, int slot0, int clim, auto pick) {
+    auto house4 = [&](auto &w, double (&tau)[BT_W], const auto &colq, auto NQc, int pv0, int nlim, int gen, auto pick) {
         constexpr int NQ = decltype(NQc)::value;
+        double Tm[BT_W][BT_W];                                       // upper triangle, built column by column (LAPACK dlarft)
 #pragma unroll
         for (int j = 0; j < BT_W; ++j) {
             const int pv = pv0 + j;
+            double rj[BT_W];                                         // R[i][j], i < j: the column's entries at the earlier pivots
+#pragma unroll
+            for (int i = 0; i < j; ++i) rj[i] = pick(w[j], pv0 + i);
+            const double alpha = pick(w[j], pv);
             double sq = 0.0;
 #pragma unroll
             for (int q = 0; q < NQ; ++q) {
-                const double m = (colq[q] > pv && colq[q] < nlim) ? w[j][q] : 0.0;
-                sq = fma(m, m, sq);
+                w[j][q] = (colq[q] > pv && colq[q] < nlim) ? w[j][q] : 0.0;
+                sq = fma(w[j][q], w[j][q], sq);
             }
-            const double alpha = pick(w[j], pv);
             const double xnorm2 = wave_sum(sq);
             double r, u1, beta;
             rt_house(alpha, xnorm2, pv < nlim - 1, r, u1, beta);
             tau[j] = (r != 0.0) ? r * fast_rcp(fabs(u1)) : 0.0;
+            if (r != 0.0) {                                          // uniform
 #pragma unroll
-            for (int q = 0; q < NQ; ++q) {
-                const int c = colq[q];
-                const double x = w[j][q];
-                // the row's final values go to pan (left of the pivot untouched, beta at it; nobody reads beyond it) and its
-                // registers become the reflector
-                if (c < clim) pan[j][slot0 + c] = (c == pv) ? beta : x;
-                double t = (c > pv && c < nlim) ? x : 0.0;
-                t = (c == pv) ? u1 : t;
-                w[j][q] = (r != 0.0) ? t : 0.0;
+                for (int q = 0; q < NQ; ++q) w[j][q] = (colq[q] == pv) ? u1 : w[j][q];
+            } else {
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) w[j][q] = 0.0;
             }
-            double dp[BT_W];
+            if (lane == 0) {
 #pragma unroll
-            for (int jp = j + 1; jp < BT_W; ++jp) {
+                for (int i = 0; i < j; ++i) panb[gen][j][i] = rj[i];
+                panb[gen][j][j] = beta;                              // (= alpha when the reflector is the identity)
+            }
+            // d[g] = v_j . (vector of row g): g > j -> the later column (update), g < j -> the earlier reflector (T)
+            double d3[3];
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+                const int g = t < j ? t : t + 1;                     // the three rows other than j
                 double s = 0.0;
 #pragma unroll
-                for (int q = 0; q < NQ; ++q) s = fma(w[j][q], w[jp][q], s);
-                dp[jp] = s;
+                for (int q = 0; q < NQ; ++q) s = fma(w[j][q], w[g][q], s);
+                d3[t] = s;
             }
+            bt_wave_sum3(d3[0], d3[1], d3[2]);
 #pragma unroll
-            for (int jp = j + 1; jp < BT_W; ++jp) dp[jp] = wave_sum(dp[jp]);
+            for (int t = j; t < 3; ++t) {                            // later columns g = t + 1
+                const double f = tau[j] * d3[t];
 #pragma unroll
-            for (int jp = j + 1; jp < BT_W; ++jp) {
-                const double f = tau[j] * dp[jp];
-#pragma unroll
-                for (int q = 0; q < NQ; ++q) w[jp][q] = fma(-f, w[j][q], w[jp][q]);
+                for (int q = 0; q < NQ; ++q) w[t + 1][q] = fma(-f, w[j][q], w[t + 1][q]);
             }
-        }
-        // T = (diag(1 / tau) + striu(V^T V))^-1, column by column (LAPACK dlarft): T[:i, i] = -tau_i T[:i, :i] (V_{:i}^T v_i)
-        double g[BT_W][BT_W];
+            // T[:j, j] = -tau_j T[:j, :j] (V_{:j}^T v_j),  T[j][j] = tau_j
 #pragma unroll
-        for (int i = 0; i < BT_W; ++i)
+            for (int l = 0; l < BT_W; ++l) Tm[l][j] = 0.0;
+            Tm[j][j] = tau[j];
 #pragma unroll
-            for (int jp = i + 1; jp < BT_W; ++jp) {
+            for (int l = 0; l < j; ++l) {
                 double s = 0.0;
 #pragma unroll
-                for (int q = 0; q < NQ; ++q) s = fma(w[i][q], w[jp][q], s);
-                g[i][jp] = s;
-            }
-#pragma unroll
-        for (int i = 0; i < BT_W; ++i)
-#pragma unroll
-            for (int jp = i + 1; jp < BT_W; ++jp) g[i][jp] = wave_sum(g[i][jp]);
-        double Tm[BT_W][BT_W];
-#pragma unroll
-        for (int i = 0; i < BT_W; ++i)
-#pragma unroll
-            for (int jp = 0; jp < BT_W; ++jp) Tm[i][jp] = 0.0;
-#pragma unroll
-        for (int i = 0; i < BT_W; ++i) {
-            Tm[i][i] = tau[i];
-#pragma unroll
-            for (int l = 0; l < i; ++l) {
-                double s = 0.0;
-#pragma unroll
-                for (int m2 = l; m2 < i; ++m2) s = fma(Tm[l][m2], g[m2][i], s);
-                Tm[l][i] = -tau[i] * s;
+                for (int m2 = l; m2 < j; ++m2) s = fma(Tm[l][m2], d3[m2], s);
+                Tm[l][j] = -tau[j] * s;
             }
         }
         if (lane == 0) {
 #pragma unroll
             for (int i = 0; i < BT_W; ++i)
 #pragma unroll
-                for (int jp = 0; jp < BT_W; ++jp) sT[i][jp] = Tm[i][jp];
+                for (int jp = 0; jp < BT_W; ++jp) sT[i][jp] = (jp >= i) ? Tm[i][jp] : 0.0;
             s_live = (tau[0] != 0.0 || tau[1] != 0.0 || tau[2] != 0.0 || tau[3] != 0.0) ? 1 : 0;
         }
     };
 
-    // the band entries of the panel's four columns, from pan[j][slot] (final values): bd[d][first + j] = B[first + j + d][first + j]
-    auto emit_band = [&](int first, int slot_first, int nlim) {      // first: tail-global column of panel row 0; nlim in the same units
-        if (lane < BT_W * (BT_W + 1)) {
-            const int j = lane / (BT_W + 1), d = lane - j * (BT_W + 1);
-            if (first + j + d < nlim) P.bd[(long)d * n + first + j] = pan[j][slot_first + j + d];
-        }
-    };
-
-    int pc = 0;                                                      // panel counter: V buffer pc & 1
-    // one panel's phases A .. D for everybody; `first` = tail-global index of the panel's first column
-    auto panel_rest = [&](const int first, const bool in_strip) {
+    int pc = 0;                                                      // panel counter: generation pc & 1 of sV / panb / panA
+#ifdef BT_PHASE_CLK
+    // tuning aid (a build with -DBT_PHASE_CLK): thread 0 accumulates the device clock between the barriers of a panel -- [0] up to A
+    // (the factorisation, or the wait for it), [1] A..B (X), [2] B..C (H, M), [3] C..D (Z), [4] D..end (update); [5] wave 0's
+    // own factorisations -- and leaves the sums in the unused corner of the band array
+    unsigned long long pclk[6] = {0, 0, 0, 0, 0, 0}, plast = wall_clock64();
+#define BT_STAMP(k) do { const unsigned long long t_ = wall_clock64(); pclk[k] += t_ - plast; plast = t_; } while (0)
+#else
+#define BT_STAMP(k) do { } while (0)
+#endif
+    // ------------------------------------------------------------------------------------------------------------
+    // phases A .. D of one panel for everybody.  `first` = tail-global index of the panel's first column
+    // ------------------------------------------------------------------------------------------------------------
+    auto panel_rest = [&](const int first, auto in_strip_c, const bool publish_next) {
+        constexpr bool in_strip = decltype(in_strip_c)::value;
         double (*const sv)[BT_W] = sV[pc & 1];
-        __syncthreads();                                             // ---- A: V, T, tau published
+        lds_barrier();                                               // ---- A: V, T, tau published
+        BT_STAMP(0);
         const bool plive = s_live != 0;                              // uniform
         const int lo = first + BT_W;                                 // first live tail-global index
         const int blk_lo = lo - S;                                   // ... as a block-local index (<= 0 in the strip phase)
@@ -212,26 +228,25 @@ __global__ __launch_bounds__(RT_NTH) void sybrd_btail_kernel(SytrdBatch b) {
             if (in_strip) {
                 const int cA = 2 * lane, cB = 128 + 2 * lane;
                 const bool okB = cB < T;
-                double vc[4][BT_W];                                  // V at the lane's four columns
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int c = ((q & 2) ? cB : cA) + (q & 1);
-                    const bool ok = (q & 2) ? okB : true;
-                    const bt_d2 v01 = ok ? *reinterpret_cast<const bt_d2 *>(&sv[OFF + c][0]) : bt_d2{0.0, 0.0};
-                    const bt_d2 v23 = ok ? *reinterpret_cast<const bt_d2 *>(&sv[OFF + c][2]) : bt_d2{0.0, 0.0};
-                    vc[q][0] = v01.x; vc[q][1] = v01.y; vc[q][2] = v23.x; vc[q][3] = v23.y;
-                }
                 const int gfirst = first / BT_W + 1;
                 for (int g = gfirst + (wid - gfirst % RT_NW + RT_NW) % RT_NW; g < S / BT_W; g += RT_NW) {
                     double pr[16];
 #pragma unroll
-                    for (int ar = 0; ar < 4; ++ar) {
-                        const double *__restrict__ row = strip + (BT_W * g + ar) * LDT;
-                        const bt_d2 ra = *reinterpret_cast<const bt_d2 *>(row + cA);
-                        const bt_d2 rb = okB ? *reinterpret_cast<const bt_d2 *>(row + cB) : bt_d2{0.0, 0.0};
+                    for (int i = 0; i < 16; ++i) pr[i] = 0.0;
+#pragma unroll 1
+                    for (int half = 0; half < 2; ++half) {           // the lane's column pair (cA | cB), one at a time (registers)
+                        if (half == 1 && !okB) break;
+                        const int cc = half ? cB : cA;
+                        const bt_d2 va01 = *reinterpret_cast<const bt_d2 *>(&sv[OFF + cc][0]), va23 = *reinterpret_cast<const bt_d2 *>(&sv[OFF + cc][2]);
+                        const bt_d2 vb01 = *reinterpret_cast<const bt_d2 *>(&sv[OFF + cc + 1][0]), vb23 = *reinterpret_cast<const bt_d2 *>(&sv[OFF + cc + 1][2]);
 #pragma unroll
-                        for (int k = 0; k < BT_W; ++k)
-                            pr[4 * ar + k] = fma(rb.y, vc[3][k], fma(rb.x, vc[2][k], fma(ra.y, vc[1][k], ra.x * vc[0][k])));
+                        for (int ar = 0; ar < 4; ++ar) {
+                            const bt_d2 ra = *reinterpret_cast<const bt_d2 *>(strip + (BT_W * g + ar) * LDT + cc);
+                            pr[4 * ar + 0] = fma(ra.y, vb01.x, fma(ra.x, va01.x, pr[4 * ar + 0]));
+                            pr[4 * ar + 1] = fma(ra.y, vb01.y, fma(ra.x, va01.y, pr[4 * ar + 1]));
+                            pr[4 * ar + 2] = fma(ra.y, vb23.x, fma(ra.x, va23.x, pr[4 * ar + 2]));
+                            pr[4 * ar + 3] = fma(ra.y, vb23.y, fma(ra.x, va23.y, pr[4 * ar + 3]));
+                        }
                     }
                     double o4[4];
                     bt_reduce16(pr, h, o4);                          // o4[a]: DPP-row sum of (row a, vector h & 3)
@@ -289,7 +304,8 @@ __global__ __launch_bounds__(RT_NTH) void sybrd_btail_kernel(SytrdBatch b) {
                 sX[RT_SMAX + i][h & 3] = (i >= blk_lo && i < TB) ? xv : 0.0;
             }
         }
-        __syncthreads();                                             // ---- B: X published
+        lds_barrier();                                               // ---- B: X published
+        BT_STAMP(1);
         if (plive && wid == 0) {
             // H = V^T X over the live indices (lane l: slots l, l + 64, ..), then M = T^T H T / 2
             double hp[16];
@@ -328,13 +344,16 @@ __global__ __launch_bounds__(RT_NTH) void sybrd_btail_kernel(SytrdBatch b) {
                 sM[ia][ib] = 0.5 * s;
             }
         }
-        __syncthreads();                                             // ---- C: M published
+        lds_barrier();                                               // ---- C: M published
+        BT_STAMP(2);
         if (tid < RT_TMAX) {                                         // Z_i = X_i T - V_i M, in place of X (dead / padding slots: zero)
             const int gidx = tid - OFF;
+            const bt_d2 v01 = *reinterpret_cast<const bt_d2 *>(&sv[tid][0]), v23 = *reinterpret_cast<const bt_d2 *>(&sv[tid][2]);
             double z[4] = {0.0, 0.0, 0.0, 0.0};
             if (plive && gidx >= lo && gidx < T) {
-                const double xx[4] = {sX[tid][0], sX[tid][1], sX[tid][2], sX[tid][3]};
-                const double vv[4] = {sv[tid][0], sv[tid][1], sv[tid][2], sv[tid][3]};
+                const bt_d2 x01 = *reinterpret_cast<const bt_d2 *>(&sX[tid][0]), x23 = *reinterpret_cast<const bt_d2 *>(&sX[tid][2]);
+                const double xx[4] = {x01.x, x01.y, x23.x, x23.y};
+                const double vv[4] = {v01.x, v01.y, v23.x, v23.y};
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     double s = 0.0;
@@ -345,10 +364,38 @@ __global__ __launch_bounds__(RT_NTH) void sybrd_btail_kernel(SytrdBatch b) {
                     z[k] = s;
                 }
             }
-#pragma unroll
-            for (int k = 0; k < 4; ++k) sX[tid][k] = z[k];
+            *reinterpret_cast<bt_d2 *>(&sX[tid][0]) = bt_d2{z[0], z[1]};
+            *reinterpret_cast<bt_d2 *>(&sX[tid][2]) = bt_d2{z[2], z[3]};
+            // the panel's reflectors to global memory (row first + j of V, tail-global column gidx)
+            if (gidx >= 0 && gidx < T) {
+                double *__restrict__ vg = P.V + (long)first * n + gidx;
+                vg[0] = v01.x; vg[n] = v01.y; vg[2 * (long)n] = v23.x; vg[3 * (long)n] = v23.y;
+            }
+        } else if (tid < RT_TMAX + BT_W * (BT_W + 1)) {
+            // the band entries of the panel's four columns: bd[d][first + j] = B[first + j + d][first + j]
+            const int e = tid - RT_TMAX, j = e / (BT_W + 1), d = e - j * (BT_W + 1);
+            if (first + j + d < T) {
+                double val;
+                if (d < BT_W - j) {                                  // inside the diagonal block: the panel row's own entry
+                    if (in_strip) val = strip[(first + j) * LDT + first + j + d];
+                    else val = panA[pc & 1][j][first - S + j + d];
+                } else {
+                    val = panb[pc & 1][j][j + d - BT_W];             // R[i][j] with first + 4 + i = first + j + d
+                }
+                P.bd[(long)d * n + first + j] = val;
+            }
         }
-        __syncthreads();                                             // ---- D: Z published
+        if (publish_next) {                                          // the next block panel's rows, as they are before this panel's update
+            const int nk = blk_lo;                                   // its first block row
+            if (wid == (nk >> 4) && gg == ((nk >> 2) & 3)) {
+#pragma unroll
+                for (int r = 0; r < RT_R; ++r)
+#pragma unroll
+                    for (int j = 0; j < RT_C; j += 2) *reinterpret_cast<bt_d2 *>(&panA[(pc + 1) & 1][r][c0 + j]) = bt_d2{a[r][j], a[r][j + 1]};
+            }
+        }
+        lds_barrier();                                               // ---- D: Z published
+        BT_STAMP(3);
         if (plive) {
             // ---- A22 -= Z V^T + V Z^T
             if (in_strip) {
@@ -388,8 +435,6 @@ __global__ __launch_bounds__(RT_NTH) void sybrd_btail_kernel(SytrdBatch b) {
                 }
             }
             if (wlive) {
-                // the wave that factors the next panel is the critical path: its update goes first
-                if (!in_strip && wid == ((blk_lo) >> 4)) __builtin_amdgcn_s_setprio(3);
 #pragma unroll
                 for (int kh = 0; kh < 4; kh += 2) {                  // two vectors at a time (registers)
                     double zr[RT_R][2], vr[RT_R][2];
@@ -414,17 +459,17 @@ __global__ __launch_bounds__(RT_NTH) void sybrd_btail_kernel(SytrdBatch b) {
                         }
                     }
                 }
-                __builtin_amdgcn_s_setprio(0);
             }
         }
         ++pc;
+        BT_STAMP(4);
     };
 
     // ------------------------------------------------------------------------------------------------------------
     // strip panels: first = 0, 4, .. < S.  The panel's rows are strip rows of group first / 4, written by their owner wave itself
     // ------------------------------------------------------------------------------------------------------------
+#pragma unroll 1
     for (int first = 0; first < S; first += BT_W) {
-        if (first + BT_W >= T - 1) break;                            // (nothing below the band any more)
         if (wid == (first / BT_W) % RT_NW) {
             __builtin_amdgcn_s_setprio(3);
             const int cA = 2 * lane, cB = 128 + 2 * lane;
@@ -438,12 +483,15 @@ __global__ __launch_bounds__(RT_NTH) void sybrd_btail_kernel(SytrdBatch b) {
                 const bt_d2 xb = okB ? *reinterpret_cast<const bt_d2 *>(row + cB) : bt_d2{0.0, 0.0};
                 w[j][0] = xa.x; w[j][1] = xa.y; w[j][2] = xb.x; w[j][3] = xb.y;
             }
-            auto pick = [&](const double (&x)[4], int c) {           // entry at tail-global column c (uniform)
+            // entry at tail-global column c (uniform).  All four candidates are read and the VALUE is selected: a select between the
+            // array's elements is turned into a run-time index by the compiler, and the array then lives in scratch memory.
+            auto pick = [&](const double (&x)[4], int c) {
                 const int l = (c < 128 ? c : c - 128) >> 1;
-                const double lo2 = (c & 1) ? x[1] : x[0], hi2 = (c & 1) ? x[3] : x[2];
-                return lane_get(c < 128 ? lo2 : hi2, l);
+                const double t0 = lane_get(x[0], l), t1 = lane_get(x[1], l), t2 = lane_get(x[2], l), t3 = lane_get(x[3], l);
+                const double lo2 = (c & 1) ? t1 : t0, hi2 = (c & 1) ? t3 : t2;
+                return c < 128 ? lo2 : hi2;
             };
-            house4(w, tau, colq, std::integral_constant<int, 4>{}, first + BT_W, T, OFF, T, pick);
+            house4(w, tau, colq, std::integral_constant<int, 4>{}, first + BT_W, T, pc & 1, pick);
             double (*const sv)[BT_W] = sV[pc & 1];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
@@ -452,69 +500,121 @@ __global__ __launch_bounds__(RT_NTH) void sybrd_btail_kernel(SytrdBatch b) {
                     *reinterpret_cast<bt_d2 *>(&sv[OFF + c][0]) = bt_d2{w[0][q], w[1][q]};
                     *reinterpret_cast<bt_d2 *>(&sv[OFF + c][2]) = bt_d2{w[2][q], w[3][q]};
                 }
-#pragma unroll
-                for (int j = 0; j < BT_W; ++j)
-                    if (c < T) P.V[(long)(first + j) * n + c] = w[j][q];
             }
             if (lane < BT_W) stau[OFF + first + lane] = tau[lane];
-            __builtin_amdgcn_wave_barrier();
-            emit_band(first, OFF + first, T);
             __builtin_amdgcn_s_setprio(0);
         }
-        panel_rest(first, true);
+        panel_rest(first, std::true_type{}, false);
     }
+    // ------------------------------------------------------------------------------------------------------------
+    // block panels (block-local first column kk = 0, 4, ..).  Wave 0 factors every one of them from the published rows.
+    // ------------------------------------------------------------------------------------------------------------
+    const int npan = TB >= BT_W + 2 ? (TB - BT_W - 2) / BT_W + 1 : 0;              // panels kk = 0, 4, .. with kk + 4 < TB - 1
+    __syncthreads();                                                 // the strip is dead: its storage becomes panA
     if (S > 0) {                                                     // the reflectors of the block panels are zero over the strip
-        __syncthreads();
         for (int idx = tid; idx < 2 * RT_SMAX * BT_W; idx += RT_NTH) {
             const int bsel = idx / (RT_SMAX * BT_W), rem = idx - bsel * RT_SMAX * BT_W;
             (&sV[bsel][0][0])[rem] = 0.0;
         }
         for (int idx = tid; idx < RT_SMAX * BT_W; idx += RT_NTH) (&sX[0][0])[idx] = 0.0;
     }
-
-    // ------------------------------------------------------------------------------------------------------------
-    // block panels (block-local first column kk = 0, 4, ..): the panel's rows are tile rows of one row group of wave kk >> 4
-    // ------------------------------------------------------------------------------------------------------------
+    if (npan > 0 && wid == 0 && gg == 0) {                           // the first block panel's rows: current (nothing pending)
+#pragma unroll
+        for (int r = 0; r < RT_R; ++r)
+#pragma unroll
+            for (int j = 0; j < RT_C; j += 2) *reinterpret_cast<bt_d2 *>(&panA[pc & 1][r][c0 + j]) = bt_d2{a[r][j], a[r][j + 1]};
+    }
+    __syncthreads();
     int kk = 0;
-    for (; kk + BT_W < TB - 1; kk += BT_W) {
-        if (wid == (kk >> 4)) {
+#pragma unroll 1
+    for (int ip = 0; ip < npan; ++ip, kk += BT_W) {
+        if (wid == 0) {
+#ifdef BT_PHASE_CLK
+            const unsigned long long tq0 = wall_clock64();
+#endif
             __builtin_amdgcn_s_setprio(3);
-            if (gg == ((kk >> 2) & 3)) {
+            // The factorisation wants the registers the wave's 4 x 12 tile occupies.  While the tile is still needed (the first
+            // three block panels; the last ones of a tiny block, whose band entries come out of the registers) it is parked in
+            // LDS behind panA for the duration -- afterwards it is dead and simply redefined: either way the compiler sees no
+            // live tile across this section.
+            const bool tile_live = (kk + BT_W <= 15) || (npan <= 3);
+            bt_d2 *const tsave = reinterpret_cast<bt_d2 *>(strip + 2 * BT_W * RT_T) + lane;
+            if (tile_live) {
 #pragma unroll
                 for (int r = 0; r < RT_R; ++r)
 #pragma unroll
-                    for (int j = 0; j < RT_C; j += 2) *reinterpret_cast<bt_d2 *>(&pan[r][RT_SMAX + c0 + j]) = bt_d2{a[r][j], a[r][j + 1]};
+                    for (int j = 0; j < RT_C; j += 2) tsave[(r * (RT_C / 2) + j / 2) * 64] = bt_d2{a[r][j], a[r][j + 1]};
             }
-            __builtin_amdgcn_wave_barrier();
             const int colq[3] = {lane, 64 + lane, 128 + lane};
             double w[BT_W][3], tau[BT_W];
 #pragma unroll
             for (int j = 0; j < BT_W; ++j)
 #pragma unroll
-                for (int q = 0; q < 3; ++q) w[j][q] = pan[j][RT_SMAX + 64 * q + lane];
-            auto pick = [&](const double (&x)[3], int c) {
-                const int q = c >> 6;
-                const double t = (q == 0) ? x[0] : (q == 1) ? x[1] : x[2];
-                return lane_get(t, c & 63);
+                for (int q = 0; q < 3; ++q) w[j][q] = panA[pc & 1][j][64 * q + lane];
+            if (ip > 0) {
+                // the rows were published before the previous panel's update: apply it here (rows kk + j, the lane's three columns)
+                double (*const svp)[BT_W] = sV[(pc - 1) & 1];
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+                    const int cs = RT_SMAX + 64 * q + lane;
+                    const bt_d2 vc01 = *reinterpret_cast<const bt_d2 *>(&svp[cs][0]), vc23 = *reinterpret_cast<const bt_d2 *>(&svp[cs][2]);
+                    const bt_d2 zc01 = *reinterpret_cast<const bt_d2 *>(&sX[cs][0]), zc23 = *reinterpret_cast<const bt_d2 *>(&sX[cs][2]);
+                    double upd[BT_W];
+#pragma unroll
+                    for (int j = 0; j < BT_W; ++j) {
+                        const int rs = RT_SMAX + kk + j;
+                        const bt_d2 vr01 = *reinterpret_cast<const bt_d2 *>(&svp[rs][0]), vr23 = *reinterpret_cast<const bt_d2 *>(&svp[rs][2]);
+                        const bt_d2 zr01 = *reinterpret_cast<const bt_d2 *>(&sX[rs][0]), zr23 = *reinterpret_cast<const bt_d2 *>(&sX[rs][2]);
+                        double e = 0.0;
+                        e = fma(zr01.x, vc01.x, e); e = fma(vr01.x, zc01.x, e);
+                        e = fma(zr01.y, vc01.y, e); e = fma(vr01.y, zc01.y, e);
+                        e = fma(zr23.x, vc23.x, e); e = fma(vr23.x, zc23.x, e);
+                        e = fma(zr23.y, vc23.y, e); e = fma(vr23.y, zc23.y, e);
+                        upd[j] = e;
+                    }
+#pragma unroll
+                    for (int j = 0; j < BT_W; ++j) w[j][q] -= upd[j];
+                }
+#pragma unroll
+                for (int j = 0; j < BT_W; ++j)
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) panA[pc & 1][j][64 * q + lane] = w[j][q];     // (the band entries are read from here)
+            }
+            auto pick = [&](const double (&x)[3], int c) {           // (values selected, not elements: see the strip phase)
+                const int q = c >> 6, l = c & 63;
+                const double t0 = lane_get(x[0], l), t1 = lane_get(x[1], l), t2 = lane_get(x[2], l);
+                return (q == 0) ? t0 : (q == 1) ? t1 : t2;
             };
-            __builtin_amdgcn_wave_barrier();
-            house4(w, tau, colq, std::integral_constant<int, 3>{}, kk + BT_W, TB, RT_SMAX, RT_T, pick);
+            house4(w, tau, colq, std::integral_constant<int, 3>{}, kk + BT_W, TB, pc & 1, pick);
             double (*const sv)[BT_W] = sV[pc & 1];
 #pragma unroll
             for (int q = 0; q < 3; ++q) {
                 const int c = 64 * q + lane;
                 *reinterpret_cast<bt_d2 *>(&sv[RT_SMAX + c][0]) = bt_d2{w[0][q], w[1][q]};
                 *reinterpret_cast<bt_d2 *>(&sv[RT_SMAX + c][2]) = bt_d2{w[2][q], w[3][q]};
-#pragma unroll
-                for (int j = 0; j < BT_W; ++j)
-                    if (c < TB) P.V[(long)(S + kk + j) * n + S + c] = w[j][q];
             }
             if (lane < BT_W) stau[RT_SMAX + kk + lane] = tau[lane];
-            __builtin_amdgcn_wave_barrier();
-            emit_band(S + kk, RT_SMAX + kk, T);
+            if (tile_live) {
+#pragma unroll
+                for (int r = 0; r < RT_R; ++r)
+#pragma unroll
+                    for (int j = 0; j < RT_C; j += 2) {
+                        const bt_d2 t2 = tsave[(r * (RT_C / 2) + j / 2) * 64];
+                        a[r][j] = t2.x;
+                        a[r][j + 1] = t2.y;
+                    }
+            } else {
+#pragma unroll
+                for (int r = 0; r < RT_R; ++r)
+#pragma unroll
+                    for (int j = 0; j < RT_C; ++j) a[r][j] = 0.0;
+            }
             __builtin_amdgcn_s_setprio(0);
+#ifdef BT_PHASE_CLK
+            pclk[5] += wall_clock64() - tq0;
+#endif
         }
-        panel_rest(S + kk, false);
+        panel_rest(S + kk, std::false_type{}, ip + 1 < npan);
     }
     // what is left of the block (columns kk ..) lies inside the band: straight out of the registers
     __syncthreads();
@@ -526,6 +626,13 @@ __global__ __launch_bounds__(RT_NTH) void sybrd_btail_kernel(SytrdBatch b) {
             if (c >= kk && i >= c && i - c <= BT_W && i < TB) P.bd[(long)(i - c) * n + S + c] = a[r][j];
         }
     for (int g = tid; g < T; g += RT_NTH) P.tau[g] = stau[OFF + g];
+#ifdef BT_PHASE_CLK
+    if (tid == 0 && n >= 8) {
+        P.bd[(long)4 * n + n - 4] = (double)pclk[0]; P.bd[(long)4 * n + n - 3] = (double)pclk[1];
+        P.bd[(long)4 * n + n - 2] = (double)pclk[2]; P.bd[(long)4 * n + n - 1] = (double)pclk[3];
+        P.bd[(long)3 * n + n - 3] = (double)pclk[4]; P.bd[(long)3 * n + n - 2] = (double)pclk[5];
+    }
+#endif
     if (b.clk && threadIdx.x == 0) b.clk[2 * blockIdx.x + 1] = wall_clock64();
 }
 

@@ -39,6 +39,15 @@ def main():
         if n >= 64:
             worst = max(worst, check_sybrd(ctx, np.ones((n, n)) + 1e-3 * np.eye(n), "rank one + small shift"))
     print("worst", worst)
+    if os.environ.get("BT_PHASE_CLK") == "1":                  # a -DBT_PHASE_CLK build leaves its phase clocks in the band's unused corner
+        for n in (188, 250):
+            t = np.arange(n) * 0.4
+            K = 0.5 * np.exp(-0.5 * (t[:, None] - t[None, :]) ** 2 / 20.0 ** 2) + 0.7 * np.exp(-np.abs(t[:, None] - t[None, :]) / 5.0)
+            K = K / np.max(np.abs(K))
+            band, V, tau = ctx.debug_sybrd(K)
+            ph = [band[4, n - 4], band[4, n - 3], band[4, n - 2], band[4, n - 1], band[3, n - 3], band[3, n - 2]]
+            print("n=%d phase clocks (us): to A %.1f  X %.1f  H/M %.1f  Z %.1f  update %.1f | wave 0's own factorisations %.1f" %
+                  tuple([n] + [0.01 * v for v in ph]))
     # timing of the tail alone (fenced debug call: upload + kernel + download; take the min of a few)
     for n in (188, 250):
         t = np.arange(n) * 0.4
