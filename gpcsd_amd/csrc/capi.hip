@@ -360,6 +360,7 @@ SymDev find_symmetry(gpcsd_ctx *c, const std::string &name, const double *pts, i
     GP_HIP(hipStreamSynchronize(c->stream));
     out.ns = ns; out.na = na;
     out.rep_i = d; out.rep_j = d + ns; out.orb = d + 2 * ns; out.sgn = d + 2 * ns + n;
+    c->sym_host[d] = std::vector<int>(tbl.begin(), tbl.begin() + 2 * ns);      // (rep_i | rep_j: the chunked copy of gpcsd_predict)
     return out;
 }
 
@@ -726,6 +727,7 @@ static SymDev identity_sym(gpcsd_ctx *c, int n) {
         GP_HIP(hipMemcpyAsync(d, tbl.data(), tbl.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
         GP_HIP(hipStreamSynchronize(c->stream));
         have = n;
+        c->sym_host[d] = std::vector<int>(tbl.begin(), tbl.begin() + 2 * n);
     }
     SymDev sy;
     sy.ns = n; sy.na = 0;
@@ -914,6 +916,7 @@ extern "C" int gpcsd_ctx_create(int device, gpcsd_ctx **out) {
         if (const char *ev = getenv("GPCSD_TAIL_EARLY_EXIT")) c->tail_early_exit = ev[0] != '0';
         if (const char *ev = getenv("GPCSD_PAIR_SHARE_X")) c->pair_share_x = ev[0] != '0';
         if (const char *ev = getenv("GPCSD_BAND_TAIL")) c->band_tail = ev[0] != '0';
+        if (const char *ev = getenv("GPCSD_PRED_CHUNKED")) c->pred_chunked = ev[0] != '0';
         GP_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
         // The two chains are the critical path and made of small launches; when they run beside another call's GEMM tail
         // (thousands of workgroups) each of those launches would otherwise queue behind the tiles: high priority.

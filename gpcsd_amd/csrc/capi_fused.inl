@@ -249,6 +249,8 @@ static const SymDev &site_symmetry(gpcsd_ctx *c, const double *z, int nz, int di
     return c->sym_z;
 }
 
+static bool pred_unfold_chunked(gpcsd_ctx *c, PredUnfoldDesc pu, int which0, int nz, size_t out_elems, bool want_lists, hipStream_t s);
+
 // predict_impl in the folded basis (see FoldMode).  Prediction sites and times must share the symmetry of the grids:
 //   out_c = Fz^T [ diag_p( (Kc_pp^T U_p) ) Bm~ diag_q( V_q^T Kt*_c,qq ) ] Ft   with Bm~ = (diag(U)^T Y~ diag(V)) / D~ ,
 // every flat GEMM split in its two parity blocks; the last pass unfolds sites and times while it transposes.
@@ -435,7 +437,7 @@ static int predict_fold(gpcsd_ctx *c, const gpcsd_hparams *hp, EigState &e, cons
             pu.R = R; pu.nt = nt; pu.C = C;
             pu.sz = sz; pu.st = fm.sym_t;
             pu.list = o_list; pu.list_stride = (long)out_elems; pu.sum = o_sum;
-            gemm_pred_unfold(c, pu, s);
+            if (!pred_unfold_chunked(c, pu, which - 1, nz, out_elems, want_lists, s)) gemm_pred_unfold(c, pu, s);
         } else {
             gemm_pair(c, g6[0], g6[1], s);
             k_unfold_swap_sum(c, comp, C, o_list, (long)out_elems, o_sum, R, nt, sz, fm.sym_t, s, ntsP, ntaP, ldcomp);
@@ -448,6 +450,81 @@ static int predict_fold(gpcsd_ctx *c, const gpcsd_hparams *hp, EigState &e, cons
         return 0;
     }
     return finish_call(c, e, nullptr, 0);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// gpcsd_predict with host outputs (the class API's predict(), gpcsd1d.py:286-293: the arrays ARE the result): the copy of 231 MB
+// at cfg3 is 4 ms on the host link against ~1 ms of device work, and it used to start when the last launch had finished.  The
+// fused last product writes whole output rows [z][t][r] per site orbit, so it is launched in chunks of column tiles and a chunk's
+// finished rows leave through the DMA engine (stream4) while the next chunk computes: the copy starts one chunk (~40 us) after
+// the product instead of ~220 us.  Rows: orbit a writes z = rep_i[a] and rep_j[a] -- runs of consecutive rows are one copy each
+// (a mirror-symmetric probe gives two runs per chunk).  Returns false when it does not apply (the caller launches the product whole).
+// gpcsd_predict_chunked_copy(ctx, 0) / GPCSD_PRED_CHUNKED=0: A/B.
+static bool pred_unfold_chunked(gpcsd_ctx *c, PredUnfoldDesc pu, int which0, int nz, size_t out_elems, bool want_lists, hipStream_t s) {
+    gpcsd_ctx::PredSink &sk = c->pred_sink;
+    if (!sk.active || !c->pred_chunked || !sk.sum[which0] || (want_lists && !sk.list[which0]) || c->prof_mode == 1) return false;
+    const auto it = c->sym_host.find(pu.sz.rep_i);
+    if (it == c->sym_host.end()) return false;
+    const int nso = pu.sz.ns;                                         // site orbits
+    if ((int)it->second.size() < 2 * nso || pu.ncolS != (long)nso * pu.R) return false;
+    const int *rep_i = it->second.data(), *rep_j = rep_i + nso;
+    const long tiles_all = (pu.ncolS + PRED_UNFOLD_BN - 1) / PRED_UNFOLD_BN;
+    const size_t row_bytes = (size_t)pu.nt * pu.R * sizeof(double);
+    const size_t total = (size_t)nz * row_bytes * (1 + (want_lists ? pu.C : 0));
+    if (total < ((size_t)32 << 20) || tiles_all < 16) return false;   // small outputs: one launch, one copy
+    // chunk boundaries in eighths of the tiles (GPCSD_PRED_CHUNKS="1,8": a first eighth, then the rest).  Every copy costs the DMA
+    // engine ~10 us of set-up and a chunk is two runs of rows x (1 + C) arrays: six equal chunks (36 copies) were SLOWER than one
+    // copy behind the whole product (5.60 against 5.41 ms per call at cfg3) -- what pays is starting the first copy early.
+    static const std::vector<int> cuts = [] {
+        std::vector<int> v;
+        const char *e = getenv("GPCSD_PRED_CHUNKS");
+        for (const char *p = e ? e : "1,8"; *p;) {
+            v.push_back(atoi(p));
+            while (*p && *p != ',') ++p;
+            if (*p == ',') ++p;
+        }
+        if (v.empty() || v.back() != 8) v.push_back(8);
+        return v;
+    }();
+    const int nchunk = (int)cuts.size();
+    hipStream_t sc = c->stream4;
+    std::vector<char> have((size_t)nz, 0);
+    int done_orbits = 0;
+    for (int k = 0; k < nchunk; ++k) {
+        pu.tile_c0 = k == 0 ? 0 : tiles_all * cuts[k - 1] / 8;
+        pu.tile_c1 = tiles_all * cuts[k] / 8;
+        gemm_pred_unfold(c, pu, s);
+        // orbits all of whose R columns lie in front of the end of this chunk are complete
+        const int upto = (k + 1 == nchunk) ? nso : (int)std::min<long>(nso, pu.tile_c1 * PRED_UNFOLD_BN / pu.R);
+        if (upto <= done_orbits) continue;
+        std::vector<int> rows;
+        for (int a = done_orbits; a < upto; ++a) {
+            for (int z : {rep_i[a], rep_j[a]})
+                if (z >= 0 && z < nz && !have[z]) { have[z] = 1; rows.push_back(z); }
+        }
+        done_orbits = upto;
+        std::sort(rows.begin(), rows.end());
+        hipEvent_t ev = c->get_event();
+        GP_HIP(hipEventRecord(ev, s));
+        GP_HIP(hipStreamWaitEvent(sc, ev, 0));
+        c->pred_sink_events.push_back(ev);                        // (back to the pool once gpcsd_predict has synchronised)
+        for (size_t i = 0; i < rows.size();) {
+            size_t j = i + 1;
+            while (j < rows.size() && rows[j] == rows[j - 1] + 1) ++j;
+            const size_t off = (size_t)rows[i] * (size_t)pu.nt * pu.R, cnt = (j - i) * row_bytes;
+            GP_HIP(hipMemcpyAsync(sk.sum[which0] + off, pu.sum + off, cnt, hipMemcpyDeviceToHost, sc));
+            if (want_lists)
+                for (int cc = 0; cc < pu.C; ++cc)
+                    GP_HIP(hipMemcpyAsync(sk.list[which0] + (size_t)cc * out_elems + off, pu.list + (size_t)cc * pu.list_stride + off, cnt,
+                                          hipMemcpyDeviceToHost, sc));
+            i = j;
+        }
+    }
+    for (int z = 0; z < nz; ++z)
+        if (!have[z]) return true;                                    // (cannot happen: every site belongs to an orbit) -- not marked done
+    sk.done[which0] = true;
+    ++c->pred_chunked_calls;
+    return true;
 }
 
 // Posterior mean into ctx-owned device buffers, already in the reference's output layout (z, t, trial):
@@ -846,15 +923,38 @@ extern "C" int gpcsd_predict(gpcsd_ctx *c, const gpcsd_hparams *hp, const double
                              int type, double *csd_list, double *csd, double *lfp_list, double *lfp) {
     GP_API_BEGIN(c)
     const bool want_lists = (csd_list != nullptr) || (lfp_list != nullptr);
-    int rc = predict_impl(c, hp, z, nz, tstar, ntstar, type, want_lists);
-    if (rc < 0) return rc;
+    // the caller's arrays are known to the tail: a folded prediction copies its outputs out chunk by chunk under its last product
+    gpcsd_ctx::PredSink &sk = c->pred_sink;
+    sk = gpcsd_ctx::PredSink();
+    sk.active = true;
+    sk.sum[0] = csd; sk.list[0] = csd_list; sk.sum[1] = lfp; sk.list[1] = lfp_list;
+    int rc;
+    try {
+        rc = predict_impl(c, hp, z, nz, tstar, ntstar, type, want_lists);
+    } catch (...) {
+        sk.active = false;
+        (void)hipStreamSynchronize(c->stream4);
+        throw;
+    }
+    sk.active = false;
+    if (rc < 0) {
+        (void)hipStreamSynchronize(c->stream4);
+        return rc;
+    }
     const size_t out_elems = (size_t)nz * ntstar * c->ntrials;
     const int C = hp->n_temporal;
-    if ((type & 1) && csd) c->download(csd, c->bufs["pred_out_csd"].p, out_elems * sizeof(double));
-    if ((type & 1) && csd_list) c->download(csd_list, c->bufs["pred_out_csd_list"].p, out_elems * C * sizeof(double));
-    if ((type & 2) && lfp) c->download(lfp, c->bufs["pred_out_lfp"].p, out_elems * sizeof(double));
-    if ((type & 2) && lfp_list) c->download(lfp_list, c->bufs["pred_out_lfp_list"].p, out_elems * C * sizeof(double));
+    if ((type & 1) && !sk.done[0]) {
+        if (csd) c->download(csd, c->bufs["pred_out_csd"].p, out_elems * sizeof(double));
+        if (csd_list) c->download(csd_list, c->bufs["pred_out_csd_list"].p, out_elems * C * sizeof(double));
+    }
+    if ((type & 2) && !sk.done[1]) {
+        if (lfp) c->download(lfp, c->bufs["pred_out_lfp"].p, out_elems * sizeof(double));
+        if (lfp_list) c->download(lfp_list, c->bufs["pred_out_lfp_list"].p, out_elems * C * sizeof(double));
+    }
+    if (sk.done[0] || sk.done[1]) GP_HIP(hipStreamSynchronize(c->stream4));
     c->sync();
+    for (hipEvent_t ev : c->pred_sink_events) c->event_pool.push_back(ev);
+    c->pred_sink_events.clear();
     return rc;
     GP_API_END(c)
 }

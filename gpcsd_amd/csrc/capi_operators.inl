@@ -613,6 +613,14 @@ extern "C" int gpcsd_pair_share_x(gpcsd_ctx *c, int on, long *calls) {
     GP_API_END(c)
 }
 
+extern "C" int gpcsd_predict_chunked_copy(gpcsd_ctx *c, int on, long *calls) {
+    GP_API_BEGIN(c)
+    if (on >= 0) c->pred_chunked = on != 0;
+    if (calls) *calls = c->pred_chunked_calls;
+    return 0;
+    GP_API_END(c)
+}
+
 extern "C" int gpcsd_band_tail(gpcsd_ctx *c, int on, long *calls) {
     GP_API_BEGIN(c)
     if (on >= 0) c->band_tail = on != 0;

@@ -185,6 +185,18 @@ struct gpcsd_ctx {
     int band_req = 0;
     int tri_band[2] = {0, 0};
     long band_tail_calls = 0;
+    // gpcsd_predict (host outputs): the caller's arrays while the call runs.  The fused last product of a folded prediction is then
+    // launched in chunks of site orbits and every chunk's finished output rows are copied out (stream4: the DMA engine) while the
+    // next chunk computes -- predict_sink_done[which] tells gpcsd_predict that nothing is left to download (capi_fused.inl).
+    struct PredSink {
+        bool active = false;
+        double *sum[2] = {nullptr, nullptr}, *list[2] = {nullptr, nullptr};       // [0] csd, [1] lfp
+        bool done[2] = {false, false};
+    } pred_sink;
+    std::vector<hipEvent_t> pred_sink_events;
+    bool pred_chunked = true;               // gpcsd_predict_chunked_copy() / GPCSD_PRED_CHUNKED=0
+    long pred_chunked_calls = 0;
+    std::map<const int *, std::vector<int>> sym_host;       // host copies (rep_i | rep_j) of the orbit tables, by device pointer
     bool pair_share_x = true;               // gpcsd_pair_share_x()
     long pair_shared_x_calls = 0;           // paired calls whose prediction read the log-likelihood's X = Y~ Q (capi_fused.inl)
     // Decomposition cache (capi.hip::front_half): predict() right after loglik() / fit() with the same hyper-parameters

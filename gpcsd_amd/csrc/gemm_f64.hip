@@ -520,6 +520,7 @@ struct PredUnfoldK {
     long list_stride;
     double *sum;                 // [z][t][r]
     int tiles_b;
+    long tile_c0;                // first column tile of this launch (chunked launches: gpcsd_predict's copy pipeline)
 };
 
 template <int CC>
@@ -540,7 +541,7 @@ __global__ __launch_bounds__(256) void gemm_pred_unfold_kernel(PredUnfoldK<CC> g
         }
     }
     const int tile_b = L % g.tiles_b;
-    const long tile_c = L / g.tiles_b;
+    const long tile_c = g.tile_c0 + L / g.tiles_b;
     const int b0 = tile_b * 32;
     const long n0 = tile_c * 32;
     const int fr = lane & 15, fq = lane >> 4;
@@ -741,10 +742,14 @@ bool gemm_pred_unfold_supported(int C, long nrows_S, int nt) {
 void gemm_pred_unfold(gpcsd_ctx *c, const PredUnfoldDesc &d, hipStream_t s) {
     GP_REQUIRE(gemm_pred_unfold_supported(d.C, d.anti_row0 + d.ncolA, d.nt), -3, "gemm_pred_unfold: unsupported shape");
     const int tiles_b = ceil_div(d.nb, 32);
-    const long tiles_c = (d.ncolS + 31) / 32;
+    const long tiles_all = (d.ncolS + 31) / 32;
+    const long tc0 = d.tile_c1 < 0 ? 0 : d.tile_c0, tc1 = d.tile_c1 < 0 ? tiles_all : std::min(d.tile_c1, tiles_all);
+    if (tc1 <= tc0) return;
+    const long tiles_c = tc1 - tc0;
     const long nblocks = tiles_b * tiles_c;
     GP_REQUIRE(nblocks < (1L << 31), GPCSD_ERR_CAPACITY, "gemm_pred_unfold: too many tiles");
-    const double flops = 2.0 * (double)(d.ncolS + d.ncolA) * d.C * ((double)d.nb * d.K[0] + (double)d.nba * d.K[1]);
+    const double flops = 2.0 * (double)(d.ncolS + d.ncolA) * d.C * ((double)d.nb * d.K[0] + (double)d.nba * d.K[1]) *
+                         ((double)tiles_c / (double)tiles_all);
     ProfScope ps(c, "gemm_pred_tstar_unfold", flops, s);
     auto fill = [&](auto &k) {
         k.S = d.S; k.lds = d.lds;
@@ -754,6 +759,7 @@ void gemm_pred_unfold(gpcsd_ctx *c, const PredUnfoldDesc &d, hipStream_t s) {
         k.nb = d.nb; k.nba = d.nba; k.ncolS = d.ncolS; k.ncolA = d.ncolA; k.anti_row0 = d.anti_row0;
         k.R = d.R; k.nt = d.nt; k.sz = d.sz; k.st = d.st; k.list = d.list; k.list_stride = d.list_stride; k.sum = d.sum;
         k.tiles_b = tiles_b;
+        k.tile_c0 = tc0;
     };
     if (d.C == 1) {
         PredUnfoldK<1> k;

@@ -78,7 +78,9 @@ struct PredUnfoldDesc {
     double *list;
     long list_stride;
     double *sum;
+    long tile_c0 = 0, tile_c1 = -1;     // column tiles (32 columns (site orbit, trial) each) of this launch; tile_c1 < 0: all
 };
+constexpr int PRED_UNFOLD_BN = 32;      // columns (site orbit, trial) per tile of the fused last product
 bool gemm_pred_unfold_supported(int C, long nrows_S, int nt);
 void gemm_pred_unfold(gpcsd_ctx *c, const PredUnfoldDesc &d, hipStream_t s);
 

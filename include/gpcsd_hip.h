@@ -305,6 +305,12 @@ int gpcsd_pair_share_x(gpcsd_ctx *ctx, int on, long *calls);
  * algebra, same results to rounding.  Applies to temporal blocks of at most 252 rows after symmetry folding.
  * on = 1 / 0 switches it (default 1; GPCSD_BAND_TAIL=0 for new contexts), < 0 only queries; *calls counts the chains that took it. */
 int gpcsd_band_tail(gpcsd_ctx *ctx, int on, long *calls);
+/* gpcsd_predict with host outputs (what the class API's predict() returns, gpcsd1d.py:286-293 / gpcsd2d.py:327-334): the last
+ * product of a folded prediction is launched in chunks of prediction sites and every chunk's finished output rows are copied to
+ * the caller's arrays while the next chunk computes (231 MB per call at 384 x 500 x 50: the copy is 4 of the call's 5 ms and no
+ * longer waits for the whole product).  Applies to outputs of at least 32 MB through the fused last product; same bits.
+ * on = 1 / 0 switches it (default 1; GPCSD_PRED_CHUNKED=0 for new contexts), < 0 only queries; *calls counts the calls that took it. */
+int gpcsd_predict_chunked_copy(gpcsd_ctx *ctx, int on, long *calls);
 /* The log-likelihood of the folded path in the basis U (x) Q instead of U (x) V.  With Kt = m Q T Q^T from the
  * tridiagonalisation alone (Q orthogonal, T tridiagonal) and the spatial side fully decomposed, Ks (x) Kt + sig2 I is a set of
  * SHIFTED TRIDIAGONAL matrices es[x'] m T + sig2 I: sum log D is the sum of the logs of their LDL^T pivots and the quadratic

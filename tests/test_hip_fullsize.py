@@ -874,6 +874,42 @@ def test_predict_returns_pinned_arrays_that_are_not_overwritten():
     assert relerr(snapshot, g["csd_pred"]) < GATE
 
 
+def test_predict_copies_its_host_arrays_out_in_chunks_under_the_last_product():
+    """gpcsd_predict_chunked_copy (round 5): predict() with host outputs of >= 32 MB launches its fused last product in chunks of
+    sites and copies every chunk's finished rows out while the next one computes.  Same bits as the one-launch, one-copy form
+    (type 'csd' and 'both', with and without the per-component lists); the counter shows which calls took it; outputs below
+    32 MB and asymmetric sites (no fused product) do not."""
+    import bench
+    w = bench.workload("cfg3")
+    m = bench.build_model(w, np.zeros((w["nx"], w["nt"], 1)))
+    lfp = bench.synth_data(w, m, 10, seed=3)
+    m.update_lfp(lfp, w["t"])
+    ctx = m._sync_device()
+    res = {}
+    for on in (False, True):
+        ctx.predict_chunked_copy(on)
+        n0 = ctx.predict_chunked_copy()
+        m.predict(w["x"], w["t"], type="csd")
+        a = (np.array(m.csd_pred), np.array(m.csd_pred_list[0]), np.array(m.csd_pred_list[1]))
+        n1 = ctx.predict_chunked_copy()
+        m.predict(w["x"], w["t"], type="both")
+        b = (np.array(m.csd_pred), np.array(m.lfp_pred), np.array(m.lfp_pred_list[1]))
+        n2 = ctx.predict_chunked_copy()
+        res[on] = (a, b, n1 - n0, n2 - n1)
+    ctx.predict_chunked_copy(True)
+    assert res[False][2] == 0 and res[False][3] == 0
+    assert res[True][2] == 1 and res[True][3] == 2                  # one chunked product per output kind
+    for x, y in zip(res[False][0] + res[False][1], res[True][0] + res[True][1]):
+        assert np.array_equal(x, y)
+    assert np.array_equal(res[True][0][0], res[True][0][1] + res[True][0][2])      # the sum of the components, as the reference's
+    # small outputs and sites without the probe's symmetry: the plain path
+    n0 = ctx.predict_chunked_copy()
+    m.predict(w["x"][:5] + np.array([[3.0, 7.0]]), w["t"], type="csd")
+    m.update_lfp(lfp[:, :, :2], w["t"])
+    m.predict(w["x"], w["t"], type="csd")
+    assert ctx.predict_chunked_copy() == n0
+
+
 # ------------------------------------------------------------------------------------------------ multi-rank bench step
 def _run(cmd, env, timeout=600):
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
