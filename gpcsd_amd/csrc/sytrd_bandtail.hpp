@@ -82,12 +82,19 @@ __global__ __launch_bounds__(RT_NTH) void sybrd_btail_kernel(SytrdBatch b) {
     if (P.k_tail != 0 || n > RT_TMAX || n < 2) return;             // (the host only launches whole problems; see sytrd_batch_launch)
     if (b.clk && threadIdx.x == 0) b.clk[2 * blockIdx.x] = wall_clock64();
     const int T = n;
+#ifdef BT_NOSTRIP                                                    // (tuning builds: the block phase alone, T <= 192)
+    const int S = 0, LDT = 2;
+#else
     const int S = bt_strip_rows(T), LDT = rt_strip_ld(T);
+#endif
     const int TB = T - S;                                            // live rows of the register block, <= RT_T
     const int OFF = RT_SMAX - S;                                     // slot of tail-global index 0 in the LDS vectors
     extern __shared__ __attribute__((aligned(16))) double strip[];   // [S][LDT]; block phase: panA[2][BT_W][RT_T]
-    __shared__ __attribute__((aligned(16))) double sV[2][RT_TMAX][BT_W];      // the panel's reflectors, [slot][j]; double-buffered
-    __shared__ __attribute__((aligned(16))) double sX[RT_TMAX][BT_W];         // X = A V, then Z in place
+    // [j][slot], vector-major: a lane reads its 12 consecutive columns of one vector as 16-byte pairs 96 bytes from its neighbour's
+    // (2-way bank conflicts, as the tridiagonal tail's vectors).  Interleaved [slot][j] -- one 32-byte record per index, lanes
+    // 384 bytes apart -- put every other lane on the same four banks: 8-way conflicts on every operand read of phases A and D.
+    __shared__ __attribute__((aligned(16))) double sV[2][BT_W][RT_TMAX];      // the panel's reflectors; double-buffered
+    __shared__ __attribute__((aligned(16))) double sX[BT_W][RT_TMAX];         // X = A V, then Z in place
     __shared__ __attribute__((aligned(16))) double part[RT_NW][4][16];        // cross-row partial sums of a wave's strip groups
     __shared__ __attribute__((aligned(16))) double sT[BT_W][BT_W], sM[BT_W][BT_W], sH[BT_W * BT_W];
     __shared__ double panb[2][BT_W][BT_W];                           // R of the panel: panb[.][j][i] = R[i][j], i <= j (R[j][j] = beta_j)
@@ -213,9 +220,15 @@ __global__ __launch_bounds__(RT_NTH) void sybrd_btail_kernel(SytrdBatch b) {
     // ------------------------------------------------------------------------------------------------------------
     // phases A .. D of one panel for everybody.  `first` = tail-global index of the panel's first column
     // ------------------------------------------------------------------------------------------------------------
+    // (Lane-dependent LDS addresses are re-derived per phase from these few values behind an opaque barrier: left to itself the
+    // compiler hoists every address of every phase out of the panel loop, ~25 registers it then spills and reloads each phase.)
+#define BT_OPAQUE(x) asm volatile("" : "+v"(x))
     auto panel_rest = [&](const int first, auto in_strip_c, const bool publish_next) {
         constexpr bool in_strip = decltype(in_strip_c)::value;
-        double (*const sv)[BT_W] = sV[pc & 1];
+        double (*const sv)[RT_TMAX] = sV[pc & 1];
+        int tid = threadIdx.x;
+        BT_OPAQUE(tid);
+        int lane = tid & 63, gg = lane >> 4, h = lane & 15, row0 = 16 * wid + 4 * gg, c0 = RT_C * h;
         lds_barrier();                                               // ---- A: V, T, tau published
         BT_STAMP(0);
         const bool plive = s_live != 0;                              // uniform
@@ -237,15 +250,14 @@ __global__ __launch_bounds__(RT_NTH) void sybrd_btail_kernel(SytrdBatch b) {
                     for (int half = 0; half < 2; ++half) {           // the lane's column pair (cA | cB), one at a time (registers)
                         if (half == 1 && !okB) break;
                         const int cc = half ? cB : cA;
-                        const bt_d2 va01 = *reinterpret_cast<const bt_d2 *>(&sv[OFF + cc][0]), va23 = *reinterpret_cast<const bt_d2 *>(&sv[OFF + cc][2]);
-                        const bt_d2 vb01 = *reinterpret_cast<const bt_d2 *>(&sv[OFF + cc + 1][0]), vb23 = *reinterpret_cast<const bt_d2 *>(&sv[OFF + cc + 1][2]);
+                        bt_d2 vk[BT_W];                               // (V[k][cc], V[k][cc + 1])
+#pragma unroll
+                        for (int k = 0; k < BT_W; ++k) vk[k] = *reinterpret_cast<const bt_d2 *>(&sv[k][OFF + cc]);
 #pragma unroll
                         for (int ar = 0; ar < 4; ++ar) {
                             const bt_d2 ra = *reinterpret_cast<const bt_d2 *>(strip + (BT_W * g + ar) * LDT + cc);
-                            pr[4 * ar + 0] = fma(ra.y, vb01.x, fma(ra.x, va01.x, pr[4 * ar + 0]));
-                            pr[4 * ar + 1] = fma(ra.y, vb01.y, fma(ra.x, va01.y, pr[4 * ar + 1]));
-                            pr[4 * ar + 2] = fma(ra.y, vb23.x, fma(ra.x, va23.x, pr[4 * ar + 2]));
-                            pr[4 * ar + 3] = fma(ra.y, vb23.y, fma(ra.x, va23.y, pr[4 * ar + 3]));
+#pragma unroll
+                            for (int k = 0; k < BT_W; ++k) pr[4 * ar + k] = fma(ra.y, vk[k].y, fma(ra.x, vk[k].x, pr[4 * ar + k]));
                         }
                     }
                     double o4[4];
@@ -257,55 +269,61 @@ __global__ __launch_bounds__(RT_NTH) void sybrd_btail_kernel(SytrdBatch b) {
                     __builtin_amdgcn_wave_barrier();
                     if (lane < 16) {
                         const double tot = (part[wid][0][lane] + part[wid][1][lane]) + (part[wid][2][lane] + part[wid][3][lane]);
-                        sX[OFF + BT_W * g + (lane >> 2)][lane & 3] = tot;
+                        sX[lane & 3][OFF + BT_W * g + (lane >> 2)] = tot;
                     }
                     __builtin_amdgcn_wave_barrier();
                 }
             }
             // block rows: the tile from registers plus (strip phase) the strip COLUMNS of these rows
+#ifndef BT_NO_X
             if (wlive) {
                 double acc[16];
 #pragma unroll
                 for (int i = 0; i < 16; ++i) acc[i] = 0.0;
+#ifndef BT_X_NOFMA
 #pragma unroll
-                for (int j = 0; j < RT_C; ++j) {
-                    const bt_d2 v01 = *reinterpret_cast<const bt_d2 *>(&sv[RT_SMAX + c0 + j][0]);
-                    const bt_d2 v23 = *reinterpret_cast<const bt_d2 *>(&sv[RT_SMAX + c0 + j][2]);
+                for (int j = 0; j < RT_C; j += 2) {
 #pragma unroll
-                    for (int r = 0; r < RT_R; ++r) {
-                        acc[4 * r + 0] = fma(a[r][j], v01.x, acc[4 * r + 0]);
-                        acc[4 * r + 1] = fma(a[r][j], v01.y, acc[4 * r + 1]);
-                        acc[4 * r + 2] = fma(a[r][j], v23.x, acc[4 * r + 2]);
-                        acc[4 * r + 3] = fma(a[r][j], v23.y, acc[4 * r + 3]);
+                    for (int k = 0; k < BT_W; ++k) {
+                        const bt_d2 v2 = *reinterpret_cast<const bt_d2 *>(&sv[k][RT_SMAX + c0 + j]);
+#pragma unroll
+                        for (int r = 0; r < RT_R; ++r) acc[4 * r + k] = fma(a[r][j + 1], v2.y, fma(a[r][j], v2.x, acc[4 * r + k]));
                     }
                 }
+#else
+                acc[0] = a[0][0]; acc[5] = a[1][1]; acc[10] = a[2][2]; acc[15] = a[3][3];
+#endif
                 if (in_strip) {
                     for (int rs = lo + (h - lo % 16 + 16) % 16; rs < S; rs += 16) {
-                        const bt_d2 v01 = *reinterpret_cast<const bt_d2 *>(&sv[OFF + rs][0]);
-                        const bt_d2 v23 = *reinterpret_cast<const bt_d2 *>(&sv[OFF + rs][2]);
+                        const double vr4[4] = {sv[0][OFF + rs], sv[1][OFF + rs], sv[2][OFF + rs], sv[3][OFF + rs]};
                         const bt_d2 s01 = *reinterpret_cast<const bt_d2 *>(strip + rs * LDT + S + row0);
                         const bt_d2 s23 = *reinterpret_cast<const bt_d2 *>(strip + rs * LDT + S + row0 + 2);
                         const double sr[4] = {s01.x, s01.y, s23.x, s23.y};
 #pragma unroll
-                        for (int r = 0; r < RT_R; ++r) {
-                            acc[4 * r + 0] = fma(sr[r], v01.x, acc[4 * r + 0]);
-                            acc[4 * r + 1] = fma(sr[r], v01.y, acc[4 * r + 1]);
-                            acc[4 * r + 2] = fma(sr[r], v23.x, acc[4 * r + 2]);
-                            acc[4 * r + 3] = fma(sr[r], v23.y, acc[4 * r + 3]);
-                        }
+                        for (int r = 0; r < RT_R; ++r)
+#pragma unroll
+                            for (int k = 0; k < BT_W; ++k) acc[4 * r + k] = fma(sr[r], vr4[k], acc[4 * r + k]);
                     }
                 }
                 double o4[4];
+#ifndef BT_X_NORED
                 bt_reduce16(acc, h, o4);
+#else
+                o4[0] = acc[0] + acc[4]; o4[1] = acc[5] + acc[1]; o4[2] = acc[10] + acc[2]; o4[3] = acc[15] + acc[3];
+#endif
                 const int ar = h >> 2;
                 const double lo01 = (ar & 1) ? o4[1] : o4[0], hi23 = (ar & 1) ? o4[3] : o4[2];
                 const double xv = (ar & 2) ? hi23 : lo01;
                 const int i = row0 + ar;                             // block row of this lane's value, vector h & 3
-                sX[RT_SMAX + i][h & 3] = (i >= blk_lo && i < TB) ? xv : 0.0;
+                sX[h & 3][RT_SMAX + i] = (i >= blk_lo && i < TB) ? xv : 0.0;
             }
+#endif
         }
         lds_barrier();                                               // ---- B: X published
         BT_STAMP(1);
+        BT_OPAQUE(tid);
+        lane = tid & 63; gg = lane >> 4; h = lane & 15; row0 = 16 * wid + 4 * gg; c0 = RT_C * h;
+#ifndef BT_NO_H
         if (plive && wid == 0) {
             // H = V^T X over the live indices (lane l: slots l, l + 64, ..), then M = T^T H T / 2
             double hp[16];
@@ -314,9 +332,7 @@ __global__ __launch_bounds__(RT_NTH) void sybrd_btail_kernel(SytrdBatch b) {
 #pragma unroll
             for (int q = 0; q < RT_TMAX / 64; ++q) {
                 const int sl = 64 * q + lane;
-                const bt_d2 v01 = *reinterpret_cast<const bt_d2 *>(&sv[sl][0]), v23 = *reinterpret_cast<const bt_d2 *>(&sv[sl][2]);
-                const bt_d2 x01 = *reinterpret_cast<const bt_d2 *>(&sX[sl][0]), x23 = *reinterpret_cast<const bt_d2 *>(&sX[sl][2]);
-                const double vv[4] = {v01.x, v01.y, v23.x, v23.y}, xx[4] = {x01.x, x01.y, x23.x, x23.y};
+                const double vv[4] = {sv[0][sl], sv[1][sl], sv[2][sl], sv[3][sl]}, xx[4] = {sX[0][sl], sX[1][sl], sX[2][sl], sX[3][sl]};
 #pragma unroll
                 for (int k1 = 0; k1 < 4; ++k1)
 #pragma unroll
@@ -344,16 +360,17 @@ __global__ __launch_bounds__(RT_NTH) void sybrd_btail_kernel(SytrdBatch b) {
                 sM[ia][ib] = 0.5 * s;
             }
         }
+#endif
         lds_barrier();                                               // ---- C: M published
         BT_STAMP(2);
+        BT_OPAQUE(tid);
+        lane = tid & 63; gg = lane >> 4; h = lane & 15; row0 = 16 * wid + 4 * gg; c0 = RT_C * h;
         if (tid < RT_TMAX) {                                         // Z_i = X_i T - V_i M, in place of X (dead / padding slots: zero)
             const int gidx = tid - OFF;
-            const bt_d2 v01 = *reinterpret_cast<const bt_d2 *>(&sv[tid][0]), v23 = *reinterpret_cast<const bt_d2 *>(&sv[tid][2]);
+            const double vv[4] = {sv[0][tid], sv[1][tid], sv[2][tid], sv[3][tid]};
             double z[4] = {0.0, 0.0, 0.0, 0.0};
             if (plive && gidx >= lo && gidx < T) {
-                const bt_d2 x01 = *reinterpret_cast<const bt_d2 *>(&sX[tid][0]), x23 = *reinterpret_cast<const bt_d2 *>(&sX[tid][2]);
-                const double xx[4] = {x01.x, x01.y, x23.x, x23.y};
-                const double vv[4] = {v01.x, v01.y, v23.x, v23.y};
+                const double xx[4] = {sX[0][tid], sX[1][tid], sX[2][tid], sX[3][tid]};
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     double s = 0.0;
@@ -364,12 +381,12 @@ __global__ __launch_bounds__(RT_NTH) void sybrd_btail_kernel(SytrdBatch b) {
                     z[k] = s;
                 }
             }
-            *reinterpret_cast<bt_d2 *>(&sX[tid][0]) = bt_d2{z[0], z[1]};
-            *reinterpret_cast<bt_d2 *>(&sX[tid][2]) = bt_d2{z[2], z[3]};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) sX[k][tid] = z[k];
             // the panel's reflectors to global memory (row first + j of V, tail-global column gidx)
             if (gidx >= 0 && gidx < T) {
                 double *__restrict__ vg = P.V + (long)first * n + gidx;
-                vg[0] = v01.x; vg[n] = v01.y; vg[2 * (long)n] = v23.x; vg[3 * (long)n] = v23.y;
+                vg[0] = vv[0]; vg[n] = vv[1]; vg[2 * (long)n] = vv[2]; vg[3 * (long)n] = vv[3];
             }
         } else if (tid < RT_TMAX + BT_W * (BT_W + 1)) {
             // the band entries of the panel's four columns: bd[d][first + j] = B[first + j + d][first + j]
@@ -396,6 +413,8 @@ __global__ __launch_bounds__(RT_NTH) void sybrd_btail_kernel(SytrdBatch b) {
         }
         lds_barrier();                                               // ---- D: Z published
         BT_STAMP(3);
+        BT_OPAQUE(tid);
+        lane = tid & 63; gg = lane >> 4; h = lane & 15; row0 = 16 * wid + 4 * gg; c0 = RT_C * h;
         if (plive) {
             // ---- A22 -= Z V^T + V Z^T
             if (in_strip) {
@@ -409,20 +428,18 @@ __global__ __launch_bounds__(RT_NTH) void sybrd_btail_kernel(SytrdBatch b) {
                     const int cc = half ? cB : cA;
                     double vc[2][4], zc[2][4];
 #pragma unroll
-                    for (int q = 0; q < 2; ++q) {
-                        const bt_d2 v01 = *reinterpret_cast<const bt_d2 *>(&sv[OFF + cc + q][0]), v23 = *reinterpret_cast<const bt_d2 *>(&sv[OFF + cc + q][2]);
-                        const bt_d2 z01 = *reinterpret_cast<const bt_d2 *>(&sX[OFF + cc + q][0]), z23 = *reinterpret_cast<const bt_d2 *>(&sX[OFF + cc + q][2]);
-                        vc[q][0] = v01.x; vc[q][1] = v01.y; vc[q][2] = v23.x; vc[q][3] = v23.y;
-                        zc[q][0] = z01.x; zc[q][1] = z01.y; zc[q][2] = z23.x; zc[q][3] = z23.y;
+                    for (int k = 0; k < 4; ++k) {
+                        const bt_d2 v2 = *reinterpret_cast<const bt_d2 *>(&sv[k][OFF + cc]), z2 = *reinterpret_cast<const bt_d2 *>(&sX[k][OFF + cc]);
+                        vc[0][k] = v2.x; vc[1][k] = v2.y;
+                        zc[0][k] = z2.x; zc[1][k] = z2.y;
                     }
                     for (int g = g0; g < S / BT_W; g += RT_NW) {
 #pragma unroll
                         for (int ar = 0; ar < 4; ++ar) {
                             const int r = BT_W * g + ar;
                             double *__restrict__ row = strip + r * LDT;
-                            const bt_d2 zr01 = *reinterpret_cast<const bt_d2 *>(&sX[OFF + r][0]), zr23 = *reinterpret_cast<const bt_d2 *>(&sX[OFF + r][2]);
-                            const bt_d2 vr01 = *reinterpret_cast<const bt_d2 *>(&sv[OFF + r][0]), vr23 = *reinterpret_cast<const bt_d2 *>(&sv[OFF + r][2]);
-                            const double zr[4] = {zr01.x, zr01.y, zr23.x, zr23.y}, vr[4] = {vr01.x, vr01.y, vr23.x, vr23.y};
+                            const double zr[4] = {sX[0][OFF + r], sX[1][OFF + r], sX[2][OFF + r], sX[3][OFF + r]};
+                            const double vr[4] = {sv[0][OFF + r], sv[1][OFF + r], sv[2][OFF + r], sv[3][OFF + r]};
                             bt_d2 e = *reinterpret_cast<const bt_d2 *>(row + cc);
 #pragma unroll
                             for (int k = 0; k < 4; ++k) {
@@ -434,32 +451,37 @@ __global__ __launch_bounds__(RT_NTH) void sybrd_btail_kernel(SytrdBatch b) {
                     }
                 }
             }
+#ifndef BT_NO_UPD
             if (wlive) {
 #pragma unroll
                 for (int kh = 0; kh < 4; kh += 2) {                  // two vectors at a time (registers)
-                    double zr[RT_R][2], vr[RT_R][2];
+                    double zr[RT_R][2], vr[RT_R][2];              // [row][vector kh, kh + 1]
 #pragma unroll
-                    for (int r = 0; r < RT_R; ++r) {
-                        const bt_d2 zz = *reinterpret_cast<const bt_d2 *>(&sX[RT_SMAX + row0 + r][kh]);
-                        const bt_d2 vv = *reinterpret_cast<const bt_d2 *>(&sv[RT_SMAX + row0 + r][kh]);
-                        zr[r][0] = zz.x; zr[r][1] = zz.y; vr[r][0] = vv.x; vr[r][1] = vv.y;
-                    }
+                    for (int kq = 0; kq < 2; ++kq)
 #pragma unroll
-                    for (int j = 0; j < RT_C; ++j) {
-                        const bt_d2 zc = *reinterpret_cast<const bt_d2 *>(&sX[RT_SMAX + c0 + j][kh]);
-                        const bt_d2 vc = *reinterpret_cast<const bt_d2 *>(&sv[RT_SMAX + c0 + j][kh]);
+                        for (int r = 0; r < RT_R; r += 2) {
+                            const bt_d2 zz = *reinterpret_cast<const bt_d2 *>(&sX[kh + kq][RT_SMAX + row0 + r]);
+                            const bt_d2 vv = *reinterpret_cast<const bt_d2 *>(&sv[kh + kq][RT_SMAX + row0 + r]);
+                            zr[r][kq] = zz.x; zr[r + 1][kq] = zz.y; vr[r][kq] = vv.x; vr[r + 1][kq] = vv.y;
+                        }
+#pragma unroll
+                    for (int j = 0; j < RT_C; j += 2) {
+                        const bt_d2 zc0 = *reinterpret_cast<const bt_d2 *>(&sX[kh][RT_SMAX + c0 + j]), zc1 = *reinterpret_cast<const bt_d2 *>(&sX[kh + 1][RT_SMAX + c0 + j]);
+                        const bt_d2 vc0 = *reinterpret_cast<const bt_d2 *>(&sv[kh][RT_SMAX + c0 + j]), vc1 = *reinterpret_cast<const bt_d2 *>(&sv[kh + 1][RT_SMAX + c0 + j]);
 #pragma unroll
                         for (int r = 0; r < RT_R; ++r) {
-                            double e = a[r][j];
-                            e = fma(-zr[r][0], vc.x, e);
-                            e = fma(-vr[r][0], zc.x, e);
-                            e = fma(-zr[r][1], vc.y, e);
-                            e = fma(-vr[r][1], zc.y, e);
+                            double e = a[r][j], f = a[r][j + 1];
+                            e = fma(-zr[r][0], vc0.x, e); f = fma(-zr[r][0], vc0.y, f);
+                            e = fma(-vr[r][0], zc0.x, e); f = fma(-vr[r][0], zc0.y, f);
+                            e = fma(-zr[r][1], vc1.x, e); f = fma(-zr[r][1], vc1.y, f);
+                            e = fma(-vr[r][1], zc1.x, e); f = fma(-vr[r][1], zc1.y, f);
                             a[r][j] = e;
+                            a[r][j + 1] = f;
                         }
                     }
                 }
             }
+#endif
         }
         ++pc;
         BT_STAMP(4);
@@ -492,14 +514,11 @@ __global__ __launch_bounds__(RT_NTH) void sybrd_btail_kernel(SytrdBatch b) {
                 return c < 128 ? lo2 : hi2;
             };
             house4(w, tau, colq, std::integral_constant<int, 4>{}, first + BT_W, T, pc & 1, pick);
-            double (*const sv)[BT_W] = sV[pc & 1];
+            double (*const sv)[RT_TMAX] = sV[pc & 1];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int c = colq[q];
-                if (c < T + (T & 1)) {                               // (the pad column of an odd T holds zeros)
-                    *reinterpret_cast<bt_d2 *>(&sv[OFF + c][0]) = bt_d2{w[0][q], w[1][q]};
-                    *reinterpret_cast<bt_d2 *>(&sv[OFF + c][2]) = bt_d2{w[2][q], w[3][q]};
-                }
+            for (int k = 0; k < BT_W; ++k) {                         // (the pad column of an odd T holds zeros)
+                *reinterpret_cast<bt_d2 *>(&sv[k][OFF + cA]) = bt_d2{w[k][0], w[k][1]};
+                if (okB) *reinterpret_cast<bt_d2 *>(&sv[k][OFF + cB]) = bt_d2{w[k][2], w[k][3]};
             }
             if (lane < BT_W) stau[OFF + first + lane] = tau[lane];
             __builtin_amdgcn_s_setprio(0);
@@ -514,9 +533,9 @@ __global__ __launch_bounds__(RT_NTH) void sybrd_btail_kernel(SytrdBatch b) {
     if (S > 0) {                                                     // the reflectors of the block panels are zero over the strip
         for (int idx = tid; idx < 2 * RT_SMAX * BT_W; idx += RT_NTH) {
             const int bsel = idx / (RT_SMAX * BT_W), rem = idx - bsel * RT_SMAX * BT_W;
-            (&sV[bsel][0][0])[rem] = 0.0;
+            sV[bsel][rem / RT_SMAX][rem % RT_SMAX] = 0.0;
         }
-        for (int idx = tid; idx < RT_SMAX * BT_W; idx += RT_NTH) (&sX[0][0])[idx] = 0.0;
+        for (int idx = tid; idx < RT_SMAX * BT_W; idx += RT_NTH) sX[idx / RT_SMAX][idx % RT_SMAX] = 0.0;
     }
     if (npan > 0 && wid == 0 && gg == 0) {                           // the first block panel's rows: current (nothing pending)
 #pragma unroll
@@ -538,6 +557,10 @@ __global__ __launch_bounds__(RT_NTH) void sybrd_btail_kernel(SytrdBatch b) {
             // LDS behind panA for the duration -- afterwards it is dead and simply redefined: either way the compiler sees no
             // live tile across this section.
             const bool tile_live = (kk + BT_W <= 15) || (npan <= 3);
+            int lane = threadIdx.x & 63;
+            BT_OPAQUE(lane);
+            const int h = lane & 15, c0 = RT_C * h;
+            (void)c0;
             bt_d2 *const tsave = reinterpret_cast<bt_d2 *>(strip + 2 * BT_W * RT_T) + lane;
             if (tile_live) {
 #pragma unroll
@@ -553,23 +576,23 @@ __global__ __launch_bounds__(RT_NTH) void sybrd_btail_kernel(SytrdBatch b) {
                 for (int q = 0; q < 3; ++q) w[j][q] = panA[pc & 1][j][64 * q + lane];
             if (ip > 0) {
                 // the rows were published before the previous panel's update: apply it here (rows kk + j, the lane's three columns)
-                double (*const svp)[BT_W] = sV[(pc - 1) & 1];
+                double (*const svp)[RT_TMAX] = sV[(pc - 1) & 1];
 #pragma unroll
                 for (int q = 0; q < 3; ++q) {
                     const int cs = RT_SMAX + 64 * q + lane;
-                    const bt_d2 vc01 = *reinterpret_cast<const bt_d2 *>(&svp[cs][0]), vc23 = *reinterpret_cast<const bt_d2 *>(&svp[cs][2]);
-                    const bt_d2 zc01 = *reinterpret_cast<const bt_d2 *>(&sX[cs][0]), zc23 = *reinterpret_cast<const bt_d2 *>(&sX[cs][2]);
+                    double vcq[4], zcq[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) { vcq[k] = svp[k][cs]; zcq[k] = sX[k][cs]; }
                     double upd[BT_W];
 #pragma unroll
                     for (int j = 0; j < BT_W; ++j) {
                         const int rs = RT_SMAX + kk + j;
-                        const bt_d2 vr01 = *reinterpret_cast<const bt_d2 *>(&svp[rs][0]), vr23 = *reinterpret_cast<const bt_d2 *>(&svp[rs][2]);
-                        const bt_d2 zr01 = *reinterpret_cast<const bt_d2 *>(&sX[rs][0]), zr23 = *reinterpret_cast<const bt_d2 *>(&sX[rs][2]);
                         double e = 0.0;
-                        e = fma(zr01.x, vc01.x, e); e = fma(vr01.x, zc01.x, e);
-                        e = fma(zr01.y, vc01.y, e); e = fma(vr01.y, zc01.y, e);
-                        e = fma(zr23.x, vc23.x, e); e = fma(vr23.x, zc23.x, e);
-                        e = fma(zr23.y, vc23.y, e); e = fma(vr23.y, zc23.y, e);
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            e = fma(sX[k][rs], vcq[k], e);
+                            e = fma(svp[k][rs], zcq[k], e);
+                        }
                         upd[j] = e;
                     }
 #pragma unroll
@@ -585,14 +608,14 @@ __global__ __launch_bounds__(RT_NTH) void sybrd_btail_kernel(SytrdBatch b) {
                 const double t0 = lane_get(x[0], l), t1 = lane_get(x[1], l), t2 = lane_get(x[2], l);
                 return (q == 0) ? t0 : (q == 1) ? t1 : t2;
             };
+#ifndef BT_NO_QR
             house4(w, tau, colq, std::integral_constant<int, 3>{}, kk + BT_W, TB, pc & 1, pick);
-            double (*const sv)[BT_W] = sV[pc & 1];
+#endif
+            double (*const sv)[RT_TMAX] = sV[pc & 1];
 #pragma unroll
-            for (int q = 0; q < 3; ++q) {
-                const int c = 64 * q + lane;
-                *reinterpret_cast<bt_d2 *>(&sv[RT_SMAX + c][0]) = bt_d2{w[0][q], w[1][q]};
-                *reinterpret_cast<bt_d2 *>(&sv[RT_SMAX + c][2]) = bt_d2{w[2][q], w[3][q]};
-            }
+            for (int q = 0; q < 3; ++q)
+#pragma unroll
+                for (int k = 0; k < BT_W; ++k) sv[k][RT_SMAX + 64 * q + lane] = w[k][q];
             if (lane < BT_W) stau[RT_SMAX + kk + lane] = tau[lane];
             if (tile_live) {
 #pragma unroll
