@@ -11,57 +11,90 @@
 // Factorisation (band_factor): a serial recurrence over the columns -- per column ten FMAs, one reciprocal -- that every lane of
 // a wave walks redundantly (one item per wave, all items of a launch in parallel); its dependent chain is reciprocal ->
 // multiplier -> next pivot.  Sweeps: lane = trial; a column step is four FMAs of which ONE is on the dependent chain (the terms
-// with the older values are summed first).  Coefficients of a column: (l1, l2, l3, l4, 1 / D, D) = L[k+1..k+4][k], the pivot's
-// reciprocal and the pivot.
+// with the older values are summed first).  Coefficients of a column k, ten doubles: L[k+1..k+4][k] (the backward sweep's), 1 / D_k,
+// D_k, L[k][k-1..k-4] (the forward sweep's: the same multipliers by rows, so that a sweep reads five values per step).
+#include <type_traits>
+
 #include "devutil.hpp"
 #include "kernels.hpp"
 
 namespace gpcsd {
 
 constexpr int BD_W = 4;                     // half-bandwidth (sytrd_bandtail.hpp: BT_W)
-constexpr int BD_NC = 6;                    // doubles per column of a factor
+constexpr int BD_NC = 10;                   // doubles per column of a factor: column k's multipliers, 1 / D, D, row k's multipliers
 constexpr int BD_KMAX = 256;                // columns of a block at most
 typedef double bd_d2 __attribute__((ext_vector_type(2)));
+// Read-only global memory through the CONSTANT address space: a load with a wave-uniform address is then a scalar load (s_load_*
+// into SGPRs).  Plain `const double *__restrict__` leaves uniform loads as vector loads -- 64 lanes fetching one address each.
+typedef const double __attribute__((address_space(4))) *bd_cptr;
+__device__ __forceinline__ bd_cptr bd_const(const double *p) { return (bd_cptr)(unsigned long long)p; }
 
-// In: cf[k][0..4] = the band of A (diagonal, four sub-diagonals) of column k, k < np.  Out: cf[k] = (l1, l2, l3, l4, 1 / D_k, D_k).
+// In: cf[k][0..4] = the band of A (diagonal, four sub-diagonals) of column k, k < np.  Out: cf[k] = (l1, l2, l3, l4, 1 / D_k, D_k,
+// L[k][k-1], L[k][k-2], L[k][k-3], L[k][k-4]).
 // Called by every lane of one wave with the same arguments (cf in LDS, wave-private); lane 0 stores.
 __device__ __forceinline__ void band_factor(double (*cf)[BD_NC], int np, int lane) {
-    // history of the last four columns c = k-1 .. k-4:  l_c[i] = L[c+i][c],  u_c[i] = l_c[i] D_c
-    double l1[4] = {0, 0, 0, 0}, l2[4] = {0, 0, 0, 0}, l3[4] = {0, 0, 0, 0}, l4[4] = {0, 0, 0, 0};
-    double u1[4] = {0, 0, 0, 0}, u2[4] = {0, 0, 0, 0}, u3[4] = {0, 0, 0, 0}, u4[4] = {0, 0, 0, 0};
-    // (index [i-1]: sub-diagonal i;  l1 = column k-1, l2 = column k-2, ..)
-    for (int k = 0; k < np; ++k) {
-        const bd_d2 a01 = *reinterpret_cast<const bd_d2 *>(&cf[k][0]), a23 = *reinterpret_cast<const bd_d2 *>(&cf[k][2]);
-        const double a4 = cf[k][4];
-        // row k of L: L[k][k-j] = l_{k-j}[j];  row k+i: L[k+i][k-j] = l_{k-j}[i+j]
-        // the terms of the older columns first, the newest column (whose multipliers come out of the previous step's reciprocal) last
-        double dk = a01.x;
-        dk = fma(-l4[3], u4[3], dk);
-        dk = fma(-l3[2], u3[2], dk);
-        dk = fma(-l2[1], u2[1], dk);
-        dk = fma(-l1[0], u1[0], dk);
-        double n1 = a01.y, n2 = a23.x, n3 = a23.y;
-        const double n4 = a4;
-        n1 = fma(-l3[3], u3[2], n1);
-        n1 = fma(-l2[2], u2[1], n1);
-        n1 = fma(-l1[1], u1[0], n1);
-        n2 = fma(-l2[3], u2[1], n2);
-        n2 = fma(-l1[2], u1[0], n2);
-        n3 = fma(-l1[3], u1[0], n3);
-        const double ri = fast_rcp(dk);
-        const double m1 = n1 * ri, m2 = n2 * ri, m3 = n3 * ri, m4 = n4 * ri;
-        if (lane == 0) {
-            *reinterpret_cast<bd_d2 *>(&cf[k][0]) = bd_d2{m1, m2};
-            *reinterpret_cast<bd_d2 *>(&cf[k][2]) = bd_d2{m3, m4};
-            *reinterpret_cast<bd_d2 *>(&cf[k][4]) = bd_d2{ri, dk};
-        }
+    // History of the last four columns, column c in slot c & 3 (the loop is unrolled by four: every slot index below is a
+    // compile-time constant -- shifting four columns of history through registers cost 48 moves per column step):
+    //   hl[s][i-1] = L[c+i][c],  hu[s][i-1] = L[c+i][c] D_c    (sub-diagonal i = 1 .. 4)
+    double hl[4][4], hu[4][4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            l4[i] = l3[i]; l3[i] = l2[i]; l2[i] = l1[i];
-            u4[i] = u3[i]; u3[i] = u2[i]; u2[i] = u1[i];
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) hl[s][i] = hu[s][i] = 0.0;
+    // the band of the next four columns is read while the current four are factored (an LDS round trip per column step, ~120
+    // cycles on a chain of ~60, was most of the first version's 0.2 us per column)
+    bd_d2 a01[4], a23[4];
+    double a4[4];
+    auto fetch = [&](int k0) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int k = min(k0 + u, np - 1);
+            a01[u] = *reinterpret_cast<const bd_d2 *>(&cf[k][0]);
+            a23[u] = *reinterpret_cast<const bd_d2 *>(&cf[k][2]);
+            a4[u] = cf[k][4];
         }
-        l1[0] = m1; l1[1] = m2; l1[2] = m3; l1[3] = m4;
-        u1[0] = n1; u1[1] = n2; u1[2] = n3; u1[3] = n4;
+    };
+    fetch(0);
+    for (int k0 = 0; k0 < np; k0 += 4) {
+        bd_d2 c01[4], c23[4];
+        double c4[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { c01[u] = a01[u]; c23[u] = a23[u]; c4[u] = a4[u]; }
+        if (k0 + 4 < np) fetch(k0 + 4);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (k0 + u < np) {                                      // wave-uniform
+                // column k = k0 + u in slot u; column k - j in slot (u - j) & 3.  Row k of L: L[k][k-j] = l_{k-j}[j];  row k+i:
+                // L[k+i][k-j] = l_{k-j}[i+j].  The terms of the older columns first, the newest column (whose multipliers come out
+                // of the previous step's reciprocal) last.
+                constexpr int S1 = 3, S2 = 2, S3 = 1;               // (u + S) & 3 = slot of column k-1, k-2, k-3; k-4 is slot u itself
+                const int s1 = (u + S1) & 3, s2 = (u + S2) & 3, s3 = (u + S3) & 3, s4 = u;
+                double dk = c01[u].x;
+                dk = fma(-hl[s4][3], hu[s4][3], dk);
+                dk = fma(-hl[s3][2], hu[s3][2], dk);
+                dk = fma(-hl[s2][1], hu[s2][1], dk);
+                dk = fma(-hl[s1][0], hu[s1][0], dk);
+                double n1 = c01[u].y, n2 = c23[u].x, n3 = c23[u].y;
+                const double n4 = c4[u];
+                n1 = fma(-hl[s3][3], hu[s3][2], n1);
+                n1 = fma(-hl[s2][2], hu[s2][1], n1);
+                n1 = fma(-hl[s1][1], hu[s1][0], n1);
+                n2 = fma(-hl[s2][3], hu[s2][1], n2);
+                n2 = fma(-hl[s1][2], hu[s1][0], n2);
+                n3 = fma(-hl[s1][3], hu[s1][0], n3);
+                const double ri = fast_rcp(dk);
+                const double m1 = n1 * ri, m2 = n2 * ri, m3 = n3 * ri, m4 = n4 * ri;
+                if (lane == 0) {
+                    *reinterpret_cast<bd_d2 *>(&cf[k0 + u][0]) = bd_d2{m1, m2};
+                    *reinterpret_cast<bd_d2 *>(&cf[k0 + u][2]) = bd_d2{m3, m4};
+                    *reinterpret_cast<bd_d2 *>(&cf[k0 + u][4]) = bd_d2{ri, dk};
+                    *reinterpret_cast<bd_d2 *>(&cf[k0 + u][6]) = bd_d2{hl[s1][0], hl[s2][1]};      // row k: L[k][k-j] = l_{k-j}[j]
+                    *reinterpret_cast<bd_d2 *>(&cf[k0 + u][8]) = bd_d2{hl[s3][2], hl[s4][3]};
+                }
+                hl[u][0] = m1; hl[u][1] = m2; hl[u][2] = m3; hl[u][3] = m4;       // (overwrites column k - 4: read above)
+                hu[u][0] = n1; hu[u][1] = n2; hu[u][2] = n3; hu[u][3] = n4;
+            }
+        }
     }
 }
 
@@ -95,26 +128,126 @@ struct BandArgs {
 constexpr int BD_PAD = 8;                   // zero columns in front of / behind a factor (the sweeps read four columns back / ahead)
 
 // ------------------------------------------------------------------------------------------------
-// log-likelihood: one wave per item, factor in the shadow of the first loads, forward sweep with the quadratic form
+// factors of all items by one launch: ONE LANE PER ITEM
+// ------------------------------------------------------------------------------------------------
+// The recurrence is serial over the columns and tiny per column (ten FMAs, a reciprocal): with a whole wave walking ONE item
+// redundantly (the first version) a launch took 60-70 us -- 62 instructions per column x 64 lanes of the same numbers.  Here a
+// lane owns an item (its own shift lam = es[x'] m_p; the band itself is shared, in LDS): 768 items are twelve waves, one per CU.
+// Coefficients go out through an LDS transpose, eight columns at a time, so that an item's factor is contiguous in global memory
+// (the sweeps read it with scalar loads: uniform addresses).  The sweeps read a factor's coefficients with SCALAR loads (s_load
+// into SGPRs, the FMAs take them as scalar operands): as broadcast reads from LDS -- 4.5 reads per column step and wave against
+// 6 FMAs, four items per CU -- they were bound by the CU's one LDS pipe (75 us for the log-likelihood's kernel, 29 us for the
+// tridiagonal form's).
+__global__ __launch_bounds__(64) void band_factor_kernel(BandArgs g) {
+    __shared__ __attribute__((aligned(16))) double sb[2][BD_KMAX + 4][6];      // the two blocks' bands, [p][k][j]; zero beyond a block
+    const int lane = threadIdx.x, nitems = 2 * g.nx;
+    const int item = blockIdx.x * 64 + lane;
+    for (int p = 0; p < 2; ++p)
+        for (int idx = lane; idx < (BD_KMAX + 4) * 6; idx += 64) {
+            const int k = idx / 6, j = idx - 6 * k;
+            sb[p][k][j] = (j < 5 && k + j < g.np[p]) ? g.bd[p][(long)j * g.ld[p] + k] : 0.0;
+        }
+    __syncthreads();
+    if (item >= nitems) return;
+    const int xr = item >> 1, p = item & 1;
+    const int np = g.np[p];
+    const double lam = g.es[xr] * g.amax[p][0], sig = g.sig[0];
+    // Layout of the output: [column k][item][BD_NC] -- the lanes of a wave (64 items) write 64 adjacent 80-byte records per column.
+    // Item-major ([item][k][..]: every lane its own cache lines, 64 lines per store instruction) made this kernel 76 us.
+    const long cs = (long)nitems * BD_NC;                          // doubles between consecutive columns of an item
+    double *__restrict__ out = g.coef + (long)item * BD_NC;
+    // history of the last four columns, column c in slot c & 3:  hl[s][i-1] = L[c+i][c],  hu[s][i-1] = L[c+i][c] D_c
+    double hl[4][4], hu[4][4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) hl[s][i] = hu[s][i] = 0.0;
+    // sum log D_k as the logarithm of a running product, renormalised by its exponent every four columns (a logarithm per column
+    // would be most of the loop)
+    double prod = 1.0;
+    int pexp = 0;
+    // one column step; CHECK: the column may lie behind the block (multipliers 0, reciprocal pivot 0, history cleared)
+    auto step = [&](const int k, auto uc, auto checkc) {
+        constexpr int u = decltype(uc)::value;
+        constexpr bool CHECK = decltype(checkc)::value;
+        constexpr int s1 = (u + 3) & 3, s2 = (u + 2) & 3, s3 = (u + 1) & 3, s4 = u;
+        const bool in = !CHECK || k < np;
+        const bd_d2 b01 = *reinterpret_cast<const bd_d2 *>(&sb[p][k][0]), b23 = *reinterpret_cast<const bd_d2 *>(&sb[p][k][2]);
+        const double b4 = sb[p][k][4];
+        double dk = fma(lam, b01.x, sig);
+        double n1 = lam * b01.y, n2 = lam * b23.x, n3 = lam * b23.y;
+        double n4 = lam * b4;
+        dk = fma(-hl[s4][3], hu[s4][3], dk);
+        dk = fma(-hl[s3][2], hu[s3][2], dk);
+        dk = fma(-hl[s2][1], hu[s2][1], dk);
+        dk = fma(-hl[s1][0], hu[s1][0], dk);
+        n1 = fma(-hl[s3][3], hu[s3][2], n1);
+        n1 = fma(-hl[s2][2], hu[s2][1], n1);
+        n1 = fma(-hl[s1][1], hu[s1][0], n1);
+        n2 = fma(-hl[s2][3], hu[s2][1], n2);
+        n2 = fma(-hl[s1][2], hu[s1][0], n2);
+        n3 = fma(-hl[s1][3], hu[s1][0], n3);
+        double ri = fast_rcp(dk);
+        bd_d2 r01 = bd_d2{hl[s1][0], hl[s2][1]}, r23 = bd_d2{hl[s3][2], hl[s4][3]};        // row k: L[k][k-j] = l_{k-j}[j]
+        if (CHECK && !in) {
+            ri = 0.0; n1 = n2 = n3 = n4 = 0.0; dk = 1.0;
+            r01 = bd_d2{0.0, 0.0}; r23 = bd_d2{0.0, 0.0};
+        }
+        const double m1 = n1 * ri, m2 = n2 * ri, m3 = n3 * ri, m4 = n4 * ri;
+        double *__restrict__ o = out + (long)k * cs;
+        *reinterpret_cast<bd_d2 *>(o + 0) = bd_d2{m1, m2};
+        *reinterpret_cast<bd_d2 *>(o + 2) = bd_d2{m3, m4};
+        *reinterpret_cast<bd_d2 *>(o + 4) = bd_d2{ri, dk};
+        *reinterpret_cast<bd_d2 *>(o + 6) = r01;
+        *reinterpret_cast<bd_d2 *>(o + 8) = r23;
+        prod *= dk;
+        hl[u][0] = m1; hl[u][1] = m2; hl[u][2] = m3; hl[u][3] = m4;
+        hu[u][0] = n1; hu[u][1] = n2; hu[u][2] = n3; hu[u][3] = n4;
+    };
+    using T0 = std::integral_constant<int, 0>; using T1 = std::integral_constant<int, 1>;
+    using T2 = std::integral_constant<int, 2>; using T3 = std::integral_constant<int, 3>;
+    const int nfull = np & ~3;                                      // (np differs between the parities: the trip count is per lane)
+    int k0 = 0;
+    for (; k0 < nfull; k0 += 4) {
+        step(k0, T0{}, std::false_type{});
+        step(k0 + 1, T1{}, std::false_type{});
+        step(k0 + 2, T2{}, std::false_type{});
+        step(k0 + 3, T3{}, std::false_type{});
+        int ex;
+        prod = frexp(prod, &ex);
+        pexp += ex;
+    }
+    for (; k0 < g.npad; k0 += 4) {                                  // the last columns of the block and the zero columns behind it
+        step(k0, T0{}, std::true_type{});
+        step(k0 + 1, T1{}, std::true_type{});
+        step(k0 + 2, T2{}, std::true_type{});
+        step(k0 + 3, T3{}, std::true_type{});
+        int ex;
+        prod = frexp(prod, &ex);
+        pexp += ex;
+    }
+    if (g.partials) g.partials[nitems + item] = np > 0 ? log(prod) + 0.6931471805599453 * (double)pexp : 0.0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// log-likelihood: one wave per item, forward sweep with the quadratic form
 // ------------------------------------------------------------------------------------------------
 constexpr int BL_CK = 16, BL_WAVES = 4;     // columns per chunk; waves (items) per workgroup
 __global__ __launch_bounds__(64 * BL_WAVES) void ll_band_kernel(BandArgs g) {
     __shared__ double tile[BL_WAVES][2][64][BL_CK + 1];
-    __shared__ __attribute__((aligned(16))) double coef[BL_WAVES][BD_PAD + BD_KMAX + BL_CK][BD_NC];
     const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int item = blockIdx.x * BL_WAVES + wid, nitems = 2 * g.nx;
+    const int item = __builtin_amdgcn_readfirstlane(blockIdx.x * BL_WAVES + wid), nitems = 2 * g.nx;
     if (item >= nitems) return;                                   // (whole waves leave: no workgroup barrier below)
     const int xr = item >> 1, p = item & 1;
     const int np = g.np[p];
     if (np <= 0) {
-        if (lane == 0) {
-            g.partials[item] = 0.0;
-            g.partials[nitems + item] = 0.0;
-        }
+        if (lane == 0) g.partials[item] = 0.0;
         return;
     }
-    const double lam_m = g.es[xr] * g.amax[p][0], sig = g.sig[0];
     const double *__restrict__ Wx = g.W + (long)xr * g.R * g.nt + g.c0[p];
+    // column k of the item's factor at cg + k * cs (layout [k][item][BD_NC]: band_factor_kernel)
+    const double *__restrict__ cg = g.coef + (long)item * BD_NC;
+    const long cs = (long)nitems * BD_NC;
     const int quarter = lane >> 4, kk_l = lane & 15;              // staging: four rows of 16 columns per load instruction
     double stg[16];
     auto load_chunk = [&](int r0, int nr, int k0) {               // all loads of a chunk are issued before any of them is used
@@ -129,22 +262,11 @@ __global__ __launch_bounds__(64 * BL_WAVES) void ll_band_kernel(BandArgs g) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) tile[wid][buf][quarter + 4 * i][kk_l] = stg[i];
     };
-    load_chunk(0, min(64, g.R), 0);                               // the first chunk's rows fly while the factor is formed
-    double (*cf)[BD_NC] = coef[wid] + BD_PAD;
-    for (int i = lane; i < BD_PAD * BD_NC; i += 64) (&coef[wid][0][0])[i] = 0.0;
-    for (int i = lane; i < BL_CK * BD_NC; i += 64) (&cf[np][0])[i] = 0.0;                  // columns behind the block: l = 0, 1 / D = 0
-    band_shift_load(cf, g.bd[p], g.ld[p], np, lam_m, sig, lane);
-    __builtin_amdgcn_wave_barrier();
-    band_factor(cf, np, lane);
-    __builtin_amdgcn_wave_barrier();
-    double lg = 0.0;
-    for (int k = lane; k < np; k += 64) lg += log(cf[k][5]);
-    const double logsum = wave_sum(lg);
     // ---- the sweeps: the item's rows in passes of 64, chunks of BL_CK columns
     double quad = 0.0;
     for (int r0 = 0; r0 < g.R; r0 += 64) {
         const int nr = min(64, g.R - r0);
-        if (r0 > 0) load_chunk(r0, nr, 0);
+        load_chunk(r0, nr, 0);
         __builtin_amdgcn_wave_barrier();
         store_chunk(0);
         double z1 = 0.0, z2 = 0.0, z3 = 0.0, z4 = 0.0, q[2] = {0.0, 0.0};
@@ -152,82 +274,50 @@ __global__ __launch_bounds__(64 * BL_WAVES) void ll_band_kernel(BandArgs g) {
         for (int k0 = 0; k0 < np; k0 += BL_CK, buf ^= 1) {
             if (k0 + BL_CK < np) load_chunk(r0, nr, k0 + BL_CK);  // the next chunk's loads fly during this chunk's recurrence
             __builtin_amdgcn_wave_barrier();
-            double wv[BL_CK];
-            bd_d2 c01[BL_CK + 4], c23[BL_CK + 4];                  // multipliers of columns k0 - 4 .. k0 + BL_CK - 1
-            double ri[BL_CK];
+#pragma unroll 1
+            for (int kb = 0; kb < BL_CK; kb += 4) {               // four rows at a time: 20 coefficients = 40 SGPRs
+                const bd_cptr ck = bd_const(cg + (long)(k0 + kb) * cs);          // uniform addresses: scalar loads
+                double wv[4];
 #pragma unroll
-            for (int kk = 0; kk < BL_CK; ++kk) {
-                wv[kk] = tile[wid][buf][lane][kk];
-                ri[kk] = cf[k0 + kk][4];
-            }
+                for (int kk = 0; kk < 4; ++kk) wv[kk] = tile[wid][buf][lane][kb + kk];
 #pragma unroll
-            for (int kk = 0; kk < BL_CK + 4; ++kk) {
-                c01[kk] = *reinterpret_cast<const bd_d2 *>(&cf[k0 + kk - 4][0]);
-                c23[kk] = *reinterpret_cast<const bd_d2 *>(&cf[k0 + kk - 4][2]);
-            }
-#pragma unroll
-            for (int kk = 0; kk < BL_CK; ++kk) {                  // row k = k0 + kk: L[k][k-j] = l_{k-j}[j] = (column kk + 4 - j of the window)[j]
-                double t = wv[kk];
-                t = fma(-c23[kk].y, z4, t);                        // l_{k-4}[4]
-                t = fma(-c23[kk + 1].x, z3, t);                    // l_{k-3}[3]
-                t = fma(-c01[kk + 2].y, z2, t);                    // l_{k-2}[2]
-                const double z = fma(-c01[kk + 3].x, z1, t);       // l_{k-1}[1]: the one dependent operation of the step
-                q[kk & 1] = fma(z * z, ri[kk], q[kk & 1]);
-                z4 = z3; z3 = z2; z2 = z1; z1 = z;
+                for (int kk = 0; kk < 4; ++kk) {                  // row k: z_k = w_k - sum_j L[k][k-j] z_{k-j}
+                    double t = wv[kk];
+                    t = fma(-ck[kk * cs + 9], z4, t);
+                    t = fma(-ck[kk * cs + 8], z3, t);
+                    t = fma(-ck[kk * cs + 7], z2, t);
+                    const double z = fma(-ck[kk * cs + 6], z1, t);      // the one dependent operation of the step
+                    q[kk & 1] = fma(z * z, ck[kk * cs + 4], q[kk & 1]);
+                    z4 = z3; z3 = z2; z2 = z1; z1 = z;
+                }
             }
             __builtin_amdgcn_wave_barrier();
             if (k0 + BL_CK < np) store_chunk(buf ^ 1);
         }
         quad += wave_sum(lane < nr ? q[0] + q[1] : 0.0);
     }
-    if (lane == 0) {
-        g.partials[item] = quad;
-        g.partials[nitems + item] = logsum;
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// prediction: factors of all items by one launch (a wave each), then the solve kernel reads them
-// ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64 * BL_WAVES) void band_factor_kernel(BandArgs g) {
-    __shared__ __attribute__((aligned(16))) double coef[BL_WAVES][BD_KMAX][BD_NC];
-    const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int item = blockIdx.x * BL_WAVES + wid, nitems = 2 * g.nx;
-    if (item >= nitems) return;
-    const int xr = item >> 1, p = item & 1;
-    const int np = g.np[p];
-    double *__restrict__ out = g.coef + (long)item * (g.npad + 2 * BD_PAD) * BD_NC;
-    // zero columns in front of and behind the block: multipliers 0, reciprocal pivot 0 (the sweeps pass through them unchanged)
-    for (int i = lane; i < BD_PAD * BD_NC; i += 64) out[i] = 0.0;
-    for (int i = BD_PAD * BD_NC + np * BD_NC + lane; i < (g.npad + 2 * BD_PAD) * BD_NC; i += 64) out[i] = 0.0;
-    if (np <= 0) return;
-    const double lam_m = g.es[xr] * g.amax[p][0], sig = g.sig[0];
-    double (*cf)[BD_NC] = coef[wid];
-    band_shift_load(cf, g.bd[p], g.ld[p], np, lam_m, sig, lane);
-    __builtin_amdgcn_wave_barrier();
-    band_factor(cf, np, lane);
-    __builtin_amdgcn_wave_barrier();
-    for (int i = lane; i < np * BD_NC; i += 64) out[BD_PAD * BD_NC + i] = (&cf[0][0])[i];
+    if (lane == 0) g.partials[item] = quad;
 }
 
 // The solve: the layout and the load / store phases of tridiag_solve_kernel (gram.hip) -- an item's rows come into LDS in one burst,
 // four waves a batch of 64 columns each, the sweeps run in place on wave 0 -- with the factor read from band_factor_kernel's
-// output instead of being formed here, and four multipliers per column.
-constexpr int BS_BATCH = 64, BS_P = 64, BS_HB = 16;
+// output (scalar loads) instead of being formed here, and four multipliers per column.
+constexpr int BS_BATCH = 64, BS_P = 64, BS_HB = 8;
 __global__ __launch_bounds__(256) void band_solve_kernel(BandArgs g) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     double *zbuf = smem;                               // [npad / 2][64][2]: w, then z, then x, in place
-    double (*cfs)[BD_NC] = reinterpret_cast<double (*)[BD_NC]>(zbuf + (long)g.npad * BS_P);     // [npad + 2 BD_PAD][BD_NC]
+    double (*cf)[BD_NC] = reinterpret_cast<double (*)[BD_NC]>(zbuf + (long)g.npad * BS_P);     // [npad][BD_NC]: the item's factor
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int ncf = (g.npad + 2 * BD_PAD) * BD_NC;
-    for (int item = blockIdx.x; item < 2 * g.nx; item += gridDim.x) {
+    const int nitems = 2 * g.nx;
+    const long cs = (long)nitems * BD_NC;
+    for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
         const int xr = item >> 1, p = item & 1;
         const int np = g.np[p];
         if (np <= 0) continue;                             // (the whole workgroup: no barrier is skipped by part of it)
         const int nbatch = (np + BS_BATCH - 1) / BS_BATCH, npad = nbatch * BS_BATCH;
         const long rowbase = (long)xr * g.R * g.nt + g.c0[p];
         const int quarter = lane >> 4, kk_l = lane & 15;   // a global access: four rows of 16 columns
-        const double *__restrict__ cin = g.coef + (long)item * ncf;
+        const double *__restrict__ cin = g.coef + (long)item * BD_NC;         // column k of the factor at cin + k * cs
         for (int r0 = 0; r0 < g.R; r0 += BS_P) {
             const int nr = min(BS_P, g.R - r0);
             const double *const wl = g.W + rowbase + (long)(r0 + quarter) * g.nt + kk_l;
@@ -247,8 +337,11 @@ __global__ __launch_bounds__(256) void band_solve_kernel(BandArgs g) {
                     stg[q][i] = v;
                 }
             }
-            if (r0 == 0)
-                for (int i = tid; i < ncf; i += 256) (&cfs[0][0])[i] = cin[i];
+            if (r0 == 0)                                                 // the factor: pairs of doubles, a column's ten contiguous
+                for (int i = tid; i < npad * (BD_NC / 2); i += 256) {
+                    const int k = i / (BD_NC / 2), j2 = i - k * (BD_NC / 2);
+                    *reinterpret_cast<bd_d2 *>(&cf[k][2 * j2]) = *reinterpret_cast<const bd_d2 *>(cin + (long)k * cs + 2 * j2);
+                }
 #pragma unroll
             for (int q = 0; q < 4; ++q)
 #pragma unroll
@@ -257,49 +350,47 @@ __global__ __launch_bounds__(256) void band_solve_kernel(BandArgs g) {
             __syncthreads();
             if (wid == 0) {
                 bd_d2 *const zl = reinterpret_cast<bd_d2 *>(zbuf) + lane;     // this lane's row: columns 2j, 2j + 1 at zl[j * 64]
-                double (*const cf)[BD_NC] = cfs + BD_PAD;                      // column k of the block
-                // ---- forward: z_k = w_k - sum_j l_{k-j}[j] z_{k-j}   (padding columns: multipliers 0 -- z passes through)
+                // ---- forward: z_k = w_k - sum_j L[k][k-j] z_{k-j}   (padding columns: multipliers 0 -- z passes through)
                 double z1 = 0.0, z2 = 0.0, z3 = 0.0, z4 = 0.0;
                 for (int h0 = 0; h0 < npad; h0 += BS_HB) {
                     bd_d2 *const zb = zl + (h0 >> 1) * BS_P;
-                    bd_d2 v[BS_HB / 2], c01[BS_HB + 4], c23[BS_HB + 4];
+                    bd_d2 v[BS_HB / 2], c67[BS_HB], c89[BS_HB];
 #pragma unroll
                     for (int j = 0; j < BS_HB / 2; ++j) v[j] = zb[j * BS_P];
 #pragma unroll
-                    for (int kk = 0; kk < BS_HB + 4; ++kk) {
-                        c01[kk] = *reinterpret_cast<const bd_d2 *>(&cf[h0 + kk - 4][0]);
-                        c23[kk] = *reinterpret_cast<const bd_d2 *>(&cf[h0 + kk - 4][2]);
+                    for (int kk = 0; kk < BS_HB; ++kk) {
+                        c67[kk] = *reinterpret_cast<const bd_d2 *>(&cf[h0 + kk][6]);
+                        c89[kk] = *reinterpret_cast<const bd_d2 *>(&cf[h0 + kk][8]);
                     }
 #pragma unroll
                     for (int kk = 0; kk < BS_HB; ++kk) {
                         double t = (kk & 1) ? v[kk >> 1].y : v[kk >> 1].x;
-                        t = fma(-c23[kk].y, z4, t);
-                        t = fma(-c23[kk + 1].x, z3, t);
-                        t = fma(-c01[kk + 2].y, z2, t);
-                        const double z = fma(-c01[kk + 3].x, z1, t);
+                        t = fma(-c89[kk].y, z4, t);
+                        t = fma(-c89[kk].x, z3, t);
+                        t = fma(-c67[kk].y, z2, t);
+                        const double z = fma(-c67[kk].x, z1, t);
                         if (kk & 1) v[kk >> 1].y = z; else v[kk >> 1].x = z;
                         z4 = z3; z3 = z2; z2 = z1; z1 = z;
                     }
 #pragma unroll
                     for (int j = 0; j < BS_HB / 2; ++j) zb[j * BS_P] = v[j];
                 }
-                // ---- backward: x_k = z_k / D_k - sum_j l_k[j] x_{k+j}
+                // ---- backward: x_k = z_k / D_k - sum_j L[k+j][k] x_{k+j}
                 double x1 = 0.0, x2 = 0.0, x3 = 0.0, x4 = 0.0;
                 for (int h0 = npad - BS_HB; h0 >= 0; h0 -= BS_HB) {
                     bd_d2 *const zb = zl + (h0 >> 1) * BS_P;
-                    bd_d2 v[BS_HB / 2], c01[BS_HB], c23[BS_HB];
-                    double ri[BS_HB];
+                    bd_d2 v[BS_HB / 2], c01[BS_HB], c23[BS_HB], c45[BS_HB];
 #pragma unroll
                     for (int j = 0; j < BS_HB / 2; ++j) v[j] = zb[j * BS_P];
 #pragma unroll
                     for (int kk = 0; kk < BS_HB; ++kk) {
                         c01[kk] = *reinterpret_cast<const bd_d2 *>(&cf[h0 + kk][0]);
                         c23[kk] = *reinterpret_cast<const bd_d2 *>(&cf[h0 + kk][2]);
-                        ri[kk] = cf[h0 + kk][4];
+                        c45[kk] = *reinterpret_cast<const bd_d2 *>(&cf[h0 + kk][4]);
                     }
 #pragma unroll
                     for (int kk = BS_HB - 1; kk >= 0; --kk) {
-                        double t = ((kk & 1) ? v[kk >> 1].y : v[kk >> 1].x) * ri[kk];
+                        double t = ((kk & 1) ? v[kk >> 1].y : v[kk >> 1].x) * c45[kk].x;
                         t = fma(-c23[kk].y, x4, t);
                         t = fma(-c23[kk].x, x3, t);
                         t = fma(-c01[kk].y, x2, t);
@@ -338,11 +429,11 @@ __global__ __launch_bounds__(256) void band_solve_kernel(BandArgs g) {
 static int band_npad(int npmax) { return (npmax + BS_BATCH - 1) / BS_BATCH * BS_BATCH; }
 static size_t band_solve_lds(int npmax) {
     const int npad = band_npad(npmax);
-    return ((size_t)npad * BS_P + (size_t)(npad + 2 * BD_PAD) * BD_NC) * sizeof(double);
+    return ((size_t)npad * BS_P + (size_t)npad * BD_NC) * sizeof(double);
 }
 // trials per pass (64) if column blocks of up to npmax fit the solve kernel's LDS block, else 0
 int k_band_solve_pass(int npmax, int R) {
-    return (R >= 16 && npmax <= BD_KMAX && band_solve_lds(npmax) <= (size_t)150 * 1024) ? BS_P : 0;
+    return (R >= 16 && npmax <= BD_KMAX && band_solve_lds(npmax) <= (size_t)156 * 1024) ? BS_P : 0;
 }
 
 static BandArgs band_args(const double *W, double *B, const double *es, const double *const bd[2], const int ld[2],
@@ -362,10 +453,17 @@ void ll_tridiag_reduce_launch(gpcsd_ctx *c, const double *partials, int nitems, 
 bool k_ll_band(gpcsd_ctx *c, const double *W, const double *es, const double *const bd[2], const int ld[2], const double *const amax[2],
                const double *sig, int nx, int R, int nt, const int np[2], const int c0[2], double *out_sumlog, double *out_quad,
                hipStream_t s, double *host_slot, const double *status_src, int status_at, int status_doubles) {
-    GP_REQUIRE(std::max(np[0], np[1]) <= BD_KMAX, -3, "ll_band: temporal blocks of %d columns", std::max(np[0], np[1]));
+    const int npmax = std::max(np[0], np[1]);
+    GP_REQUIRE(npmax <= BD_KMAX, -3, "ll_band: temporal blocks of %d columns", npmax);
     BandArgs g = band_args(W, nullptr, es, bd, ld, amax, sig, nx, R, nt, np, c0);
     const int nitems = 2 * nx;
+    g.npad = band_npad(npmax);
     g.partials = c->buf<double>("ll_tridiag_partials", (size_t)2 * nitems);
+    g.coef = c->buf<double>("band_coef_ll", (size_t)nitems * g.npad * BD_NC);
+    {
+        ProfScope ps(c, "band_factor_ll", 0.0, s);
+        hipLaunchKernelGGL(band_factor_kernel, dim3(ceil_div(nitems, 64)), dim3(64), 0, s, g);
+    }
     ProfScope ps(c, "ll_band", 0.0, s);
     hipLaunchKernelGGL(ll_band_kernel, dim3(ceil_div(nitems, BL_WAVES)), dim3(64 * BL_WAVES), 0, s, g);
     bool wrote = false;
@@ -381,7 +479,8 @@ void k_band_solve(gpcsd_ctx *c, const double *W, double *B, const double *es, co
     BandArgs g = band_args(W, B, es, bd, ld, amax, sig, nx, R, nt, np, c0);
     g.npad = band_npad(npmax);
     const int nitems = 2 * nx;
-    g.coef = c->buf<double>("band_coef", (size_t)nitems * (g.npad + 2 * BD_PAD) * BD_NC);
+    g.coef = c->buf<double>("band_coef", (size_t)nitems * g.npad * BD_NC);
+    g.partials = nullptr;
     const size_t lds = band_solve_lds(npmax);
     static size_t attr = 0;
     if (lds > attr) {
@@ -390,7 +489,7 @@ void k_band_solve(gpcsd_ctx *c, const double *W, double *B, const double *es, co
     }
     {
         ProfScope ps(c, "band_factor", 0.0, s);
-        hipLaunchKernelGGL(band_factor_kernel, dim3(ceil_div(nitems, BL_WAVES)), dim3(64 * BL_WAVES), 0, s, g);
+        hipLaunchKernelGGL(band_factor_kernel, dim3(ceil_div(nitems, 64)), dim3(64), 0, s, g);
     }
     ProfScope ps(c, "band_solve", 6.0 * nx * (double)R * nt, s);
     static const int grid_cap = getenv("GPCSD_TS_GRID") ? atoi(getenv("GPCSD_TS_GRID")) : 192;     // (as k_tridiag_solve: leave CUs to the chains)

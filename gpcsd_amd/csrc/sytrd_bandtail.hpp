@@ -212,7 +212,7 @@ __global__ __launch_bounds__(RT_NTH) void sybrd_btail_kernel(SytrdBatch b) {
     // tuning aid (a build with -DBT_PHASE_CLK): thread 0 accumulates the device clock between the barriers of a panel -- [0] up to A
     // (the factorisation, or the wait for it), [1] A..B (X), [2] B..C (H, M), [3] C..D (Z), [4] D..end (update); [5] wave 0's
     // own factorisations -- and leaves the sums in the unused corner of the band array
-    unsigned long long pclk[6] = {0, 0, 0, 0, 0, 0}, plast = wall_clock64();
+    unsigned long long pclk[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, plast = wall_clock64();
 #define BT_STAMP(k) do { const unsigned long long t_ = wall_clock64(); pclk[k] += t_ - plast; plast = t_; } while (0)
 #else
 #define BT_STAMP(k) do { } while (0)
@@ -235,6 +235,7 @@ __global__ __launch_bounds__(RT_NTH) void sybrd_btail_kernel(SytrdBatch b) {
         const int lo = first + BT_W;                                 // first live tail-global index
         const int blk_lo = lo - S;                                   // ... as a block-local index (<= 0 in the strip phase)
         const bool wlive = 16 * wid + 15 >= blk_lo;                  // this wave still owns a live block row
+        double hs[BT_W] = {0.0, 0.0, 0.0, 0.0};                      // this lane's share of H = V^T X (row k1 = 0 .. 3, column h & 3)
         if (plive) {
             // ---- X = A22 V.  Strip rows of this wave (groups g = wid, wid + 12, .. behind the panel's): lane l covers the columns
             // (2l, 2l + 1), (128 + 2l, 129 + 2l); a group's 16 partial sums (row a, vector k) are reduced over the wave together.
@@ -269,7 +270,10 @@ __global__ __launch_bounds__(RT_NTH) void sybrd_btail_kernel(SytrdBatch b) {
                     __builtin_amdgcn_wave_barrier();
                     if (lane < 16) {
                         const double tot = (part[wid][0][lane] + part[wid][1][lane]) + (part[wid][2][lane] + part[wid][3][lane]);
-                        sX[lane & 3][OFF + BT_W * g + (lane >> 2)] = tot;
+                        const int sl = OFF + BT_W * g + (lane >> 2);
+                        sX[lane & 3][sl] = tot;
+#pragma unroll
+                        for (int k1 = 0; k1 < BT_W; ++k1) hs[k1] = fma(sv[k1][sl], tot, hs[k1]);      // H[k1][lane & 3] += V[row][k1] X[row][lane & 3]
                     }
                     __builtin_amdgcn_wave_barrier();
                 }
@@ -315,9 +319,23 @@ __global__ __launch_bounds__(RT_NTH) void sybrd_btail_kernel(SytrdBatch b) {
                 const double lo01 = (ar & 1) ? o4[1] : o4[0], hi23 = (ar & 1) ? o4[3] : o4[2];
                 const double xv = (ar & 2) ? hi23 : lo01;
                 const int i = row0 + ar;                             // block row of this lane's value, vector h & 3
-                sX[h & 3][RT_SMAX + i] = (i >= blk_lo && i < TB) ? xv : 0.0;
+                const double xm = (i >= blk_lo && i < TB) ? xv : 0.0;
+                sX[h & 3][RT_SMAX + i] = xm;
+#pragma unroll
+                for (int k1 = 0; k1 < BT_W; ++k1) hs[k1] = fma(sv[k1][RT_SMAX + i], xm, hs[k1]);
             }
 #endif
+            // H = V^T X: the lane holds products for column h & 3 -- summed over the four lanes of the DPP row that share it (two
+            // rotations), the row groups' and the waves' partial sums go through LDS to wave 0
+#pragma unroll
+            for (int k1 = 0; k1 < BT_W; ++k1) {
+                hs[k1] += dpp_mov<0x124>(hs[k1]);                    // row_ror:4
+                hs[k1] += dpp_mov<0x128>(hs[k1]);                    // row_ror:8
+            }
+            if (h < 4) {
+#pragma unroll
+                for (int k1 = 0; k1 < BT_W; ++k1) part[wid][gg][4 * k1 + h] = hs[k1];
+            }
         }
         lds_barrier();                                               // ---- B: X published
         BT_STAMP(1);
@@ -325,39 +343,28 @@ __global__ __launch_bounds__(RT_NTH) void sybrd_btail_kernel(SytrdBatch b) {
         lane = tid & 63; gg = lane >> 4; h = lane & 15; row0 = 16 * wid + 4 * gg; c0 = RT_C * h;
 #ifndef BT_NO_H
         if (plive && wid == 0) {
-            // H = V^T X over the live indices (lane l: slots l, l + 64, ..), then M = T^T H T / 2
-            double hp[16];
+            // H: entry e = lane & 15 (k1 = e >> 2, k2 = e & 3), the 48 partial sums (12 waves x 4 row groups) a quarter per lane group
+            // in a fixed order, then M = T^T H T / 2
+            const int e = lane & 15, q = lane >> 4;
+            double t = 0.0;
 #pragma unroll
-            for (int i = 0; i < 16; ++i) hp[i] = 0.0;
-#pragma unroll
-            for (int q = 0; q < RT_TMAX / 64; ++q) {
-                const int sl = 64 * q + lane;
-                const double vv[4] = {sv[0][sl], sv[1][sl], sv[2][sl], sv[3][sl]}, xx[4] = {sX[0][sl], sX[1][sl], sX[2][sl], sX[3][sl]};
-#pragma unroll
-                for (int k1 = 0; k1 < 4; ++k1)
-#pragma unroll
-                    for (int k2 = 0; k2 < 4; ++k2) hp[4 * k1 + k2] = fma(vv[k1], xx[k2], hp[4 * k1 + k2]);
-            }
-            double o4[4];
-            bt_reduce16(hp, h, o4);                                  // o4[k1]: DPP-row sum of H[k1][h & 3]
-            if (h < 4) {
-#pragma unroll
-                for (int k1 = 0; k1 < 4; ++k1) part[0][gg][4 * k1 + h] = o4[k1];
-            }
+            for (int w = 0; w < RT_NW; ++w) t += part[w][q][e];
+            __builtin_amdgcn_wave_barrier();
+            part[0][q][e] = t;
             __builtin_amdgcn_wave_barrier();
             if (lane < 16) sH[lane] = (part[0][0][lane] + part[0][1][lane]) + (part[0][2][lane] + part[0][3][lane]);
             __builtin_amdgcn_wave_barrier();
             if (lane < 16) {
                 const int ia = lane >> 2, ib = lane & 3;             // M[ia][ib] = 1/2 sum_{k,l} T[k][ia] H[k][l] T[l][ib]
-                double s = 0.0;
+                double s2 = 0.0;
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    double t = 0.0;
+                    double u = 0.0;
 #pragma unroll
-                    for (int l = 0; l < 4; ++l) t = fma(sH[4 * k + l], sT[l][ib], t);
-                    s = fma(sT[k][ia], t, s);
+                    for (int l = 0; l < 4; ++l) u = fma(sH[4 * k + l], sT[l][ib], u);
+                    s2 = fma(sT[k][ia], u, s2);
                 }
-                sM[ia][ib] = 0.5 * s;
+                sM[ia][ib] = 0.5 * s2;
             }
         }
 #endif
@@ -603,6 +610,10 @@ __global__ __launch_bounds__(RT_NTH) void sybrd_btail_kernel(SytrdBatch b) {
 #pragma unroll
                     for (int q = 0; q < 3; ++q) panA[pc & 1][j][64 * q + lane] = w[j][q];     // (the band entries are read from here)
             }
+#ifdef BT_PHASE_CLK
+            const unsigned long long tq1 = wall_clock64();
+            pclk[6] += tq1 - tq0;
+#endif
             auto pick = [&](const double (&x)[3], int c) {           // (values selected, not elements: see the strip phase)
                 const int q = c >> 6, l = c & 63;
                 const double t0 = lane_get(x[0], l), t1 = lane_get(x[1], l), t2 = lane_get(x[2], l);
@@ -610,6 +621,10 @@ __global__ __launch_bounds__(RT_NTH) void sybrd_btail_kernel(SytrdBatch b) {
             };
 #ifndef BT_NO_QR
             house4(w, tau, colq, std::integral_constant<int, 3>{}, kk + BT_W, TB, pc & 1, pick);
+#endif
+#ifdef BT_PHASE_CLK
+            const unsigned long long tq2 = wall_clock64();
+            pclk[7] += tq2 - tq1;
 #endif
             double (*const sv)[RT_TMAX] = sV[pc & 1];
 #pragma unroll
@@ -654,6 +669,7 @@ __global__ __launch_bounds__(RT_NTH) void sybrd_btail_kernel(SytrdBatch b) {
         P.bd[(long)4 * n + n - 4] = (double)pclk[0]; P.bd[(long)4 * n + n - 3] = (double)pclk[1];
         P.bd[(long)4 * n + n - 2] = (double)pclk[2]; P.bd[(long)4 * n + n - 1] = (double)pclk[3];
         P.bd[(long)3 * n + n - 3] = (double)pclk[4]; P.bd[(long)3 * n + n - 2] = (double)pclk[5];
+        P.bd[(long)3 * n + n - 1] = (double)pclk[6]; P.bd[(long)2 * n + n - 2] = (double)pclk[7];
     }
 #endif
     if (b.clk && threadIdx.x == 0) b.clk[2 * blockIdx.x + 1] = wall_clock64();
