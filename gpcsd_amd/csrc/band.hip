@@ -450,6 +450,23 @@ static BandArgs band_args(const double *W, double *B, const double *es, const do
 void ll_tridiag_reduce_launch(gpcsd_ctx *c, const double *partials, int nitems, double *out_sumlog, double *out_quad, double *host_slot,
                               const double *status_src, int status_at, int status_doubles, hipStream_t s, bool *wrote);
 
+// The log-likelihood's factors (band_factor_kernel with the log-determinants) on stream `sf`: the caller orders `sf` behind the
+// spatial spectrum and the band, and the sweep (k_ll_band, on its own stream) behind this launch.
+void k_ll_band_factor(gpcsd_ctx *c, const double *es, const double *const bd[2], const int ld[2], const double *const amax[2],
+                      const double *sig, int nx, const int np[2], hipStream_t sf) {
+    const int npmax = std::max(np[0], np[1]);
+    GP_REQUIRE(npmax <= BD_KMAX, -3, "ll_band: temporal blocks of %d columns", npmax);
+    const int c0[2] = {0, 0};
+    BandArgs g = band_args(nullptr, nullptr, es, bd, ld, amax, sig, nx, 0, 0, np, c0);
+    const int nitems = 2 * nx;
+    g.npad = band_npad(npmax);
+    g.partials = c->buf<double>("ll_tridiag_partials", (size_t)2 * nitems);
+    g.coef = c->buf<double>("band_coef_ll", (size_t)nitems * g.npad * BD_NC);
+    ProfScope ps(c, "band_factor_ll", 0.0, sf);
+    hipLaunchKernelGGL(band_factor_kernel, dim3(ceil_div(nitems, 64)), dim3(64), 0, sf, g);
+    GP_HIP(hipGetLastError());
+}
+
 bool k_ll_band(gpcsd_ctx *c, const double *W, const double *es, const double *const bd[2], const int ld[2], const double *const amax[2],
                const double *sig, int nx, int R, int nt, const int np[2], const int c0[2], double *out_sumlog, double *out_quad,
                hipStream_t s, double *host_slot, const double *status_src, int status_at, int status_doubles) {
@@ -460,10 +477,6 @@ bool k_ll_band(gpcsd_ctx *c, const double *W, const double *es, const double *co
     g.npad = band_npad(npmax);
     g.partials = c->buf<double>("ll_tridiag_partials", (size_t)2 * nitems);
     g.coef = c->buf<double>("band_coef_ll", (size_t)nitems * g.npad * BD_NC);
-    {
-        ProfScope ps(c, "band_factor_ll", 0.0, s);
-        hipLaunchKernelGGL(band_factor_kernel, dim3(ceil_div(nitems, 64)), dim3(64), 0, s, g);
-    }
     ProfScope ps(c, "ll_band", 0.0, s);
     hipLaunchKernelGGL(ll_band_kernel, dim3(ceil_div(nitems, BL_WAVES)), dim3(64 * BL_WAVES), 0, s, g);
     bool wrote = false;

@@ -934,6 +934,7 @@ extern "C" int gpcsd_ctx_create(int device, gpcsd_ctx **out) {
         GP_HIP(hipEventCreateWithFlags(&c->ev_chol_d, hipEventDisableTiming));
         for (int i = 0; i < 2; ++i) GP_HIP(hipEventCreateWithFlags(&c->ev_q[i], hipEventDisableTiming));
         GP_HIP(hipEventCreateWithFlags(&c->ev_t1, hipEventDisableTiming));
+        GP_HIP(hipEventCreateWithFlags(&c->ev_fac, hipEventDisableTiming));
         for (int i = 0; i < 2; ++i) GP_HIP(hipEventCreateWithFlags(&c->ev_tri_done[i], hipEventDisableTiming));
         GP_HIP(hipHostMalloc(reinterpret_cast<void **>(&c->h_result), gpcsd_ctx::RESULT_DOUBLES * sizeof(double), hipHostMallocDefault));
         GP_HIP(hipHostMalloc(reinterpret_cast<void **>(&c->h_ll), gpcsd_ctx::LL_SLOTS * gpcsd_ctx::RESULT_DOUBLES * sizeof(double),
@@ -977,6 +978,7 @@ extern "C" int gpcsd_ctx_destroy(gpcsd_ctx *c) {
     for (int i = 0; i < 2; ++i)
         if (c->ev_q[i]) (void)hipEventDestroy(c->ev_q[i]);
     if (c->ev_t1) (void)hipEventDestroy(c->ev_t1);
+    if (c->ev_fac) (void)hipEventDestroy(c->ev_fac);
     for (int i = 0; i < 2; ++i)
         if (c->ev_tri_done[i]) (void)hipEventDestroy(c->ev_tri_done[i]);
     if (c->stream) (void)hipStreamDestroy(c->stream);

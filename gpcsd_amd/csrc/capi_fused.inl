@@ -69,6 +69,30 @@ static bool loglik_tri_tail(gpcsd_ctx *c, EigState &e, const FoldMode &fm, const
     hipStream_t s = c->stream;
     ++c->fold_gemm_calls;
     ++c->ll_tridiag_calls;
+    if (e.band) {
+        // Band form: the 2 nx shifted band factorisations are a serial recurrence per item (~60 us for the launch, twelve waves) that
+        // needs the spatial spectrum and the band only -- queued on the spatial chain's stream, behind that chain and the temporal
+        // chain's stage 1, it runs beside the main stream's products; the sweep below waits for ev_fac.
+        const char *const *tg = eigh_fold_tags(c, 1);
+        const double *am[2], *bd[2];
+        int np[2];
+        for (int p = 0; p < 2; ++p) {
+            np[p] = p ? fm.ft.na : fm.ft.ns;
+            const EigArenaView av = eigh_arena_view(c, tg[p], np[p], e.tri_count);
+            const long o = (long)e.tri_rep * av.blk;
+            am[p] = av.amax + o; bd[p] = av.bd + o;
+        }
+        hipStream_t sf = c->stream3;
+        GP_HIP(hipStreamWaitEvent(sf, c->ev_t1, 0));
+        {                                              // (the noise variance's upload and, for a cached spatial side, its readiness: main stream)
+            hipEvent_t ev = c->get_event();
+            GP_HIP(hipEventRecord(ev, s));
+            GP_HIP(hipStreamWaitEvent(sf, ev, 0));
+            c->event_pool.push_back(ev);
+        }
+        k_ll_band_factor(c, fm.fs.w, bd, np, am, e.d_sig, nx, np, sf);
+        GP_HIP(hipEventRecord(c->ev_fac, sf));
+    }
     join_spatial(c, e);
     double *X = c->buf<double>("ll_X", (size_t)nx * R * nt);
     if (ll_order() == 1) {
@@ -87,6 +111,7 @@ static bool loglik_tri_tail(gpcsd_ctx *c, EigState &e, const FoldMode &fm, const
         const long o = (long)e.tri_rep * av.blk;
         d[p] = av.d + o; ee[p] = av.e + o; am[p] = av.amax + o; bd[p] = av.bd + o;
     }
+    if (e.band) GP_HIP(hipStreamWaitEvent(s, c->ev_fac, 0));
     const bool wrote = e.band
         ? k_ll_band(c, W, fm.fs.w, bd, np, am, e.d_sig, nx, R, nt, np, c0, e.scal, e.scal + 1, s, host_slot,
                     e.scal + gpcsd_ctx::SCAL_N, gpcsd_ctx::SCAL_N, gpcsd_ctx::RESULT_DOUBLES - gpcsd_ctx::SCAL_N)

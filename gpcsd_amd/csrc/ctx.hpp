@@ -121,6 +121,7 @@ struct gpcsd_ctx {
     // Single-buffered, the next step's tridiagonalisation waited for the previous prediction's solve (0.3 ms per step).
     int tgen = 0;
     hipEvent_t ev_t1 = nullptr;
+    hipEvent_t ev_fac = nullptr;            // band form: the log-likelihood's shifted band factors are there (recorded on stream3: band.hip)
     bool q_queued[2] = {false, false};      // a stage 3 has been queued on this generation since its last temporal chain started (staged_chain_guard)
     // ... and the last reader of those single-buffered stage-1 outputs (Q, the tridiagonal, its scale) on the main stream: the next
     // temporal chain must not overwrite them before it (a caller may queue several steps deep)

@@ -144,6 +144,8 @@ void k_tridiag_solve(gpcsd_ctx *c, const double *W, double *B, const double *es,
 // The same two operations for a temporal side reduced to HALF-BANDWIDTH 4 instead of a tridiagonal matrix (band.hip; the band tail
 // of the tridiagonalisation, sytrd_bandtail.hpp): bd[p][j * ld[p] + k] = B_p[k + j][k], j = 0 .. 4.  Shifted banded L D L^T
 // factorisations, four multipliers per column.  k_band_solve_pass: as k_tridiag_solve_pass.
+void k_ll_band_factor(gpcsd_ctx *c, const double *es, const double *const bd[2], const int ld[2], const double *const amax[2],
+                      const double *sig, int nx, const int np[2], hipStream_t sf);       // the factors k_ll_band sweeps with (any stream)
 bool k_ll_band(gpcsd_ctx *c, const double *W, const double *es, const double *const bd[2], const int ld[2], const double *const amax[2],
                const double *sig, int nx, int R, int nt, const int np[2], const int c0[2], double *out_sumlog, double *out_quad,
                hipStream_t s, double *host_slot = nullptr, const double *status_src = nullptr, int status_at = 0, int status_doubles = 0);
