@@ -184,6 +184,7 @@ SIGNATURES = {
     "gpcsd_ll_tridiag": (_I, [_P, _I, ctypes.POINTER(_L)]),
     "gpcsd_pair_share_x": (_I, [_P, _I, ctypes.POINTER(_L)]),
     "gpcsd_band_tail": (_I, [_P, _I, ctypes.POINTER(_L)]),
+    "gpcsd_q_pipeline": (_I, [_P, _I, ctypes.POINTER(_L)]),
     "gpcsd_predict_chunked_copy": (_I, [_P, _I, ctypes.POINTER(_L)]),
     "gpcsd_debug_sybrd": (_I, [_P, _DP, _I, _DP, _DP, _DP]),
     "gpcsd_tail_early_exit": (_I, [_P, _I, ctypes.POINTER(_I)]),
@@ -793,6 +794,13 @@ class Context:
         returns the number of temporal chains that took it."""
         n = _L(0)
         self._check(self._lib.gpcsd_band_tail(self._h, -1 if on is None else int(bool(on)), ctypes.byref(n)))
+        return int(n.value)
+
+    def q_pipeline(self, on=None):
+        """Switch (True/False) or query (None) the panel-by-panel formation of Q and X = Y~ Q under the running tridiagonalisation
+        (DESIGN 4.12); returns the number of temporal chains that took it."""
+        n = _L(0)
+        self._check(self._lib.gpcsd_q_pipeline(self._h, -1 if on is None else int(bool(on)), ctypes.byref(n)))
         return int(n.value)
 
     def predict_chunked_copy(self, on=None):

@@ -36,6 +36,7 @@ static void drain_after_failure(gpcsd_ctx *c) {
     if (c->stream2) (void)hipStreamSynchronize(c->stream2);
     if (c->stream3) (void)hipStreamSynchronize(c->stream3);
     if (c->stream4) (void)hipStreamSynchronize(c->stream4);
+    if (c->stream5) (void)hipStreamSynchronize(c->stream5);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     c->status_zeroed = false;
     c->async_pending = false;                   // everything is drained: no deferred status
@@ -402,6 +403,16 @@ struct EigState {
     bool tri = false, wait_q = false;
     int tri_rep = 0, tri_count = 1;
     int band = 0;                  // tri: half-bandwidth of what the temporal chain left (0: tridiagonal d / e; 4: EigArenaView::bd)
+    // tri: stage 1 ran with progress words and NO stage 3 was queued -- loglik_tri_pre queues stage 5 instead (queue_q_pipeline:
+    // T factors and Q on stream4, X = Y~ Q block of columns by block on the main stream), with the arguments of the stage-1 call
+    bool pipe_pending = false;
+    struct {
+        double *Kt = nullptr, *et = nullptr, *Qt = nullptr;
+        const SymDev *sym_t = nullptr;
+        int *status = nullptr;
+        int nt = 0, nT = 1, stride = 0, rep = 0, q_gen = -1;
+        bool need_merged = false;
+    } pa;
 };
 
 // May a staged temporal chain whose consumers all take the basis U (x) Q stop at the band form?  Both halves must fit the band tail
@@ -410,6 +421,50 @@ static bool band_tail_applies(const gpcsd_ctx *c, const SymDev *sym_t, int R, bo
     if (!c->band_tail || !sym_t) return false;
     const int hi = std::max(sym_t->ns, sym_t->na);
     return hi <= bt_max_rows() && hi > 8 && (!with_predict || k_band_solve_pass(hi, R) > 0);
+}
+
+// Stage 5 instead of stage 3 (gpcsd_ctx::q_pipe): both halves whole in the register tail, the temporal product first in the
+// log-likelihood's tail (GPCSD_LL_ORDER=0), and the caller has promised to form X through loglik_tri_pre (q_pipe_want).
+static int ll_order() {                    // GPCSD_LL_ORDER: order of the log-likelihood's two products (capi_fused.inl)
+    static const int o = getenv("GPCSD_LL_ORDER") ? atoi(getenv("GPCSD_LL_ORDER")) : 0;
+    return o;
+}
+// (and only where a prediction takes the tridiagonal form as well: a paired call whose prediction needs the eigenvectors keeps
+// stage 3 -- its stage 4 reads stage 3's T factors -- and a log-likelihood must give the same bits alone and in a pair)
+static bool q_pipe_applies(const gpcsd_ctx *c, const SymDev *sym_t) {
+    return c->q_pipe && c->q_pipe_want && sym_t && std::max(sym_t->ns, sym_t->na) <= eigh_regtail_rows() && ll_order() == 0 &&
+           k_tridiag_solve_pass(std::max(sym_t->ns, sym_t->na), c->ntrials) > 0;
+}
+// Queue stage 5 (EigState::pipe_pending): on stream4, behind ev_t0, T factor and forward apply panel by panel under the running
+// stage 1; on the main stream, behind an event per panel, X[:, panel's columns] = src Q[:, panel's columns] -> xname (eigh_dc.hip).
+// The main stream is in order behind every earlier reader of X and behind whatever built src.
+static void queue_q_pipeline(gpcsd_ctx *c, EigState &e, const double *src, const char *xname) {
+    hipStream_t sq = c->stream4;
+    GP_HIP(hipStreamWaitEvent(sq, c->ev_t0, 0));
+    GP_HIP(hipStreamWaitEvent(sq, c->ev_pc, 0));      // the side stream's last readers of Q (the previous predictions' Pcat products)
+    gpcsd_ctx::QPipeX x;
+    x.in = src;
+    x.out = c->buf<double>(xname, (size_t)c->nx * c->ntrials * c->nt);
+    x.M = c->nx * c->ntrials; x.ld = e.pa.nt;
+    x.c0[0] = 0; x.c0[1] = e.pa.sym_t->ns;
+    x.rep = e.pa.rep;
+    c->q_pipe_x = x;
+    try {
+        eigh_pair_device(c, nullptr, 0, nullptr, nullptr, nullptr, e.pa.Kt, e.pa.nt, e.pa.et, e.pa.Qt, e.pa.sym_t, e.pa.status, sq,
+                         e.pa.need_merged, e.pa.nT, e.pa.stride, -1, 2, /*stage=*/5);
+    } catch (...) {
+        c->q_pipe_x = gpcsd_ctx::QPipeX();
+        throw;
+    }
+    c->q_pipe_x = gpcsd_ctx::QPipeX();
+    GP_HIP(hipEventRecord(c->ev_q[c->tgen], sq));
+    c->tl("Q end", sq);
+    c->q_queued[c->tgen] = true;
+    c->q_gen = e.pa.q_gen;
+    e.pipe_pending = false;
+    e.wait_q = false;                      // (the main stream has passed the last panel's event)
+    c->t1_wait_pending = true;             // ... but not the end of stage 1 itself: the readers of d / e wait for ev_t1
+    ++c->q_pipe_calls;
 }
 
 // The prediction in the basis U (x) Q as well (k_tridiag_solve instead of (W V) / D): with it NO consumer of a staged temporal
@@ -627,21 +682,35 @@ EigState front_half(gpcsd_ctx *c, const gpcsd_hparams *hp, double jitter, bool n
                 c->band_req = (tri && band_tail_applies(c, sym_t, c->ntrials, true)) ? 4 : 0;
                 c->tri_band[c->tgen] = c->band_req;
                 if (c->band_req) ++c->band_tail_calls;
+                // stage 5 instead of stage 3: the tail publishes its progress, the caller's loglik_tri_pre queues the rest
+                const bool pipe = tri && !c->band_req && q_pipe_applies(c, sym_t);
+                if (pipe) GP_HIP(hipEventRecord(c->ev_t0, s2));
+                c->pipe_req = pipe ? 1 : 0;
                 eigh_pair_device(c, nullptr, 0, nullptr, nullptr, nullptr, Kt, nt, e.et, e.Qt, sym_t, e.status + 1, s2, need_merged, 1, 0,
                                  -1, 2, /*stage=*/1);
                 c->band_req = 0;
+                c->pipe_req = 0;
                 GP_HIP(hipEventRecord(c->ev_t1, s2));
                 if (!tri)
                     eigh_pair_device(c, nullptr, 0, nullptr, nullptr, nullptr, Kt, nt, e.et, e.Qt, sym_t, late + 1, s2, need_merged, 1, 0,
                                      -1, 2, /*stage=*/2);
                 {
                     hipStream_t sq = c->stream4;
-                    GP_HIP(hipStreamWaitEvent(sq, c->ev_t1, 0));
-                    eigh_pair_device(c, nullptr, 0, nullptr, nullptr, nullptr, Kt, nt, e.et, e.Qt, sym_t, e.status + 1, sq,
-                                     need_merged, 1, 0, -1, 2, /*stage=*/3);
-                    GP_HIP(hipEventRecord(c->ev_q[c->tgen], sq));
-                    c->q_queued[c->tgen] = true;
-                    c->q_gen = c->eig_gen[1];
+                    if (pipe) {
+                        e.pipe_pending = true;
+                        e.pa.Kt = Kt; e.pa.nt = nt; e.pa.et = e.et; e.pa.Qt = e.Qt; e.pa.sym_t = sym_t; e.pa.status = e.status + 1;
+                        e.pa.need_merged = need_merged; e.pa.nT = 1; e.pa.stride = 0; e.pa.rep = 0; e.pa.q_gen = c->eig_gen[1];
+                        c->q_queued[c->tgen] = false;
+                        c->q_gen = -1;         // (until stage 5 is queued)
+                    } else {
+                        GP_HIP(hipStreamWaitEvent(sq, c->ev_t1, 0));
+                        GP_HIP(hipStreamWaitEvent(sq, c->ev_pc, 0));      // (stream5's readers of the Q about to be rewritten)
+                        eigh_pair_device(c, nullptr, 0, nullptr, nullptr, nullptr, Kt, nt, e.et, e.Qt, sym_t, e.status + 1, sq,
+                                         need_merged, 1, 0, -1, 2, /*stage=*/3);
+                        GP_HIP(hipEventRecord(c->ev_q[c->tgen], sq));
+                        c->q_queued[c->tgen] = true;
+                        c->q_gen = c->eig_gen[1];
+                    }
                 }
                 if (!tri) {
                     GP_HIP(hipStreamWaitEvent(s2, c->ev_q[c->tgen], 0));
@@ -916,6 +985,7 @@ extern "C" int gpcsd_ctx_create(int device, gpcsd_ctx **out) {
         if (const char *ev = getenv("GPCSD_TAIL_EARLY_EXIT")) c->tail_early_exit = ev[0] != '0';
         if (const char *ev = getenv("GPCSD_PAIR_SHARE_X")) c->pair_share_x = ev[0] != '0';
         if (const char *ev = getenv("GPCSD_BAND_TAIL")) c->band_tail = ev[0] != '0';
+        if (const char *ev = getenv("GPCSD_Q_PIPE")) c->q_pipe = ev[0] != '0';
         if (const char *ev = getenv("GPCSD_PRED_CHUNKED")) c->pred_chunked = ev[0] != '0';
         GP_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
         // The two chains are the critical path and made of small launches; when they run beside another call's GEMM tail
@@ -924,7 +994,17 @@ extern "C" int gpcsd_ctx_create(int device, gpcsd_ctx **out) {
         GP_HIP(hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
         GP_HIP(hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, prio_greatest));
         GP_HIP(hipStreamCreateWithPriority(&c->stream3, hipStreamNonBlocking, prio_greatest));
-        GP_HIP(hipStreamCreateWithFlags(&c->stream4, hipStreamNonBlocking));
+        // stream4: stage 3 / stage 5 of a staged temporal chain (on the log-likelihood's critical path, beside the previous call's
+        // products) and the prediction's two small side products -- high priority as well (GPCSD_S4_PRIO=0: A/B)
+        {
+            const char *ev = getenv("GPCSD_S4_PRIO");
+            if (ev && ev[0] == '0') GP_HIP(hipStreamCreateWithFlags(&c->stream4, hipStreamNonBlocking));
+            else GP_HIP(hipStreamCreateWithPriority(&c->stream4, hipStreamNonBlocking, prio_greatest));
+        }
+        // (stream5 = stream4.  A fifth stream for the prediction's side products -- any priority -- made the STEP slower, 1.5 instead
+        // of 0.95 ms at cfg3, with or without stage 5: measured, not understood; the runtime's mapping of streams to hardware queues
+        // is not ours to see.  The name stays: the side products' stream.)
+        c->stream5 = c->stream4;
         GP_HIP(hipEventCreateWithFlags(&c->ev_sjoin, hipEventDisableTiming));
         for (int i = 0; i < 4; ++i) GP_HIP(hipEventCreateWithFlags(&c->ev_mark[i / 2][i % 2], hipEventDisableTiming));
         GP_HIP(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
@@ -935,6 +1015,11 @@ extern "C" int gpcsd_ctx_create(int device, gpcsd_ctx **out) {
         for (int i = 0; i < 2; ++i) GP_HIP(hipEventCreateWithFlags(&c->ev_q[i], hipEventDisableTiming));
         GP_HIP(hipEventCreateWithFlags(&c->ev_t1, hipEventDisableTiming));
         GP_HIP(hipEventCreateWithFlags(&c->ev_fac, hipEventDisableTiming));
+        GP_HIP(hipEventCreateWithFlags(&c->ev_t0, hipEventDisableTiming));
+        for (int i = 0; i < 8; ++i) GP_HIP(hipEventCreateWithFlags(&c->ev_stage[i], hipEventDisableTiming));
+        GP_HIP(hipEventCreateWithFlags(&c->ev_prelude, hipEventDisableTiming));
+        GP_HIP(hipEventCreateWithFlags(&c->ev_m1, hipEventDisableTiming));
+        if (const char *ev = getenv("GPCSD_QPIPE_MASK")) c->q_pipe_mask = atoi(ev);
         for (int i = 0; i < 2; ++i) GP_HIP(hipEventCreateWithFlags(&c->ev_tri_done[i], hipEventDisableTiming));
         GP_HIP(hipHostMalloc(reinterpret_cast<void **>(&c->h_result), gpcsd_ctx::RESULT_DOUBLES * sizeof(double), hipHostMallocDefault));
         GP_HIP(hipHostMalloc(reinterpret_cast<void **>(&c->h_ll), gpcsd_ctx::LL_SLOTS * gpcsd_ctx::RESULT_DOUBLES * sizeof(double),
@@ -970,6 +1055,7 @@ extern "C" int gpcsd_ctx_destroy(gpcsd_ctx *c) {
         if (c->ev_mark[i / 2][i % 2]) (void)hipEventDestroy(c->ev_mark[i / 2][i % 2]);
     if (c->stream3) (void)hipStreamDestroy(c->stream3);
     if (c->stream4) (void)hipStreamDestroy(c->stream4);
+    if (c->stream5 && c->stream5 != c->stream4) (void)hipStreamDestroy(c->stream5);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     if (c->ev_aux) (void)hipEventDestroy(c->ev_aux);
     if (c->ev_pc) (void)hipEventDestroy(c->ev_pc);
@@ -979,6 +1065,11 @@ extern "C" int gpcsd_ctx_destroy(gpcsd_ctx *c) {
         if (c->ev_q[i]) (void)hipEventDestroy(c->ev_q[i]);
     if (c->ev_t1) (void)hipEventDestroy(c->ev_t1);
     if (c->ev_fac) (void)hipEventDestroy(c->ev_fac);
+    if (c->ev_t0) (void)hipEventDestroy(c->ev_t0);
+    for (int i = 0; i < 8; ++i)
+        if (c->ev_stage[i]) (void)hipEventDestroy(c->ev_stage[i]);
+    if (c->ev_prelude) (void)hipEventDestroy(c->ev_prelude);
+    if (c->ev_m1) (void)hipEventDestroy(c->ev_m1);
     for (int i = 0; i < 2; ++i)
         if (c->ev_tri_done[i]) (void)hipEventDestroy(c->ev_tri_done[i]);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -1033,6 +1124,8 @@ extern "C" int gpcsd_device_synchronize(gpcsd_ctx *c) {
     GP_API_BEGIN(c)
     GP_HIP(hipStreamSynchronize(c->stream2));
     GP_HIP(hipStreamSynchronize(c->stream3));
+    GP_HIP(hipStreamSynchronize(c->stream4));
+    GP_HIP(hipStreamSynchronize(c->stream5));
     c->sync();
     c->timeline_dump();
     return drain_async(c);

@@ -33,10 +33,7 @@ static int finish_loglik_async(gpcsd_ctx *c, const EigState &e, bool two, bool s
 // Order of the log-likelihood's two products: X = Y~ Q then W = U^T X (0: the temporal product first, behind Q and in front of the
 // wait for the spatial chain), or W0 = U^T Y~ then W = W0 Q (1: the spatial product first, behind the spatial chain and in front
 // of the wait for Q).  Same flops, same shapes; whichever chain ends first should have its product first.  GPCSD_LL_ORDER.
-static int ll_order() {
-    static const int o = getenv("GPCSD_LL_ORDER") ? atoi(getenv("GPCSD_LL_ORDER")) : 0;
-    return o;
-}
+// (ll_order(): capi.hip, beside q_pipe_applies)
 
 // out[(x, r)][t~ block p] = in[(x, r)][t~ block p] Q_p, both parity blocks in one launch (Q of replica e.tri_rep; waits for stage 3)
 static void tri_times_Q(gpcsd_ctx *c, EigState &e, const FoldMode &fm, const double *in, double *out, const char *prof) {
@@ -60,6 +57,10 @@ static void tri_times_Q(gpcsd_ctx *c, EigState &e, const FoldMode &fm, const dou
 static void loglik_tri_pre(gpcsd_ctx *c, EigState &e, const FoldMode &fm, const double *Yf, const char *xname = "ll_X",
                            const char *prof = "gemm_ll_YQ", bool is_ll = true) {
     if (is_ll && ll_order() == 1) return;              // spatial product first: everything happens in the tail
+    if (e.pipe_pending) {                              // stage 1 ran with progress words: T, Q and X panel by panel (queue_q_pipeline)
+        queue_q_pipeline(c, e, Yf, xname);
+        return;
+    }
     tri_times_Q(c, e, fm, Yf, c->buf<double>(xname, (size_t)c->nx * c->ntrials * c->nt), prof);
 }
 
@@ -112,6 +113,10 @@ static bool loglik_tri_tail(gpcsd_ctx *c, EigState &e, const FoldMode &fm, const
         d[p] = av.d + o; ee[p] = av.e + o; am[p] = av.amax + o; bd[p] = av.bd + o;
     }
     if (e.band) GP_HIP(hipStreamWaitEvent(s, c->ev_fac, 0));
+    if (c->t1_wait_pending) {              // stage 5: nothing on this stream is ordered behind the END of stage 1 yet (d, e, the scale)
+        GP_HIP(hipStreamWaitEvent(s, c->ev_t1, 0));
+        c->t1_wait_pending = false;
+    }
     const bool wrote = e.band
         ? k_ll_band(c, W, fm.fs.w, bd, np, am, e.d_sig, nx, R, nt, np, c0, e.scal, e.scal + 1, s, host_slot,
                     e.scal + gpcsd_ctx::SCAL_N, gpcsd_ctx::SCAL_N, gpcsd_ctx::RESULT_DOUBLES - gpcsd_ctx::SCAL_N)
@@ -163,7 +168,15 @@ static int loglik_parts_impl(gpcsd_ctx *c, const gpcsd_hparams *hp, double *out2
     const FoldMode fm0 = fold_mode(c, hp);                          // the decision; its views are of the previous generation
     const double *Yf = fm0.on ? folded_lfp(c, fm0) : nullptr;
     // (the spatial chain is joined by the tail: the tridiagonal form queues its first product in front of that wait)
-    EigState e = front_half(c, hp, hp->jitter, !fm0.on, /*join_s=*/!fm0.on, /*want_tri=*/fm0.on);
+    c->q_pipe_want = fm0.on && fm0.ft.on;                           // (X = Y~ Q goes through loglik_tri_pre below: stage 5 may apply)
+    EigState e;
+    try {
+        e = front_half(c, hp, hp->jitter, !fm0.on, /*join_s=*/!fm0.on, /*want_tri=*/fm0.on);
+    } catch (...) {
+        c->q_pipe_want = false;
+        throw;
+    }
+    c->q_pipe_want = false;
     const FoldMode fm = fold_mode(c, hp);                           // views of the generation the front half just launched
     const int nx = c->nx, nt = c->nt, R = c->ntrials;
     hipStream_t s = c->stream;
@@ -282,7 +295,8 @@ static bool pred_unfold_chunked(gpcsd_ctx *c, PredUnfoldDesc pu, int which0, int
 static int predict_fold(gpcsd_ctx *c, const gpcsd_hparams *hp, EigState &e, const FoldMode &fm, const double *Yf, const SymDev &sz,
                         const double *dz, int nz, const double *dts, int type, bool want_lists, bool async,
                         const std::function<void()> *after_spatial_join = nullptr,
-                        const std::function<void()> *before_spatial_join = nullptr, const char *shared_x = nullptr) {
+                        const std::function<void()> *before_spatial_join = nullptr, const char *shared_x = nullptr,
+                        bool prelude_side = false) {
     const Geo g = resident_geo(c);
     const int nx = c->nx, nt = c->nt, R = c->ntrials, C = hp->n_temporal;
     const long RT = (long)R * nt;
@@ -313,18 +327,23 @@ static int predict_fold(gpcsd_ctx *c, const gpcsd_hparams *hp, EigState &e, cons
     ++c->fold_gemm_calls;
     // what needs neither decomposition runs first, beside both chains: the cross-covariances and the prediction-time Grams,
     // folded
+    // (prelude_side -- the paired call: on stream5, behind the previous call's side products there; the main stream is still busy
+    // with the previous prediction and has the log-likelihood's products to queue first)
+    hipStream_t sp = prelude_side ? c->stream5 : s;
+    if (prelude_side && c->m1_read_queued) GP_HIP(hipStreamWaitEvent(sp, c->ev_m1, 0));     // the last reader of Kc~ on the main stream
     for (int which = 1; which <= 2; ++which) {
         if (!(type & which)) continue;
         double *kf = Kcf + (size_t)(which - 1) * kcf_sz;
-        if (which == 1) build_kphig(c, g, hp->R, hp->eps, hp->ell_s, dz, nz, Kc, s);        // gpcsd1d.py:273
-        else build_kphi(c, g, hp->R, hp->eps, hp->ell_s, dz, nz, 0.0, Kc, s);               // gpcsd1d.py:275
-        k_sym_fold_rect(c, Kc, nz, fm.sym_s, sz, kf, kf + (size_t)ns * nzs, s);
+        if (which == 1) build_kphig(c, g, hp->R, hp->eps, hp->ell_s, dz, nz, Kc, sp);       // gpcsd1d.py:273
+        else build_kphi(c, g, hp->R, hp->eps, hp->ell_s, dz, nz, 0.0, Kc, sp);              // gpcsd1d.py:275
+        k_sym_fold_rect(c, Kc, nz, fm.sym_s, sz, kf, kf + (size_t)ns * nzs, sp);
     }
     for (int cc = 0; cc < C; ++cc) {
-        temporal_cross_gram(c, hp, cc, dts, nt, t, nt, Kts + (size_t)cc * nt * nt, s);
+        temporal_cross_gram(c, hp, cc, dts, nt, t, nt, Kts + (size_t)cc * nt * nt, sp);
         k_sym_fold_rect(c, Kts + (size_t)cc * nt * nt, nt, fm.sym_t, fm.sym_t, Ktf + cc * ktf_sz,
-                        Ktf + cc * ktf_sz + (size_t)nts * nts, s);
+                        Ktf + cc * ktf_sz + (size_t)nts * nts, sp);
     }
+    if (prelude_side) GP_HIP(hipEventRecord(c->ev_prelude, sp));
     // then everything that needs only the spatial eigenvectors, beside the temporal eigensolver
     if (before_spatial_join) (*before_spatial_join)();
     // tridiagonal form (EigState::tri): X = Y~ Q needs the temporal tridiagonalisation + Q only and is queued in front of the wait
@@ -346,6 +365,7 @@ static int predict_fold(gpcsd_ctx *c, const gpcsd_hparams *hp, EigState &e, cons
         e.wait_q = false;
     }
     fold_proj_spatial(c, fm.fs, e.tri ? c->buf<double>(xname, (size_t)nx * RT) : Yf, W, RT, s);   // W~ = diag(U)^T Y~ (or of Y~ Q)
+    if (prelude_side) GP_HIP(hipStreamWaitEvent(s, c->ev_prelude, 0));
     for (int which = 1; which <= 2; ++which) {
         if (!(type & which)) continue;
         const double *kf = Kcf + (size_t)(which - 1) * kcf_sz;
@@ -361,6 +381,8 @@ static int predict_fold(gpcsd_ctx *c, const gpcsd_hparams *hp, EigState &e, cons
             gemm_f64(c, gm, s);
         }
     }
+    GP_HIP(hipEventRecord(c->ev_m1, s));
+    c->m1_read_queued = true;
     // the temporal basis of everything below: the eigenvectors V_p (blocks of fm.ft.U), or in the tridiagonal form the orthogonal
     // factors Q_p of the tridiagonalisation (replica e.tri_rep of the temporal classes)
     const double *Tb[2] = {fm.ft.U, fm.ft.U + (size_t)nts * nts};
@@ -387,7 +409,7 @@ static int predict_fold(gpcsd_ctx *c, const gpcsd_hparams *hp, EigState &e, cons
     // own beside the large Bm~ / S~ products of the main stream instead of in front of them (two small launches off the
     // serial tail) -- not on stream2, where it would sit between this call's temporal chain and the next call's
     GP_HIP(hipEventRecord(c->ev_aux, s));                            // Kt*~ and the temporal eigenvectors are complete here
-    GP_HIP(hipStreamWaitEvent(c->stream4, c->ev_aux, 0));
+    GP_HIP(hipStreamWaitEvent(c->stream5, c->ev_aux, 0));
     for (int p = 0; p < 2; ++p) {
         const int np = p ? nta : nts, npP = p ? ntaP : ntsP;
         if (np == 0) continue;
@@ -398,10 +420,10 @@ static int predict_fold(gpcsd_ctx *c, const gpcsd_hparams *hp, EigState &e, cons
         gp.C = Pc + (p ? pc_s : 0); gp.ldc = (long)C * npP;
         gp.batch = C; gp.sA = 0; gp.sB = (long)ktf_sz; gp.sC = npP;
         gp.prof_name = "gemm_pred_Pc";
-        gemm_f64(c, gp, c->stream4);
+        gemm_f64(c, gp, c->stream5);
     }
-    GP_HIP(hipEventRecord(c->ev_pc, c->stream4));
-    c->tl("Pc end (s4)", c->stream4);
+    GP_HIP(hipEventRecord(c->ev_pc, c->stream5));
+    c->tl("Pc end (s5)", c->stream5);
     if (e.tri) {
         // Bm~ = the solutions of the shifted tridiagonal systems (es[x'] m T_p + sig2 I) b = w, row by row of W~ = diag(U)^T Y~ Q
         const char *const *tg = eigh_fold_tags(c, 1);
@@ -413,6 +435,10 @@ static int predict_fold(gpcsd_ctx *c, const gpcsd_hparams *hp, EigState &e, cons
             const EigArenaView av = eigh_arena_view(c, tg[p], np[p], e.tri_count);
             const long o = (long)e.tri_rep * av.blk;
             d[p] = av.d + o; ee[p] = av.e + o; am[p] = av.amax + o; bd[p] = av.bd + o;
+        }
+        if (c->t1_wait_pending) {
+            GP_HIP(hipStreamWaitEvent(s, c->ev_t1, 0));
+            c->t1_wait_pending = false;
         }
         if (e.band) k_band_solve(c, W, Bm, fm.fs.w, bd, np, am, e.d_sig, nx, R, nt, np, c0, s);
         else k_tridiag_solve(c, W, Bm, fm.fs.w, d, ee, am, e.d_sig, nx, R, nt, np, c0, s);
@@ -436,7 +462,7 @@ static int predict_fold(gpcsd_ctx *c, const gpcsd_hparams *hp, EigState &e, cons
             g5[p].prof_name = "gemm_pred_cross";
         }
         gemm_pair(c, g5[0], g5[1], s);
-        if (which == 1 || !(type & 1)) GP_HIP(hipStreamWaitEvent(s, c->ev_pc, 0));     // Pcat (stream4) before its first use
+        if (which == 1 || !(type & 1)) GP_HIP(hipStreamWaitEvent(s, c->ev_pc, 0));     // Pcat (stream5) before its first use
         for (int p = 0; p < 2; ++p) {     // comp~[(zq, r)][p][cc][b] = sum_i' S~[(zq, r)][p block i'] Pcat_p[i'][cc*npP + b]
             const int np = p ? nta : nts, npP = p ? ntaP : ntsP, c0 = p ? nts : 0;
             // (the padding columns between two components are computed along -- whatever Pcat holds there only reaches comp~'s
@@ -582,7 +608,15 @@ static int predict_impl(gpcsd_ctx *c, const gpcsd_hparams *hp, const double *z, 
         if (sz.ns > 0 && sz.ns + sz.na == nz) {
             // the chains go first (they need no upload of this call), then the host-side uploads
             const bool ptri = fm0.ft.on && predict_tridiag_applies(fm0.ft.ns, fm0.ft.na, c->ntrials);
-            EigState ef = front_half(c, hp, 0.0, false, /*join_s=*/false, /*want_tri=*/ptri, fold_s ? -1 : 1);  // no jitter in predict (gpcsd1d.py:258)
+            c->q_pipe_want = ptri;                                          // (X = Y~ Q goes through loglik_tri_pre: stage 5 may apply)
+            EigState ef;
+            try {
+                ef = front_half(c, hp, 0.0, false, /*join_s=*/false, /*want_tri=*/ptri, fold_s ? -1 : 1);  // no jitter in predict (gpcsd1d.py:258)
+            } catch (...) {
+                c->q_pipe_want = false;
+                throw;
+            }
+            c->q_pipe_want = false;
             const FoldMode fm = fold_mode(c, hp, fold_s);
             const double *Yf = folded_lfp(c, fm);
             double *dzf = c->upload_cached<double>("pred_z", z, (size_t)nz * c->dim);
@@ -629,6 +663,8 @@ static int predict_impl(gpcsd_ctx *c, const gpcsd_hparams *hp, const double *z, 
         gm.prof_name = "gemm_pred_M1";
         gemm_f64(c, gm, s);
     }
+    GP_HIP(hipEventRecord(c->ev_m1, s));          // (a later paired call rewrites the cross-covariances on stream5)
+    c->m1_read_queued = true;
     for (int cc = 0; cc < C; ++cc) {
         // Ktstar_c = cov_c.compute_Kt(tstar): (ntstar, nt); its FIRST axis is contracted with the training
         // time index (reference quirk when tstar != t)      gpcsd1d.py:277-279
@@ -727,6 +763,7 @@ static void front_half_pair(gpcsd_ctx *c, const gpcsd_hparams *const hp[2], cons
     // assembled once and copied (the same GEMM output plus the same diagonal add: the same bits).
     const bool tfill = temporal_fill_applies(c, sym_t, nt, false);       // (the paired call is refused for host temporal Grams)
     const bool staged = tfill && ll_tridiag_enabled(c) && eigh_stageable(sym_t, nt);
+    bool pipe = false;                   // stage 5 instead of stage 3: decided in part 1 (not in band mode)
     // part 1: the inputs and (staged) stage 1, or the whole chain; part 2 (staged only): stage 2, and stage 3 beside it
     auto run_T = [&](int part) {
         if (part == 1) {
@@ -748,8 +785,14 @@ static void front_half_pair(gpcsd_ctx *c, const gpcsd_hparams *const hp[2], cons
                 c->band_req = (pred_tri && band_tail_applies(c, sym_t, c->ntrials, true)) ? 4 : 0;
                 c->tri_band[c->tgen] = c->band_req;
                 if (c->band_req) ++c->band_tail_calls;
+                // (only when the prediction takes the tridiagonal form too: a stage 4 behind stage 5 would read T factors summed in
+                // another order than stage 3's, and the pair would differ from its fenced calls in the last bits)
+                pipe = pred_tri && !c->band_req && q_pipe_applies(c, sym_t);
+                if (pipe) GP_HIP(hipEventRecord(c->ev_t0, s2));
+                c->pipe_req = pipe ? 1 : 0;
                 eigh_pair_device(c, nullptr, 0, nullptr, nullptr, nullptr, Kt, nt, et, Qt, sym_t, status + 1, s2, false, nT, 2, -1, 2, 1);
                 c->band_req = 0;
+                c->pipe_req = 0;
                 GP_HIP(hipEventRecord(c->ev_t1, s2));
                 c->tl("T stage 1 end (s2)", s2);
                 return;
@@ -761,11 +804,16 @@ static void front_half_pair(gpcsd_ctx *c, const gpcsd_hparams *const hp[2], cons
                 if (!pred_tri)
                     eigh_pair_device(c, nullptr, 0, nullptr, nullptr, nullptr, Kt, nt, et, Qt, sym_t, late + 1, s2, false, nT, 2, -1, 2, 2);
                 hipStream_t sq = c->stream4;
-                GP_HIP(hipStreamWaitEvent(sq, c->ev_t1, 0));
-                eigh_pair_device(c, nullptr, 0, nullptr, nullptr, nullptr, Kt, nt, et, Qt, sym_t, status + 1, sq, false, nT, 2, -1, 2, 3);
-                GP_HIP(hipEventRecord(c->ev_q[c->tgen], sq));
-                c->tl("Q end", sq);
-                c->q_queued[c->tgen] = true;
+                if (pipe) {              // (stage 5 is queued by the log-likelihood's loglik_tri_pre: EigState::pipe_pending)
+                    c->q_queued[c->tgen] = false;
+                } else {
+                    GP_HIP(hipStreamWaitEvent(sq, c->ev_t1, 0));
+                        GP_HIP(hipStreamWaitEvent(sq, c->ev_pc, 0));      // (stream5's readers of the Q about to be rewritten)
+                    eigh_pair_device(c, nullptr, 0, nullptr, nullptr, nullptr, Kt, nt, et, Qt, sym_t, status + 1, sq, false, nT, 2, -1, 2, 3);
+                    GP_HIP(hipEventRecord(c->ev_q[c->tgen], sq));
+                    c->tl("Q end", sq);
+                    c->q_queued[c->tgen] = true;
+                }
                 c->q_gen = -1;           // (replicas: not what a separate call's cache looks for)
                 if (!pred_tri) {
                     GP_HIP(hipStreamWaitEvent(s2, c->ev_q[c->tgen], 0));
@@ -831,6 +879,11 @@ static void front_half_pair(gpcsd_ctx *c, const gpcsd_hparams *const hp[2], cons
             e.tri_rep = bt;
             e.tri_count = nT;
             e.band = c->tri_band[c->tgen];
+            if (pipe && b == 0) {        // X with replica 0's Q: the log-likelihood's set
+                e.pipe_pending = true;
+                e.pa.Kt = Kt; e.pa.nt = nt; e.pa.et = et; e.pa.Qt = Qt; e.pa.sym_t = sym_t; e.pa.status = status + 1;
+                e.pa.need_merged = false; e.pa.nT = nT; e.pa.stride = 2; e.pa.rep = 0; e.pa.q_gen = -1;
+            }
         }
         FoldMode &fm = out.fm[b];
         fm = fold_mode(c, hp[b], fold_s);               // replica 0 of the generations just started ...
@@ -906,10 +959,21 @@ extern "C" int gpcsd_loglik_predict_async(gpcsd_ctx *c, const gpcsd_hparams *hp_
     PairFront pf;
     // (decided here, where the fold sizes are known: does the prediction take the tridiagonal form too?)
     const bool pred_tri = fm0.ft.on && predict_tridiag_applies(fm0.ft.ns, fm0.ft.na, c->ntrials);
-    front_half_pair(c, hps, jit, pf, pred_tri, fold_s);
+    c->q_pipe_want = fm0.ft.on;                          // (the log-likelihood's X goes through loglik_tri_pre: stage 5 may apply)
+    try {
+        front_half_pair(c, hps, jit, pf, pred_tri, fold_s);
+    } catch (...) {
+        c->q_pipe_want = false;
+        throw;
+    }
+    c->q_pipe_want = false;
     const double *Yf = folded_lfp(c, pf.fm[1]);
+    const long up0 = c->upload_count;
     double *dzf = c->upload_cached<double>("pred_z", z, (size_t)nz * c->dim);
     double *dtf = c->upload_cached<double>("pred_tstar", tstar, ntstar);
+    // (sites or times uploaded just now, on the main stream: the builders that read them stay there)
+    static const bool side_off = getenv("GPCSD_PRELUDE_SIDE") && getenv("GPCSD_PRELUDE_SIDE")[0] == '0';
+    const bool prelude_side = !side_off && c->upload_count == up0 && pf.e[0].pipe_pending;
     const std::function<void()> ll_pre = [&]() {
         if (pf.e[0].tri) loglik_tri_pre(c, pf.e[0], pf.fm[0], Yf);
     };
@@ -927,7 +991,7 @@ extern "C" int gpcsd_loglik_predict_async(gpcsd_ctx *c, const gpcsd_hparams *hp_
     const bool share_x = c->pair_share_x && pf.e[0].tri && pf.e[1].tri && ll_order() == 0 && same_temporal(hp_ll, hp_pr);
     if (share_x) ++c->pair_shared_x_calls;
     return predict_fold(c, hp_pr, pf.e[1], pf.fm[1], Yf, sz, dzf, nz, dtf, type, want_lists != 0, true, &ll_tail, &ll_pre,
-                        share_x ? "ll_X" : nullptr);
+                        share_x ? "ll_X" : nullptr, prelude_side);
     GP_API_END(c)
 }
 

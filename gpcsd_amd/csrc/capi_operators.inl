@@ -629,6 +629,14 @@ extern "C" int gpcsd_band_tail(gpcsd_ctx *c, int on, long *calls) {
     GP_API_END(c)
 }
 
+extern "C" int gpcsd_q_pipeline(gpcsd_ctx *c, int on, long *calls) {
+    GP_API_BEGIN(c)
+    if (on >= 0) c->q_pipe = on != 0;
+    if (calls) *calls = c->q_pipe_calls;
+    return 0;
+    GP_API_END(c)
+}
+
 extern "C" int gpcsd_fold_gemm(gpcsd_ctx *c, int on, long *calls) {
     GP_API_BEGIN(c)
     if (on >= 0) c->fold_gemm_on = on != 0;

@@ -66,7 +66,9 @@ struct gpcsd_ctx {
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;          // temporal chain (Kt, its eigen-decomposition)
     hipStream_t stream3 = nullptr;          // spatial chain (Ks assembly, its eigen-decomposition)
-    hipStream_t stream4 = nullptr;          // predict: the small Pcat products, beside the large GEMMs of the main stream
+    hipStream_t stream4 = nullptr;          // stage 3 / stage 5 of a staged temporal chain; the chunked copy-out of gpcsd_predict
+    hipStream_t stream5 = nullptr;          // predict: what needs no decomposition (paired call) and the small Pcat products, beside
+                                            // the large GEMMs of the main stream
     // Scalars and status words of the fused calls share one device allocation ("scal_status") and travel in one copy:
     // SCAL_N doubles, then STATUS_N ints.  Words [0..3]: the spatial chain ([0], second replica [2]) and the temporal chain
     // ([1], [3]) up to and including what a log-likelihood in the tridiagonal form consumes (stages 1 and 3 of a staged chain,
@@ -186,6 +188,33 @@ struct gpcsd_ctx {
     int band_req = 0;
     int tri_band[2] = {0, 0};
     long band_tail_calls = 0;
+    // Pipelined stage 3 (round 5; wy.hip: wy_q_pipeline): the register tail of a staged temporal chain publishes its progress panel by
+    // panel; T factors and the finished columns of Q follow on stream4 WHILE the tail reduces the next panel, and the matching
+    // columns of X = Y~ Q on the main stream behind an event per panel -- behind the tail only the last panel's share is left (T, Q
+    // and X stood for 0.18 ms of a 0.95 ms cfg3 step).
+    // q_pipe: the switch (gpcsd_q_pipeline() / GPCSD_Q_PIPE=0).  q_pipe_want: set by a caller around its front half -- it promises to
+    // form X through loglik_tri_pre, where stage 5 is queued (EigState::pipe_pending).  pipe_req: set around the stage-1 call
+    // (problem set-up, graph key).  q_pipe_x: what stage 5 hangs on every finished block of columns -- in / out (nx R rows of nt), the
+    // parity blocks' first columns.
+    bool q_pipe = true;
+    bool q_pipe_want = false;
+    int pipe_req = 0;
+    long q_pipe_calls = 0;
+    struct QPipeX {
+        const double *in = nullptr;
+        double *out = nullptr;
+        int M = 0, ld = 0, c0[2] = {0, 0}, rep = 0;
+    } q_pipe_x;
+    hipEvent_t ev_t0 = nullptr;             // the temporal chain's inputs are in place (stream2, in front of stage 1): stage 5 starts behind it
+    bool t1_wait_pending = false;           // stage 5 was queued: the main stream's first reader of d / e still has to wait for ev_t1
+    hipEvent_t ev_stage[8] = {};            // stage 5: panel k's columns of Q are final (stream4) -> the main stream's product on them
+    // the paired call's prediction builds what needs no decomposition (cross-covariances, prediction-time Grams: ~0.1 ms of small
+    // launches) on stream5 instead of in front of the log-likelihood's products on the main stream
+    hipEvent_t ev_prelude = nullptr;        // ... done (stream5)
+    hipEvent_t ev_m1 = nullptr;             // the main stream's readers of the folded cross-covariances are done (any predict)
+    bool m1_read_queued = false;
+    int q_pipe_mask = -1;                   // stage 5: bit p set = the product on Q's finished columns is launched behind panel p
+                                            // (always behind the last; a skipped panel's columns ride in the next launch); -1: default
     // gpcsd_predict (host outputs): the caller's arrays while the call runs.  The fused last product of a folded prediction is then
     // launched in chunks of site orbits and every chunk's finished output rows are copied out (stream4: the DMA engine) while the
     // next chunk computes -- predict_sink_done[which] tells gpcsd_predict that nothing is left to download (capi_fused.inl).
@@ -248,6 +277,7 @@ struct gpcsd_ctx {
     // upload that is skipped when the named device buffer already holds exactly these bytes (hyper-parameter vectors,
     // prediction sites and times repeat from call to call; a pageable host-to-device copy costs ~10 us of host time)
     std::map<std::string, std::vector<unsigned char>> upload_shadow;
+    long upload_count = 0;                  // uploads upload_cached() really queued (on the main stream)
     template <typename T = double>
     T *upload_cached(const std::string &name, const T *host, size_t count) {
         const size_t bytes = count * sizeof(T);
@@ -256,6 +286,7 @@ struct gpcsd_ctx {
         T *d = buf<T>(name, count);
         if (alloc_epoch == epoch_before && sh.size() == bytes && bytes > 0 && memcmp(sh.data(), host, bytes) == 0) return d;
         if (count) GP_HIP(hipMemcpyAsync(d, stage_small(host, bytes), bytes, hipMemcpyHostToDevice, stream));
+        ++upload_count;
         sh.assign(reinterpret_cast<const unsigned char *>(host), reinterpret_cast<const unsigned char *>(host) + bytes);
         return d;
     }

@@ -420,13 +420,15 @@ void eigh_pair_device(gpcsd_ctx *c, double *A0, int n0, double *w0, double *Z0, 
     const bool any_large = !force_jacobi() && (n0 > JACOBI_LDS_MAX || n1 > JACOBI_LDS_MAX);
     // profiling mode 3 keeps replaying graphs, so the outer scopes time the chains as they run in production
     const bool prof_graph = c->prof_mode == 3;
-    if (!any_large || (c->prof_on && !prof_graph) || !graphs_enabled()) {
+    // (stage 5 records events and queues products on the main stream between its launches: never captured)
+    if (!any_large || (c->prof_on && !prof_graph) || !graphs_enabled() || stage == 5) {
         eigh_pair_enqueue(c, A0, n0, w0, Z0, sym0, A1, n1, w1, Z1, sym1, d_status, s, need_merged, count, status_stride, count1, prefolded_mask, stage);
         return;
     }
     // (the generation of each slot picks the fold-order output buffers, which are not among the arguments)
     // (... and SytrdProb::psd of the prefilled classes, a kernel argument: what their fills announced, and the context's switch)
-    int psd_sig = (c->tail_early_exit ? 16 : 0) | (c->claim_psd ? 32 : 0) | (c->band_req ? 64 : 0);   // (band mode: another tail kernel)
+    int psd_sig = (c->tail_early_exit ? 16 : 0) | (c->claim_psd ? 32 : 0) | (c->band_req ? 64 : 0) |  // (band mode: another tail kernel)
+                  (c->pipe_req ? 128 : 0);                                                           // (progress words: a kernel argument)
     for (int p = 0; p < 2; ++p) {
         const char *const *tg = eigh_fold_tags(c, p);
         for (int h = 0; h < 2; ++h) {
@@ -434,8 +436,10 @@ void eigh_pair_device(gpcsd_ctx *c, double *A0, int n0, double *w0, double *Z0, 
             if (((prefolded_mask >> p) & 1) && it != c->arena_psd.end() && it->second) psd_sig |= 1 << (2 * p + h);
         }
     }
-    char key[368];
-    snprintf(key, sizeof(key), "eigh|%p|%d|%p|%p|%p|%d|%p|%d|%p|%p|%p|%d|%p|%p|%d|%d|%d|%d%d|%d|%d|%d|%d|%d", (void *)A0, n0, (void *)w0, (void *)Z0,
+    char key[448];
+    const gpcsd_ctx::QPipeX qx = stage == 5 ? c->q_pipe_x : gpcsd_ctx::QPipeX();       // (stage 5 launches the caller's products)
+    int nk = snprintf(key, sizeof(key), "x%p|%p|%d|%d|%d|%d|%d|", (const void *)qx.in, (void *)qx.out, qx.M, qx.ld, qx.c0[0], qx.c0[1], qx.rep);
+    snprintf(key + nk, sizeof(key) - nk, "eigh|%p|%d|%p|%p|%p|%d|%p|%d|%p|%p|%p|%d|%p|%p|%d|%d|%d|%d%d|%d|%d|%d|%d|%d", (void *)A0, n0, (void *)w0, (void *)Z0,
              (void *)(sym0 ? sym0->rep_i : nullptr), sym0 ? sym0->ns : 0, (void *)A1, n1, (void *)w1, (void *)Z1,
              (void *)(sym1 ? sym1->rep_i : nullptr), sym1 ? sym1->ns : 0, (void *)d_status, (void *)s, (int)need_merged, count,
              status_stride, c->par[0], c->par[1], count1, prefolded_mask, (int)(c->prof_mode == 3),   // (mode 3 graphs carry clock stamps)

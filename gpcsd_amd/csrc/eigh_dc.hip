@@ -87,7 +87,10 @@ struct SytrdProb {
     long blk;             // replica stride of the arena, in doubles
     double *bd;           // band mode: (BT_W + 1) x n, bd[j * n + k] = B[k + j][k] (sytrd_bandtail.hpp)
     int band;             // 0: tridiagonal (d, e);  4: the tail reduces to half-bandwidth 4 (bd) -- whole problems of <= bt_max_rows() rows
+    int pipe;             // the register tail publishes its progress panel by panel (sy_progress_word; whole problems only)
 };
+// the progress word of a problem: behind tau's n + WY_NB entries (the slice has two more; cleared with tau by whoever fills the arena)
+__host__ __device__ inline unsigned *sy_progress_word(const SytrdProb &P) { return reinterpret_cast<unsigned *>(P.tau + P.n + WY_NB); }
 struct SytrdBatch {
     SytrdProb p[MAX_BATCH];
     int start[MAX_BATCH + 1];
@@ -271,6 +274,7 @@ __global__ void sytrd_last_diag_kernel(SytrdBatch b) {
 
 // rows the single-workgroup tail (sytrd_regtail.hpp) can hold: 192 in registers + up to 64 strip rows in LDS
 static int sy_regtail_rows() { return RT_TMAX; }
+int eigh_regtail_rows() { return RT_TMAX; }
 
 static void sytrd_batch_launch(gpcsd_ctx *c, const SytrdBatch &b, int nclass, int nmax, hipStream_t s) {
     int klast = -1;                                        // last column handled by per-column launches
@@ -440,7 +444,7 @@ static void layout_arena(gpcsd_ctx *c, const std::string &tag, int n, int count,
     const std::string T = "eig_" + tag + "_";
     const int npanels = std::max(1, ceil_div(std::max(n - 2, 1), WY_NB));
     ArenaLayout L;
-    const size_t oA0 = L.take(nn), oA1 = L.take(nn), oV = L.take((size_t)(n + WY_NB) * n), otau = L.take(n + WY_NB);
+    const size_t oA0 = L.take(nn), oA1 = L.take(nn), oV = L.take((size_t)(n + WY_NB) * n), otau = L.take(n + WY_NB + 2);
     const size_t od = L.take(n), oe = L.take(n), oy0 = L.take(n), oy1 = L.take(n), oamax = L.take(2 + AMAX_PARTS);
     const size_t oT = L.take((size_t)npanels * WY_NB * WY_NB);
     const size_t obd = L.take((size_t)(BT_W + 1) * n);
@@ -480,6 +484,8 @@ static void prep_problem(gpcsd_ctx *c, EigProb &p, hipStream_t s) {
     // band mode on the word of the caller (gpcsd_ctx::band_req: a staged chain whose consumers all take the banded form), for whole
     // problems the band tail can hold
     p.sp.band = (c->band_req == BT_W && p.sp.k_tail == 0 && n <= bt_max_rows()) ? BT_W : 0;
+    // progress words on the word of the caller too (gpcsd_ctx::pipe_req: stage 5 of a staged chain follows on another stream)
+    p.sp.pipe = (c->pipe_req && p.sp.k_tail == 0 && !p.sp.band) ? 1 : 0;
     (void)s;
 }
 
@@ -555,7 +561,7 @@ __global__ __launch_bounds__(256) void scale_copy_zero_batch_kernel(PrepBatch b)
     if (bad && v.status) atomicMax(v.status, 4);
     const long nv = (n + WY_NB) * n;
     for (long i = i0; i < nv; i += stride) P.V[i] = 0.0;
-    for (long i = i0; i < n + WY_NB; i += stride) P.tau[i] = 0.0;
+    for (long i = i0; i < n + WY_NB + 2; i += stride) P.tau[i] = 0.0;     // (+2: the progress word)
 }
 
 static PrepBatch prep_batch_launch(gpcsd_ctx *c, EigProb *probs, int nclass, hipStream_t s, int *d_status = nullptr,
@@ -674,6 +680,81 @@ void eigh_large_batch(gpcsd_ctx *c, EigProb *probs, int nclass, int *d_status, i
             wb.p[i].blk = p.sp.blk; wb.p[i].sZ = p.sZ; wb.p[i].sw = p.sw;
         }
     if (stage == 1) return;                    // the tridiagonalisation alone
+    if (stage == 5) {
+        // Stage 3 panel by panel beside a stage 1 that is still running (wy.hip: wy_q_pipeline; the tails were launched with
+        // SytrdProb::pipe), each finished block of columns of Q followed by the caller's product on it (gpcsd_ctx::q_pipe_x).
+        ProfScope ps(c, "eigh_stage5_TQX", 0.0, s);
+        WyBatch wq = wb;
+        wq.status = d_status;
+        double *Qv[MAX_BATCH];
+        for (int i = 0; i < nclass; ++i) {
+            GP_REQUIRE(probs[i].sp.k_tail == 0, -3, "eigh: stage 5 needs whole problems in the register tail (n=%d)", probs[i].n);
+            Qv[i] = eigh_Q_view(c, probs[i].tag.c_str(), probs[i].n, probs[i].count);
+            wq.p[i].Z = Qv[i];
+            wq.p[i].sZ = (long)probs[i].n * probs[i].n;
+            wq.p[i].w_scale = nullptr;
+        }
+        const gpcsd_ctx::QPipeX x = c->q_pipe_x;
+        GP_REQUIRE(!x.in || nclass <= 2, -3, "eigh: stage 5 with a product serves one folded problem (two classes)");
+        int stage_k = 0, maxP = 0;
+        for (int i = 0; i < nclass; ++i) maxP = std::max(maxP, wq.p[i].npanels);
+        // which panels are followed by a launch of the product: a 64-column launch costs a tile's whole latency (~40 us for ~26 us
+        // worth of the full product), so the first two panels share one (GPCSD_QPIPE_MASK, gpcsd_ctx::q_pipe_mask)
+        const int mask = c->q_pipe_mask >= 0 ? c->q_pipe_mask : ~1;
+        static const int chunk_cfg = getenv("GPCSD_QPIPE_CFG") ? atoi(getenv("GPCSD_QPIPE_CFG")) : 0;
+        int pend0[MAX_BATCH], pend1[MAX_BATCH];            // columns of Q finished and not yet multiplied
+        for (int i = 0; i < MAX_BATCH; ++i) pend0[i] = pend1[i] = -1;
+        wy_q_pipeline(c, wq, nclass, s, [&](const int *col0_in, const int *col1_in) {
+            if (!x.in) return;
+            const int k = stage_k;
+            for (int i = 0; i < nclass; ++i)
+                if (col1_in[i] > col0_in[i]) {
+                    if (pend0[i] < 0) pend0[i] = col0_in[i];
+                    pend1[i] = col1_in[i];
+                }
+            if (!((mask >> k) & 1) && k + 1 < maxP) {      // no launch behind this panel: its columns wait for the next one
+                ++stage_k;
+                return;
+            }
+            int col0[MAX_BATCH], col1[MAX_BATCH];
+            for (int i = 0; i < nclass; ++i) {
+                col0[i] = pend0[i] >= 0 ? pend0[i] : 0;
+                col1[i] = pend0[i] >= 0 ? pend1[i] : 0;
+                pend0[i] = pend1[i] = -1;
+            }
+            // the product on the panel's columns runs on the MAIN stream behind the panel's event: beside the previous call's large
+            // products it would only take their CUs (measured: 40 us of tiles took 190), behind them it fills the main stream's idle
+            // time under the end of the tail
+            hipEvent_t ev = c->ev_stage[stage_k++ & 7];
+            c->tl("stage 5 panel end (s4)", s);
+            GP_HIP(hipEventRecord(ev, s));
+            GP_HIP(hipStreamWaitEvent(c->stream, ev, 0));
+            hipStream_t sx = c->stream;
+            GemmDesc g[2];
+            int live = 0;
+            for (int i = 0; i < nclass; ++i) {
+                const int np = probs[i].n, w = col1[i] - col0[i];
+                if (w <= 0) continue;
+                GemmDesc &d = g[live++];
+                d.M = x.M; d.N = w; d.K = np;
+                d.A = x.in + x.c0[i]; d.lda = x.ld;
+                d.B = Qv[i] + (size_t)x.rep * np * np + col0[i]; d.ldb = np;
+                d.C = x.out + x.c0[i] + col0[i]; d.ldc = x.ld;
+                d.prof_name = "gemm_ll_YQ";
+                d.cfg = chunk_cfg;
+            }
+            if (live == 2 && g[0].N == g[1].N && g[0].K == g[1].K) {     // the two parity blocks as one batched launch
+                g[0].batch = 2;
+                g[0].sA = g[1].A - g[0].A; g[0].sB = g[1].B - g[0].B; g[0].sC = g[1].C - g[0].C;
+                gemm_f64(c, g[0], sx);
+            } else {
+                for (int i = 0; i < live; ++i) gemm_f64(c, g[i], sx);
+            }
+            c->tl("X block end (main)", sx);
+        });
+        GP_HIP(hipGetLastError());
+        return;
+    }
     if (stage == 3) {
         // T factors of the reflector panels as a launch of their own (unstaged they ride in the divide & conquer's leaf launch),
         // then Q = the panels applied to the identity (the back-transformation's apply launch, its slab of Z starting as

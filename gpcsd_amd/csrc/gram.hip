@@ -221,8 +221,8 @@ __global__ __launch_bounds__(256) void temporal_fold_fill_kernel(TFoldFillArgs g
         const long nvs = (long)(ns + 64) * ns, nva = (long)(na + 64) * na;
         for (long i = i0; i < nvs; i += stride) Vs[i] = 0.0;
         for (long i = i0; i < nva; i += stride) Va[i] = 0.0;
-        for (long i = i0; i < ns + 64; i += stride) ts[i] = 0.0;
-        for (long i = i0; i < na + 64; i += stride) ta[i] = 0.0;
+        for (long i = i0; i < ns + 66; i += stride) ts[i] = 0.0;           // (+2: the tail's progress word, eigh_dc.hip)
+        for (long i = i0; i < na + 66; i += stride) ta[i] = 0.0;
         if (blockIdx.x == g.elem_blocks && threadIdx.x == 0) {
             const double mr = g.tab ? tfold_scale(g.tab[rep].sigma2_t, g.tab[rep].ncomp) : g.m[rep];
             g.amaxs[rep * g.blks] = mr;

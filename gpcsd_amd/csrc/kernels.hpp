@@ -1,5 +1,6 @@
 // Device-pointer launchers shared between translation units of libgpcsd_hip.so.
 #pragma once
+#include <functional>
 #include "ctx.hpp"
 
 namespace gpcsd {
@@ -211,6 +212,7 @@ struct EigArenaView {
     bool *psd;                   // host flag of the class (gpcsd_ctx::arena_psd): a fill that writes a positive semi-definite matrix sets it
     double *bd;                  // band mode (gpcsd_ctx::band_req): 5 x n, bd[j * n + k] = B[k + j][k] of A0 = Q B Q^T, half-bandwidth 4
 };
+int eigh_regtail_rows();         // rows of a whole problem the register tail (sytrd_regtail.hpp) holds: stage 5 applies up to here
 int bt_max_rows();               // rows of a whole problem the band tail (sytrd_bandtail.hpp) can hold
 EigArenaView eigh_arena_view(gpcsd_ctx *c, const char *tag, int n, int count);
 // tags of the two half-size classes of problem `slot` (0 / 1) of eigh_pair_device: [0] symmetric, [1] antisymmetric
@@ -289,6 +291,7 @@ struct WyBatch {
     WyProb p[MAX_EIG_BATCH];         // one entry per class
     int start[MAX_EIG_BATCH + 1];    // prefix sums of the replica counts (see class_of)
     unsigned long long *clk = nullptr;   // measurement aid (GPCSD_WY_CLK=1): wall-clock stamps of workgroup (0, 0) at its phase boundaries
+    int *status = nullptr;               // stage 5 (wy_q_pipeline): a gate whose time ran out reports failure 7 here
 };
 __device__ __forceinline__ WyProb wy_resolve(const WyBatch &b, int g) {
     int cls, rep;
@@ -305,6 +308,10 @@ bool wy_fused_supported(int nmax);
 // prep_done: the T factors were already formed by the D&C leaf launch (stedc_batch_device with a WyBatch)
 void wy_batch_device(gpcsd_ctx *c, const WyBatch &b, int nclass, hipStream_t s, bool prep_done = false);
 void wy_prep_device(gpcsd_ctx *c, const WyBatch &b, int nclass, hipStream_t s);     // the T factors only
+// Q panel by panel behind the progress words of a register tail that is still running (wy.hip); chunk: the caller's work on the
+// columns [col0[i], col1[i]) of class i's Q that the panel just applied completes
+void wy_q_pipeline(gpcsd_ctx *c, const WyBatch &b, int nclass, hipStream_t s,
+                   const std::function<void(const int *col0, const int *col1)> &chunk);
 // stages of the large-n solver, exposed for tests / diagnostics
 void sytrd_device(gpcsd_ctx *c, double *A, int n, double *d, double *e, double *V, double *tau, hipStream_t s);
 // the band tail on its own (sytrd_bandtail.hpp): A = Q B Q^T, band (5 x n: band[j * n + k] = B[k + j][k]), reflectors as sytrd_device

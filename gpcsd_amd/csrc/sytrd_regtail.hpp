@@ -30,6 +30,7 @@ namespace gpcsd {
 
 constexpr int RT_R = 4, RT_C = 12, RT_T = 192, RT_NTH = (RT_T / RT_R) * (RT_T / RT_C), RT_NW = RT_NTH / 64;
 constexpr int RT_SMAX = 64, RT_TMAX = RT_T + RT_SMAX;     // strip rows, largest tail
+constexpr unsigned RT_PROG_DONE = 0x7fffffffu;            // progress word of a finished launch (see sytrd_rtail_kernel)
 static_assert(RT_T / RT_C == 16 && RT_NTH == 768, "one DPP row per row group");
 
 // strip rows are LDT doubles apart: LDT / 2 odd, so that sixteen consecutive rows start in distinct 16-byte bank groups
@@ -46,6 +47,9 @@ __device__ __forceinline__ double row16_sum(double v) {
     v += dpp_mov<0x140>(v);
     return v;
 }
+
+// a store that is visible to the other XCDs once it has completed (relaxed, agent scope: written through this XCD's L2)
+__device__ __forceinline__ void rt_store_agent(double *p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 // Householder scalars of a column with pivot alpha and squared norm xnorm2 below it: H = I - tau u u^T with
 // u = (alpha - beta, x_2, ..) left UN-normalised: u is known as soon as s = sqrt(alpha^2 + |x|^2) is, and
@@ -107,6 +111,28 @@ __global__ __launch_bounds__(RT_NTH) void sytrd_rtail_kernel(SytrdBatch b) {
     const int row0 = 16 * wid + 4 * gg, c0 = RT_C * h;
     const double *__restrict__ Ain = (k0 & 1) ? P.A1 : P.A0;
     const double *__restrict__ yin = (k0 & 1) ? P.y1 : P.y0;
+    // Progress word (SytrdProb::pipe, whole problems only): the number of leading reflectors whose rows of V and whose tau are
+    // complete in global memory, published at every multiple of 64 -- one compact-WY panel -- and RT_PROG_DONE behind the last
+    // store of the launch.  The consumers of a staged chain (wy.hip: the T factor of a panel, the columns of Q and of X = Y~ Q the
+    // panel completes) start on their panel while this workgroup is still reducing the next one.
+    unsigned *const prog = sy_progress_word(P);
+    const bool pipe = P.pipe != 0 && k0 == 0;
+    if (pipe && threadIdx.x == 0) reinterpret_cast<unsigned long long *>(prog)[1] = wall_clock64();      // (measurement: GPCSD_QPIPE_CLK)
+    int published = 0;
+    // (uniform; called behind a barrier that follows the last column's tau in LDS.)  Every thread fences its own fire-and-forget
+    // stores of reflector rows, the barrier collects the fences, one thread releases the word.
+    // (The rows of V and tau leave as agent-scope stores -- written through the XCD's L2 -- so that the release needs no write-back
+    // of that L2 (a __threadfence here writes back whatever the GEMM tiles of the other streams left dirty in it: the tail of a
+    // pipelined cfg3 step measured 35 us longer); every thread waits for its own stores, the barrier collects the waits.)
+    auto publish = [&](const int done) {
+        const int upto = done & ~63;
+        if (!pipe || upto <= published) return;
+        for (int g = published + tid; g < upto; g += RT_NTH) rt_store_agent(P.tau + g, st[OFF + g]);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) __hip_atomic_store(prog, (unsigned)upto, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        published = upto;
+    };
 
     // pending rank-2 update of step k0-1 (its reflector and y = A v are in global memory): v -> sv2[0], w -> sy
     {
@@ -237,7 +263,7 @@ __global__ __launch_bounds__(RT_NTH) void sytrd_rtail_kernel(SytrdBatch b) {
                 double t = (c > k + 1) ? x[q] : 0.0;                       // (a pad column c == T reads 0 and stays 0)
                 t = (c == k + 1) ? u1 : t;
                 tv[q] = (r != 0.0 || c == k + 1) ? t : 0.0;
-                if (c < T) vrow[c] = tv[q];                                // fire and forget: the barriers wait for LDS only
+                if (c < T) rt_store_agent(vrow + c, tv[q]);                // fire and forget: the barriers wait for LDS only
             }
             *reinterpret_cast<double2 *>(sv + cA) = double2{tv[0], tv[1]};
             if (okB) *reinterpret_cast<double2 *>(sv + cB) = double2{tv[2], tv[3]};
@@ -365,6 +391,7 @@ __global__ __launch_bounds__(RT_NTH) void sytrd_rtail_kernel(SytrdBatch b) {
             sv2[0][OFF + tid] = 0.0;
             sv2[1][OFF + tid] = 0.0;
         }
+        publish(S);                                // (a full strip is one panel)
     }
 
     // ------------------------------------------------------------------------------------------------------------
@@ -423,7 +450,7 @@ __global__ __launch_bounds__(RT_NTH) void sytrd_rtail_kernel(SytrdBatch b) {
                 t = (c == kk + 1) ? u1 : t;
                 t = (r != 0.0 || c == kk + 1) ? t : 0.0;
                 svb[c] = t;
-                if (c < TB) vrow[c] = t;
+                if (c < TB) rt_store_agent(vrow + c, t);
             }
             if (lane == 0) {
                 sdb[kk] = dk;
@@ -512,6 +539,7 @@ __global__ __launch_bounds__(RT_NTH) void sytrd_rtail_kernel(SytrdBatch b) {
         // (read behind the last column's barrier B: the flag was set in front of one of this group's barriers A)
         exit_at = s_exit_at;                                         // uniform: every thread reads the same LDS word
         if (exit_at >= 0) break;
+        publish(S + min(kb + 4, TB - 1));                            // columns S .. S + kb + 3 are done (behind their barrier B)
     }
     if (exit_at >= 0) {
         // Columns exit_at .. kb + 3 of the group were still reduced (harmless: noise); from kb + 4 on the block is left as it
@@ -541,7 +569,15 @@ __global__ __launch_bounds__(RT_NTH) void sytrd_rtail_kernel(SytrdBatch b) {
     for (int kk = tid; kk < T; kk += RT_NTH) {
         P.d[k0 + kk] = sd[OFF + kk];
         P.e[k0 + kk] = se[OFF + kk];
-        P.tau[k0 + kk] = st[OFF + kk];
+        if (pipe) rt_store_agent(P.tau + k0 + kk, st[OFF + kk]);
+        else P.tau[k0 + kk] = st[OFF + kk];
+    }
+    if (pipe) {
+        // the consumers of the progress word read V and tau (agent-scope stores: complete = visible); d and e are read by launches
+        // that are ordered behind the END of this one by an event (capi: ev_t1), as without the progress words
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) __hip_atomic_store(prog, RT_PROG_DONE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     if (b.clk && threadIdx.x == 0) b.clk[2 * blockIdx.x + 1] = wall_clock64();
 }

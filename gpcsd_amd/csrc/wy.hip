@@ -9,6 +9,7 @@
 // T = (diag(1/tau) + striu(G))^{-1} by wave-parallel back substitution (closed form of the compact-WY T factor).
 // Every launch-bound GEMM chain this replaces cost ~8 us per panel and problem.
 #include <algorithm>
+#include <functional>
 
 #include "devutil.hpp"
 #include "kernels.hpp"
@@ -197,6 +198,273 @@ __global__ __launch_bounds__(WY_NT) void wy_apply_kernel(WyBatch b) {
     stamp();
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Q panel by panel, beside the tridiagonalisation that is still producing the later panels (stage 5 of a staged chain).
+//
+// Reflector i is zero up to column i, so H_i only touches columns > i of whatever it multiplies from the right: the columns
+// [0, 64 (p + 1)) of Q = H_0 H_1 .. are final once panel p is.  Q is accumulated FORWARD on its transpose,
+//     Zt = Q^T = P_{np-1}^T .. P_1^T P_0^T,   P_p^T = I - V_p^T T_p^T V_p,
+// one launch per panel: a workgroup keeps a 16-column slab of Zt -- sixteen rows of Q -- in LDS exactly as the
+// back-transformation does, applies ONE panel and writes the rows of Zt from the panel's first column on back to Q (row-major,
+// Q[r][j] = Zt[j][r]): the panel's own 64 columns of Q are final, the rest is the state the next panel's launch reads.
+// The T factor of the panel comes from a launch of the preparation body that first WAITS for the register tail's progress word
+// (sytrd_regtail.hpp: reflectors and tau of the panel are in global memory): the only place where a launch of one stream spins
+// on a running kernel of another.  The wait is bounded; when the time is up the launch reports failure 7 and goes on.
+// ------------------------------------------------------------------------------------------------------------------
+constexpr unsigned WY_PROG_DONE = 0x7fffffffu;        // = RT_PROG_DONE
+constexpr unsigned long long WY_GATE_TICKS = 20000000ull;   // 0.2 s of the 100 MHz wall clock: a tail takes < 1 ms
+
+// One launch per panel, FOUR waves per workgroup and ~75 KB of LDS: the launches run beside the previous call's large products,
+// under which a CU never drains -- a workgroup that needs a whole CU (the back-transformation's 1024 threads, the preparation
+// launch's 130 KB) waits there for as long as the flood of tiles lasts (measured: a 75 us panel stage took 250 us), one the size
+// of a GEMM tile's workgroup takes the place of the next tile that retires.  Workgroup (slab, problem):
+//   gate   thread 0 waits for the tail's progress word (bounded), everybody takes the acquire fence;
+//   T      the panel's T factor, by every workgroup for itself (64 x 64 Gram of the panel on MFMA, ~8 us at 250 rows, 2 us for
+//          the last panel; the blocked inverse of wy_prep.hpp on four waves) -- no launch and no dependence between workgroups;
+//          slab 0 also stores it (stage 4 of a chain with an eigenvector-form consumer reads it);
+//   apply  the slab: rows j >= 64 p of Zt from Q (panel 0: the identity), W1 = V_p Zc, W2 = T_p^T W1, Zc -= V_p^T W2, back to Q.
+constexpr int WQ_NT = 256;
+constexpr int WQ_KC = 64, WQ_LDV = WQ_KC + 2;
+// LDS (doubles): phase T: chunk / G [64][66], T [64][65], products [32][33], tau [64];  phase apply (overlaid): Zs [n][18], W1, W2 [64][18]
+inline size_t wq_lds_bytes(int n) {
+    const size_t t_phase = (size_t)WY_NB * WQ_LDV + (size_t)WY_NB * WY_LDG + 32 * WY_LDP + WY_NB;
+    const size_t a_phase = (size_t)n * WY_LD + 2 * (size_t)WY_NB * WY_LD;
+    return std::max(t_phase, a_phase) * sizeof(double);
+}
+
+__global__ __launch_bounds__(WQ_NT) void wy_qstage_kernel(WyBatch b, int p) {
+    const WyProb P = wy_resolve(b, blockIdx.y);
+    const int n = P.n;
+    const int r0 = blockIdx.x * WY_ZC;                 // rows r0 .. r0 + 15 of Q = this slab's columns of Zt
+    if (r0 >= n || p >= P.npanels) return;
+    extern __shared__ double smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 15, fq = lane >> 4;
+    // (GPCSD_QPIPE_CLK=1: phase clocks of workgroup (0, 0) of the last two panels' launches, clk[32 + 8 (p & 1) + k])
+    int nst = 0;
+    auto stamp = [&]() {
+        if (b.clk && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0 && nst < 8) b.clk[32 + 8 * (p & 1) + nst] = wall_clock64();
+        ++nst;
+    };
+    // ---- gate
+    if (tid == 0) {
+        const unsigned target = (p + 1 < P.npanels) ? (unsigned)(WY_NB * (p + 1)) : WY_PROG_DONE;
+        const unsigned *prog = reinterpret_cast<const unsigned *>(P.tau + n + WY_NB);
+        const unsigned long long t0 = wall_clock64();
+        const bool stamping = b.clk && blockIdx.x == 0;
+        if (stamping) b.clk[3 * (p * 4 + blockIdx.y)] = t0;              // (GPCSD_QPIPE_CLK=1: when the gate started, passed, and the tail's start)
+        bool ok = true;
+        while (__hip_atomic_load(prog, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            if (wall_clock64() - t0 > WY_GATE_TICKS) {
+                ok = false;
+                break;
+            }
+            __builtin_amdgcn_s_sleep(2);
+        }
+        if (!ok && b.status) atomicMax(b.status, 7);
+        if (stamping) {
+            b.clk[3 * (p * 4 + blockIdx.y) + 1] = wall_clock64();
+            b.clk[3 * (p * 4 + blockIdx.y) + 2] = *reinterpret_cast<const unsigned long long *>(P.tau + n + WY_NB + 1);
+        }
+    }
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");    // every wave reads the panel the tail's workgroup has just released
+    __builtin_amdgcn_s_setprio(3);                        // (on the log-likelihood's critical path, beside a flood of GEMM tiles)
+    stamp();
+    const double *__restrict__ Vp = P.V + (long)p * WY_NB * n;
+    const int kstart = (p * WY_NB) & ~3;                  // reflector k is zero up to column k
+    // ---- T factor (wy_prep.hpp's scheme on four waves): G = V_p V_p^T, upper blocks only
+    double *vs = smem, *g = smem, *tl = smem + WY_NB * WQ_LDV, *pl = tl + WY_NB * WY_LDG, *st = pl + 32 * WY_LDP;
+    constexpr int LDG = WY_LDG;
+    {
+        const int bi = (wid >> 1) & 1, bj = wid & 1;      // wave 2 would own the lower block: nobody reads it
+        const bool upper = bi <= bj;
+        d4 acc[2][2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[i][j] = d4{0.0, 0.0, 0.0, 0.0};
+        for (int kc = kstart; kc < n; kc += WQ_KC) {
+            const int kn = min(WQ_KC, (n - kc + 3) & ~3);
+            __syncthreads();
+#pragma unroll
+            for (int u = 0; u < WY_NB * WQ_KC / WQ_NT; ++u) {
+                const int idx = tid + WQ_NT * u;
+                const int r = idx / WQ_KC, k = idx % WQ_KC;
+                if (k < kn) vs[r * WQ_LDV + k] = (kc + k < n) ? Vp[(long)r * n + kc + k] : 0.0;
+            }
+            __syncthreads();
+            if (upper) {
+                const double *__restrict__ va = vs + (32 * bi + fr) * WQ_LDV + fq, *__restrict__ vb = vs + (32 * bj + fr) * WQ_LDV + fq;
+#pragma unroll 4
+                for (int k0 = 0; k0 < kn; k0 += 4) {
+                    const double a0 = va[k0], a1 = va[16 * WQ_LDV + k0], b0 = vb[k0], b1 = vb[16 * WQ_LDV + k0];
+                    acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
+                    acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
+                    acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
+                    acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();                                   // G lands where the chunk was
+        for (int idx = tid; idx < WY_NB * LDG; idx += WQ_NT) tl[idx] = 0.0;
+        if (upper) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) g[(32 * bi + 16 * i + fq + 4 * r) * LDG + 32 * bj + 16 * j + fr] = acc[i][j][r];
+        }
+        if (tid < WY_NB) {
+            const int kk = p * WY_NB + tid;
+            st[tid] = (kk < P.nrefl) ? P.tau[kk] : 0.0;
+        }
+        __syncthreads();
+    }
+    stamp();
+    // diagonal 16 x 16 blocks of T = (diag(1 / tau) + striu(G))^-1: wave w owns block w, LANE c its column c -- sixteen entries in
+    // registers, x_c = tau_c, x_j = -tau_j sum_{l > j} G_jl x_l going up (entries below the diagonal stay zero, so the sums need no
+    // masks); the G entries are broadcast LDS reads at compile-time offsets.  (The axpy form of wy_prep.hpp, a lane per ROW and
+    // forty dependent lane-read steps, was 8 of the 30 us the last panel's launch took.)
+    {
+        const int b0 = 16 * wid, cidx = lane & 15;
+        const double *__restrict__ gb = g + b0 * LDG + b0;
+        double x[16];
+#pragma unroll
+        for (int j = 15; j >= 0; --j) {
+            double sum = 0.0;
+#pragma unroll
+            for (int l = j + 1; l < 16; ++l) sum = fma(gb[j * LDG + l], x[l], sum);
+            const double tj = st[b0 + j];
+            x[j] = (j == cidx) ? tj : ((j < cidx) ? -tj * sum : 0.0);
+        }
+        if (lane < 16) {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) tl[(b0 + j) * LDG + b0 + cidx] = x[j];
+        }
+    }
+    __syncthreads();
+    stamp();
+    // off-diagonal blocks by doubling: T_ab = -T_aa (G_ab T_bb) at block size 16, then 32
+    auto frag = [&](const double *A, int lda, const double *B, int ldb, int K) {      // A[fr][k] B[k][fr] over k < K
+        d4 acc = {0.0, 0.0, 0.0, 0.0};
+        for (int k0 = 0; k0 < K; k0 += 4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(A[fr * lda + k0 + fq], B[(k0 + fq) * ldb + fr], acc, 0, 0, 0);
+        return acc;
+    };
+    if (wid < 2) {
+        const int a = 32 * wid, bb = a + 16;
+        const d4 pr = frag(g + a * LDG + bb, LDG, tl + bb * LDG + bb, LDG, 16);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) pl[(16 * wid + fq + 4 * r) * WY_LDP + fr] = pr[r];
+    }
+    __syncthreads();
+    if (wid < 2) {
+        const int a = 32 * wid, bb = a + 16;
+        const d4 tr = frag(tl + a * LDG + a, LDG, pl + 16 * wid * WY_LDP, WY_LDP, 16);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) tl[(a + fq + 4 * r) * LDG + bb + fr] = -tr[r];
+    }
+    __syncthreads();
+    {
+        const int fi = wid >> 1, fj = wid & 1;
+        const d4 pr = frag(g + (16 * fi) * LDG + 32, LDG, tl + 32 * LDG + 32 + 16 * fj, LDG, 32);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) pl[(16 * fi + fq + 4 * r) * WY_LDP + 16 * fj + fr] = pr[r];
+    }
+    __syncthreads();
+    {
+        const int fi = wid >> 1, fj = wid & 1;
+        const d4 tr = frag(tl + (16 * fi) * LDG, LDG, pl + 16 * fj, WY_LDP, 32);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) tl[(16 * fi + fq + 4 * r) * LDG + 32 + 16 * fj + fr] = -tr[r];
+    }
+    __syncthreads();
+    if (blockIdx.x == 0) {
+        double *__restrict__ Tg = P.T + (long)p * WY_NB * WY_NB;
+#pragma unroll
+        for (int u = 0; u < WY_NB * WY_NB / WQ_NT; ++u) {
+            const int idx = tid + WQ_NT * u;
+            Tg[idx] = tl[(idx >> 6) * LDG + (idx & 63)];
+        }
+    }
+    // this wave's operand of W2 = T_p^T W1 (rows 16 wid .. of T^T = columns of T) into registers: the LDS is reused below
+    double ta[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) ta[u] = tl[(4 * u + fq) * LDG + 16 * wid + fr];
+    __syncthreads();
+    stamp();
+    // ---- apply
+    double *Zs = smem;                         // [n][WY_LD]
+    double *W1 = Zs + (size_t)n * WY_LD;       // [64][WY_LD]
+    double *W2 = W1 + WY_NB * WY_LD;           // [64][WY_LD]
+    const int j0 = (p * WY_NB) & ~15;          // the panel's reflectors are zero in front of column 64 p + 1
+    for (int j = j0 + tid; j < n; j += WQ_NT) {
+#pragma unroll
+        for (int rr = 0; rr < WY_ZC; ++rr) {
+            double v;
+            if (p == 0) v = (j == r0 + rr) ? 1.0 : 0.0;
+            else v = (r0 + rr < n) ? P.Z[(long)(r0 + rr) * n + j] : 0.0;
+            Zs[j * WY_LD + rr] = v;
+        }
+    }
+    __syncthreads();
+    stamp();
+    {   // W1 = V_p Zc: wave w owns panel rows 16 w .. 16 w + 15 over the whole K range
+        const double *__restrict__ ra = Vp + (long)(16 * wid + fr) * n;
+        d4 acc = {0.0, 0.0, 0.0, 0.0};
+        for (int k0 = kstart; k0 < n; k0 += 32) {
+            double a8[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int k = k0 + 4 * u + fq;
+                a8[u] = ra[k < n ? k : n - 1];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int k = k0 + 4 * u + fq;
+                const double bb = Zs[(k < n ? k : n - 1) * WY_LD + fr];
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(k < n ? a8[u] : 0.0, bb, acc, 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) W1[(16 * wid + fq + 4 * r) * WY_LD + fr] = acc[r];
+    }
+    lds_barrier();
+    {   // W2 = T_p^T W1
+        d4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int u = 0; u < 16; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ta[u], W1[(4 * u + fq) * WY_LD + fr], acc, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) W2[(16 * wid + fq + 4 * r) * WY_LD + fr] = acc[r];
+    }
+    lds_barrier();
+    stamp();
+    {   // Zc -= V_p^T W2, rows from the panel's first reflector on
+        const int nfrag = (n + 15) / 16;
+        for (int fm = (p * WY_NB) / 16 + wid; fm < nfrag; fm += WQ_NT / 64) {
+            const int m = 16 * fm + fr;
+            const double *__restrict__ vm = Vp + (m < n ? m : n - 1) + (long)fq * n;
+            d4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int u = 0; u < 16; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(vm[(long)(4 * u) * n], W2[(4 * u + fq) * WY_LD + fr], acc, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = 16 * fm + fq + 4 * r;
+                if (row < n) Zs[row * WY_LD + fr] -= acc[r];
+            }
+        }
+    }
+    __syncthreads();
+    stamp();
+    for (int j = j0 + tid; j < n; j += WQ_NT) {
+#pragma unroll
+        for (int rr = 0; rr < WY_ZC; ++rr)
+            if (r0 + rr < n) P.Z[(long)(r0 + rr) * n + j] = Zs[j * WY_LD + rr];
+    }
+    stamp();
+}
+
 static bool wy_clk_on() {
     static const bool on = getenv("GPCSD_WY_CLK") && getenv("GPCSD_WY_CLK")[0] == '1';
     return on;
@@ -267,6 +535,44 @@ void wy_batch_device(gpcsd_ctx *c, const WyBatch &b, int nclass, hipStream_t s, 
     else hipLaunchKernelGGL(wy_apply_kernel<1>, dim3(ceil_div(nmax, WY_ZC), count), dim3(WY_NT), sh, s, w);
     if (w.clk) wy_clk_print(c, w.clk, "wy_apply, last column block: init, then per panel W1 | W2 + loads | update, store", 8, 2 + 3 * maxP + 1, s);
     GP_HIP(hipGetLastError());
+}
+
+// Stage 5 (see above): for every panel the gated T factor, the forward apply, then whatever the caller hangs on the columns the
+// panel completes -- chunk(class i: first and one-past-last final column of this stage; empty ranges for a class that has no
+// such panel).  Z of the batch = the Q buffers (row-major).
+void wy_q_pipeline(gpcsd_ctx *c, const WyBatch &b, int nclass, hipStream_t s,
+                   const std::function<void(const int *col0, const int *col1)> &chunk) {
+    int maxP = 0, nmax = 0;
+    for (int i = 0; i < nclass; ++i) {
+        maxP = std::max(maxP, b.p[i].npanels);
+        nmax = std::max(nmax, b.p[i].n);
+    }
+    if (maxP == 0) return;
+    const int count = b.start[MAX_EIG_BATCH];
+    const size_t sh = wq_lds_bytes(nmax);
+    GP_REQUIRE(sh <= 160 * 1024, -3, "wy_q_pipeline: %d rows do not fit the stage kernel", nmax);
+    static bool attr_set = false;
+    if (!attr_set) {
+        GP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(wy_qstage_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    WyBatch bc = b;
+    static const bool gate_clk = getenv("GPCSD_QPIPE_CLK") && getenv("GPCSD_QPIPE_CLK")[0] == '1';
+    if (gate_clk) bc.clk = c->buf<unsigned long long>("wy_clk", 64);        // (tools/qpipe_probe.py reads it)
+    for (int p = 0; p < maxP; ++p) {
+        hipLaunchKernelGGL(wy_qstage_kernel, dim3(ceil_div(nmax, WY_ZC), count), dim3(WQ_NT), sh, s, bc, p);
+        GP_HIP(hipGetLastError());
+        int col0[MAX_EIG_BATCH], col1[MAX_EIG_BATCH];
+        for (int i = 0; i < nclass; ++i) {
+            const int P = b.p[i].npanels;
+            col0[i] = col1[i] = 0;
+            if (p < P) {
+                col0[i] = WY_NB * p;
+                col1[i] = (p + 1 < P) ? WY_NB * (p + 1) : b.p[i].n;
+            }
+        }
+        if (chunk) chunk(col0, col1);
+    }
 }
 
 }  // namespace gpcsd

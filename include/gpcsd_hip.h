@@ -303,8 +303,20 @@ int gpcsd_pair_share_x(gpcsd_ctx *ctx, int on, long *calls);
  * reduction kernel synchronises once per panel of four columns instead of per column (it is the longest launch of a
  * latency-bound step), and the shifted systems become banded L D L^T factorisations with four multipliers per column.  Exact
  * algebra, same results to rounding.  Applies to temporal blocks of at most 252 rows after symmetry folding.
- * on = 1 / 0 switches it (default 1; GPCSD_BAND_TAIL=0 for new contexts), < 0 only queries; *calls counts the chains that took it. */
+ * on = 1 / 0 switches it (default 0 -- measured slower end to end; GPCSD_BAND_TAIL=1 for new contexts), < 0 only
+ * queries; *calls counts the chains that took it. */
 int gpcsd_band_tail(gpcsd_ctx *ctx, int on, long *calls);
+/* Pipelined orthogonal factor (round 5).  The tridiagonal forms (gpcsd_ll_tridiag below) need Q of Kt = Q T Q^T
+ * (utility_functions.py:58) and X = Y~ Q before anything else of their tails can start, and both used to wait for the END of the
+ * tridiagonalisation -- the longest launch of a step.  Column j of Q only depends on the reflectors in front of it, so the
+ * single-workgroup reduction publishes its progress every 64 reflectors and the T factor of that panel, the 64 finished columns of Q
+ * and the matching 64 columns of X follow on another stream while the reduction is still at work on the next panel; behind it only
+ * the last panel's share is left.  Same reflectors, same T factors; Q and X agree with the unpipelined form to rounding (the products
+ * are summed in another order).  Applies to temporal blocks of at most 256 rows after symmetry folding.
+ * on = 1 / 0 switches it (default 1; GPCSD_Q_PIPE=0 for new contexts -- needed under a profiler that serialises kernels, where a
+ * launch that waits for a running one cannot make progress: the wait is bounded and then reports failure 7), < 0 only queries;
+ * *calls counts the temporal chains that took it. */
+int gpcsd_q_pipeline(gpcsd_ctx *ctx, int on, long *calls);
 /* gpcsd_predict with host outputs (what the class API's predict() returns, gpcsd1d.py:286-293 / gpcsd2d.py:327-334): the last
  * product of a folded prediction is launched in chunks of prediction sites and every chunk's finished output rows are copied to
  * the caller's arrays while the next chunk computes (231 MB per call at 384 x 500 x 50: the copy is 4 of the call's 5 ms and no
