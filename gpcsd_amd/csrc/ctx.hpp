@@ -196,6 +196,10 @@ struct gpcsd_ctx {
     // form X through loglik_tri_pre, where stage 5 is queued (EigState::pipe_pending).  pipe_req: set around the stage-1 call
     // (problem set-up, graph key).  q_pipe_x: what stage 5 hangs on every finished block of columns -- in / out (nx R rows of nt), the
     // parity blocks' first columns.
+    // gpcsd_prefetch_pair (capi_fused.inl): the next paired call's front half, queued ahead of that call (PairPrefetch, owned here;
+    // dropped by any other front half)
+    void *pair_prefetch = nullptr;
+    long pair_prefetch_queued = 0, pair_prefetch_taken = 0;
     bool q_pipe = true;
     bool q_pipe_want = false;
     int pipe_req = 0;
@@ -228,6 +232,14 @@ struct gpcsd_ctx {
     long pred_chunked_calls = 0;
     std::map<const int *, std::vector<int>> sym_host;       // host copies (rep_i | rep_j) of the orbit tables, by device pointer
     bool pair_share_x = true;               // gpcsd_pair_share_x()
+    // ... and ONE spatial decomposition when the two sets differ by their jitter only (every loglik -> predict pair: the reference
+    // adds jitter I to Ks in loglik, gpcsd2d.py:139, and not in predict, :296): the eigenvectors of Ks + j I are those of Ks and the
+    // spectrum is shifted by j, so the prediction takes the log-likelihood's eigenvectors, its spectrum minus j, and -- with X shared
+    // as well -- its projected data W.  gpcsd_pair_share_s() / GPCSD_PAIR_SHARE_S=1.  OFF by default: 154 MB less traffic and one large
+    // product less per cfg3 step, but the step measured 6-10 % SLOWER (the prediction's LDS-filling solve then starts 70 us earlier and
+    // lands on the next step's spatial Gram assembly: DESIGN 4.13), and the pair no longer has the bits of its fenced calls.
+    bool pair_share_s = false;
+    long pair_shared_s_calls = 0;
     long pair_shared_x_calls = 0;           // paired calls whose prediction read the log-likelihood's X = Y~ Q (capi_fused.inl)
     // Decomposition cache (capi.hip::front_half): predict() right after loglik() / fit() with the same hyper-parameters
     // (neuropixels/fit_gpcsd2d.py:101-107) decomposes the very same Kt again, repeated predict() calls the same Ks as well.

@@ -741,7 +741,10 @@ void eigh_large_batch(gpcsd_ctx *c, EigProb *probs, int nclass, int *d_status, i
                 d.B = Qv[i] + (size_t)x.rep * np * np + col0[i]; d.ldb = np;
                 d.C = x.out + x.c0[i] + col0[i]; d.ldc = x.ld;
                 d.prof_name = "gemm_ll_YQ";
-                d.cfg = chunk_cfg;
+                // the tile configuration of the WHOLE product (as tri_times_Q launches it): a block of columns then has the bits it
+                // has there -- the order of the K loop does not depend on the configuration, but nothing else should either
+                const bool both_equal = nclass == 2 && probs[0].n == probs[1].n;
+                d.cfg = chunk_cfg ? chunk_cfg : gemm_auto_cfg(x.M, np, np, both_equal ? 2 : 1);
             }
             if (live == 2 && g[0].N == g[1].N && g[0].K == g[1].K) {     // the two parity blocks as one batched launch
                 g[0].batch = 2;

@@ -838,6 +838,12 @@ static void launch_trans(const GemmK &k, bool ta, bool tb, int epi, dim3 grid, h
     else launch_epi<WM, WN, FM, FN, BK, true, true>(k, epi, grid, s);
 }
 
+// the tile configuration gemm_f64 picks by itself for a plain product of this shape (GemmDesc::cfg == 0; see the rule below)
+int gemm_auto_cfg(int M, int N, int K, int batch) {
+    const long tiles = (long)ceil_div(M, 64) * ceil_div(N, 64) * std::max(batch, 1);
+    return (tiles >= 512) ? ((K <= 320) ? 2 : 3) : 5;
+}
+
 void gemm_f64(gpcsd_ctx *c, const GemmDesc &g, hipStream_t s) {
     if (!s) s = c->stream;
     GP_REQUIRE(g.M > 0 && g.N > 0 && g.K > 0, -3, "gemm_f64: empty problem %dx%dx%d", g.M, g.N, g.K);

@@ -1119,6 +1119,16 @@ __global__ void add_diag_kernel(double *A, int n, double v, const HpDev *__restr
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) A[(long)i * n + i] += v;
 }
+// dst = src + v (a spectrum shifted by a multiple of the identity: the paired call's shared spatial side)
+__global__ void shift_copy_kernel(const double *__restrict__ src, double *__restrict__ dst, int n, double v) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = src[i] + v;
+}
+void k_shift_copy(gpcsd_ctx *c, const double *src, double *dst, int n, double v, hipStream_t s) {
+    hipLaunchKernelGGL(shift_copy_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, s, src, dst, n, v);
+    GP_HIP(hipGetLastError());
+}
+
 void k_add_diag(gpcsd_ctx *c, double *A, int n, double v, hipStream_t s, const HpDev *tab, int B, long s_out) {
     hipLaunchKernelGGL(add_diag_kernel, dim3(ceil_div(n, 256), 1, tab ? B : 1), dim3(256), 0, s, A, n, v, tab, s_out);
     GP_HIP(hipGetLastError());

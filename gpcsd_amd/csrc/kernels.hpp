@@ -62,6 +62,7 @@ struct GemmDesc {
     const char *prof_name = "gemm_f64";
 };
 
+int gemm_auto_cfg(int M, int N, int K, int batch);      // the configuration gemm_f64 picks for a plain product when GemmDesc::cfg == 0
 void gemm_f64(gpcsd_ctx *c, const GemmDesc &g, hipStream_t s = nullptr);
 
 // Last product of a folded prediction with the unfold, the (r, t) -> (t, r) relayout and the sum over components fused into
@@ -154,6 +155,7 @@ int k_band_solve_pass(int npmax, int R);
 void k_band_solve(gpcsd_ctx *c, const double *W, double *B, const double *es, const double *const bd[2], const int ld[2],
                   const double *const amax[2], const double *sig, int nx, int R, int nt, const int np[2], const int c0[2], hipStream_t s);
 void k_add_diag(gpcsd_ctx *c, double *A, int n, double v, hipStream_t s, const HpDev *tab = nullptr, int B = 1, long s_out = 0);
+void k_shift_copy(gpcsd_ctx *c, const double *src, double *dst, int n, double v, hipStream_t s);     // dst = src + v
 void k_sum_partials(gpcsd_ctx *c, double *out, const double *P, long n, int parts, hipStream_t s);
 // D[x*nt + i] = es[x]*et[i] + sig[x or 0]; also sumlog -> *sumlog_out (deterministic)
 // with a table (B sets): scalar noise from tab[b].sig2n when nsig == 1, else set b's list at sig + b * nx

@@ -51,6 +51,12 @@ __device__ __forceinline__ double row16_sum(double v) {
 // a store that is visible to the other XCDs once it has completed (relaxed, agent scope: written through this XCD's L2)
 __device__ __forceinline__ void rt_store_agent(double *p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
+// a reflector entry: written through only when somebody reads it while this launch is still running (pipe, uniform)
+__device__ __forceinline__ void rt_store_v(bool pipe, double *p, double v) {
+    if (pipe) rt_store_agent(p, v);
+    else *p = v;
+}
+
 // Householder scalars of a column with pivot alpha and squared norm xnorm2 below it: H = I - tau u u^T with
 // u = (alpha - beta, x_2, ..) left UN-normalised: u is known as soon as s = sqrt(alpha^2 + |x|^2) is, and
 // tau = 1 / (s (|alpha| + s)) = r / |u_1| is formed by every wave after the barrier, off the generating wave's chain.
@@ -263,7 +269,7 @@ __global__ __launch_bounds__(RT_NTH) void sytrd_rtail_kernel(SytrdBatch b) {
                 double t = (c > k + 1) ? x[q] : 0.0;                       // (a pad column c == T reads 0 and stays 0)
                 t = (c == k + 1) ? u1 : t;
                 tv[q] = (r != 0.0 || c == k + 1) ? t : 0.0;
-                if (c < T) rt_store_agent(vrow + c, tv[q]);                // fire and forget: the barriers wait for LDS only
+                if (c < T) rt_store_v(pipe, vrow + c, tv[q]);              // fire and forget: the barriers wait for LDS only
             }
             *reinterpret_cast<double2 *>(sv + cA) = double2{tv[0], tv[1]};
             if (okB) *reinterpret_cast<double2 *>(sv + cB) = double2{tv[2], tv[3]};
@@ -450,7 +456,7 @@ __global__ __launch_bounds__(RT_NTH) void sytrd_rtail_kernel(SytrdBatch b) {
                 t = (c == kk + 1) ? u1 : t;
                 t = (r != 0.0 || c == kk + 1) ? t : 0.0;
                 svb[c] = t;
-                if (c < TB) rt_store_agent(vrow + c, t);
+                if (c < TB) rt_store_v(pipe, vrow + c, t);
             }
             if (lane == 0) {
                 sdb[kk] = dk;

@@ -215,6 +215,18 @@ int gpcsd_loglik_parts_wait(gpcsd_ctx *ctx, double *out2);
  * covariances, grids or prediction sites without the mirror symmetry). */
 int gpcsd_loglik_predict_async(gpcsd_ctx *ctx, const gpcsd_hparams *hp_loglik, const gpcsd_hparams *hp_predict,
                                const double *z, int nz, const double *tstar, int ntstar, int type, int want_lists);
+/* Announce the NEXT gpcsd_loglik_predict_async.  A caller that knows the hyper-parameters of its next paired evaluation before
+ * the current one has been collected -- a grid or a chain of proposals fixed in advance, a benchmark loop; NOT an optimiser, whose
+ * next point depends on the value it is waiting for (gpcsd1d.py:211) -- passes them here right after queueing the current call:
+ * the two decomposition chains of the next call (utility_functions.py:58-59 for Kt and Ks) are queued at once and start as soon as
+ * their streams are free, i.e. under the current call's products instead of behind the host's collection of its log-likelihood.
+ * The next gpcsd_loglik_predict_async with the same hyper-parameters, sites and times takes them over (same launches, same
+ * buffers, same bits); any other evaluation on the context in between drops them (they have then run for nothing).
+ * Returns 1 when queued, 0 when the paired form does not apply to these arguments (nothing queued), < 0 on error. */
+int gpcsd_prefetch_pair(gpcsd_ctx *ctx, const gpcsd_hparams *hp_loglik, const gpcsd_hparams *hp_predict, const double *z, int nz,
+                        const double *tstar, int ntstar);
+/* how many front halves gpcsd_prefetch_pair queued, and how many of them a paired call took over */
+int gpcsd_prefetch_stats(gpcsd_ctx *ctx, long *queued, long *taken);
 /* Local log-likelihood pieces and the gradient of  L_loc = -0.5*ntrials_resident*out2[0] - 0.5*out2[1]  with respect
  * to the natural hyper-parameters [R, ell_s (dim), (ell_t, sigma2_t) per component, sig2n]; with a per-electrode
  * noise list (hp->n_sig2n == nx, indexed by eigen-row as utility_functions.py:54-63) the tail holds nx entries and the
@@ -296,6 +308,16 @@ int gpcsd_fold_gemm(gpcsd_ctx *ctx, int on, long *calls);
  * would recompute the same bits.  on = 1 / 0 switches it (default 1; GPCSD_PAIR_SHARE_X=0 for new contexts), < 0 only queries;
  * *calls counts the paired calls that shared the product.  Results are bit-identical either way. */
 int gpcsd_pair_share_x(gpcsd_ctx *ctx, int on, long *calls);
+/* ... and ONE spatial decomposition for the pair when the two sets have equal spatial hyper-parameters and differ by the jitter
+ * only -- every loglik -> predict pair: the reference adds jitter * I to Ks in loglik (gpcsd1d.py:116, gpcsd2d.py:139) and not in
+ * predict (gpcsd1d.py:258, gpcsd2d.py:296).  eigh(Ks + j I) has the eigenvectors of eigh(Ks) and its spectrum shifted by j
+ * (utility_functions.py:58-59 applied to either), so the prediction takes the log-likelihood's eigenvectors, its spectrum minus j
+ * and -- with X shared as well -- its projected data.  Exact in exact arithmetic; in floating point the prediction then differs from
+ * the separately decomposed one by the eigensolver's own backward error (1e-13 relative at 384 x 500, tests/test_pair_share_s.py).
+ * on = 1 / 0 switches it (default 0: it saves a large product and 154 MB of traffic per 384 x 500 x 50 step, but the step measured
+ * slower, DESIGN 4.13, and the pair then differs from its fenced calls in the last bits; GPCSD_PAIR_SHARE_S=1 for new contexts),
+ * < 0 only queries; *calls counts the pairs that took it. */
+int gpcsd_pair_share_s(gpcsd_ctx *ctx, int on, long *calls);
 /* Band tail (round 5).  A fused call whose consumers all work in the basis U (x) Q -- the log-likelihood (gpcsd1d.py:113-128) and
  * the prediction (gpcsd1d.py:248-293) in their shifted-system forms (gpcsd_ll_tridiag below) -- never reads the temporal spectrum,
  * only solves (es[x'] m B + sig2 I) systems and takes their determinants.  Its temporal side (utility_functions.py:58, the eigh of

@@ -88,6 +88,7 @@ def test_paired_call_in_the_band_form_is_bitwise_its_fenced_calls():
     from gpcsd_amd import _hip
     w, m, lfp = _step_model(12)
     ctx = m._sync_device()
+    ctx.pair_share_s(False)        # (bit-for-bit against the fenced calls: the pair decomposes both spatial matrices, as they do)
     ctx.decomposition_cache(False)
     ctx.band_tail(True)
     try:

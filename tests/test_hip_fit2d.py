@@ -388,6 +388,7 @@ def test_npx69_reference_2d_shape_loglik_predict_and_gradient_vs_oracle():
     w, m, lfp, geom, hp, hp0 = _npx69(6)
     assert w["nx"] == 69 and w["nt"] == 376 and geom.ngl1 == 30 and geom.ngl2 == 120
     ctx = m._sync_device()
+    ctx.pair_share_s(False)        # (bit-for-bit against the fenced calls: the pair decomposes both spatial matrices, as they do)
     n_fold, n_tri = ctx.fold_gemm(), ctx.ll_tridiag()
     ll = float(m.loglik())
     ll_ref = O.loglik(geom, hp, lfp)

@@ -639,6 +639,7 @@ def test_paired_call_shares_the_product_with_the_temporal_basis_and_changes_no_b
     lfp = C.synth_lfp(99, 384, 500, 16)
     m = _model_from_case(c, g, lfp)
     ctx = m._sync_device()
+    ctx.pair_share_s(False)        # (bit-for-bit against the fenced calls: the pair decomposes both spatial matrices, as they do)
     ctx.decomposition_cache(False)
     z, t = np.ascontiguousarray(c["x"]), c["t"]
     h1, k1 = m._hparams(m.JITTER)
@@ -686,6 +687,7 @@ def test_predict_resident_is_asynchronous_and_changes_no_bits(name):
     c, g, geom, hp, lfp = load_model_case(name)
     m = _model_from_case(c, g, lfp)
     ctx = m._sync_device()
+    ctx.pair_share_s(False)        # (bit-for-bit against the fenced calls: the pair decomposes both spatial matrices, as they do)
     ctx.decomposition_cache(False)
     z, t = np.ascontiguousarray(c["x"]), c["t"]
     shape = (z.shape[0], t.shape[0], lfp.shape[2])
@@ -1297,6 +1299,7 @@ def test_asymmetric_prediction_sites_on_a_symmetric_probe_keep_the_folded_tempor
     lfp = C.synth_lfp(233, 384, 500, 3)
     m = _model_from_case(c, g, lfp)
     ctx = m._sync_device()
+    ctx.pair_share_s(False)        # (bit-for-bit against the fenced calls: the pair decomposes both spatial matrices, as they do)
     z = np.stack([24.0 * np.ones(4), np.array([2260.0, 2450.0, 2650.0, 2785.0])]).T
     n0 = ctx.fold_gemm()
     m.predict(z, c["t"], type="both")

@@ -69,6 +69,7 @@ def test_paired_call_with_the_pipeline_is_bitwise_its_fenced_calls_and_replays(R
     from gpcsd_amd import _hip
     w, m, lfp = _step_model(R)
     ctx = m._sync_device()
+    ctx.pair_share_s(False)        # (bit-for-bit against the fenced calls: the pair decomposes both spatial matrices, as they do)
     ctx.decomposition_cache(False)
     z = w["x"]
     n0 = ctx.q_pipeline()
@@ -107,7 +108,7 @@ def test_pipeline_over_panel_counts_and_odd_grids(nt):
     w = bench.workload("cfg2")
     w["nt"] = nt
     w["t"] = 0.5 * np.arange(float(nt))[:, None]
-    R = 8
+    R = 16                                   # (the pipeline applies where the prediction takes the tridiagonal form too: >= 16 trials)
     m = bench.build_model(w, np.zeros((w["nx"], nt, 1)))
     lfp = bench.synth_data(w, m, R, seed=nt)
     m.update_lfp(lfp, w["t"])

@@ -35,6 +35,8 @@ def main():
     def step():
         if paired and not sync_ll:
             ctx.loglik_predict_async(hp, hp0, z, w["t"], _hip.PRED_CSD, want_lists=True)
+            if os.environ.get("STEP_PREFETCH") == "1":
+                ctx.prefetch_pair(hp, hp0, z, w["t"])
             ctx.loglik_parts_wait()
         elif sync_ll:
             ctx.loglik_parts(hp)
