@@ -335,9 +335,9 @@ def cpu_baseline(w, m, lfp, budget_s=45.0):
 
 
 # ------------------------------------------------------------------------------------------------------- committed profiles
-# rocprofv3 summaries of `bench.py --only-value [--workload W]` (tools/profile_r03.sh), one set per workload: a line never
+# rocprofv3 summaries of `bench.py --only-value [--workload W]` (tools/profile_r05.sh), one set per workload: a line never
 # inherits another workload's numbers (no file for the workload, or a non-default trial count: null).
-PROFILE_ROUND = "r04"
+PROFILE_ROUND = "r05"
 
 
 def _profile(kind, wl, ext):

@@ -3,17 +3,18 @@
 // 24 x 500 problem.
 //
 // Two block levels.  Outer blocks of NBO = 256 columns carry the flops: per outer step
-//   D  the nb x nb diagonal block is factored AND inverted (X = L11^-1) -- 64-column sub-steps inside the block, each one
-//      launch of one workgroup for the 64 x 64 factor + inverse (registers + LDS, one barrier per column) and small MFMA
-//      products for the rest of the block; the block inverse is assembled from the 64 x 64 inverses by doubling
-//      (X_lowerleft = -X_C (B X_A): two products per pair);
-//   P  the panel solve L21 = A21 X^T is ONE MFMA GEMM with K = nb (the 64-column scheme solved against 64 x 64 inverses: four
-//      dependent K = 64 products over all rows per 256 columns);
-//   T  the trailing update A22 -= L21 L21^T is a rank-256 MFMA GEMM over the tiles on or below the diagonal only (rank 64 is
-//      8 flop per byte of the read-modify-write of A22 -- HBM-bound below the fp64 MFMA ridge of ~10; rank 256 is 32).
-// Look-ahead: T is issued as the next panel's columns first (T_a), then the rest (T_b); D of the NEXT step runs on a side
-// stream behind T_a, beside T_b, so the latency-bound block factorisations hide behind the machine-filling updates for as long
-// as those are longer (n = 12 000: the first ~20 of 47 steps).
+//   D  the 256 x 256 diagonal block is factored AND inverted (X = L11^-1): diag128_kernel on its two NB = 128 sub-blocks -- one
+//      workgroup of 512 threads each: 16-column panel steps by one wave (v_readlane multipliers), the rank-16 update of the rest of
+//      the sub-block on MFMA by all eight waves, then the inverse of the triangular factor by doubling, 16 -> 32 -> 64 -> 128 with
+//      MFMA products -- a 128 x 128 EPI_SUB product between them, and the block inverse assembled from the two sub-block inverses
+//      (X_lowerleft = -X_22 (L21 X_11): two small products);
+//   P  the panel solve L21 = A21 X^T is ONE MFMA GEMM with K = 256 (no triangular solve kernel: trsm by inverted diagonal blocks
+//      is a product);
+//   T  the trailing update A22 -= L21 L21^T is a rank-256 MFMA GEMM over the tiles on or below the diagonal only, accumulators
+//      preloaded with -C (EPI_SUB: no second pass over A22); rank 256 is 32 flop per byte of A22, above the fp64 MFMA ridge of ~10.
+// Look-ahead with gates: the next step's D runs on a side stream beside T, which is split by rows into T_b1 / T_b2 behind one-wave
+// gate launches that hold each part back until the diagonal workgroup it has to leave a CU to is resident (under the update's
+// thousands of tiles no CU ever drains by itself).  n = 12 000: 18 ms = 0.40 of the fp64 MFMA peak.
 // Triangular solves with many right-hand sides use the same inverted-diagonal-block + GEMM scheme.
 #include "kernels.hpp"
 

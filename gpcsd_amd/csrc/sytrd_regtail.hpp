@@ -93,7 +93,7 @@ __device__ __forceinline__ void rt_house(double alpha, double xnorm2, bool ok, d
 // the reduction itself commits.  The Gram matrices of smooth kernels are numerically low-rank: the 192-row halves of the
 // 384-channel Ks have ~58 eigenvalues above 1e-13 of the largest, and two thirds of the serial column steps of their tails
 // multiplied noise.  gpcsd_tail_early_exit(ctx, 0) / GPCSD_TAIL_EARLY_EXIT=0 keep every column step (the host then never sets
-// SytrdProb::psd): the A/B and the cross-check of tests/test_hip_fullsize.py::test_tail_early_exit_*.
+// SytrdProb::psd): the A/B and the cross-check of tests/test_tail_early_exit.py.
 
 __global__ __launch_bounds__(RT_NTH) void sytrd_rtail_kernel(SytrdBatch b) {
     const SytrdProb P = sy_resolve(b, blockIdx.x);

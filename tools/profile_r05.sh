@@ -22,6 +22,10 @@ rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt" -o kt -- pytho
 cp "$(find "$OUT/kt" -name '*kernel_stats.csv' | head -1)" "profiles/r05_kernel_stats_$WL.csv"
 cp "$OUT/kt_bench.json" "profiles/r05_only_value_under_rocprof_$WL.json"
 python3 tools/step_timeline.py "$(find "$OUT/kt" -name '*kernel_trace.csv' | head -1)" > "profiles/r05_step_timeline_$WL.txt"
+# (counter collection serialises kernels: a launch that waits for a running one -- the gated stage of the unannounced pipelined
+# chain, taken by the very first step only -- cannot make progress under it; the steady state of the announced loop queues the same
+# kernels ungated, so the switch changes nothing that is measured)
+export GPCSD_Q_PIPE=0
 echo "[profile] pmc FETCH_SIZE"
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -o f -- python3 $CMD --steps 20 --setup-steps 20 > "$OUT/pmc_fetch.json"
 echo "[profile] pmc WRITE_SIZE"
