@@ -1,6 +1,7 @@
 """Soak of the queued call forms: N steps with hyper-parameters that change every step, the paired / queued / two-deep forms
 against the same calls fenced one by one -- every log-likelihood and the final predictions bit for bit.  Mixes the forms at
-random, so generations, chain streams and the result ring see every hand-over.   python tools/soak_paired.py [cfg3|cfg2] [N] [tri] [R]
+random, so generations, chain streams and the result ring see every hand-over; three paired calls in four announce a next step
+(gpcsd_prefetch_pair), one in five of those a step that does not come.   python tools/soak_paired.py [cfg3|cfg2] [N] [tri] [R]
 (R resident trials, default 6; from 16 on the prediction takes its tridiagonal form too)
 ("tri": with the shifted-tridiagonal log-likelihood forced on, gpcsd_ll_tridiag mode 1 -- its fenced values are also held to
 1e-12 of the eigenvector form's; without it the eigenvector form is forced)."""
@@ -63,7 +64,8 @@ if TRI:
 
 for cache in (False, True):
     ctx.decomposition_cache(cache)
-    got, outstanding, keep = [], 0, []
+    got, outstanding, keep, announced = [], 0, [], 0
+    q0, t0 = ctx.prefetch_stats()
     for k in range(N):
         h1, h0 = hps(k)
         keep.append((h1, h0))
@@ -80,6 +82,13 @@ for cache in (False, True):
             ctx.predict_resident(h0[0], z, w["t"], kinds[k][0], want_lists=kinds[k][1])
         else:                                   # paired call
             ctx.loglik_predict_async(h1[0], h0[0], z, w["t"], kinds[k][0], want_lists=kinds[k][1]); outstanding += 1
+            u = rs.rand()
+            if u < 0.75 and k + 1 < N:          # ... that announces the next step (gpcsd_prefetch_pair): truthfully, or -- one in five --
+                ka = k + 1 if u < 0.6 else int(rs.randint(N))        # some other step's hyper-parameters (dropped by whatever comes next)
+                a1, a0 = hps(ka)
+                keep.append((a1, a0))
+                ctx.prefetch_pair(a1[0], a0[0], z, w["t"])
+                announced += 1
         while outstanding > (2 if form == 3 else 0) or outstanding >= 4:      # form 3 leaves up to two outstanding
             got.append(ctx.loglik_parts_wait()); outstanding -= 1
     while outstanding:
@@ -87,8 +96,9 @@ for cache in (False, True):
     pred = [ctx.fetch(nm, sh) for nm, sh in outs]
     same = all(np.array_equal(a, b) for a, b in zip(pred, ref_pred))
     bad = [k for k in range(N) if got[k] != ref_ll[k]]
-    print("%s cache=%s: %d steps, log-likelihood mismatches %d, predictions (csd, lfp, both lists) %s" % (
-        name, cache, N, len(bad), "identical" if same else "DIFFER"), flush=True)
+    q1, t1 = ctx.prefetch_stats()
+    print("%s cache=%s: %d steps, log-likelihood mismatches %d, predictions (csd, lfp, both lists) %s; %d announcements, %d taken over" % (
+        name, cache, N, len(bad), "identical" if same else "DIFFER", q1 - q0, t1 - t0), flush=True)
     if bad or not same:
         print("first mismatches:", bad[:5])
         sys.exit(1)
