@@ -595,8 +595,10 @@ def potrf_bench(n=12000, reps=3):
     # median of single factorisations: each takes ~600 launches that the host has to keep ahead of; one host stall (a BLAS worker
     # pool of the CPU baseline still spinning: a driver-style run once read 28.5 ms where the event scopes of the same process
     # said 20.7) would otherwise sit in the mean
+    g0 = ctx.potrf_gate_timeouts()
     runs = sorted(ctx.potrf_bench(n, reps=1) for _ in range(max(3, reps)))
     ms, tf = runs[len(runs) // 2]
+    gate_timeouts = ctx.potrf_gate_timeouts() - g0         # (gates that gave up waiting: they steer the order of execution only)
     ctx.prof_reset()
     ctx.prof_enable(1)
     ctx.potrf_bench(n, reps=1)
@@ -611,7 +613,7 @@ def potrf_bench(n=12000, reps=3):
            "trailing_update": {"kernel": "gemm_f64_kernel<EPI_SUB, lower> [potrf_syrk]: rank-256 update A22 -= L21 L21^T, tiles on or "
                                          "below the diagonal", "ms": tu.get("ms"), "launches": tu.get("launches"),
                                "tflops": tu.get("tflops"), "frac": (tu.get("tflops") or 0.0) / FP64_MFMA_SPEC_TFLOPS},
-           "scopes": split, "diag128_phases_us": ctx.potrf_diag_probe(),
+           "scopes": split, "diag128_phases_us": ctx.potrf_diag_probe(), "gate_timeouts": gate_timeouts,
            "config": {"workload": "blocked Cholesky of a %d x %d SPD matrix resident in HBM (N of BASELINE cfg2: 24 x 500)" % (n, n)}}
     out["headline"] = {"ms": ms, "frac": out["frac_of_fp64_mfma_peak"], "trailing_update_frac": out["trailing_update"]["frac"]}
     return out

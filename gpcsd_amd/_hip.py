@@ -217,6 +217,7 @@ SIGNATURES = {
     "gpcsd_hbm_copy_peak": (_I, [_P, _L, _DP]),
     "gpcsd_gemm_bench": (_I, [_P, _I, _I, _I, _I, _I, _I, _I, _DP]),
     "gpcsd_potrf_bench": (_I, [_P, _I, _I, _DP]),
+    "gpcsd_potrf_gate_timeouts": (_I, [_P, ctypes.POINTER(_L)]),
     "gpcsd_potrf_diag_probe": (_I, [_P, _DP]),
 }
 
@@ -717,6 +718,12 @@ class Context:
         if rc < 0:
             self._check(rc)
         return rc == 1
+
+    def potrf_gate_timeouts(self):
+        """Gate launches of the dense Cholesky that gave up waiting since the context was created (a performance counter)."""
+        n = _L(0)
+        self._check(self._lib.gpcsd_potrf_gate_timeouts(self._h, ctypes.byref(n)))
+        return int(n.value)
 
     def prefetch_stats(self):
         """(front halves queued by prefetch_pair, front halves a paired call took over)."""

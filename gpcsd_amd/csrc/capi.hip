@@ -1050,8 +1050,8 @@ extern "C" int gpcsd_ctx_create(int device, gpcsd_ctx **out) {
         GP_HIP(hipHostMalloc(reinterpret_cast<void **>(&c->h_ll), gpcsd_ctx::LL_SLOTS * gpcsd_ctx::RESULT_DOUBLES * sizeof(double),
                              hipHostMallocDefault));
         for (auto &sl : c->ll_slot) GP_HIP(hipEventCreateWithFlags(&sl.ev, hipEventDisableTiming));
-        GP_HIP(hipHostMalloc(reinterpret_cast<void **>(&c->h_chol_flag), 64, hipHostMallocDefault));
-        c->h_chol_flag[0] = 0u;
+        GP_HIP(hipMalloc(reinterpret_cast<void **>(&c->h_chol_flag), 64));          // (device memory: agent-scope atomics, chol.hip)
+        GP_HIP(hipMemset(c->h_chol_flag, 0, 64));
         *out = c;
         return 0;
     } catch (const HipError &e) {
@@ -1102,7 +1102,7 @@ extern "C" int gpcsd_ctx_destroy(gpcsd_ctx *c) {
     if (c->stream2) (void)hipStreamDestroy(c->stream2);
     if (c->h_result) (void)hipHostFree(c->h_result);
     if (c->h_ll) (void)hipHostFree(c->h_ll);
-    if (c->h_chol_flag) (void)hipHostFree(c->h_chol_flag);
+    if (c->h_chol_flag) (void)hipFree(c->h_chol_flag);
     if (c->stage_ring) (void)hipHostFree(c->stage_ring);
     if (c->tail_clk_host) (void)hipHostFree(c->tail_clk_host);
     for (auto &sl : c->ll_slot)

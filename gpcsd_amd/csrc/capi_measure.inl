@@ -163,6 +163,17 @@ __global__ void spd_test_matrix_kernel(double *A, int n) {
     }
 }
 
+extern "C" int gpcsd_potrf_gate_timeouts(gpcsd_ctx *c, long *count) {
+    GP_API_BEGIN(c)
+    GP_REQUIRE(count != nullptr, -3, "potrf_gate_timeouts: null output");
+    unsigned int w[2] = {0u, 0u};
+    c->sync();
+    if (c->h_chol_flag) GP_HIP(hipMemcpy(w, c->h_chol_flag, sizeof(w), hipMemcpyDeviceToHost));
+    *count = (long)w[1];
+    return 0;
+    GP_API_END(c)
+}
+
 extern "C" int gpcsd_potrf_bench(gpcsd_ctx *c, int n, int reps, double *ms_out) {
     GP_API_BEGIN(c)
     GP_REQUIRE(ms_out != nullptr && n >= 1 && n <= 32768 && reps >= 1, -3, "potrf_bench: bad arguments");

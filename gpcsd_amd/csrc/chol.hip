@@ -135,14 +135,14 @@ __device__ __forceinline__ void inverse_level(double *As, int wid, int lane) {
 // FACTOR: Cholesky of the nb x nb (<= 128) block at Ablk (in: its lower part; out: L in place, upper part zeroed), then inv(L) to
 // Xout (lower; leading dimension ldx).  !FACTOR: the block already is a Cholesky factor: inverse only.
 // status: first failing pivot + 1 (global index pivot_base + j).  Blocks smaller than 128 are padded with the identity.
-// started (pinned host word, may be null): stamped with `token` as soon as the workgroup runs -- it then HAS its CU; potrf's gate
+// started (device word, agent-scope store: visible to the other XCDs at once; may be null): stamped with `token` as soon as the workgroup runs -- it then HAS its CU; potrf's gate
 // launches poll the word before they let the trailing update's tiles take every other one (see potrf_device).
 template <bool FACTOR>
 __global__ __launch_bounds__(DNT) void diag128_kernel(double *Ablk, long lda, int nb, double *Xout, long ldx, int *status,
                                                        int pivot_base, unsigned long long *clk, unsigned int *started,
                                                        unsigned int token) {
     __builtin_amdgcn_s_setprio(3);
-    if (started && threadIdx.x == 0) __atomic_store_n(started, token, __ATOMIC_RELAXED);
+    if (started && threadIdx.x == 0) __hip_atomic_store(started, token, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     // clk (measurement aid, normally null): wall-clock stamps (100 MHz) at the phase boundaries -- [0] start, [1] block loaded,
     // [2] / [3] ticks spent in the serial panels / the rank-16 updates, [4] L stored, [5] diagonal inverses, [6..8] doubling levels,
     // [9] X stored
@@ -361,12 +361,21 @@ static void assemble_block_inverse(gpcsd_ctx *c, const double *Lblk, long ld, in
 // One wave that waits (bounded) until *flag has reached token: placed in front of a machine-filling launch, it holds that launch
 // back until a workgroup of another stream that needs a whole CU is resident.  Steers the order of execution only: every data
 // dependence is an event; when the time is up the stream simply goes on.
-__global__ __launch_bounds__(64) void gate_kernel(const unsigned int *flag, unsigned int token, unsigned int max_ticks) {
+// The word lives in device memory (flag[0]; flag[1] counts the gates whose time ran out -- gpcsd_potrf_bench reports them, so a
+// regression shows as a count and not as unexplained milliseconds); loads and stores are agent-scope atomics.
+__global__ __launch_bounds__(64) void gate_kernel(unsigned int *flag, unsigned int token, unsigned int max_ticks) {
+    if (threadIdx.x != 0) return;
     const unsigned long long t0 = wall_clock64();
-    while ((int)(__atomic_load_n(flag, __ATOMIC_RELAXED) - token) < 0 && wall_clock64() - t0 < max_ticks) __builtin_amdgcn_s_sleep(8);
+    while ((int)(__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - token) < 0) {
+        if (wall_clock64() - t0 >= max_ticks) {
+            atomicAdd(flag + 1, 1u);
+            break;
+        }
+        __builtin_amdgcn_s_sleep(8);
+    }
 }
 
-// first_token != 0: the diagonal launches stamp c->h_chol_flag with first_token, first_token + 1, ..
+// first_token != 0: the diagonal launches stamp c->h_chol_flag (a device word) with first_token, first_token + 1, ..
 static void factor_diag_block(gpcsd_ctx *c, double *Ablk, long ld, int nb, double *X, double *tmp, double *Wsub, int *d_status,
                               int pivot_base, hipStream_t s, unsigned int first_token = 0) {
     ProfScope ps(c, "potrf_diag_block", (double)nb * nb * nb * (1.0 / 3.0 + 1.0 / 3.0), s);
@@ -498,7 +507,7 @@ void potrf_device(gpcsd_ctx *c, double *A, int n, int *d_status, hipStream_t s_i
                 update_rows(0, mm);
             } else {
                 const unsigned int max_ticks = 30000;                  // 300 us
-                hipLaunchKernelGGL(gate_kernel, dim3(1), dim3(64), 0, s, (const unsigned int *)c->h_chol_flag, tok, max_ticks);
+                hipLaunchKernelGGL(gate_kernel, dim3(1), dim3(64), 0, s, c->h_chol_flag, tok, max_ticks);
                 int r1 = mm;
                 if (ndiag > 1) {                                       // T_b1: ~100 us of tiles (first diagonal launch + the two small products)
                     const double frac = std::min(0.5, tb1_us / t_update_us);
@@ -506,7 +515,7 @@ void potrf_device(gpcsd_ctx *c, double *A, int n, int *d_status, hipStream_t s_i
                 }
                 update_rows(0, r1);
                 if (r1 < mm) {
-                    hipLaunchKernelGGL(gate_kernel, dim3(1), dim3(64), 0, s, (const unsigned int *)c->h_chol_flag, tok + 1, max_ticks);
+                    hipLaunchKernelGGL(gate_kernel, dim3(1), dim3(64), 0, s, c->h_chol_flag, tok + 1, max_ticks);
                     update_rows(r1, mm);
                 }
             }

@@ -108,7 +108,8 @@ struct gpcsd_ctx {
     int ll_head = 0, ll_count = 0;          // oldest outstanding slot, number outstanding
     hipEvent_t ev_aux = nullptr, ev_pc = nullptr;   // predict: small products of the tail on stream2 beside the large ones
     hipEvent_t ev_chol_a = nullptr, ev_chol_d = nullptr;   // potrf look-ahead (chol.hip): next panel updated / next diagonal block factored
-    unsigned int *h_chol_flag = nullptr;    // pinned word the diagonal kernel stamps when its workgroup is resident (potrf's gates poll it)
+    unsigned int *h_chol_flag = nullptr;    // DEVICE words: [0] stamped by the diagonal kernel when its workgroup is resident (potrf's
+                                            // gates poll it, agent-scope atomics), [1] gates whose time ran out (gpcsd_potrf_gate_timeouts)
     unsigned int chol_token = 0;            // last token handed out
     // staged temporal chain (capi.hip front_half): ev_t1 = stage 1 (tridiagonalisation) done, recorded on stream2; ev_q = stage 3
     // (T factors and the orthogonal factor Q, on stream4 behind ev_t1) done -- the log-likelihood's tail needs nothing more of

@@ -433,6 +433,10 @@ int gpcsd_gemm_bench(gpcsd_ctx *ctx, int transA, int transB, int M, int N, int K
  * factor at N = nx * nt) on a device-resident, device-generated SPD test matrix of order n; events on the call's own stream
  * around the factorisation alone.  Kernel split through the profiling scopes (potrf_*). */
 int gpcsd_potrf_bench(gpcsd_ctx *ctx, int n, int reps, double *ms_out);
+/* how many of the factorisation's gate launches (the one-wave launches that hold the trailing update back until the next diagonal
+ * block's workgroup is resident, numpy.linalg.cholesky at gpcsd1d.py:303-304) gave up waiting since the context was created:
+ * the gates steer the order of execution only, so this is a performance counter, never an error */
+int gpcsd_potrf_gate_timeouts(gpcsd_ctx *ctx, long *count);
 /* phase split (us) of the one-workgroup 128 x 128 factor + invert launch inside that Cholesky: {load, serial panels, rank-16
  * MFMA updates, store L, diagonal-block inverses, doubling levels 16 / 32 / 64, store X, total} -- a tuning aid */
 int gpcsd_potrf_diag_probe(gpcsd_ctx *ctx, double *out10);
