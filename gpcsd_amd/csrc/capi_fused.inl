@@ -1118,8 +1118,11 @@ extern "C" int gpcsd_loglik_predict_async(gpcsd_ctx *c, const gpcsd_hparams *hp_
     // (gpcsd_pair_share_x(ctx, 0, ..) / GPCSD_PAIR_SHARE_X=0: A/B)
     const bool share_x = c->pair_share_x && pf.e[0].tri && pf.e[1].tri && ll_order() == 0 && same_temporal(hp_ll, hp_pr);
     if (share_x) ++c->pair_shared_x_calls;
+    // one spatial decomposition (PairFront::share_s): the two projected data sets W~ = diag(U)^T (Y~ Q or Y~) are then the same
+    // product whenever both sets take the same form -- tridiagonal with X shared, or both with the temporal eigenvectors
+    const bool share_w = pf.share_s && (share_x || (!pf.e[0].tri && !pf.e[1].tri));
     return predict_fold(c, hp_pr, pf.e[1], pf.fm[1], Yf, sz, dzf, nz, dtf, type, want_lists != 0, true, &ll_tail, &ll_pre,
-                        share_x ? "ll_X" : nullptr, prelude_side, (share_x && pf.share_s) ? "proj_W_ll" : nullptr);
+                        share_x ? "ll_X" : nullptr, prelude_side, share_w ? "proj_W_ll" : nullptr);
     GP_API_END(c)
 }
 

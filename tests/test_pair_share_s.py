@@ -25,11 +25,12 @@ def _step_model(R, name):
     return w, m, lfp
 
 
-@pytest.mark.parametrize("name,R", [("cfg3", 16), ("cfg3", 12), ("cfg2", 24), ("npx69", 20), ("npx72sym", 20)])
+@pytest.mark.parametrize("name,R", [("cfg3", 16), ("cfg3", 12), ("cfg3", 80), ("cfg2", 24), ("npx69", 20), ("npx72sym", 20)])
 def test_pair_with_one_spatial_decomposition_vs_two_and_oracle(name, R):
     """The queued pair with the spatial side shared and not: the log-likelihood is the same bits (its own decomposition either way),
     the prediction agrees to the eigensolver's backward error and with the oracle within the usual gate.  Folded and unfolded spatial
-    sides (npx69's sites do not share the electrodes' symmetry), tridiagonal and eigenvector form of the prediction (12 trials)."""
+    sides (npx69's sites do not share the electrodes' symmetry), tridiagonal and eigenvector form of the prediction (12 trials), both
+    sets in the eigenvector form (80 trials: past the size where the tridiagonal forms switch themselves off; W is shared there too)."""
     import bench
     from gpcsd_amd import _hip
     w, m, lfp = _step_model(R, name)
