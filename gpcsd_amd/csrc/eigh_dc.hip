@@ -754,7 +754,7 @@ void eigh_large_batch(gpcsd_ctx *c, EigProb *probs, int nclass, int *d_status, i
                 for (int i = 0; i < live; ++i) gemm_f64(c, g[i], sx);
             }
             c->tl("X block end (main)", sx);
-        });
+        }, /*one_launch=*/x.in == nullptr);
         GP_HIP(hipGetLastError());
         return;
     }

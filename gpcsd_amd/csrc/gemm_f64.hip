@@ -867,6 +867,12 @@ void gemm_f64(gpcsd_ctx *c, const GemmDesc &g, hipStream_t s) {
     k.lower = g.lower ? 1 : 0;
     k.lower_shift = g.lower ? g.lower_shift : 0;
     k.prio = g.prio;
+    {
+        // products on the chains' streams (spatial Gram assembly, divide & conquer merges, the prediction's side products) are small
+        // launches on a dependent chain beside the main stream's floods of tiles: their waves issue first (GPCSD_CHAIN_GEMM_PRIO=0: A/B)
+        static const bool off = getenv("GPCSD_CHAIN_GEMM_PRIO") && getenv("GPCSD_CHAIN_GEMM_PRIO")[0] == '0';
+        if (!off && k.prio == 0 && (s == c->stream2 || s == c->stream3 || s == c->stream4)) k.prio = 1;
+    }
     k.kscale = g.kscale; k.sKscale = g.sKscale; k.sKscale2 = g.sKscale2;
     const int batch2 = g.batch2 > 1 ? g.batch2 : 1;
     k.batch1 = batch2 > 1 ? g.batch : 0;

@@ -313,7 +313,7 @@ void wy_prep_device(gpcsd_ctx *c, const WyBatch &b, int nclass, hipStream_t s); 
 // Q panel by panel behind the progress words of a register tail that is still running (wy.hip); chunk: the caller's work on the
 // columns [col0[i], col1[i]) of class i's Q that the panel just applied completes
 void wy_q_pipeline(gpcsd_ctx *c, const WyBatch &b, int nclass, hipStream_t s,
-                   const std::function<void(const int *col0, const int *col1)> &chunk);
+                   const std::function<void(const int *col0, const int *col1)> &chunk, bool one_launch = false);
 // stages of the large-n solver, exposed for tests / diagnostics
 void sytrd_device(gpcsd_ctx *c, double *A, int n, double *d, double *e, double *V, double *tau, hipStream_t s);
 // the band tail on its own (sytrd_bandtail.hpp): A = Q B Q^T, band (5 x n: band[j * n + k] = B[k + j][k]), reflectors as sytrd_device

@@ -59,6 +59,7 @@ struct DcLevel {           // kernel argument of one level: one DcWork per CLASS
     int aux[MAX_BATCH];       // leaves: number of leaves; tears: number of boundaries (offset in seg_off)
     int start[MAX_BATCH + 1]; // prefix sums of the replica counts (class_of)
     int status_stride;        // replica r reports failure in status[r * status_stride]
+    int prio;                 // the level's waves raise their issue priority (GPCSD_DC_PRIO=0: A/B)
 };
 
 // workgroup's problem index g -> its class and replica, and the class's DcWork with every pointer moved to the replica
@@ -227,6 +228,7 @@ __global__ __launch_bounds__(64) void dc_leaf_reg_kernel(DcLevel L, int *status,
 // would otherwise be a 35 us launch of their own later in the chain; the others run sixteen leaf / zero-fill units each.
 __global__ __launch_bounds__(1024) void dc_leaf_wyprep_kernel(DcLevel L, int *status, int nleaf_max, int nunits, WyBatch wb,
                                                               int nprep) {
+    if (L.prio) __builtin_amdgcn_s_setprio(3);
     if ((int)blockIdx.x < nprep) {
         wy_prep_role(wy_resolve(wb, blockIdx.y), (int)blockIdx.x, (int)threadIdx.x);
         return;
@@ -254,8 +256,9 @@ struct SetupSharedT {
     __device__ __forceinline__ int *cidx() { return reinterpret_cast<int *>(sz); }
 };
 using SetupShared = SetupSharedT<EIG_MAXN>;
-// the fused small-level kernel merges at most DC_SMALL rows and reuses sd | sz | ds | zs as its 64 x 64 U tile
-using SetupSharedSmall = SetupSharedT<1024>;
+// the fused small-level kernel merges at most SM rows (SM = 32 or DC_SMALL = 64) and reuses sd | sz | ds | zs as its SM x SM U tile
+template <int SM>
+using SetupSharedSmallT = SetupSharedT<SM * SM / 4>;
 
 // z, merged order, deflation scan, compacted poles.  Whole workgroup (NW waves).
 template <int NW, class SS>
@@ -683,6 +686,7 @@ __device__ void dc_place_body(const DcWork &w, const Seg sg, const int r0, const
     const Seg sg = load_seg(w, L.seg_off[cls], m);
 
 __global__ __launch_bounds__(256) void dc_setup_kernel(DcLevel L) {
+    if (L.prio) __builtin_amdgcn_s_setprio(3);
     DC_PROLOGUE
     __shared__ SetupShared S;
     dc_setup_body<4>(w, sg, m, S);
@@ -691,6 +695,7 @@ __global__ __launch_bounds__(256) void dc_setup_kernel(DcLevel L) {
 constexpr int ROT_ROWS = 32;
 
 __global__ __launch_bounds__(256) void dc_place_kernel(DcLevel L) {
+    if (L.prio) __builtin_amdgcn_s_setprio(3);
     DC_PROLOGUE
     const int r0 = sg.lo + blockIdx.x * 4;
     if (r0 >= sg.hi) return;
@@ -703,6 +708,7 @@ __global__ __launch_bounds__(256) void dc_place_kernel(DcLevel L) {
 //   B: z-hat                         | rank sort of roots + poles (both need the roots only)
 //   C: column norms                  | UNNORMALISED U             (both need z-hat; the norms scale the GEMM's columns)
 __global__ __launch_bounds__(256) void dc_rotsec_kernel(DcLevel L, int rot_blocks) {
+    if (L.prio) __builtin_amdgcn_s_setprio(3);
     DC_PROLOGUE
     const int K = w.meta[2 * m];
     if ((int)blockIdx.x < rot_blocks) {
@@ -717,6 +723,7 @@ __global__ __launch_bounds__(256) void dc_rotsec_kernel(DcLevel L, int rot_block
 }
 
 __global__ __launch_bounds__(256) void dc_zhat_rank_kernel(DcLevel L, int zhat_blocks) {
+    if (L.prio) __builtin_amdgcn_s_setprio(3);
     DC_PROLOGUE
     const int K = w.meta[2 * m];
     if ((int)blockIdx.x < zhat_blocks) {
@@ -731,6 +738,7 @@ __global__ __launch_bounds__(256) void dc_zhat_rank_kernel(DcLevel L, int zhat_b
 }
 
 __global__ __launch_bounds__(256) void dc_colnorm_U_kernel(DcLevel L, int norm_blocks, int tiles_j) {
+    if (L.prio) __builtin_amdgcn_s_setprio(3);
     DC_PROLOGUE
     const int lo = sg.lo, n = w.n;
     const int K = w.meta[2 * m];
@@ -773,17 +781,19 @@ __device__ __forceinline__ double oct_prod(double v) {
     return v;
 }
 
-struct SmallShared {
-    double kd[DC_SMALL], kz[DC_SMALL];          // non-deflated poles / weights
-    double mu[DC_SMALL], lam[DC_SMALL], zh[DC_SMALL];
-    int org[DC_SMALL];
+template <int SM>
+struct SmallSharedT {
+    double kd[SM], kz[SM];                      // non-deflated poles / weights
+    double mu[SM], lam[SM], zh[SM];
+    int org[SM];
 };
 
 // Secular equation, EIGHT lanes per root (octet o = root, lane s of the octet sums poles s, s+8, ...): all K <= 64 roots
 // of the merge advance together on the 512 threads.  Same iteration as dc_secular_root (origin shift to the nearer pole,
 // two-pole rational step, bisection safeguard); the step itself uses fast reciprocals, the convergence test does not
 // depend on them.
-__device__ void dc_secular_oct(const SmallShared &Q, SmallShared &Qw, const int K, const double rho) {
+template <class SQ>
+__device__ void dc_secular_oct(const SQ &Q, SQ &Qw, const int K, const double rho) {
     const int i = threadIdx.x >> 3, s = threadIdx.x & 7;
     const double *__restrict__ dk = Q.kd;
     const double *__restrict__ zk = Q.kz;
@@ -904,12 +914,13 @@ __device__ void dc_secular_oct(const SmallShared &Q, SmallShared &Qw, const int 
 }
 
 typedef double dc_d4 __attribute__((ext_vector_type(4)));
-constexpr int Q2_LD = DC_SMALL + 1;
 
 // Everything after the deflation scan of a small merge, on LDS-resident data: roots (8 lanes each), z-hat (8 lanes per
 // pole), U with normalised columns, W = Q2 U on fp64 MFMA 16x16x4 (operands from LDS), rank sort, placement.
-__device__ void dc_small_tail(const DcWork &w, const Seg sg, SetupSharedSmall &S, SmallShared &Q, double *Q2s, const int K,
+template <int SM>
+__device__ void dc_small_tail(const DcWork &w, const Seg sg, SetupSharedSmallT<SM> &S, SmallSharedT<SM> &Q, double *Q2s, const int K,
                               const double rho) {
+    constexpr int NT = 8 * SM, Q2_LD = SM + 1;
     const int lo = sg.lo, hi = sg.hi, n = w.n, N = hi - lo;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int o = tid >> 3, s = tid & 7;                  // octet index (root / pole / column), lane inside the octet
@@ -931,13 +942,13 @@ __device__ void dc_small_tail(const DcWork &w, const Seg sg, SetupSharedSmall &S
         }
     }
     __syncthreads();
-    double *U = S.sd;                                     // sd | sz | ds | zs: 4 * 1024 doubles = 64 x 64
-    {                                                     // column o of U, rows s, s+8, ...; zero padded to 64 x 64
-        double u[8], ss = 0.0;
+    double *U = S.sd;                                     // sd | sz | ds | zs: 4 * (SM * SM / 4) doubles = SM x SM
+    {                                                     // column o of U, rows s, s+8, ...; zero padded to SM x SM
+        double u[SM / 8], ss = 0.0;
         const bool colok = o < K;
         const double dorg = colok ? Q.kd[Q.org[o]] : 0.0, muo = colok ? Q.mu[o] : 0.0;
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
+        for (int q = 0; q < SM / 8; ++q) {
             const int i = s + 8 * q;
             u[q] = (colok && i < K) ? Q.zh[i] / ((Q.kd[i] - dorg) - muo) : 0.0;
             ss += u[q] * u[q];
@@ -945,39 +956,42 @@ __device__ void dc_small_tail(const DcWork &w, const Seg sg, SetupSharedSmall &S
         ss = oct_sum(ss);
         const double inv = colok ? 1.0 / sqrt(ss) : 0.0;
 #pragma unroll
-        for (int q = 0; q < 8; ++q) U[(s + 8 * q) * DC_SMALL + o] = u[q] * inv;
+        for (int q = 0; q < SM / 8; ++q) U[(s + 8 * q) * SM + o] = u[q] * inv;
     }
-    for (int idx = tid; idx < DC_SMALL * DC_SMALL; idx += NT_SMALL) {
-        const int r = idx / DC_SMALL, j = idx % DC_SMALL;
+    for (int idx = tid; idx < SM * SM; idx += NT) {
+        const int r = idx / SM, j = idx % SM;
         Q2s[r * Q2_LD + j] = (r < N && j < K) ? w.Q2w[(long)(lo + r) * n + lo + j] : 0.0;
     }
     __syncthreads();
-    // W = Q2 U: 4 x 4 output fragments of 16 x 16, two per wave (A lane l holds A[l&15][l>>4], B holds B[l>>4][l&15])
-    dc_d4 acc[2];
+    // W = Q2 U: (SM / 16)^2 output fragments of 16 x 16 over the SM / 8 waves -- two per wave at SM = 64, one at 32 (A lane l holds
+    // A[l&15][l>>4], B holds B[l>>4][l&15])
+    constexpr int TPD = SM / 16, NWV = SM / 8, TPW = (TPD * TPD) / NWV;
+    static_assert(TPW >= 1 && TPW * NWV == TPD * TPD, "fragments must divide evenly over the waves");
+    dc_d4 acc[TPW];
     const int fr = lane & 15, fq = lane >> 4;
     const int ksteps = (K + 3) >> 2;
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
-        const int tile = wid + 8 * t, tm = tile >> 2, tn = tile & 3;
+    for (int t = 0; t < TPW; ++t) {
+        const int tile = wid + NWV * t, tm = tile / TPD, tn = tile % TPD;
         acc[t] = dc_d4{0.0, 0.0, 0.0, 0.0};
         if (16 * tm < N && 16 * tn < K) {                 // wave-uniform
             const double *qa = Q2s + (16 * tm + fr) * Q2_LD + fq;
-            const double *ub = U + fq * DC_SMALL + 16 * tn + fr;
+            const double *ub = U + fq * SM + 16 * tn + fr;
             for (int ks = 0; ks < ksteps; ++ks)
-                acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(qa[4 * ks], ub[4 * ks * DC_SMALL], acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(qa[4 * ks], ub[4 * ks * SM], acc[t], 0, 0, 0);
         }
     }
     __syncthreads();                                      // every fragment read of Q2s is done: reuse it for W
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
-        const int tile = wid + 8 * t, tm = tile >> 2, tn = tile & 3;
+    for (int t = 0; t < TPW; ++t) {
+        const int tile = wid + NWV * t, tm = tile / TPD, tn = tile % TPD;
 #pragma unroll
         for (int r = 0; r < 4; ++r) Q2s[(16 * tm + fq + 4 * r) * Q2_LD + 16 * tn + fr] = acc[t][r];
     }
     __syncthreads();
-    dc_rank_body<NT_SMALL>(w, sg, K, S.sd, S.sperm);      // U is dead: its storage holds the sort keys
+    dc_rank_body<NT>(w, sg, K, S.sd, S.sperm);            // U is dead: its storage holds the sort keys
     __syncthreads();
-    for (int idx = tid; idx < N * N; idx += NT_SMALL) {   // Qnext[:, rank[t]] = root ? W[:, t] : Qcur[:, deflated idx]
+    for (int idx = tid; idx < N * N; idx += NT) {         // Qnext[:, rank[t]] = root ? W[:, t] : Qcur[:, deflated idx]
         const int r = idx / N, t = idx % N;
         const int sc = w.rotb[lo + t];
         const double v = (sc < 0) ? Q2s[r * Q2_LD + (-1 - sc)] : w.Qcur[(long)(lo + r) * n + lo + sc];
@@ -985,31 +999,39 @@ __device__ void dc_small_tail(const DcWork &w, const Seg sg, SetupSharedSmall &S
     }
 }
 
-__global__ __launch_bounds__(NT_SMALL) void dc_small_level_kernel(DcLevel L) {
+// SM = 64: 512 threads, 74 KB of LDS.  SM = 32 (round 5: merges of up to 32 rows -- the two lowest levels of a 192- or 250-row
+// problem): 256 threads, 20 KB -- a workgroup the size of a GEMM tile's.  The levels run under the previous call's fused last
+// product, whose workgroups leave 43 KB of LDS and 120 registers per lane free on a CU: the 64-row form has to wait for two of
+// them to retire together (measured 87 + 71 us for the two lowest levels of the cfg3 spatial problem, 20 + 21 alone).
+template <int SM>
+__global__ __launch_bounds__(8 * SM) void dc_small_level_kernel(DcLevel L) {
     int cls, rep;
     const DcWork w = dc_resolve(L, blockIdx.z, cls, rep);
     const int m = blockIdx.x;
     if (m >= L.nseg[cls]) return;
     const Seg sg = load_seg(w, L.seg_off[cls], m);
-    constexpr int NW = NT_SMALL / 64;
-    __shared__ SetupSharedSmall S;
-    __shared__ SmallShared Q;
-    __shared__ double Q2s[DC_SMALL * Q2_LD];
+    constexpr int NT = 8 * SM, NW = NT / 64;
+    // (a chain of dependent scalar work beside a flood of GEMM waves: its instructions go first on the SIMDs they share)
+    if (L.prio) __builtin_amdgcn_s_setprio(3);
+    __shared__ SetupSharedSmallT<SM> S;
+    __shared__ SmallSharedT<SM> Q;
+    __shared__ double Q2s[SM * (SM + 1)];
     const int lo = sg.lo, hi = sg.hi;
     const int tid = threadIdx.x;
     dc_setup_body<NW>(w, sg, m, S);
     __syncthreads();
     const int K = S.K, nrot = S.nrot;
-    dc_rotate_compact_body<NT_SMALL>(w, sg, K, nrot, lo, hi);
+    dc_rotate_compact_body<NT>(w, sg, K, nrot, lo, hi);
     const double rho = 2.0 * fabs(w.e[sg.mid - 1]);
-    if (tid < DC_SMALL) {
+    if (tid < SM) {
         Q.kd[tid] = (tid < K) ? w.dk[lo + tid] : 0.0;
         Q.kz[tid] = (tid < K) ? w.zk[lo + tid] : 0.0;
     }
     __syncthreads();
-    dc_small_tail(w, sg, S, Q, Q2s, K, rho);
+    dc_small_tail<SM>(w, sg, S, Q, Q2s, K, rho);
 }
-static_assert(4 * 1024 >= DC_SMALL * DC_SMALL && offsetof(SetupSharedSmall, zs) == 3 * 1024 * sizeof(double),
+static_assert(offsetof(SetupSharedSmallT<64>, zs) == 3 * (64 * 64 / 4) * sizeof(double) &&
+                  offsetof(SetupSharedSmallT<32>, zs) == 3 * (32 * 32 / 4) * sizeof(double),
               "U tile must fit the reused, contiguous setup arrays");
 
 __global__ void copy_vec_kernel(const double *__restrict__ a, double *__restrict__ b, long n) {
@@ -1130,6 +1152,10 @@ void stedc_batch_device(gpcsd_ctx *c, StedcProb *probs, int nclass, int *d_statu
     GP_REQUIRE(nclass >= 1 && nclass <= MAX_BATCH, -3, "stedc: %d problem classes outside [1,%d]", nclass, MAX_BATCH);
     std::vector<DcPlan> plans;
     DcLevel L{};
+    {
+        static const bool prio_off = getenv("GPCSD_DC_PRIO") && getenv("GPCSD_DC_PRIO")[0] == '0';
+        L.prio = prio_off ? 0 : 1;
+    }
     L.status_stride = status_stride;
     size_t nlevels = 0;
     int nmax = 0, max_leaves = 0, count = 0;
@@ -1178,8 +1204,11 @@ void stedc_batch_device(gpcsd_ctx *c, StedcProb *probs, int nclass, int *d_statu
         if (li + 1 == nlevels)                 // the top merge covers the whole matrix: placed in the caller's arrays (dc_resolve)
             for (int p = 0; p < nclass; ++p)
                 if (L.nseg[p] > 0) L.w[p].top = 1;
-        if (maxN <= DC_SMALL) {
-            hipLaunchKernelGGL(dc_small_level_kernel, dim3(max_seg, 1, count), dim3(NT_SMALL), 0, s, L);
+        static const bool small32 = !(getenv("GPCSD_DC_SMALL32") && getenv("GPCSD_DC_SMALL32")[0] == '0');     // (A/B)
+        if (maxN <= 32 && small32) {
+            hipLaunchKernelGGL(dc_small_level_kernel<32>, dim3(max_seg, 1, count), dim3(8 * 32), 0, s, L);
+        } else if (maxN <= DC_SMALL) {
+            hipLaunchKernelGGL(dc_small_level_kernel<DC_SMALL>, dim3(max_seg, 1, count), dim3(NT_SMALL), 0, s, L);
         } else {
             hipLaunchKernelGGL(dc_setup_kernel, dim3(1, max_seg, count), dim3(256), 0, s, L);
             const int rot_blocks = ceil_div(maxN, ROT_ROWS), root_blocks = ceil_div(maxN, 4), tj = ceil_div(maxN, 64);

@@ -232,11 +232,19 @@ inline size_t wq_lds_bytes(int n) {
     return std::max(t_phase, a_phase) * sizeof(double);
 }
 
-__global__ __launch_bounds__(WQ_NT) void wy_qstage_kernel(WyBatch b, int p) {
+__global__ __launch_bounds__(WQ_NT) void wy_qstage_kernel(WyBatch b, int p0, int np) {
     const WyProb P = wy_resolve(b, blockIdx.y);
     const int n = P.n;
     const int r0 = blockIdx.x * WY_ZC;                 // rows r0 .. r0 + 15 of Q = this slab's columns of Zt
-    if (r0 >= n || p >= P.npanels) return;
+    if (r0 >= n) return;
+    // np > 1 (the unpipelined form: every panel in ONE launch -- behind the tail the four launches of the pipelined form cost a
+    // launch's scheduling under the main stream's products each, 250 us for 4 x 20): the slab travels through Q between panels,
+    // written and read by this workgroup only
+    for (int p = p0; p < p0 + np && p < P.npanels; ++p) {
+    if (p > p0) {
+        __threadfence_block();
+        __syncthreads();
+    }
     extern __shared__ double smem[];
     const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int fr = lane & 15, fq = lane >> 4;
@@ -463,6 +471,7 @@ __global__ __launch_bounds__(WQ_NT) void wy_qstage_kernel(WyBatch b, int p) {
             if (r0 + rr < n) P.Z[(long)(r0 + rr) * n + j] = Zs[j * WY_LD + rr];
     }
     stamp();
+    }
 }
 
 static bool wy_clk_on() {
@@ -541,7 +550,7 @@ void wy_batch_device(gpcsd_ctx *c, const WyBatch &b, int nclass, hipStream_t s, 
 // panel completes -- chunk(class i: first and one-past-last final column of this stage; empty ranges for a class that has no
 // such panel).  Z of the batch = the Q buffers (row-major).
 void wy_q_pipeline(gpcsd_ctx *c, const WyBatch &b, int nclass, hipStream_t s,
-                   const std::function<void(const int *col0, const int *col1)> &chunk) {
+                   const std::function<void(const int *col0, const int *col1)> &chunk, bool one_launch) {
     int maxP = 0, nmax = 0;
     for (int i = 0; i < nclass; ++i) {
         maxP = std::max(maxP, b.p[i].npanels);
@@ -559,8 +568,13 @@ void wy_q_pipeline(gpcsd_ctx *c, const WyBatch &b, int nclass, hipStream_t s,
     WyBatch bc = b;
     static const bool gate_clk = getenv("GPCSD_QPIPE_CLK") && getenv("GPCSD_QPIPE_CLK")[0] == '1';
     if (gate_clk) bc.clk = c->buf<unsigned long long>("wy_clk", 64);        // (tools/qpipe_probe.py reads it)
+    if (one_launch) {                      // unpipelined (behind the tail): every panel in one launch, nothing hangs on the panels
+        hipLaunchKernelGGL(wy_qstage_kernel, dim3(ceil_div(nmax, WY_ZC), count), dim3(WQ_NT), sh, s, bc, 0, maxP);
+        GP_HIP(hipGetLastError());
+        return;
+    }
     for (int p = 0; p < maxP; ++p) {
-        hipLaunchKernelGGL(wy_qstage_kernel, dim3(ceil_div(nmax, WY_ZC), count), dim3(WQ_NT), sh, s, bc, p);
+        hipLaunchKernelGGL(wy_qstage_kernel, dim3(ceil_div(nmax, WY_ZC), count), dim3(WQ_NT), sh, s, bc, p, 1);
         GP_HIP(hipGetLastError());
         int col0[MAX_EIG_BATCH], col1[MAX_EIG_BATCH];
         for (int i = 0; i < nclass; ++i) {
