@@ -1103,8 +1103,8 @@ def run_step_bench(args, w, rank, world, local_rank, backend, compact=False, cpu
                    "class_api_predict_cached_trials_per_sec": pcie_predict_cached,
                    "class_api_predict_cached_host_gb_per_sec": pcie_predict_cached / R_local * out_bytes / 1e9},
         "pipelining": "a step queues loglik + predict as one paired call (gpcsd_loglik_predict_async: the eigenproblems of the step -- "
-                      "Kt twice, Ks with jitter for loglik and without for predict -- share launches as replicas of one temporal and "
-                      "one spatial chain; nothing is reused from another step; results stay in HBM), then "
+                      "Kt (once: both sets have the same temporal hyper-parameters), Ks with jitter for loglik and without for predict -- "
+                      "run as one temporal and one spatial chain; nothing is reused from another step; results stay in HBM), then "
                       "waits for the log-likelihood; the next step's chains run beside this step's predict GEMMs "
                       "(double-buffered chain outputs).  Every "
                       "step's log-likelihood is returned to the host inside the step; the timed region ends with a full "

@@ -744,7 +744,11 @@ static void front_half_pair(gpcsd_ctx *c, const gpcsd_hparams *const hp[2], cons
     hipStream_t s = c->stream, s2 = c->stream2, s3 = c->stream3;
     const SymDev *sym_s = c->sym_s.ns > 0 ? &c->sym_s : nullptr, *sym_t = c->sym_t.ns > 0 ? &c->sym_t : nullptr;
     const double *t = (const double *)c->bufs["time_t"].p;
-    const int nT = (c->decomp_cache_on && same_temporal(hp[0], hp[1])) ? 1 : 2;      // replicas of the temporal problem
+    // replicas of the temporal problem: ONE when the two sets have the same temporal hyper-parameters (every loglik -> predict
+    // pair: the jitter is spatial) and either the decomposition cache or the pair's sharing of X says that equal sides are formed
+    // once -- the second replica would be the same launches on the same matrix, the same bits (GPCSD_PAIR_ONE_KT=0: A/B)
+    static const bool one_kt_off = getenv("GPCSD_PAIR_ONE_KT") && getenv("GPCSD_PAIR_ONE_KT")[0] == '0';
+    const int nT = (same_temporal(hp[0], hp[1]) && (c->decomp_cache_on || (c->pair_share_x && !one_kt_off))) ? 1 : 2;
     double *scal = c->buf<double>("scal_status", gpcsd_ctx::RESULT_DOUBLES);
     int *status = reinterpret_cast<int *>(scal + gpcsd_ctx::SCAL_N);
     int *late = status + gpcsd_ctx::STATUS_LATE;           // stages 2 and 4 of a staged temporal chain report here
