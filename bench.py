@@ -957,6 +957,16 @@ def run_step_bench(args, w, rank, world, local_rank, backend, compact=False, cpu
     # mode 2: asynchronous scopes, chains launched eagerly so the scopes inside them record (per-kernel launch times);
     # mode 3: asynchronous scopes with the chains replayed as hipGraphs exactly as in the timed loop (chain-level scopes)
     def profiled_pass(mode, n):
+        # (without announcements: the tail's own clock stamps of a step are read when its log-likelihood is back, i.e. when ITS
+        # chains have finished -- an announced next chain would be in flight on the same stamps.  The kernels are the same.)
+        was_announcing = announce["on"]
+        announce["on"] = False
+        try:
+            return _profiled_pass(mode, n)
+        finally:
+            announce["on"] = was_announcing
+
+    def _profiled_pass(mode, n):
         flush()
         ctx.synchronize()
         ctx.prof_reset()
