@@ -1104,8 +1104,10 @@ extern "C" int gpcsd_loglik_predict_async(gpcsd_ctx *c, const gpcsd_hparams *hp_
     double *dzf = c->upload_cached<double>("pred_z", z, (size_t)nz * c->dim);
     double *dtf = c->upload_cached<double>("pred_tstar", tstar, ntstar);
     // (sites or times uploaded just now, on the main stream: the builders that read them stay there)
-    static const bool side_off = getenv("GPCSD_PRELUDE_SIDE") && getenv("GPCSD_PRELUDE_SIDE")[0] == '0';
-    const bool prelude_side = !side_off && c->upload_count == up0 && pf.e[0].pipe_pending;
+    // GPCSD_PRELUDE_SIDE: 0 never, 1 (default) when stage 5 is pipelined, 2 always, 3 also for announced pairs
+    static const int side_mode = getenv("GPCSD_PRELUDE_SIDE") ? atoi(getenv("GPCSD_PRELUDE_SIDE")) : 1;
+    const bool prelude_side = side_mode != 0 && c->upload_count == up0 &&
+                              (pf.e[0].pipe_pending || side_mode == 2 || (side_mode == 3 && taken));
     const std::function<void()> ll_pre = [&]() {
         if (pf.e[0].tri) loglik_tri_pre(c, pf.e[0], pf.fm[0], Yf);
     };
