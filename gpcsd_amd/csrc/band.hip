@@ -20,7 +20,7 @@
 
 namespace gpcsd {
 
-constexpr int BD_W = 4;                     // half-bandwidth (sytrd_bandtail.hpp: BT_W)
+// (half-bandwidth 4 throughout: sytrd_bandtail.hpp's BT_W)
 constexpr int BD_NC = 10;                   // doubles per column of a factor: column k's multipliers, 1 / D, D, row k's multipliers
 constexpr int BD_KMAX = 256;                // columns of a block at most
 typedef double bd_d2 __attribute__((ext_vector_type(2)));
@@ -122,10 +122,9 @@ struct BandArgs {
     const double *sig;           // scalar noise variance (device)
     int nx, R, nt, np[2], c0[2];
     double *partials;            // ll: [0, nitems) quadratic forms, [nitems, 2 nitems) log-determinants
-    double *coef;                // factor / solve: [item][BD_KMAX + BD_PAD][BD_NC]
+    double *coef;                // factor / solve: [column][item][BD_NC]
     int npad;
 };
-constexpr int BD_PAD = 8;                   // zero columns in front of / behind a factor (the sweeps read four columns back / ahead)
 
 // ------------------------------------------------------------------------------------------------
 // factors of all items by one launch: ONE LANE PER ITEM

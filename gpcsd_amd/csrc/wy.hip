@@ -93,7 +93,6 @@ __global__ __launch_bounds__(WY_NT) void wy_apply_kernel(WyBatch b) {
     for (int p = P.npanels - 1; p >= 0; --p) {
         const double *__restrict__ Vp = P.V + (long)p * WY_NB * n;
         const double *__restrict__ Tp = P.T + (long)p * WY_NB * WY_NB;
-        const int kstart = (p * WY_NB) & ~3;
         // T_p on its way to LDS (KS > 1: there is room): four coalesced loads per thread issued here, in front of the W1 product
         // they do not depend on -- as strided fragment loads in the W2 phase they were a 2 us round trip per panel
         double tl4[4];
