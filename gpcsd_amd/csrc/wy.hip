@@ -247,10 +247,10 @@ __global__ __launch_bounds__(WQ_NT) void wy_qstage_kernel(WyBatch b, int p0, int
     extern __shared__ double smem[];
     const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int fr = lane & 15, fq = lane >> 4;
-    // (GPCSD_QPIPE_CLK=1: phase clocks of workgroup (0, 0) of the last two panels' launches, clk[32 + 8 (p & 1) + k])
+    // (GPCSD_QPIPE_CLK=1: phase clocks of workgroup (0, 0) of the last two panels' launches, clk[48 + 8 (p & 1) + k]; the gates' stamps fill [0, 48): three per (panel, problem))
     int nst = 0;
     auto stamp = [&]() {
-        if (b.clk && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0 && nst < 8) b.clk[32 + 8 * (p & 1) + nst] = wall_clock64();
+        if (b.clk && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0 && nst < 8) b.clk[48 + 8 * (p & 1) + nst] = wall_clock64();
         ++nst;
     };
     // ---- gate

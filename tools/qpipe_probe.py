@@ -39,10 +39,10 @@ if os.environ.get("GPCSD_QPIPE_CLK") == "1":
     ctx.synchronize()
     raw = ctx.fetch("wy_clk", (64,)).view(np.uint64)
     for par in (0, 1):
-        st = [int(v) for v in raw[32 + 8 * par: 40 + 8 * par]]
+        st = [int(v) for v in raw[48 + 8 * par: 56 + 8 * par]]
         print("panel parity %d, workgroup (0, 0): gate passed -> G %.1f | diagonal blocks %.1f | doubling + store %.1f | slab load %.1f | W1, W2 %.1f | "
               "update %.1f | store %.1f us" % tuple([par] + [0.01 * (st[k + 1] - st[k]) for k in range(7)]))
-    clk = raw[:63].reshape(-1, 3)
+    clk = raw[:48].reshape(-1, 3)
     for p in range(4):
         for y in range(2):
             e, x, t0 = [int(v) for v in clk[p * 4 + y]]
