@@ -424,6 +424,8 @@ def main():
     ap.add_argument("--only-value", action="store_true",
                     help="setup + warm-up + timed loop, then print value / ms_per_step and exit: the command profiled under profiles/")
     ap.add_argument("--no-sub-results", action="store_true", help="skip the compact cfg2 / cfg5 sub-results of the default line")
+    ap.add_argument("--sub-result", default=None, choices=SUB_RESULT_KEYS,
+                    help="measure one sub-result of the default line and print its dict (what the default run starts as a child)")
     ap.add_argument("--cpu-budget-s", type=float, default=45.0)
     ap.add_argument("--fit-batch", type=int, default=None, help="cfg5: restarts evaluated per lock-step batch")
     ap.add_argument("--fit-maxiter", type=int, default=15)
@@ -473,6 +475,14 @@ def main():
         else:
             td.init_process_group(backend, rank=rank, world_size=world)
 
+    if args.sub_result is not None:                   # one sub-result of the default line, as a command of its own
+        legs = []
+        r = sub_result_one(args, args.sub_result, local_rank, backend, legs)
+        for leg in legs:
+            leg()
+        sys.stdout.flush()
+        print(SUB_RESULT_MARK + json.dumps(r, default=_JSON_DEFAULT), flush=True)
+        return
     if args.workload == "potrf":                      # the dense Cholesky path on its own (the command profiled as r04_*_potrf)
         if rank == 0:
             emit(potrf_bench())
@@ -572,7 +582,7 @@ def compact_record(full):
 def emit(full):
     """Write the full result dict to DETAIL_FILE beside the script (and under gpurun_out/ when that exists, so that a gpurun call
     brings it home), then print the compact line -- the last thing on stdout."""
-    blob = json.dumps(full, indent=1, default=lambda o: float(o) if isinstance(o, np.floating) else str(o))
+    blob = json.dumps(full, indent=1, default=_JSON_DEFAULT)
     for d in (ROOT, os.path.join(ROOT, "gpurun_out")):
         if os.path.isdir(d):
             try:
@@ -626,13 +636,13 @@ def _quiesce_host(seconds=0.25):
     time.sleep(seconds)
 
 
-def sub_results(args, local_rank, backend, cpu_legs):
-    """Compact cfg2 (BASELINE configs[1]), cfg5 (configs[4], this GPU's share at N=1: all 32 restarts), dense Cholesky, npx69 (the
-    reference's 2D script shape) and aud24 (its 1D script shape) results, measured by the same functions `--workload <name>` runs.
-    GPU work only: every parity check against the oracle is appended to `cpu_legs` and runs after the last GPU measurement."""
+SUB_RESULT_KEYS = ("cfg2", "cfg5", "npx69", "aud24", "potrf")
+
+
+def sub_result_one(args, key, local_rank, backend, cpu_legs):
+    """One sub-result of the default line, measured by the same functions `--workload <name>` runs.  GPU work only: every parity
+    check against the oracle is appended to `cpu_legs` (the caller runs them after the last GPU measurement)."""
     import copy
-    out = {}
-    t0 = time.perf_counter()
 
     def step(name, steps, warmup, setup):
         a = copy.copy(args)
@@ -655,14 +665,6 @@ def sub_results(args, local_rank, backend, cpu_legs):
             r["fit"].pop("nll_values", None)
         return r
 
-    def guarded(key, fn):                                          # a sub-result must never take the headline down
-        try:
-            out[key] = fn()
-        except Exception as e:
-            out[key] = {"error": repr(e)}
-
-    guarded("cfg2", lambda: step("cfg2", 100, 5, 60))
-
     def npx():
         # the reference's own 2D workload shape (69 channels without mirror symmetry) beside a point-symmetric control
         r69, r72 = step("npx69", 200, 5, 150), step("npx72sym", 200, 5, 150)
@@ -674,13 +676,56 @@ def sub_results(args, local_rank, backend, cpu_legs):
                            "loglik_evals_per_sec": r69["loglik_evals_per_sec"], "fit_evals_per_sec": rf["value"],
                            "step_over_symmetric_control": r69["step_over_symmetric_control"]}
         return r69
+
+    if key == "cfg2":
+        return step("cfg2", 100, 5, 60)
+    if key == "cfg5":
+        return fit("cfg5")
+    if key == "npx69":
+        return npx()
+    if key == "aud24":                                 # the reference's 1D script shape: per-electrode noise list (fit_gpcsd_baseline.py:79-105)
+        return fit("aud24")
+    if key == "potrf":
+        return potrf_bench()
+    raise SystemExit("bench.py: unknown sub-result %r (one of %s)" % (key, ", ".join(SUB_RESULT_KEYS)))
+
+
+_JSON_DEFAULT = lambda o: float(o) if isinstance(o, np.floating) else str(o)
+SUB_RESULT_MARK = "BENCH_SUB_RESULT "
+
+
+def sub_result_child(key, timeout_s=240.0):
+    """Run one sub-result as a command of its own -- `python bench.py --sub-result <key>`, a fresh child process -- and return its
+    dict.  Each workload then runs on a context, streams and hardware queues of its own, exactly as `--workload <key>` does: the
+    round-5 rehearsals of the driver command read cfg2 at 0.90-0.91 ms per step in two runs out of three (0.62 in the third) when
+    its context was the second one created inside the cfg3 process, against 0.624-0.629 ms in six runs as a command of its own.
+    The parent is idle on the GPU while a child runs (one child at a time), and no exec happens in a GPU-initialised process:
+    the child is started with subprocess and this process goes on to print the line."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--sub-result", key]
+    p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=timeout_s, cwd=ROOT)
+    for ln in reversed(p.stdout.splitlines()):
+        if ln.startswith(SUB_RESULT_MARK):
+            return json.loads(ln[len(SUB_RESULT_MARK):])
+    raise RuntimeError("sub-result %s: exit code %d, no result line; stderr tail: %s" % (key, p.returncode, p.stderr[-400:]))
+
+
+def sub_results(args, local_rank, backend, cpu_legs):
+    """Compact cfg2 (BASELINE configs[1]), cfg5 (configs[4], this GPU's share at N=1: all 32 restarts), dense Cholesky, npx69 (the
+    reference's 2D script shape) and aud24 (its 1D script shape) results.  Each is measured in a child process of its own
+    (sub_result_child); GPCSD_BENCH_SUB_INPROC=1 measures them inside this process instead, CPU legs deferred to `cpu_legs`."""
+    out = {}
+    t0 = time.perf_counter()
+    inproc = os.environ.get("GPCSD_BENCH_SUB_INPROC") == "1"
+    out["measured_in"] = "this process" if inproc else "one child process per sub-result (python bench.py --sub-result <key>)"
     # Order: the latency-bound step loops first, the machine-filling legs last.  The dense Cholesky (18 ms launches at 0.4 of the
     # MFMA peak) leaves the card's clocks low for the next tenth of a second: the driver's round-5 rehearsal read npx69 at 1.13 ms
     # per step right behind it against 0.586 ms as a command of its own (and 0.57 for its control, which ran one leg later).
-    guarded("cfg5", lambda: fit("cfg5"))
-    guarded("npx69", npx)
-    guarded("aud24", lambda: fit("aud24"))            # the reference's 1D script shape: per-electrode noise list (fit_gpcsd_baseline.py:79-105)
-    guarded("potrf", potrf_bench)
+    for key in ("cfg2", "cfg5", "npx69", "aud24", "potrf"):
+        try:                                                       # a sub-result must never take the headline down
+            out[key] = sub_result_one(args, key, local_rank, backend, cpu_legs) if inproc else sub_result_child(key)
+        except Exception as e:
+            out[key] = {"error": repr(e)}
     out["seconds_spent_gpu_legs"] = time.perf_counter() - t0
     return out
 
