@@ -696,9 +696,11 @@ SUB_RESULT_MARK = "BENCH_SUB_RESULT "
 
 def sub_result_child(key, timeout_s=240.0):
     """Run one sub-result as a command of its own -- `python bench.py --sub-result <key>`, a fresh child process -- and return its
-    dict.  Each workload then runs on a context, streams and hardware queues of its own, exactly as `--workload <key>` does: the
-    round-5 rehearsals of the driver command read cfg2 at 0.90-0.91 ms per step in two runs out of three (0.62 in the third) when
-    its context was the second one created inside the cfg3 process, against 0.624-0.629 ms in six runs as a command of its own.
+    dict: every workload is then measured as `--workload <key>` measures it, in the first step loop of its process.  Measured in
+    the same process behind the cfg3 legs, cfg2 read 0.90-0.91 ms per step in two rehearsals of the driver command out of three
+    (0.62 in the third) against 0.624-0.629 ms in six runs as a command of its own: on some boxes a loop that is not the first one
+    of its process contains one stall of 5-25 ms in which no kernel of the process runs (tools/two_models_probe.py, DESIGN 6: not
+    the streams, not Python's collector, not the allocator, not NUMA balancing; first loops are hit about once in thirty).
     The parent is idle on the GPU while a child runs (one child at a time), and no exec happens in a GPU-initialised process:
     the child is started with subprocess and this process goes on to print the line."""
     import subprocess

@@ -134,6 +134,7 @@ _DP = _c_double_p
 SIGNATURES = {
     "gpcsd_ctx_create": (_I, [_I, ctypes.POINTER(_P)]),
     "gpcsd_ctx_destroy": (_I, [_P]),
+    "gpcsd_ctx_stream_handle": (_I, [_P, _I, ctypes.POINTER(ctypes.c_ulonglong)]),
     "gpcsd_last_error": (ctypes.c_char_p, [_P]),
     "gpcsd_version": (_I, []),
     "gpcsd_device_synchronize": (_I, [_P]),
@@ -376,6 +377,24 @@ class Context:
             self.close()
         except Exception:
             pass
+
+    def stream_handles(self):
+        """The context's four hipStream_t as integers: (main, temporal chain, spatial chain, side stream)."""
+        out = []
+        for which in range(4):
+            v = ctypes.c_ulonglong()
+            self._check(self._lib.gpcsd_ctx_stream_handle(self._h, which, ctypes.byref(v)))
+            out.append(int(v.value))
+        return tuple(out)
+
+    def stream_pool_stats(self):
+        """(stream sets created, stream sets taken over from a closed context) in this process."""
+        out = []
+        for which in (-1, -2):
+            v = ctypes.c_ulonglong()
+            self._check(self._lib.gpcsd_ctx_stream_handle(None, which, ctypes.byref(v)))
+            out.append(int(v.value))
+        return tuple(out)
 
     # ---- error convention (include/gpcsd_hip.h) ----
     def _check(self, rc):

@@ -992,6 +992,79 @@ extern "C" const char *gpcsd_last_error(gpcsd_ctx *ctx) {
     return g_last_error.c_str();
 }
 
+// ---- the streams of a context ---------------------------------------------------------------------------------------------
+// A context runs on four streams (main; the temporal and the spatial chain; the side stream).  Which hardware queue -- and
+// behind it which pipe of the command processor -- a stream lands on is decided by the runtime and the kernel driver when the
+// stream is created.  A closed context's streams are therefore not destroyed: they go back to a per-device pool and the next
+// context of the process takes them over (last in, first out), so that models opened one after another run on the very same
+// queues, whatever number of models the process has opened before; opening a model costs no queue creation either.  Contexts
+// that are alive together get sets of their own.  GPCSD_STREAM_POOL=0: create and destroy per context (A/B).  Pooled streams
+// live until the process ends.
+// (What the pool does NOT cure, measured with tools/two_models_probe.py: on some boxes the step loop of a model that is not the
+// first one of its process contains ONE stall of 5-25 ms in which no kernel of the process runs (rocprofv3 kernel trace; the host
+// sits in hipEventSynchronize) -- 0.63 -> 0.87-0.92 ms per cfg2 step over a 100-step loop.  With or without the pool, Python's
+// collector off, malloc trimming off, NUMA balancing off on the box; other boxes show it in one loop of twelve.  DESIGN 6.)
+struct StreamSet {
+    hipStream_t s[4];
+};
+static std::mutex g_stream_pool_mu;
+static std::map<int, std::vector<StreamSet>> g_stream_pool;
+static long g_stream_sets_created = 0, g_stream_sets_reused = 0;
+static bool stream_pool_on() {
+    static const bool on = !(getenv("GPCSD_STREAM_POOL") && getenv("GPCSD_STREAM_POOL")[0] == '0');
+    return on;
+}
+static StreamSet stream_set_acquire(int device) {
+    {
+        std::lock_guard<std::mutex> lk(g_stream_pool_mu);
+        auto &v = g_stream_pool[device];
+        if (stream_pool_on() && !v.empty()) {
+            const StreamSet ss = v.back();
+            v.pop_back();
+            ++g_stream_sets_reused;
+            return ss;
+        }
+    }
+    StreamSet ss{};
+    int prio_least = 0, prio_greatest = 0;
+    GP_HIP(hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
+    GP_HIP(hipStreamCreateWithFlags(&ss.s[0], hipStreamNonBlocking));
+    GP_HIP(hipStreamCreateWithPriority(&ss.s[1], hipStreamNonBlocking, prio_greatest));
+    GP_HIP(hipStreamCreateWithPriority(&ss.s[2], hipStreamNonBlocking, prio_greatest));
+    const char *ev = getenv("GPCSD_S4_PRIO");
+    if (ev && ev[0] == '0') GP_HIP(hipStreamCreateWithFlags(&ss.s[3], hipStreamNonBlocking));
+    else GP_HIP(hipStreamCreateWithPriority(&ss.s[3], hipStreamNonBlocking, prio_greatest));
+    std::lock_guard<std::mutex> lk(g_stream_pool_mu);
+    ++g_stream_sets_created;
+    return ss;
+}
+// (the caller has drained the streams)
+static void stream_set_release(int device, const StreamSet &ss) {
+    if (!ss.s[0] && !ss.s[1] && !ss.s[2] && !ss.s[3]) return;
+    if (stream_pool_on() && ss.s[0] && ss.s[1] && ss.s[2] && ss.s[3]) {
+        std::lock_guard<std::mutex> lk(g_stream_pool_mu);
+        g_stream_pool[device].push_back(ss);
+        return;
+    }
+    for (int i = 0; i < 4; ++i)
+        if (ss.s[i]) (void)hipStreamDestroy(ss.s[i]);
+}
+
+/* which: 0 main, 1 temporal chain, 2 spatial chain, 3 side stream -> the hipStream_t as an integer; which = -1: sets created so
+ * far in this process, -2: sets taken over from a closed context */
+extern "C" int gpcsd_ctx_stream_handle(gpcsd_ctx *c, int which, unsigned long long *out) {
+    if (!out) return -3;
+    if (which < 0) {
+        std::lock_guard<std::mutex> lk(g_stream_pool_mu);
+        *out = (unsigned long long)(which == -1 ? g_stream_sets_created : g_stream_sets_reused);
+        return which >= -2 ? 0 : -3;
+    }
+    if (!c || which > 3) return -3;
+    hipStream_t s[4] = {c->stream, c->stream2, c->stream3, c->stream4};
+    *out = (unsigned long long)(uintptr_t)s[which];
+    return 0;
+}
+
 extern "C" int gpcsd_ctx_create(int device, gpcsd_ctx **out) {
     if (!out) return -1;
     *out = nullptr;
@@ -1012,19 +1085,17 @@ extern "C" int gpcsd_ctx_create(int device, gpcsd_ctx **out) {
         if (const char *ev = getenv("GPCSD_BAND_TAIL")) c->band_tail = ev[0] != '0';
         if (const char *ev = getenv("GPCSD_Q_PIPE")) c->q_pipe = ev[0] != '0';
         if (const char *ev = getenv("GPCSD_PRED_CHUNKED")) c->pred_chunked = ev[0] != '0';
-        GP_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
         // The two chains are the critical path and made of small launches; when they run beside another call's GEMM tail
         // (thousands of workgroups) each of those launches would otherwise queue behind the tiles: high priority.
-        int prio_least = 0, prio_greatest = 0;
-        GP_HIP(hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
-        GP_HIP(hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, prio_greatest));
-        GP_HIP(hipStreamCreateWithPriority(&c->stream3, hipStreamNonBlocking, prio_greatest));
         // stream4: stage 3 / stage 5 of a staged temporal chain (on the log-likelihood's critical path, beside the previous call's
         // products) and the prediction's two small side products -- high priority as well (GPCSD_S4_PRIO=0: A/B)
+        // The four streams come from a per-device pool that contexts return theirs to (stream_set_acquire).
         {
-            const char *ev = getenv("GPCSD_S4_PRIO");
-            if (ev && ev[0] == '0') GP_HIP(hipStreamCreateWithFlags(&c->stream4, hipStreamNonBlocking));
-            else GP_HIP(hipStreamCreateWithPriority(&c->stream4, hipStreamNonBlocking, prio_greatest));
+            const StreamSet ss = stream_set_acquire(device);
+            c->stream = ss.s[0];
+            c->stream2 = ss.s[1];
+            c->stream3 = ss.s[2];
+            c->stream4 = ss.s[3];
         }
         // (stream5 = stream4.  A fifth stream for the prediction's side products -- any priority -- made the STEP slower, 1.5 instead
         // of 0.95 ms at cfg3, with or without stage 5: measured, not understood; the runtime's mapping of streams to hardware queues
@@ -1055,6 +1126,7 @@ extern "C" int gpcsd_ctx_create(int device, gpcsd_ctx **out) {
         *out = c;
         return 0;
     } catch (const HipError &e) {
+        if (c) stream_set_release(c->device, StreamSet{{c->stream, c->stream2, c->stream3, c->stream4}});
         delete c;
         return fail(nullptr, e);
     }
@@ -1079,8 +1151,6 @@ extern "C" int gpcsd_ctx_destroy(gpcsd_ctx *c) {
     if (c->ev_sjoin) (void)hipEventDestroy(c->ev_sjoin);
     for (int i = 0; i < 4; ++i)
         if (c->ev_mark[i / 2][i % 2]) (void)hipEventDestroy(c->ev_mark[i / 2][i % 2]);
-    if (c->stream3) (void)hipStreamDestroy(c->stream3);
-    if (c->stream4) (void)hipStreamDestroy(c->stream4);
     if (c->stream5 && c->stream5 != c->stream4) (void)hipStreamDestroy(c->stream5);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     if (c->ev_aux) (void)hipEventDestroy(c->ev_aux);
@@ -1098,8 +1168,7 @@ extern "C" int gpcsd_ctx_destroy(gpcsd_ctx *c) {
     if (c->ev_m1) (void)hipEventDestroy(c->ev_m1);
     for (int i = 0; i < 2; ++i)
         if (c->ev_tri_done[i]) (void)hipEventDestroy(c->ev_tri_done[i]);
-    if (c->stream) (void)hipStreamDestroy(c->stream);
-    if (c->stream2) (void)hipStreamDestroy(c->stream2);
+    stream_set_release(c->device, StreamSet{{c->stream, c->stream2, c->stream3, c->stream4}});      // (drained above)
     if (c->h_result) (void)hipHostFree(c->h_result);
     if (c->h_ll) (void)hipHostFree(c->h_ll);
     if (c->h_chol_flag) (void)hipFree(c->h_chol_flag);

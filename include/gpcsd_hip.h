@@ -74,6 +74,13 @@ typedef struct gpcsd_hparams {
 /* ---- context -------------------------------------------------------------------- */
 int  gpcsd_ctx_create(int device, gpcsd_ctx **out);
 int  gpcsd_ctx_destroy(gpcsd_ctx *ctx);
+/* The HIP streams a context queues on, as integers (hipStream_t): which = 0 the main stream (every fused call's products and
+ * results; an integrator orders its own HIP work against the library with an event on this one), 1 / 2 the temporal / spatial
+ * eigen chains (utility_functions.py:58-59), 3 the side stream.  A closed context's four streams go back to a per-device pool and
+ * the next context of the process takes them over (the stream -> hardware queue mapping is fixed when a stream is created: models
+ * opened one after another run on the same queues); which = -1 / -2 (ctx may be NULL): stream sets created / taken over so far in
+ * this process.  GPCSD_STREAM_POOL=0 switches the pool off. */
+int  gpcsd_ctx_stream_handle(gpcsd_ctx *ctx, int which, unsigned long long *out);
 const char *gpcsd_last_error(gpcsd_ctx *ctx);     /* ctx may be NULL: last global error */
 int  gpcsd_version(void);
 /* waits for everything queued on the context; also reports (rc > 0) a pending asynchronous gpcsd_predict_resident's failure */
