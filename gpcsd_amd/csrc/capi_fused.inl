@@ -1127,6 +1127,13 @@ extern "C" int gpcsd_loglik_predict_async(gpcsd_ctx *c, const gpcsd_hparams *hp_
     // one spatial decomposition (PairFront::share_s): the two projected data sets W~ = diag(U)^T (Y~ Q or Y~) are then the same
     // product whenever both sets take the same form -- tridiagonal with X shared, or both with the temporal eigenvectors
     const bool share_w = pf.share_s && (share_x || (!pf.e[0].tri && !pf.e[1].tri));
+    // a pair that queued its own front half is (in a loop) followed by one that does the same while this one's solve runs: the
+    // narrow form of the solve leaves room beside it (gram.hip: k_tridiag_solve)
+    struct SolvePass {
+        gpcsd_ctx *c;
+        SolvePass(gpcsd_ctx *cc, int v) : c(cc) { c->solve_pass = v; }
+        ~SolvePass() { c->solve_pass = 0; }
+    } solve_pass(c, taken ? 64 : 32);
     return predict_fold(c, hp_pr, pf.e[1], pf.fm[1], Yf, sz, dzf, nz, dtf, type, want_lists != 0, true, &ll_tail, &ll_pre,
                         share_x ? "ll_X" : nullptr, prelude_side, share_w ? "proj_W_ll" : nullptr);
     GP_API_END(c)

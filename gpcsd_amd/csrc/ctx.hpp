@@ -240,6 +240,7 @@ struct gpcsd_ctx {
     // product less per cfg3 step, but the step measured 6-10 % SLOWER (the prediction's LDS-filling solve then starts 70 us earlier and
     // lands on the next step's spatial Gram assembly: DESIGN 4.13), and the pair no longer has the bits of its fenced calls.
     bool pair_share_s = false;
+    int solve_pass = 0;                     // trials per pass of the next tridiagonal solve: 0 / 64 the one-pass form, 32 the two-per-CU form (gram.hip: k_tridiag_solve)
     long pair_shared_s_calls = 0;
     long pair_shared_x_calls = 0;           // paired calls whose prediction read the log-likelihood's X = Y~ Q (capi_fused.inl)
     // Decomposition cache (capi.hip::front_half): predict() right after loglik() / fit() with the same hyper-parameters

@@ -685,7 +685,8 @@ bool k_ll_tridiag(gpcsd_ctx *c, const double *W, const double *es, const double 
 // log-likelihood's kernel does: 83 us per item against ~15 -- and with 122 KB of LDS per item only one item runs per CU, three
 // rounds per launch.)
 constexpr int TS_BATCH = 64;                    // columns per batch of the sweeps / of the load burst
-constexpr int TS_P = 64;                        // LDS row of a column: one entry per lane (trial) of the pass
+constexpr int TS_P = 64;                        // LDS row of a column: one entry per lane (trial) of the pass (the widest form)
+constexpr int TS_P_DEFAULT = 64;
 struct TriSolveArgs {
     const double *W;             // (U^T Y Q) in the layout [x'][r][t~], rows of nt doubles
     double *B;                   // the solutions, same layout (may be W)
@@ -708,11 +709,13 @@ struct TriSolveArgs {
 // ~40 cycles per column step against the 8 of the dependent FMA itself.
 constexpr int TS_HB = 32;                       // columns per half batch of a sweep (registers: 32 values + 2 x 32 coefficients)
 constexpr int TS_KMAX = 256;                    // columns of a block at most: one per thread of the pivot scan, one batch per wave
-__global__ __launch_bounds__(256) void tridiag_solve_kernel(TriSolveArgs g) {
+template <int P>
+__global__ __launch_bounds__(256, P == 32 ? 2 : 1) void tridiag_solve_kernel(TriSolveArgs g) {
+    constexpr int HB = (P == 32) ? 16 : TS_HB;     // columns per half batch of a sweep: the two-per-CU form has half the registers
     extern __shared__ __attribute__((aligned(16))) double smem[];
     double *zbuf = smem;                               // [npad / 2][64][2]: w, then z, then x, in place -- two consecutive columns of
                                                        // a lane side by side (one 16-byte LDS access per two column steps)
-    double *pinv = zbuf + (long)g.npad * TS_P;         // [TS_KMAX + TS_BATCH]: 1 / D_k
+    double *pinv = zbuf + (long)g.npad * P;         // [TS_KMAX + TS_BATCH]: 1 / D_k
     double *lmul = pinv + TS_KMAX + TS_BATCH;          // [TS_KMAX + TS_BATCH]: l_k = b_{k-1} / D_{k-1} (0 for k = 0 and k >= np)
     double *scan = lmul + TS_KMAX + TS_BATCH;          // [2][256][4]: the 2 x 2 prefix products of the pivot scan (pass 0)
     auto stamp = [&](int k) { if (g.clk && blockIdx.x == 0 && threadIdx.x == 0) g.clk[k] = wall_clock64(); };
@@ -731,14 +734,14 @@ __global__ __launch_bounds__(256) void tridiag_solve_kernel(TriSolveArgs g) {
     const double *__restrict__ dd = g.d[p], *__restrict__ ee = g.e[p];
     const long rowbase = (long)xr * g.R * g.nt + g.c0[p];
     const int quarter = lane >> 4, kk_l = lane & 15;   // a global access: four rows of 16 columns
-    for (int r0 = 0; r0 < g.R; r0 += TS_P) {
-        const int nr = min(TS_P, g.R - r0);
+    for (int r0 = 0; r0 < g.R; r0 += P) {
+        const int nr = min(P, g.R - r0);
         const bool first = r0 == 0;
         const double *const wl = g.W + rowbase + (long)(r0 + quarter) * g.nt + kk_l;     // this lane's corner of a piece
         // ---- the rows of this pass into LDS: wave w takes batch w (npad <= 256: at most four batches, one per wave); the loads
         // are issued first and land while the pivots are formed
         const int b0 = wid * TS_BATCH;
-        double stg[4][16];
+        double stg[4][P / 4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int kq = b0 + 16 * q;                              // wave-uniform classification of the piece's columns
@@ -747,7 +750,7 @@ __global__ __launch_bounds__(256) void tridiag_solve_kernel(TriSolveArgs g) {
             // (its multipliers are zero) -- and 64 loop-invariant lane masks would live in SGPRs the kernel does not have
             const int kc = min(kk_l, max(np - 1 - kq, 0));
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
+            for (int i = 0; i < P / 4; ++i) {
                 double v = 0.0;
                 if (4 * i < nr && kq < np) {                         // wave-uniform: some row / column of the piece exists
                     const int rc = min(quarter + 4 * i, nr - 1) - quarter;
@@ -798,58 +801,59 @@ __global__ __launch_bounds__(256) void tridiag_solve_kernel(TriSolveArgs g) {
 #pragma unroll
         for (int q = 0; q < 4; ++q)
 #pragma unroll
-            for (int i = 0; i < 16; ++i)
-                if (b0 < npad) zbuf[((b0 + 16 * q + kk_l) >> 1) * (2 * TS_P) + (quarter + 4 * i) * 2 + (kk_l & 1)] = stg[q][i];
+            for (int i = 0; i < P / 4; ++i)
+                if (b0 < npad) zbuf[((b0 + 16 * q + kk_l) >> 1) * (2 * P) + (quarter + 4 * i) * 2 + (kk_l & 1)] = stg[q][i];
         __syncthreads();
         stamp(1);
         if (wid == 0) {
             typedef double dbl2 __attribute__((ext_vector_type(2)));
-            dbl2 *const zl = reinterpret_cast<dbl2 *>(zbuf) + lane;  // this lane's row of the block: columns 2j, 2j + 1 at zl[j * 64]
+            dbl2 *const zl = reinterpret_cast<dbl2 *>(zbuf) + (lane & (P - 1));      // this lane's row of the block: columns 2j, 2j + 1 at
+                                                                               // zl[j * P] (P = 32: the upper half wave doubles the lower)
             // ---- forward sweep in place: z_k = w_k - l_k z_{k-1}
             double z = 0.0;
-            for (int h0 = 0; h0 < npad; h0 += TS_HB) {
-                dbl2 *const zb = zl + (h0 >> 1) * TS_P;
+            for (int h0 = 0; h0 < npad; h0 += HB) {
+                dbl2 *const zb = zl + (h0 >> 1) * P;
                 const dbl2 *const lc = reinterpret_cast<const dbl2 *>(lmul + h0);
-                dbl2 v[TS_HB / 2], cl[TS_HB / 2];
+                dbl2 v[HB / 2], cl[HB / 2];
 #pragma unroll
-                for (int j = 0; j < TS_HB / 2; ++j) {
-                    v[j] = zb[j * TS_P];
+                for (int j = 0; j < HB / 2; ++j) {
+                    v[j] = zb[j * P];
                     cl[j] = lc[j];
                 }
 #pragma unroll
-                for (int j = 0; j < TS_HB / 2; ++j) {
+                for (int j = 0; j < HB / 2; ++j) {
                     z = fma(-cl[j].x, z, v[j].x);
                     v[j].x = z;
                     z = fma(-cl[j].y, z, v[j].y);
                     v[j].y = z;
                 }
 #pragma unroll
-                for (int j = 0; j < TS_HB / 2; ++j) zb[j * TS_P] = v[j];
+                for (int j = 0; j < HB / 2; ++j) zb[j * P] = v[j];
             }
             stamp(2);
             // ---- backward sweep in place: x_k = z_k / D_k - l_{k+1} x_{k+1}
             double x = 0.0;
-            for (int h0 = npad - TS_HB; h0 >= 0; h0 -= TS_HB) {
-                dbl2 *const zb = zl + (h0 >> 1) * TS_P;
+            for (int h0 = npad - HB; h0 >= 0; h0 -= HB) {
+                dbl2 *const zb = zl + (h0 >> 1) * P;
                 const dbl2 *const pc = reinterpret_cast<const dbl2 *>(pinv + h0);
-                double cl[TS_HB + 1];                                // l_{h0 + 1} .. l_{h0 + 32}: an odd offset, read singly
-                dbl2 v[TS_HB / 2], cp[TS_HB / 2];
+                double cl[HB + 1];                                // l_{h0 + 1} .. l_{h0 + 32}: an odd offset, read singly
+                dbl2 v[HB / 2], cp[HB / 2];
 #pragma unroll
-                for (int j = 0; j < TS_HB / 2; ++j) {
-                    v[j] = zb[j * TS_P];
+                for (int j = 0; j < HB / 2; ++j) {
+                    v[j] = zb[j * P];
                     cp[j] = pc[j];
                 }
 #pragma unroll
-                for (int kk = 0; kk < TS_HB; ++kk) cl[kk] = lmul[h0 + kk + 1];
+                for (int kk = 0; kk < HB; ++kk) cl[kk] = lmul[h0 + kk + 1];
 #pragma unroll
-                for (int j = TS_HB / 2 - 1; j >= 0; --j) {
+                for (int j = HB / 2 - 1; j >= 0; --j) {
                     x = fma(v[j].y, cp[j].y, -cl[2 * j + 1] * x);
                     v[j].y = x;
                     x = fma(v[j].x, cp[j].x, -cl[2 * j] * x);
                     v[j].x = x;
                 }
 #pragma unroll
-                for (int j = 0; j < TS_HB / 2; ++j) zb[j * TS_P] = v[j];
+                for (int j = 0; j < HB / 2; ++j) zb[j * P] = v[j];
             }
         }
         __syncthreads();
@@ -864,9 +868,9 @@ __global__ __launch_bounds__(256) void tridiag_solve_kernel(TriSolveArgs g) {
                 if (kq >= np) continue;                              // wave-uniform
                 const bool kfull = kq + 15 < np, kok = kq + kk_l < np;
 #pragma unroll
-                for (int i = 0; i < 16; ++i) {
+                for (int i = 0; i < P / 4; ++i) {
                     if (4 * i >= nr) continue;                       // wave-uniform
-                    const double v = zbuf[((kq + kk_l) >> 1) * (2 * TS_P) + (quarter + 4 * i) * 2 + (kk_l & 1)];
+                    const double v = zbuf[((kq + kk_l) >> 1) * (2 * P) + (quarter + 4 * i) * 2 + (kk_l & 1)];
                     if (kfull && 4 * i + 3 < nr) bl[(long)(4 * i) * g.nt + kq] = v;      // whole piece: no lane mask
                     else if (kok && quarter + 4 * i < nr) bl[(long)(4 * i) * g.nt + kq] = v;
                 }
@@ -879,9 +883,9 @@ __global__ __launch_bounds__(256) void tridiag_solve_kernel(TriSolveArgs g) {
 }
 
 static int tridiag_solve_npad(int npmax) { return (npmax + TS_BATCH - 1) / TS_BATCH * TS_BATCH; }
-static size_t tridiag_solve_lds(int npmax) {
+static size_t tridiag_solve_lds(int npmax, int P = TS_P) {
     const int npad = tridiag_solve_npad(npmax);
-    return ((size_t)npad * TS_P + 2 * (size_t)(256 + TS_BATCH) + 2 * 256 * 4) * sizeof(double);
+    return ((size_t)npad * P + 2 * (size_t)(256 + TS_BATCH) + 2 * 256 * 4) * sizeof(double);
 }
 // trials per pass (64: a lane each) if column blocks of up to npmax fit the kernel's LDS block, else 0 (not supported: the caller keeps
 // the eigenvector form).  R < 16 leaves most of the wave's lanes idle: the GEMM form is the better one there.
@@ -900,18 +904,29 @@ void k_tridiag_solve(gpcsd_ctx *c, const double *W, double *B, const double *es,
     const int npmax = std::max(np[0], np[1]);
     GP_REQUIRE(k_tridiag_solve_pass(npmax, R) > 0, -3, "tridiag_solve: temporal blocks of %d columns do not fit the solve kernel", npmax);
     g.npad = tridiag_solve_npad(npmax);
-    const size_t lds = tridiag_solve_lds(npmax);
-    static size_t attr = 0;
-    if (lds > attr) {
-        GP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(tridiag_solve_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr = lds;
+    // Trials per pass: 64 (a lane each: one pass for up to 64 trials, 131 KB of LDS and 336 registers per lane: nothing else lives
+    // on a CU beside such a workgroup) or 32 (two passes for 50 trials; 66 KB, 193 registers: two per CU, and other streams'
+    // workgroups beside them).  Same recurrences per trial, same bits.  The caller says which (gpcsd_ctx::solve_pass): the paired
+    // call of a step loop WITHOUT announcements asks for 32 -- the next step's eigen-chains start while this solve runs, and their
+    // spatial Gram assembly took 204 us beside the wide form against 91 alone (0.901 against 0.941 ms per cfg3 step; with
+    // announcements the chains are not there to be disturbed and the narrow form's second pass costs 2.4 %: 0.811 against 0.792).
+    // Up to 32 trials the narrow form is one pass as well and always taken.  GPCSD_TS_P=32|64 forces one (A/B).
+    static const int forced = getenv("GPCSD_TS_P") ? (atoi(getenv("GPCSD_TS_P")) == 32 ? 32 : 64) : 0;
+    const int P = forced ? forced : (R <= 32 || c->solve_pass == 32) ? 32 : TS_P_DEFAULT;
+    const size_t lds = tridiag_solve_lds(npmax, P);
+    static size_t attr[2] = {0, 0};
+    if (lds > attr[P == 32]) {
+        if (P == 32) GP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(tridiag_solve_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        else GP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(tridiag_solve_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr[P == 32] = lds;
     }
     static const bool clk_on = getenv("GPCSD_TS_CLK") && getenv("GPCSD_TS_CLK")[0] == '1';
     g.clk = clk_on ? c->buf<unsigned long long>("ts_clk", 8) : nullptr;
     ProfScope ps(c, "tridiag_solve", 6.0 * nx * (double)R * nt, s);
     static const int grid_cap = getenv("GPCSD_TS_GRID") ? atoi(getenv("GPCSD_TS_GRID")) : 192;     // (A/B: 0 = one workgroup per item)
     const int grid = grid_cap > 0 ? std::min(2 * nx, grid_cap) : 2 * nx;
-    hipLaunchKernelGGL(tridiag_solve_kernel, dim3(grid), dim3(256), lds, s, g);
+    if (P == 32) hipLaunchKernelGGL(tridiag_solve_kernel<32>, dim3(grid), dim3(256), lds, s, g);
+    else hipLaunchKernelGGL(tridiag_solve_kernel<64>, dim3(grid), dim3(256), lds, s, g);
     GP_HIP(hipGetLastError());
     if (clk_on) {
         unsigned long long h[8];
