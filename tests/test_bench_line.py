@@ -91,3 +91,29 @@ def test_sub_result_headlines_are_flattened_into_config():
     assert h["cfg2_trials_per_sec"] == sub["cfg2"]["value"] and h["cfg5_fit_evals_per_sec"] == sub["cfg5"]["fit"]["evals_per_sec"]
     assert h["potrf_ms"] == sub["potrf"]["ms"] and h["npx69_ms_per_step"] == sub["npx69"]["ms_per_step"]
     assert bench.sub_headlines({"cfg2": {"error": "boom"}})["cfg2_trials_per_sec"] is None      # a failed leg leaves nulls, no raise
+
+
+def test_sub_results_run_as_child_commands_and_a_failed_one_leaves_nulls(monkeypatch):
+    """The default line measures every sub-workload in a child process of its own (`bench.py --sub-result <key>`): the child's
+    dict comes back through one marked stdout line; a child that dies leaves an error entry, the headline survives."""
+    import subprocess
+    import types
+    calls = []
+
+    def fake_run(cmd, **kw):
+        calls.append(cmd)
+        key = cmd[cmd.index("--sub-result") + 1]
+        assert cmd[0] == sys.executable and os.path.basename(cmd[1]) == "bench.py" and kw.get("timeout")
+        if key == "cfg5":                                          # a child that crashed before printing its result
+            return types.SimpleNamespace(stdout="noise\n", stderr="boom", returncode=1)
+        d = {"value": 123.0, "ms_per_step": 0.5, "headline": {"ms": 18.0, "frac": 0.4}}
+        return types.SimpleNamespace(stdout="import noise\n" + bench.SUB_RESULT_MARK + json.dumps(d) + "\n", stderr="", returncode=0)
+
+    monkeypatch.setattr(subprocess, "run", fake_run)
+    monkeypatch.delenv("GPCSD_BENCH_SUB_INPROC", raising=False)
+    sub = bench.sub_results(types.SimpleNamespace(), 0, "nccl", [])
+    assert [c[c.index("--sub-result") + 1] for c in calls] == ["cfg2", "cfg5", "npx69", "aud24", "potrf"]
+    assert sub["cfg2"]["value"] == 123.0 and "error" in sub["cfg5"] and "child process" in sub["measured_in"]
+    h = bench.sub_headlines(sub)
+    assert h["cfg2_ms_per_step"] == 0.5 and h["cfg5_evals_per_sec"] is None and h["potrf_frac"] == 0.4
+    assert set(bench.SUB_RESULT_KEYS) == {"cfg2", "cfg5", "npx69", "aud24", "potrf"}
