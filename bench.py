@@ -62,6 +62,16 @@ def workload(name):
         return dict(dim=2, nx=384, nt=500, x=neuropixels_xy(384), t=0.4 * np.arange(500.0)[:, None], ngl1=20, ngl2=60,
                     R=100.0, eps=80.0, ell_s=(40.0, 150.0), temporal=[(0, 20.0, 0.5), (1, 5.0, 0.7)], sig2n=0.05,
                     trials_per_gpu=50, label="GPCSD2D 384ch x 500t x 50 trials/GPU, fp64, ngl 20x60 (BASELINE cfg3/cfg4)")
+    if name == "cfg3fit":
+        # GPCSD2D.fit() at the headline geometry (gpcsd2d.py:153-287: obj_fun :196-219, minimize(..., jac=grad) :250): the unit is
+        # one objective + analytic-gradient evaluation over the 50 resident trials.  Restarts start 0.25 log-units around the
+        # hyper-parameters the data were drawn from (the default priors' variance draws are 1e8 x the data's scale on this
+        # geometry -- Ks is O(1e8) -- so prior-drawn starts would time a degenerate objective).
+        w = workload("cfg3")
+        w.update(restarts=8, starts_around_truth=0.25,
+                 label="GPCSD2D fit, 384ch x 500t x 50 trials on every GPU, fp64, ngl 20x60: objective + analytic gradient per "
+                       "evaluation, 8 restarts 0.25 log-units around the generating hyper-parameters (gpcsd2d.py:153-287)")
+        return w
     if name in ("cfg2", "cfg5"):
         w = dict(dim=1, nx=24, nt=500, x=np.linspace(0, 2300, 24)[:, None], t=np.arange(500.0)[:, None], ngl=100,
                  R=100.0, eps=0.0, ell_s=(200.0,), temporal=[(0, 20.0, 0.5), (1, 5.0, 0.7)], sig2n=0.05,
@@ -337,7 +347,7 @@ def cpu_baseline(w, m, lfp, budget_s=45.0):
 # ------------------------------------------------------------------------------------------------------- committed profiles
 # rocprofv3 summaries of `bench.py --only-value [--workload W]` (tools/profile_r05.sh), one set per workload: a line never
 # inherits another workload's numbers (no file for the workload, or a non-default trial count: null).
-PROFILE_ROUND = "r05"
+PROFILE_ROUND = "r06"
 
 
 def _profile(kind, wl, ext):
@@ -493,7 +503,7 @@ def main():
     # 1.12 ms per step for 0.86: its sub-result ran after the CPU baseline, whose OpenBLAS workers were still spinning on the CPUs
     # the launch thread is bound to.)
     cpu_legs = []
-    if args.workload in ("cfg5", "npx69fit", "aud24"):
+    if args.workload in FIT_WORKLOADS:
         out = run_fit_bench(args, w, rank, world, local_rank, backend, cpu_legs=cpu_legs)
     else:
         out = run_step_bench(args, w, rank, world, local_rank, backend, cpu_legs=cpu_legs)
@@ -520,6 +530,14 @@ def sub_headlines(sub):
     g = lambda d, *ks: (g(d.get(ks[0]), *ks[1:]) if len(ks) > 1 else d.get(ks[0])) if isinstance(d, dict) else None
     h["cfg2_trials_per_sec"] = g(sub, "cfg2", "value")
     h["cfg2_ms_per_step"] = g(sub, "cfg2", "ms_per_step")
+    h["cfg3fit_evals_per_sec"] = g(sub, "cfg3fit", "value")
+    h["cfg3fit_single_eval_ms"] = g(sub, "cfg3fit", "single_eval_ms")
+    h["cfg3fit_single_eval_over_fenced_loglik"] = g(sub, "cfg3fit", "single_eval_over_fenced_loglik")
+    h["cfg3fit_batch4_evals_per_sec"] = g(sub, "cfg3fit", "evals_by_lockstep_batch", "4", "evals_per_sec")
+    h["cfg3fit_fit_evals_per_sec"] = g(sub, "cfg3fit", "fit", "evals_per_sec")
+    h["cfg3fit_frac"] = g(sub, "cfg3fit", "roofline_frac_step_executed")
+    h["cfg3fit_grad_err_vs_oracle"] = g(sub, "cfg3fit", "parity", "gradient_worst_component_rel_err_vs_oracle_closed_form")
+    h["cfg3fit_cpu_evals_per_sec"] = g(sub, "cfg3fit", "cpu_baseline", "value")
     h["cfg5_evals_per_sec"] = g(sub, "cfg5", "value")
     h["cfg5_fit_evals_per_sec"] = g(sub, "cfg5", "fit", "evals_per_sec")
     for k in ("potrf", "npx69"):
@@ -545,7 +563,10 @@ _NESTED_KEYS = {
                "lockstep_batch", "class_api_predict_trials_per_sec", "class_api_predict_host_gb_per_sec",
                "class_api_predict_cached_trials_per_sec", "fenced_loglik_ms", "fenced_predict_ms", "two_steps_in_flight_ms",
                "next_step_announced", "pair_shares_spatial_side", "unannounced_ms_per_step", "library_default_ms_per_step",
-               "cfg2_trials_per_sec", "cfg2_ms_per_step", "cfg5_evals_per_sec", "cfg5_fit_evals_per_sec",
+               "cfg2_trials_per_sec", "cfg2_ms_per_step", "cfg3fit_evals_per_sec", "cfg3fit_single_eval_ms",
+               "cfg3fit_single_eval_over_fenced_loglik", "cfg3fit_batch4_evals_per_sec", "cfg3fit_fit_evals_per_sec", "cfg3fit_frac",
+               "cfg3fit_grad_err_vs_oracle", "cfg3fit_cpu_evals_per_sec", "single_eval_ms", "single_eval_over_fenced_loglik",
+               "batch4_evals_per_sec", "cfg5_evals_per_sec", "cfg5_fit_evals_per_sec",
                "potrf_ms", "potrf_frac", "potrf_trailing_update_frac", "npx69_trials_per_sec", "npx69_ms_per_step",
                "npx69_fit_evals_per_sec", "npx69_step_over_symmetric_control", "aud24_evals_per_sec", "aud24_fit_evals_per_sec",
                "aud24_predict_trials_per_sec", "aud24_grad_err_vs_oracle_fd", "fit_evals_per_sec", "fit_restarts_per_sec",
@@ -636,7 +657,8 @@ def _quiesce_host(seconds=0.25):
     time.sleep(seconds)
 
 
-SUB_RESULT_KEYS = ("cfg2", "cfg5", "npx69", "aud24", "potrf")
+SUB_RESULT_KEYS = ("cfg2", "cfg3fit", "cfg5", "npx69", "aud24", "potrf")
+FIT_WORKLOADS = ("cfg5", "npx69fit", "aud24", "cfg3fit")
 
 
 def sub_result_one(args, key, local_rank, backend, cpu_legs):
@@ -660,7 +682,8 @@ def sub_result_one(args, key, local_rank, backend, cpu_legs):
         a = copy.copy(args)
         a.workload, a.steps, a.warmup, a.setup_steps, a.fit_batch, a.fit_groups = name, 40, 3, 30, None, 1
         r = run_fit_bench(a, workload(name), 0, 1, local_rank, backend, compact=True, cpu_legs=cpu_legs)
-        r.pop("roofline", None)
+        roof = r.pop("roofline", None) or {}
+        r["roofline_frac_step_executed"], r["hbm_traffic_bytes_per_step"] = roof.get("frac"), roof.get("traffic")
         if isinstance(r.get("fit"), dict):
             r["fit"].pop("nll_values", None)
         return r
@@ -681,6 +704,8 @@ def sub_result_one(args, key, local_rank, backend, cpu_legs):
         return step("cfg2", 100, 5, 60)
     if key == "cfg5":
         return fit("cfg5")
+    if key == "cfg3fit":                               # GPCSD2D.fit() at the headline geometry: objective + analytic gradient
+        return fit("cfg3fit")
     if key == "npx69":
         return npx()
     if key == "aud24":                                 # the reference's 1D script shape: per-electrode noise list (fit_gpcsd_baseline.py:79-105)
@@ -723,7 +748,7 @@ def sub_results(args, local_rank, backend, cpu_legs):
     # Order: the latency-bound step loops first, the machine-filling legs last.  The dense Cholesky (18 ms launches at 0.4 of the
     # MFMA peak) leaves the card's clocks low for the next tenth of a second: the driver's round-5 rehearsal read npx69 at 1.13 ms
     # per step right behind it against 0.586 ms as a command of its own (and 0.57 for its control, which ran one leg later).
-    for key in ("cfg2", "cfg5", "npx69", "aud24", "potrf"):
+    for key in ("cfg2", "cfg3fit", "cfg5", "npx69", "aud24", "potrf"):
         try:                                                       # a sub-result must never take the headline down
             out[key] = sub_result_one(args, key, local_rank, backend, cpu_legs) if inproc else sub_result_child(key)
         except Exception as e:
@@ -876,6 +901,11 @@ def run_step_bench(args, w, rank, world, local_rank, backend, compact=False, cpu
         }
     ms_per_step = 1e3 * elapsed / args.steps
     pf_queued, pf_taken = ctx.prefetch_stats()
+    # the prediction the TIMED loop's last step left in HBM, in the mode `value` is timed in (announced, one spatial decomposition
+    # per pair: not the bits of a fenced call), fetched before anything else is queued: the line's parity gate reads this one
+    timed_pred = None
+    if not args.only_value and world == 1:
+        timed_pred = {"csd": ctx.fetch("pred_out_csd", (z.shape[0], w["nt"], R_local)).copy()}
     if args.only_value:
         if rank != 0:
             return None
@@ -1212,7 +1242,8 @@ def run_step_bench(args, w, rank, world, local_rank, backend, compact=False, cpu
         # the GPU half of the parity spot check now (the step's own prediction, fetched); the oracle half is a CPU leg
         hp0, _k = m._hparams(0.0)
         ctx.predict_resident(hp0, z, w["t"], _hip.PRED_CSD, want_lists=True)
-        got = ctx.fetch("pred_out_csd", (z.shape[0], w["nt"], R_local))
+        got_fenced = ctx.fetch("pred_out_csd", (z.shape[0], w["nt"], R_local))
+        got = timed_pred["csd"] if timed_pred is not None else got_fenced
         ll_gpu = float(ll)
 
         def cpu_leg():
@@ -1225,9 +1256,13 @@ def run_step_bench(args, w, rank, world, local_rank, backend, compact=False, cpu
                 O, geom, hpo, hpo0 = oracle_setup(w, m)
                 ll_cpu = O.loglik(geom, hpo, lfp)
                 pred_cpu = O.predict(geom, hpo0, lfp, z, w["t"], type="csd")["csd"]
-            # parity spot check beside the numbers: the GPU step's own outputs vs the oracle on the same trials
+            # parity spot check beside the numbers: the outputs of the TIMED loop's last step (its log-likelihood and the prediction
+            # it left in HBM, in the mode `value` is timed in) vs the oracle on the same trials; the fenced call's beside it
             out["parity_rel_err_loglik_vs_oracle"] = abs(ll_gpu - ll_cpu) / abs(ll_cpu)
             out["parity_rel_err_predict_vs_oracle"] = float(np.max(np.abs(got - pred_cpu)) / np.max(np.abs(pred_cpu)))
+            out["parity_predict_source"] = ("last step of the timed loop (announced=%s, one spatial decomposition per pair=%s)"
+                                            % (bool(announce["on"]), bool(share_s))) if timed_pred is not None else "fenced call"
+            out["parity_rel_err_fenced_predict_vs_oracle"] = float(np.max(np.abs(got_fenced - pred_cpu)) / np.max(np.abs(pred_cpu)))
         if cpu_legs is None:
             cpu_leg()
         else:
@@ -1259,9 +1294,16 @@ def run_fit_bench(args, w, rank, world, local_rank, backend, compact=False, cpu_
         m.shard_restarts(sharding)
     # restart k starts from the k-th draw of the default priors (np.random.seed(k), sampled on the host)
     starts = []
-    for k in range(total_restarts):
-        np.random.seed(k)
-        starts.append(m._sample_start(False))
+    if "starts_around_truth" in w:
+        tp_true = m._current_tparams()
+        lo, hi = (np.array([b[i] for b in m._bounds()], dtype=float) for i in (0, 1))
+        for k in range(total_restarts):
+            s0 = tp_true + w["starts_around_truth"] * np.random.RandomState(k).standard_normal(tp_true.size)
+            starts.append(np.minimum(np.maximum(s0, lo + 1e-6), hi - 1e-6))
+    else:
+        for k in range(total_restarts):
+            np.random.seed(k)
+            starts.append(m._sample_start(False))
     ng = 1 + m.dim + 2 * len(m.temporal_cov_list) + int(np.size(m.sig2n["value"]))
 
     def hp_of(tp):
@@ -1314,6 +1356,14 @@ def run_fit_bench(args, w, rank, world, local_rank, backend, compact=False, cpu_
         cg.synchronize()
     fence()
     elapsed = time.perf_counter() - t0
+    if args.only_value:                    # the command the rocprofv3 passes under profiles/ are taken over: nothing after the loop
+        if rank != 0:
+            return None
+        return {"metric": "gpcsd_fit_loglik_grad_evals_per_sec", "value": G * B * world * args.steps / elapsed, "unit": "evals/s",
+                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+                "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+                "config": {"workload": w["label"], "n_elec": w["nx"], "n_t": w["nt"], "trials_per_gpu": w["trials_per_gpu"],
+                           "lockstep_batch": B}, "only_value": "setup + warm-up + timed loop only (the command profiled under profiles/)"}
     # one group alone, for reference
     fence()
     t0g = time.perf_counter()
@@ -1331,6 +1381,31 @@ def run_fit_bench(args, w, rank, world, local_rank, backend, compact=False, cpu_
         ctx.loglik_grad(hps[i % len(hps)], ng)
     ctx.synchronize()
     seq_s = (time.perf_counter() - t1) / nseq
+    # the same evaluations in lock-step batches of 1 / 4 / 8 sets (what a rank of an N-GPU fit holds), and the fenced
+    # log-likelihood alone beside them: the gradient's price over the value's
+    by_batch, ll_fenced_ms = None, None
+    if w.get("starts_around_truth") and world == 1:
+        by_batch = {}
+        for bb in (1, 2, 4, 8):
+            if bb > len(hps):
+                break
+            for _ in range(3):
+                ctx.loglik_grad_batch(hps[:bb], ng)
+            ctx.synchronize()
+            tb = time.perf_counter()
+            nb_ = max(10, args.steps // 2)
+            for _ in range(nb_):
+                ctx.loglik_grad_batch(hps[:bb], ng)
+            ctx.synchronize()
+            dtb = (time.perf_counter() - tb) / nb_
+            by_batch[str(bb)] = {"ms_per_batched_call": 1e3 * dtb, "evals_per_sec": bb / dtb}
+        for _ in range(3):
+            ctx.loglik_parts(hps[0])
+        ctx.synchronize()
+        tl = time.perf_counter()
+        for _ in range(20):
+            ctx.loglik_parts(hps[0])
+        ll_fenced_ms = 1e3 * (time.perf_counter() - tl) / 20
     if sharding is not None:
         import torch.distributed as td
         tt = torch.tensor([elapsed, seq_s], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
@@ -1407,6 +1482,36 @@ def run_fit_bench(args, w, rank, world, local_rank, backend, compact=False, cpu_
             res["parity"] = {"objective_rel_err_vs_oracle": abs(f_gpu - f_cpu) / abs(f_cpu),
                              "gradient_max_err_over_max_component_vs_oracle_fd":
                                  float(np.max(np.abs(g_gpu - g_cpu)) / np.max(np.abs(g_cpu)))}
+            # ... and against the oracle's closed-form gradient (O.loglik_and_grad: pinned by central differences in the CPU
+            # suite), timed as the CPU baseline of this workload: one objective + gradient evaluation on the host cores
+            from threadpoolctl import threadpool_limits
+            hh0 = O.hparams_from_tparams(tp0, w["dim"], kinds, n_sig, eps=w["eps"], jitter=m.JITTER)
+            dlp = np.zeros_like(tp0)                                 # d log-prior / d tp (priors.py is host arithmetic on both sides)
+            slots = [m.R] + [m.spatial_cov.params[nm] for nm in snames]
+            for tc in m.temporal_cov_list:
+                slots += [tc.params["ell"], tc.params["sigma2"]]
+            nat = [hh0["R"]] + list(hh0["ell_s"]) + [v for (_, ell, s2) in hh0["temporal"] for v in (ell, s2)]
+            for i, (sl, v) in enumerate(zip(slots, nat)):
+                dlp[i] = sl["prior"].dlpdf(v) * v
+            sv = np.atleast_1d(hh0["sig2n"])
+            prs = [m.sig2n["prior"]] if n_sig == 1 else list(m.sig2n["prior"])
+            for j, (pr, v) in enumerate(zip(prs, sv)):
+                dlp[len(nat) + j] = pr.dlpdf(v) * v
+            nthreads = min(16, os.cpu_count() or 1)
+            with threadpool_limits(limits=nthreads):
+                O.loglik_and_grad(geom, lfp, tp0, kinds, n_sig, eps=w["eps"], jitter=m.JITTER)          # warm
+                ts = []
+                while len(ts) < 3 or (sum(ts) < 10.0 and len(ts) < 20):
+                    tc0 = time.perf_counter()
+                    ll_cf, g_cf = O.loglik_and_grad(geom, lfp, tp0, kinds, n_sig, eps=w["eps"], jitter=m.JITTER)
+                    ts.append(time.perf_counter() - tc0)
+            g_cf = -(g_cf + dlp)
+            res["parity"]["gradient_worst_component_rel_err_vs_oracle_closed_form"] = float(
+                np.max(np.abs(g_gpu - g_cf) / np.maximum(np.abs(g_cf), 1e-9 * np.max(np.abs(g_cf)))))
+            res["cpu_baseline"] = {"value": 1.0 / float(np.median(ts)), "unit": "evals/s", "cores": nthreads, "kind": "port",
+                                   "blas_threads": nthreads, "host_cpus": os.cpu_count(),
+                                   "sample": "oracle objective + closed-form gradient (O.loglik_and_grad) on the bench's own %d "
+                                             "trials, %d repetitions, median, %d BLAS threads" % (lfp.shape[2], len(ts), nthreads)}
     # the script's next step (fit_gpcsd_baseline.py:103-105): predict at the electrodes -- and at 100 depths -- with the fitted model;
     # here at the hyper-parameters the data were drawn from, results left in HBM, every call fenced (rank-local)
     pred = None
@@ -1458,6 +1563,22 @@ def run_fit_bench(args, w, rank, world, local_rank, backend, compact=False, cpu_
                      "per_kernel_ms_per_step": {k: v["ms"] / 3.0 for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])[:16]}},
     }
     res["config"]["fit_evals_per_sec"], res["config"]["fit_restarts_per_sec"] = fit_main["evals_per_sec"], fit_main["restarts_per_sec"]
+    if by_batch is not None:
+        res["evals_by_lockstep_batch"] = by_batch
+        res["single_eval_ms"] = by_batch["1"]["ms_per_batched_call"]
+        res["fenced_loglik_ms"] = ll_fenced_ms
+        res["single_eval_over_fenced_loglik"] = by_batch["1"]["ms_per_batched_call"] / ll_fenced_ms
+        res["config"].update(single_eval_ms=res["single_eval_ms"], fenced_loglik_ms=ll_fenced_ms,
+                             single_eval_over_fenced_loglik=res["single_eval_over_fenced_loglik"],
+                             batch4_evals_per_sec=by_batch.get("4", {}).get("evals_per_sec"))
+    # HBM traffic per batched step from the committed rocprofv3 --pmc passes over `bench.py --workload <this> --only-value`
+    traffic, traffic_src = pmc_step_traffic(args.workload) if (world == 1 and args.fit_batch is None) else (None, None)
+    res["roofline"]["traffic"] = traffic
+    if traffic_src:
+        res["roofline"]["traffic_source"] = traffic_src
+        # algorithmic bytes of one evaluation: the trials read once; a batch reads them once per set
+        res["roofline"]["algorithmic_bytes_per_step"] = 8.0 * w["nx"] * w["nt"] * w["trials_per_gpu"] * B
+        res["roofline"]["traffic_over_algorithmic"] = traffic / res["roofline"]["algorithmic_bytes_per_step"]
     if pred:
         res.update(pred)
         res["config"].update(pred)

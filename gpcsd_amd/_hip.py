@@ -181,6 +181,7 @@ SIGNATURES = {
     "gpcsd_predict": (_I, [_P, ctypes.POINTER(HParams), _DP, _I, _DP, _I, _I, _DP, _DP, _DP, _DP]),
     "gpcsd_predict_resident": (_I, [_P, ctypes.POINTER(HParams), _DP, _I, _DP, _I, _I, _I]),
     "gpcsd_fetch": (_I, [_P, ctypes.c_char_p, _DP, _L]),
+    "gpcsd_device_buffer": (_I, [_P, ctypes.c_char_p, ctypes.POINTER(ctypes.c_ulonglong), ctypes.POINTER(ctypes.c_ulonglong)]),
     "gpcsd_sample_prior": (_I, [_P, ctypes.POINTER(HParams), _I, _DP, _I, _DP]),
     "gpcsd_set_gram_precision": (_I, [_P, _I]),
     "gpcsd_fold_gemm": (_I, [_P, _I, ctypes.POINTER(_L)]),
@@ -189,6 +190,7 @@ SIGNATURES = {
     "gpcsd_pair_share_s": (_I, [_P, _I, ctypes.POINTER(_L)]),
     "gpcsd_band_tail": (_I, [_P, _I, ctypes.POINTER(_L)]),
     "gpcsd_q_pipeline": (_I, [_P, _I, ctypes.POINTER(_L)]),
+    "gpcsd_q_pipeline_stats": (_I, [_P, ctypes.POINTER(_I), ctypes.POINTER(_L), ctypes.c_longlong]),
     "gpcsd_predict_chunked_copy": (_I, [_P, _I, ctypes.POINTER(_L)]),
     "gpcsd_debug_sybrd": (_I, [_P, _DP, _I, _DP, _DP, _DP]),
     "gpcsd_tail_early_exit": (_I, [_P, _I, ctypes.POINTER(_I)]),
@@ -347,6 +349,33 @@ class PinnedPool:
 
 
 pinned_pool = PinnedPool()
+
+
+class DeviceArray:
+    """A float64 C-contiguous view of library-owned device memory (`__cuda_array_interface__` version 3)."""
+
+    def __init__(self, ptr, shape, owner, name=None):
+        self.ptr, self.shape, self._owner, self.name = int(ptr), tuple(shape), owner, name   # (the context stays alive with the view)
+        self.__cuda_array_interface__ = {"shape": self.shape, "typestr": "<f8", "data": (self.ptr, False), "version": 3,
+                                         "strides": None, "stream": None}
+
+    def __getitem__(self, i):
+        """Sub-array i along the first axis (component i of a `*_list` buffer), still a zero-copy device view."""
+        i = int(i)
+        if not self.shape or not (0 <= i < self.shape[0]):
+            raise IndexError(i)
+        sub = self.shape[1:]
+        return DeviceArray(self.ptr + 8 * i * int(np.prod(sub)), sub, self._owner, None)
+
+    def torch(self, device=None):
+        import torch
+        return torch.as_tensor(self, device=device if device is not None else "cuda")
+
+    def numpy(self):
+        """A host copy (through the library's page-locked pool when the view is a whole named buffer)."""
+        if self.name is not None:
+            return self._owner.fetch(self.name, self.shape)
+        return self.torch().cpu().numpy()
 
 
 class Context:
@@ -803,6 +832,17 @@ class Context:
         self._check(self._lib.gpcsd_fetch(self._h, name.encode(), _ptr(out), out.size))
         return out
 
+    def device_array(self, name, shape):
+        """The named device buffer (what fetch() copies out) as a zero-copy object with `__cuda_array_interface__` (float64, C
+        order): `torch.as_tensor(ctx.device_array("pred_out_csd", (nz, nt, R)), device="cuda")`, cupy.asarray(...).  The context's
+        streams are drained first; the memory belongs to the library and is rewritten by the next call that produces it."""
+        p, nb = ctypes.c_ulonglong(0), ctypes.c_ulonglong(0)
+        self._check(self._lib.gpcsd_device_buffer(self._h, name.encode(), ctypes.byref(p), ctypes.byref(nb)))
+        shape = tuple(int(v) for v in shape)
+        if 8 * int(np.prod(shape)) > nb.value:
+            raise ValueError("device buffer %r holds %d bytes, shape %r needs %d" % (name, nb.value, shape, 8 * int(np.prod(shape))))
+        return DeviceArray(p.value, shape, self, name)
+
     def sample_prior(self, hp, which, normals):
         normals = _arr(np.atleast_3d(normals))
         out = np.empty_like(normals)
@@ -842,7 +882,13 @@ class Context:
         only (eigenvectors shared, spectrum shifted); returns the number of paired calls that took it."""
         n = _L(0)
         self._check(self._lib.gpcsd_pair_share_s(self._h, -1 if on is None else int(bool(on)), ctypes.byref(n)))
+        if on is not None:
+            self._pair_share_s_on = bool(on)
         return int(n.value)
+
+    def pair_share_s_on(self):
+        """The switch as it stands (new contexts: GPCSD_PAIR_SHARE_S, default off)."""
+        return getattr(self, "_pair_share_s_on", os.environ.get("GPCSD_PAIR_SHARE_S", "0")[:1] not in ("", "0"))
 
     def band_tail(self, on=None):
         """Switch (True/False) or query (None) the band form of the temporal side for consumers in the basis U (x) Q (DESIGN 4.11);
@@ -857,6 +903,13 @@ class Context:
         n = _L(0)
         self._check(self._lib.gpcsd_q_pipeline(self._h, -1 if on is None else int(bool(on)), ctypes.byref(n)))
         return int(n.value)
+
+    def q_pipeline_stats(self, gate_ticks=None):
+        """(pipeline on?, evaluations repeated because a gate of the pipelined stage gave up -- a scheduling miss).
+        gate_ticks: the gates' bound in 100 MHz ticks (0: every gate gives up at once, the test aid of the repeat path)."""
+        on, n = _I(0), _L(0)
+        self._check(self._lib.gpcsd_q_pipeline_stats(self._h, ctypes.byref(on), ctypes.byref(n), -1 if gate_ticks is None else int(gate_ticks)))
+        return bool(on.value), int(n.value)
 
     def predict_chunked_copy(self, on=None):
         """Switch (True/False) or query (None) the chunked copy-out of predict()'s host arrays under its last product; returns the

@@ -1084,6 +1084,7 @@ extern "C" int gpcsd_ctx_create(int device, gpcsd_ctx **out) {
         if (const char *ev = getenv("GPCSD_PAIR_SHARE_S")) c->pair_share_s = ev[0] != '0';
         if (const char *ev = getenv("GPCSD_BAND_TAIL")) c->band_tail = ev[0] != '0';
         if (const char *ev = getenv("GPCSD_Q_PIPE")) c->q_pipe = ev[0] != '0';
+        if (const char *ev = getenv("GPCSD_QPIPE_GATE_TICKS")) c->q_gate_ticks = strtoull(ev, nullptr, 10);
         if (const char *ev = getenv("GPCSD_PRED_CHUNKED")) c->pred_chunked = ev[0] != '0';
         // The two chains are the critical path and made of small launches; when they run beside another call's GEMM tail
         // (thousands of workgroups) each of those launches would otherwise queue behind the tiles: high priority.

@@ -210,10 +210,45 @@ static int loglik_parts_impl(gpcsd_ctx *c, const gpcsd_hparams *hp, double *out2
     return finish_call(c, e, out2, 2);
 }
 
+// Status 7 is not a numerical failure: a gate of the pipelined stage 5 (wy.hip: wy_qstage_kernel) gave up waiting for the
+// tridiagonalisation that should have been running beside it -- kernels serialised by a profiler or a debugger, an oversubscribed
+// card, a tail that could not get a CU.  The launch did nothing with the unfinished reflectors, so the evaluation is void, not
+// wrong.  The call that collects it switches the pipeline off for this context (latched: the conditions that made one gate miss
+// make the next one miss), counts it (gpcsd_q_pipeline_stats) and evaluates again: behind the END of the tail queue_stage5_plain
+// forms the same T, Q and X.  `piped`: the call was queued while the pipeline was on.
+static bool q_pipe_missed(gpcsd_ctx *c, int rc, bool piped) {
+    if (rc != 7 || !piped) return false;
+    c->q_pipe = false;
+    ++c->q_pipe_timeouts;
+    drain_after_failure(c);                // (also drops an announced front half: it was queued with the pipeline on)
+    if (int *dst = reinterpret_cast<int *>(c->buf<double>("scal_status", gpcsd_ctx::RESULT_DOUBLES) + gpcsd_ctx::SCAL_N)) {
+        GP_HIP(hipMemsetAsync(dst, 0, gpcsd_ctx::STATUS_N * sizeof(int), c->stream));
+        GP_HIP(hipStreamSynchronize(c->stream));
+        c->status_zeroed = true;
+    }
+    c->last_error.clear();
+    return true;
+}
+
+static void keep_prediction(gpcsd_ctx *c, bool piped, const gpcsd_hparams *hp, const double *z, int nz, const double *tstar, int ntstar,
+                            int type, bool want_lists) {
+    gpcsd_ctx::PredKeep &k = c->last_pred;
+    ++c->pred_seq;
+    k.have = true;
+    k.piped = piped;
+    k.hp.set(hp);
+    k.z.assign(z, z + (size_t)nz * c->dim);
+    k.ts.assign(tstar, tstar + ntstar);
+    k.nz = nz; k.nts = ntstar; k.type = type; k.lists = want_lists;
+}
+
 extern "C" int gpcsd_loglik_parts(gpcsd_ctx *c, const gpcsd_hparams *hp, double *out2) {
     GP_API_BEGIN(c)
     GP_REQUIRE(out2 != nullptr, -3, "null output");
-    return loglik_parts_impl(c, hp, out2, false);
+    const bool piped = c->q_pipe;
+    int rc = loglik_parts_impl(c, hp, out2, false);
+    if (q_pipe_missed(c, rc, piped)) rc = loglik_parts_impl(c, hp, out2, false);
+    return rc;
     GP_API_END(c)
 }
 
@@ -222,9 +257,16 @@ extern "C" int gpcsd_loglik_parts_async(gpcsd_ctx *c, const gpcsd_hparams *hp) {
         return fail(c, HipError{-3, "loglik_parts_async: too many asynchronous evaluations outstanding (collect with "
                                     "gpcsd_loglik_parts_wait)"});
     GP_API_BEGIN(c)
+    gpcsd_ctx::LlSlot &sl = c->ll_slot[(c->ll_head + c->ll_count) % gpcsd_ctx::LL_SLOTS];
+    sl.piped = c->q_pipe;
+    sl.pred_seq = -1;
+    if (hp) sl.hp.set(hp);
     return loglik_parts_impl(c, hp, nullptr, true);
     GP_API_END(c)
 }
+
+static int predict_impl(gpcsd_ctx *c, const gpcsd_hparams *hp, const double *z, int nz, const double *tstar, int ntstar,
+                        int type, bool want_lists, bool async);
 
 extern "C" int gpcsd_loglik_parts_wait(gpcsd_ctx *c, double *out2) {
     if (c && (!out2 || c->ll_count == 0))
@@ -255,6 +297,16 @@ extern "C" int gpcsd_loglik_parts_wait(gpcsd_ctx *c, double *out2) {
         // Now that a failure has been reported: drain everything and clear them, so that evaluations queued from here on
         // start clean.  Evaluations that were ALREADY outstanding copied the words as they stood and report the failure too
         // (a failed wait poisons the ones queued before it returned; documented in gpcsd_hip.h).
+        if (q_pipe_missed(c, bad, sl.piped)) {
+            // a scheduling miss of the pipelined stage 5, not a failure: this evaluation again (unpipelined now), and the paired
+            // prediction with it when it is still the one that owns the resident outputs
+            int rc = loglik_parts_impl(c, &sl.hp.hp, out2, false);
+            if (rc == 0 && sl.pred_seq >= 0 && sl.pred_seq == c->pred_seq && c->last_pred.have) {
+                const gpcsd_ctx::PredKeep &k = c->last_pred;
+                rc = predict_impl(c, &k.hp.hp, k.z.data(), k.nz, k.ts.data(), k.nts, k.type, k.lists, false);
+            }
+            return rc;
+        }
         drain_after_failure(c);
         if (int *dst = reinterpret_cast<int *>(c->buf<double>("scal_status", gpcsd_ctx::RESULT_DOUBLES) + gpcsd_ctx::SCAL_N)) {
             GP_HIP(hipMemsetAsync(dst, 0, gpcsd_ctx::STATUS_N * sizeof(int), c->stream));
@@ -583,7 +635,7 @@ static bool pred_unfold_chunked(gpcsd_ctx *c, PredUnfoldDesc pu, int which0, int
 //   pred_out_csd / pred_out_lfp            (nz, ntstar, R)
 //   pred_out_csd_list / pred_out_lfp_list  (C, nz, ntstar, R)     when want_lists
 static int predict_impl(gpcsd_ctx *c, const gpcsd_hparams *hp, const double *z, int nz, const double *tstar, int ntstar,
-                        int type, bool want_lists, bool async = false) {
+                        int type, bool want_lists, bool async) {
     GP_REQUIRE(z && tstar && nz > 0 && ntstar > 0, -3, "predict: bad arguments");
     GP_REQUIRE(type >= 1 && type <= 3, -3, "predict: type must be CSD(1), LFP(2) or BOTH(3)");
     GP_REQUIRE(c->nt > 0 && ntstar == c->nt, -22,
@@ -932,13 +984,21 @@ static int drain_async(gpcsd_ctx *c) {
     int *st = reinterpret_cast<int *>(c->buf<double>("scal_status", gpcsd_ctx::RESULT_DOUBLES) + gpcsd_ctx::SCAL_N);
     GP_HIP(hipStreamSynchronize(c->stream2));
     GP_HIP(hipStreamSynchronize(c->stream3));
-    return finish_status(c, st, gpcsd_ctx::STATUS_N);          // downloads + synchronises; the words are cleared by the next call's front half
+    int rc = finish_status(c, st, gpcsd_ctx::STATUS_N);        // downloads + synchronises; the words are cleared by the next call's front half
+    if (c->last_pred.have && q_pipe_missed(c, rc, c->last_pred.piped)) {      // (see q_pipe_missed: the queued prediction again)
+        const gpcsd_ctx::PredKeep &k = c->last_pred;
+        rc = predict_impl(c, &k.hp.hp, k.z.data(), k.nz, k.ts.data(), k.nts, k.type, k.lists, false);
+    }
+    return rc;
 }
 
 extern "C" int gpcsd_predict_resident(gpcsd_ctx *c, const gpcsd_hparams *hp, const double *z, int nz, const double *tstar,
                                       int ntstar, int type, int want_lists) {
     GP_API_BEGIN(c)
-    return predict_impl(c, hp, z, nz, tstar, ntstar, type, want_lists != 0, /*async=*/true);
+    const bool piped = c->q_pipe;
+    const int rc = predict_impl(c, hp, z, nz, tstar, ntstar, type, want_lists != 0, /*async=*/true);
+    if (rc == 0) keep_prediction(c, piped, hp, z, nz, tstar, ntstar, type, want_lists != 0);
+    return rc;
     GP_API_END(c)
 }
 
@@ -1072,6 +1132,13 @@ extern "C" int gpcsd_loglik_predict_async(gpcsd_ctx *c, const gpcsd_hparams *hp_
     const bool pair = P.pair;
     const bool fold_s = P.fold_s;
     const SymDev sz = P.sz;
+    {   // what gpcsd_loglik_parts_wait needs to evaluate the pair again (q_pipe_missed)
+        gpcsd_ctx::LlSlot &sl = c->ll_slot[(c->ll_head + c->ll_count) % gpcsd_ctx::LL_SLOTS];
+        sl.piped = c->q_pipe;
+        sl.hp.set(hp_ll);
+        keep_prediction(c, sl.piped, hp_pr, z, nz, tstar, ntstar, type, want_lists != 0);
+        sl.pred_seq = c->pred_seq;
+    }
     if (!pair) {
         const int rc = loglik_parts_impl(c, hp_ll, nullptr, true);
         if (rc != 0) return rc;
@@ -1146,9 +1213,29 @@ extern "C" int gpcsd_fetch(gpcsd_ctx *c, const char *name, double *host, long co
     GP_REQUIRE(it != c->bufs.end() && it->second.p, -2, "fetch: no device buffer named '%s'", name);
     GP_REQUIRE((size_t)count * sizeof(double) <= it->second.bytes, -3, "fetch: '%s' holds %zu bytes, asked for %ld doubles", name,
                it->second.bytes, count);
+    // a numerical failure of a preceding asynchronous predict surfaces here -- collected BEFORE the copy: a prediction whose
+    // pipelined stage missed its tail is evaluated again by drain_async (q_pipe_missed), and the caller gets that result
+    const int rc = drain_async(c);
     c->download(host, it->second.p, (size_t)count * sizeof(double));
     c->sync();
-    return drain_async(c);                // a numerical failure of a preceding asynchronous predict surfaces here
+    return rc;
+    GP_API_END(c)
+}
+
+// The device address of a named result buffer (what gpcsd_fetch copies from), for callers that keep working on the GPU: a
+// prediction left in HBM by gpcsd_predict_resident gathered over ranks with RCCL, handed to another library through
+// __cuda_array_interface__ / DLPack.  Collects a queued prediction's deferred status first (as gpcsd_fetch does) and drains the
+// context's streams: the buffer is complete when the call returns, and stays valid until the next call that writes it.
+extern "C" int gpcsd_device_buffer(gpcsd_ctx *c, const char *name, unsigned long long *dev_ptr, unsigned long long *bytes) {
+    GP_API_BEGIN(c)
+    GP_REQUIRE(name && dev_ptr && bytes, -3, "device_buffer: bad arguments");
+    auto it = c->bufs.find(name);
+    GP_REQUIRE(it != c->bufs.end() && it->second.p, -2, "device_buffer: no device buffer named '%s'", name);
+    const int rc = drain_async(c);
+    c->sync();
+    *dev_ptr = (unsigned long long)(uintptr_t)it->second.p;
+    *bytes = (unsigned long long)it->second.bytes;
+    return rc;
     GP_API_END(c)
 }
 
@@ -1163,7 +1250,15 @@ extern "C" int gpcsd_predict(gpcsd_ctx *c, const gpcsd_hparams *hp, const double
     sk.sum[0] = csd; sk.list[0] = csd_list; sk.sum[1] = lfp; sk.list[1] = lfp_list;
     int rc;
     try {
-        rc = predict_impl(c, hp, z, nz, tstar, ntstar, type, want_lists);
+        const bool piped = c->q_pipe;
+        rc = predict_impl(c, hp, z, nz, tstar, ntstar, type, want_lists, false);
+        if (q_pipe_missed(c, rc, piped)) {         // (a scheduling miss of the pipelined stage 5: again, unpipelined)
+            (void)hipStreamSynchronize(c->stream4);
+            for (hipEvent_t ev : c->pred_sink_events) c->event_pool.push_back(ev);
+            c->pred_sink_events.clear();
+            sk.done[0] = sk.done[1] = false;
+            rc = predict_impl(c, hp, z, nz, tstar, ntstar, type, want_lists, false);
+        }
     } catch (...) {
         sk.active = false;
         (void)hipStreamSynchronize(c->stream4);

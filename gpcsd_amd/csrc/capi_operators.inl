@@ -645,6 +645,15 @@ extern "C" int gpcsd_q_pipeline(gpcsd_ctx *c, int on, long *calls) {
     GP_API_END(c)
 }
 
+extern "C" int gpcsd_q_pipeline_stats(gpcsd_ctx *c, int *on, long *timeouts, long long gate_ticks) {
+    GP_API_BEGIN(c)
+    if (gate_ticks >= 0) c->q_gate_ticks = (unsigned long long)gate_ticks;
+    if (on) *on = c->q_pipe ? 1 : 0;
+    if (timeouts) *timeouts = c->q_pipe_timeouts;
+    return 0;
+    GP_API_END(c)
+}
+
 extern "C" int gpcsd_fold_gemm(gpcsd_ctx *c, int on, long *calls) {
     GP_API_BEGIN(c)
     if (on >= 0) c->fold_gemm_on = on != 0;

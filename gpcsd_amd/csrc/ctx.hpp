@@ -97,12 +97,38 @@ struct gpcsd_ctx {
     // h_result) behind that slot's event; up to LL_SLOTS evaluations may be outstanding, gpcsd_loglik_parts_wait collects
     // them oldest first.  two: the quadratic form came back as two partial sums; done: evaluated at once (profiling on).
     static constexpr int LL_SLOTS = 4;
+    // A queued call's arguments, kept until its result has been collected: a call whose pipelined stage 5 missed its
+    // tridiagonalisation (status 7: a scheduling miss, not a numerical failure -- wy.hip, q_pipe_timeouts below) is evaluated
+    // again, unpipelined, by the call that collects it.
+    struct HpKeep {
+        gpcsd_hparams hp{};
+        std::vector<double> sig;
+        void set(const gpcsd_hparams *h) {
+            hp = *h;
+            sig.assign(h->sig2n, h->sig2n + (h->n_sig2n > 0 ? h->n_sig2n : 0));
+            hp.sig2n = sig.data();
+        }
+    };
+    struct PredKeep {
+        bool have = false, piped = false, lists = false;
+        HpKeep hp;
+        std::vector<double> z, ts;
+        int nz = 0, nts = 0, type = 0;
+    };
     struct LlSlot {
         hipEvent_t ev = nullptr;
         bool two = false, done = false;
         double out[2] = {0.0, 0.0};
         int rc = 0;
+        bool piped = false;                 // queued while the Q pipeline was on: status 7 means "run me again"
+        HpKeep hp;
+        long pred_seq = -1;                 // the paired call's prediction (pred_seq at the time), -1: a log-likelihood alone
     };
+    long pred_seq = 0;                      // predictions queued so far: only the LAST one owns the resident outputs
+    PredKeep last_pred;
+    long q_pipe_timeouts = 0;               // calls evaluated again because a gate of the pipelined stage 5 gave up
+    unsigned long long q_gate_ticks = 20000000ull;   // a gate's patience in 100 MHz ticks (0.2 s; a tail takes < 1 ms).
+                                            // GPCSD_QPIPE_GATE_TICKS=0: test aid, every gate gives up at once
     double *h_ll = nullptr;                 // LL_SLOTS x RESULT_DOUBLES
     LlSlot ll_slot[LL_SLOTS];
     int ll_head = 0, ll_count = 0;          // oldest outstanding slot, number outstanding

@@ -293,7 +293,9 @@ struct WyBatch {
     WyProb p[MAX_EIG_BATCH];         // one entry per class
     int start[MAX_EIG_BATCH + 1];    // prefix sums of the replica counts (see class_of)
     unsigned long long *clk = nullptr;   // measurement aid (GPCSD_WY_CLK=1): wall-clock stamps of workgroup (0, 0) at its phase boundaries
-    int *status = nullptr;               // stage 5 (wy_q_pipeline): a gate whose time ran out reports failure 7 here
+    int *status = nullptr;               // stage 5 (wy_q_pipeline): a gate whose time ran out reports 7 here (a scheduling miss: the
+                                         // collecting call evaluates again, unpipelined -- gpcsd_ctx::q_pipe_timeouts)
+    unsigned long long gate_ticks = 20000000ull;   // the gate's patience, 100 MHz ticks; 0: give up at once (test aid)
 };
 __device__ __forceinline__ WyProb wy_resolve(const WyBatch &b, int g) {
     int cls, rep;

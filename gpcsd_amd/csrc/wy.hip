@@ -211,7 +211,7 @@ __global__ __launch_bounds__(WY_NT) void wy_apply_kernel(WyBatch b) {
 // on a running kernel of another.  The wait is bounded; when the time is up the launch reports failure 7 and goes on.
 // ------------------------------------------------------------------------------------------------------------------
 constexpr unsigned WY_PROG_DONE = 0x7fffffffu;        // = RT_PROG_DONE
-constexpr unsigned long long WY_GATE_TICKS = 20000000ull;   // 0.2 s of the 100 MHz wall clock: a tail takes < 1 ms
+// (the gate's patience travels in WyBatch::gate_ticks: 0.2 s of the 100 MHz wall clock by default -- a tail takes < 1 ms)
 
 // One launch per panel, FOUR waves per workgroup and ~75 KB of LDS: the launches run beside the previous call's large products,
 // under which a CU never drains -- a workgroup that needs a whole CU (the back-transformation's 1024 threads, the preparation
@@ -254,27 +254,33 @@ __global__ __launch_bounds__(WQ_NT) void wy_qstage_kernel(WyBatch b, int p0, int
         ++nst;
     };
     // ---- gate
+    __shared__ bool gate_failed;
     if (tid == 0) {
         const unsigned target = (p + 1 < P.npanels) ? (unsigned)(WY_NB * (p + 1)) : WY_PROG_DONE;
         const unsigned *prog = reinterpret_cast<const unsigned *>(P.tau + n + WY_NB);
         const unsigned long long t0 = wall_clock64();
         const bool stamping = b.clk && blockIdx.x == 0;
         if (stamping) b.clk[3 * (p * 4 + blockIdx.y)] = t0;              // (GPCSD_QPIPE_CLK=1: when the gate started, passed, and the tail's start)
-        bool ok = true;
-        while (__hip_atomic_load(prog, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target) {
-            if (wall_clock64() - t0 > WY_GATE_TICKS) {
+        bool ok = b.gate_ticks != 0;                                     // (0: the test aid -- every gate gives up at once)
+        while (ok && __hip_atomic_load(prog, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            if (wall_clock64() - t0 > b.gate_ticks) {
                 ok = false;
                 break;
             }
             __builtin_amdgcn_s_sleep(2);
         }
+        // The tail is not running beside this launch (kernels serialised by a profiler or a debugger, an oversubscribed card): not a
+        // numerical failure.  Report 7 and do NOTHING with the unfinished reflectors; the call that collects this evaluation runs
+        // it again behind the end of the tail (capi_fused.inl: q_pipe_missed).
         if (!ok && b.status) atomicMax(b.status, 7);
+        gate_failed = !ok;
         if (stamping) {
             b.clk[3 * (p * 4 + blockIdx.y) + 1] = wall_clock64();
             b.clk[3 * (p * 4 + blockIdx.y) + 2] = *reinterpret_cast<const unsigned long long *>(P.tau + n + WY_NB + 1);
         }
     }
     __syncthreads();
+    if (gate_failed) return;                              // (LDS flag, uniform over the workgroup)
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");    // every wave reads the panel the tail's workgroup has just released
     __builtin_amdgcn_s_setprio(3);                        // (on the log-likelihood's critical path, beside a flood of GEMM tiles)
     stamp();
@@ -559,12 +565,15 @@ void wy_q_pipeline(gpcsd_ctx *c, const WyBatch &b, int nclass, hipStream_t s,
     const int count = b.start[MAX_EIG_BATCH];
     const size_t sh = wq_lds_bytes(nmax);
     GP_REQUIRE(sh <= 160 * 1024, -3, "wy_q_pipeline: %d rows do not fit the stage kernel", nmax);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static bool attr_set[64] = {};                 // per device: a function attribute belongs to the device's code object
+    if (!attr_set[c->device & 63]) {
         GP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(wy_qstage_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
+        attr_set[c->device & 63] = true;
     }
     WyBatch bc = b;
+    // behind the END of the tail (one_launch) a gate finds its word at "done" whatever its patience; beside a running tail it is
+    // gpcsd_ctx::q_gate_ticks (GPCSD_QPIPE_GATE_TICKS=0: every gate gives up -- tests/test_q_pipeline.py drives the replay with it)
+    bc.gate_ticks = one_launch ? 20000000ull : c->q_gate_ticks;
     static const bool gate_clk = getenv("GPCSD_QPIPE_CLK") && getenv("GPCSD_QPIPE_CLK")[0] == '1';
     if (gate_clk) bc.clk = c->buf<unsigned long long>("wy_clk", 64);        // (tools/qpipe_probe.py reads it)
     if (one_launch) {                      // unpipelined (behind the tail): every panel in one launch, nothing hangs on the panels

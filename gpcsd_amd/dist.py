@@ -12,7 +12,7 @@ import numpy as np
 class TrialSharding:
     STAGING_RING = 4            # outstanding asynchronous all-reduces of one message size before the oldest is waited for
 
-    def __init__(self, group=None, gather_predictions=False, device=None):
+    def __init__(self, group=None, gather_predictions=False, device=None, gather_dst=None):
         import torch
         import torch.distributed as td
         if not td.is_initialized():
@@ -21,6 +21,7 @@ class TrialSharding:
         self.rank = td.get_rank(group)
         self.world_size = td.get_world_size(group)
         self.gather_predictions = gather_predictions
+        self.gather_dst = gather_dst            # rank that receives gathered predictions on the host (None: every rank)
         backend = td.get_backend(group)
         if device is None:
             device = ("cuda:%d" % torch.cuda.current_device()) if backend == "nccl" else "cpu"
@@ -113,6 +114,40 @@ class TrialSharding:
         self._td.all_gather(outs, t, group=self._group)
         parts = [np.moveaxis(o.cpu().numpy(), 0, -1)[..., :c] for o, c in zip(outs, counts)]
         return np.concatenate(parts, axis=-1)
+
+    def on_device(self):
+        """True when the collectives run on device tensors (backend nccl = RCCL over xGMI)."""
+        return self._device.type == "cuda"
+
+    d2h_bytes = 0               # bytes gather_trials_device has copied to the host on this rank (tests read it)
+
+    def gather_trials_device(self, dev_local, dst=None):
+        """All-gather a DEVICE array whose last axis is this rank's trial block -- a prediction left in HBM by
+        gpcsd_predict_resident, as the zero-copy view Context.device_array() returns -- over the ranks ON THE DEVICE (one RCCL
+        all-gather over xGMI: 230 MB per rank at 384 x 500 x 50 trials), reorder it to (..., all trials) there, and
+        copy it out ONCE, into a page-locked array, on rank `dst` only (on every rank when dst is None).  Other ranks get None.
+        No host staging: the only device-to-host traffic is the gathered result on the gathering rank(s)."""
+        torch, td = self._torch, self._td
+        from . import _hip
+        x = torch.as_tensor(dev_local, device=self._device)
+        counts = self.allreduce_sum(np.eye(self.world_size)[self.rank] * x.shape[-1]).astype(int)
+        rmax = int(counts.max())
+        xin = x.movedim(-1, 0)                                  # (local trials, ...): the trial blocks concatenate along axis 0
+        if x.shape[-1] < rmax:
+            xin = torch.cat([xin, xin.new_zeros((rmax - x.shape[-1],) + tuple(xin.shape[1:]))], dim=0)
+        xin = xin.contiguous()
+        out = torch.empty((self.world_size * rmax,) + tuple(xin.shape[1:]), dtype=xin.dtype, device=self._device)
+        td.all_gather_into_tensor(out, xin, group=self._group)
+        if dst is not None and self.rank != dst:
+            return None
+        if int(counts.min()) < rmax:                            # ragged blocks: drop the padding rows
+            keep = torch.cat([torch.arange(r * rmax, r * rmax + int(c), device=self._device) for r, c in enumerate(counts)])
+            out = out.index_select(0, keep)
+        full = out.movedim(0, -1).contiguous()                  # (..., all trials), the reference's layout
+        host = _hip.pinned_pool.empty(tuple(full.shape))
+        torch.from_numpy(host).copy_(full)                      # the one device-to-host copy (synchronous)
+        self.d2h_bytes += host.nbytes
+        return host
 
     def barrier(self):
         self._td.barrier(group=self._group)

@@ -691,8 +691,35 @@ class GPCSDModel:
         return None
 
     # ------------------------------------------------------------------ prediction
-    def predict(self, z, t, type="csd"):
-        """Posterior mean of CSD and/or LFP at sites z and times t for every (local) trial."""
+    _PRED_BUFFERS = (("csd", _hip.PRED_CSD, "pred_out_csd"), ("lfp", _hip.PRED_LFP, "pred_out_lfp"))
+
+    def _device_predictions(self, ctx, code, nz, nt, R_local):
+        """Zero-copy views (`_hip.DeviceArray`) of the posterior means a resident prediction left in HBM."""
+        C = len(self.temporal_cov_list)
+        res = {}
+        for name, bit, buf in self._PRED_BUFFERS:
+            if code & bit:
+                res[name] = ctx.device_array(buf, (nz, nt, R_local))
+                res[name + "_list"] = ctx.device_array(buf + "_list", (C, nz, nt, R_local))
+        return res
+
+    def _store_predictions(self, res, z, t):
+        if res.get("csd") is not None:
+            self.csd_pred_list = [res["csd_list"][i] for i in range(res["csd_list"].shape[0])]
+            self.csd_pred = res["csd"]
+        if res.get("lfp") is not None:
+            self.lfp_pred_list = [res["lfp_list"][i] for i in range(res["lfp_list"].shape[0])]
+            self.lfp_pred = res["lfp"]
+        self.t_pred = t
+        self.x_pred = z
+
+    def predict(self, z, t, type="csd", resident=False):
+        """Posterior mean of CSD and/or LFP at sites z and times t for every (local) trial (gpcsd1d.py:248-293 / gpcsd2d.py:289-334).
+
+        resident=True (no reference counterpart) leaves the results in HBM: `csd_pred` / `lfp_pred` are then zero-copy device views
+        (`__cuda_array_interface__`, float64, (nz, nt, ntrials); the `*_list` attributes (C, nz, nt, ntrials)) instead of NumPy
+        arrays -- `torch.as_tensor(m.csd_pred, device="cuda")` -- valid until the model's next prediction.  Returning host arrays
+        is bound by the PCIe link (231 MB per call at 384 x 500 x 50), the resident form by the GPU."""
         if type not in ("csd", "lfp", "both"):
             raise ValueError("type must be 'csd', 'lfp' or 'both'")
         ctx = self._sync_device()
@@ -702,18 +729,74 @@ class GPCSDModel:
         hp, _keep = self._hparams(0.0, tstar=t)            # no jitter in predict
         code = {"csd": _hip.PRED_CSD, "lfp": _hip.PRED_LFP, "both": _hip.PRED_BOTH}[type]
         R_local = self._local_lfp().shape[2]
-        res = ctx.predict(hp, z2, t, code, (z2.shape[0], t.shape[0], R_local))
         sh = getattr(self, "_sharding", None)
-        if sh is not None and getattr(sh, "gather_predictions", False):
-            res = {k: sh.gather_trials(v) for k, v in res.items()}
-        if "csd" in res:
-            self.csd_pred_list = [res["csd_list"][i] for i in range(res["csd_list"].shape[0])]
-            self.csd_pred = res["csd"]
-        if "lfp" in res:
-            self.lfp_pred_list = [res["lfp_list"][i] for i in range(res["lfp_list"].shape[0])]
-            self.lfp_pred = res["lfp"]
-        self.t_pred = t
-        self.x_pred = z
+        gather = sh is not None and getattr(sh, "gather_predictions", False)
+        if resident or (gather and sh.on_device()):
+            ctx.predict_resident(hp, z2, t, code, want_lists=True)
+            res = self._device_predictions(ctx, code, z2.shape[0], t.shape[0], R_local)
+            if gather:
+                # trial blocks gathered ON THE DEVICE (RCCL all-gather over xGMI), one copy out on the gathering rank(s) only
+                res = {k: sh.gather_trials_device(v, dst=getattr(sh, "gather_dst", None)) for k, v in res.items()}
+        else:
+            res = ctx.predict(hp, z2, t, code, (z2.shape[0], t.shape[0], R_local))
+            if gather:
+                res = {k: sh.gather_trials(v) for k, v in res.items()}
+        self._store_predictions(res, z, t)
+
+    def loglik_predict_many(self, param_sets, z, t, type="csd", resident=False, share_spatial=False):
+        """loglik() and predict(z, t, type) under each of a LIST of hyper-parameter sets -- dicts as extract_model_params() returns
+        them: the optima of every restart of a fit, a grid, posterior draws -- in order.  Returns the log-likelihoods, one per set;
+        the prediction attributes hold the LAST set's posterior means as after predict() (resident=True: left in HBM, see
+        predict), and the model's hyper-parameters are left at the last set.
+
+        No reference counterpart as ONE call: the reference's callers loop restore_model_params -> loglik -> predict
+        (neuropixels/fit_gpcsd2d.py:93-107).  Because the sets are known up front, every set's evaluation is queued as one paired
+        call (its four eigenproblems share launches two by two) that ANNOUNCES the next set (gpcsd_prefetch_pair): the next set's
+        decomposition chains run under this set's products instead of behind the host's collection of its value.
+        share_spatial=True additionally decomposes ONE spatial matrix per set where both calls have the same spatial
+        hyper-parameters (Ks + jitter I and Ks share eigenvectors; results then differ from the fenced calls in the last bits)."""
+        if type not in ("csd", "lfp", "both"):
+            raise ValueError("type must be 'csd', 'lfp' or 'both'")
+        param_sets = list(param_sets)
+        if not param_sets:
+            return np.zeros(0)
+        ctx = self._sync_device()
+        z = np.asarray(z, dtype=np.float64)
+        z2 = np.ascontiguousarray(z.reshape(-1, 1) if self.dim == 1 else z)
+        t = np.asarray(t)
+        code = {"csd": _hip.PRED_CSD, "lfp": _hip.PRED_LFP, "both": _hip.PRED_BOTH}[type]
+        sets = []
+        for p in param_sets:                               # every set's two hyper-parameter structs, before anything is queued
+            self.restore_model_params(p)
+            sets.append((self._hparams(self.JITTER), self._hparams(0.0, tstar=t)))
+        R_local = self._local_lfp().shape[2]
+        ntrials = np.shape(self.lfp)[2]
+        sh = getattr(self, "_sharding", None)
+        was = ctx.pair_share_s_on()
+        ctx.pair_share_s(bool(share_spatial))
+        out = np.empty(len(sets))
+        try:
+            for k, ((hp, _k1), (hp0, _k0)) in enumerate(sets):
+                ctx.loglik_predict_async(hp, hp0, z2, t, code, want_lists=True)
+                if k + 1 < len(sets):
+                    (hn, _a), (hn0, _b) = sets[k + 1]
+                    ctx.prefetch_pair(hn, hn0, z2, t)
+                sumlog, quad = ctx.loglik_parts_wait()
+                if sh is not None:
+                    quad = float(sh.allreduce_sum(np.array([quad]))[0])
+                out[k] = -0.5 * ntrials * sumlog - 0.5 * quad
+        finally:
+            ctx.pair_share_s(was)
+        res = self._device_predictions(ctx, code, z2.shape[0], t.shape[0], R_local)
+        gather = sh is not None and getattr(sh, "gather_predictions", False)
+        if gather and sh.on_device():
+            res = {k: sh.gather_trials_device(v, dst=getattr(sh, "gather_dst", None)) for k, v in res.items()}
+        elif not resident or gather:
+            res = {k: ctx.fetch(v.name, v.shape) for k, v in res.items()}
+            if gather:
+                res = {k: sh.gather_trials(v) for k, v in res.items()}
+        self._store_predictions(res, z, t)
+        return out
 
     def _sample_prior_from_normals(self, normals, which):
         """Ls Z_r Lt^T on the GPU for host-supplied standard normals (nx, nt, ntrials)."""

@@ -269,6 +269,13 @@ int gpcsd_predict_resident(gpcsd_ctx *ctx, const gpcsd_hparams *hp, const double
 /* copy `count` doubles of the named ctx-owned device buffer to host; rc -2 if the name is unknown; rc > 0 if the
  * asynchronous gpcsd_predict_resident that produced the buffer failed numerically */
 int gpcsd_fetch(gpcsd_ctx *ctx, const char *name, double *host, long count);
+/* The device address and size in bytes of the same named buffer, for callers that go on working on the GPU instead of copying out:
+ * the posterior means gpcsd_predict_resident leaves in HBM ("pred_out_csd", "pred_out_csd_list", "pred_out_lfp",
+ * "pred_out_lfp_list": gpcsd1d.py:286-293 / gpcsd2d.py:327-334, layout (nz, nt, ntrials) / (C, nz, nt, ntrials)) gathered over the
+ * ranks of a trial-sharded job by an RCCL all-gather (gpcsd_amd/dist.py), or handed to another library (__cuda_array_interface__,
+ * DLPack).  Collects a queued prediction's deferred status (rc > 0 as gpcsd_fetch) and drains the context's streams first: the
+ * buffer is complete on return and stays valid until the next call that writes it; the library keeps ownership. */
+int gpcsd_device_buffer(gpcsd_ctx *ctx, const char *name, unsigned long long *dev_ptr, unsigned long long *bytes);
 /* sample_prior with host-supplied standard normals (nx, nt, ntrials): Ls Z_r Lt^T
  * gpcsd1d.py:295-309 / gpcsd2d.py:336-360.  which: GPCSD_PRED_CSD (compute_Ks) or GPCSD_PRED_LFP (compKphi) */
 int gpcsd_sample_prior(gpcsd_ctx *ctx, const gpcsd_hparams *hp, int which,
@@ -342,10 +349,19 @@ int gpcsd_band_tail(gpcsd_ctx *ctx, int on, long *calls);
  * and the matching 64 columns of X follow on another stream while the reduction is still at work on the next panel; behind it only
  * the last panel's share is left.  Same reflectors, same T factors; Q and X agree with the unpipelined form to rounding (the products
  * are summed in another order).  Applies to temporal blocks of at most 256 rows after symmetry folding.
- * on = 1 / 0 switches it (default 1; GPCSD_Q_PIPE=0 for new contexts -- needed under a profiler that serialises kernels, where a
- * launch that waits for a running one cannot make progress: the wait is bounded and then reports failure 7), < 0 only queries;
+ * on = 1 / 0 switches it (default 1; GPCSD_Q_PIPE=0 for new contexts -- cheaper under a profiler that serialises kernels, where a
+ * launch that waits for a running one cannot make progress: gpcsd_q_pipeline_stats below), < 0 only queries;
  * *calls counts the temporal chains that took it. */
 int gpcsd_q_pipeline(gpcsd_ctx *ctx, int on, long *calls);
+/* The one place where a launch waits for a RUNNING kernel of another stream is bounded (0.2 s).  A wait that runs out is a
+ * scheduling miss, not a numerical failure (kernels serialised by a profiler or a debugger, an oversubscribed card): the launch
+ * leaves the unfinished reflectors alone, and the call that collects the evaluation -- the synchronous call itself,
+ * gpcsd_loglik_parts_wait, or whichever call next synchronises behind a gpcsd_predict_resident -- switches the pipeline off for
+ * the context (latched), evaluates again behind the end of the reduction (same T, Q, X as with on = 0) and returns that result.
+ * *on: the switch as it stands; *timeouts: evaluations repeated for this reason; gate_ticks >= 0 sets the bound in 100 MHz ticks
+ * (0: every wait gives up at once -- the test aid that drives the repeat path; GPCSD_QPIPE_GATE_TICKS for new contexts), < 0
+ * leaves it.  No reference counterpart (utility_functions.py:58-59 is one LAPACK call). */
+int gpcsd_q_pipeline_stats(gpcsd_ctx *ctx, int *on, long *timeouts, long long gate_ticks);
 /* gpcsd_predict with host outputs (what the class API's predict() returns, gpcsd1d.py:286-293 / gpcsd2d.py:327-334): the last
  * product of a folded prediction is launched in chunks of prediction sites and every chunk's finished output rows are copied to
  * the caller's arrays while the next chunk computes (231 MB per call at 384 x 500 x 50: the copy is 4 of the call's 5 ms and no

@@ -554,6 +554,98 @@ def loglik_grad_fd(geom, lfp, tp, kinds, n_sig, eps=0.0, jitter=0.0, h=1e-6):
     return g
 
 
+def loglik_and_grad(geom, lfp, tp, kinds, n_sig, eps=0.0, jitter=0.0, R_fixed=None):
+    """loglik and its gradient w.r.t. the log-parameter vector of fit() (gpcsd1d.py:161-174 / gpcsd2d.py:196-211) in closed
+    form: what reverse mode through the reference's own forward pass yields (gpcsd1d.py:211 `jac=grad(obj_fun)`: matmuls,
+    elementwise kernels and the eigh VJP  Kbar = Q (diag(wbar) + (Q^T Qbar) o F) Q^T, F_xy = 1 / (w_y - w_x)), simplified by hand.
+    No executable reference gradient exists here (autograd is not installed); this restatement is pinned by central
+    differences of `loglik` -- itself pinned by the reference's outputs -- in tests/test_oracle_golden.py.
+
+    With B_r = alpha_r / D, alpha_r = Qs^T Y_r Qt, D_xi = es_x et_i + s2_x (s2 indexed by EIGEN-index x, utility_functions.py:54-63):
+      dL/dD = -R/2 / D + 1/2 sum_r B_r^2;   dL/ds2_x = sum_i dL/dD_xi;
+      Ghat_s[x,y] = 1/2 sum_{r,i} B[x,i] et_i B[y,i] - R/2 delta_xy sum_i et_i / D_xi
+                    - 1/2 (s2_x - s2_y) / (es_y - es_x) sum_{r,i} B[x,i] B[y,i]      (x != y; zero for a scalar s2),
+      Ghat_t[i,j] = 1/2 sum_{r,x} B[x,i] es_x B[x,j] - R/2 delta_ij sum_x es_x / D_xi;   Gs = Qs Ghat_s Qs^T, Gt = Qt Ghat_t Qt^T;
+      dL/dtheta_t = <Gt, dKt/dtheta>,  dL/dell_s = <A^T Gs A, dKgl/dell>,  dL/dR = 2 <Gs A Kgl, dA/dR>.
+    Returns (loglik, gradient): d loglik / d tp_k = natural derivative x natural value (every parameter is an exponential of
+    its tp entry); the R entry is 0 when R_fixed is given (gpcsd1d.py:161-162)."""
+    tp = np.asarray(tp, dtype=np.float64)
+    hp = hparams_from_tparams(tp, geom.dim, kinds, n_sig, eps=eps, jitter=jitter, R_fixed=R_fixed)
+    lfp = np.atleast_3d(lfp)
+    nx, nt, R = lfp.shape
+    Rv, ell_s = hp["R"], hp["ell_s"]
+    if geom.dim == 1:
+        A = fwd_weights_1d(geom.x, geom.gl_x, geom.gl_w, Rv)
+        dx = geom.gl_x[:, None] - geom.gl_x[None, :]
+        Kgl = np.exp(-0.5 * np.square(dx / ell_s[0]))
+        dKgl = [Kgl * np.square(dx) / ell_s[0] ** 3]
+        r = geom.gl_x[None, :] - geom.x
+        q = np.square(r / Rv)
+        dA = geom.gl_w[None, :] * (np.sqrt(q) - q / np.sqrt(q + 1.0)) / Rv
+    else:
+        A = fwd_weights_2d(geom.x, geom.gl_x1, geom.gl_w1, geom.gl_x2, geom.gl_w2, Rv, hp["eps"])
+        g = expand_grid(geom.gl_x1, geom.gl_x2)
+        s1 = np.square(g[:, 0][:, None] - g[:, 0][None, :])
+        s2 = np.square(g[:, 1][:, None] - g[:, 1][None, :])
+        Kgl = np.exp(-0.5 * s1 / ell_s[0] ** 2) * np.exp(-0.5 * s2 / ell_s[1] ** 2)
+        dKgl = [Kgl * s1 / ell_s[0] ** 3, Kgl * s2 / ell_s[1] ** 3]
+        wprod = np.prod(expand_grid(geom.gl_w1, geom.gl_w2), axis=1)
+        w2 = np.square(g[:, 0][None, :] - geom.x[:, 0][:, None]) + np.square(g[:, 1][None, :] - geom.x[:, 1][:, None])
+        dA = wprod[None, :] / np.sqrt((Rv + hp["eps"]) ** 2 + w2)
+    T = A @ Kgl
+    Ks = T @ A.T + hp["jitter"] * np.eye(nx)
+    Kt = temporal_sum(hp["temporal"], geom.t)
+    et, Qt = _eigh(Kt)                                    # eig_D (utility_functions.py:44-64) with the spectra kept
+    es, Qs = _eigh(Ks)
+    D = es[:, None] * et[None, :] + (np.asarray(hp["sig2n"], dtype=np.float64)[:, None] if n_sig > 1 else float(hp["sig2n"]))
+    Y = np.ascontiguousarray(np.moveaxis(lfp, 2, 0))
+    alpha = np.matmul(np.matmul(Qs.T, Y), Qt)
+    Bm = alpha / D[None]
+    ll = float(-0.5 * R * np.sum(np.log(D)) - 0.5 * np.sum(alpha * Bm))
+    P = -0.5 * R / D + 0.5 * np.sum(np.square(Bm), axis=0)
+    BmT = np.transpose(Bm, (0, 2, 1))
+    Ghs = 0.5 * np.sum(np.matmul(Bm * et[None, None, :], BmT), axis=0) - 0.5 * R * np.diag(np.sum(et[None, :] / D, axis=1))
+    Ght = 0.5 * np.sum(np.matmul(BmT, Bm * es[None, :, None]), axis=0) - 0.5 * R * np.diag(np.sum(es[:, None] / D, axis=0))
+    if n_sig > 1:
+        sv = np.asarray(hp["sig2n"], dtype=np.float64)
+        S = np.sum(np.matmul(Bm, BmT), axis=0)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            F = (sv[:, None] - sv[None, :]) / (es[None, :] - es[:, None])
+        F[np.arange(nx), np.arange(nx)] = 0.0
+        Ghs = Ghs - 0.5 * F * S
+        dsig = np.sum(P, axis=1)
+    else:
+        dsig = np.array([np.sum(P)])
+    Gs = Qs @ Ghs @ Qs.T
+    Gt = Qt @ Ght @ Qt.T
+    grad = np.zeros_like(tp)
+    grad[0] = 0.0 if R_fixed is not None else 2.0 * np.sum((Gs @ T) * dA) * Rv
+    M = A.T @ (Gs @ A)
+    for k in range(geom.dim):
+        grad[1 + k] = np.sum(M * dKgl[k]) * ell_s[k]
+    p = 1 + geom.dim
+    tt = geom.t.reshape(-1, 1)
+    d = tt - tt.T
+    for kind, ell, sigma2 in hp["temporal"]:
+        Kc = temporal_gram(kind, tt, tt, ell, sigma2)
+        dK_dell = Kc * np.square(d) / ell ** 3 if kind == SE else Kc * np.abs(d) / ell ** 2
+        grad[p] = np.sum(Gt * dK_dell) * ell
+        grad[p + 1] = np.sum(Gt * Kc)                     # dK/dsigma2 * sigma2 = K_c
+        p += 2
+    grad[p:p + n_sig] = dsig * np.atleast_1d(hp["sig2n"])
+    return ll, grad
+
+
+def invgamma_dlpdf(x, alpha, beta):
+    """d/dx of invgamma_lpdf."""
+    return -(alpha + 1.0) / x + beta / (x * x)
+
+
+def halfnormal_dlpdf(x, sd):
+    """d/dx of halfnormal_lpdf."""
+    return -x / (sd * sd)
+
+
 # --------------------------------------------------------------------------------------
 # downstream per-trial consumer of (Qs, Qt, Dvec) (SURVEY section 8f row N4)
 # --------------------------------------------------------------------------------------

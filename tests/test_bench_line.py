@@ -112,8 +112,8 @@ def test_sub_results_run_as_child_commands_and_a_failed_one_leaves_nulls(monkeyp
     monkeypatch.setattr(subprocess, "run", fake_run)
     monkeypatch.delenv("GPCSD_BENCH_SUB_INPROC", raising=False)
     sub = bench.sub_results(types.SimpleNamespace(), 0, "nccl", [])
-    assert [c[c.index("--sub-result") + 1] for c in calls] == ["cfg2", "cfg5", "npx69", "aud24", "potrf"]
+    assert [c[c.index("--sub-result") + 1] for c in calls] == ["cfg2", "cfg3fit", "cfg5", "npx69", "aud24", "potrf"]
     assert sub["cfg2"]["value"] == 123.0 and "error" in sub["cfg5"] and "child process" in sub["measured_in"]
     h = bench.sub_headlines(sub)
     assert h["cfg2_ms_per_step"] == 0.5 and h["cfg5_evals_per_sec"] is None and h["potrf_frac"] == 0.4
-    assert set(bench.SUB_RESULT_KEYS) == {"cfg2", "cfg5", "npx69", "aud24", "potrf"}
+    assert set(bench.SUB_RESULT_KEYS) == {"cfg2", "cfg3fit", "cfg5", "npx69", "aud24", "potrf"}

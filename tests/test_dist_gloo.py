@@ -441,3 +441,43 @@ def test_lockstep_chains_match_independent_runs():
         assert out[i][0] == ref.fun and np.array_equal(out[i][1], ref.x)
     assert max(sizes) == 4 and ev.points == sum(sizes) and ev.batches == len(sizes)
     assert sum(1 for n in sizes if n == 4) > len(sizes) // 2      # most evaluations really were batched four wide
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# device-side gather of predictions ("direct ... all-gather across the 7 links")
+# ---------------------------------------------------------------------------------------------------------------------
+def _device_gather_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch
+    import torch.distributed as td
+    td.init_process_group("gloo", rank=rank, world_size=world)
+    from gpcsd_amd.dist import TrialSharding
+    sh = TrialSharding(gather_dst=None)
+    full = np.random.RandomState(5).standard_normal((2, 3, 7, 5))         # (C, nz, nt, all trials): 5 trials over 2 ranks = 3 + 2
+    a, b = TrialSharding.block(5, rank, world)
+    local = torch.from_numpy(np.ascontiguousarray(full[..., a:b]))
+    every = sh.gather_trials_device(local)                                # dst=None: every rank copies the result out
+    only0 = sh.gather_trials_device(local, dst=0)
+    q.put((rank, bool(np.array_equal(every, full)), only0 is None or bool(np.array_equal(only0, full)), only0 is None, sh.d2h_bytes))
+    td.destroy_process_group()
+
+
+def test_device_gather_of_ragged_trial_blocks_world2():
+    """TrialSharding.gather_trials_device -- one all_gather_into_tensor on the tensors' own device, the reorder to
+    (..., all trials) there, one copy out on the gathering rank(s) -- with uneven trial blocks, here on CPU tensors over gloo
+    (the RCCL run with device tensors is tests/test_resident_predictions.py on the GPU box)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_device_gather_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=30)
+    full_bytes = 2 * 3 * 7 * 5 * 8
+    assert res[0][1] and res[1][1] and res[0][2] and res[1][2]
+    assert not res[0][3] and res[1][3]                                   # dst=0: rank 1 gets nothing back
+    assert res[0][4] == 2 * full_bytes and res[1][4] == full_bytes       # bytes copied out: the gathered result, on the gathering ranks only

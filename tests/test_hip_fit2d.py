@@ -234,6 +234,87 @@ def test_gpcsd2d_fit_on_the_cfg3_geometry_vs_scipy_on_oracle():
     assert abs(got - ref.fun) / abs(ref.fun) < 2e-3
 
 
+def _oracle_prior(pr, x):
+    """(lpdf, dlpdf) of one of the model's prior objects at x, from the ORACLE's expressions (priors.py:23-28, :46-51)."""
+    if hasattr(pr, "alpha"):
+        return O.invgamma_lpdf(x, pr.alpha, pr.beta), O.invgamma_dlpdf(x, pr.alpha, pr.beta)
+    return O.halfnormal_lpdf(x, pr.sd), O.halfnormal_dlpdf(x, pr.sd)
+
+
+def _cpu_objective_2d_closed_form(m, geom, lfp, kinds, eps):
+    """tp -> (-(oracle loglik + log prior), its gradient) with the oracle's closed-form gradient (O.loglik_and_grad, pinned by
+    central differences in tests/test_oracle_golden.py) -- the checker for full-size evaluations, where central differences of a
+    1e7-sized objective cannot resolve 1e-6 of a component."""
+    priors = [m.R["prior"], m.spatial_cov.params["ell1"]["prior"], m.spatial_cov.params["ell2"]["prior"]]
+    for tc in m.temporal_cov_list:
+        priors += [tc.params["ell"]["prior"], tc.params["sigma2"]["prior"]]
+    priors.append(m.sig2n["prior"])
+
+    def fg(tp):
+        hp = O.hparams_from_tparams(tp, 2, kinds, 1, eps=eps, jitter=JITTER_2D)
+        nat = [hp["R"]] + list(hp["ell_s"]) + [v for (_, ell, s2) in hp["temporal"] for v in (ell, s2)] + [hp["sig2n"]]
+        ll, g = O.loglik_and_grad(geom, lfp, tp, kinds, 1, eps=eps, jitter=JITTER_2D)
+        lp, dlp = 0.0, np.zeros_like(g)
+        for i, (pr, v) in enumerate(zip(priors, nat)):
+            a, b = _oracle_prior(pr, v)
+            lp += a
+            dlp[i] = b * v
+        return -(ll + lp), -(g + dlp)
+    return fg
+
+
+# ------------------------------------------------------------------------------------------------ headline geometry, 50 trials
+def test_cfg3_objective_and_gradient_at_50_trials_vs_oracle_every_component():
+    """GPCSD2D.fit()'s objective + analytic gradient (gpcsd2d.py:196-219, :250) at the headline configuration -- 384 channels x 500
+    samples x 50 trials -- against the oracle's objective and closed-form gradient: 1e-9 on the value, 1e-6 relative on EVERY
+    component (scalar noise; a component below 1e-9 of the largest is compared on that floor), at the generating point and at
+    a point with every parameter moved; two components also against 4th-order central differences of the oracle's loglik."""
+    m, geom, lfp, kinds, eps = _case_2d("cfg3s_2d_384x500x2", ntrials=50, structured=True)
+    fg = _cpu_objective_2d_closed_form(m, geom, lfp, kinds, eps)
+    tp = m._current_tparams()
+    worst = 0.0
+    for pt in (tp, tp + 0.2 * np.array([1, -1, 1, -1, 1, 1, -1, 1.0])):
+        calls0 = _folded_calls(m)
+        val, grad = m._objective_and_grad(pt, False)
+        assert _folded_calls(m) > calls0
+        fval, fgrad = fg(pt)
+        assert abs(val - fval) / abs(fval) < 1e-9
+        rel = np.abs(grad - fgrad) / np.maximum(np.abs(fgrad), 1e-9 * np.max(np.abs(fgrad)))
+        worst = max(worst, float(rel.max()))
+        assert rel.max() < GATE, (grad, fgrad, rel)
+    print("cfg3 x 50 trials: gradient vs oracle closed form, worst component %.2e" % worst)
+    f, _ = _cpu_objective_2d(m, geom, lfp, kinds, eps)
+    h = 2e-3
+    for i in (3, 7):                                     # temporal SE length scale, noise variance
+        e = np.zeros_like(tp)
+        e[i] = h
+        fd = (8.0 * (f(tp + e) - f(tp - e)) - (f(tp + 2 * e) - f(tp - 2 * e))) / (12.0 * h)
+        assert abs(grad[i] - fd) < 1e-6 * np.max(np.abs(grad)) + 2e-5 * abs(fd), (i, grad[i], fd)
+
+
+def test_cfg3_fit_20_iterations_two_restarts_at_50_trials_vs_scipy_on_oracle():
+    """GPCSD2D.fit() at 384 x 500 x 50: two restarts, up to 20 L-BFGS-B iterations each (lock-step batch of two), against
+    scipy.optimize.minimize on the oracle's objective + closed-form gradient from the same starts, same options and bounds:
+    final nll within 1e-6 relative, and the value reported at each optimum is the oracle's objective there."""
+    m, geom, lfp, kinds, eps = _case_2d("cfg3s_2d_384x500x2", ntrials=50, structured=True)
+    fg = _cpu_objective_2d_closed_form(m, geom, lfp, kinds, eps)
+    tp0 = m._current_tparams()
+    starts = [tp0 + 0.15 * np.array([1, -1, 1, 1, -1, 1, -1, 1.0]), tp0 - 0.1 * np.array([1, 1, -1, -1, 1, -1, 1, 1.0])]
+    opts = dict(OPTS, maxiter=20)
+    m.fit(n_restarts=2, options=opts, starts=starts)
+    got = np.asarray(m.fit_nll_values_)
+    nb, npts = m.fit_batches_
+    assert npts > nb                                     # evaluations were served two at a time
+    ref = [scipy.optimize.minimize(fg, s0, jac=True, method="L-BFGS-B", bounds=m._bounds(), options=opts) for s0 in starts]
+    for k in range(2):
+        at_opt, _ = fg(np.asarray(m.fit_params_[k]))
+        assert abs(at_opt - got[k]) / abs(at_opt) < 1e-9, (k, at_opt, got[k])
+        assert got[k] < fg(starts[k])[0]
+    dev = np.abs(got - np.array([r.fun for r in ref])) / np.abs([r.fun for r in ref])
+    print("cfg3 x 50 trials fit: nll GPU %s  SciPy-on-oracle %s  rel dev %s  iterations %s" % (got, [r.fun for r in ref], dev, [r.nit for r in ref]))
+    assert np.all(dev < GATE)
+
+
 def _reference_draw_order(m, fix_R):
     """Starting point of one restart, drawn in the order of gpcsd2d.py:223-238."""
     tp = [np.log(m.R["value"]) - np.log(100) if fix_R else np.log(m.R["prior"].sample()) - np.log(100)]

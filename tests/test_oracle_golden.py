@@ -219,3 +219,39 @@ def test_traditional_csd_estimators_vs_reference():
     np.testing.assert_array_equal(O.trad_csd_1d(g["lfp1"]), g["csd1"])
     np.testing.assert_array_equal(O.trad_csd_1d(g["lfp1e"]), g["csd1e"])
     np.testing.assert_array_equal(O.trad_csd_2d(g["lfp2"]), g["csd2"])
+
+
+def _tparams_of(hp):
+    tp = [np.log(hp["R"] / 100.0)] + [np.log(e / 100.0) for e in hp["ell_s"]]
+    for _, ell, s2 in hp["temporal"]:
+        tp += [np.log(ell), np.log(s2)]
+    return np.array(tp + list(np.log(np.atleast_1d(hp["sig2n"]))))
+
+
+@pytest.mark.parametrize("name", ["cfg1_1d_24x100x1", "1d_siglist_12x40x4", "1d_odd_17x37x5", "2d_grid_48x40x2"])
+def test_closed_form_gradient_vs_central_differences_of_the_pinned_loglik(name):
+    """O.loglik_and_grad (the closed form of what gpcsd1d.py:211 / gpcsd2d.py:250 `jac=grad(obj_fun)` differentiates) against
+    4th-order central differences of O.loglik, which the fixtures above pin to the reference: scalar noise, a per-electrode
+    noise list (eigenvector-rotation term), 1D and 2D forward models, SE and Matern components, R held fixed."""
+    c, g, geom, hp, lfp = load_model_case(name)
+    jit = float(g["jitter"])
+    kinds = [k for k, _, _ in hp["temporal"]]
+    n_sig = int(np.size(hp["sig2n"]))
+    tp = _tparams_of(hp)
+    tp = tp + 0.05 * np.cos(np.arange(tp.size))          # away from the fixture's own point, every parameter moved
+    ll, grad = O.loglik_and_grad(geom, lfp, tp, kinds, n_sig, eps=c["eps"], jitter=jit)
+    f = lambda v: O.loglik(geom, O.hparams_from_tparams(v, geom.dim, kinds, n_sig, c["eps"], jit), lfp)
+    assert ll == f(tp)
+    h, fd = 1e-3, np.zeros_like(tp)
+    for i in range(tp.size):
+        e = np.zeros_like(tp)
+        e[i] = h
+        fd[i] = (8.0 * (f(tp + e) - f(tp - e)) - (f(tp + 2 * e) - f(tp - 2 * e))) / (12.0 * h)
+    assert np.max(np.abs(grad - fd)) / np.max(np.abs(fd)) < 1e-7, (grad, fd)
+    ll_fix, grad_fix = O.loglik_and_grad(geom, lfp, tp, kinds, n_sig, eps=c["eps"], jitter=jit, R_fixed=hp["R"])
+    assert grad_fix[0] == 0.0 and ll_fix == f(np.concatenate([[np.log(hp["R"] / 100.0)], tp[1:]]))
+    # prior derivatives used beside it by the fit checkers
+    for x in (0.3, 2.0, 40.0):
+        a, b = O.invgamma_params(1.0, 20.0)
+        assert abs(O.invgamma_dlpdf(x, a, b) - (O.invgamma_lpdf(x + 1e-6, a, b) - O.invgamma_lpdf(x - 1e-6, a, b)) / 2e-6) < 1e-6 * (1 + abs(O.invgamma_dlpdf(x, a, b)))
+        assert abs(O.halfnormal_dlpdf(x, 1.5) - (O.halfnormal_lpdf(x + 1e-6, 1.5) - O.halfnormal_lpdf(x - 1e-6, 1.5)) / 2e-6) < 1e-6 * (1 + x)

@@ -138,3 +138,66 @@ def test_pipeline_over_panel_counts_and_odd_grids(nt):
     assert abs(vals[True][0] - ll_ref) <= 1e-9 * abs(ll_ref)
     assert np.max(np.abs(vals[True][1] - vals[False][1])) <= 1e-9 * sc
     assert np.max(np.abs(vals[True][1] - ref["csd"])) <= 1e-8 * sc
+
+
+@pytest.mark.parametrize("form", ["fenced", "paired", "resident", "class_api"])
+def test_a_gate_that_gives_up_is_a_scheduling_miss_and_the_call_is_evaluated_again(form):
+    """ADVICE r5 (wy.hip gate): when the tridiagonalisation is not running beside the launch that waits for it (kernels serialised by
+    a profiler, an oversubscribed card) the gate's bounded wait runs out.  That is not a numerical failure: the stage launch leaves
+    the unfinished reflectors alone, and the collecting call switches the pipeline off for the context (latched), counts the miss
+    and evaluates again unpipelined -- the caller sees the unpipelined result, no LinAlgError.  Forced here with a patience of zero
+    ticks (gpcsd_q_pipeline_stats), through every call form that can carry a pipelined chain."""
+    from gpcsd_amd import _hip
+    R = 16
+    w, m, lfp = _step_model(R)
+    ctx = m._sync_device()
+    ctx.decomposition_cache(False)
+    ctx.pair_share_s(False)
+    z = w["x"]
+    hp, k1 = m._hparams(m.JITTER)
+    hp0, k0 = m._hparams(0.0)
+    ctx.q_pipeline(False)                                     # the answer: the unpipelined form
+    want_ll = ctx.loglik_parts(hp)
+    ctx.predict_resident(hp0, z, w["t"], _hip.PRED_CSD, want_lists=True)
+    ctx.synchronize()
+    want_pr = ctx.fetch("pred_out_csd", (z.shape[0], w["nt"], R)).copy()
+    ctx.q_pipeline(True)
+    try:
+        ctx.q_pipeline_stats(gate_ticks=0)                    # every gate gives up at once
+        on0, miss0 = ctx.q_pipeline_stats()
+        assert on0 and miss0 == 0
+        if form == "fenced":
+            got_ll = ctx.loglik_parts(hp)
+            ctx.q_pipeline(True)                              # (latched off by the miss: on again for the second call form)
+            ctx.predict_resident(hp0, z, w["t"], _hip.PRED_CSD, want_lists=True)
+            ctx.synchronize()                                 # the deferred status of the queued prediction is collected here
+        elif form == "paired":
+            ctx.loglik_predict_async(hp, hp0, z, w["t"], _hip.PRED_CSD, want_lists=True)
+            got_ll = ctx.loglik_parts_wait()
+            ctx.synchronize()
+        elif form == "resident":
+            ctx.loglik_parts_async(hp)
+            got_ll = ctx.loglik_parts_wait()
+            ctx.q_pipeline(True)
+            ctx.predict_resident(hp0, z, w["t"], _hip.PRED_CSD, want_lists=True)
+            # (no synchronize: gpcsd_fetch itself collects the queued prediction's status -- and evaluates it again -- before it copies)
+        else:
+            got_ll = None
+            ll_class = float(m.loglik())
+            ctx.q_pipeline(True)
+            m.predict(z, w["t"], type="csd")
+        on1, miss1 = ctx.q_pipeline_stats()
+        assert not on1 and miss1 >= 1, (on1, miss1)           # latched off, counted
+        got_pr = ctx.fetch("pred_out_csd", (z.shape[0], w["nt"], R)).copy()
+        if form == "class_api":
+            assert ll_class == -0.5 * R * want_ll[0] - 0.5 * want_ll[1]
+            assert np.array_equal(np.asarray(m.csd_pred), want_pr)
+        else:
+            assert tuple(got_ll) == tuple(want_ll)
+        assert np.array_equal(got_pr, want_pr)                # bit for bit the unpipelined evaluation
+        # ... and the context works on (pipeline off) with a normal patience
+        ctx.q_pipeline_stats(gate_ticks=20000000)
+        assert tuple(ctx.loglik_parts(hp)) == tuple(want_ll)
+    finally:
+        ctx.q_pipeline_stats(gate_ticks=20000000)
+        ctx.q_pipeline(True)
