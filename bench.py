@@ -1399,6 +1399,7 @@ def run_fit_bench(args, w, rank, world, local_rank, backend, compact=False, cpu_
             ctx.synchronize()
             dtb = (time.perf_counter() - tb) / nb_
             by_batch[str(bb)] = {"ms_per_batched_call": 1e3 * dtb, "evals_per_sec": bb / dtb}
+        ctx.decomposition_cache(False)                  # (every call decomposes both sides, as an optimiser's evaluations do)
         for _ in range(3):
             ctx.loglik_parts(hps[0])
         ctx.synchronize()
@@ -1406,6 +1407,7 @@ def run_fit_bench(args, w, rank, world, local_rank, backend, compact=False, cpu_
         for _ in range(20):
             ctx.loglik_parts(hps[0])
         ll_fenced_ms = 1e3 * (time.perf_counter() - tl) / 20
+        ctx.decomposition_cache(True)
     if sharding is not None:
         import torch.distributed as td
         tt = torch.tensor([elapsed, seq_s], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")

@@ -1174,6 +1174,8 @@ extern "C" int gpcsd_ctx_destroy(gpcsd_ctx *c) {
     if (c->h_ll) (void)hipHostFree(c->h_ll);
     if (c->h_chol_flag) (void)hipFree(c->h_chol_flag);
     if (c->stage_ring) (void)hipHostFree(c->stage_ring);
+    for (auto &kv : c->pinned_bufs)
+        if (kv.second.first) (void)hipHostFree(kv.second.first);
     if (c->tail_clk_host) (void)hipHostFree(c->tail_clk_host);
     for (auto &sl : c->ll_slot)
         if (sl.ev) (void)hipEventDestroy(sl.ev);

@@ -69,11 +69,28 @@ static int loglik_grad_impl(gpcsd_ctx *c, const gpcsd_hparams *hps, int B, doubl
     double *es = c->buf<double>("b_es", (size_t)nx * B), *et = c->buf<double>("b_et", (size_t)nt * B);
     double *D = c->buf<double>("b_D", nD * B), *Dinv = c->buf<double>("b_Dinv", nD * B);
     constexpr int NS = 8;                                     // scalars per set: sumlog, quad, sum B^2, sum 1/D
-    double *scal = c->buf<double>("b_scal", (size_t)NS * B);
-    int *st = c->buf<int>("b_status", (size_t)2 * B);        // [0, B): spatial chains, [B, 2B): temporal chains
-    double *A = c->buf<double>("b_ks_A", nxG * B), *Kgl = c->buf<double>("b_ks_Kgl", GG * B), *T = c->buf<double>("b_ks_T", nxG * B);
+    // everything the host reads back lives in ONE block -- [scalars NS B][gradient slots 64 B][status words 2 B] -- so that it
+    // comes back in one copy into a page-locked block (three copies into pageable vectors were three staged round trips, ~70 us)
+    const size_t res_doubles = (size_t)(NS + 64 + 1) * B;
+    double *resblk = c->buf<double>("b_result", res_doubles);
+    double *scal = resblk;
+    int *st = reinterpret_cast<int *>(resblk + (size_t)(NS + 64) * B);        // [0, B): spatial chains, [B, 2B): temporal chains
+    // 2D: the GL grid is a tensor grid and Kgl = K1 (x) K2 (covariances.py:216).  Forward AND backward then run on the per-axis
+    // factors (kron below); 1D keeps the flat Kgl.  GPCSD_GRAD_KRON=0: the flat form in 2D as well (A/B, cross-check).
+    static const bool kron_off = getenv("GPCSD_GRAD_KRON") && getenv("GPCSD_GRAD_KRON")[0] == '0';
+    const bool kron = g.dim == 2 && !kron_off;
+    double *A = c->buf<double>("b_ks_A", nxG * B), *T = c->buf<double>("b_ks_T", nxG * B);
+    double *Kgl = kron ? nullptr : c->buf<double>("b_ks_Kgl", GG * B);
+    const int n1 = g.ngl1, n2 = g.dim == 2 ? g.ngl2 : 0;
+    double *K1 = nullptr, *K2 = nullptr, *dK1 = nullptr, *dK2 = nullptr, *Uk = nullptr, *U2 = nullptr, *Tl1 = nullptr, *Tl2 = nullptr;
+    if (kron) {
+        K1 = c->buf<double>("b_ks_K1", (size_t)n1 * n1 * B); dK1 = c->buf<double>("b_ks_dK1", (size_t)n1 * n1 * B);
+        K2 = c->buf<double>("b_ks_K2", (size_t)n2 * n2 * B); dK2 = c->buf<double>("b_ks_dK2", (size_t)n2 * n2 * B);
+        Uk = c->buf<double>("b_ks_U", nxG * B); U2 = c->buf<double>("b_ks_U2", nxG * B);
+        Tl1 = c->buf<double>("b_ks_Tl1", nxG * B); Tl2 = c->buf<double>("b_ks_Tl2", nxG * B);
+    }
     double *W = c->buf<double>("b_W", nxRT * B), *Bm = c->buf<double>("b_Bm", nxRT * B);
-    double *gdev = c->buf<double>("b_grad_out", (size_t)64 * B);
+    double *gdev = resblk + (size_t)NS * B;
     const double *t = (const double *)c->bufs["time_t"].p;
     const bool host_kt = uses_host_kt(&hps[0]);
     // (a caller-supplied Gram need not commute with the reflection of the time grid: that side is not folded, cf. front_half)
@@ -121,15 +138,43 @@ static int loglik_grad_impl(gpcsd_ctx *c, const gpcsd_hparams *hps, int B, doubl
         k_se_1d(c, g.gx1, G, g.gx1, G, 0.0, Kgl, s, tab, B, GG);
     } else {
         k_fwd_weights_2d(c, g.x, nx, g.gx1, g.gw1, g.ngl1, g.gx2, g.gw2, g.ngl2, 0.0, 0.0, A, s, tab, B, nxG);
-        k_se_2d(c, g.gx1, g.gx2, G, g.ngl2, g.gx1, g.gx2, G, g.ngl2, 0.0, 0.0, Kgl, s, tab, B, GG);
+        if (!kron) k_se_2d(c, g.gx1, g.gx2, G, g.ngl2, g.gx1, g.gx2, G, g.ngl2, 0.0, 0.0, Kgl, s, tab, B, GG);
     }
+    // out[x][(h1,h2)] = sum_g1 F1[g1][h1] V[x][(g1,h2)], one small product per electrode and set (F1 = K1 or dK1)
+    auto kron_axis1 = [&](const double *F1, const double *V, double *out, const char *name) {
+        GemmDesc v;
+        v.M = n1; v.N = n2; v.K = n1;
+        v.A = F1; v.lda = n1; v.transA = true; v.B = V; v.ldb = n2; v.C = out; v.ldc = n2;
+        v.batch = nx; v.sA = 0; v.sB = G; v.sC = G;
+        v.batch2 = B; v.sA2 = (long)n1 * n1; v.sB2 = nxG; v.sC2 = nxG;
+        v.prof_name = name;
+        gemm_f64(c, v, s);
+    };
+    // out[(x,g1)][h2] = sum_g2 A[(x,g1)][g2] F2[g2][h2] (F2 = K2 or dK2)
+    auto kron_axis2 = [&](const double *F2, double *out, const char *name) {
+        GemmDesc u;
+        u.M = nx * n1; u.N = n2; u.K = n2;
+        u.A = A; u.lda = n2; u.B = F2; u.ldb = n2; u.C = out; u.ldc = n2;
+        u.batch2 = B; u.sA2 = nxG; u.sB2 = (long)n2 * n2; u.sC2 = nxG;
+        u.prof_name = name;
+        gemm_f64(c, u, s);
+    };
     {
-        GemmDesc d1;                                   // T = A Kgl
-        d1.M = nx; d1.N = G; d1.K = G;
-        d1.A = A; d1.lda = G; d1.B = Kgl; d1.ldb = G; d1.C = T; d1.ldc = G;
-        d1.batch2 = B; d1.sA2 = nxG; d1.sB2 = GG; d1.sC2 = nxG;
-        d1.prof_name = "gemm_Ks_AKgl";
-        gemm_f64(c, d1, s);
+        if (kron) {
+            // T = A (K1 (x) K2) as two small products (build_kphi does the same for the fused calls: 74 MF instead of 1.1 GF at
+            // 384 x 20 x 60, and Kgl's 1200^2 exponentials are never formed)
+            k_se_axis_tab(c, g.gx1, n1, 0, tab, B, K1, dK1, s);
+            k_se_axis_tab(c, g.gx2, n2, 1, tab, B, K2, dK2, s);
+            kron_axis2(K2, Uk, "gemm_Ks_AK2");
+            kron_axis1(K1, Uk, T, "gemm_Ks_K1U");
+        } else {
+            GemmDesc d1;                                   // T = A Kgl
+            d1.M = nx; d1.N = G; d1.K = G;
+            d1.A = A; d1.lda = G; d1.B = Kgl; d1.ldb = G; d1.C = T; d1.ldc = G;
+            d1.batch2 = B; d1.sA2 = nxG; d1.sB2 = GG; d1.sC2 = nxG;
+            d1.prof_name = "gemm_Ks_AKgl";
+            gemm_f64(c, d1, s);
+        }
         GemmDesc d2;                                   // Ks = T A^T
         d2.M = nx; d2.N = nx; d2.K = G;
         d2.A = T; d2.lda = G; d2.B = A; d2.ldb = G; d2.transB = true; d2.C = Ks; d2.ldc = nx;
@@ -150,11 +195,24 @@ static int loglik_grad_impl(gpcsd_ctx *c, const gpcsd_hparams *hps, int B, doubl
         ProfScope ps(c, "eigh_spatial", 9.0 * (double)nx * nx * nx * B, s);
         eigh_pair_device(c, Ks, nx, es, Qs, sym_s, nullptr, 0, nullptr, nullptr, nullptr, st, s, !fold, B, 1, -1, sfill ? 1 : 0);
     }
+    if (kron) {
+        // the backward pass's hyper-parameter-only factors, queued here where the main stream would otherwise wait for the chains:
+        // Tl1 = A (dK1 (x) K2) = dK1^T (A K2),  Tl2 = A (K1 (x) dK2) = K1^T (A dK2)
+        kron_axis1(dK1, Uk, Tl1, "gemm_grad_dK1U");
+        kron_axis2(dK2, U2, "gemm_grad_AdK2");
+        kron_axis1(K1, U2, Tl2, "gemm_grad_K1U2");
+    }
     double *av = c->buf<double>("b_grad_a", (size_t)nx * B), *bv = c->buf<double>("b_grad_b", (size_t)nt * B);
     double *Gs = c->buf<double>("b_grad_Gs", nxx * B), *Gt = c->buf<double>("b_grad_Gt", ntt * B);
     const long nmx = (long)std::max(nx, nt) * std::max(nx, nt);
     double *T1 = c->buf<double>("b_grad_T1", (size_t)nmx * B);
-    const int CH = 512;                   // row chunk of the Ghat_t sums
+    // row chunk of the Ghat_t sums (GPCSD_GRAD_CH: A/B).  A chunk is one K range of a 64 x 64 tile: with 512 rows the 250-column
+    // halves of 384 x 500 x 50 gave 592 tiles of 32 dependent K steps -- too few to hide the load latency (94 us per parity for
+    // 2.4 GF); 256 rows: 61 us (128: 63; the 32 x 32 tiles of configuration 5: 137)
+    static const int CH = getenv("GPCSD_GRAD_CH") ? std::max(64, atoi(getenv("GPCSD_GRAD_CH"))) : 256;
+    static const int GS_CFG = getenv("GPCSD_GRAD_GS_CFG") ? atoi(getenv("GPCSD_GRAD_GS_CFG")) : 3;
+    static const int GT_CFG = getenv("GPCSD_GRAD_GT_CFG") ? atoi(getenv("GPCSD_GRAD_GT_CFG")) : 3;
+    hipStream_t sT = s;                   // the stream of the gradient's temporal half (folded path: stream2, see below)
     bool quad_in_two = false;             // the quadratic form came out as two partial sums (parity blocks of unequal shape)
     if (fold) {
         ++c->fold_gemm_calls;
@@ -226,6 +284,56 @@ static int loglik_grad_impl(gpcsd_ctx *c, const gpcsd_hparams *hps, int B, doubl
             }
         }
         k_D_sums(c, D, S_.w, T_.w, nx, nt, av, bv, scal + 3, s, B, NS);   // a, b in fold order; scal[b][3] = sum 1/D
+        // From here the spatial and the temporal half of the gradient are independent (both read B~, a, b): the temporal one --
+        // Ghat_t, its rotation back, <Gt, dKt> -- runs on stream2, idle since its chain ended, beside the spatial one on the main
+        // stream; each branch's small launches (reductions, the rotations' 8 us products) hide under the other's large products.
+        // GPCSD_GRAD_BRANCHES=0: one after the other on the main stream (A/B; same kernels, same bits).
+        static const bool branches_off = getenv("GPCSD_GRAD_BRANCHES") && getenv("GPCSD_GRAD_BRANCHES")[0] == '0';
+        if (!branches_off && c->prof_mode != 1) {
+            sT = s2;
+            hipEvent_t ev = c->get_event();
+            GP_HIP(hipEventRecord(ev, s));
+            GP_HIP(hipStreamWaitEvent(sT, ev, 0));
+            c->event_pool.push_back(ev);
+        }
+        // Ghat_t~ parity blocks: 1/2 sum_{(x,r)} (B~ ws)[:, q]^T B~[:, q] - R/2 diag(b[q block])   (row chunks, then a fixed-order sum)
+        const long rows = (long)nx * R;
+        double *wsr = c->buf<double>("b_grad_ws_rows", (size_t)rows * B);        // ws spread over the (x', r) rows
+        k_repeat_rows(c, S_.w, nx, nx, R, B, wsr, sT);
+        const int nfull = (int)(rows / CH), rem = (int)(rows % CH), nchunk = nfull + (rem > 0 ? 1 : 0);
+        const long sCt = (long)nchunk * sUt;
+        double *Ct = c->buf<double>("b_grad_Ct", (size_t)sCt * B);
+        double *Ght = c->buf<double>("b_grad_Ght", (size_t)sUt * B);
+        for (int q = 0; q < 2; ++q) {
+            const int nq = q ? T_.na : T_.ns, c0 = q ? T_.ns : 0;
+            const long o_in = q ? (long)nchunk * T_.ns * T_.ns : 0, o_out = q ? (long)T_.ns * T_.ns : 0, nqq = (long)nq * nq;
+            if (nq == 0) continue;
+            if (nfull > 0) {
+                GemmDesc gt;
+                gt.M = nq; gt.N = nq; gt.K = CH;
+                gt.A = Bm + c0; gt.lda = nt; gt.transA = true; gt.B = Bm + c0; gt.ldb = nt; gt.C = Ct + o_in; gt.ldc = nq;
+                gt.kscale = wsr; gt.sKscale = CH; gt.sKscale2 = rows;         // (B~ ws)^T B~: the factor runs along the contracted row
+                gt.batch = nfull; gt.sA = (long)CH * nt; gt.sB = (long)CH * nt; gt.sC = nqq;
+                gt.batch2 = B; gt.sA2 = nxRT; gt.sB2 = nxRT; gt.sC2 = sCt;
+                if (nq >= 64) gt.cfg = GT_CFG;
+                gt.lower = true;
+                gt.prof_name = "gemm_grad_Gt";
+                gemm_f64(c, gt, sT);
+            }
+            if (rem > 0) {
+                GemmDesc gt;
+                gt.M = nq; gt.N = nq; gt.K = rem;
+                if (nq >= 64) gt.cfg = GT_CFG;
+                gt.lower = true;
+                gt.A = Bm + (long)nfull * CH * nt + c0; gt.lda = nt; gt.transA = true; gt.B = Bm + (long)nfull * CH * nt + c0; gt.ldb = nt;
+                gt.kscale = wsr + (long)nfull * CH; gt.sKscale2 = rows;
+                gt.C = Ct + o_in + (long)nfull * nqq; gt.ldc = nq;
+                gt.batch2 = B; gt.sA2 = nxRT; gt.sB2 = nxRT; gt.sC2 = sCt;
+                gt.prof_name = "gemm_grad_Gt";
+                gemm_f64(c, gt, sT);
+            }
+            k_batch_reduce(c, Ct + o_in, nchunk, nqq, nq, 0.5, bv + c0, -0.5 * R, Ght + o_out, sT, B, sCt, nt, sUt);
+        }
         // Ghat_s~ parity blocks: 1/2 sum_r (B~ wt)[p rows] B~[p rows]^T - R/2 diag(a[p rows])
         const long sCs = (long)R * sUs;
         double *Cs = c->buf<double>("b_grad_Cs", (size_t)sCs * B);
@@ -242,71 +350,37 @@ static int loglik_grad_impl(gpcsd_ctx *c, const gpcsd_hparams *hps, int B, doubl
             gs.batch2 = B; gs.sA2 = nxRT; gs.sB2 = nxRT; gs.sC2 = sCs;
             // the tile configuration must not depend on B (a set has to run the same tiles alone or in a batch): these
             // half-size products have few tiles per set, which the automatic choice would read as "latency-bound"
-            if (np >= 64) gs.cfg = 3;
+            if (np >= 64) gs.cfg = GS_CFG;
+            gs.lower = true;                                              // symmetric: k_batch_reduce mirrors the lower triangle
             gs.prof_name = "gemm_grad_Gs";
             gemm_f64(c, gs, s);
             k_batch_reduce(c, Cs + o_in, R, (long)np * np, np, 0.5, av + r0, -0.5 * R, Ghs + o_out, s, B, sCs, nx, sUs);
         }
-        // Ghat_t~ parity blocks: 1/2 sum_{(x,r)} (B~ ws)[:, q]^T B~[:, q] - R/2 diag(b[q block])   (row chunks, then a fixed-order sum)
-        const long rows = (long)nx * R;
-        double *wsr = c->buf<double>("b_grad_ws_rows", (size_t)rows * B);        // ws spread over the (x', r) rows
-        k_repeat_rows(c, S_.w, nx, nx, R, B, wsr, s);
-        const int nfull = (int)(rows / CH), rem = (int)(rows % CH), nchunk = nfull + (rem > 0 ? 1 : 0);
-        const long sCt = (long)nchunk * sUt;
-        double *Ct = c->buf<double>("b_grad_Ct", (size_t)sCt * B);
-        double *Ght = c->buf<double>("b_grad_Ght", (size_t)sUt * B);
-        for (int q = 0; q < 2; ++q) {
-            const int nq = q ? T_.na : T_.ns, c0 = q ? T_.ns : 0;
-            const long o_in = q ? (long)nchunk * T_.ns * T_.ns : 0, o_out = q ? (long)T_.ns * T_.ns : 0, nqq = (long)nq * nq;
-            if (nq == 0) continue;
-            if (nfull > 0) {
-                GemmDesc gt;
-                gt.M = nq; gt.N = nq; gt.K = CH;
-                gt.A = Bm + c0; gt.lda = nt; gt.transA = true; gt.B = Bm + c0; gt.ldb = nt; gt.C = Ct + o_in; gt.ldc = nq;
-                gt.kscale = wsr; gt.sKscale = CH; gt.sKscale2 = rows;         // (B~ ws)^T B~: the factor runs along the contracted row
-                gt.batch = nfull; gt.sA = (long)CH * nt; gt.sB = (long)CH * nt; gt.sC = nqq;
-                gt.batch2 = B; gt.sA2 = nxRT; gt.sB2 = nxRT; gt.sC2 = sCt;
-                if (nq >= 64) gt.cfg = 3;
-                gt.prof_name = "gemm_grad_Gt";
-                gemm_f64(c, gt, s);
-            }
-            if (rem > 0) {
-                GemmDesc gt;
-                gt.M = nq; gt.N = nq; gt.K = rem;
-                if (nq >= 64) gt.cfg = 3;
-                gt.A = Bm + (long)nfull * CH * nt + c0; gt.lda = nt; gt.transA = true; gt.B = Bm + (long)nfull * CH * nt + c0; gt.ldb = nt;
-                gt.kscale = wsr + (long)nfull * CH; gt.sKscale2 = rows;
-                gt.C = Ct + o_in + (long)nfull * nqq; gt.ldc = nq;
-                gt.batch2 = B; gt.sA2 = nxRT; gt.sB2 = nxRT; gt.sC2 = sCt;
-                gt.prof_name = "gemm_grad_Gt";
-                gemm_f64(c, gt, s);
-            }
-            k_batch_reduce(c, Ct + o_in, nchunk, nqq, nq, 0.5, bv + c0, -0.5 * R, Ght + o_out, s, B, sCt, nt, sUt);
-        }
         // back to the original bases, block by block: G~_pp = U_p Ghat_pp U_p^T, then G = F^T diag(G~_ss, G~_aa) F
         double *Gsf = c->buf<double>("b_grad_Gsf", (size_t)sUs * B), *Gtf = c->buf<double>("b_grad_Gtf", (size_t)sUt * B);
-        auto sandwich_blocks = [&](const Side &sd, const double *H, long sH, double *outf) {
+        double *T1t = c->buf<double>("b_grad_T1t", (size_t)nmx * B);          // (the temporal branch's own scratch)
+        auto sandwich_blocks = [&](const Side &sd, const double *H, long sH, double *outf, double *tmp, hipStream_t sq) {
             for (int p = 0; p < 2; ++p) {
                 const int np = p ? sd.na : sd.ns;
                 const long o = p ? (long)sd.ns * sd.ns : 0;
                 if (np == 0) continue;
                 GemmDesc a;
-                a.M = np; a.N = np; a.K = np; a.A = sd.U + o; a.lda = np; a.B = H + o; a.ldb = np; a.C = T1; a.ldc = np;
+                a.M = np; a.N = np; a.K = np; a.A = sd.U + o; a.lda = np; a.B = H + o; a.ldb = np; a.C = tmp; a.ldc = np;
                 a.batch2 = B; a.sA2 = sd.sU; a.sB2 = sH; a.sC2 = nmx;
                 a.prof_name = "gemm_grad_sandwich";
-                gemm_f64(c, a, s);
+                gemm_f64(c, a, sq);
                 GemmDesc bq;
-                bq.M = np; bq.N = np; bq.K = np; bq.A = T1; bq.lda = np; bq.B = sd.U + o; bq.ldb = np; bq.transB = true;
+                bq.M = np; bq.N = np; bq.K = np; bq.A = tmp; bq.lda = np; bq.B = sd.U + o; bq.ldb = np; bq.transB = true;
                 bq.C = outf + o; bq.ldc = np;
                 bq.batch2 = B; bq.sA2 = nmx; bq.sB2 = sd.sU; bq.sC2 = sH;
                 bq.prof_name = "gemm_grad_sandwich";
-                gemm_f64(c, bq, s);
+                gemm_f64(c, bq, sq);
             }
         };
-        sandwich_blocks(S_, Ghs, sUs, Gsf);
-        sandwich_blocks(T_, Ght, sUt, Gtf);
+        sandwich_blocks(T_, Ght, sUt, Gtf, T1t, sT);
+        k_sym_unfold_mat(c, Gtf, sUt, T_.sym, nt, Gt, sT, B);
+        sandwich_blocks(S_, Ghs, sUs, Gsf, T1, s);
         k_sym_unfold_mat(c, Gsf, sUs, S_.sym, nx, Gs, s, B);
-        k_sym_unfold_mat(c, Gtf, sUt, T_.sym, nt, Gt, s, B);
     } else {
         GemmDesc g1;                          // W_b = Qs_b^T Y          (gpcsd1d.py:125 inner dot; the data is shared)
         g1.M = nx; g1.N = (int)RT; g1.K = nx;
@@ -336,6 +410,7 @@ static int loglik_grad_impl(gpcsd_ctx *c, const gpcsd_hparams *hps, int B, doubl
         gs.kscale = et; gs.sKscale = 0; gs.sKscale2 = nt;
         gs.batch = R; gs.sA = nt; gs.sB = nt; gs.sC = nxx;
         gs.batch2 = B; gs.sA2 = nxRT; gs.sB2 = nxRT; gs.sC2 = sCs;
+        gs.lower = true;                                                  // symmetric: k_batch_reduce mirrors the lower triangle
         gs.prof_name = "gemm_grad_Gs";
         gemm_f64(c, gs, s);
         double *Ghs = c->buf<double>("b_grad_Ghs", nxx * B);
@@ -367,11 +442,13 @@ static int loglik_grad_impl(gpcsd_ctx *c, const gpcsd_hparams *hps, int B, doubl
             gt.kscale = wsr; gt.sKscale = CH; gt.sKscale2 = rows;
             gt.batch = nfull; gt.sA = (long)CH * nt; gt.sB = (long)CH * nt; gt.sC = ntt;
             gt.batch2 = B; gt.sA2 = nxRT; gt.sB2 = nxRT; gt.sC2 = sCt;
+            gt.lower = true;
             gt.prof_name = "gemm_grad_Gt";
             gemm_f64(c, gt, s);
         }
         if (rem > 0) {
             GemmDesc gt;
+            gt.lower = true;
             gt.M = nt; gt.N = nt; gt.K = rem;
             gt.A = Bm + (long)nfull * CH * nt; gt.lda = nt; gt.transA = true; gt.B = Bm + (long)nfull * CH * nt; gt.ldb = nt;
             gt.kscale = wsr + (long)nfull * CH; gt.sKscale2 = rows;
@@ -402,23 +479,38 @@ static int loglik_grad_impl(gpcsd_ctx *c, const gpcsd_hparams *hps, int B, doubl
     // natural-parameter order: [R, ell_s (dim), (ell_t, sigma2_t) per component, sig2n]; 64 slots per set
     if (host_kt) {                        // <Gt, d Kt / d theta_k> with the caller's derivative matrices
         double *dK = c->upload<double>("b_host_dkt", c->host_dkt.data(), (size_t)2 * C * ntt);
-        k_frob_inner(c, Gt, dK, ntt, 2 * C, gdev + 1 + g.dim, s);
+        if (sT != s) {                    // (the upload is on the main stream)
+            hipEvent_t ev = c->get_event();
+            GP_HIP(hipEventRecord(ev, s));
+            GP_HIP(hipStreamWaitEvent(sT, ev, 0));
+            c->event_pool.push_back(ev);
+        }
+        k_frob_inner(c, Gt, dK, ntt, 2 * C, gdev + 1 + g.dim, sT);
     } else {
-        k_temporal_grad(c, &hps[0], Gt, t, nt, gdev + 1 + g.dim, s, tab, B, 64);
+        k_temporal_grad(c, &hps[0], Gt, t, nt, gdev + 1 + g.dim, sT, tab, B, 64);
+    }
+    hipEvent_t ev_tbranch = nullptr;
+    if (sT != s) {                        // the temporal branch ends here; the main stream takes it in before the results are copied
+        ev_tbranch = c->get_event();
+        GP_HIP(hipEventRecord(ev_tbranch, sT));
     }
     double *P = c->buf<double>("b_grad_P", nxG * B);
-    double *Mg = c->buf<double>("b_grad_M", GG * B);
     GemmDesc gp;                          // P = Gs A
     gp.M = nx; gp.N = G; gp.K = nx; gp.A = Gs; gp.lda = nx; gp.B = A; gp.ldb = G; gp.C = P; gp.ldc = G;
     gp.batch2 = B; gp.sA2 = nxx; gp.sB2 = nxG; gp.sC2 = nxG;
     gp.prof_name = "gemm_grad_GsA";
     gemm_f64(c, gp, s);
-    GemmDesc gm;                          // M = A^T P
-    gm.M = G; gm.N = G; gm.K = nx; gm.A = A; gm.lda = G; gm.transA = true; gm.B = P; gm.ldb = G; gm.C = Mg; gm.ldc = G;
-    gm.batch2 = B; gm.sA2 = nxG; gm.sB2 = nxG; gm.sC2 = GG;
-    gm.prof_name = "gemm_grad_AtP";
-    gemm_f64(c, gm, s);
-    k_kgl_grad(c, Mg, Kgl, g.gx1, g.gx2, G, g.dim == 2 ? g.ngl2 : 0, 0.0, 0.0, gdev + 1, s, tab, B, 64);
+    if (kron) {                           // <A^T Gs A, dKgl/dell_k> = <Gs A, Tl_k>   (grad.hip: k_frob_pair)
+        k_frob_pair(c, P, Tl1, Tl2, nxG, gdev + 1, s, B, 64);
+    } else {
+        double *Mg = c->buf<double>("b_grad_M", GG * B);
+        GemmDesc gm;                      // M = A^T P
+        gm.M = G; gm.N = G; gm.K = nx; gm.A = A; gm.lda = G; gm.transA = true; gm.B = P; gm.ldb = G; gm.C = Mg; gm.ldc = G;
+        gm.batch2 = B; gm.sA2 = nxG; gm.sB2 = nxG; gm.sC2 = GG;
+        gm.prof_name = "gemm_grad_AtP";
+        gemm_f64(c, gm, s);
+        k_kgl_grad(c, Mg, Kgl, g.gx1, g.gx2, G, g.dim == 2 ? g.ngl2 : 0, 0.0, 0.0, gdev + 1, s, tab, B, 64);
+    }
     GemmDesc gr;                          // S = Gs T  (T = A Kgl from the forward pass)
     gr.M = nx; gr.N = G; gr.K = nx; gr.A = Gs; gr.lda = nx; gr.B = T; gr.ldb = G; gr.C = P; gr.ldc = G;
     gr.batch2 = B; gr.sA2 = nxx; gr.sB2 = nxG; gr.sC2 = nxG;
@@ -434,13 +526,16 @@ static int loglik_grad_impl(gpcsd_ctx *c, const gpcsd_hparams *hps, int B, doubl
         c->download(hb2.data(), b2row, hb2.size() * sizeof(double));
         c->download(hinv.data(), c->bufs["grad_s1row"].p, hinv.size() * sizeof(double));   // written by k_D_sums, [set][x]
     }
-    std::vector<double> hs((size_t)NS * B), hg((size_t)64 * B);
-    std::vector<int> hst((size_t)2 * B);
-    c->download(hs.data(), scal, hs.size() * sizeof(double));
-    c->download(hg.data(), gdev, hg.size() * sizeof(double));
-    c->download(hst.data(), st, hst.size() * sizeof(int));
+    if (ev_tbranch) {
+        GP_HIP(hipStreamWaitEvent(s, ev_tbranch, 0));
+        c->event_pool.push_back(ev_tbranch);
+    }
+    double *hres = c->pinned<double>("b_result_host", res_doubles);
+    c->download(hres, resblk, res_doubles * sizeof(double));
     GP_HIP(hipStreamSynchronize(s2));
     c->sync();
+    const double *hs = hres, *hg = hres + (size_t)NS * B;
+    const int *hst = reinterpret_cast<const int *>(hres + (size_t)(NS + 64) * B);
     if (c->prof_mode == 1) c->prof_collect();
     int worst = 0;
     for (int b = 0; b < B; ++b) {

@@ -307,6 +307,22 @@ struct gpcsd_ctx {
         }
         return reinterpret_cast<T *>(b.p);
     }
+    // page-locked host blocks: grow-only, keyed by name, freed in destroy (results that come back in ONE true asynchronous copy: a
+    // copy into pageable memory is staged and makes the host wait per call)
+    std::map<std::string, std::pair<void *, size_t>> pinned_bufs;
+    template <typename T = double>
+    T *pinned(const std::string &name, size_t count) {
+        const size_t bytes = std::max<size_t>(count * sizeof(T), sizeof(T));
+        auto &b = pinned_bufs[name];
+        if (b.second < bytes) {
+            if (b.first) GP_HIP(hipHostFree(b.first));
+            b.first = nullptr;
+            b.second = 0;
+            GP_HIP(hipHostMalloc(&b.first, bytes, hipHostMallocDefault));
+            b.second = bytes;
+        }
+        return reinterpret_cast<T *>(b.first);
+    }
     template <typename T = double>
     T *upload(const std::string &name, const T *host, size_t count) {
         T *d = buf<T>(name, count);

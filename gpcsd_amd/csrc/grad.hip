@@ -63,25 +63,37 @@ __global__ __launch_bounds__(256) void d_rowsums_kernel(const double *__restrict
     }
 }
 
-// b_i = sum_x es_x / D_xi; one thread per eigen-column i (coalesced across i)
+// b_i = sum_x es_x / D_xi.  A workgroup owns 32 eigen-columns (coalesced across i); eight row groups walk the rows x = g, g + 8, ..
+// in order and their partial sums are added in a fixed order.  (One thread per column over all nx rows -- nx dependent divisions
+// on two workgroups -- was 104 us of every objective + gradient evaluation at 384 x 500.)
+constexpr int DCS_COLS = 32, DCS_GROUPS = 8;
 __global__ __launch_bounds__(256) void d_colsums_kernel(const double *__restrict__ D, const double *__restrict__ es, int nx,
                                                         int nt, double *__restrict__ b) {
+    __shared__ double part[DCS_GROUPS][DCS_COLS];
     {                                           // blockIdx.y = hyper-parameter set
         const long q = blockIdx.y;
         D += q * nx * nt; es += q * nx; b += q * nt;
     }
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= nt) return;
+    const int col = threadIdx.x % DCS_COLS, g = threadIdx.x / DCS_COLS;
+    const int i = blockIdx.x * DCS_COLS + col;
     double s = 0.0;
-    for (int x = 0; x < nx; ++x) s += es[x] / D[(long)x * nt + i];
-    b[i] = s;
+    if (i < nt)
+        for (int x = g; x < nx; x += DCS_GROUPS) s += es[x] / D[(long)x * nt + i];
+    part[g][col] = s;
+    __syncthreads();
+    if (g == 0 && i < nt) {
+        double t = part[0][col];
+#pragma unroll
+        for (int k = 1; k < DCS_GROUPS; ++k) t += part[k][col];
+        b[i] = t;
+    }
 }
 
 void k_D_sums(gpcsd_ctx *c, const double *D, const double *es, const double *et, int nx, int nt, double *a, double *b,
               double *s1_out, hipStream_t s, int B, long s_s1) {
     double *s1row = c->buf<double>("grad_s1row", (size_t)nx * B);
     hipLaunchKernelGGL(d_rowsums_kernel, dim3(nx, B), dim3(256), 0, s, D, et, nt, a, s1row);
-    hipLaunchKernelGGL(d_colsums_kernel, dim3(ceil_div(nt, 256), B), dim3(256), 0, s, D, es, nx, nt, b);
+    hipLaunchKernelGGL(d_colsums_kernel, dim3(ceil_div(nt, DCS_COLS), B), dim3(256), 0, s, D, es, nx, nt, b);
     hipLaunchKernelGGL(final_sums_kernel, dim3(1, B), dim3(256), 0, s, (const double *)s1row, nx, s1_out, (long)nx, s_s1);
     GP_HIP(hipGetLastError());
 }
@@ -100,14 +112,17 @@ __global__ __launch_bounds__(256) void batch_reduce_kernel(const double *__restr
     const long e = (blockIdx.x * 256L + threadIdx.x) / LPE;
     const int g = threadIdx.x % LPE;
     const bool ok = e < (long)n * n;
+    const int i = ok ? (int)(e / n) : 0, j = ok ? (int)(e % n) : 0;
+    // every summand is a symmetric product (B diag(w) B^T), formed on and below the diagonal only (GemmDesc::lower: the tiles above
+    // it exit at once): an entry above the diagonal is its mirror image's sum -- half the flops, and the result exactly symmetric
+    const long src = j > i ? (long)j * n + i : e;
     double s = 0.0;
     if (ok)
-        for (int b = g; b < nb; b += LPE) s += in[b * stride + e];
+        for (int b = g; b < nb; b += LPE) s += in[b * stride + src];
 #pragma unroll
     for (int off = LPE / 2; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);   // (LPE lanes of an element sit in one wave)
     if (!ok || g != 0) return;
     s *= scale;
-    const int i = (int)(e / n), j = (int)(e % n);
     if (i == j) s += dscale * dvec[i];
     out[e] = s;
 }
@@ -188,7 +203,7 @@ void k_temporal_grad(gpcsd_ctx *c, const gpcsd_hparams *hp, const double *Gt, co
         p.sigma2[i] = hp->sigma2_t[i];
     }
     const int nblocks = 256, nb = tab ? B : 1;
-    double *part = c->buf<double>("grad_partials", (size_t)GR_MAXV * 1024 * nb);
+    double *part = c->buf<double>("grad_partials_t", (size_t)GR_MAXV * 1024 * nb);      // (own scratch: runs beside the spatial half, capi_grad.inl)
     // the sums land directly in the caller's gradient vector(s): 2 * n_temporal values per set, s_out apart
     hipLaunchKernelGGL(temporal_grad_kernel, dim3(nblocks, nb), dim3(256), 0, s, p, Gt, t, nt, part, tab);
     hipLaunchKernelGGL(final_sums_kernel, dim3(2 * hp->n_temporal, nb), dim3(256), 0, s, (const double *)part, nblocks, out2C,
@@ -229,7 +244,7 @@ __global__ __launch_bounds__(256) void frob_inner_kernel(const double *__restric
 void k_frob_inner(gpcsd_ctx *c, const double *Gt, const double *dK, long n2, int nm, double *out, hipStream_t s) {
     GP_REQUIRE(nm >= 1 && nm <= GR_MAXV, -3, "frob_inner: %d matrices (max %d)", nm, GR_MAXV);
     const int nblocks = 256;
-    double *part = c->buf<double>("grad_partials", (size_t)GR_MAXV * 1024);
+    double *part = c->buf<double>("grad_partials_t", (size_t)GR_MAXV * 1024);      // (own scratch: runs beside the spatial half, capi_grad.inl)
     hipLaunchKernelGGL(frob_inner_kernel, dim3(nblocks), dim3(256), 0, s, Gt, dK, n2, nm, part);
     hipLaunchKernelGGL(final_sums_kernel, dim3(nm, 1), dim3(256), 0, s, (const double *)part, nblocks, out, (long)GR_MAXV * 1024, 0L);
     GP_HIP(hipGetLastError());
@@ -271,6 +286,35 @@ void k_kgl_grad(gpcsd_ctx *c, const double *M, const double *Kgl, const double *
     hipLaunchKernelGGL(kgl_grad_kernel, dim3(nblocks, nb), dim3(256), 0, s, M, Kgl, gx1, gx2, G, ngl2, ell1, ell2, part, tab);
     hipLaunchKernelGGL(final_sums_kernel, dim3(ngl2 > 0 ? 2 : 1, nb), dim3(256), 0, s, (const double *)part, nblocks, out2,
                        (long)GR_MAXV * 1024, s_out);
+    GP_HIP(hipGetLastError());
+}
+
+// ---- spatial length scales on the 2D tensor grid: Kgl = K1 (x) K2 (covariances.py:216), so
+//   <A^T Gs A, dKgl/dell1> = <Gs A, A (dK1 (x) K2)>,   <A^T Gs A, dKgl/dell2> = <Gs A, A (K1 (x) dK2)>:
+// two elementwise inner products of nx x G matrices (the factors A (dK1 (x) K2), A (K1 (x) dK2) are Kronecker-structured small
+// products, capi_grad.inl) instead of the G x G contraction of A^T (Gs A) with dKgl (1.1 GF + 2 x 1.44 M kernel terms at 384 x 1200).
+__global__ __launch_bounds__(256) void frob_pair_kernel(const double *__restrict__ P, const double *__restrict__ T1,
+                                                        const double *__restrict__ T2, long n, double *partials) {
+    {                                           // blockIdx.y = hyper-parameter set: operands n apart, partials GR_MAXV*1024 apart
+        const long b = blockIdx.y;
+        P += b * n; T1 += b * n; T2 += b * n;
+        partials += b * GR_MAXV * 1024;
+    }
+    double v[2] = {0.0, 0.0};
+    for (long e = blockIdx.x * 256L + threadIdx.x; e < n; e += (long)gridDim.x * 256) {
+        const double p = P[e];
+        v[0] += p * T1[e];
+        v[1] += p * T2[e];
+    }
+    block_partials<2>(v, partials, gridDim.x, blockIdx.x);
+}
+
+void k_frob_pair(gpcsd_ctx *c, const double *P, const double *T1, const double *T2, long n, double *out2, hipStream_t s, int B,
+                 long s_out) {
+    const int nblocks = 256;
+    double *part = c->buf<double>("grad_partials", (size_t)GR_MAXV * 1024 * B);
+    hipLaunchKernelGGL(frob_pair_kernel, dim3(nblocks, B), dim3(256), 0, s, P, T1, T2, n, part);
+    hipLaunchKernelGGL(final_sums_kernel, dim3(2, B), dim3(256), 0, s, (const double *)part, nblocks, out2, (long)GR_MAXV * 1024, s_out);
     GP_HIP(hipGetLastError());
 }
 

@@ -1125,6 +1125,29 @@ void k_se_axis(gpcsd_ctx *c, const double *a, int n, double ell, double *out, hi
     GP_HIP(hipGetLastError());
 }
 
+// The same factor and its derivative w.r.t. the length scale for every hyper-parameter set of a batched evaluation
+// (blockIdx.y = set, ell = tab[set].ell_s[axis]): K = exp(-0.5 d^2 / ell^2), dK = K d^2 / ell^3 -- the per-axis pieces of
+// dKgl/dell1 = dK1 (x) K2 and dKgl/dell2 = K1 (x) dK2 (the gradient's Kronecker form, grad.hip: k_frob_pair).
+template <typename T>
+__global__ __launch_bounds__(256) void se_axis_tab_kernel(const double *__restrict__ a, int n, int axis, const HpDev *__restrict__ tab,
+                                                          double *__restrict__ K, double *__restrict__ dK) {
+    const T ell = T(tab[blockIdx.y].ell_s[axis]);
+    K += (long)blockIdx.y * n * n;
+    dK += (long)blockIdx.y * n * n;
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < n * n; e += gridDim.x * 256) {
+        const T d = T(a[e / n]) - T(a[e % n]);
+        const T k = exp(T(-0.5) * (d * d) / (ell * ell));
+        K[e] = (double)k;
+        dK[e] = (double)(k * (d * d) / (ell * ell * ell));
+    }
+}
+void k_se_axis_tab(gpcsd_ctx *c, const double *a, int n, int axis, const HpDev *tab, int B, double *K, double *dK, hipStream_t s) {
+    const int grid = ceil_div((long)n * n, 256);
+    if (c->gram_fp32) hipLaunchKernelGGL(se_axis_tab_kernel<float>, dim3(grid, B), dim3(256), 0, s, a, n, axis, tab, K, dK);
+    else hipLaunchKernelGGL(se_axis_tab_kernel<double>, dim3(grid, B), dim3(256), 0, s, a, n, axis, tab, K, dK);
+    GP_HIP(hipGetLastError());
+}
+
 __global__ void add_diag_kernel(double *A, int n, double v, const HpDev *__restrict__ tab, long s_out) {
     if (tab) {
         v = tab[blockIdx.z].jitter;

@@ -126,6 +126,8 @@ void k_se_2d(gpcsd_ctx *c, const double *a1, const double *a2, int na, int na2, 
              long s_out = 0);
 // one axis factor of the tensor-grid SE kernel: out(n,n) = exp(-0.5 (a_i - a_j)^2 / ell^2)
 void k_se_axis(gpcsd_ctx *c, const double *a, int n, double ell, double *out, hipStream_t s);
+// ... and with its derivative w.r.t. the length scale, for the B sets of a batched evaluation (ell = tab[set].ell_s[axis])
+void k_se_axis_tab(gpcsd_ctx *c, const double *a, int n, int axis, const HpDev *tab, int B, double *K, double *dK, hipStream_t s);
 // Log-likelihood pieces in the basis U (x) Q (gram.hip): with Kt_p = amax_p Q_p T_p Q_p^T (T_p tridiagonal: d_p, e_p) the
 // block of Ks (x) Kt + sig2 I of spatial eigen-row x' and temporal parity p is Q_p (es[x'] amax_p T_p + sig2 I) Q_p^T;
 // *out_sumlog = sum of the log pivots of all these tridiagonal matrices (= sum log D), *out_quad = sum over the rows w of
@@ -349,6 +351,9 @@ void k_repeat_rows(gpcsd_ctx *c, const double *in, long s_in, int n, int R, int 
 // out[k] = <Gt, dK_k> for nm matrices dK_k (n2 doubles each, contiguous): user-defined temporal covariances
 void k_frob_inner(gpcsd_ctx *c, const double *Gt, const double *dK, long n2, int nm, double *out, hipStream_t s);
 // out[0..1] = <M, dKgl/d ell_1>, <M, dKgl/d ell_2>   (ngl2 == 0: 1D, only out[0] meaningful)
+// out2[set * s_out + q] = <P, T_q>, q = 0, 1: the two spatial length-scale derivatives in the Kronecker form (grad.hip)
+void k_frob_pair(gpcsd_ctx *c, const double *P, const double *T1, const double *T2, long n, double *out2, hipStream_t s, int B,
+                 long s_out);
 void k_kgl_grad(gpcsd_ctx *c, const double *M, const double *Kgl, const double *gx1, const double *gx2, int G, int ngl2,
                 double ell1, double ell2, double *out2, hipStream_t s, const HpDev *tab = nullptr, int B = 1, long s_out = 0);
 // out[0] = 2 <S, dA/dR>

@@ -254,7 +254,7 @@ __global__ __launch_bounds__(WQ_NT) void wy_qstage_kernel(WyBatch b, int p0, int
         ++nst;
     };
     // ---- gate
-    __shared__ bool gate_failed;
+    int gate_failed = 0;
     if (tid == 0) {
         const unsigned target = (p + 1 < P.npanels) ? (unsigned)(WY_NB * (p + 1)) : WY_PROG_DONE;
         const unsigned *prog = reinterpret_cast<const unsigned *>(P.tau + n + WY_NB);
@@ -279,8 +279,12 @@ __global__ __launch_bounds__(WQ_NT) void wy_qstage_kernel(WyBatch b, int p0, int
             b.clk[3 * (p * 4 + blockIdx.y) + 2] = *reinterpret_cast<const unsigned long long *>(P.tau + n + WY_NB + 1);
         }
     }
+    // thread 0's verdict through the first word of the (not yet used) dynamic LDS: a static flag or __syncthreads_or's own would
+    // take static LDS out of the 160 KB the launch asks for as dynamic
+    if (tid == 0) reinterpret_cast<volatile int *>(smem)[0] = gate_failed;
     __syncthreads();
-    if (gate_failed) return;                              // (LDS flag, uniform over the workgroup)
+    gate_failed = reinterpret_cast<volatile int *>(smem)[0];
+    if (gate_failed) return;
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");    // every wave reads the panel the tail's workgroup has just released
     __builtin_amdgcn_s_setprio(3);                        // (on the log-likelihood's critical path, beside a flood of GEMM tiles)
     stamp();

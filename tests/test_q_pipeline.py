@@ -186,9 +186,9 @@ def test_a_gate_that_gives_up_is_a_scheduling_miss_and_the_call_is_evaluated_aga
             ll_class = float(m.loglik())
             ctx.q_pipeline(True)
             m.predict(z, w["t"], type="csd")
+        got_pr = ctx.fetch("pred_out_csd", (z.shape[0], w["nt"], R)).copy()     # (collects a queued prediction's status first)
         on1, miss1 = ctx.q_pipeline_stats()
         assert not on1 and miss1 >= 1, (on1, miss1)           # latched off, counted
-        got_pr = ctx.fetch("pred_out_csd", (z.shape[0], w["nt"], R)).copy()
         if form == "class_api":
             assert ll_class == -0.5 * R * want_ll[0] - 0.5 * want_ll[1]
             assert np.array_equal(np.asarray(m.csd_pred), want_pr)

@@ -22,7 +22,7 @@ step 400 bench_cfg3fit.txt python bench.py --workload cfg3fit --steps 40 --warmu
 tail -c 3000 $OUT/bench_cfg3fit.txt
 cp bench_detail.json $OUT/bench_detail_cfg3fit.json 2>/dev/null
 cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
-step 300 prof_fit.txt rocprofv3 --kernel-trace --stats -d $OUT/prof_fit -o fit -- python3 bench.py --workload cfg3fit --only-value --fit-batch 1 --steps 30 --warmup 3
+step 300 prof_fit.txt rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_fit -o fit -- python3 bench.py --workload cfg3fit --only-value --fit-batch 1 --steps 30 --warmup 3
 fi
 if [ "$1" = "stall" ] || [ "$1" = "all" ]; then
 for v in "base:" "keep:--keep" "close:--close" "noann:--no-announce" "pin:--pin-lfp"; do
