@@ -190,6 +190,7 @@ SIGNATURES = {
     "gpcsd_pair_share_s": (_I, [_P, _I, ctypes.POINTER(_L)]),
     "gpcsd_band_tail": (_I, [_P, _I, ctypes.POINTER(_L)]),
     "gpcsd_q_pipeline": (_I, [_P, _I, ctypes.POINTER(_L)]),
+    "gpcsd_bounce_stats": (_I, [_P, ctypes.POINTER(_L)]),
     "gpcsd_q_pipeline_stats": (_I, [_P, ctypes.POINTER(_I), ctypes.POINTER(_L), ctypes.c_longlong]),
     "gpcsd_predict_chunked_copy": (_I, [_P, _I, ctypes.POINTER(_L)]),
     "gpcsd_debug_sybrd": (_I, [_P, _DP, _I, _DP, _DP, _DP]),
@@ -902,6 +903,13 @@ class Context:
         (DESIGN 4.12); returns the number of temporal chains that took it."""
         n = _L(0)
         self._check(self._lib.gpcsd_q_pipeline(self._h, -1 if on is None else int(bool(on)), ctypes.byref(n)))
+        return int(n.value)
+
+    def bounce_stats(self):
+        """Bytes moved between pageable caller memory and the device through the context's page-locked bounce blocks (the library
+        never hands pageable memory to the runtime: DESIGN 6, the queue-eviction stall)."""
+        n = _L(0)
+        self._check(self._lib.gpcsd_bounce_stats(self._h, ctypes.byref(n)))
         return int(n.value)
 
     def q_pipeline_stats(self, gate_ticks=None):

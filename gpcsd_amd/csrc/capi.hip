@@ -281,8 +281,7 @@ void temporal_cross_gram(gpcsd_ctx *c, const gpcsd_hparams *hp, int cc, const do
                        c->host_kt_cross.size() == (size_t)hp->n_temporal * ntstar * nt, -3,
                    "predict with user-defined temporal covariances needs the per-component cross Grams "
                    "(gpcsd_set_host_temporal_gram: Kt_cross of shape (%d, %d, %d))", hp->n_temporal, ntstar, nt);
-        GP_HIP(hipMemcpyAsync(out, c->host_kt_cross.data() + (size_t)cc * ntstar * nt, (size_t)ntstar * nt * sizeof(double),
-                              hipMemcpyHostToDevice, s));
+        c->copy_in(out, c->host_kt_cross.data() + (size_t)cc * ntstar * nt, (size_t)ntstar * nt * sizeof(double), s);
         return;
     }
     k_temporal_gram(c, 1, &hp->kind[cc], &hp->ell_t[cc], &hp->sigma2_t[cc], dts, ntstar, t, nt, out, s);
@@ -360,7 +359,7 @@ SymDev find_symmetry(gpcsd_ctx *c, const std::string &name, const double *pts, i
             ++a;
         }
     int *d = c->buf<int>(name, tbl.size());
-    GP_HIP(hipMemcpyAsync(d, tbl.data(), tbl.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
+    c->copy_in(d, tbl.data(), tbl.size() * sizeof(int), c->stream);
     GP_HIP(hipStreamSynchronize(c->stream));
     out.ns = ns; out.na = na;
     out.rep_i = d; out.rep_j = d + ns; out.orb = d + 2 * ns; out.sgn = d + 2 * ns + n;
@@ -611,7 +610,7 @@ EigState front_half(gpcsd_ctx *c, const gpcsd_hparams *hp, double jitter, bool n
     // a caller-supplied Gram need not commute with the reflection of the time grid (non-stationary kernels): no folding
     const SymDev *sym_s = c->sym_s.ns > 0 ? &c->sym_s : nullptr, *sym_t = (c->sym_t.ns > 0 && !host_kt) ? &c->sym_t : nullptr;
     auto make_kt = [&](hipStream_t st) {
-        if (host_kt) GP_HIP(hipMemcpyAsync(Kt, c->host_kt.data(), (size_t)nt * nt * sizeof(double), hipMemcpyHostToDevice, st));
+        if (host_kt) c->copy_in(Kt, c->host_kt.data(), (size_t)nt * nt * sizeof(double), st);
         else build_kt(c, hp, t, nt, t, nt, Kt, st);
     };
     // The status words are zeroed at the END of the previous call (finish_call / finish_status), off the critical path of
@@ -817,7 +816,7 @@ static SymDev identity_sym(gpcsd_ctx *c, int n) {
             tbl[2 * n + i] = i;          // orb
             tbl[3 * n + i] = 0;          // sgn
         }
-        GP_HIP(hipMemcpyAsync(d, tbl.data(), tbl.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
+        c->copy_in(d, tbl.data(), tbl.size() * sizeof(int), c->stream);
         GP_HIP(hipStreamSynchronize(c->stream));
         have = n;
         c->sym_host[d] = std::vector<int>(tbl.begin(), tbl.begin() + 2 * n);
@@ -1176,6 +1175,10 @@ extern "C" int gpcsd_ctx_destroy(gpcsd_ctx *c) {
     if (c->stage_ring) (void)hipHostFree(c->stage_ring);
     for (auto &kv : c->pinned_bufs)
         if (kv.second.first) (void)hipHostFree(kv.second.first);
+    for (int k = 0; k < 2; ++k) {
+        if (c->bounce[k]) (void)hipHostFree(c->bounce[k]);
+        if (c->bounce_ev[k]) (void)hipEventDestroy(c->bounce_ev[k]);
+    }
     if (c->tail_clk_host) (void)hipHostFree(c->tail_clk_host);
     for (auto &sl : c->ll_slot)
         if (sl.ev) (void)hipEventDestroy(sl.ev);

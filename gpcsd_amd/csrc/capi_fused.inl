@@ -1246,7 +1246,12 @@ extern "C" int gpcsd_predict(gpcsd_ctx *c, const gpcsd_hparams *hp, const double
     // the caller's arrays are known to the tail: a folded prediction copies its outputs out chunk by chunk under its last product
     gpcsd_ctx::PredSink &sk = c->pred_sink;
     sk = gpcsd_ctx::PredSink();
+    // (... into page-locked arrays only -- the class API's come from its pinned pool.  Pageable arrays of another caller are
+    // filled through the context's bounce blocks after the product: the runtime never gets to register the caller's pages,
+    // ctx.hpp copy_in / copy_out)
     sk.active = true;
+    for (const double *p : {csd, csd_list, lfp, lfp_list})
+        if (p && !gpcsd_ctx::host_is_pinned(p)) sk.active = false;
     sk.sum[0] = csd; sk.list[0] = csd_list; sk.sum[1] = lfp; sk.list[1] = lfp_list;
     int rc;
     try {
@@ -1311,7 +1316,7 @@ extern "C" int gpcsd_sample_prior(gpcsd_ctx *c, const gpcsd_hparams *hp, int whi
     }
     if (uses_host_kt(hp)) {
         GP_REQUIRE(c->host_kt_nt == nt && (int)c->host_kt.size() == nt * nt, -3, "host temporal Gram does not match nt=%d", nt);
-        GP_HIP(hipMemcpyAsync(Kt, c->host_kt.data(), (size_t)nt * nt * sizeof(double), hipMemcpyHostToDevice, s));
+        c->copy_in(Kt, c->host_kt.data(), (size_t)nt * nt * sizeof(double), s);
     } else {
         build_kt(c, hp, t, nt, t, nt, Kt, s);
     }

@@ -123,7 +123,7 @@ static int loglik_grad_impl(gpcsd_ctx *c, const gpcsd_hparams *hps, int B, doubl
         const EigArenaView as = eigh_arena_view(c, tg[0], sym_t->ns, B), aa = eigh_arena_view(c, tg[1], sym_t->na, B);
         k_temporal_fold_fill_tab(c, tab, B, t, nt, *sym_t, as, aa, st + B, 1, s2, variances_nonneg);
     } else if (host_kt) {
-        GP_HIP(hipMemcpyAsync(Kt, c->host_kt.data(), (size_t)ntt * sizeof(double), hipMemcpyHostToDevice, s2));
+        c->copy_in(Kt, c->host_kt.data(), (size_t)ntt * sizeof(double), s2);
     } else {
         k_temporal_gram(c, C, nullptr, nullptr, nullptr, t, nt, t, nt, Kt, s2, tab, B, ntt);
     }

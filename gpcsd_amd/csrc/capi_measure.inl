@@ -168,7 +168,10 @@ extern "C" int gpcsd_potrf_gate_timeouts(gpcsd_ctx *c, long *count) {
     GP_REQUIRE(count != nullptr, -3, "potrf_gate_timeouts: null output");
     unsigned int w[2] = {0u, 0u};
     c->sync();
-    if (c->h_chol_flag) GP_HIP(hipMemcpy(w, c->h_chol_flag, sizeof(w), hipMemcpyDeviceToHost));
+    if (c->h_chol_flag) {
+        GP_HIP(hipDeviceSynchronize());
+        c->copy_out(w, c->h_chol_flag, sizeof(w), c->stream);
+    }
     *count = (long)w[1];
     return 0;
     GP_API_END(c)

@@ -265,7 +265,7 @@ extern "C" int gpcsd_debug_stedc(gpcsd_ctx *c, const double *d, const double *e,
     double *dd = c->upload<double>("dbg_d", d, n);
     double *de = c->buf<double>("dbg_e", n);
     GP_HIP(hipMemsetAsync(de, 0, n * sizeof(double), c->stream));
-    if (n > 1) GP_HIP(hipMemcpyAsync(de, e, (n - 1) * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    if (n > 1) c->copy_in(de, e, (n - 1) * sizeof(double), c->stream);
     double *dw = c->buf<double>("op_w", n);
     double *dZ = c->buf<double>("op_out", (size_t)n * n);
     int *st = c->buf<int>("status", 4);
@@ -641,6 +641,13 @@ extern "C" int gpcsd_q_pipeline(gpcsd_ctx *c, int on, long *calls) {
     GP_API_BEGIN(c)
     if (on >= 0) c->q_pipe = on != 0;
     if (calls) *calls = c->q_pipe_calls;
+    return 0;
+    GP_API_END(c)
+}
+
+extern "C" int gpcsd_bounce_stats(gpcsd_ctx *c, long *bytes) {
+    GP_API_BEGIN(c)
+    if (bytes) *bytes = c->bounced_bytes;
     return 0;
     GP_API_END(c)
 }

@@ -323,10 +323,91 @@ struct gpcsd_ctx {
         }
         return reinterpret_cast<T *>(b.first);
     }
+    // ---- host <-> device copies never hand the CALLER'S pageable memory to the runtime ----
+    // A hipMemcpy whose host side is pageable makes the runtime register the caller's pages with the driver (a "userptr" mapping)
+    // and keep that registration in a cache.  When those pages are later unmapped, trimmed or migrated -- the NumPy array is freed,
+    // its allocator gives the range back -- the driver's MMU notifier EVICTS EVERY QUEUE OF THE PROCESS and restores them one to
+    // three timer ticks later: 9 / 19 / 29 ms in which no kernel of the process runs, somewhere inside a later step loop (DESIGN 6,
+    // tools/stall_probe.py: 4 of 8 successive models stalled; 0 of 8 with the trials uploaded from page-locked memory).  Every
+    // transfer whose host side is not page-locked therefore goes through two page-locked bounce blocks of the context: one host
+    // memcpy per 4 MB chunk, overlapped with the previous chunk's DMA.
+    static constexpr size_t BOUNCE_BYTES = 4u << 20;
+    unsigned char *bounce[2] = {nullptr, nullptr};
+    hipEvent_t bounce_ev[2] = {nullptr, nullptr};
+    bool bounce_busy[2] = {false, false};
+    long bounced_bytes = 0;                 // bytes that took the bounce path (tests read it through gpcsd_bounce_stats)
+    static bool host_is_pinned(const void *p) {
+        hipPointerAttribute_t a;
+        if (hipPointerGetAttributes(&a, p) != hipSuccess) {
+            (void)hipGetLastError();         // (plain malloc / mmap memory: "invalid value", not an error here)
+            return false;
+        }
+        return a.type == hipMemoryTypeHost;
+    }
+    void bounce_init() {
+        for (int k = 0; k < 2; ++k) {
+            if (!bounce[k]) GP_HIP(hipHostMalloc(reinterpret_cast<void **>(&bounce[k]), BOUNCE_BYTES, hipHostMallocDefault));
+            if (!bounce_ev[k]) GP_HIP(hipEventCreateWithFlags(&bounce_ev[k], hipEventDisableTiming));
+        }
+    }
+    void bounce_wait(int k) {
+        if (bounce_busy[k]) GP_HIP(hipEventSynchronize(bounce_ev[k]));
+        bounce_busy[k] = false;
+    }
+    // host -> device on stream st; the host range may be reused when this returns (as with a pageable hipMemcpyAsync)
+    void copy_in(void *dev, const void *host, size_t bytes, hipStream_t st) {
+        if (bytes == 0) return;
+        if (capturing || host_is_pinned(host)) {        // (nothing is uploaded inside a stream capture; kept as it was if it ever is)
+            GP_HIP(hipMemcpyAsync(dev, host, bytes, hipMemcpyHostToDevice, st));
+            return;
+        }
+        if (bytes <= STAGE_SLOT && st == stream) {      // (the ring of small slots is fenced against the main stream)
+            GP_HIP(hipMemcpyAsync(dev, stage_small(host, bytes), bytes, hipMemcpyHostToDevice, st));
+            return;
+        }
+        bounce_init();
+        bounced_bytes += (long)bytes;
+        int k = 0;
+        for (size_t off = 0; off < bytes; off += BOUNCE_BYTES, k ^= 1) {
+            const size_t n = std::min(BOUNCE_BYTES, bytes - off);
+            bounce_wait(k);
+            memcpy(bounce[k], static_cast<const unsigned char *>(host) + off, n);
+            GP_HIP(hipMemcpyAsync(static_cast<unsigned char *>(dev) + off, bounce[k], n, hipMemcpyHostToDevice, st));
+            GP_HIP(hipEventRecord(bounce_ev[k], st));
+            bounce_busy[k] = true;
+        }
+    }
+    // device -> host on stream st.  Page-locked destination: queued, the caller synchronises (as before).  Pageable destination:
+    // through the bounce blocks, complete on return (what a pageable hipMemcpyAsync amounts to as well).
+    void copy_out(void *host, const void *dev, size_t bytes, hipStream_t st) {
+        if (bytes == 0) return;
+        if (host_is_pinned(host)) {
+            GP_HIP(hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, st));
+            return;
+        }
+        bounce_init();
+        bounced_bytes += (long)bytes;
+        size_t prev_off = 0, prev_n = 0;
+        int k = 0, prev_k = -1;
+        for (size_t off = 0; off < bytes; off += BOUNCE_BYTES, k ^= 1) {
+            const size_t n = std::min(BOUNCE_BYTES, bytes - off);
+            bounce_wait(k);
+            GP_HIP(hipMemcpyAsync(bounce[k], static_cast<const unsigned char *>(dev) + off, n, hipMemcpyDeviceToHost, st));
+            GP_HIP(hipEventRecord(bounce_ev[k], st));
+            bounce_busy[k] = true;
+            if (prev_k >= 0) {
+                bounce_wait(prev_k);
+                memcpy(static_cast<unsigned char *>(host) + prev_off, bounce[prev_k], prev_n);
+            }
+            prev_k = k; prev_off = off; prev_n = n;
+        }
+        bounce_wait(prev_k);
+        memcpy(static_cast<unsigned char *>(host) + prev_off, bounce[prev_k], prev_n);
+    }
     template <typename T = double>
     T *upload(const std::string &name, const T *host, size_t count) {
         T *d = buf<T>(name, count);
-        if (count) GP_HIP(hipMemcpyAsync(d, host, count * sizeof(T), hipMemcpyHostToDevice, stream));
+        if (count) copy_in(d, host, count * sizeof(T), stream);
         if (!upload_shadow.empty()) upload_shadow.erase(name);       // a plain upload makes any cached image of this buffer stale
         return d;
     }
@@ -341,7 +422,7 @@ struct gpcsd_ctx {
         const long epoch_before = alloc_epoch;
         T *d = buf<T>(name, count);
         if (alloc_epoch == epoch_before && sh.size() == bytes && bytes > 0 && memcmp(sh.data(), host, bytes) == 0) return d;
-        if (count) GP_HIP(hipMemcpyAsync(d, stage_small(host, bytes), bytes, hipMemcpyHostToDevice, stream));
+        if (count) copy_in(d, host, bytes, stream);
         ++upload_count;
         sh.assign(reinterpret_cast<const unsigned char *>(host), reinterpret_cast<const unsigned char *>(host) + bytes);
         return d;
@@ -369,9 +450,7 @@ struct gpcsd_ctx {
         memcpy(slot, host, bytes);
         return slot;
     }
-    void download(void *host, const void *dev, size_t bytes) {
-        GP_HIP(hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, stream));
-    }
+    void download(void *host, const void *dev, size_t bytes) { copy_out(host, dev, bytes, stream); }
     void sync() { GP_HIP(hipStreamSynchronize(stream)); }
 
     hipEvent_t get_event() {

@@ -930,7 +930,7 @@ void k_tridiag_solve(gpcsd_ctx *c, const double *W, double *B, const double *es,
     GP_HIP(hipGetLastError());
     if (clk_on) {
         unsigned long long h[8];
-        GP_HIP(hipMemcpyAsync(h, g.clk, sizeof(h), hipMemcpyDeviceToHost, s));
+        c->copy_out(h, g.clk, sizeof(h), s);
         GP_HIP(hipStreamSynchronize(s));
         fprintf(stderr, "[tridiag_solve] item 0 (10 ns ticks): load+pivots %llu  forward %llu  backward %llu  store %llu\n", h[1] - h[0],
                 h[2] - h[1], h[3] - h[2], h[4] - h[3]);

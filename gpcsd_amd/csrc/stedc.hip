@@ -1137,7 +1137,7 @@ static DcWork make_work(gpcsd_ctx *c, const StedcProb &p, const DcPlan &plan, hi
     int *dtbl = c->buf<int>(PN, plan.tbl.size() + 4);
     int &cached_n = c->int_cache[PN];
     if (cached_n != n) {
-        GP_HIP(hipMemcpyAsync(dtbl, plan.tbl.data(), plan.tbl.size() * sizeof(int), hipMemcpyHostToDevice, s));
+        c->copy_in(dtbl, plan.tbl.data(), plan.tbl.size() * sizeof(int), s);
         GP_HIP(hipStreamSynchronize(s));  // plan is a temporary of the caller
         cached_n = n;
     }

@@ -489,7 +489,7 @@ static bool wy_clk_on() {
 }
 static void wy_clk_print(gpcsd_ctx *c, unsigned long long *d, const char *what, int first, int n, hipStream_t s) {
     unsigned long long h[32];
-    GP_HIP(hipMemcpyAsync(h, d, sizeof(h), hipMemcpyDeviceToHost, s));
+    c->copy_out(h, d, sizeof(h), s);
     GP_HIP(hipStreamSynchronize(s));
     fprintf(stderr, "[%s] phases (10 ns ticks):", what);
     for (int i = first + 1; i < first + n; ++i) fprintf(stderr, " %llu", h[i] >= h[i - 1] ? h[i] - h[i - 1] : 0ull);

@@ -269,6 +269,13 @@ int gpcsd_predict_resident(gpcsd_ctx *ctx, const gpcsd_hparams *hp, const double
 /* copy `count` doubles of the named ctx-owned device buffer to host; rc -2 if the name is unknown; rc > 0 if the
  * asynchronous gpcsd_predict_resident that produced the buffer failed numerically */
 int gpcsd_fetch(gpcsd_ctx *ctx, const char *name, double *host, long count);
+/* Bytes this context has moved between the caller's PAGEABLE host memory and the device through its own page-locked bounce blocks.
+ * The library never passes pageable caller memory to the HIP runtime: the runtime would register those pages with the driver and
+ * keep the registration cached, and when the pages are later freed or moved the driver evicts every queue of the process for
+ * 10-30 ms (measured: one such stall in every second later step loop of a process, none with this in place).  Arrays in
+ * page-locked memory (gpcsd_host_alloc; the class API's results) are copied directly.  No reference counterpart (NumPy arrays
+ * in, NumPy arrays out: gpcsd1d.py:21-62). */
+int gpcsd_bounce_stats(gpcsd_ctx *ctx, long *bytes);
 /* The device address and size in bytes of the same named buffer, for callers that go on working on the GPU instead of copying out:
  * the posterior means gpcsd_predict_resident leaves in HBM ("pred_out_csd", "pred_out_csd_list", "pred_out_lfp",
  * "pred_out_lfp_list": gpcsd1d.py:286-293 / gpcsd2d.py:327-334, layout (nz, nt, ntrials) / (C, nz, nt, ntrials)) gathered over the

@@ -171,6 +171,9 @@ def test_three_models_in_one_process_have_no_step_interval_above_3_ms():
         w, m, lfp = _step_model(200, "cfg2", seed=100 + loop)
         ctx = m._sync_device()
         ctx.decomposition_cache(False)
+        # the cause that was found: pageable uploads made the runtime register the caller's pages with the driver, whose MMU notifier
+        # later evicted every queue of the process.  The trials (a pageable NumPy array here) went through the bounce blocks:
+        assert ctx.bounce_stats() >= lfp.nbytes
         hp, k1 = m._hparams(m.JITTER)
         hp0, k0 = m._hparams(0.0)
 
