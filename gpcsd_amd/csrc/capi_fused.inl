@@ -281,7 +281,18 @@ extern "C" int gpcsd_loglik_parts_wait(gpcsd_ctx *c, double *out2) {
         out2[1] = sl.out[1];
         return sl.rc;
     }
-    GP_HIP(hipEventSynchronize(sl.ev));
+    {
+        // GPCSD_LL_WAIT=spin: poll the event instead of blocking in hipEventSynchronize (A/B for DESIGN 6's stall: does a blocked
+        // host wait miss its wake-up?)
+        static const bool spin = getenv("GPCSD_LL_WAIT") && !strcmp(getenv("GPCSD_LL_WAIT"), "spin");
+        if (spin) {
+            hipError_t q;
+            while ((q = hipEventQuery(sl.ev)) == hipErrorNotReady) {}
+            if (q != hipSuccess) GP_HIP(q);
+        } else {
+            GP_HIP(hipEventSynchronize(sl.ev));
+        }
+    }
     const double *host = c->h_ll + gpcsd_ctx::RESULT_DOUBLES * k;
     out2[0] = host[0];
     out2[1] = sl.two ? host[1] + host[2] : host[1];

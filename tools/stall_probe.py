@@ -51,8 +51,15 @@ for loop in range(nloops):
         if announce:
             ctx.prefetch_pair(hp, hp0, z, w["t"])
         return ctx.loglik_parts_wait()
+    t_first_call = time.perf_counter()                    # the model's device allocations happen in its first evaluations
+    warm_stamps = [t_first_call]
     for _ in range(60):
         step()
+        warm_stamps.append(time.perf_counter())
+    if "--settle" in flags:                               # keep stepping (untimed) until 0.45 s after the first evaluation
+        while time.perf_counter() - t_first_call < 0.45:
+            step()
+            warm_stamps.append(time.perf_counter())
     ctx.synchronize()
     setup_s = time.perf_counter() - t_setup
     stamps = [time.perf_counter()]
@@ -60,10 +67,15 @@ for loop in range(nloops):
         step()
         stamps.append(time.perf_counter())
     ctx.synchronize()
-    iv = 1e3 * np.diff(np.array(stamps))
+    st = np.array(stamps)
+    iv = 1e3 * np.diff(st)
+    wiv = 1e3 * np.diff(np.array(warm_stamps))
     worst = int(np.argmax(iv))
     out.append({"loop": loop, "median_ms": round(float(np.median(iv)), 4), "mean_ms": round(float(iv.mean()), 4),
-                "max_ms": round(float(iv.max()), 3), "at_step": worst, "over_2ms": int(np.sum(iv > 2.0)), "setup_s": round(setup_s, 2)})
+                "max_ms": round(float(iv.max()), 3), "at_step": worst, "over_2ms": int(np.sum(iv > 2.0)), "setup_s": round(setup_s, 2),
+                "stall_s_after_first_evaluation": [round(float(st[i + 1] - t_first_call), 3) for i in np.nonzero(iv > 3.0)[0]],
+                "untimed_stalls_s_after_first_evaluation": [(round(float(warm_stamps[i + 1] - t_first_call), 3), round(float(wiv[i]), 1))
+                                                            for i in np.nonzero(wiv > 3.0)[0] if i >= 3]})
     if "--keep" in flags:
         keepalive.append((m, ctx, lfp))
     prev = (m, ctx)
