@@ -336,6 +336,16 @@ struct gpcsd_ctx {
     hipEvent_t bounce_ev[2] = {nullptr, nullptr};
     bool bounce_busy[2] = {false, false};
     long bounced_bytes = 0;                 // bytes that took the bounce path (tests read it through gpcsd_bounce_stats)
+    // the context's own page-locked blocks (results, staging, pool): no query needed for those
+    bool own_pinned(const void *p) const {
+        auto in = [p](const void *b, size_t n) { return b && p >= b && p < static_cast<const unsigned char *>(b) + n; };
+        if (in(h_result, RESULT_DOUBLES * sizeof(double)) || in(h_ll, (size_t)LL_SLOTS * RESULT_DOUBLES * sizeof(double)) ||
+            in(stage_ring, STAGE_SLOT * STAGE_SLOTS) || in(bounce[0], BOUNCE_BYTES) || in(bounce[1], BOUNCE_BYTES))
+            return true;
+        for (const auto &kv : pinned_bufs)
+            if (in(kv.second.first, kv.second.second)) return true;
+        return false;
+    }
     static bool host_is_pinned(const void *p) {
         hipPointerAttribute_t a;
         if (hipPointerGetAttributes(&a, p) != hipSuccess) {
@@ -357,7 +367,7 @@ struct gpcsd_ctx {
     // host -> device on stream st; the host range may be reused when this returns (as with a pageable hipMemcpyAsync)
     void copy_in(void *dev, const void *host, size_t bytes, hipStream_t st) {
         if (bytes == 0) return;
-        if (capturing || host_is_pinned(host)) {        // (nothing is uploaded inside a stream capture; kept as it was if it ever is)
+        if (capturing || own_pinned(host) || host_is_pinned(host)) {   // (nothing is uploaded inside a stream capture; kept as it was if it ever is)
             GP_HIP(hipMemcpyAsync(dev, host, bytes, hipMemcpyHostToDevice, st));
             return;
         }
@@ -381,7 +391,7 @@ struct gpcsd_ctx {
     // through the bounce blocks, complete on return (what a pageable hipMemcpyAsync amounts to as well).
     void copy_out(void *host, const void *dev, size_t bytes, hipStream_t st) {
         if (bytes == 0) return;
-        if (host_is_pinned(host)) {
+        if (own_pinned(host) || host_is_pinned(host)) {
             GP_HIP(hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, st));
             return;
         }

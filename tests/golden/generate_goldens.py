@@ -327,8 +327,64 @@ def gen_trad_csd():
     print("wrote trad_csd")
 
 
+def gen_recipe_1d():
+    """The reference's own script recipe end to end (BASELINE cfg1's "plumbing"), in the order of
+    simulation_studies/sim_from_gp_1D.py: generator model on a dense grid (:49-56) -> sample_prior (:59) -> interpolation to the
+    interior electrodes (:60-63) -> fwd_model_1d per trial (:66-68) -> white noise + normalize (:69-70) -> new model on the
+    held-out half with the generating hyper-parameters (:100-107) -> predict(xshort, t) (:110) -> MSE / R^2 against the ground
+    truth (:151-156).  kCSD and the plots are left out; 4 + 4 trials instead of 50 + 50 (fixture size).  Every array a drop-in
+    backend must reproduce is stored: the sampled CSD (RNG stream included), the simulated LFP, the prediction, the two metrics."""
+    import scipy.interpolate
+    out = dict(META)
+    np.random.seed(1)
+    ntrials = 4
+    a, b, nt, nx, nz = 0, 2300, 60, 24, 100
+    t = np.linspace(0, nt, nt)[:, None]
+    x = np.linspace(a, b, nx)[:, None]
+    xshort = x[1:-1]
+    z = np.linspace(a, b, nz)[:, None]
+    hyp = dict(R=100.0, ellSE=200.0, sig2tM=0.7, elltM=5.0, sig2tSE=0.5, elltSE=20.0, sig2n=0.0001)
+
+    def set_true(m):
+        m.R['value'] = hyp["R"]
+        m.sig2n['value'] = hyp["sig2n"]
+        m.spatial_cov.params['ell']['value'] = hyp["ellSE"]
+        m.temporal_cov_list[0].params['ell']['value'] = hyp["elltSE"]
+        m.temporal_cov_list[0].params['sigma2']['value'] = hyp["sig2tSE"]
+        m.temporal_cov_list[1].params['ell']['value'] = hyp["elltM"]
+        m.temporal_cov_list[1].params['sigma2']['value'] = hyp["sig2tM"]
+    gen = GPCSD1D(np.zeros((nz, nt)), z, t, temporal_cov_list=[rcov.GPCSDTemporalCovSE(t), rcov.GPCSDTemporalCovMatern(t)])
+    set_true(gen)
+    st = np.random.get_state()                            # (the constructor has drawn from the global stream: the position is data)
+    out["rng_key_before_sample_prior"], out["rng_pos_before_sample_prior"] = st[1], np.array([st[2], st[3]])
+    out["rng_gauss_before_sample_prior"] = np.array(st[4])
+    csd = gen.sample_prior(2 * ntrials)
+    csd_interior = np.zeros((nx - 2, nt, 2 * ntrials))
+    for trial in range(2 * ntrials):
+        interp = scipy.interpolate.RectBivariateSpline(z, t, csd[:, :, trial])
+        csd_interior[:, :, trial] = interp(xshort, t)
+    lfp = np.zeros((nx, nt, 2 * ntrials))
+    for trial in range(2 * ntrials):
+        lfp[:, :, trial] = rfm.fwd_model_1d(csd[:, :, trial], z, x, hyp["R"])
+    lfp_clean = lfp.copy()
+    noise = np.random.normal(0, np.sqrt(hyp["sig2n"]), size=(nx, nt, 2 * ntrials))
+    lfp = ruf.normalize(lfp + noise)
+    model = GPCSD1D(lfp[:, :, ntrials:], x, t)
+    set_true(model)
+    model.predict(xshort, t)
+    truth = ruf.normalize(csd_interior[1:-1, :, ntrials:])
+    pred = ruf.normalize(model.csd_pred[1:-1, :, :])
+    out.update(ntrials=ntrials, t=t, x=x, z=z, hyp=np.array([hyp[k] for k in ("R", "ellSE", "sig2tM", "elltM", "sig2tSE", "elltSE", "sig2n")]),
+               csd=csd, csd_interior=csd_interior, lfp_forward=lfp_clean, noise=noise, lfp=lfp, csd_pred=model.csd_pred,
+               csd_pred_list=np.stack(model.csd_pred_list), loglik=np.array(model.loglik()),
+               mse=np.nanmean(np.square(pred - truth), axis=(0, 1)),
+               rsq=1 - np.sum(np.square(pred - truth), axis=(0, 1)) / np.sum(np.square(truth), axis=(0, 1)))
+    np.savez_compressed(os.path.join(HERE, "recipe_1d.npz"), **out)
+    print("wrote recipe_1d: mse %s  rsq %s" % (out["mse"], out["rsq"]))
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["shift_objective", "ops", "sample_prior", "models", "trad_csd"]
+    which = sys.argv[1:] or ["shift_objective", "ops", "sample_prior", "models", "trad_csd", "recipe_1d"]
     for name in which:                                       # a subset regenerates only those fixtures
         {"shift_objective": gen_shift_objective, "ops": gen_ops, "sample_prior": gen_sample_prior, "models": gen_models,
-         "trad_csd": gen_trad_csd}[name]()
+         "trad_csd": gen_trad_csd, "recipe_1d": gen_recipe_1d}[name]()

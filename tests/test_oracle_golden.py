@@ -255,3 +255,41 @@ def test_closed_form_gradient_vs_central_differences_of_the_pinned_loglik(name):
         a, b = O.invgamma_params(1.0, 20.0)
         assert abs(O.invgamma_dlpdf(x, a, b) - (O.invgamma_lpdf(x + 1e-6, a, b) - O.invgamma_lpdf(x - 1e-6, a, b)) / 2e-6) < 1e-6 * (1 + abs(O.invgamma_dlpdf(x, a, b)))
         assert abs(O.halfnormal_dlpdf(x, 1.5) - (O.halfnormal_lpdf(x + 1e-6, 1.5) - O.halfnormal_lpdf(x - 1e-6, 1.5)) / 2e-6) < 1e-6 * (1 + x)
+
+
+def test_the_reference_script_recipe_end_to_end_with_the_oracle():
+    """tests/golden/recipe_1d.npz is the reference run through its own script recipe (simulation_studies/sim_from_gp_1D.py:49-70,
+    100-110, 151-156: sample_prior -> fwd_model_1d -> noise + normalize -> new model -> predict -> MSE / R^2).  The oracle's pieces
+    chained the same way reproduce every stored stage (the RNG stream is NumPy's: the normals are re-drawn from the stored generator
+    state -- the reference's constructors draw initial hyper-parameters from the same global stream first)."""
+    g = golden("recipe_1d")
+    n, t, x, z = int(g["ntrials"]), g["t"], g["x"], g["z"]
+    R, ellSE, sig2tM, elltM, sig2tSE, elltSE, sig2n = (float(v) for v in g["hyp"])
+    temporal = [(O.SE, elltSE, sig2tSE), (O.MATERN, elltM, sig2tM)]
+    np.random.set_state(("MT19937", g["rng_key_before_sample_prior"], int(g["rng_pos_before_sample_prior"][0]),
+                         int(g["rng_pos_before_sample_prior"][1]), float(g["rng_gauss_before_sample_prior"])))
+    normals = np.stack([np.random.normal(0, 1, (z.shape[0], t.shape[0])) for _ in range(2 * n)], axis=2)
+    gen = O.Geometry1D(z, t)
+    hp_gen = O.make_hparams(R, (ellSE,), temporal, sig2n)
+    csd, _, _ = O.sample_prior_from_normals(gen, hp_gen, normals, which="csd", jitter=1e-8)
+    assert relerr(csd, g["csd"]) < 1e-10
+    lfp = np.stack([O.fwd_model_1d(csd[:, :, r], z, x, R) for r in range(2 * n)], axis=2)
+    assert relerr(lfp, g["lfp_forward"]) < 1e-12
+    noise = np.random.normal(0, np.sqrt(sig2n), size=lfp.shape)
+    assert np.array_equal(noise, g["noise"])
+    lfp = lfp + noise
+    lfp = lfp / np.max(np.abs(lfp), axis=(0, 1))
+    assert relerr(lfp, g["lfp"]) < 1e-12
+    geom = O.Geometry1D(x, t)
+    hp = O.make_hparams(R, (ellSE,), temporal, sig2n)
+    assert abs(O.loglik(geom, with_jitter(hp, 1e-8), lfp[:, :, n:]) - float(g["loglik"])) <= 1e-9 * abs(float(g["loglik"]))
+    pred = O.predict(geom, hp, lfp[:, :, n:], x[1:-1], t, type="csd")
+    # (sig2n = 1e-4 as the script has it: K = Ks (x) Kt + 1e-4 I is conditioned ~1e9, and the reference's dense (nx nt)^2 algebra
+    # (gpcsd1d.py:262-265) and the structured form differ by their own rounding, ~1e-6 of the posterior mean)
+    assert relerr(pred["csd"], g["csd_pred"]) < 5e-6 and relerr(pred["csd_list"], g["csd_pred_list"]) < 5e-6
+    nrm = lambda a: a / np.max(np.abs(a), axis=(0, 1))
+    truth, est = nrm(g["csd_interior"][1:-1, :, n:]), nrm(pred["csd"][1:-1])
+    mse = np.nanmean(np.square(est - truth), axis=(0, 1))
+    rsq = 1 - np.sum(np.square(est - truth), axis=(0, 1)) / np.sum(np.square(truth), axis=(0, 1))
+    print("recipe: mse rel dev %.1e, R^2 rel dev %.1e" % (relerr(mse, g["mse"]), relerr(rsq, g["rsq"])))
+    assert relerr(mse, g["mse"]) < 1e-4 and relerr(rsq, g["rsq"]) < 1e-7

@@ -1,0 +1,18 @@
+#!/bin/bash
+set -o pipefail
+OUT=gpurun_out/r6g
+mkdir -p $OUT
+step() {
+    local secs=$1 log=$2; shift 2
+    echo "== $* -> $log"
+    timeout -k 10 $secs "$@" > $OUT/$log 2>&1
+    local rc=$?
+    echo "   rc=$rc"
+    if [ $rc -ge 124 ]; then echo "step $log timed out or was killed: stopping"; tail -5 $OUT/$log; exit $rc; fi
+    return 0
+}
+step 400 bench_default.txt python bench.py --gpus 1 --steps 20 --warmup 5
+tail -1 $OUT/bench_default.txt | cut -c1-4200
+cp bench_detail.json $OUT/bench_detail_default.json 2>/dev/null
+step 900 t_all.txt python -m pytest -x -q -m gpu tests -p no:cacheprovider
+tail -6 $OUT/t_all.txt
