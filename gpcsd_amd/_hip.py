@@ -188,12 +188,10 @@ SIGNATURES = {
     "gpcsd_ll_tridiag": (_I, [_P, _I, ctypes.POINTER(_L)]),
     "gpcsd_pair_share_x": (_I, [_P, _I, ctypes.POINTER(_L)]),
     "gpcsd_pair_share_s": (_I, [_P, _I, ctypes.POINTER(_L)]),
-    "gpcsd_band_tail": (_I, [_P, _I, ctypes.POINTER(_L)]),
     "gpcsd_q_pipeline": (_I, [_P, _I, ctypes.POINTER(_L)]),
     "gpcsd_bounce_stats": (_I, [_P, ctypes.POINTER(_L)]),
     "gpcsd_q_pipeline_stats": (_I, [_P, ctypes.POINTER(_I), ctypes.POINTER(_L), ctypes.c_longlong]),
     "gpcsd_predict_chunked_copy": (_I, [_P, _I, ctypes.POINTER(_L)]),
-    "gpcsd_debug_sybrd": (_I, [_P, _DP, _I, _DP, _DP, _DP]),
     "gpcsd_tail_early_exit": (_I, [_P, _I, ctypes.POINTER(_I)]),
     "gpcsd_debug_fault_stage2": (_I, [_P, _I]),
     "gpcsd_decomposition_cache": (_I, [_P, _I, ctypes.POINTER(_L)]),
@@ -639,14 +637,6 @@ class Context:
         self._check(self._lib.gpcsd_debug_sytrd(self._h, _ptr(A), n, _ptr(d), _ptr(e), _ptr(V), _ptr(tau)))
         return d, e[:n - 1], V, tau
 
-    def debug_sybrd(self, A):
-        """Band tail on its own: (band (5, n) with band[j, k] = B[k + j, k], reflectors V (n, n) by rows, tau (n)) of A = Q B Q^T."""
-        A = _arr(A)
-        n = A.shape[0]
-        band, tau, V = np.empty((5, n)), np.empty(n), np.empty((n, n))
-        self._check(self._lib.gpcsd_debug_sybrd(self._h, _ptr(A), n, _ptr(band), _ptr(V), _ptr(tau)))
-        return band, V, tau
-
     def debug_stedc(self, d, e):
         d, e = _arr(d).reshape(-1), _arr(e).reshape(-1)
         n = d.size
@@ -890,13 +880,6 @@ class Context:
     def pair_share_s_on(self):
         """The switch as it stands (new contexts: GPCSD_PAIR_SHARE_S, default off)."""
         return getattr(self, "_pair_share_s_on", os.environ.get("GPCSD_PAIR_SHARE_S", "0")[:1] not in ("", "0"))
-
-    def band_tail(self, on=None):
-        """Switch (True/False) or query (None) the band form of the temporal side for consumers in the basis U (x) Q (DESIGN 4.11);
-        returns the number of temporal chains that took it."""
-        n = _L(0)
-        self._check(self._lib.gpcsd_band_tail(self._h, -1 if on is None else int(bool(on)), ctypes.byref(n)))
-        return int(n.value)
 
     def q_pipeline(self, on=None):
         """Switch (True/False) or query (None) the panel-by-panel formation of Q and X = Y~ Q under the running tridiagonalisation

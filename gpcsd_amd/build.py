@@ -14,7 +14,7 @@ CSRC = os.path.join(HERE, "csrc")
 OBJDIR = os.path.join(CSRC, os.environ.get("GPCSD_BUILD_OBJDIR", "_build"))
 # developer knobs for A/B experiments (tools/ab_bench.py, tools/sytrd_time.py): another output name and extra compiler flags
 LIB = os.environ.get("GPCSD_BUILD_LIB") or os.path.join(HERE, "libgpcsd_hip.so")
-SOURCES = ["capi.hip", "gemm_f64.hip", "gram.hip", "band.hip", "eigh.hip", "eigh_dc.hip", "stedc.hip", "wy.hip", "grad.hip", "chol.hip"]
+SOURCES = ["capi.hip", "gemm_f64.hip", "gram.hip", "eigh.hip", "eigh_dc.hip", "stedc.hip", "wy.hip", "grad.hip", "chol.hip"]
 ARCH = "gfx950"
 # -amdgpu-mfma-vgpr-form: keep MFMA accumulators in VGPRs; the default AGPR form made hipcc copy all of them AGPR<->VGPR
 # around every K tile of the GEMM main loop (64 v_accvgpr moves + s_nop per 16 MFMAs)

@@ -160,15 +160,21 @@ void build_kphi(gpcsd_ctx *c, const Geo &g, double R, double eps, const double *
         double *U = c->buf<double>(P + "U", (size_t)g.nx * G);
         k_se_axis(c, g.gx1, n1, ell[0], K1, s);
         k_se_axis(c, g.gx2, n2, ell[1], K2, s);
+        // GPCSD_KS_CFG=ab: tile configurations of the two small products (a: A K2, b: K1^T U; 0 = automatic, i.e. the 32 x 32 / BK 64
+        // tile of latency-bound launches -- 64 KB of LDS per workgroup, which beside another stream's flood of 64 x 64 tiles only
+        // finds room where two of those have retired on one CU: 72 us in the step loop for 12 alone).  A/B.
+        static const char *ks_cfg = getenv("GPCSD_KS_CFG");
         GemmDesc u;                                // U[(x,g1)][h2] = sum_g2 A[(x,g1)][g2] K2[g2][h2]
         u.M = g.nx * n1; u.N = n2; u.K = n2;
         u.A = A; u.lda = n2; u.B = K2; u.ldb = n2; u.C = U; u.ldc = n2;
+        if (ks_cfg && ks_cfg[0] > '0') u.cfg = ks_cfg[0] - '0';
         u.prof_name = "gemm_Ks_AK2";
         gemm_f64(c, u, s);
         GemmDesc v;                                // T_x (n1 x n2) = K1^T U_x, one small product per electrode
         v.M = n1; v.N = n2; v.K = n1;
         v.A = K1; v.lda = n1; v.transA = true; v.B = U; v.ldb = n2; v.C = T; v.ldc = n2;
         v.batch = g.nx; v.sA = 0; v.sB = G; v.sC = G;
+        if (ks_cfg && ks_cfg[0] && ks_cfg[1] > '0') v.cfg = ks_cfg[1] - '0';
         v.prof_name = "gemm_Ks_K1U";
         gemm_f64(c, v, s);
     }
@@ -404,7 +410,6 @@ struct EigState {
     // stage-1 outputs are still those of this temporal problem), replica `tri_rep` of the temporal classes is this call's
     bool tri = false, wait_q = false;
     int tri_rep = 0, tri_count = 1;
-    int band = 0;                  // tri: half-bandwidth of what the temporal chain left (0: tridiagonal d / e; 4: EigArenaView::bd)
     // tri: stage 1 ran with progress words and NO stage 3 was queued -- loglik_tri_pre queues stage 5 instead (queue_q_pipeline:
     // T factors and Q on stream4, X = Y~ Q block of columns by block on the main stream), with the arguments of the stage-1 call
     bool pipe_pending = false;
@@ -416,14 +421,6 @@ struct EigState {
         bool need_merged = false;
     } pa;
 };
-
-// May a staged temporal chain whose consumers all take the basis U (x) Q stop at the band form?  Both halves must fit the band tail
-// and the banded solve kernel (the log-likelihood's kernel takes what the tail can hold).  gpcsd_band_tail(ctx, 0) / GPCSD_BAND_TAIL=0.
-static bool band_tail_applies(const gpcsd_ctx *c, const SymDev *sym_t, int R, bool with_predict) {
-    if (!c->band_tail || !sym_t) return false;
-    const int hi = std::max(sym_t->ns, sym_t->na);
-    return hi <= bt_max_rows() && hi > 8 && (!with_predict || k_band_solve_pass(hi, R) > 0);
-}
 
 // Stage 5 instead of stage 3 (gpcsd_ctx::q_pipe): both halves whole in the register tail, the temporal product first in the
 // log-likelihood's tail (GPCSD_LL_ORDER=0), and the caller has promised to form X through loglik_tri_pre (q_pipe_want).
@@ -696,18 +693,13 @@ EigState front_half(gpcsd_ctx *c, const gpcsd_hparams *hp, double jitter, bool n
                 // starts its tail behind stage 3 and never waits for stages 2 and 4.
                 const bool tri = tri_consumer;
                 int *late = e.status + gpcsd_ctx::STATUS_LATE;    // stages 2 and 4 report here (gpcsd_ctx::STATUS_LATE)
-                // a chain that stops behind stages 1 + 3 may stop at the band form (nobody reads the spectrum)
-                c->band_req = (tri && band_tail_applies(c, sym_t, c->ntrials, true)) ? 4 : 0;
-                c->tri_band[c->tgen] = c->band_req;
-                if (c->band_req) ++c->band_tail_calls;
                 // stage 5 instead of stage 3: the tail publishes its progress, the caller's loglik_tri_pre queues the rest
-                const bool st5 = tri && !c->band_req && q_stage5_applies(c, sym_t);      // T, Q by stage 5's kernels
+                const bool st5 = tri && q_stage5_applies(c, sym_t);                      // T, Q by stage 5's kernels
                 const bool pipe = st5 && q_pipe_applies(c, sym_t);                       // ... under the running stage 1
                 if (pipe) GP_HIP(hipEventRecord(c->ev_t0, s2));
                 c->pipe_req = st5 ? 1 : 0;
                 eigh_pair_device(c, nullptr, 0, nullptr, nullptr, nullptr, Kt, nt, e.et, e.Qt, sym_t, e.status + 1, s2, need_merged, 1, 0,
                                  -1, 2, /*stage=*/1);
-                c->band_req = 0;
                 c->pipe_req = 0;
                 GP_HIP(hipEventRecord(c->ev_t1, s2));
                 if (!tri)
@@ -741,7 +733,6 @@ EigState front_half(gpcsd_ctx *c, const gpcsd_hparams *hp, double jitter, bool n
                                      -1, 2, /*stage=*/4);
                 }
                 e.tri = e.wait_q = tri;
-                e.band = tri ? c->tri_band[c->tgen] : 0;
                 c->decomp_t_full = !tri;
             } else {
                 eigh_pair_device(c, nullptr, 0, nullptr, nullptr, nullptr, Kt, nt, e.et, e.Qt, sym_t, e.status + 1, s2, need_merged, 1, 0,
@@ -774,7 +765,6 @@ EigState front_half(gpcsd_ctx *c, const gpcsd_hparams *hp, double jitter, bool n
     if (!run_t) e.wait_temporal = true;
     if (!run_t && tri_consumer) {    // the temporal side is reused from the cache and its stage-1 outputs are those of this problem
         e.tri = true;
-        e.band = c->tri_band[c->tgen];
         e.wait_q = c->q_queued[c->tgen];      // (the stage 3 that left Q there may still be running)
     }
     e.d_sig = c->upload_cached<double>("sig2n", hp->sig2n, hp->n_sig2n);
@@ -1081,7 +1071,6 @@ extern "C" int gpcsd_ctx_create(int device, gpcsd_ctx **out) {
         if (const char *ev = getenv("GPCSD_TAIL_EARLY_EXIT")) c->tail_early_exit = ev[0] != '0';
         if (const char *ev = getenv("GPCSD_PAIR_SHARE_X")) c->pair_share_x = ev[0] != '0';
         if (const char *ev = getenv("GPCSD_PAIR_SHARE_S")) c->pair_share_s = ev[0] != '0';
-        if (const char *ev = getenv("GPCSD_BAND_TAIL")) c->band_tail = ev[0] != '0';
         if (const char *ev = getenv("GPCSD_Q_PIPE")) c->q_pipe = ev[0] != '0';
         if (const char *ev = getenv("GPCSD_QPIPE_GATE_TICKS")) c->q_gate_ticks = strtoull(ev, nullptr, 10);
         if (const char *ev = getenv("GPCSD_PRED_CHUNKED")) c->pred_chunked = ev[0] != '0';
@@ -1110,7 +1099,6 @@ extern "C" int gpcsd_ctx_create(int device, gpcsd_ctx **out) {
         GP_HIP(hipEventCreateWithFlags(&c->ev_chol_d, hipEventDisableTiming));
         for (int i = 0; i < 2; ++i) GP_HIP(hipEventCreateWithFlags(&c->ev_q[i], hipEventDisableTiming));
         GP_HIP(hipEventCreateWithFlags(&c->ev_t1, hipEventDisableTiming));
-        GP_HIP(hipEventCreateWithFlags(&c->ev_fac, hipEventDisableTiming));
         GP_HIP(hipEventCreateWithFlags(&c->ev_t0, hipEventDisableTiming));
         for (int i = 0; i < 8; ++i) GP_HIP(hipEventCreateWithFlags(&c->ev_stage[i], hipEventDisableTiming));
         GP_HIP(hipEventCreateWithFlags(&c->ev_prelude, hipEventDisableTiming));
@@ -1160,7 +1148,6 @@ extern "C" int gpcsd_ctx_destroy(gpcsd_ctx *c) {
     for (int i = 0; i < 2; ++i)
         if (c->ev_q[i]) (void)hipEventDestroy(c->ev_q[i]);
     if (c->ev_t1) (void)hipEventDestroy(c->ev_t1);
-    if (c->ev_fac) (void)hipEventDestroy(c->ev_fac);
     if (c->ev_t0) (void)hipEventDestroy(c->ev_t0);
     for (int i = 0; i < 8; ++i)
         if (c->ev_stage[i]) (void)hipEventDestroy(c->ev_stage[i]);

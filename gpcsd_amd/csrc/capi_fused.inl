@@ -70,30 +70,6 @@ static bool loglik_tri_tail(gpcsd_ctx *c, EigState &e, const FoldMode &fm, const
     hipStream_t s = c->stream;
     ++c->fold_gemm_calls;
     ++c->ll_tridiag_calls;
-    if (e.band) {
-        // Band form: the 2 nx shifted band factorisations are a serial recurrence per item (~60 us for the launch, twelve waves) that
-        // needs the spatial spectrum and the band only -- queued on the spatial chain's stream, behind that chain and the temporal
-        // chain's stage 1, it runs beside the main stream's products; the sweep below waits for ev_fac.
-        const char *const *tg = eigh_fold_tags(c, 1);
-        const double *am[2], *bd[2];
-        int np[2];
-        for (int p = 0; p < 2; ++p) {
-            np[p] = p ? fm.ft.na : fm.ft.ns;
-            const EigArenaView av = eigh_arena_view(c, tg[p], np[p], e.tri_count);
-            const long o = (long)e.tri_rep * av.blk;
-            am[p] = av.amax + o; bd[p] = av.bd + o;
-        }
-        hipStream_t sf = c->stream3;
-        GP_HIP(hipStreamWaitEvent(sf, c->ev_t1, 0));
-        {                                              // (the noise variance's upload and, for a cached spatial side, its readiness: main stream)
-            hipEvent_t ev = c->get_event();
-            GP_HIP(hipEventRecord(ev, s));
-            GP_HIP(hipStreamWaitEvent(sf, ev, 0));
-            c->event_pool.push_back(ev);
-        }
-        k_ll_band_factor(c, fm.fs.w, bd, np, am, e.d_sig, nx, np, sf);
-        GP_HIP(hipEventRecord(c->ev_fac, sf));
-    }
     join_spatial(c, e);
     double *X = c->buf<double>("ll_X", (size_t)nx * R * nt);
     if (ll_order() == 1) {
@@ -103,25 +79,21 @@ static bool loglik_tri_tail(gpcsd_ctx *c, EigState &e, const FoldMode &fm, const
         fold_proj_spatial(c, fm.fs, X, W, (long)R * nt, s);
     }
     const char *const *tg = eigh_fold_tags(c, 1);
-    const double *d[2], *ee[2], *am[2], *bd[2];
+    const double *d[2], *ee[2], *am[2];
     int np[2], c0[2];
     for (int p = 0; p < 2; ++p) {
         np[p] = p ? fm.ft.na : fm.ft.ns;
         c0[p] = p ? fm.ft.ns : 0;
         const EigArenaView av = eigh_arena_view(c, tg[p], np[p], e.tri_count);
         const long o = (long)e.tri_rep * av.blk;
-        d[p] = av.d + o; ee[p] = av.e + o; am[p] = av.amax + o; bd[p] = av.bd + o;
+        d[p] = av.d + o; ee[p] = av.e + o; am[p] = av.amax + o;
     }
-    if (e.band) GP_HIP(hipStreamWaitEvent(s, c->ev_fac, 0));
     if (c->t1_wait_pending) {              // stage 5: nothing on this stream is ordered behind the END of stage 1 yet (d, e, the scale)
         GP_HIP(hipStreamWaitEvent(s, c->ev_t1, 0));
         c->t1_wait_pending = false;
     }
-    const bool wrote = e.band
-        ? k_ll_band(c, W, fm.fs.w, bd, np, am, e.d_sig, nx, R, nt, np, c0, e.scal, e.scal + 1, s, host_slot,
-                    e.scal + gpcsd_ctx::SCAL_N, gpcsd_ctx::SCAL_N, gpcsd_ctx::RESULT_DOUBLES - gpcsd_ctx::SCAL_N)
-        : k_ll_tridiag(c, W, fm.fs.w, d, ee, am, e.d_sig, nx, R, nt, np, c0, e.scal, e.scal + 1, s, host_slot,
-                       e.scal + gpcsd_ctx::SCAL_N, gpcsd_ctx::SCAL_N, gpcsd_ctx::RESULT_DOUBLES - gpcsd_ctx::SCAL_N);
+    const bool wrote = k_ll_tridiag(c, W, fm.fs.w, d, ee, am, e.d_sig, nx, R, nt, np, c0, e.scal, e.scal + 1, s, host_slot,
+                                    e.scal + gpcsd_ctx::SCAL_N, gpcsd_ctx::SCAL_N, gpcsd_ctx::RESULT_DOUBLES - gpcsd_ctx::SCAL_N);
     GP_HIP(hipEventRecord(c->ev_tri_done[c->tgen], s));
     c->tri_reader_queued[c->tgen] = true;
     return wrote;
@@ -491,21 +463,20 @@ static int predict_fold(gpcsd_ctx *c, const gpcsd_hparams *hp, EigState &e, cons
     if (e.tri) {
         // Bm~ = the solutions of the shifted tridiagonal systems (es[x'] m T_p + sig2 I) b = w, row by row of W~ = diag(U)^T Y~ Q
         const char *const *tg = eigh_fold_tags(c, 1);
-        const double *d[2], *ee[2], *am[2], *bd[2];
+        const double *d[2], *ee[2], *am[2];
         int np[2], c0[2];
         for (int p = 0; p < 2; ++p) {
             np[p] = p ? nta : nts;
             c0[p] = p ? nts : 0;
             const EigArenaView av = eigh_arena_view(c, tg[p], np[p], e.tri_count);
             const long o = (long)e.tri_rep * av.blk;
-            d[p] = av.d + o; ee[p] = av.e + o; am[p] = av.amax + o; bd[p] = av.bd + o;
+            d[p] = av.d + o; ee[p] = av.e + o; am[p] = av.amax + o;
         }
         if (c->t1_wait_pending) {
             GP_HIP(hipStreamWaitEvent(s, c->ev_t1, 0));
             c->t1_wait_pending = false;
         }
-        if (e.band) k_band_solve(c, W, Bm, fm.fs.w, bd, np, am, e.d_sig, nx, R, nt, np, c0, s);
-        else k_tridiag_solve(c, W, Bm, fm.fs.w, d, ee, am, e.d_sig, nx, R, nt, np, c0, s);
+        k_tridiag_solve(c, W, Bm, fm.fs.w, d, ee, am, e.d_sig, nx, R, nt, np, c0, s);
         GP_HIP(hipEventRecord(c->ev_tri_done[c->tgen], s));     // the last reader of Q / the tridiagonal on this stream
         c->tri_reader_queued[c->tgen] = true;
     } else {
@@ -832,7 +803,7 @@ static void front_half_pair(gpcsd_ctx *c, const gpcsd_hparams *const hp[2], cons
     // assembled once and copied (the same GEMM output plus the same diagonal add: the same bits).
     const bool tfill = temporal_fill_applies(c, sym_t, nt, false);       // (the paired call is refused for host temporal Grams)
     const bool staged = tfill && ll_tridiag_enabled(c) && eigh_stageable(sym_t, nt);
-    bool st5 = false, pipe = false;      // stage 5's kernels instead of stage 3's, and pipelined: decided in part 1 (not in band mode)
+    bool st5 = false, pipe = false;      // stage 5's kernels instead of stage 3's, and pipelined: decided in part 1
     // part 1: the inputs and (staged) stage 1, or the whole chain; part 2 (staged only): stage 2, and stage 3 beside it
     auto run_T = [&](int part) {
         if (part == 1) {
@@ -850,18 +821,13 @@ static void front_half_pair(gpcsd_ctx *c, const gpcsd_hparams *const hp[2], cons
         {
             ProfScope ps(c, part == 2 ? "eigh_temporal_stage2" : "eigh_temporal", part == 2 ? 0.0 : 9.0 * (double)nt * nt * nt * nT, s2);
             if (staged && part == 1) {   // the log-likelihood's tail starts behind stages 1 + 3 (see front_half, EigState::tri)
-                // both consumers in the basis U (x) Q: the chain may stop at the band form (capi.hip: band_tail_applies)
-                c->band_req = (pred_tri && band_tail_applies(c, sym_t, c->ntrials, true)) ? 4 : 0;
-                c->tri_band[c->tgen] = c->band_req;
-                if (c->band_req) ++c->band_tail_calls;
                 // (only when the prediction takes the tridiagonal form too: a stage 4 behind stage 5 would read T factors summed in
                 // another order than stage 3's, and the pair would differ from its fenced calls in the last bits)
-                st5 = pred_tri && !c->band_req && q_stage5_applies(c, sym_t);
+                st5 = pred_tri && q_stage5_applies(c, sym_t);
                 pipe = st5 && q_pipe_applies(c, sym_t);
                 if (pipe) GP_HIP(hipEventRecord(c->ev_t0, s2));
                 c->pipe_req = st5 ? 1 : 0;
                 eigh_pair_device(c, nullptr, 0, nullptr, nullptr, nullptr, Kt, nt, et, Qt, sym_t, status + 1, s2, false, nT, 2, -1, 2, 1);
-                c->band_req = 0;
                 c->pipe_req = 0;
                 GP_HIP(hipEventRecord(c->ev_t1, s2));
                 c->tl("T stage 1 end (s2)", s2);
@@ -972,7 +938,6 @@ static void front_half_pair(gpcsd_ctx *c, const gpcsd_hparams *const hp[2], cons
             e.tri = e.wait_q = true;
             e.tri_rep = bt;
             e.tri_count = nT;
-            e.band = c->tri_band[c->tgen];
             if (pipe && b == 0) {        // X with replica 0's Q: the log-likelihood's set
                 e.pipe_pending = true;
                 e.pa.Kt = Kt; e.pa.nt = nt; e.pa.et = et; e.pa.Qt = Qt; e.pa.sym_t = sym_t; e.pa.status = status + 1;
@@ -1056,7 +1021,7 @@ static std::vector<unsigned char> pair_key(const gpcsd_ctx *c, const gpcsd_hpara
         for (int i = 0; i < h->n_temporal; ++i) { k.push_back((double)h->kind[i]); k.push_back(h->ell_t[i]); k.push_back(h->sigma2_t[i]); }
     }
     const double cfg[] = {(double)P.pred_tri, (double)P.fold_s, (double)c->grid_epoch, (double)c->alloc_epoch, (double)c->ntrials, (double)c->nx,
-                          (double)c->nt, (double)c->q_pipe, (double)c->band_tail, (double)c->pair_share_s, (double)c->tail_early_exit,
+                          (double)c->nt, (double)c->q_pipe, (double)c->pair_share_s, (double)c->tail_early_exit,
                           (double)c->ll_tridiag_mode, (double)c->gram_fp32, (double)c->decomp_cache_on, (double)c->fold_gemm_on};
     k.insert(k.end(), cfg, cfg + sizeof(cfg) / sizeof(cfg[0]));
     const unsigned char *p = reinterpret_cast<const unsigned char *>(k.data());

@@ -244,21 +244,6 @@ extern "C" int gpcsd_debug_sytrd(gpcsd_ctx *c, const double *A, int n, double *d
     GP_API_END(c)
 }
 
-extern "C" int gpcsd_debug_sybrd(gpcsd_ctx *c, const double *A, int n, double *band, double *V, double *tau) {
-    GP_API_BEGIN(c)
-    GP_REQUIRE(A && band && V && tau && n > 0, -3, "debug_sybrd: bad arguments");
-    double *dA = c->upload<double>("op_in0", A, (size_t)n * n);
-    double *db = c->buf<double>("dbg_band", (size_t)5 * n), *dt = c->buf<double>("dbg_tau", n);
-    double *dV = c->buf<double>("op_out", (size_t)n * n);
-    sybrd_device(c, dA, n, db, dV, dt, c->stream);
-    c->download(band, db, (size_t)5 * n * sizeof(double));
-    c->download(tau, dt, n * sizeof(double));
-    c->download(V, dV, (size_t)n * n * sizeof(double));
-    c->sync();
-    return 0;
-    GP_API_END(c)
-}
-
 extern "C" int gpcsd_debug_stedc(gpcsd_ctx *c, const double *d, const double *e, int n, double *w, double *Z) {
     GP_API_BEGIN(c)
     GP_REQUIRE(d && e && w && Z && n > 0, -3, "debug_stedc: bad arguments");
@@ -617,14 +602,6 @@ extern "C" int gpcsd_predict_chunked_copy(gpcsd_ctx *c, int on, long *calls) {
     GP_API_BEGIN(c)
     if (on >= 0) c->pred_chunked = on != 0;
     if (calls) *calls = c->pred_chunked_calls;
-    return 0;
-    GP_API_END(c)
-}
-
-extern "C" int gpcsd_band_tail(gpcsd_ctx *c, int on, long *calls) {
-    GP_API_BEGIN(c)
-    if (on >= 0) c->band_tail = on != 0;
-    if (calls) *calls = c->band_tail_calls;
     return 0;
     GP_API_END(c)
 }

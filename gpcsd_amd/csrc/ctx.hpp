@@ -150,7 +150,6 @@ struct gpcsd_ctx {
     // Single-buffered, the next step's tridiagonalisation waited for the previous prediction's solve (0.3 ms per step).
     int tgen = 0;
     hipEvent_t ev_t1 = nullptr;
-    hipEvent_t ev_fac = nullptr;            // band form: the log-likelihood's shifted band factors are there (recorded on stream3: band.hip)
     bool q_queued[2] = {false, false};      // a stage 3 has been queued on this generation since its last temporal chain started (staged_chain_guard)
     // ... and the last reader of those single-buffered stage-1 outputs (Q, the tridiagonal, its scale) on the main stream: the next
     // temporal chain must not overwrite them before it (a caller may queue several steps deep)
@@ -206,15 +205,6 @@ struct gpcsd_ctx {
     int ll_tridiag_mode = 2;                // gpcsd_ll_tridiag(): log-likelihood in the basis U (x) Q -- 0 off, 1 on, 2 by size (capi.hip)
     long ll_tridiag_calls = 0;
     long fold_gemm_calls = 0;
-    // Band tail (round 5; sytrd_bandtail.hpp, band.hip): a staged temporal chain none of whose consumers reads the spectrum stops at
-    // HALF-BANDWIDTH 4 instead of a tridiagonal matrix -- one synchronisation per four columns instead of per column.
-    // band_tail: the switch (gpcsd_band_tail() / GPCSD_BAND_TAIL=0).  band_req: set by the front halves around the stage-1 call of
-    // such a chain (read by the eigensolver's problem set-up, part of its graph key).  tri_band[g]: what the last stage 1 of
-    // generation g of the temporal classes left there (0: d / e tridiagonal, 4: the band in EigArenaView::bd).
-    bool band_tail = false;                 // (off until it is the faster form: the first build measured 1.04 ms per 250-row tail against 0.585)
-    int band_req = 0;
-    int tri_band[2] = {0, 0};
-    long band_tail_calls = 0;
     // Pipelined stage 3 (round 5; wy.hip: wy_q_pipeline): the register tail of a staged temporal chain publishes its progress panel by
     // panel; T factors and the finished columns of Q follow on stream4 WHILE the tail reduces the next panel, and the matching
     // columns of X = Y~ Q on the main stream behind an event per panel -- behind the tail only the last panel's share is left (T, Q

@@ -427,7 +427,7 @@ void eigh_pair_device(gpcsd_ctx *c, double *A0, int n0, double *w0, double *Z0, 
     }
     // (the generation of each slot picks the fold-order output buffers, which are not among the arguments)
     // (... and SytrdProb::psd of the prefilled classes, a kernel argument: what their fills announced, and the context's switch)
-    int psd_sig = (c->tail_early_exit ? 16 : 0) | (c->claim_psd ? 32 : 0) | (c->band_req ? 64 : 0) |  // (band mode: another tail kernel)
+    int psd_sig = (c->tail_early_exit ? 16 : 0) | (c->claim_psd ? 32 : 0) |
                   (c->pipe_req ? 128 : 0);                                                           // (progress words: a kernel argument)
     for (int p = 0; p < 2; ++p) {
         const char *const *tg = eigh_fold_tags(c, p);

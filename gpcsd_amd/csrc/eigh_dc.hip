@@ -85,8 +85,6 @@ struct SytrdProb {
     int k_tail;           // first column handled by the in-LDS tail kernel (n - 1: no tail)
     int psd;              // the matrix is a Gram matrix (positive semi-definite up to rounding): the tail may stop early (sytrd_regtail.hpp)
     long blk;             // replica stride of the arena, in doubles
-    double *bd;           // band mode: (BT_W + 1) x n, bd[j * n + k] = B[k + j][k] (sytrd_bandtail.hpp)
-    int band;             // 0: tridiagonal (d, e);  4: the tail reduces to half-bandwidth 4 (bd) -- whole problems of <= bt_max_rows() rows
     int pipe;             // the register tail publishes its progress panel by panel (sy_progress_word; whole problems only)
 };
 // the progress word of a problem: behind tau's n + WY_NB entries (the slice has two more; cleared with tau by whoever fills the arena)
@@ -104,24 +102,13 @@ __device__ __forceinline__ SytrdProb sy_resolve(const SytrdBatch &b, int g) {
     class_of(b.start, g, cls, rep);
     SytrdProb P = b.p[cls];
     const long o = rep * P.blk;
-    P.A0 += o; P.A1 += o; P.V += o; P.tau += o; P.d += o; P.e += o; P.y0 += o; P.y1 += o; P.bd += o;
+    P.A0 += o; P.A1 += o; P.V += o; P.tau += o; P.d += o; P.e += o; P.y0 += o; P.y1 += o;
     return P;
 }
 
 }  // namespace gpcsd
 #include "sytrd_regtail.hpp"
-#include "sytrd_bandtail.hpp"
 namespace gpcsd {
-
-// rows of a whole problem the band tail can hold: its strip (LDS) beside 41 KB of vectors
-int bt_max_rows() {
-    static int m = 0;
-    if (!m) {
-        for (int T = RT_TMAX; T >= 2; --T)
-            if (bt_lds_bytes(T) + 42 * 1024 <= (size_t)160 * 1024) { m = T; break; }
-    }
-    return m;
-}
 
 // JQ = ceil(trailing columns / 64) this launch may need (2, 4, 8, 16, 32 or 64).  Every global load of the step -- the slab
 // rows, the pivot row, the previous reflector and its y -- is issued before the first barrier, so a step costs one
@@ -321,21 +308,7 @@ static void sytrd_batch_launch(gpcsd_ctx *c, const SytrdBatch &b, int nclass, in
             c->tail_clk_count[region] = count;
             c->tail_clk_flops[region] = fl;
         }
-        bool band = true;                                  // every class in band mode (a chain is one or the other)
-        for (int i = 0; i < nclass; ++i) band = band && b.p[i].band == BT_W && b.p[i].k_tail == 0;
-        if (band) {
-            size_t shb = 0;
-            for (int i = 0; i < nclass; ++i) shb = std::max(shb, bt_lds_bytes(b.p[i].n));
-            static bool bt_attr_set = false;
-            if (!bt_attr_set) {
-                GP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(sybrd_btail_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)bt_lds_bytes(bt_max_rows())));
-                bt_attr_set = true;
-            }
-            hipLaunchKernelGGL(sybrd_btail_kernel, dim3(count), dim3(RT_NTH), shb, s, bt);
-        } else {
-            hipLaunchKernelGGL(sytrd_rtail_kernel, dim3(count), dim3(RT_NTH), sh, s, bt);
-        }
+        hipLaunchKernelGGL(sytrd_rtail_kernel, dim3(count), dim3(RT_NTH), sh, s, bt);
     }
     if (!all_tail) hipLaunchKernelGGL(sytrd_last_diag_kernel, dim3(count), dim3(64), 0, s, b);
     GP_HIP(hipGetLastError());
@@ -447,21 +420,19 @@ static void layout_arena(gpcsd_ctx *c, const std::string &tag, int n, int count,
     const size_t oA0 = L.take(nn), oA1 = L.take(nn), oV = L.take((size_t)(n + WY_NB) * n), otau = L.take(n + WY_NB + 2);
     const size_t od = L.take(n), oe = L.take(n), oy0 = L.take(n), oy1 = L.take(n), oamax = L.take(2 + AMAX_PARTS);
     const size_t oT = L.take((size_t)npanels * WY_NB * WY_NB);
-    const size_t obd = L.take((size_t)(BT_W + 1) * n);
     double *base = c->buf<double>(T + "arena", L.off * (size_t)std::max(count, 1));
     sp.blk = (long)L.off;
     sp.A0 = base + oA0; sp.A1 = base + oA1; sp.V = base + oV; sp.tau = base + otau;
     sp.d = base + od; sp.e = base + oe; sp.y0 = base + oy0; sp.y1 = base + oy1;
     amax = base + oamax;
     wyT = base + oT;
-    sp.bd = base + obd;
 }
 
 EigArenaView eigh_arena_view(gpcsd_ctx *c, const char *tag, int n, int count) {
     SytrdProb sp{};
     double *amax = nullptr, *wyT = nullptr;
     layout_arena(c, tag, n, count, sp, amax, wyT);
-    return EigArenaView{sp.A0, sp.V, sp.tau, amax, sp.blk, sp.d, sp.e, &c->arena_psd[tag], sp.bd};
+    return EigArenaView{sp.A0, sp.V, sp.tau, amax, sp.blk, sp.d, sp.e, &c->arena_psd[tag]};
 }
 
 double *eigh_Q_view(gpcsd_ctx *c, const char *tag, int n, int count) {
@@ -481,11 +452,8 @@ static void prep_problem(gpcsd_ctx *c, EigProb &p, hipStream_t s) {
     bool &psd = c->arena_psd[p.tag];
     if (!p.prefilled) psd = c->claim_psd;         // (... unless the caller vouches for it: gpcsd_eigh_psd)
     p.sp.psd = (psd && c->tail_early_exit) ? 1 : 0;
-    // band mode on the word of the caller (gpcsd_ctx::band_req: a staged chain whose consumers all take the banded form), for whole
-    // problems the band tail can hold
-    p.sp.band = (c->band_req == BT_W && p.sp.k_tail == 0 && n <= bt_max_rows()) ? BT_W : 0;
-    // progress words on the word of the caller too (gpcsd_ctx::pipe_req: stage 5 of a staged chain follows on another stream)
-    p.sp.pipe = (c->pipe_req && p.sp.k_tail == 0 && !p.sp.band) ? 1 : 0;
+    // progress words on the word of the caller (gpcsd_ctx::pipe_req: stage 5 of a staged chain follows on another stream)
+    p.sp.pipe = (c->pipe_req && p.sp.k_tail == 0) ? 1 : 0;
     (void)s;
 }
 
@@ -515,7 +483,7 @@ __device__ __forceinline__ PrepView prep_resolve(const PrepBatch &b, int g) {
     PrepView v;
     v.P = b.sp[cls];
     const long o = rep * v.P.blk;
-    v.P.A0 += o; v.P.A1 += o; v.P.V += o; v.P.tau += o; v.P.d += o; v.P.e += o; v.P.y0 += o; v.P.y1 += o; v.P.bd += o;
+    v.P.A0 += o; v.P.A1 += o; v.P.V += o; v.P.tau += o; v.P.d += o; v.P.e += o; v.P.y0 += o; v.P.y1 += o;
     v.A = b.A[cls] + rep * b.sA[cls];
     v.amax = b.amax[cls] + o;
     v.w = b.w[cls] ? b.w[cls] + rep * b.sw[cls] : nullptr;
@@ -615,31 +583,6 @@ void sytrd_device(gpcsd_ctx *c, double *A, int n, double *d, double *e, double *
     // d, e are those of A / max|A|; rescale so the caller sees the tridiagonal of A itself
     hipLaunchKernelGGL(scale_vec_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, s, d, n, (const double *)p.amax);
     hipLaunchKernelGGL(scale_vec_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, s, e, n, (const double *)p.amax);
-    GP_HIP(hipGetLastError());
-}
-
-// The band tail on its own (gpcsd_debug_sybrd): A = Q B Q^T with half-bandwidth 4; band (5 x n, band[j * n + k] = B[k + j][k]) at the
-// scale of A, reflectors V (n x n, by rows) and tau as sytrd_device leaves them.
-void sybrd_device(gpcsd_ctx *c, double *A, int n, double *band, double *V, double *tau, hipStream_t s) {
-    GP_REQUIRE(n > 8 && n <= bt_max_rows(), -3, "sybrd: n=%d outside (8,%d]", n, bt_max_rows());
-    EigProb p;
-    p.A = A; p.n = n; p.tag = "dbgb"; p.w = nullptr; p.Z = nullptr;
-    c->band_req = BT_W;
-    PrepBatch pb;
-    try {
-        pb = prep_batch_launch(c, &p, 1, s);
-    } catch (...) {
-        c->band_req = 0;
-        throw;
-    }
-    c->band_req = 0;
-    GP_REQUIRE(p.sp.band == BT_W, -3, "sybrd: band mode was not taken (n=%d)", n);
-    GP_HIP(hipMemsetAsync(p.sp.bd, 0, (size_t)(BT_W + 1) * n * sizeof(double), s));
-    sytrd_batch_launch(c, sytrd_batch_of(pb), 1, n, s);
-    GP_HIP(hipMemcpyAsync(band, p.sp.bd, (size_t)(BT_W + 1) * n * sizeof(double), hipMemcpyDeviceToDevice, s));
-    GP_HIP(hipMemcpyAsync(tau, p.sp.tau, n * sizeof(double), hipMemcpyDeviceToDevice, s));
-    GP_HIP(hipMemcpyAsync(V, p.sp.V, (size_t)n * n * sizeof(double), hipMemcpyDeviceToDevice, s));
-    hipLaunchKernelGGL(scale_vec_kernel, dim3(ceil_div((BT_W + 1) * n, 256)), dim3(256), 0, s, band, (BT_W + 1) * n, (const double *)p.amax);
     GP_HIP(hipGetLastError());
 }
 

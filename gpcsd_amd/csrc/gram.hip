@@ -633,7 +633,7 @@ __global__ __launch_bounds__(256) void ll_tridiag_reduce_kernel(const double *__
     if (host_slot && blockIdx.x == 0 && (int)threadIdx.x < status_doubles) host_slot[status_at + threadIdx.x] = status_src[threadIdx.x];
 }
 
-// the final sums of the per-item partials (shared with the banded form, band.hip)
+// the final sums of the per-item partials
 void ll_tridiag_reduce_launch(gpcsd_ctx *c, const double *partials, int nitems, double *out_sumlog, double *out_quad, double *host_slot,
                               const double *status_src, int status_at, int status_doubles, hipStream_t s, bool *wrote) {
     (void)c;

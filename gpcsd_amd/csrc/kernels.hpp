@@ -145,17 +145,6 @@ int k_tridiag_solve_pass(int npmax, int R);
 void k_tridiag_solve(gpcsd_ctx *c, const double *W, double *B, const double *es, const double *const d[2], const double *const e[2],
                      const double *const amax[2], const double *sig, int nx, int R, int nt, const int np[2], const int c0[2],
                      hipStream_t s);
-// The same two operations for a temporal side reduced to HALF-BANDWIDTH 4 instead of a tridiagonal matrix (band.hip; the band tail
-// of the tridiagonalisation, sytrd_bandtail.hpp): bd[p][j * ld[p] + k] = B_p[k + j][k], j = 0 .. 4.  Shifted banded L D L^T
-// factorisations, four multipliers per column.  k_band_solve_pass: as k_tridiag_solve_pass.
-void k_ll_band_factor(gpcsd_ctx *c, const double *es, const double *const bd[2], const int ld[2], const double *const amax[2],
-                      const double *sig, int nx, const int np[2], hipStream_t sf);       // the factors k_ll_band sweeps with (any stream)
-bool k_ll_band(gpcsd_ctx *c, const double *W, const double *es, const double *const bd[2], const int ld[2], const double *const amax[2],
-               const double *sig, int nx, int R, int nt, const int np[2], const int c0[2], double *out_sumlog, double *out_quad,
-               hipStream_t s, double *host_slot = nullptr, const double *status_src = nullptr, int status_at = 0, int status_doubles = 0);
-int k_band_solve_pass(int npmax, int R);
-void k_band_solve(gpcsd_ctx *c, const double *W, double *B, const double *es, const double *const bd[2], const int ld[2],
-                  const double *const amax[2], const double *sig, int nx, int R, int nt, const int np[2], const int c0[2], hipStream_t s);
 void k_add_diag(gpcsd_ctx *c, double *A, int n, double v, hipStream_t s, const HpDev *tab = nullptr, int B = 1, long s_out = 0);
 void k_shift_copy(gpcsd_ctx *c, const double *src, double *dst, int n, double v, hipStream_t s);     // dst = src + v
 void k_sum_partials(gpcsd_ctx *c, double *out, const double *P, long n, int parts, hipStream_t s);
@@ -214,10 +203,8 @@ struct EigArenaView {
     long blk;
     double *d, *e;               // the tridiagonal of A0 = Q T Q^T once the tridiagonalisation has run (n entries each)
     bool *psd;                   // host flag of the class (gpcsd_ctx::arena_psd): a fill that writes a positive semi-definite matrix sets it
-    double *bd;                  // band mode (gpcsd_ctx::band_req): 5 x n, bd[j * n + k] = B[k + j][k] of A0 = Q B Q^T, half-bandwidth 4
 };
 int eigh_regtail_rows();         // rows of a whole problem the register tail (sytrd_regtail.hpp) holds: stage 5 applies up to here
-int bt_max_rows();               // rows of a whole problem the band tail (sytrd_bandtail.hpp) can hold
 EigArenaView eigh_arena_view(gpcsd_ctx *c, const char *tag, int n, int count);
 // tags of the two half-size classes of problem `slot` (0 / 1) of eigh_pair_device: [0] symmetric, [1] antisymmetric
 const char *const *eigh_fold_tags(const gpcsd_ctx *c, int slot);     // (slot 1: the tag set of the context's current generation, gpcsd_ctx::tgen)
@@ -320,8 +307,6 @@ void wy_q_pipeline(gpcsd_ctx *c, const WyBatch &b, int nclass, hipStream_t s,
                    const std::function<void(const int *col0, const int *col1)> &chunk, bool one_launch = false);
 // stages of the large-n solver, exposed for tests / diagnostics
 void sytrd_device(gpcsd_ctx *c, double *A, int n, double *d, double *e, double *V, double *tau, hipStream_t s);
-// the band tail on its own (sytrd_bandtail.hpp): A = Q B Q^T, band (5 x n: band[j * n + k] = B[k + j][k]), reflectors as sytrd_device
-void sybrd_device(gpcsd_ctx *c, double *A, int n, double *band, double *V, double *tau, hipStream_t s);
 void stedc_device(gpcsd_ctx *c, const double *d, const double *e, int n, double *w, double *Z, int *d_status,
                   hipStream_t s, const char *tag);
 

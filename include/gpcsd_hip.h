@@ -169,10 +169,6 @@ int gpcsd_eigh_batch(gpcsd_ctx *ctx, const double *A, int n, int count, double *
 /* Diagnostics for the large-n eigensolver stages (no reference counterpart; LAPACK does these inside dsyevd):
  * Householder tridiagonalisation A = Q T Q^T: d (n), e (n, last unused), reflectors V (n,n) by rows, tau (n) */
 int gpcsd_debug_sytrd(gpcsd_ctx *ctx, const double *A, int n, double *d, double *e, double *V, double *tau);
-/* the BAND tail of the same stage on its own (gpcsd_band_tail below): A = Q B Q^T with B of half-bandwidth 4,
- * band (5,n): band[j][k] = B[k + j][k]; reflectors V (n,n) by rows (reflector k has its support from row k + 4 on), tau (n).
- * 8 < n <= 252 (what the single-workgroup kernel holds). */
-int gpcsd_debug_sybrd(gpcsd_ctx *ctx, const double *A, int n, double *band, double *V, double *tau);
 /* divide & conquer eigen-decomposition of tridiag(d (n), e (n-1)): w ascending, Z (n,n) eigenvectors in columns */
 int gpcsd_debug_stedc(gpcsd_ctx *ctx, const double *d, const double *e, int n, double *w, double *Z);
 /* comp_eig_D(Ks, Kt, sig2n)            utility_functions.py:44-64 ; Dvec has nx*nt entries */
@@ -339,16 +335,6 @@ int gpcsd_pair_share_x(gpcsd_ctx *ctx, int on, long *calls);
  * slower, DESIGN 4.13, and the pair then differs from its fenced calls in the last bits; GPCSD_PAIR_SHARE_S=1 for new contexts),
  * < 0 only queries; *calls counts the pairs that took it. */
 int gpcsd_pair_share_s(gpcsd_ctx *ctx, int on, long *calls);
-/* Band tail (round 5).  A fused call whose consumers all work in the basis U (x) Q -- the log-likelihood (gpcsd1d.py:113-128) and
- * the prediction (gpcsd1d.py:248-293) in their shifted-system forms (gpcsd_ll_tridiag below) -- never reads the temporal spectrum,
- * only solves (es[x'] m B + sig2 I) systems and takes their determinants.  Its temporal side (utility_functions.py:58, the eigh of
- * Kt) is then reduced to a matrix B of HALF-BANDWIDTH 4 instead of a tridiagonal one: the same flops, but the single-workgroup
- * reduction kernel synchronises once per panel of four columns instead of per column (it is the longest launch of a
- * latency-bound step), and the shifted systems become banded L D L^T factorisations with four multipliers per column.  Exact
- * algebra, same results to rounding.  Applies to temporal blocks of at most 252 rows after symmetry folding.
- * on = 1 / 0 switches it (default 0 -- measured slower end to end; GPCSD_BAND_TAIL=1 for new contexts), < 0 only
- * queries; *calls counts the chains that took it. */
-int gpcsd_band_tail(gpcsd_ctx *ctx, int on, long *calls);
 /* Pipelined orthogonal factor (round 5).  The tridiagonal forms (gpcsd_ll_tridiag below) need Q of Kt = Q T Q^T
  * (utility_functions.py:58) and X = Y~ Q before anything else of their tails can start, and both used to wait for the END of the
  * tridiagonalisation -- the longest launch of a step.  Column j of Q only depends on the reflectors in front of it, so the

@@ -350,105 +350,6 @@ def loglik_tridiagonal(geom, hp, lfp):
     return -0.5 * R * sumlog - 0.5 * quad
 
 
-def band_reduce(A, b=4):
-    """Q^T A Q = B with half-bandwidth b by panels of b columns (NumPy model of gpcsd_amd/csrc/sytrd_bandtail.hpp; checker code):
-    per panel a Householder QR of the part below the band, then the two-sided update of the trailing block.  Returns
-    (band (b + 1, n) with band[j, k] = B[k + j, k], V (n, n): row k = reflector k, tau (n))."""
-    A = np.array(A, dtype=np.float64, copy=True)
-    n = A.shape[0]
-    Vs, taus = np.zeros((n, n)), np.zeros(n)
-    j0 = 0
-    while j0 + b < n - 1:
-        m0 = j0 + b
-        P = A[m0:, j0:j0 + b].copy()
-        m = n - m0
-        V, tau = np.zeros((m, b)), np.zeros(b)
-        for j in range(b):
-            if m - j < 2:
-                break
-            x = P[j:, j]
-            alpha, xn2 = x[0], float(x[1:] @ x[1:])
-            if xn2 <= 0.0 or alpha * alpha + xn2 <= 1e-100:
-                continue
-            s = np.sqrt(alpha * alpha + xn2)
-            beta = -np.copysign(s, alpha)
-            v = x.copy()
-            v[0] = alpha - beta
-            t = (1.0 / s) / abs(v[0])                     # H = I - t v v^T
-            V[j:, j], tau[j] = v, t
-            for jp in range(j + 1, b):
-                P[j:, jp] -= t * (v @ P[j:, jp]) * v
-            P[j, j] = beta
-            P[j + 1:, j] = 0.0
-        T = np.zeros((b, b))
-        for i in range(b):                                # compact WY: Q_p = I - V T V^T (LAPACK dlarft)
-            T[i, i] = tau[i]
-            if i > 0:
-                T[:i, i] = -tau[i] * (T[:i, :i] @ (V[:, :i].T @ V[:, i]))
-        A22 = A[m0:, m0:]
-        X = A22 @ V
-        Y = X @ T
-        M = T.T @ (V.T @ X) @ T
-        Z = Y - 0.5 * V @ M
-        A22 -= Z @ V.T + V @ Z.T
-        A[m0:, j0:j0 + b] = P
-        A[j0:j0 + b, m0:] = P.T
-        for j in range(b):
-            Vs[j0 + j, m0:] = V[:, j]
-            taus[j0 + j] = tau[j]
-        j0 += b
-    band = np.zeros((b + 1, n))
-    for j in range(b + 1):
-        band[j, :n - j] = np.diagonal(A, -j)
-    return band, Vs, taus
-
-
-def band_q(V, tau):
-    """Q = H_0 H_1 ... of the reflectors by rows of V (H_k = I - tau_k v_k v_k^T)."""
-    n = V.shape[0]
-    Q = np.eye(n)
-    for k in range(n):
-        if tau[k] != 0.0:
-            Q -= tau[k] * np.outer(Q @ V[k], V[k])
-    return Q
-
-
-def band_dense(band):
-    b1, n = band.shape
-    B = np.zeros((n, n))
-    for j in range(b1):
-        idx = np.arange(n - j)
-        B[idx + j, idx] = band[j, :n - j]
-        B[idx, idx + j] = band[j, :n - j]
-    return B
-
-
-def loglik_banded(geom, hp, lfp, b=4):
-    """The log-likelihood from the BAND form of the temporal side: Kt = Q B Q^T with half-bandwidth b, so that
-    Ks (x) Kt + sig2n I is, in the basis Qs (x) Q, the set of shifted banded matrices es[x] B + sig2n I -- their Cholesky factors
-    give sum log D and the quadratic form (gpcsd1d.py:113-128).  Checker code (SciPy banded Cholesky), scalar noise only."""
-    import scipy.linalg as sla
-    lfp = np.atleast_3d(lfp)
-    nx, nt, R = lfp.shape
-    assert np.ndim(hp["sig2n"]) == 0
-    Ks = spatial_kphi(geom, hp) + hp["jitter"] * np.eye(nx)
-    Kt = temporal_sum(hp["temporal"], geom.t)
-    es, Qs = np.linalg.eigh(Ks)
-    band, V, tau = band_reduce(Kt, b)
-    Q = band_q(V, tau)
-    sig2 = float(hp["sig2n"])
-    W = np.einsum("xa,xtr,tb->abr", Qs, lfp, Q)      # (x', t', r)
-    sumlog, quad = 0.0, 0.0
-    for a in range(nx):
-        ab = es[a] * band
-        ab[0] += sig2
-        cb = sla.cholesky_banded(ab, lower=True)
-        sumlog += 2.0 * np.sum(np.log(cb[0]))
-        x = sla.cho_solve_banded((cb, True), W[a])
-        quad += np.sum(W[a] * x)
-    return -0.5 * R * sumlog - 0.5 * quad
-
-
 def predict(geom, hp, lfp, z, tstar, type="csd"):
     """Posterior mean, structured form of gpcsd1d.py:248-293 / gpcsd2d.py:289-334.
 

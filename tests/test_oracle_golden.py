@@ -121,35 +121,6 @@ def test_model_loglik_tridiagonal_form(name):
     assert abs(ll_tri - float(g["loglik"])) / abs(float(g["loglik"])) < 1e-9
 
 
-@pytest.mark.parametrize("name", [n for n in MODEL_CASES if np.ndim(C.model_cases()[n]["sig2n"]) == 0
-                                  and C.model_cases()[n]["x"].shape[0] * C.model_cases()[n]["t"].shape[0] <= 24 * 100])
-def test_model_loglik_banded_form(name):
-    """... and with the temporal side only reduced to half-bandwidth 4 (the device's band tail): shifted banded
-    Cholesky factors per spatial eigen-row, restated in NumPy/SciPy -- equal to the eigen form and to the reference's golden value."""
-    c, g, geom, hp, lfp = load_model_case(name)
-    hpj = with_jitter(hp, float(g["jitter"]))
-    ll_band = O.loglik_banded(geom, hpj, lfp)
-    ll = O.loglik(geom, hpj, lfp)
-    assert abs(ll_band - ll) <= 2e-9 * abs(ll)
-    assert abs(ll_band - float(g["loglik"])) / abs(float(g["loglik"])) < 1e-9
-
-
-def test_band_reduction_model():
-    """The NumPy model of the band tail itself: Q^T A Q = B with half-bandwidth 4, Q orthogonal, the spectrum preserved."""
-    rs = np.random.RandomState(3)
-    for n in (9, 23, 64, 101):
-        t = np.arange(n) * 0.4
-        K = 0.5 * np.exp(-0.5 * (t[:, None] - t[None, :]) ** 2 / 20.0 ** 2) + 0.7 * np.exp(-np.abs(t[:, None] - t[None, :]) / 5.0)
-        G = rs.standard_normal((n, n))
-        for A in (K, G + G.T):
-            band, V, tau = O.band_reduce(A, 4)
-            Q, B = O.band_q(V, tau), O.band_dense(band)
-            sc = np.max(np.abs(A))
-            assert np.max(np.abs(Q.T @ Q - np.eye(n))) < 1e-13
-            assert np.max(np.abs(Q.T @ A @ Q - B)) < 1e-13 * n * sc
-            assert np.max(np.abs(np.triu(B, 5))) == 0.0
-
-
 @pytest.mark.parametrize("name", [n for n in MODEL_CASES if not C.model_cases()[n].get("loglik_only")])
 def test_model_predict(name):
     c, g, geom, hp, lfp = load_model_case(name)
