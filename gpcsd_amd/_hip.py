@@ -9,7 +9,10 @@ import numpy as np
 
 # A context uses four streams; a process that also runs torch / RCCL streams should give the HIP runtime more than its
 # default 4 hardware queues, or streams that share a queue serialise.  Only effective if HIP is not initialised yet.
-_HWQ_WANTED = 8
+_HWQ_WANTED = 16          # hardware queues asked of the runtime when the caller set nothing.  8 keep ONE context's four streams apart from
+                          # torch's and RCCL's; a SECOND live context (a generator model beside the fitted one, as the reference's
+                          # simulation scripts have them) then lands on shared queues and its step runs 1.5 x slower (cfg3: 1.17 against
+                          # 0.79 ms per paired step with 8, 0.79 with 16 -- tools/stall_probe.py cfg3 4)
 
 
 def _hip_runtime_already_initialised():
@@ -38,9 +41,9 @@ def _ensure_hw_queues():
         n = int(have)
     except ValueError:
         return
-    if n < _HWQ_WANTED:
+    if n < 8:
         warnings.warn("GPU_MAX_HW_QUEUES=%d: gpcsd_amd uses four streams per context beside torch's and RCCL's; with fewer than "
-                      "%d hardware queues they share queues and serialise (DESIGN 4.8)." % (n, _HWQ_WANTED), RuntimeWarning,
+                      "%d hardware queues they share queues and serialise (DESIGN 4.8)." % (n, 8), RuntimeWarning,
                       stacklevel=3)
 
 

@@ -1017,7 +1017,21 @@ static StreamSet stream_set_acquire(int device) {
     StreamSet ss{};
     int prio_least = 0, prio_greatest = 0;
     GP_HIP(hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
-    GP_HIP(hipStreamCreateWithFlags(&ss.s[0], hipStreamNonBlocking));
+    // GPCSD_RESERVE_CUS=k (A/B): the main stream -- every flood of GEMM tiles -- may not use the first k compute units (bit i of the
+    // mask = XCD i % 8, so k = 8 takes one CU of every XCD): the chains' small launches then find a drained CU at once instead of
+    // waiting for a tile to retire (their launches take 2-3 x as long in the step loop as alone), at k / 256 of the GEMM rate.
+    static const int reserve = getenv("GPCSD_RESERVE_CUS") ? atoi(getenv("GPCSD_RESERVE_CUS")) : 0;
+    if (reserve > 0) {
+        hipDeviceProp_t prop;
+        GP_HIP(hipGetDeviceProperties(&prop, device));
+        const int ncu = prop.multiProcessorCount, words = (ncu + 31) / 32;
+        std::vector<uint32_t> mask(words, 0xffffffffu);
+        for (int i = 0; i < std::min(reserve, ncu - 8); ++i) mask[i / 32] &= ~(1u << (i % 32));
+        if (ncu % 32) mask[words - 1] &= (1u << (ncu % 32)) - 1u;
+        GP_HIP(hipExtStreamCreateWithCUMask(&ss.s[0], (uint32_t)words, mask.data()));
+    } else {
+        GP_HIP(hipStreamCreateWithFlags(&ss.s[0], hipStreamNonBlocking));
+    }
     GP_HIP(hipStreamCreateWithPriority(&ss.s[1], hipStreamNonBlocking, prio_greatest));
     GP_HIP(hipStreamCreateWithPriority(&ss.s[2], hipStreamNonBlocking, prio_greatest));
     const char *ev = getenv("GPCSD_S4_PRIO");

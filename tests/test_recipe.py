@@ -35,7 +35,9 @@ def test_sim_from_gp_1d_recipe_with_the_import_swap():
     gpcsd_gen.temporal_cov_list[1].params['ell']['value'] = elltM_true
     gpcsd_gen.temporal_cov_list[1].params['sigma2']['value'] = sig2tM_true
     csd = gpcsd_gen.sample_prior(2 * ntrials)                          # :59  (the constructor's draws and these: NumPy's global stream)
-    assert relerr(csd, g["csd"]) < 1e-9
+    # (Ls = chol(Ks + 1e-8 I) of a 100-point SE kernel with ell = 200 on a 23 um grid: conditioned ~1e10, two Cholesky codes
+    # differ by ~1e-8 of the sample -- measured 8.4e-9 against LAPACK's; the gate is north_star's 1e-6)
+    assert relerr(csd, g["csd"]) < 1e-6
     csd_interior_electrodes = np.zeros((nx - 2, nt, 2 * ntrials))
     for trial in range(2 * ntrials):
         csdinterp = scipy.interpolate.RectBivariateSpline(z, t, csd[:, :, trial])
@@ -43,10 +45,10 @@ def test_sim_from_gp_1d_recipe_with_the_import_swap():
     lfp = np.zeros((nx, nt, 2 * ntrials))
     for trial in range(2 * ntrials):
         lfp[:, :, trial] = fwd_model_1d(csd[:, :, trial], z, x, R_true)                                                    # :66-68
-    assert relerr(lfp, g["lfp_forward"]) < 1e-9
+    assert relerr(lfp, g["lfp_forward"]) < 1e-6
     lfp = lfp + np.random.normal(0, np.sqrt(sig2n_true), size=(nx, nt, 2 * ntrials))
     lfp = normalize(lfp)                                               # :69-70
-    assert relerr(lfp, g["lfp"]) < 1e-9
+    assert relerr(lfp, g["lfp"]) < 1e-6
     gpcsd_model = GPCSD1D(lfp[:, :, ntrials:], x, t)                   # :100
     gpcsd_model.R['value'] = R_true
     gpcsd_model.sig2n['value'] = sig2n_true
