@@ -1015,6 +1015,7 @@ static StreamSet stream_set_acquire(int device) {
         }
     }
     StreamSet ss{};
+    try {
     int prio_least = 0, prio_greatest = 0;
     GP_HIP(hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
     // GPCSD_RESERVE_CUS=k (A/B): the main stream -- every flood of GEMM tiles -- may not use the first k compute units (bit i of the
@@ -1037,6 +1038,11 @@ static StreamSet stream_set_acquire(int device) {
     const char *ev = getenv("GPCSD_S4_PRIO");
     if (ev && ev[0] == '0') GP_HIP(hipStreamCreateWithFlags(&ss.s[3], hipStreamNonBlocking));
     else GP_HIP(hipStreamCreateWithPriority(&ss.s[3], hipStreamNonBlocking, prio_greatest));
+    } catch (...) {                        // a stream that could not be created: the ones that were do not leak
+        for (int i = 0; i < 4; ++i)
+            if (ss.s[i]) (void)hipStreamDestroy(ss.s[i]);
+        throw;
+    }
     std::lock_guard<std::mutex> lk(g_stream_pool_mu);
     ++g_stream_sets_created;
     return ss;
@@ -1128,8 +1134,9 @@ extern "C" int gpcsd_ctx_create(int device, gpcsd_ctx **out) {
         *out = c;
         return 0;
     } catch (const HipError &e) {
-        if (c) stream_set_release(c->device, StreamSet{{c->stream, c->stream2, c->stream3, c->stream4}});
-        delete c;
+        // the same teardown as a context that was created: events, page-locked blocks and streams made so far (every handle of a
+        // fresh gpcsd_ctx is null until it is created, and gpcsd_ctx_destroy checks each)
+        if (c) (void)gpcsd_ctx_destroy(c);
         return fail(nullptr, e);
     }
 }

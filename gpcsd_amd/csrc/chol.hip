@@ -284,13 +284,12 @@ __global__ __launch_bounds__(DNT) void diag128_kernel(double *Ablk, long lda, in
 
 static void launch_diag(double *Ablk, long lda, int nb, double *Xout, long ldx, int *status, int pivot_base, bool factor,
                         hipStream_t s, unsigned long long *clk = nullptr, unsigned int *started = nullptr, unsigned int token = 0) {
-    static bool attr_done = false;
-    if (!attr_done) {
+    static PerDeviceOnce attr_once;
+    if (attr_once.first()) {
         GP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(diag128_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int)DIAG_LDS_BYTES));
         GP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(diag128_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int)DIAG_LDS_BYTES));
-        attr_done = true;
     }
     if (factor)
         hipLaunchKernelGGL(diag128_kernel<true>, dim3(1), dim3(DNT), DIAG_LDS_BYTES, s, Ablk, lda, nb, Xout, ldx, status, pivot_base, clk,

@@ -61,6 +61,22 @@ struct SymDev {
 
 }  // namespace gpcsd
 
+// hipFuncSetAttribute applies to the CURRENT device's copy of a kernel: raise an attribute once per (call site, device), not once
+// per process (a second device of the same process would otherwise launch with the default 64 KB of dynamic LDS)
+namespace gpcsd {
+struct PerDeviceOnce {
+    bool done[64] = {};
+    bool first() {
+        int d = 0;
+        (void)hipGetDevice(&d);
+        d &= 63;
+        if (done[d]) return false;
+        done[d] = true;
+        return true;
+    }
+};
+}  // namespace gpcsd
+
 struct gpcsd_ctx {
     int device = 0;
     hipStream_t stream = nullptr;

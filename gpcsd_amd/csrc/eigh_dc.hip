@@ -286,12 +286,10 @@ static void sytrd_batch_launch(gpcsd_ctx *c, const SytrdBatch &b, int nclass, in
         size_t sh = 0;
         for (int i = 0; i < nclass; ++i)
             if (b.p[i].k_tail < b.p[i].n - 1) sh = std::max(sh, rt_strip_bytes(b.p[i].n - b.p[i].k_tail));
-        static bool rt_attr_set = false;
-        if (!rt_attr_set) {
+        static PerDeviceOnce rt_attr;
+        if (rt_attr.first())
             GP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(sytrd_rtail_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)rt_strip_bytes(RT_TMAX)));
-            rt_attr_set = true;
-        }
         // profiled on its own: this single launch (one workgroup per problem) is the largest share of the GPU time of an
         // evaluation; flops = (4/3) T^3 per problem, the nominal count of a Householder tridiagonalisation
         double fl = 0.0;

@@ -914,7 +914,8 @@ void k_tridiag_solve(gpcsd_ctx *c, const double *W, double *B, const double *es,
     static const int forced = getenv("GPCSD_TS_P") ? (atoi(getenv("GPCSD_TS_P")) == 32 ? 32 : 64) : 0;
     const int P = forced ? forced : (R <= 32 || c->solve_pass == 32) ? 32 : TS_P_DEFAULT;
     const size_t lds = tridiag_solve_lds(npmax, P);
-    static size_t attr[2] = {0, 0};
+    static size_t attr_dev[64][2] = {};            // (per device: the attribute belongs to the device's copy of the kernel)
+    size_t *attr = attr_dev[c->device & 63];
     if (lds > attr[P == 32]) {
         if (P == 32) GP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(tridiag_solve_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         else GP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(tridiag_solve_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

@@ -130,6 +130,13 @@ __global__ __launch_bounds__(RT_NTH) void sytrd_rtail_kernel(SytrdBatch b) {
     // (The rows of V and tau leave as agent-scope stores -- written through the XCD's L2 -- so that the release needs no write-back
     // of that L2 (a __threadfence here writes back whatever the GEMM tiles of the other streams left dirty in it: the tail of a
     // pipelined cfg3 step measured 35 us longer); every thread waits for its own stores, the barrier collects the waits.)
+    // The word itself is published by a RELAXED agent-scope store behind `s_waitcnt vmcnt(0)` + the barrier: that is a release only
+    // where stores are counted in vmcnt and agent-scope (sc1) stores write through the L2 -- gfx942 / gfx950.  A target with a
+    // separate store counter (vscnt) needs __ATOMIC_RELEASE here (measured on gfx950: +30 us per tail, the fence writes the XCD's
+    // whole L2 back under the other streams' GEMM traffic).  build.py compiles for gfx950 only; anything else must not get this far:
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__) && !defined(__gfx942__)
+#error "sytrd_regtail.hpp: the progress word's release relies on gfx942 / gfx950 memory-counter semantics (see publish())"
+#endif
     auto publish = [&](const int done) {
         const int upto = done & ~63;
         if (!pipe || upto <= published) return;

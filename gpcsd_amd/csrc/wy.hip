@@ -497,11 +497,10 @@ static void wy_clk_print(gpcsd_ctx *c, unsigned long long *d, const char *what, 
 }
 
 static void wy_prep_launch(const WyBatch &b, int maxP, int count, hipStream_t s) {
-    static bool attr_set = false;
-    if (!attr_set) {
+    static PerDeviceOnce attr_once;
+    if (attr_once.first()) {
         GP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(wy_prep_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int)WY_PREP_LDS));
-        attr_set = true;
     }
     hipLaunchKernelGGL(wy_prep_kernel, dim3(maxP, count), dim3(1024), WY_PREP_LDS, s, b);
 }
@@ -539,13 +538,12 @@ void wy_batch_device(gpcsd_ctx *c, const WyBatch &b, int nclass, hipStream_t s, 
     const int count = b.start[MAX_EIG_BATCH];          // all replicas of all classes
     const bool split = wy_apply_lds(nmax, WY_KS) <= 160 * 1024;
     const size_t sh = wy_apply_lds(nmax, split ? WY_KS : 1);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static PerDeviceOnce attr_once;
+    if (attr_once.first()) {
         GP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(wy_apply_kernel<WY_KS>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         GP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(wy_apply_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                    160 * 1024));
-        attr_set = true;
     }
     const WyBatch w = wy_with_clk(c, b, s);
     if (!prep_done) wy_prep_launch(w, maxP, count, s);
@@ -569,11 +567,9 @@ void wy_q_pipeline(gpcsd_ctx *c, const WyBatch &b, int nclass, hipStream_t s,
     const int count = b.start[MAX_EIG_BATCH];
     const size_t sh = wq_lds_bytes(nmax);
     GP_REQUIRE(sh <= 160 * 1024, -3, "wy_q_pipeline: %d rows do not fit the stage kernel", nmax);
-    static bool attr_set[64] = {};                 // per device: a function attribute belongs to the device's code object
-    if (!attr_set[c->device & 63]) {
+    static PerDeviceOnce attr_once;
+    if (attr_once.first())
         GP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(wy_qstage_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set[c->device & 63] = true;
-    }
     WyBatch bc = b;
     // behind the END of the tail (one_launch) a gate finds its word at "done" whatever its patience; beside a running tail it is
     // gpcsd_ctx::q_gate_ticks (GPCSD_QPIPE_GATE_TICKS=0: every gate gives up -- tests/test_q_pipeline.py drives the replay with it)
