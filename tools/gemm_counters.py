@@ -11,6 +11,8 @@ import sys
 
 d, out = sys.argv[1], sys.argv[2]
 top = int(sys.argv[3]) if len(sys.argv) > 3 else 4
+WANT = ("gemm", "wy_qstage", "wy_apply", "tridiag_solve")          # the MFMA kernels of a step (round 6: stage 5's and the solve as well)
+want = lambda name: any(w in name for w in WANT)
 cc = glob.glob(d + "/**/*counter_collection.csv", recursive=True)
 kt = glob.glob(d + "/**/*kernel_trace.csv", recursive=True)
 assert cc, "no counter_collection.csv under " + d
@@ -20,14 +22,14 @@ key = lambda r: (r["Kernel_Name"], r.get("Grid_Size", r.get("Grid_Size_X", "")))
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 disp = collections.defaultdict(set)
 for r in rows:
-    if "gemm" not in r["Kernel_Name"]:
+    if not want(r["Kernel_Name"]):
         continue
     acc[key(r)][r["Counter_Name"]].append(float(r["Counter_Value"]))
     disp[key(r)].add(r.get("Dispatch_Id", ""))
 dur = collections.defaultdict(list)
 seen = set()
 for r in rows:                                     # (the counter rows carry their dispatch's time stamps)
-    if "gemm" in r["Kernel_Name"] and r.get("Dispatch_Id") not in seen and r.get("Start_Timestamp"):
+    if want(r["Kernel_Name"]) and r.get("Dispatch_Id") not in seen and r.get("Start_Timestamp"):
         seen.add(r.get("Dispatch_Id"))
         dur[key(r)].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
 med = lambda v: sorted(v)[len(v) // 2] if v else None
