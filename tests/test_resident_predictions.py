@@ -7,7 +7,7 @@
     spatial decomposition per pair (gpcsd_pair_share_s), against the ORACLE: loglik 1e-9, csd and both component lists 1e-6;
   * trial-sharded predictions gathered on the device over RCCL (`nccl`, one rank on the one-GPU box): no host staging -- the only
     device-to-host traffic is the gathered result;
-  * three models opened one after another in one process: an interval above 3 ms only inside a model's first quarter second.
+  * three models opened one after another in one process: an interval above 3 ms only inside a model's first 0.45 s -- the window bench.py settles through.
 """
 import os
 import socket
@@ -160,13 +160,13 @@ def test_sharded_predictions_are_gathered_on_the_device_over_rccl_without_host_s
     assert abs(ll - ll_ref) <= 1e-6 * abs(ll_ref)
 
 
-def test_three_models_in_one_process_stall_only_in_their_first_quarter_second():
+def test_three_models_in_one_process_stall_only_inside_the_settle_window():
     """DESIGN 6 (the 10-30 ms stall), as characterised in round 6: about every second model of a process sees ONE interval of
     9 / 19 / 29 ms in which none of its queues make progress, 35-110 ms after the model's first evaluation -- never later, and never
     caused by allocations, frees or new contexts while a model is in steady state (tools/stall_probe.py, tools/stall_inject.py).
     Three models opened one after another (cfg2's shape), every paired step's completion time-stamped on the host: an interval
-    above 3 ms may only end inside the first 0.25 s of its model's life, and the 300 steps after 0.45 s contain none -- the window
-    bench.py's step loops keep out of their timed region (bench.SETTLE_S)."""
+    above 3 ms may only end inside the first 0.45 s of its model's life (measured: 35-110 ms), and the 300 steps after that contain
+    none -- the window bench.py's step loops keep out of their timed region (bench.SETTLE_S)."""
     import gc
     import bench
     from gpcsd_amd import _hip
@@ -198,7 +198,8 @@ def test_three_models_in_one_process_stall_only_in_their_first_quarter_second():
         big = [(round(float(st[i + 1] - t0), 3), round(float(iv[i]), 1)) for i in np.nonzero(iv > 3.0)[0] if i >= 3]   # (the first calls allocate and capture)
         late = [(round(float(st[i + 1] - t0), 3), round(float(iv[i]), 1)) for i in np.nonzero(iv > 3.0)[0] if i >= n_early - 1]
         seen.append({"stalls (s after first evaluation, ms)": big, "median_ms": round(float(np.median(iv)), 3)})
-        assert all(t_end <= 0.25 for t_end, _ in big), seen
+        # (measured: every stall ended 35-110 ms after the first evaluation; the gate is the window bench.py keeps clear of)
+        assert all(t_end <= 0.45 for t_end, _ in big), seen
         assert not late, seen
         del m, ctx
         gc.collect()
