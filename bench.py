@@ -11,11 +11,13 @@ predict(z = electrodes, t, type="csd") of every resident trial, inputs resident 
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
     python bench.py --workload cfg2          # GPCSD1D 24 x 500 x 200 trials (BASELINE configs[1]), same step
+    python bench.py --workload cfg3fit       # GPCSD2D.fit() at the headline geometry: objective + analytic gradient evaluations
     python bench.py --workload cfg5          # GPCSD1D fit: restarts evaluated in lock-step batches (BASELINE configs[4])
     python bench.py --only-value             # setup + warm-up + timed loop and nothing else: the command the rocprofv3 kernel
-                                             # stats / PMC passes under profiles/ are taken over (tools/profile_r03.sh)
-The default cfg3 line at N=1 also carries compact cfg2 and cfg5 sub-results (`sub_results`, a few seconds) so that the driver's
-record holds them; --no-sub-results skips them.
+                                             # stats / PMC passes under profiles/ are taken over (tools/profile_r06.sh)
+The default cfg3 line at N=1 also carries compact cfg2 / cfg3fit / cfg5 / npx69 / aud24 / potrf sub-results (each a child process of
+its own) so that the driver's record holds them; --no-sub-results skips them.  The measuring code lives in benchlib/ (workloads,
+step, fit, cpu, profiles, line); this file is the contract: CLI, rank launch, sub-results, the printed line.
 
 Rank 0 prints ONE JSON line.
   roofline      step level, as SURVEY 8(d) specifies: flops per step / ms_per_step against the fp64 MFMA peak, once in flops
@@ -47,344 +49,15 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
 
-SETTLE_S = 0.5                    # the timed region of a step loop starts no earlier than this after the model's first evaluation
-FP64_MFMA_SPEC_TFLOPS = 78.6      # AMD public MI355X fp64 matrix spec (v_mfma_f64_16x16x4_f64); not in the local guides
-HBM_PEAK_GBS = 8000.0
-N_CUS = 256
 
-
-def neuropixels_xy(nchan):
-    c = np.arange(nchan)
-    return np.stack([np.array([16.0, 48.0, 0.0, 32.0])[c % 4], np.floor(c / 2) * 20.0], axis=1)
-
-
-def workload(name):
-    if name == "cfg3":
-        return dict(dim=2, nx=384, nt=500, x=neuropixels_xy(384), t=0.4 * np.arange(500.0)[:, None], ngl1=20, ngl2=60,
-                    R=100.0, eps=80.0, ell_s=(40.0, 150.0), temporal=[(0, 20.0, 0.5), (1, 5.0, 0.7)], sig2n=0.05,
-                    trials_per_gpu=50, label="GPCSD2D 384ch x 500t x 50 trials/GPU, fp64, ngl 20x60 (BASELINE cfg3/cfg4)")
-    if name == "cfg3fit":
-        # GPCSD2D.fit() at the headline geometry (gpcsd2d.py:153-287: obj_fun :196-219, minimize(..., jac=grad) :250): the unit is
-        # one objective + analytic-gradient evaluation over the 50 resident trials.  Restarts start 0.25 log-units around the
-        # hyper-parameters the data were drawn from (the default priors' variance draws are 1e8 x the data's scale on this
-        # geometry -- Ks is O(1e8) -- so prior-drawn starts would time a degenerate objective).
-        w = workload("cfg3")
-        w.update(restarts=8, starts_around_truth=0.25,
-                 label="GPCSD2D fit, 384ch x 500t x 50 trials on every GPU, fp64, ngl 20x60: objective + analytic gradient per "
-                       "evaluation, 8 restarts 0.25 log-units around the generating hyper-parameters (gpcsd2d.py:153-287)")
-        return w
-    if name in ("cfg2", "cfg5"):
-        w = dict(dim=1, nx=24, nt=500, x=np.linspace(0, 2300, 24)[:, None], t=np.arange(500.0)[:, None], ngl=100,
-                 R=100.0, eps=0.0, ell_s=(200.0,), temporal=[(0, 20.0, 0.5), (1, 5.0, 0.7)], sig2n=0.05,
-                 trials_per_gpu=200, label="GPCSD1D 24 x 500t x 200 trials/GPU, fp64, ngl 100 (BASELINE cfg2)")
-        if name == "cfg5":
-            w["label"] = ("GPCSD1D fit, 24 x 500t x 200 trials on every GPU, restarts sharded over GPUs (BASELINE cfg5: "
-                          "32 restarts over 8 GPUs = 4 per GPU)")
-            w["restarts_per_gpu"] = 4
-        return w
-    if name == "aud24":
-        # The reference's own 1D workload (auditory_lfp/fit_gpcsd_baseline.py:31-37,79-101): a 24-contact laminar probe, the 500 ms
-        # baseline period at 1 kHz, integration limits widened to (-200, 2600), an SE + a Matern temporal component with the
-        # script's ell priors, and ONE HALF-NORMAL NOISE PRIOR PER ELECTRODE -- a 24-entry sig2n list, i.e. 30 parameters, the
-        # merged eigen-order path and the eigenvector-rotation term of the gradient -- then fit(n_restarts) and predict.
-        nx = 24
-        return dict(dim=1, nx=nx, nt=500, x=np.linspace(0, 2300, nx)[:, None], t=np.arange(-500.0, 0.0)[:, None], ngl=100,
-                    a=-200.0, b=2600.0, R=100.0, eps=0.0, ell_s=(200.0,), temporal=[(0, 50.0, 0.5), (1, 5.0, 0.7)],
-                    ell_priors=[(30.0, 100.0), (1.0, 20.0)],
-                    sig2n=0.05, sig2n_list=[0.03 + 0.04 * ((7 * k) % 24) / 23.0 for k in range(nx)], trials_per_gpu=200, restarts=20,
-                    z100=np.linspace(0, 2300, 100)[:, None],
-                    label="GPCSD1D fit, 24 x 500t x 200 trials/GPU, 24-entry sig2n list, a=-200 b=2600, 20 restarts in lock-step "
-                          "(auditory_lfp/fit_gpcsd_baseline.py:79-101; the script itself sets n_restarts = 10 at :25)")
-    if name == "npx69fit":
-        w = workload("npx69")
-        w["label"] = "GPCSD2D fit, " + w["label"] + ": 20 restarts in lock-step"
-        return w
-    if name in ("npx69", "npx72sym"):
-        # The reference's own 2D workload (neuropixels/fit_gpcsd2d.py:36-41,86-90,101,107): the 69 V1 channels of one probe (a slice of
-        # the checkerboard without its two reference channels: NO mirror symmetry), 376 samples at 2.5 kHz (-40 .. 110 ms), 150
-        # trials, ngl 30 x 120, eps = 1, integration limits widened by 16 / 100 um, fit(n_restarts=20), then predict at four
-        # off-grid depths.  "npx72sym": the control -- 72 channels of the same probe that ARE point-symmetric (212 .. 283).
-        if name == "npx69":
-            chans = np.array([c for c in range(213, 284) if c not in (227, 264)])
-        else:
-            chans = np.arange(212, 284)
-        x = neuropixels_xy(384)[chans]
-        t = (-40.0 + 0.4 * np.arange(376.0))[:, None]
-        return dict(dim=2, nx=len(chans), nt=376, x=x, t=t, ngl1=30, ngl2=120, R=100.0, eps=1.0, ell_s=(40.0, 150.0),
-                    temporal=[(0, 20.0, 0.5), (1, 5.0, 0.7)], sig2n=0.05, trials_per_gpu=150,
-                    limits=dict(a1=float(x[:, 0].min()) - 16.0, b1=float(x[:, 0].max()) + 16.0, a2=float(x[:, 1].min()) - 100.0,
-                                b2=float(x[:, 1].max()) + 100.0),
-                    # npx69: the script's four depths.  The control predicts at four sites that share ITS electrodes' point symmetry
-                    # (centre (24, 2470)): both then run the paired, folded step and the comparison is of the spatial side alone
-                    z=(np.stack([24.0 * np.ones(4), np.array([2260.0, 2450.0, 2650.0, 2785.0])]).T if name == "npx69" else
-                       np.stack([24.0 * np.ones(4), np.array([2260.0, 2400.0, 2540.0, 2680.0])]).T), restarts=20,
-                    label="GPCSD2D %d ch%s x 376t x 150 trials/GPU, fp64, ngl 30x120, eps 1, predict at 4 off-grid sites "
-                          "(neuropixels/fit_gpcsd2d.py%s)" % (len(chans), " (no mirror symmetry)" if name == "npx69" else " (point-symmetric control)",
-                                                              "" if name == "npx69" else "'s shape"))
-    raise SystemExit("unknown workload %r" % name)
-
-
-def build_model(w, lfp):
-    from gpcsd_amd.gpcsd1d import GPCSD1D
-    from gpcsd_amd.gpcsd2d import GPCSD2D
-    from gpcsd_amd.covariances import GPCSDTemporalCovSE, GPCSDTemporalCovMatern
-    np.random.seed(0)
-    tcl = []
-    for i, (kind, ell, s2) in enumerate(w["temporal"]):
-        tc = GPCSDTemporalCovSE(w["t"]) if kind == 0 else GPCSDTemporalCovMatern(w["t"])
-        if "ell_priors" in w:
-            tc.params["ell"]["prior"].set_params(*w["ell_priors"][i])
-        tc.params["ell"]["value"], tc.params["sigma2"]["value"] = ell, s2
-        tcl.append(tc)
-    if w["dim"] == 1:
-        from gpcsd_amd.priors import GPCSDHalfNormalPrior
-        noise = [GPCSDHalfNormalPrior(0.1) for _ in range(w["nx"])] if "sig2n_list" in w else None
-        m = GPCSD1D(lfp, w["x"], w["t"], a=w.get("a", 0.0), b=w.get("b", 2300.0), ngl=w["ngl"], temporal_cov_list=tcl, sig2n_prior=noise)
-        m.spatial_cov.params["ell"]["value"] = w["ell_s"][0]
-    else:
-        m = GPCSD2D(lfp, w["x"], w["t"], ngl1=w["ngl1"], ngl2=w["ngl2"], temporal_cov_list=tcl, eps=w["eps"], **w.get("limits", {}))
-        m.spatial_cov.params["ell1"]["value"], m.spatial_cov.params["ell2"]["value"] = w["ell_s"]
-    m.R["value"] = w["R"]
-    m.sig2n["value"] = np.array(w["sig2n_list"], dtype=float) if "sig2n_list" in w else w["sig2n"]
-    return m
-
-
-def synth_data(w, m, ntrials, seed):
-    """Draw trials from the model itself: Y = Qs sqrt(es+) Z (Qt sqrt(et+))^T + sqrt(sig2n) E.
-    In 2D the temporal variances are first rescaled by 1/mean(diag Ks) so Ks (x) Kt is O(1)."""
-    from gpcsd_amd import _hip
-    ctx = _hip.default_context()
-    if w["dim"] == 2:
-        Ks = m.spatial_cov.compKphi_2d(w["R"], w["eps"])
-        md = float(np.mean(np.diag(Ks)))
-        for tc, (_, _, s2) in zip(m.temporal_cov_list, w["temporal"]):
-            tc.params["sigma2"]["value"] = s2 / md
-    else:
-        Ks = m.spatial_cov.compKphi_1d(w["R"])
-    Kt = sum(tc.compute_Kt() for tc in m.temporal_cov_list)
-    es, Qs = ctx.eigh(Ks)
-    et, Qt = ctx.eigh(Kt)
-    # eigenvector signs are solver-dependent: fix them (largest |component| positive) so the synthetic data set does
-    # not change when the eigensolver does
-    for Q in (Qs, Qt):
-        Q *= np.sign(Q[np.argmax(np.abs(Q), axis=0), np.arange(Q.shape[1])])[None, :]
-    Ls = Qs * np.sqrt(np.maximum(es, 0.0))[None, :]
-    Lt = Qt * np.sqrt(np.maximum(et, 0.0))[None, :]
-    rs = np.random.RandomState(seed)
-    Z = rs.standard_normal((ntrials, w["nx"], w["nt"]))
-    E = rs.standard_normal((ntrials, w["nx"], w["nt"]))
-    noise_sd = np.sqrt(np.array(w["sig2n_list"]))[None, :, None] if "sig2n_list" in w else np.sqrt(w["sig2n"])
-    Y = np.matmul(np.matmul(Ls, Z), Lt.T) + noise_sd * E
-    return np.ascontiguousarray(np.moveaxis(Y, 0, 2))           # (nx, nt, R) like the reference
-
-
-def algorithmic_flops(w, R, nz, C):
-    """flops of the reference's (Kronecker-structured) algorithm per loglik evaluation / predict call."""
-    nx, nt = w["nx"], w["nt"]
-    G = w["ngl"] if w["dim"] == 1 else w["ngl1"] * w["ngl2"]
-    # SURVEY 8(d): a build that exploits Kgl = K1 (x) K2 on the 2D tensor grid must count the reduced product it executes
-    f_akgl = 2.0 * nx * G * G if w["dim"] == 1 else 2.0 * nx * G * (w["ngl1"] + w["ngl2"])
-    f_spatial = f_akgl + 2.0 * nx * nx * G
-    f_eig = 9.0 * (nx ** 3 + nt ** 3)
-    f_proj = 2.0 * nx * nx * nt + 2.0 * nx * nt * nt
-    loglik = f_spatial + f_eig + R * f_proj
-    pred_trial = 2.0 * f_proj + 2.0 * nz * nx * nt + C * 2.0 * nz * nt * nt
-    predict = f_spatial + f_eig + 2.0 * nx * G * nz + R * pred_trial
-    return loglik, predict, pred_trial
-
-
-# ------------------------------------------------------------------------------------------------------- CPU baseline
-def _physical_cores():
-    """Distinct (package, core) pairs among the CPUs this process may run on; None if /proc/cpuinfo does not say."""
-    try:
-        allowed = os.sched_getaffinity(0)
-        seen, cpu, pkg = set(), None, None
-        for line in open("/proc/cpuinfo"):
-            k, _, v = line.partition(":")
-            k, v = k.strip(), v.strip()
-            if k == "processor":
-                cpu, pkg = int(v), None
-            elif k == "physical id":
-                pkg = v
-            elif k == "core id" and cpu in allowed:
-                seen.add((pkg, v))
-        return len(seen) or None
-    except Exception:
-        return None
-
-
-def oracle_setup(w, m):
-    from oracle import gpcsd_oracle as O
-    temporal = [(tc.kind, tc.params["ell"]["value"], tc.params["sigma2"]["value"]) for tc in m.temporal_cov_list]
-    if w["dim"] == 1:
-        geom = O.Geometry1D(w["x"], w["t"], a=w.get("a", 0.0), b=w.get("b", 2300.0), ngl=w["ngl"])
-        jit = 1e-8
-    else:
-        geom = O.Geometry2D(w["x"], w["t"], ngl1=w["ngl1"], ngl2=w["ngl2"], **w.get("limits", {}))
-        jit = 1e-7
-    hp = O.make_hparams(w["R"], w["ell_s"], temporal, np.array(w["sig2n_list"]) if "sig2n_list" in w else w["sig2n"], eps=w["eps"],
-                        jitter=jit)
-    hp0 = dict(hp)
-    hp0["jitter"] = 0.0
-    return O, geom, hp, hp0
-
-
-def cpu_baseline(w, m, lfp, budget_s=45.0):
-    """Oracle (NumPy/LAPACK port of the reference's algorithm) timed on the host cores at the SAME trial count as the GPU
-    step.  Checker code, never the product.  Returns (report, loglik, csd prediction) -- the last two feed the parity
-    spot check printed beside the numbers."""
-    from threadpoolctl import threadpool_info, threadpool_limits
-    O, geom, hp, hp0 = oracle_setup(w, m)
-    R = lfp.shape[2]
-    blas_max = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
-    try:
-        affinity = len(os.sched_getaffinity(0))
-    except Exception:
-        affinity = os.cpu_count() or 1
-    cand = sorted({n for n in (1, 8, 16, 32, 64, affinity, blas_max) if 1 <= n <= blas_max})
-    z, t = w.get("z", w["x"]), w["t"]
-
-    def t_loglik(reps):
-        ts, ll = [], None
-        for _ in range(reps):
-            t0 = time.perf_counter()
-            ll = O.loglik(geom, hp, lfp)
-            ts.append(time.perf_counter() - t0)
-        return ts, ll
-
-    def t_predict(reps):
-        ts, out = [], None
-        for _ in range(reps):
-            t0 = time.perf_counter()
-            out = O.predict(geom, hp0, lfp, z, t, type="csd")["csd"]
-            ts.append(time.perf_counter() - t0)
-        return ts, out
-
-    t_begin = time.perf_counter()
-    with threadpool_limits(limits=min(16, blas_max)):
-        O.loglik(geom, hp, lfp[:, :, :1])                         # warm BLAS / page in
-    sweep = {}
-    for n in cand:                                               # quick sweep: which BLAS thread count is fastest here
-        if n == 1:
-            continue                                             # timed on its own below
-        with threadpool_limits(limits=n):
-            ts, _ = t_loglik(2)
-        sweep[n] = min(ts)
-    best = min(sweep, key=sweep.get) if sweep else 1
-    with threadpool_limits(limits=best):
-        ll_ts, ll = t_loglik(5)
-        # >= 20 loglik repetitions unless the time budget is exhausted first (a slow host must not stall the bench)
-        while len(ll_ts) < 20 and time.perf_counter() - t_begin < 0.4 * budget_s:
-            more, ll = t_loglik(1)
-            ll_ts += more
-        pr_ts, pred = t_predict(3)
-    with threadpool_limits(limits=1):
-        ll1_ts, _ = t_loglik(3)
-        pr1_ts, _ = t_predict(3)
-    # The reference projects trial by trial on strided slices lfp[:, :, r] of the (nx, nt, R) array (gpcsd2d.py:147-148); the
-    # oracle uses contiguous trials and one batched matmul (the "fair" flavour of SURVEY 8(d)).  The reference's loglik is
-    # timed directly, piece by piece, in its own order: covariance assembly, comp_eig_D, then its per-trial loop on at most 8
-    # trials (scaled to R; the loop is R independent, identical iterations).
-    nxs = lfp.shape[0]
-    with threadpool_limits(limits=best):
-        t0 = time.perf_counter()
-        Ks = O.spatial_kphi(geom, hp) + hp["jitter"] * np.eye(nxs)
-        Kt = O.temporal_sum(hp["temporal"], geom.t)
-        t_assembly = time.perf_counter() - t0
-        t0 = time.perf_counter()
-        Qs, Qt, D = O.eig_D(Ks, Kt, hp["sig2n"])
-        t_eig = time.perf_counter() - t0
-        nf = min(8, R)
-        quad = 0.0
-        for r in range(min(2, nf)):                                # warm the strided access path
-            alpha = np.reshape(np.dot(np.dot(Qs.T, lfp[:, :, r]), Qt), (nxs * lfp.shape[1]))
-        t0 = time.perf_counter()
-        for r in range(nf):
-            alpha = np.reshape(np.dot(np.dot(Qs.T, lfp[:, :, r]), Qt), (nxs * lfp.shape[1]))
-            quad += np.sum(np.square(alpha) / D)
-        strided_ms = (time.perf_counter() - t0) * 1e3 / nf
-        Yc = np.ascontiguousarray(np.moveaxis(lfp[:, :, :nf], 2, 0))
-        t0 = time.perf_counter()
-        for r in range(nf):
-            alpha = np.reshape(np.dot(np.dot(Qs.T, Yc[r]), Qt), (nxs * lfp.shape[1]))
-            quad += np.sum(np.square(alpha) / D)
-        contiguous_ms = (time.perf_counter() - t0) * 1e3 / nf
-    med = lambda v: float(np.median(v))
-    t_ll_oracle, t_pr = med(ll_ts), med(pr_ts)
-    faithful_ll_s = t_assembly + t_eig + R * strided_ms * 1e-3
-    # two CPU codes compute the log-likelihood: the oracle's batched contiguous products and the reference's own per-trial loop
-    # (timed above, in its order and layout); which is faster depends on the host's BLAS -- `value` takes the faster one
-    t_ll = min(t_ll_oracle, faithful_ll_s)
-    ll_path = ("oracle (contiguous trials, one batched product)" if t_ll_oracle <= faithful_ll_s else
-               "reference order and layout (per-trial products on strided slices, gpcsd2d.py:147-148)")
-    host_cpus = os.cpu_count() or affinity
-    phys = _physical_cores()
-    cores_used = int(min(best, phys)) if phys else int(best)
-    rep = {
-        "value": R / (t_ll + t_pr), "unit": "trials/s", "cores": cores_used, "blas_threads": int(best), "host_cpus": int(host_cpus),
-        "host_physical_cores_in_affinity": phys,
-        "kind": "port", "loglik_path_used_for_value": ll_path,
-        "sample": "oracle loglik x%d (or the reference-layout loop, the faster) + predict(csd) x%d, the bench's own %d trials, medians, "
-                  "%d BLAS threads" % (len(ll_ts), len(pr_ts), R, best),
-        "sample_detail": "bench geometry; NumPy %s; %d BLAS threads = best of sweep %s, on %d physical cores; host has %d cpus, affinity "
-                         "%d, BLAS max %d" % (np.__version__, best, sorted(sweep), cores_used, host_cpus, affinity, blas_max),
-        "loglik_evals_per_sec": 1.0 / t_ll, "oracle_loglik_evals_per_sec": 1.0 / t_ll_oracle, "predict_trials_per_sec": R / t_pr,
-        "single_thread": {"value": R / (med(ll1_ts) + med(pr1_ts)), "loglik_evals_per_sec": 1.0 / med(ll1_ts),
-                          "predict_trials_per_sec": R / med(pr1_ts), "reps": [len(ll1_ts), len(pr1_ts)]},
-        "thread_sweep_loglik_s": {str(k): v for k, v in sorted(sweep.items())},
-        "faithful_layout": {"loglik_evals_per_sec": 1.0 / faithful_ll_s, "loglik_s": faithful_ll_s,
-                            "assembly_s": t_assembly, "eig_pair_s": t_eig,
-                            "projection_ms_per_trial_reference_layout": strided_ms,
-                            "projection_ms_per_trial_contiguous": contiguous_ms,
-                            "note": "the reference's loglik timed directly in its own order: covariance assembly + comp_eig_D + "
-                                    "its per-trial loop on strided slices lfp[:, :, r] (gpcsd2d.py:147-148), the loop timed on %d "
-                                    "trials and scaled to %d; its predict is dense (2 x 295 GB at 384 x 500) and cannot run at "
-                                    "this size, so predict is the structured form in both flavours" % (nf, R)},
-        "seconds_spent": time.perf_counter() - t_begin,
-    }
-    return rep, ll, pred
-
-
-# ------------------------------------------------------------------------------------------------------- committed profiles
-# rocprofv3 summaries of `bench.py --only-value [--workload W]` (tools/profile_r05.sh), one set per workload: a line never
-# inherits another workload's numbers (no file for the workload, or a non-default trial count: null).
-PROFILE_ROUND = "r06"
-
-
-def _profile(kind, wl, ext):
-    p = os.path.join(ROOT, "profiles", "%s_%s_%s.%s" % (PROFILE_ROUND, kind, wl, ext))
-    return p if os.path.exists(p) else None
-
-
-def pmc_step_traffic(wl):
-    """HBM bytes per step from the committed rocprofv3 --pmc passes over `bench.py --only-value` for this workload (FETCH_SIZE
-    x2 on gfx950 + WRITE_SIZE, separate passes; tools/pmc_summary.py).  (None, None) if no profile is committed for it."""
-    path = _profile("pmc_traffic", wl, "json")
-    if path is None:
-        return None, None
-    with open(path) as fh:
-        d = json.load(fh)
-    per_step = d.get("hbm_traffic_bytes_per_step")
-    top = sorted((r for r in d.get("rows", []) if "hbm_traffic_bytes_per_launch" in r),
-                 key=lambda r: -r["hbm_traffic_bytes_per_launch"] * r.get("launches", 1))[:4]
-    return per_step, {"source": "profiles/" + os.path.basename(path), "steps_in_profile": d.get("steps"),
-                      "largest": [{"kernel": r["kernel"][:60], "bytes_per_launch": r["hbm_traffic_bytes_per_launch"],
-                                   "launches_per_step": r.get("launches_per_step")} for r in top]}
-
-
-def rocprof_kernel(wl, kernel_substr):
-    """(share of GPU time, average launch ms, launches, source) of a kernel in the committed `rocprofv3 --kernel-trace --stats`
-    summary of `bench.py --only-value` for this workload; Nones if no profile is committed for it."""
-    import csv
-    path = _profile("kernel_stats", wl, "csv")
-    if path is None:
-        return None, None, None, None
-    with open(path) as fh:
-        for row in csv.DictReader(fh):
-            if kernel_substr in row.get("Name", ""):
-                return (float(row["Percentage"]) / 100.0, float(row["AverageNs"]) * 1e-6, int(row["Calls"]),
-                        "profiles/" + os.path.basename(path))
-    return None, None, None, "profiles/" + os.path.basename(path)
+# The parts (names re-exported: tests and tools use bench.workload, bench.build_model, bench.synth_data, ...)
+from benchlib.workloads import (FP64_MFMA_SPEC_TFLOPS, HBM_PEAK_GBS, N_CUS, SETTLE_S, algorithmic_flops, build_model,  # noqa: E402,F401
+                                neuropixels_xy, oracle_setup, synth_data, workload)
+from benchlib.cpu import cpu_baseline  # noqa: E402,F401
+from benchlib.profiles import PROFILE_ROUND, pmc_step_traffic, rocprof_kernel  # noqa: E402,F401
+from benchlib.line import DETAIL_FILE, LINE_LIMIT, _NESTED_KEYS, _TOP_KEYS, compact_record, sub_headlines  # noqa: E402,F401
+from benchlib.step import run_step_bench  # noqa: E402,F401
+from benchlib.fit import _quiesce_host, potrf_bench, run_fit_bench  # noqa: E402,F401
 
 
 # ------------------------------------------------------------------------------------------------------- launcher
@@ -525,82 +198,6 @@ def main():
         emit(out)
 
 
-def sub_headlines(sub):
-    """Headline scalars of the sub-results, flat, for `config` of the compact line."""
-    h = {}
-    g = lambda d, *ks: (g(d.get(ks[0]), *ks[1:]) if len(ks) > 1 else d.get(ks[0])) if isinstance(d, dict) else None
-    h["cfg2_trials_per_sec"] = g(sub, "cfg2", "value")
-    h["cfg2_ms_per_step"] = g(sub, "cfg2", "ms_per_step")
-    h["cfg3fit_evals_per_sec"] = g(sub, "cfg3fit", "value")
-    h["cfg3fit_single_eval_ms"] = g(sub, "cfg3fit", "single_eval_ms")
-    h["cfg3fit_single_eval_over_fenced_loglik"] = g(sub, "cfg3fit", "single_eval_over_fenced_loglik")
-    h["cfg3fit_batch4_evals_per_sec"] = g(sub, "cfg3fit", "evals_by_lockstep_batch", "4", "evals_per_sec")
-    h["cfg3fit_fit_evals_per_sec"] = g(sub, "cfg3fit", "fit", "evals_per_sec")
-    h["cfg3fit_frac"] = g(sub, "cfg3fit", "roofline_frac_step_executed")
-    h["cfg3fit_grad_err_vs_oracle"] = g(sub, "cfg3fit", "parity", "gradient_worst_component_rel_err_vs_oracle_closed_form")
-    h["cfg3fit_cpu_evals_per_sec"] = g(sub, "cfg3fit", "cpu_baseline", "value")
-    h["cfg5_evals_per_sec"] = g(sub, "cfg5", "value")
-    h["cfg5_fit_evals_per_sec"] = g(sub, "cfg5", "fit", "evals_per_sec")
-    for k in ("potrf", "npx69"):
-        for kk, vv in (g(sub, k, "headline") or {}).items():
-            h["%s_%s" % (k, kk)] = vv
-    h["aud24_evals_per_sec"] = g(sub, "aud24", "value")
-    h["aud24_fit_evals_per_sec"] = g(sub, "aud24", "fit", "evals_per_sec")
-    h["aud24_predict_trials_per_sec"] = g(sub, "aud24", "predict_trials_per_sec")
-    h["aud24_grad_err_vs_oracle_fd"] = g(sub, "aud24", "parity", "gradient_max_err_over_max_component_vs_oracle_fd")
-    return h
-
-
-# ------------------------------------------------------------------------------------------------------- the printed line
-LINE_LIMIT = 4096          # bytes; the driver keeps an 8 KB stdout tail and parses the last line (round 4's 20 KB line was lost)
-DETAIL_FILE = "bench_detail.json"
-
-_TOP_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "setup_steps", "ms_per_step", "higher_is_better", "scaling",
-             "vs_baseline", "dtype", "data", "loglik", "parity_rel_err_loglik_vs_oracle", "parity_rel_err_predict_vs_oracle",
-             "n", "ms", "tflops", "frac_of_fp64_mfma_peak", "evals_per_sec_one_at_a_time_per_gpu", "batched_over_sequential",
-             "only_value")
-_NESTED_KEYS = {
-    "config": ("workload", "n_elec", "n_t", "trials_per_gpu", "total_trials", "parallelism", "restarts_total", "restarts_per_gpu",
-               "lockstep_batch", "class_api_predict_trials_per_sec", "class_api_predict_host_gb_per_sec",
-               "class_api_predict_cached_trials_per_sec", "fenced_loglik_ms", "fenced_predict_ms", "two_steps_in_flight_ms",
-               "next_step_announced", "pair_shares_spatial_side", "unannounced_ms_per_step", "library_default_ms_per_step",
-               "cfg2_trials_per_sec", "cfg2_ms_per_step", "cfg3fit_evals_per_sec", "cfg3fit_single_eval_ms",
-               "cfg3fit_single_eval_over_fenced_loglik", "cfg3fit_batch4_evals_per_sec", "cfg3fit_fit_evals_per_sec", "cfg3fit_frac",
-               "cfg3fit_grad_err_vs_oracle", "cfg3fit_cpu_evals_per_sec", "single_eval_ms", "single_eval_over_fenced_loglik",
-               "batch4_evals_per_sec", "cfg5_evals_per_sec", "cfg5_fit_evals_per_sec",
-               "potrf_ms", "potrf_frac", "potrf_trailing_update_frac", "npx69_trials_per_sec", "npx69_ms_per_step",
-               "npx69_fit_evals_per_sec", "npx69_step_over_symmetric_control", "aud24_evals_per_sec", "aud24_fit_evals_per_sec",
-               "aud24_predict_trials_per_sec", "aud24_grad_err_vs_oracle_fd", "fit_evals_per_sec", "fit_restarts_per_sec",
-               "predict_trials_per_sec", "predict100_trials_per_sec"),
-    "roofline": ("bound", "unit", "peak", "achieved", "frac", "executed_gflop_per_step", "dominant_kernel_name",
-                 "dominant_kernel_frac", "dominant_kernel_avg_ms", "dominant_kernel_share", "largest_gemm_frac", "all_gemm_frac",
-                 "traffic", "algorithmic_bytes_per_step", "traffic_over_algorithmic", "measured_mfma_f64_peak_tflops",
-                 "reference_algorithm_frac"),
-    "cpu_baseline": ("value", "unit", "kind", "cores", "blas_threads", "host_cpus", "loglik_evals_per_sec", "predict_trials_per_sec",
-                     "reference_layout_loglik_evals_per_sec", "single_thread_trials_per_sec", "sample"),
-    "distributed": ("ranks", "rccl_ranks", "collective_backend", "scaling_efficiency"),
-}
-
-
-def compact_record(full):
-    """The ONE line bench.py prints: scalars only, one level deep inside config / roofline / cpu_baseline / distributed, a fixed set
-    of keys, at most LINE_LIMIT bytes.  Everything else (notes, per-kernel tables, sub-result dicts) lives in DETAIL_FILE."""
-    def scalar(v):
-        return v is None or isinstance(v, (bool, int, float)) or (isinstance(v, str) and len(v) <= 200)
-    rec = {k: full[k] for k in _TOP_KEYS if k in full and scalar(full[k])}
-    for obj, keys in _NESTED_KEYS.items():
-        src = full.get(obj)
-        if isinstance(src, dict):
-            rec[obj] = {k: src[k] for k in keys if k in src and scalar(src[k])}
-        elif obj in full:
-            rec[obj] = None
-    rec["detail"] = DETAIL_FILE
-    line = json.dumps(rec)
-    if len(line) > LINE_LIMIT:
-        raise AssertionError("bench.py: the result line is %d bytes (limit %d): move keys to the detail file" % (len(line), LINE_LIMIT))
-    return line
-
-
 def emit(full):
     """Write the full result dict to DETAIL_FILE beside the script (and under gpurun_out/ when that exists, so that a gpurun call
     brings it home), then print the compact line -- the last thing on stdout."""
@@ -614,48 +211,6 @@ def emit(full):
                 print("bench.py: could not write %s: %s" % (os.path.join(d, DETAIL_FILE), e), file=sys.stderr)
     sys.stdout.flush()
     print(compact_record(full), flush=True)
-
-
-def potrf_bench(n=12000, reps=3):
-    """The dense Cholesky path (north_star: "(Ks (x) Kt + sig2 I) Cholesky factor, log-det and triangular solves") at the one size of
-    BASELINE's configurations where the dense matrix fits one GPU -- cfg2's N = 24 x 500 = 12 000 (1.15 GB): the blocked factorisation
-    on a device-resident SPD matrix (gpcsd_potrf_bench: HIP events on the library's stream around the factorisation alone), n^3 / 3
-    flops against the fp64 MFMA peak, with the event-scope split of one profiled factorisation."""
-    from gpcsd_amd import _hip
-    ctx = _hip.default_context()
-    _quiesce_host()
-    # median of single factorisations: each takes ~600 launches that the host has to keep ahead of; one host stall (a BLAS worker
-    # pool of the CPU baseline still spinning: a driver-style run once read 28.5 ms where the event scopes of the same process
-    # said 20.7) would otherwise sit in the mean
-    g0 = ctx.potrf_gate_timeouts()
-    runs = sorted(ctx.potrf_bench(n, reps=1) for _ in range(max(3, reps)))
-    ms, tf = runs[len(runs) // 2]
-    gate_timeouts = ctx.potrf_gate_timeouts() - g0         # (gates that gave up waiting: they steer the order of execution only)
-    ctx.prof_reset()
-    ctx.prof_enable(1)
-    ctx.potrf_bench(n, reps=1)
-    ctx.prof_enable(0)
-    prof = {k: v for k, v in ctx.prof_all().items() if k.startswith("potrf") and v["count"]}
-    # (the profiled call factors twice: one untimed repetition + one)
-    split = {k: {"ms": v["ms"] / 2.0, "launches": v["count"] // 2,
-                 "tflops": ((v["flops"] / 2.0) / (v["ms"] / 2.0 * 1e-3) / 1e12) if (v["ms"] and v["flops"]) else None} for k, v in prof.items()}
-    tu = split.get("potrf_syrk", {})
-    out = {"metric": "gpcsd_dense_cholesky_factorisations_per_sec", "value": 1e3 / ms, "unit": "factorisations/s", "n": n, "ms": ms,
-           "dtype": "f64", "flops": n ** 3 / 3.0, "tflops": tf, "frac_of_fp64_mfma_peak": tf / FP64_MFMA_SPEC_TFLOPS,
-           "trailing_update": {"kernel": "gemm_f64_kernel<EPI_SUB, lower> [potrf_syrk]: rank-256 update A22 -= L21 L21^T, tiles on or "
-                                         "below the diagonal", "ms": tu.get("ms"), "launches": tu.get("launches"),
-                               "tflops": tu.get("tflops"), "frac": (tu.get("tflops") or 0.0) / FP64_MFMA_SPEC_TFLOPS},
-           "scopes": split, "diag128_phases_us": ctx.potrf_diag_probe(), "gate_timeouts": gate_timeouts,
-           "config": {"workload": "blocked Cholesky of a %d x %d SPD matrix resident in HBM (N of BASELINE cfg2: 24 x 500)" % (n, n)}}
-    out["headline"] = {"ms": ms, "frac": out["frac_of_fp64_mfma_peak"], "trailing_update_frac": out["trailing_update"]["frac"]}
-    return out
-
-
-def _quiesce_host(seconds=0.25):
-    """The CPU legs of this script (oracle parity checks, the CPU baseline's thread sweep) leave OpenBLAS workers spinning for
-    tens of milliseconds after their last call, on the very CPUs the launch thread is bound to; a GPU measurement that starts
-    in that window sees 20-30 ms host stalls (cfg2's sub-result once read 1.09 ms per step for 0.86).  Wait them out."""
-    time.sleep(seconds)
 
 
 SUB_RESULT_KEYS = ("cfg2", "cfg3fit", "cfg5", "npx69", "aud24", "potrf")
@@ -756,859 +311,6 @@ def sub_results(args, local_rank, backend, cpu_legs):
             out[key] = {"error": repr(e)}
     out["seconds_spent_gpu_legs"] = time.perf_counter() - t0
     return out
-
-
-def run_step_bench(args, w, rank, world, local_rank, backend, compact=False, cpu_legs=None):
-    import torch
-    from gpcsd_amd import _hip
-    from gpcsd_amd.dist import TrialSharding
-    n_gpus = world
-    R_local = args.trials_per_gpu or w["trials_per_gpu"]
-    sharding = TrialSharding() if (world > 1 or os.environ.get("GPCSD_BENCH_FORCE_DIST") == "1") else None
-
-    # ---- synthetic resident data (each rank draws its own block of trials) ----
-    m = build_model(w, np.zeros((w["nx"], w["nt"], 1)))
-    m.set_device(local_rank)
-    lfp = synth_data(w, m, R_local, seed=1000 + rank)
-    m.update_lfp(lfp, w["t"])
-    ctx = m._sync_device()
-    # `value` is measured with every call doing its own decompositions: the library's decomposition cache (predict right
-    # after loglik reuses the unchanged temporal side) is switched off here and reported as a separate line below
-    ctx.decomposition_cache(False)
-    z = w.get("z", w["x"])
-    C = len(m.temporal_cov_list)
-    R_total = R_local * n_gpus
-
-    # Hyper-parameters originate on rank 0: ONE broadcast before the loop (what fit() does -- every rank then walks the same
-    # deterministic optimiser trajectory, no per-evaluation broadcast is needed); every rank re-assembles Ks / Kt and their
-    # decompositions itself (deterministic kernels: bit-identical replicas).  Per step the only collective is the sum
-    # all-reduce of the partial quadratic term (one double over RCCL).
-    if sharding is not None:
-        m._set_from_tparams(sharding.broadcast(m._current_tparams(), src=0), False)
-
-    paired = os.environ.get("GPCSD_BENCH_UNPAIRED") != "1"
-    # Successive steps of a throughput loop are independent and their hyper-parameters known: each step ANNOUNCES the next
-    # (gpcsd_prefetch_pair) right after queueing itself, so that the next step's two decomposition chains start under this step's
-    # products instead of behind the host's collection of its log-likelihood -- every chain is still queued, run and consumed
-    # inside the timed region (the last announcement is work nobody takes).  An optimiser cannot do this (its next point depends on
-    # the value it waits for): `unannounced_ms_per_step` in the line is the same loop without announcements.
-    # GPCSD_BENCH_ANNOUNCE=0 / GPCSD_BENCH_SHARE_S=0: A/B.  Sharing the spatial side (one decomposition for Ks + jitter I and Ks:
-    # same eigenvectors, shifted spectrum -- gpcsd_pair_share_s) is off in the library by default and switched on here, where the
-    # main stream is the bound.
-    announce = {"on": paired and os.environ.get("GPCSD_BENCH_ANNOUNCE", "1") == "1"}
-    share_s = paired and os.environ.get("GPCSD_BENCH_SHARE_S", "1") == "1"
-    ctx.pair_share_s(share_s)
-
-    def one_step():
-        hp, keep = m._hparams(m.JITTER)
-        hp0, keep0 = m._hparams(0.0)
-        # queue both calls, then come back for the log-likelihood.  As one paired call (gpcsd_loglik_predict_async) the two
-        # temporal and the two spatial eigenproblems of the step share one chain of launches as replicas -- every one of them
-        # is solved, the results are the bits of the two calls made separately -- and the next step's chain runs beside this
-        # step's predict GEMMs.  GPCSD_BENCH_UNPAIRED=1: the same as two queued calls (four chains per step).
-        if paired:
-            ctx.loglik_predict_async(hp, hp0, z, w["t"], _hip.PRED_CSD, want_lists=True)
-            if announce["on"]:
-                ctx.prefetch_pair(hp, hp0, z, w["t"])
-        else:
-            ctx.loglik_parts_async(hp)
-            ctx.predict_resident(hp0, z, w["t"], _hip.PRED_CSD, want_lists=True)
-        if sharding is None:
-            sumlog, quad = ctx.loglik_parts_wait()
-            return -0.5 * R_total * sumlog - 0.5 * quad, 0.0, 0.0
-        # Multi-rank: the only collective of a step is one double summed over the ranks (RCCL).  A rank has its partial sum
-        # when its log-likelihood comes back; the host then queues the next step FIRST and runs the all-reduce of the step
-        # before behind that queueing -- while the GPU works on the next step's eigen-chain and the host would be idle
-        # anyway (issuing it in front of the queueing costs 0.25 ms of host time per step on the critical path).  The global
-        # log-likelihood of step k is therefore complete during step k+1 (the last one before the final fence).
-        ll_prev = flush()
-        sumlog, quad = ctx.loglik_parts_wait()
-        state["partial"] = (sumlog, quad)
-        return ll_prev, 0.0, 0.0
-
-    def solo_step():
-        hp, keep = m._hparams(m.JITTER)
-        hp0, keep0 = m._hparams(0.0)
-        ctx.loglik_predict_async(hp, hp0, z, w["t"], _hip.PRED_CSD, want_lists=True)
-        return ctx.loglik_parts_wait()
-
-    state = {}
-
-    def flush():
-        prev = state.pop("partial", None)
-        if prev is None or sharding is None:
-            return None
-        return -0.5 * R_total * prev[0] - 0.5 * float(sharding.allreduce_sum_async(np.array([prev[1]]))()[0])
-
-    def fence():
-        last = flush()
-        if last is not None:
-            state["ll"] = last
-        ctx.synchronize()
-        torch.cuda.synchronize()
-        if sharding is not None:
-            import torch.distributed as td
-            td.barrier()
-
-    # Setup, not warm-up: a fresh process on a cold box needs a few evaluations before it is in steady state (first call
-    # eager + allocations, second captured into hipGraphs, third replayed; GPU clocks and host caches ramp over the first
-    # tenths of a second -- a 10-step timed region measured 4.6 ms/step as the first command on a fresh box against 2.63
-    # afterwards).  A fixed number of untimed evaluations (reported as "setup_steps"; the same count on every rank, each
-    # step carries collectives), then the W warm-up steps the contract asks for, then K timed.
-    t_first_eval = time.perf_counter()
-    for _ in range(args.setup_steps):
-        one_step()
-    # A model's first ~0.1 s: on this pool every second model sees ONE interval of 9 / 19 / 29 ms, 35-110 ms after its first
-    # evaluation, in which none of the process's queues make progress (not the host's wait, not allocations, frees or
-    # new contexts injected into a model in steady state; tools/stall_probe.py, tools/stall_inject.py).  With the driver's K = 20
-    # the timed region is 16 ms: it starts no earlier than SETTLE_S after the model's first evaluation, the setup steps continuing
-    # until then (the same count on every rank: rank 0 decides).
-    n_settle = 0
-    if sharding is None:
-        while time.perf_counter() - t_first_eval < SETTLE_S:
-            one_step()
-            n_settle += 1
-    else:                                                  # every step carries a collective: the same count on every rank
-        n_settle = 400
-        for _ in range(n_settle):
-            one_step()
-    for _ in range(args.warmup):
-        one_step()
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        ll, _a, _b = one_step()
-    fence()
-    elapsed = time.perf_counter() - t0
-    if sharding is not None:
-        ll = state["ll"]                          # the last step's global log-likelihood, collected inside the timed region
-    dist_info = None
-    if sharding is not None:
-        import torch.distributed as td
-        # the same steps on every rank WITHOUT the collective (each rank alone with its card, as an N = 1 run): what the
-        # sharded job's rate is quoted against when no N = 1 figure is handed in (--n1-value)
-        for _ in range(min(args.warmup, 3)):
-            solo_step()
-        ctx.synchronize()
-        tsolo = time.perf_counter()
-        for _ in range(args.steps):
-            solo_step()
-        ctx.synchronize()
-        solo = time.perf_counter() - tsolo
-        dev = "cuda" if backend == "nccl" else "cpu"
-        per_rank = torch.zeros(2 * world, dtype=torch.float64, device=dev)
-        per_rank[rank], per_rank[world + rank] = elapsed, solo
-        td.all_reduce(per_rank, op=td.ReduceOp.SUM)
-        per_rank = per_rank.cpu().numpy()
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        td.all_reduce(tt, op=td.ReduceOp.MAX)
-        elapsed = float(tt.cpu()[0])
-        unsharded_rate = float(np.sum(R_local * args.steps / per_rank[world:]))
-        value_now = R_total * args.steps / elapsed
-        dist_info = {
-            "collective_backend": td.get_backend(), "rccl_ranks": td.get_world_size() if td.get_backend() == "nccl" else 0,
-            "ranks": td.get_world_size(),
-            "per_rank_ms_per_step": [1e3 * float(v) / args.steps for v in per_rank[:world]],
-            "per_rank_ms_per_step_without_collectives": [1e3 * float(v) / args.steps for v in per_rank[world:]],
-            "efficiency_vs_ranks_without_collectives": value_now / unsharded_rate,
-            "scaling_efficiency": (value_now / (world * args.n1_value)) if args.n1_value else value_now / unsharded_rate,
-            "scaling_efficiency_against": ("--n1-value %.6g trials/s" % args.n1_value) if args.n1_value else
-                                          "sum of the ranks' own rates over the same steps without the all-reduce (same processes)",
-        }
-    ms_per_step = 1e3 * elapsed / args.steps
-    pf_queued, pf_taken = ctx.prefetch_stats()
-    # the prediction the TIMED loop's last step left in HBM, in the mode `value` is timed in (announced, one spatial decomposition
-    # per pair: not the bits of a fenced call), fetched before anything else is queued: the line's parity gate reads this one
-    timed_pred = None
-    if not args.only_value and world == 1:
-        timed_pred = {"csd": ctx.fetch("pred_out_csd", (z.shape[0], w["nt"], R_local)).copy()}
-    if args.only_value:
-        if rank != 0:
-            return None
-        return {"metric": "gpcsd_loglik_plus_predict_trials_per_sec", "value": R_total * args.steps / elapsed, "unit": "trials/s",
-                "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup, "setup_steps": args.setup_steps + n_settle,
-                "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
-                "data": "synthetic", "loglik": float(ll),
-                "config": {"workload": w["label"], "n_elec": w["nx"], "n_t": w["nt"], "trials_per_gpu": R_local,
-                           "total_trials": R_total, "parallelism": "trial-sharded x%d" % n_gpus,
-                           "next_step_announced": bool(announce["on"]), "pair_shares_spatial_side": bool(share_s)},
-                "only_value": "setup + warm-up + timed loop only (the command profiled under profiles/)", "distributed": dist_info}
-
-    # ---- the two halves on their own (rank-local, every call fenced: nothing of one call overlaps the next) ----
-    # In the step loop above predict_resident returns with its GEMM tail in flight (its results stay on the device) and
-    # the next loglik's temporal chain runs beside that tail, so the per-call host times of the loop do not separate the
-    # halves; these two loops do.  Their sum is the unpipelined step.
-    n_sub = max(10, min(args.steps, 50))
-    hp_s, keep_s = m._hparams(m.JITTER)
-    hp0_s, keep0_s = m._hparams(0.0)
-    ctx.synchronize()
-    ts0 = time.perf_counter()
-    for _ in range(n_sub):
-        ctx.loglik_parts(hp_s)
-    t_ll = (time.perf_counter() - ts0) / n_sub
-    ts0 = time.perf_counter()
-    for _ in range(n_sub):
-        ctx.predict_resident(hp0_s, z, w["t"], _hip.PRED_CSD, want_lists=True)
-        ctx.synchronize()
-    t_pr = (time.perf_counter() - ts0) / n_sub
-
-    # ---- the same loop WITHOUT announcements (every step queues its own chains when it starts: what a caller whose next
-    # hyper-parameters depend on this step's value gets), and with the library's defaults on top (spatial side not shared:
-    # the pair then has the bits of its fenced calls) -- never part of `value`; the same counts on every rank (collectives) ----
-    unannounced_ms = default_ms = None
-    if paired and (announce["on"] or share_s):
-        n_un = max(10, min(args.steps, 100))
-
-        def timed_loop(n):
-            for _ in range(5):
-                one_step()
-            flush()
-            ctx.synchronize()
-            tu = time.perf_counter()
-            for _ in range(n):
-                one_step()
-            flush()
-            ctx.synchronize()
-            return 1e3 * (time.perf_counter() - tu) / n
-        was = announce["on"]
-        announce["on"] = False
-        unannounced_ms = timed_loop(n_un)
-        ctx.pair_share_s(False)
-        default_ms = timed_loop(n_un)
-        ctx.pair_share_s(share_s)
-        announce["on"] = was
-
-    # ---- the same steps with the host loop two steps deep: step k+1 is queued before step k's log-likelihood is collected, so
-    # the chains of consecutive steps run back to back (rank-local, no collective; never part of `value`, whose steps each
-    # return their result before the next one is queued) ----
-    deep_ms = None
-    if paired:
-        hp_d, keep_d = m._hparams(m.JITTER)
-        hp0_d, keep0_d = m._hparams(0.0)
-
-        def run_deep(n):
-            ctx.loglik_predict_async(hp_d, hp0_d, z, w["t"], _hip.PRED_CSD, want_lists=True)
-            for _ in range(n - 1):
-                ctx.loglik_predict_async(hp_d, hp0_d, z, w["t"], _hip.PRED_CSD, want_lists=True)
-                ctx.loglik_parts_wait()
-            return ctx.loglik_parts_wait()
-        run_deep(10)
-        ctx.synchronize()
-        td0 = time.perf_counter()
-        n_deep = max(10, min(args.steps, 100))
-        run_deep(n_deep)
-        ctx.synchronize()
-        deep_ms = 1e3 * (time.perf_counter() - td0) / n_deep
-        # ... and the same with the eigenvector form of the log-likelihood forced (gpcsd_ll_tridiag mode 0): the tridiagonal form
-        # (the default at this size) makes the next temporal chain wait for the previous log-likelihood's tail, which is what a
-        # two-deep loop would overlap -- DESIGN 4.9
-        ctx.ll_tridiag(0)
-        run_deep(10)
-        ctx.synchronize()
-        td1 = time.perf_counter()
-        run_deep(n_deep)
-        ctx.synchronize()
-        deep_ms_eig = 1e3 * (time.perf_counter() - td1) / n_deep
-        ctx.ll_tridiag(int(os.environ.get("GPCSD_LL_TRIDIAG", "2")[:1] or 2))      # back to the mode this context was created with
-
-    # ---- same step with the decomposition cache on (a user's loglik -> predict sequence; never part of `value`) ----
-    ctx.decomposition_cache(True)
-    for _ in range(5):
-        one_step()
-    ctx.synchronize()
-    tc0 = time.perf_counter()
-    n_cached = max(10, min(args.steps, 50))
-    for _ in range(n_cached):
-        one_step()
-    flush()
-    ctx.synchronize()
-    cached_ms = 1e3 * (time.perf_counter() - tc0) / n_cached
-    ctx.decomposition_cache(False)
-
-    # ---- the class API as a drop-in user calls it: predict() returns host arrays (PCIe inclusive), rank-local ----
-    for _ in range(3):                                         # the result arrays ping-pong between two pinned blocks of the
-        m.predict(z, w["t"], type="csd")                       # pool: both exist after the second call (steady state of a loop)
-    t1 = time.perf_counter()
-    n_pcie = 3
-    for _ in range(n_pcie):
-        m.predict(z, w["t"], type="csd")
-    pcie_predict = R_local * n_pcie / (time.perf_counter() - t1)
-    out_bytes = (1 + C) * z.shape[0] * w["nt"] * R_local * 8
-    # ... and with the decomposition cache on, the library's default: what predict() costs right after fit() / loglik() at the
-    # fitted hyper-parameters (neuropixels/fit_gpcsd2d.py:101-107) -- both decompositions are reused, the call is its GEMM tail
-    # and the copy
-    ctx.decomposition_cache(True)
-    for _ in range(3):
-        m.predict(z, w["t"], type="csd")
-    t1 = time.perf_counter()
-    for _ in range(n_pcie):
-        m.predict(z, w["t"], type="csd")
-    pcie_predict_cached = R_local * n_pcie / (time.perf_counter() - t1)
-    ctx.decomposition_cache(False)
-
-    # ---- roofline: HIP events around the kernels of the SAME paired, queued step the timed loop runs ----
-    # mode 2: asynchronous scopes, chains launched eagerly so the scopes inside them record (per-kernel launch times);
-    # mode 3: asynchronous scopes with the chains replayed as hipGraphs exactly as in the timed loop (chain-level scopes)
-    def profiled_pass(mode, n):
-        # (without announcements: the tail's own clock stamps of a step are read when its log-likelihood is back, i.e. when ITS
-        # chains have finished -- an announced next chain would be in flight on the same stamps.  The kernels are the same.)
-        was_announcing = announce["on"]
-        announce["on"] = False
-        try:
-            return _profiled_pass(mode, n)
-        finally:
-            announce["on"] = was_announcing
-
-    def _profiled_pass(mode, n):
-        flush()
-        ctx.synchronize()
-        ctx.prof_reset()
-        ctx.prof_enable(mode)
-        for _ in range(3):
-            one_step()
-        flush()
-        ctx.synchronize()
-        ctx.prof_reset()
-        clk = {0: [], 1: []}
-        tp0 = time.perf_counter()
-        for _ in range(n):
-            one_step()
-            # the step's log-likelihood is back, so both of its chains have finished: the tridiagonalisation tail's own
-            # wall-clock stamps of this step (the one timing that also exists inside a replayed hipGraph, mode 3)
-            for region in (0, 1):
-                ms, nwg, fl = ctx.prof_tail_clock(region)
-                if ms > 0.0:
-                    clk[region].append((ms, nwg, fl))
-        flush()
-        ctx.synchronize()
-        dt = (time.perf_counter() - tp0) / n
-        ctx.prof_enable(0)
-        return ctx.prof_all(), 1e3 * dt, clk
-    n_prof = max(10, min(args.steps, 40))
-    prof, eager_ms, _clk_eager = profiled_pass(2, n_prof)
-    prof_graph, graph_ms, clk_graph = profiled_pass(3, n_prof)
-    if rank != 0:
-        return None
-
-    f_ll, f_pred, f_pred_trial = algorithmic_flops(w, R_local, z.shape[0], C)
-    ref_flops = f_ll + f_pred
-    gemms = {k: v for k, v in prof_graph.items() if k.startswith("gemm_") and v["count"] > 0}
-    # flops actually launched per step: every GEMM launch as recorded by the library (2 M N K per launch, batch included:
-    # folded-basis projections, Gram assembly, D&C merge products), the tridiagonalisations ((4/3) n^3 per half problem) and
-    # the compact-WY back-transformations (4 n^3 per half problem: V Z, T W, V^T W per panel of 64 reflectors)
-    gemm_flops = sum(v["flops"] for k, v in prof.items() if k.startswith("gemm_")) / n_prof       # (incl. the D&C merge products)
-    tail = prof.get("sytrd_rtail")
-    tail_flops = tail["flops"] / n_prof if tail else 0.0
-    wy_flops = 3.0 * tail_flops                                  # 4 n^3 = 3 x (4/3) n^3 for the same half problems
-    exec_flops = gemm_flops + tail_flops + wy_flops
-    step_s = ms_per_step * 1e-3
-    wl = args.workload if (args.trials_per_gpu is None and n_gpus == 1) else "none"
-    roof = {
-        "bound": "mfma", "unit": "TFLOP/s", "peak": FP64_MFMA_SPEC_TFLOPS,
-        "achieved": exec_flops / step_s / 1e12, "frac": exec_flops / step_s / 1e12 / FP64_MFMA_SPEC_TFLOPS,
-        "scope": "one step = loglik + predict(csd) of %d trials; flops actually launched (folded-basis GEMMs, "
-                 "symmetry-folded eigensolver) / ms_per_step" % R_local,
-        "executed_gflop_per_step": exec_flops / 1e9,
-        "executed_breakdown_gflop": {"gemm": gemm_flops / 1e9, "tridiagonalisation": tail_flops / 1e9,
-                                     "back_transformation": wy_flops / 1e9},
-        "reference_algorithm": {"gflop_per_step": ref_flops / 1e9, "achieved": ref_flops / step_s / 1e12,
-                                "frac": ref_flops / step_s / 1e12 / FP64_MFMA_SPEC_TFLOPS,
-                                "note": "SURVEY 8(d) unit: F_spatial + F_eig + R F_proj (+ predict); the library executes "
-                                        "about half of its GEMM part and a quarter of its eigensolver part"},
-        "measured_mfma_f64_peak_tflops": ctx.mfma_f64_peak(),
-        "profiled_passes": {"steps": n_prof, "eager_chains_ms_per_step": eager_ms, "graph_chains_ms_per_step": graph_ms,
-                            "note": "the timed step re-run with event scopes on the library's streams: chains eager (per-kernel "
-                                    "scopes below) and chains as hipGraphs (chain-level scopes); both leave the step queued and paired"},
-    }
-    if tail and tail["count"]:
-        avg = tail["ms"] / tail["count"]
-        per_launch = tail["flops"] / tail["count"]
-        share, rp_avg, rp_calls, src = rocprof_kernel(wl, "sytrd_rtail_kernel")
-        lps = tail["count"] / n_prof
-        # the same kernel inside the replayed hipGraphs of the timed loop (mode 3): its workgroups' own wall-clock stamps
-        in_graph = None
-        stamps = clk_graph[0] + clk_graph[1]
-        if stamps:
-            g_avg = sum(ms for ms, _, _ in stamps) / len(stamps)
-            g_fl = sum(fl for _, _, fl in stamps) / len(stamps)
-            in_graph = {"avg_launch_ms": g_avg, "launches_timed": len(stamps),
-                        "temporal_chain_ms": (sum(ms for ms, _, _ in clk_graph[0]) / len(clk_graph[0])) if clk_graph[0] else None,
-                        "spatial_chain_ms": (sum(ms for ms, _, _ in clk_graph[1]) / len(clk_graph[1])) if clk_graph[1] else None,
-                        "achieved": g_fl / (g_avg * 1e-3) / 1e12, "frac": g_fl / (g_avg * 1e-3) / 1e12 / FP64_MFMA_SPEC_TFLOPS,
-                        "how": "last end - first start over the launch's workgroups, device wall clock stamped by the kernel "
-                               "itself (graph replay, where event scopes cannot record)"}
-        roof["dominant_kernel"] = {
-            "kernel": "sytrd_rtail_kernel", "why": "largest share of GPU time in the rocprofv3 kernel stats of `bench.py --only-value`",
-            "in_graph_replay": in_graph,
-            "share_of_gpu_time_rocprof": share, "rocprof_avg_launch_ms": rp_avg, "rocprof_launches": rp_calls, "rocprof_source": src,
-            # the headline figures are those of the kernel as it runs in the timed loop (graph replay: its own clock stamps,
-            # which the committed rocprofv3 average reproduces); HIP events exist for the eagerly launched chains of the
-            # other profiled pass only, where the host issues ~100 launches per chain and the tails overlap other work differently
-            "avg_launch_ms": in_graph["avg_launch_ms"] if in_graph else avg,
-            "avg_launch_ms_hip_events_eager_chains": avg,
-            "launches_per_step": lps, "ms_per_step": (in_graph["avg_launch_ms"] if in_graph else avg) * lps, "flops_per_launch": per_launch,
-            "achieved": in_graph["achieved"] if in_graph else per_launch / (avg * 1e-3) / 1e12,
-            "frac": in_graph["frac"] if in_graph else per_launch / (avg * 1e-3) / 1e12 / FP64_MFMA_SPEC_TFLOPS,
-            "workgroups_per_launch": 4 if paired else 2,
-            "cus_busy": "%d of %d (one 768-thread workgroup per half problem)" % (4 if paired else 2, N_CUS),
-            "bound": "latency: ~250 dependent Householder columns per launch, two workgroup barriers each",
-            "note": "one launch per chain "
-                    "per step, each with the two replicas' half problems as workgroups -- the temporal chain's (4 x 250 rows, "
-                    "on the critical path) and the spatial chain's (4 x 192 rows, beside it); the two overlap in time, so "
-                    "their sum is not a share of the step's wall time",
-        }
-    if gemms:
-        name = max(gemms, key=lambda k: gemms[k]["ms"])
-        g = gemms[name]
-        avg_ms = g["ms"] / g["count"]
-        ach = (g["flops"] / g["count"]) / (avg_ms * 1e-3) / 1e12
-        roof["largest_gemm"] = {
-            "kernel": "gemm_f64_kernel [" + name + "]", "avg_launch_ms": avg_ms, "flops_per_launch": g["flops"] / g["count"],
-            "achieved": ach, "frac": ach / FP64_MFMA_SPEC_TFLOPS, "share_of_step_wall": (g["count"] / n_prof) * avg_ms / ms_per_step,
-            "all_gemm_tflops": sum(v["flops"] for v in gemms.values()) / (sum(v["ms"] for v in gemms.values()) * 1e-3) / 1e12}
-    traffic, tdetail = pmc_step_traffic(wl)
-    alg_bytes = 2 * w["nx"] * w["nt"] * R_local * 8 + out_bytes          # lfp read once per call + predict outputs written once
-    roof["traffic"] = traffic
-    roof["traffic_unit"] = "HBM bytes per step (rocprofv3 --pmc over `bench.py --only-value`, corrected as the gfx950 guide prescribes)"
-    roof["traffic_detail"] = tdetail
-    roof["algorithmic_bytes_per_step"] = alg_bytes
-    roof["per_kernel_ms_per_step"] = {k: v["ms"] / n_prof for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])}
-    roof["per_kernel_launches_per_step"] = {k: v["count"] / n_prof for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])}
-    roof["chains_ms_per_step_graph_replay"] = {k: v["ms"] / n_prof for k, v in sorted(prof_graph.items(), key=lambda kv: -kv[1]["ms"])
-                                               if v["count"] > 0}
-
-    # scalars of the nested reports once more at the first level of `roofline` (a record that keeps scalars only keeps these)
-    dk, lg = roof.get("dominant_kernel"), roof.get("largest_gemm")
-    if dk:
-        roof["dominant_kernel_name"] = dk["kernel"]
-        roof["dominant_kernel_frac"] = dk["frac"]
-        roof["dominant_kernel_avg_ms"] = dk["avg_launch_ms"]
-        roof["dominant_kernel_share"] = dk["share_of_gpu_time_rocprof"]
-    if lg:
-        roof["largest_gemm_frac"] = lg["frac"]
-        roof["largest_gemm_avg_ms"] = lg["avg_launch_ms"]
-        roof["all_gemm_frac"] = lg["all_gemm_tflops"] / FP64_MFMA_SPEC_TFLOPS
-    roof["traffic_over_algorithmic"] = (traffic / alg_bytes) if traffic else None
-    roof["reference_algorithm_frac"] = roof["reference_algorithm"]["frac"]
-
-    out = {
-        "metric": "gpcsd_loglik_plus_predict_trials_per_sec",
-        "value": R_total * args.steps / elapsed,
-        "unit": "trials/s",
-        "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup, "setup_steps": args.setup_steps + n_settle,
-        "ms_per_step": ms_per_step,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f64", "data": "synthetic",
-        "config": {"workload": w["label"], "n_elec": w["nx"], "n_t": w["nt"], "trials_per_gpu": R_local,
-                   "total_trials": R_total, "predict": "z=%s, t*=t, type=csd, %d temporal components" % ("electrodes" if "z" not in w else "%d sites" % len(z), C),
-                   "parallelism": "trial-sharded x%d" % n_gpus,
-                   "class_api_predict_trials_per_sec": pcie_predict, "class_api_predict_host_gb_per_sec": pcie_predict / R_local * out_bytes / 1e9,
-                   "class_api_predict_cached_trials_per_sec": pcie_predict_cached,
-                   "class_api_predict_cached_host_gb_per_sec": pcie_predict_cached / R_local * out_bytes / 1e9},
-        "pipelining": "a step queues loglik + predict as one paired call (gpcsd_loglik_predict_async: the eigenproblems of the step -- "
-                      "Kt (once: both sets have the same temporal hyper-parameters), Ks with jitter for loglik and without for predict -- "
-                      "run as one temporal and one spatial chain; nothing is reused from another step; results stay in HBM), then "
-                      "waits for the log-likelihood; the next step's chains run beside this step's predict GEMMs "
-                      "(double-buffered chain outputs).  Every "
-                      "step's log-likelihood is returned to the host inside the step; the timed region ends with a full "
-                      "device fence.  Each step announces the next one (gpcsd_prefetch_pair: the next step's two chains are queued "
-                      "behind this step's launches and start under its products -- config.next_step_announced; "
-                      "config.unannounced_ms_per_step is the same loop without) and its pair decomposes ONE spatial matrix "
-                      "(Ks + jitter I and Ks share eigenvectors: config.pair_shares_spatial_side; the prediction then agrees with "
-                      "the separately decomposed one to 1e-13, config.library_default_ms_per_step is the loop with neither)."
-                      + ("  N > 1: a rank's partial sum is back inside the step; the 8-byte RCCL all-reduce that completes the "
-                         "global log-likelihood of step k runs behind the queueing of step k+1 (the last one before the final "
-                         "fence)." if n_gpus > 1 or sharding is not None else ""),
-        "fenced_calls": {"loglik_ms": 1e3 * t_ll, "predict_resident_ms": 1e3 * t_pr, "sum_ms": 1e3 * (t_ll + t_pr),
-                         "loglik_evals_per_sec_per_gpu": 1.0 / t_ll, "loglik_trial_evals_per_sec_per_gpu": R_local / t_ll,
-                         "predict_trials_per_sec_per_gpu": R_local / t_pr,
-                         "note": "each call alone, device fenced after every call (rank-local, no collective)"},
-        "two_steps_in_flight": None if deep_ms is None else {
-            "ms_per_step": deep_ms, "trials_per_sec_per_gpu": R_local / (deep_ms * 1e-3),
-            "ms_per_step_eigenvector_form": deep_ms_eig,
-            "note": "host loop two steps deep (step k+1 queued before step k's log-likelihood is collected; up to four "
-                    "evaluations may be outstanding per context): the chains of consecutive steps run back to back.  NOT "
-                    "part of value, whose steps each hand their result back before the next step is queued.  With the "
-                    "log-likelihood's tridiagonal form (the default at this size, built for the one-deep loop) the next "
-                    "temporal chain waits for the previous log-likelihood's tail; ms_per_step_eigenvector_form is the same "
-                    "loop with gpcsd_ll_tridiag mode 0"},
-        "with_decomposition_cache": {"ms_per_step": cached_ms, "trials_per_sec_per_gpu": R_local / (cached_ms * 1e-3),
-                                     "note": "library default for users (predict after loglik reuses the unchanged temporal "
-                                             "eigendecomposition, bit-identical); NOT part of value"},
-        "class_api_predict_trials_per_sec_per_gpu_pcie_inclusive": pcie_predict,
-        "class_api_predict_host_gb_per_sec": pcie_predict / R_local * out_bytes / 1e9,
-        "class_api_predict_cached_trials_per_sec_per_gpu_pcie_inclusive": pcie_predict_cached,
-        "class_api_predict_cached_host_gb_per_sec": pcie_predict_cached / R_local * out_bytes / 1e9,
-        "class_api_predict_note": "predict() returns host arrays: device time + one PCIe copy of (1 + C) nz nt R doubles into pinned "
-                                  "blocks.  First pair: every call decomposes both sides (cache off, as `value`); `cached`: the "
-                                  "library default, unchanged hyper-parameters reuse both decompositions",
-        "loglik": float(ll),
-        "distributed": dist_info,
-        "roofline": roof,
-    }
-    out["config"]["fenced_loglik_ms"], out["config"]["fenced_predict_ms"] = 1e3 * t_ll, 1e3 * t_pr
-    out["config"]["two_steps_in_flight_ms"] = deep_ms
-    out["config"]["next_step_announced"] = bool(announce["on"])
-    out["config"]["pair_shares_spatial_side"] = bool(share_s)
-    out["config"]["unannounced_ms_per_step"] = unannounced_ms
-    out["config"]["library_default_ms_per_step"] = default_ms
-    out["config"]["announcements_taken"] = pf_taken
-    want_baseline = not args.no_cpu_baseline and world == 1       # the CPU baseline is reported at N=1 only
-    if want_baseline or compact:
-        # the GPU half of the parity spot check now (the step's own prediction, fetched); the oracle half is a CPU leg
-        hp0, _k = m._hparams(0.0)
-        ctx.predict_resident(hp0, z, w["t"], _hip.PRED_CSD, want_lists=True)
-        got_fenced = ctx.fetch("pred_out_csd", (z.shape[0], w["nt"], R_local))
-        got = timed_pred["csd"] if timed_pred is not None else got_fenced
-        ll_gpu = float(ll)
-
-        def cpu_leg():
-            if want_baseline:
-                cb, ll_cpu, pred_cpu = cpu_baseline(w, m, lfp, args.cpu_budget_s)
-                out["cpu_baseline"] = cb
-                cb["reference_layout_loglik_evals_per_sec"] = cb["faithful_layout"]["loglik_evals_per_sec"]
-                cb["single_thread_trials_per_sec"] = cb["single_thread"]["value"]
-            else:                                    # sub-result of the default line: parity spot check without the timing legs
-                O, geom, hpo, hpo0 = oracle_setup(w, m)
-                ll_cpu = O.loglik(geom, hpo, lfp)
-                pred_cpu = O.predict(geom, hpo0, lfp, z, w["t"], type="csd")["csd"]
-            # parity spot check beside the numbers: the outputs of the TIMED loop's last step (its log-likelihood and the prediction
-            # it left in HBM, in the mode `value` is timed in) vs the oracle on the same trials; the fenced call's beside it
-            out["parity_rel_err_loglik_vs_oracle"] = abs(ll_gpu - ll_cpu) / abs(ll_cpu)
-            out["parity_rel_err_predict_vs_oracle"] = float(np.max(np.abs(got - pred_cpu)) / np.max(np.abs(pred_cpu)))
-            out["parity_predict_source"] = ("last step of the timed loop (announced=%s, one spatial decomposition per pair=%s)"
-                                            % (bool(announce["on"]), bool(share_s))) if timed_pred is not None else "fenced call"
-            out["parity_rel_err_fenced_predict_vs_oracle"] = float(np.max(np.abs(got_fenced - pred_cpu)) / np.max(np.abs(pred_cpu)))
-        if cpu_legs is None:
-            cpu_leg()
-        else:
-            cpu_legs.append(cpu_leg)
-    return out
-
-
-def run_fit_bench(args, w, rank, world, local_rank, backend, compact=False, cpu_legs=None):
-    """BASELINE cfg5: GPCSD1D hyper-parameter fit, 24 x 500 x 200 trials resident on every GPU, 32 restarts sharded over the
-    GPUs.  The unit of work is one objective + analytic-gradient evaluation of one restart (what L-BFGS-B asks for); a step
-    evaluates one lock-step batch of B restarts in one chain of launches (gpcsd_loglik_grad_batch).  Reported: evaluations/s
-    through the batched call, the same through one-at-a-time calls (the round-1 path), and a truncated real fit()
-    (SciPy L-BFGS-B chains in lock-step) with restarts/s."""
-    import torch
-    from gpcsd_amd.dist import TrialSharding
-    total_restarts = int(w.get("restarts", 32))
-    mine = [k for k in range(total_restarts) if k % world == rank]
-    B = args.fit_batch or min(32, len(mine))                        # all of this rank's restarts advance in one lock-step batch
-    m = build_model(w, np.zeros((w["nx"], w["nt"], 1)))
-    m.set_device(local_rank)
-    lfp = synth_data(w, m, w["trials_per_gpu"], seed=1000)          # every rank holds the same trials
-    data_sigma2 = [float(tc.params["sigma2"]["value"]) for tc in m.temporal_cov_list]   # (2D: rescaled by 1 / mean diag Ks)
-    m.update_lfp(lfp, w["t"])
-    if os.environ.get("GPCSD_GRAM_PRECISION") == "32":              # BASELINE cfg5 names "fp32 kernel build + fp64 factor"
-        m.gram_precision = 32
-    ctx = m._sync_device()
-    sharding = TrialSharding() if (world > 1 or os.environ.get("GPCSD_BENCH_FORCE_DIST") == "1") else None
-    if sharding is not None:
-        m.shard_restarts(sharding)
-    # restart k starts from the k-th draw of the default priors (SURVEY 8(d): np.random.seed(k), sampled on the host)
-    starts = []
-    if "starts_around_truth" in w:
-        tp_true = m._current_tparams()
-        lo, hi = (np.array([b[i] for b in m._bounds()], dtype=float) for i in (0, 1))
-        for k in range(total_restarts):
-            s0 = tp_true + w["starts_around_truth"] * np.random.RandomState(k).standard_normal(tp_true.size)
-            starts.append(np.minimum(np.maximum(s0, lo + 1e-6), hi - 1e-6))
-    else:
-        for k in range(total_restarts):
-            np.random.seed(k)
-            starts.append(m._sample_start(False))
-    ng = 1 + m.dim + 2 * len(m.temporal_cov_list) + int(np.size(m.sig2n["value"]))
-
-    def hp_of(tp):
-        m._set_from_tparams(tp, False)
-        return m._hparams(m.JITTER)
-    sets = [hp_of(starts[k]) for k in mine[:B]]
-    hps = [h for h, _ in sets]
-
-    def fence():
-        ctx.synchronize()
-        torch.cuda.synchronize()
-        if sharding is not None:
-            import torch.distributed as td
-            td.barrier()
-    # G lock-step groups side by side, each with its own context (what fit(batch=B, workers=G) does): a step is one batched
-    # evaluation of EVERY group, i.e. G * B objective+gradient evaluations
-    G = max(1, args.fit_groups)
-    ctxs, group_hps = [ctx], [hps]
-    for gi in range(1, G):
-        mg = m._clone_for_worker()
-        mg.set_device(local_rank)
-        cg = mg._sync_device()
-        ks = mine[gi * B:(gi + 1) * B] or mine[:B]
-        gh = []
-        for k in ks:
-            mg._set_from_tparams(starts[k], False)
-            gh.append(mg._hparams(mg.JITTER))
-        ctxs.append(cg)
-        group_hps.append([h for h, _ in gh])
-        sets.extend(gh)                                          # keep the sig2n arrays alive
-
-    def run_groups(nsteps):
-        if G == 1:
-            for _ in range(nsteps):
-                ctx.loglik_grad_batch(hps, ng)
-            return
-        import threading
-        ths = [threading.Thread(target=lambda c=c, h=h: [c.loglik_grad_batch(h, ng) for _ in range(nsteps)])
-               for c, h in zip(ctxs, group_hps)]
-        for th in ths:
-            th.start()
-        for th in ths:
-            th.join()
-    t_first_eval = time.perf_counter()
-    run_groups(max(3, min(args.setup_steps, 20)))
-    while world == 1 and time.perf_counter() - t_first_eval < SETTLE_S:      # (see run_step_bench: a model's first tenth of a second)
-        run_groups(1)
-    run_groups(args.warmup)
-    fence()
-    t0 = time.perf_counter()
-    run_groups(args.steps)
-    for cg in ctxs:
-        cg.synchronize()
-    fence()
-    elapsed = time.perf_counter() - t0
-    if args.only_value:                    # the command the rocprofv3 passes under profiles/ are taken over: nothing after the loop
-        if rank != 0:
-            return None
-        return {"metric": "gpcsd_fit_loglik_grad_evals_per_sec", "value": G * B * world * args.steps / elapsed, "unit": "evals/s",
-                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
-                "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-                "config": {"workload": w["label"], "n_elec": w["nx"], "n_t": w["nt"], "trials_per_gpu": w["trials_per_gpu"],
-                           "lockstep_batch": B}, "only_value": "setup + warm-up + timed loop only (the command profiled under profiles/)"}
-    # one group alone, for reference
-    fence()
-    t0g = time.perf_counter()
-    for _ in range(args.steps):
-        sumlog, quad, grad, st = ctx.loglik_grad_batch(hps, ng)
-    ctx.synchronize()
-    one_group_s = (time.perf_counter() - t0g) / args.steps
-    # one at a time (what a chain on its own costs; fit(workers=1) of round 1)
-    nseq = max(8, min(args.steps, 40))
-    for _ in range(3):
-        ctx.loglik_grad(hps[0], ng)
-    ctx.synchronize()
-    t1 = time.perf_counter()
-    for i in range(nseq):
-        ctx.loglik_grad(hps[i % len(hps)], ng)
-    ctx.synchronize()
-    seq_s = (time.perf_counter() - t1) / nseq
-    # the same evaluations in lock-step batches of 1 / 4 / 8 sets (what a rank of an N-GPU fit holds), and the fenced
-    # log-likelihood alone beside them: the gradient's price over the value's
-    by_batch, ll_fenced_ms = None, None
-    if w.get("starts_around_truth") and world == 1:
-        by_batch = {}
-        for bb in (1, 2, 4, 8):
-            if bb > len(hps):
-                break
-            for _ in range(3):
-                ctx.loglik_grad_batch(hps[:bb], ng)
-            ctx.synchronize()
-            tb = time.perf_counter()
-            nb_ = max(10, args.steps // 2)
-            for _ in range(nb_):
-                ctx.loglik_grad_batch(hps[:bb], ng)
-            ctx.synchronize()
-            dtb = (time.perf_counter() - tb) / nb_
-            by_batch[str(bb)] = {"ms_per_batched_call": 1e3 * dtb, "evals_per_sec": bb / dtb}
-        ctx.decomposition_cache(False)                  # (every call decomposes both sides, as an optimiser's evaluations do)
-        for _ in range(3):
-            ctx.loglik_parts(hps[0])
-        ctx.synchronize()
-        tl = time.perf_counter()
-        for _ in range(20):
-            ctx.loglik_parts(hps[0])
-        ll_fenced_ms = 1e3 * (time.perf_counter() - tl) / 20
-        ctx.decomposition_cache(True)
-    if sharding is not None:
-        import torch.distributed as td
-        tt = torch.tensor([elapsed, seq_s], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
-        td.all_reduce(tt, op=td.ReduceOp.MAX)
-        elapsed, seq_s = (float(v) for v in tt.cpu())
-    # profiled pass of the batched step
-    ctx.prof_reset()
-    ctx.prof_enable(True)
-    for _ in range(3):
-        ctx.loglik_grad_batch(hps, ng)
-    ctx.prof_enable(False)
-    prof = ctx.prof_all()
-    # a truncated real fit: lock-step SciPy chains, all of this rank's restarts
-    opts = {"maxiter": args.fit_maxiter, "disp": False, "gtol": 1e-5, "ftol": 1e7 * np.finfo(float).eps}
-    def timed_fit(driver):
-        m.fit_driver = driver
-        m.fit(n_restarts=total_restarts, options=opts, starts=starts, batch=B, workers=G)          # warm (allocations, graphs)
-        tf = time.perf_counter()
-        m.fit(n_restarts=total_restarts, options=opts, starts=starts, batch=B, workers=G)
-        dt = time.perf_counter() - tf
-        nb_, npts_ = getattr(m, "fit_batches_", (0, 0))
-        return {"driver": getattr(m, "fit_driver_used_", driver), "restarts": total_restarts, "maxiter": args.fit_maxiter, "seconds": dt,
-                "restarts_per_sec": total_restarts / dt, "evals": int(npts_) * world, "batched_calls": int(nb_),
-                "evals_per_sec": npts_ * world / dt, "best_nll": float(np.min(m.fit_nll_values_)),
-                "nll_values": [float(v) for v in np.asarray(m.fit_nll_values_)]}
-    # the round-2 driver (unmodified minimize() calls on threads that rendezvous per evaluation) beside the default one
-    # (one driver stepping SciPy's L-BFGS-B states through its reverse-communication interface): same optima, bit for bit
-    fit_threads = timed_fit("threads")
-    fit_main = timed_fit("auto")
-    fit_s = fit_main["seconds"]
-    nb, npts = fit_main["batched_calls"], fit_main["evals"] // max(world, 1)
-    if rank != 0:
-        return None
-    n_eval = G * B * world * args.steps
-    # parity spot check beside the numbers: the HIP objective and analytic gradient at restart 0's start against the oracle
-    # objective and its central differences (checker code; 2 p + 1 oracle evaluations)
-    cpu_leg = None
-    if world == 1:
-        kinds = [k for k, _, _ in w["temporal"]]
-        snames = ("ell",) if w["dim"] == 1 else ("ell1", "ell2")
-        n_sig = int(np.size(m.sig2n["value"]))
-        # at the hyper-parameters the data were drawn from (a well-scaled point: central differences of a prior-drawn start,
-        # where the objective is ~1e7 and dominated by one term, only measure the differences' own rounding)
-        m.R["value"] = w["R"]
-        m.sig2n["value"] = w["sig2n"] if n_sig == 1 else np.array(w["sig2n_list"], dtype=float)
-        for nm, v in zip(snames, w["ell_s"]):
-            m.spatial_cov.params[nm]["value"] = v
-        for tc, (_, ell, _s2), s2 in zip(m.temporal_cov_list, w["temporal"], data_sigma2):
-            tc.params["ell"]["value"], tc.params["sigma2"]["value"] = ell, s2
-        tp0 = m._current_tparams()
-        f_gpu, g_gpu = m._objective_and_grad(tp0, False)          # the GPU half now; the oracle half is a CPU leg
-
-        def cpu_leg():
-            O, geom, hpo, _hpo0 = oracle_setup(w, m)
-
-            def cpu_obj(tp):
-                hh = O.hparams_from_tparams(tp, w["dim"], kinds, n_sig, eps=w["eps"], jitter=m.JITTER)
-                lp = m.R["prior"].lpdf(hh["R"])
-                if n_sig == 1:
-                    lp += m.sig2n["prior"].lpdf(hh["sig2n"])
-                else:
-                    lp += sum(pr.lpdf(v) for pr, v in zip(m.sig2n["prior"], np.atleast_1d(hh["sig2n"])))
-                for nm, v in zip(snames, hh["ell_s"]):
-                    lp += m.spatial_cov.params[nm]["prior"].lpdf(v)
-                for tc, (_, ell, s2) in zip(m.temporal_cov_list, hh["temporal"]):
-                    lp += tc.params["ell"]["prior"].lpdf(ell) + tc.params["sigma2"]["prior"].lpdf(s2)
-                return -(O.loglik(geom, hh, lfp) + lp)
-            f_cpu = cpu_obj(tp0)
-            g_cpu = np.zeros_like(tp0)
-            for i in range(tp0.size):
-                e = np.zeros_like(tp0)
-                e[i] = 1e-5
-                g_cpu[i] = (cpu_obj(tp0 + e) - cpu_obj(tp0 - e)) / 2e-5
-            res["parity"] = {"objective_rel_err_vs_oracle": abs(f_gpu - f_cpu) / abs(f_cpu),
-                             "gradient_max_err_over_max_component_vs_oracle_fd":
-                                 float(np.max(np.abs(g_gpu - g_cpu)) / np.max(np.abs(g_cpu)))}
-            # ... and against the oracle's closed-form gradient (O.loglik_and_grad: pinned by central differences in the CPU
-            # suite), timed as the CPU baseline of this workload: one objective + gradient evaluation on the host cores
-            from threadpoolctl import threadpool_limits
-            hh0 = O.hparams_from_tparams(tp0, w["dim"], kinds, n_sig, eps=w["eps"], jitter=m.JITTER)
-            dlp = np.zeros_like(tp0)                                 # d log-prior / d tp (priors.py is host arithmetic on both sides)
-            slots = [m.R] + [m.spatial_cov.params[nm] for nm in snames]
-            for tc in m.temporal_cov_list:
-                slots += [tc.params["ell"], tc.params["sigma2"]]
-            nat = [hh0["R"]] + list(hh0["ell_s"]) + [v for (_, ell, s2) in hh0["temporal"] for v in (ell, s2)]
-            for i, (sl, v) in enumerate(zip(slots, nat)):
-                dlp[i] = sl["prior"].dlpdf(v) * v
-            sv = np.atleast_1d(hh0["sig2n"])
-            prs = [m.sig2n["prior"]] if n_sig == 1 else list(m.sig2n["prior"])
-            for j, (pr, v) in enumerate(zip(prs, sv)):
-                dlp[len(nat) + j] = pr.dlpdf(v) * v
-            nthreads = min(16, os.cpu_count() or 1)
-            with threadpool_limits(limits=nthreads):
-                O.loglik_and_grad(geom, lfp, tp0, kinds, n_sig, eps=w["eps"], jitter=m.JITTER)          # warm
-                ts = []
-                while len(ts) < 3 or (sum(ts) < 10.0 and len(ts) < 20):
-                    tc0 = time.perf_counter()
-                    ll_cf, g_cf = O.loglik_and_grad(geom, lfp, tp0, kinds, n_sig, eps=w["eps"], jitter=m.JITTER)
-                    ts.append(time.perf_counter() - tc0)
-            g_cf = -(g_cf + dlp)
-            res["parity"]["gradient_worst_component_rel_err_vs_oracle_closed_form"] = float(
-                np.max(np.abs(g_gpu - g_cf) / np.maximum(np.abs(g_cf), 1e-9 * np.max(np.abs(g_cf)))))
-            res["cpu_baseline"] = {"value": 1.0 / float(np.median(ts)), "unit": "evals/s", "cores": nthreads, "kind": "port",
-                                   "blas_threads": nthreads, "host_cpus": os.cpu_count(),
-                                   "sample": "oracle objective + closed-form gradient (O.loglik_and_grad) on the bench's own %d "
-                                             "trials, %d repetitions, median, %d BLAS threads" % (lfp.shape[2], len(ts), nthreads)}
-    # the script's next step (fit_gpcsd_baseline.py:103-105): predict at the electrodes -- and at 100 depths -- with the fitted model;
-    # here at the hyper-parameters the data were drawn from, results left in HBM, every call fenced (rank-local)
-    pred = None
-    if "z100" in w and world == 1:
-        from gpcsd_amd import _hip as _h
-        pred = {}
-        hp0, _k0 = m._hparams(0.0)
-        for key, zz in (("predict_trials_per_sec", w["x"]), ("predict100_trials_per_sec", w["z100"])):
-            for _ in range(3):
-                ctx.predict_resident(hp0, zz, w["t"], _h.PRED_CSD, want_lists=True)
-            ctx.synchronize()
-            tpz = time.perf_counter()
-            for _ in range(20):
-                ctx.predict_resident(hp0, zz, w["t"], _h.PRED_CSD, want_lists=True)
-                ctx.synchronize()
-            pred[key] = w["trials_per_gpu"] * 20 / (time.perf_counter() - tpz)
-    gemm_flops = sum(v["flops"] for k, v in prof.items() if k.startswith("gemm_")) / 3.0
-    tail = prof.get("sytrd_rtail")
-    eig_flops = 4.0 * tail["flops"] / 3.0 if tail else 0.0           # tridiagonalisation + 3x for the back-transformation
-    step_s = elapsed / args.steps
-    res = {
-        "metric": "gpcsd_fit_loglik_grad_evals_per_sec",
-        "value": n_eval / elapsed, "unit": "evals/s",
-        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "setup_steps": max(3, min(args.setup_steps, 20)),
-        "ms_per_step": 1e3 * step_s, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-        "dtype": "f64" if m.gram_precision == 64 else "f32 Gram build + f64", "data": "synthetic",
-        "config": {"workload": w["label"], "n_elec": w["nx"], "n_t": w["nt"], "trials_per_gpu": w["trials_per_gpu"],
-                   "restarts_total": total_restarts, "restarts_per_gpu": len(mine), "lockstep_batch": B, "lockstep_groups": G,
-                   "parallelism": "restart-sharded x%d, %d lock-step groups of %d restarts per GPU" % (world, G, B)},
-        "evals_per_sec_one_at_a_time_per_gpu": 1.0 / seq_s,
-        "evals_per_sec_one_group_per_gpu": B / one_group_s,
-        "batched_over_sequential": (B / one_group_s) / (1.0 / seq_s),
-        "parity": None,
-        "all_groups_over_sequential": (G * B / step_s) / (1.0 / seq_s),
-        "fit": dict(fit_main, evals_per_sec_through_scipy=fit_main["evals_per_sec"],
-                    real_fit_over_synthetic_evals_per_sec=fit_main["evals_per_sec"] / (n_eval / elapsed),
-                    same_optima_as_threads_driver=fit_main["nll_values"] == fit_threads["nll_values"]),
-        "fit_threads_driver": {k: v for k, v in fit_threads.items() if k != "nll_values"},
-        "roofline": {"bound": "mfma", "unit": "TFLOP/s", "peak": FP64_MFMA_SPEC_TFLOPS,
-                     "achieved": G * (gemm_flops + eig_flops) / step_s / 1e12,
-                     "frac": G * (gemm_flops + eig_flops) / step_s / 1e12 / FP64_MFMA_SPEC_TFLOPS,
-                     "scope": "one step = %d lock-step group(s) x %d objective+gradient evaluations, each group one chain of launches; "
-                              "flops actually launched (profiled on one group)" % (G, B),
-                     "executed_gflop_per_step": G * (gemm_flops + eig_flops) / 1e9, "traffic": None,
-                     "dominant_kernel": None if not tail else {
-                         "kernel": "sytrd_rtail_kernel", "avg_launch_ms": tail["ms"] / tail["count"],
-                         "launches_per_step": tail["count"] / 3.0, "workgroups_per_launch": "%d (one per half problem and set)" % (2 * B),
-                         "share_of_step_wall": tail["ms"] / 3.0 / (1e3 * step_s)},
-                     "per_kernel_ms_per_step": {k: v["ms"] / 3.0 for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])[:16]}},
-    }
-    res["config"]["fit_evals_per_sec"], res["config"]["fit_restarts_per_sec"] = fit_main["evals_per_sec"], fit_main["restarts_per_sec"]
-    if by_batch is not None:
-        res["evals_by_lockstep_batch"] = by_batch
-        res["single_eval_ms"] = by_batch["1"]["ms_per_batched_call"]
-        res["fenced_loglik_ms"] = ll_fenced_ms
-        res["single_eval_over_fenced_loglik"] = by_batch["1"]["ms_per_batched_call"] / ll_fenced_ms
-        res["config"].update(single_eval_ms=res["single_eval_ms"], fenced_loglik_ms=ll_fenced_ms,
-                             single_eval_over_fenced_loglik=res["single_eval_over_fenced_loglik"],
-                             batch4_evals_per_sec=by_batch.get("4", {}).get("evals_per_sec"))
-    # HBM traffic per batched step from the committed rocprofv3 --pmc passes over `bench.py --workload <this> --only-value`
-    traffic, traffic_src = pmc_step_traffic(args.workload) if (world == 1 and args.fit_batch is None) else (None, None)
-    res["roofline"]["traffic"] = traffic
-    if traffic_src:
-        res["roofline"]["traffic_source"] = traffic_src
-        # algorithmic bytes of one evaluation: the trials read once (SURVEY 8(d)); a batch reads them once per set
-        res["roofline"]["algorithmic_bytes_per_step"] = 8.0 * w["nx"] * w["nt"] * w["trials_per_gpu"] * B
-        res["roofline"]["traffic_over_algorithmic"] = traffic / res["roofline"]["algorithmic_bytes_per_step"]
-    if pred:
-        res.update(pred)
-        res["config"].update(pred)
-    if cpu_leg is not None:
-        if cpu_legs is None:
-            cpu_leg()
-        else:
-            cpu_legs.append(cpu_leg)
-    return res
 
 
 if __name__ == "__main__":
