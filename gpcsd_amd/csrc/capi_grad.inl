@@ -206,14 +206,12 @@ static int loglik_grad_impl(gpcsd_ctx *c, const gpcsd_hparams *hps, int B, doubl
     double *Gs = c->buf<double>("b_grad_Gs", nxx * B), *Gt = c->buf<double>("b_grad_Gt", ntt * B);
     const long nmx = (long)std::max(nx, nt) * std::max(nx, nt);
     double *T1 = c->buf<double>("b_grad_T1", (size_t)nmx * B);
-    // row chunk of the Ghat_t sums (GPCSD_GRAD_CH: A/B).  A chunk is one K range of a 64 x 64 tile: with 512 rows the 250-column
-    // halves of 384 x 500 x 50 gave 592 tiles of 32 dependent K steps -- too few to hide the load latency (94 us per parity for
-    // 2.4 GF); 256 rows: 61 us (128: 63; the 32 x 32 tiles of configuration 5: 137)
-    // Short sums (24 channels x 200 trials = 4800 rows) keep 512: there a launch has tiles enough at a batch of sets, and halving the
-    // chunk doubles the partial matrices written and read back (cfg5, 32 sets: 7.8 k against 8.5 k evaluations/s).  The choice
-    // depends on the set's own shape only, never on the batch: a set is summed the same way alone and in a batch.
-    static const int CH_ENV = getenv("GPCSD_GRAD_CH") ? std::max(64, atoi(getenv("GPCSD_GRAD_CH"))) : 0;
-    const int CH = CH_ENV ? CH_ENV : ((long)nx * R >= 16384 ? 256 : 512);
+    // row chunk of the Ghat_t sums (GPCSD_GRAD_CH: A/B).  A chunk is one K range of a 64 x 64 tile.  Measured: 256-row chunks make the
+    // product itself faster for ONE set at 384 x 500 x 50 (592 tiles of 32 dependent K steps are too few to hide the load latency:
+    // 94 -> 61 us per parity) but the evaluation no faster (the product runs beside the spatial branch), and every batch slower (twice
+    // the partial matrices written and read back: 8 sets 4.41 against 4.17 ms; cfg5 at 32 sets 7.8 k against 8.5 k evaluations/s).
+    // 512 it stays; the choice never depends on the batch: a set is summed the same way alone and in a batch.
+    static const int CH = getenv("GPCSD_GRAD_CH") ? std::max(64, atoi(getenv("GPCSD_GRAD_CH"))) : 512;
     static const int GS_CFG = getenv("GPCSD_GRAD_GS_CFG") ? atoi(getenv("GPCSD_GRAD_GS_CFG")) : 3;
     static const int GT_CFG = getenv("GPCSD_GRAD_GT_CFG") ? atoi(getenv("GPCSD_GRAD_GT_CFG")) : 3;
     hipStream_t sT = s;                   // the stream of the gradient's temporal half (folded path: stream2, see below)
