@@ -214,6 +214,10 @@ static int loglik_grad_impl(gpcsd_ctx *c, const gpcsd_hparams *hps, int B, doubl
     static const int CH = getenv("GPCSD_GRAD_CH") ? std::max(64, atoi(getenv("GPCSD_GRAD_CH"))) : 512;
     static const int GS_CFG = getenv("GPCSD_GRAD_GS_CFG") ? atoi(getenv("GPCSD_GRAD_GS_CFG")) : 3;
     static const int GT_CFG = getenv("GPCSD_GRAD_GT_CFG") ? atoi(getenv("GPCSD_GRAD_GT_CFG")) : 3;
+    // tile configuration of the mid-size products of the tail (Gs A, Gs T: nx x G x nx; the rotations U Ghat U^T from 128 rows): the
+    // automatic choice looks at ONE set's tile count (it must not depend on the batch) and takes the 32 x 32 latency tile, which at
+    // a batch of 8 sets is 13 % of the GPU time at a sixth of the MFMA rate.  Default 3 (64 x 64, BK 16): 8 sets 4.30 -> 4.05 ms, one set unchanged.  GPCSD_GRAD_MID_CFG=0: automatic (A/B).
+    static const int MID_CFG = getenv("GPCSD_GRAD_MID_CFG") ? atoi(getenv("GPCSD_GRAD_MID_CFG")) : 3;
     hipStream_t sT = s;                   // the stream of the gradient's temporal half (folded path: stream2, see below)
     bool quad_in_two = false;             // the quadratic form came out as two partial sums (parity blocks of unequal shape)
     if (fold) {
@@ -369,12 +373,14 @@ static int loglik_grad_impl(gpcsd_ctx *c, const gpcsd_hparams *hps, int B, doubl
                 GemmDesc a;
                 a.M = np; a.N = np; a.K = np; a.A = sd.U + o; a.lda = np; a.B = H + o; a.ldb = np; a.C = tmp; a.ldc = np;
                 a.batch2 = B; a.sA2 = sd.sU; a.sB2 = sH; a.sC2 = nmx;
+                if (np >= 128) a.cfg = MID_CFG;
                 a.prof_name = "gemm_grad_sandwich";
                 gemm_f64(c, a, sq);
                 GemmDesc bq;
                 bq.M = np; bq.N = np; bq.K = np; bq.A = tmp; bq.lda = np; bq.B = sd.U + o; bq.ldb = np; bq.transB = true;
                 bq.C = outf + o; bq.ldc = np;
                 bq.batch2 = B; bq.sA2 = nmx; bq.sB2 = sd.sU; bq.sC2 = sH;
+                if (np >= 128) bq.cfg = MID_CFG;
                 bq.prof_name = "gemm_grad_sandwich";
                 gemm_f64(c, bq, sq);
             }
@@ -500,6 +506,7 @@ static int loglik_grad_impl(gpcsd_ctx *c, const gpcsd_hparams *hps, int B, doubl
     GemmDesc gp;                          // P = Gs A
     gp.M = nx; gp.N = G; gp.K = nx; gp.A = Gs; gp.lda = nx; gp.B = A; gp.ldb = G; gp.C = P; gp.ldc = G;
     gp.batch2 = B; gp.sA2 = nxx; gp.sB2 = nxG; gp.sC2 = nxG;
+    if (nx >= 128) gp.cfg = MID_CFG;
     gp.prof_name = "gemm_grad_GsA";
     gemm_f64(c, gp, s);
     if (kron) {                           // <A^T Gs A, dKgl/dell_k> = <Gs A, Tl_k>   (grad.hip: k_frob_pair)
@@ -516,6 +523,7 @@ static int loglik_grad_impl(gpcsd_ctx *c, const gpcsd_hparams *hps, int B, doubl
     GemmDesc gr;                          // S = Gs T  (T = A Kgl from the forward pass)
     gr.M = nx; gr.N = G; gr.K = nx; gr.A = Gs; gr.lda = nx; gr.B = T; gr.ldb = G; gr.C = P; gr.ldc = G;
     gr.batch2 = B; gr.sA2 = nxx; gr.sB2 = nxG; gr.sC2 = nxG;
+    if (nx >= 128) gr.cfg = MID_CFG;
     gr.prof_name = "gemm_grad_GsT";
     gemm_f64(c, gr, s);
     k_fwdR_grad(c, P, g.x, nx, g.gx1, g.gw1, g.gx2, g.gw2, G, g.dim == 2 ? g.ngl2 : 0, 0.0, 0.0, gdev, s, tab, B, 64);

@@ -17,7 +17,7 @@ mkdir -p "$OUT"
 export TMPDIR=/tmp
 cd "$ROOT"
 if [ "$WL" = "cfg3fit" ]; then
-    CMD="bench.py --only-value --workload cfg3fit --fit-batch 1 --steps $STEPS --warmup 5"
+    CMD="bench.py --only-value --workload cfg3fit --steps $STEPS --warmup 5"      # (the bench step: all 8 restarts in one lock-step batch)
     STEPK="fwdR_grad_kernel"
 else
     CMD="bench.py --only-value --workload $WL --steps $STEPS --warmup 5"
