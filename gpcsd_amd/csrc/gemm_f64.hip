@@ -523,9 +523,11 @@ struct PredUnfoldK {
     long tile_c0;                // first column tile of this launch (chunked launches: gpcsd_predict's copy pipeline)
 };
 
-template <int CC>
+// BF = fragments of 16 time orbits per wave (workgroup = 32 * BF orbits): BF = 2 halves the number of workgroups that stream
+// one S~ panel and issues 8 MFMAs per 6 fragment reads instead of 4 per 4; every element's K order is the same in both.
+template <int CC, int BF>
 __global__ __launch_bounds__(256) void gemm_pred_unfold_kernel(PredUnfoldK<CC> g) {
-    constexpr int NT = 256, BK = 16, BM = 32 * CC, BN = 64;
+    constexpr int NT = 256, BK = 16, BB = 32 * BF, BM = BB * CC, BN = 64;
     using TileA = Tile<BM, true, NT, BK>;     // Pcat: global [K][rows]
     using TileB = Tile<BN, false, NT, BK>;    // S~: global [cols][K]
     __shared__ double lds[2 * (TileA::LDS_ELEMS + TileB::LDS_ELEMS)];
@@ -542,15 +544,15 @@ __global__ __launch_bounds__(256) void gemm_pred_unfold_kernel(PredUnfoldK<CC> g
     }
     const int tile_b = L % g.tiles_b;
     const long tile_c = g.tile_c0 + L / g.tiles_b;
-    const int b0 = tile_b * 32;
+    const int b0 = tile_b * BB;
     const long n0 = tile_c * 32;
     const int fr = lane & 15, fq = lane >> 4;
 
-    d4 acc[2][CC][2];
+    d4 acc[2][CC * BF][2];                                     // [time parity][component * BF + orbit fragment][site parity]
 #pragma unroll
     for (int tp = 0; tp < 2; ++tp)
 #pragma unroll
-        for (int i = 0; i < CC; ++i)
+        for (int i = 0; i < CC * BF; ++i)
 #pragma unroll
             for (int j = 0; j < 2; ++j) acc[tp][i][j] = d4{0.0, 0.0, 0.0, 0.0};
 
@@ -567,11 +569,11 @@ __global__ __launch_bounds__(256) void gemm_pred_unfold_kernel(PredUnfoldK<CC> g
         const int K = g.K[tp];
         if (K <= 0) continue;                                  // (no antisymmetric time block: wave-uniform)
         const int nbt = tp ? g.nba : g.nb;                     // valid b of this parity
-        // per-thread slots: A' slot i = (row o = oa0 [+ 0], k = ka0 + DK i), row o -> component o / 32, time orbit b0 + o % 32
+        // per-thread slots: A' slot i = (row o = oa0 [+ 0], k = ka0 + DK i), row o -> component o / BB, time orbit b0 + o % BB
         unsigned offA[TileA::PER_THREAD], offB[TileB::PER_THREAD];
         int colA;
         {
-            const int cc = oa0 >> 5, bb = b0 + (oa0 & 31);
+            const int cc = oa0 / BB, bb = b0 + (oa0 % BB);
             colA = cc * g.npP[tp] + (bb < nbt ? bb : nbt - 1);
 #pragma unroll
             for (int i = 0; i < TileA::PER_THREAD; ++i) offA[i] = (unsigned)(((long)(ka0 + TileA::DK * i) * g.ldp[tp] + colA) * 8);
@@ -630,13 +632,13 @@ __global__ __launch_bounds__(256) void gemm_pred_unfold_kernel(PredUnfoldK<CC> g
 #pragma unroll
             for (int kk = 0; kk < BK / 4; ++kk) {
                 if (kk < steps) {                              // wave-uniform
-                    double a[CC], b[2];
+                    double a[CC * BF], b[2];
 #pragma unroll
-                    for (int i = 0; i < CC; ++i) a[i] = LDS_FRAG(sa + TileA::lds_index(i * 32, kk * 4));
+                    for (int i = 0; i < CC * BF; ++i) a[i] = LDS_FRAG(sa + TileA::lds_index(i * 32, kk * 4));
 #pragma unroll
                     for (int j = 0; j < 2; ++j) b[j] = LDS_FRAG(sb + TileB::lds_index(j * 32, kk * 4));
 #pragma unroll
-                    for (int i = 0; i < CC; ++i)
+                    for (int i = 0; i < CC * BF; ++i)
 #pragma unroll
                         for (int j = 0; j < 2; ++j)
                             acc[tp][i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[tp][i][j], 0, 0, 0);
@@ -692,8 +694,10 @@ __global__ __launch_bounds__(256) void gemm_pred_unfold_kernel(PredUnfoldK<CC> g
     const long rowlen = (long)g.nt * g.R;
     double *const sum_i = g.sum + (long)zi * rowlen + rr, *const sum_j = g.sum + (long)zj * rowlen + rr;
 #pragma unroll
+    for (int f = 0; f < BF; ++f)
+#pragma unroll
     for (int r4 = 0; r4 < 4; ++r4) {
-        const int bb = b0 + wr * 16 + fq + 4 * r4;
+        const int bb = b0 + f * 32 + wr * 16 + fq + 4 * r4;
         if (bb >= g.nb) continue;
         const int tk = g.st.rep_i[bb], tl = g.st.rep_j[bb];
         const double wt = (tk == tl) ? 1.0 : isq2;
@@ -701,10 +705,10 @@ __global__ __launch_bounds__(256) void gemm_pred_unfold_kernel(PredUnfoldK<CC> g
         double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
 #pragma unroll
         for (int cc = 0; cc < CC; ++cc) {
-            const double ss = wz * wt * acc[0][cc][0][r4];
-            const double sa = has_ta ? wz * isq2 * acc[1][cc][0][r4] : 0.0;
-            const double as = has_za ? isq2 * wt * acc[0][cc][1][r4] : 0.0;
-            const double aa = (has_za && has_ta) ? 0.5 * acc[1][cc][1][r4] : 0.0;
+            const double ss = wz * wt * acc[0][cc * BF + f][0][r4];
+            const double sa = has_ta ? wz * isq2 * acc[1][cc * BF + f][0][r4] : 0.0;
+            const double as = has_za ? isq2 * wt * acc[0][cc * BF + f][1][r4] : 0.0;
+            const double aa = (has_za && has_ta) ? 0.5 * acc[1][cc * BF + f][1][r4] : 0.0;
             const double v0 = (ss + sa) + (as + aa);           // (zi, tk)
             const double v1 = (ss - sa) + (as - aa);           // (zi, tl)
             const double v2 = (ss + sa) - (as + aa);           // (zj, tk)
@@ -741,7 +745,12 @@ bool gemm_pred_unfold_supported(int C, long nrows_S, int nt) {
 
 void gemm_pred_unfold(gpcsd_ctx *c, const PredUnfoldDesc &d, hipStream_t s) {
     GP_REQUIRE(gemm_pred_unfold_supported(d.C, d.anti_row0 + d.ncolA, d.nt), -3, "gemm_pred_unfold: unsupported shape");
-    const int tiles_b = ceil_div(d.nb, 32);
+    // GPCSD_UNFOLD_BF=2: 64 time orbits per workgroup.  Measured at 384 x 500 x 50 (round 6): S~ is fetched 2.0 instead of
+    // 2.8 times (the panels in flight on one XCD plus Pcat are about the size of its L2 either way), 80 MB less traffic per
+    // step, but one wave per SIMD and 234 instead of 205 us per launch; the step is the same.  Default stays 32.
+    const char *const bf_env = getenv("GPCSD_UNFOLD_BF");      // read per call: tests switch it
+    const bool wide = bf_env && atoi(bf_env) == 2;
+    const int tiles_b = ceil_div(d.nb, wide ? 64 : 32);
     const long tiles_all = (d.ncolS + 31) / 32;
     const long tc0 = d.tile_c1 < 0 ? 0 : d.tile_c0, tc1 = d.tile_c1 < 0 ? tiles_all : std::min(d.tile_c1, tiles_all);
     if (tc1 <= tc0) return;
@@ -764,11 +773,13 @@ void gemm_pred_unfold(gpcsd_ctx *c, const PredUnfoldDesc &d, hipStream_t s) {
     if (d.C == 1) {
         PredUnfoldK<1> k;
         fill(k);
-        hipLaunchKernelGGL(gemm_pred_unfold_kernel<1>, dim3((unsigned)nblocks), dim3(256), 0, s, k);
+        if (wide) hipLaunchKernelGGL((gemm_pred_unfold_kernel<1, 2>), dim3((unsigned)nblocks), dim3(256), 0, s, k);
+        else hipLaunchKernelGGL((gemm_pred_unfold_kernel<1, 1>), dim3((unsigned)nblocks), dim3(256), 0, s, k);
     } else {
         PredUnfoldK<2> k;
         fill(k);
-        hipLaunchKernelGGL(gemm_pred_unfold_kernel<2>, dim3((unsigned)nblocks), dim3(256), 0, s, k);
+        if (wide) hipLaunchKernelGGL((gemm_pred_unfold_kernel<2, 2>), dim3((unsigned)nblocks), dim3(256), 0, s, k);
+        else hipLaunchKernelGGL((gemm_pred_unfold_kernel<2, 1>), dim3((unsigned)nblocks), dim3(256), 0, s, k);
     }
     GP_HIP(hipGetLastError());
 }

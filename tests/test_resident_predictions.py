@@ -56,6 +56,22 @@ def test_resident_predict_gives_device_views_with_the_bits_of_the_host_arrays(na
     assert np.array_equal(np.asarray(m.x_pred), np.asarray(z)) and np.array_equal(np.asarray(m.t_pred), np.asarray(w["t"]))
 
 
+@pytest.mark.parametrize("name,R,kind", [("cfg3", 7, "both"), ("cfg2", 5, "csd")])
+def test_the_64_orbit_unfold_writes_the_bits_of_the_32_orbit_one(name, R, kind, monkeypatch):
+    """GPCSD_UNFOLD_BF=2 (gemm_f64.hip: gemm_pred_unfold_kernel<CC, 2>, opt-in: fewer S~ fetches, slower launch) changes which
+    workgroup owns an output, not the order any element is accumulated in: predictions equal bit for bit (ragged trial count,
+    250 and 40 time orbits: the second does not fill a 64-orbit tile)."""
+    w, m, lfp = _step_model(R, name, seed=5)
+    z = w.get("z", w["x"])
+    m.predict(z, w["t"], type=kind)
+    ref = [np.array(m.csd_pred)] + [np.array(a) for a in m.csd_pred_list] + ([np.array(m.lfp_pred)] if kind == "both" else [])
+    monkeypatch.setenv("GPCSD_UNFOLD_BF", "2")
+    m.predict(z, w["t"], type=kind)
+    got = [np.array(m.csd_pred)] + [np.array(a) for a in m.csd_pred_list] + ([np.array(m.lfp_pred)] if kind == "both" else [])
+    assert all(np.array_equal(a, b) for a, b in zip(ref, got))
+    assert np.isfinite(ref[0]).all() and np.abs(ref[0]).max() > 0
+
+
 def test_loglik_predict_many_announced_with_one_spatial_decomposition_at_cfg3_x_50_vs_oracle():
     """The mode `value` is timed in (announcements + one spatial decomposition per pair) through its class-API caller, at 50 trials,
     against the oracle on every set's log-likelihood (1e-9) and the last set's csd and BOTH per-component lists (1e-6); then the
