@@ -7,8 +7,20 @@ host and the largest interval of every loop reported.  One variable per run (env
     python tools/stall_probe.py cfg2 8 --close         # previous context closed explicitly, gc.collect(), device fence, 0.3 s pause
     python tools/stall_probe.py cfg2 8 --no-announce   # the library-default loop (no gpcsd_prefetch_pair, two spatial decompositions)
     python tools/stall_probe.py cfg2 8 --pin-lfp       # the trials uploaded from a page-locked block (no pageable H2D copy at all)
+    python tools/stall_probe.py cfg2 8 --thp-off       # prctl(PR_SET_THP_DISABLE) before anything is mapped: no huge-page collapse
+    python tools/stall_probe.py cfg2 8 --mempolicy     # set_mempolicy(MPOL_PREFERRED, node 0): the kernel's automatic NUMA
+                                                       # balancing does not scan (unmap / migrate) mappings with an explicit policy
 """
 import gc, json, os, sys, time
+import ctypes
+_libc = ctypes.CDLL(None, use_errno=True)
+if "--thp-off" in sys.argv:
+    rc = _libc.prctl(41, 1, 0, 0, 0)                                           # PR_SET_THP_DISABLE
+    print("prctl(PR_SET_THP_DISABLE) ->", rc, ctypes.get_errno(), file=sys.stderr)
+if "--mempolicy" in sys.argv:
+    mask = ctypes.c_ulong(1)
+    rc = _libc.syscall(238, 1, ctypes.byref(mask), 65)                         # x86-64 set_mempolicy(MPOL_PREFERRED, {0}, maxnode)
+    print("set_mempolicy(MPOL_PREFERRED, node 0) ->", rc, ctypes.get_errno(), file=sys.stderr)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import bench
