@@ -196,6 +196,13 @@ def main():
         out["host_affinity"] = ({"bound_to_numa_node": host_numa["node"], "cpus": host_numa["cpus"], "device_pci": host_numa["pci"]}
                                 if host_numa else {"bound_to_numa_node": None, "cpus": len(os.sched_getaffinity(0))})
         emit(out)
+    if world > 1 or force_dist:                       # the line is out; leave the communicator the orderly way (no exit-time warning)
+        import torch.distributed as td
+        try:
+            if td.is_initialized():
+                td.destroy_process_group()
+        except Exception as e:
+            print("bench.py: destroy_process_group: %r" % (e,), file=sys.stderr)
 
 
 def emit(full):
